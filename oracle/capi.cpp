@@ -1,0 +1,102 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see gl.hpp header).  C entry points for ctypes (tests/,
+// __graft_entry__.smoke(), bench.py cpu_baseline).  Parity pinned against the reference's in-tree
+// known answers (tests/test_oracle_kat.py); the protocol-level pieces (transcript bytes, PoW
+// witness, proof framing) are "parity unpinned" -- see DESIGN.md.
+#include "gl.hpp"
+#include "poseidon2.hpp"
+#include "ntt.hpp"
+#include "lmcs.hpp"
+#include <cstring>
+
+using namespace oracle;
+
+extern "C" {
+
+uint64_t orc_fmul(uint64_t a, uint64_t b) { return fmul(a, b); }
+uint64_t orc_fadd(uint64_t a, uint64_t b) { return fadd(a, b); }
+uint64_t orc_fsub(uint64_t a, uint64_t b) { return fsub(a, b); }
+uint64_t orc_finv(uint64_t a) { return finv(a); }
+uint64_t orc_fpow(uint64_t a, uint64_t e) { return fpow(a, e); }
+uint64_t orc_two_adic_generator(int k) { return two_adic_generator(k); }
+uint64_t orc_canonical_lde_shift(int log_lde) { return canonical_lde_shift(log_lde); }
+void orc_emul(const uint64_t a[2], const uint64_t b[2], uint64_t out[2]) {
+  E2 r = emul(E2{a[0], a[1]}, E2{b[0], b[1]});
+  out[0] = r.c0; out[1] = r.c1;
+}
+void orc_einv(const uint64_t a[2], uint64_t out[2]) {
+  E2 r = einv(E2{a[0], a[1]});
+  out[0] = r.c0; out[1] = r.c1;
+}
+
+// n states of 12 felts, in place
+void orc_permute(uint64_t* states, size_t n) {
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < (long)n; i++) p2_permute(states + 12 * i);
+}
+void orc_hash_elements(const uint64_t* in, size_t n, uint64_t out[4]) { hash_elements(in, n, out); }
+void orc_compress(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]) { compress(l, r, out); }
+void orc_sponge_absorb(uint64_t state[12], const uint64_t* in, size_t n) { sponge_absorb(state, in, n); }
+
+void orc_naive_dft(const uint64_t* in, size_t n, int inverse, uint64_t* out) {
+  std::vector<uint64_t> v(in, in + n);
+  auto r = naive_dft(v, inverse != 0);
+  memcpy(out, r.data(), n * 8);
+}
+void orc_dft(uint64_t* a, size_t n, int inverse) { dft_inplace(a, n, inverse != 0); }
+
+// row-major n x w -> row-major (n<<added_bits) x w, physical rows bit-reversed
+void orc_coset_lde_bitrev(const uint64_t* m, size_t n, size_t w, int added_bits, uint64_t shift, uint64_t* out) {
+  auto r = coset_lde_matrix_bitrev(m, n, w, added_bits, shift);
+  memcpy(out, r.data(), r.size() * 8);
+}
+
+// LMCS over already bit-reversed row-major matrices (ascending heights).
+// layers_out (optional): all digest layers bottom(leaf, domain order)-up concatenated: 2H-1 digests.
+void orc_lmcs_build(int n_mats, const uint64_t* const* ptrs, const size_t* heights, const size_t* widths,
+                    uint64_t root_out[4], uint64_t* layers_out) {
+  std::vector<Mat> mats;
+  for (int i = 0; i < n_mats; i++) mats.push_back(Mat{ptrs[i], heights[i], widths[i]});
+  LmcsTree t = lmcs_build(mats);
+  Digest r = t.root();
+  memcpy(root_out, r.data(), 32);
+  if (layers_out) {
+    size_t off = 0;
+    for (int d = (int)t.layers.size() - 1; d >= 0; d--) {
+      memcpy(layers_out + off, t.layers[d].data(), t.layers[d].size() * 32);
+      off += t.layers[d].size() * 4;
+    }
+  }
+}
+
+// commit_traces (prover/commit.rs:142-180): natural-order row-major traces (ascending heights)
+// -> per-trace coset LDE with the canonical shift for ITS OWN lde order -> LMCS.
+// Optionally returns the LDE matrices (bit-reversed row-major) via lde_out[i] (may be null),
+// opened aligned rows + siblings for `n_idx` domain indices via fields_out/commit_out.
+void orc_commit_traces(int n_mats, const uint64_t* const* ptrs, const int* log_heights, const size_t* widths,
+                       int log_blowup, uint64_t root_out[4], uint64_t* const* lde_out,
+                       const size_t* indices, size_t n_idx, size_t alignment,
+                       uint64_t* fields_out, size_t* n_fields, uint64_t* commit_out, size_t* n_commit) {
+  std::vector<std::vector<uint64_t>> ldes(n_mats);
+  std::vector<Mat> mats;
+  for (int i = 0; i < n_mats; i++) {
+    size_t n = (size_t)1 << log_heights[i];
+    uint64_t shift = canonical_lde_shift(log_heights[i] + log_blowup);
+    ldes[i] = coset_lde_matrix_bitrev(ptrs[i], n, widths[i], log_blowup, shift);
+    mats.push_back(Mat{ldes[i].data(), n << log_blowup, widths[i]});
+    if (lde_out && lde_out[i]) memcpy(lde_out[i], ldes[i].data(), ldes[i].size() * 8);
+  }
+  LmcsTree t = lmcs_build(mats);
+  Digest r = t.root();
+  memcpy(root_out, r.data(), 32);
+  if (n_idx) {
+    std::vector<uint64_t> f;
+    std::vector<Digest> c;
+    lmcs_prove_batch(t, std::vector<size_t>(indices, indices + n_idx), alignment, f, c);
+    memcpy(fields_out, f.data(), f.size() * 8);
+    *n_fields = f.size();
+    memcpy(commit_out, c.data(), c.size() * 32);
+    *n_commit = c.size();
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see gl.hpp header).
+//
+// Lifted Matrix Commitment Scheme (LMCS) with the Poseidon2 sponge, restating
+//   crates/lifted-stark/src/lmcs/lifted_tree.rs:202-284 (build_with_alignment),
+//   :363-417 (build_leaf_states_upsampled), :427-461 (absorb_matrix),
+//   :472-511 (compress_uniform), :326-341 (collect_rows), :155-180 (prove_batch),
+//   crates/lifted-stark/src/lmcs/tree_indices.rs:185-240 (MissingSiblingsIter).
+// Matrices are row-major with BIT-REVERSED physical rows (exactly the reference's storage),
+// sorted by ascending height.  The HIP path uses a different physical layout; parity is on
+// roots, digests, opened rows and sibling lists.
+#pragma once
+#include "poseidon2.hpp"
+#include <algorithm>
+#include <array>
+#include <vector>
+
+namespace oracle {
+
+struct Mat {
+  const uint64_t* v;  // row-major, physical (bit-reversed) row order
+  size_t h, w;
+};
+typedef std::array<uint64_t, 4> Digest;
+
+struct LmcsTree {
+  std::vector<Mat> leaves;
+  // digest_layers[d] has 2^d nodes; [0] = root, last = leaf digests in DOMAIN (natural) order.
+  std::vector<std::vector<Digest>> layers;
+  size_t height() const { return leaves.back().h; }
+  Digest root() const { return layers[0][0]; }
+};
+
+static inline LmcsTree lmcs_build(const std::vector<Mat>& mats) {
+  LmcsTree t;
+  t.leaves = mats;
+  size_t H = mats.back().h;
+  int lgH = log2_strict(H);
+  // lifted_tree.rs:363-417: per-leaf sponge states carried across matrices; when the height
+  // grows, state i is duplicated to slots [i*f, (i+1)*f).
+  std::vector<std::array<uint64_t, 12>> st(H), scratch(H);
+  for (auto& s : st) s.fill(0);
+  size_t active = mats.front().h;
+  for (const Mat& m : mats) {
+    if (m.h > active) {
+      size_t f = m.h / active;
+      for (size_t i = 0; i < active; i++)
+        for (size_t k = 0; k < f; k++) scratch[i * f + k] = st[i];
+      std::swap(st, scratch);
+    }
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < (long)m.h; r++) sponge_absorb(st[r].data(), m.v + (size_t)r * m.w, m.w);
+    active = m.h;
+  }
+  // lifted_tree.rs:247-258: digest[i] = squeeze(state[bitrev(i)])
+  std::vector<Digest> cur(H);
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < (long)H; i++) {
+    const auto& s = st[bitrev((uint32_t)i, lgH)];
+    cur[i] = Digest{s[0], s[1], s[2], s[3]};
+  }
+  std::vector<std::vector<Digest>> up;
+  up.push_back(cur);
+  while (up.back().size() > 1) {
+    const auto& prev = up.back();
+    std::vector<Digest> next(prev.size() / 2);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)next.size(); i++) compress(prev[2 * i].data(), prev[2 * i + 1].data(), next[i].data());
+    up.push_back(std::move(next));
+  }
+  std::reverse(up.begin(), up.end());
+  t.layers = std::move(up);
+  return t;
+}
+
+// lifted_tree.rs:326-341: rows of every matrix for DOMAIN index `idx`, each padded with zeros to a
+// multiple of `alignment` (alignment 1 = unpadded).
+static inline std::vector<uint64_t> lmcs_rows(const LmcsTree& t, size_t idx, size_t alignment) {
+  size_t H = t.height();
+  int lgH = log2_strict(H);
+  size_t br = bitrev((uint32_t)idx, lgH);
+  std::vector<uint64_t> out;
+  for (const Mat& m : t.leaves) {
+    int sh = log2_strict(H / m.h);
+    const uint64_t* row = m.v + (br >> sh) * m.w;
+    out.insert(out.end(), row, row + m.w);
+    size_t padded = (m.w + alignment - 1) / alignment * alignment;
+    out.insert(out.end(), padded - m.w, 0);
+  }
+  return out;
+}
+
+// tree_indices.rs: sorted+dedup indices at `depth`; missing siblings bottom-up, left-to-right.
+// Returns (depth, position) pairs.
+static inline std::vector<std::pair<int, size_t>> missing_siblings(std::vector<size_t> idx, int depth) {
+  std::sort(idx.begin(), idx.end());
+  idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
+  std::vector<std::pair<int, size_t>> out;
+  std::vector<size_t> cur = idx;
+  for (int d = depth; d > 0; d--) {
+    std::vector<size_t> next;
+    for (size_t i = 0; i < cur.size();) {
+      size_t node = cur[i], sib = node ^ 1;
+      bool present = (i + 1 < cur.size() && cur[i + 1] == sib);
+      if (next.empty() || next.back() != (node >> 1)) next.push_back(node >> 1);
+      if (!present) out.push_back({d, sib});
+      i += present ? 2 : 1;
+    }
+    cur = next;
+  }
+  return out;
+}
+
+// lifted_tree.rs:155-180 prove_batch: hinted felts (opened aligned rows per sorted unique index)
+// and hinted commitments (missing siblings).
+static inline void lmcs_prove_batch(const LmcsTree& t, std::vector<size_t> indices, size_t alignment,
+                                    std::vector<uint64_t>& fields, std::vector<Digest>& commitments) {
+  std::sort(indices.begin(), indices.end());
+  indices.erase(std::unique(indices.begin(), indices.end()), indices.end());
+  for (size_t i : indices) {
+    auto r = lmcs_rows(t, i, alignment);
+    fields.insert(fields.end(), r.begin(), r.end());
+  }
+  int depth = log2_strict(t.height());
+  for (auto& s : missing_siblings(indices, depth)) commitments.push_back(t.layers[s.first][s.second]);
+}
+
+}  // namespace oracle

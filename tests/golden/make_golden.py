@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Extract the reference's own known-answer vectors for the Poseidon2/Merkle hot path into
+tests/golden/kat.json.  Run in the build container (needs /root/reference); the JSON is committed
+because /root/reference does not exist on the GPU box.
+
+Vectors:
+  1. Poseidon2 permutation KAT .... crates/crypto/src/hash/algebraic_sponge/poseidon2/test.rs:7-39
+  2. RELATION_DIGEST ............... air/src/config.rs:93-98  (= hash_elements([0] ++ ACE_ROOT))
+  3. ACE_CIRCUIT_REGISTRY_ROOT ..... air/src/config.rs:103-108 (depth-3 merge tree over the leaves)
+  4. ACE_CIRCUIT_REGISTRY_LEAVES ... air/src/config.rs:126-175 (leaves 6,7 = hash_elements([0xace,i]))
+  5. EMPTY_SUBTREES ................ crates/crypto/src/merkle/empty_roots.rs:49-.. (chain of merge(x,x))
+  6. Poseidon2 constants ........... .../poseidon2/constants.rs:18-211 (cross-check of p2_constants.inc)
+"""
+import json, os, re
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+def ints(s):
+    return [int(x, 16) if x.startswith("0x") else int(x) for x in re.findall(r"new_unchecked\((0x[0-9a-fA-F]+|\d+)\)", s)]
+
+def const_block(src, name):
+    m = re.search(r"const %s:[^=]*=\s*&?\[(.*?)\n\];" % name, src, re.S)
+    assert m, name
+    return ints(m.group(1))
+
+def main():
+    out = {}
+    t = open(f"{REF}/crates/crypto/src/hash/algebraic_sponge/poseidon2/test.rs").read()
+    body = t[t.index("fn permutation_test_vector"):t.index("fn test_poseidon2_permutation_basic")]
+    exp = [int(x, 16) for x in re.findall(r"perm\[\d+\], Felt::new_unchecked\((0x[0-9a-f]+)\)", body)]
+    assert len(exp) == 12
+    out["permutation_kat"] = {"input": list(range(12)), "output": exp}
+    cfg = open(f"{REF}/air/src/config.rs").read()
+    out["relation_digest"] = const_block(cfg, "RELATION_DIGEST")
+    out["ace_root"] = const_block(cfg, "ACE_CIRCUIT_REGISTRY_ROOT")
+    leaves = const_block(cfg, "ACE_CIRCUIT_REGISTRY_LEAVES")
+    assert len(leaves) == 32
+    out["ace_leaves"] = [leaves[4*i:4*i+4] for i in range(8)]
+    er = open(f"{REF}/crates/crypto/src/merkle/empty_roots.rs").read()
+    es = const_block(er, "EMPTY_SUBTREES")
+    assert len(es) == 1024
+    out["empty_subtrees"] = [es[4*i:4*i+4] for i in range(256)]
+    c = open(f"{REF}/crates/crypto/src/hash/algebraic_sponge/poseidon2/constants.rs").read()
+    def hexblock(name):
+        m = re.search(r"const %s:[^=]*=\s*\[(.*?)\];\n" % name, c, re.S)
+        return [int(x, 16) for x in re.findall(r"0x[0-9a-fA-F]+", m.group(1))]
+    out["p2_constants"] = {k: hexblock(k) for k in ("MAT_DIAG", "ARK_EXT_INITIAL", "ARK_INT", "ARK_EXT_TERMINAL")}
+    out["root_2_32"] = int(re.search(r"const ROOT_UNITY = (\d+)", open(f"{REF}/crates/lib/core/asm/stark/constants.masm").read()).group(1))
+    with open(os.path.join(HERE, "kat.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("wrote kat.json:", {k: (len(v) if hasattr(v, '__len__') else v) for k, v in out.items()})
+
+if __name__ == "__main__":
+    main()
