@@ -1,0 +1,93 @@
+/* libmidenhip — C ABI of the MI355X-native STARK proving backend for Miden VM.
+ *
+ * Drop-in boundary: these entry points are what a Rust FFI shim under
+ * `miden_prover::prove_stark()` (reference prover/src/lib.rs:317-355) binds; see INTEGRATION.md
+ * for the `extern "C"` block and the cfg-gated `prove_stark_hip`.  Conventions, following the
+ * reference's own C-ABI precedent (crates/crypto/src/hash/algebraic_sponge/rescue/arch/mod.rs:12-21):
+ *   - plain pointers and sizes only; all field elements are uint64_t Goldilocks values
+ *     (p = 2^64 - 2^32 + 1); inputs may be non-canonical (< 2^64), outputs are canonical;
+ *   - extension-field elements are 2 consecutive uint64_t [c0, c1] (x^2 = 7);
+ *   - every function returns 0 on success or an MH_ERR_* code; mh_last_error(ctx) gives the
+ *     message; no exception or panic crosses the boundary;
+ *   - the caller owns host buffers; the library owns device buffers until the matching *_free;
+ *   - one ctx per proving thread, calls on one ctx are blocking and not re-entrant.
+ */
+#ifndef MIDENHIP_H
+#define MIDENHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_OK 0
+#define MH_ERR_INVALID 1
+#define MH_ERR_HIP 2
+#define MH_ERR_OOM 3
+#define MH_ERR_INTERNAL 4
+
+typedef struct mh_ctx mh_ctx;
+typedef struct mh_trace mh_trace; /* device-resident trace matrix (column-major) */
+typedef struct mh_tree mh_tree;   /* device-resident LMCS tree + its LDE matrices */
+
+/* ---- context ------------------------------------------------------------------------------ */
+int mh_ctx_create(int device_id, mh_ctx** out);
+void mh_ctx_destroy(mh_ctx* ctx);
+const char* mh_last_error(const mh_ctx* ctx);
+int mh_device_count(void);
+
+/* Kernel profiler: HIP events recorded on the ctx's private stream around each kernel class.
+ * mh_prof_get returns accumulated milliseconds, attributed algorithmic bytes and launch count. */
+int mh_prof_enable(mh_ctx* ctx, int on);
+int mh_prof_reset(mh_ctx* ctx);
+int mh_prof_get(mh_ctx* ctx, const char* name, double* ms, double* bytes, long* count);
+/* writes up to cap bytes of a '\n'-separated "name ms bytes count" listing */
+int mh_prof_dump(mh_ctx* ctx, char* buf, size_t cap);
+
+/* ---- unit-parity entry points --------------------------------------------------------------- */
+/* Poseidon2 permutation (replaces Poseidon2Permutation256::permute_mut,
+ * crates/crypto/src/hash/algebraic_sponge/poseidon2/mod.rs:340,380-386) on n states of 12 felts,
+ * host array-of-states layout [n][12], in place. */
+int mh_poseidon2_permute(mh_ctx* ctx, uint64_t* states, size_t n);
+
+/* Coset LDE of a host row-major matrix (replaces Radix2DitParallel::coset_lde_batch as called at
+ * crates/lifted-stark/src/prover/commit.rs:173): `out` receives the (n<<added_bits) x width
+ * row-major matrix in the REFERENCE's storage order (physical row r = evaluation at
+ * shift * w^bitrev(r)), for parity checks. */
+int mh_coset_lde_batch(mh_ctx* ctx, const uint64_t* rowmajor, int log_n, size_t width, int added_bits,
+                       uint64_t shift, uint64_t* out);
+
+/* ---- device-resident traces ----------------------------------------------------------------- */
+/* Upload a host row-major RowMajorMatrix<Felt> (values, width) of height 2^log_n: one H2D copy +
+ * an on-device transpose to column-major; canonicalises felts. */
+int mh_trace_upload(mh_ctx* ctx, const uint64_t* rowmajor, int log_n, size_t width, mh_trace** out);
+void mh_trace_free(mh_trace* t);
+
+/* ---- commitments (K1-K3) -------------------------------------------------------------------- */
+/* commit_traces (crates/lifted-stark/src/prover/commit.rs:142-180): per trace (proof order =
+ * ascending height) coset-LDE by 2^log_blowup on the canonical shift of ITS lde order, then the
+ * aligned LMCS tree (Lmcs::build_aligned_tree, lmcs/config.rs:125-137).  root = 4 felts. */
+int mh_commit_traces(mh_ctx* ctx, int n_traces, mh_trace* const* traces, int log_blowup, mh_tree** out,
+                     uint64_t root[4]);
+void mh_tree_free(mh_tree* t);
+int mh_tree_root(const mh_tree* t, uint64_t root[4]);
+int mh_tree_log_height(const mh_tree* t);
+
+/* LmcsTree::prove_batch (lmcs/lifted_tree.rs:155-180): for sorted, de-duplicated domain indices
+ * (this call sorts/dedups), the opened rows of every matrix padded to `alignment`, then the
+ * missing sibling digests bottom-up, left-to-right.  fields/commits must hold
+ * n_idx * sum(aligned widths) and n_idx * depth * 4 felts at most. */
+int mh_tree_open(mh_ctx* ctx, const mh_tree* t, const uint64_t* indices, size_t n_idx, size_t alignment,
+                 uint64_t* fields, size_t* n_fields, uint64_t* commits, size_t* n_commit_felts);
+
+/* Parity/debug: download matrix `mat` of the tree in the reference's storage order
+ * (row-major, bit-reversed rows). */
+int mh_tree_download_lde(mh_ctx* ctx, const mh_tree* t, int mat, uint64_t* out_rowmajor_bitrev);
+/* Parity/debug: download all digest layers, leaf layer (domain order) first: (2H-1)*4 felts. */
+int mh_tree_download_layers(mh_ctx* ctx, const mh_tree* t, uint64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIDENHIP_H */

@@ -1,0 +1,220 @@
+"""miden-vm_amd: host-side mirror of the reference's prover interface over libmidenhip's C ABI.
+
+The reference's host language is Rust (no toolchain in this image), so this Python layer stands in
+for the Rust shim in tests and benches; names follow the reference:
+  commit_traces ............... crates/lifted-stark/src/prover/commit.rs:142-180
+  Committed.root()/tree() ..... crates/lifted-stark/src/prover/commit.rs:60-77
+  LmcsTree.prove_batch ........ crates/lifted-stark/src/lmcs/lifted_tree.rs:155-180
+  coset_lde_batch ............. p3-dft call at prover/commit.rs:173
+  Poseidon2Permutation256 ..... crates/crypto/src/hash/algebraic_sponge/poseidon2/mod.rs:340-386
+There is NO CPU fallback: if libmidenhip.so or a GPU is missing, construction raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmidenhip.so")
+P = 0xFFFFFFFF00000001
+u64p = C.POINTER(C.c_uint64)
+
+EXPORTS = [
+    "mh_ctx_create", "mh_ctx_destroy", "mh_last_error", "mh_device_count", "mh_prof_enable", "mh_prof_reset",
+    "mh_prof_get", "mh_prof_dump", "mh_poseidon2_permute", "mh_coset_lde_batch", "mh_trace_upload", "mh_trace_free",
+    "mh_commit_traces", "mh_tree_free", "mh_tree_root", "mh_tree_log_height", "mh_tree_open", "mh_tree_download_lde",
+    "mh_tree_download_layers",
+]
+
+_lib = None
+
+
+class MidenHipError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen libmidenhip.so (does not touch the GPU)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MidenHipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    lib.mh_last_error.restype = C.c_char_p
+    lib.mh_last_error.argtypes = [C.c_void_p]
+    lib.mh_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.mh_ctx_destroy.argtypes = [C.c_void_p]
+    lib.mh_trace_free.argtypes = [C.c_void_p]
+    lib.mh_tree_free.argtypes = [C.c_void_p]
+    lib.mh_tree_log_height.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _arr(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.uint64))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(u64p)
+
+
+class Ctx:
+    """One proving context = one GPU + one private stream (mh_ctx)."""
+
+    def __init__(self, device_id=0):
+        self.lib = load_library()
+        if self.lib.mh_device_count() <= 0:
+            raise MidenHipError("no HIP device visible: libmidenhip has no CPU fallback")
+        h = C.c_void_p()
+        rc = self.lib.mh_ctx_create(device_id, C.byref(h))
+        if rc != 0:
+            raise MidenHipError(f"mh_ctx_create failed with code {rc}")
+        self.h = h
+
+    def check(self, rc):
+        if rc != 0:
+            raise MidenHipError(f"libmidenhip error {rc}: {self.lib.mh_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mh_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- profiler ----
+    def prof_enable(self, on=True):
+        self.check(self.lib.mh_prof_enable(self.h, int(on)))
+
+    def prof_reset(self):
+        self.check(self.lib.mh_prof_reset(self.h))
+
+    def prof(self):
+        buf = C.create_string_buffer(1 << 16)
+        self.check(self.lib.mh_prof_dump(self.h, buf, C.c_size_t(len(buf))))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, by, cnt = line.split()
+            out[name] = {"ms": float(ms), "bytes": float(by), "count": int(cnt)}
+        return out
+
+    # ---- unit-parity entry points ----
+    def poseidon2_permute(self, states):
+        s = _arr(states).copy().reshape(-1, 12)
+        self.check(self.lib.mh_poseidon2_permute(self.h, _ptr(s), C.c_size_t(s.shape[0])))
+        return s
+
+    def coset_lde_batch(self, matrix, added_bits, shift):
+        """Reference storage order: row-major, physical row r = eval at shift*w^bitrev(r)."""
+        m = _arr(matrix)
+        n, w = m.shape
+        log_n = int(n).bit_length() - 1
+        assert 1 << log_n == n
+        out = np.zeros((n << added_bits, w), dtype=np.uint64)
+        self.check(self.lib.mh_coset_lde_batch(self.h, _ptr(m), log_n, C.c_size_t(w), added_bits,
+                                               C.c_uint64(int(shift)), _ptr(out)))
+        return out
+
+    def upload_trace(self, matrix):
+        return Trace(self, matrix)
+
+
+class Trace:
+    """Device-resident RowMajorMatrix<Felt> (stored column-major on the GPU)."""
+
+    def __init__(self, ctx, matrix):
+        m = _arr(matrix)
+        n, w = m.shape
+        self.log_n = int(n).bit_length() - 1
+        assert 1 << self.log_n == n, "trace height must be a power of two"
+        self.width = w
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mh_trace_upload(ctx.h, _ptr(m), self.log_n, C.c_size_t(w), C.byref(h)))
+        self.h = h
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.mh_trace_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class LmcsTree:
+    def __init__(self, ctx, h, widths, log_heights, log_blowup):
+        self.ctx, self.h = ctx, h
+        self.widths, self.log_heights, self.log_blowup = widths, log_heights, log_blowup
+        self.log_height = ctx.lib.mh_tree_log_height(h)
+
+    def root(self):
+        r = np.zeros(4, dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.mh_tree_root(self.h, _ptr(r)))
+        return r
+
+    def prove_batch(self, indices, alignment=8):
+        """-> (hinted felts, hinted commitments[k][4]) exactly as streamed into the transcript."""
+        idx = _arr(list(indices))
+        n = idx.size
+        tot_w = sum(((w + alignment - 1) // alignment) * alignment for w in self.widths)
+        fields = np.zeros(max(1, n * tot_w), dtype=np.uint64)
+        commits = np.zeros(max(1, n * self.log_height * 4), dtype=np.uint64)
+        nf, nc = C.c_size_t(0), C.c_size_t(0)
+        self.ctx.check(self.ctx.lib.mh_tree_open(self.ctx.h, self.h, _ptr(idx), C.c_size_t(n), C.c_size_t(alignment),
+                                                 _ptr(fields), C.byref(nf), _ptr(commits), C.byref(nc)))
+        return fields[:nf.value].copy(), commits[:nc.value].reshape(-1, 4).copy()
+
+    def download_lde(self, mat):
+        rows = 1 << (self.log_heights[mat] + self.log_blowup)
+        out = np.zeros((rows, self.widths[mat]), dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.mh_tree_download_lde(self.ctx.h, self.h, mat, _ptr(out)))
+        return out
+
+    def download_layers(self):
+        out = np.zeros(((2 << self.log_height) - 1, 4), dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.mh_tree_download_layers(self.ctx.h, self.h, _ptr(out)))
+        return out
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.mh_tree_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Committed:
+    """Mirror of prover/commit.rs `Committed`: root() + tree()."""
+
+    def __init__(self, tree):
+        self._tree = tree
+
+    def root(self):
+        return self._tree.root()
+
+    def tree(self):
+        return self._tree
+
+
+def commit_traces(ctx, traces, log_blowup):
+    """traces: list of Trace in proof order (ascending height)."""
+    n = len(traces)
+    arr = (C.c_void_p * n)(*[t.h for t in traces])
+    h = C.c_void_p()
+    root = np.zeros(4, dtype=np.uint64)
+    ctx.check(ctx.lib.mh_commit_traces(ctx.h, n, arr, log_blowup, C.byref(h), _ptr(root)))
+    return Committed(LmcsTree(ctx, h, [t.width for t in traces], [t.log_n for t in traces], log_blowup))

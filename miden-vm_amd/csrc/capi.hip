@@ -1,0 +1,281 @@
+// extern "C" boundary of libmidenhip (include/midenhip.h).  Exceptions stop here.
+#include "../../include/midenhip.h"
+#include "ctx.hpp"
+#include "gl.cuh"
+#include "kernels.hpp"
+#include <algorithm>
+#include <cstring>
+
+#define MH_TRY(ctx_expr) mh_ctx* _c = (ctx_expr); try {
+#define MH_CATCH                                                   \
+  }                                                                \
+  catch (const MhError& e) {                                       \
+    if (_c) _c->err = e.what();                                    \
+    return e.code;                                                 \
+  }                                                                \
+  catch (const std::exception& e) {                                \
+    if (_c) _c->err = e.what();                                    \
+    return MH_ERR_INTERNAL;                                        \
+  }                                                                \
+  return MH_OK;
+
+// coset-major column-major LDE -> reference layout (row-major, bit-reversed physical rows)
+__global__ void k_lde_to_reference_layout(const u64* __restrict__ lde, u64* __restrict__ out, int log_n, int lb, size_t w) {
+  size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  size_t rows = (size_t)1 << (log_n + lb);
+  if (t >= rows * w) return;
+  size_t pr = t / w, cidx = t % w;
+  size_t i = bitrev32((u32)pr, log_n + lb);
+  size_t j = i & (((size_t)1 << lb) - 1), r = i >> lb;
+  out[t] = lde[(((cidx << lb) + j) << log_n) + r];
+}
+
+static std::vector<u64> coset_shifts(int log_n, int lb) {
+  // shift * w_K^j for j < B, K of order 2^(log_n+lb), canonical shift of that order (domain.rs:358-361)
+  u64 g = gl_lde_shift(log_n + lb);
+  u64 wk = gl_two_adic_generator(log_n + lb);
+  std::vector<u64> s((size_t)1 << lb);
+  u64 x = g;
+  for (auto& v : s) {
+    v = x;
+    x = gl_mul(x, wk);
+  }
+  return s;
+}
+
+extern "C" {
+
+int mh_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int mh_ctx_create(int device_id, mh_ctx** out) {
+  if (!out) return MH_ERR_INVALID;
+  *out = nullptr;
+  mh_ctx* c = new mh_ctx();
+  try {
+    int n = 0;
+    HIP_CHECK(hipGetDeviceCount(&n));
+    MH_REQUIRE(device_id >= 0 && device_id < n, "no such HIP device (libmidenhip needs an AMD GPU; there is no CPU fallback)");
+    HIP_CHECK(hipSetDevice(device_id));
+    c->device = device_id;
+    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  } catch (const std::exception& e) {
+    fprintf(stderr, "mh_ctx_create: %s\n", e.what());
+    delete c;
+    return MH_ERR_HIP;
+  }
+  *out = c;
+  return MH_OK;
+}
+
+void mh_ctx_destroy(mh_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto e : c->event_pool) (void)hipEventDestroy(e);
+  c->tw_fwd.clear(); c->tw_inv.clear(); c->tables.clear();
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* mh_last_error(const mh_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+int mh_prof_enable(mh_ctx* c, int on) {
+  MH_TRY(c)
+  MH_REQUIRE(c, "null ctx");
+  c->prof_resolve();
+  c->prof_on = on != 0;
+  MH_CATCH
+}
+int mh_prof_reset(mh_ctx* c) {
+  MH_TRY(c)
+  MH_REQUIRE(c, "null ctx");
+  c->prof_resolve();
+  c->prof.clear();
+  MH_CATCH
+}
+int mh_prof_get(mh_ctx* c, const char* name, double* ms, double* bytes, long* count) {
+  MH_TRY(c)
+  MH_REQUIRE(c && name, "null argument");
+  c->prof_resolve();
+  auto it = c->prof.find(name);
+  ProfEntry e = it == c->prof.end() ? ProfEntry{} : it->second;
+  if (ms) *ms = e.ms;
+  if (bytes) *bytes = e.bytes;
+  if (count) *count = e.count;
+  MH_CATCH
+}
+int mh_prof_dump(mh_ctx* c, char* buf, size_t cap) {
+  MH_TRY(c)
+  MH_REQUIRE(c && buf && cap, "null argument");
+  c->prof_resolve();
+  std::string s;
+  for (auto& kv : c->prof) {
+    char line[256];
+    snprintf(line, sizeof line, "%s %.6f %.0f %ld\n", kv.first.c_str(), kv.second.ms, kv.second.bytes, kv.second.count);
+    s += line;
+  }
+  size_t n = std::min(cap - 1, s.size());
+  memcpy(buf, s.data(), n);
+  buf[n] = 0;
+  MH_CATCH
+}
+
+int mh_poseidon2_permute(mh_ctx* c, uint64_t* states, size_t n) {
+  MH_TRY(c)
+  MH_REQUIRE(c && (states || !n), "null argument");
+  if (!n) return MH_OK;
+  HIP_CHECK(hipSetDevice(c->device));
+  DevBuf aos(n * 96), soa(n * 96);
+  HIP_CHECK(hipMemcpyAsync(aos.p, states, n * 96, hipMemcpyHostToDevice, c->stream));
+  launch_transpose_rm_to_cm(c, aos.u(), soa.u(), n, 12);  // [n][12] -> [12][n], canonicalises
+  {
+    ProfScope ps(c, "poseidon2_permute", 192.0 * n);
+    poseidon2_permute_device(c, soa.u(), n);
+  }
+  launch_transpose_rm_to_cm(c, soa.u(), aos.u(), 12, n);  // back to [n][12]
+  HIP_CHECK(hipMemcpyAsync(states, aos.p, n * 96, hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+  MH_CATCH
+}
+
+int mh_trace_upload(mh_ctx* c, const uint64_t* rowmajor, int log_n, size_t width, mh_trace** out) {
+  MH_TRY(c)
+  MH_REQUIRE(c && rowmajor && out, "null argument");
+  MH_REQUIRE(log_n >= 0 && log_n <= 29 && width > 0, "bad trace shape");
+  HIP_CHECK(hipSetDevice(c->device));
+  size_t n = (size_t)1 << log_n;
+  std::unique_ptr<mh_trace> t(new mh_trace());
+  t->ctx = c; t->log_n = log_n; t->width = width;
+  DevBuf staging(n * width * 8);
+  t->cols.alloc(n * width * 8);
+  HIP_CHECK(hipMemcpyAsync(staging.p, rowmajor, n * width * 8, hipMemcpyHostToDevice, c->stream));
+  {
+    ProfScope ps(c, "transpose_in", 16.0 * n * width);
+    launch_transpose_rm_to_cm(c, staging.u(), t->cols.u(), n, width);
+  }
+  c->sync();
+  *out = t.release();
+  MH_CATCH
+}
+void mh_trace_free(mh_trace* t) {
+  if (!t) return;
+  (void)hipSetDevice(t->ctx->device);
+  delete t;
+}
+
+// LDE of one uploaded trace into coset-major layout on the canonical shift of its own LDE order.
+static LdeMatrix lde_trace(mh_ctx* c, const mh_trace* tr, int lb) {
+  LdeMatrix m;
+  m.log_n = tr->log_n; m.width = tr->width;
+  size_t N = (size_t)1 << tr->log_n;
+  m.lde.alloc((N << lb) * tr->width * 8);
+  DevBuf scratch(N * tr->width * 8);
+  MH_REQUIRE(tr->log_n + lb <= 32, "LDE order exceeds the field's two-adicity");
+  ProfScope ps(c, "lde", (double)(1 + (1 << lb)) * N * tr->width * 8.0);
+  lde_columns(c, tr->cols.u(), tr->width, tr->log_n, 1, coset_shifts(tr->log_n, lb), m.lde.u(), scratch.u());
+  return m;
+}
+
+int mh_commit_traces(mh_ctx* c, int n_traces, mh_trace* const* traces, int log_blowup, mh_tree** out, uint64_t root[4]) {
+  MH_TRY(c)
+  MH_REQUIRE(c && traces && out && n_traces > 0, "null/empty argument");
+  MH_REQUIRE(log_blowup >= 0 && log_blowup <= 8, "bad log_blowup");
+  HIP_CHECK(hipSetDevice(c->device));
+  std::unique_ptr<mh_tree> t(new mh_tree());
+  t->ctx = c; t->log_blowup = log_blowup;
+  for (int i = 0; i < n_traces; i++) {
+    MH_REQUIRE(traces[i], "null trace");
+    t->mats.push_back(lde_trace(c, traces[i], log_blowup));
+  }
+  lmcs_build_tree(c, t.get());
+  if (root) memcpy(root, t->root, 32);
+  *out = t.release();
+  MH_CATCH
+}
+void mh_tree_free(mh_tree* t) {
+  if (!t) return;
+  (void)hipSetDevice(t->ctx->device);
+  delete t;
+}
+int mh_tree_root(const mh_tree* t, uint64_t root[4]) {
+  if (!t || !root) return MH_ERR_INVALID;
+  memcpy(root, t->root, 32);
+  return MH_OK;
+}
+int mh_tree_log_height(const mh_tree* t) { return t ? t->log_height : -1; }
+
+int mh_tree_open(mh_ctx* c, const mh_tree* t, const uint64_t* indices, size_t n_idx, size_t alignment, uint64_t* fields,
+                 size_t* n_fields, uint64_t* commits, size_t* n_commit_felts) {
+  MH_TRY(c)
+  MH_REQUIRE(c && t && (indices || !n_idx) && n_fields && n_commit_felts, "null argument");
+  MH_REQUIRE(alignment > 0, "alignment must be non-zero");
+  HIP_CHECK(hipSetDevice(c->device));
+  std::vector<size_t> idx(indices, indices + n_idx);
+  std::sort(idx.begin(), idx.end());
+  idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
+  std::vector<u64> f, cm;
+  lmcs_open(c, t, idx, alignment, f, cm);
+  if (!f.empty()) memcpy(fields, f.data(), f.size() * 8);
+  if (!cm.empty()) memcpy(commits, cm.data(), cm.size() * 8);
+  *n_fields = f.size();
+  *n_commit_felts = cm.size();
+  MH_CATCH
+}
+
+int mh_tree_download_lde(mh_ctx* c, const mh_tree* t, int mat, uint64_t* out) {
+  MH_TRY(c)
+  MH_REQUIRE(c && t && out && mat >= 0 && (size_t)mat < t->mats.size(), "bad argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  const LdeMatrix& m = t->mats[mat];
+  size_t total = (((size_t)1 << m.log_n) << t->log_blowup) * m.width;
+  DevBuf tmp(total * 8);
+  hipLaunchKernelGGL(k_lde_to_reference_layout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, m.lde.u(),
+                     tmp.u(), m.log_n, t->log_blowup, m.width);
+  HIP_CHECK(hipMemcpyAsync(out, tmp.p, total * 8, hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+  MH_CATCH
+}
+
+int mh_tree_download_layers(mh_ctx* c, const mh_tree* t, uint64_t* out) {
+  MH_TRY(c)
+  MH_REQUIRE(c && t && out, "bad argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  size_t total = ((size_t)2 << t->log_height) - 1;
+  std::vector<u64> raw(total * 4);
+  HIP_CHECK(hipMemcpyAsync(raw.data(), t->nodes.p, total * 32, hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+  size_t o = 0;
+  for (int d = t->log_height; d >= 0; d--)
+    for (size_t p = 0; p < ((size_t)1 << d); p++, o += 4)
+      memcpy(out + o, raw.data() + 4 * (t->layer_off[d] + t->node_slot(d, p)), 32);
+  MH_CATCH
+}
+
+int mh_coset_lde_batch(mh_ctx* c, const uint64_t* rowmajor, int log_n, size_t width, int added_bits, uint64_t shift,
+                       uint64_t* out) {
+  MH_TRY(c)
+  MH_REQUIRE(c && rowmajor && out && width > 0 && log_n >= 0 && added_bits >= 0, "bad argument");
+  MH_REQUIRE(log_n + added_bits <= 32, "LDE order exceeds the field's two-adicity");
+  HIP_CHECK(hipSetDevice(c->device));
+  size_t N = (size_t)1 << log_n, total = (N << added_bits) * width;
+  DevBuf staging(N * width * 8), cols(N * width * 8), scratch(N * width * 8), lde(total * 8), tmp(total * 8);
+  HIP_CHECK(hipMemcpyAsync(staging.p, rowmajor, N * width * 8, hipMemcpyHostToDevice, c->stream));
+  launch_transpose_rm_to_cm(c, staging.u(), cols.u(), N, width);
+  u64 wk = gl_two_adic_generator(log_n + added_bits);
+  std::vector<u64> shifts((size_t)1 << added_bits);
+  u64 x = gl_canon(shift);
+  for (auto& v : shifts) { v = x; x = gl_mul(x, wk); }
+  lde_columns(c, cols.u(), width, log_n, 1, shifts, lde.u(), scratch.u());
+  hipLaunchKernelGGL(k_lde_to_reference_layout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, lde.u(), tmp.u(),
+                     log_n, added_bits, width);
+  HIP_CHECK(hipMemcpyAsync(out, tmp.p, total * 8, hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+  MH_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+// Runtime context of the MI355X proving backend: one HIP device, one private stream, cached
+// twiddle / coset tables, a kernel profiler (HIP events on the private stream) and error state.
+// One ctx per proving thread (SURVEY.md section 8b "Threading"): no global mutable state.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+typedef uint64_t u64;
+
+struct MhError : std::runtime_error {
+  int code;
+  MhError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define MH_ERR_INVALID 1
+#define MH_ERR_HIP 2
+#define MH_ERR_OOM 3
+#define MH_ERR_INTERNAL 4
+
+#define HIP_CHECK(expr)                                                                          \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess)                                                                        \
+      throw MhError(_e == hipErrorOutOfMemory ? MH_ERR_OOM : MH_ERR_HIP,                         \
+                    std::string(#expr) + " failed: " + hipGetErrorString(_e) + " at " + __FILE__ + ":" + \
+                        std::to_string(__LINE__));                                               \
+  } while (0)
+
+#define MH_REQUIRE(cond, msg)                                        \
+  do {                                                               \
+    if (!(cond)) throw MhError(MH_ERR_INVALID, std::string(msg));    \
+  } while (0)
+
+// RAII device allocation.
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() {}
+  explicit DevBuf(size_t n) { alloc(n); }
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) {
+      release();
+      p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0;
+    }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void alloc(size_t n) {
+    release();
+    if (n == 0) return;
+    HIP_CHECK(hipMalloc(&p, n));
+    bytes = n;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr; bytes = 0;
+  }
+  u64* u() const { return (u64*)p; }
+};
+
+struct ProfEntry {
+  double ms = 0;
+  double bytes = 0;  // algorithmic bytes attributed by the caller
+  long count = 0;
+};
+
+struct mh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // profiler
+  bool prof_on = false;
+  struct Pending { std::string name; hipEvent_t a, b; double bytes; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+  std::map<std::string, ProfEntry> prof;
+  // caches: log_n -> device table of w_N^k (k < N/2) forward / inverse
+  std::map<int, DevBuf> tw_fwd, tw_inv;
+  // coset-scale tables keyed by (log_n, log_blowup, kind)
+  std::map<std::string, DevBuf> tables;
+
+  hipEvent_t get_event();
+  void prof_begin(const char* name, double bytes);
+  void prof_end();
+  void prof_resolve();
+  void sync();
+  const u64* twiddles(int log_n, bool inverse);
+};
+
+// RAII helper: time everything launched on ctx->stream within the scope under `name`.
+struct ProfScope {
+  mh_ctx* c;
+  ProfScope(mh_ctx* ctx, const char* name, double bytes = 0) : c(ctx) {
+    if (c->prof_on) c->prof_begin(name, bytes);
+  }
+  ~ProfScope() {
+    if (c->prof_on) c->prof_end();
+  }
+};

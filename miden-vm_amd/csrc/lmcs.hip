@@ -1,0 +1,255 @@
+// K2 / K3 / K10 / K13: Lifted Matrix Commitment Scheme with the Poseidon2 sponge, gfx950.
+//
+// Replaces crates/lifted-stark/src/lmcs/lifted_tree.rs:
+//   :363-461 build_leaf_states_upsampled / absorb_matrix  -> k_leaf_absorb
+//   :247-258 squeeze + bit-reverse                        -> folded into the layouts below
+//   :472-511 compress_uniform                             -> k_compress
+//   :155-180, :326-341 prove_batch / collect_rows         -> lmcs_open
+// Sponge: crates/stateful-hasher/src/field_sponge.rs:41-64 (overwrite mode, rate 8, zero-pad the
+// trailing partial chunk, state carried across matrices).  Compression: perm([L|R|0000])[0..4]
+// (air/src/config.rs:213-220).
+//
+// Layout (MI355X-first, differs from the reference's bit-reversed row-major storage):
+//   leaf slot q = j*N + r  <->  domain (natural) index i = r*B + j   (B = 2^log_blowup cosets)
+//   Tree pairs (2p, 2p+1) in natural order = cosets (2j', 2j'+1) at equal r: for the first
+//   log_blowup levels both children streams are unit-stride; afterwards the layer is in plain
+//   natural order and children are adjacent (64 contiguous bytes per lane).
+//   A lifted (shorter) matrix contributes row r mod N_m of coset j (i mod B*N_m).
+// One sponge per lane, state in VGPRs; Poseidon2 is integer-ALU bound.
+#include "ctx.hpp"
+#include "kernels.hpp"
+#include "poseidon2.cuh"
+#include <algorithm>
+
+static constexpr int LEAF_MAX_MATS = 8;
+static constexpr int LEAF_THREADS = 256;
+
+__global__ __launch_bounds__(256) void k_permute_soa(u64* st, size_t n) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 s[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) s[j] = st[j * n + i];
+  p2_permute(s);
+#pragma unroll
+  for (int j = 0; j < 12; j++) st[j * n + i] = s[j];
+}
+
+void poseidon2_permute_device(mh_ctx* c, u64* states_soa, size_t n) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_permute_soa, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, states_soa, n);
+}
+
+struct LeafMat {
+  const u64* data;  // [width][B][N_m]
+  u32 width;
+};
+struct LeafArgs {
+  LeafMat m[LEAF_MAX_MATS];
+  int n_mats;
+  int log_blowup;
+  int log_n;             // height (per coset) of this group
+  const u64* state_in;   // [12][B * 2^log_n_prev] or null (zero state)
+  int log_n_prev;
+  u64* state_out;        // [12][B * 2^log_n] or null
+  u64* digest_out;       // [B * 2^log_n][4] or null
+};
+
+__global__ __launch_bounds__(LEAF_THREADS) void k_leaf_absorb(LeafArgs a) {
+  const size_t leaves = (size_t)1 << (a.log_n + a.log_blowup);
+  const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (q >= leaves) return;
+  const size_t j = q >> a.log_n, r = q & (((size_t)1 << a.log_n) - 1);
+  u64 s[12];
+  if (a.state_in) {
+    const size_t leaves_prev = (size_t)1 << (a.log_n_prev + a.log_blowup);
+    const size_t qi = (j << a.log_n_prev) + (r & (((size_t)1 << a.log_n_prev) - 1));
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = a.state_in[i * leaves_prev + qi];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+  }
+  const size_t col_stride = leaves;  // B * N
+#pragma unroll 1
+  for (int mi = 0; mi < a.n_mats; mi++) {
+    const u64* base = a.m[mi].data + q;
+    const u32 w = a.m[mi].width;
+#pragma unroll 1
+    for (u32 c0 = 0; c0 < w; c0 += 8) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) s[k] = (c0 + k < w) ? base[(size_t)(c0 + k) * col_stride] : 0;
+      p2_permute(s);
+    }
+  }
+  if (a.digest_out) {
+    ulonglong2* o = reinterpret_cast<ulonglong2*>(a.digest_out + 4 * q);
+    o[0] = make_ulonglong2(s[0], s[1]);
+    o[1] = make_ulonglong2(s[2], s[3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; i++) a.state_out[i * leaves + q] = s[i];
+  }
+}
+
+// out[q] = compress(in[left(q)], in[left(q) + sib]) ; coset phase: left = (2j')*N + r, sib = N;
+// natural phase: left = 2q, sib = 1.
+__global__ __launch_bounds__(256) void k_compress(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out, int log_n_coset) {
+  const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (q >= n_out) return;
+  size_t l, rgt;
+  if (log_n_coset >= 0) {
+    size_t N = (size_t)1 << log_n_coset;
+    size_t jp = q >> log_n_coset, r = q & (N - 1);
+    l = ((2 * jp) << log_n_coset) + r;
+    rgt = l + N;
+  } else {
+    l = 2 * q;
+    rgt = l + 1;
+  }
+  const ulonglong2* pl = reinterpret_cast<const ulonglong2*>(in + 4 * l);
+  const ulonglong2* pr = reinterpret_cast<const ulonglong2*>(in + 4 * rgt);
+  ulonglong2 l0 = pl[0], l1 = pl[1], r0 = pr[0], r1 = pr[1];
+  u64 s[12] = {l0.x, l0.y, l1.x, l1.y, r0.x, r0.y, r1.x, r1.y, 0, 0, 0, 0};
+  p2_permute(s);
+  ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 4 * q);
+  o[0] = make_ulonglong2(s[0], s[1]);
+  o[1] = make_ulonglong2(s[2], s[3]);
+}
+
+void lmcs_build_tree(mh_ctx* c, mh_tree* t) {
+  MH_REQUIRE(!t->mats.empty(), "cannot commit empty batch");
+  const int lb = t->log_blowup;
+  const int log_n_max = t->mats.back().log_n;
+  t->log_height = log_n_max + lb;
+  const size_t H = (size_t)1 << t->log_height;
+  for (size_t i = 1; i < t->mats.size(); i++)
+    MH_REQUIRE(t->mats[i - 1].log_n <= t->mats[i].log_n, "matrices must be sorted by ascending height");
+  // layers: depth L (H nodes) first, then L-1, ..., 0
+  t->layer_off.assign(t->log_height + 1, 0);
+  size_t off = 0;
+  for (int d = t->log_height; d >= 0; d--) {
+    t->layer_off[d] = off;
+    off += (size_t)1 << d;
+  }
+  t->nodes.alloc(off * 32);
+
+  // ---- leaves: one launch per (height group, <=8 matrices) chained through a state buffer
+  DevBuf st_a, st_b;
+  const u64* state_in = nullptr;
+  int log_n_prev = 0;
+  size_t i = 0;
+  const size_t nm = t->mats.size();
+  while (i < nm) {
+    int ln = t->mats[i].log_n;
+    LeafArgs a{};
+    a.n_mats = 0;
+    double bytes = 0;
+    while (i < nm && t->mats[i].log_n == ln && a.n_mats < LEAF_MAX_MATS) {
+      a.m[a.n_mats].data = t->mats[i].lde.u();
+      a.m[a.n_mats].width = (u32)t->mats[i].width;
+      bytes += (double)t->mats[i].width * 8.0 * (double)((size_t)1 << (ln + lb));
+      a.n_mats++;
+      i++;
+    }
+    a.log_blowup = lb;
+    a.log_n = ln;
+    a.state_in = state_in;
+    a.log_n_prev = log_n_prev;
+    const bool last = (i == nm);
+    const size_t leaves = (size_t)1 << (ln + lb);
+    DevBuf& outbuf = (state_in == st_a.u()) ? st_b : st_a;
+    if (last) {
+      a.digest_out = t->nodes.u() + 4 * t->layer_off[t->log_height];
+      a.state_out = nullptr;
+      bytes += 32.0 * leaves;
+    } else {
+      outbuf.alloc(leaves * 12 * 8);
+      a.state_out = outbuf.u();
+      a.digest_out = nullptr;
+      bytes += 96.0 * leaves;
+    }
+    if (state_in) bytes += 96.0 * leaves;
+    {
+      ProfScope ps(c, "lmcs_leaf_absorb", bytes);
+      hipLaunchKernelGGL(k_leaf_absorb, dim3((unsigned)((leaves + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0,
+                         c->stream, a);
+    }
+    state_in = a.state_out;
+    log_n_prev = ln;
+  }
+  // ---- compress layers
+  {
+    ProfScope ps(c, "lmcs_compress", 96.0 * (double)H);
+    for (int d = t->log_height - 1; d >= 0; d--) {
+      size_t n_out = (size_t)1 << d;
+      int cbits_child = (d + 1) - (t->log_height - lb);  // coset bits of the child layer
+      int log_n_coset = cbits_child > 0 ? (t->log_height - lb) : -1;
+      hipLaunchKernelGGL(k_compress, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream,
+                         t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
+    }
+  }
+  HIP_CHECK(hipMemcpyAsync(t->root, t->nodes.u() + 4 * t->layer_off[0], 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+
+// tree_indices.rs:185-240 (MissingSiblingsIter): bottom-up, left-to-right.
+std::vector<std::pair<int, size_t>> lmcs_missing_siblings(const std::vector<size_t>& idx, int depth) {
+  std::vector<std::pair<int, size_t>> out;
+  std::vector<size_t> cur(idx);
+  for (int d = depth; d > 0; d--) {
+    std::vector<size_t> next;
+    next.reserve(cur.size());
+    for (size_t i = 0; i < cur.size();) {
+      size_t node = cur[i], sib = node ^ 1;
+      bool present = (i + 1 < cur.size() && cur[i + 1] == sib);
+      if (next.empty() || next.back() != (node >> 1)) next.push_back(node >> 1);
+      if (!present) out.emplace_back(d, sib);
+      i += present ? 2 : 1;
+    }
+    cur.swap(next);
+  }
+  return out;
+}
+
+// gather list: out[k] = src[k] dereferenced
+__global__ void k_gather(const u64* const* __restrict__ ptrs, u64* __restrict__ out, size_t n) {
+  size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (k < n) out[k] = ptrs[k] ? *ptrs[k] : 0;
+}
+
+void lmcs_open(mh_ctx* c, const mh_tree* t, const std::vector<size_t>& idx, size_t alignment, std::vector<u64>& fields,
+               std::vector<u64>& commitments) {
+  const int lb = t->log_blowup;
+  const size_t Bm = ((size_t)1 << lb) - 1;
+  std::vector<const u64*> ptrs;
+  for (size_t i : idx) {
+    MH_REQUIRE(i < ((size_t)1 << t->log_height), "opening index out of range");
+    size_t j = i & Bm, r = i >> lb;
+    for (const LdeMatrix& m : t->mats) {
+      size_t N = (size_t)1 << m.log_n;
+      size_t rm = r & (N - 1);
+      for (size_t cidx = 0; cidx < m.width; cidx++) ptrs.push_back(m.lde.u() + (((cidx << lb) + j) << m.log_n) + rm);
+      size_t padded = (m.width + alignment - 1) / alignment * alignment;
+      for (size_t k = m.width; k < padded; k++) ptrs.push_back(nullptr);
+    }
+  }
+  const size_t n_fields = ptrs.size();
+  auto sib = lmcs_missing_siblings(idx, t->log_height);
+  for (auto& s : sib) {
+    const u64* p = t->nodes.u() + 4 * (t->layer_off[s.first] + t->node_slot(s.first, s.second));
+    for (int k = 0; k < 4; k++) ptrs.push_back(p + k);
+  }
+  const size_t n = ptrs.size();
+  fields.clear();
+  commitments.clear();
+  if (!n) return;
+  DevBuf dptrs(n * 8), dout(n * 8);
+  HIP_CHECK(hipMemcpyAsync(dptrs.p, ptrs.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const u64* const*)dptrs.p, dout.u(), n);
+  std::vector<u64> host(n);
+  HIP_CHECK(hipMemcpyAsync(host.data(), dout.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  fields.assign(host.begin(), host.begin() + n_fields);
+  commitments.assign(host.begin() + n_fields, host.end());
+}
