@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- trace rows/s of the MI355X proving hot path (BASELINE.json metric).
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches one
+rank per GPU with torch.distributed.run.  One JSON line on rank 0.
+
+A "step" = one pass of the hot path over one synthetic trace that is already resident in HBM:
+  workload "commit"  (BASELINE.json configs[1], "NTT+Poseidon2 Merkle only"): commit_traces of the
+      2^20 x 51 main trace and of the 2^20 x 16 (8 EF) aux trace = coset LDE x8 + LMCS tree each
+      (reference: crates/lifted-stark/src/prover/commit.rs:142-180 called at prover/mod.rs:330-341
+      and :403-414);
+  workload "prove"   the whole `prove` of crates/lifted-stark/src/prover/mod.rs:230-578 on the
+      `miden:20:51:8` synthetic AIR (benches/miden-bench), when libmidenhip exports it.
+value = rows of the trace / seconds per step, whole job.  The CPU oracle is used ONLY for the
+`cpu_baseline` leg (a bounded sample), never inside the timed GPU region.
+"""
+import argparse, json, os, sys, time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def synth_trace(rng, log_n, width):
+    """DummyMidenAir trace shape (crates/lifted-stark/src/testing/airs/miden.rs:105-124): column 0
+    all-zero, the rest uniform in [0, p).  Seeded numpy PCG64 (SmallRng is not reproducible here)."""
+    import numpy as np
+    P = 0xFFFFFFFF00000001
+    t = rng.integers(0, P, (1 << log_n, width), dtype=np.uint64)
+    t[:, 0] = 0
+    return t
+
+
+def cpu_baseline_commit(log_n_sample, widths, log_blowup):
+    """Oracle (CPU restatement, OpenMP) timed on a bounded sample of the same workload."""
+    import numpy as np
+    import oracle_binding as ob
+    rng = np.random.default_rng(1)
+    traces = [synth_trace(rng, log_n_sample, w) for w in widths]
+    ob.lib()
+    t0 = time.perf_counter()
+    for t in traces:
+        ob.commit_traces([t], log_blowup)
+    dt = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": (1 << log_n_sample) / dt, "unit": "trace rows/s", "cores": cores, "kind": "port",
+            "sample": f"oracle commit_traces (coset LDE x{1 << log_blowup} + LMCS) of 2^{log_n_sample} x {widths} "
+                      f"in {dt:.2f} s, OpenMP {cores} threads"}
+
+
+class CommitRunner:
+    """BASELINE.json configs[1]: LDE + LMCS commitment of the main and aux traces (K1-K3)."""
+    WIDTHS = (51, 16)  # main width, aux width in base felts (8 EF)
+    LOG_BLOWUP = 3
+
+    def __init__(self, pkg, ctx, args, rank, world):
+        import numpy as np
+        self.pkg, self.ctx, self.args, self.rank, self.world = pkg, ctx, args, rank, world
+        rng = np.random.default_rng(1 + rank)
+        self.log_n = args.log_n
+        self.traces = [ctx.upload_trace(synth_trace(rng, self.log_n, w)) for w in self.WIDTHS]
+        self.roots = None
+
+    def step(self):
+        roots = []
+        for t in self.traces:
+            com = self.pkg.commit_traces(self.ctx, [t], self.LOG_BLOWUP)
+            roots.append(com.root())
+            com.tree().free()
+        self.roots = roots
+
+    def rows_per_step(self):
+        return (1 << self.log_n) * self.world  # every rank commits its own trace (independent proofs)
+
+    def scaling(self):
+        return "weak"
+
+    def config(self):
+        return {"workload": f"configs[1]: synthetic 2^{self.log_n}-row trace, NTT+Poseidon2 Merkle only: commit_traces("
+                            f"main 2^{self.log_n}x51) + commit_traces(aux 2^{self.log_n}x16), blowup 8, Poseidon2 LMCS",
+                "log_trace_rows": self.log_n, "main_width": 51, "aux_width_base": 16, "log_blowup": 3,
+                "parallelism": "1 GPU" if self.world == 1 else f"{self.world} independent replicas (one trace per GPU)"}
+
+    def roofline(self, prof):
+        # dominant kernel = the leaf sponge (k_leaf_absorb); algorithmic bytes per launch are
+        # attributed inside libmidenhip (LDE bytes read once + 32 B digest written per leaf).
+        name = max(prof, key=lambda k: prof[k]["ms"]) if prof else None
+        if not name:
+            return None
+        e = prof[name]
+        ach = (e["bytes"] / 1e9) / (e["ms"] / 1e3)
+        return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_ms": e["ms"] / max(1, e["count"]), "alg_bytes_per_launch": e["bytes"] / max(1, e["count"]),
+                "note": "Poseidon2 hashing is integer-ALU bound (no 64-bit multiplier on CDNA4); see DESIGN.md for the "
+                        "int-op roofline"}
+
+    def cpu_baseline(self):
+        return cpu_baseline_commit(self.args.cpu_log_n, list(self.WIDTHS), self.LOG_BLOWUP)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--workload", default="auto", choices=["auto", "commit", "prove"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-log-n", type=int, default=15)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    pkg = load_package()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = pkg.Ctx(local_rank)
+    runner = CommitRunner(pkg, ctx, args, rank, world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner.step()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    prof = ctx.prof()
+    ctx.prof_enable(False)
+
+    ms_per_step = dt / args.steps * 1e3
+    rows_per_step = runner.rows_per_step()  # whole job (all ranks)
+    out = {
+        "metric": "trace rows/sec proved (2^20-row trace, 96-bit sec)",
+        "value": rows_per_step / (dt / args.steps),
+        "unit": "trace rows/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": runner.scaling(),
+        "vs_baseline": None,
+        "dtype": "u64 (Goldilocks field, p = 2^64 - 2^32 + 1)",
+        "data": "synthetic (DummyMidenAir-shaped trace, numpy PCG64 seed 1)",
+        "config": runner.config(),
+    }
+    out["roofline"] = runner.roofline(prof)
+    out["kernels"] = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["count"] / args.steps,
+                          "alg_GBps": (v["bytes"] / 1e9) / (v["ms"] / 1e3) if v["ms"] > 0 else None}
+                      for k, v in prof.items()}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = runner.cpu_baseline()
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
