@@ -6,7 +6,9 @@
 #include "poseidon2.hpp"
 #include "ntt.hpp"
 #include "lmcs.hpp"
+#include "stark.hpp"
 #include <cstring>
+#include <cstdio>
 
 using namespace oracle;
 
@@ -96,6 +98,81 @@ void orc_commit_traces(int n_mats, const uint64_t* const* ptrs, const int* log_h
     *n_fields = f.size();
     memcpy(commit_out, c.data(), c.size() * 32);
     *n_commit = c.size();
+  }
+}
+
+
+// ---- whole-protocol entry points (stark.hpp) ----------------------------------------------------
+static Challenger make_challenger(const uint64_t init_state[12], const uint64_t* pre_observe, size_t n_pre) {
+  Challenger c;
+  for (int i = 0; i < 12; i++) c.st[i] = init_state[i];
+  for (size_t i = 0; i < n_pre; i++) c.observe(pre_observe[i]);
+  return c;
+}
+static PcsParams make_params(const int p[7]) { return PcsParams{p[0], p[1], p[2], p[3], p[4], p[5], p[6]}; }
+static void set_err(char* err, size_t cap, const char* msg) {
+  if (err && cap) snprintf(err, cap, "%s", msg);
+}
+
+// params = {log_blowup, log_folding_arity, log_final_degree, folding_pow_bits, deep_pow_bits,
+//           num_queries, query_pow_bits}
+int orc_prove(const int params[7], int n_airs, const uint64_t* const* dags, const size_t* dag_lens,
+              const uint64_t* const* traces, const int* log_heights, const uint64_t* publics, size_t n_publics,
+              const uint64_t init_state[12], const uint64_t* pre_observe, size_t n_pre, AuxBuilder cb, void* user,
+              uint64_t* fields_out, size_t fields_cap, size_t* n_fields, uint64_t* commits_out, size_t commits_cap,
+              size_t* n_commits, uint64_t digest[4], char* err, size_t errcap) {
+  try {
+    ProverInput in;
+    in.params = make_params(params);
+    for (int i = 0; i < n_airs; i++) {
+      in.airs.push_back(Air::parse(dags[i], dag_lens[i]));
+      in.traces.push_back(traces[i]);
+      in.log_heights.push_back(log_heights[i]);
+    }
+    in.publics.assign(publics, publics + n_publics);
+    in.challenger = make_challenger(init_state, pre_observe, n_pre);
+    in.aux_builder = cb;
+    in.aux_user = user;
+    Proof p = prove(in);
+    if (p.fields.size() > fields_cap || p.commitments.size() > commits_cap) {
+      set_err(err, errcap, "output buffers too small");
+      return 2;
+    }
+    memcpy(fields_out, p.fields.data(), p.fields.size() * 8);
+    memcpy(commits_out, p.commitments.data(), p.commitments.size() * 32);
+    *n_fields = p.fields.size();
+    *n_commits = p.commitments.size();
+    memcpy(digest, p.digest.data(), 32);
+    return 0;
+  } catch (const std::exception& e) {
+    set_err(err, errcap, e.what());
+    return 1;
+  }
+}
+
+int orc_verify(const int params[7], int n_airs, const uint64_t* const* dags, const size_t* dag_lens, const int* log_heights,
+               const uint64_t* publics, size_t n_publics, const uint64_t init_state[12], const uint64_t* pre_observe,
+               size_t n_pre, const uint64_t* fields, size_t n_fields, const uint64_t* commits, size_t n_commits,
+               uint64_t digest[4], char* err, size_t errcap) {
+  try {
+    VerifierInput in;
+    in.params = make_params(params);
+    Proof p;
+    for (int i = 0; i < n_airs; i++) {
+      in.airs.push_back(Air::parse(dags[i], dag_lens[i]));
+      p.log_trace_heights.push_back((uint8_t)log_heights[i]);
+    }
+    in.publics.assign(publics, publics + n_publics);
+    in.challenger = make_challenger(init_state, pre_observe, n_pre);
+    p.fields.assign(fields, fields + n_fields);
+    p.commitments.resize(n_commits);
+    memcpy(p.commitments.data(), commits, n_commits * 32);
+    Digest d = verify(in, p);
+    memcpy(digest, d.data(), 32);
+    return 0;
+  } catch (const std::exception& e) {
+    set_err(err, errcap, e.what());
+    return 1;
   }
 }
 

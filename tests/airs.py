@@ -1,0 +1,114 @@
+"""Small test AIRs (constraints as DAG blobs + trace/aux generators) exercising every builder input:
+two-row windows, selectors, public values, periodic columns, EF aux columns, randomness, aux values,
+base and extension constraints, and different per-AIR quotient degrees.  They play the role of the
+reference's tiny test AIRs (crates/lifted-stark/src/testing/test_tiny_air.rs:177-410,
+test_per_air_degree.rs, test_multi_aux_alignment.rs)."""
+import numpy as np
+from __graft_entry__ import load_package
+
+pkg = load_package()
+from miden_vm_amd import dag  # noqa: E402
+
+P = dag.P
+
+
+def emul(a, b):
+    return ((a[0] * b[0] + 7 * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def eadd(a, b):
+    return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
+
+
+# ------------------------------------------------------------------------------------------------
+def fib_air():
+    """2 main columns (a, b): a' = b, b' = a + b; boundary values are public inputs.
+    Aux (1 EF column): running product p' = p * (r0 + a) with p[0] = 1; aux value = p_last*(r0+a_last)."""
+    b = dag.AirBuilder(2, aux_width=1, num_randomness=1, num_aux_values=1, num_public=3)
+    a0, b0, a1, b1 = b.main(0), b.main(1), b.main(0, 1), b.main(1, 1)
+    tr = b.is_transition()
+    b.assert_zero(tr * (a1 - b0))
+    b.assert_zero(tr * (b1 - (a0 + b0)))
+    b.assert_zero(b.is_first_row() * (a0 - b.public(0)))
+    b.assert_zero(b.is_first_row() * (b0 - b.public(1)))
+    b.assert_zero(b.is_last_row() * (b0 - b.public(2)))
+    p0, p1, r = b.aux(0), b.aux(0, 1), b.randomness(0)
+    b.assert_zero_ext(b.is_first_row() * (p0 - 1))
+    b.assert_zero_ext(tr * (p1 - p0 * (r + a0)))
+    b.assert_zero_ext(b.is_last_row() * (p0 * (r + a0) - b.aux_value(0)))
+
+    def build_aux(main, randomness):
+        n = main.shape[0]
+        r = randomness[0]
+        aux = np.zeros((n, 2), dtype=np.uint64)
+        p = (1, 0)
+        for i in range(n):
+            aux[i] = p
+            p = emul(p, eadd(r, (int(main[i, 0]), 0)))
+        return aux, [p[0], p[1]]
+
+    return dag.Air(b, build_aux, "fib")
+
+
+def fib_trace(log_n, a=1, b_=1):
+    n = 1 << log_n
+    t = np.zeros((n, 2), dtype=np.uint64)
+    x, y = a % P, b_ % P
+    for i in range(n):
+        t[i] = (x, y)
+        x, y = y, (x + y) % P
+    return t, [a % P, b_ % P, int(t[n - 1, 1])]
+
+
+# ------------------------------------------------------------------------------------------------
+PERIODIC_COLS = ([3, 5, 7, 11], [2, 9, 4, 6, 1, 8, 13, 12])
+
+
+def periodic_air(num_public=3):
+    """1 working column c (+ 2 free columns): c' = c^2 * k1 + k2 with periodic k1 (period 4), k2 (period 8).
+    Degree 3 -> 2 quotient chunks.  2 EF aux columns: s' = s + r0*c (running sum), t = constant r1."""
+    b = dag.AirBuilder(3, aux_width=2, num_randomness=2, num_aux_values=2, num_public=num_public, periodic=PERIODIC_COLS)
+    c0, c1 = b.main(0), b.main(0, 1)
+    tr = b.is_transition()
+    b.assert_zero(tr * (c1 - (c0 * c0 * b.periodic_value(0) + b.periodic_value(1))))
+    b.assert_zero(b.main(1) * b.main(2) - b.main(1) * b.main(2))  # trivially zero, keeps columns live
+    s0, s1, t0, t1 = b.aux(0), b.aux(0, 1), b.aux(1), b.aux(1, 1)
+    r0, r1 = b.randomness(0), b.randomness(1)
+    b.assert_zero_ext(tr * (s1 - (s0 + r0 * c0)))
+    b.assert_zero_ext(b.is_first_row() * s0)
+    b.assert_zero_ext(t0 - r1)
+    b.assert_zero_ext(tr * (t1 - t0))
+    b.assert_zero_ext(b.is_last_row() * (s0 + r0 * c0 - b.aux_value(0)))
+    b.assert_zero_ext(b.aux_value(1) - r1)
+
+    def build_aux(main, randomness):
+        n = main.shape[0]
+        r0, r1 = randomness[0], randomness[1]
+        aux = np.zeros((n, 4), dtype=np.uint64)
+        s = (0, 0)
+        for i in range(n):
+            aux[i, 0:2] = s
+            aux[i, 2:4] = r1
+            s = eadd(s, emul(r0, (int(main[i, 0]), 0)))
+        return aux, [s[0], s[1], r1[0], r1[1]]
+
+    return dag.Air(b, build_aux, "periodic")
+
+
+def periodic_trace(log_n, seed=5):
+    n = 1 << log_n
+    rng = np.random.default_rng(seed)
+    t = rng.integers(0, P, (n, 3), dtype=np.uint64)
+    c = 7
+    for i in range(n):
+        t[i, 0] = c
+        c = (c * c * PERIODIC_COLS[0][i % 4] + PERIODIC_COLS[1][i % 8]) % P
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+def dummy_trace(log_n, width, seed=1):
+    rng = np.random.default_rng(seed)
+    t = rng.integers(0, P, (1 << log_n, width), dtype=np.uint64)
+    t[:, 0] = 0
+    return t

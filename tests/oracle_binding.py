@@ -122,3 +122,108 @@ def commit_traces(traces, log_blowup, indices=(), alignment=8, want_lde=False):
                             idx.ctypes.data_as(C.POINTER(C.c_size_t)), C.c_size_t(nidx), C.c_size_t(alignment),
                             ptr(fields), C.byref(nf), ptr(commits), C.byref(nc))
     return {"root": root, "ldes": ldes, "fields": fields[:nf.value].copy(), "commitments": commits[:nc.value].copy()}
+
+
+# ---- whole protocol (oracle/stark.hpp) -----------------------------------------------------------
+AUX_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, u64p, u64p, u64p)
+
+# production PCS parameters (air/src/config.rs:54-67): blowup 8, arity 4, final degree 2^7,
+# folding PoW 4, DEEP PoW 12, 27 queries, query PoW 16
+PROD_PARAMS = dict(log_blowup=3, log_folding_arity=2, log_final_degree=7, folding_pow_bits=4, deep_pow_bits=12,
+                   num_queries=27, query_pow_bits=16)
+# RELATION_DIGEST (air/src/config.rs:93-98), pinned by tests/golden/kat.json
+PARAM_ORDER = ("log_blowup", "log_folding_arity", "log_final_degree", "folding_pow_bits", "deep_pow_bits", "num_queries",
+               "query_pow_bits")
+
+
+def params_array(p):
+    return (C.c_int * 7)(*[int(p[k]) for k in PARAM_ORDER])
+
+
+def protocol_pre_observe(p, publics, aux_inputs=()):
+    """observe_protocol_params (air/src/config.rs:188-198) followed by the default statement framing
+    (crates/lifted-air/src/air.rs:307-324)."""
+    pre = [p["num_queries"], p["query_pow_bits"], p["deep_pow_bits"], p["folding_pow_bits"], p["log_blowup"],
+           p["log_final_degree"], 1 << p["log_folding_arity"], 0]
+    pre += [len(publics)] + [int(x) for x in publics] + [0, len(aux_inputs)] + [int(x) for x in aux_inputs]
+    return pre
+
+
+def challenger_state(relation_digest=(0, 0, 0, 0)):
+    return [0] * 8 + [int(x) for x in relation_digest]
+
+
+def make_aux_callback(airs, traces):
+    """ctypes callback around each AIR's build_aux(main, randomness) (None -> zeros)."""
+    def cb(user, idx, rand_p, aux_p, vals_p):
+        try:
+            air = airs[idx]
+            if air.build_aux is None:
+                return 0
+            rnd = [(int(rand_p[2 * i]), int(rand_p[2 * i + 1])) for i in range(air.num_randomness)]
+            aux, vals = air.build_aux(traces[idx], rnd)
+            n = traces[idx].shape[0]
+            flat = np.ascontiguousarray(aux, dtype=np.uint64).reshape(-1)
+            assert flat.size == n * 2 * air.aux_width
+            C.memmove(aux_p, flat.ctypes.data, flat.size * 8)
+            for i, v in enumerate(vals):
+                vals_p[i] = int(v)
+            return 0
+        except Exception as e:  # pragma: no cover
+            print("aux builder failed:", e)
+            return 1
+    return AUX_CB(cb)
+
+
+def _air_arrays(airs):
+    blobs = [arr(a.blob) for a in airs]
+    n = len(airs)
+    return blobs, (u64p * n)(*[ptr(b) for b in blobs]), (C.c_size_t * n)(*[b.size for b in blobs])
+
+
+def prove(airs, traces, publics, params=PROD_PARAMS, init_state=None, pre_observe=None):
+    """-> dict(fields, commitments[k][4], digest)."""
+    traces = [arr(t) for t in traces]
+    n = len(airs)
+    blobs, dag_ptrs, dag_lens = _air_arrays(airs)
+    tr_ptrs = (u64p * n)(*[ptr(t) for t in traces])
+    lhs = (C.c_int * n)(*[int(t.shape[0]).bit_length() - 1 for t in traces])
+    pub = arr(list(publics) or [0])
+    st = arr(init_state if init_state is not None else challenger_state())
+    pre = arr(pre_observe if pre_observe is not None else protocol_pre_observe(params, publics))
+    cb = make_aux_callback(airs, traces)
+    cap_f, cap_c = 1 << 22, 1 << 18
+    fields = np.zeros(cap_f, dtype=np.uint64)
+    commits = np.zeros((cap_c, 4), dtype=np.uint64)
+    nf, nc = C.c_size_t(0), C.c_size_t(0)
+    digest = np.zeros(4, dtype=np.uint64)
+    err = C.create_string_buffer(512)
+    L = lib()
+    L.orc_prove.restype = C.c_int
+    rc = L.orc_prove(params_array(params), C.c_int(n), dag_ptrs, dag_lens, tr_ptrs, lhs, ptr(pub), C.c_size_t(len(publics)),
+                     ptr(st), ptr(pre), C.c_size_t(pre.size), cb, None, ptr(fields), C.c_size_t(cap_f), C.byref(nf),
+                     ptr(commits), C.c_size_t(cap_c), C.byref(nc), ptr(digest), err, C.c_size_t(512))
+    if rc != 0:
+        raise RuntimeError("oracle prove failed: " + err.value.decode())
+    return {"fields": fields[:nf.value].copy(), "commitments": commits[:nc.value].copy(), "digest": digest,
+            "log_heights": [int(x) for x in lhs]}
+
+
+def verify(airs, log_heights, publics, proof, params=PROD_PARAMS, init_state=None, pre_observe=None):
+    """Returns (ok, message_or_digest)."""
+    n = len(airs)
+    blobs, dag_ptrs, dag_lens = _air_arrays(airs)
+    lhs = (C.c_int * n)(*[int(x) for x in log_heights])
+    pub = arr(list(publics) or [0])
+    st = arr(init_state if init_state is not None else challenger_state())
+    pre = arr(pre_observe if pre_observe is not None else protocol_pre_observe(params, publics))
+    f = arr(proof["fields"])
+    c = arr(proof["commitments"]).reshape(-1)
+    digest = np.zeros(4, dtype=np.uint64)
+    err = C.create_string_buffer(512)
+    L = lib()
+    L.orc_verify.restype = C.c_int
+    rc = L.orc_verify(params_array(params), C.c_int(n), dag_ptrs, dag_lens, lhs, ptr(pub), C.c_size_t(len(publics)), ptr(st),
+                      ptr(pre), C.c_size_t(pre.size), ptr(f), C.c_size_t(f.size), ptr(c), C.c_size_t(c.size // 4),
+                      ptr(digest), err, C.c_size_t(512))
+    return (True, digest) if rc == 0 else (False, err.value.decode())
