@@ -30,6 +30,8 @@ extern "C" {
 typedef struct mh_ctx mh_ctx;
 typedef struct mh_trace mh_trace; /* device-resident trace matrix (column-major) */
 typedef struct mh_tree mh_tree;   /* device-resident LMCS tree + its LDE matrices */
+typedef struct mh_air mh_air;     /* an AIR: constraint DAG compiled for the device interpreter */
+typedef struct mh_proof mh_proof; /* host-resident proof: transcript fields + commitments */
 
 /* ---- context ------------------------------------------------------------------------------ */
 int mh_ctx_create(int device_id, mh_ctx** out);
@@ -86,6 +88,55 @@ int mh_tree_open(mh_ctx* ctx, const mh_tree* t, const uint64_t* indices, size_t 
 int mh_tree_download_lde(mh_ctx* ctx, const mh_tree* t, int mat, uint64_t* out_rowmajor_bitrev);
 /* Parity/debug: download all digest layers, leaf layer (domain order) first: (2H-1)*4 felts. */
 int mh_tree_download_layers(mh_ctx* ctx, const mh_tree* t, uint64_t* out);
+
+/* ---- AIRs as data: the constraint DAG blob "MHDAG001" ------------------------------------------ */
+/* The Rust side captures `air.eval` once on a symbolic builder (the route of
+ * crates/ace-codegen/src/pipeline.rs:71-123) and ships a flat u64 blob:
+ *   [0] magic 0x4d48444147303031  [1] main_width  [2] aux_width (EF columns)  [3] num_randomness
+ *   [4] num_aux_values  [5] num_public_values  [6] n_periodic  [7] log_quotient_degree
+ *   [8] n_nodes  [9] n_constraints  [10..11] reserved
+ *   n_periodic x { len, values[len] }            periodic columns (power-of-two lengths)
+ *   n_nodes x { op | a << 8 | b << 36, const }   ops: 0 CONST(const) 1 MAIN(a=col,b=row offset)
+ *        2 AUX(a=EF col,b=row) 3 PUBLIC(a) 4 PERIODIC(a) 5 IS_FIRST 6 IS_LAST 7 IS_TRANSITION
+ *        8 RANDOMNESS(a) 9 AUX_VALUE(a) 10 ADD(a,b) 11 SUB(a,b) 12 MUL(a,b) 13 NEG(a); a, b < node id
+ *   n_constraints x node id                      in emission order (constraint k folds with alpha^(K-1-k))
+ * miden-vm_amd/dag.py is the reference exporter used by tests and bench. */
+int mh_air_load(mh_ctx* ctx, const uint64_t* blob, size_t n_words, mh_air** out);
+void mh_air_free(mh_air* air);
+int mh_air_log_quotient_degree(const mh_air* air);
+
+/* ---- the whole proof: miden_prover::prove_stark (prover/src/lib.rs:317-355) -> ------------------ */
+/* ProverInstance::prove (crates/lifted-stark/src/prover/mod.rs:230-578).                           */
+typedef struct mh_pcs_params { /* PcsParams::new argument order regrouped (pcs/params.rs:52-96) */
+  int log_blowup, log_folding_arity, log_final_degree, folding_pow_bits, deep_pow_bits, num_queries, query_pow_bits;
+} mh_pcs_params;
+
+/* LiftedAir::build_aux_trace (crates/lifted-air/src/air.rs): called once per AIR instance, in
+ * instance order, after the main commitment.  randomness = 2*max_num_randomness felts; the callee
+ * fills the flattened EF aux trace (rows x 2*aux_width, row-major) and 2*num_aux_values felts.
+ * A non-zero return aborts the proof (this is also where Statement::eval_external failures go).
+ * NULL = every aux trace and aux value is zero (DummyMidenAir), generated on the device. */
+typedef int (*mh_aux_builder)(void* user, int instance_idx, const uint64_t* randomness, uint64_t* aux_out,
+                              uint64_t* aux_values_out);
+
+/* airs / traces in INSTANCE order.  challenger_state = the 12-felt sponge state of the prototype
+ * challenger (air/src/config.rs:255-273: RELATION_DIGEST in state[8..12]); pre_observe = every felt
+ * observed before observe_shape (protocol parameters, air/src/config.rs:188-198, then
+ * Statement::observe).  The transcript, PoW witnesses (smallest valid witness) and query openings
+ * are produced inside; the result is the reference's StarkProofData. */
+int mh_prove(mh_ctx* ctx, const mh_pcs_params* params, int n_airs, mh_air* const* airs, mh_trace* const* traces,
+             const uint64_t* public_values, size_t n_public_values, const uint64_t challenger_state[12],
+             const uint64_t* pre_observe, size_t n_pre_observe, mh_aux_builder aux_builder, void* user, mh_proof** out);
+void mh_proof_free(mh_proof* p);
+size_t mh_proof_num_fields(const mh_proof* p);
+size_t mh_proof_num_commitments(const mh_proof* p);
+const uint64_t* mh_proof_fields(const mh_proof* p);       /* TranscriptData::fields */
+const uint64_t* mh_proof_commitments(const mh_proof* p);  /* TranscriptData::commitments, 4 felts each */
+const uint64_t* mh_proof_digest(const mh_proof* p);       /* StarkOutput::digest, 4 felts */
+size_t mh_proof_num_traces(const mh_proof* p);
+const uint8_t* mh_proof_log_trace_heights(const mh_proof* p);
+/* Serialise StarkProofData; returns the byte length needed (writes only if cap is large enough). */
+size_t mh_proof_serialize(const mh_proof* p, uint8_t* out, size_t cap);
 
 #ifdef __cplusplus
 }

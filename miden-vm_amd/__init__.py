@@ -22,7 +22,9 @@ EXPORTS = [
     "mh_ctx_create", "mh_ctx_destroy", "mh_last_error", "mh_device_count", "mh_prof_enable", "mh_prof_reset",
     "mh_prof_get", "mh_prof_dump", "mh_poseidon2_permute", "mh_coset_lde_batch", "mh_trace_upload", "mh_trace_free",
     "mh_commit_traces", "mh_tree_free", "mh_tree_root", "mh_tree_log_height", "mh_tree_open", "mh_tree_download_lde",
-    "mh_tree_download_layers",
+    "mh_tree_download_layers", "mh_air_load", "mh_air_free", "mh_air_log_quotient_degree", "mh_prove", "mh_proof_free",
+    "mh_proof_num_fields", "mh_proof_num_commitments", "mh_proof_fields", "mh_proof_commitments", "mh_proof_digest",
+    "mh_proof_num_traces", "mh_proof_log_trace_heights", "mh_proof_serialize",
 ]
 
 _lib = None
@@ -48,6 +50,19 @@ def load_library():
     lib.mh_trace_free.argtypes = [C.c_void_p]
     lib.mh_tree_free.argtypes = [C.c_void_p]
     lib.mh_tree_log_height.argtypes = [C.c_void_p]
+    lib.mh_air_free.argtypes = [C.c_void_p]
+    lib.mh_air_log_quotient_degree.argtypes = [C.c_void_p]
+    lib.mh_proof_free.argtypes = [C.c_void_p]
+    for name in ("mh_proof_num_fields", "mh_proof_num_commitments", "mh_proof_num_traces"):
+        getattr(lib, name).restype = C.c_size_t
+        getattr(lib, name).argtypes = [C.c_void_p]
+    for name in ("mh_proof_fields", "mh_proof_commitments", "mh_proof_digest"):
+        getattr(lib, name).restype = u64p
+        getattr(lib, name).argtypes = [C.c_void_p]
+    lib.mh_proof_log_trace_heights.restype = C.POINTER(C.c_uint8)
+    lib.mh_proof_log_trace_heights.argtypes = [C.c_void_p]
+    lib.mh_proof_serialize.restype = C.c_size_t
+    lib.mh_proof_serialize.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     _lib = lib
     return lib
 
@@ -218,3 +233,93 @@ def commit_traces(ctx, traces, log_blowup):
     root = np.zeros(4, dtype=np.uint64)
     ctx.check(ctx.lib.mh_commit_traces(ctx.h, n, arr, log_blowup, C.byref(h), _ptr(root)))
     return Committed(LmcsTree(ctx, h, [t.width for t in traces], [t.log_n for t in traces], log_blowup))
+
+
+# ---- the whole proof (miden_prover::prove_stark -> lifted_stark::prover::prove) ---------------------
+AUX_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, u64p, u64p, u64p)
+
+
+class PcsParams(C.Structure):
+    """mh_pcs_params; defaults = the production parameters of air/src/config.rs:54-67."""
+    _fields_ = [(k, C.c_int) for k in ("log_blowup", "log_folding_arity", "log_final_degree", "folding_pow_bits",
+                                       "deep_pow_bits", "num_queries", "query_pow_bits")]
+
+    @classmethod
+    def production(cls):
+        return cls(3, 2, 7, 4, 12, 27, 16)
+
+    @classmethod
+    def from_dict(cls, d):
+        return cls(*[int(d[k]) for k, _ in cls._fields_])
+
+
+class DeviceAir:
+    """mh_air: a constraint-DAG blob (miden-vm_amd/dag.py) loaded and compiled for the device."""
+
+    def __init__(self, ctx, air):
+        self.ctx, self.air = ctx, air
+        blob = _arr(air.blob)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mh_air_load(ctx.h, _ptr(blob), C.c_size_t(blob.size), C.byref(h)))
+        self.h = h
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.mh_air_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Proof:
+    """StarkProofData + digest (crates/lifted-stark/src/proof.rs:58-63)."""
+
+    def __init__(self, lib, h):
+        nf, nc, nt = lib.mh_proof_num_fields(h), lib.mh_proof_num_commitments(h), lib.mh_proof_num_traces(h)
+        self.fields = np.ctypeslib.as_array(lib.mh_proof_fields(h), shape=(max(nf, 1),))[:nf].copy()
+        self.commitments = np.ctypeslib.as_array(lib.mh_proof_commitments(h), shape=(max(nc, 1) * 4,))[:nc * 4].copy().reshape(-1, 4)
+        self.digest = np.ctypeslib.as_array(lib.mh_proof_digest(h), shape=(4,)).copy()
+        lh = lib.mh_proof_log_trace_heights(h)
+        self.log_trace_heights = [int(lh[i]) for i in range(nt)]
+        need = lib.mh_proof_serialize(h, None, 0)
+        buf = (C.c_uint8 * need)()
+        lib.mh_proof_serialize(h, buf, need)
+        self.bytes = bytes(buf)
+        lib.mh_proof_free(h)
+
+
+def prove(ctx, airs, traces, public_values, params, challenger_state, pre_observe, aux_builder=None):
+    """airs: list of DeviceAir, traces: list of Trace (instance order).  aux_builder: None (all-zero aux
+    traces, DummyMidenAir) or a Python callable (instance_idx, randomness[(c0,c1)...]) ->
+    (aux[n, 2*aux_width] uint64, flat aux values)."""
+    n = len(airs)
+    a_arr = (C.c_void_p * n)(*[a.h for a in airs])
+    t_arr = (C.c_void_p * n)(*[t.h for t in traces])
+    pub = _arr(list(public_values) or [0])
+    st = _arr(challenger_state)
+    pre = _arr(list(pre_observe) or [0])
+    max_rand = max(a.air.num_randomness for a in airs)
+
+    def cb(user, idx, rand_p, aux_p, vals_p):
+        try:
+            rnd = [(int(rand_p[2 * i]), int(rand_p[2 * i + 1])) for i in range(max_rand)]
+            aux, vals = aux_builder(idx, rnd)
+            flat = np.ascontiguousarray(aux, dtype=np.uint64).reshape(-1)
+            C.memmove(aux_p, flat.ctypes.data, flat.size * 8)
+            for i, v in enumerate(vals):
+                vals_p[i] = int(v)
+            return 0
+        except Exception as e:  # pragma: no cover
+            print("aux builder failed:", e)
+            return 1
+
+    c_cb = AUX_CB(cb) if aux_builder is not None else C.cast(None, AUX_CB)
+    h = C.c_void_p()
+    p = params if isinstance(params, PcsParams) else PcsParams.from_dict(params)
+    ctx.check(ctx.lib.mh_prove(ctx.h, C.byref(p), C.c_int(n), a_arr, t_arr, _ptr(pub), C.c_size_t(len(public_values)),
+                               _ptr(st), _ptr(pre), C.c_size_t(len(pre_observe)), c_cb, None, C.byref(h)))
+    return Proof(ctx.lib, h)

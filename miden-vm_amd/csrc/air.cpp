@@ -1,0 +1,184 @@
+// Constraint-DAG blob -> interpreter program (see air.hpp).
+#include "air.hpp"
+#include <algorithm>
+#include <cstring>
+#include <memory>
+
+namespace {
+struct Node {
+  uint32_t op, a, b;
+  u64 c;
+  bool ext = false;
+};
+}  // namespace
+
+mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
+  MH_REQUIRE(n >= 12 && w[0] == DAG_MAGIC, "constraint DAG blob: bad magic / too short");
+  std::unique_ptr<mh_air> air(new mh_air());
+  air->ctx = ctx;
+  air->main_width = w[1]; air->aux_width = w[2]; air->num_randomness = w[3]; air->num_aux_values = w[4];
+  air->num_public = w[5];
+  const size_t n_periodic = w[6];
+  air->log_quotient_degree = (int)w[7];
+  const size_t n_nodes = w[8], n_cons = w[9];
+  MH_REQUIRE(air->main_width > 0 && air->main_width < 65536 && air->aux_width < 32768, "constraint DAG blob: bad widths");
+  MH_REQUIRE(air->log_quotient_degree >= 0 && air->log_quotient_degree <= 8, "constraint DAG blob: bad quotient degree");
+  size_t pos = 12;
+  for (size_t i = 0; i < n_periodic; i++) {
+    MH_REQUIRE(pos < n, "constraint DAG blob: truncated periodic table");
+    size_t len = w[pos++];
+    MH_REQUIRE(len > 0 && (len & (len - 1)) == 0 && pos + len <= n, "constraint DAG blob: bad periodic column");
+    air->periodic.emplace_back(w + pos, w + pos + len);
+    pos += len;
+  }
+  MH_REQUIRE(n_nodes < ((size_t)1 << 28) && pos + 2 * n_nodes + n_cons <= n, "constraint DAG blob: truncated");
+  std::vector<Node> nodes(n_nodes);
+  for (size_t i = 0; i < n_nodes; i++) {
+    u64 x = w[pos + 2 * i];
+    Node nd{(uint32_t)(x & 0xFF), (uint32_t)((x >> 8) & 0xFFFFFFF), (uint32_t)(x >> 36), w[pos + 2 * i + 1]};
+    switch (nd.op) {
+      case DOP_CONST: case DOP_IS_FIRST: case DOP_IS_LAST: case DOP_IS_TRANSITION: break;
+      case DOP_MAIN: MH_REQUIRE(nd.a < air->main_width && nd.b < 2, "DAG: main column out of range"); break;
+      case DOP_AUX: MH_REQUIRE(nd.a < air->aux_width && nd.b < 2, "DAG: aux column out of range"); nd.ext = true; break;
+      case DOP_PUBLIC: MH_REQUIRE(nd.a < air->num_public, "DAG: public value out of range"); break;
+      case DOP_PERIODIC: MH_REQUIRE(nd.a < n_periodic, "DAG: periodic column out of range"); break;
+      case DOP_RANDOMNESS: MH_REQUIRE(nd.a < air->num_randomness, "DAG: randomness out of range"); nd.ext = true; break;
+      case DOP_AUX_VALUE: MH_REQUIRE(nd.a < air->num_aux_values, "DAG: aux value out of range"); nd.ext = true; break;
+      case DOP_ADD: case DOP_SUB: case DOP_MUL:
+        MH_REQUIRE(nd.a < i && nd.b < i, "DAG: forward reference");
+        nd.ext = nodes[nd.a].ext || nodes[nd.b].ext;
+        break;
+      case DOP_NEG:
+        MH_REQUIRE(nd.a < i, "DAG: forward reference");
+        nd.ext = nodes[nd.a].ext;
+        break;
+      default: throw MhError(MH_ERR_INVALID, "DAG: unknown op");
+    }
+    if (nd.op == DOP_IS_FIRST || nd.op == DOP_IS_LAST) air->uses_first_last = true;
+    nodes[i] = nd;
+  }
+  pos += 2 * n_nodes;
+  std::vector<uint32_t> cons(n_cons);
+  for (size_t i = 0; i < n_cons; i++) {
+    MH_REQUIRE(w[pos + i] < n_nodes, "DAG: constraint id out of range");
+    cons[i] = (uint32_t)w[pos + i];
+  }
+  air->n_constraints = n_cons;
+
+  // ---- reachability: only nodes some constraint depends on are emitted
+  std::vector<char> live(n_nodes, 0);
+  for (uint32_t c : cons) live[c] = 1;
+  for (size_t i = n_nodes; i-- > 0;) {
+    if (!live[i]) continue;
+    const Node& nd = nodes[i];
+    if (nd.op >= DOP_ADD) {
+      live[nd.a] = 1;
+      if (nd.op != DOP_NEG) live[nd.b] = 1;
+    }
+  }
+  // constraints attached to each node, in emission order
+  std::vector<std::vector<uint32_t>> folds(n_nodes);
+  for (size_t k = 0; k < n_cons; k++) folds[cons[k]].push_back((uint32_t)k);
+
+  // ---- emission order: interior nodes in id order, leaves right before their first use
+  struct Ev {
+    uint32_t node;
+    int32_t fold_k;  // -1: compute node; >= 0: fold constraint k of `node`
+  };
+  std::vector<Ev> seq;
+  std::vector<char> emitted(n_nodes, 0);
+  auto emit_node = [&](uint32_t id) {
+    if (emitted[id]) return;
+    emitted[id] = 1;
+    seq.push_back({id, -1});
+    for (uint32_t k : folds[id]) seq.push_back({id, (int32_t)k});
+  };
+  for (size_t i = 0; i < n_nodes; i++) {
+    if (!live[i]) continue;
+    const Node& nd = nodes[i];
+    if (nd.op >= DOP_ADD) {
+      emit_node(nd.a);  // no-op unless a is a not-yet-materialised leaf
+      if (nd.op != DOP_NEG) emit_node(nd.b);
+      emit_node((uint32_t)i);
+    } else if (!folds[i].empty()) {
+      emit_node((uint32_t)i);  // a constraint directly on a leaf
+    }
+  }
+  // ---- liveness + slot assignment
+  std::vector<int64_t> last_use(n_nodes, -1);
+  for (size_t p = 0; p < seq.size(); p++) {
+    const Node& nd = nodes[seq[p].node];
+    if (seq[p].fold_k >= 0) {
+      last_use[seq[p].node] = (int64_t)p;
+    } else if (nd.op >= DOP_ADD) {
+      last_use[nd.a] = (int64_t)p;
+      if (nd.op != DOP_NEG) last_use[nd.b] = (int64_t)p;
+    }
+  }
+  std::vector<int32_t> slot(n_nodes, -1);
+  std::vector<uint32_t> free_slots;
+  uint32_t n_slots = 0;
+  auto release = [&](uint32_t id, size_t p) {
+    if (slot[id] >= 0 && last_use[id] == (int64_t)p) {
+      free_slots.push_back((uint32_t)slot[id]);
+      slot[id] = -2;
+    }
+  };
+  for (size_t p = 0; p < seq.size(); p++) {
+    const uint32_t id = seq[p].node;
+    const Node& nd = nodes[id];
+    AirIns ins;
+    memset(&ins, 0, sizeof ins);
+    if (seq[p].fold_k >= 0) {
+      MH_REQUIRE(slot[id] >= 0, "internal: folding a dead value");
+      ins.op = DOP_FOLD;
+      ins.a = (uint16_t)slot[id];
+      ins.a_ext = nd.ext;
+      ins.imm_lo = (uint32_t)seq[p].fold_k;
+      air->code.push_back(ins);
+      release(id, p);
+      continue;
+    }
+    ins.op = (uint8_t)nd.op;
+    if (nd.op >= DOP_ADD) {
+      MH_REQUIRE(slot[nd.a] >= 0 && (nd.op == DOP_NEG || slot[nd.b] >= 0), "internal: operand not live");
+      ins.a = (uint16_t)slot[nd.a];
+      ins.a_ext = nodes[nd.a].ext;
+      if (nd.op != DOP_NEG) {
+        ins.b = (uint32_t)slot[nd.b];
+        ins.b_ext = nodes[nd.b].ext;
+      }
+      // operands that die here free their slots before dst is chosen (dst may alias an operand:
+      // the interpreter reads both operands before writing)
+      release(nd.a, p);
+      if (nd.op != DOP_NEG && nd.b != nd.a) release(nd.b, p);
+    } else {
+      ins.b = nd.a;                // column / index
+      ins.imm_lo = (uint32_t)nd.c; // constant (low), or row offset for MAIN/AUX
+      ins.imm_hi = (uint32_t)(nd.c >> 32);
+      if (nd.op == DOP_MAIN || nd.op == DOP_AUX) ins.imm_lo = nd.b;
+      if (nd.op == DOP_CONST) {
+        u64 cv = nd.c % 0xFFFFFFFF00000001ULL;
+        ins.imm_lo = (uint32_t)cv;
+        ins.imm_hi = (uint32_t)(cv >> 32);
+      }
+    }
+    if (last_use[id] < 0) continue;  // value never consumed (cannot happen for live nodes)
+    uint32_t s;
+    if (!free_slots.empty()) {
+      s = free_slots.back();
+      free_slots.pop_back();
+    } else {
+      s = n_slots++;
+    }
+    MH_REQUIRE(s < 65535, "constraint DAG needs too many live values");
+    slot[id] = (int32_t)s;
+    ins.dst = (uint16_t)s;
+    air->code.push_back(ins);
+  }
+  air->n_slots = n_slots ? n_slots : 1;
+  air->d_code.alloc(std::max<size_t>(1, air->code.size()) * sizeof(AirIns));
+  if (!air->code.empty())
+    HIP_CHECK(hipMemcpy(air->d_code.p, air->code.data(), air->code.size() * sizeof(AirIns), hipMemcpyHostToDevice));
+  return air.release();
+}

@@ -30,19 +30,6 @@ __global__ void k_lde_to_reference_layout(const u64* __restrict__ lde, u64* __re
   out[t] = lde[(((cidx << lb) + j) << log_n) + r];
 }
 
-static std::vector<u64> coset_shifts(int log_n, int lb) {
-  // shift * w_K^j for j < B, K of order 2^(log_n+lb), canonical shift of that order (domain.rs:358-361)
-  u64 g = gl_lde_shift(log_n + lb);
-  u64 wk = gl_two_adic_generator(log_n + lb);
-  std::vector<u64> s((size_t)1 << lb);
-  u64 x = g;
-  for (auto& v : s) {
-    v = x;
-    x = gl_mul(x, wk);
-  }
-  return s;
-}
-
 extern "C" {
 
 int mh_device_count(void) {
@@ -148,18 +135,7 @@ int mh_trace_upload(mh_ctx* c, const uint64_t* rowmajor, int log_n, size_t width
   MH_REQUIRE(c && rowmajor && out, "null argument");
   MH_REQUIRE(log_n >= 0 && log_n <= 29 && width > 0, "bad trace shape");
   HIP_CHECK(hipSetDevice(c->device));
-  size_t n = (size_t)1 << log_n;
-  std::unique_ptr<mh_trace> t(new mh_trace());
-  t->ctx = c; t->log_n = log_n; t->width = width;
-  DevBuf staging(n * width * 8);
-  t->cols.alloc(n * width * 8);
-  HIP_CHECK(hipMemcpyAsync(staging.p, rowmajor, n * width * 8, hipMemcpyHostToDevice, c->stream));
-  {
-    ProfScope ps(c, "transpose_in", 16.0 * n * width);
-    launch_transpose_rm_to_cm(c, staging.u(), t->cols.u(), n, width);
-  }
-  c->sync();
-  *out = t.release();
+  *out = trace_upload(c, rowmajor, log_n, width);
   MH_CATCH
 }
 void mh_trace_free(mh_trace* t) {
@@ -168,31 +144,17 @@ void mh_trace_free(mh_trace* t) {
   delete t;
 }
 
-// LDE of one uploaded trace into coset-major layout on the canonical shift of its own LDE order.
-static LdeMatrix lde_trace(mh_ctx* c, const mh_trace* tr, int lb) {
-  LdeMatrix m;
-  m.log_n = tr->log_n; m.width = tr->width;
-  size_t N = (size_t)1 << tr->log_n;
-  m.lde.alloc((N << lb) * tr->width * 8);
-  DevBuf scratch(N * tr->width * 8);
-  MH_REQUIRE(tr->log_n + lb <= 32, "LDE order exceeds the field's two-adicity");
-  ProfScope ps(c, "lde", (double)(1 + (1 << lb)) * N * tr->width * 8.0);
-  lde_columns(c, tr->cols.u(), tr->width, tr->log_n, 1, coset_shifts(tr->log_n, lb), m.lde.u(), scratch.u());
-  return m;
-}
-
 int mh_commit_traces(mh_ctx* c, int n_traces, mh_trace* const* traces, int log_blowup, mh_tree** out, uint64_t root[4]) {
   MH_TRY(c)
   MH_REQUIRE(c && traces && out && n_traces > 0, "null/empty argument");
   MH_REQUIRE(log_blowup >= 0 && log_blowup <= 8, "bad log_blowup");
   HIP_CHECK(hipSetDevice(c->device));
-  std::unique_ptr<mh_tree> t(new mh_tree());
-  t->ctx = c; t->log_blowup = log_blowup;
+  std::vector<const mh_trace*> v;
   for (int i = 0; i < n_traces; i++) {
     MH_REQUIRE(traces[i], "null trace");
-    t->mats.push_back(lde_trace(c, traces[i], log_blowup));
+    v.push_back(traces[i]);
   }
-  lmcs_build_tree(c, t.get());
+  std::unique_ptr<mh_tree> t(commit_traces(c, v, log_blowup));
   if (root) memcpy(root, t->root, 32);
   *out = t.release();
   MH_CATCH

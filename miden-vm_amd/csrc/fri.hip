@@ -1,0 +1,194 @@
+// K9 / K10 / K11 / K14: FRI folding, per-round commitments and proof-of-work grinding, gfx950.
+//
+// Replaces crates/lifted-stark/src/pcs/fri/prover.rs:93-242 (FriPolys::new),
+// pcs/fri/fold/arity4.rs:46-121 and arity2.rs (fold_evals), and the PoW search of
+// crates/stark-transcript/src/prover.rs:140-144 (p3 `grind`, external).
+//
+// Layout: a FRI layer of n = Nl*C points is stored coset-major like every LDE here:
+// slot j*Nl + r  <->  natural index i = r*C + j  (C = 2^cbits cosets; cbits = log_blowup until the
+// layer gets shorter than 4 rows per coset, then 0).  The arity-`a` coset of natural index i0 is
+// {i0 + m*n/a} = rows r0 + m*Nl/a of the SAME coset j, so a fold reads `a` unit-stride streams and
+// writes one; the reference's bit-reversed row [y0,y2,y1,y3] is rebuilt only in the leaf hash and
+// in query openings.
+// s_inv for row i0 is w_n^(-i0) (fri/prover.rs:117-142: the coset shift is deliberately ignored).
+#include "gl.cuh"
+#include "kernels.hpp"
+#include "poseidon2.cuh"
+
+__device__ __forceinline__ e2 ld_e2(const u64* p, size_t idx) {
+  const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(p + 2 * idx);
+  return e2{v.x, v.y};
+}
+__device__ __forceinline__ void st_e2(u64* p, size_t idx, e2 v) { *reinterpret_cast<ulonglong2*>(p + 2 * idx) = make_ulonglong2(v.c0, v.c1); }
+
+// reference row order inside a leaf: position p holds y_{bitrev(p)}
+__device__ __forceinline__ u32 fri_row_pos(u32 p, int log_arity) { return bitrev32(p, log_arity); }
+
+// ---- leaf digests: one permutation per leaf for arity 4 (8 felts = the rate), ---------------------
+// sponge over 2*arity felts in general.
+__global__ __launch_bounds__(256) void k_fri_leaf_hash(const u64* __restrict__ ev, int log_rows /* Nl */, int cbits, int log_arity,
+                                                       u64* __restrict__ digests) {
+  const int log_q = log_rows - log_arity;  // rows per coset after grouping
+  const size_t leaves = (size_t)1 << (log_q + cbits);
+  const size_t s = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (s >= leaves) return;
+  const size_t j = s >> log_q, r0 = s & (((size_t)1 << log_q) - 1);
+  const u32 arity = 1u << log_arity;
+  u64 st[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) st[i] = 0;
+  // absorb in chunks of 4 EF = 8 felts
+  for (u32 p0 = 0; p0 < arity; p0 += 4) {
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+      e2 v = e2_make(0);
+      if (p0 + k < arity) v = ld_e2(ev, (j << log_rows) + r0 + ((size_t)fri_row_pos(p0 + k, log_arity) << log_q));
+      st[2 * k] = (p0 + k < arity) ? v.c0 : 0;
+      st[2 * k + 1] = (p0 + k < arity) ? v.c1 : 0;
+    }
+    p2_permute(st);
+  }
+  ulonglong2* o = reinterpret_cast<ulonglong2*>(digests + 4 * s);
+  o[0] = make_ulonglong2(st[0], st[1]);
+  o[1] = make_ulonglong2(st[2], st[3]);
+}
+
+// ---- fold ----------------------------------------------------------------------------------------
+struct FoldArgs {
+  const u64* ev;
+  u64* out;
+  int log_rows, cbits, log_arity;
+  const u64* tw_inv;     // w_Nl^(-k), k < Nl/2   (Nl = rows per coset of the INPUT layer)
+  const u64* coset_inv;  // [C] w_n^(-j)
+  e2 beta;
+  u64 w4, inv_arity;
+};
+__global__ __launch_bounds__(256) void k_fri_fold(FoldArgs a) {
+  const int log_q = a.log_rows - a.log_arity;
+  const size_t total = (size_t)1 << (log_q + a.cbits);
+  const size_t s = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (s >= total) return;
+  const size_t j = s >> log_q, r0 = s & (((size_t)1 << log_q) - 1);
+  // s_inv = w_n^(-(r0*C + j)) = w_Nl^(-r0) * w_n^(-j);  r0 < Nl/arity <= Nl/2
+  const u64 s_inv = gl_mul(a.log_rows ? a.tw_inv[r0] : 1, a.coset_inv[j]);
+  const e2 x = e2_mulf(a.beta, s_inv);
+  const size_t base = (j << a.log_rows) + r0;
+  e2 res;
+  if (a.log_arity == 1) {
+    e2 y0 = ld_e2(a.ev, base), y1 = ld_e2(a.ev, base + ((size_t)1 << log_q));
+    res = e2_add(e2_add(y0, y1), e2_mul(e2_sub(y0, y1), x));
+  } else {
+    e2 y0 = ld_e2(a.ev, base), y1 = ld_e2(a.ev, base + ((size_t)1 << log_q)), y2 = ld_e2(a.ev, base + ((size_t)2 << log_q)),
+       y3 = ld_e2(a.ev, base + ((size_t)3 << log_q));
+    e2 s02 = e2_add(y0, y2), d02 = e2_sub(y0, y2), s13 = e2_add(y1, y3), d31w = e2_mulf(e2_sub(y3, y1), a.w4);
+    e2 c0 = e2_add(s02, s13), c1 = e2_add(d02, d31w), c2 = e2_sub(s02, s13), c3 = e2_sub(d02, d31w);
+    e2 x2 = e2_sqr(x), x3 = e2_mul(x2, x);
+    res = e2_add(e2_add(c0, e2_mul(c1, x)), e2_add(e2_mul(c2, x2), e2_mul(c3, x3)));
+  }
+  st_e2(a.out, s, e2_mulf(res, a.inv_arity));
+}
+
+// coset-major [C][Nl] -> natural order [Nl*C]
+__global__ void k_fri_to_natural(const u64* ev, u64* out, int log_rows, int cbits) {
+  const size_t total = (size_t)1 << (log_rows + cbits);
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const size_t j = i & (((size_t)1 << cbits) - 1), r = i >> cbits;
+  st_e2(out, i, ld_e2(ev, (j << log_rows) + r));
+}
+
+void fri_leaf_hash(mh_ctx* c, const u64* ev, int log_rows, int cbits, int log_arity, u64* digests) {
+  const size_t leaves = (size_t)1 << (log_rows - log_arity + cbits);
+  ProfScope ps(c, "fri_leaf_hash", (double)leaves * (16.0 * (1 << log_arity) + 32.0));
+  hipLaunchKernelGGL(k_fri_leaf_hash, dim3((unsigned)((leaves + 255) / 256)), dim3(256), 0, c->stream, ev, log_rows, cbits, log_arity,
+                     digests);
+}
+
+void fri_fold(mh_ctx* c, const u64* ev, int log_rows, int cbits, int log_arity, e2 beta, u64* out) {
+  MH_REQUIRE(log_arity == 1 || log_arity == 2, "FRI folding arity must be 2 or 4");
+  MH_REQUIRE(log_rows >= log_arity, "internal: FRI layer too short for a coset-major fold");
+  const int logn = log_rows + cbits;
+  const size_t C = (size_t)1 << cbits;
+  std::vector<u64> ci(C);
+  const u64 wn_inv = gl_inv(gl_two_adic_generator(logn));
+  u64 x = 1;
+  for (size_t j = 0; j < C; j++) {
+    ci[j] = x;
+    x = gl_mul(x, wn_inv);
+  }
+  DevBuf d(C * 8);
+  HIP_CHECK(hipMemcpyAsync(d.p, ci.data(), C * 8, hipMemcpyHostToDevice, c->stream));
+  FoldArgs a{};
+  a.ev = ev; a.out = out; a.log_rows = log_rows; a.cbits = cbits; a.log_arity = log_arity;
+  a.tw_inv = log_rows ? c->twiddles(log_rows, true) : nullptr;
+  a.coset_inv = d.u();
+  a.beta = beta;
+  a.w4 = gl_two_adic_generator(2);
+  a.inv_arity = gl_inv((u64)1 << log_arity);
+  const size_t total = (size_t)1 << (logn - log_arity);
+  {
+    ProfScope ps(c, "fri_fold", (double)total * 16.0 * ((1 << log_arity) + 1));
+    hipLaunchKernelGGL(k_fri_fold, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, a);
+  }
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+
+void fri_to_natural(mh_ctx* c, const u64* ev, int log_rows, int cbits, u64* out) {
+  const size_t total = (size_t)1 << (log_rows + cbits);
+  hipLaunchKernelGGL(k_fri_to_natural, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, ev, out, log_rows, cbits);
+}
+
+// ---- proof-of-work grinding ------------------------------------------------------------------------
+// Device mirror of DuplexChallenger::check_witness on a snapshot of the host challenger: lane i tries
+// witness base + i and the smallest passing witness of the window wins (deterministic result).
+struct GrindArgs {
+  u64 st[12];
+  u64 in[8];
+  int n_in, bits;
+  u64 base;
+  unsigned long long* best;
+};
+__global__ __launch_bounds__(256) void k_grind(GrindArgs a) {
+  const u64 w = a.base + blockIdx.x * (u64)256 + threadIdx.x;
+  if (w >= GL_P) return;
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = a.st[i];
+  // observe(w): append to the input buffer; the buffer then holds n_in + 1 <= 8 elements and either
+  // way exactly one duplexing happens before the sample (at 8 inside observe, otherwise in sample).
+  const int k = a.n_in + 1;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u64 v = (i < a.n_in) ? a.in[i] : (i == a.n_in ? w : 0);
+    s[i] = (i < k) ? v : 0;
+  }
+  s[8] = gl_add(s[8], (u64)k);
+  p2_permute(s);
+  const u64 x = s[7];  // first sample after a duplexing = rate[7]
+  if (((x & 0xFFFFFFFFULL) & (((u64)1 << a.bits) - 1)) == 0) atomicMin(a.best, (unsigned long long)w);
+}
+
+// Returns the smallest witness >= 0 accepted by `check_witness` for the given challenger snapshot.
+u64 fri_grind(mh_ctx* c, const u64 st[12], const u64* in, int n_in, int bits) {
+  MH_REQUIRE(bits > 0 && bits < 32 && n_in >= 0 && n_in < 8, "bad grind request");
+  DevBuf best(8);
+  GrindArgs a{};
+  for (int i = 0; i < 12; i++) a.st[i] = st[i];
+  for (int i = 0; i < n_in; i++) a.in[i] = in[i];
+  a.n_in = n_in; a.bits = bits;
+  a.best = (unsigned long long*)best.p;
+  // window ~ 4x the expected number of trials, at least one full wave of the chip
+  u64 window = (u64)1 << (bits + 2);
+  if (window < 65536) window = 65536;
+  ProfScope ps(c, "grind", 0);
+  for (u64 base = 0;; base += window) {
+    unsigned long long init = ~0ULL;
+    HIP_CHECK(hipMemcpyAsync(best.p, &init, 8, hipMemcpyHostToDevice, c->stream));
+    a.base = base;
+    hipLaunchKernelGGL(k_grind, dim3((unsigned)(window / 256)), dim3(256), 0, c->stream, a);
+    unsigned long long got = 0;
+    HIP_CHECK(hipMemcpyAsync(&got, best.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (got != ~0ULL) return (u64)got;
+  }
+}

@@ -35,6 +35,10 @@ struct mh_tree {
   int log_blowup;  // number of coset bits in the leaf layer layout (may be 0)
   int log_height;  // tree depth L (leaves = 2^L)
   std::vector<LdeMatrix> mats;
+  // FRI round trees (fri.hip) commit one EF layer instead of LDE matrices: rows are rebuilt from it
+  DevBuf fri_layer;      // EF pairs, coset-major [2^log_blowup][2^fri_log_rows]
+  int fri_log_rows = -1; // rows per coset of the layer (before grouping by arity); -1 = not a FRI tree
+  int fri_log_arity = 0;
   DevBuf nodes;                    // all layers, leaf layer first
   std::vector<size_t> layer_off;   // layer_off[d] = element offset (in digests) of depth-d layer
   u64 root[4];
@@ -50,7 +54,32 @@ struct mh_tree {
 void poseidon2_permute_device(mh_ctx* c, u64* states_soa, size_t n);  // [12][n]
 // Build leaf digests + all layers for `t->mats` (already filled); sets t->root.
 void lmcs_build_tree(mh_ctx* c, mh_tree* t);
+// Pieces of the above for trees whose leaf digests come from another kernel (FRI rounds):
+void lmcs_alloc_layers(mh_tree* t, int log_height);  // sets log_height, layer_off, nodes
+u64* lmcs_leaf_layer(mh_tree* t);                     // device pointer of the leaf digest layer
+void lmcs_compress_layers(mh_ctx* c, mh_tree* t);     // leaf layer -> root (copies root to host)
 // Gather opened rows (aligned, per sorted unique index) and missing siblings.
 void lmcs_open(mh_ctx* c, const mh_tree* t, const std::vector<size_t>& sorted_unique_idx, size_t alignment,
                std::vector<u64>& fields, std::vector<u64>& commitments);
 std::vector<std::pair<int, size_t>> lmcs_missing_siblings(const std::vector<size_t>& sorted_unique_idx, int depth);
+
+// ---- prover.hip (commit helpers shared with the C ABI) -------------------------------------------
+std::vector<u64> coset_shifts(int log_n, int lb);  // g*w_K^j, j < 2^lb, for the canonical shift of order log_n+lb
+mh_trace* trace_upload(mh_ctx* c, const u64* rowmajor, int log_n, size_t width);
+mh_trace* trace_zeros(mh_ctx* c, int log_n, size_t width);
+mh_tree* commit_traces(mh_ctx* c, const std::vector<const mh_trace*>& traces, int log_blowup);
+// ---- quotient.hip ------------------------------------------------------------------------------
+struct mh_air;
+#include "gl.cuh"
+void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& main, const LdeMatrix& aux, int log_blowup, int log_d,
+                              const std::vector<u64>& publics, const std::vector<e2>& randomness, const std::vector<e2>& aux_values,
+                              e2 alpha, const u64* acc_in, int log_n_prev, e2 beta, u64* acc_out);
+// ---- deep.hip ----------------------------------------------------------------------------------
+void deep_ood_eval_matrix(mh_ctx* c, const LdeMatrix& m, int log_blowup, e2 y0, e2 y1, std::vector<e2>& out0, std::vector<e2>& out1);
+void deep_assemble(mh_ctx* c, const std::vector<const LdeMatrix*>& mats, const std::vector<uint32_t>& coef_off, int log_n, int log_blowup,
+                   const std::vector<e2>& negc, e2 z0, e2 z1, e2 fred0, e2 fred1, e2 beta, u64* out);
+// ---- fri.hip -----------------------------------------------------------------------------------
+void fri_leaf_hash(mh_ctx* c, const u64* ev, int log_rows, int cbits, int log_arity, u64* digests);
+void fri_fold(mh_ctx* c, const u64* ev, int log_rows, int cbits, int log_arity, e2 beta, u64* out);
+void fri_to_natural(mh_ctx* c, const u64* ev, int log_rows, int cbits, u64* out);
+u64 fri_grind(mh_ctx* c, const u64 st[12], const u64* in, int n_in, int bits);

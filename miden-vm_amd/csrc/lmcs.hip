@@ -19,6 +19,7 @@
 #include "ctx.hpp"
 #include "kernels.hpp"
 #include "poseidon2.cuh"
+#include "gl.cuh"
 #include <algorithm>
 
 static constexpr int LEAF_MAX_MATS = 8;
@@ -117,22 +118,43 @@ __global__ __launch_bounds__(256) void k_compress(const u64* __restrict__ in, u6
   o[1] = make_ulonglong2(s[2], s[3]);
 }
 
-void lmcs_build_tree(mh_ctx* c, mh_tree* t) {
-  MH_REQUIRE(!t->mats.empty(), "cannot commit empty batch");
-  const int lb = t->log_blowup;
-  const int log_n_max = t->mats.back().log_n;
-  t->log_height = log_n_max + lb;
-  const size_t H = (size_t)1 << t->log_height;
-  for (size_t i = 1; i < t->mats.size(); i++)
-    MH_REQUIRE(t->mats[i - 1].log_n <= t->mats[i].log_n, "matrices must be sorted by ascending height");
+void lmcs_alloc_layers(mh_tree* t, int log_height) {
+  t->log_height = log_height;
   // layers: depth L (H nodes) first, then L-1, ..., 0
-  t->layer_off.assign(t->log_height + 1, 0);
+  t->layer_off.assign(log_height + 1, 0);
   size_t off = 0;
-  for (int d = t->log_height; d >= 0; d--) {
+  for (int d = log_height; d >= 0; d--) {
     t->layer_off[d] = off;
     off += (size_t)1 << d;
   }
   t->nodes.alloc(off * 32);
+}
+u64* lmcs_leaf_layer(mh_tree* t) { return t->nodes.u() + 4 * t->layer_off[t->log_height]; }
+
+void lmcs_compress_layers(mh_ctx* c, mh_tree* t) {
+  const int lb = t->log_blowup;
+  const size_t H = (size_t)1 << t->log_height;
+  {
+    ProfScope ps(c, "lmcs_compress", 96.0 * (double)H);
+    for (int d = t->log_height - 1; d >= 0; d--) {
+      size_t n_out = (size_t)1 << d;
+      int cbits_child = (d + 1) - (t->log_height - lb);  // coset bits of the child layer
+      int log_n_coset = cbits_child > 0 ? (t->log_height - lb) : -1;
+      hipLaunchKernelGGL(k_compress, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream,
+                         t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
+    }
+  }
+  HIP_CHECK(hipMemcpyAsync(t->root, t->nodes.u() + 4 * t->layer_off[0], 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+
+void lmcs_build_tree(mh_ctx* c, mh_tree* t) {
+  MH_REQUIRE(!t->mats.empty(), "cannot commit empty batch");
+  const int lb = t->log_blowup;
+  const int log_n_max = t->mats.back().log_n;
+  for (size_t i = 1; i < t->mats.size(); i++)
+    MH_REQUIRE(t->mats[i - 1].log_n <= t->mats[i].log_n, "matrices must be sorted by ascending height");
+  lmcs_alloc_layers(t, log_n_max + lb);
 
   // ---- leaves: one launch per (height group, <=8 matrices) chained through a state buffer
   DevBuf st_a, st_b;
@@ -178,19 +200,7 @@ void lmcs_build_tree(mh_ctx* c, mh_tree* t) {
     state_in = a.state_out;
     log_n_prev = ln;
   }
-  // ---- compress layers
-  {
-    ProfScope ps(c, "lmcs_compress", 96.0 * (double)H);
-    for (int d = t->log_height - 1; d >= 0; d--) {
-      size_t n_out = (size_t)1 << d;
-      int cbits_child = (d + 1) - (t->log_height - lb);  // coset bits of the child layer
-      int log_n_coset = cbits_child > 0 ? (t->log_height - lb) : -1;
-      hipLaunchKernelGGL(k_compress, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream,
-                         t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
-    }
-  }
-  HIP_CHECK(hipMemcpyAsync(t->root, t->nodes.u() + 4 * t->layer_off[0], 32, hipMemcpyDeviceToHost, c->stream));
-  HIP_CHECK(hipStreamSynchronize(c->stream));
+  lmcs_compress_layers(c, t);
 }
 
 // tree_indices.rs:185-240 (MissingSiblingsIter): bottom-up, left-to-right.
@@ -226,6 +236,17 @@ void lmcs_open(mh_ctx* c, const mh_tree* t, const std::vector<size_t>& idx, size
   for (size_t i : idx) {
     MH_REQUIRE(i < ((size_t)1 << t->log_height), "opening index out of range");
     size_t j = i & Bm, r = i >> lb;
+    if (t->fri_log_rows >= 0) {
+      // FRI round tree: the leaf row is the arity-coset of EF values, bit-reversed inside the row
+      // (fri/prover.rs:117-142), flattened [c0, c1]; FRI trees are unaligned (build_tree).
+      const int log_q = t->fri_log_rows - t->fri_log_arity;
+      for (u32 p = 0; p < (1u << t->fri_log_arity); p++) {
+        size_t e = (j << t->fri_log_rows) + r + ((size_t)bitrev32(p, t->fri_log_arity) << log_q);
+        ptrs.push_back(t->fri_layer.u() + 2 * e);
+        ptrs.push_back(t->fri_layer.u() + 2 * e + 1);
+      }
+      continue;
+    }
     for (const LdeMatrix& m : t->mats) {
       size_t N = (size_t)1 << m.log_n;
       size_t rm = r & (N - 1);

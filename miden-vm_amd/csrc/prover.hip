@@ -1,0 +1,447 @@
+// The lifted-STARK prover on the MI355X: host orchestration of the device kernels.
+//
+// Replaces `prove` of crates/lifted-stark/src/prover/mod.rs:230-578 as reached from
+// miden_prover::prove_stark (prover/src/lib.rs:317-355), including commit_traces
+// (prover/commit.rs:142-180), commit_quotient (prover/quotient.rs:143-217), sample_ood_point
+// (domain.rs:539-553) and pcs::open_with_channel (pcs/prover.rs:34-101).
+// Every pass over LDE-sized data is a device kernel on resident buffers; the host keeps the
+// Fiat-Shamir transcript (challenger.hpp) and only ever receives the values the transcript observes:
+// 3 + #FRI-rounds roots, the OOD evaluations, PoW witnesses, the final polynomial, query openings.
+// Transcript order: SURVEY.md Appendix A.
+#include "../../include/midenhip.h"
+#include "air.hpp"
+#include "challenger.hpp"
+#include "ctx.hpp"
+#include "gl.cuh"
+#include "kernels.hpp"
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <numeric>
+
+// -------------------------------------------------------------------------------------------------
+std::vector<u64> coset_shifts(int log_n, int lb) {
+  // shift * w_K^j for j < B, K of order 2^(log_n+lb), canonical shift of that order (domain.rs:358-361)
+  u64 g = gl_lde_shift(log_n + lb);
+  u64 wk = gl_two_adic_generator(log_n + lb);
+  std::vector<u64> s((size_t)1 << lb);
+  u64 x = g;
+  for (auto& v : s) {
+    v = x;
+    x = gl_mul(x, wk);
+  }
+  return s;
+}
+
+mh_trace* trace_upload(mh_ctx* c, const u64* rowmajor, int log_n, size_t width) {
+  size_t n = (size_t)1 << log_n;
+  std::unique_ptr<mh_trace> t(new mh_trace());
+  t->ctx = c; t->log_n = log_n; t->width = width;
+  DevBuf staging(n * width * 8);
+  t->cols.alloc(n * width * 8);
+  HIP_CHECK(hipMemcpyAsync(staging.p, rowmajor, n * width * 8, hipMemcpyHostToDevice, c->stream));
+  {
+    ProfScope ps(c, "transpose_in", 16.0 * n * width);
+    launch_transpose_rm_to_cm(c, staging.u(), t->cols.u(), n, width);
+  }
+  c->sync();
+  return t.release();
+}
+
+mh_trace* trace_zeros(mh_ctx* c, int log_n, size_t width) {
+  size_t n = (size_t)1 << log_n;
+  std::unique_ptr<mh_trace> t(new mh_trace());
+  t->ctx = c; t->log_n = log_n; t->width = width;
+  t->cols.alloc(n * width * 8);
+  HIP_CHECK(hipMemsetAsync(t->cols.p, 0, n * width * 8, c->stream));
+  return t.release();
+}
+
+// LDE of one uploaded trace into coset-major layout on the canonical shift of its own LDE order.
+static LdeMatrix lde_trace(mh_ctx* c, const mh_trace* tr, int lb) {
+  LdeMatrix m;
+  m.log_n = tr->log_n; m.width = tr->width;
+  size_t N = (size_t)1 << tr->log_n;
+  MH_REQUIRE(tr->log_n + lb <= 32, "LDE order exceeds the field's two-adicity");
+  m.lde.alloc((N << lb) * tr->width * 8);
+  DevBuf scratch(N * tr->width * 8);
+  ProfScope ps(c, "lde", (double)(1 + (1 << lb)) * N * tr->width * 8.0);
+  lde_columns(c, tr->cols.u(), tr->width, tr->log_n, 1, coset_shifts(tr->log_n, lb), m.lde.u(), scratch.u());
+  return m;
+}
+
+mh_tree* commit_traces(mh_ctx* c, const std::vector<const mh_trace*>& traces, int log_blowup) {
+  std::unique_ptr<mh_tree> t(new mh_tree());
+  t->ctx = c; t->log_blowup = log_blowup;
+  for (const mh_trace* tr : traces) t->mats.push_back(lde_trace(c, tr, log_blowup));
+  lmcs_build_tree(c, t.get());
+  return t.release();
+}
+
+// -------------------------------------------------------------------------------------------------
+struct mh_proof {
+  std::vector<uint8_t> log_trace_heights;  // instance order
+  std::vector<u64> fields;
+  std::vector<u64> commitments;  // 4 felts each
+  u64 digest[4];
+};
+
+static size_t align8(size_t w) { return (w + 7) / 8 * 8; }
+
+static void do_grind(mh_ctx* c, HostTranscript& tr, int bits) {
+  if (bits == 0) {
+    tr.fields.push_back(0);
+    return;
+  }
+  u64 w = fri_grind(c, tr.ch.st, tr.ch.in.data(), (int)tr.ch.in.size(), bits);
+  MH_REQUIRE(tr.ch.check_witness(bits, w), "internal: device PoW witness rejected by the host challenger");
+  tr.fields.push_back(w);
+}
+
+static int fri_num_rounds(const mh_pcs_params& p, int log_lde) {
+  int log_max_final = p.log_final_degree + p.log_blowup;
+  int steps = log_lde > log_max_final ? log_lde - log_max_final : 0;
+  return (steps + p.log_folding_arity - 1) / p.log_folding_arity;
+}
+
+static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* const* airs_in, mh_trace* const* traces_in,
+                       const u64* publics_in, size_t n_publics, const u64 init_state[12], const u64* pre_observe, size_t n_pre,
+                       mh_aux_builder cb, void* user, mh_proof& proof) {
+  MH_REQUIRE(n_airs > 0 && n_airs <= 256, "need between 1 and 256 AIR instances");
+  const int lb = pp.log_blowup;
+  MH_REQUIRE(lb > 0 && lb <= 8, "log_blowup must be in 1..8");
+  MH_REQUIRE(pp.log_folding_arity == 1 || pp.log_folding_arity == 2, "FRI folding arity must be 2 or 4");
+  MH_REQUIRE(pp.num_queries > 0, "num_queries must be > 0");
+  MH_REQUIRE(pp.log_final_degree + lb >= pp.log_folding_arity - 1, "final degree unreachable by fixed-arity folding");
+  const size_t B = (size_t)1 << lb;
+  // ---- trust boundary (prover/mod.rs:199-214) ----
+  std::vector<int> lhs(n_airs);
+  for (int i = 0; i < n_airs; i++) {
+    MH_REQUIRE(airs_in[i] && traces_in[i], "null AIR or trace");
+    MH_REQUIRE(traces_in[i]->width == airs_in[i]->main_width, "trace width does not match the AIR");
+    MH_REQUIRE(airs_in[i]->num_public == n_publics, "AIR expects a different number of public values");
+    MH_REQUIRE(traces_in[i]->log_n >= 1, "trace needs at least 2 rows");
+    MH_REQUIRE(((size_t)1 << traces_in[i]->log_n) >= airs_in[i]->max_period(), "trace shorter than a periodic column");
+    MH_REQUIRE(airs_in[i]->aux_width > 0, "AIR must declare at least one aux column");
+    lhs[i] = traces_in[i]->log_n;
+  }
+  std::vector<int> order(n_airs);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lhs[a] < lhs[b]; });
+  const int log_N = lhs[order.back()];
+  const int L = log_N + lb;
+  MH_REQUIRE(L <= 32, "LDE order exceeds the field's two-adicity");
+  const size_t N = (size_t)1 << log_N;
+  int logD = 0;
+  for (int i = 0; i < n_airs; i++) logD = std::max(logD, airs_in[i]->log_quotient_degree);
+  MH_REQUIRE(logD <= lb, "constraint degree too high for the blowup");
+  for (int i = 0; i < n_airs; i++)
+    MH_REQUIRE(airs_in[i]->log_quotient_degree == logD,
+               "AIRs with different quotient degrees in one proof are not supported by this backend yet");
+  const size_t D = (size_t)1 << logD;
+  std::vector<u64> publics(publics_in, publics_in + n_publics);
+
+  HostTranscript tr;
+  for (int i = 0; i < 12; i++) tr.ch.st[i] = gl_canon(init_state[i]);
+  for (size_t i = 0; i < n_pre; i++) tr.ch.observe(pre_observe[i]);
+  tr.ch.observe((u64)n_airs);                              // order.rs:154-163
+  for (int i = 0; i < n_airs; i++) tr.ch.observe((u64)lhs[i]);
+
+  // ---- 1. main commitment ----
+  std::vector<const mh_trace*> main_tr;
+  for (int j = 0; j < n_airs; j++) main_tr.push_back(traces_in[order[j]]);
+  std::unique_ptr<mh_tree> main_tree(commit_traces(c, main_tr, lb));
+  tr.send_commitment(main_tree->root);
+
+  // ---- 2. randomness, aux traces (instance order), aux commitment ----
+  size_t max_rand = 0;
+  for (int i = 0; i < n_airs; i++) max_rand = std::max(max_rand, airs_in[i]->num_randomness);
+  std::vector<e2> randomness;
+  for (size_t i = 0; i < max_rand; i++) randomness.push_back(tr.ch.sample_ef());
+  std::vector<u64> rand_flat;
+  for (e2 r : randomness) { rand_flat.push_back(r.c0); rand_flat.push_back(r.c1); }
+  if (rand_flat.empty()) rand_flat.push_back(0);
+  std::vector<std::unique_ptr<mh_trace>> aux_tr(n_airs);
+  std::vector<std::vector<e2>> aux_vals(n_airs);
+  for (int i = 0; i < n_airs; i++) {
+    const mh_air* a = airs_in[i];
+    const size_t n = (size_t)1 << lhs[i], w = 2 * a->aux_width;
+    aux_vals[i].assign(a->num_aux_values, e2_make(0));
+    if (cb) {
+      std::vector<u64> host(n * w, 0), vals(2 * std::max<size_t>(1, a->num_aux_values), 0);
+      int rc = cb(user, i, rand_flat.data(), host.data(), vals.data());
+      MH_REQUIRE(rc == 0, "aux trace builder / external assertion failed");
+      for (size_t k = 0; k < a->num_aux_values; k++) aux_vals[i][k] = e2{gl_canon(vals[2 * k]), gl_canon(vals[2 * k + 1])};
+      aux_tr[i].reset(trace_upload(c, host.data(), lhs[i], w));
+    } else {
+      aux_tr[i].reset(trace_zeros(c, lhs[i], w));  // DummyMidenAir::build_aux_trace (testing/airs/miden.rs:79-89)
+    }
+  }
+  std::vector<const mh_trace*> aux_po;
+  for (int j = 0; j < n_airs; j++) aux_po.push_back(aux_tr[order[j]].get());
+  std::unique_ptr<mh_tree> aux_tree(commit_traces(c, aux_po, lb));
+  tr.send_commitment(aux_tree->root);
+  aux_tr.clear();
+  for (int j = 0; j < n_airs; j++)
+    for (e2 v : aux_vals[order[j]]) tr.send_ef(v);
+
+  // ---- 3. alpha, beta; 4. quotient evaluation + accumulation ----
+  const e2 alpha = tr.ch.sample_ef();
+  const e2 beta = tr.ch.sample_ef();
+  DevBuf acc, acc_prev;
+  int log_n_prev = 0;
+  for (int j = 0; j < n_airs; j++) {
+    const mh_air* a = airs_in[order[j]];
+    const int ln = lhs[order[j]];
+    DevBuf out(((size_t)2 * D << ln) * 8);
+    std::vector<e2> rnd(randomness.begin(), randomness.begin() + a->num_randomness);
+    quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], lb, logD, publics, rnd, aux_vals[order[j]], alpha,
+                             j ? acc.u() : nullptr, log_n_prev, beta, out.u());
+    acc = std::move(out);
+    log_n_prev = ln;
+  }
+
+  // ---- 5. quotient commitment (quotient.rs:143-217): chunk t = columns 2t, 2t+1 ----
+  std::unique_ptr<mh_tree> quot_tree(new mh_tree());
+  quot_tree->ctx = c; quot_tree->log_blowup = lb;
+  {
+    LdeMatrix qm;
+    qm.log_n = log_N; qm.width = 2 * D;
+    qm.lde.alloc((N << lb) * 2 * D * 8);
+    DevBuf scratch(2 * N * 8);
+    const u64 g = gl_lde_shift(L);
+    const u64 wJ = gl_two_adic_generator(log_N + logD);
+    const std::vector<u64> outs = coset_shifts(log_N, lb);
+    {
+      ProfScope ps(c, "lde", (double)(1 + (1 << lb)) * N * 2 * D * 8.0);
+      for (size_t t = 0; t < D; t++)
+        lde_columns(c, acc.u() + 2 * t * N, 2, log_N, gl_mul(g, gl_pow(wJ, t)), outs, qm.lde.u() + 2 * t * B * N, scratch.u());
+    }
+    quot_tree->mats.push_back(std::move(qm));
+    lmcs_build_tree(c, quot_tree.get());
+  }
+  acc.release();
+  tr.send_commitment(quot_tree->root);
+
+  // ---- 6. OOD point ----
+  const u64 g = gl_lde_shift(L), g_inv = gl_inv(g);
+  e2 z;
+  for (;;) {
+    z = tr.ch.sample_ef();
+    if (e2_is_zero(z)) continue;
+    if (e2_eq(e2_exp_pow2(z, log_N), e2_make(1))) continue;
+    if (e2_eq(e2_exp_pow2(e2_mulf(z, g_inv), L), e2_make(1))) continue;
+    break;
+  }
+  const e2 z_next = e2_mulf(z, gl_two_adic_generator(log_N));
+
+  // ---- 7. DEEP ----
+  std::vector<const LdeMatrix*> mats;
+  for (auto& m : main_tree->mats) mats.push_back(&m);
+  for (auto& m : aux_tree->mats) mats.push_back(&m);
+  mats.push_back(&quot_tree->mats[0]);
+  std::vector<u32> coef_off;
+  size_t W = 0;
+  for (auto* m : mats) {
+    coef_off.push_back((u32)W);
+    W += align8(m->width);
+  }
+  std::vector<e2> ev0(W, e2_make(0)), ev1(W, e2_make(0));
+  for (size_t i = 0; i < mats.size(); i++) {
+    const int lift = log_N - mats[i]->log_n;
+    std::vector<e2> o0, o1;
+    deep_ood_eval_matrix(c, *mats[i], lb, e2_exp_pow2(z, lift), e2_exp_pow2(z_next, lift), o0, o1);
+    for (size_t k = 0; k < o0.size(); k++) {
+      ev0[coef_off[i] + k] = o0[k];
+      ev1[coef_off[i] + k] = o1[k];
+    }
+  }
+  for (e2 v : ev0) tr.send_ef(v);
+  for (e2 v : ev1) tr.send_ef(v);
+  do_grind(c, tr, pp.deep_pow_bits);
+  const e2 alpha_d = tr.ch.sample_ef();
+  const e2 beta_d = tr.ch.sample_ef();
+  e2 fred0 = e2_make(0), fred1 = e2_make(0);
+  for (size_t i = 0; i < W; i++) {
+    fred0 = e2_add(e2_mul(fred0, alpha_d), ev0[i]);
+    fred1 = e2_add(e2_mul(fred1, alpha_d), ev1[i]);
+  }
+  std::vector<e2> negc(W);
+  {
+    e2 pw = e2_make(GL_P - 1);
+    for (size_t i = W; i-- > 0;) {
+      negc[i] = pw;
+      pw = e2_mul(pw, alpha_d);
+    }
+  }
+  DevBuf layer((N << lb) * 16);
+  deep_assemble(c, mats, coef_off, log_N, lb, negc, z, z_next, fred0, fred1, beta_d, layer.u());
+
+  // ---- 8. FRI commit phase ----
+  const int la = pp.log_folding_arity;
+  const int rounds = fri_num_rounds(pp, L);
+  std::vector<std::unique_ptr<mh_tree>> fri_trees;
+  int log_rows = log_N, cbits = lb;
+  for (int r = 0; r < rounds; r++) {
+    if (log_rows < la) {  // tiny layer: fewer than `arity` rows per coset -> single-coset (natural) layout
+      DevBuf nat(((size_t)1 << (log_rows + cbits)) * 16);
+      fri_to_natural(c, layer.u(), log_rows, cbits, nat.u());
+      c->sync();
+      layer = std::move(nat);
+      log_rows += cbits;
+      cbits = 0;
+    }
+    std::unique_ptr<mh_tree> t(new mh_tree());
+    t->ctx = c; t->log_blowup = cbits;
+    t->fri_log_rows = log_rows; t->fri_log_arity = la;
+    lmcs_alloc_layers(t.get(), log_rows + cbits - la);
+    fri_leaf_hash(c, layer.u(), log_rows, cbits, la, lmcs_leaf_layer(t.get()));
+    lmcs_compress_layers(c, t.get());
+    tr.send_commitment(t->root);
+    do_grind(c, tr, pp.folding_pow_bits);
+    const e2 fb = tr.ch.sample_ef();
+    DevBuf next(((size_t)1 << (log_rows + cbits - la)) * 16);
+    fri_fold(c, layer.u(), log_rows, cbits, la, fb, next.u());
+    t->fri_layer = std::move(layer);
+    layer = std::move(next);
+    log_rows -= la;
+    fri_trees.push_back(std::move(t));
+  }
+  {
+    // final polynomial (fri/prover.rs:212-239): evaluations on the order-fpd subgroup = natural indices
+    // i = r * (n_f / fpd); interpolate on the host, send in descending degree order.
+    const int logn_f = log_rows + cbits;
+    const int log_fpd = std::max(0, logn_f - lb);
+    const size_t n_f = (size_t)1 << logn_f, fpd = (size_t)1 << log_fpd;
+    std::vector<u64> host(2 * n_f);
+    HIP_CHECK(hipMemcpyAsync(host.data(), layer.p, n_f * 16, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    std::vector<e2> vals(fpd);
+    for (size_t r = 0; r < fpd; r++) {
+      size_t i = r << (logn_f - log_fpd);
+      size_t slot = ((i & (((size_t)1 << cbits) - 1)) << log_rows) + (i >> cbits);
+      vals[r] = e2{host[2 * slot], host[2 * slot + 1]};
+    }
+    const u64 w_inv = gl_inv(gl_two_adic_generator(log_fpd)), n_inv = gl_inv((u64)fpd);
+    std::vector<e2> coef(fpd);
+    for (size_t k = 0; k < fpd; k++) {
+      e2 s = e2_make(0);
+      u64 wk = gl_pow(w_inv, k), x = 1;
+      for (size_t r = 0; r < fpd; r++) {
+        s = e2_add(s, e2_mulf(vals[r], x));
+        x = gl_mul(x, wk);
+      }
+      coef[k] = e2_mulf(s, n_inv);
+    }
+    for (size_t k = fpd; k-- > 0;) tr.send_ef(coef[k]);
+  }
+
+  // ---- 9. queries ----
+  do_grind(c, tr, pp.query_pow_bits);
+  std::vector<size_t> idx;
+  for (int i = 0; i < pp.num_queries; i++) idx.push_back(tr.ch.sample_bits(L));
+  std::sort(idx.begin(), idx.end());
+  idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
+  for (const mh_tree* t : {main_tree.get(), aux_tree.get(), quot_tree.get()}) {
+    std::vector<u64> f, cm;
+    lmcs_open(c, t, idx, 8, f, cm);
+    tr.hint_fields(f);
+    tr.hint_commitments(cm);
+  }
+  int depth = L;
+  for (auto& t : fri_trees) {
+    depth -= la;
+    const size_t mask = ((size_t)1 << depth) - 1;
+    for (auto& i : idx) i &= mask;
+    std::sort(idx.begin(), idx.end());
+    idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
+    std::vector<u64> f, cm;
+    lmcs_open(c, t.get(), idx, 1, f, cm);
+    tr.hint_fields(f);
+    tr.hint_commitments(cm);
+  }
+  // finalize (CanFinalizeDigest, external): flush pending input, squeeze 4 felts
+  if (!tr.ch.in.empty()) tr.ch.duplexing();
+  for (int i = 0; i < 4; i++) proof.digest[i] = tr.ch.st[i];
+  for (int i = 0; i < n_airs; i++) proof.log_trace_heights.push_back((uint8_t)lhs[i]);
+  proof.fields = std::move(tr.fields);
+  for (auto& d : tr.commitments) proof.commitments.insert(proof.commitments.end(), d.begin(), d.end());
+}
+
+// -------------------------------------------------------------------------------------------------
+#define MH_TRY(ctx_expr) mh_ctx* _c = (ctx_expr); try {
+#define MH_CATCH                                                   \
+  }                                                                \
+  catch (const MhError& e) {                                       \
+    if (_c) _c->err = e.what();                                    \
+    return e.code;                                                 \
+  }                                                                \
+  catch (const std::exception& e) {                                \
+    if (_c) _c->err = e.what();                                    \
+    return MH_ERR_INTERNAL;                                        \
+  }                                                                \
+  return MH_OK;
+
+extern "C" {
+
+int mh_air_load(mh_ctx* c, const uint64_t* blob, size_t n_words, mh_air** out) {
+  MH_TRY(c)
+  MH_REQUIRE(c && blob && out, "null argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  *out = mh_air::load(c, blob, n_words);
+  MH_CATCH
+}
+void mh_air_free(mh_air* a) {
+  if (!a) return;
+  (void)hipSetDevice(a->ctx->device);
+  delete a;
+}
+int mh_air_log_quotient_degree(const mh_air* a) { return a ? a->log_quotient_degree : -1; }
+
+int mh_prove(mh_ctx* c, const mh_pcs_params* params, int n_airs, mh_air* const* airs, mh_trace* const* traces,
+             const uint64_t* public_values, size_t n_public_values, const uint64_t challenger_state[12],
+             const uint64_t* pre_observe, size_t n_pre_observe, mh_aux_builder aux_builder, void* user, mh_proof** out) {
+  MH_TRY(c)
+  MH_REQUIRE(c && params && airs && traces && challenger_state && out, "null argument");
+  MH_REQUIRE(public_values || !n_public_values, "null public values");
+  MH_REQUIRE(pre_observe || !n_pre_observe, "null pre_observe");
+  HIP_CHECK(hipSetDevice(c->device));
+  std::unique_ptr<mh_proof> p(new mh_proof());
+  prove_impl(c, *params, n_airs, airs, traces, public_values, n_public_values, challenger_state, pre_observe, n_pre_observe,
+             aux_builder, user, *p);
+  *out = p.release();
+  MH_CATCH
+}
+void mh_proof_free(mh_proof* p) { delete p; }
+size_t mh_proof_num_fields(const mh_proof* p) { return p ? p->fields.size() : 0; }
+size_t mh_proof_num_commitments(const mh_proof* p) { return p ? p->commitments.size() / 4 : 0; }
+const uint64_t* mh_proof_fields(const mh_proof* p) { return p ? p->fields.data() : nullptr; }
+const uint64_t* mh_proof_commitments(const mh_proof* p) { return p ? p->commitments.data() : nullptr; }
+const uint64_t* mh_proof_digest(const mh_proof* p) { return p ? p->digest : nullptr; }
+size_t mh_proof_num_traces(const mh_proof* p) { return p ? p->log_trace_heights.size() : 0; }
+const uint8_t* mh_proof_log_trace_heights(const mh_proof* p) { return p ? p->log_trace_heights.data() : nullptr; }
+
+// StarkProofData { log_trace_heights: Vec<u8>, transcript: { fields: Vec<Felt>, commitments: Vec<[Felt;4]> } }
+// (crates/lifted-stark/src/proof.rs:58-63) in bincode-style framing: u64 LE length prefixes, u64 LE felts.
+// PARITY UNPINNED: the reference frames with wincode 0.5.5 (external); see DESIGN.md.
+size_t mh_proof_serialize(const mh_proof* p, uint8_t* out, size_t cap) {
+  if (!p) return 0;
+  const size_t need = 8 + p->log_trace_heights.size() + 8 + 8 * p->fields.size() + 8 + 8 * p->commitments.size();
+  if (!out || cap < need) return need;
+  uint8_t* o = out;
+  auto put64 = [&](u64 v) {
+    memcpy(o, &v, 8);
+    o += 8;
+  };
+  put64(p->log_trace_heights.size());
+  memcpy(o, p->log_trace_heights.data(), p->log_trace_heights.size());
+  o += p->log_trace_heights.size();
+  put64(p->fields.size());
+  memcpy(o, p->fields.data(), 8 * p->fields.size());
+  o += 8 * p->fields.size();
+  put64(p->commitments.size() / 4);
+  memcpy(o, p->commitments.data(), 8 * p->commitments.size());
+  return need;
+}
+
+}  // extern "C"

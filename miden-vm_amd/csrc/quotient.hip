@@ -1,0 +1,288 @@
+// K4 / K5 / K12: constraint evaluation on the quotient coset, alpha-fold, 1/Z_H, and the
+// cross-AIR beta accumulation, gfx950.
+//
+// Replaces crates/lifted-stark/src/prover/constraints/mod.rs:83-278 (evaluate_constraints_into),
+// constraints/folder.rs:88-105 (finalize_constraints), domain.rs:698-750 (selectors,
+// inv_vanishing_evals), prover/quotient.rs:83-111 (cyclic_extend_and_accumulate).
+//
+// Layout: the quotient coset gJ (size n*D) is the union of the D committed cosets
+// jc = t*B/D of the coset-major LDE, so point (t, r) reads row r of coset jc of every column
+// (unit stride across lanes) and its "next row" is r+1 of the same coset -- no bit-reversed
+// gather (the reference's packed_row_bitrev.rs) exists here.  The accumulator is the N x 2D
+// column-major base matrix the quotient commit consumes directly: acc[(2t+e)*n + r].
+// The AIR is an interpreter program (air.hpp); its slot file lives in LDS, SoA across lanes.
+// Roofline: HBM (reads the touched main/aux columns once per AIR, writes 16 B per point); for real
+// AIRs with thousands of gates the interpreter is VALU bound.
+#include "air.hpp"
+#include "gl.cuh"
+#include "kernels.hpp"
+
+struct QuotArgs {
+  const AirIns* code;
+  u32 n_ins, n_slots;
+  const u64* main_lde;
+  const u64* aux_lde;
+  int log_n, log_blowup, log_d;
+  const u64* tw;         // w_n^k (k < n/2)
+  const u64* coset_tab;  // [3][D]: x-coordinate of coset t at r = 0, Z_H on coset t, 1/Z_H
+  u64 wh_inv;
+  const u64* inv_first;  // [D*n] 1/(x-1)      (null when the AIR never asks)
+  const u64* inv_last;   // [D*n] 1/(x-w_H^-1)
+  const u64* periodic;   // [n_periodic][periodic_rows], natural gJ index mod periodic_rows
+  u32 periodic_rows;
+  const u64* publics;
+  const u64* randomness;  // EF pairs
+  const u64* aux_values;  // EF pairs
+  const u64* alpha_pows;  // EF pairs: alpha^(K-1-k) at index k
+  const u64* acc_in;      // [2D][n_prev] or null
+  int log_n_prev;
+  e2 beta;
+  u64* acc_out;           // [2D][n]
+};
+
+__device__ __forceinline__ u64 coset_point(const u64* tw, int log_n, u64 cx, size_t r) {
+  const size_t half = ((size_t)1 << log_n) >> 1;
+  u64 w = (r < half || half == 0) ? tw[half ? r : 0] : gl_neg(tw[r - half]);
+  return gl_mul(cx, w);
+}
+
+__global__ __launch_bounds__(256) void k_eval_quotient(QuotArgs a) {
+  extern __shared__ u64 slots[];
+  const u32 T = blockDim.x, tid = threadIdx.x;
+  const size_t n = (size_t)1 << a.log_n;
+  const size_t D = (size_t)1 << a.log_d;
+  const size_t q = blockIdx.x * (size_t)T + tid;
+  if (q >= n * D) return;
+  const size_t t = q >> a.log_n, r = q & (n - 1);
+  const size_t r_next = (r + 1) & (n - 1);
+  const size_t jc = t << (a.log_blowup - a.log_d);
+  const size_t B = (size_t)1 << a.log_blowup;
+  const u64 x = coset_point(a.tw, a.log_n, a.coset_tab[t], r);
+  e2 acc = e2_make(0);
+#define SLOT0(s) slots[(size_t)(2 * (s)) * T + tid]
+#define SLOT1(s) slots[(size_t)(2 * (s) + 1) * T + tid]
+#pragma unroll 1
+  for (u32 pc = 0; pc < a.n_ins; pc++) {
+    const AirIns ins = a.code[pc];
+    e2 va, vb, v;
+    switch (ins.op) {
+      case DOP_CONST: v = e2_make(((u64)ins.imm_hi << 32) | ins.imm_lo); break;
+      case DOP_MAIN: v = e2_make(a.main_lde[(((size_t)ins.b * B + jc) << a.log_n) + (ins.imm_lo ? r_next : r)]); break;
+      case DOP_AUX: {
+        const size_t rr = ins.imm_lo ? r_next : r;
+        v.c0 = a.aux_lde[(((size_t)(2 * ins.b) * B + jc) << a.log_n) + rr];
+        v.c1 = a.aux_lde[(((size_t)(2 * ins.b + 1) * B + jc) << a.log_n) + rr];
+        break;
+      }
+      case DOP_PUBLIC: v = e2_make(a.publics[ins.b]); break;
+      case DOP_PERIODIC: v = e2_make(a.periodic[(size_t)ins.b * a.periodic_rows + ((r * D + t) % a.periodic_rows)]); break;
+      case DOP_IS_FIRST: v = e2_make(gl_mul(a.coset_tab[D + t], a.inv_first[q])); break;
+      case DOP_IS_LAST: v = e2_make(gl_mul(a.coset_tab[D + t], a.inv_last[q])); break;
+      case DOP_IS_TRANSITION: v = e2_make(gl_sub(x, a.wh_inv)); break;
+      case DOP_RANDOMNESS: v = e2{a.randomness[2 * ins.b], a.randomness[2 * ins.b + 1]}; break;
+      case DOP_AUX_VALUE: v = e2{a.aux_values[2 * ins.b], a.aux_values[2 * ins.b + 1]}; break;
+      case DOP_FOLD: {
+        va.c0 = SLOT0(ins.a);
+        va.c1 = ins.a_ext ? SLOT1(ins.a) : 0;
+        const e2 pw = e2{a.alpha_pows[2 * ins.imm_lo], a.alpha_pows[2 * ins.imm_lo + 1]};
+        acc = e2_add(acc, ins.a_ext ? e2_mul(pw, va) : e2_mulf(pw, va.c0));
+        continue;
+      }
+      default: {
+        va.c0 = SLOT0(ins.a);
+        va.c1 = ins.a_ext ? SLOT1(ins.a) : 0;
+        if (ins.op != DOP_NEG) {
+          vb.c0 = SLOT0(ins.b);
+          vb.c1 = ins.b_ext ? SLOT1(ins.b) : 0;
+        }
+        const bool ext = ins.a_ext || ins.b_ext;
+        if (ins.op == DOP_ADD) v = ext ? e2_add(va, vb) : e2_make(gl_add(va.c0, vb.c0));
+        else if (ins.op == DOP_SUB) v = ext ? e2_sub(va, vb) : e2_make(gl_sub(va.c0, vb.c0));
+        else if (ins.op == DOP_NEG) v = ins.a_ext ? e2_neg(va) : e2_make(gl_neg(va.c0));
+        else {  // MUL
+          if (ins.a_ext && ins.b_ext) v = e2_mul(va, vb);
+          else if (ins.a_ext) v = e2_mulf(va, vb.c0);
+          else if (ins.b_ext) v = e2_mulf(vb, va.c0);
+          else v = e2_make(gl_mul(va.c0, vb.c0));
+        }
+        break;
+      }
+    }
+    SLOT0(ins.dst) = v.c0;
+    SLOT1(ins.dst) = v.c1;
+  }
+#undef SLOT0
+#undef SLOT1
+  e2 qv = e2_mulf(acc, a.coset_tab[2 * D + t]);  // * 1/Z_H
+  if (a.acc_in) {
+    const size_t n_prev = (size_t)1 << a.log_n_prev;
+    const size_t rp = r & (n_prev - 1);
+    e2 old = e2{a.acc_in[((2 * t) << a.log_n_prev) + rp], a.acc_in[((2 * t + 1) << a.log_n_prev) + rp]};
+    qv = e2_add(e2_mul(old, a.beta), qv);
+  }
+  a.acc_out[((2 * t) << a.log_n) + r] = qv.c0;
+  a.acc_out[((2 * t + 1) << a.log_n) + r] = qv.c1;
+}
+
+// 1/(x - 1) and 1/(x - w_H^-1) for every point of the quotient coset (batch inversion: 4 points per
+// lane, one Fermat inversion per 8 denominators).
+__global__ __launch_bounds__(256) void k_selector_inverses(const u64* tw, const u64* coset_tab, int log_n, int log_d, u64 wh_inv,
+                                                           u64* inv_first, u64* inv_last) {
+  const size_t n = (size_t)1 << log_n, total = n << log_d;
+  const size_t base = (size_t)blockIdx.x * (4 * 256) + threadIdx.x;
+  u64 d[8], pre[8];
+  u64 run = 1;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    size_t q = base + (size_t)k * 256;
+    u64 x = 2;  // harmless filler for out-of-range lanes
+    if (q < total) x = coset_point(tw, log_n, coset_tab[q >> log_n], q & (n - 1));
+    d[2 * k] = gl_sub(x, 1);
+    d[2 * k + 1] = gl_sub(x, wh_inv);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    pre[k] = run;
+    run = gl_mul(run, d[k]);
+  }
+  u64 inv = gl_inv(run);
+#pragma unroll
+  for (int k = 7; k >= 0; k--) {
+    u64 v = gl_mul(inv, pre[k]);
+    inv = gl_mul(inv, d[k]);
+    size_t q = base + (size_t)(k >> 1) * 256;
+    if (q < total) {
+      if (k & 1) inv_last[q] = v;
+      else inv_first[q] = v;
+    }
+  }
+}
+
+// Evaluate AIR `air` (trace height 2^log_n, LDE matrices main/aux) on its quotient coset and fold the
+// result into the accumulator.  Requires the AIR's quotient degree to equal the batch degree
+// (`log_d`); see prover.cpp for the upsample path.
+void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& main, const LdeMatrix& aux, int log_blowup, int log_d,
+                              const std::vector<u64>& publics, const std::vector<e2>& randomness, const std::vector<e2>& aux_values,
+                              e2 alpha, const u64* acc_in, int log_n_prev, e2 beta, u64* acc_out) {
+  const int log_n = main.log_n;
+  const size_t n = (size_t)1 << log_n, D = (size_t)1 << log_d, B = (size_t)1 << log_blowup;
+  MH_REQUIRE(log_d <= log_blowup, "quotient degree exceeds blowup");
+  const int L = log_n + log_blowup;
+  const u64 g = gl_lde_shift(L), wK = gl_two_adic_generator(L);
+  // per-coset tables
+  std::vector<u64> tab(3 * D);
+  const u64 g_pow_n = gl_exp_pow2(g, log_n);
+  const u64 wd = gl_two_adic_generator(log_d);
+  u64 wt = 1;
+  for (size_t t = 0; t < D; t++) {
+    tab[t] = gl_mul(g, gl_pow(wK, t * (B / D)));
+    u64 zh = gl_sub(gl_mul(g_pow_n, wt), 1);
+    tab[D + t] = zh;
+    tab[2 * D + t] = gl_inv(zh);
+    wt = gl_mul(wt, wd);
+  }
+  // alpha powers: constraint k gets alpha^(K-1-k)
+  const size_t K = air->n_constraints;
+  std::vector<u64> apow(2 * std::max<size_t>(K, 1));
+  {
+    e2 p = e2_make(1);
+    for (size_t k = K; k-- > 0;) {
+      apow[2 * k] = p.c0;
+      apow[2 * k + 1] = p.c1;
+      p = e2_mul(p, alpha);
+    }
+  }
+  // periodic table on the quotient coset (prover/periodic.rs:49-77), O(P^2 D) on the host
+  const size_t Pm = air->max_period();
+  const size_t prow = Pm ? Pm * D : 1;
+  std::vector<u64> ptab(std::max<size_t>(1, air->periodic.size() * prow));
+  if (Pm) {
+    int logP = 0;
+    while (((size_t)1 << logP) < Pm) logP++;
+    MH_REQUIRE(logP <= log_n, "periodic column longer than the trace");
+    const u64 pshift = gl_exp_pow2(g, log_n - logP);
+    const u64 wP = gl_two_adic_generator(logP), wPD = gl_two_adic_generator(logP + log_d);
+    const u64 pinv = gl_inv((u64)Pm);
+    for (size_t col = 0; col < air->periodic.size(); col++) {
+      const auto& pc = air->periodic[col];
+      // coefficients of the interpolant over the order-Pm subgroup (column repeated to Pm)
+      std::vector<u64> coef(Pm);
+      for (size_t k = 0; k < Pm; k++) {
+        u64 s = 0, wk = gl_inv(gl_pow(wP, k)), x = 1;
+        for (size_t r = 0; r < Pm; r++) {
+          s = gl_add(s, gl_mul(pc[r % pc.size()] % GL_P, x));
+          x = gl_mul(x, wk);
+        }
+        coef[k] = gl_mul(s, pinv);
+      }
+      u64 y = pshift;
+      for (size_t m = 0; m < prow; m++) {
+        u64 v = 0;
+        for (size_t k = Pm; k-- > 0;) v = gl_add(gl_mul(v, y), coef[k]);
+        ptab[col * prow + m] = v;
+        y = gl_mul(y, wPD);
+      }
+    }
+  }
+  std::vector<u64> pub(std::max<size_t>(1, publics.size())), rnd(2 * std::max<size_t>(1, randomness.size())),
+      av(2 * std::max<size_t>(1, aux_values.size()));
+  for (size_t i = 0; i < publics.size(); i++) pub[i] = gl_canon(publics[i]);
+  for (size_t i = 0; i < randomness.size(); i++) { rnd[2 * i] = randomness[i].c0; rnd[2 * i + 1] = randomness[i].c1; }
+  for (size_t i = 0; i < aux_values.size(); i++) { av[2 * i] = aux_values[i].c0; av[2 * i + 1] = aux_values[i].c1; }
+  // one upload for all the small tables
+  std::vector<u64> blob;
+  auto put = [&](const std::vector<u64>& v) {
+    size_t off = blob.size();
+    blob.insert(blob.end(), v.begin(), v.end());
+    return off;
+  };
+  const size_t o_tab = put(tab), o_ap = put(apow), o_pt = put(ptab), o_pub = put(pub), o_rnd = put(rnd), o_av = put(av);
+  DevBuf dblob(blob.size() * 8);
+  HIP_CHECK(hipMemcpyAsync(dblob.p, blob.data(), blob.size() * 8, hipMemcpyHostToDevice, c->stream));
+  const u64* tw = log_n ? c->twiddles(log_n, false) : nullptr;
+  DevBuf one;
+  if (!tw) {  // n = 1: a one-entry table holding w^0
+    one.alloc(8);
+    u64 v = 1;
+    HIP_CHECK(hipMemcpyAsync(one.p, &v, 8, hipMemcpyHostToDevice, c->stream));
+    tw = one.u();
+  }
+  const u64 wh_inv = gl_inv(gl_two_adic_generator(log_n));
+  DevBuf inv_first, inv_last;
+  if (air->uses_first_last) {
+    inv_first.alloc(n * D * 8);
+    inv_last.alloc(n * D * 8);
+    ProfScope ps(c, "quotient_selectors", 16.0 * n * D);
+    hipLaunchKernelGGL(k_selector_inverses, dim3((unsigned)((n * D + 1023) / 1024)), dim3(256), 0, c->stream, tw, dblob.u() + o_tab,
+                       log_n, log_d, wh_inv, inv_first.u(), inv_last.u());
+  }
+  QuotArgs a{};
+  a.code = (const AirIns*)air->d_code.p;
+  a.n_ins = (u32)air->code.size();
+  a.n_slots = air->n_slots;
+  a.main_lde = main.lde.u();
+  a.aux_lde = aux.lde.u();
+  a.log_n = log_n; a.log_blowup = log_blowup; a.log_d = log_d;
+  a.tw = tw;
+  a.coset_tab = dblob.u() + o_tab;
+  a.wh_inv = wh_inv;
+  a.inv_first = inv_first.u(); a.inv_last = inv_last.u();
+  a.periodic = dblob.u() + o_pt;
+  a.periodic_rows = (u32)prow;
+  a.publics = dblob.u() + o_pub; a.randomness = dblob.u() + o_rnd; a.aux_values = dblob.u() + o_av;
+  a.alpha_pows = dblob.u() + o_ap;
+  a.acc_in = acc_in; a.log_n_prev = log_n_prev; a.beta = beta; a.acc_out = acc_out;
+  // slot file: 16 B per slot per lane in LDS
+  unsigned T = 256;
+  while (T > 64 && (size_t)air->n_slots * 16 * T > 48 * 1024) T >>= 1;
+  const size_t lds = (size_t)air->n_slots * 16 * T;
+  MH_REQUIRE(lds <= 160 * 1024, "constraint DAG needs more live values than fit in LDS (160 KiB per workgroup)");
+  if (lds > 64 * 1024)
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_eval_quotient, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  {
+    // algorithmic bytes: every main/aux column the program touches is read once, 16 B written
+    ProfScope ps(c, "quotient_eval", (double)n * D * (8.0 * (air->main_width + 2 * air->aux_width) + 16.0));
+    hipLaunchKernelGGL(k_eval_quotient, dim3((unsigned)((n * D + T - 1) / T)), dim3(T), lds, c->stream, a);
+  }
+  HIP_CHECK(hipStreamSynchronize(c->stream));  // tables die with this scope
+}

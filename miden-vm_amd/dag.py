@@ -1,5 +1,5 @@
 """Constraint-DAG exporter: the symbolic `AirBuilder` that turns an AIR's `eval` into the flat
-"MHDAG001" blob libmidenhip (and the CPU oracle) evaluate per point.
+"MHDAG001" blob libmidenhip evaluates per point.
 
 Reference analogue: running `air.eval(&mut SymbolicAirBuilder)` and lowering to an
 Add/Sub/Mul/Neg/Const/Input DAG, crates/ace-codegen/src/pipeline.rs:71-123, dag/ir.rs:45-59.  The
