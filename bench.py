@@ -101,6 +101,61 @@ class CommitRunner:
         return cpu_baseline_commit(self.args.cpu_log_n, list(self.WIDTHS), self.LOG_BLOWUP)
 
 
+class ProveRunner:
+    """The whole proof (`prove`, crates/lifted-stark/src/prover/mod.rs:230-578) of the miden-bench
+    synthetic instance `miden:LOG_N:51:8` (benches/miden-bench/src/main.rs, DummyMidenAir 51 columns +
+    8 EF aux columns) with the production PCS parameters (air/src/config.rs:54-67: blowup 8, FRI arity 4,
+    final degree 2^7, 27 queries, PoW 4/12/16) and Poseidon2 LMCS + challenger."""
+
+    def __init__(self, pkg, ctx, args, rank, world):
+        import numpy as np
+        import oracle_binding as ob  # only for the shared constants / pre-observe framing (no oracle compute)
+        from miden_vm_amd import dag
+        self.pkg, self.ctx, self.args, self.rank, self.world = pkg, ctx, args, rank, world
+        self.log_n = args.log_n
+        self.air = dag.dummy_miden_air(51, 8)
+        self.dair = pkg.DeviceAir(ctx, self.air)
+        rng = np.random.default_rng(1 + rank)
+        self.trace = ctx.upload_trace(synth_trace(rng, self.log_n, 51))
+        self.params = dict(ob.PROD_PARAMS)
+        self.state = ob.challenger_state()
+        self.pre = ob.protocol_pre_observe(self.params, [])
+        self.proof = None
+
+    def step(self):
+        self.proof = self.pkg.prove(self.ctx, [self.dair], [self.trace], [], self.params, self.state, self.pre, None)
+
+    def rows_per_step(self):
+        return (1 << self.log_n) * self.world
+
+    def scaling(self):
+        return "weak"
+
+    def config(self):
+        return {"workload": f"full proof of miden:{self.log_n}:51:8 (DummyMidenAir 2^{self.log_n} x 51 + 8 EF aux), 96-bit "
+                            "production PCS params (blowup 8, FRI arity 4, 27 queries, PoW 4/12/16), Poseidon2 LMCS; "
+                            "trace resident in HBM, transcript on host",
+                "log_trace_rows": self.log_n, "main_width": 51, "aux_width_ef": 8, "log_blowup": 3,
+                "proof_bytes": len(self.proof.bytes) if self.proof else None,
+                "parallelism": "1 GPU" if self.world == 1 else f"{self.world} independent proofs (one trace per GPU)"}
+
+    roofline = CommitRunner.roofline
+
+    def cpu_baseline(self):
+        import numpy as np
+        import oracle_binding as ob
+        log_s = self.args.cpu_log_n
+        t = synth_trace(np.random.default_rng(1), log_s, 51)
+        ob.lib()
+        t0 = time.perf_counter()
+        ob.prove([self.air], [t], [], self.params)
+        dt = time.perf_counter() - t0
+        cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+        return {"value": (1 << log_s) / dt, "unit": "trace rows/s", "cores": cores, "kind": "port",
+                "sample": f"CPU restatement (oracle/, OpenMP {cores} threads) proving miden:{log_s}:51:8 with the same "
+                          f"parameters in {dt:.2f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,7 +164,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--workload", default="auto", choices=["auto", "commit", "prove"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log-n", type=int, default=15)
+    ap.add_argument("--cpu-log-n", type=int, default=14)
     args = ap.parse_args()
 
     import numpy as np
@@ -130,7 +185,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ctx = pkg.Ctx(local_rank)
-    runner = CommitRunner(pkg, ctx, args, rank, world)
+    workload = "prove" if args.workload in ("auto", "prove") else "commit"
+    runner = (ProveRunner if workload == "prove" else CommitRunner)(pkg, ctx, args, rank, world)
 
     def barrier():
         if world > 1:
