@@ -13,7 +13,7 @@
 // s_inv for row i0 is w_n^(-i0) (fri/prover.rs:117-142: the coset shift is deliberately ignored).
 #include "gl.cuh"
 #include "kernels.hpp"
-#include "poseidon2.cuh"
+#include "poseidon2_fast.cuh"
 
 __device__ __forceinline__ e2 ld_e2(const u64* p, size_t idx) {
   const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(p + 2 * idx);
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_fri_leaf_hash(const u64* __restrict__ e
       st[2 * k] = (p0 + k < arity) ? v.c0 : 0;
       st[2 * k + 1] = (p0 + k < arity) ? v.c1 : 0;
     }
-    p2_permute(st);
+    p2f_permute(st);
   }
   ulonglong2* o = reinterpret_cast<ulonglong2*>(digests + 4 * s);
   o[0] = make_ulonglong2(st[0], st[1]);
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_grind(GrindArgs a) {
     s[i] = (i < k) ? v : 0;
   }
   s[8] = gl_add(s[8], (u64)k);
-  p2_permute(s);
+  p2f_permute(s);
   const u64 x = s[7];  // first sample after a duplexing = rate[7]
   if (((x & 0xFFFFFFFFULL) & (((u64)1 << a.bits) - 1)) == 0) atomicMin(a.best, (unsigned long long)w);
 }

@@ -18,7 +18,7 @@
 // One sponge per lane, state in VGPRs; Poseidon2 is integer-ALU bound.
 #include "ctx.hpp"
 #include "kernels.hpp"
-#include "poseidon2.cuh"
+#include "poseidon2_fast.cuh"
 #include "gl.cuh"
 #include <algorithm>
 
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_permute_soa(u64* st, size_t n) {
   u64 s[12];
 #pragma unroll
   for (int j = 0; j < 12; j++) s[j] = st[j * n + i];
-  p2_permute(s);
+  p2f_permute(s);
 #pragma unroll
   for (int j = 0; j < 12; j++) st[j * n + i] = s[j];
 }
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_absorb(LeafArgs a) {
     for (u32 c0 = 0; c0 < w; c0 += 8) {
 #pragma unroll
       for (int k = 0; k < 8; k++) s[k] = (c0 + k < w) ? base[(size_t)(c0 + k) * col_stride] : 0;
-      p2_permute(s);
+      p2f_permute(s);
     }
   }
   if (a.digest_out) {
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_compress(const u64* __restrict__ in, u6
   const ulonglong2* pr = reinterpret_cast<const ulonglong2*>(in + 4 * rgt);
   ulonglong2 l0 = pl[0], l1 = pl[1], r0 = pr[0], r1 = pr[1];
   u64 s[12] = {l0.x, l0.y, l1.x, l1.y, r0.x, r0.y, r1.x, r1.y, 0, 0, 0, 0};
-  p2_permute(s);
+  p2f_permute(s);
   ulonglong2* o = reinterpret_cast<ulonglong2*>(out + 4 * q);
   o[0] = make_ulonglong2(s[0], s[1]);
   o[1] = make_ulonglong2(s[2], s[3]);
