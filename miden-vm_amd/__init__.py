@@ -11,6 +11,7 @@ There is NO CPU fallback: if libmidenhip.so or a GPU is missing, construction ra
 """
 import ctypes as C
 import os
+import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -87,6 +88,7 @@ class Ctx:
         if rc != 0:
             raise MidenHipError(f"mh_ctx_create failed with code {rc}")
         self.h = h
+        self._children = weakref.WeakSet()  # device objects that must be freed before the ctx
 
     def check(self, rc):
         if rc != 0:
@@ -94,6 +96,8 @@ class Ctx:
 
     def close(self):
         if getattr(self, "h", None):
+            for child in list(self._children):
+                child.free()
             self.lib.mh_ctx_destroy(self.h)
             self.h = None
 
@@ -153,6 +157,7 @@ class Trace:
         h = C.c_void_p()
         ctx.check(ctx.lib.mh_trace_upload(ctx.h, _ptr(m), self.log_n, C.c_size_t(w), C.byref(h)))
         self.h = h
+        ctx._children.add(self)
 
     def free(self):
         if getattr(self, "h", None):
@@ -169,6 +174,7 @@ class Trace:
 class LmcsTree:
     def __init__(self, ctx, h, widths, log_heights, log_blowup):
         self.ctx, self.h = ctx, h
+        ctx._children.add(self)
         self.widths, self.log_heights, self.log_blowup = widths, log_heights, log_blowup
         self.log_height = ctx.lib.mh_tree_log_height(h)
 
@@ -262,6 +268,7 @@ class DeviceAir:
         h = C.c_void_p()
         ctx.check(ctx.lib.mh_air_load(ctx.h, _ptr(blob), C.c_size_t(blob.size), C.byref(h)))
         self.h = h
+        ctx._children.add(self)
 
     def free(self):
         if getattr(self, "h", None):

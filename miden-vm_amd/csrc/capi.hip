@@ -6,7 +6,7 @@
 #include <algorithm>
 #include <cstring>
 
-#define MH_TRY(ctx_expr) mh_ctx* _c = (ctx_expr); try {
+#define MH_TRY(ctx_expr) mh_ctx* _c = (ctx_expr); PoolScope _ps(_c); try {
 #define MH_CATCH                                                   \
   }                                                                \
   catch (const MhError& e) {                                       \
@@ -64,7 +64,11 @@ void mh_ctx_destroy(mh_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
-  c->tw_fwd.clear(); c->tw_inv.clear(); c->tables.clear();
+  {
+    PoolScope ps(c);
+    c->tw_fwd.clear(); c->tw_inv.clear(); c->tables.clear();
+  }
+  c->pool.trim();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -141,6 +145,7 @@ int mh_trace_upload(mh_ctx* c, const uint64_t* rowmajor, int log_n, size_t width
 void mh_trace_free(mh_trace* t) {
   if (!t) return;
   (void)hipSetDevice(t->ctx->device);
+  PoolScope ps(t->ctx);
   delete t;
 }
 
@@ -162,6 +167,7 @@ int mh_commit_traces(mh_ctx* c, int n_traces, mh_trace* const* traces, int log_b
 void mh_tree_free(mh_tree* t) {
   if (!t) return;
   (void)hipSetDevice(t->ctx->device);
+  PoolScope ps(t->ctx);
   delete t;
 }
 int mh_tree_root(const mh_tree* t, uint64_t root[4]) {

@@ -1,6 +1,8 @@
 // Context plumbing: stream, profiler (HIP events on the private stream), sync.
 #include "ctx.hpp"
 
+thread_local DevPool* g_dev_pool = nullptr;
+
 hipEvent_t mh_ctx::get_event() {
   if (!event_pool.empty()) {
     hipEvent_t e = event_pool.back();

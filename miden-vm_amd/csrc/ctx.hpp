@@ -37,19 +37,48 @@ struct MhError : std::runtime_error {
     if (!(cond)) throw MhError(MH_ERR_INVALID, std::string(msg));    \
   } while (0)
 
+// Per-context cache of device allocations.  A proof allocates the same few dozen buffer sizes every
+// time; hipMalloc/hipFree cost milliseconds (hipFree also synchronises the device), so freed
+// buffers are kept by size and handed back to the next request.  All work of a ctx is ordered on
+// its one stream, so reuse is stream-ordered and safe.  mh_ctx_destroy / mh_ctx_trim release it.
+struct DevPool {
+  std::multimap<size_t, void*> free_list;
+  size_t cached_bytes = 0;
+  void* take(size_t n) {
+    auto it = free_list.find(n);
+    if (it == free_list.end()) return nullptr;
+    void* p = it->second;
+    free_list.erase(it);
+    cached_bytes -= n;
+    return p;
+  }
+  void give(void* p, size_t n) {
+    free_list.emplace(n, p);
+    cached_bytes += n;
+  }
+  void trim() {
+    for (auto& kv : free_list) (void)hipFree(kv.second);
+    free_list.clear();
+    cached_bytes = 0;
+  }
+};
+// The pool of the ctx whose API call is running on this thread (set by the C-ABI entry points).
+extern thread_local DevPool* g_dev_pool;
+
 // RAII device allocation.
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  DevPool* pool = nullptr;
   DevBuf() {}
   explicit DevBuf(size_t n) { alloc(n); }
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), pool(o.pool) { o.p = nullptr; o.bytes = 0; }
   DevBuf& operator=(DevBuf&& o) noexcept {
     if (this != &o) {
       release();
-      p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0;
+      p = o.p; bytes = o.bytes; pool = o.pool; o.p = nullptr; o.bytes = 0;
     }
     return *this;
   }
@@ -57,11 +86,28 @@ struct DevBuf {
   void alloc(size_t n) {
     release();
     if (n == 0) return;
-    HIP_CHECK(hipMalloc(&p, n));
+    pool = g_dev_pool;
+    if (pool && (p = pool->take(n))) {
+      bytes = n;
+      return;
+    }
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipErrorOutOfMemory && pool && pool->cached_bytes) {  // give cached buffers back and retry
+      (void)hipGetLastError();
+      pool->trim();
+      e = hipMalloc(&p, n);
+    }
+    if (e != hipSuccess) {
+      p = nullptr;
+      HIP_CHECK(e);
+    }
     bytes = n;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) {
+      if (pool) pool->give(p, bytes);
+      else (void)hipFree(p);
+    }
     p = nullptr; bytes = 0;
   }
   u64* u() const { return (u64*)p; }
@@ -75,6 +121,7 @@ struct ProfEntry {
 
 struct mh_ctx {
   int device = 0;
+  DevPool pool;
   hipStream_t stream = nullptr;
   std::string err;
   // profiler
@@ -94,6 +141,15 @@ struct mh_ctx {
   void prof_resolve();
   void sync();
   const u64* twiddles(int log_n, bool inverse);
+};
+
+// RAII: make `c`'s allocation pool current for the duration of one C-ABI call.
+struct PoolScope {
+  DevPool* prev;
+  explicit PoolScope(mh_ctx* c) : prev(g_dev_pool) {
+    if (c) g_dev_pool = &c->pool;
+  }
+  ~PoolScope() { g_dev_pool = prev; }
 };
 
 // RAII helper: time everything launched on ctx->stream within the scope under `name`.

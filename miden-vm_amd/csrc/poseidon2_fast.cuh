@@ -2,7 +2,7 @@
 //
 // Same function as p2_permute (poseidon2.cuh; reference:
 // crates/crypto/src/hash/algebraic_sponge/poseidon2/mod.rs:22-37, schedule core/src/chiplets/
-// hasher.rs:89-115) -- parity is checked bit-for-bit against the oracle.  What differs is the
+// hasher.rs:89-115) -- parity is checked bit-for-bit by the GPU tests.  What differs is the
 // arithmetic schedule.  Measured on MI355X (tools/instbench): every VALU instruction, including
 // v_mad_u64_u32 (32x32+64) and the 64-bit v_lshl_add_u64, costs about the same issue slot, and a
 // canonical modular add costs ~6 of them.  So:

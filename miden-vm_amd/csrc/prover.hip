@@ -369,7 +369,7 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
 }
 
 // -------------------------------------------------------------------------------------------------
-#define MH_TRY(ctx_expr) mh_ctx* _c = (ctx_expr); try {
+#define MH_TRY(ctx_expr) mh_ctx* _c = (ctx_expr); PoolScope _ps(_c); try {
 #define MH_CATCH                                                   \
   }                                                                \
   catch (const MhError& e) {                                       \
@@ -394,6 +394,7 @@ int mh_air_load(mh_ctx* c, const uint64_t* blob, size_t n_words, mh_air** out) {
 void mh_air_free(mh_air* a) {
   if (!a) return;
   (void)hipSetDevice(a->ctx->device);
+  PoolScope ps(a->ctx);
   delete a;
 }
 int mh_air_log_quotient_degree(const mh_air* a) { return a ? a->log_quotient_degree : -1; }
