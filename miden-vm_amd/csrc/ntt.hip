@@ -127,30 +127,66 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
   }
   __syncthreads();
 
-  const u32 half = tile_n >> 1;
-  for (int i = 0; i < a.r_bits; i++) {
-    const int st = a.dif ? (a.r_bits - 1 - i) : i;  // local stage
-    const int b = st + a.cb;                        // local bit
-    const int s = a.s_lo + st;                      // global stage (span 2^s)
-    const int tw_shift = a.log_n - s - 1;
-    for (u32 q = threadIdx.x; q < half; q += NTT_THREADS) {
-      u32 low = q & ((1u << b) - 1);
-      u32 l0 = ((q >> b) << (b + 1)) | low;
-      u32 l1 = l0 | (1u << b);
-      // global index of l0 modulo 2^s
-      size_t gm = (((size_t)((l0 >> a.cb) & ((1u << st) - 1))) << a.s_lo) | (lo0 << a.cb) | (l0 & cb_mask);
-      u64 w = a.tw[gm << tw_shift];
-      u64 x = lds[l0], y = lds[l1];
+  // Butterflies: two stages at a time on 4 LDS elements held in registers (one radix-4 step =
+  // 4 twiddle multiplications, like two radix-2 stages, but half the LDS traffic, half the barriers
+  // and one index computation per 4 butterflies); a lone radix-2 stage when r_bits is odd.
+  // Global index of local l modulo 2^s:  gm(l, st) = ((l >> cb) mod 2^st) << s_lo | lo0 << cb | l mod 2^cb.
+  auto single_stage = [&](int st) {
+    const int b = st + a.cb, s = a.s_lo + st, tw_shift = a.log_n - s - 1;
+    for (u32 q = threadIdx.x; q < (tile_n >> 1); q += NTT_THREADS) {
+      const u32 low = q & ((1u << b) - 1);
+      const u32 l0 = ((q >> b) << (b + 1)) | low, l1 = l0 | (1u << b);
+      const size_t gm = (((size_t)((l0 >> a.cb) & ((1u << st) - 1))) << a.s_lo) | (lo0 << a.cb) | (l0 & cb_mask);
+      const u64 w = a.tw[gm << tw_shift];
+      const u64 x = lds[l0], y = lds[l1];
       if (a.dif) {
         lds[l0] = gl_add(x, y);
         lds[l1] = gl_mul(gl_sub(x, y), w);
       } else {
-        u64 wy = gl_mul(y, w);
+        const u64 wy = gl_mul(y, w);
         lds[l0] = gl_add(x, wy);
         lds[l1] = gl_sub(x, wy);
       }
     }
     __syncthreads();
+  };
+  auto double_stage = [&](int st) {  // local stages st (low) and st + 1 (high)
+    const int b = st + a.cb, s = a.s_lo + st;
+    const int sh_hi = a.log_n - s - 2;  // table shift of the higher stage (twiddle order 2^(s+2))
+    const size_t quarter = (size_t)1 << (a.log_n - 2);
+    for (u32 q = threadIdx.x; q < (tile_n >> 2); q += NTT_THREADS) {
+      const u32 low = q & ((1u << b) - 1);
+      const u32 l00 = ((q >> b) << (b + 2)) | low;
+      const u32 l01 = l00 | (1u << b), l10 = l00 | (2u << b), l11 = l00 | (3u << b);
+      const size_t k = (((size_t)((l00 >> a.cb) & ((1u << st) - 1))) << a.s_lo) | (lo0 << a.cb) | (l00 & cb_mask);
+      // higher stage: w_{2^(s+2)}^k for (l00,l10), times w_4 for (l01,l11); lower stage: its square
+      const u64 wh0 = a.tw[k << sh_hi], wh1 = a.tw[(k << sh_hi) + quarter];
+      const u64 wl = a.tw[k << (sh_hi + 1)];
+      u64 x0 = lds[l00], x1 = lds[l01], x2 = lds[l10], x3 = lds[l11];
+      if (a.dif) {  // high stage first, then low
+        u64 t0 = gl_add(x0, x2), t2 = gl_mul(gl_sub(x0, x2), wh0);
+        u64 t1 = gl_add(x1, x3), t3 = gl_mul(gl_sub(x1, x3), wh1);
+        x0 = gl_add(t0, t1); x1 = gl_mul(gl_sub(t0, t1), wl);
+        x2 = gl_add(t2, t3); x3 = gl_mul(gl_sub(t2, t3), wl);
+      } else {  // low stage first, then high
+        u64 m1 = gl_mul(x1, wl), m3 = gl_mul(x3, wl);
+        u64 t0 = gl_add(x0, m1), t1 = gl_sub(x0, m1), t2 = gl_add(x2, m3), t3 = gl_sub(x2, m3);
+        u64 n2 = gl_mul(t2, wh0), n3 = gl_mul(t3, wh1);
+        x0 = gl_add(t0, n2); x2 = gl_sub(t0, n2);
+        x1 = gl_add(t1, n3); x3 = gl_sub(t1, n3);
+      }
+      lds[l00] = x0; lds[l01] = x1; lds[l10] = x2; lds[l11] = x3;
+    }
+    __syncthreads();
+  };
+  if (a.dif) {
+    int st = a.r_bits - 1;
+    if (a.r_bits & 1) single_stage(st--);
+    for (; st >= 1; st -= 2) double_stage(st - 1);
+  } else {
+    int st = 0;
+    for (; st + 1 < a.r_bits; st += 2) double_stage(st);
+    if (st < a.r_bits) single_stage(st);
   }
 
   for (u32 l = threadIdx.x; l < tile_n; l += NTT_THREADS) {

@@ -135,9 +135,6 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
   int logD = 0;
   for (int i = 0; i < n_airs; i++) logD = std::max(logD, airs_in[i]->log_quotient_degree);
   MH_REQUIRE(logD <= lb, "constraint degree too high for the blowup");
-  for (int i = 0; i < n_airs; i++)
-    MH_REQUIRE(airs_in[i]->log_quotient_degree == logD,
-               "AIRs with different quotient degrees in one proof are not supported by this backend yet");
   const size_t D = (size_t)1 << logD;
   std::vector<u64> publics(publics_in, publics_in + n_publics);
 
@@ -195,8 +192,16 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
     const int ln = lhs[order[j]];
     DevBuf out(((size_t)2 * D << ln) * 8);
     std::vector<e2> rnd(randomness.begin(), randomness.begin() + a->num_randomness);
-    quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], lb, logD, publics, rnd, aux_vals[order[j]], alpha,
-                             j ? acc.u() : nullptr, log_n_prev, beta, out.u());
+    const int logDj = a->log_quotient_degree;
+    if (logDj == logD) {
+      quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], lb, logD, publics, rnd, aux_vals[order[j]], alpha,
+                               j ? acc.u() : nullptr, log_n_prev, beta, out.u());
+    } else {  // native coset of n*Dj points, then upsample to n*D (prover/mod.rs:520-528)
+      DevBuf small(((size_t)2 << (logDj + ln)) * 8);
+      quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], lb, logDj, publics, rnd, aux_vals[order[j]], alpha, nullptr,
+                               0, beta, small.u());
+      quotient_upsample_accumulate(c, small.u(), ln, lb, logDj, logD, j ? acc.u() : nullptr, log_n_prev, beta, out.u());
+    }
     acc = std::move(out);
     log_n_prev = ln;
   }

@@ -286,3 +286,58 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
   }
   HIP_CHECK(hipStreamSynchronize(c->stream));  // tables die with this scope
 }
+
+// ---- per-AIR quotient degree below the batch degree (prover/mod.rs:520-528, quotient.rs:45-58) ------
+// Q_j is known on the n*Dj-point coset g_j*J_j (cosets t' = 0..Dj-1 in `q_small`, planes [2Dj][n]);
+// the batch needs it on the n*D-point coset (same shift, denser subgroup).  Same polynomial, so:
+// natural-order column -> LDE by (log D - log Dj) bits -> regroup into the D cosets, fused with the
+// beta accumulation.
+__global__ void k_quot_to_natural(const u64* __restrict__ q_small, u64* __restrict__ nat, int log_n, int log_dj) {
+  const size_t n = (size_t)1 << log_n, Dj = (size_t)1 << log_dj;
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n * Dj) return;
+  const size_t r = i >> log_dj, tp = i & (Dj - 1);
+  nat[i] = q_small[((2 * tp) << log_n) + r];
+  nat[n * Dj + i] = q_small[((2 * tp + 1) << log_n) + r];
+}
+__global__ void k_quot_regroup_accumulate(const u64* __restrict__ lde, int log_n, int log_dj, int log_d, const u64* __restrict__ acc_in,
+                                          int log_n_prev, e2 beta, u64* __restrict__ acc_out) {
+  const size_t n = (size_t)1 << log_n;
+  const int ab = log_d - log_dj;
+  const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (q >= (n << log_d)) return;
+  const size_t t = q >> log_n, r = q & (n - 1);
+  const size_t tp = t >> ab, u = t & (((size_t)1 << ab) - 1);
+  const size_t nd = n << log_dj;                       // column length of the small coset
+  const size_t src = (u * nd) + (r << log_dj) + tp;    // column e at offset e * 2^ab * nd
+  e2 v = e2{lde[src], lde[((size_t)1 << ab) * nd + src]};
+  if (acc_in) {
+    const size_t n_prev = (size_t)1 << log_n_prev, rp = r & (n_prev - 1);
+    e2 old = e2{acc_in[((2 * t) << log_n_prev) + rp], acc_in[((2 * t + 1) << log_n_prev) + rp]};
+    v = e2_add(e2_mul(old, beta), v);
+  }
+  acc_out[((2 * t) << log_n) + r] = v.c0;
+  acc_out[((2 * t + 1) << log_n) + r] = v.c1;
+}
+
+void quotient_upsample_accumulate(mh_ctx* c, const u64* q_small, int log_n, int log_blowup, int log_dj, int log_d, const u64* acc_in,
+                                  int log_n_prev, e2 beta, u64* acc_out) {
+  const size_t n = (size_t)1 << log_n, nd = n << log_dj;
+  const int ab = log_d - log_dj;
+  MH_REQUIRE(ab > 0, "internal: nothing to upsample");
+  DevBuf nat(2 * nd * 8), scratch(2 * nd * 8), lde((2 * nd << ab) * 8);
+  hipLaunchKernelGGL(k_quot_to_natural, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, c->stream, q_small, nat.u(), log_n, log_dj);
+  // evaluations on g_j * <w_{n Dj}>  ->  on g_j * w_{n D}^u * <w_{n Dj}>, u < 2^ab
+  const u64 gj = gl_lde_shift(log_n + log_blowup), w = gl_two_adic_generator(log_n + log_d);
+  std::vector<u64> outs((size_t)1 << ab);
+  u64 x = gj;
+  for (auto& v : outs) {
+    v = x;
+    x = gl_mul(x, w);
+  }
+  lde_columns(c, nat.u(), 2, log_n + log_dj, gj, outs, lde.u(), scratch.u());
+  const size_t total = n << log_d;
+  hipLaunchKernelGGL(k_quot_regroup_accumulate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, lde.u(), log_n, log_dj,
+                     log_d, acc_in, log_n_prev, beta, acc_out);
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+}

@@ -83,6 +83,15 @@ def test_multi_air_mixed_heights(ctx):
     check_same(ctx, airs_[::-1], [A.periodic_trace(9), t1], pub, FAST)
 
 
+def test_mixed_quotient_degrees(ctx):
+    # per-AIR degree optimisation: D_j in {2, 2, 8}, quotient evaluated natively then upsampled
+    tf, pub = A.fib_trace(7)
+    airs_ = [A.periodic_air(3), A.fib_air(), dag.dummy_miden_air(11, 2, num_public=3)]
+    traces = [A.periodic_trace(5), tf, A.dummy_trace(6, 11)]
+    check_same(ctx, airs_, traces, pub, FAST)
+    check_same(ctx, airs_[::-1], traces[::-1], pub, FAST)
+
+
 def test_arity2_blowup2(ctx):
     t, pub = A.fib_trace(6)
     check_same(ctx, [A.fib_air()], [t], pub, dict(FAST, log_folding_arity=1, log_blowup=2, log_final_degree=1))
