@@ -156,6 +156,43 @@ class ProveRunner:
                           f"parameters in {dt:.2f} s"}
 
 
+def sharded_commit_probe(pkg, ctx, args, rank, world, dist):
+    """Strong scaling of commit_traces(main 2^log_n x 51) + commit_traces(aux x 16) sharded by cosets
+    (miden-vm_amd/sharding.py).  Same trace on every rank (same seed)."""
+    import numpy as np
+    import torch
+    from miden_vm_amd import sharding
+    rng = np.random.default_rng(7)
+    traces = [ctx.upload_trace(synth_trace(rng, args.log_n, w)) for w in (51, 16)]
+    roots = None
+
+    def once():
+        r = []
+        for t in traces:
+            sc = sharding.ShardedCommit(ctx, [t], 3, rank, world)
+            r.append(sc.root())
+            sc.free()
+        return r
+
+    once()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        roots = once()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    for t in traces:
+        t.free()
+    return {"workload": f"coset-sharded commit of 2^{args.log_n} x (51 + 16) over {world} GPUs (one trace, strong scaling)",
+            "ms": float(tt.item()) * 1e3, "rows_per_s": (1 << args.log_n) / float(tt.item()),
+            "root0": [int(x) for x in roots[0]]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,6 +272,13 @@ def main():
         out["cpu_baseline"] = runner.cpu_baseline()
     elif rank == 0:
         out["cpu_baseline"] = None
+    if world > 1:
+        # Extra (not part of `value`): the coset-sharded commitment of ONE 2^log_n x (51 + 16) trace pair
+        # across all ranks -- the path with a real exchange step (digest all-to-all over RCCL).
+        try:
+            out["sharded_commit"] = sharded_commit_probe(pkg, ctx, args, rank, world, dist)
+        except Exception as e:  # never lose the main line to the probe
+            out["sharded_commit"] = {"error": repr(e)[:300]}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -89,6 +89,26 @@ int mh_tree_download_lde(mh_ctx* ctx, const mh_tree* t, int mat, uint64_t* out_r
 /* Parity/debug: download all digest layers, leaf layer (domain order) first: (2H-1)*4 felts. */
 int mh_tree_download_layers(mh_ctx* ctx, const mh_tree* t, uint64_t* out);
 
+/* ---- coset-sharded commitment across the GPUs of a node (one process + one ctx per GPU) -------- */
+/* The LDE is stored coset-major, so rank k of `world` (a power of two <= 2^log_blowup) owns cosets
+ * [k*B/world, (k+1)*B/world) of every column: it runs the (replicated) inverse NTT, the forward NTT
+ * of ITS cosets only and the leaf sponges of its leaves.  The Merkle tree is indexed in domain order
+ * (crates/lifted-stark/src/lmcs/lifted_tree.rs:247-258), i.e. by rows first, so one all-to-all of
+ * leaf digests follows (done by the host layer with RCCL / torch.distributed, see
+ * miden-vm_amd/sharding.py): rank d receives rows [d*N/world, (d+1)*N/world) of every coset, laid
+ * out [B][N/world] digests, builds that subtree, and the `world` subroots (all-gathered, 32 B each)
+ * are combined on the host.  The result equals mh_commit_traces' root on one GPU. */
+typedef struct mh_shard mh_shard;
+int mh_shard_commit_leaves(mh_ctx* ctx, int n_traces, mh_trace* const* traces, int log_blowup, int rank, int world,
+                           mh_shard** out);
+void mh_shard_free(mh_shard* s);
+/* DEVICE pointer to this rank's leaf digests, [cosets_local][N] x 4 felts (coset-major). */
+uint64_t* mh_shard_leaf_digests(mh_shard* s, size_t* n_digests);
+/* digests_device: DEVICE pointer to the exchanged digests [B][N/world] x 4 felts. */
+int mh_shard_build_subtree(mh_ctx* ctx, mh_shard* s, const uint64_t* digests_device, uint64_t subroot[4]);
+/* Host only (no GPU needed): Merkle root over `world` subroots given in rank order. */
+int mh_merkle_cap_root(const uint64_t* subroots, int world, uint64_t root[4]);
+
 /* ---- AIRs as data: the constraint DAG blob "MHDAG001" ------------------------------------------ */
 /* The Rust side captures `air.eval` once on a symbolic builder (the route of
  * crates/ace-codegen/src/pipeline.rs:71-123) and ships a flat u64 blob:

@@ -55,6 +55,7 @@ void poseidon2_permute_device(mh_ctx* c, u64* states_soa, size_t n);  // [12][n]
 // Build leaf digests + all layers for `t->mats` (already filled); sets t->root.
 void lmcs_build_tree(mh_ctx* c, mh_tree* t);
 // Pieces of the above for trees whose leaf digests come from another kernel (FRI rounds):
+void lmcs_hash_leaves(mh_ctx* c, const std::vector<LdeMatrix>& mats, int lb, u64* digests);
 void lmcs_alloc_layers(mh_tree* t, int log_height);  // sets log_height, layer_off, nodes
 u64* lmcs_leaf_layer(mh_tree* t);                     // device pointer of the leaf digest layer
 void lmcs_compress_layers(mh_ctx* c, mh_tree* t);     // leaf layer -> root (copies root to host)
@@ -68,6 +69,8 @@ std::vector<u64> coset_shifts(int log_n, int lb);  // g*w_K^j, j < 2^lb, for the
 mh_trace* trace_upload(mh_ctx* c, const u64* rowmajor, int log_n, size_t width);
 mh_trace* trace_zeros(mh_ctx* c, int log_n, size_t width);
 mh_tree* commit_traces(mh_ctx* c, const std::vector<const mh_trace*>& traces, int log_blowup);
+// LDE of `tr` onto the cosets [first, first + count) only of the 2^lb cosets (count a power of two)
+LdeMatrix lde_trace_cosets(mh_ctx* c, const mh_trace* tr, int lb, size_t first, size_t count);
 // ---- quotient.hip ------------------------------------------------------------------------------
 struct mh_air;
 #include "gl.cuh"

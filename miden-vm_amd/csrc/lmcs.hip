@@ -150,27 +150,32 @@ void lmcs_compress_layers(mh_ctx* c, mh_tree* t) {
 
 void lmcs_build_tree(mh_ctx* c, mh_tree* t) {
   MH_REQUIRE(!t->mats.empty(), "cannot commit empty batch");
-  const int lb = t->log_blowup;
-  const int log_n_max = t->mats.back().log_n;
-  for (size_t i = 1; i < t->mats.size(); i++)
-    MH_REQUIRE(t->mats[i - 1].log_n <= t->mats[i].log_n, "matrices must be sorted by ascending height");
-  lmcs_alloc_layers(t, log_n_max + lb);
+  lmcs_alloc_layers(t, t->mats.back().log_n + t->log_blowup);
+  lmcs_hash_leaves(c, t->mats, t->log_blowup, lmcs_leaf_layer(t));
+  lmcs_compress_layers(c, t);
+}
 
-  // ---- leaves: one launch per (height group, <=8 matrices) chained through a state buffer
+// Leaf digests of a group of LDE matrices holding 2^lb cosets each (all cosets, or one rank's share
+// of them in the coset-sharded commit): digest slot j*N + r, N = tallest height.
+void lmcs_hash_leaves(mh_ctx* c, const std::vector<LdeMatrix>& mats, int lb, u64* digests) {
+  MH_REQUIRE(!mats.empty(), "cannot commit empty batch");
+  for (size_t i = 1; i < mats.size(); i++)
+    MH_REQUIRE(mats[i - 1].log_n <= mats[i].log_n, "matrices must be sorted by ascending height");
+  // one launch per (height group, <=8 matrices) chained through a state buffer
   DevBuf st_a, st_b;
   const u64* state_in = nullptr;
   int log_n_prev = 0;
   size_t i = 0;
-  const size_t nm = t->mats.size();
+  const size_t nm = mats.size();
   while (i < nm) {
-    int ln = t->mats[i].log_n;
+    int ln = mats[i].log_n;
     LeafArgs a{};
     a.n_mats = 0;
     double bytes = 0;
-    while (i < nm && t->mats[i].log_n == ln && a.n_mats < LEAF_MAX_MATS) {
-      a.m[a.n_mats].data = t->mats[i].lde.u();
-      a.m[a.n_mats].width = (u32)t->mats[i].width;
-      bytes += (double)t->mats[i].width * 8.0 * (double)((size_t)1 << (ln + lb));
+    while (i < nm && mats[i].log_n == ln && a.n_mats < LEAF_MAX_MATS) {
+      a.m[a.n_mats].data = mats[i].lde.u();
+      a.m[a.n_mats].width = (u32)mats[i].width;
+      bytes += (double)mats[i].width * 8.0 * (double)((size_t)1 << (ln + lb));
       a.n_mats++;
       i++;
     }
@@ -182,7 +187,7 @@ void lmcs_build_tree(mh_ctx* c, mh_tree* t) {
     const size_t leaves = (size_t)1 << (ln + lb);
     DevBuf& outbuf = (state_in == st_a.u()) ? st_b : st_a;
     if (last) {
-      a.digest_out = t->nodes.u() + 4 * t->layer_off[t->log_height];
+      a.digest_out = digests;
       a.state_out = nullptr;
       bytes += 32.0 * leaves;
     } else {
@@ -200,7 +205,6 @@ void lmcs_build_tree(mh_ctx* c, mh_tree* t) {
     state_in = a.state_out;
     log_n_prev = ln;
   }
-  lmcs_compress_layers(c, t);
 }
 
 // tree_indices.rs:185-240 (MissingSiblingsIter): bottom-up, left-to-right.

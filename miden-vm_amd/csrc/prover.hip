@@ -14,6 +14,7 @@
 #include "ctx.hpp"
 #include "gl.cuh"
 #include "kernels.hpp"
+#include "poseidon2.cuh"
 #include <algorithm>
 #include <cstring>
 #include <memory>
@@ -57,18 +58,23 @@ mh_trace* trace_zeros(mh_ctx* c, int log_n, size_t width) {
   return t.release();
 }
 
-// LDE of one uploaded trace into coset-major layout on the canonical shift of its own LDE order.
-static LdeMatrix lde_trace(mh_ctx* c, const mh_trace* tr, int lb) {
+// LDE of one uploaded trace into coset-major layout on the canonical shift of its own LDE order;
+// only cosets [first, first + count) are produced (all of them for a single-GPU commitment).
+LdeMatrix lde_trace_cosets(mh_ctx* c, const mh_trace* tr, int lb, size_t first, size_t count) {
   LdeMatrix m;
   m.log_n = tr->log_n; m.width = tr->width;
   size_t N = (size_t)1 << tr->log_n;
   MH_REQUIRE(tr->log_n + lb <= 32, "LDE order exceeds the field's two-adicity");
-  m.lde.alloc((N << lb) * tr->width * 8);
+  MH_REQUIRE(count > 0 && first + count <= ((size_t)1 << lb), "coset range out of bounds");
+  m.lde.alloc(N * count * tr->width * 8);
   DevBuf scratch(N * tr->width * 8);
-  ProfScope ps(c, "lde", (double)(1 + (1 << lb)) * N * tr->width * 8.0);
-  lde_columns(c, tr->cols.u(), tr->width, tr->log_n, 1, coset_shifts(tr->log_n, lb), m.lde.u(), scratch.u());
+  std::vector<u64> all = coset_shifts(tr->log_n, lb);
+  std::vector<u64> mine(all.begin() + first, all.begin() + first + count);
+  ProfScope ps(c, "lde", (double)(1 + count) * N * tr->width * 8.0);
+  lde_columns(c, tr->cols.u(), tr->width, tr->log_n, 1, mine, m.lde.u(), scratch.u());
   return m;
 }
+static LdeMatrix lde_trace(mh_ctx* c, const mh_trace* tr, int lb) { return lde_trace_cosets(c, tr, lb, 0, (size_t)1 << lb); }
 
 mh_tree* commit_traces(mh_ctx* c, const std::vector<const mh_trace*>& traces, int log_blowup) {
   std::unique_ptr<mh_tree> t(new mh_tree());
@@ -403,6 +409,81 @@ void mh_air_free(mh_air* a) {
   delete a;
 }
 int mh_air_log_quotient_degree(const mh_air* a) { return a ? a->log_quotient_degree : -1; }
+
+// ---- coset-sharded commitment (one process per GPU) -------------------------
+struct mh_shard {
+  mh_ctx* ctx;
+  int log_blowup, log_n, rank, world, log_world;
+  std::vector<LdeMatrix> mats;  // this rank's 2^(lb - log_world) cosets of every matrix
+  DevBuf leaf_digests;          // [cosets_local][N] digests (4 felts each)
+  std::unique_ptr<mh_tree> subtree;
+};
+
+int mh_shard_commit_leaves(mh_ctx* c, int n_traces, mh_trace* const* traces, int log_blowup, int rank, int world, mh_shard** out) {
+  MH_TRY(c)
+  MH_REQUIRE(c && traces && out && n_traces > 0, "null/empty argument");
+  int lw = 0;
+  while ((1 << lw) < world) lw++;
+  MH_REQUIRE(world >= 1 && (1 << lw) == world && lw <= log_blowup, "world must be a power of two not larger than the blowup");
+  MH_REQUIRE(rank >= 0 && rank < world, "rank out of range");
+  HIP_CHECK(hipSetDevice(c->device));
+  std::unique_ptr<mh_shard> s(new mh_shard());
+  s->ctx = c; s->log_blowup = log_blowup; s->rank = rank; s->world = world; s->log_world = lw;
+  const size_t per = (size_t)1 << (log_blowup - lw);
+  for (int i = 0; i < n_traces; i++) {
+    MH_REQUIRE(traces[i], "null trace");
+    MH_REQUIRE(traces[i]->log_n >= lw, "trace too short to shard by rows");
+    s->mats.push_back(lde_trace_cosets(c, traces[i], log_blowup, (size_t)rank * per, per));
+  }
+  s->log_n = s->mats.back().log_n;
+  s->leaf_digests.alloc((per << s->log_n) * 32);
+  lmcs_hash_leaves(c, s->mats, log_blowup - lw, s->leaf_digests.u());
+  c->sync();
+  *out = s.release();
+  MH_CATCH
+}
+void mh_shard_free(mh_shard* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->ctx->device);
+  PoolScope ps(s->ctx);
+  delete s;
+}
+uint64_t* mh_shard_leaf_digests(mh_shard* s, size_t* n_digests) {
+  if (!s) return nullptr;
+  if (n_digests) *n_digests = s->leaf_digests.bytes / 32;
+  return s->leaf_digests.u();
+}
+int mh_shard_build_subtree(mh_ctx* c, mh_shard* s, const uint64_t* digests_device, uint64_t subroot[4]) {
+  MH_TRY(c)
+  MH_REQUIRE(c && s && digests_device && subroot, "null argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  std::unique_ptr<mh_tree> t(new mh_tree());
+  t->ctx = c; t->log_blowup = s->log_blowup;
+  lmcs_alloc_layers(t.get(), s->log_n - s->log_world + s->log_blowup);
+  const size_t leaves = (size_t)1 << t->log_height;
+  HIP_CHECK(hipMemcpyAsync(lmcs_leaf_layer(t.get()), digests_device, leaves * 32, hipMemcpyDeviceToDevice, c->stream));
+  lmcs_compress_layers(c, t.get());
+  memcpy(subroot, t->root, 32);
+  s->subtree = std::move(t);
+  MH_CATCH
+}
+// Root of the cap: `world` subtree roots (rank order = domain order) -> the commitment (host only).
+int mh_merkle_cap_root(const uint64_t* subroots, int world, uint64_t root[4]) {
+  if (!subroots || !root || world < 1 || (world & (world - 1))) return MH_ERR_INVALID;
+  std::vector<u64> cur(subroots, subroots + 4 * (size_t)world);
+  for (int n = world; n > 1; n >>= 1) {
+    std::vector<u64> next(4 * (size_t)(n / 2));
+    for (int i = 0; i < n / 2; i++) {
+      u64 st[12] = {0};
+      for (int k = 0; k < 4; k++) { st[k] = gl_canon(cur[8 * i + k]); st[4 + k] = gl_canon(cur[8 * i + 4 + k]); }
+      p2_permute(st);
+      for (int k = 0; k < 4; k++) next[4 * i + k] = st[k];
+    }
+    cur.swap(next);
+  }
+  memcpy(root, cur.data(), 32);
+  return MH_OK;
+}
 
 int mh_prove(mh_ctx* c, const mh_pcs_params* params, int n_airs, mh_air* const* airs, mh_trace* const* traces,
              const uint64_t* public_values, size_t n_public_values, const uint64_t challenger_state[12],

@@ -1,0 +1,109 @@
+"""Coset-sharded commitment across the GPUs of one node: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests).
+
+Why this shape: a leaf of the LMCS tree is one sponge over the WHOLE row across
+all matrices (crates/lifted-stark/src/lmcs/lifted_tree.rs:344-417), so column shards cannot produce
+the reference root; cosets of the trace domain can.  The device LDE is coset-major, rank k owns cosets
+[k*B/G, (k+1)*B/G): LDE and leaf hashing are local.  The tree is indexed by domain order = rows first
+(lifted_tree.rs:247-258), so ONE all-to-all of leaf digests (32 B each) regroups them by row range,
+each rank builds the subtree of its row range, and the G subroots are all-gathered (32 B each) and
+combined on the host.  No other data moves.
+"""
+import ctypes as C
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class _DevPtr:
+    """Expose a raw device pointer to torch through __cuda_array_interface__ (zero copy)."""
+
+    def __init__(self, ptr, n_i64):
+        self.__cuda_array_interface__ = {"shape": (n_i64,), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+
+
+def device_tensor(ptr, n_i64):
+    return torch.as_tensor(_DevPtr(ptr, n_i64), device="cuda")
+
+
+def exchange_leaf_digests(local, world, group=None):
+    """local: int64 tensor [B_loc, N, 4] (this rank's cosets, coset-major).  Returns [B, N // world, 4]:
+    every coset's digests for THIS rank's row range (source rank k contributes cosets k*B_loc..)."""
+    b_loc, n, four = local.shape
+    assert four == 4 and n % world == 0
+    if world == 1:
+        return local
+    send = local.view(b_loc, world, n // world, 4).permute(1, 0, 2, 3).contiguous()
+    recv = torch.empty_like(send)
+    backend = dist.get_backend(group)
+    if backend == "gloo" and send.is_cuda:  # single-GPU test boxes: stage through the host
+        s, r = send.cpu(), torch.empty(send.shape, dtype=send.dtype)
+        dist.all_to_all_single(r.view(-1), s.view(-1), group=group)
+        recv.copy_(r)
+    else:
+        dist.all_to_all_single(recv.view(-1), send.view(-1), group=group)
+    return recv.view(world * b_loc, n // world, 4)
+
+
+def gather_subroots(subroot, world, group=None, device="cpu"):
+    """subroot: 4 uint64 (numpy).  Returns [world, 4] uint64 in rank order."""
+    if world == 1:
+        return np.asarray(subroot, dtype=np.uint64).reshape(1, 4)
+    t = torch.from_numpy(np.asarray(subroot, dtype=np.uint64).view(np.int64).copy())
+    if dist.get_backend(group) == "nccl":
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    return torch.stack(out).cpu().numpy().view(np.uint64)
+
+
+def cap_root(lib, subroots):
+    s = np.ascontiguousarray(subroots, dtype=np.uint64)
+    root = np.zeros(4, dtype=np.uint64)
+    u64p = C.POINTER(C.c_uint64)
+    rc = lib.mh_merkle_cap_root(s.ctypes.data_as(u64p), C.c_int(s.shape[0]), root.ctypes.data_as(u64p))
+    if rc != 0:
+        raise RuntimeError("mh_merkle_cap_root failed")
+    return root
+
+
+class ShardedCommit:
+    """commit_traces of the reference (prover/commit.rs:142-180) spread over `world` ranks."""
+
+    def __init__(self, ctx, traces, log_blowup, rank, world, group=None):
+        self.ctx, self.rank, self.world, self.group = ctx, rank, world, group
+        lib = ctx.lib
+        lib.mh_shard_leaf_digests.restype = C.POINTER(C.c_uint64)
+        lib.mh_shard_leaf_digests.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        lib.mh_shard_free.argtypes = [C.c_void_p]
+        n = len(traces)
+        arr = (C.c_void_p * n)(*[t.h for t in traces])
+        h = C.c_void_p()
+        ctx.check(lib.mh_shard_commit_leaves(ctx.h, n, arr, log_blowup, rank, world, C.byref(h)))
+        self.h = h
+        self.log_n = max(t.log_n for t in traces)
+        self.b_loc = (1 << log_blowup) // world
+
+    def root(self):
+        lib = self.ctx.lib
+        nd = C.c_size_t(0)
+        p = lib.mh_shard_leaf_digests(self.h, C.byref(nd))
+        local = device_tensor(C.cast(p, C.c_void_p).value, nd.value * 4).view(self.b_loc, 1 << self.log_n, 4)
+        mine = exchange_leaf_digests(local, self.world, self.group).contiguous()
+        torch.cuda.synchronize()
+        sub = np.zeros(4, dtype=np.uint64)
+        self.ctx.check(lib.mh_shard_build_subtree(self.ctx.h, self.h, C.c_void_p(mine.data_ptr()),
+                                                  sub.ctypes.data_as(C.POINTER(C.c_uint64))))
+        subs = gather_subroots(sub, self.world, self.group, device="cuda")
+        return cap_root(lib, subs)
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.mh_shard_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

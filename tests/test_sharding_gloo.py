@@ -1,0 +1,66 @@
+"""CPU, world_size 2, gloo: the N>1 path of the coset-sharded commitment.  The device stages (LDE of
+the rank's cosets, leaf sponges, subtree) are stood in for by the oracle here; what is under test is
+the product's exchange layer (miden-vm_amd/sharding.py: all-to-all regrouping of leaf digests,
+subroot all-gather) and the host cap-root of libmidenhip -- the result must equal the single-process
+LMCS root for every world size."""
+import os, sys
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, shapes, lb, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from miden_vm_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(99)
+        traces = [rng.integers(0, ob.P, (1 << lh, w), dtype=np.uint64) for lh, w in shapes]
+        exp = ob.commit_traces(traces, lb, want_lde=True)
+        _, layers = ob.lmcs_build(exp["ldes"], want_layers=True)
+        B, N = 1 << lb, 1 << shapes[-1][0]
+        leaves = layers[: B * N]                      # domain order i = r*B + j
+        b_loc = B // world
+        cos = leaves.reshape(N, B, 4).transpose(1, 0, 2)  # [j][r]
+        local = torch.from_numpy(np.ascontiguousarray(cos[rank * b_loc:(rank + 1) * b_loc]).view(np.int64).copy())
+        mine = sharding.exchange_leaf_digests(local, world).numpy().view(np.uint64)  # [B][N/world][4]
+        assert mine.shape == (B, N // world, 4)
+        # rows [rank*N/world, ...) of every coset, i.e. the contiguous domain range of subtree `rank`
+        r0 = rank * (N // world)
+        assert (mine == cos[:, r0:r0 + N // world]).all()
+        level = mine.transpose(1, 0, 2).reshape(-1, 4)  # domain order inside the subtree
+        while level.shape[0] > 1:
+            level = np.stack([ob.compress(level[2 * i], level[2 * i + 1]) for i in range(level.shape[0] // 2)])
+        subs = sharding.gather_subroots(level[0], world)
+        root = sharding.cap_root(pkg.load_library(), subs)
+        ret[rank] = bool((root == exp["root"]).all())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shapes,lb", [(2, [(4, 5)], 3), (2, [(3, 3), (5, 9)], 2), (4, [(4, 7)], 2)])
+def test_sharded_commit_exchange_matches_single_process_root(world, shapes, lb):
+    port = 29500 + (os.getpid() + world * 7 + lb) % 2000
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, shapes, lb, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_cap_root_single_rank_is_identity():
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from miden_vm_amd import sharding
+    r = np.array([[1, 2, 3, 4]], dtype=np.uint64)
+    assert (sharding.cap_root(pkg.load_library(), r) == r[0]).all()
