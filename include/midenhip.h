@@ -52,6 +52,9 @@ int mh_prof_dump(mh_ctx* ctx, char* buf, size_t cap);
  * crates/crypto/src/hash/algebraic_sponge/poseidon2/mod.rs:340,380-386) on n states of 12 felts,
  * host array-of-states layout [n][12], in place. */
 int mh_poseidon2_permute(mh_ctx* ctx, uint64_t* states, size_t n);
+/* Measurement aid: permutations per second of the same device permutation with the state held in
+ * registers (no memory traffic) = the VALU ceiling bench.py reports hash kernels against. */
+int mh_poseidon2_register_rate(mh_ctx* ctx, double* perms_per_second);
 
 /* Coset LDE of a host row-major matrix (replaces Radix2DitParallel::coset_lde_batch as called at
  * crates/lifted-stark/src/prover/commit.rs:173): `out` receives the (n<<added_bits) x width

@@ -21,7 +21,7 @@ u64p = C.POINTER(C.c_uint64)
 
 EXPORTS = [
     "mh_ctx_create", "mh_ctx_destroy", "mh_last_error", "mh_device_count", "mh_prof_enable", "mh_prof_reset",
-    "mh_prof_get", "mh_prof_dump", "mh_poseidon2_permute", "mh_coset_lde_batch", "mh_trace_upload", "mh_trace_free",
+    "mh_prof_get", "mh_prof_dump", "mh_poseidon2_permute", "mh_poseidon2_register_rate", "mh_coset_lde_batch", "mh_trace_upload", "mh_trace_free",
     "mh_commit_traces", "mh_tree_free", "mh_tree_root", "mh_tree_log_height", "mh_tree_open", "mh_tree_download_lde",
     "mh_tree_download_layers", "mh_air_load", "mh_air_free", "mh_air_log_quotient_degree", "mh_prove", "mh_proof_free",
     "mh_proof_num_fields", "mh_proof_num_commitments", "mh_proof_fields", "mh_proof_commitments", "mh_proof_digest",
@@ -123,6 +123,11 @@ class Ctx:
             name, ms, by, cnt = line.split()
             out[name] = {"ms": float(ms), "bytes": float(by), "count": int(cnt)}
         return out
+
+    def poseidon2_register_rate(self):
+        r = C.c_double(0)
+        self.check(self.lib.mh_poseidon2_register_rate(self.h, C.byref(r)))
+        return r.value
 
     # ---- unit-parity entry points ----
     def poseidon2_permute(self, states):

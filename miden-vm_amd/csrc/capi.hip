@@ -134,6 +134,14 @@ int mh_poseidon2_permute(mh_ctx* c, uint64_t* states, size_t n) {
   MH_CATCH
 }
 
+int mh_poseidon2_register_rate(mh_ctx* c, double* perms_per_second) {
+  MH_TRY(c)
+  MH_REQUIRE(c && perms_per_second, "null argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  *perms_per_second = poseidon2_register_rate(c);
+  MH_CATCH
+}
+
 int mh_trace_upload(mh_ctx* c, const uint64_t* rowmajor, int log_n, size_t width, mh_trace** out) {
   MH_TRY(c)
   MH_REQUIRE(c && rowmajor && out, "null argument");

@@ -52,6 +52,7 @@ struct mh_tree {
 
 // ---- lmcs.hip --------------------------------------------------------------------------------
 void poseidon2_permute_device(mh_ctx* c, u64* states_soa, size_t n);  // [12][n]
+double poseidon2_register_rate(mh_ctx* c);  // permutations/s with the state held in registers (VALU ceiling)
 // Build leaf digests + all layers for `t->mats` (already filled); sets t->root.
 void lmcs_build_tree(mh_ctx* c, mh_tree* t);
 // Pieces of the above for trees whose leaf digests come from another kernel (FRI rounds):

@@ -41,6 +41,34 @@ void poseidon2_permute_device(mh_ctx* c, u64* states_soa, size_t n) {
   hipLaunchKernelGGL(k_permute_soa, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, states_soa, n);
 }
 
+// Register-only permutation chain: the VALU ceiling the hash kernels are measured against (bench.py).
+__global__ __launch_bounds__(256) void k_perm_rate(u64* out, int iters, u64 seed) {
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl_canon(seed * (i + 1) + threadIdx.x + blockIdx.x * 131);
+#pragma unroll 1
+  for (int i = 0; i < iters; i++) p2f_permute(s);
+  u64 x = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) x ^= s[i];
+  out[blockIdx.x * 256 + threadIdx.x] = x;
+}
+double poseidon2_register_rate(mh_ctx* c) {
+  const int blocks = 2048, iters = 32;
+  DevBuf out((size_t)blocks * 256 * 8);
+  hipEvent_t a = c->get_event(), b = c->get_event();
+  hipLaunchKernelGGL(k_perm_rate, dim3(blocks), dim3(256), 0, c->stream, out.u(), 2, 1ULL);
+  HIP_CHECK(hipEventRecord(a, c->stream));
+  hipLaunchKernelGGL(k_perm_rate, dim3(blocks), dim3(256), 0, c->stream, out.u(), iters, 12345ULL);
+  HIP_CHECK(hipEventRecord(b, c->stream));
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  float ms = 0;
+  HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+  c->event_pool.push_back(a);
+  c->event_pool.push_back(b);
+  return (double)blocks * 256 * iters / (ms * 1e-3);
+}
+
 struct LeafMat {
   const u64* data;  // [width][B][N_m]
   u32 width;
