@@ -97,6 +97,32 @@ def test_arity2_blowup2(ctx):
     check_same(ctx, [A.fib_air()], [t], pub, dict(FAST, log_folding_arity=1, log_blowup=2, log_final_degree=1))
 
 
+def test_blowup16_more_queries(ctx):
+    # BASELINE configs[4]-style parameters (blowup 16, more queries/PoW) at a size the oracle can follow
+    prm = dict(log_blowup=4, log_folding_arity=2, log_final_degree=3, folding_pow_bits=2, deep_pow_bits=5, num_queries=12,
+               query_pow_bits=6)
+    check_same(ctx, [dag.dummy_miden_air(16, 1)], [A.dummy_trace(7, 16)], [], prm)
+
+
+def test_full_size_proof_verifies(ctx):
+    """BASELINE size (2^20 x 51, production parameters): too big for the oracle PROVER, but verification is
+    size-independent -- the oracle verifier must accept the device proof, and a tampered one must fail."""
+    pkg = load_package()
+    air = dag.dummy_miden_air(51, 8)
+    log_n = 20
+    got = gpu_prove(ctx, [air], [A.dummy_trace(log_n, 51)], [], ob.PROD_PARAMS)
+    assert got.log_trace_heights == [log_n]
+    proof = {"fields": got.fields, "commitments": got.commitments}
+    ok, msg = ob.verify([air], [log_n], [], proof, ob.PROD_PARAMS)
+    assert ok, msg
+    assert (msg == got.digest).all()
+    assert 100_000 < len(got.bytes) < 200_000  # reference: ~100-140 KB proofs (README.md:118-121)
+    bad = got.fields.copy()
+    bad[300] = (int(bad[300]) + 1) % A.P
+    ok, _ = ob.verify([air], [log_n], [], {"fields": bad, "commitments": got.commitments}, ob.PROD_PARAMS)
+    assert not ok
+
+
 def test_rejects_bad_shapes(ctx):
     pkg = load_package()
     air = pkg.DeviceAir(ctx, dag.dummy_miden_air(11, 2))
