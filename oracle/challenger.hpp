@@ -13,6 +13,7 @@
 // no in-tree restatement; this oracle takes the smallest witness and squeezes state[0..4].
 #pragma once
 #include "poseidon2.hpp"
+#include <algorithm>
 #include <array>
 #include <stdexcept>
 #include <vector>
@@ -63,13 +64,30 @@ struct Challenger {
     observe(w);
     return sample_bits(bits) == 0;
   }
+  // check_witness on a stack copy of the state (no heap traffic): exactly one duplexing happens
+  // between observe(w) and the sampled bits, whether the buffer fills up (8) or not.
+  bool trial(int bits, uint64_t w) const {
+    uint64_t s[12];
+    for (int i = 0; i < 12; i++) s[i] = st[i];
+    size_t k = in.size() + 1;
+    for (size_t i = 0; i < 8; i++) s[i] = i < in.size() ? in[i] : (i == in.size() ? w : 0);
+    s[8] = fadd(s[8], (uint64_t)k);
+    p2_permute(s);
+    return ((s[7] & 0xFFFFFFFFULL) & (((uint64_t)1 << bits) - 1)) == 0;
+  }
   uint64_t grind(int bits) {
     if (bits == 0) return 0;
-    for (uint64_t w = 0;; w++) {
-      Challenger c = *this;
-      if (c.check_witness(bits, w)) {
-        *this = c;
-        return w;
+    // smallest valid witness; windows searched in parallel (OpenMP), result independent of threads
+    const uint64_t window = 4096;
+    for (uint64_t base = 0;; base += window) {
+      uint64_t best = ~0ULL;
+#pragma omp parallel for reduction(min : best) schedule(static)
+      for (long i = 0; i < (long)window; i++)
+        if (trial(bits, base + (uint64_t)i)) best = std::min(best, base + (uint64_t)i);
+      if (best != ~0ULL) {
+        bool ok = check_witness(bits, best);
+        if (!ok) throw std::runtime_error("oracle grind: fast trial disagrees with check_witness");
+        return best;
       }
     }
   }

@@ -28,7 +28,24 @@ static const int TWO_ADICITY = 32;
 static inline uint64_t fadd(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a + b) % P); }
 static inline uint64_t fsub(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a + P - b) % P); }
 static inline uint64_t fneg(uint64_t a) { return a == 0 ? 0 : P - a; }
+#ifdef ORACLE_FAST
+// Build variant for bench.py's cpu_baseline leg only (liboracle_fast.so): same results as the
+// obviously-correct `% P` form below (tests/test_oracle_kat.py cross-checks the two libraries), but
+// without a 128-bit division per multiplication, so the CPU baseline is not handicapped.
+static inline uint64_t fmul(uint64_t a, uint64_t b) {
+  u128 p = (u128)a * b;
+  uint64_t lo = (uint64_t)p, hi = (uint64_t)(p >> 64);
+  uint64_t hh = hi >> 32, hl = hi & 0xFFFFFFFFULL;
+  uint64_t t0 = lo - hh;
+  if (lo < hh) t0 -= 0xFFFFFFFFULL;
+  uint64_t t1 = (hl << 32) - hl;
+  uint64_t r = t0 + t1;
+  if (r < t1) r += 0xFFFFFFFFULL;
+  return r >= P ? r - P : r;
+}
+#else
 static inline uint64_t fmul(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a * b) % P); }
+#endif
 static inline uint64_t fpow(uint64_t a, uint64_t e) {
   uint64_t r = 1;
   while (e) {

@@ -25,6 +25,9 @@
 #include <algorithm>
 #include <map>
 #include <numeric>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace oracle {
 
@@ -134,7 +137,19 @@ struct ProverInput {
   void* aux_user = nullptr;
 };
 
+struct StageTimer {  // ORACLE_TIMING=1 prints per-stage wall time (used to keep the CPU baseline honest)
+  bool on = getenv("ORACLE_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char* name) {
+    if (!on) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[oracle] %-22s %8.3f s\n", name, std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
+};
+
 static inline Proof prove(ProverInput& in) {
+  StageTimer tm;
   const PcsParams& pp = in.params;
   const int lb = pp.log_blowup;
   const size_t B = (size_t)1 << lb;
@@ -180,6 +195,7 @@ static inline Proof prove(ProverInput& in) {
   LmcsTree main_tree = commit(main_mats, main_w, main_lde);
   ch.send_commitment(main_tree.root());
 
+  tm.lap("commit main");
   // ---- 2. randomness, aux traces -----------------------------------------------------------
   size_t max_rand = 0;
   for (auto& a : in.airs) max_rand = std::max(max_rand, a.num_randomness);
@@ -209,6 +225,7 @@ static inline Proof prove(ProverInput& in) {
   for (size_t j = 0; j < n_airs; j++)
     for (uint64_t v : aux_vals[order[j]]) ch.send_field(v);
 
+  tm.lap("commit aux");
   // ---- 3. alpha, beta ----------------------------------------------------------------------
   E2 alpha = ch.ch.sample_ef();
   E2 beta = ch.ch.sample_ef();
@@ -312,6 +329,7 @@ static inline Proof prove(ProverInput& in) {
   const size_t N = (size_t)1 << log_n_max;
   if (acc.size() != N * D) throw std::runtime_error("internal: accumulator size");
 
+  tm.lap("constraints");
   // ---- 5. commit quotient (quotient.rs:143-217) ---------------------------------------------
   std::vector<uint64_t> quot_lde(NB * 2 * D);
   {
@@ -335,6 +353,7 @@ static inline Proof prove(ProverInput& in) {
   LmcsTree quot_tree = lmcs_build({Mat{quot_lde.data(), NB, 2 * D}});
   ch.send_commitment(quot_tree.root());
 
+  tm.lap("commit quotient");
   // ---- 6. OOD point (domain.rs:539-553) -----------------------------------------------------
   E2 z;
   const uint64_t g_inv = finv(g);
@@ -382,6 +401,7 @@ static inline Proof prove(ProverInput& in) {
       off += align8(m.w);
     }
   }
+  tm.lap("ood evals");
   for (int k = 0; k < 2; k++)
     for (E2 v : evals[k]) ch.send_ef(v);
   ch.grind(pp.deep_pow_bits);
@@ -429,6 +449,7 @@ static inline Proof prove(ProverInput& in) {
     }
   }
 
+  tm.lap("deep");
   // ---- 8. FRI commit phase ------------------------------------------------------------------
   const int la = pp.log_folding_arity;
   const size_t arity = (size_t)1 << la;
@@ -468,6 +489,7 @@ static inline Proof prove(ProverInput& in) {
     for (size_t i = fpd; i-- > 0;) ch.send_ef(E2{c0[i], c1[i]});
   }
 
+  tm.lap("fri");
   // ---- 9. queries ---------------------------------------------------------------------------
   ch.grind(pp.query_pow_bits);
   std::vector<size_t> idx;
@@ -494,6 +516,7 @@ static inline Proof prove(ProverInput& in) {
     ch.hint_fields(f);
     ch.hint_commitments(c);
   }
+  tm.lap("queries");
   Proof pr;
   for (int lh : in.log_heights) pr.log_trace_heights.push_back((uint8_t)lh);
   pr.digest = ch.ch.finalize();

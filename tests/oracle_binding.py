@@ -10,10 +10,21 @@ _lib = None
 u64p = C.POINTER(C.c_uint64)
 
 
+def use_fast_library(on=True):
+    """Switch to liboracle_fast.so (ORACLE_FAST build: same results, fast field multiplication).  Only
+    bench.py's cpu_baseline leg and the cross-check test use it."""
+    global _lib, _so_name
+    _so_name = "liboracle_fast.so" if on else "liboracle.so"
+    _lib = None
+
+
+_so_name = "liboracle.so"
+
+
 def lib():
     global _lib
     if _lib is None:
-        so = os.path.join(ROOT, "oracle", "liboracle.so")
+        so = os.path.join(ROOT, "oracle", _so_name)
         if not os.path.exists(so):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
         _lib = C.CDLL(so)

@@ -136,3 +136,19 @@ def test_lmcs_upsampled_equivalence():
     # parent layer
     assert (layers[H] == ob.compress(layers[0], layers[1])).all()
     assert (layers[-1] == root).all()
+
+
+def test_fast_build_agrees_with_reference_build():
+    """liboracle_fast.so (cpu_baseline leg) must be bit-identical to the `% P` build."""
+    rng = np.random.default_rng(123)
+    s = rng.integers(0, ob.P, (300, 12), dtype=np.uint64)
+    t = rng.integers(0, ob.P, (1 << 6, 7), dtype=np.uint64)
+    ref_p = ob.permute(s)
+    ref_c = ob.commit_traces([t], 3)["root"]
+    ob.use_fast_library(True)
+    try:
+        assert (ob.permute(s) == ref_p).all()
+        assert (ob.commit_traces([t], 3)["root"] == ref_c).all()
+        assert ob.lib().orc_fmul(ob.P - 1, ob.P - 1) == 1
+    finally:
+        ob.use_fast_library(False)
