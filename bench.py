@@ -164,41 +164,36 @@ class ProveRunner:
                           f"parameters in {dt:.2f} s"}
 
 
-def sharded_commit_probe(pkg, ctx, args, rank, world, dist):
-    """Strong scaling of commit_traces(main 2^log_n x 51) + commit_traces(aux x 16) sharded by cosets
-    (miden-vm_amd/sharding.py).  Same trace on every rank (same seed)."""
+def sharded_prove_probe(pkg, ctx, args, rank, world, runner):
+    """Strong scaling: ONE proof of the same miden:LOG_N:51:8 instance sharded by cosets over all ranks
+    (mh_prove_sharded + miden-vm_amd/sharding.py; digest all-to-alls, subroot / quotient-coefficient
+    all-gathers and opening all-reduces over RCCL).  Every rank holds the same trace (same seed)."""
     import numpy as np
     import torch
+    import torch.distributed as dist
     from miden_vm_amd import sharding
-    rng = np.random.default_rng(7)
-    traces = [ctx.upload_trace(synth_trace(rng, args.log_n, w)) for w in (51, 16)]
-    roots = None
+    trace = ctx.upload_trace(synth_trace(np.random.default_rng(7), args.log_n, 51))
+    comm = sharding.TorchComm(rank, world)
 
     def once():
-        r = []
-        for t in traces:
-            sc = sharding.ShardedCommit(ctx, [t], 3, rank, world)
-            r.append(sc.root())
-            sc.free()
-        return r
+        return sharding.prove_sharded(pkg, ctx, comm, [runner.dair], [trace], [], runner.params, runner.state, runner.pre, None)
 
-    once()
+    proof = once()
     dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
     reps = 3
+    t0 = time.perf_counter()
     for _ in range(reps):
-        roots = once()
+        proof = once()
     dist.barrier()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    for t in traces:
-        t.free()
-    return {"workload": f"coset-sharded commit of 2^{args.log_n} x (51 + 16) over {world} GPUs (one trace, strong scaling)",
-            "ms": float(tt.item()) * 1e3, "rows_per_s": (1 << args.log_n) / float(tt.item()),
-            "root0": [int(x) for x in roots[0]]}
+    trace.free()
+    return {"workload": f"one proof of miden:{args.log_n}:51:8 sharded by cosets over {world} GPUs (strong scaling)",
+            "ms_per_proof": float(tt.item()) * 1e3, "rows_per_s": (1 << args.log_n) / float(tt.item()),
+            "proof_bytes": len(proof.bytes), "digest": [int(x) for x in proof.digest]}
 
 
 def main():
@@ -209,6 +204,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--workload", default="auto", choices=["auto", "commit", "prove"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sharded-probe", action="store_true")
     ap.add_argument("--cpu-log-n", type=int, default=16)
     args = ap.parse_args()
 
@@ -290,15 +286,27 @@ def main():
         out["cpu_baseline"] = runner.cpu_baseline()
     elif rank == 0:
         out["cpu_baseline"] = None
-    if world > 1:
-        # Extra (not part of `value`): the coset-sharded commitment of ONE 2^log_n x (51 + 16) trace pair
-        # across all ranks -- the path with a real exchange step (digest all-to-all over RCCL).
+    if world > 1 and workload == "prove" and not args.no_sharded_probe:
+        # Extra (not part of `value`): ONE proof sharded over all ranks -- the path with real exchange
+        # steps.  A watchdog guarantees the main line is printed even if a collective misbehaves.
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(240.0):
+                if rank == 0:
+                    out["sharded_prove"] = {"error": "timed out after 240 s"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
         try:
-            out["sharded_commit"] = sharded_commit_probe(pkg, ctx, args, rank, world, dist)
+            out["sharded_prove"] = sharded_prove_probe(pkg, ctx, args, rank, world, runner)
         except Exception as e:  # never lose the main line to the probe
-            out["sharded_commit"] = {"error": repr(e)[:300]}
+            out["sharded_prove"] = {"error": repr(e)[:300]}
+        done.set()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -150,6 +150,28 @@ typedef int (*mh_aux_builder)(void* user, int instance_idx, const uint64_t* rand
 int mh_prove(mh_ctx* ctx, const mh_pcs_params* params, int n_airs, mh_air* const* airs, mh_trace* const* traces,
              const uint64_t* public_values, size_t n_public_values, const uint64_t challenger_state[12],
              const uint64_t* pre_observe, size_t n_pre_observe, mh_aux_builder aux_builder, void* user, mh_proof** out);
+/* One proof sharded over `world` GPUs (one process + one ctx per GPU, all ranks call this with the same
+ * arguments and traces; every rank returns the same proof).  The coset-major layout makes every pass over
+ * LDE-sized data local to a rank's cosets; what crosses ranks goes through these three collectives on
+ * DEVICE buffers (implemented by the host layer over RCCL, see miden-vm_amd/sharding.py):
+ *   all_to_all  (leaf digests of every commitment, 32 B per leaf),
+ *   all_gather  (subtree roots; quotient-chunk coefficients; a FRI layer once it has fewer rows per
+ *                coset than ranks),
+ *   all_reduce_sum_u64 (query openings: every value is contributed by exactly one rank).
+ * Each callback returns 0 on success; the library synchronises its stream before calling and expects the
+ * collective to be complete on return.  world must be a power of two <= min(2^log_blowup, quotient
+ * degree); every AIR of the proof must share one quotient degree. */
+typedef struct mh_comm {
+  int rank, world;
+  void* user;
+  int (*all_to_all)(void* user, const void* send_dev, void* recv_dev, size_t bytes_per_peer);
+  int (*all_gather)(void* user, const void* send_dev, void* recv_dev, size_t bytes_per_rank);
+  int (*all_reduce_sum_u64)(void* user, uint64_t* buf_dev, size_t n);
+} mh_comm;
+int mh_prove_sharded(mh_ctx* ctx, const mh_comm* comm, const mh_pcs_params* params, int n_airs, mh_air* const* airs,
+                     mh_trace* const* traces, const uint64_t* public_values, size_t n_public_values,
+                     const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe,
+                     mh_aux_builder aux_builder, void* user, mh_proof** out);
 void mh_proof_free(mh_proof* p);
 size_t mh_proof_num_fields(const mh_proof* p);
 size_t mh_proof_num_commitments(const mh_proof* p);

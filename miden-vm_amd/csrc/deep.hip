@@ -88,7 +88,9 @@ __global__ __launch_bounds__(256) void k_ood_partial(const u64* lde, int log_n, 
 void deep_ood_eval_matrix(mh_ctx* c, const LdeMatrix& m, int log_blowup, e2 y0, e2 y1, std::vector<e2>& out0, std::vector<e2>& out1) {
   const int log_n = m.log_n;
   const size_t n = (size_t)1 << log_n;
-  const u64 g = gl_lde_shift(log_n + log_blowup);
+  // any coset of H determines the polynomial: use the first one this rank stores
+  // (shift g_m * w_{K_m}^coset0; coset 0 on a single GPU, as the reference does)
+  const u64 g = gl_mul(gl_lde_shift(log_n + log_blowup), gl_pow(gl_two_adic_generator(log_n + log_blowup), m.coset0));
   DevBuf w0(n * 16), w1(n * 16), one;
   const u64* tw = log_n ? c->twiddles(log_n, false) : nullptr;
   if (!tw) {
@@ -102,7 +104,7 @@ void deep_ood_eval_matrix(mh_ctx* c, const LdeMatrix& m, int log_blowup, e2 y0, 
   {
     ProfScope ps(c, "deep_ood_eval", (double)n * 8.0 * m.width + 64.0 * n);
     hipLaunchKernelGGL(k_bary_weights, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, c->stream, tw, log_n, g, y0, y1, w0.u(), w1.u());
-    hipLaunchKernelGGL(k_ood_partial, dim3(chunks, (unsigned)m.width), dim3(256), 0, c->stream, m.lde.u(), log_n, log_blowup, w0.u(),
+    hipLaunchKernelGGL(k_ood_partial, dim3(chunks, (unsigned)m.width), dim3(256), 0, c->stream, m.lde.u(), log_n, m.log_cosets, w0.u(),
                        w1.u(), partial.u(), chunks);
   }
   std::vector<u64> host(m.width * chunks * 4);
@@ -135,7 +137,7 @@ struct DeepMat {
 };
 struct DeepArgs {
   DeepMat m[DEEP_MAX_MATS];
-  int n_mats, log_n, log_blowup;  // log_n = max trace height
+  int n_mats, log_n, log_blowup;  // log_n = max trace height; log_blowup = coset bits stored on this rank
   const u64* negc;                // EF pairs per aligned column
   const u64* tw;                  // w_N^k
   const u64* coset_x;             // [B] g*w_K^j
@@ -214,13 +216,16 @@ __global__ __launch_bounds__(256) void k_deep_assemble(DeepArgs a) {
 void deep_assemble(mh_ctx* c, const std::vector<const LdeMatrix*>& mats, const std::vector<u32>& coef_off, int log_n, int log_blowup,
                    const std::vector<e2>& negc, e2 z0, e2 z1, e2 fred0, e2 fred1, e2 beta, u64* out) {
   MH_REQUIRE(mats.size() <= (size_t)DEEP_MAX_MATS, "too many committed matrices for one DEEP pass");
-  const size_t N = (size_t)1 << log_n, B = (size_t)1 << log_blowup;
+  const int lbl = mats[0]->log_cosets;  // cosets stored on this rank (all matrices alike)
+  const size_t coset0 = mats[0]->coset0;
+  for (auto* m : mats) MH_REQUIRE(m->log_cosets == lbl && m->coset0 == coset0, "internal: matrices cover different cosets");
+  const size_t N = (size_t)1 << log_n, B = (size_t)1 << lbl;
   const int L = log_n + log_blowup;
   std::vector<u64> blob;
   for (e2 v : negc) { blob.push_back(v.c0); blob.push_back(v.c1); }
   const size_t o_cx = blob.size();
   const u64 g = gl_lde_shift(L), wK = gl_two_adic_generator(L);
-  u64 x = g;
+  u64 x = gl_mul(g, gl_pow(wK, coset0));
   for (size_t j = 0; j < B; j++) {
     blob.push_back(x);
     x = gl_mul(x, wK);
@@ -238,10 +243,10 @@ void deep_assemble(mh_ctx* c, const std::vector<const LdeMatrix*>& mats, const s
   double bytes = 16.0 * N * B;
   for (size_t i = 0; i < mats.size(); i++) {
     a.m[i] = DeepMat{mats[i]->lde.u(), (u32)mats[i]->width, coef_off[i], mats[i]->log_n};
-    bytes += 8.0 * (double)mats[i]->width * (double)(((size_t)1 << mats[i]->log_n) << log_blowup);
+    bytes += 8.0 * (double)mats[i]->width * (double)(((size_t)1 << mats[i]->log_n) << lbl);
   }
   a.n_mats = (int)mats.size();
-  a.log_n = log_n; a.log_blowup = log_blowup;
+  a.log_n = log_n; a.log_blowup = lbl;
   a.negc = dblob.u(); a.tw = tw; a.coset_x = dblob.u() + o_cx;
   a.z0 = z0; a.z1 = z1; a.fred0 = fred0; a.fred1 = fred1; a.beta = beta; a.out = out;
   {

@@ -104,14 +104,14 @@ void fri_leaf_hash(mh_ctx* c, const u64* ev, int log_rows, int cbits, int log_ar
                      digests);
 }
 
-void fri_fold(mh_ctx* c, const u64* ev, int log_rows, int cbits, int log_arity, e2 beta, u64* out) {
+void fri_fold(mh_ctx* c, const u64* ev, int log_rows, int cbits, int cbits_global, size_t coset0, int log_arity, e2 beta, u64* out) {
   MH_REQUIRE(log_arity == 1 || log_arity == 2, "FRI folding arity must be 2 or 4");
   MH_REQUIRE(log_rows >= log_arity, "internal: FRI layer too short for a coset-major fold");
-  const int logn = log_rows + cbits;
-  const size_t C = (size_t)1 << cbits;
+  const int logn = log_rows + cbits_global;  // size of the whole layer
+  const size_t C = (size_t)1 << cbits;       // cosets stored here
   std::vector<u64> ci(C);
   const u64 wn_inv = gl_inv(gl_two_adic_generator(logn));
-  u64 x = 1;
+  u64 x = gl_pow(wn_inv, coset0);
   for (size_t j = 0; j < C; j++) {
     ci[j] = x;
     x = gl_mul(x, wn_inv);
@@ -125,7 +125,7 @@ void fri_fold(mh_ctx* c, const u64* ev, int log_rows, int cbits, int log_arity, 
   a.beta = beta;
   a.w4 = gl_two_adic_generator(2);
   a.inv_arity = gl_inv((u64)1 << log_arity);
-  const size_t total = (size_t)1 << (logn - log_arity);
+  const size_t total = (size_t)1 << (log_rows + cbits - log_arity);
   {
     ProfScope ps(c, "fri_fold", (double)total * 16.0 * ((1 << log_arity) + 1));
     hipLaunchKernelGGL(k_fri_fold, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, a);

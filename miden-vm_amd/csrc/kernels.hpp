@@ -21,11 +21,24 @@ struct mh_trace {
 
 // A committed (LDE'd) matrix: coset-major column-major: lde[(c*B + j)*N + r] = f_c(shift*w_K^j*w_H^r)
 // = evaluation at natural index i = r*B + j of the max-domain-lifted polynomial.
+// A rank of a sharded proof stores only cosets [coset0, coset0 + 2^log_cosets) of the 2^log_blowup.
 struct LdeMatrix {
   int log_n;  // trace height
   size_t width;
   DevBuf lde;
-  const u64* col(size_t c, int log_blowup) const { return lde.u() + ((c << log_blowup) << log_n); }
+  int log_cosets = 0;  // coset bits stored here (= log_blowup on a single GPU)
+  size_t coset0 = 0;   // global index of the first stored coset
+};
+
+// Collectives of one sharded proof (include/midenhip.h mh_comm); world == 1: every call is a no-op.
+struct mh_comm;
+struct Dist {
+  const mh_comm* comm = nullptr;
+  int rank = 0, world = 1, logG = 0;
+  bool on() const { return world > 1; }
+  void all_to_all(mh_ctx* c, const void* send, void* recv, size_t bytes_per_peer) const;
+  void all_gather(mh_ctx* c, const void* send, void* recv, size_t bytes_per_rank) const;
+  void all_reduce_sum(mh_ctx* c, u64* buf, size_t n) const;
 };
 
 // LMCS tree over a group of LDE matrices (ascending heights).  Node (depth d, natural position p)
@@ -36,9 +49,16 @@ struct mh_tree {
   int log_height;  // tree depth L (leaves = 2^L)
   std::vector<LdeMatrix> mats;
   // FRI round trees (fri.hip) commit one EF layer instead of LDE matrices: rows are rebuilt from it
-  DevBuf fri_layer;      // EF pairs, coset-major [2^log_blowup][2^fri_log_rows]
+  DevBuf fri_layer;      // EF pairs, coset-major [2^fri_log_cosets][2^fri_log_rows] (this rank's cosets)
   int fri_log_rows = -1; // rows per coset of the layer (before grouping by arity); -1 = not a FRI tree
   int fri_log_arity = 0;
+  int fri_log_cosets = 0;
+  size_t fri_coset0 = 0;
+  // Sharded proofs: `nodes` is the subtree over this rank's ROW range (all cosets), of height
+  // log_height = full height - shard_logG; `cap` holds the top shard_logG + 1 levels on the host
+  // (node (d, p) at cap[4 * ((1 << d) - 1 + p)]).  shard_logG == 0: an ordinary full tree.
+  int shard_logG = 0, shard_rank = 0;
+  std::vector<u64> cap;
   DevBuf nodes;                    // all layers, leaf layer first
   std::vector<size_t> layer_off;   // layer_off[d] = element offset (in digests) of depth-d layer
   u64 root[4];
@@ -62,7 +82,10 @@ u64* lmcs_leaf_layer(mh_tree* t);                     // device pointer of the l
 void lmcs_compress_layers(mh_ctx* c, mh_tree* t);     // leaf layer -> root (copies root to host)
 // Gather opened rows (aligned, per sorted unique index) and missing siblings.
 void lmcs_open(mh_ctx* c, const mh_tree* t, const std::vector<size_t>& sorted_unique_idx, size_t alignment,
-               std::vector<u64>& fields, std::vector<u64>& commitments);
+               std::vector<u64>& fields, std::vector<u64>& commitments, const Dist* dist = nullptr);
+// Sharded tree build: local leaf digests [2^lbl][2^log_rows] -> all-to-all -> subtree over this rank's
+// row range -> all-gather of subroots -> cap on the host.  t->log_blowup = global coset bits.
+void lmcs_build_sharded(mh_ctx* c, mh_tree* t, const Dist& dist, const u64* local_digests, int log_rows);
 std::vector<std::pair<int, size_t>> lmcs_missing_siblings(const std::vector<size_t>& sorted_unique_idx, int depth);
 
 // ---- prover.hip (commit helpers shared with the C ABI) -------------------------------------------
@@ -75,6 +98,8 @@ LdeMatrix lde_trace_cosets(mh_ctx* c, const mh_trace* tr, int lb, size_t first, 
 // ---- quotient.hip ------------------------------------------------------------------------------
 struct mh_air;
 #include "gl.cuh"
+// log_d = quotient degree of the evaluation (global); the rank evaluates the 2^(log_d - logG) cosets it
+// stores (all of them on one GPU).  acc layouts are [2 * D_local][n].
 void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& main, const LdeMatrix& aux, int log_blowup, int log_d,
                               const std::vector<u64>& publics, const std::vector<e2>& randomness, const std::vector<e2>& aux_values,
                               e2 alpha, const u64* acc_in, int log_n_prev, e2 beta, u64* acc_out);
@@ -86,6 +111,7 @@ void deep_assemble(mh_ctx* c, const std::vector<const LdeMatrix*>& mats, const s
                    const std::vector<e2>& negc, e2 z0, e2 z1, e2 fred0, e2 fred1, e2 beta, u64* out);
 // ---- fri.hip -----------------------------------------------------------------------------------
 void fri_leaf_hash(mh_ctx* c, const u64* ev, int log_rows, int cbits, int log_arity, u64* digests);
-void fri_fold(mh_ctx* c, const u64* ev, int log_rows, int cbits, int log_arity, e2 beta, u64* out);
+// cbits = coset bits stored locally, cbits_global / coset0 locate them in the whole layer
+void fri_fold(mh_ctx* c, const u64* ev, int log_rows, int cbits, int cbits_global, size_t coset0, int log_arity, e2 beta, u64* out);
 void fri_to_natural(mh_ctx* c, const u64* ev, int log_rows, int cbits, u64* out);
 u64 fri_grind(mh_ctx* c, const u64 st[12], const u64* in, int n_in, int bits);

@@ -21,6 +21,7 @@
 #include "poseidon2_fast.cuh"
 #include "gl.cuh"
 #include <algorithm>
+#include <cstring>
 
 static constexpr int LEAF_MAX_MATS = 8;
 static constexpr int LEAF_THREADS = 256;
@@ -265,37 +266,56 @@ __global__ void k_gather(const u64* const* __restrict__ ptrs, u64* __restrict__ 
 }
 
 void lmcs_open(mh_ctx* c, const mh_tree* t, const std::vector<size_t>& idx, size_t alignment, std::vector<u64>& fields,
-               std::vector<u64>& commitments) {
-  const int lb = t->log_blowup;
+               std::vector<u64>& commitments, const Dist* dist) {
+  // Sharded proofs: every opened value lives on exactly one rank (rows: the rank that stores the coset;
+  // tree nodes: the rank whose row range covers them; the cap: known to all).  Each rank gathers what
+  // it owns, leaves zeros elsewhere, and one all-reduce (sum) assembles the identical answer everywhere.
+  const bool distributed = dist && dist->on();
+  const bool i_contribute = !distributed || t->shard_logG > 0 || dist->rank == 0;  // unsharded tree in a sharded proof: rank 0
+  const int lb = t->log_blowup, G = t->shard_logG;
+  const int full_height = t->log_height + G;
   const size_t Bm = ((size_t)1 << lb) - 1;
   std::vector<const u64*> ptrs;
   for (size_t i : idx) {
-    MH_REQUIRE(i < ((size_t)1 << t->log_height), "opening index out of range");
+    MH_REQUIRE(i < ((size_t)1 << full_height), "opening index out of range");
     size_t j = i & Bm, r = i >> lb;
     if (t->fri_log_rows >= 0) {
       // FRI round tree: the leaf row is the arity-coset of EF values, bit-reversed inside the row
       // (fri/prover.rs:117-142), flattened [c0, c1]; FRI trees are unaligned (build_tree).
       const int log_q = t->fri_log_rows - t->fri_log_arity;
+      const bool mine = i_contribute && j >= t->fri_coset0 && j < t->fri_coset0 + ((size_t)1 << t->fri_log_cosets);
       for (u32 p = 0; p < (1u << t->fri_log_arity); p++) {
-        size_t e = (j << t->fri_log_rows) + r + ((size_t)bitrev32(p, t->fri_log_arity) << log_q);
-        ptrs.push_back(t->fri_layer.u() + 2 * e);
-        ptrs.push_back(t->fri_layer.u() + 2 * e + 1);
+        size_t e = ((j - t->fri_coset0) << t->fri_log_rows) + r + ((size_t)bitrev32(p, t->fri_log_arity) << log_q);
+        ptrs.push_back(mine ? t->fri_layer.u() + 2 * e : nullptr);
+        ptrs.push_back(mine ? t->fri_layer.u() + 2 * e + 1 : nullptr);
       }
       continue;
     }
     for (const LdeMatrix& m : t->mats) {
       size_t N = (size_t)1 << m.log_n;
       size_t rm = r & (N - 1);
-      for (size_t cidx = 0; cidx < m.width; cidx++) ptrs.push_back(m.lde.u() + (((cidx << lb) + j) << m.log_n) + rm);
+      const bool mine = i_contribute && j >= m.coset0 && j < m.coset0 + ((size_t)1 << m.log_cosets);
+      for (size_t cidx = 0; cidx < m.width; cidx++)
+        ptrs.push_back(mine ? m.lde.u() + (((cidx << m.log_cosets) + (j - m.coset0)) << m.log_n) + rm : nullptr);
       size_t padded = (m.width + alignment - 1) / alignment * alignment;
       for (size_t k = m.width; k < padded; k++) ptrs.push_back(nullptr);
     }
   }
   const size_t n_fields = ptrs.size();
-  auto sib = lmcs_missing_siblings(idx, t->log_height);
+  auto sib = lmcs_missing_siblings(idx, full_height);
+  std::vector<std::pair<size_t, const u64*>> cap_fill;  // (output position, host digest)
   for (auto& s : sib) {
-    const u64* p = t->nodes.u() + 4 * (t->layer_off[s.first] + t->node_slot(s.first, s.second));
-    for (int k = 0; k < 4; k++) ptrs.push_back(p + k);
+    const int d = s.first;
+    const size_t p = s.second;
+    if (G > 0 && d <= G) {
+      cap_fill.emplace_back(ptrs.size(), t->cap.data() + 4 * ((((size_t)1) << d) - 1 + p));
+      for (int k = 0; k < 4; k++) ptrs.push_back(nullptr);
+      continue;
+    }
+    const bool mine = i_contribute && (G == 0 || (p >> (d - G)) == (size_t)t->shard_rank);
+    const size_t pl = G ? (p & ((((size_t)1) << (d - G)) - 1)) : p;
+    const u64* q = t->nodes.u() + 4 * (t->layer_off[d - G] + t->node_slot(d - G, pl));
+    for (int k = 0; k < 4; k++) ptrs.push_back(mine ? q + k : nullptr);
   }
   const size_t n = ptrs.size();
   fields.clear();
@@ -304,9 +324,54 @@ void lmcs_open(mh_ctx* c, const mh_tree* t, const std::vector<size_t>& idx, size
   DevBuf dptrs(n * 8), dout(n * 8);
   HIP_CHECK(hipMemcpyAsync(dptrs.p, ptrs.data(), n * 8, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const u64* const*)dptrs.p, dout.u(), n);
+  if (distributed) dist->all_reduce_sum(c, dout.u(), n);
   std::vector<u64> host(n);
   HIP_CHECK(hipMemcpyAsync(host.data(), dout.p, n * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_CHECK(hipStreamSynchronize(c->stream));
+  for (auto& cf : cap_fill)
+    for (int k = 0; k < 4; k++) host[cf.first + k] = cf.second[k];
   fields.assign(host.begin(), host.begin() + n_fields);
   commitments.assign(host.begin() + n_fields, host.end());
+}
+
+// [2^lbl][2^log_rows] digests -> [G][2^lbl][rows/G]: the block of every destination rank contiguous
+__global__ void k_repack_digests(const ulonglong2* __restrict__ in, ulonglong2* __restrict__ out, int lbl, int log_rows, int logG) {
+  const size_t total = (size_t)1 << (lbl + log_rows);
+  const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (q >= total) return;
+  const int log_rl = log_rows - logG;
+  const size_t jl = q >> log_rows, r = q & (((size_t)1 << log_rows) - 1);
+  const size_t d = r >> log_rl, rr = r & (((size_t)1 << log_rl) - 1);
+  const size_t o = (((d << lbl) + jl) << log_rl) + rr;
+  out[2 * o] = in[2 * q];
+  out[2 * o + 1] = in[2 * q + 1];
+}
+
+void lmcs_build_sharded(mh_ctx* c, mh_tree* t, const Dist& dist, const u64* local_digests, int log_rows) {
+  const int G = dist.logG, lb = t->log_blowup, lbl = lb - G;
+  MH_REQUIRE(G > 0 && lbl >= 0 && log_rows >= G, "internal: bad sharded tree shape");
+  const size_t local = (size_t)1 << (lbl + log_rows);
+  DevBuf packed(local * 32);
+  hipLaunchKernelGGL(k_repack_digests, dim3((unsigned)((local + 255) / 256)), dim3(256), 0, c->stream,
+                     (const ulonglong2*)local_digests, (ulonglong2*)packed.p, lbl, log_rows, G);
+  lmcs_alloc_layers(t, log_rows - G + lb);
+  dist.all_to_all(c, packed.p, lmcs_leaf_layer(t), (local >> G) * 32);
+  lmcs_compress_layers(c, t);  // subroot in t->root and at layer 0 of t->nodes
+  DevBuf all((size_t)32 << G);
+  dist.all_gather(c, t->nodes.u() + 4 * t->layer_off[0], all.p, 32);
+  const size_t Gn = (size_t)1 << G;
+  t->cap.assign(4 * (2 * Gn - 1), 0);
+  HIP_CHECK(hipMemcpyAsync(t->cap.data() + 4 * (Gn - 1), all.p, 32 * Gn, hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  for (int d = G - 1; d >= 0; d--)
+    for (size_t p = 0; p < ((size_t)1 << d); p++) {
+      u64 st[12] = {0};
+      const u64* l = t->cap.data() + 4 * ((((size_t)2) << d) - 1 + 2 * p);
+      for (int k = 0; k < 8; k++) st[k] = l[k];
+      p2_permute(st);
+      memcpy(t->cap.data() + 4 * ((((size_t)1) << d) - 1 + p), st, 32);
+    }
+  memcpy(t->root, t->cap.data(), 32);
+  t->shard_logG = G;
+  t->shard_rank = dist.rank;
 }

@@ -58,6 +58,29 @@ mh_trace* trace_zeros(mh_ctx* c, int log_n, size_t width) {
   return t.release();
 }
 
+// ---- collectives of a sharded proof ------------------------------------------------------------------
+void Dist::all_to_all(mh_ctx* c, const void* send, void* recv, size_t bytes_per_peer) const {
+  c->sync();
+  if (!on()) {
+    HIP_CHECK(hipMemcpy(recv, send, bytes_per_peer, hipMemcpyDeviceToDevice));
+    return;
+  }
+  MH_REQUIRE(comm->all_to_all(comm->user, send, recv, bytes_per_peer) == 0, "all_to_all callback failed");
+}
+void Dist::all_gather(mh_ctx* c, const void* send, void* recv, size_t bytes_per_rank) const {
+  c->sync();
+  if (!on()) {
+    HIP_CHECK(hipMemcpy(recv, send, bytes_per_rank, hipMemcpyDeviceToDevice));
+    return;
+  }
+  MH_REQUIRE(comm->all_gather(comm->user, send, recv, bytes_per_rank) == 0, "all_gather callback failed");
+}
+void Dist::all_reduce_sum(mh_ctx* c, u64* buf, size_t n) const {
+  if (!on()) return;
+  c->sync();
+  MH_REQUIRE(comm->all_reduce_sum_u64(comm->user, buf, n) == 0, "all_reduce callback failed");
+}
+
 // LDE of one uploaded trace into coset-major layout on the canonical shift of its own LDE order;
 // only cosets [first, first + count) are produced (all of them for a single-GPU commitment).
 LdeMatrix lde_trace_cosets(mh_ctx* c, const mh_trace* tr, int lb, size_t first, size_t count) {
@@ -65,7 +88,9 @@ LdeMatrix lde_trace_cosets(mh_ctx* c, const mh_trace* tr, int lb, size_t first, 
   m.log_n = tr->log_n; m.width = tr->width;
   size_t N = (size_t)1 << tr->log_n;
   MH_REQUIRE(tr->log_n + lb <= 32, "LDE order exceeds the field's two-adicity");
-  MH_REQUIRE(count > 0 && first + count <= ((size_t)1 << lb), "coset range out of bounds");
+  MH_REQUIRE(count > 0 && (count & (count - 1)) == 0 && first + count <= ((size_t)1 << lb), "coset range out of bounds");
+  m.coset0 = first;
+  while (((size_t)1 << m.log_cosets) < count) m.log_cosets++;
   m.lde.alloc(N * count * tr->width * 8);
   DevBuf scratch(N * tr->width * 8);
   std::vector<u64> all = coset_shifts(tr->log_n, lb);
@@ -81,6 +106,20 @@ mh_tree* commit_traces(mh_ctx* c, const std::vector<const mh_trace*>& traces, in
   t->ctx = c; t->log_blowup = log_blowup;
   for (const mh_trace* tr : traces) t->mats.push_back(lde_trace(c, tr, log_blowup));
   lmcs_build_tree(c, t.get());
+  return t.release();
+}
+
+// commit_traces of a sharded proof: this rank's cosets only, then the digest exchange.
+static mh_tree* commit_traces_dist(mh_ctx* c, const std::vector<const mh_trace*>& traces, int lb, const Dist& dist) {
+  if (!dist.on()) return commit_traces(c, traces, lb);
+  std::unique_ptr<mh_tree> t(new mh_tree());
+  t->ctx = c; t->log_blowup = lb;
+  const size_t per = (size_t)1 << (lb - dist.logG);
+  for (const mh_trace* tr : traces) t->mats.push_back(lde_trace_cosets(c, tr, lb, (size_t)dist.rank * per, per));
+  const int log_n = t->mats.back().log_n;
+  DevBuf dig((per << log_n) * 32);
+  lmcs_hash_leaves(c, t->mats, lb - dist.logG, dig.u());
+  lmcs_build_sharded(c, t.get(), dist, dig.u(), log_n);
   return t.release();
 }
 
@@ -122,7 +161,7 @@ static int fri_num_rounds(const mh_pcs_params& p, int log_lde) {
 
 static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* const* airs_in, mh_trace* const* traces_in,
                        const u64* publics_in, size_t n_publics, const u64 init_state[12], const u64* pre_observe, size_t n_pre,
-                       mh_aux_builder cb, void* user, mh_proof& proof) {
+                       mh_aux_builder cb, void* user, mh_proof& proof, const Dist& dist) {
   MH_REQUIRE(n_airs > 0 && n_airs <= 256, "need between 1 and 256 AIR instances");
   const int lb = pp.log_blowup;
   MH_REQUIRE(lb > 0 && lb <= 8, "log_blowup must be in 1..8");
@@ -153,6 +192,16 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
   MH_REQUIRE(logD <= lb, "constraint degree too high for the blowup");
   const size_t D = (size_t)1 << logD;
   std::vector<u64> publics(publics_in, publics_in + n_publics);
+  if (dist.on()) {
+    MH_REQUIRE(dist.logG <= lb && dist.logG <= logD, "more ranks than cosets / quotient chunks");
+    for (int i = 0; i < n_airs; i++) {
+      MH_REQUIRE(airs_in[i]->log_quotient_degree == logD, "sharded proofs need one quotient degree for every AIR");
+      MH_REQUIRE(lhs[i] >= dist.logG, "trace shorter than the number of ranks");
+    }
+  }
+  const int lbl = lb - dist.logG;                    // coset bits stored on this rank
+  const size_t B_loc = (size_t)1 << lbl, coset0 = (size_t)dist.rank * B_loc;
+  const size_t D_loc = D >> dist.logG;               // quotient chunks owned by this rank
 
   HostTranscript tr;
   for (int i = 0; i < 12; i++) tr.ch.st[i] = gl_canon(init_state[i]);
@@ -163,7 +212,7 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
   // ---- 1. main commitment ----
   std::vector<const mh_trace*> main_tr;
   for (int j = 0; j < n_airs; j++) main_tr.push_back(traces_in[order[j]]);
-  std::unique_ptr<mh_tree> main_tree(commit_traces(c, main_tr, lb));
+  std::unique_ptr<mh_tree> main_tree(commit_traces_dist(c, main_tr, lb, dist));
   tr.send_commitment(main_tree->root);
 
   // ---- 2. randomness, aux traces (instance order), aux commitment ----
@@ -192,7 +241,7 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
   }
   std::vector<const mh_trace*> aux_po;
   for (int j = 0; j < n_airs; j++) aux_po.push_back(aux_tr[order[j]].get());
-  std::unique_ptr<mh_tree> aux_tree(commit_traces(c, aux_po, lb));
+  std::unique_ptr<mh_tree> aux_tree(commit_traces_dist(c, aux_po, lb, dist));
   tr.send_commitment(aux_tree->root);
   aux_tr.clear();
   for (int j = 0; j < n_airs; j++)
@@ -206,13 +255,13 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
   for (int j = 0; j < n_airs; j++) {
     const mh_air* a = airs_in[order[j]];
     const int ln = lhs[order[j]];
-    DevBuf out(((size_t)2 * D << ln) * 8);
+    DevBuf out(((size_t)2 * D_loc << ln) * 8);
     std::vector<e2> rnd(randomness.begin(), randomness.begin() + a->num_randomness);
     const int logDj = a->log_quotient_degree;
     if (logDj == logD) {
       quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], lb, logD, publics, rnd, aux_vals[order[j]], alpha,
                                j ? acc.u() : nullptr, log_n_prev, beta, out.u());
-    } else {  // native coset of n*Dj points, then upsample to n*D (prover/mod.rs:520-528)
+    } else {  // native coset of n*Dj points, then upsample to n*D (prover/mod.rs:520-528); single GPU only
       DevBuf small(((size_t)2 << (logDj + ln)) * 8);
       quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], lb, logDj, publics, rnd, aux_vals[order[j]], alpha, nullptr,
                                0, beta, small.u());
@@ -223,23 +272,43 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
   }
 
   // ---- 5. quotient commitment (quotient.rs:143-217): chunk t = columns 2t, 2t+1 ----
+  // acc holds this rank's chunks as evaluations on the cosets g*w_J^t*H: inverse NTT in place, gather
+  // every chunk's coefficients (sharded proofs: 16 B * N per chunk), forward NTT onto the local cosets.
   std::unique_ptr<mh_tree> quot_tree(new mh_tree());
   quot_tree->ctx = c; quot_tree->log_blowup = lb;
   {
     LdeMatrix qm;
     qm.log_n = log_N; qm.width = 2 * D;
-    qm.lde.alloc((N << lb) * 2 * D * 8);
-    DevBuf scratch(2 * N * 8);
+    qm.log_cosets = lbl; qm.coset0 = coset0;
+    qm.lde.alloc(N * B_loc * 2 * D * 8);
     const u64 g = gl_lde_shift(L);
     const u64 wJ = gl_two_adic_generator(log_N + logD);
-    const std::vector<u64> outs = coset_shifts(log_N, lb);
+    const std::vector<u64> all_outs = coset_shifts(log_N, lb);
+    DevBuf gathered;
+    const u64* coef = acc.u();
     {
-      ProfScope ps(c, "lde", (double)(1 + (1 << lb)) * N * 2 * D * 8.0);
-      for (size_t t = 0; t < D; t++)
-        lde_columns(c, acc.u() + 2 * t * N, 2, log_N, gl_mul(g, gl_pow(wJ, t)), outs, qm.lde.u() + 2 * t * B * N, scratch.u());
+      ProfScope ps(c, "lde", (double)(1 + B_loc) * N * 2 * D * 8.0);
+      ntt_inverse_dif_inplace(c, acc.u(), 2 * D_loc, log_N);
+      if (dist.on()) {
+        gathered.alloc(2 * D * N * 8);
+        dist.all_gather(c, acc.u(), gathered.p, 2 * D_loc * N * 8);
+        coef = gathered.u();
+      }
+      for (size_t t = 0; t < D; t++) {
+        const u64 in_inv = gl_inv(gl_mul(g, gl_pow(wJ, t)));
+        std::vector<u64> bases(B_loc);
+        for (size_t z = 0; z < B_loc; z++) bases[z] = gl_mul(all_outs[coset0 + z], in_inv);
+        ntt_forward_cosets(c, coef + 2 * t * N, 2, log_N, bases, qm.lde.u() + 2 * t * B_loc * N);
+      }
     }
     quot_tree->mats.push_back(std::move(qm));
-    lmcs_build_tree(c, quot_tree.get());
+    if (dist.on()) {
+      DevBuf dig((B_loc << log_N) * 32);
+      lmcs_hash_leaves(c, quot_tree->mats, lbl, dig.u());
+      lmcs_build_sharded(c, quot_tree.get(), dist, dig.u(), log_N);
+    } else {
+      lmcs_build_tree(c, quot_tree.get());
+    }
   }
   acc.release();
   tr.send_commitment(quot_tree->root);
@@ -295,56 +364,90 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
       pw = e2_mul(pw, alpha_d);
     }
   }
-  DevBuf layer((N << lb) * 16);
+  DevBuf layer((N << lbl) * 16);
   deep_assemble(c, mats, coef_off, log_N, lb, negc, z, z_next, fred0, fred1, beta_d, layer.u());
 
   // ---- 8. FRI commit phase ----
   const int la = pp.log_folding_arity;
   const int rounds = fri_num_rounds(pp, L);
   std::vector<std::unique_ptr<mh_tree>> fri_trees;
-  int log_rows = log_N, cbits = lb;
+  // cbits = coset bits of the whole layer, cb_loc = those stored on this rank (cosets fri_c0 ..)
+  int log_rows = log_N, cbits = lb, cb_loc = lbl;
+  size_t fri_c0 = coset0;
+  bool sharded = dist.on();
   for (int r = 0; r < rounds; r++) {
+    if (sharded && log_rows - la < dist.logG) {
+      // fewer leaf rows per coset than ranks: the row-range split of the tree is over; every rank takes
+      // the whole (small) layer and continues redundantly
+      DevBuf full(((size_t)1 << (log_rows + cbits)) * 16);
+      dist.all_gather(c, layer.p, full.p, ((size_t)1 << (log_rows + cb_loc)) * 16);
+      layer = std::move(full);
+      cb_loc = cbits;
+      fri_c0 = 0;
+      sharded = false;
+    }
     if (log_rows < la) {  // tiny layer: fewer than `arity` rows per coset -> single-coset (natural) layout
+      MH_REQUIRE(!sharded, "internal: sharded FRI layer shorter than the arity");
       DevBuf nat(((size_t)1 << (log_rows + cbits)) * 16);
       fri_to_natural(c, layer.u(), log_rows, cbits, nat.u());
       c->sync();
       layer = std::move(nat);
       log_rows += cbits;
       cbits = 0;
+      cb_loc = 0;
     }
     std::unique_ptr<mh_tree> t(new mh_tree());
     t->ctx = c; t->log_blowup = cbits;
     t->fri_log_rows = log_rows; t->fri_log_arity = la;
-    lmcs_alloc_layers(t.get(), log_rows + cbits - la);
-    fri_leaf_hash(c, layer.u(), log_rows, cbits, la, lmcs_leaf_layer(t.get()));
-    lmcs_compress_layers(c, t.get());
+    t->fri_log_cosets = cb_loc; t->fri_coset0 = fri_c0;
+    if (sharded) {
+      DevBuf dig(((size_t)1 << (log_rows - la + cb_loc)) * 32);
+      fri_leaf_hash(c, layer.u(), log_rows, cb_loc, la, dig.u());
+      lmcs_build_sharded(c, t.get(), dist, dig.u(), log_rows - la);
+    } else {
+      lmcs_alloc_layers(t.get(), log_rows + cbits - la);
+      fri_leaf_hash(c, layer.u(), log_rows, cbits, la, lmcs_leaf_layer(t.get()));
+      lmcs_compress_layers(c, t.get());
+    }
     tr.send_commitment(t->root);
     do_grind(c, tr, pp.folding_pow_bits);
     const e2 fb = tr.ch.sample_ef();
-    DevBuf next(((size_t)1 << (log_rows + cbits - la)) * 16);
-    fri_fold(c, layer.u(), log_rows, cbits, la, fb, next.u());
+    DevBuf next(((size_t)1 << (log_rows + cb_loc - la)) * 16);
+    fri_fold(c, layer.u(), log_rows, cb_loc, cbits, fri_c0, la, fb, next.u());
     t->fri_layer = std::move(layer);
     layer = std::move(next);
     log_rows -= la;
     fri_trees.push_back(std::move(t));
   }
   {
-    // final polynomial (fri/prover.rs:212-239): evaluations on the order-fpd subgroup = natural indices
-    // i = r * (n_f / fpd); interpolate on the host, send in descending degree order.
+    // final polynomial (fri/prover.rs:212-239): it has degree < fpd = n_f / B, so the fpd evaluations
+    // on ONE coset s*<w_fpd> of the final layer determine it (s = w_{n_f}^(first local coset); s = 1 on
+    // a single GPU = the reference's first fpd bit-reversed entries).  Interpolate on the host, undo
+    // the shift, send in descending degree order.
     const int logn_f = log_rows + cbits;
     const int log_fpd = std::max(0, logn_f - lb);
-    const size_t n_f = (size_t)1 << logn_f, fpd = (size_t)1 << log_fpd;
-    std::vector<u64> host(2 * n_f);
-    HIP_CHECK(hipMemcpyAsync(host.data(), layer.p, n_f * 16, hipMemcpyDeviceToHost, c->stream));
+    const size_t fpd = (size_t)1 << log_fpd;
+    const size_t n_loc = (size_t)1 << (log_rows + cb_loc);
+    std::vector<u64> host(2 * n_loc);
+    HIP_CHECK(hipMemcpyAsync(host.data(), layer.p, n_loc * 16, hipMemcpyDeviceToHost, c->stream));
     c->sync();
     std::vector<e2> vals(fpd);
-    for (size_t r = 0; r < fpd; r++) {
-      size_t i = r << (logn_f - log_fpd);
-      size_t slot = ((i & (((size_t)1 << cbits) - 1)) << log_rows) + (i >> cbits);
-      vals[r] = e2{host[2 * slot], host[2 * slot + 1]};
+    u64 s_shift = 1;
+    if (sharded) {
+      MH_REQUIRE(cbits == lb && fpd == ((size_t)1 << log_rows), "internal: final layer shape");
+      for (size_t r = 0; r < fpd; r++) vals[r] = e2{host[2 * r], host[2 * r + 1]};  // first local coset
+      s_shift = gl_pow(gl_two_adic_generator(logn_f), fri_c0);
+    } else {
+      for (size_t r = 0; r < fpd; r++) {
+        size_t i = r << (logn_f - log_fpd);
+        size_t slot = ((i & (((size_t)1 << cbits) - 1)) << log_rows) + (i >> cbits);
+        vals[r] = e2{host[2 * slot], host[2 * slot + 1]};
+      }
     }
     const u64 w_inv = gl_inv(gl_two_adic_generator(log_fpd)), n_inv = gl_inv((u64)fpd);
+    const u64 s_inv = gl_inv(s_shift);
     std::vector<e2> coef(fpd);
+    u64 sk = 1;
     for (size_t k = 0; k < fpd; k++) {
       e2 s = e2_make(0);
       u64 wk = gl_pow(w_inv, k), x = 1;
@@ -352,7 +455,8 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
         s = e2_add(s, e2_mulf(vals[r], x));
         x = gl_mul(x, wk);
       }
-      coef[k] = e2_mulf(s, n_inv);
+      coef[k] = e2_mulf(s, gl_mul(n_inv, sk));
+      sk = gl_mul(sk, s_inv);
     }
     for (size_t k = fpd; k-- > 0;) tr.send_ef(coef[k]);
   }
@@ -365,7 +469,7 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
   idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
   for (const mh_tree* t : {main_tree.get(), aux_tree.get(), quot_tree.get()}) {
     std::vector<u64> f, cm;
-    lmcs_open(c, t, idx, 8, f, cm);
+    lmcs_open(c, t, idx, 8, f, cm, &dist);
     tr.hint_fields(f);
     tr.hint_commitments(cm);
   }
@@ -377,7 +481,7 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
     std::sort(idx.begin(), idx.end());
     idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
     std::vector<u64> f, cm;
-    lmcs_open(c, t.get(), idx, 1, f, cm);
+    lmcs_open(c, t.get(), idx, 1, f, cm, &dist);
     tr.hint_fields(f);
     tr.hint_commitments(cm);
   }
@@ -505,7 +609,29 @@ int mh_prove(mh_ctx* c, const mh_pcs_params* params, int n_airs, mh_air* const* 
   HIP_CHECK(hipSetDevice(c->device));
   std::unique_ptr<mh_proof> p(new mh_proof());
   prove_impl(c, *params, n_airs, airs, traces, public_values, n_public_values, challenger_state, pre_observe, n_pre_observe,
-             aux_builder, user, *p);
+             aux_builder, user, *p, Dist{});
+  *out = p.release();
+  MH_CATCH
+}
+
+int mh_prove_sharded(mh_ctx* c, const mh_comm* comm, const mh_pcs_params* params, int n_airs, mh_air* const* airs,
+                     mh_trace* const* traces, const uint64_t* public_values, size_t n_public_values,
+                     const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe,
+                     mh_aux_builder aux_builder, void* user, mh_proof** out) {
+  MH_TRY(c)
+  MH_REQUIRE(c && comm && params && airs && traces && challenger_state && out, "null argument");
+  MH_REQUIRE(public_values || !n_public_values, "null public values");
+  MH_REQUIRE(pre_observe || !n_pre_observe, "null pre_observe");
+  MH_REQUIRE(comm->world >= 1 && (comm->world & (comm->world - 1)) == 0 && comm->rank >= 0 && comm->rank < comm->world,
+             "world must be a power of two and 0 <= rank < world");
+  MH_REQUIRE(comm->world == 1 || (comm->all_to_all && comm->all_gather && comm->all_reduce_sum_u64), "missing collective callbacks");
+  HIP_CHECK(hipSetDevice(c->device));
+  Dist d;
+  d.comm = comm; d.rank = comm->rank; d.world = comm->world;
+  while ((1 << d.logG) < d.world) d.logG++;
+  std::unique_ptr<mh_proof> p(new mh_proof());
+  prove_impl(c, *params, n_airs, airs, traces, public_values, n_public_values, challenger_state, pre_observe, n_pre_observe,
+             aux_builder, user, *p, d);
   *out = p.release();
   MH_CATCH
 }

@@ -22,9 +22,10 @@ struct QuotArgs {
   u32 n_ins, n_slots;
   const u64* main_lde;
   const u64* aux_lde;
-  int log_n, log_blowup, log_d;
+  int log_n, log_cosets, log_d, log_dl, jc_shift;  // log_d: quotient degree; log_dl: quotient cosets on this rank
+  u32 t0;                // global index of this rank's first quotient coset
   const u64* tw;         // w_n^k (k < n/2)
-  const u64* coset_tab;  // [3][D]: x-coordinate of coset t at r = 0, Z_H on coset t, 1/Z_H
+  const u64* coset_tab;  // [3][Dl]: x-coordinate of local coset t at r = 0, Z_H on it, 1/Z_H
   u64 wh_inv;
   const u64* inv_first;  // [D*n] 1/(x-1)      (null when the AIR never asks)
   const u64* inv_last;   // [D*n] 1/(x-w_H^-1)
@@ -50,13 +51,13 @@ __global__ __launch_bounds__(256) void k_eval_quotient(QuotArgs a) {
   extern __shared__ u64 slots[];
   const u32 T = blockDim.x, tid = threadIdx.x;
   const size_t n = (size_t)1 << a.log_n;
-  const size_t D = (size_t)1 << a.log_d;
+  const size_t D = (size_t)1 << a.log_d, Dl = (size_t)1 << a.log_dl;
   const size_t q = blockIdx.x * (size_t)T + tid;
-  if (q >= n * D) return;
-  const size_t t = q >> a.log_n, r = q & (n - 1);
+  if (q >= n * Dl) return;
+  const size_t t = q >> a.log_n, r = q & (n - 1);  // t: local quotient coset
   const size_t r_next = (r + 1) & (n - 1);
-  const size_t jc = t << (a.log_blowup - a.log_d);
-  const size_t B = (size_t)1 << a.log_blowup;
+  const size_t jc = t << a.jc_shift;               // local index of the LDE coset it lives on
+  const size_t B = (size_t)1 << a.log_cosets;
   const u64 x = coset_point(a.tw, a.log_n, a.coset_tab[t], r);
   e2 acc = e2_make(0);
 #define SLOT0(s) slots[(size_t)(2 * (s)) * T + tid]
@@ -75,9 +76,9 @@ __global__ __launch_bounds__(256) void k_eval_quotient(QuotArgs a) {
         break;
       }
       case DOP_PUBLIC: v = e2_make(a.publics[ins.b]); break;
-      case DOP_PERIODIC: v = e2_make(a.periodic[(size_t)ins.b * a.periodic_rows + ((r * D + t) % a.periodic_rows)]); break;
-      case DOP_IS_FIRST: v = e2_make(gl_mul(a.coset_tab[D + t], a.inv_first[q])); break;
-      case DOP_IS_LAST: v = e2_make(gl_mul(a.coset_tab[D + t], a.inv_last[q])); break;
+      case DOP_PERIODIC: v = e2_make(a.periodic[(size_t)ins.b * a.periodic_rows + ((r * D + a.t0 + t) % a.periodic_rows)]); break;
+      case DOP_IS_FIRST: v = e2_make(gl_mul(a.coset_tab[Dl + t], a.inv_first[q])); break;
+      case DOP_IS_LAST: v = e2_make(gl_mul(a.coset_tab[Dl + t], a.inv_last[q])); break;
       case DOP_IS_TRANSITION: v = e2_make(gl_sub(x, a.wh_inv)); break;
       case DOP_RANDOMNESS: v = e2{a.randomness[2 * ins.b], a.randomness[2 * ins.b + 1]}; break;
       case DOP_AUX_VALUE: v = e2{a.aux_values[2 * ins.b], a.aux_values[2 * ins.b + 1]}; break;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void k_eval_quotient(QuotArgs a) {
   }
 #undef SLOT0
 #undef SLOT1
-  e2 qv = e2_mulf(acc, a.coset_tab[2 * D + t]);  // * 1/Z_H
+  e2 qv = e2_mulf(acc, a.coset_tab[2 * Dl + t]);  // * 1/Z_H
   if (a.acc_in) {
     const size_t n_prev = (size_t)1 << a.log_n_prev;
     const size_t rp = r & (n_prev - 1);
@@ -165,17 +166,24 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
                               const std::vector<u64>& publics, const std::vector<e2>& randomness, const std::vector<e2>& aux_values,
                               e2 alpha, const u64* acc_in, int log_n_prev, e2 beta, u64* acc_out) {
   const int log_n = main.log_n;
-  const size_t n = (size_t)1 << log_n, D = (size_t)1 << log_d, B = (size_t)1 << log_blowup;
+  const size_t n = (size_t)1 << log_n, Dg = (size_t)1 << log_d, B = (size_t)1 << log_blowup;
   MH_REQUIRE(log_d <= log_blowup, "quotient degree exceeds blowup");
+  // this rank stores 2^log_cosets of the 2^log_blowup cosets: it evaluates the quotient cosets among them
+  const int G = log_blowup - main.log_cosets;
+  MH_REQUIRE(G >= 0 && log_d >= G && aux.log_cosets == main.log_cosets && aux.coset0 == main.coset0,
+             "quotient degree smaller than the number of ranks");
+  const int log_dl = log_d - G;
+  const size_t D = (size_t)1 << log_dl;  // local quotient cosets
+  const size_t t0 = main.coset0 >> (log_blowup - log_d);
   const int L = log_n + log_blowup;
   const u64 g = gl_lde_shift(L), wK = gl_two_adic_generator(L);
   // per-coset tables
   std::vector<u64> tab(3 * D);
   const u64 g_pow_n = gl_exp_pow2(g, log_n);
   const u64 wd = gl_two_adic_generator(log_d);
-  u64 wt = 1;
+  u64 wt = gl_pow(wd, t0);
   for (size_t t = 0; t < D; t++) {
-    tab[t] = gl_mul(g, gl_pow(wK, t * (B / D)));
+    tab[t] = gl_mul(g, gl_pow(wK, (t0 + t) * (B / Dg)));
     u64 zh = gl_sub(gl_mul(g_pow_n, wt), 1);
     tab[D + t] = zh;
     tab[2 * D + t] = gl_inv(zh);
@@ -194,7 +202,7 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
   }
   // periodic table on the quotient coset (prover/periodic.rs:49-77), O(P^2 D) on the host
   const size_t Pm = air->max_period();
-  const size_t prow = Pm ? Pm * D : 1;
+  const size_t prow = Pm ? Pm * Dg : 1;
   std::vector<u64> ptab(std::max<size_t>(1, air->periodic.size() * prow));
   if (Pm) {
     int logP = 0;
@@ -254,7 +262,7 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
     inv_last.alloc(n * D * 8);
     ProfScope ps(c, "quotient_selectors", 16.0 * n * D);
     hipLaunchKernelGGL(k_selector_inverses, dim3((unsigned)((n * D + 1023) / 1024)), dim3(256), 0, c->stream, tw, dblob.u() + o_tab,
-                       log_n, log_d, wh_inv, inv_first.u(), inv_last.u());
+                       log_n, log_dl, wh_inv, inv_first.u(), inv_last.u());
   }
   QuotArgs a{};
   a.code = (const AirIns*)air->d_code.p;
@@ -262,7 +270,9 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
   a.n_slots = air->n_slots;
   a.main_lde = main.lde.u();
   a.aux_lde = aux.lde.u();
-  a.log_n = log_n; a.log_blowup = log_blowup; a.log_d = log_d;
+  a.log_n = log_n; a.log_cosets = main.log_cosets; a.log_d = log_d; a.log_dl = log_dl;
+  a.jc_shift = log_blowup - log_d;
+  a.t0 = (u32)t0;
   a.tw = tw;
   a.coset_tab = dblob.u() + o_tab;
   a.wh_inv = wh_inv;

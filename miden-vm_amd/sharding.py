@@ -107,3 +107,102 @@ class ShardedCommit:
             self.free()
         except Exception:
             pass
+
+
+# ---- whole proofs sharded over ranks: the three collectives of include/midenhip.h `mh_comm` --------------
+class MhComm(C.Structure):
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("user", C.c_void_p),
+                ("all_to_all", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)),
+                ("all_gather", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)),
+                ("all_reduce_sum_u64", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t))]
+
+
+class TorchComm:
+    """mh_comm implemented with torch.distributed on zero-copy views of the library's device buffers.
+    backend nccl (= RCCL over xGMI): collectives run on the GPU; backend gloo (single-GPU test boxes,
+    several ranks sharing one device): staged through host memory."""
+
+    def __init__(self, rank, world, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.staged = world > 1 and dist.get_backend(group) == "gloo"
+        a2a_t, ag_t, ar_t = (MhComm._fields_[3][1], MhComm._fields_[4][1], MhComm._fields_[5][1])
+        self._cbs = (a2a_t(self._all_to_all), ag_t(self._all_gather), ar_t(self._all_reduce))
+        self.struct = MhComm(rank, world, None, *self._cbs)
+
+    def _wrap(self, fn):
+        try:
+            fn()
+            torch.cuda.synchronize()
+            return 0
+        except Exception as e:  # pragma: no cover
+            print("collective failed:", repr(e))
+            return 1
+
+    def _all_to_all(self, user, send, recv, bytes_per_peer):
+        def go():
+            n = bytes_per_peer // 8 * self.world
+            s, r = device_tensor(send, n), device_tensor(recv, n)
+            if self.staged:
+                hs, hr = s.cpu(), torch.empty(n, dtype=torch.int64)
+                dist.all_to_all_single(hr, hs, group=self.group)
+                r.copy_(hr)
+            else:
+                dist.all_to_all_single(r, s, group=self.group)
+        return self._wrap(go)
+
+    def _all_gather(self, user, send, recv, bytes_per_rank):
+        def go():
+            n = bytes_per_rank // 8
+            s, r = device_tensor(send, n), device_tensor(recv, n * self.world)
+            if self.staged:
+                hs = s.cpu()
+                out = [torch.empty(n, dtype=torch.int64) for _ in range(self.world)]
+                dist.all_gather(out, hs, group=self.group)
+                r.copy_(torch.cat(out))
+            else:
+                dist.all_gather_into_tensor(r, s, group=self.group)
+        return self._wrap(go)
+
+    def _all_reduce(self, user, buf, n):
+        def go():
+            t = device_tensor(buf, n)
+            if self.staged:
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return self._wrap(go)
+
+
+def prove_sharded(pkg, ctx, comm, airs, traces, public_values, params, challenger_state, pre_observe, aux_builder=None):
+    """mh_prove_sharded: same arguments as pkg.prove plus the communicator; every rank gets the proof."""
+    n = len(airs)
+    a_arr = (C.c_void_p * n)(*[a.h for a in airs])
+    t_arr = (C.c_void_p * n)(*[t.h for t in traces])
+    pub = np.ascontiguousarray(np.asarray(list(public_values) or [0], dtype=np.uint64))
+    st = np.ascontiguousarray(np.asarray(challenger_state, dtype=np.uint64))
+    pre = np.ascontiguousarray(np.asarray(list(pre_observe) or [0], dtype=np.uint64))
+    u64p = C.POINTER(C.c_uint64)
+    max_rand = max(a.air.num_randomness for a in airs)
+
+    def cb(user, idx, rand_p, aux_p, vals_p):
+        try:
+            rnd = [(int(rand_p[2 * i]), int(rand_p[2 * i + 1])) for i in range(max_rand)]
+            aux, vals = aux_builder(idx, rnd)
+            flat = np.ascontiguousarray(aux, dtype=np.uint64).reshape(-1)
+            C.memmove(aux_p, flat.ctypes.data, flat.size * 8)
+            for i, v in enumerate(vals):
+                vals_p[i] = int(v)
+            return 0
+        except Exception as e:  # pragma: no cover
+            print("aux builder failed:", e)
+            return 1
+
+    c_cb = pkg.AUX_CB(cb) if aux_builder is not None else C.cast(None, pkg.AUX_CB)
+    p = params if isinstance(params, pkg.PcsParams) else pkg.PcsParams.from_dict(params)
+    h = C.c_void_p()
+    ctx.check(ctx.lib.mh_prove_sharded(ctx.h, C.byref(comm.struct), C.byref(p), C.c_int(n), a_arr, t_arr, pub.ctypes.data_as(u64p),
+                                       C.c_size_t(len(public_values)), st.ctypes.data_as(u64p), pre.ctypes.data_as(u64p),
+                                       C.c_size_t(len(pre_observe)), c_cb, None, C.byref(h)))
+    return pkg.Proof(ctx.lib, h)

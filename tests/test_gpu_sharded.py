@@ -46,3 +46,69 @@ def test_sharded_commit_root_equals_single_gpu_root(world, shapes, lb):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, shapes, lb, ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+# ---- whole proofs: sharded over ranks == single GPU, bit for bit -------------------------------------------
+def _prove_worker(rank, world, port, case, ret):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    import airs as A
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from miden_vm_amd import sharding, dag
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        ctx = pkg.Ctx(0)
+        if case == "miden":
+            airs_, traces, pub, prm = [dag.dummy_miden_air(51, 8)], [A.dummy_trace(10, 51)], [], ob.PROD_PARAMS
+        elif case == "miden_small":
+            airs_, traces, pub, prm = [dag.dummy_miden_air(11, 2)], [A.dummy_trace(6, 11)], [], dict(
+                log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=5, query_pow_bits=3)
+        else:  # two AIRs with aux columns, selectors, periodic columns, different heights (D = 2)
+            t1, pub = A.fib_trace(8)
+            airs_, traces = [A.periodic_air(3), A.fib_air()], [A.periodic_trace(6), t1]
+            prm = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=6,
+                       query_pow_bits=3)
+        dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+        dtr = [ctx.upload_trace(t) for t in traces]
+        need_cb = any(a.build_aux is not None for a in airs_)
+
+        def aux_builder(idx, rnd):
+            a = airs_[idx]
+            if a.build_aux is None:
+                return np.zeros((traces[idx].shape[0], 2 * a.aux_width), dtype=np.uint64), [0] * (2 * a.num_aux_values)
+            return a.build_aux(traces[idx], rnd[:a.num_randomness])
+
+        st, pre = ob.challenger_state(), ob.protocol_pre_observe(prm, pub)
+        comm = sharding.TorchComm(rank, world)
+        got = sharding.prove_sharded(pkg, ctx, comm, dairs, dtr, pub, prm, st, pre, aux_builder if need_cb else None)
+        ref = pkg.prove(ctx, dairs, dtr, pub, prm, st, pre, aux_builder if need_cb else None)
+        same = (got.fields.size == ref.fields.size and (got.fields == ref.fields).all()
+                and got.commitments.shape == ref.commitments.shape and (got.commitments == ref.commitments).all()
+                and (got.digest == ref.digest).all())
+        ok, msg = ob.verify(airs_, got.log_trace_heights, pub, {"fields": got.fields, "commitments": got.commitments}, prm)
+        ret[rank] = bool(same and ok)
+        if not (same and ok):
+            nf = min(got.fields.size, ref.fields.size)
+            bad = np.nonzero(got.fields[:nf] != ref.fields[:nf])[0]
+            nc = min(len(got.commitments), len(ref.commitments))
+            badc = [i for i in range(nc) if (got.commitments[i] != ref.commitments[i]).any()]
+            print(f"rank {rank}: same={same} verify={ok} {msg if not ok else ''} first bad field {bad[:3]} of {nf}, bad commitments {badc[:5]}")
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "miden_small"), (8, "miden_small"), (2, "multi"), (4, "miden"), (8, "miden")])
+def test_sharded_proof_equals_single_gpu_proof(world, case):
+    port = 29500 + (os.getpid() + 31 * world + len(case)) % 2000
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_prove_worker, args=(world, port, case, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
