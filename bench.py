@@ -188,7 +188,7 @@ def sharded_prove_probe(pkg, ctx, args, rank, world, runner):
     dist.barrier()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     trace.free()
     return {"workload": f"one proof of miden:{args.log_n}:51:8 sharded by cosets over {world} GPUs (strong scaling)",
@@ -221,11 +221,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # MIDEN_BENCH_BACKEND=gloo lets several ranks share the GPUs of a small test box (RCCL refuses two
+    # ranks on one device); the driver's multi-GPU runs use the default nccl (= RCCL over xGMI).
+    backend = os.environ.get("MIDEN_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
-    ctx = pkg.Ctx(local_rank)
+    ctx = pkg.Ctx(dev_index)
     workload = "prove" if args.workload in ("auto", "prove") else "commit"
     runner = (ProveRunner if workload == "prove" else CommitRunner)(pkg, ctx, args, rank, world)
 
@@ -245,7 +252,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     prof = ctx.prof()
