@@ -19,6 +19,7 @@
 #include "ctx.hpp"
 #include "kernels.hpp"
 #include "poseidon2_fast.cuh"
+#include "poseidon2_lanes.cuh"
 #include "gl.cuh"
 #include <algorithm>
 #include <cstring>
@@ -151,6 +152,31 @@ __global__ __launch_bounds__(256) void k_compress(const u64* __restrict__ in, u6
   o[1] = make_ulonglong2(s[2], s[3]);
 }
 
+// Same compression with one state element per lane (16 lanes per node): the low-latency form for the
+// small layers near the root (poseidon2_lanes.cuh).
+static constexpr size_t COMPRESS_LANES_MAX_NODES = 8192;
+__global__ __launch_bounds__(256) void k_compress_lanes(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out, int log_n_coset) {
+  const size_t node = (blockIdx.x * (size_t)256 + threadIdx.x) >> 4;
+  const int g = threadIdx.x & 15;
+  const bool active = node < n_out;
+  const size_t q = active ? node : 0;  // idle groups recompute node 0 (keeps every wave converged)
+  size_t l, rgt;
+  if (log_n_coset >= 0) {
+    const size_t N = (size_t)1 << log_n_coset;
+    const size_t jp = q >> log_n_coset, r = q & (N - 1);
+    l = ((2 * jp) << log_n_coset) + r;
+    rgt = l + N;
+  } else {
+    l = 2 * q;
+    rgt = l + 1;
+  }
+  u64 s = 0;
+  if (g < 4) s = in[4 * l + g];
+  else if (g < 8) s = in[4 * rgt + (g - 4)];
+  s = p2l_permute(s);
+  if (active && g < 4) out[4 * q + g] = s;
+}
+
 void lmcs_alloc_layers(mh_tree* t, int log_height) {
   t->log_height = log_height;
   // layers: depth L (H nodes) first, then L-1, ..., 0
@@ -173,8 +199,12 @@ void lmcs_compress_layers(mh_ctx* c, mh_tree* t) {
       size_t n_out = (size_t)1 << d;
       int cbits_child = (d + 1) - (t->log_height - lb);  // coset bits of the child layer
       int log_n_coset = cbits_child > 0 ? (t->log_height - lb) : -1;
-      hipLaunchKernelGGL(k_compress, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream,
-                         t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
+      if (n_out <= COMPRESS_LANES_MAX_NODES)
+        hipLaunchKernelGGL(k_compress_lanes, dim3((unsigned)((n_out * 16 + 255) / 256)), dim3(256), 0, c->stream,
+                           t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
+      else
+        hipLaunchKernelGGL(k_compress, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream,
+                           t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
     }
   }
   HIP_CHECK(hipMemcpyAsync(t->root, t->nodes.u() + 4 * t->layer_off[0], 32, hipMemcpyDeviceToHost, c->stream));

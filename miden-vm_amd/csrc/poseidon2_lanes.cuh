@@ -1,0 +1,109 @@
+// Poseidon2 with ONE STATE ELEMENT PER LANE (16-lane groups, 12 active): the low-latency form used
+// for the small top layers of every Merkle tree.
+//
+// A one-state-per-lane permutation (poseidon2_fast.cuh) is ~16 k dependent-ish VALU instructions =
+// ~45 us for a lone wave.  The top 13 levels of a tree have fewer nodes than the chip has lanes, so each
+// of them costs one such latency, 10 trees per proof.  Spreading a state over 12 lanes makes the 12
+// S-boxes of a full round run side by side and turns the linear layers into a handful of cross-lane
+// reads: ~5 k instructions per permutation, same arithmetic (wide values, scaled internal rounds) and
+// bit-identical results.  Throughput per lane is 3x worse, so only layers of <= 8192 nodes use it.
+#pragma once
+#include "poseidon2_fast.cuh"
+
+#if defined(__HIP_DEVICE_COMPILE__)
+
+// Cross-lane reads as DPP modifiers (a few cycles) instead of ds_bpermute (LDS-crossbar latency):
+// quad_perm for the 4-blocks, row_ror for the three 4-blocks of a 16-lane row, row_newbcast for lane 0.
+template <int CTRL>
+__device__ __forceinline__ u64 p2l_dpp(u64 v) {
+  const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)lo32(v), CTRL, 0xF, 0xF, false);
+  const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)hi32(v), CTRL, 0xF, 0xF, false);
+  return ((u64)hi << 32) | lo;
+}
+#define P2L_QUAD(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+#define P2L_ROW_ROR(n) (0x120 + (n))
+#define P2L_ROW_BCAST0 0x150
+
+// out_g = (circ(2*M4, M4, M4) * s)_g + rc_g, folded to 64 bits.  g = element index (lanes 12..15 of the
+// group idle but execute), grp0 = first lane of the 16-lane group.
+__device__ __forceinline__ u64 p2l_external(u64 s, int g, const unsigned long long* rc) {
+  // lane k of a quad reads lanes k+1, k+2, k+3 (mod 4)
+  const u64 x1 = p2l_dpp<P2L_QUAD(1, 2, 3, 0)>(s), x2 = p2l_dpp<P2L_QUAD(2, 3, 0, 1)>(s), x3 = p2l_dpp<P2L_QUAD(3, 0, 1, 2)>(s);
+  // row k of M4 = [2, 3, 1, 1] rotated: 2*x_k + 3*x_{k+1} + x_{k+2} + x_{k+3}
+  u64 oL = p2f_mad<2>(p2f_mad<3>(p2f_mad<1>(p2f_zmul<1>(lo32(x3)), lo32(x2)), lo32(x1)), lo32(s));
+  u64 oH = p2f_mad<2>(p2f_mad<3>(p2f_mad<1>(p2f_zmul<1>(hi32(x3)), hi32(x2)), hi32(x1)), hi32(s));
+  if (g >= 12) { oL = 0; oH = 0; }
+  // + sum over the three 4-blocks of the same position k (the idle quad contributes zeros)
+  const u64 sL = oL + p2l_dpp<P2L_ROW_ROR(4)>(oL) + p2l_dpp<P2L_ROW_ROR(8)>(oL) + p2l_dpp<P2L_ROW_ROR(12)>(oL);
+  const u64 sH = oH + p2l_dpp<P2L_ROW_ROR(4)>(oH) + p2l_dpp<P2L_ROW_ROR(8)>(oH) + p2l_dpp<P2L_ROW_ROR(12)>(oH);
+  u64 L = oL + sL, H = oH + sH;
+  if (rc) {
+    const u64 c = rc[g < 12 ? g : 0];
+    L += c & 0xFFFFFFFFULL;
+    H += c >> 32;
+  }
+  return p2f_fold(L, H);
+}
+
+// One permutation per 16-lane group; lane g < 12 holds element g on entry and exit (canonical).
+__device__ __forceinline__ u64 p2l_permute(u64 s) {
+  const int lane = threadIdx.x & 63, g = lane & 15;
+  s = p2l_external(s, g, p2c::P2_ARK_EXT_INITIAL);
+#pragma unroll 1
+  for (int r = 0; r < 4; r++) {
+    s = p2f_sbox(s);
+    s = p2l_external(s, g, r < 3 ? p2c::P2_ARK_EXT_INITIAL + 12 * (r + 1) : nullptr);
+  }
+  // ---- internal rounds, state scaled by 8^r, every lane wide; integer diagonal per lane ----
+  // 8 * diag = [-16, 8, 16, 4, 24, 32, -4, -24, -32, 2, -2, 1]
+  const u32 mag_tab[16] = {16, 8, 16, 4, 24, 32, 4, 24, 32, 2, 2, 1, 0, 0, 0, 0};
+  const u32 neg_bits = 0x5C1;  // elements 0, 6, 7, 8, 10
+  const u64 mag = mag_tab[g];
+  const u64 sgn = ((neg_bits >> g) & 1) ? ~(u64)0 : 0;  // all-ones where the coefficient is negative
+  u64 t0 = p2f_add_canon(s, p2c::P2F_ARK_INT_SCALED[0]);  // used from lane 0 only
+  u64 L = (g >= 1 && g < 12) ? (u64)lo32(s) : 0, H = (g >= 1 && g < 12) ? (u64)hi32(s) : 0;
+#pragma unroll 1
+  for (int r = 0; r < 22; r++) {
+    const u64 y = p2l_dpp<P2L_ROW_BCAST0>(p2f_mul(p2f_sbox(t0), p2c::P2F_INT_K[r]));  // lane 0's S-box output
+    if (g == 0) {
+      L = lo32(y);
+      H = hi32(y);
+    }
+    u64 sL = L, sH = H;  // sum over the 16 lanes of the row, left in every lane
+    sL += p2l_dpp<P2L_ROW_ROR(8)>(sL); sH += p2l_dpp<P2L_ROW_ROR(8)>(sH);
+    sL += p2l_dpp<P2L_ROW_ROR(4)>(sL); sH += p2l_dpp<P2L_ROW_ROR(4)>(sH);
+    sL += p2l_dpp<P2L_QUAD(2, 3, 0, 1)>(sL); sH += p2l_dpp<P2L_QUAD(2, 3, 0, 1)>(sH);
+    sL += p2l_dpp<P2L_QUAD(1, 0, 3, 2)>(sL); sH += p2l_dpp<P2L_QUAD(1, 0, 3, 2)>(sH);
+    // T' = coeff * T + 8 * sum   (two's complement arithmetic on the signed wide parts)
+    const u64 mL = L * mag, mH = H * mag;
+    L = (sL << 3) + ((mL ^ sgn) - sgn);
+    H = (sH << 3) + ((mH ^ sgn) - sgn);
+    if (g >= 12) { L = 0; H = 0; }
+    // lane 0: next S-box input = T_0' + scaled round constant, folded
+    u64 nL = L, nH = H;
+    if (r < 21) {
+      const u64 rc = p2c::P2F_ARK_INT_SCALED[r + 1];
+      nL += rc & 0xFFFFFFFFULL;
+      nH += rc >> 32;
+    }
+    t0 = p2f_fold_signed(nL, nH);
+    if ((r & 3) == 3) {  // refold the wide parts before they outgrow 2^61 (<= 7 bits per round)
+      const u64 v = p2f_fold_signed(L, H);
+      L = lo32(v);
+      H = hi32(v);
+      if (g >= 12) { L = 0; H = 0; }
+    }
+  }
+  // leave the scaled domain, first terminal round constants
+  s = p2f_add_canon(p2f_mul(p2f_fold_signed(L, H), p2c::P2F_DESCALE), p2c::P2_ARK_EXT_TERMINAL[g < 12 ? g : 0]);
+#pragma unroll 1
+  for (int r = 0; r < 4; r++) {
+    s = p2f_sbox(s);
+    s = p2l_external(s, g, r < 3 ? p2c::P2_ARK_EXT_TERMINAL + 12 * (r + 1) : nullptr);
+  }
+  return gl_canon(s);
+}
+
+#else
+__device__ u64 p2l_permute(u64 s);
+#endif

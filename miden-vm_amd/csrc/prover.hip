@@ -168,7 +168,6 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
   MH_REQUIRE(pp.log_folding_arity == 1 || pp.log_folding_arity == 2, "FRI folding arity must be 2 or 4");
   MH_REQUIRE(pp.num_queries > 0, "num_queries must be > 0");
   MH_REQUIRE(pp.log_final_degree + lb >= pp.log_folding_arity - 1, "final degree unreachable by fixed-arity folding");
-  const size_t B = (size_t)1 << lb;
   // ---- trust boundary (prover/mod.rs:199-214) ----
   std::vector<int> lhs(n_airs);
   for (int i = 0; i < n_airs; i++) {
