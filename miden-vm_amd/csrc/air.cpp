@@ -1,5 +1,6 @@
 // Constraint-DAG blob -> interpreter program (see air.hpp).
 #include "air.hpp"
+#include "gl.cuh"
 #include <algorithm>
 #include <cstring>
 #include <memory>
@@ -65,9 +66,19 @@ mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
   }
   air->n_constraints = n_cons;
 
-  // ---- reachability: only nodes some constraint depends on are emitted
+  // ---- constant folding + reachability ----------------------------------------------------------
+  // (a CONST op CONST node becomes a CONST, so an instruction never needs two immediates)
+  for (size_t i = 0; i < n_nodes; i++) {
+    Node& nd = nodes[i];
+    if (nd.op == DOP_CONST) nd.c = nd.c % GL_P;
+    if (nd.op >= DOP_ADD && nodes[nd.a].op == DOP_CONST && (nd.op == DOP_NEG || nodes[nd.b].op == DOP_CONST)) {
+      const u64 x = nodes[nd.a].c, y = nd.op == DOP_NEG ? 0 : nodes[nd.b].c;
+      nd.c = nd.op == DOP_ADD ? gl_add(x, y) : nd.op == DOP_SUB ? gl_sub(x, y) : nd.op == DOP_MUL ? gl_mul(x, y) : gl_neg(x);
+      nd.op = DOP_CONST;
+    }
+  }
   std::vector<char> live(n_nodes, 0);
-  for (uint32_t c : cons) live[c] = 1;
+  for (uint32_t cidx : cons) live[cidx] = 1;
   for (size_t i = n_nodes; i-- > 0;) {
     if (!live[i]) continue;
     const Node& nd = nodes[i];
@@ -80,37 +91,25 @@ mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
   std::vector<std::vector<uint32_t>> folds(n_nodes);
   for (size_t k = 0; k < n_cons; k++) folds[cons[k]].push_back((uint32_t)k);
 
-  // ---- emission order: interior nodes in id order, leaves right before their first use
+  // ---- emission order: interior nodes in id order; a FOLD right after the node it consumes ------
   struct Ev {
     uint32_t node;
     int32_t fold_k;  // -1: compute node; >= 0: fold constraint k of `node`
   };
   std::vector<Ev> seq;
-  std::vector<char> emitted(n_nodes, 0);
-  auto emit_node = [&](uint32_t id) {
-    if (emitted[id]) return;
-    emitted[id] = 1;
-    seq.push_back({id, -1});
-    for (uint32_t k : folds[id]) seq.push_back({id, (int32_t)k});
-  };
   for (size_t i = 0; i < n_nodes; i++) {
     if (!live[i]) continue;
-    const Node& nd = nodes[i];
-    if (nd.op >= DOP_ADD) {
-      emit_node(nd.a);  // no-op unless a is a not-yet-materialised leaf
-      if (nd.op != DOP_NEG) emit_node(nd.b);
-      emit_node((uint32_t)i);
-    } else if (!folds[i].empty()) {
-      emit_node((uint32_t)i);  // a constraint directly on a leaf
-    }
+    if (nodes[i].op >= DOP_ADD) seq.push_back({(uint32_t)i, -1});
+    for (uint32_t k : folds[i]) seq.push_back({(uint32_t)i, (int32_t)k});
   }
-  // ---- liveness + slot assignment
+  // ---- liveness of interior nodes + slot assignment
+  auto interior = [&](uint32_t id) { return nodes[id].op >= DOP_ADD; };
   std::vector<int64_t> last_use(n_nodes, -1);
   for (size_t p = 0; p < seq.size(); p++) {
     const Node& nd = nodes[seq[p].node];
     if (seq[p].fold_k >= 0) {
       last_use[seq[p].node] = (int64_t)p;
-    } else if (nd.op >= DOP_ADD) {
+    } else {
       last_use[nd.a] = (int64_t)p;
       if (nd.op != DOP_NEG) last_use[nd.b] = (int64_t)p;
     }
@@ -119,10 +118,24 @@ mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
   std::vector<uint32_t> free_slots;
   uint32_t n_slots = 0;
   auto release = [&](uint32_t id, size_t p) {
-    if (slot[id] >= 0 && last_use[id] == (int64_t)p) {
+    if (interior(id) && slot[id] >= 0 && last_use[id] == (int64_t)p) {
       free_slots.push_back((uint32_t)slot[id]);
       slot[id] = -2;
     }
+  };
+  // operand descriptor of node `id`: a slot (interior) or the leaf itself
+  auto operand = [&](uint32_t id, uint8_t& kind, uint32_t& idx, uint64_t& imm) {
+    const Node& nd = nodes[id];
+    if (interior(id)) {
+      MH_REQUIRE(slot[id] >= 0, "internal: operand not live");
+      kind = OPK_SLOT;
+      idx = (uint32_t)slot[id];
+      return;
+    }
+    kind = (uint8_t)nd.op;
+    idx = nd.a;
+    if (nd.op == DOP_MAIN || nd.op == DOP_AUX) idx = nd.a | (nd.b << 31);
+    if (nd.op == DOP_CONST) imm = nd.c;
   };
   for (size_t p = 0; p < seq.size(); p++) {
     const uint32_t id = seq[p].node;
@@ -130,40 +143,26 @@ mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
     AirIns ins;
     memset(&ins, 0, sizeof ins);
     if (seq[p].fold_k >= 0) {
-      MH_REQUIRE(slot[id] >= 0, "internal: folding a dead value");
       ins.op = DOP_FOLD;
-      ins.a = (uint16_t)slot[id];
-      ins.a_ext = nd.ext;
-      ins.imm_lo = (uint32_t)seq[p].fold_k;
+      operand(id, ins.a_kind, ins.a, ins.imm);
+      ins.ext = nd.ext ? 1 : 0;
+      ins.b = (uint32_t)seq[p].fold_k;
       air->code.push_back(ins);
       release(id, p);
       continue;
     }
     ins.op = (uint8_t)nd.op;
-    if (nd.op >= DOP_ADD) {
-      MH_REQUIRE(slot[nd.a] >= 0 && (nd.op == DOP_NEG || slot[nd.b] >= 0), "internal: operand not live");
-      ins.a = (uint16_t)slot[nd.a];
-      ins.a_ext = nodes[nd.a].ext;
-      if (nd.op != DOP_NEG) {
-        ins.b = (uint32_t)slot[nd.b];
-        ins.b_ext = nodes[nd.b].ext;
-      }
-      // operands that die here free their slots before dst is chosen (dst may alias an operand:
-      // the interpreter reads both operands before writing)
-      release(nd.a, p);
-      if (nd.op != DOP_NEG && nd.b != nd.a) release(nd.b, p);
-    } else {
-      ins.b = nd.a;                // column / index
-      ins.imm_lo = (uint32_t)nd.c; // constant (low), or row offset for MAIN/AUX
-      ins.imm_hi = (uint32_t)(nd.c >> 32);
-      if (nd.op == DOP_MAIN || nd.op == DOP_AUX) ins.imm_lo = nd.b;
-      if (nd.op == DOP_CONST) {
-        u64 cv = nd.c % 0xFFFFFFFF00000001ULL;
-        ins.imm_lo = (uint32_t)cv;
-        ins.imm_hi = (uint32_t)(cv >> 32);
-      }
+    operand(nd.a, ins.a_kind, ins.a, ins.imm);
+    ins.ext = nodes[nd.a].ext ? 1 : 0;
+    if (nd.op != DOP_NEG) {
+      operand(nd.b, ins.b_kind, ins.b, ins.imm);
+      ins.ext |= nodes[nd.b].ext ? 2 : 0;
     }
-    if (last_use[id] < 0) continue;  // value never consumed (cannot happen for live nodes)
+    // operands that die here free their slots before dst is chosen (dst may alias an operand: the
+    // interpreter reads both operands before writing)
+    release(nd.a, p);
+    if (nd.op != DOP_NEG && nd.b != nd.a) release(nd.b, p);
+    if (last_use[id] < 0) continue;  // cannot happen for live nodes
     uint32_t s;
     if (!free_slots.empty()) {
       s = free_slots.back();

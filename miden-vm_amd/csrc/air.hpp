@@ -18,13 +18,20 @@ enum DagOp : uint32_t {
 };
 static const u64 DAG_MAGIC = 0x4d48444147303031ULL;
 
-// One interpreter instruction (16 bytes): op | flags, dst slot, operand slots / indices, immediate.
+// One interpreter instruction (24 bytes).  Only interior nodes (ADD/SUB/MUL/NEG) and FOLD are
+// instructions; leaves are OPERANDS read where they are used (trace cells straight from the coset-major
+// LDE, which stays L1/L2 resident for the lane), so the LDS slot file only holds live intermediates.
+// Operand kind = the leaf's DagOp (DOP_MAIN: index = col | row << 31, DOP_AUX likewise, DOP_CONST: value
+// in `imm`, ...) or OPK_SLOT for an intermediate.
+static const uint8_t OPK_SLOT = 255;
 struct AirIns {
   uint8_t op;
-  uint8_t a_ext, b_ext, pad;
-  uint16_t dst, a;
-  uint32_t b;   // slot, or column / index for loads
-  uint32_t imm_lo, imm_hi;  // constant value, row offset (loads) or constraint index (FOLD)
+  uint8_t a_kind, b_kind;
+  uint8_t ext;   // bit 0: a is EF-valued, bit 1: b is EF-valued
+  uint16_t dst;  // slot
+  uint16_t pad;
+  uint32_t a, b; // slot or leaf index; FOLD: b = constraint index
+  uint64_t imm;  // the constant operand (at most one per instruction: constant pairs are folded)
 };
 
 struct mh_air {

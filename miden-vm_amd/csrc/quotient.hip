@@ -60,57 +60,60 @@ __global__ __launch_bounds__(256) void k_eval_quotient(QuotArgs a) {
   const size_t B = (size_t)1 << a.log_cosets;
   const u64 x = coset_point(a.tw, a.log_n, a.coset_tab[t], r);
   e2 acc = e2_make(0);
+  // selectors (domain.rs:698-735): Z_H(x)/(x-1), Z_H(x)/(x-w_H^-1), x - w_H^-1
+  u64 sel_first = 0, sel_last = 0;
+  if (a.inv_first) {
+    sel_first = gl_mul(a.coset_tab[Dl + t], a.inv_first[q]);
+    sel_last = gl_mul(a.coset_tab[Dl + t], a.inv_last[q]);
+  }
+  const u64 sel_trans = gl_sub(x, a.wh_inv);
 #define SLOT0(s) slots[(size_t)(2 * (s)) * T + tid]
 #define SLOT1(s) slots[(size_t)(2 * (s) + 1) * T + tid]
+  auto fetch = [&](uint8_t kind, u32 idx, bool ext, u64 imm) -> e2 {
+    switch (kind) {
+      case OPK_SLOT: return e2{SLOT0(idx), ext ? SLOT1(idx) : 0};
+      case DOP_CONST: return e2_make(imm);
+      case DOP_MAIN: return e2_make(a.main_lde[(((size_t)(idx & 0x7FFFFFFFu) * B + jc) << a.log_n) + ((idx >> 31) ? r_next : r)]);
+      case DOP_AUX: {
+        const size_t rr = (idx >> 31) ? r_next : r, cc = idx & 0x7FFFFFFFu;
+        return e2{a.aux_lde[(((size_t)(2 * cc) * B + jc) << a.log_n) + rr], a.aux_lde[(((size_t)(2 * cc + 1) * B + jc) << a.log_n) + rr]};
+      }
+      case DOP_PUBLIC: return e2_make(a.publics[idx]);
+      case DOP_PERIODIC: return e2_make(a.periodic[(size_t)idx * a.periodic_rows + ((r * D + a.t0 + t) % a.periodic_rows)]);
+      case DOP_IS_FIRST: return e2_make(sel_first);
+      case DOP_IS_LAST: return e2_make(sel_last);
+      case DOP_IS_TRANSITION: return e2_make(sel_trans);
+      case DOP_RANDOMNESS: return e2{a.randomness[2 * idx], a.randomness[2 * idx + 1]};
+      default: return e2{a.aux_values[2 * idx], a.aux_values[2 * idx + 1]};  // DOP_AUX_VALUE
+    }
+  };
 #pragma unroll 1
   for (u32 pc = 0; pc < a.n_ins; pc++) {
     const AirIns ins = a.code[pc];
-    e2 va, vb, v;
-    switch (ins.op) {
-      case DOP_CONST: v = e2_make(((u64)ins.imm_hi << 32) | ins.imm_lo); break;
-      case DOP_MAIN: v = e2_make(a.main_lde[(((size_t)ins.b * B + jc) << a.log_n) + (ins.imm_lo ? r_next : r)]); break;
-      case DOP_AUX: {
-        const size_t rr = ins.imm_lo ? r_next : r;
-        v.c0 = a.aux_lde[(((size_t)(2 * ins.b) * B + jc) << a.log_n) + rr];
-        v.c1 = a.aux_lde[(((size_t)(2 * ins.b + 1) * B + jc) << a.log_n) + rr];
-        break;
-      }
-      case DOP_PUBLIC: v = e2_make(a.publics[ins.b]); break;
-      case DOP_PERIODIC: v = e2_make(a.periodic[(size_t)ins.b * a.periodic_rows + ((r * D + a.t0 + t) % a.periodic_rows)]); break;
-      case DOP_IS_FIRST: v = e2_make(gl_mul(a.coset_tab[Dl + t], a.inv_first[q])); break;
-      case DOP_IS_LAST: v = e2_make(gl_mul(a.coset_tab[Dl + t], a.inv_last[q])); break;
-      case DOP_IS_TRANSITION: v = e2_make(gl_sub(x, a.wh_inv)); break;
-      case DOP_RANDOMNESS: v = e2{a.randomness[2 * ins.b], a.randomness[2 * ins.b + 1]}; break;
-      case DOP_AUX_VALUE: v = e2{a.aux_values[2 * ins.b], a.aux_values[2 * ins.b + 1]}; break;
-      case DOP_FOLD: {
-        va.c0 = SLOT0(ins.a);
-        va.c1 = ins.a_ext ? SLOT1(ins.a) : 0;
-        const e2 pw = e2{a.alpha_pows[2 * ins.imm_lo], a.alpha_pows[2 * ins.imm_lo + 1]};
-        acc = e2_add(acc, ins.a_ext ? e2_mul(pw, va) : e2_mulf(pw, va.c0));
-        continue;
-      }
-      default: {
-        va.c0 = SLOT0(ins.a);
-        va.c1 = ins.a_ext ? SLOT1(ins.a) : 0;
-        if (ins.op != DOP_NEG) {
-          vb.c0 = SLOT0(ins.b);
-          vb.c1 = ins.b_ext ? SLOT1(ins.b) : 0;
-        }
-        const bool ext = ins.a_ext || ins.b_ext;
-        if (ins.op == DOP_ADD) v = ext ? e2_add(va, vb) : e2_make(gl_add(va.c0, vb.c0));
-        else if (ins.op == DOP_SUB) v = ext ? e2_sub(va, vb) : e2_make(gl_sub(va.c0, vb.c0));
-        else if (ins.op == DOP_NEG) v = ins.a_ext ? e2_neg(va) : e2_make(gl_neg(va.c0));
-        else {  // MUL
-          if (ins.a_ext && ins.b_ext) v = e2_mul(va, vb);
-          else if (ins.a_ext) v = e2_mulf(va, vb.c0);
-          else if (ins.b_ext) v = e2_mulf(vb, va.c0);
-          else v = e2_make(gl_mul(va.c0, vb.c0));
-        }
-        break;
+    const bool a_ext = ins.ext & 1, b_ext = ins.ext & 2;
+    const e2 va = fetch(ins.a_kind, ins.a, a_ext, ins.imm);
+    if (ins.op == DOP_FOLD) {
+      const e2 pw = e2{a.alpha_pows[2 * ins.b], a.alpha_pows[2 * ins.b + 1]};
+      acc = e2_add(acc, a_ext ? e2_mul(pw, va) : e2_mulf(pw, va.c0));
+      continue;
+    }
+    e2 v;
+    if (ins.op == DOP_NEG) {
+      v = a_ext ? e2_neg(va) : e2_make(gl_neg(va.c0));
+    } else {
+      const e2 vb = fetch(ins.b_kind, ins.b, b_ext, ins.imm);
+      const bool ext = a_ext || b_ext;
+      if (ins.op == DOP_ADD) v = ext ? e2_add(va, vb) : e2_make(gl_add(va.c0, vb.c0));
+      else if (ins.op == DOP_SUB) v = ext ? e2_sub(va, vb) : e2_make(gl_sub(va.c0, vb.c0));
+      else {  // MUL
+        if (a_ext && b_ext) v = e2_mul(va, vb);
+        else if (a_ext) v = e2_mulf(va, vb.c0);
+        else if (b_ext) v = e2_mulf(vb, va.c0);
+        else v = e2_make(gl_mul(va.c0, vb.c0));
       }
     }
     SLOT0(ins.dst) = v.c0;
-    SLOT1(ins.dst) = v.c1;
+    if (a_ext || b_ext) SLOT1(ins.dst) = v.c1;
   }
 #undef SLOT0
 #undef SLOT1

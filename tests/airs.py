@@ -112,3 +112,31 @@ def dummy_trace(log_n, width, seed=1):
     t = rng.integers(0, P, (1 << log_n, width), dtype=np.uint64)
     t[:, 0] = 0
     return t
+
+
+# ------------------------------------------------------------------------------------------------
+def synthetic_big_air(width=51, aux_width=8, n_constraints=300, terms=3, seed=11, num_public=0):
+    """A Miden-SIZED constraint system (thousands of gates, hundreds of constraints, degree <= 9, two-row
+    window, aux columns + randomness) for exercising the DAG interpreter at the scale of the real AIRs
+    (~5.2 k gates over the three Miden AIRs, air/src/snapshots/*relation_digest*.snap).  The constraints
+    are random polynomials, so a random trace does NOT satisfy them: proofs are still deterministic and
+    must be bit-identical between the oracle and the GPU, but no verifier accepts them."""
+    rng = np.random.default_rng(seed)
+    b = dag.AirBuilder(width, aux_width=aux_width, num_randomness=2, num_aux_values=aux_width, num_public=num_public)
+    for k in range(n_constraints):
+        acc = None
+        for _ in range(terms):
+            deg = int(rng.integers(2, 9))
+            cols = rng.integers(0, width, deg)
+            rows = rng.integers(0, 2, deg)
+            t = b.main(int(cols[0]), int(rows[0]))
+            for c, r in zip(cols[1:], rows[1:]):
+                t = t * b.main(int(c), int(r)) if rng.random() < 0.7 else t * (b.main(int(c), int(r)) + int(rng.integers(1, 1000)))
+            acc = t if acc is None else (acc + t if rng.random() < 0.5 else acc - t)
+        if k % 5 == 0:  # every fifth constraint is extension-valued
+            a = b.aux(int(rng.integers(0, aux_width)), int(rng.integers(0, 2)))
+            e = a * (b.randomness(0) + b.main(int(rng.integers(0, width)))) - b.aux(int(rng.integers(0, aux_width)), 1) * b.randomness(1)
+            b.assert_zero_ext(b.is_transition() * e + acc * 0 + acc)
+        else:
+            b.assert_zero(b.is_transition() * acc if rng.random() < 0.5 else acc)
+    return dag.Air(b, build_aux=None, name=f"synthetic:{width}:{aux_width}:{n_constraints}")

@@ -97,6 +97,19 @@ def test_arity2_blowup2(ctx):
     check_same(ctx, [A.fib_air()], [t], pub, dict(FAST, log_folding_arity=1, log_blowup=2, log_final_degree=1))
 
 
+def test_miden_sized_constraint_dag(ctx):
+    """~6.5 k gates, 300 constraints (base and extension), two-row window: the interpreter at the scale
+    of the real Miden AIRs.  Random constraints are not satisfied by a random trace, so only the
+    prover-side parity (bit-identical transcript) is checked, not verification."""
+    air = A.synthetic_big_air()
+    tr = A.dummy_trace(6, 51, seed=3)
+    exp = ob.prove([air], [tr], [], FAST)
+    got = gpu_prove(ctx, [air], [tr], [], FAST)
+    assert (got.commitments == exp["commitments"]).all()
+    assert got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all()
+    assert (got.digest == exp["digest"]).all()
+
+
 def test_blowup16_more_queries(ctx):
     # BASELINE configs[4]-style parameters (blowup 16, more queries/PoW) at a size the oracle can follow
     prm = dict(log_blowup=4, log_folding_arity=2, log_final_degree=3, folding_pow_bits=2, deep_pow_bits=5, num_queries=12,
