@@ -95,8 +95,16 @@ class CommitRunner:
             return None
         e = prof[name]
         ach = (e["bytes"] / 1e9) / (e["ms"] / 1e3)
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this build (profiles/), if present
+        traffic = None
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_leaf_absorb.json")))
+            if name == "lmcs_leaf_absorb" and abs(t["hbm_bytes_per_launch"] / (e["bytes"] / max(1, e["count"])) - 1) < 0.5:
+                traffic = t["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_ms": e["ms"] / max(1, e["count"]), "alg_bytes_per_launch": e["bytes"] / max(1, e["count"]),
                 "note": "Poseidon2 hashing is integer-ALU bound (no 64-bit multiplier on CDNA4); see DESIGN.md for the "
                         "int-op roofline"}
