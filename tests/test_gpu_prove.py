@@ -110,6 +110,25 @@ def test_miden_sized_constraint_dag(ctx):
     assert (got.digest == exp["digest"]).all()
 
 
+@pytest.mark.parametrize("log_n", [1, 2, 3, 4])
+def test_tiny_traces(ctx, log_n):
+    # edge cases: FRI with zero or one round, final polynomial straight from the DEEP quotient,
+    # layers shorter than the folding arity (single-coset relayout), 2-row traces
+    t, pub = A.fib_trace(log_n)
+    check_same(ctx, [A.fib_air()], [t], pub, FAST)
+    check_same(ctx, [A.fib_air()], [t], pub, dict(FAST, log_final_degree=0, log_folding_arity=1))
+
+
+def test_many_proofs_one_ctx_pool_reuse(ctx):
+    # alternate sizes on one ctx: the buffer pool must never hand out a buffer that is still in use
+    air = dag.dummy_miden_air(11, 2)
+    ref = {}
+    for log_n in [9, 5, 9, 7, 5, 9]:
+        got = gpu_prove(ctx, [air], [A.dummy_trace(log_n, 11)], [], FAST)
+        key = (got.fields.tobytes(), got.commitments.tobytes())
+        assert ref.setdefault(log_n, key) == key
+
+
 def test_blowup16_more_queries(ctx):
     # BASELINE configs[4]-style parameters (blowup 16, more queries/PoW) at a size the oracle can follow
     prm = dict(log_blowup=4, log_folding_arity=2, log_final_degree=3, folding_pow_bits=2, deep_pow_bits=5, num_queries=12,
