@@ -172,6 +172,52 @@ int mh_prove_sharded(mh_ctx* ctx, const mh_comm* comm, const mh_pcs_params* para
                      mh_trace* const* traces, const uint64_t* public_values, size_t n_public_values,
                      const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe,
                      mh_aux_builder aux_builder, void* user, mh_proof** out);
+/* ---- staged proof session: the caller owns the Fiat-Shamir transcript ------------------------------
+ * The same device stages `mh_prove` runs, one entry point per step of ProverInstance::prove
+ * (crates/lifted-stark/src/prover/mod.rs:230-578), for a host that keeps p3's DuplexChallenger /
+ * ProverTranscript itself: every call takes the challenges the transcript sampled and returns what the
+ * transcript must observe next.  Calls out of protocol order return MH_ERR_INVALID.  EF values are
+ * (c0, c1) pairs of canonical felts.  `comm` NULL (or world 1) = single GPU; otherwise every rank makes the
+ * same calls with the same challenges (as in mh_prove_sharded).  The session BORROWS the airs and traces:
+ * they must outlive it.
+ *
+ *   begin                    channel.observe(n_airs, log heights...)               order.rs:154-163
+ *   commit_main   -> root    channel.send_commitment(root)                         mod.rs:300-318
+ *   commit_aux(randomness[num_randomness]) -> root, aux values (proof order)       mod.rs:330-412
+ *   commit_quotient(alpha, beta) -> root                                           mod.rs:420-560
+ *   ood_point_ok(z) / ood(z) -> evals[2][ood_width] (row z, then row z*w_H)        pcs/prover.rs:70-136
+ *   [grind deep_pow_bits]  deep(alpha_deep, beta_deep)                             deep/prover.rs:147-193
+ *   num_fri_rounds x { fri_commit -> root, [grind folding_pow_bits], fri_fold(beta) }   fri/prover.rs:113-205
+ *   fri_final -> final_poly_len coefficients, descending degree                    fri/prover.rs:212-239
+ *   [grind query_pow_bits]  open(indices) -> hinted felts + digests, transcript order   pcs/prover.rs:138-195 */
+typedef struct mh_session mh_session;
+typedef struct mh_session_shape_t {
+  int log_lde_height;    /* query indices are sampled with this many bits */
+  size_t num_randomness; /* EF challenges to sample after the main commitment (max over the AIRs) */
+  size_t num_aux_values; /* EF aux values sent after the aux commitment (all instances, proof order) */
+  size_t ood_width;      /* EF evaluations per OOD point: every committed matrix, each padded to 8 columns */
+  int num_fri_rounds;
+  size_t final_poly_len; /* EF coefficients of the final polynomial */
+} mh_session_shape_t;
+int mh_session_begin(mh_ctx* ctx, const mh_comm* comm, const mh_pcs_params* params, int n_airs, mh_air* const* airs,
+                     mh_trace* const* traces, const uint64_t* public_values, size_t n_public_values, mh_session** out);
+void mh_session_free(mh_session* s);
+int mh_session_shape(const mh_session* s, mh_session_shape_t* out);
+int mh_session_commit_main(mh_session* s, uint64_t root[4]);
+int mh_session_commit_aux(mh_session* s, const uint64_t* randomness, mh_aux_builder aux_builder, void* user,
+                          uint64_t root[4], uint64_t* aux_values_out);
+int mh_session_commit_quotient(mh_session* s, const uint64_t alpha[2], const uint64_t beta[2], uint64_t root[4]);
+int mh_session_ood_point_ok(const mh_session* s, const uint64_t z[2]); /* 1 = acceptable, 0 = resample */
+int mh_session_ood(mh_session* s, const uint64_t z[2], uint64_t* evals_out);
+int mh_session_deep(mh_session* s, const uint64_t alpha[2], const uint64_t beta[2]);
+int mh_session_fri_commit(mh_session* s, uint64_t root[4]);
+int mh_session_fri_fold(mh_session* s, const uint64_t beta[2]);
+int mh_session_fri_final(mh_session* s, uint64_t* coeffs_out);
+/* The result holds only the hints: mh_proof_fields / mh_proof_commitments = what ProverTranscript::hint_* receives. */
+int mh_session_open(mh_session* s, const uint64_t* indices, size_t n_indices, mh_proof** out);
+/* GrindingChallenger::grind on the device: `state` = the sponge state, `pending` = felts observed since the
+ * last permutation (< 8).  Returns the smallest witness; the caller replays check_witness on its challenger. */
+int mh_grind(mh_ctx* ctx, const uint64_t state[12], const uint64_t* pending, size_t n_pending, int bits, uint64_t* witness);
 void mh_proof_free(mh_proof* p);
 size_t mh_proof_num_fields(const mh_proof* p);
 size_t mh_proof_num_commitments(const mh_proof* p);

@@ -27,6 +27,9 @@ EXPORTS = [
     "mh_proof_num_fields", "mh_proof_num_commitments", "mh_proof_fields", "mh_proof_commitments", "mh_proof_digest",
     "mh_proof_num_traces", "mh_proof_log_trace_heights", "mh_proof_serialize", "mh_shard_commit_leaves", "mh_shard_free",
     "mh_shard_leaf_digests", "mh_shard_build_subtree", "mh_merkle_cap_root", "mh_prove_sharded",
+    "mh_session_begin", "mh_session_free", "mh_session_shape", "mh_session_commit_main", "mh_session_commit_aux",
+    "mh_session_commit_quotient", "mh_session_ood_point_ok", "mh_session_ood", "mh_session_deep", "mh_session_fri_commit",
+    "mh_session_fri_fold", "mh_session_fri_final", "mh_session_open", "mh_grind",
 ]
 
 _lib = None
@@ -55,6 +58,11 @@ def load_library():
     lib.mh_air_free.argtypes = [C.c_void_p]
     lib.mh_air_log_quotient_degree.argtypes = [C.c_void_p]
     lib.mh_proof_free.argtypes = [C.c_void_p]
+    lib.mh_session_free.argtypes = [C.c_void_p]
+    for name in ("mh_session_shape", "mh_session_commit_main", "mh_session_commit_aux", "mh_session_commit_quotient",
+                 "mh_session_ood_point_ok", "mh_session_ood", "mh_session_deep", "mh_session_fri_commit",
+                 "mh_session_fri_fold", "mh_session_fri_final", "mh_session_open"):
+        getattr(lib, name).restype = C.c_int
     for name in ("mh_proof_num_fields", "mh_proof_num_commitments", "mh_proof_num_traces"):
         getattr(lib, name).restype = C.c_size_t
         getattr(lib, name).argtypes = [C.c_void_p]
@@ -336,3 +344,128 @@ def prove(ctx, airs, traces, public_values, params, challenger_state, pre_observ
     ctx.check(ctx.lib.mh_prove(ctx.h, C.byref(p), C.c_int(n), a_arr, t_arr, _ptr(pub), C.c_size_t(len(public_values)),
                                _ptr(st), _ptr(pre), C.c_size_t(len(pre_observe)), c_cb, None, C.byref(h)))
     return Proof(ctx.lib, h)
+
+
+def _aux_callback(aux_builder, max_rand):
+    if aux_builder is None:
+        return C.cast(None, AUX_CB)
+
+    def cb(user, idx, rand_p, aux_p, vals_p):
+        try:
+            rnd = [(int(rand_p[2 * i]), int(rand_p[2 * i + 1])) for i in range(max_rand)]
+            aux, vals = aux_builder(idx, rnd)
+            flat = np.ascontiguousarray(aux, dtype=np.uint64).reshape(-1)
+            C.memmove(aux_p, flat.ctypes.data, flat.size * 8)
+            for i, v in enumerate(vals):
+                vals_p[i] = int(v)
+            return 0
+        except Exception as e:  # pragma: no cover
+            print("aux builder failed:", e)
+            return 1
+
+    return AUX_CB(cb)
+
+
+class SessionShape(C.Structure):
+    _fields_ = [("log_lde_height", C.c_int), ("num_randomness", C.c_size_t), ("num_aux_values", C.c_size_t),
+                ("ood_width", C.c_size_t), ("num_fri_rounds", C.c_int), ("final_poly_len", C.c_size_t)]
+
+
+class Session:
+    """mh_session: the device stages of one proof, driven by a caller-owned transcript
+    (ProverInstance::prove, crates/lifted-stark/src/prover/mod.rs:230-578, one method per step).
+    EF values are (c0, c1) tuples."""
+
+    def __init__(self, ctx, airs, traces, public_values, params, comm=None):
+        self.ctx, self.lib = ctx, ctx.lib
+        self._keep = (list(airs), list(traces))  # the session borrows them until it is freed
+        n = len(airs)
+        a_arr = (C.c_void_p * n)(*[a.h for a in airs])
+        t_arr = (C.c_void_p * n)(*[t.h for t in traces])
+        pub = _arr(list(public_values) or [0])
+        self.params = params if isinstance(params, PcsParams) else PcsParams.from_dict(params)
+        h = C.c_void_p()
+        ctx.check(self.lib.mh_session_begin(ctx.h, C.byref(comm) if comm is not None else None, C.byref(self.params), C.c_int(n),
+                                            a_arr, t_arr, _ptr(pub), C.c_size_t(len(public_values)), C.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+        self.shape = SessionShape()
+        ctx.check(self.lib.mh_session_shape(self.h, C.byref(self.shape)))
+
+    @staticmethod
+    def _e(v):
+        return _arr([int(v[0]), int(v[1])])
+
+    def _root(self, fn, *args):
+        root = np.zeros(4, dtype=np.uint64)
+        self.ctx.check(fn(self.h, *args, _ptr(root)))
+        return root
+
+    def commit_main(self):
+        return self._root(self.lib.mh_session_commit_main)
+
+    def commit_aux(self, randomness, aux_builder=None):
+        """-> (root, aux values as a flat uint64 array [2 * num_aux_values], proof order)."""
+        rnd = _arr([int(x) for r in randomness for x in r] or [0])
+        vals = np.zeros(max(1, 2 * self.shape.num_aux_values), dtype=np.uint64)
+        cb = _aux_callback(aux_builder, self.shape.num_randomness)
+        root = np.zeros(4, dtype=np.uint64)
+        self.ctx.check(self.lib.mh_session_commit_aux(self.h, _ptr(rnd), cb, None, _ptr(root), _ptr(vals)))
+        return root, vals[:2 * self.shape.num_aux_values]
+
+    def commit_quotient(self, alpha, beta):
+        a, b = self._e(alpha), self._e(beta)
+        return self._root(self.lib.mh_session_commit_quotient, _ptr(a), _ptr(b))
+
+    def ood_point_ok(self, z):
+        zz = self._e(z)
+        return bool(self.lib.mh_session_ood_point_ok(self.h, _ptr(zz)))
+
+    def ood(self, z):
+        """-> flat uint64 [2 * 2 * ood_width]: the row at z, then the row at z * w_H."""
+        zz = self._e(z)
+        out = np.zeros(4 * self.shape.ood_width, dtype=np.uint64)
+        self.ctx.check(self.lib.mh_session_ood(self.h, _ptr(zz), _ptr(out)))
+        return out
+
+    def deep(self, alpha, beta):
+        a, b = self._e(alpha), self._e(beta)
+        self.ctx.check(self.lib.mh_session_deep(self.h, _ptr(a), _ptr(b)))
+
+    def fri_commit(self):
+        return self._root(self.lib.mh_session_fri_commit)
+
+    def fri_fold(self, beta):
+        b = self._e(beta)
+        self.ctx.check(self.lib.mh_session_fri_fold(self.h, _ptr(b)))
+
+    def fri_final(self):
+        out = np.zeros(2 * self.shape.final_poly_len, dtype=np.uint64)
+        self.ctx.check(self.lib.mh_session_fri_final(self.h, _ptr(out)))
+        return out
+
+    def open(self, indices):
+        """-> Proof carrying only the hinted fields / commitments."""
+        idx = _arr([int(i) for i in indices])
+        h = C.c_void_p()
+        self.ctx.check(self.lib.mh_session_open(self.h, _ptr(idx), C.c_size_t(idx.size), C.byref(h)))
+        return Proof(self.lib, h)
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.lib.mh_session_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def grind(ctx, state, pending, bits):
+    """mh_grind: smallest PoW witness for the challenger (state[12], pending absorbed felts)."""
+    st, pe = _arr(state), _arr(list(pending) or [0])
+    w = C.c_uint64(0)
+    ctx.check(ctx.lib.mh_grind(ctx.h, _ptr(st), _ptr(pe), C.c_size_t(len(pending)), C.c_int(bits), C.byref(w)))
+    return int(w.value)

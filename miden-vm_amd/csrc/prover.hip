@@ -133,149 +133,177 @@ struct mh_proof {
 
 static size_t align8(size_t w) { return (w + 7) / 8 * 8; }
 
-static void do_grind(mh_ctx* c, HostTranscript& tr, int bits) {
-  if (bits == 0) {
-    tr.fields.push_back(0);
-    return;
-  }
-  if (bits <= 5) {  // ~2^bits trials: cheaper on the host than one kernel launch + round trip
-    for (u64 w = 0;; w++) {
-      HostChallenger trial = tr.ch;
-      if (trial.check_witness(bits, w)) {
-        tr.ch = trial;
-        tr.fields.push_back(w);
-        return;
-      }
-    }
-  }
-  u64 w = fri_grind(c, tr.ch.st, tr.ch.in.data(), (int)tr.ch.in.size(), bits);
-  MH_REQUIRE(tr.ch.check_witness(bits, w), "internal: device PoW witness rejected by the host challenger");
-  tr.fields.push_back(w);
-}
-
 static int fri_num_rounds(const mh_pcs_params& p, int log_lde) {
   int log_max_final = p.log_final_degree + p.log_blowup;
   int steps = log_lde > log_max_final ? log_lde - log_max_final : 0;
   return (steps + p.log_folding_arity - 1) / p.log_folding_arity;
 }
 
-static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* const* airs_in, mh_trace* const* traces_in,
-                       const u64* publics_in, size_t n_publics, const u64 init_state[12], const u64* pre_observe, size_t n_pre,
-                       mh_aux_builder cb, void* user, mh_proof& proof, const Dist& dist) {
-  MH_REQUIRE(n_airs > 0 && n_airs <= 256, "need between 1 and 256 AIR instances");
-  const int lb = pp.log_blowup;
-  MH_REQUIRE(lb > 0 && lb <= 8, "log_blowup must be in 1..8");
-  MH_REQUIRE(pp.log_folding_arity == 1 || pp.log_folding_arity == 2, "FRI folding arity must be 2 or 4");
-  MH_REQUIRE(pp.num_queries > 0, "num_queries must be > 0");
-  MH_REQUIRE(pp.log_final_degree + lb >= pp.log_folding_arity - 1, "final degree unreachable by fixed-arity folding");
-  // ---- trust boundary (prover/mod.rs:199-214) ----
-  std::vector<int> lhs(n_airs);
-  for (int i = 0; i < n_airs; i++) {
-    MH_REQUIRE(airs_in[i] && traces_in[i], "null AIR or trace");
-    MH_REQUIRE(traces_in[i]->width == airs_in[i]->main_width, "trace width does not match the AIR");
-    MH_REQUIRE(airs_in[i]->num_public == n_publics, "AIR expects a different number of public values");
-    MH_REQUIRE(traces_in[i]->log_n >= 1, "trace needs at least 2 rows");
-    MH_REQUIRE(((size_t)1 << traces_in[i]->log_n) >= airs_in[i]->max_period(), "trace shorter than a periodic column");
-    MH_REQUIRE(airs_in[i]->aux_width > 0, "AIR must declare at least one aux column");
-    lhs[i] = traces_in[i]->log_n;
-  }
-  std::vector<int> order(n_airs);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lhs[a] < lhs[b]; });
-  const int log_N = lhs[order.back()];
-  const int L = log_N + lb;
-  MH_REQUIRE(L <= 32, "LDE order exceeds the field's two-adicity");
-  const size_t N = (size_t)1 << log_N;
-  int logD = 0;
-  for (int i = 0; i < n_airs; i++) logD = std::max(logD, airs_in[i]->log_quotient_degree);
-  MH_REQUIRE(logD <= lb, "constraint degree too high for the blowup");
-  const size_t D = (size_t)1 << logD;
-  std::vector<u64> publics(publics_in, publics_in + n_publics);
-  if (dist.on()) {
-    MH_REQUIRE(dist.logG <= lb && dist.logG <= logD, "more ranks than cosets / quotient chunks");
-    for (int i = 0; i < n_airs; i++) {
-      MH_REQUIRE(airs_in[i]->log_quotient_degree == logD, "sharded proofs need one quotient degree for every AIR");
-      MH_REQUIRE(lhs[i] >= dist.logG, "trace shorter than the number of ranks");
-    }
-  }
-  const int lbl = lb - dist.logG;                    // coset bits stored on this rank
-  const size_t B_loc = (size_t)1 << lbl, coset0 = (size_t)dist.rank * B_loc;
-  const size_t D_loc = D >> dist.logG;               // quotient chunks owned by this rank
+// One proof in flight: every device stage of `prove` (prover/mod.rs:230-578) as a method that takes the
+// challenges the transcript produced and returns the values the transcript must observe next.  mh_prove
+// drives it with the built-in challenger; the mh_session_* entry points expose the same methods so a
+// host that owns the Fiat-Shamir state (the Rust shim with p3's DuplexChallenger) can drive it itself.
+struct mh_session {
+  mh_ctx* c;
+  mh_pcs_params pp;
+  Dist dist;
+  int n_airs = 0;
+  std::vector<mh_air*> airs;        // instance order
+  std::vector<mh_trace*> traces;
+  std::vector<u64> publics;
+  std::vector<int> lhs, order;      // log heights (instance order), proof order -> instance index
+  int lb = 0, log_N = 0, L = 0, logD = 0, lbl = 0;
+  size_t N = 0, D = 0, B_loc = 0, coset0 = 0, D_loc = 0;
+  size_t max_rand = 0;
+  int stage = 0;                    // protocol position, enforced on every call
+  std::unique_ptr<mh_tree> main_tree, aux_tree, quot_tree;
+  std::vector<e2> randomness;
+  std::vector<std::vector<e2>> aux_vals;  // instance order
+  // DEEP
+  std::vector<const LdeMatrix*> mats;
+  std::vector<u32> coef_off;
+  size_t W = 0;
+  e2 z, z_next;
+  std::vector<e2> ev0, ev1;
+  // FRI
+  DevBuf layer;
+  std::vector<std::unique_ptr<mh_tree>> fri_trees;
+  int rounds = 0, log_rows = 0, cbits = 0, cb_loc = 0;
+  size_t fri_c0 = 0;
+  bool sharded = false, round_committed = false;
 
-  HostTranscript tr;
-  for (int i = 0; i < 12; i++) tr.ch.st[i] = gl_canon(init_state[i]);
-  for (size_t i = 0; i < n_pre; i++) tr.ch.observe(pre_observe[i]);
-  tr.ch.observe((u64)n_airs);                              // order.rs:154-163
-  for (int i = 0; i < n_airs; i++) tr.ch.observe((u64)lhs[i]);
+  void begin(mh_ctx* ctx, const mh_pcs_params& params, int n, mh_air* const* airs_in, mh_trace* const* traces_in,
+             const u64* publics_in, size_t n_publics, const Dist& d) {
+    c = ctx; pp = params; dist = d; n_airs = n;
+    MH_REQUIRE(n_airs > 0 && n_airs <= 256, "need between 1 and 256 AIR instances");
+    lb = pp.log_blowup;
+    MH_REQUIRE(lb > 0 && lb <= 8, "log_blowup must be in 1..8");
+    MH_REQUIRE(pp.log_folding_arity == 1 || pp.log_folding_arity == 2, "FRI folding arity must be 2 or 4");
+    MH_REQUIRE(pp.num_queries > 0, "num_queries must be > 0");
+    MH_REQUIRE(pp.log_final_degree + lb >= pp.log_folding_arity - 1, "final degree unreachable by fixed-arity folding");
+    // ---- trust boundary (prover/mod.rs:199-214) ----
+    lhs.resize(n_airs);
+    for (int i = 0; i < n_airs; i++) {
+      MH_REQUIRE(airs_in[i] && traces_in[i], "null AIR or trace");
+      MH_REQUIRE(traces_in[i]->width == airs_in[i]->main_width, "trace width does not match the AIR");
+      MH_REQUIRE(airs_in[i]->num_public == n_publics, "AIR expects a different number of public values");
+      MH_REQUIRE(traces_in[i]->log_n >= 1, "trace needs at least 2 rows");
+      MH_REQUIRE(((size_t)1 << traces_in[i]->log_n) >= airs_in[i]->max_period(), "trace shorter than a periodic column");
+      MH_REQUIRE(airs_in[i]->aux_width > 0, "AIR must declare at least one aux column");
+      lhs[i] = traces_in[i]->log_n;
+      airs.push_back(airs_in[i]);
+      traces.push_back(traces_in[i]);
+      max_rand = std::max(max_rand, airs_in[i]->num_randomness);
+    }
+    order.resize(n_airs);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lhs[a] < lhs[b]; });
+    log_N = lhs[order.back()];
+    L = log_N + lb;
+    MH_REQUIRE(L <= 32, "LDE order exceeds the field's two-adicity");
+    N = (size_t)1 << log_N;
+    for (int i = 0; i < n_airs; i++) logD = std::max(logD, airs[i]->log_quotient_degree);
+    MH_REQUIRE(logD <= lb, "constraint degree too high for the blowup");
+    D = (size_t)1 << logD;
+    publics.assign(publics_in, publics_in + n_publics);
+    if (dist.on()) {
+      MH_REQUIRE(dist.logG <= lb && dist.logG <= logD, "more ranks than cosets / quotient chunks");
+      for (int i = 0; i < n_airs; i++) {
+        MH_REQUIRE(airs[i]->log_quotient_degree == logD, "sharded proofs need one quotient degree for every AIR");
+        MH_REQUIRE(lhs[i] >= dist.logG, "trace shorter than the number of ranks");
+      }
+    }
+    lbl = lb - dist.logG;  // coset bits stored on this rank
+    B_loc = (size_t)1 << lbl;
+    coset0 = (size_t)dist.rank * B_loc;
+    D_loc = D >> dist.logG;  // quotient chunks owned by this rank
+    rounds = fri_num_rounds(pp, L);
+    stage = 1;
+  }
+  size_t ood_width() const {
+    size_t w = 0;
+    for (int i = 0; i < n_airs; i++) w += align8(airs[i]->main_width) + align8(2 * airs[i]->aux_width);
+    return w + align8(2 * D);
+  }
+  size_t num_aux_values() const {
+    size_t k = 0;
+    for (int i = 0; i < n_airs; i++) k += airs[i]->num_aux_values;
+    return k;
+  }
+  size_t final_poly_len() const { return (size_t)1 << std::max(0, L - rounds * pp.log_folding_arity - lb); }
+  void expect(int s, const char* what) { MH_REQUIRE(stage == s, std::string("session call out of protocol order: ") + what); }
 
   // ---- 1. main commitment ----
-  std::vector<const mh_trace*> main_tr;
-  for (int j = 0; j < n_airs; j++) main_tr.push_back(traces_in[order[j]]);
-  std::unique_ptr<mh_tree> main_tree(commit_traces_dist(c, main_tr, lb, dist));
-  tr.send_commitment(main_tree->root);
-
-  // ---- 2. randomness, aux traces (instance order), aux commitment ----
-  size_t max_rand = 0;
-  for (int i = 0; i < n_airs; i++) max_rand = std::max(max_rand, airs_in[i]->num_randomness);
-  std::vector<e2> randomness;
-  for (size_t i = 0; i < max_rand; i++) randomness.push_back(tr.ch.sample_ef());
-  std::vector<u64> rand_flat;
-  for (e2 r : randomness) { rand_flat.push_back(r.c0); rand_flat.push_back(r.c1); }
-  if (rand_flat.empty()) rand_flat.push_back(0);
-  std::vector<std::unique_ptr<mh_trace>> aux_tr(n_airs);
-  std::vector<std::vector<e2>> aux_vals(n_airs);
-  for (int i = 0; i < n_airs; i++) {
-    const mh_air* a = airs_in[i];
-    const size_t n = (size_t)1 << lhs[i], w = 2 * a->aux_width;
-    aux_vals[i].assign(a->num_aux_values, e2_make(0));
-    if (cb) {
-      std::vector<u64> host(n * w, 0), vals(2 * std::max<size_t>(1, a->num_aux_values), 0);
-      int rc = cb(user, i, rand_flat.data(), host.data(), vals.data());
-      MH_REQUIRE(rc == 0, "aux trace builder / external assertion failed");
-      for (size_t k = 0; k < a->num_aux_values; k++) aux_vals[i][k] = e2{gl_canon(vals[2 * k]), gl_canon(vals[2 * k + 1])};
-      aux_tr[i].reset(trace_upload(c, host.data(), lhs[i], w));
-    } else {
-      aux_tr[i].reset(trace_zeros(c, lhs[i], w));  // DummyMidenAir::build_aux_trace (testing/airs/miden.rs:79-89)
-    }
+  void commit_main(u64 root[4]) {
+    expect(1, "commit_main");
+    std::vector<const mh_trace*> po;
+    for (int j = 0; j < n_airs; j++) po.push_back(traces[order[j]]);
+    main_tree.reset(commit_traces_dist(c, po, lb, dist));
+    memcpy(root, main_tree->root, 32);
+    stage = 2;
   }
-  std::vector<const mh_trace*> aux_po;
-  for (int j = 0; j < n_airs; j++) aux_po.push_back(aux_tr[order[j]].get());
-  std::unique_ptr<mh_tree> aux_tree(commit_traces_dist(c, aux_po, lb, dist));
-  tr.send_commitment(aux_tree->root);
-  aux_tr.clear();
-  for (int j = 0; j < n_airs; j++)
-    for (e2 v : aux_vals[order[j]]) tr.send_ef(v);
-
-  // ---- 3. alpha, beta; 4. quotient evaluation + accumulation ----
-  const e2 alpha = tr.ch.sample_ef();
-  const e2 beta = tr.ch.sample_ef();
-  DevBuf acc, acc_prev;
-  int log_n_prev = 0;
-  for (int j = 0; j < n_airs; j++) {
-    const mh_air* a = airs_in[order[j]];
-    const int ln = lhs[order[j]];
-    DevBuf out(((size_t)2 * D_loc << ln) * 8);
-    std::vector<e2> rnd(randomness.begin(), randomness.begin() + a->num_randomness);
-    const int logDj = a->log_quotient_degree;
-    if (logDj == logD) {
-      quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], lb, logD, publics, rnd, aux_vals[order[j]], alpha,
-                               j ? acc.u() : nullptr, log_n_prev, beta, out.u());
-    } else {  // native coset of n*Dj points, then upsample to n*D (prover/mod.rs:520-528); single GPU only
-      DevBuf small(((size_t)2 << (logDj + ln)) * 8);
-      quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], lb, logDj, publics, rnd, aux_vals[order[j]], alpha, nullptr,
-                               0, beta, small.u());
-      quotient_upsample_accumulate(c, small.u(), ln, lb, logDj, logD, j ? acc.u() : nullptr, log_n_prev, beta, out.u());
+  // ---- 2. aux traces (built by the caller from the sampled randomness, instance order) + commitment ----
+  // aux_values_out: the aux values in PROOF order, flattened EF, exactly as they enter the transcript.
+  void commit_aux(const std::vector<e2>& rnd, mh_aux_builder cb, void* user, u64 root[4], std::vector<e2>& aux_values_out) {
+    expect(2, "commit_aux");
+    MH_REQUIRE(rnd.size() == max_rand, "wrong number of randomness elements");
+    randomness = rnd;
+    std::vector<u64> rand_flat;
+    for (e2 r : randomness) { rand_flat.push_back(r.c0); rand_flat.push_back(r.c1); }
+    if (rand_flat.empty()) rand_flat.push_back(0);
+    std::vector<std::unique_ptr<mh_trace>> aux_tr(n_airs);
+    aux_vals.assign(n_airs, {});
+    for (int i = 0; i < n_airs; i++) {
+      const mh_air* a = airs[i];
+      const size_t n = (size_t)1 << lhs[i], w = 2 * a->aux_width;
+      aux_vals[i].assign(a->num_aux_values, e2_make(0));
+      if (cb) {
+        std::vector<u64> host(n * w, 0), vals(2 * std::max<size_t>(1, a->num_aux_values), 0);
+        int rc = cb(user, i, rand_flat.data(), host.data(), vals.data());
+        MH_REQUIRE(rc == 0, "aux trace builder / external assertion failed");
+        for (size_t k = 0; k < a->num_aux_values; k++) aux_vals[i][k] = e2{gl_canon(vals[2 * k]), gl_canon(vals[2 * k + 1])};
+        aux_tr[i].reset(trace_upload(c, host.data(), lhs[i], w));
+      } else {
+        aux_tr[i].reset(trace_zeros(c, lhs[i], w));  // DummyMidenAir::build_aux_trace (testing/airs/miden.rs:79-89)
+      }
     }
-    acc = std::move(out);
-    log_n_prev = ln;
+    std::vector<const mh_trace*> po;
+    for (int j = 0; j < n_airs; j++) po.push_back(aux_tr[order[j]].get());
+    aux_tree.reset(commit_traces_dist(c, po, lb, dist));
+    memcpy(root, aux_tree->root, 32);
+    aux_values_out.clear();
+    for (int j = 0; j < n_airs; j++)
+      for (e2 v : aux_vals[order[j]]) aux_values_out.push_back(v);
+    stage = 3;
   }
-
-  // ---- 5. quotient commitment (quotient.rs:143-217): chunk t = columns 2t, 2t+1 ----
-  // acc holds this rank's chunks as evaluations on the cosets g*w_J^t*H: inverse NTT in place, gather
-  // every chunk's coefficients (sharded proofs: 16 B * N per chunk), forward NTT onto the local cosets.
-  std::unique_ptr<mh_tree> quot_tree(new mh_tree());
-  quot_tree->ctx = c; quot_tree->log_blowup = lb;
-  {
+  // ---- 4. + 5. constraint evaluation, accumulation, quotient commitment ----
+  void commit_quotient(e2 alpha, e2 beta, u64 root[4]) {
+    expect(3, "commit_quotient");
+    DevBuf acc;
+    int log_n_prev = 0;
+    for (int j = 0; j < n_airs; j++) {
+      const mh_air* a = airs[order[j]];
+      const int ln = lhs[order[j]];
+      DevBuf out(((size_t)2 * D_loc << ln) * 8);
+      std::vector<e2> rnd(randomness.begin(), randomness.begin() + a->num_randomness);
+      const int logDj = a->log_quotient_degree;
+      if (logDj == logD) {
+        quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], lb, logD, publics, rnd, aux_vals[order[j]], alpha,
+                                 j ? acc.u() : nullptr, log_n_prev, beta, out.u());
+      } else {  // native coset of n*Dj points, then upsample to n*D (prover/mod.rs:520-528); single GPU only
+        DevBuf small(((size_t)2 << (logDj + ln)) * 8);
+        quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], lb, logDj, publics, rnd, aux_vals[order[j]], alpha,
+                                 nullptr, 0, beta, small.u());
+        quotient_upsample_accumulate(c, small.u(), ln, lb, logDj, logD, j ? acc.u() : nullptr, log_n_prev, beta, out.u());
+      }
+      acc = std::move(out);
+      log_n_prev = ln;
+    }
+    // quotient commitment (quotient.rs:143-217): chunk t = columns 2t, 2t+1.  acc holds this rank's
+    // chunks as evaluations on the cosets g*w_J^t*H: inverse NTT in place, gather every chunk's
+    // coefficients (sharded proofs: 16 B * N per chunk), forward NTT onto the local cosets.
+    quot_tree.reset(new mh_tree());
+    quot_tree->ctx = c; quot_tree->log_blowup = lb;
     LdeMatrix qm;
     qm.log_n = log_N; qm.width = 2 * D;
     qm.log_cosets = lbl; qm.coset0 = coset0;
@@ -296,7 +324,7 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
       for (size_t t = 0; t < D; t++) {
         const u64 in_inv = gl_inv(gl_mul(g, gl_pow(wJ, t)));
         std::vector<u64> bases(B_loc);
-        for (size_t z = 0; z < B_loc; z++) bases[z] = gl_mul(all_outs[coset0 + z], in_inv);
+        for (size_t zc = 0; zc < B_loc; zc++) bases[zc] = gl_mul(all_outs[coset0 + zc], in_inv);
         ntt_forward_cosets(c, coef + 2 * t * N, 2, log_N, bases, qm.lde.u() + 2 * t * B_loc * N);
       }
     }
@@ -308,73 +336,71 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
     } else {
       lmcs_build_tree(c, quot_tree.get());
     }
+    memcpy(root, quot_tree->root, 32);
+    stage = 4;
   }
-  acc.release();
-  tr.send_commitment(quot_tree->root);
-
-  // ---- 6. OOD point ----
-  const u64 g = gl_lde_shift(L), g_inv = gl_inv(g);
-  e2 z;
-  for (;;) {
-    z = tr.ch.sample_ef();
-    if (e2_is_zero(z)) continue;
-    if (e2_eq(e2_exp_pow2(z, log_N), e2_make(1))) continue;
-    if (e2_eq(e2_exp_pow2(e2_mulf(z, g_inv), L), e2_make(1))) continue;
-    break;
+  // ---- 6. is this OOD candidate acceptable? (domain.rs:539-553: nonzero, outside H and gK) ----
+  bool ood_point_ok(e2 cand) const {
+    if (e2_is_zero(cand)) return false;
+    if (e2_eq(e2_exp_pow2(cand, log_N), e2_make(1))) return false;
+    const u64 g_inv = gl_inv(gl_lde_shift(L));
+    if (e2_eq(e2_exp_pow2(e2_mulf(cand, g_inv), L), e2_make(1))) return false;
+    return true;
   }
-  const e2 z_next = e2_mulf(z, gl_two_adic_generator(log_N));
-
-  // ---- 7. DEEP ----
-  std::vector<const LdeMatrix*> mats;
-  for (auto& m : main_tree->mats) mats.push_back(&m);
-  for (auto& m : aux_tree->mats) mats.push_back(&m);
-  mats.push_back(&quot_tree->mats[0]);
-  std::vector<u32> coef_off;
-  size_t W = 0;
-  for (auto* m : mats) {
-    coef_off.push_back((u32)W);
-    W += align8(m->width);
-  }
-  std::vector<e2> ev0(W, e2_make(0)), ev1(W, e2_make(0));
-  for (size_t i = 0; i < mats.size(); i++) {
-    const int lift = log_N - mats[i]->log_n;
-    std::vector<e2> o0, o1;
-    deep_ood_eval_matrix(c, *mats[i], lb, e2_exp_pow2(z, lift), e2_exp_pow2(z_next, lift), o0, o1);
-    for (size_t k = 0; k < o0.size(); k++) {
-      ev0[coef_off[i] + k] = o0[k];
-      ev1[coef_off[i] + k] = o1[k];
+  // ---- 7a. OOD evaluations at z and z*w_H: all trees, all matrices, aligned to 8 columns ----
+  void ood(e2 zp) {
+    expect(4, "ood");
+    MH_REQUIRE(ood_point_ok(zp), "OOD point lies on the trace domain or the LDE coset");
+    z = zp;
+    z_next = e2_mulf(z, gl_two_adic_generator(log_N));
+    mats.clear(); coef_off.clear();
+    for (auto& m : main_tree->mats) mats.push_back(&m);
+    for (auto& m : aux_tree->mats) mats.push_back(&m);
+    mats.push_back(&quot_tree->mats[0]);
+    W = 0;
+    for (auto* m : mats) {
+      coef_off.push_back((u32)W);
+      W += align8(m->width);
     }
+    ev0.assign(W, e2_make(0));
+    ev1.assign(W, e2_make(0));
+    for (size_t i = 0; i < mats.size(); i++) {
+      const int lift = log_N - mats[i]->log_n;
+      std::vector<e2> o0, o1;
+      deep_ood_eval_matrix(c, *mats[i], lb, e2_exp_pow2(z, lift), e2_exp_pow2(z_next, lift), o0, o1);
+      for (size_t k = 0; k < o0.size(); k++) {
+        ev0[coef_off[i] + k] = o0[k];
+        ev1[coef_off[i] + k] = o1[k];
+      }
+    }
+    stage = 5;
   }
-  for (e2 v : ev0) tr.send_ef(v);
-  for (e2 v : ev1) tr.send_ef(v);
-  do_grind(c, tr, pp.deep_pow_bits);
-  const e2 alpha_d = tr.ch.sample_ef();
-  const e2 beta_d = tr.ch.sample_ef();
-  e2 fred0 = e2_make(0), fred1 = e2_make(0);
-  for (size_t i = 0; i < W; i++) {
-    fred0 = e2_add(e2_mul(fred0, alpha_d), ev0[i]);
-    fred1 = e2_add(e2_mul(fred1, alpha_d), ev1[i]);
-  }
-  std::vector<e2> negc(W);
-  {
+  // ---- 7b. DEEP quotient ----
+  void deep(e2 alpha_d, e2 beta_d) {
+    expect(5, "deep");
+    e2 fred0 = e2_make(0), fred1 = e2_make(0);
+    for (size_t i = 0; i < W; i++) {
+      fred0 = e2_add(e2_mul(fred0, alpha_d), ev0[i]);
+      fred1 = e2_add(e2_mul(fred1, alpha_d), ev1[i]);
+    }
+    std::vector<e2> negc(W);
     e2 pw = e2_make(GL_P - 1);
     for (size_t i = W; i-- > 0;) {
       negc[i] = pw;
       pw = e2_mul(pw, alpha_d);
     }
+    layer.alloc((N << lbl) * 16);
+    deep_assemble(c, mats, coef_off, log_N, lb, negc, z, z_next, fred0, fred1, beta_d, layer.u());
+    // cbits = coset bits of the whole layer, cb_loc = those stored on this rank (cosets fri_c0 ..)
+    log_rows = log_N; cbits = lb; cb_loc = lbl; fri_c0 = coset0;
+    sharded = dist.on();
+    stage = 6;
   }
-  DevBuf layer((N << lbl) * 16);
-  deep_assemble(c, mats, coef_off, log_N, lb, negc, z, z_next, fred0, fred1, beta_d, layer.u());
-
-  // ---- 8. FRI commit phase ----
-  const int la = pp.log_folding_arity;
-  const int rounds = fri_num_rounds(pp, L);
-  std::vector<std::unique_ptr<mh_tree>> fri_trees;
-  // cbits = coset bits of the whole layer, cb_loc = those stored on this rank (cosets fri_c0 ..)
-  int log_rows = log_N, cbits = lb, cb_loc = lbl;
-  size_t fri_c0 = coset0;
-  bool sharded = dist.on();
-  for (int r = 0; r < rounds; r++) {
+  // ---- 8. FRI: commit the current layer, then fold it ----
+  void fri_commit(u64 root[4]) {
+    expect(6, "fri_commit");
+    MH_REQUIRE((int)fri_trees.size() < rounds && !round_committed, "no FRI round left to commit");
+    const int la = pp.log_folding_arity;
     if (sharded && log_rows - la < dist.logG) {
       // fewer leaf rows per coset than ranks: the row-range split of the tree is over; every rank takes
       // the whole (small) layer and continues redundantly
@@ -408,21 +434,28 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
       fri_leaf_hash(c, layer.u(), log_rows, cbits, la, lmcs_leaf_layer(t.get()));
       lmcs_compress_layers(c, t.get());
     }
-    tr.send_commitment(t->root);
-    do_grind(c, tr, pp.folding_pow_bits);
-    const e2 fb = tr.ch.sample_ef();
+    memcpy(root, t->root, 32);
+    fri_trees.push_back(std::move(t));
+    round_committed = true;
+  }
+  void fri_fold_round(e2 fb) {
+    expect(6, "fri_fold");
+    MH_REQUIRE(round_committed, "fold before the round's commitment");
+    const int la = pp.log_folding_arity;
     DevBuf next(((size_t)1 << (log_rows + cb_loc - la)) * 16);
     fri_fold(c, layer.u(), log_rows, cb_loc, cbits, fri_c0, la, fb, next.u());
-    t->fri_layer = std::move(layer);
+    fri_trees.back()->fri_layer = std::move(layer);
     layer = std::move(next);
     log_rows -= la;
-    fri_trees.push_back(std::move(t));
+    round_committed = false;
   }
-  {
-    // final polynomial (fri/prover.rs:212-239): it has degree < fpd = n_f / B, so the fpd evaluations
-    // on ONE coset s*<w_fpd> of the final layer determine it (s = w_{n_f}^(first local coset); s = 1 on
-    // a single GPU = the reference's first fpd bit-reversed entries).  Interpolate on the host, undo
-    // the shift, send in descending degree order.
+  // final polynomial (fri/prover.rs:212-239): it has degree < fpd = n_f / B, so the fpd evaluations on
+  // ONE coset s*<w_fpd> of the final layer determine it (s = w_{n_f}^(first local coset); s = 1 on a
+  // single GPU = the reference's first fpd bit-reversed entries).  Interpolated on the host, shift undone,
+  // returned in descending degree order.
+  void fri_final(std::vector<e2>& desc) {
+    expect(6, "fri_final");
+    MH_REQUIRE((int)fri_trees.size() == rounds && !round_committed, "FRI rounds not finished");
     const int logn_f = log_rows + cbits;
     const int log_fpd = std::max(0, logn_f - lb);
     const size_t fpd = (size_t)1 << log_fpd;
@@ -457,37 +490,114 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
       coef[k] = e2_mulf(s, gl_mul(n_inv, sk));
       sk = gl_mul(sk, s_inv);
     }
-    for (size_t k = fpd; k-- > 0;) tr.send_ef(coef[k]);
+    desc.assign(coef.rbegin(), coef.rend());
+    layer.release();
+    stage = 7;
   }
-
-  // ---- 9. queries ----
-  do_grind(c, tr, pp.query_pow_bits);
-  std::vector<size_t> idx;
-  for (int i = 0; i < pp.num_queries; i++) idx.push_back(tr.ch.sample_bits(L));
-  std::sort(idx.begin(), idx.end());
-  idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
-  for (const mh_tree* t : {main_tree.get(), aux_tree.get(), quot_tree.get()}) {
-    std::vector<u64> f, cm;
-    lmcs_open(c, t, idx, 8, f, cm, &dist);
-    tr.hint_fields(f);
-    tr.hint_commitments(cm);
-  }
-  int depth = L;
-  for (auto& t : fri_trees) {
-    depth -= la;
-    const size_t mask = ((size_t)1 << depth) - 1;
-    for (auto& i : idx) i &= mask;
+  // ---- 9. openings of every tree at the sampled domain indices, in transcript (hint) order ----
+  void open(std::vector<size_t> idx, std::vector<u64>& fields, std::vector<u64>& commitments) {
+    expect(7, "open");
     std::sort(idx.begin(), idx.end());
     idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
-    std::vector<u64> f, cm;
-    lmcs_open(c, t.get(), idx, 1, f, cm, &dist);
-    tr.hint_fields(f);
-    tr.hint_commitments(cm);
+    for (size_t i : idx) MH_REQUIRE(i < ((size_t)1 << L), "query index out of range");
+    for (const mh_tree* t : {main_tree.get(), aux_tree.get(), quot_tree.get()}) {
+      std::vector<u64> f, cm;
+      lmcs_open(c, t, idx, 8, f, cm, &dist);
+      fields.insert(fields.end(), f.begin(), f.end());
+      commitments.insert(commitments.end(), cm.begin(), cm.end());
+    }
+    int depth = L;
+    for (auto& t : fri_trees) {
+      depth -= pp.log_folding_arity;
+      const size_t mask = ((size_t)1 << depth) - 1;
+      for (auto& i : idx) i &= mask;
+      std::sort(idx.begin(), idx.end());
+      idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
+      std::vector<u64> f, cm;
+      lmcs_open(c, t.get(), idx, 1, f, cm, &dist);
+      fields.insert(fields.end(), f.begin(), f.end());
+      commitments.insert(commitments.end(), cm.begin(), cm.end());
+    }
+    stage = 8;
   }
+};
+
+static void do_grind(mh_ctx* c, HostTranscript& tr, int bits) {
+  if (bits == 0) {
+    tr.fields.push_back(0);
+    return;
+  }
+  if (bits <= 5) {  // ~2^bits trials: cheaper on the host than one kernel launch + round trip
+    for (u64 w = 0;; w++) {
+      HostChallenger trial = tr.ch;
+      if (trial.check_witness(bits, w)) {
+        tr.ch = trial;
+        tr.fields.push_back(w);
+        return;
+      }
+    }
+  }
+  u64 w = fri_grind(c, tr.ch.st, tr.ch.in.data(), (int)tr.ch.in.size(), bits);
+  MH_REQUIRE(tr.ch.check_witness(bits, w), "internal: device PoW witness rejected by the host challenger");
+  tr.fields.push_back(w);
+}
+
+// `prove` with the built-in transcript: the exact sequence of SURVEY.md Appendix A.
+static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* const* airs_in, mh_trace* const* traces_in,
+                       const u64* publics_in, size_t n_publics, const u64 init_state[12], const u64* pre_observe, size_t n_pre,
+                       mh_aux_builder cb, void* user, mh_proof& proof, const Dist& dist) {
+  mh_session s;
+  s.begin(c, pp, n_airs, airs_in, traces_in, publics_in, n_publics, dist);
+  HostTranscript tr;
+  for (int i = 0; i < 12; i++) tr.ch.st[i] = gl_canon(init_state[i]);
+  for (size_t i = 0; i < n_pre; i++) tr.ch.observe(pre_observe[i]);
+  tr.ch.observe((u64)n_airs);  // order.rs:154-163
+  for (int i = 0; i < n_airs; i++) tr.ch.observe((u64)s.lhs[i]);
+
+  u64 root[4];
+  s.commit_main(root);
+  tr.send_commitment(root);
+  std::vector<e2> rnd;
+  for (size_t i = 0; i < s.max_rand; i++) rnd.push_back(tr.ch.sample_ef());
+  std::vector<e2> aux_values;
+  s.commit_aux(rnd, cb, user, root, aux_values);
+  tr.send_commitment(root);
+  for (e2 v : aux_values) tr.send_ef(v);
+  const e2 alpha = tr.ch.sample_ef();
+  const e2 beta = tr.ch.sample_ef();
+  s.commit_quotient(alpha, beta, root);
+  tr.send_commitment(root);
+  e2 z;
+  do {
+    z = tr.ch.sample_ef();
+  } while (!s.ood_point_ok(z));
+  s.ood(z);
+  for (e2 v : s.ev0) tr.send_ef(v);
+  for (e2 v : s.ev1) tr.send_ef(v);
+  do_grind(c, tr, pp.deep_pow_bits);
+  const e2 alpha_d = tr.ch.sample_ef();
+  const e2 beta_d = tr.ch.sample_ef();
+  s.deep(alpha_d, beta_d);
+  for (int r = 0; r < s.rounds; r++) {
+    s.fri_commit(root);
+    tr.send_commitment(root);
+    do_grind(c, tr, pp.folding_pow_bits);
+    s.fri_fold_round(tr.ch.sample_ef());
+  }
+  std::vector<e2> final_poly;
+  s.fri_final(final_poly);
+  for (e2 v : final_poly) tr.send_ef(v);
+  do_grind(c, tr, pp.query_pow_bits);
+  std::vector<size_t> idx;
+  for (int i = 0; i < pp.num_queries; i++) idx.push_back(tr.ch.sample_bits(s.L));
+  std::vector<u64> f, cm;
+  s.open(idx, f, cm);
+  tr.hint_fields(f);
+  tr.hint_commitments(cm);
   // finalize (CanFinalizeDigest, external): flush pending input, squeeze 4 felts
   if (!tr.ch.in.empty()) tr.ch.duplexing();
   for (int i = 0; i < 4; i++) proof.digest[i] = tr.ch.st[i];
-  for (int i = 0; i < n_airs; i++) proof.log_trace_heights.push_back((uint8_t)lhs[i]);
+  for (int i = 0; i < n_airs; i++) proof.log_trace_heights.push_back((uint8_t)s.lhs[i]);
   proof.fields = std::move(tr.fields);
   for (auto& d : tr.commitments) proof.commitments.insert(proof.commitments.end(), d.begin(), d.end());
 }
@@ -634,6 +744,133 @@ int mh_prove_sharded(mh_ctx* c, const mh_comm* comm, const mh_pcs_params* params
   *out = p.release();
   MH_CATCH
 }
+
+// ---- staged session: the host owns the transcript --------------------------
+#define MH_STRY MH_TRY(s ? s->c : nullptr) MH_REQUIRE(s, "null session"); HIP_CHECK(hipSetDevice(s->c->device));
+static e2 e2_in(const uint64_t v[2]) { return e2{gl_canon(v[0]), gl_canon(v[1])}; }
+static void e2_out(const std::vector<e2>& v, uint64_t* out) {
+  for (size_t i = 0; i < v.size(); i++) { out[2 * i] = v[i].c0; out[2 * i + 1] = v[i].c1; }
+}
+
+int mh_session_begin(mh_ctx* c, const mh_comm* comm, const mh_pcs_params* params, int n_airs, mh_air* const* airs,
+                     mh_trace* const* traces, const uint64_t* public_values, size_t n_public_values, mh_session** out) {
+  MH_TRY(c)
+  MH_REQUIRE(c && params && airs && traces && out, "null argument");
+  MH_REQUIRE(public_values || !n_public_values, "null public values");
+  HIP_CHECK(hipSetDevice(c->device));
+  Dist d;
+  if (comm && comm->world > 1) {
+    MH_REQUIRE((comm->world & (comm->world - 1)) == 0 && comm->rank >= 0 && comm->rank < comm->world,
+               "world must be a power of two and 0 <= rank < world");
+    MH_REQUIRE(comm->all_to_all && comm->all_gather && comm->all_reduce_sum_u64, "missing collective callbacks");
+    d.comm = comm; d.rank = comm->rank; d.world = comm->world;
+    while ((1 << d.logG) < d.world) d.logG++;
+  }
+  std::unique_ptr<mh_session> s(new mh_session());
+  s->begin(c, *params, n_airs, airs, traces, public_values, n_public_values, d);
+  *out = s.release();
+  MH_CATCH
+}
+void mh_session_free(mh_session* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->c->device);
+  PoolScope ps(s->c);
+  delete s;
+}
+int mh_session_shape(const mh_session* s, mh_session_shape_t* out) {
+  if (!s || !out) return MH_ERR_INVALID;
+  out->log_lde_height = s->L;
+  out->num_randomness = s->max_rand;
+  out->num_aux_values = s->num_aux_values();
+  out->ood_width = s->ood_width();
+  out->num_fri_rounds = s->rounds;
+  out->final_poly_len = s->final_poly_len();
+  return MH_OK;
+}
+int mh_session_commit_main(mh_session* s, uint64_t root[4]) {
+  MH_STRY
+  MH_REQUIRE(root, "null argument");
+  s->commit_main(root);
+  MH_CATCH
+}
+int mh_session_commit_aux(mh_session* s, const uint64_t* randomness, mh_aux_builder aux_builder, void* user, uint64_t root[4],
+                          uint64_t* aux_values_out) {
+  MH_STRY
+  MH_REQUIRE(root && (randomness || !s->max_rand) && (aux_values_out || !s->num_aux_values()), "null argument");
+  std::vector<e2> rnd, vals;
+  for (size_t i = 0; i < s->max_rand; i++) rnd.push_back(e2_in(randomness + 2 * i));
+  s->commit_aux(rnd, aux_builder, user, root, vals);
+  e2_out(vals, aux_values_out);
+  MH_CATCH
+}
+int mh_session_commit_quotient(mh_session* s, const uint64_t alpha[2], const uint64_t beta[2], uint64_t root[4]) {
+  MH_STRY
+  MH_REQUIRE(alpha && beta && root, "null argument");
+  s->commit_quotient(e2_in(alpha), e2_in(beta), root);
+  MH_CATCH
+}
+int mh_session_ood_point_ok(const mh_session* s, const uint64_t z[2]) { return s && z && s->ood_point_ok(e2_in(z)) ? 1 : 0; }
+int mh_session_ood(mh_session* s, const uint64_t z[2], uint64_t* evals_out) {
+  MH_STRY
+  MH_REQUIRE(z && evals_out, "null argument");
+  s->ood(e2_in(z));
+  e2_out(s->ev0, evals_out);
+  e2_out(s->ev1, evals_out + 2 * s->W);
+  MH_CATCH
+}
+int mh_session_deep(mh_session* s, const uint64_t alpha[2], const uint64_t beta[2]) {
+  MH_STRY
+  MH_REQUIRE(alpha && beta, "null argument");
+  s->deep(e2_in(alpha), e2_in(beta));
+  MH_CATCH
+}
+int mh_session_fri_commit(mh_session* s, uint64_t root[4]) {
+  MH_STRY
+  MH_REQUIRE(root, "null argument");
+  s->fri_commit(root);
+  MH_CATCH
+}
+int mh_session_fri_fold(mh_session* s, const uint64_t beta[2]) {
+  MH_STRY
+  MH_REQUIRE(beta, "null argument");
+  s->fri_fold_round(e2_in(beta));
+  MH_CATCH
+}
+int mh_session_fri_final(mh_session* s, uint64_t* coeffs_out) {
+  MH_STRY
+  MH_REQUIRE(coeffs_out, "null argument");
+  std::vector<e2> desc;
+  s->fri_final(desc);
+  e2_out(desc, coeffs_out);
+  MH_CATCH
+}
+// The hints of all openings, in transcript order, as an mh_proof holding only hinted fields/commitments.
+int mh_session_open(mh_session* s, const uint64_t* indices, size_t n_indices, mh_proof** out) {
+  MH_STRY
+  MH_REQUIRE(indices && n_indices && out, "null/empty argument");
+  std::unique_ptr<mh_proof> p(new mh_proof());
+  memset(p->digest, 0, sizeof p->digest);
+  std::vector<size_t> idx(indices, indices + n_indices);
+  s->open(idx, p->fields, p->commitments);
+  for (int i = 0; i < s->n_airs; i++) p->log_trace_heights.push_back((uint8_t)s->lhs[i]);
+  *out = p.release();
+  MH_CATCH
+}
+// Proof-of-work: the smallest witness w such that observing w (after the `n_pending` absorbed-but-not-yet-
+// permuted felts) and sampling `bits` bits yields zero  (p3 GrindingChallenger::grind, any valid witness verifies).
+int mh_grind(mh_ctx* c, const uint64_t state[12], const uint64_t* pending, size_t n_pending, int bits, uint64_t* witness) {
+  MH_TRY(c)
+  MH_REQUIRE(c && state && witness && (pending || !n_pending), "null argument");
+  MH_REQUIRE(n_pending < 8 && bits >= 0 && bits <= 40, "pending input must be shorter than the rate; bits in 0..40");
+  HIP_CHECK(hipSetDevice(c->device));
+  HostTranscript tr;
+  for (int i = 0; i < 12; i++) tr.ch.st[i] = gl_canon(state[i]);
+  for (size_t i = 0; i < n_pending; i++) tr.ch.in.push_back(gl_canon(pending[i]));
+  do_grind(c, tr, bits);
+  *witness = tr.fields.back();
+  MH_CATCH
+}
+
 void mh_proof_free(mh_proof* p) { delete p; }
 size_t mh_proof_num_fields(const mh_proof* p) { return p ? p->fields.size() : 0; }
 size_t mh_proof_num_commitments(const mh_proof* p) { return p ? p->commitments.size() / 4 : 0; }

@@ -176,4 +176,29 @@ int orc_verify(const int params[7], int n_airs, const uint64_t* const* dags, con
   }
 }
 
+// ---- the duplex challenger as an object (tests drive the staged device session with it) ----------
+void* orc_ch_new(const uint64_t state[12]) {
+  Challenger* c = new Challenger();
+  for (int i = 0; i < 12; i++) c->st[i] = state[i] % P;
+  return c;
+}
+void orc_ch_free(void* h) { delete (Challenger*)h; }
+void orc_ch_observe(void* h, const uint64_t* x, size_t n) {
+  for (size_t i = 0; i < n; i++) ((Challenger*)h)->observe(x[i] % P);
+}
+uint64_t orc_ch_sample(void* h) { return ((Challenger*)h)->sample(); }
+uint64_t orc_ch_sample_bits(void* h, int bits) { return ((Challenger*)h)->sample_bits(bits); }
+uint64_t orc_ch_grind(void* h, int bits) { return ((Challenger*)h)->grind(bits); }
+int orc_ch_check_witness(void* h, int bits, uint64_t w) { return ((Challenger*)h)->check_witness(bits, w) ? 1 : 0; }
+size_t orc_ch_state(void* h, uint64_t state[12], uint64_t pending[8]) {
+  Challenger* c = (Challenger*)h;
+  for (int i = 0; i < 12; i++) state[i] = c->st[i];
+  for (size_t i = 0; i < c->in.size(); i++) pending[i] = c->in[i];
+  return c->in.size();
+}
+void orc_ch_finalize(void* h, uint64_t digest[4]) {
+  Digest d = ((Challenger*)h)->finalize();
+  memcpy(digest, d.data(), 32);
+}
+
 }  // extern "C"

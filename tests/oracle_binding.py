@@ -238,3 +238,63 @@ def verify(airs, log_heights, publics, proof, params=PROD_PARAMS, init_state=Non
                       ptr(pre), C.c_size_t(pre.size), ptr(f), C.c_size_t(f.size), ptr(c), C.c_size_t(c.size // 4),
                       ptr(digest), err, C.c_size_t(512))
     return (True, digest) if rc == 0 else (False, err.value.decode())
+
+
+class Challenger:
+    """oracle::Challenger (DuplexChallenger restatement) as an object, for driving a staged proof."""
+
+    def __init__(self, state=None):
+        L = lib()
+        L.orc_ch_new.restype = C.c_void_p
+        L.orc_ch_new.argtypes = [u64p]
+        for name in ("orc_ch_sample", "orc_ch_sample_bits", "orc_ch_grind"):
+            getattr(L, name).restype = C.c_uint64
+        L.orc_ch_sample.argtypes = [C.c_void_p]
+        L.orc_ch_sample_bits.argtypes = [C.c_void_p, C.c_int]
+        L.orc_ch_grind.argtypes = [C.c_void_p, C.c_int]
+        L.orc_ch_check_witness.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+        L.orc_ch_observe.argtypes = [C.c_void_p, u64p, C.c_size_t]
+        L.orc_ch_state.restype = C.c_size_t
+        L.orc_ch_state.argtypes = [C.c_void_p, u64p, u64p]
+        L.orc_ch_finalize.argtypes = [C.c_void_p, u64p]
+        L.orc_ch_free.argtypes = [C.c_void_p]
+        self.L = L
+        st = arr(state if state is not None else challenger_state())
+        self.h = L.orc_ch_new(ptr(st))
+
+    def observe(self, xs):
+        a = arr(np.asarray(xs, dtype=np.uint64).reshape(-1))
+        if a.size:
+            self.L.orc_ch_observe(self.h, ptr(a), C.c_size_t(a.size))
+
+    def sample(self):
+        return int(self.L.orc_ch_sample(self.h))
+
+    def sample_ef(self):
+        c0 = self.sample()
+        return (c0, self.sample())
+
+    def sample_bits(self, bits):
+        return int(self.L.orc_ch_sample_bits(self.h, bits))
+
+    def grind(self, bits):
+        return int(self.L.orc_ch_grind(self.h, bits))
+
+    def check_witness(self, bits, w):
+        return bool(self.L.orc_ch_check_witness(self.h, bits, C.c_uint64(w)))
+
+    def state(self):
+        st, pend = np.zeros(12, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+        k = self.L.orc_ch_state(self.h, ptr(st), ptr(pend))
+        return st, pend[:k]
+
+    def finalize(self):
+        d = np.zeros(4, dtype=np.uint64)
+        self.L.orc_ch_finalize(self.h, ptr(d))
+        return d
+
+    def __del__(self):
+        try:
+            self.L.orc_ch_free(self.h)
+        except Exception:
+            pass

@@ -163,3 +163,101 @@ def test_rejects_bad_shapes(ctx):
         pkg.prove(ctx, [air], [tr], [], FAST, ob.challenger_state(), ob.protocol_pre_observe(FAST, []))
     with pytest.raises(pkg.MidenHipError):
         pkg.DeviceAir(ctx, type("X", (), {"blob": np.zeros(16, dtype=np.uint64)})())
+
+
+# ---- staged session: the caller owns the transcript (here: the oracle's challenger) ------------------
+def staged_prove(ctx, airs_, traces, publics, params, device_grind=True):
+    """Drive mh_session_* with an external challenger in the order of SURVEY.md Appendix A; returns
+    (fields, commitments[k][4], digest) exactly as a host-side ProverTranscript would record them."""
+    pkg = load_package()
+    dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+    dtr = [ctx.upload_trace(t) for t in traces]
+    need_cb = any(a.build_aux is not None for a in airs_)
+
+    def aux_builder(idx, rnd):
+        a = airs_[idx]
+        if a.build_aux is None:
+            return np.zeros((traces[idx].shape[0], 2 * a.aux_width), dtype=np.uint64), [0] * (2 * a.num_aux_values)
+        return a.build_aux(traces[idx], rnd[:a.num_randomness])
+
+    ch = ob.Challenger(ob.challenger_state())
+    ch.observe(ob.protocol_pre_observe(params, publics))
+    ch.observe([len(airs_)] + [int(t.shape[0]).bit_length() - 1 for t in traces])
+    fields, commits = [], []
+
+    def send_fields(v):
+        fields.extend(int(x) for x in v)
+        ch.observe(v)
+
+    def send_commitment(root):
+        commits.append([int(x) for x in root])
+        ch.observe(root)
+
+    def grind(bits):
+        if device_grind and bits > 0:
+            st, pend = ch.state()
+            w = pkg.grind(ctx, st, pend, bits)
+            assert ch.check_witness(bits, w)
+        else:
+            w = ch.grind(bits)
+        fields.append(w)
+
+    s = pkg.Session(ctx, dairs, dtr, publics, params)
+    sh = s.shape
+    send_commitment(s.commit_main())
+    rnd = [ch.sample_ef() for _ in range(sh.num_randomness)]
+    root, aux_vals = s.commit_aux(rnd, aux_builder if need_cb else None)
+    send_commitment(root)
+    send_fields(aux_vals)
+    alpha, beta = ch.sample_ef(), ch.sample_ef()
+    send_commitment(s.commit_quotient(alpha, beta))
+    z = ch.sample_ef()
+    while not s.ood_point_ok(z):
+        z = ch.sample_ef()
+    send_fields(s.ood(z))
+    grind(params["deep_pow_bits"])
+    alpha_d, beta_d = ch.sample_ef(), ch.sample_ef()
+    s.deep(alpha_d, beta_d)
+    for _ in range(sh.num_fri_rounds):
+        send_commitment(s.fri_commit())
+        grind(params["folding_pow_bits"])
+        s.fri_fold(ch.sample_ef())
+    send_fields(s.fri_final())
+    grind(params["query_pow_bits"])
+    idx = [ch.sample_bits(sh.log_lde_height) for _ in range(params["num_queries"])]
+    hints = s.open(idx)
+    fields.extend(int(x) for x in hints.fields)
+    commits.extend([int(x) for x in c] for c in hints.commitments)
+    s.free()
+    return np.array(fields, dtype=np.uint64), np.array(commits, dtype=np.uint64).reshape(-1, 4), ch.finalize()
+
+
+@pytest.mark.parametrize("case", ["fib", "multi", "prod"])
+def test_staged_session_equals_mh_prove(ctx, case):
+    if case == "fib":
+        t, pub = A.fib_trace(7)
+        airs_, traces, params = [A.fib_air()], [t], FAST
+    elif case == "multi":
+        airs_, traces, params = [A.periodic_air(0), dag.dummy_miden_air(9, 2)], [A.periodic_trace(9), A.dummy_trace(6, 9)], FAST
+    else:
+        airs_, traces, params = [dag.dummy_miden_air(51, 8)], [A.dummy_trace(12, 51)], ob.PROD_PARAMS
+    pub = pub if case == "fib" else []
+    one = gpu_prove(ctx, airs_, traces, pub, params)
+    f, c, d = staged_prove(ctx, airs_, traces, pub, params)
+    assert f.size == one.fields.size and (f == one.fields).all()
+    assert c.shape == one.commitments.shape and (c == one.commitments).all()
+    assert (d == one.digest).all()
+    ok, msg = ob.verify(airs_, one.log_trace_heights, pub, {"fields": f, "commitments": c}, params)
+    assert ok, msg
+
+
+def test_staged_session_rejects_out_of_order_calls(ctx):
+    pkg = load_package()
+    t, pub = A.fib_trace(6)
+    s = pkg.Session(ctx, [pkg.DeviceAir(ctx, A.fib_air())], [ctx.upload_trace(t)], pub, FAST)
+    with pytest.raises(pkg.MidenHipError, match="out of protocol order"):
+        s.commit_quotient((1, 2), (3, 4))
+    s.commit_main()
+    with pytest.raises(pkg.MidenHipError, match="out of protocol order"):
+        s.fri_commit()
+    s.free()
