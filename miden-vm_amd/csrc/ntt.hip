@@ -12,13 +12,15 @@
 //     r + N/4 strides -- all unit-stride for the kernels downstream.
 //   * iNTT = DIF (natural in, bit-reversed out), coset NTT = DIT (bit-reversed in, natural out):
 //     no bit-reversal permutation pass ever touches HBM.
-//   * each pass stages a 2^12-element tile (32 KB) in LDS and runs up to 12 butterfly stages on
-//     it; strided passes move >=128-byte contiguous segments.
-// Roofline: HBM-bound; algorithmic bytes per column = (1 + B) * N * 8 (read trace once, write
-// LDE once); this first implementation moves (4 + 4B) * N * 8.
+//   * each pass stages a 2^12-element tile (32 KB + padding) in LDS and runs up to 12 butterfly stages
+//     on it as radix-16 rounds in registers; strided passes move >=128-byte contiguous segments.
+// Roofline: algorithmic bytes per column = (1 + B) * N * 8 (read trace once, write LDE once), two
+// passes move (4 + 4B) * N * 8; measured, the passes are VALU-issue bound (no 64-bit multiplier on
+// CDNA4: ~23 VALU instructions per element-stage), see DESIGN.md section 3.
 #include "ctx.hpp"
 #include "gl.cuh"
 #include "kernels.hpp"
+#include "poseidon2_fast.cuh"
 
 static constexpr int NTT_TILE_LOG = 12;
 static constexpr int NTT_THREADS = 256;
@@ -54,7 +56,8 @@ const u64* mh_ctx::twiddles(int log_n, bool inverse) {
   auto& m = inverse ? tw_inv : tw_fwd;
   auto it = m.find(log_n);
   if (it != m.end()) return it->second.u();
-  size_t half = log_n ? ((size_t)1 << (log_n - 1)) : 1;
+  // w^k for ALL k < N (the radix-16 passes index up to N-1; the other users only the first half)
+  size_t half = (size_t)1 << log_n;
   DevBuf b(half * 8);
   u64 w = gl_two_adic_generator(log_n);
   if (inverse) w = gl_inv(w);
@@ -101,8 +104,143 @@ struct NttPassArgs {
   size_t scale_lo_z, scale_hi_z;
 };
 
-__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
-  __shared__ u64 lds[1 << NTT_TILE_LOG];
+// ---------------------------------------------------------------------------------------------
+// Radix-16 passes.  A thread keeps 2^G (G <= 4) elements in registers and runs G butterfly stages on
+// them between two LDS round trips (a 12-stage pass = 3 round trips instead of 12):
+//   DIT round over stages s..s+G-1:  x_e *= W^rev(e), W = w_{2^(s+G)}^gm (one table load each), then a
+//     2^G-point DFT whose twiddles are powers of w_16 = 2^156 (w_16^-1 = 2^36): SHIFTS, not products
+//     (2^96 = -1, 2^64 = 2^32 - 1 mod p);
+//   DIF round: the transpose (DFT first, then y_e *= W^rev(e)).
+// Arithmetic is lazy: values are any representative < 2^64; a +- t needs only t canonical.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ u64 ntt_canon(u64 t) {  // t >= p  <=>  t + eps carries out of 64 bits
+  const u64 u = t + GL_EPS;
+  return u < t ? u : t;
+}
+__device__ __forceinline__ u64 ntt_add(u64 a, u64 t) {  // t canonical
+  u64 s = a + t;
+  s += (s < t) ? GL_EPS : 0;
+  return s;
+}
+__device__ __forceinline__ u64 ntt_sub(u64 a, u64 t) {  // t canonical
+  u64 d = a - t;
+  d -= (a < t) ? GL_EPS : 0;
+  return d;
+}
+// x * 2^S for a compile-time S in [0, 96); any x < 2^64, result some representative.
+__device__ __forceinline__ u64 ntt_mul_pow2(u64 x, int S) {
+  const int q = S >> 5, r = S & 31;
+  const u64 y01 = x << r;                              // low 64 bits of the 96-bit x * 2^r
+  const u32 y2 = r ? (u32)(hi32(x) >> (32 - r)) : 0u;  // its top limb (< 2^r)
+  if (q == 0) {  // y01 + y2 * 2^64
+    u64 v = (u64)y2 * 0xFFFFFFFFu + y01;
+    v += (v < y01) ? GL_EPS : 0;
+    return v;
+  }
+  if (q == 1) {  // y0 * 2^32 + y1 * 2^64 + y2 * 2^96 = (y0 << 32) + y1 * eps - y2
+    const u64 a0 = (u64)lo32(y01) << 32;
+    u64 v = (u64)hi32(y01) * 0xFFFFFFFFu + a0;
+    v += (v < a0) ? GL_EPS : 0;
+    u64 w = v - y2;
+    w -= (v < (u64)y2) ? GL_EPS : 0;
+    return w;
+  }
+  // q == 2: y0 * 2^64 + y1 * 2^96 + y2 * 2^128 = y0 * eps - (y1 + y2 * 2^32)
+  const u64 v = (u64)lo32(y01) * 0xFFFFFFFFu;
+  const u64 b = ((u64)y2 << 32) | hi32(y01);
+  u64 w = v - b;
+  w -= (v < b) ? GL_EPS : 0;
+  return w;
+}
+// (a, b) <- (a + 2^E b, a - 2^E b), E in [0, 192)   [DIT]
+__device__ __forceinline__ void ntt_bfly_dit(u64& a, u64& b, int E) {
+  const u64 t = ntt_canon(E % 96 ? ntt_mul_pow2(b, E % 96) : b);
+  const u64 s = ntt_add(a, t), d = ntt_sub(a, t);
+  if (E >= 96) { a = d; b = s; } else { a = s; b = d; }
+}
+// (a, b) <- (a + b, 2^E (a - b))   [DIF]
+__device__ __forceinline__ void ntt_bfly_dif(u64& a, u64& b, int E) {
+  const u64 t = ntt_canon(b);
+  const u64 s = ntt_add(a, t);
+  const u64 d = E >= 96 ? ntt_sub(t, ntt_canon(a)) : ntt_sub(a, t);  // sign of 2^96 = -1 folded into the difference
+  a = s;
+  b = E % 96 ? ntt_mul_pow2(d, E % 96) : d;
+}
+// 2^G-point DFT on registers; position bit m is stage m.  DIT: bit-reversed in, natural out; DIF: the transpose.
+template <int G, bool INV>
+__device__ __forceinline__ void ntt_dft_regs(u64 (&x)[1 << G], bool dif) {
+  constexpr int W16 = INV ? 36 : 156;  // log2 of w_16 in the transform direction
+  if (!dif) {
+#pragma unroll
+    for (int m = 0; m < G; m++)
+#pragma unroll
+      for (int e = 0; e < (1 << G); e++)
+        if (!(e & (1 << m))) ntt_bfly_dit(x[e], x[e | (1 << m)], (W16 * (8 >> m) * (e & ((1 << m) - 1))) % 192);
+  } else {
+#pragma unroll
+    for (int m = G - 1; m >= 0; m--)
+#pragma unroll
+      for (int e = 0; e < (1 << G); e++)
+        if (!(e & (1 << m))) ntt_bfly_dif(x[e], x[e | (1 << m)], (W16 * (8 >> m) * (e & ((1 << m) - 1))) % 192);
+  }
+}
+#else
+template <int G, bool INV>
+__device__ void ntt_dft_regs(u64 (&x)[1 << G], bool dif);
+__device__ u64 ntt_canon(u64 t);
+#endif
+
+#ifndef NTT16_OCC
+#define NTT16_OCC
+#endif
+static constexpr int NTT2_LDS = (1 << NTT_TILE_LOG) + (1 << (NTT_TILE_LOG - 4));  // one pad element per 16
+__device__ __forceinline__ u32 ntt_pad(u32 l) { return l + (l >> 4); }
+
+template <int G, bool INV>
+__device__ __forceinline__ void ntt_round(const NttPassArgs& a, u64* lds, int st, u32 tile_n, size_t lo0, u64* dst_direct,
+                                          size_t gbase) {
+  const int b0 = st + a.cb, s = a.s_lo + st;
+  const u32 cb_mask = (1u << a.cb) - 1;
+  const int tw_shift = a.log_n - s - G;
+  for (u32 q = threadIdx.x; q < (tile_n >> G); q += NTT_THREADS) {
+    const u32 low = q & ((1u << b0) - 1);
+    const u32 l0 = ((q >> b0) << (b0 + G)) | low;
+    const u32 gm = (((l0 >> a.cb) & ((1u << st) - 1)) << a.s_lo) | ((u32)lo0 << a.cb) | (l0 & cb_mask);
+    u64 x[1 << G];
+#pragma unroll
+    for (int e = 0; e < (1 << G); e++) x[e] = lds[ntt_pad(l0 | ((u32)e << b0))];
+    if (!INV && s > 0) {
+#pragma unroll
+      for (int e = 1; e < (1 << G); e++) {
+        const u32 rho = __brev((u32)e) >> (32 - G);
+        x[e] = p2f_mul(x[e], a.tw[(size_t)(gm * rho) << tw_shift]);
+      }
+    }
+    ntt_dft_regs<G, INV>(x, INV);
+    if (INV && s > 0) {
+#pragma unroll
+      for (int e = 1; e < (1 << G); e++) {
+        const u32 rho = __brev((u32)e) >> (32 - G);
+        x[e] = p2f_mul(x[e], a.tw[(size_t)(gm * rho) << tw_shift]);
+      }
+    }
+    if (dst_direct) {
+#pragma unroll
+      for (int e = 0; e < (1 << G); e++) {
+        const u32 l = l0 | ((u32)e << b0);
+        dst_direct[gbase | ((size_t)(l >> a.cb) << a.s_lo) | (l & cb_mask)] = ntt_canon(x[e]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < (1 << G); e++) lds[ntt_pad(l0 | ((u32)e << b0))] = x[e];
+    }
+  }
+}
+
+// INV: the inverse transform, always run as DIF (natural in, bit-reversed out); forward = DIT.
+template <bool INV>
+__global__ __launch_bounds__(NTT_THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a) {
+  __shared__ u64 lds[NTT2_LDS];
   const int tile_log = a.r_bits + a.cb;
   const u32 tile_n = 1u << tile_log;
   const u32 cb_mask = (1u << a.cb) - 1;
@@ -119,79 +257,40 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPassArgs a) {
     u64 v = src[g];
     if (a.scale_lo) {
       u32 k = bitrev32((u32)g, a.log_n);
-      u64 s = gl_mul(a.scale_lo[blockIdx.z * a.scale_lo_z + (k & ((1u << a.lb) - 1))],
-                     a.scale_hi[blockIdx.z * a.scale_hi_z + (k >> a.lb)]);
-      v = gl_mul(v, s);
+      u64 sc = p2f_mul(a.scale_lo[blockIdx.z * a.scale_lo_z + (k & ((1u << a.lb) - 1))],
+                       a.scale_hi[blockIdx.z * a.scale_hi_z + (k >> a.lb)]);
+      v = p2f_mul(v, sc);
     }
-    lds[l] = v;
+    lds[ntt_pad(l)] = v;
   }
   __syncthreads();
-
-  // Butterflies: two stages at a time on 4 LDS elements held in registers (one radix-4 step =
-  // 4 twiddle multiplications, like two radix-2 stages, but half the LDS traffic, half the barriers
-  // and one index computation per 4 butterflies); a lone radix-2 stage when r_bits is odd.
-  // Global index of local l modulo 2^s:  gm(l, st) = ((l >> cb) mod 2^st) << s_lo | lo0 << cb | l mod 2^cb.
-  auto single_stage = [&](int st) {
-    const int b = st + a.cb, s = a.s_lo + st, tw_shift = a.log_n - s - 1;
-    for (u32 q = threadIdx.x; q < (tile_n >> 1); q += NTT_THREADS) {
-      const u32 low = q & ((1u << b) - 1);
-      const u32 l0 = ((q >> b) << (b + 1)) | low, l1 = l0 | (1u << b);
-      const size_t gm = (((size_t)((l0 >> a.cb) & ((1u << st) - 1))) << a.s_lo) | (lo0 << a.cb) | (l0 & cb_mask);
-      const u64 w = a.tw[gm << tw_shift];
-      const u64 x = lds[l0], y = lds[l1];
-      if (a.dif) {
-        lds[l0] = gl_add(x, y);
-        lds[l1] = gl_mul(gl_sub(x, y), w);
-      } else {
-        const u64 wy = gl_mul(y, w);
-        lds[l0] = gl_add(x, wy);
-        lds[l1] = gl_sub(x, wy);
-      }
-    }
-    __syncthreads();
-  };
-  auto double_stage = [&](int st) {  // local stages st (low) and st + 1 (high)
-    const int b = st + a.cb, s = a.s_lo + st;
-    const int sh_hi = a.log_n - s - 2;  // table shift of the higher stage (twiddle order 2^(s+2))
-    const size_t quarter = (size_t)1 << (a.log_n - 2);
-    for (u32 q = threadIdx.x; q < (tile_n >> 2); q += NTT_THREADS) {
-      const u32 low = q & ((1u << b) - 1);
-      const u32 l00 = ((q >> b) << (b + 2)) | low;
-      const u32 l01 = l00 | (1u << b), l10 = l00 | (2u << b), l11 = l00 | (3u << b);
-      const size_t k = (((size_t)((l00 >> a.cb) & ((1u << st) - 1))) << a.s_lo) | (lo0 << a.cb) | (l00 & cb_mask);
-      // higher stage: w_{2^(s+2)}^k for (l00,l10), times w_4 for (l01,l11); lower stage: its square
-      const u64 wh0 = a.tw[k << sh_hi], wh1 = a.tw[(k << sh_hi) + quarter];
-      const u64 wl = a.tw[k << (sh_hi + 1)];
-      u64 x0 = lds[l00], x1 = lds[l01], x2 = lds[l10], x3 = lds[l11];
-      if (a.dif) {  // high stage first, then low
-        u64 t0 = gl_add(x0, x2), t2 = gl_mul(gl_sub(x0, x2), wh0);
-        u64 t1 = gl_add(x1, x3), t3 = gl_mul(gl_sub(x1, x3), wh1);
-        x0 = gl_add(t0, t1); x1 = gl_mul(gl_sub(t0, t1), wl);
-        x2 = gl_add(t2, t3); x3 = gl_mul(gl_sub(t2, t3), wl);
-      } else {  // low stage first, then high
-        u64 m1 = gl_mul(x1, wl), m3 = gl_mul(x3, wl);
-        u64 t0 = gl_add(x0, m1), t1 = gl_sub(x0, m1), t2 = gl_add(x2, m3), t3 = gl_sub(x2, m3);
-        u64 n2 = gl_mul(t2, wh0), n3 = gl_mul(t3, wh1);
-        x0 = gl_add(t0, n2); x2 = gl_sub(t0, n2);
-        x1 = gl_add(t1, n3); x3 = gl_sub(t1, n3);
-      }
-      lds[l00] = x0; lds[l01] = x1; lds[l10] = x2; lds[l11] = x3;
-    }
-    __syncthreads();
-  };
-  if (a.dif) {
-    int st = a.r_bits - 1;
-    if (a.r_bits & 1) single_stage(st--);
-    for (; st >= 1; st -= 2) double_stage(st - 1);
-  } else {
-    int st = 0;
-    for (; st + 1 < a.r_bits; st += 2) double_stage(st);
-    if (st < a.r_bits) single_stage(st);
+  // stage groups: as many radix-16 rounds as fit, the remainder (1..3 stages) in one smaller round.
+  // DIT ascends (small group first keeps the last, directly-stored round wide); DIF descends.
+  const int rem = a.r_bits & 3, n16 = a.r_bits >> 2;
+  const int n_rounds = n16 + (rem ? 1 : 0);
+  if (n_rounds == 0) {  // a 1-point transform: only the scaling above
+    if (threadIdx.x == 0) dst[gbase] = ntt_canon(lds[0]);
+    return;
   }
-
-  for (u32 l = threadIdx.x; l < tile_n; l += NTT_THREADS) {
-    size_t g = gbase | ((size_t)(l >> a.cb) << a.s_lo) | (l & cb_mask);
-    dst[g] = lds[l];
+  for (int i = 0; i < n_rounds; i++) {
+    // round i of a DIT pass covers [st, st+g); a DIF pass runs the same rounds in reverse order
+    const int ri = INV ? n_rounds - 1 - i : i;
+    int st, g;
+    if (rem) {
+      st = ri == 0 ? 0 : rem + 4 * (ri - 1);
+      g = ri == 0 ? rem : 4;
+    } else {
+      st = 4 * ri;
+      g = 4;
+    }
+    u64* direct = (i == n_rounds - 1) ? dst : nullptr;
+    switch (g) {
+      case 4: ntt_round<4, INV>(a, lds, st, tile_n, lo0, direct, gbase); break;
+      case 3: ntt_round<3, INV>(a, lds, st, tile_n, lo0, direct, gbase); break;
+      case 2: ntt_round<2, INV>(a, lds, st, tile_n, lo0, direct, gbase); break;
+      default: ntt_round<1, INV>(a, lds, st, tile_n, lo0, direct, gbase); break;
+    }
+    if (!direct) __syncthreads();
   }
 }
 
@@ -220,7 +319,8 @@ static std::vector<PassPlan> plan_passes(int log_n) {
 static void launch_pass(mh_ctx* c, NttPassArgs a, size_t n_cols, size_t n_z) {
   size_t tiles = (size_t)1 << (a.log_n - a.r_bits - a.cb);
   dim3 grid((unsigned)tiles, (unsigned)n_cols, (unsigned)n_z);
-  hipLaunchKernelGGL(k_ntt_pass, grid, dim3(NTT_THREADS), 0, c->stream, a);
+  if (a.dif) hipLaunchKernelGGL(k_ntt16_pass<true>, grid, dim3(NTT_THREADS), 0, c->stream, a);
+  else hipLaunchKernelGGL(k_ntt16_pass<false>, grid, dim3(NTT_THREADS), 0, c->stream, a);
 }
 
 // In-place inverse DFT (unscaled: result = N * coefficients) of `n_cols` contiguous columns of

@@ -220,4 +220,7 @@ __device__ __forceinline__ void p2f_permute(u64 s[12]) {
 #else
 // host pass: kernels are only parsed, never code-generated
 __device__ void p2f_permute(u64 s[12]);
+__device__ u64 p2f_mul(u64 a, u64 b);
+__device__ u32 lo32(u64 x);
+__device__ u32 hi32(u64 x);
 #endif  // __HIP_DEVICE_COMPILE__
