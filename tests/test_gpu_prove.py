@@ -155,6 +155,46 @@ def test_full_size_proof_verifies(ctx):
     assert not ok
 
 
+def _prove_and_verify(ctx, airs_, traces, params):
+    got = gpu_prove(ctx, airs_, traces, [], params)
+    lh = [int(t.shape[0]).bit_length() - 1 for t in traces]
+    assert got.log_trace_heights == lh
+    ok, msg = ob.verify(airs_, lh, [], {"fields": got.fields, "commitments": got.commitments}, params)
+    assert ok, msg
+    assert (msg == got.digest).all()
+    return got
+
+
+def test_config3_shape_three_airs_2p22(ctx):
+    """BASELINE configs[2] shape (blake3-bench at 2^22 rows): the three Miden AIRs'
+    widths -- core 2^22 x 51 (+4 EF aux), chiplets 2^21 x 22 (+3 EF), poseidon2 2^20 x 16 (+1 EF) -- as
+    DummyMidenAir-style instances, production parameters; verified by the (size-independent) oracle verifier."""
+    airs_ = [dag.dummy_miden_air(51, 4), dag.dummy_miden_air(22, 3), dag.dummy_miden_air(16, 1)]
+    traces = [A.dummy_trace(22, 51, seed=3), A.dummy_trace(21, 22, seed=4), A.dummy_trace(20, 16, seed=5)]
+    _prove_and_verify(ctx, airs_, traces, ob.PROD_PARAMS)
+
+
+def test_config2_realistic_mixed_heights(ctx):
+    """SURVEY section 8d config 2, mixed-height variant ("consume B2AGG note"): core 2^18 x 51, chiplets 2^20 x 22."""
+    airs_ = [dag.dummy_miden_air(51, 4), dag.dummy_miden_air(22, 3)]
+    _prove_and_verify(ctx, airs_, [A.dummy_trace(18, 51, seed=6), A.dummy_trace(20, 22, seed=7)], ob.PROD_PARAMS)
+
+
+def test_config4_2p24_rows_one_gpu(ctx):
+    """BASELINE configs[3] size (2^24 x 51 + 8 EF aux) on ONE GPU: ~140 GB of LDE matrices, trees and FRI layers
+    resident in the 288 GB of HBM3E (the 8-GPU sharded form of the same proof is covered at small sizes by
+    tests/test_gpu_sharded.py: sharded proofs are bit-identical to single-GPU ones)."""
+    _prove_and_verify(ctx, [dag.dummy_miden_air(51, 8)], [A.dummy_trace(24, 51, seed=8)], ob.PROD_PARAMS)
+
+
+def test_config5_blowup16_128bit_2p20(ctx):
+    """BASELINE configs[4] shape: Poseidon2-permutation-AIR-sized trace (2^20 x 16 + 1 EF aux), FRI blowup 16,
+    ~128-bit parameters (28 queries x 4 bits + 16 bits of query PoW)."""
+    prm = dict(log_blowup=4, log_folding_arity=2, log_final_degree=7, folding_pow_bits=4, deep_pow_bits=12, num_queries=28,
+               query_pow_bits=16)
+    _prove_and_verify(ctx, [dag.dummy_miden_air(16, 1)], [A.dummy_trace(20, 16, seed=9)], prm)
+
+
 def test_rejects_bad_shapes(ctx):
     pkg = load_package()
     air = pkg.DeviceAir(ctx, dag.dummy_miden_air(11, 2))
