@@ -127,6 +127,10 @@ int mh_merkle_cap_root(const uint64_t* subroots, int world, uint64_t root[4]);
 int mh_air_load(mh_ctx* ctx, const uint64_t* blob, size_t n_words, mh_air** out);
 void mh_air_free(mh_air* air);
 int mh_air_log_quotient_degree(const mh_air* air);
+/* Number of specialised kernels the DAG was compiled into (hiprtc at load time, code objects cached on disk
+ * under $MH_JIT_CACHE_DIR or ~/.cache/midenhip); 0 = small DAG, evaluated by the generic interpreter kernel.
+ * MH_JIT=0 / MH_JIT=1 in the environment force either path (both are bit-identical). */
+int mh_air_compiled_chunks(const mh_air* air);
 
 /* ---- the whole proof: miden_prover::prove_stark (prover/src/lib.rs:317-355) -> ------------------ */
 /* ProverInstance::prove (crates/lifted-stark/src/prover/mod.rs:230-578).                           */

@@ -23,7 +23,7 @@ EXPORTS = [
     "mh_ctx_create", "mh_ctx_destroy", "mh_last_error", "mh_device_count", "mh_prof_enable", "mh_prof_reset",
     "mh_prof_get", "mh_prof_dump", "mh_poseidon2_permute", "mh_poseidon2_register_rate", "mh_coset_lde_batch", "mh_trace_upload", "mh_trace_free",
     "mh_commit_traces", "mh_tree_free", "mh_tree_root", "mh_tree_log_height", "mh_tree_open", "mh_tree_download_lde",
-    "mh_tree_download_layers", "mh_air_load", "mh_air_free", "mh_air_log_quotient_degree", "mh_prove", "mh_proof_free",
+    "mh_tree_download_layers", "mh_air_load", "mh_air_free", "mh_air_log_quotient_degree", "mh_air_compiled_chunks", "mh_prove", "mh_proof_free",
     "mh_proof_num_fields", "mh_proof_num_commitments", "mh_proof_fields", "mh_proof_commitments", "mh_proof_digest",
     "mh_proof_num_traces", "mh_proof_log_trace_heights", "mh_proof_serialize", "mh_shard_commit_leaves", "mh_shard_free",
     "mh_shard_leaf_digests", "mh_shard_build_subtree", "mh_merkle_cap_root", "mh_prove_sharded",
@@ -283,6 +283,8 @@ class DeviceAir:
         ctx.check(ctx.lib.mh_air_load(ctx.h, _ptr(blob), C.c_size_t(blob.size), C.byref(h)))
         self.h = h
         ctx._children.add(self)
+        ctx.lib.mh_air_compiled_chunks.argtypes = [C.c_void_p]
+        self.compiled_chunks = int(ctx.lib.mh_air_compiled_chunks(h))
 
     def free(self):
         if getattr(self, "h", None):

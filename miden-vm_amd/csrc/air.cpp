@@ -5,46 +5,38 @@
 #include <cstring>
 #include <memory>
 
-namespace {
-struct Node {
-  uint32_t op, a, b;
-  u64 c;
-  bool ext = false;
-};
-}  // namespace
-
-mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
+DagIR dag_parse(const u64* w, size_t n) {
   MH_REQUIRE(n >= 12 && w[0] == DAG_MAGIC, "constraint DAG blob: bad magic / too short");
-  std::unique_ptr<mh_air> air(new mh_air());
-  air->ctx = ctx;
-  air->main_width = w[1]; air->aux_width = w[2]; air->num_randomness = w[3]; air->num_aux_values = w[4];
-  air->num_public = w[5];
+  DagIR ir;
+  ir.main_width = w[1]; ir.aux_width = w[2]; ir.num_randomness = w[3]; ir.num_aux_values = w[4];
+  ir.num_public = w[5];
   const size_t n_periodic = w[6];
-  air->log_quotient_degree = (int)w[7];
+  ir.log_quotient_degree = (int)w[7];
   const size_t n_nodes = w[8], n_cons = w[9];
-  MH_REQUIRE(air->main_width > 0 && air->main_width < 65536 && air->aux_width < 32768, "constraint DAG blob: bad widths");
-  MH_REQUIRE(air->log_quotient_degree >= 0 && air->log_quotient_degree <= 8, "constraint DAG blob: bad quotient degree");
+  MH_REQUIRE(ir.main_width > 0 && ir.main_width < 65536 && ir.aux_width < 32768, "constraint DAG blob: bad widths");
+  MH_REQUIRE(ir.log_quotient_degree >= 0 && ir.log_quotient_degree <= 8, "constraint DAG blob: bad quotient degree");
   size_t pos = 12;
   for (size_t i = 0; i < n_periodic; i++) {
     MH_REQUIRE(pos < n, "constraint DAG blob: truncated periodic table");
     size_t len = w[pos++];
     MH_REQUIRE(len > 0 && (len & (len - 1)) == 0 && pos + len <= n, "constraint DAG blob: bad periodic column");
-    air->periodic.emplace_back(w + pos, w + pos + len);
+    ir.periodic.emplace_back(w + pos, w + pos + len);
     pos += len;
   }
   MH_REQUIRE(n_nodes < ((size_t)1 << 28) && pos + 2 * n_nodes + n_cons <= n, "constraint DAG blob: truncated");
-  std::vector<Node> nodes(n_nodes);
+  std::vector<DagNode>& nodes = ir.nodes;
+  nodes.resize(n_nodes);
   for (size_t i = 0; i < n_nodes; i++) {
     u64 x = w[pos + 2 * i];
-    Node nd{(uint32_t)(x & 0xFF), (uint32_t)((x >> 8) & 0xFFFFFFF), (uint32_t)(x >> 36), w[pos + 2 * i + 1]};
+    DagNode nd{(uint32_t)(x & 0xFF), (uint32_t)((x >> 8) & 0xFFFFFFF), (uint32_t)(x >> 36), w[pos + 2 * i + 1], false};
     switch (nd.op) {
       case DOP_CONST: case DOP_IS_FIRST: case DOP_IS_LAST: case DOP_IS_TRANSITION: break;
-      case DOP_MAIN: MH_REQUIRE(nd.a < air->main_width && nd.b < 2, "DAG: main column out of range"); break;
-      case DOP_AUX: MH_REQUIRE(nd.a < air->aux_width && nd.b < 2, "DAG: aux column out of range"); nd.ext = true; break;
-      case DOP_PUBLIC: MH_REQUIRE(nd.a < air->num_public, "DAG: public value out of range"); break;
+      case DOP_MAIN: MH_REQUIRE(nd.a < ir.main_width && nd.b < 2, "DAG: main column out of range"); break;
+      case DOP_AUX: MH_REQUIRE(nd.a < ir.aux_width && nd.b < 2, "DAG: aux column out of range"); nd.ext = true; break;
+      case DOP_PUBLIC: MH_REQUIRE(nd.a < ir.num_public, "DAG: public value out of range"); break;
       case DOP_PERIODIC: MH_REQUIRE(nd.a < n_periodic, "DAG: periodic column out of range"); break;
-      case DOP_RANDOMNESS: MH_REQUIRE(nd.a < air->num_randomness, "DAG: randomness out of range"); nd.ext = true; break;
-      case DOP_AUX_VALUE: MH_REQUIRE(nd.a < air->num_aux_values, "DAG: aux value out of range"); nd.ext = true; break;
+      case DOP_RANDOMNESS: MH_REQUIRE(nd.a < ir.num_randomness, "DAG: randomness out of range"); nd.ext = true; break;
+      case DOP_AUX_VALUE: MH_REQUIRE(nd.a < ir.num_aux_values, "DAG: aux value out of range"); nd.ext = true; break;
       case DOP_ADD: case DOP_SUB: case DOP_MUL:
         MH_REQUIRE(nd.a < i && nd.b < i, "DAG: forward reference");
         nd.ext = nodes[nd.a].ext || nodes[nd.b].ext;
@@ -55,21 +47,19 @@ mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
         break;
       default: throw MhError(MH_ERR_INVALID, "DAG: unknown op");
     }
-    if (nd.op == DOP_IS_FIRST || nd.op == DOP_IS_LAST) air->uses_first_last = true;
+    if (nd.op == DOP_IS_FIRST || nd.op == DOP_IS_LAST) ir.uses_first_last = true;
     nodes[i] = nd;
   }
   pos += 2 * n_nodes;
-  std::vector<uint32_t> cons(n_cons);
+  ir.cons.resize(n_cons);
   for (size_t i = 0; i < n_cons; i++) {
     MH_REQUIRE(w[pos + i] < n_nodes, "DAG: constraint id out of range");
-    cons[i] = (uint32_t)w[pos + i];
+    ir.cons[i] = (uint32_t)w[pos + i];
   }
-  air->n_constraints = n_cons;
-
   // ---- constant folding + reachability ----------------------------------------------------------
   // (a CONST op CONST node becomes a CONST, so an instruction never needs two immediates)
   for (size_t i = 0; i < n_nodes; i++) {
-    Node& nd = nodes[i];
+    DagNode& nd = nodes[i];
     if (nd.op == DOP_CONST) nd.c = nd.c % GL_P;
     if (nd.op >= DOP_ADD && nodes[nd.a].op == DOP_CONST && (nd.op == DOP_NEG || nodes[nd.b].op == DOP_CONST)) {
       const u64 x = nodes[nd.a].c, y = nd.op == DOP_NEG ? 0 : nodes[nd.b].c;
@@ -77,16 +67,34 @@ mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
       nd.op = DOP_CONST;
     }
   }
-  std::vector<char> live(n_nodes, 0);
-  for (uint32_t cidx : cons) live[cidx] = 1;
+  ir.live.assign(n_nodes, 0);
+  for (uint32_t cidx : ir.cons) ir.live[cidx] = 1;
   for (size_t i = n_nodes; i-- > 0;) {
-    if (!live[i]) continue;
-    const Node& nd = nodes[i];
+    if (!ir.live[i]) continue;
+    const DagNode& nd = nodes[i];
     if (nd.op >= DOP_ADD) {
-      live[nd.a] = 1;
-      if (nd.op != DOP_NEG) live[nd.b] = 1;
+      ir.live[nd.a] = 1;
+      if (nd.op != DOP_NEG) ir.live[nd.b] = 1;
     }
   }
+  return ir;
+}
+
+mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
+  DagIR ir = dag_parse(w, n);
+  std::unique_ptr<mh_air> air(new mh_air());
+  air->ctx = ctx;
+  air->main_width = ir.main_width; air->aux_width = ir.aux_width; air->num_randomness = ir.num_randomness;
+  air->num_aux_values = ir.num_aux_values; air->num_public = ir.num_public;
+  air->log_quotient_degree = ir.log_quotient_degree;
+  air->periodic = ir.periodic;
+  air->uses_first_last = ir.uses_first_last;
+  const std::vector<DagNode>& nodes = ir.nodes;
+  const std::vector<uint32_t>& cons = ir.cons;
+  const std::vector<char>& live = ir.live;
+  const size_t n_nodes = nodes.size(), n_cons = cons.size();
+  air->n_constraints = n_cons;
+
   // constraints attached to each node, in emission order
   std::vector<std::vector<uint32_t>> folds(n_nodes);
   for (size_t k = 0; k < n_cons; k++) folds[cons[k]].push_back((uint32_t)k);
@@ -106,7 +114,7 @@ mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
   auto interior = [&](uint32_t id) { return nodes[id].op >= DOP_ADD; };
   std::vector<int64_t> last_use(n_nodes, -1);
   for (size_t p = 0; p < seq.size(); p++) {
-    const Node& nd = nodes[seq[p].node];
+    const DagNode& nd = nodes[seq[p].node];
     if (seq[p].fold_k >= 0) {
       last_use[seq[p].node] = (int64_t)p;
     } else {
@@ -125,7 +133,7 @@ mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
   };
   // operand descriptor of node `id`: a slot (interior) or the leaf itself
   auto operand = [&](uint32_t id, uint8_t& kind, uint32_t& idx, uint64_t& imm) {
-    const Node& nd = nodes[id];
+    const DagNode& nd = nodes[id];
     if (interior(id)) {
       MH_REQUIRE(slot[id] >= 0, "internal: operand not live");
       kind = OPK_SLOT;
@@ -139,7 +147,7 @@ mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
   };
   for (size_t p = 0; p < seq.size(); p++) {
     const uint32_t id = seq[p].node;
-    const Node& nd = nodes[id];
+    const DagNode& nd = nodes[id];
     AirIns ins;
     memset(&ins, 0, sizeof ins);
     if (seq[p].fold_k >= 0) {
@@ -179,5 +187,6 @@ mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
   air->d_code.alloc(std::max<size_t>(1, air->code.size()) * sizeof(AirIns));
   if (!air->code.empty())
     HIP_CHECK(hipMemcpy(air->d_code.p, air->code.data(), air->code.size() * sizeof(AirIns), hipMemcpyHostToDevice));
+  air->jit = jit_program_build(ctx, ir);  // null for small DAGs (or MH_JIT=0): the interpreter runs
   return air.release();
 }

@@ -34,6 +34,28 @@ struct AirIns {
   uint64_t imm;  // the constant operand (at most one per instruction: constant pairs are folded)
 };
 
+// The validated, constant-folded DAG (host only): what both back ends (interpreter program below,
+// specialised kernels in air_jit.cpp) are generated from.
+struct DagNode {
+  uint32_t op, a, b;
+  u64 c;
+  bool ext;
+};
+struct DagIR {
+  size_t main_width = 0, aux_width = 0, num_randomness = 0, num_aux_values = 0, num_public = 0;
+  int log_quotient_degree = 0;
+  std::vector<std::vector<u64>> periodic;
+  std::vector<DagNode> nodes;
+  std::vector<uint32_t> cons;  // constraint k = nodes[cons[k]]
+  std::vector<char> live;      // reachable from a constraint
+  bool uses_first_last = false;
+};
+DagIR dag_parse(const u64* w, size_t n);
+
+struct JitProgram;  // air_jit.cpp
+void jit_program_free(JitProgram* p);
+JitProgram* jit_program_build(mh_ctx* c, const DagIR& ir);
+
 struct mh_air {
   mh_ctx* ctx;
   size_t main_width = 0, aux_width = 0, num_randomness = 0, num_aux_values = 0, num_public = 0;
@@ -44,6 +66,8 @@ struct mh_air {
   std::vector<AirIns> code;
   uint32_t n_slots = 0;
   DevBuf d_code;
+  JitProgram* jit = nullptr;  // specialised constraint kernels (large DAGs), else the interpreter runs
+  ~mh_air() { jit_program_free(jit); }
 
   size_t max_period() const {
     size_t m = 0;

@@ -1,0 +1,486 @@
+// DAG -> HIP source -> hiprtc -> gfx950 code objects (see air_jit.hpp).
+#include "air_jit.hpp"
+#include "gl.cuh"
+#include <hip/hiprtc.h>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <mutex>
+#include <set>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace {
+
+// Self-contained device prelude: canonical Goldilocks arithmetic identical to gl.cuh (so that compiled and
+// interpreted evaluation agree bit for bit) and the argument block of air_jit.hpp.
+const char* JIT_PRELUDE = R"SRC(
+typedef unsigned long long u64;
+typedef unsigned int u32;
+#define GL_P 0xFFFFFFFF00000001ULL
+#define GL_EPS 0xFFFFFFFFULL
+#define FI static __device__ inline __attribute__((always_inline))
+FI u64 gl_add(u64 a, u64 b) { u64 s = a + b; u64 t = s + GL_EPS; return (s < a || s >= GL_P) ? t : s; }
+FI u64 gl_sub(u64 a, u64 b) { u64 d = a - b; return (a < b) ? d - GL_EPS : d; }
+FI u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
+FI u64 gl_reduce128(u64 hi, u64 lo) {
+  u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+  u64 t0 = lo - hi_hi;
+  if (lo < hi_hi) t0 -= GL_EPS;
+  u64 t1 = (hi_lo << 32) - hi_lo;
+  u64 r = t0 + t1;
+  if (r < t1) r += GL_EPS;
+  return r >= GL_P ? r - GL_P : r;
+}
+FI u64 gl_mul(u64 a, u64 b) { return gl_reduce128(__umul64hi(a, b), a * b); }
+struct e2 { u64 c0, c1; };
+FI u64 gl_mul7(u64 a) { u64 a2 = gl_add(a, a), a4 = gl_add(a2, a2), a8 = gl_add(a4, a4); return gl_sub(a8, a); }
+FI e2 e2_add(e2 a, e2 b) { return {gl_add(a.c0, b.c0), gl_add(a.c1, b.c1)}; }
+FI e2 e2_sub(e2 a, e2 b) { return {gl_sub(a.c0, b.c0), gl_sub(a.c1, b.c1)}; }
+FI e2 e2_neg(e2 a) { return {gl_neg(a.c0), gl_neg(a.c1)}; }
+FI e2 e2_addf(e2 a, u64 b) { return {gl_add(a.c0, b), a.c1}; }
+FI e2 e2_subf(e2 a, u64 b) { return {gl_sub(a.c0, b), a.c1}; }
+FI e2 e2_fsub(u64 a, e2 b) { return {gl_sub(a, b.c0), gl_neg(b.c1)}; }
+FI e2 e2_mul(e2 a, e2 b) {
+  u64 a0b0 = gl_mul(a.c0, b.c0), a1b1 = gl_mul(a.c1, b.c1);
+  u64 cross = gl_mul(gl_add(a.c0, a.c1), gl_add(b.c0, b.c1));
+  return {gl_add(a0b0, gl_mul7(a1b1)), gl_sub(gl_sub(cross, a0b0), a1b1)};
+}
+FI e2 e2_mulf(e2 a, u64 b) { return {gl_mul(a.c0, b), gl_mul(a.c1, b)}; }
+struct JitArgs {
+  const u64* main_lde; const u64* aux_lde; u64* spill; u64* acc; const u64* tw; const u64* coset_tab;
+  const u64* inv_first; const u64* inv_last; const u64* periodic; const u64* publics; const u64* randomness;
+  const u64* aux_values; const u64* alpha_pows;
+  u64 wh_inv, q0, q_count, spill_stride;
+  int log_n, log_cosets, log_d, log_dl, jc_shift;
+  u32 t0, periodic_rows;
+};
+static_assert(sizeof(JitArgs) == 168, "JitArgs layout");
+)SRC";
+
+struct Ev {
+  uint32_t node;
+  int32_t fold_k;  // -1: compute the node, >= 0: fold constraint k (= this node) into the accumulator
+};
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+struct Chunk {
+  size_t ev_lo, ev_hi;
+  std::string src;
+  std::vector<char> code;
+  std::string log;
+};
+
+// ---- on-disk cache of compiled chunks: an AIR is fixed per application, its kernels are compiled once ----
+// $MH_JIT_CACHE_DIR, else $XDG_CACHE_HOME/midenhip, else $HOME/.cache/midenhip; "off" disables it.
+std::string cache_dir() {
+  const char* d = getenv("MH_JIT_CACHE_DIR");
+  std::string dir;
+  if (d && *d) {
+    if (std::string(d) == "off") return "";
+    dir = d;
+  } else if (const char* x = getenv("XDG_CACHE_HOME")) {
+    dir = std::string(x) + "/midenhip";
+  } else if (const char* h = getenv("HOME")) {
+    dir = std::string(h) + "/.cache/midenhip";
+  } else {
+    return "";
+  }
+  std::string cmd_path;
+  for (size_t i = 1; i <= dir.size(); i++)  // mkdir -p
+    if (i == dir.size() || dir[i] == '/') {
+      cmd_path = dir.substr(0, i);
+      (void)mkdir(cmd_path.c_str(), 0755);
+    }
+  return dir;
+}
+std::string cache_key(const std::string& src) {
+  u64 h1 = 0xcbf29ce484222325ULL, h2 = 0x9ae16a3b2f90404fULL;  // two FNV-1a style streams
+  for (unsigned char ch : src) {
+    h1 = (h1 ^ ch) * 0x100000001b3ULL;
+    h2 = (h2 ^ ch) * 0x9e3779b97f4a7c15ULL + 0x7f4a7c15ULL;
+  }
+  int ver_major = 0, ver_minor = 0;
+  (void)hiprtcVersion(&ver_major, &ver_minor);
+  char buf[96];
+  snprintf(buf, sizeof buf, "gfx950-rtc%d.%d-%016llx%016llx.co", ver_major, ver_minor, (unsigned long long)h1, (unsigned long long)h2);
+  return buf;
+}
+bool cache_load(const std::string& path, std::vector<char>& code) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  code.assign((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  return code.size() > 64;
+}
+void cache_store(const std::string& path, const std::vector<char>& code) {
+  const std::string tmp = path + ".tmp" + std::to_string((unsigned long long)getpid());
+  {
+    std::ofstream f(tmp, std::ios::binary);
+    if (!f) return;
+    f.write(code.data(), (std::streamsize)code.size());
+    if (!f) return;
+  }
+  if (rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
+}
+
+void hiprtc_check(hiprtcResult r, const char* what) {
+  if (r != HIPRTC_SUCCESS) throw MhError(MH_ERR_INTERNAL, std::string("hiprtc: ") + what + ": " + hiprtcGetErrorString(r));
+}
+
+}  // namespace
+
+struct JitProgram {
+  mh_ctx* ctx = nullptr;
+  std::vector<hipModule_t> modules;
+  std::vector<hipFunction_t> fns;
+  size_t n_spill = 0;  // u64 slots per point crossing chunk boundaries
+};
+
+void jit_program_free(JitProgram* p) {
+  if (!p) return;
+  for (hipModule_t m : p->modules) (void)hipModuleUnload(m);
+  delete p;
+}
+size_t jit_program_chunks(const JitProgram* p) { return p ? p->fns.size() : 0; }
+
+JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
+  const int mode = env_int("MH_JIT", -1);  // 0: never, 1: always, default: large DAGs only
+  if (mode == 0) return nullptr;
+  const std::vector<DagNode>& nodes = ir.nodes;
+  auto interior = [&](uint32_t id) { return nodes[id].op >= DOP_ADD; };
+  size_t n_gates = 0;
+  for (size_t i = 0; i < nodes.size(); i++) n_gates += ir.live[i] && interior((uint32_t)i);
+  if (mode != 1 && n_gates < (size_t)env_int("MH_JIT_MIN_GATES", 400)) return nullptr;
+
+  // ---- emission order: depth-first from each constraint in turn (a value is computed when first needed,
+  // which keeps the cut sets between chunks small), the fold right after the constraint's node ----
+  std::vector<Ev> seq;
+  {
+    std::vector<char> done(nodes.size(), 0);
+    std::vector<std::pair<uint32_t, int>> st;
+    for (size_t k = 0; k < ir.cons.size(); k++) {
+      const uint32_t root = ir.cons[k];
+      if (interior(root) && !done[root]) st.push_back({root, 0});
+      while (!st.empty()) {
+        auto& [id, phase] = st.back();
+        const DagNode& nd = nodes[id];
+        if (done[id]) { st.pop_back(); continue; }
+        if (phase == 0) {
+          phase = 1;
+          if (interior(nd.a) && !done[nd.a]) { st.push_back({nd.a, 0}); continue; }
+        }
+        if (phase == 1) {
+          phase = 2;
+          if (nd.op != DOP_NEG && interior(nd.b) && !done[nd.b]) { st.push_back({nd.b, 0}); continue; }
+        }
+        done[id] = 1;
+        seq.push_back({id, -1});
+        st.pop_back();
+      }
+      seq.push_back({root, (int32_t)k});
+    }
+  }
+  // ---- cut into chunks of roughly equal multiplication count ----
+  auto cost = [&](const Ev& e) -> int {
+    const DagNode& nd = nodes[e.node];
+    if (e.fold_k >= 0) return nd.ext ? 3 : 2;
+    if (nd.op != DOP_MUL) return 1;
+    const bool ea = nodes[nd.a].ext, eb = nodes[nd.b].ext;
+    return ea && eb ? 4 : (ea || eb ? 2 : 1);
+  };
+  const int budget = std::max(16, env_int("MH_JIT_CHUNK", 320));
+  std::vector<Chunk> chunks;
+  {
+    size_t lo = 0;
+    int acc = 0;
+    for (size_t i = 0; i < seq.size(); i++) {
+      acc += cost(seq[i]);
+      // never separate a node from the fold that consumes it
+      const bool fold_next = i + 1 < seq.size() && seq[i + 1].fold_k >= 0;
+      if (acc >= budget && !fold_next) {
+        chunks.push_back({lo, i + 1, {}, {}, {}});
+        lo = i + 1;
+        acc = 0;
+      }
+    }
+    if (lo < seq.size()) chunks.push_back({lo, seq.size(), {}, {}, {}});
+  }
+  const size_t n_chunks = chunks.size();
+  // ---- values crossing chunk boundaries -> spill slots (one u64 plane each), reused once dead ----
+  std::vector<int32_t> def_chunk(nodes.size(), -1), last_use(nodes.size(), -1);
+  for (size_t ci = 0; ci < n_chunks; ci++)
+    for (size_t i = chunks[ci].ev_lo; i < chunks[ci].ev_hi; i++)
+      if (seq[i].fold_k < 0) def_chunk[seq[i].node] = (int32_t)ci;
+  for (size_t ci = 0; ci < n_chunks; ci++)
+    for (size_t i = chunks[ci].ev_lo; i < chunks[ci].ev_hi; i++) {
+      const DagNode& nd = nodes[seq[i].node];
+      auto use = [&](uint32_t id) {
+        if (interior(id)) last_use[id] = std::max(last_use[id], (int32_t)ci);
+      };
+      if (seq[i].fold_k >= 0) use(seq[i].node);
+      else {
+        use(nd.a);
+        if (nd.op != DOP_NEG) use(nd.b);
+      }
+    }
+  std::vector<int32_t> slot(nodes.size(), -1);
+  size_t n_spill = 0;
+  {
+    std::vector<uint32_t> free_slots;
+    std::vector<std::vector<uint32_t>> dies(n_chunks);
+    for (size_t ci = 0; ci < n_chunks; ci++) {
+      for (size_t i = chunks[ci].ev_lo; i < chunks[ci].ev_hi; i++) {
+        if (seq[i].fold_k >= 0) continue;
+        const uint32_t id = seq[i].node;
+        if (last_use[id] <= (int32_t)ci) continue;
+        const int need = nodes[id].ext ? 2 : 1;
+        // ext values take two consecutive fresh or two separately recycled planes: keep it simple, (s, s+1)
+        uint32_t s;
+        if (need == 1 && !free_slots.empty()) {
+          s = free_slots.back();
+          free_slots.pop_back();
+        } else {
+          s = (uint32_t)n_spill;
+          n_spill += need;
+        }
+        slot[id] = (int32_t)s;
+        dies[last_use[id]].push_back(id);
+      }
+      for (uint32_t id : dies[ci]) {
+        free_slots.push_back((uint32_t)slot[id]);
+        if (nodes[id].ext) free_slots.push_back((uint32_t)slot[id] + 1);
+      }
+    }
+  }
+  // ---- source per chunk ----
+  char buf[256];
+  for (size_t ci = 0; ci < n_chunks; ci++) {
+    Chunk& ch = chunks[ci];
+    std::ostringstream decl, body;
+    std::set<std::string> declared;
+    bool need_x = false, need_fl = false;
+    auto ref = [&](uint32_t id) -> std::string {
+      const DagNode& nd = nodes[id];
+      std::string name;
+      switch (nd.op) {
+        case DOP_CONST:
+          snprintf(buf, sizeof buf, "0x%llxULL", (unsigned long long)nd.c);
+          return buf;
+        case DOP_MAIN:
+          snprintf(buf, sizeof buf, "m%u_%u", nd.a, nd.b);
+          name = buf;
+          if (declared.insert(name).second) {
+            snprintf(buf, sizeof buf, "  const u64 %s = a.main_lde[((%uull * B + jc) << a.log_n) + %s];\n", name.c_str(), nd.a,
+                     nd.b ? "rn" : "r");
+            decl << buf;
+          }
+          return name;
+        case DOP_AUX:
+          snprintf(buf, sizeof buf, "x%u_%u", nd.a, nd.b);
+          name = buf;
+          if (declared.insert(name).second) {
+            const char* rr = nd.b ? "rn" : "r";
+            snprintf(buf, sizeof buf, "  const e2 %s = {a.aux_lde[((%uull * B + jc) << a.log_n) + %s], ", name.c_str(), 2 * nd.a, rr);
+            decl << buf;
+            snprintf(buf, sizeof buf, "a.aux_lde[((%uull * B + jc) << a.log_n) + %s]};\n", 2 * nd.a + 1, rr);
+            decl << buf;
+          }
+          return name;
+        case DOP_PUBLIC:
+          snprintf(buf, sizeof buf, "a.publics[%u]", nd.a);
+          return buf;
+        case DOP_PERIODIC:
+          snprintf(buf, sizeof buf, "per%u", nd.a);
+          name = buf;
+          if (declared.insert(name).second) {
+            snprintf(buf, sizeof buf, "  const u64 %s = a.periodic[%uull * a.periodic_rows + ((r * D + a.t0 + t) %% a.periodic_rows)];\n",
+                     name.c_str(), nd.a);
+            decl << buf;
+          }
+          return name;
+        case DOP_IS_FIRST: need_fl = true; return "sel_first";
+        case DOP_IS_LAST: need_fl = true; return "sel_last";
+        case DOP_IS_TRANSITION: need_x = true; return "sel_trans";
+        case DOP_RANDOMNESS:
+          snprintf(buf, sizeof buf, "e2{a.randomness[%u], a.randomness[%u]}", 2 * nd.a, 2 * nd.a + 1);
+          return buf;
+        case DOP_AUX_VALUE:
+          snprintf(buf, sizeof buf, "e2{a.aux_values[%u], a.aux_values[%u]}", 2 * nd.a, 2 * nd.a + 1);
+          return buf;
+        default: break;
+      }
+      snprintf(buf, sizeof buf, "v%u", id);
+      name = buf;
+      if (def_chunk[id] != (int32_t)ci && declared.insert(name).second) {  // produced by an earlier chunk
+        if (nd.ext)
+          snprintf(buf, sizeof buf, "  const e2 %s = {a.spill[%dull * a.spill_stride + qb], a.spill[%dull * a.spill_stride + qb]};\n",
+                   name.c_str(), slot[id], slot[id] + 1);
+        else
+          snprintf(buf, sizeof buf, "  const u64 %s = a.spill[%dull * a.spill_stride + qb];\n", name.c_str(), slot[id]);
+        decl << buf;
+      }
+      return name;
+    };
+    bool any_fold = false;
+    for (size_t i = ch.ev_lo; i < ch.ev_hi; i++) {
+      const uint32_t id = seq[i].node;
+      const DagNode& nd = nodes[id];
+      if (seq[i].fold_k >= 0) {
+        any_fold = true;
+        const std::string x = ref(id);
+        snprintf(buf, sizeof buf, "e2{a.alpha_pows[%d], a.alpha_pows[%d]}", 2 * seq[i].fold_k, 2 * seq[i].fold_k + 1);
+        body << "  acc = e2_add(acc, " << (nd.ext ? "e2_mul(" : "e2_mulf(") << buf << ", " << x << "));\n";
+        continue;
+      }
+      const std::string A = ref(nd.a);
+      const bool ea = nodes[nd.a].ext;
+      std::string rhs;
+      if (nd.op == DOP_NEG) {
+        rhs = (ea ? "e2_neg(" : "gl_neg(") + A + ")";
+      } else {
+        const std::string Bv = ref(nd.b);
+        const bool eb = nodes[nd.b].ext;
+        if (nd.op == DOP_ADD)
+          rhs = ea && eb ? "e2_add(" + A + ", " + Bv + ")" : ea ? "e2_addf(" + A + ", " + Bv + ")" : eb ? "e2_addf(" + Bv + ", " + A + ")"
+                                                                                                     : "gl_add(" + A + ", " + Bv + ")";
+        else if (nd.op == DOP_SUB)
+          rhs = ea && eb ? "e2_sub(" + A + ", " + Bv + ")" : ea ? "e2_subf(" + A + ", " + Bv + ")" : eb ? "e2_fsub(" + A + ", " + Bv + ")"
+                                                                                                     : "gl_sub(" + A + ", " + Bv + ")";
+        else
+          rhs = ea && eb ? "e2_mul(" + A + ", " + Bv + ")" : ea ? "e2_mulf(" + A + ", " + Bv + ")" : eb ? "e2_mulf(" + Bv + ", " + A + ")"
+                                                                                                     : "gl_mul(" + A + ", " + Bv + ")";
+      }
+      body << "  const " << (nd.ext ? "e2" : "u64") << " v" << id << " = " << rhs << ";\n";
+      if (last_use[id] > (int32_t)ci) {
+        if (nd.ext)
+          body << "  a.spill[" << slot[id] << "ull * a.spill_stride + qb] = v" << id << ".c0; a.spill[" << slot[id] + 1
+               << "ull * a.spill_stride + qb] = v" << id << ".c1;\n";
+        else
+          body << "  a.spill[" << slot[id] << "ull * a.spill_stride + qb] = v" << id << ";\n";
+      }
+    }
+    std::ostringstream src;
+    src << JIT_PRELUDE;
+    src << "extern \"C\" __global__ __launch_bounds__(256) void mh_jit_chunk(JitArgs a) {\n"
+           "  const u64 qb = blockIdx.x * 256ull + threadIdx.x;\n"
+           "  if (qb >= a.q_count) return;\n"
+           "  const u64 q = a.q0 + qb;\n"
+           "  const u64 n = 1ull << a.log_n, D = 1ull << a.log_d, Dl = 1ull << a.log_dl, B = 1ull << a.log_cosets;\n"
+           "  const u64 t = q >> a.log_n, r = q & (n - 1), rn = (r + 1) & (n - 1);\n"
+           "  const u64 jc = t << a.jc_shift;\n"
+           "  (void)D; (void)Dl; (void)B; (void)rn; (void)jc;\n";
+    if (need_x || need_fl)
+      src << "  const u64 half = n >> 1;\n"
+             "  const u64 w = (r < half || half == 0) ? a.tw[half ? r : 0] : gl_neg(a.tw[r - half]);\n"
+             "  const u64 x = gl_mul(a.coset_tab[t], w);\n"
+             "  const u64 sel_trans = gl_sub(x, a.wh_inv); (void)sel_trans;\n";
+    if (need_fl)
+      src << "  const u64 sel_first = gl_mul(a.coset_tab[Dl + t], a.inv_first[q]);\n"
+             "  const u64 sel_last = gl_mul(a.coset_tab[Dl + t], a.inv_last[q]);\n";
+    src << "  e2 acc = {0, 0};\n" << decl.str() << body.str();
+    if (any_fold || ci == 0) {
+      src << "  u64* p0 = a.acc + (((2 * t) << a.log_n) + r);\n  u64* p1 = a.acc + (((2 * t + 1) << a.log_n) + r);\n";
+      if (ci == 0) src << "  *p0 = acc.c0; *p1 = acc.c1;\n";
+      else src << "  *p0 = gl_add(*p0, acc.c0); *p1 = gl_add(*p1, acc.c1);\n";
+    }
+    src << "}\n";
+    ch.src = src.str();
+  }
+  if (const char* dir = getenv("MH_JIT_DUMP")) {
+    for (size_t ci = 0; ci < n_chunks; ci++) {
+      std::ofstream f(std::string(dir) + "/chunk" + std::to_string(ci) + ".hip");
+      f << chunks[ci].src;
+    }
+  }
+  if (env_int("MH_JIT_NO_COMPILE", 0)) return nullptr;  // source generation only (tools, no GPU)
+
+  // ---- compile the chunks in parallel (cached on disk by source hash) ----
+  const std::string cdir = cache_dir();
+  std::atomic<size_t> next{0};
+  std::atomic<bool> failed{false};
+  std::string first_error;
+  std::mutex err_mu;
+  auto worker = [&]() {
+    for (;;) {
+      const size_t ci = next.fetch_add(1);
+      if (ci >= n_chunks || failed.load()) return;
+      Chunk& ch = chunks[ci];
+      try {
+        const std::string cpath = cdir.empty() ? "" : cdir + "/" + cache_key(ch.src);
+        if (!cpath.empty() && cache_load(cpath, ch.code)) continue;
+        hiprtcProgram prog;
+        hiprtc_check(hiprtcCreateProgram(&prog, ch.src.c_str(), "mh_jit_chunk.hip", 0, nullptr, nullptr), "create");
+        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+        const hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+        if (r != HIPRTC_SUCCESS) {
+          size_t ls = 0;
+          hiprtcGetProgramLogSize(prog, &ls);
+          std::string lg(ls, 0);
+          if (ls) hiprtcGetProgramLog(prog, &lg[0]);
+          hiprtcDestroyProgram(&prog);
+          throw MhError(MH_ERR_INTERNAL, "hiprtc compile of constraint chunk " + std::to_string(ci) + " failed: " + lg.substr(0, 800));
+        }
+        size_t cs = 0;
+        hiprtc_check(hiprtcGetCodeSize(prog, &cs), "code size");
+        ch.code.resize(cs);
+        hiprtc_check(hiprtcGetCode(prog, ch.code.data()), "get code");
+        hiprtcDestroyProgram(&prog);
+        if (!cpath.empty()) cache_store(cpath, ch.code);
+      } catch (const std::exception& e) {
+        std::lock_guard<std::mutex> g(err_mu);
+        if (!failed.exchange(true)) first_error = e.what();
+      }
+    }
+  };
+  {
+    unsigned nt = std::max(1u, std::min<unsigned>((unsigned)n_chunks, std::min(64u, std::thread::hardware_concurrency())));
+    nt = (unsigned)std::max(1, env_int("MH_JIT_THREADS", (int)nt));
+    std::vector<std::thread> th;
+    for (unsigned i = 0; i < nt; i++) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+  }
+  if (failed.load()) throw MhError(MH_ERR_INTERNAL, first_error);
+  std::unique_ptr<JitProgram> prog(new JitProgram());
+  prog->ctx = ctx;
+  prog->n_spill = n_spill;
+  try {
+    for (size_t ci = 0; ci < n_chunks; ci++) {
+      hipModule_t m;
+      HIP_CHECK(hipModuleLoadData(&m, chunks[ci].code.data()));
+      prog->modules.push_back(m);
+      hipFunction_t f;
+      HIP_CHECK(hipModuleGetFunction(&f, m, "mh_jit_chunk"));
+      prog->fns.push_back(f);
+    }
+  } catch (...) {
+    jit_program_free(prog.release());
+    throw;
+  }
+  return prog.release();
+}
+
+void jit_quotient_run(mh_ctx* c, const JitProgram* p, JitArgs a, size_t total) {
+  // Points are swept in blocks of 2^21 so that the spill planes stay bounded (n_spill * 16 MB) for any trace
+  // height.  (Measured on a 6.5 k-gate system at 2^23 points: 2^16-point blocks 72 ms, 2^18 45.8, 2^20 45.3,
+  // one block 43.4 -- cache-sized blocks do not pay, launches do.)
+  const size_t block = std::min(total, (size_t)1 << std::max(10, env_int("MH_JIT_BLOCK_LOG", 21)));
+  DevBuf spill(std::max<size_t>(1, p->n_spill) * block * 8);
+  a.spill = spill.u();
+  a.spill_stride = block;
+  for (size_t q0 = 0; q0 < total; q0 += block) {
+    a.q0 = q0;
+    a.q_count = std::min(block, total - q0);
+    void* params[] = {&a};
+    for (hipFunction_t f : p->fns)
+      HIP_CHECK(hipModuleLaunchKernel(f, (unsigned)((a.q_count + 255) / 256), 1, 1, 256, 1, 1, 0, c->stream, params, nullptr));
+  }
+  HIP_CHECK(hipStreamSynchronize(c->stream));  // the spill area dies with this scope
+}

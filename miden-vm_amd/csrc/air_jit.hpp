@@ -1,0 +1,39 @@
+// Specialised constraint kernels: the AIR's DAG compiled (hiprtc) into straight-line gfx950 code.
+//
+// The interpreter (quotient.hip) re-reads every trace cell each time a gate uses it; for a Miden-sized
+// system (thousands of gates over ~130 cells) that is megabytes of L2 traffic per wavefront.  Compiled
+// code keeps cells and intermediates in VGPRs.  One kernel per CHUNK of the DAG (a few hundred gates:
+// the compiler's time is super-linear in the size of a straight-line block); values that cross a chunk
+// boundary go through an HBM spill area, the alpha-fold is accumulated in the quotient buffer itself.
+// Replaces, like the interpreter, `air.eval(&mut ProverConstraintFolder)` of
+// crates/lifted-stark/src/prover/constraints/mod.rs:244-246 + folder.rs:88-105.
+#pragma once
+#include "air.hpp"
+#include "gl.cuh"
+
+// Kernel argument block; the generated source carries a textual copy (air_jit.cpp, JIT_PRELUDE).
+struct JitArgs {
+  const u64* main_lde;
+  const u64* aux_lde;
+  u64* spill;           // [n_spill][spill_stride]
+  u64* acc;             // partial alpha-folds, planes [2 * Dl][n]
+  const u64* tw;        // w_n^k
+  const u64* coset_tab; // [3][Dl]
+  const u64* inv_first;
+  const u64* inv_last;
+  const u64* periodic;
+  const u64* publics;
+  const u64* randomness;
+  const u64* aux_values;
+  const u64* alpha_pows;
+  u64 wh_inv;
+  u64 q0, q_count;      // this launch covers points q0 .. q0 + q_count - 1
+  u64 spill_stride;
+  int log_n, log_cosets, log_d, log_dl, jc_shift;
+  u32 t0, periodic_rows;
+};
+static_assert(sizeof(JitArgs) == 13 * 8 + 4 * 8 + 7 * 4 + 4, "JitArgs layout is mirrored in the generated source");
+
+// Runs every chunk over all `total` points of the quotient coset(s); a.q0 / q_count / spill are filled here.
+void jit_quotient_run(mh_ctx* c, const JitProgram* p, JitArgs a, size_t total);
+size_t jit_program_chunks(const JitProgram* p);

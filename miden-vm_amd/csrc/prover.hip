@@ -10,6 +10,7 @@
 // Transcript order: SURVEY.md Appendix A.
 #include "../../include/midenhip.h"
 #include "air.hpp"
+#include "air_jit.hpp"
 #include "challenger.hpp"
 #include "ctx.hpp"
 #include "gl.cuh"
@@ -632,6 +633,7 @@ void mh_air_free(mh_air* a) {
   delete a;
 }
 int mh_air_log_quotient_degree(const mh_air* a) { return a ? a->log_quotient_degree : -1; }
+int mh_air_compiled_chunks(const mh_air* a) { return a ? (int)jit_program_chunks(a->jit) : -1; }
 
 // ---- coset-sharded commitment (one process per GPU) -------------------------
 struct mh_shard {

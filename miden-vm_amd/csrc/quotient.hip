@@ -14,6 +14,7 @@
 // Roofline: HBM (reads the touched main/aux columns once per AIR, writes 16 B per point); for real
 // AIRs with thousands of gates the interpreter is VALU bound.
 #include "air.hpp"
+#include "air_jit.hpp"
 #include "gl.cuh"
 #include "kernels.hpp"
 
@@ -126,6 +127,25 @@ __global__ __launch_bounds__(256) void k_eval_quotient(QuotArgs a) {
   }
   a.acc_out[((2 * t) << a.log_n) + r] = qv.c0;
   a.acc_out[((2 * t + 1) << a.log_n) + r] = qv.c1;
+}
+
+// After the compiled chunks (air_jit.cpp) left sum_k alpha^(K-1-k) C_k in `acc`: * 1/Z_H, + beta * previous AIRs.
+__global__ void k_quot_finish(u64* __restrict__ acc, const u64* __restrict__ coset_tab, int log_n, int log_dl, const u64* __restrict__ acc_in,
+                              int log_n_prev, e2 beta) {
+  const size_t n = (size_t)1 << log_n, Dl = (size_t)1 << log_dl;
+  const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (q >= n * Dl) return;
+  const size_t t = q >> log_n, r = q & (n - 1);
+  u64* p0 = acc + ((2 * t) << log_n) + r;
+  u64* p1 = acc + ((2 * t + 1) << log_n) + r;
+  e2 qv = e2_mulf(e2{*p0, *p1}, coset_tab[2 * Dl + t]);
+  if (acc_in) {
+    const size_t n_prev = (size_t)1 << log_n_prev, rp = r & (n_prev - 1);
+    e2 old = e2{acc_in[((2 * t) << log_n_prev) + rp], acc_in[((2 * t + 1) << log_n_prev) + rp]};
+    qv = e2_add(e2_mul(old, beta), qv);
+  }
+  *p0 = qv.c0;
+  *p1 = qv.c1;
 }
 
 // 1/(x - 1) and 1/(x - w_H^-1) for every point of the quotient coset (batch inversion: 4 points per
@@ -266,6 +286,26 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
     ProfScope ps(c, "quotient_selectors", 16.0 * n * D);
     hipLaunchKernelGGL(k_selector_inverses, dim3((unsigned)((n * D + 1023) / 1024)), dim3(256), 0, c->stream, tw, dblob.u() + o_tab,
                        log_n, log_dl, wh_inv, inv_first.u(), inv_last.u());
+  }
+  if (air->jit) {  // compiled chunks: large constraint systems
+    JitArgs j{};
+    j.main_lde = main.lde.u(); j.aux_lde = aux.lde.u();
+    j.acc = acc_out;
+    j.tw = tw; j.coset_tab = dblob.u() + o_tab;
+    j.inv_first = inv_first.u(); j.inv_last = inv_last.u();
+    j.periodic = dblob.u() + o_pt; j.periodic_rows = (u32)prow;
+    j.publics = dblob.u() + o_pub; j.randomness = dblob.u() + o_rnd; j.aux_values = dblob.u() + o_av;
+    j.alpha_pows = dblob.u() + o_ap;
+    j.wh_inv = wh_inv;
+    j.log_n = log_n; j.log_cosets = main.log_cosets; j.log_d = log_d; j.log_dl = log_dl;
+    j.jc_shift = log_blowup - log_d;
+    j.t0 = (u32)t0;
+    ProfScope ps(c, "quotient_eval", (double)n * D * (8.0 * (air->main_width + 2 * air->aux_width) + 16.0));
+    jit_quotient_run(c, air->jit, j, n * D);
+    hipLaunchKernelGGL(k_quot_finish, dim3((unsigned)((n * D + 255) / 256)), dim3(256), 0, c->stream, acc_out, dblob.u() + o_tab, log_n,
+                       log_dl, acc_in, log_n_prev, beta);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return;
   }
   QuotArgs a{};
   a.code = (const AirIns*)air->d_code.p;

@@ -13,7 +13,9 @@ log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 ctx = pkg.Ctx(0)
 air = A.synthetic_big_air()
 print("nodes", int(air.blob[8]), "constraints", int(air.blob[9]))
+t0 = time.perf_counter()
 dair = pkg.DeviceAir(ctx, air)
+print("mh_air_load (incl. kernel specialisation) s", time.perf_counter() - t0)
 tr = ctx.upload_trace(A.dummy_trace(log_n, 51))
 prm = ob.PROD_PARAMS
 st, pre = ob.challenger_state(), ob.protocol_pre_observe(prm, [])
