@@ -30,6 +30,7 @@ EXPORTS = [
     "mh_session_begin", "mh_session_free", "mh_session_shape", "mh_session_commit_main", "mh_session_commit_aux",
     "mh_session_commit_quotient", "mh_session_ood_point_ok", "mh_session_ood", "mh_session_deep", "mh_session_fri_commit",
     "mh_session_fri_fold", "mh_session_fri_final", "mh_session_open", "mh_grind",
+    "mh_lookup_load", "mh_lookup_free", "mh_air_attach_lookup", "mh_lookup_build_aux", "mh_trace_download",
 ]
 
 _lib = None
@@ -161,6 +162,18 @@ class Ctx:
 class Trace:
     """Device-resident RowMajorMatrix<Felt> (stored column-major on the GPU)."""
 
+    @classmethod
+    def from_handle(cls, ctx, h, log_n, width):
+        t = cls.__new__(cls)
+        t.ctx, t.h, t.log_n, t.width = ctx, h, log_n, width
+        ctx._children.add(t)
+        return t
+
+    def download(self):
+        out = np.zeros((1 << self.log_n, self.width), dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.mh_trace_download(self.ctx.h, self.h, _ptr(out)))
+        return out
+
     def __init__(self, ctx, matrix):
         m = _arr(matrix)
         n, w = m.shape
@@ -285,10 +298,49 @@ class DeviceAir:
         ctx._children.add(self)
         ctx.lib.mh_air_compiled_chunks.argtypes = [C.c_void_p]
         self.compiled_chunks = int(ctx.lib.mh_air_compiled_chunks(h))
+        self._lookup = None
+
+    def attach_lookup(self, dev_lookup):
+        """Build this AIR's LogUp aux trace on the device during proofs (None detaches)."""
+        self.ctx.check(self.ctx.lib.mh_air_attach_lookup(self.h, dev_lookup.h if dev_lookup is not None else None))
+        self._lookup = dev_lookup
 
     def free(self):
         if getattr(self, "h", None):
             self.ctx.lib.mh_air_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceLookup:
+    """mh_lookup: a LogUp lookup program ("MHLKP001" blob, dag.LookupBuilder) compiled for the device."""
+
+    def __init__(self, ctx, lookup):
+        self.ctx, self.lookup = ctx, lookup
+        blob = _arr(lookup.blob)
+        h = C.c_void_p()
+        ctx.lib.mh_lookup_free.argtypes = [C.c_void_p]
+        ctx.check(ctx.lib.mh_lookup_load(ctx.h, _ptr(blob), C.c_size_t(blob.size), C.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+
+    def build_aux(self, main_trace, randomness):
+        """-> (aux Trace on the device [n, 2 * num_cols], (c0, c1) accumulator final)."""
+        rnd = _arr([int(x) for r in randomness for x in r] or [0])
+        h = C.c_void_p()
+        fin = np.zeros(2, dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.mh_lookup_build_aux(self.ctx.h, self.h, main_trace.h, _ptr(rnd), C.c_size_t(len(randomness)),
+                                                        C.byref(h), _ptr(fin)))
+        return Trace.from_handle(self.ctx, h, main_trace.log_n, 2 * self.lookup.num_cols), (int(fin[0]), int(fin[1]))
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.mh_lookup_free(self.h)
             self.h = None
 
     def __del__(self):

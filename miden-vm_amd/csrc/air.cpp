@@ -190,3 +190,50 @@ mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
   air->jit = jit_program_build(ctx, ir);  // null for small DAGs (or MH_JIT=0): the interpreter runs
   return air.release();
 }
+
+// ---- lookup blob -> DagIR in output mode -> compiled kernels ----------------------------------------------
+mh_lookup* mh_lookup::load(mh_ctx* ctx, const u64* w, size_t n) {
+  MH_REQUIRE(n >= 12 && w[0] == LOOKUP_MAGIC, "lookup blob: bad magic / too short");
+  // Same header / periodic / node sections as a constraint DAG (no aux columns, publics or aux values); the
+  // tail lists, per aux column, its fraction count and (multiplicity node, denominator node) pairs.
+  const size_t n_periodic = w[6], n_nodes = w[8], n_cols = w[2];
+  MH_REQUIRE(n_cols > 0 && n_cols < 4096, "lookup blob: bad column count");
+  size_t pos = 12;
+  for (size_t i = 0; i < n_periodic; i++) {
+    MH_REQUIRE(pos < n && w[pos] < n, "lookup blob: truncated periodic table");
+    pos += 1 + w[pos];
+  }
+  MH_REQUIRE(n_nodes < ((size_t)1 << 28) && pos + 2 * n_nodes <= n, "lookup blob: truncated");
+  const size_t tail = pos + 2 * n_nodes;
+  std::vector<u64> blob(w, w + tail);
+  blob[0] = DAG_MAGIC;
+  blob[2] = 0; blob[4] = 0; blob[5] = 0; blob[7] = 0;
+  std::unique_ptr<mh_lookup> lk(new mh_lookup());
+  lk->ctx = ctx;
+  size_t p = tail;
+  std::vector<u64> outs;
+  for (size_t c = 0; c < n_cols; c++) {
+    MH_REQUIRE(p < n, "lookup blob: truncated column list");
+    const size_t cnt = w[p++];
+    MH_REQUIRE(cnt < 65536 && p + 2 * cnt <= n, "lookup blob: truncated fraction list");
+    lk->col_count.push_back((uint32_t)cnt);
+    for (size_t j = 0; j < 2 * cnt; j++) outs.push_back(w[p + j]);
+    p += 2 * cnt;
+  }
+  MH_REQUIRE(!outs.empty(), "lookup blob: no fractions");
+  blob[9] = outs.size();
+  blob.insert(blob.end(), outs.begin(), outs.end());
+  DagIR ir = dag_parse(blob.data(), blob.size());
+  for (size_t i = 0; i < ir.nodes.size(); i++)
+    MH_REQUIRE(!ir.live[i] || (ir.nodes[i].op != DOP_IS_FIRST && ir.nodes[i].op != DOP_IS_LAST && ir.nodes[i].op != DOP_IS_TRANSITION),
+               "lookup blob: row selectors have no meaning in a bus message");
+  ir.outputs = true;
+  lk->main_width = ir.main_width;
+  lk->num_cols = n_cols;
+  lk->num_randomness = ir.num_randomness;
+  lk->periodic = ir.periodic;
+  for (uint32_t id : ir.cons) lk->out_ext.push_back(ir.nodes[id].ext ? 1 : 0);
+  lk->jit = jit_program_build(ctx, ir);
+  MH_REQUIRE(lk->jit, "internal: lookup program was not compiled");
+  return lk.release();
+}

@@ -49,12 +49,15 @@ struct DagIR {
   std::vector<uint32_t> cons;  // constraint k = nodes[cons[k]]
   std::vector<char> live;      // reachable from a constraint
   bool uses_first_last = false;
+  // false: `cons` are constraints, alpha-folded into one EF value per point (quotient evaluation);
+  // true: `cons` are plain outputs, each stored to its own pair of planes (LogUp fractions, logup.hip)
+  bool outputs = false;
 };
 DagIR dag_parse(const u64* w, size_t n);
 
 struct JitProgram;  // air_jit.cpp
 void jit_program_free(JitProgram* p);
-JitProgram* jit_program_build(mh_ctx* c, const DagIR& ir);
+JitProgram* jit_program_build(mh_ctx* c, const DagIR& ir);  // null: DAG too small (never null when ir.outputs)
 
 struct mh_air {
   mh_ctx* ctx;
@@ -67,6 +70,7 @@ struct mh_air {
   uint32_t n_slots = 0;
   DevBuf d_code;
   JitProgram* jit = nullptr;  // specialised constraint kernels (large DAGs), else the interpreter runs
+  const struct mh_lookup* lookup = nullptr;  // attached LogUp program: the aux trace is built on the device
   ~mh_air() { jit_program_free(jit); }
 
   size_t max_period() const {
@@ -75,4 +79,21 @@ struct mh_air {
     return m;
   }
   static mh_air* load(mh_ctx* c, const u64* w, size_t n);
+};
+
+// ---- LogUp lookup program ("MHLKP001" blob, include/midenhip.h): per aux column a list of fractions
+// (multiplicity, denominator), both DAG expressions over the main-trace row window, periodic columns and
+// the lookup challenges.  Replaces the collection phase of air/src/lookup/prover.rs (build_lookup_fractions)
+// for AIRs whose bus messages are exported as expressions; the accumulation (aux_builder.rs:202-330) is logup.hip.
+static const u64 LOOKUP_MAGIC = 0x4d484c4b50303031ULL;  // "MHLKP001"
+struct mh_lookup {
+  mh_ctx* ctx;
+  size_t main_width = 0, num_cols = 0, num_randomness = 0;
+  std::vector<std::vector<u64>> periodic;
+  std::vector<uint32_t> col_count;  // fractions of column c
+  std::vector<char> out_ext;        // per output (m_0, d_0, m_1, d_1, ...): EF-valued?
+  JitProgram* jit = nullptr;
+  ~mh_lookup() { jit_program_free(jit); }
+  size_t n_fractions() const { return out_ext.size() / 2; }
+  static mh_lookup* load(mh_ctx* c, const u64* w, size_t n);
 };

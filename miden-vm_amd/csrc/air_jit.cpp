@@ -152,7 +152,7 @@ void jit_program_free(JitProgram* p) {
 size_t jit_program_chunks(const JitProgram* p) { return p ? p->fns.size() : 0; }
 
 JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
-  const int mode = env_int("MH_JIT", -1);  // 0: never, 1: always, default: large DAGs only
+  const int mode = ir.outputs ? 1 : env_int("MH_JIT", -1);  // 0: never, 1: always, default: large DAGs only
   if (mode == 0) return nullptr;
   const std::vector<DagNode>& nodes = ir.nodes;
   auto interior = [&](uint32_t id) { return nodes[id].op >= DOP_ADD; };
@@ -336,6 +336,15 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
       if (seq[i].fold_k >= 0) {
         any_fold = true;
         const std::string x = ref(id);
+        if (ir.outputs) {  // output k -> planes 2k (c0) and 2k+1 (c1, EF outputs only), rows r (single coset)
+          const int k = seq[i].fold_k;
+          if (nd.ext)
+            body << "  a.acc[(" << 2 * k << "ull << a.log_n) + r] = " << x << ".c0; a.acc[(" << 2 * k + 1 << "ull << a.log_n) + r] = " << x
+                 << ".c1;\n";
+          else
+            body << "  a.acc[(" << 2 * k << "ull << a.log_n) + r] = " << x << ";\n";
+          continue;
+        }
         snprintf(buf, sizeof buf, "e2{a.alpha_pows[%d], a.alpha_pows[%d]}", 2 * seq[i].fold_k, 2 * seq[i].fold_k + 1);
         body << "  acc = e2_add(acc, " << (nd.ext ? "e2_mul(" : "e2_mulf(") << buf << ", " << x << "));\n";
         continue;
@@ -385,8 +394,8 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
     if (need_fl)
       src << "  const u64 sel_first = gl_mul(a.coset_tab[Dl + t], a.inv_first[q]);\n"
              "  const u64 sel_last = gl_mul(a.coset_tab[Dl + t], a.inv_last[q]);\n";
-    src << "  e2 acc = {0, 0};\n" << decl.str() << body.str();
-    if (any_fold || ci == 0) {
+    src << "  e2 acc = {0, 0}; (void)acc;\n" << decl.str() << body.str();
+    if (!ir.outputs && (any_fold || ci == 0)) {
       src << "  u64* p0 = a.acc + (((2 * t) << a.log_n) + r);\n  u64* p1 = a.acc + (((2 * t + 1) << a.log_n) + r);\n";
       if (ci == 0) src << "  *p0 = acc.c0; *p1 = acc.c1;\n";
       else src << "  *p0 = gl_add(*p0, acc.c0); *p1 = gl_add(*p1, acc.c1);\n";

@@ -115,3 +115,7 @@ void fri_leaf_hash(mh_ctx* c, const u64* ev, int log_rows, int cbits, int log_ar
 void fri_fold(mh_ctx* c, const u64* ev, int log_rows, int cbits, int cbits_global, size_t coset0, int log_arity, e2 beta, u64* out);
 void fri_to_natural(mh_ctx* c, const u64* ev, int log_rows, int cbits, u64* out);
 u64 fri_grind(mh_ctx* c, const u64 st[12], const u64* in, int n_in, int bits);
+
+// logup.hip
+struct mh_lookup;
+mh_trace* lookup_build_aux(mh_ctx* c, const mh_lookup* lk, const mh_trace* main, const std::vector<e2>& randomness, e2* acc_final);

@@ -97,6 +97,7 @@ struct NttPassArgs {
   size_t src_col_stride, dst_col_stride, dst_z_stride;  // in elements
   int log_n, s_lo, r_bits, cb;                          // stages s_lo .. s_lo+r_bits-1, tile = 2^(r_bits+cb)
   int dif;                                              // 1 = DIF (a+b,(a-b)w), descending; 0 = DIT
+  int canon_out;                                        // store canonical values (last pass of a transform whose output leaves the NTT)
   const u64* tw;                                        // w^k (k < N/2) for the transform direction
   const u64* scale_lo;                                  // optional: multiply on load by
   const u64* scale_hi;                                  //   scale_lo[z][k & m] * scale_hi[z][k >> lb], k = bitrev(pos)
@@ -228,7 +229,7 @@ __device__ __forceinline__ void ntt_round(const NttPassArgs& a, u64* lds, int st
 #pragma unroll
       for (int e = 0; e < (1 << G); e++) {
         const u32 l = l0 | ((u32)e << b0);
-        dst_direct[gbase | ((size_t)(l >> a.cb) << a.s_lo) | (l & cb_mask)] = ntt_canon(x[e]);
+        dst_direct[gbase | ((size_t)(l >> a.cb) << a.s_lo) | (l & cb_mask)] = a.canon_out ? ntt_canon(x[e]) : x[e];
       }
     } else {
 #pragma unroll
@@ -336,6 +337,7 @@ void ntt_inverse_dif_inplace(mh_ctx* c, u64* cols, size_t n_cols, int log_n) {
     a.dst_z_stride = 0;
     a.log_n = log_n; a.s_lo = plan[i].s_lo; a.r_bits = plan[i].r_bits; a.cb = plan[i].cb;
     a.dif = 1; a.tw = tw; a.scale_lo = nullptr; a.scale_hi = nullptr;
+    a.canon_out = 0;  // the coefficients only feed the forward passes' multiplications
     launch_pass(c, a, n_cols, 1);
   }
 }
@@ -389,6 +391,7 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
     }
     a.log_n = log_n; a.s_lo = plan[i].s_lo; a.r_bits = plan[i].r_bits; a.cb = plan[i].cb;
     a.dif = 0; a.tw = tw;
+    a.canon_out = i + 1 == plan.size();
     if (i == 0) {
       launch_pass(c, a, n_cols, nz);
     } else {

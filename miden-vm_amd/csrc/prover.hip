@@ -258,7 +258,11 @@ struct mh_session {
       const mh_air* a = airs[i];
       const size_t n = (size_t)1 << lhs[i], w = 2 * a->aux_width;
       aux_vals[i].assign(a->num_aux_values, e2_make(0));
-      if (cb) {
+      if (a->lookup) {  // LogUp aux trace built on the device from the AIR's lookup program; value = acc_final
+        e2 fin;
+        aux_tr[i].reset(lookup_build_aux(c, a->lookup, traces[i], randomness, &fin));
+        aux_vals[i][0] = fin;
+      } else if (cb) {
         std::vector<u64> host(n * w, 0), vals(2 * std::max<size_t>(1, a->num_aux_values), 0);
         int rc = cb(user, i, rand_flat.data(), host.data(), vals.data());
         MH_REQUIRE(rc == 0, "aux trace builder / external assertion failed");
@@ -633,6 +637,58 @@ void mh_air_free(mh_air* a) {
   delete a;
 }
 int mh_air_log_quotient_degree(const mh_air* a) { return a ? a->log_quotient_degree : -1; }
+// ---- LogUp lookup programs -----------------------------------------------------------------------------
+int mh_lookup_load(mh_ctx* c, const uint64_t* blob, size_t n_words, mh_lookup** out) {
+  MH_TRY(c)
+  MH_REQUIRE(c && blob && out, "null argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  *out = mh_lookup::load(c, blob, n_words);
+  MH_CATCH
+}
+void mh_lookup_free(mh_lookup* l) {
+  if (!l) return;
+  (void)hipSetDevice(l->ctx->device);
+  PoolScope ps(l->ctx);
+  delete l;
+}
+int mh_air_attach_lookup(mh_air* a, const mh_lookup* l) {
+  MH_TRY(a ? a->ctx : nullptr)
+  MH_REQUIRE(a, "null argument");
+  if (l) {
+    MH_REQUIRE(l->main_width == a->main_width, "lookup program and AIR disagree on the trace width");
+    MH_REQUIRE(l->num_cols == a->aux_width, "lookup program and AIR disagree on the number of aux columns");
+    MH_REQUIRE(a->num_aux_values == 1, "a LogUp AIR commits exactly one aux value (the accumulator's final)");
+    MH_REQUIRE(l->num_randomness <= a->num_randomness, "lookup program needs more challenges than the AIR samples");
+  }
+  a->lookup = l;
+  MH_CATCH
+}
+int mh_lookup_build_aux(mh_ctx* c, const mh_lookup* l, const mh_trace* main_trace, const uint64_t* randomness, size_t n_randomness,
+                        mh_trace** aux_out, uint64_t acc_final[2]) {
+  MH_TRY(c)
+  MH_REQUIRE(c && l && main_trace && aux_out && acc_final && (randomness || !n_randomness), "null argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  std::vector<e2> rnd;
+  for (size_t i = 0; i < n_randomness; i++) rnd.push_back(e2{gl_canon(randomness[2 * i]), gl_canon(randomness[2 * i + 1])});
+  e2 fin;
+  *aux_out = lookup_build_aux(c, l, main_trace, rnd, &fin);
+  acc_final[0] = fin.c0;
+  acc_final[1] = fin.c1;
+  MH_CATCH
+}
+int mh_trace_download(mh_ctx* c, const mh_trace* t, uint64_t* rowmajor_out) {
+  MH_TRY(c)
+  MH_REQUIRE(c && t && rowmajor_out, "null argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  const size_t n = (size_t)1 << t->log_n;
+  std::vector<u64> cm(n * t->width);
+  HIP_CHECK(hipMemcpyAsync(cm.data(), t->cols.p, cm.size() * 8, hipMemcpyDeviceToHost, c->stream));
+  c->sync();
+  for (size_t col = 0; col < t->width; col++)
+    for (size_t r = 0; r < n; r++) rowmajor_out[r * t->width + col] = cm[col * n + r];
+  MH_CATCH
+}
+
 int mh_air_compiled_chunks(const mh_air* a) { return a ? (int)jit_program_chunks(a->jit) : -1; }
 
 // ---- coset-sharded commitment (one process per GPU) -------------------------

@@ -163,3 +163,47 @@ def dummy_miden_air(width, num_aux_cols, num_public=0):
         prod = prod * b.main(j)
     b.assert_zero(prod)
     return Air(b, build_aux=None, name=f"miden:{width}:{num_aux_cols}")
+
+
+LOOKUP_MAGIC = 0x4d484c4b50303031  # "MHLKP001"
+
+
+class LookupBuilder(AirBuilder):
+    """Exporter of an AIR's LogUp bus messages as a lookup program (include/midenhip.h, "MHLKP001"): per aux
+    column a list of fractions (multiplicity, denominator), expressions over the main-trace row window, periodic
+    columns and the lookup challenges.  Reference analogue: `LookupAir::eval` on a `ProverLookupBuilder`
+    (air/src/lookup/prover.rs), whose pushes `(m, d)` per column are what build_lookup_fractions collects."""
+
+    def __init__(self, main_width, num_cols, num_randomness=2, periodic=()):
+        super().__init__(main_width, aux_width=0, num_randomness=num_randomness, periodic=periodic)
+        self.num_cols = num_cols
+        self.columns = [[] for _ in range(num_cols)]
+
+    def randomness(self, i):  # challenges are EF even though the program has no aux columns
+        assert 0 <= i < self.num_randomness
+        return self._node(OP_RANDOMNESS, i, 0, 0, 0, True)
+
+    def fraction(self, col, multiplicity, denominator):
+        m = multiplicity if isinstance(multiplicity, Expr) else self.const(multiplicity)
+        d = denominator if isinstance(denominator, Expr) else self.const(denominator)
+        self.columns[col].append((m.id, d.id))
+
+    def blob(self):
+        w = [LOOKUP_MAGIC, self.main_width, self.num_cols, self.num_randomness, 0, 0, len(self.periodic), 0, len(self.nodes), 0, 0, 0]
+        for col in self.periodic:
+            w.append(len(col))
+            w.extend(col)
+        for op, a, b, c in self.nodes:
+            w.append(op | (a << 8) | (b << 36))
+            w.append(c)
+        for col in self.columns:
+            w.append(len(col))
+            for m, d in col:
+                w.extend((m, d))
+        return np.array(w, dtype=np.uint64)
+
+
+class Lookup:
+    def __init__(self, builder, name="lookup"):
+        self.name, self.main_width, self.num_cols, self.num_randomness = name, builder.main_width, builder.num_cols, builder.num_randomness
+        self.blob = builder.blob()

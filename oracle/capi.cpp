@@ -7,6 +7,7 @@
 #include "ntt.hpp"
 #include "lmcs.hpp"
 #include "stark.hpp"
+#include "lookup.hpp"
 #include <cstring>
 #include <cstdio>
 
@@ -199,6 +200,24 @@ size_t orc_ch_state(void* h, uint64_t state[12], uint64_t pending[8]) {
 void orc_ch_finalize(void* h, uint64_t digest[4]) {
   Digest d = ((Challenger*)h)->finalize();
   memcpy(digest, d.data(), 32);
+}
+
+// ---- LogUp aux trace (oracle/lookup.hpp) ----
+int orc_lookup_build_aux(const uint64_t* blob, size_t n_words, const uint64_t* main_rowmajor, int log_n, const uint64_t* randomness,
+                         size_t n_rand, uint64_t* aux_rowmajor, uint64_t acc_final[2], char* err, size_t errcap) {
+  try {
+    Lookup lk = Lookup::parse(blob, n_words);
+    std::vector<E2> rnd;
+    for (size_t i = 0; i < n_rand; i++) rnd.push_back(E2{randomness[2 * i] % P, randomness[2 * i + 1] % P});
+    rnd.resize(std::max(rnd.size(), lk.dag.num_randomness), e2(0));
+    E2 f = lookup_build_aux(lk, main_rowmajor, (size_t)1 << log_n, rnd.data(), aux_rowmajor);
+    acc_final[0] = f.c0;
+    acc_final[1] = f.c1;
+    return 0;
+  } catch (const std::exception& e) {
+    set_err(err, errcap, e.what());
+    return 1;
+  }
 }
 
 }  // extern "C"

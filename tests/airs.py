@@ -140,3 +140,70 @@ def synthetic_big_air(width=51, aux_width=8, n_constraints=300, terms=3, seed=11
         else:
             b.assert_zero(b.is_transition() * acc if rng.random() < 0.5 else acc)
     return dag.Air(b, build_aux=None, name=f"synthetic:{width}:{aux_width}:{n_constraints}")
+
+
+# ------------------------------------------------------------------------------------------------
+LOGUP_PERIODIC = ([1, 0, 0, 1, 1, 0, 1, 0],)
+
+
+def logup_air():
+    """A LogUp AIR in the reference's shape (air/src/lookup/aux_builder.rs): aux column 0 = running-sum accumulator,
+    aux column 1 = a per-row fraction column, one aux value = the accumulator's final.  Main columns
+    V, T, M, A, B, C, E, F:  bus 0 looks V up in table T with multiplicities M, bus 1 is a permutation A ~ B
+    (B = A shuffled across rows); two pairs that cancel inside every row exercise next-row reads (E_next vs F,
+    F[r] = E[r+1]) and a periodic multiplicity (zero on some rows: those fractions are skipped).
+    Returns (Air, Lookup): the constraint DAG and the lookup program exported from the same definitions."""
+    def denoms(b):
+        r0, r1 = b.randomness(0), b.randomness(1)
+        V, T, M, A_, B_, C_, F = b.main(0), b.main(1), b.main(2), b.main(3), b.main(4), b.main(5), b.main(7)
+        E_next = b.main(6, 1)
+        return dict(dV=r0 + V + r1 * 3, dT=r0 + T + r1 * 3, dA=r0 + r1 + A_, dB=r0 + r1 + B_, dC=r0 + r1 * 7 + C_,
+                    dEn=r0 + r1 * 5 + E_next, dF=r0 + r1 * 5 + F, M=M)
+
+    b = dag.AirBuilder(8, aux_width=2, num_randomness=2, num_aux_values=1, num_public=0, periodic=LOGUP_PERIODIC)
+    d = denoms(b)
+    acc, acc_next, f1 = b.aux(0), b.aux(0, 1), b.aux(1)
+    b.assert_zero_ext(f1 * d["dA"] * d["dB"] - (d["dB"] - d["dA"]))
+    own = d["dT"] - d["M"] * d["dV"]  # numerator of 1/dV - M/dT over dV*dT
+    b.assert_zero_ext(b.is_transition() * ((acc_next - acc - f1) * d["dV"] * d["dT"] - own))
+    b.assert_zero_ext(b.is_first_row() * acc)
+    b.assert_zero_ext(b.is_last_row() * ((b.aux_value(0) - acc - f1) * d["dV"] * d["dT"] - own))
+
+    lb = dag.LookupBuilder(8, num_cols=2, num_randomness=2, periodic=LOGUP_PERIODIC)
+    d = denoms(lb)
+    per = lb.periodic_value(0)
+    lb.fraction(0, 1, d["dV"])
+    lb.fraction(0, -d["M"], d["dT"])
+    lb.fraction(0, 1, d["dEn"])
+    lb.fraction(0, P - 1, d["dF"])
+    lb.fraction(1, 1, d["dA"])
+    lb.fraction(1, lb.const(P - 1), d["dB"])
+    lb.fraction(1, per, d["dC"])
+    lb.fraction(1, -per, d["dC"])
+    lookup = dag.Lookup(lb, "logup")
+
+    def build_aux(main, randomness):
+        import oracle_binding as ob
+        aux, fin = ob.lookup_build_aux(lookup, main, randomness)
+        return aux, [int(fin[0]), int(fin[1])]
+
+    return dag.Air(b, build_aux, "logup"), lookup
+
+
+def logup_trace(log_n, seed=3, valid=True):
+    n = 1 << log_n
+    rng = np.random.default_rng(seed)
+    t = np.zeros((n, 8), dtype=np.uint64)
+    table = rng.integers(0, P, n, dtype=np.uint64)
+    picks = rng.integers(0, n, n)
+    t[:, 0] = table[picks]
+    t[:, 1] = table
+    t[:, 2] = np.bincount(picks, minlength=n).astype(np.uint64)
+    t[:, 3] = rng.integers(0, P, n, dtype=np.uint64)
+    t[:, 4] = rng.permutation(t[:, 3])
+    t[:, 5] = rng.integers(0, P, n, dtype=np.uint64)
+    t[:, 6] = rng.integers(0, P, n, dtype=np.uint64)
+    t[:, 7] = np.roll(t[:, 6], -1)
+    if not valid:
+        t[n // 2, 0] = (int(t[n // 2, 0]) + 1) % P  # a value that is not in the table: the buses no longer balance
+    return t

@@ -240,6 +240,23 @@ def verify(airs, log_heights, publics, proof, params=PROD_PARAMS, init_state=Non
     return (True, digest) if rc == 0 else (False, err.value.decode())
 
 
+def lookup_build_aux(lookup, main, randomness):
+    """oracle/lookup.hpp: (aux[n, 2 * num_cols] uint64, acc_final[2]) of a dag.Lookup over a row-major main trace."""
+    m = arr(main)
+    n = m.shape[0]
+    blob = arr(lookup.blob)
+    rnd = arr([int(x) for r in randomness for x in r] or [0])
+    aux = np.zeros((n, 2 * lookup.num_cols), dtype=np.uint64)
+    fin = np.zeros(2, dtype=np.uint64)
+    err = C.create_string_buffer(512)
+    L = lib()
+    rc = L.orc_lookup_build_aux(ptr(blob), C.c_size_t(blob.size), ptr(m), C.c_int(n.bit_length() - 1), ptr(rnd),
+                                C.c_size_t(len(randomness)), ptr(aux), ptr(fin), err, C.c_size_t(512))
+    if rc != 0:
+        raise RuntimeError("oracle lookup_build_aux failed: " + err.value.decode())
+    return aux, fin
+
+
 class Challenger:
     """oracle::Challenger (DuplexChallenger restatement) as an object, for driving a staged proof."""
 

@@ -1,0 +1,91 @@
+"""GPU (run with -m gpu): the LogUp aux trace built on the device (csrc/logup.hip + the compiled lookup program)
+against the oracle's restatement of air/src/lookup/aux_builder.rs -- bit-exact aux trace and accumulator final --
+and whole proofs whose aux trace never leaves the GPU against the oracle prover (host-built aux trace)."""
+import numpy as np
+import pytest
+import oracle_binding as ob
+import airs as A
+from __graft_entry__ import load_package
+from miden_vm_amd import dag
+
+pytestmark = pytest.mark.gpu
+FAST = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=5,
+            query_pow_bits=3)
+RND = [(123456789012345, 987654321), (55555, 2**63 + 17)]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    pkg = load_package()
+    c = pkg.Ctx(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("log_n,valid", [(3, True), (4, False), (7, True), (11, True), (12, False), (16, True)])
+def test_device_aux_trace_equals_oracle(ctx, log_n, valid):
+    pkg = load_package()
+    _, lookup = A.logup_air()
+    dl = pkg.DeviceLookup(ctx, lookup)
+    main = A.logup_trace(log_n, seed=log_n, valid=valid)
+    aux_dev, fin = dl.build_aux(ctx.upload_trace(main), RND)
+    aux, exp_fin = ob.lookup_build_aux(lookup, main, RND)
+    got = aux_dev.download()
+    assert got.shape == aux.shape
+    bad = np.argwhere(got != aux)
+    assert bad.size == 0, f"first differing aux cell (row, col) = {bad[0]}"
+    assert fin == (int(exp_fin[0]), int(exp_fin[1]))
+    assert (fin == (0, 0)) == valid
+
+
+def test_proof_with_device_built_aux_equals_oracle(ctx):
+    pkg = load_package()
+    for log_n in (5, 9):
+        air, lookup = A.logup_air()
+        main = A.logup_trace(log_n, seed=2)
+        exp = ob.prove([air], [main], [], FAST)  # the oracle builds the aux trace in its host callback
+        dair = pkg.DeviceAir(ctx, air)
+        dair.attach_lookup(pkg.DeviceLookup(ctx, lookup))
+
+        def never(idx, rnd):  # the host aux builder must not be consulted for an AIR with a lookup program
+            raise AssertionError("host aux builder called")
+
+        got = pkg.prove(ctx, [dair], [ctx.upload_trace(main)], [], FAST, ob.challenger_state(), ob.protocol_pre_observe(FAST, []), never)
+        assert (got.fields == exp["fields"]).all() and (got.commitments == exp["commitments"]).all()
+        assert (got.digest == exp["digest"]).all()
+        ok, msg = ob.verify([air], [log_n], [], {"fields": got.fields, "commitments": got.commitments}, FAST)
+        assert ok, msg
+
+
+def test_full_size_logup_proof_verifies(ctx):
+    """2^20 rows, production parameters: the aux trace (2 EF columns) is built, LDE'd and committed without a host
+    round trip; the oracle verifier accepts, and the committed accumulator final is 0 (balanced buses)."""
+    pkg = load_package()
+    air, lookup = A.logup_air()
+    log_n = 20
+    main = A.logup_trace(log_n, seed=4)
+    dair = pkg.DeviceAir(ctx, air)
+    dair.attach_lookup(pkg.DeviceLookup(ctx, lookup))
+    got = pkg.prove(ctx, [dair], [ctx.upload_trace(main)], [], ob.PROD_PARAMS, ob.challenger_state(),
+                    ob.protocol_pre_observe(ob.PROD_PARAMS, []), None)
+    ok, msg = ob.verify([air], [log_n], [], {"fields": got.fields, "commitments": got.commitments}, ob.PROD_PARAMS)
+    assert ok, msg
+    assert (got.fields[:2] == 0).all()  # first transcript fields = the aux value (acc_final)
+
+
+def test_zero_denominator_is_an_error(ctx):
+    pkg = load_package()
+    lb = dag.LookupBuilder(2, num_cols=1, num_randomness=2)
+    lb.fraction(0, 1, lb.main(0) - lb.main(1) + lb.randomness(0) * 0)
+    dl = pkg.DeviceLookup(ctx, dag.Lookup(lb))
+    main = np.ones((8, 2), dtype=np.uint64)
+    with pytest.raises(pkg.MidenHipError, match="denominator"):
+        dl.build_aux(ctx.upload_trace(main), RND)
+
+
+def test_lookup_shape_mismatch_is_rejected(ctx):
+    pkg = load_package()
+    _, lookup = A.logup_air()
+    dair = pkg.DeviceAir(ctx, dag.dummy_miden_air(9, 2))
+    with pytest.raises(pkg.MidenHipError):
+        dair.attach_lookup(pkg.DeviceLookup(ctx, lookup))
