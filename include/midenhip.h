@@ -68,6 +68,10 @@ int mh_coset_lde_batch(mh_ctx* ctx, const uint64_t* rowmajor, int log_n, size_t 
  * an on-device transpose to column-major; canonicalises felts. */
 int mh_trace_upload(mh_ctx* ctx, const uint64_t* rowmajor, int log_n, size_t width, mh_trace** out);
 void mh_trace_free(mh_trace* t);
+/* Page-locked host memory (hipHostMalloc): a trace built in it uploads by direct DMA at PCIe line rate; any
+ * other host pointer works too, staged by the runtime (several times slower).  NULL on failure. */
+void* mh_host_alloc(size_t bytes);
+void mh_host_free(void* p);
 
 /* ---- commitments (K1-K3) -------------------------------------------------------------------- */
 /* commit_traces (crates/lifted-stark/src/prover/commit.rs:142-180): per trace (proof order =

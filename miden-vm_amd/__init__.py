@@ -30,7 +30,7 @@ EXPORTS = [
     "mh_session_begin", "mh_session_free", "mh_session_shape", "mh_session_commit_main", "mh_session_commit_aux",
     "mh_session_commit_quotient", "mh_session_ood_point_ok", "mh_session_ood", "mh_session_deep", "mh_session_fri_commit",
     "mh_session_fri_fold", "mh_session_fri_final", "mh_session_open", "mh_grind",
-    "mh_lookup_load", "mh_lookup_free", "mh_air_attach_lookup", "mh_lookup_build_aux", "mh_trace_download",
+    "mh_host_alloc", "mh_host_free", "mh_lookup_load", "mh_lookup_free", "mh_air_attach_lookup", "mh_lookup_build_aux", "mh_trace_download",
 ]
 
 _lib = None
@@ -157,6 +157,25 @@ class Ctx:
 
     def upload_trace(self, matrix):
         return Trace(self, matrix)
+
+
+def pinned_array(lib, shape):
+    """A numpy uint64 array in page-locked host memory (mh_host_alloc); keep the returned owner alive."""
+    n = int(np.prod(shape))
+    lib.mh_host_alloc.restype = C.c_void_p
+    lib.mh_host_alloc.argtypes = [C.c_size_t]
+    lib.mh_host_free.argtypes = [C.c_void_p]
+    p = lib.mh_host_alloc(n * 8)
+    if not p:
+        raise MidenHipError("mh_host_alloc failed")
+    buf = (C.c_uint64 * n).from_address(p)
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(shape)
+
+    class _Owner:
+        def __del__(self, lib=lib, p=p):
+            lib.mh_host_free(p)
+
+    return a, _Owner()
 
 
 class Trace:

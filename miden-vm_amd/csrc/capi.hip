@@ -150,6 +150,16 @@ int mh_trace_upload(mh_ctx* c, const uint64_t* rowmajor, int log_n, size_t width
   *out = trace_upload(c, rowmajor, log_n, width);
   MH_CATCH
 }
+// Page-locked host memory for traces: a RowMajorMatrix built in it is DMA'd at PCIe line rate by
+// mh_trace_upload instead of being staged through the runtime's bounce buffers.
+void* mh_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void mh_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
 void mh_trace_free(mh_trace* t) {
   if (!t) return;
   (void)hipSetDevice(t->ctx->device);
