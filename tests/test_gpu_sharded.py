@@ -70,6 +70,13 @@ def _prove_worker(rank, world, port, case, ret):
         elif case == "miden_small":
             airs_, traces, pub, prm = [dag.dummy_miden_air(11, 2)], [A.dummy_trace(6, 11)], [], dict(
                 log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=5, query_pow_bits=3)
+        elif case == "logup_compiled":  # compiled constraint kernels + device-built LogUp aux trace on every rank
+            os.environ["MH_JIT"] = "1"
+            os.environ["MH_JIT_CHUNK"] = "24"
+            air, lookup = A.logup_air()
+            airs_, traces, pub = [air], [A.logup_trace(8)], []
+            prm = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=6,
+                       query_pow_bits=3)
         else:  # two AIRs with aux columns, selectors, periodic columns, different heights (D = 2)
             t1, pub = A.fib_trace(8)
             airs_, traces = [A.periodic_air(3), A.fib_air()], [A.periodic_trace(6), t1]
@@ -78,6 +85,10 @@ def _prove_worker(rank, world, port, case, ret):
         dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
         dtr = [ctx.upload_trace(t) for t in traces]
         need_cb = any(a.build_aux is not None for a in airs_)
+        if case == "logup_compiled":
+            assert dairs[0].compiled_chunks > 1
+            dairs[0].attach_lookup(pkg.DeviceLookup(ctx, lookup))
+            need_cb = False
 
         def aux_builder(idx, rnd):
             a = airs_[idx]
@@ -105,7 +116,8 @@ def _prove_worker(rank, world, port, case, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case", [(2, "miden_small"), (8, "miden_small"), (2, "multi"), (4, "miden"), (8, "miden")])
+@pytest.mark.parametrize("world,case", [(2, "miden_small"), (8, "miden_small"), (2, "multi"), (2, "logup_compiled"), (4, "miden"),
+                                        (8, "miden")])
 def test_sharded_proof_equals_single_gpu_proof(world, case):
     port = 29500 + (os.getpid() + 31 * world + len(case)) % 2000
     mgr = mp.get_context("spawn").Manager()
