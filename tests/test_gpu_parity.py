@@ -36,7 +36,11 @@ def test_poseidon2_kat_and_random(ctx):
     assert (ctx.poseidon2_permute(s) == ob.permute(exp_in)).all()
 
 
-@pytest.mark.parametrize("log_n,w,ab", [(1, 1, 1), (3, 5, 3), (6, 9, 3), (10, 4, 2), (12, 3, 3), (13, 2, 1), (15, 2, 3), (17, 1, 2)])
+# every pass shape of the radix-16 NTT: 1..12 stages in one tile (rounds of 4 + a 1..3-stage round), and the
+# strided second pass with 1..8 stages (log_n 13..20)
+@pytest.mark.parametrize("log_n,w,ab", [(1, 1, 1), (2, 2, 2), (3, 5, 3), (4, 1, 1), (5, 2, 2), (6, 9, 3), (7, 1, 1), (8, 2, 1), (9, 1, 2),
+                                       (10, 4, 2), (11, 1, 1), (12, 3, 3), (13, 2, 1), (14, 1, 1), (15, 2, 3), (16, 1, 1), (17, 1, 2),
+                                       (18, 1, 1), (19, 1, 1), (20, 1, 1)])
 def test_coset_lde_matches_oracle(ctx, log_n, w, ab):
     rng = np.random.default_rng(100 + log_n)
     m = rnd(rng, (1 << log_n, w))
