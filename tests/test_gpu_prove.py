@@ -346,3 +346,37 @@ def test_miden_sized_dag_uses_compiled_kernels(ctx):
     d = pkg.DeviceAir(ctx, A.synthetic_big_air())
     assert d.compiled_chunks >= 4
     d.free()
+
+
+def test_two_contexts_prove_concurrently():
+    """SURVEY section 8b threading contract: one ctx per proving thread, no global state -- two host threads, each
+    with its own ctx / HIP stream on the same GPU, prove different instances at the same time and get exactly the
+    proofs a lone context produces."""
+    import threading
+    pkg = load_package()
+    t_fib, pub = A.fib_trace(9)
+    jobs = [([A.fib_air()], [t_fib], pub, FAST), ([dag.dummy_miden_air(51, 8)], [A.dummy_trace(12, 51)], [], ob.PROD_PARAMS)]
+    solo_ctx = pkg.Ctx(0)
+    expect = [gpu_prove(solo_ctx, *job) for job in jobs]
+    solo_ctx.close()
+    results, errors = [None, None], []
+
+    def run(i):
+        try:
+            c = pkg.Ctx(0)
+            outs = [gpu_prove(c, *jobs[i]) for _ in range(4)]
+            c.close()
+            results[i] = outs
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        for got in results[i]:
+            assert (got.fields == expect[i].fields).all() and (got.commitments == expect[i].commitments).all()
+            assert (got.digest == expect[i].digest).all()
