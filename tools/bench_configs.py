@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Proof times at the other BASELINE.json config shapes (not bench lines: bench.py reports configs[1]).
+Usage: python tools/bench_configs.py"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle_binding as ob
+import airs as A
+from __graft_entry__ import load_package
+from miden_vm_amd import dag
+pkg = load_package()
+ctx = pkg.Ctx(0)
+
+
+def run(name, airs_, traces, prm, lookups=None, reps=3):
+    dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+    for d, l in zip(dairs, lookups or []):
+        if l is not None:
+            d.attach_lookup(pkg.DeviceLookup(ctx, l))
+    dtr = [ctx.upload_trace(t) for t in traces]
+    st, pre = ob.challenger_state(), ob.protocol_pre_observe(prm, [])
+    pkg.prove(ctx, dairs, dtr, [], prm, st, pre, None)
+    ctx.prof_enable(True); ctx.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        p = pkg.prove(ctx, dairs, dtr, [], prm, st, pre, None)
+    dt = (time.perf_counter() - t0) / reps
+    rows = max(t.shape[0] for t in traces)
+    prof = {k: round(v["ms"] / reps, 2) for k, v in sorted(ctx.prof().items(), key=lambda kv: -kv[1]["ms"])[:6]}
+    print(f"{name:58s} {dt * 1e3:9.1f} ms  {rows / dt / 1e6:7.2f} M rows/s  proof {len(p.bytes) / 1024:6.1f} KiB  {prof}", flush=True)
+    for d in dtr + dairs:
+        d.free()
+
+
+P16 = dict(log_blowup=4, log_folding_arity=2, log_final_degree=7, folding_pow_bits=4, deep_pow_bits=12, num_queries=28, query_pow_bits=16)
+run("configs[1] miden:20:51:8 (bench.py workload)", [dag.dummy_miden_air(51, 8)], [A.dummy_trace(20, 51)], ob.PROD_PARAMS)
+run("configs[2] shape: 2^22x51(+4) 2^21x22(+3) 2^20x16(+1)", [dag.dummy_miden_air(51, 4), dag.dummy_miden_air(22, 3), dag.dummy_miden_air(16, 1)],
+    [A.dummy_trace(22, 51, 3), A.dummy_trace(21, 22, 4), A.dummy_trace(20, 16, 5)], ob.PROD_PARAMS)
+run("  ... with a Miden-sized constraint DAG on the 2^22 core", [A.synthetic_big_air(51, 4), dag.dummy_miden_air(22, 3), dag.dummy_miden_air(16, 1)],
+    [A.dummy_trace(22, 51, 3), A.dummy_trace(21, 22, 4), A.dummy_trace(20, 16, 5)], ob.PROD_PARAMS)
+run("configs[3] size: 2^24x51(+8) on one GPU", [dag.dummy_miden_air(51, 8)], [A.dummy_trace(24, 51, 8)], ob.PROD_PARAMS, reps=2)
+run("configs[4] shape: 2^20x16(+1), blowup 16, 128-bit", [dag.dummy_miden_air(16, 1)], [A.dummy_trace(20, 16, 9)], P16)
+air, lookup = A.logup_air()
+run("LogUp AIR 2^20x8, aux trace built on the device", [air], [A.logup_trace(20, 4)], ob.PROD_PARAMS, lookups=[lookup])
