@@ -66,7 +66,7 @@ void mh_ctx_destroy(mh_ctx* c) {
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
   {
     PoolScope ps(c);
-    c->tw_fwd.clear(); c->tw_inv.clear(); c->tables.clear();
+    c->tw_fwd.clear(); c->tw_inv.clear(); c->tables.clear(); c->table_index.clear();
   }
   c->pool.trim();
   if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -134,6 +134,7 @@ struct mh_ctx {
   std::map<int, DevBuf> tw_fwd, tw_inv;
   // coset-scale tables keyed by (log_n, log_blowup, kind)
   std::map<std::string, DevBuf> tables;
+  std::map<std::string, std::vector<size_t>> table_index;  // host-side offsets into `tables` entries
 
   hipEvent_t get_event();
   void prof_begin(const char* name, double bytes);

@@ -56,8 +56,7 @@ const u64* mh_ctx::twiddles(int log_n, bool inverse) {
   auto& m = inverse ? tw_inv : tw_fwd;
   auto it = m.find(log_n);
   if (it != m.end()) return it->second.u();
-  // w^k for ALL k < N (the radix-16 passes index up to N-1; the other users only the first half)
-  size_t half = (size_t)1 << log_n;
+  size_t half = log_n ? ((size_t)1 << (log_n - 1)) : 1;
   DevBuf b(half * 8);
   u64 w = gl_two_adic_generator(log_n);
   if (inverse) w = gl_inv(w);
@@ -98,7 +97,7 @@ struct NttPassArgs {
   int log_n, s_lo, r_bits, cb;                          // stages s_lo .. s_lo+r_bits-1, tile = 2^(r_bits+cb)
   int dif;                                              // 1 = DIF (a+b,(a-b)w), descending; 0 = DIT
   int canon_out;                                        // store canonical values (last pass of a transform whose output leaves the NTT)
-  const u64* tw;                                        // w^k (k < N/2) for the transform direction
+  const u64* tw_round[3];                               // per round of this pass: plane [2^G - 1][2^s] of W^rev(e), W = w_{2^(s+G)}^gm
   const u64* scale_lo;                                  // optional: multiply on load by
   const u64* scale_hi;                                  //   scale_lo[z][k & m] * scale_hi[z][k >> lb], k = bitrev(pos)
   int lb;
@@ -199,10 +198,9 @@ __device__ __forceinline__ u32 ntt_pad(u32 l) { return l + (l >> 4); }
 
 template <int G, bool INV>
 __device__ __forceinline__ void ntt_round(const NttPassArgs& a, u64* lds, int st, u32 tile_n, size_t lo0, u64* dst_direct,
-                                          size_t gbase) {
+                                          size_t gbase, const u64* __restrict__ tw) {
   const int b0 = st + a.cb, s = a.s_lo + st;
   const u32 cb_mask = (1u << a.cb) - 1;
-  const int tw_shift = a.log_n - s - G;
   for (u32 q = threadIdx.x; q < (tile_n >> G); q += NTT_THREADS) {
     const u32 low = q & ((1u << b0) - 1);
     const u32 l0 = ((q >> b0) << (b0 + G)) | low;
@@ -213,16 +211,14 @@ __device__ __forceinline__ void ntt_round(const NttPassArgs& a, u64* lds, int st
     if (!INV && s > 0) {
 #pragma unroll
       for (int e = 1; e < (1 << G); e++) {
-        const u32 rho = __brev((u32)e) >> (32 - G);
-        x[e] = p2f_mul(x[e], a.tw[(size_t)(gm * rho) << tw_shift]);
+        x[e] = p2f_mul(x[e], tw[((size_t)(e - 1) << s) | gm]);  // consecutive lanes = consecutive gm: coalesced
       }
     }
     ntt_dft_regs<G, INV>(x, INV);
     if (INV && s > 0) {
 #pragma unroll
       for (int e = 1; e < (1 << G); e++) {
-        const u32 rho = __brev((u32)e) >> (32 - G);
-        x[e] = p2f_mul(x[e], a.tw[(size_t)(gm * rho) << tw_shift]);
+        x[e] = p2f_mul(x[e], tw[((size_t)(e - 1) << s) | gm]);
       }
     }
     if (dst_direct) {
@@ -286,10 +282,10 @@ __global__ __launch_bounds__(NTT_THREADS) NTT16_OCC void k_ntt16_pass(NttPassArg
     }
     u64* direct = (i == n_rounds - 1) ? dst : nullptr;
     switch (g) {
-      case 4: ntt_round<4, INV>(a, lds, st, tile_n, lo0, direct, gbase); break;
-      case 3: ntt_round<3, INV>(a, lds, st, tile_n, lo0, direct, gbase); break;
-      case 2: ntt_round<2, INV>(a, lds, st, tile_n, lo0, direct, gbase); break;
-      default: ntt_round<1, INV>(a, lds, st, tile_n, lo0, direct, gbase); break;
+      case 4: ntt_round<4, INV>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri]); break;
+      case 3: ntt_round<3, INV>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri]); break;
+      case 2: ntt_round<2, INV>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri]); break;
+      default: ntt_round<1, INV>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri]); break;
     }
     if (!direct) __syncthreads();
   }
@@ -319,6 +315,77 @@ static std::vector<PassPlan> plan_passes(int log_n) {
   return p;
 }
 
+// Rounds of a pass, in ascending stage order (mirrors k_ntt16_pass): (first local stage, number of stages).
+static std::vector<std::pair<int, int>> pass_rounds(int r_bits) {
+  std::vector<std::pair<int, int>> r;
+  const int rem = r_bits & 3;
+  int st = 0;
+  if (rem) {
+    r.push_back({0, rem});
+    st = rem;
+  }
+  for (; st < r_bits; st += 4) r.push_back({st, 4});
+  return r;
+}
+// Twiddle planes of every round of every pass of a 2^log_n transform, laid out in the order the lanes read
+// them: plane(s, G)[e - 1][gm] = w^((gm * rev_G(e)) << (log_n - s - G)), gm < 2^s.  ~N entries in total, built
+// once per (size, direction).  (Indexing one w^k table instead scatters a wave's loads over one 64 B sector
+// per lane; at 2^24 that table no longer fits the caches and the passes turned memory bound.)
+__global__ void k_fill_round_plane(u64* out, int s, int G, int log_n, PowTable t) {
+  const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (idx >= ((size_t)((1 << G) - 1) << s)) return;
+  const u32 e = (u32)(idx >> s) + 1;
+  const size_t gm = idx & (((size_t)1 << s) - 1);
+  const u32 rho = bitrev32(e, G);
+  size_t ex = (gm * rho) << (log_n - s - G);
+  u64 r = 1;
+#pragma unroll 1
+  for (int i = 0; ex; i++, ex >>= 1)
+    if (ex & 1) r = gl_mul(r, t.pw[i]);
+  out[idx] = r;
+}
+struct NttPlanes {
+  const u64* base;
+  std::vector<size_t> off;  // [pass * 3 + round]
+};
+static NttPlanes ntt_planes(mh_ctx* c, int log_n, bool inverse, const std::vector<PassPlan>& plan) {
+  const std::string key = "nttp:" + std::to_string(log_n) + (inverse ? ":i" : ":f");
+  auto it = c->tables.find(key);
+  if (it == c->tables.end()) {
+    std::vector<size_t> off(plan.size() * 3, 0);
+    size_t total = 1;
+    for (size_t i = 0; i < plan.size(); i++) {
+      auto rounds = pass_rounds(plan[i].r_bits);
+      for (size_t k = 0; k < rounds.size(); k++) {
+        const int s = plan[i].s_lo + rounds[k].first, G = rounds[k].second;
+        off[i * 3 + k] = total;
+        if (s > 0) total += (size_t)((1 << G) - 1) << s;
+      }
+    }
+    DevBuf b(total * 8);
+    PowTable t;
+    u64 w = gl_two_adic_generator(log_n);
+    if (inverse) w = gl_inv(w);
+    for (int i = 0; i < 32; i++) {
+      t.pw[i] = w;
+      w = gl_sqr(w);
+    }
+    for (size_t i = 0; i < plan.size(); i++) {
+      auto rounds = pass_rounds(plan[i].r_bits);
+      for (size_t k = 0; k < rounds.size(); k++) {
+        const int s = plan[i].s_lo + rounds[k].first, G = rounds[k].second;
+        if (s == 0) continue;
+        const size_t cnt = (size_t)((1 << G) - 1) << s;
+        hipLaunchKernelGGL(k_fill_round_plane, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, b.u() + off[i * 3 + k], s, G,
+                           log_n, t);
+      }
+    }
+    c->table_index[key] = off;
+    it = c->tables.emplace(key, std::move(b)).first;
+  }
+  return NttPlanes{it->second.u(), c->table_index[key]};
+}
+
 static void launch_pass(mh_ctx* c, NttPassArgs a, size_t n_cols, size_t n_z) {
   size_t tiles = (size_t)1 << (a.log_n - a.r_bits - a.cb);
   dim3 grid((unsigned)tiles, (unsigned)n_cols, (unsigned)n_z);
@@ -331,14 +398,15 @@ static void launch_pass(mh_ctx* c, NttPassArgs a, size_t n_cols, size_t n_z) {
 void ntt_inverse_dif_inplace(mh_ctx* c, u64* cols, size_t n_cols, int log_n) {
   if (log_n == 0) return;
   auto plan = plan_passes(log_n);
-  const u64* tw = c->twiddles(log_n, true);
+  const NttPlanes tw = ntt_planes(c, log_n, true, plan);
   for (int i = (int)plan.size() - 1; i >= 0; i--) {
     NttPassArgs a{};
     a.src = cols; a.dst = cols;
     a.src_col_stride = a.dst_col_stride = (size_t)1 << log_n;
     a.dst_z_stride = 0;
     a.log_n = log_n; a.s_lo = plan[i].s_lo; a.r_bits = plan[i].r_bits; a.cb = plan[i].cb;
-    a.dif = 1; a.tw = tw; a.scale_lo = nullptr; a.scale_hi = nullptr;
+    a.dif = 1; a.scale_lo = nullptr; a.scale_hi = nullptr;
+    for (int k = 0; k < 3; k++) a.tw_round[k] = tw.base + tw.off[i * 3 + k];
     a.canon_out = 0;  // the coefficients only feed the forward passes' multiplications
     launch_pass(c, a, n_cols, 1);
   }
@@ -373,7 +441,7 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
   u64 n_inv = gl_inv((u64)N % GL_P);
   CosetTables t = make_coset_tables(c, log_n, bases, n_inv);
   auto plan = plan_passes(log_n);
-  const u64* tw = log_n ? c->twiddles(log_n, false) : nullptr;
+  const NttPlanes tw = ntt_planes(c, log_n, false, plan);
   for (size_t i = 0; i < plan.size(); i++) {
     NttPassArgs a{};
     a.dst = out;
@@ -392,7 +460,8 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
       a.scale_lo = nullptr; a.scale_hi = nullptr;
     }
     a.log_n = log_n; a.s_lo = plan[i].s_lo; a.r_bits = plan[i].r_bits; a.cb = plan[i].cb;
-    a.dif = 0; a.tw = tw;
+    a.dif = 0;
+    for (int k = 0; k < 3; k++) a.tw_round[k] = tw.base + tw.off[i * 3 + k];
     a.canon_out = i + 1 == plan.size();
     if (i == 0) {
       launch_pass(c, a, n_cols, nz);
