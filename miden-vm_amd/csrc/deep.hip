@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_deep_assemble(DeepArgs a) {
     const size_t nm_mask = ((size_t)1 << m.log_n) - 1;
     const u64* colp = m.lde + (j << m.log_n);
     const size_t cstride = (size_t)1 << (m.log_n + a.log_blowup);
-#pragma unroll 1
+#pragma unroll 4  // 16 independent loads in flight per lane: the loop is latency bound otherwise
     for (u32 cidx = 0; cidx < m.width; cidx++) {
       const e2 cf = e2{a.negc[2 * (m.coef_off + cidx)], a.negc[2 * (m.coef_off + cidx) + 1]};
 #pragma unroll
