@@ -130,6 +130,8 @@ void deep_ood_eval_matrix(mh_ctx* c, const LdeMatrix& m, int log_blowup, e2 y0, 
 
 // ---- DEEP reduce + assemble ----------------------------------------------------------------------
 static constexpr int DEEP_MAX_MATS = 24;
+static constexpr unsigned DEEP_FLUSH = 128;
+static constexpr int DEEP_PTS = 2;  // points per lane (they share one Fermat inversion); more costs occupancy
 struct DeepMat {
   const u64* lde;
   u32 width, coef_off;  // coef_off: index of this matrix's first column in the aligned coefficient list
@@ -148,38 +150,89 @@ struct DeepArgs {
 __global__ __launch_bounds__(256) void k_deep_assemble(DeepArgs a) {
   const size_t N = (size_t)1 << a.log_n;
   const size_t j = blockIdx.y;
-  const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
-  size_t r[4];
+  const size_t base = (size_t)blockIdx.x * (256 * DEEP_PTS) + threadIdx.x;
+  size_t r[DEEP_PTS];
 #pragma unroll
-  for (int k = 0; k < 4; k++) r[k] = base + (size_t)k * 256;
-  e2 neg[4];
+  for (int k = 0; k < DEEP_PTS; k++) r[k] = base + (size_t)k * 256;
+  // neg[k] = sum over columns of cf_col * v_col(r[k]) with the modular reduction DELAYED: cf (uniform, EF) is cut
+  // into 16-bit limbs, v into 32-bit halves, and the 48-bit partial products are summed by weight
+  // 2^0, 2^16, .., 2^80 in plain 64-bit accumulators (one v_mad_u64_u32 each, no carries); one reduction per
+  // <= DEEP_FLUSH columns.  16 multiply-adds per (column, point) instead of two modular multiplications.
+  e2 neg[DEEP_PTS];
+  u64 w[DEEP_PTS][2][6];
 #pragma unroll
-  for (int k = 0; k < 4; k++) neg[k] = e2_make(0);
+  for (int k = 0; k < DEEP_PTS; k++) {
+    neg[k] = e2_make(0);
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+#pragma unroll
+      for (int i = 0; i < 6; i++) w[k][e][i] = 0;
+  }
+  auto flush = [&]() {
+    const u64 C[6] = {1ULL, 1ULL << 16, 1ULL << 32, 1ULL << 48, GL_EPS, GL_EPS << 16};  // 2^(16 i) mod p
+#pragma unroll
+    for (int k = 0; k < DEEP_PTS; k++) {
+      u64 s0 = w[k][0][0], s1 = w[k][1][0];  // < 2^57: canonical
+#pragma unroll
+      for (int i = 1; i < 6; i++) {
+        s0 = gl_add(s0, gl_mul(w[k][0][i], C[i]));
+        s1 = gl_add(s1, gl_mul(w[k][1][i], C[i]));
+      }
+      neg[k] = e2_add(neg[k], e2{s0, s1});
+#pragma unroll
+      for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int i = 0; i < 6; i++) w[k][e][i] = 0;
+    }
+  };
+  u32 pending = 0;
 #pragma unroll 1
   for (int mi = 0; mi < a.n_mats; mi++) {
     const DeepMat m = a.m[mi];
     const size_t nm_mask = ((size_t)1 << m.log_n) - 1;
     const u64* colp = m.lde + (j << m.log_n);
     const size_t cstride = (size_t)1 << (m.log_n + a.log_blowup);
-#pragma unroll 4  // 16 independent loads in flight per lane: the loop is latency bound otherwise
+#pragma unroll 2
     for (u32 cidx = 0; cidx < m.width; cidx++) {
-      const e2 cf = e2{a.negc[2 * (m.coef_off + cidx)], a.negc[2 * (m.coef_off + cidx) + 1]};
+      const u64 cf0 = a.negc[2 * (m.coef_off + cidx)], cf1 = a.negc[2 * (m.coef_off + cidx) + 1];
+      u32 al[2][4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int i = 0; i < 4; i++) {
+        al[0][i] = (u32)(cf0 >> (16 * i)) & 0xFFFFu;
+        al[1][i] = (u32)(cf1 >> (16 * i)) & 0xFFFFu;
+      }
+#pragma unroll
+      for (int k = 0; k < DEEP_PTS; k++) {
         if (r[k] < N) {
-          u64 v = colp[r[k] & nm_mask];
-          neg[k] = e2_add(neg[k], e2_mulf(cf, v));
+          const u64 v = colp[r[k] & nm_mask];
+          const u32 v0 = (u32)v, v1 = (u32)(v >> 32);
+#pragma unroll
+          for (int e = 0; e < 2; e++) {
+            w[k][e][0] += (u64)al[e][0] * v0;
+            w[k][e][1] += (u64)al[e][1] * v0;
+            w[k][e][2] += (u64)al[e][2] * v0;
+            w[k][e][3] += (u64)al[e][3] * v0;
+            w[k][e][2] += (u64)al[e][0] * v1;
+            w[k][e][3] += (u64)al[e][1] * v1;
+            w[k][e][4] += (u64)al[e][2] * v1;
+            w[k][e][5] += (u64)al[e][3] * v1;
+          }
         }
       }
       colp += cstride;
+      if (++pending == DEEP_FLUSH) {  // 2 * DEEP_FLUSH products of < 2^48 per accumulator stay below 2^57
+        flush();
+        pending = 0;
+      }
     }
   }
+  flush();
   const size_t half = N >> 1;
   const u64 cx = a.coset_x[j];
-  e2 den[8];
-  u64 nrm[8], pre[8];
+  e2 den[2 * DEEP_PTS];
+  u64 nrm[2 * DEEP_PTS], pre[2 * DEEP_PTS];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < DEEP_PTS; k++) {
     u64 x = 0;
     if (r[k] < N) x = gl_mul(cx, half ? (r[k] < half ? a.tw[r[k]] : gl_neg(a.tw[r[k] - half])) : 1);
     den[2 * k] = e2_sub(a.z0, e2_make(x));
@@ -187,21 +240,21 @@ __global__ __launch_bounds__(256) void k_deep_assemble(DeepArgs a) {
   }
   u64 run = 1;
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
+  for (int k = 0; k < 2 * DEEP_PTS; k++) {
     nrm[k] = gl_sub(gl_sqr(den[k].c0), gl_mul7(gl_sqr(den[k].c1)));
     pre[k] = run;
     run = gl_mul(run, nrm[k]);
   }
   u64 inv = gl_inv(run);
-  e2 qinv[8];
+  e2 qinv[2 * DEEP_PTS];
 #pragma unroll
-  for (int k = 7; k >= 0; k--) {
+  for (int k = 2 * DEEP_PTS - 1; k >= 0; k--) {
     u64 ni = gl_mul(inv, pre[k]);
     inv = gl_mul(inv, nrm[k]);
     qinv[k] = e2{gl_mul(den[k].c0, ni), gl_mul(gl_neg(den[k].c1), ni)};
   }
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < DEEP_PTS; k++) {
     if (r[k] < N) {
       e2 v = e2_mul(qinv[2 * k], e2_add(a.fred0, neg[k]));
       v = e2_add(v, e2_mul(e2_mul(a.beta, qinv[2 * k + 1]), e2_add(a.fred1, neg[k])));
@@ -251,7 +304,7 @@ void deep_assemble(mh_ctx* c, const std::vector<const LdeMatrix*>& mats, const s
   a.z0 = z0; a.z1 = z1; a.fred0 = fred0; a.fred1 = fred1; a.beta = beta; a.out = out;
   {
     ProfScope ps(c, "deep_assemble", bytes);
-    hipLaunchKernelGGL(k_deep_assemble, dim3((unsigned)((N + 1023) / 1024), (unsigned)B), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_deep_assemble, dim3((unsigned)((N + 256 * DEEP_PTS - 1) / (256 * DEEP_PTS)), (unsigned)B), dim3(256), 0, c->stream, a);
   }
   HIP_CHECK(hipStreamSynchronize(c->stream));
 }
