@@ -6,6 +6,7 @@ O = os.path.join(ROOT, "gpurun_out", "final")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
 out = []
 out.append("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline   (4 proofs of miden:20:51:8; ns)")
+out.append("# (k_perm_rate = the register-only Poseidon2 calibration of bench.py's roofline_valu.peak; it runs once, outside the timed region)")
 out.append(open(os.path.join(O, "kt", "kt_kernel_stats.csv")).read().strip())
 
 
@@ -28,7 +29,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         out.append(f"{k},{disp[k]},{v[c]:.0f},{v[c] / disp[k]:.1f}")
         per_launch.setdefault(k, {})[c] = v[c] / disp[k]
 agg, disp = pmc("SQ")
-out.append("# rocprofv3 --pmc SQ_* (own pass, 3 proofs)\nkernel,dispatches,waves,valu_insts,valu_per_wave,valu_active_frac(SQ_ACTIVE_INST_VALU*4/SQ_BUSY_CYCLES per SE),wait_inst_any/wave_cycles,wait_any/wave_cycles")
+out.append("# rocprofv3 --pmc SQ_* (own pass, 3 proofs)\nkernel,dispatches,waves,valu_insts,valu_per_wave,SQ_ACTIVE_INST_VALU/SQ_BUSY_CYCLES(raw ratio: compare kernels with each other),wait_inst_any/wave_cycles,wait_any/wave_cycles")
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["SQ_INSTS_VALU"])[:8]:
     w = max(1.0, v["SQ_WAVES"])
     out.append(f"{k},{disp[k]},{int(w)},{v['SQ_INSTS_VALU']:.3e},{v['SQ_INSTS_VALU'] / w:.0f},{v['SQ_ACTIVE_INST_VALU'] / max(1, v['SQ_BUSY_CYCLES']):.3f},"
