@@ -246,6 +246,17 @@ int mh_session_open(mh_session* s, const uint64_t* indices, size_t n_indices, mh
 /* GrindingChallenger::grind on the device: `state` = the sponge state, `pending` = felts observed since the
  * last permutation (< 8).  Returns the smallest witness; the caller replays check_witness on its challenger. */
 int mh_grind(mh_ctx* ctx, const uint64_t state[12], const uint64_t* pending, size_t n_pending, int bits, uint64_t* witness);
+/* ---- verifier (host only: no GPU, no ctx) ---------------------------------------------------------------------
+ * Replays a proof against the AIRs' constraint-DAG blobs: crates/lifted-stark/src/verifier/mod.rs (flow, constraint
+ * identity), pcs/verifier.rs + lmcs/config.rs:172-211 (openings), pcs/deep/verifier.rs, pcs/fri/verifier.rs.
+ * Inputs mirror mh_prove: AIR blobs and log heights in INSTANCE order, the same challenger state / pre-observed
+ * felts, and the proof's two streams (mh_proof_fields / mh_proof_commitments).  MH_OK + the transcript digest, or
+ * MH_ERR_INVALID with the reason in `err`. */
+int mh_verify(const mh_pcs_params* params, int n_airs, const uint64_t* const* air_blobs, const size_t* air_blob_words,
+              const uint8_t* log_trace_heights, const uint64_t* public_values, size_t n_public_values,
+              const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe,
+              const uint64_t* fields, size_t n_fields, const uint64_t* commitments, size_t n_commitments,
+              uint64_t digest[4], char* err, size_t err_cap);
 void mh_proof_free(mh_proof* p);
 size_t mh_proof_num_fields(const mh_proof* p);
 size_t mh_proof_num_commitments(const mh_proof* p);

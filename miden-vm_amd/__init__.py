@@ -30,7 +30,7 @@ EXPORTS = [
     "mh_session_begin", "mh_session_free", "mh_session_shape", "mh_session_commit_main", "mh_session_commit_aux",
     "mh_session_commit_quotient", "mh_session_ood_point_ok", "mh_session_ood", "mh_session_deep", "mh_session_fri_commit",
     "mh_session_fri_fold", "mh_session_fri_final", "mh_session_open", "mh_grind",
-    "mh_host_alloc", "mh_host_free", "mh_lookup_load", "mh_lookup_free", "mh_air_attach_lookup", "mh_lookup_build_aux", "mh_trace_download",
+    "mh_host_alloc", "mh_host_free", "mh_verify", "mh_lookup_load", "mh_lookup_free", "mh_air_attach_lookup", "mh_lookup_build_aux", "mh_trace_download",
 ]
 
 _lib = None
@@ -542,3 +542,23 @@ def grind(ctx, state, pending, bits):
     w = C.c_uint64(0)
     ctx.check(ctx.lib.mh_grind(ctx.h, _ptr(st), _ptr(pe), C.c_size_t(len(pending)), C.c_int(bits), C.byref(w)))
     return int(w.value)
+
+
+def verify(airs, log_trace_heights, public_values, params, challenger_state, pre_observe, fields, commitments):
+    """mh_verify (host only, no GPU): airs = dag.Air objects in instance order.  Returns (ok, digest or message)."""
+    lib = load_library()
+    n = len(airs)
+    blobs = [_arr(a.blob) for a in airs]
+    bp = (u64p * n)(*[_ptr(b) for b in blobs])
+    bl = (C.c_size_t * n)(*[b.size for b in blobs])
+    lh = (C.c_uint8 * n)(*[int(x) for x in log_trace_heights])
+    pub, st, pre = _arr(list(public_values) or [0]), _arr(challenger_state), _arr(list(pre_observe) or [0])
+    f = _arr(fields)
+    c = _arr(np.asarray(commitments, dtype=np.uint64).reshape(-1))
+    p = params if isinstance(params, PcsParams) else PcsParams.from_dict(params)
+    digest = np.zeros(4, dtype=np.uint64)
+    err = C.create_string_buffer(512)
+    rc = lib.mh_verify(C.byref(p), C.c_int(n), bp, bl, lh, _ptr(pub), C.c_size_t(len(public_values)), _ptr(st), _ptr(pre),
+                       C.c_size_t(len(pre_observe)), _ptr(f), C.c_size_t(f.size), _ptr(c), C.c_size_t(c.size // 4), _ptr(digest), err,
+                       C.c_size_t(512))
+    return (True, digest) if rc == 0 else (False, err.value.decode())

@@ -1,0 +1,443 @@
+// Host-only verifier of the lifted STARK: accepts or rejects the proofs mh_prove
+// produces without a GPU, a ctx or a Rust toolchain.  Restated from the reference's verifier:
+//   crates/lifted-stark/src/verifier/mod.rs      protocol flow, constraint identity, quotient reconstruction
+//   crates/lifted-stark/src/pcs/verifier.rs      aligned openings of the three trace trees
+//   crates/lifted-stark/src/pcs/deep/verifier.rs reduced openings -> DEEP quotient values at the query points
+//   crates/lifted-stark/src/pcs/fri/verifier.rs  per-round openings, folding consistency, final polynomial
+//   crates/lifted-stark/src/lmcs/config.rs:172-211 batch opening against a root
+// Fiat-Shamir is challenger.hpp (the same HostChallenger mh_prove uses); AIRs are the constraint-DAG blobs of
+// include/midenhip.h, evaluated at the out-of-domain point over the extension field.
+#include "../../include/midenhip.h"
+#include "air.hpp"
+#include "challenger.hpp"
+#include "gl.cuh"
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <string>
+
+namespace {
+
+struct Reject : MhError {
+  explicit Reject(const std::string& m) : MhError(MH_ERR_INVALID, "proof rejected: " + m) {}
+};
+
+// The two streams of a proof, consumed front to back (crates/stark-transcript/src/verifier.rs).
+struct Reader {
+  HostChallenger ch;
+  const u64* f;
+  size_t nf, pf = 0;
+  const u64* c;
+  size_t nc, pc = 0;  // commitments counted in digests
+  u64 hint_field() {
+    if (pf >= nf) throw Reject("transcript ran out of field elements");
+    const u64 v = f[pf++];
+    if (v >= GL_P) throw Reject("non-canonical field element");
+    return v;
+  }
+  Digest4 hint_digest() {
+    if (pc >= nc) throw Reject("transcript ran out of commitments");
+    Digest4 d;
+    for (int i = 0; i < 4; i++) {
+      d[i] = c[4 * pc + i];
+      if (d[i] >= GL_P) throw Reject("non-canonical digest element");
+    }
+    pc++;
+    return d;
+  }
+  u64 recv_field() {
+    const u64 v = hint_field();
+    ch.observe(v);
+    return v;
+  }
+  e2 recv_ef() {
+    const u64 a = recv_field();
+    return e2{a, recv_field()};
+  }
+  Digest4 recv_digest() {
+    Digest4 d = hint_digest();
+    ch.observe_digest(d.data());
+    return d;
+  }
+  void check_pow(int bits) {  // the witness is a transcript field (stark-transcript/src/verifier.rs grind check)
+    const u64 w = hint_field();
+    if (!ch.check_witness(bits, w)) throw Reject("proof-of-work witness");
+  }
+};
+
+size_t align8(size_t w) { return (w + 7) / 8 * 8; }
+
+// Overwrite-mode sponge over whole (already aligned / short) rows: crates/stateful-hasher/src/field_sponge.rs:41-59.
+void absorb(u64 st[12], const u64* v, size_t n) {
+  for (size_t off = 0; off < n; off += 8) {
+    const size_t k = std::min<size_t>(8, n - off);
+    for (size_t i = 0; i < k; i++) st[i] = v[off + i];
+    for (size_t i = k; i < 8; i++) st[i] = 0;
+    p2_permute(st);
+  }
+}
+Digest4 compress2(const Digest4& l, const Digest4& r) {
+  u64 st[12] = {l[0], l[1], l[2], l[3], r[0], r[1], r[2], r[3], 0, 0, 0, 0};
+  p2_permute(st);
+  return Digest4{st[0], st[1], st[2], st[3]};
+}
+
+// lmcs/config.rs:172-211: per sorted unique index the opened rows (one per matrix, already padded), then the
+// siblings that cannot be derived, level by level, left to right.  Returns the rows, concatenated per index.
+std::vector<std::vector<u64>> open_batch(Reader& rd, const Digest4& root, const std::vector<size_t>& widths,
+                                         const std::vector<size_t>& idx, int depth) {
+  size_t total = 0;
+  for (size_t w : widths) total += w;
+  std::vector<std::vector<u64>> rows(idx.size(), std::vector<u64>(total));
+  std::vector<std::pair<size_t, Digest4>> level;
+  for (size_t q = 0; q < idx.size(); q++) {
+    for (auto& x : rows[q]) x = rd.hint_field();
+    u64 st[12] = {0};
+    size_t off = 0;
+    for (size_t w : widths) {
+      absorb(st, rows[q].data() + off, w);
+      off += w;
+    }
+    level.push_back({idx[q], Digest4{st[0], st[1], st[2], st[3]}});
+  }
+  for (int d = depth; d > 0; d--) {
+    std::vector<std::pair<size_t, Digest4>> up;
+    for (size_t i = 0; i < level.size();) {
+      const size_t node = level[i].first;
+      Digest4 sib;
+      size_t used = 1;
+      if (i + 1 < level.size() && level[i + 1].first == (node ^ 1)) {
+        sib = level[i + 1].second;
+        used = 2;
+      } else {
+        sib = rd.hint_digest();
+      }
+      up.push_back({node >> 1, (node & 1) ? compress2(sib, level[i].second) : compress2(level[i].second, sib)});
+      i += used;
+    }
+    level.swap(up);
+  }
+  if (level.size() != 1 || level[0].second != root) throw Reject("Merkle root mismatch");
+  return rows;
+}
+
+int fri_rounds(const mh_pcs_params& p, int log_lde) {
+  const int log_max_final = p.log_final_degree + p.log_blowup;
+  const int steps = log_lde > log_max_final ? log_lde - log_max_final : 0;
+  return (steps + p.log_folding_arity - 1) / p.log_folding_arity;
+}
+
+// One folding step on an opened row (fri/fold/mod.rs:113-180, arity4.rs:46-121): the row holds the evaluations on
+// the coset s * <w_arity> in bit-reversed order; the result is the interpolant's value at beta.
+e2 fold_row(const e2* y, int log_arity, u64 s_inv, e2 beta) {
+  const e2 x = e2_mulf(beta, s_inv);
+  if (log_arity == 1) {
+    const e2 r = e2_add(e2_add(y[0], y[1]), e2_mul(e2_sub(y[0], y[1]), x));
+    return e2_mulf(r, gl_inv(2));
+  }
+  const e2 y0 = y[0], y2 = y[1], y1 = y[2], y3 = y[3];
+  const u64 w4 = gl_two_adic_generator(2);
+  const e2 s02 = e2_add(y0, y2), d02 = e2_sub(y0, y2), s13 = e2_add(y1, y3), d31 = e2_mulf(e2_sub(y3, y1), w4);
+  const e2 c0 = e2_add(s02, s13), c1 = e2_add(d02, d31), c2 = e2_sub(s02, s13), c3 = e2_sub(d02, d31);
+  const e2 x2 = e2_mul(x, x), x3 = e2_mul(x2, x);
+  return e2_mulf(e2_add(e2_add(c0, e2_mul(c1, x)), e2_add(e2_mul(c2, x2), e2_mul(c3, x3))), gl_inv(4));
+}
+
+// Everything an AIR's constraints can read at the out-of-domain point.
+struct PointEnv {
+  const e2 *main_cur, *main_next, *aux_cur, *aux_next, *periodic, *randomness, *aux_values;
+  const u64* publics;
+  e2 is_first, is_last, is_transition;
+};
+// sum_k alpha^(K-1-k) C_k at the point (constraints/folder.rs:88-105 read backwards = Horner).
+e2 fold_constraints(const DagIR& ir, const PointEnv& e, e2 alpha) {
+  std::vector<e2> v(ir.nodes.size(), e2_make(0));
+  for (size_t i = 0; i < ir.nodes.size(); i++) {
+    if (!ir.live[i]) continue;
+    const DagNode& nd = ir.nodes[i];
+    switch (nd.op) {
+      case DOP_CONST: v[i] = e2_make(nd.c); break;
+      case DOP_MAIN: v[i] = (nd.b ? e.main_next : e.main_cur)[nd.a]; break;
+      case DOP_AUX: v[i] = (nd.b ? e.aux_next : e.aux_cur)[nd.a]; break;
+      case DOP_PUBLIC: v[i] = e2_make(gl_canon(e.publics[nd.a])); break;
+      case DOP_PERIODIC: v[i] = e.periodic[nd.a]; break;
+      case DOP_IS_FIRST: v[i] = e.is_first; break;
+      case DOP_IS_LAST: v[i] = e.is_last; break;
+      case DOP_IS_TRANSITION: v[i] = e.is_transition; break;
+      case DOP_RANDOMNESS: v[i] = e.randomness[nd.a]; break;
+      case DOP_AUX_VALUE: v[i] = e.aux_values[nd.a]; break;
+      case DOP_ADD: v[i] = e2_add(v[nd.a], v[nd.b]); break;
+      case DOP_SUB: v[i] = e2_sub(v[nd.a], v[nd.b]); break;
+      case DOP_MUL: v[i] = e2_mul(v[nd.a], v[nd.b]); break;
+      default: v[i] = e2_neg(v[nd.a]); break;
+    }
+  }
+  e2 acc = e2_make(0);
+  for (uint32_t c : ir.cons) acc = e2_add(e2_mul(acc, alpha), v[c]);
+  return acc;
+}
+// Value at y of the polynomial of degree < P that takes the column's values on the subgroup of order P.
+e2 periodic_at(const std::vector<u64>& col, e2 y) {
+  const size_t P = col.size();
+  int logp = 0;
+  while (((size_t)1 << logp) < P) logp++;
+  const u64 w_inv = gl_inv(gl_two_adic_generator(logp)), p_inv = gl_inv((u64)P);
+  e2 acc = e2_make(0);
+  for (size_t k = P; k-- > 0;) {  // coefficient k = (1/P) sum_r col[r] w^(-k r), Horner from the top
+    u64 s = 0, x = 1;
+    const u64 wk = gl_pow(w_inv, k);
+    for (size_t r = 0; r < P; r++) {
+      s = gl_add(s, gl_mul(col[r] % GL_P, x));
+      x = gl_mul(x, wk);
+    }
+    acc = e2_add(e2_mul(acc, y), e2_make(gl_mul(s, p_inv)));
+  }
+  return acc;
+}
+
+void verify_impl(const mh_pcs_params& pp, const std::vector<DagIR>& airs, const std::vector<int>& lhs, const std::vector<u64>& publics,
+                 Reader& rd, u64 digest[4]) {
+  const size_t n_airs = airs.size();
+  const int lb = pp.log_blowup, la = pp.log_folding_arity;
+  if (lb < 1 || lb > 8 || (la != 1 && la != 2) || pp.num_queries < 1) throw Reject("unsupported PCS parameters");
+  for (size_t i = 0; i < n_airs; i++) {
+    if (lhs[i] < 1) throw Reject("trace too small");
+    size_t pmax = 0;
+    for (auto& c : airs[i].periodic) pmax = std::max(pmax, c.size());
+    if (((size_t)1 << lhs[i]) < pmax) throw Reject("trace shorter than a periodic column");
+    if (airs[i].num_public != publics.size()) throw Reject("public value count");
+  }
+  // proof order: ascending height, ties by instance index (order.rs)
+  std::vector<int> order(n_airs);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lhs[a] < lhs[b]; });
+  const int log_n = lhs[order.back()], L = log_n + lb;
+  if (L > 32) throw Reject("LDE order exceeds the field's two-adicity");
+  int logD = 0;
+  size_t max_rand = 0;
+  for (auto& a : airs) {
+    logD = std::max(logD, a.log_quotient_degree);
+    max_rand = std::max(max_rand, a.num_randomness);
+  }
+  if (logD > lb) throw Reject("constraint degree too high for the blowup");
+  const size_t D = (size_t)1 << logD;
+  const u64 g = gl_lde_shift(L), g_inv = gl_inv(g);
+
+  rd.ch.observe((u64)n_airs);
+  for (int lh : lhs) rd.ch.observe((u64)lh);
+  // ---- commit phase replay (verifier/mod.rs) ----
+  const Digest4 main_root = rd.recv_digest();
+  std::vector<e2> randomness;
+  for (size_t i = 0; i < max_rand; i++) randomness.push_back(rd.ch.sample_ef());
+  const Digest4 aux_root = rd.recv_digest();
+  std::vector<std::vector<e2>> aux_values(n_airs);  // proof order
+  for (size_t j = 0; j < n_airs; j++)
+    for (size_t k = 0; k < airs[order[j]].num_aux_values; k++) aux_values[j].push_back(rd.recv_ef());
+  const e2 alpha = rd.ch.sample_ef(), beta = rd.ch.sample_ef();
+  const Digest4 quot_root = rd.recv_digest();
+  e2 z;
+  for (;;) {  // domain.rs:539-553
+    z = rd.ch.sample_ef();
+    if (e2_is_zero(z)) continue;
+    if (e2_eq(e2_exp_pow2(z, log_n), e2_make(1))) continue;
+    if (e2_eq(e2_exp_pow2(e2_mulf(z, g_inv), L), e2_make(1))) continue;
+    break;
+  }
+  const e2 zs[2] = {z, e2_mulf(z, gl_two_adic_generator(log_n))};
+  // aligned widths per tree (pcs/verifier.rs)
+  std::vector<size_t> widths[3];
+  for (size_t j = 0; j < n_airs; j++) widths[0].push_back(align8(airs[order[j]].main_width));
+  for (size_t j = 0; j < n_airs; j++) widths[1].push_back(align8(2 * airs[order[j]].aux_width));
+  widths[2].push_back(align8(2 * D));
+  const Digest4 roots[3] = {main_root, aux_root, quot_root};
+  size_t W = 0;
+  for (auto& ws : widths)
+    for (size_t w : ws) W += w;
+  std::vector<e2> ev[2];
+  for (int k = 0; k < 2; k++)
+    for (size_t i = 0; i < W; i++) ev[k].push_back(rd.recv_ef());
+  rd.check_pow(pp.deep_pow_bits);
+  const e2 alpha_d = rd.ch.sample_ef(), beta_d = rd.ch.sample_ef();
+  e2 fred[2];
+  for (int k = 0; k < 2; k++) {
+    e2 a = e2_make(0);
+    for (size_t i = 0; i < W; i++) a = e2_add(e2_mul(a, alpha_d), ev[k][i]);
+    fred[k] = a;
+  }
+  const int rounds = fri_rounds(pp, L);
+  std::vector<Digest4> fri_roots;
+  std::vector<e2> fri_betas;
+  for (int r = 0; r < rounds; r++) {
+    fri_roots.push_back(rd.recv_digest());
+    rd.check_pow(pp.folding_pow_bits);
+    fri_betas.push_back(rd.ch.sample_ef());
+  }
+  const size_t fpd = (size_t)1 << std::max(0, L - rounds * la - lb);
+  std::vector<e2> final_poly;  // descending degree
+  for (size_t i = 0; i < fpd; i++) final_poly.push_back(rd.recv_ef());
+  rd.check_pow(pp.query_pow_bits);
+  std::vector<size_t> idx;
+  for (int i = 0; i < pp.num_queries; i++) idx.push_back(rd.ch.sample_bits(L));
+  std::sort(idx.begin(), idx.end());
+  idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
+
+  // ---- query phase: trace openings -> DEEP quotient values (deep/verifier.rs) ----
+  std::vector<e2> reduced(idx.size(), e2_make(0));
+  for (int t = 0; t < 3; t++) {
+    auto rows = open_batch(rd, roots[t], widths[t], idx, L);
+    for (size_t q = 0; q < idx.size(); q++)
+      for (u64 v : rows[q]) reduced[q] = e2_add(e2_mul(reduced[q], alpha_d), e2_make(v));
+  }
+  const u64 wK = gl_two_adic_generator(L);
+  std::vector<std::pair<size_t, e2>> cur;  // (index in the current FRI domain, value)
+  for (size_t q = 0; q < idx.size(); q++) {
+    const e2 x = e2_make(gl_mul(g, gl_pow(wK, idx[q])));
+    e2 acc = e2_make(0), bp = e2_make(1);
+    for (int k = 0; k < 2; k++) {
+      const e2 den = e2_sub(zs[k], x);
+      if (e2_is_zero(den)) throw Reject("out-of-domain point on the LDE coset");
+      acc = e2_add(acc, e2_mul(e2_mul(bp, e2_sub(fred[k], reduced[q])), e2_inv(den)));
+      bp = e2_mul(bp, beta_d);
+    }
+    cur.push_back({idx[q], acc});
+  }
+  // ---- FRI (fri/verifier.rs): each round's row must contain the running value and folds to the next one ----
+  int logn = L;
+  u64 gen_inv = gl_inv(gl_two_adic_generator(L));
+  const size_t arity = (size_t)1 << la;
+  for (int r = 0; r < rounds; r++) {
+    const int logf = logn - la;
+    const size_t mask = ((size_t)1 << logf) - 1;
+    std::vector<size_t> ridx;
+    for (auto& kv : cur) ridx.push_back(kv.first & mask);
+    std::sort(ridx.begin(), ridx.end());
+    ridx.erase(std::unique(ridx.begin(), ridx.end()), ridx.end());
+    auto rows = open_batch(rd, fri_roots[r], {arity * 2}, ridx, logf);
+    std::vector<std::pair<size_t, e2>> next;
+    for (auto& kv : cur) {
+      const size_t row = kv.first & mask;
+      const size_t pos = bitrev32((u32)(kv.first >> logf), la);
+      const size_t q = std::lower_bound(ridx.begin(), ridx.end(), row) - ridx.begin();
+      e2 y[4];
+      for (size_t k = 0; k < arity; k++) y[k] = e2{rows[q][2 * k], rows[q][2 * k + 1]};
+      if (!e2_eq(y[pos], kv.second)) throw Reject("FRI round " + std::to_string(r) + ": opened row disagrees with the folded value");
+      const e2 folded = fold_row(y, la, gl_pow(gen_inv, row), fri_betas[r]);
+      if (next.empty() || next.back().first != row) next.push_back({row, folded});
+      else if (!e2_eq(next.back().second, folded)) throw Reject("FRI: two queries fold to different values");
+    }
+    std::sort(next.begin(), next.end(), [](auto& a, auto& b) { return a.first < b.first; });
+    next.erase(std::unique(next.begin(), next.end(), [](auto& a, auto& b) { return a.first == b.first; }), next.end());
+    cur.swap(next);
+    logn = logf;
+    gen_inv = gl_exp_pow2(gen_inv, la);
+  }
+  {
+    const u64 gen = gl_two_adic_generator(logn);
+    for (auto& kv : cur) {
+      const u64 x = gl_pow(gen, kv.first);
+      e2 acc = e2_make(0);
+      for (e2 c : final_poly) acc = e2_add(e2_mulf(acc, x), c);
+      if (!e2_eq(acc, kv.second)) throw Reject("FRI: final polynomial mismatch");
+    }
+  }
+  // ---- constraint identity at z (verifier/mod.rs): sum over AIRs (beta-folded) == Q(z) * Z_H(z) ----
+  e2 accumulated = e2_make(0);
+  size_t off_main = 0, off_aux = 0;
+  for (size_t j = 0; j < n_airs; j++) off_aux += widths[0][j];
+  size_t off_quot = off_aux;
+  for (size_t j = 0; j < n_airs; j++) off_quot += widths[1][j];
+  const e2 X = e2{0, 1};  // the extension's generator: an EF column is f0 + X * f1 of its two base columns
+  for (size_t j = 0; j < n_airs; j++) {
+    const DagIR& air = airs[order[j]];
+    const int lh = lhs[order[j]];
+    std::vector<e2> mc(air.main_width), mn(air.main_width), ac(air.aux_width), an(air.aux_width), per;
+    for (size_t c = 0; c < air.main_width; c++) {
+      mc[c] = ev[0][off_main + c];
+      mn[c] = ev[1][off_main + c];
+    }
+    for (size_t c = 0; c < air.aux_width; c++) {
+      ac[c] = e2_add(ev[0][off_aux + 2 * c], e2_mul(ev[0][off_aux + 2 * c + 1], X));
+      an[c] = e2_add(ev[1][off_aux + 2 * c], e2_mul(ev[1][off_aux + 2 * c + 1], X));
+    }
+    off_main += widths[0][j];
+    off_aux += widths[1][j];
+    const e2 y = e2_exp_pow2(z, log_n - lh);  // the point on this instance's own domain
+    const e2 van = e2_sub(e2_exp_pow2(y, lh), e2_make(1));
+    const u64 wh_inv = gl_inv(gl_two_adic_generator(lh));
+    for (auto& col : air.periodic) {
+      int logp = 0;
+      while (((size_t)1 << logp) < col.size()) logp++;
+      per.push_back(periodic_at(col, e2_exp_pow2(z, log_n - logp)));
+    }
+    PointEnv e{};
+    e.main_cur = mc.data(); e.main_next = mn.data(); e.aux_cur = ac.data(); e.aux_next = an.data();
+    e.periodic = per.data(); e.randomness = randomness.data(); e.aux_values = aux_values[j].data();
+    e.publics = publics.data();
+    e.is_first = e2_mul(van, e2_inv(e2_sub(y, e2_make(1))));        // domain.rs:518-531
+    e.is_last = e2_mul(van, e2_inv(e2_sub(y, e2_make(wh_inv))));
+    e.is_transition = e2_sub(y, e2_make(wh_inv));
+    accumulated = e2_add(e2_mul(accumulated, beta), fold_constraints(air, e, alpha));
+  }
+  {  // reconstruct_quotient (domain.rs:773-794): barycentric recombination of the D chunk openings
+    const u64 wD = gl_two_adic_generator(logD);
+    const e2 u = e2_exp_pow2(e2_mulf(z, g_inv), log_n);
+    e2 num = e2_make(0), den = e2_make(0);
+    u64 wt = 1;
+    for (size_t t = 0; t < D; t++) {
+      const e2 chunk = e2_add(ev[0][off_quot + 2 * t], e2_mul(ev[0][off_quot + 2 * t + 1], X));
+      const e2 d = e2_sub(u, e2_make(wt));
+      if (e2_is_zero(d)) throw Reject("out-of-domain point on a quotient chunk domain");
+      const e2 wgt = e2_mulf(e2_inv(d), wt);
+      num = e2_add(num, e2_mul(wgt, chunk));
+      den = e2_add(den, wgt);
+      wt = gl_mul(wt, wD);
+    }
+    const e2 qz = e2_mul(num, e2_inv(den));
+    const e2 van = e2_sub(e2_exp_pow2(z, log_n), e2_make(1));
+    if (!e2_eq(accumulated, e2_mul(qz, van))) throw Reject("constraints do not vanish on the trace domain (quotient identity)");
+  }
+  if (rd.pf != rd.nf || rd.pc != rd.nc) throw Reject("trailing data in the transcript");
+  if (!rd.ch.in.empty()) rd.ch.duplexing();
+  for (int i = 0; i < 4; i++) digest[i] = rd.ch.st[i];
+}
+
+}  // namespace
+
+extern "C" int mh_verify(const mh_pcs_params* params, int n_airs, const uint64_t* const* air_blobs, const size_t* air_blob_words,
+                         const uint8_t* log_trace_heights, const uint64_t* public_values, size_t n_public_values,
+                         const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe, const uint64_t* fields,
+                         size_t n_fields, const uint64_t* commitments, size_t n_commitments, uint64_t digest[4], char* err,
+                         size_t err_cap) {
+  auto fail = [&](int code, const char* msg) {
+    if (err && err_cap) {
+      strncpy(err, msg, err_cap - 1);
+      err[err_cap - 1] = 0;
+    }
+    return code;
+  };
+  try {
+    MH_REQUIRE(params && air_blobs && air_blob_words && log_trace_heights && challenger_state && digest, "null argument");
+    MH_REQUIRE(n_airs > 0 && n_airs <= 256, "need between 1 and 256 AIR instances");
+    MH_REQUIRE((public_values || !n_public_values) && (pre_observe || !n_pre_observe) && (fields || !n_fields) &&
+                   (commitments || !n_commitments),
+               "null array");
+    std::vector<DagIR> airs;
+    std::vector<int> lhs;
+    for (int i = 0; i < n_airs; i++) {
+      airs.push_back(dag_parse(air_blobs[i], air_blob_words[i]));
+      lhs.push_back(log_trace_heights[i]);
+    }
+    Reader rd;
+    for (int i = 0; i < 12; i++) rd.ch.st[i] = gl_canon(challenger_state[i]);
+    for (size_t i = 0; i < n_pre_observe; i++) rd.ch.observe(pre_observe[i]);
+    rd.f = fields; rd.nf = n_fields;
+    rd.c = commitments; rd.nc = n_commitments;
+    verify_impl(*params, airs, lhs, std::vector<u64>(public_values, public_values + n_public_values), rd, digest);
+    if (err && err_cap) err[0] = 0;
+    return MH_OK;
+  } catch (const MhError& e) {
+    return fail(e.code, e.what());
+  } catch (const std::exception& e) {
+    return fail(MH_ERR_INTERNAL, e.what());
+  }
+}

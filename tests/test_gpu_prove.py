@@ -52,6 +52,12 @@ def check_same(ctx, airs_, traces, publics, params):
     ok, msg = ob.verify(airs_, got.log_trace_heights, publics,
                         {"fields": got.fields, "commitments": got.commitments}, params)
     assert ok, msg
+    # the product's own host verifier (mh_verify) agrees with the oracle's
+    pkg = load_package()
+    ok2, dig2 = pkg.verify(airs_, got.log_trace_heights, publics, params, ob.challenger_state(), ob.protocol_pre_observe(params, publics),
+                           got.fields, got.commitments)
+    assert ok2, dig2
+    assert (dig2 == got.digest).all()
     return got
 
 
@@ -162,6 +168,9 @@ def _prove_and_verify(ctx, airs_, traces, params):
     ok, msg = ob.verify(airs_, lh, [], {"fields": got.fields, "commitments": got.commitments}, params)
     assert ok, msg
     assert (msg == got.digest).all()
+    ok2, dig2 = load_package().verify(airs_, lh, [], params, ob.challenger_state(), ob.protocol_pre_observe(params, []), got.fields,
+                                      got.commitments)
+    assert ok2 and (dig2 == got.digest).all()
     return got
 
 

@@ -1,0 +1,83 @@
+"""CPU: the product's host-only verifier (mh_verify, csrc/verifier.cpp) against the oracle.  Two restatements of
+the reference's verifier must agree: mh_verify accepts every proof the oracle prover makes (same digest as the
+oracle verifier), and rejects what the oracle verifier rejects -- tampered fields, commitments, parameters."""
+import numpy as np
+import pytest
+import oracle_binding as ob
+import airs as A
+from __graft_entry__ import load_package
+
+pkg = load_package()
+from miden_vm_amd import dag  # noqa: E402
+
+SMALL = dict(log_blowup=2, log_folding_arity=1, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=1, num_queries=6,
+             query_pow_bits=2)
+ARITY4 = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=5,
+              query_pow_bits=3)
+
+
+def cases():
+    t, pub = A.fib_trace(6)
+    yield "fib", [A.fib_air()], [t], pub, SMALL
+    yield "fib_arity4", [A.fib_air()], [t], pub, ARITY4
+    yield "periodic", [A.periodic_air(0)], [A.periodic_trace(6)], [], ARITY4
+    yield "dummy", [dag.dummy_miden_air(11, 2)], [A.dummy_trace(5, 11)], [], ARITY4
+    air, _ = A.logup_air()
+    yield "logup", [air], [A.logup_trace(5)], [], SMALL
+    t1, pub1 = A.fib_trace(7)
+    yield "multi", [A.periodic_air(3), A.fib_air()], [A.periodic_trace(5), t1], pub1, ARITY4
+
+
+def product_verify(airs_, lhs, pub, prm, fields, commits):
+    return pkg.verify(airs_, lhs, pub, prm, ob.challenger_state(), ob.protocol_pre_observe(prm, pub), fields, commits)
+
+
+@pytest.mark.parametrize("name,airs_,traces,pub,prm", list(cases()), ids=[c[0] for c in cases()])
+def test_product_verifier_accepts_oracle_proofs(name, airs_, traces, pub, prm):
+    proof = ob.prove(airs_, traces, pub, prm)
+    lhs = proof["log_heights"]
+    ok, dig = product_verify(airs_, lhs, pub, prm, proof["fields"], proof["commitments"])
+    assert ok, dig
+    assert (dig == proof["digest"]).all()
+    ok2, dig2 = ob.verify(airs_, lhs, pub, proof, prm)
+    assert ok2 and (dig2 == dig).all()
+
+
+def test_product_verifier_rejects_what_the_oracle_rejects():
+    t, pub = A.fib_trace(6)
+    airs_, prm = [A.fib_air()], ARITY4
+    proof = ob.prove(airs_, [t], pub, prm)
+    f, c, lhs = proof["fields"], proof["commitments"], proof["log_heights"]
+    rng = np.random.default_rng(0)
+    n_bad = 0
+    for pos in list(rng.integers(0, f.size, 40)) + [0, 1, f.size - 1]:
+        bad = f.copy()
+        bad[pos] = (int(bad[pos]) + 1) % A.P
+        ok_p, _ = product_verify(airs_, lhs, pub, prm, bad, c)
+        ok_o, _ = ob.verify(airs_, lhs, pub, {"fields": bad, "commitments": c}, prm)
+        assert ok_p == ok_o
+        n_bad += not ok_p
+    assert n_bad >= 40  # (a flipped PoW witness can stay valid; everything else must fail)
+    for pos in (0, 1, 2, len(c) - 1):
+        bad = c.copy()
+        bad[pos, 0] = (int(bad[pos, 0]) + 1) % A.P
+        assert not product_verify(airs_, lhs, pub, prm, f, bad)[0]
+    assert not product_verify(airs_, lhs, [pub[0], pub[1], (pub[2] + 1) % A.P], prm, f, c)[0]   # wrong statement
+    assert not product_verify(airs_, lhs, pub, dict(prm, num_queries=6), f, c)[0]               # wrong parameters
+    assert not product_verify(airs_, [lhs[0] + 1], pub, prm, f, c)[0]                           # wrong trace height
+    assert not product_verify(airs_, lhs, pub, prm, f[:-1], c)[0]                               # truncated
+    assert not product_verify(airs_, lhs, pub, prm, np.append(f, 0), c)[0]                      # trailing data
+    wrong_air = [A.periodic_air(3)]
+    assert not product_verify(wrong_air, lhs, pub, prm, f, c)[0]
+
+
+def test_unsatisfied_constraints_are_rejected():
+    """A trace that violates the AIR still yields a transcript; both verifiers must refuse it at the quotient identity."""
+    t, pub = A.fib_trace(6)
+    t = t.copy()
+    t[10, 0] = (int(t[10, 0]) + 5) % A.P
+    airs_, prm = [A.fib_air()], ARITY4
+    proof = ob.prove(airs_, [t], pub, prm)
+    ok, msg = product_verify(airs_, proof["log_heights"], pub, prm, proof["fields"], proof["commitments"])
+    assert not ok and "quotient identity" in msg
+    assert not ob.verify(airs_, proof["log_heights"], pub, proof, prm)[0]
