@@ -67,6 +67,8 @@ int mh_coset_lde_batch(mh_ctx* ctx, const uint64_t* rowmajor, int log_n, size_t 
 /* Upload a host row-major RowMajorMatrix<Felt> (values, width) of height 2^log_n: one H2D copy +
  * an on-device transpose to column-major; canonicalises felts. */
 int mh_trace_upload(mh_ctx* ctx, const uint64_t* rowmajor, int log_n, size_t width, mh_trace** out);
+/* The same for a row-major matrix that is already in device memory (a GPU trace generator): no PCIe traffic. */
+int mh_trace_from_device(mh_ctx* ctx, const uint64_t* device_rowmajor, int log_n, size_t width, mh_trace** out);
 void mh_trace_free(mh_trace* t);
 /* Page-locked host memory (hipHostMalloc): a trace built in it uploads by direct DMA at PCIe line rate; any
  * other host pointer works too, staged by the runtime (several times slower).  NULL on failure. */

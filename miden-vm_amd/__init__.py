@@ -30,7 +30,7 @@ EXPORTS = [
     "mh_session_begin", "mh_session_free", "mh_session_shape", "mh_session_commit_main", "mh_session_commit_aux",
     "mh_session_commit_quotient", "mh_session_ood_point_ok", "mh_session_ood", "mh_session_deep", "mh_session_fri_commit",
     "mh_session_fri_fold", "mh_session_fri_final", "mh_session_open", "mh_grind",
-    "mh_host_alloc", "mh_host_free", "mh_verify", "mh_lookup_load", "mh_lookup_free", "mh_air_attach_lookup", "mh_lookup_build_aux", "mh_trace_download",
+    "mh_host_alloc", "mh_host_free", "mh_verify", "mh_trace_from_device", "mh_lookup_load", "mh_lookup_free", "mh_air_attach_lookup", "mh_lookup_build_aux", "mh_trace_download",
 ]
 
 _lib = None
@@ -187,6 +187,13 @@ class Trace:
         t.ctx, t.h, t.log_n, t.width = ctx, h, log_n, width
         ctx._children.add(t)
         return t
+
+    @classmethod
+    def from_device(cls, ctx, device_ptr, log_n, width):
+        """mh_trace_from_device: wrap a row-major [2^log_n][width] matrix already in device memory."""
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mh_trace_from_device(ctx.h, C.c_void_p(device_ptr), C.c_int(log_n), C.c_size_t(width), C.byref(h)))
+        return cls.from_handle(ctx, h, log_n, width)
 
     def download(self):
         out = np.zeros((1 << self.log_n, self.width), dtype=np.uint64)

@@ -5,6 +5,7 @@
 #include "kernels.hpp"
 #include <algorithm>
 #include <cstring>
+#include <memory>
 
 #define MH_TRY(ctx_expr) mh_ctx* _c = (ctx_expr); PoolScope _ps(_c); try {
 #define MH_CATCH                                                   \
@@ -148,6 +149,25 @@ int mh_trace_upload(mh_ctx* c, const uint64_t* rowmajor, int log_n, size_t width
   MH_REQUIRE(log_n >= 0 && log_n <= 29 && width > 0, "bad trace shape");
   HIP_CHECK(hipSetDevice(c->device));
   *out = trace_upload(c, rowmajor, log_n, width);
+  MH_CATCH
+}
+// A trace that already lives in device memory (row-major, any stream-ordered producer finished): transposed and
+// canonicalised on the device, no PCIe traffic (trace generation hand-off).
+int mh_trace_from_device(mh_ctx* c, const uint64_t* device_rowmajor, int log_n, size_t width, mh_trace** out) {
+  MH_TRY(c)
+  MH_REQUIRE(c && device_rowmajor && out, "null argument");
+  MH_REQUIRE(log_n >= 0 && log_n <= 29 && width > 0, "bad trace shape");
+  HIP_CHECK(hipSetDevice(c->device));
+  hipPointerAttribute_t attr;
+  MH_REQUIRE(hipPointerGetAttributes(&attr, device_rowmajor) == hipSuccess && attr.type == hipMemoryTypeDevice,
+             "mh_trace_from_device needs a device pointer (use mh_trace_upload for host memory)");
+  const size_t n = (size_t)1 << log_n;
+  std::unique_ptr<mh_trace> t(new mh_trace());
+  t->ctx = c; t->log_n = log_n; t->width = width;
+  t->cols.alloc(n * width * 8);
+  launch_transpose_rm_to_cm(c, device_rowmajor, t->cols.u(), n, width);
+  c->sync();
+  *out = t.release();
   MH_CATCH
 }
 // Page-locked host memory for traces: a RowMajorMatrix built in it is DMA'd at PCIe line rate by

@@ -4,6 +4,7 @@ import json, os
 import numpy as np
 import pytest
 import oracle_binding as ob
+import airs as A
 from __graft_entry__ import load_package
 
 pytestmark = pytest.mark.gpu
@@ -137,3 +138,25 @@ def test_commit_large_properties(ctx):
         acc = L.orc_fadd(L.orc_fmul(acc, x), int(coeffs[k]))
     f, _ = tree.prove_batch([i], alignment=8)
     assert int(f[7]) == acc
+
+
+def test_trace_from_device_memory(ctx):
+    """mh_trace_from_device: a trace that already sits in device memory (hipMalloc + a copy stand in for a GPU trace
+    generator) commits to the same root as the same matrix uploaded from the host; a host pointer is refused."""
+    import ctypes as C
+    pkg = load_package()
+    hip = C.CDLL("libamdhip64.so")  # the runtime libmidenhip itself is linked against
+    m = A.dummy_trace(10, 13, seed=21)
+    dptr = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dptr), C.c_size_t(m.nbytes)) == 0
+    assert hip.hipMemcpy(dptr, C.c_void_p(m.ctypes.data), C.c_size_t(m.nbytes), C.c_int(1)) == 0  # hipMemcpyHostToDevice
+    try:
+        t_dev = pkg.Trace.from_device(ctx, dptr.value, 10, 13)
+        assert (t_dev.download() == m).all()
+        r_dev = pkg.commit_traces(ctx, [t_dev], 3).root()
+        r_host = pkg.commit_traces(ctx, [ctx.upload_trace(m)], 3).root()
+        assert list(r_dev) == list(r_host)
+        with pytest.raises(pkg.MidenHipError):
+            pkg.Trace.from_device(ctx, m.ctypes.data, 10, 13)
+    finally:
+        hip.hipFree(dptr)
