@@ -146,8 +146,10 @@ class TorchComm:
                 hs, hr = s.cpu(), torch.empty(n, dtype=torch.int64)
                 dist.all_to_all_single(hr, hs, group=self.group)
                 r.copy_(hr)
-            else:
-                dist.all_to_all_single(r, s, group=self.group)
+            else:  # RCCL sees only torch-owned buffers: the library's allocations belong to another HIP runtime instance
+                ts, tr = s.clone(), torch.empty_like(r)
+                dist.all_to_all_single(tr, ts, group=self.group)
+                r.copy_(tr)
         return self._wrap(go)
 
     def _all_gather(self, user, send, recv, bytes_per_rank):
@@ -160,7 +162,9 @@ class TorchComm:
                 dist.all_gather(out, hs, group=self.group)
                 r.copy_(torch.cat(out))
             else:
-                dist.all_gather_into_tensor(r, s, group=self.group)
+                ts, tr = s.clone(), torch.empty_like(r)
+                dist.all_gather_into_tensor(tr, ts, group=self.group)
+                r.copy_(tr)
         return self._wrap(go)
 
     def _all_reduce(self, user, buf, n):
@@ -171,7 +175,9 @@ class TorchComm:
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
                 t.copy_(h)
             else:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                tt = t.clone()
+                dist.all_reduce(tt, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(tt)
         return self._wrap(go)
 
 
