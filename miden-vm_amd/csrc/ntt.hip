@@ -22,8 +22,15 @@
 #include "kernels.hpp"
 #include "poseidon2_fast.cuh"
 
+// LDS tile of a pass: 2^12 elements (34 KB with padding, 256 threads, 4 workgroups per CU) up to 2^20-point
+// transforms; 2^14 elements (136 KB, 1024 threads, one workgroup per CU -- the same 4 waves per SIMD) beyond, so
+// that 2^21 and 2^22 still take two passes over HBM instead of three.
 static constexpr int NTT_TILE_LOG = 12;
+static constexpr int NTT_TILE_LOG_BIG = 14;
 static constexpr int NTT_THREADS = 256;
+// (measured, LDE per proof: 2^22 three-AIR shape 69.4 -> 63.2 ms with the big tile; at 2^24 the 10-stage strided
+// pass it implies -- 128 B segments, 1024 rows -- loses to three small-tile passes, 289.7 vs 259.6 ms)
+static int ntt_tile_log(int log_n) { return log_n > 20 && log_n <= 22 ? NTT_TILE_LOG_BIG : NTT_TILE_LOG; }
 
 // ---------------------------------------------------------------------------------------------
 // twiddle table: tw[k] = w^k, k < n_half, given w^(2^i) in pw[]
@@ -97,7 +104,7 @@ struct NttPassArgs {
   int log_n, s_lo, r_bits, cb;                          // stages s_lo .. s_lo+r_bits-1, tile = 2^(r_bits+cb)
   int dif;                                              // 1 = DIF (a+b,(a-b)w), descending; 0 = DIT
   int canon_out;                                        // store canonical values (last pass of a transform whose output leaves the NTT)
-  const u64* tw_round[3];                               // per round of this pass: plane [2^G - 1][2^s] of W^rev(e), W = w_{2^(s+G)}^gm
+  const u64* tw_round[4];                               // per round of this pass: plane [2^G - 1][2^s] of W^rev(e), W = w_{2^(s+G)}^gm
   const u64* scale_lo;                                  // optional: multiply on load by
   const u64* scale_hi;                                  //   scale_lo[z][k & m] * scale_hi[z][k >> lb], k = bitrev(pos)
   int lb;
@@ -193,7 +200,7 @@ __device__ u64 ntt_canon(u64 t);
 #ifndef NTT16_OCC
 #define NTT16_OCC
 #endif
-static constexpr int NTT2_LDS = (1 << NTT_TILE_LOG) + (1 << (NTT_TILE_LOG - 4));  // one pad element per 16
+static size_t ntt_lds_bytes(int tile_log) { return (((size_t)1 << tile_log) + ((size_t)1 << (tile_log - 4))) * 8; }  // one pad element per 16
 __device__ __forceinline__ u32 ntt_pad(u32 l) { return l + (l >> 4); }
 
 template <int G, bool INV>
@@ -201,7 +208,7 @@ __device__ __forceinline__ void ntt_round(const NttPassArgs& a, u64* lds, int st
                                           size_t gbase, const u64* __restrict__ tw) {
   const int b0 = st + a.cb, s = a.s_lo + st;
   const u32 cb_mask = (1u << a.cb) - 1;
-  for (u32 q = threadIdx.x; q < (tile_n >> G); q += NTT_THREADS) {
+  for (u32 q = threadIdx.x; q < (tile_n >> G); q += blockDim.x) {
     const u32 low = q & ((1u << b0) - 1);
     const u32 l0 = ((q >> b0) << (b0 + G)) | low;
     const u32 gm = (((l0 >> a.cb) & ((1u << st) - 1)) << a.s_lo) | ((u32)lo0 << a.cb) | (l0 & cb_mask);
@@ -235,9 +242,9 @@ __device__ __forceinline__ void ntt_round(const NttPassArgs& a, u64* lds, int st
 }
 
 // INV: the inverse transform, always run as DIF (natural in, bit-reversed out); forward = DIT.
-template <bool INV>
-__global__ __launch_bounds__(NTT_THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a) {
-  __shared__ u64 lds[NTT2_LDS];
+template <bool INV, int THREADS>
+__global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a) {
+  extern __shared__ u64 lds[];
   const int tile_log = a.r_bits + a.cb;
   const u32 tile_n = 1u << tile_log;
   const u32 cb_mask = (1u << a.cb) - 1;
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(NTT_THREADS) NTT16_OCC void k_ntt16_pass(NttPassArg
   const u64* src = a.src + (size_t)blockIdx.y * a.src_col_stride;
   u64* dst = a.dst + (size_t)blockIdx.y * a.dst_col_stride + (size_t)blockIdx.z * a.dst_z_stride;
 
-  for (u32 l = threadIdx.x; l < tile_n; l += NTT_THREADS) {
+  for (u32 l = threadIdx.x; l < tile_n; l += THREADS) {
     size_t g = gbase | ((size_t)(l >> a.cb) << a.s_lo) | (l & cb_mask);
     u64 v = src[g];
     if (a.scale_lo) {
@@ -297,18 +304,19 @@ struct PassPlan {
 // stages [0, log_n) split into one contiguous pass (low stages) + strided passes, ascending order.
 static std::vector<PassPlan> plan_passes(int log_n) {
   std::vector<PassPlan> p;
-  int c = log_n < NTT_TILE_LOG ? log_n : NTT_TILE_LOG;
+  const int T = ntt_tile_log(log_n);
+  int c = log_n < T ? log_n : T;
   p.push_back({0, c, 0});
   int rem = log_n - c;
   if (rem > 0) {
-    const int max_r = NTT_TILE_LOG - 4;  // keep >= 16 consecutive elements (128 B) per segment
+    const int max_r = T - 4;  // keep >= 16 consecutive elements (128 B) per segment
     // balanced strided passes.  (Unbalanced 8 + remainder needs fewer radix-16 rounds but measured slower at
     // 2^22 / 2^24 -- 106.5 vs 102.8 ms and 517 vs 420 ms of LDE per proof: its last pass strides by 8 MB.)
     int np = (rem + max_r - 1) / max_r;
     int s = c;
     for (int i = 0; i < np; i++) {
       int r = rem / np + (i < rem % np ? 1 : 0);
-      p.push_back({s, r, NTT_TILE_LOG - r});
+      p.push_back({s, r, T - r});
       s += r;
     }
   }
@@ -346,19 +354,19 @@ __global__ void k_fill_round_plane(u64* out, int s, int G, int log_n, PowTable t
 }
 struct NttPlanes {
   const u64* base;
-  std::vector<size_t> off;  // [pass * 3 + round]
+  std::vector<size_t> off;  // [pass * 4 + round]
 };
 static NttPlanes ntt_planes(mh_ctx* c, int log_n, bool inverse, const std::vector<PassPlan>& plan) {
   const std::string key = "nttp:" + std::to_string(log_n) + (inverse ? ":i" : ":f");
   auto it = c->tables.find(key);
   if (it == c->tables.end()) {
-    std::vector<size_t> off(plan.size() * 3, 0);
+    std::vector<size_t> off(plan.size() * 4, 0);
     size_t total = 1;
     for (size_t i = 0; i < plan.size(); i++) {
       auto rounds = pass_rounds(plan[i].r_bits);
       for (size_t k = 0; k < rounds.size(); k++) {
         const int s = plan[i].s_lo + rounds[k].first, G = rounds[k].second;
-        off[i * 3 + k] = total;
+        off[i * 4 + k] = total;
         if (s > 0) total += (size_t)((1 << G) - 1) << s;
       }
     }
@@ -376,7 +384,7 @@ static NttPlanes ntt_planes(mh_ctx* c, int log_n, bool inverse, const std::vecto
         const int s = plan[i].s_lo + rounds[k].first, G = rounds[k].second;
         if (s == 0) continue;
         const size_t cnt = (size_t)((1 << G) - 1) << s;
-        hipLaunchKernelGGL(k_fill_round_plane, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, b.u() + off[i * 3 + k], s, G,
+        hipLaunchKernelGGL(k_fill_round_plane, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, b.u() + off[i * 4 + k], s, G,
                            log_n, t);
       }
     }
@@ -389,8 +397,21 @@ static NttPlanes ntt_planes(mh_ctx* c, int log_n, bool inverse, const std::vecto
 static void launch_pass(mh_ctx* c, NttPassArgs a, size_t n_cols, size_t n_z) {
   size_t tiles = (size_t)1 << (a.log_n - a.r_bits - a.cb);
   dim3 grid((unsigned)tiles, (unsigned)n_cols, (unsigned)n_z);
-  if (a.dif) hipLaunchKernelGGL(k_ntt16_pass<true>, grid, dim3(NTT_THREADS), 0, c->stream, a);
-  else hipLaunchKernelGGL(k_ntt16_pass<false>, grid, dim3(NTT_THREADS), 0, c->stream, a);
+  const int T = ntt_tile_log(a.log_n);
+  const size_t lds = ntt_lds_bytes(T);
+  if (T == NTT_TILE_LOG) {
+    if (a.dif) hipLaunchKernelGGL((k_ntt16_pass<true, NTT_THREADS>), grid, dim3(NTT_THREADS), lds, c->stream, a);
+    else hipLaunchKernelGGL((k_ntt16_pass<false, NTT_THREADS>), grid, dim3(NTT_THREADS), lds, c->stream, a);
+  } else {
+    static bool once = false;  // > 64 KB of dynamic LDS must be requested per kernel
+    if (!once) {
+      HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt16_pass<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt16_pass<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      once = true;
+    }
+    if (a.dif) hipLaunchKernelGGL((k_ntt16_pass<true, 1024>), grid, dim3(1024), lds, c->stream, a);
+    else hipLaunchKernelGGL((k_ntt16_pass<false, 1024>), grid, dim3(1024), lds, c->stream, a);
+  }
 }
 
 // In-place inverse DFT (unscaled: result = N * coefficients) of `n_cols` contiguous columns of
@@ -406,7 +427,7 @@ void ntt_inverse_dif_inplace(mh_ctx* c, u64* cols, size_t n_cols, int log_n) {
     a.dst_z_stride = 0;
     a.log_n = log_n; a.s_lo = plan[i].s_lo; a.r_bits = plan[i].r_bits; a.cb = plan[i].cb;
     a.dif = 1; a.scale_lo = nullptr; a.scale_hi = nullptr;
-    for (int k = 0; k < 3; k++) a.tw_round[k] = tw.base + tw.off[i * 3 + k];
+    for (int k = 0; k < 4; k++) a.tw_round[k] = tw.base + tw.off[i * 4 + k];
     a.canon_out = 0;  // the coefficients only feed the forward passes' multiplications
     launch_pass(c, a, n_cols, 1);
   }
@@ -461,7 +482,7 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
     }
     a.log_n = log_n; a.s_lo = plan[i].s_lo; a.r_bits = plan[i].r_bits; a.cb = plan[i].cb;
     a.dif = 0;
-    for (int k = 0; k < 3; k++) a.tw_round[k] = tw.base + tw.off[i * 3 + k];
+    for (int k = 0; k < 4; k++) a.tw_round[k] = tw.base + tw.off[i * 4 + k];
     a.canon_out = i + 1 == plan.size();
     if (i == 0) {
       launch_pass(c, a, n_cols, nz);
