@@ -13,7 +13,7 @@ import numpy as np
 P = 0xFFFFFFFF00000001
 MAGIC = 0x4d48444147303031  # "MHDAG001"
 (OP_CONST, OP_MAIN, OP_AUX, OP_PUBLIC, OP_PERIODIC, OP_IS_FIRST, OP_IS_LAST, OP_IS_TRANSITION, OP_RANDOMNESS,
- OP_AUX_VALUE, OP_ADD, OP_SUB, OP_MUL, OP_NEG) = range(14)
+ OP_AUX_VALUE, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_PREPROCESSED) = range(15)
 
 
 class Expr:
@@ -50,8 +50,9 @@ class Expr:
 
 
 class AirBuilder:
-    def __init__(self, main_width, aux_width=0, num_randomness=0, num_aux_values=0, num_public=0, periodic=()):
-        self.main_width, self.aux_width = main_width, aux_width
+    def __init__(self, main_width, aux_width=0, num_randomness=0, num_aux_values=0, num_public=0, periodic=(),
+                 preprocessed_width=0):
+        self.main_width, self.aux_width, self.preprocessed_width = main_width, aux_width, preprocessed_width
         self.num_randomness, self.num_aux_values, self.num_public = num_randomness, num_aux_values, num_public
         self.periodic = [[int(v) % P for v in col] for col in periodic]
         for col in self.periodic:
@@ -78,6 +79,11 @@ class AirBuilder:
     def main(self, col, row=0):
         assert 0 <= col < self.main_width and row in (0, 1)
         return self._node(OP_MAIN, col, row, 0, 1, False)
+
+    def preprocessed(self, col, row=0):
+        """Fixed circuit column committed at setup (BaseAir::preprocessed_trace, crates/lifted-stark/src/preprocessed.rs)."""
+        assert 0 <= col < self.preprocessed_width and row in (0, 1)
+        return self._node(OP_PREPROCESSED, col, row, 0, 1, False)
 
     def aux(self, col, row=0):
         assert 0 <= col < self.aux_width and row in (0, 1)
@@ -126,7 +132,7 @@ class AirBuilder:
 
     def blob(self):
         w = [MAGIC, self.main_width, self.aux_width, self.num_randomness, self.num_aux_values, self.num_public,
-             len(self.periodic), self.log_quotient_degree(), len(self.nodes), len(self.constraints), 0, 0]
+             len(self.periodic), self.log_quotient_degree(), len(self.nodes), len(self.constraints), self.preprocessed_width, 0]
         for col in self.periodic:
             w.append(len(col))
             w.extend(col)
@@ -142,8 +148,12 @@ class Air:
     """An AIR = its blob + the shape needed by callers + an optional aux-trace builder
     (LiftedAir::build_aux_trace): f(main, randomness[list of (c0,c1)]) -> (aux[n, 2*aux_width] u64, aux_values flat)."""
 
-    def __init__(self, builder, build_aux=None, name="air"):
+    def __init__(self, builder, build_aux=None, name="air", preprocessed=None):
         self.name = name
+        # the AIR's preprocessed matrix [n, preprocessed_width] (None if it declares no preprocessed columns)
+        self.preprocessed = None if preprocessed is None else np.ascontiguousarray(preprocessed, dtype=np.uint64)
+        self.preprocessed_width = builder.preprocessed_width
+        assert (self.preprocessed is None) == (builder.preprocessed_width == 0)
         self.main_width, self.aux_width = builder.main_width, builder.aux_width
         self.num_randomness, self.num_aux_values = builder.num_randomness, builder.num_aux_values
         self.num_public = builder.num_public

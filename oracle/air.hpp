@@ -17,7 +17,8 @@ namespace oracle {
 
 enum DagOp : uint32_t {
   OP_CONST = 0, OP_MAIN = 1, OP_AUX = 2, OP_PUBLIC = 3, OP_PERIODIC = 4, OP_IS_FIRST = 5, OP_IS_LAST = 6,
-  OP_IS_TRANSITION = 7, OP_RANDOMNESS = 8, OP_AUX_VALUE = 9, OP_ADD = 10, OP_SUB = 11, OP_MUL = 12, OP_NEG = 13
+  OP_IS_TRANSITION = 7, OP_RANDOMNESS = 8, OP_AUX_VALUE = 9, OP_ADD = 10, OP_SUB = 11, OP_MUL = 12, OP_NEG = 13,
+  OP_PREPROCESSED = 14  // fixed circuit columns committed at setup (crates/lifted-stark/src/preprocessed.rs)
 };
 static const uint64_t DAG_MAGIC = 0x4d48444147303031ULL;  // "MHDAG001"
 
@@ -27,7 +28,7 @@ struct DagNode {
 };
 
 struct Air {
-  size_t main_width = 0, aux_width = 0, num_randomness = 0, num_aux_values = 0, num_public = 0;
+  size_t main_width = 0, aux_width = 0, num_randomness = 0, num_aux_values = 0, num_public = 0, preprocessed_width = 0;
   int log_quotient_degree = 0;
   std::vector<std::vector<uint64_t>> periodic;  // each a power-of-two-length column
   std::vector<DagNode> nodes;
@@ -50,6 +51,7 @@ struct Air {
     size_t n_periodic = w[6];
     a.log_quotient_degree = (int)w[7];
     size_t n_nodes = w[8], n_cons = w[9];
+    a.preprocessed_width = w[10];
     size_t pos = 12;
     for (size_t i = 0; i < n_periodic; i++) {
       need(pos < n);
@@ -62,7 +64,8 @@ struct Air {
     for (size_t i = 0; i < n_nodes; i++) {
       uint64_t x = w[pos + 2 * i];
       DagNode nd{(uint32_t)(x & 0xFF), (uint32_t)((x >> 8) & 0xFFFFFFF), (uint32_t)(x >> 36), w[pos + 2 * i + 1]};
-      if (nd.op >= OP_ADD) need(nd.a < i && (nd.op == OP_NEG || nd.b < i));
+      if (nd.op >= OP_ADD && nd.op <= OP_NEG) need(nd.a < i && (nd.op == OP_NEG || nd.b < i));
+      if (nd.op == OP_PREPROCESSED) need(nd.a < a.preprocessed_width && nd.b < 2);
       a.nodes.push_back(nd);
     }
     pos += 2 * n_nodes;
@@ -79,6 +82,8 @@ struct Air {
 struct EvalEnv {
   const uint64_t* main_cur;
   const uint64_t* main_next;
+  const uint64_t* prep_cur = nullptr;  // preprocessed window (base values; prover side)
+  const uint64_t* prep_next = nullptr;
   const E2* aux_cur;
   const E2* aux_next;
   const uint64_t* publics;
@@ -92,6 +97,8 @@ struct EvalEnv {
 struct EvalEnvExt {
   const E2* main_cur;
   const E2* main_next;
+  const E2* prep_cur = nullptr;
+  const E2* prep_next = nullptr;
 };
 
 static inline E2 dag_fold(const Air& air, const EvalEnv& e, const EvalEnvExt* ext_main, E2 alpha, std::vector<E2>& scratch) {
@@ -106,6 +113,10 @@ static inline E2 dag_fold(const Air& air, const EvalEnv& e, const EvalEnvExt* ex
         else v = e2((n.b ? e.main_next : e.main_cur)[n.a]);
         break;
       case OP_AUX: v = (n.b ? e.aux_next : e.aux_cur)[n.a]; break;
+      case OP_PREPROCESSED:
+        if (ext_main) v = (n.b ? ext_main->prep_next : ext_main->prep_cur)[n.a];
+        else v = e2((n.b ? e.prep_next : e.prep_cur)[n.a]);
+        break;
       case OP_PUBLIC: v = e2(e.publics[n.a]); break;
       case OP_PERIODIC: v = e.periodic[n.a]; break;
       case OP_IS_FIRST: v = e.is_first; break;

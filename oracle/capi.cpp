@@ -121,7 +121,8 @@ int orc_prove(const int params[7], int n_airs, const uint64_t* const* dags, cons
               const uint64_t* const* traces, const int* log_heights, const uint64_t* publics, size_t n_publics,
               const uint64_t init_state[12], const uint64_t* pre_observe, size_t n_pre, AuxBuilder cb, void* user,
               uint64_t* fields_out, size_t fields_cap, size_t* n_fields, uint64_t* commits_out, size_t commits_cap,
-              size_t* n_commits, uint64_t digest[4], char* err, size_t errcap) {
+              size_t* n_commits, uint64_t digest[4], char* err, size_t errcap,
+              const uint64_t* const* preprocessed /* per instance (NULL entries allowed), or NULL */) {
   try {
     ProverInput in;
     in.params = make_params(params);
@@ -129,6 +130,7 @@ int orc_prove(const int params[7], int n_airs, const uint64_t* const* dags, cons
       in.airs.push_back(Air::parse(dags[i], dag_lens[i]));
       in.traces.push_back(traces[i]);
       in.log_heights.push_back(log_heights[i]);
+      in.preprocessed.push_back(preprocessed ? preprocessed[i] : nullptr);
     }
     in.publics.assign(publics, publics + n_publics);
     in.challenger = make_challenger(init_state, pre_observe, n_pre);
@@ -154,7 +156,7 @@ int orc_prove(const int params[7], int n_airs, const uint64_t* const* dags, cons
 int orc_verify(const int params[7], int n_airs, const uint64_t* const* dags, const size_t* dag_lens, const int* log_heights,
                const uint64_t* publics, size_t n_publics, const uint64_t init_state[12], const uint64_t* pre_observe,
                size_t n_pre, const uint64_t* fields, size_t n_fields, const uint64_t* commits, size_t n_commits,
-               uint64_t digest[4], char* err, size_t errcap) {
+               uint64_t digest[4], char* err, size_t errcap, const uint64_t* preprocessed_root /* [4] or NULL */) {
   try {
     VerifierInput in;
     in.params = make_params(params);
@@ -165,6 +167,10 @@ int orc_verify(const int params[7], int n_airs, const uint64_t* const* dags, con
     }
     in.publics.assign(publics, publics + n_publics);
     in.challenger = make_challenger(init_state, pre_observe, n_pre);
+    if (preprocessed_root) {
+      in.has_preprocessed = true;
+      memcpy(in.preprocessed_root.data(), preprocessed_root, 32);
+    }
     p.fields.assign(fields, fields + n_fields);
     p.commitments.resize(n_commits);
     memcpy(p.commitments.data(), commits, n_commits * 32);

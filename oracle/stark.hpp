@@ -24,6 +24,7 @@
 #include "ntt.hpp"
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <numeric>
 #include <chrono>
 #include <cstdio>
@@ -130,6 +131,10 @@ struct ProverInput {
   PcsParams params;
   std::vector<Air> airs;                 // instance order
   std::vector<const uint64_t*> traces;   // row-major natural order
+  // per instance: the AIR's preprocessed matrix (same height as its trace, row-major) or nullptr.  The tree over
+  // their LDEs is the setup-time commitment (preprocessed.rs:74-135); its root must already be in `challenger`
+  // (observed after the protocol parameters, before the statement: prover/mod.rs:282-286).
+  std::vector<const uint64_t*> preprocessed;
   std::vector<int> log_heights;
   std::vector<uint64_t> publics;
   Challenger challenger;                 // already bound to protocol params + statement
@@ -185,6 +190,28 @@ static inline Proof prove(ProverInput& in) {
     }
     return lmcs_build(ms);
   };
+  // preprocessed tree: the AIRs that declare preprocessed columns, in proof order (preprocessed.rs:100-133)
+  std::vector<int> prep_of(n_airs, -1);  // proof position j -> index in the preprocessed tree
+  std::vector<std::vector<uint64_t>> prep_lde;
+  std::vector<size_t> prep_w;
+  std::unique_ptr<LmcsTree> prep_tree;
+  int prep_depth = 0;
+  {
+    std::vector<Mat> ms;
+    for (size_t j = 0; j < n_airs; j++) {
+      const Air& a = in.airs[order[j]];
+      if (!a.preprocessed_width) continue;
+      if (in.preprocessed.size() != n_airs || !in.preprocessed[order[j]]) throw std::runtime_error("AIR declares preprocessed columns but none were supplied");
+      int lh = in.log_heights[order[j]];
+      size_t n = (size_t)1 << lh;
+      prep_of[j] = (int)prep_lde.size();
+      prep_lde.push_back(coset_lde_matrix_bitrev(in.preprocessed[order[j]], n, a.preprocessed_width, lb, canonical_lde_shift(lh + lb)));
+      prep_w.push_back(a.preprocessed_width);
+      prep_depth = lh + lb;
+    }
+    for (size_t k = 0; k < prep_lde.size(); k++) ms.push_back(Mat{prep_lde[k].data(), prep_lde[k].size() / prep_w[k], prep_w[k]});
+    if (!ms.empty()) prep_tree.reset(new LmcsTree(lmcs_build(ms)));
+  }
   std::vector<const uint64_t*> main_mats;
   std::vector<size_t> main_w;
   for (size_t j = 0; j < n_airs; j++) {
@@ -278,6 +305,8 @@ static inline Proof prove(ProverInput& in) {
     }
     const uint64_t* M = main_lde[j].data();
     const uint64_t* A = aux_lde[j].data();
+    const uint64_t* PP = prep_of[j] >= 0 ? prep_lde[prep_of[j]].data() : nullptr;
+    const size_t pw = air.preprocessed_width;
     const size_t mw = air.main_width, aw2 = 2 * air.aux_width;
     std::vector<E2> aux_values(air.num_aux_values);
     for (size_t k = 0; k < air.num_aux_values; k++) aux_values[k] = E2{aux_vals[order[j]][2 * k], aux_vals[order[j]][2 * k + 1]};
@@ -297,6 +326,7 @@ static inline Proof prove(ProverInput& in) {
         for (size_t c = 0; c < per.size(); c++) per[c] = e2(ptab[c][i % (Pm * Dj)]);
         EvalEnv e;
         e.main_cur = M + r_cur * mw; e.main_next = M + r_nxt * mw;
+        if (PP) { e.prep_cur = PP + r_cur * pw; e.prep_next = PP + r_nxt * pw; }
         e.aux_cur = ac.data(); e.aux_next = an.data();
         e.publics = in.publics.data(); e.periodic = per.data();
         uint64_t z_h = zh[i % Dj];
@@ -373,6 +403,7 @@ static inline Proof prove(ProverInput& in) {
     size_t h, w;
   };
   std::vector<OpenMat> mats;
+  for (size_t k = 0; k < prep_lde.size(); k++) mats.push_back({prep_lde[k].data(), prep_lde[k].size() / prep_w[k], prep_w[k]});  // group order: [preprocessed?, main, aux, quotient]
   for (size_t j = 0; j < n_airs; j++) mats.push_back({main_lde[j].data(), main_lde[j].size() / main_w[j], main_w[j]});
   for (size_t j = 0; j < n_airs; j++) mats.push_back({aux_lde[j].data(), aux_lde[j].size() / aux_w[j], aux_w[j]});
   mats.push_back({quot_lde.data(), NB, 2 * D});
@@ -496,6 +527,18 @@ static inline Proof prove(ProverInput& in) {
   for (int i = 0; i < pp.num_queries; i++) idx.push_back(ch.ch.sample_bits(L));
   std::sort(idx.begin(), idx.end());
   idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
+  if (prep_tree) {  // a shorter tree is virtually lifted: indices fold to its depth by their low bits (tree_indices.rs:72-84)
+    std::vector<size_t> pidx(idx);
+    const size_t mask = ((size_t)1 << prep_depth) - 1;
+    for (auto& i : pidx) i &= mask;
+    std::sort(pidx.begin(), pidx.end());
+    pidx.erase(std::unique(pidx.begin(), pidx.end()), pidx.end());
+    std::vector<uint64_t> f;
+    std::vector<Digest> c;
+    lmcs_prove_batch(*prep_tree, pidx, 8, f, c);
+    ch.hint_fields(f);
+    ch.hint_commitments(c);
+  }
   for (const LmcsTree* t : {&main_tree, &aux_tree, &quot_tree}) {
     std::vector<uint64_t> f;
     std::vector<Digest> c;
@@ -581,7 +624,9 @@ struct VerifierInput {
   PcsParams params;
   std::vector<Air> airs;
   std::vector<uint64_t> publics;
-  Challenger challenger;
+  Challenger challenger;  // preprocessed commitment (if any) already observed, like the statement
+  bool has_preprocessed = false;
+  Digest preprocessed_root{};
 };
 
 static inline Digest verify(const VerifierInput& in, const Proof& proof) {
@@ -634,12 +679,31 @@ static inline Digest verify(const VerifierInput& in, const Proof& proof) {
   }
   E2 zs[2] = {z, emulf(z, two_adic_generator(log_n_max))};
 
-  // commitment groups: aligned widths (pcs/verifier.rs verify_aligned)
-  std::vector<std::vector<size_t>> groups(3);
-  for (size_t j = 0; j < n_airs; j++) groups[0].push_back(align8(in.airs[order[j]].main_width));
-  for (size_t j = 0; j < n_airs; j++) groups[1].push_back(align8(2 * in.airs[order[j]].aux_width));
-  groups[2].push_back(align8(2 * D));
-  Digest roots[3] = {main_root, aux_root, quot_root};
+  // commitment groups: aligned widths (pcs/verifier.rs verify_aligned); [preprocessed?, main, aux, quotient] (proof.rs:326-375)
+  std::vector<std::vector<size_t>> groups;
+  std::vector<Digest> roots;
+  std::vector<int> depths;
+  bool any_prep = false;
+  for (auto& a : in.airs) any_prep |= a.preprocessed_width > 0;
+  if (any_prep != in.has_preprocessed) throw VerifyError("preprocessed commitment presence mismatch");
+  if (any_prep) {
+    groups.emplace_back();
+    int dp = 0;
+    for (size_t j = 0; j < n_airs; j++)
+      if (in.airs[order[j]].preprocessed_width) {
+        groups.back().push_back(align8(in.airs[order[j]].preprocessed_width));
+        dp = std::max(dp, lhs[order[j]] + lb);
+      }
+    roots.push_back(in.preprocessed_root);
+    depths.push_back(dp);
+  }
+  const size_t g_main = groups.size();
+  groups.emplace_back(); groups.emplace_back(); groups.emplace_back();
+  for (size_t j = 0; j < n_airs; j++) groups[g_main].push_back(align8(in.airs[order[j]].main_width));
+  for (size_t j = 0; j < n_airs; j++) groups[g_main + 1].push_back(align8(2 * in.airs[order[j]].aux_width));
+  groups[g_main + 2].push_back(align8(2 * D));
+  roots.push_back(main_root); roots.push_back(aux_root); roots.push_back(quot_root);
+  depths.push_back(L); depths.push_back(L); depths.push_back(L);
   size_t W = 0;
   for (auto& gset : groups)
     for (size_t w : gset) W += w;
@@ -679,10 +743,15 @@ static inline Digest verify(const VerifierInput& in, const Proof& proof) {
   // DEEP open_batch
   std::map<size_t, E2> reduced;
   for (size_t i : idx) reduced[i] = e2(0);
-  for (int gi = 0; gi < 3; gi++) {
-    auto rows = lmcs_verify_batch(ch, roots[gi], groups[gi], idx, L);
+  for (size_t gi = 0; gi < groups.size(); gi++) {
+    std::vector<size_t> gidx(idx);
+    const size_t mask = ((size_t)1 << depths[gi]) - 1;
+    for (auto& i : gidx) i &= mask;
+    std::sort(gidx.begin(), gidx.end());
+    gidx.erase(std::unique(gidx.begin(), gidx.end()), gidx.end());
+    auto rows = lmcs_verify_batch(ch, roots[gi], groups[gi], gidx, depths[gi]);
     for (auto& kv : reduced)
-      for (uint64_t v : rows[kv.first]) kv.second = eadd(emul(kv.second, alpha_d), e2(v));
+      for (uint64_t v : rows[kv.first & mask]) kv.second = eadd(emul(kv.second, alpha_d), e2(v));
   }
   std::map<size_t, E2> fevals;
   const uint64_t wK = two_adic_generator(L);
@@ -735,7 +804,9 @@ static inline Digest verify(const VerifierInput& in, const Proof& proof) {
 
   // constraint identity (verifier/mod.rs step 9-12)
   E2 accumulated = e2(0);
-  size_t off_main = 0, off_aux = 0;
+  size_t off_prep = 0, off_main = 0, off_aux = 0;
+  for (size_t j = 0; j < n_airs; j++) off_main += in.airs[order[j]].preprocessed_width ? align8(in.airs[order[j]].preprocessed_width) : 0;
+  off_aux = off_main;
   for (size_t j = 0; j < n_airs; j++) off_aux += align8(in.airs[order[j]].main_width);
   size_t off_quot = off_aux;
   for (size_t j = 0; j < n_airs; j++) off_quot += align8(2 * in.airs[order[j]].aux_width);
@@ -744,6 +815,9 @@ static inline Digest verify(const VerifierInput& in, const Proof& proof) {
     const Air& air = in.airs[order[j]];
     int lh = lhs[order[j]];
     std::vector<E2> mc(air.main_width), mn(air.main_width), ac(air.aux_width), an(air.aux_width), per;
+    std::vector<E2> pc(air.preprocessed_width), pn(air.preprocessed_width);
+    for (size_t c = 0; c < air.preprocessed_width; c++) { pc[c] = evals[0][off_prep + c]; pn[c] = evals[1][off_prep + c]; }
+    if (air.preprocessed_width) off_prep += align8(air.preprocessed_width);
     for (size_t c = 0; c < air.main_width; c++) { mc[c] = evals[0][off_main + c]; mn[c] = evals[1][off_main + c]; }
     for (size_t c = 0; c < air.aux_width; c++) {
       // EF value of an EF column from its two base-column openings: v = f0(z) + x*f1(z)
@@ -767,7 +841,7 @@ static inline Digest verify(const VerifierInput& in, const Proof& proof) {
     e.publics = in.publics.data(); e.periodic = per.data();
     e.is_first = s.is_first; e.is_last = s.is_last; e.is_transition = s.is_transition;
     e.randomness = randomness.data(); e.aux_values = aux_values[j].data();
-    EvalEnvExt em{mc.data(), mn.data()};
+    EvalEnvExt em{mc.data(), mn.data(), pc.data(), pn.data()};
     E2 folded = dag_fold(air, e, &em, alpha, scratch);
     accumulated = eadd(emul(accumulated, beta), folded);
   }

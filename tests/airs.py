@@ -207,3 +207,34 @@ def logup_trace(log_n, seed=3, valid=True):
     if not valid:
         t[n // 2, 0] = (int(t[n // 2, 0]) + 1) % P  # a value that is not in the table: the buses no longer balance
     return t
+
+
+# ------------------------------------------------------------------------------------------------
+def prep_air(log_n, seed=13):
+    """An AIR with PREPROCESSED columns (fixed circuit data committed at setup, crates/lifted-stark/src/preprocessed.rs):
+    S (a 0/1 selector) and T (a table).  Main columns a, c, d:  a' = S ? a + T : a * c  (degree 3 with the selector),
+    d = T_next (reads the preprocessed column's next row).  One all-zero EF aux column (the protocol wants one)."""
+    n = 1 << log_n
+    rng = np.random.default_rng(seed)
+    S = rng.integers(0, 2, n, dtype=np.uint64)
+    T = rng.integers(0, P, n, dtype=np.uint64)
+    b = dag.AirBuilder(3, aux_width=1, num_randomness=1, num_aux_values=0, preprocessed_width=2)
+    a0, a1, c0, d0 = b.main(0), b.main(0, 1), b.main(1), b.main(2)
+    s, t, t_next = b.preprocessed(0), b.preprocessed(1), b.preprocessed(1, 1)
+    b.assert_zero(b.is_transition() * (s * (a1 - a0 - t) + (b.const(1) - s) * (a1 - a0 * c0)))
+    b.assert_zero(d0 - t_next)
+    b.assert_zero_ext(b.aux(0) * b.randomness(0))  # aux column is zero
+    air = dag.Air(b, build_aux=None, name=f"prep:{log_n}", preprocessed=np.stack([S, T], axis=1))
+
+    def trace(seed2=17):
+        r2 = np.random.default_rng(seed2)
+        m = np.zeros((n, 3), dtype=np.uint64)
+        m[:, 1] = r2.integers(0, P, n, dtype=np.uint64)
+        a = 5
+        for r in range(n):
+            m[r, 0] = a
+            m[r, 2] = T[(r + 1) % n]
+            a = (a + int(T[r])) % P if S[r] else (a * int(m[r, 1])) % P
+        return m
+
+    return air, trace

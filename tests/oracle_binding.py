@@ -151,11 +151,14 @@ def params_array(p):
     return (C.c_int * 7)(*[int(p[k]) for k in PARAM_ORDER])
 
 
-def protocol_pre_observe(p, publics, aux_inputs=()):
-    """observe_protocol_params (air/src/config.rs:188-198) followed by the default statement framing
+def protocol_pre_observe(p, publics, aux_inputs=(), preprocessed_root=None):
+    """observe_protocol_params (air/src/config.rs:188-198), then the preprocessed commitment when there is one
+    (crates/lifted-stark/src/prover/mod.rs:282-286), then the default statement framing
     (crates/lifted-air/src/air.rs:307-324)."""
     pre = [p["num_queries"], p["query_pow_bits"], p["deep_pow_bits"], p["folding_pow_bits"], p["log_blowup"],
            p["log_final_degree"], 1 << p["log_folding_arity"], 0]
+    if preprocessed_root is not None:
+        pre += [int(x) for x in preprocessed_root]
     pre += [len(publics)] + [int(x) for x in publics] + [0, len(aux_inputs)] + [int(x) for x in aux_inputs]
     return pre
 
@@ -192,6 +195,16 @@ def _air_arrays(airs):
     return blobs, (u64p * n)(*[ptr(b) for b in blobs]), (C.c_size_t * n)(*[b.size for b in blobs])
 
 
+def preprocessed_commitment(airs, log_heights, params=PROD_PARAMS):
+    """Setup (crates/lifted-stark/src/preprocessed.rs:74-135): the LMCS root over the LDEs of the AIRs' preprocessed
+    matrices, in proof order (ascending height, ties by instance index).  None when no AIR declares any."""
+    order = sorted(range(len(airs)), key=lambda i: (log_heights[i], i))
+    mats = [airs[i].preprocessed for i in order if getattr(airs[i], "preprocessed", None) is not None]
+    if not mats:
+        return None
+    return commit_traces(mats, params["log_blowup"])["root"]
+
+
 def prove(airs, traces, publics, params=PROD_PARAMS, init_state=None, pre_observe=None):
     """-> dict(fields, commitments[k][4], digest)."""
     traces = [arr(t) for t in traces]
@@ -201,7 +214,10 @@ def prove(airs, traces, publics, params=PROD_PARAMS, init_state=None, pre_observ
     lhs = (C.c_int * n)(*[int(t.shape[0]).bit_length() - 1 for t in traces])
     pub = arr(list(publics) or [0])
     st = arr(init_state if init_state is not None else challenger_state())
-    pre = arr(pre_observe if pre_observe is not None else protocol_pre_observe(params, publics))
+    preps = [arr(a.preprocessed) if getattr(a, "preprocessed", None) is not None else None for a in airs]
+    prep_root = preprocessed_commitment(airs, [int(x) for x in lhs], params)
+    pre = arr(pre_observe if pre_observe is not None else protocol_pre_observe(params, publics, preprocessed_root=prep_root))
+    prep_ptrs = (u64p * n)(*[ptr(m) if m is not None else None for m in preps]) if prep_root is not None else None
     cb = make_aux_callback(airs, traces)
     cap_f, cap_c = 1 << 22, 1 << 18
     fields = np.zeros(cap_f, dtype=np.uint64)
@@ -213,11 +229,11 @@ def prove(airs, traces, publics, params=PROD_PARAMS, init_state=None, pre_observ
     L.orc_prove.restype = C.c_int
     rc = L.orc_prove(params_array(params), C.c_int(n), dag_ptrs, dag_lens, tr_ptrs, lhs, ptr(pub), C.c_size_t(len(publics)),
                      ptr(st), ptr(pre), C.c_size_t(pre.size), cb, None, ptr(fields), C.c_size_t(cap_f), C.byref(nf),
-                     ptr(commits), C.c_size_t(cap_c), C.byref(nc), ptr(digest), err, C.c_size_t(512))
+                     ptr(commits), C.c_size_t(cap_c), C.byref(nc), ptr(digest), err, C.c_size_t(512), prep_ptrs)
     if rc != 0:
         raise RuntimeError("oracle prove failed: " + err.value.decode())
     return {"fields": fields[:nf.value].copy(), "commitments": commits[:nc.value].copy(), "digest": digest,
-            "log_heights": [int(x) for x in lhs]}
+            "log_heights": [int(x) for x in lhs], "preprocessed_root": prep_root}
 
 
 def verify(airs, log_heights, publics, proof, params=PROD_PARAMS, init_state=None, pre_observe=None):
@@ -227,7 +243,8 @@ def verify(airs, log_heights, publics, proof, params=PROD_PARAMS, init_state=Non
     lhs = (C.c_int * n)(*[int(x) for x in log_heights])
     pub = arr(list(publics) or [0])
     st = arr(init_state if init_state is not None else challenger_state())
-    pre = arr(pre_observe if pre_observe is not None else protocol_pre_observe(params, publics))
+    prep_root = preprocessed_commitment(airs, [int(x) for x in log_heights], params)  # setup data, trusted like the AIRs
+    pre = arr(pre_observe if pre_observe is not None else protocol_pre_observe(params, publics, preprocessed_root=prep_root))
     f = arr(proof["fields"])
     c = arr(proof["commitments"]).reshape(-1)
     digest = np.zeros(4, dtype=np.uint64)
@@ -236,7 +253,7 @@ def verify(airs, log_heights, publics, proof, params=PROD_PARAMS, init_state=Non
     L.orc_verify.restype = C.c_int
     rc = L.orc_verify(params_array(params), C.c_int(n), dag_ptrs, dag_lens, lhs, ptr(pub), C.c_size_t(len(publics)), ptr(st),
                       ptr(pre), C.c_size_t(pre.size), ptr(f), C.c_size_t(f.size), ptr(c), C.c_size_t(c.size // 4),
-                      ptr(digest), err, C.c_size_t(512))
+                      ptr(digest), err, C.c_size_t(512), ptr(arr(prep_root)) if prep_root is not None else None)
     return (True, digest) if rc == 0 else (False, err.value.decode())
 
 
