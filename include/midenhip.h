@@ -123,11 +123,12 @@ int mh_merkle_cap_root(const uint64_t* subroots, int world, uint64_t root[4]);
  * crates/ace-codegen/src/pipeline.rs:71-123) and ships a flat u64 blob:
  *   [0] magic 0x4d48444147303031  [1] main_width  [2] aux_width (EF columns)  [3] num_randomness
  *   [4] num_aux_values  [5] num_public_values  [6] n_periodic  [7] log_quotient_degree
- *   [8] n_nodes  [9] n_constraints  [10..11] reserved
+ *   [8] n_nodes  [9] n_constraints  [10] preprocessed_width  [11] reserved
  *   n_periodic x { len, values[len] }            periodic columns (power-of-two lengths)
  *   n_nodes x { op | a << 8 | b << 36, const }   ops: 0 CONST(const) 1 MAIN(a=col,b=row offset)
  *        2 AUX(a=EF col,b=row) 3 PUBLIC(a) 4 PERIODIC(a) 5 IS_FIRST 6 IS_LAST 7 IS_TRANSITION
- *        8 RANDOMNESS(a) 9 AUX_VALUE(a) 10 ADD(a,b) 11 SUB(a,b) 12 MUL(a,b) 13 NEG(a); a, b < node id
+ *        8 RANDOMNESS(a) 9 AUX_VALUE(a) 10 ADD(a,b) 11 SUB(a,b) 12 MUL(a,b) 13 NEG(a) 14 PREPROCESSED(a=col,b=row);
+ *        a, b < node id for the four gates
  *   n_constraints x node id                      in emission order (constraint k folds with alpha^(K-1-k))
  * miden-vm_amd/dag.py is the reference exporter used by tests and bench. */
 int mh_air_load(mh_ctx* ctx, const uint64_t* blob, size_t n_words, mh_air** out);
@@ -137,6 +138,13 @@ int mh_air_log_quotient_degree(const mh_air* air);
  * under $MH_JIT_CACHE_DIR or ~/.cache/midenhip); 0 = small DAG, evaluated by the generic interpreter kernel.
  * MH_JIT=0 / MH_JIT=1 in the environment force either path (both are bit-identical). */
 int mh_air_compiled_chunks(const mh_air* air);
+/* Preprocessed columns (fixed circuit data committed once at setup: crates/lifted-stark/src/preprocessed.rs; blob word
+ * [10] = preprocessed width, DAG op 14 PREPROCESSED(a = col, b = row offset)).  Setup = mh_commit_traces of the
+ * preprocessed matrices of the AIRs that declare some, in PROOF order (ascending height, ties by instance index), with
+ * the proving blowup; its root is observed by the caller right after the protocol parameters and before the statement
+ * (prover/mod.rs:282-286), i.e. it belongs in `pre_observe`.  Each such AIR is then pointed at its matrix of that tree;
+ * proofs open the tree first (`[preprocessed?, main, aux, quotient]`).  The tree must outlive the proofs. */
+int mh_air_attach_preprocessed(mh_air* air, const mh_tree* tree, int matrix_index); /* tree = NULL detaches */
 
 /* ---- LogUp aux trace on the device -------------------------------------------------------------------------
  * Replaces `build_logup_aux_trace` (air/src/lookup/aux_builder.rs:49-96) for an AIR whose bus messages are
@@ -258,6 +266,7 @@ int mh_verify(const mh_pcs_params* params, int n_airs, const uint64_t* const* ai
               const uint8_t* log_trace_heights, const uint64_t* public_values, size_t n_public_values,
               const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe,
               const uint64_t* fields, size_t n_fields, const uint64_t* commitments, size_t n_commitments,
+              const uint64_t* preprocessed_root /* [4]: the setup commitment, NULL if no AIR has preprocessed columns */,
               uint64_t digest[4], char* err, size_t err_cap);
 void mh_proof_free(mh_proof* p);
 size_t mh_proof_num_fields(const mh_proof* p);

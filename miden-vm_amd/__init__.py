@@ -30,7 +30,7 @@ EXPORTS = [
     "mh_session_begin", "mh_session_free", "mh_session_shape", "mh_session_commit_main", "mh_session_commit_aux",
     "mh_session_commit_quotient", "mh_session_ood_point_ok", "mh_session_ood", "mh_session_deep", "mh_session_fri_commit",
     "mh_session_fri_fold", "mh_session_fri_final", "mh_session_open", "mh_grind",
-    "mh_host_alloc", "mh_host_free", "mh_verify", "mh_trace_from_device", "mh_lookup_load", "mh_lookup_free", "mh_air_attach_lookup", "mh_lookup_build_aux", "mh_trace_download",
+    "mh_host_alloc", "mh_host_free", "mh_verify", "mh_trace_from_device", "mh_lookup_load", "mh_lookup_free", "mh_air_attach_lookup", "mh_air_attach_preprocessed", "mh_lookup_build_aux", "mh_trace_download",
 ]
 
 _lib = None
@@ -326,6 +326,11 @@ class DeviceAir:
         self.compiled_chunks = int(ctx.lib.mh_air_compiled_chunks(h))
         self._lookup = None
 
+    def attach_preprocessed(self, tree, matrix_index):
+        """Point this AIR at its preprocessed LDE: matrix `matrix_index` of the setup-time LmcsTree (None detaches)."""
+        self.ctx.check(self.ctx.lib.mh_air_attach_preprocessed(self.h, tree.h if tree is not None else None, C.c_int(matrix_index)))
+        self._prep_tree = tree
+
     def attach_lookup(self, dev_lookup):
         """Build this AIR's LogUp aux trace on the device during proofs (None detaches)."""
         self.ctx.check(self.ctx.lib.mh_air_attach_lookup(self.h, dev_lookup.h if dev_lookup is not None else None))
@@ -551,8 +556,10 @@ def grind(ctx, state, pending, bits):
     return int(w.value)
 
 
-def verify(airs, log_trace_heights, public_values, params, challenger_state, pre_observe, fields, commitments):
-    """mh_verify (host only, no GPU): airs = dag.Air objects in instance order.  Returns (ok, digest or message)."""
+def verify(airs, log_trace_heights, public_values, params, challenger_state, pre_observe, fields, commitments,
+           preprocessed_root=None):
+    """mh_verify (host only, no GPU): airs = dag.Air objects in instance order; preprocessed_root = the setup commitment when
+    some AIR has preprocessed columns (it must also be in pre_observe).  Returns (ok, digest or message)."""
     lib = load_library()
     n = len(airs)
     blobs = [_arr(a.blob) for a in airs]
@@ -565,7 +572,8 @@ def verify(airs, log_trace_heights, public_values, params, challenger_state, pre
     p = params if isinstance(params, PcsParams) else PcsParams.from_dict(params)
     digest = np.zeros(4, dtype=np.uint64)
     err = C.create_string_buffer(512)
+    proot = _arr(preprocessed_root) if preprocessed_root is not None else None
     rc = lib.mh_verify(C.byref(p), C.c_int(n), bp, bl, lh, _ptr(pub), C.c_size_t(len(public_values)), _ptr(st), _ptr(pre),
-                       C.c_size_t(len(pre_observe)), _ptr(f), C.c_size_t(f.size), _ptr(c), C.c_size_t(c.size // 4), _ptr(digest), err,
-                       C.c_size_t(512))
+                       C.c_size_t(len(pre_observe)), _ptr(f), C.c_size_t(f.size), _ptr(c), C.c_size_t(c.size // 4),
+                       _ptr(proot) if proot is not None else None, _ptr(digest), err, C.c_size_t(512))
     return (True, digest) if rc == 0 else (False, err.value.decode())

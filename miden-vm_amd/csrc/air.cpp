@@ -13,6 +13,8 @@ DagIR dag_parse(const u64* w, size_t n) {
   const size_t n_periodic = w[6];
   ir.log_quotient_degree = (int)w[7];
   const size_t n_nodes = w[8], n_cons = w[9];
+  ir.preprocessed_width = w[10];
+  MH_REQUIRE(ir.preprocessed_width < 65536, "constraint DAG blob: bad preprocessed width");
   MH_REQUIRE(ir.main_width > 0 && ir.main_width < 65536 && ir.aux_width < 32768, "constraint DAG blob: bad widths");
   MH_REQUIRE(ir.log_quotient_degree >= 0 && ir.log_quotient_degree <= 8, "constraint DAG blob: bad quotient degree");
   size_t pos = 12;
@@ -33,6 +35,7 @@ DagIR dag_parse(const u64* w, size_t n) {
       case DOP_CONST: case DOP_IS_FIRST: case DOP_IS_LAST: case DOP_IS_TRANSITION: break;
       case DOP_MAIN: MH_REQUIRE(nd.a < ir.main_width && nd.b < 2, "DAG: main column out of range"); break;
       case DOP_AUX: MH_REQUIRE(nd.a < ir.aux_width && nd.b < 2, "DAG: aux column out of range"); nd.ext = true; break;
+      case DOP_PREP: MH_REQUIRE(nd.a < ir.preprocessed_width && nd.b < 2, "DAG: preprocessed column out of range"); break;
       case DOP_PUBLIC: MH_REQUIRE(nd.a < ir.num_public, "DAG: public value out of range"); break;
       case DOP_PERIODIC: MH_REQUIRE(nd.a < n_periodic, "DAG: periodic column out of range"); break;
       case DOP_RANDOMNESS: MH_REQUIRE(nd.a < ir.num_randomness, "DAG: randomness out of range"); nd.ext = true; break;
@@ -61,7 +64,7 @@ DagIR dag_parse(const u64* w, size_t n) {
   for (size_t i = 0; i < n_nodes; i++) {
     DagNode& nd = nodes[i];
     if (nd.op == DOP_CONST) nd.c = nd.c % GL_P;
-    if (nd.op >= DOP_ADD && nodes[nd.a].op == DOP_CONST && (nd.op == DOP_NEG || nodes[nd.b].op == DOP_CONST)) {
+    if (dag_is_gate(nd.op) && nodes[nd.a].op == DOP_CONST && (nd.op == DOP_NEG || nodes[nd.b].op == DOP_CONST)) {
       const u64 x = nodes[nd.a].c, y = nd.op == DOP_NEG ? 0 : nodes[nd.b].c;
       nd.c = nd.op == DOP_ADD ? gl_add(x, y) : nd.op == DOP_SUB ? gl_sub(x, y) : nd.op == DOP_MUL ? gl_mul(x, y) : gl_neg(x);
       nd.op = DOP_CONST;
@@ -72,7 +75,7 @@ DagIR dag_parse(const u64* w, size_t n) {
   for (size_t i = n_nodes; i-- > 0;) {
     if (!ir.live[i]) continue;
     const DagNode& nd = nodes[i];
-    if (nd.op >= DOP_ADD) {
+    if (dag_is_gate(nd.op)) {
       ir.live[nd.a] = 1;
       if (nd.op != DOP_NEG) ir.live[nd.b] = 1;
     }
@@ -86,6 +89,7 @@ mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
   air->ctx = ctx;
   air->main_width = ir.main_width; air->aux_width = ir.aux_width; air->num_randomness = ir.num_randomness;
   air->num_aux_values = ir.num_aux_values; air->num_public = ir.num_public;
+  air->preprocessed_width = ir.preprocessed_width;
   air->log_quotient_degree = ir.log_quotient_degree;
   air->periodic = ir.periodic;
   air->uses_first_last = ir.uses_first_last;
@@ -107,11 +111,11 @@ mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
   std::vector<Ev> seq;
   for (size_t i = 0; i < n_nodes; i++) {
     if (!live[i]) continue;
-    if (nodes[i].op >= DOP_ADD) seq.push_back({(uint32_t)i, -1});
+    if (dag_is_gate(nodes[i].op)) seq.push_back({(uint32_t)i, -1});
     for (uint32_t k : folds[i]) seq.push_back({(uint32_t)i, (int32_t)k});
   }
   // ---- liveness of interior nodes + slot assignment
-  auto interior = [&](uint32_t id) { return nodes[id].op >= DOP_ADD; };
+  auto interior = [&](uint32_t id) { return dag_is_gate(nodes[id].op); };
   std::vector<int64_t> last_use(n_nodes, -1);
   for (size_t p = 0; p < seq.size(); p++) {
     const DagNode& nd = nodes[seq[p].node];
@@ -142,7 +146,7 @@ mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
     }
     kind = (uint8_t)nd.op;
     idx = nd.a;
-    if (nd.op == DOP_MAIN || nd.op == DOP_AUX) idx = nd.a | (nd.b << 31);
+    if (nd.op == DOP_MAIN || nd.op == DOP_AUX || nd.op == DOP_PREP) idx = nd.a | (nd.b << 31);
     if (nd.op == DOP_CONST) imm = nd.c;
   };
   for (size_t p = 0; p < seq.size(); p++) {
@@ -207,7 +211,7 @@ mh_lookup* mh_lookup::load(mh_ctx* ctx, const u64* w, size_t n) {
   const size_t tail = pos + 2 * n_nodes;
   std::vector<u64> blob(w, w + tail);
   blob[0] = DAG_MAGIC;
-  blob[2] = 0; blob[4] = 0; blob[5] = 0; blob[7] = 0;
+  blob[2] = 0; blob[4] = 0; blob[5] = 0; blob[7] = 0; blob[10] = 0;
   std::unique_ptr<mh_lookup> lk(new mh_lookup());
   lk->ctx = ctx;
   size_t p = tail;

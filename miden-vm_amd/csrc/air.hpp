@@ -14,8 +14,10 @@
 enum DagOp : uint32_t {
   DOP_CONST = 0, DOP_MAIN = 1, DOP_AUX = 2, DOP_PUBLIC = 3, DOP_PERIODIC = 4, DOP_IS_FIRST = 5, DOP_IS_LAST = 6,
   DOP_IS_TRANSITION = 7, DOP_RANDOMNESS = 8, DOP_AUX_VALUE = 9, DOP_ADD = 10, DOP_SUB = 11, DOP_MUL = 12, DOP_NEG = 13,
-  DOP_FOLD = 14  // program-only: acc += alpha_pow[imm] * slot[a]
+  DOP_PREP = 14,  // preprocessed column (a = col, b = row offset): fixed circuit data committed at setup
+  DOP_FOLD = 15   // program-only: acc += alpha_pow[imm] * slot[a]
 };
+static inline bool dag_is_gate(uint32_t op) { return op >= DOP_ADD && op <= DOP_NEG; }
 static const u64 DAG_MAGIC = 0x4d48444147303031ULL;
 
 // One interpreter instruction (24 bytes).  Only interior nodes (ADD/SUB/MUL/NEG) and FOLD are
@@ -42,7 +44,7 @@ struct DagNode {
   bool ext;
 };
 struct DagIR {
-  size_t main_width = 0, aux_width = 0, num_randomness = 0, num_aux_values = 0, num_public = 0;
+  size_t main_width = 0, aux_width = 0, num_randomness = 0, num_aux_values = 0, num_public = 0, preprocessed_width = 0;
   int log_quotient_degree = 0;
   std::vector<std::vector<u64>> periodic;
   std::vector<DagNode> nodes;
@@ -59,9 +61,13 @@ struct JitProgram;  // air_jit.cpp
 void jit_program_free(JitProgram* p);
 JitProgram* jit_program_build(mh_ctx* c, const DagIR& ir);  // null: DAG too small (never null when ir.outputs)
 
+struct mh_tree;
 struct mh_air {
   mh_ctx* ctx;
-  size_t main_width = 0, aux_width = 0, num_randomness = 0, num_aux_values = 0, num_public = 0;
+  size_t main_width = 0, aux_width = 0, num_randomness = 0, num_aux_values = 0, num_public = 0, preprocessed_width = 0;
+  // the setup-time tree holding this AIR's preprocessed LDE, and its matrix index there (mh_air_attach_preprocessed)
+  const mh_tree* prep_tree = nullptr;
+  int prep_index = -1;
   int log_quotient_degree = 0;
   std::vector<std::vector<u64>> periodic;
   size_t n_constraints = 0;

@@ -52,14 +52,14 @@ FI e2 e2_mul(e2 a, e2 b) {
 }
 FI e2 e2_mulf(e2 a, u64 b) { return {gl_mul(a.c0, b), gl_mul(a.c1, b)}; }
 struct JitArgs {
-  const u64* main_lde; const u64* aux_lde; u64* spill; u64* acc; const u64* tw; const u64* coset_tab;
+  const u64* main_lde; const u64* aux_lde; const u64* prep_lde; u64* spill; u64* acc; const u64* tw; const u64* coset_tab;
   const u64* inv_first; const u64* inv_last; const u64* periodic; const u64* publics; const u64* randomness;
   const u64* aux_values; const u64* alpha_pows;
   u64 wh_inv, q0, q_count, spill_stride;
   int log_n, log_cosets, log_d, log_dl, jc_shift;
   u32 t0, periodic_rows;
 };
-static_assert(sizeof(JitArgs) == 168, "JitArgs layout");
+static_assert(sizeof(JitArgs) == 176, "JitArgs layout");
 )SRC";
 
 struct Ev {
@@ -155,7 +155,7 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
   const int mode = ir.outputs ? 1 : env_int("MH_JIT", -1);  // 0: never, 1: always, default: large DAGs only
   if (mode == 0) return nullptr;
   const std::vector<DagNode>& nodes = ir.nodes;
-  auto interior = [&](uint32_t id) { return nodes[id].op >= DOP_ADD; };
+  auto interior = [&](uint32_t id) { return dag_is_gate(nodes[id].op); };
   size_t n_gates = 0;
   for (size_t i = 0; i < nodes.size(); i++) n_gates += ir.live[i] && interior((uint32_t)i);
   if (mode != 1 && n_gates < (size_t)env_int("MH_JIT_MIN_GATES", 400)) return nullptr;
@@ -291,6 +291,15 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
             snprintf(buf, sizeof buf, "  const e2 %s = {a.aux_lde[((%uull * B + jc) << a.log_n) + %s], ", name.c_str(), 2 * nd.a, rr);
             decl << buf;
             snprintf(buf, sizeof buf, "a.aux_lde[((%uull * B + jc) << a.log_n) + %s]};\n", 2 * nd.a + 1, rr);
+            decl << buf;
+          }
+          return name;
+        case DOP_PREP:
+          snprintf(buf, sizeof buf, "p%u_%u", nd.a, nd.b);
+          name = buf;
+          if (declared.insert(name).second) {
+            snprintf(buf, sizeof buf, "  const u64 %s = a.prep_lde[((%uull * B + jc) << a.log_n) + %s];\n", name.c_str(), nd.a,
+                     nd.b ? "rn" : "r");
             decl << buf;
           }
           return name;

@@ -15,6 +15,7 @@
 struct JitArgs {
   const u64* main_lde;
   const u64* aux_lde;
+  const u64* prep_lde;  // preprocessed LDE of this AIR (same coset-major layout), or null
   u64* spill;           // [n_spill][spill_stride]
   u64* acc;             // partial alpha-folds, planes [2 * Dl][n]
   const u64* tw;        // w_n^k
@@ -32,7 +33,7 @@ struct JitArgs {
   int log_n, log_cosets, log_d, log_dl, jc_shift;
   u32 t0, periodic_rows;
 };
-static_assert(sizeof(JitArgs) == 13 * 8 + 4 * 8 + 7 * 4 + 4, "JitArgs layout is mirrored in the generated source");
+static_assert(sizeof(JitArgs) == 14 * 8 + 4 * 8 + 7 * 4 + 4, "JitArgs layout is mirrored in the generated source");
 
 // Runs every chunk over all `total` points of the quotient coset(s); a.q0 / q_count / spill are filled here.
 void jit_quotient_run(mh_ctx* c, const JitProgram* p, JitArgs a, size_t total);

@@ -100,7 +100,8 @@ struct mh_air;
 #include "gl.cuh"
 // log_d = quotient degree of the evaluation (global); the rank evaluates the 2^(log_d - logG) cosets it
 // stores (all of them on one GPU).  acc layouts are [2 * D_local][n].
-void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& main, const LdeMatrix& aux, int log_blowup, int log_d,
+void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& main, const LdeMatrix& aux, const LdeMatrix* prep,
+                              int log_blowup, int log_d,
                               const std::vector<u64>& publics, const std::vector<e2>& randomness, const std::vector<e2>& aux_values,
                               e2 alpha, const u64* acc_in, int log_n_prev, e2 beta, u64* acc_out);
 void quotient_upsample_accumulate(mh_ctx* c, const u64* q_small, int log_n, int log_blowup, int log_dj, int log_d, const u64* acc_in,

@@ -158,6 +158,8 @@ struct mh_session {
   size_t max_rand = 0;
   int stage = 0;                    // protocol position, enforced on every call
   std::unique_ptr<mh_tree> main_tree, aux_tree, quot_tree;
+  const mh_tree* prep_tree = nullptr;   // setup-time tree of the preprocessed LDEs (borrowed), or null
+  std::vector<int> prep_of;             // proof position j -> matrix index in prep_tree, -1 if the AIR has none
   std::vector<e2> randomness;
   std::vector<std::vector<e2>> aux_vals;  // instance order
   // DEEP
@@ -218,12 +220,35 @@ struct mh_session {
     B_loc = (size_t)1 << lbl;
     coset0 = (size_t)dist.rank * B_loc;
     D_loc = D >> dist.logG;  // quotient chunks owned by this rank
+    // ---- preprocessed columns (crates/lifted-stark/src/preprocessed.rs validate_preprocessed): every AIR that
+    // declares some must point at ONE setup tree whose matrices are those AIRs' LDEs in proof order ----
+    prep_of.assign(n_airs, -1);
+    int n_prep = 0;
+    for (int j = 0; j < n_airs; j++) {
+      const mh_air* a = airs[order[j]];
+      if (!a->preprocessed_width) continue;
+      MH_REQUIRE(a->prep_tree, "AIR declares preprocessed columns but no preprocessed tree is attached");
+      MH_REQUIRE(!prep_tree || prep_tree == a->prep_tree, "all AIRs must share one preprocessed tree");
+      MH_REQUIRE(!dist.on(), "sharded proofs with preprocessed columns are not supported");
+      prep_tree = a->prep_tree;
+      MH_REQUIRE(a->prep_index == n_prep, "preprocessed matrices must be committed in proof order (ascending height, ties by instance)");
+      MH_REQUIRE((size_t)a->prep_index < prep_tree->mats.size(), "preprocessed matrix index out of range");
+      const LdeMatrix& m = prep_tree->mats[a->prep_index];
+      MH_REQUIRE(m.width == a->preprocessed_width, "preprocessed matrix width differs from the AIR's declaration");
+      MH_REQUIRE(m.log_n == lhs[order[j]], "preprocessed matrix height differs from the main trace height");
+      prep_of[j] = n_prep++;
+    }
+    if (prep_tree) {
+      MH_REQUIRE(prep_tree->log_blowup == lb, "preprocessed tree was committed under a different blowup");
+      MH_REQUIRE((int)prep_tree->mats.size() == n_prep, "preprocessed tree holds matrices no AIR declares");
+    }
     rounds = fri_num_rounds(pp, L);
     stage = 1;
   }
   size_t ood_width() const {
     size_t w = 0;
-    for (int i = 0; i < n_airs; i++) w += align8(airs[i]->main_width) + align8(2 * airs[i]->aux_width);
+    for (int i = 0; i < n_airs; i++)
+      w += align8(airs[i]->main_width) + align8(2 * airs[i]->aux_width) + (airs[i]->preprocessed_width ? align8(airs[i]->preprocessed_width) : 0);
     return w + align8(2 * D);
   }
   size_t num_aux_values() const {
@@ -293,11 +318,11 @@ struct mh_session {
       std::vector<e2> rnd(randomness.begin(), randomness.begin() + a->num_randomness);
       const int logDj = a->log_quotient_degree;
       if (logDj == logD) {
-        quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], lb, logD, publics, rnd, aux_vals[order[j]], alpha,
+        quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], prep_of[j] >= 0 ? &prep_tree->mats[prep_of[j]] : nullptr, lb, logD, publics, rnd, aux_vals[order[j]], alpha,
                                  j ? acc.u() : nullptr, log_n_prev, beta, out.u());
       } else {  // native coset of n*Dj points, then upsample to n*D (prover/mod.rs:520-528); single GPU only
         DevBuf small(((size_t)2 << (logDj + ln)) * 8);
-        quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], lb, logDj, publics, rnd, aux_vals[order[j]], alpha,
+        quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], prep_of[j] >= 0 ? &prep_tree->mats[prep_of[j]] : nullptr, lb, logDj, publics, rnd, aux_vals[order[j]], alpha,
                                  nullptr, 0, beta, small.u());
         quotient_upsample_accumulate(c, small.u(), ln, lb, logDj, logD, j ? acc.u() : nullptr, log_n_prev, beta, out.u());
       }
@@ -359,6 +384,8 @@ struct mh_session {
     z = zp;
     z_next = e2_mulf(z, gl_two_adic_generator(log_N));
     mats.clear(); coef_off.clear();
+    if (prep_tree)  // group order [preprocessed?, main, aux, quotient] (prover/mod.rs:552-560)
+      for (auto& m : prep_tree->mats) mats.push_back(&m);
     for (auto& m : main_tree->mats) mats.push_back(&m);
     for (auto& m : aux_tree->mats) mats.push_back(&m);
     mats.push_back(&quot_tree->mats[0]);
@@ -505,6 +532,17 @@ struct mh_session {
     std::sort(idx.begin(), idx.end());
     idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
     for (size_t i : idx) MH_REQUIRE(i < ((size_t)1 << L), "query index out of range");
+    if (prep_tree) {  // a tree shorter than the max domain is virtually lifted: indices fold by their low bits
+      std::vector<size_t> pidx(idx);
+      const size_t mask = ((size_t)1 << prep_tree->log_height) - 1;
+      for (auto& i : pidx) i &= mask;
+      std::sort(pidx.begin(), pidx.end());
+      pidx.erase(std::unique(pidx.begin(), pidx.end()), pidx.end());
+      std::vector<u64> f, cm;
+      lmcs_open(c, prep_tree, pidx, 8, f, cm, &dist);
+      fields.insert(fields.end(), f.begin(), f.end());
+      commitments.insert(commitments.end(), cm.begin(), cm.end());
+    }
     for (const mh_tree* t : {main_tree.get(), aux_tree.get(), quot_tree.get()}) {
       std::vector<u64> f, cm;
       lmcs_open(c, t, idx, 8, f, cm, &dist);
@@ -689,6 +727,19 @@ int mh_trace_download(mh_ctx* c, const mh_trace* t, uint64_t* rowmajor_out) {
   MH_CATCH
 }
 
+int mh_air_attach_preprocessed(mh_air* a, const mh_tree* tree, int matrix_index) {
+  MH_TRY(a ? a->ctx : nullptr)
+  MH_REQUIRE(a, "null argument");
+  if (tree) {
+    MH_REQUIRE(a->preprocessed_width > 0, "this AIR declares no preprocessed columns");
+    MH_REQUIRE(matrix_index >= 0 && (size_t)matrix_index < tree->mats.size(), "preprocessed matrix index out of range");
+    MH_REQUIRE(tree->mats[matrix_index].width == a->preprocessed_width, "preprocessed matrix width differs from the AIR's declaration");
+    MH_REQUIRE(tree->mats[matrix_index].log_cosets == tree->log_blowup, "the preprocessed tree must hold every coset (single-GPU commitment)");
+  }
+  a->prep_tree = tree;
+  a->prep_index = tree ? matrix_index : -1;
+  MH_CATCH
+}
 int mh_air_compiled_chunks(const mh_air* a) { return a ? (int)jit_program_chunks(a->jit) : -1; }
 
 // ---- coset-sharded commitment (one process per GPU) -------------------------

@@ -23,6 +23,7 @@ struct QuotArgs {
   u32 n_ins, n_slots;
   const u64* main_lde;
   const u64* aux_lde;
+  const u64* prep_lde;  // preprocessed columns of this AIR (or null)
   int log_n, log_cosets, log_d, log_dl, jc_shift;  // log_d: quotient degree; log_dl: quotient cosets on this rank
   u32 t0;                // global index of this rank's first quotient coset
   const u64* tw;         // w_n^k (k < n/2)
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(256) void k_eval_quotient(QuotArgs a) {
         const size_t rr = (idx >> 31) ? r_next : r, cc = idx & 0x7FFFFFFFu;
         return e2{a.aux_lde[(((size_t)(2 * cc) * B + jc) << a.log_n) + rr], a.aux_lde[(((size_t)(2 * cc + 1) * B + jc) << a.log_n) + rr]};
       }
+      case DOP_PREP: return e2_make(a.prep_lde[(((size_t)(idx & 0x7FFFFFFFu) * B + jc) << a.log_n) + ((idx >> 31) ? r_next : r)]);
       case DOP_PUBLIC: return e2_make(a.publics[idx]);
       case DOP_PERIODIC: return e2_make(a.periodic[(size_t)idx * a.periodic_rows + ((r * D + a.t0 + t) % a.periodic_rows)]);
       case DOP_IS_FIRST: return e2_make(sel_first);
@@ -185,12 +187,18 @@ __global__ __launch_bounds__(256) void k_selector_inverses(const u64* tw, const 
 // Evaluate AIR `air` (trace height 2^log_n, LDE matrices main/aux) on its quotient coset and fold the
 // result into the accumulator.  Requires the AIR's quotient degree to equal the batch degree
 // (`log_d`); see prover.cpp for the upsample path.
-void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& main, const LdeMatrix& aux, int log_blowup, int log_d,
+void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& main, const LdeMatrix& aux, const LdeMatrix* prep,
+                              int log_blowup, int log_d,
                               const std::vector<u64>& publics, const std::vector<e2>& randomness, const std::vector<e2>& aux_values,
                               e2 alpha, const u64* acc_in, int log_n_prev, e2 beta, u64* acc_out) {
   const int log_n = main.log_n;
   const size_t n = (size_t)1 << log_n, Dg = (size_t)1 << log_d, B = (size_t)1 << log_blowup;
   MH_REQUIRE(log_d <= log_blowup, "quotient degree exceeds blowup");
+  MH_REQUIRE((air->preprocessed_width == 0) == (prep == nullptr), "internal: preprocessed matrix presence");
+  if (prep)
+    MH_REQUIRE(prep->log_n == main.log_n && prep->width == air->preprocessed_width && prep->log_cosets == main.log_cosets &&
+                   prep->coset0 == main.coset0,
+               "preprocessed matrix does not match the AIR / trace shape");
   // this rank stores 2^log_cosets of the 2^log_blowup cosets: it evaluates the quotient cosets among them
   const int G = log_blowup - main.log_cosets;
   MH_REQUIRE(G >= 0 && log_d >= G && aux.log_cosets == main.log_cosets && aux.coset0 == main.coset0,
@@ -290,6 +298,7 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
   if (air->jit) {  // compiled chunks: large constraint systems
     JitArgs j{};
     j.main_lde = main.lde.u(); j.aux_lde = aux.lde.u();
+    j.prep_lde = prep ? prep->lde.u() : nullptr;
     j.acc = acc_out;
     j.tw = tw; j.coset_tab = dblob.u() + o_tab;
     j.inv_first = inv_first.u(); j.inv_last = inv_last.u();
@@ -313,6 +322,7 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
   a.n_slots = air->n_slots;
   a.main_lde = main.lde.u();
   a.aux_lde = aux.lde.u();
+  a.prep_lde = prep ? prep->lde.u() : nullptr;
   a.log_n = log_n; a.log_cosets = main.log_cosets; a.log_d = log_d; a.log_dl = log_dl;
   a.jc_shift = log_blowup - log_d;
   a.t0 = (u32)t0;

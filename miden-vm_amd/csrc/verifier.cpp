@@ -145,7 +145,7 @@ e2 fold_row(const e2* y, int log_arity, u64 s_inv, e2 beta) {
 
 // Everything an AIR's constraints can read at the out-of-domain point.
 struct PointEnv {
-  const e2 *main_cur, *main_next, *aux_cur, *aux_next, *periodic, *randomness, *aux_values;
+  const e2 *main_cur, *main_next, *prep_cur, *prep_next, *aux_cur, *aux_next, *periodic, *randomness, *aux_values;
   const u64* publics;
   e2 is_first, is_last, is_transition;
 };
@@ -159,6 +159,7 @@ e2 fold_constraints(const DagIR& ir, const PointEnv& e, e2 alpha) {
       case DOP_CONST: v[i] = e2_make(nd.c); break;
       case DOP_MAIN: v[i] = (nd.b ? e.main_next : e.main_cur)[nd.a]; break;
       case DOP_AUX: v[i] = (nd.b ? e.aux_next : e.aux_cur)[nd.a]; break;
+      case DOP_PREP: v[i] = (nd.b ? e.prep_next : e.prep_cur)[nd.a]; break;
       case DOP_PUBLIC: v[i] = e2_make(gl_canon(e.publics[nd.a])); break;
       case DOP_PERIODIC: v[i] = e.periodic[nd.a]; break;
       case DOP_IS_FIRST: v[i] = e.is_first; break;
@@ -196,7 +197,7 @@ e2 periodic_at(const std::vector<u64>& col, e2 y) {
 }
 
 void verify_impl(const mh_pcs_params& pp, const std::vector<DagIR>& airs, const std::vector<int>& lhs, const std::vector<u64>& publics,
-                 Reader& rd, u64 digest[4]) {
+                 const u64* prep_root, Reader& rd, u64 digest[4]) {
   const size_t n_airs = airs.size();
   const int lb = pp.log_blowup, la = pp.log_folding_arity;
   if (lb < 1 || lb > 8 || (la != 1 && la != 2) || pp.num_queries < 1) throw Reject("unsupported PCS parameters");
@@ -244,12 +245,31 @@ void verify_impl(const mh_pcs_params& pp, const std::vector<DagIR>& airs, const 
     break;
   }
   const e2 zs[2] = {z, e2_mulf(z, gl_two_adic_generator(log_n))};
-  // aligned widths per tree (pcs/verifier.rs)
-  std::vector<size_t> widths[3];
-  for (size_t j = 0; j < n_airs; j++) widths[0].push_back(align8(airs[order[j]].main_width));
-  for (size_t j = 0; j < n_airs; j++) widths[1].push_back(align8(2 * airs[order[j]].aux_width));
-  widths[2].push_back(align8(2 * D));
-  const Digest4 roots[3] = {main_root, aux_root, quot_root};
+  // commitment groups, aligned widths, tree depths: [preprocessed?, main, aux, quotient] (proof.rs:326-375)
+  std::vector<std::vector<size_t>> widths;
+  std::vector<Digest4> roots;
+  std::vector<int> depths;
+  bool any_prep = false;
+  for (auto& a : airs) any_prep |= a.preprocessed_width > 0;
+  if (any_prep != (prep_root != nullptr)) throw Reject("preprocessed commitment presence does not match the AIRs");
+  if (any_prep) {
+    widths.emplace_back();
+    int dp = 0;
+    for (size_t j = 0; j < n_airs; j++)
+      if (airs[order[j]].preprocessed_width) {
+        widths.back().push_back(align8(airs[order[j]].preprocessed_width));
+        dp = std::max(dp, lhs[order[j]] + lb);
+      }
+    roots.push_back(Digest4{prep_root[0], prep_root[1], prep_root[2], prep_root[3]});
+    depths.push_back(dp);
+  }
+  const size_t g_main = widths.size();
+  widths.resize(g_main + 3);
+  for (size_t j = 0; j < n_airs; j++) widths[g_main].push_back(align8(airs[order[j]].main_width));
+  for (size_t j = 0; j < n_airs; j++) widths[g_main + 1].push_back(align8(2 * airs[order[j]].aux_width));
+  widths[g_main + 2].push_back(align8(2 * D));
+  roots.push_back(main_root); roots.push_back(aux_root); roots.push_back(quot_root);
+  for (int k = 0; k < 3; k++) depths.push_back(L);
   size_t W = 0;
   for (auto& ws : widths)
     for (size_t w : ws) W += w;
@@ -283,10 +303,18 @@ void verify_impl(const mh_pcs_params& pp, const std::vector<DagIR>& airs, const 
 
   // ---- query phase: trace openings -> DEEP quotient values (deep/verifier.rs) ----
   std::vector<e2> reduced(idx.size(), e2_make(0));
-  for (int t = 0; t < 3; t++) {
-    auto rows = open_batch(rd, roots[t], widths[t], idx, L);
-    for (size_t q = 0; q < idx.size(); q++)
-      for (u64 v : rows[q]) reduced[q] = e2_add(e2_mul(reduced[q], alpha_d), e2_make(v));
+  for (size_t t = 0; t < widths.size(); t++) {
+    // a tree shorter than the max domain is opened at the indices' low bits (lmcs/tree_indices.rs:72-84)
+    const size_t mask = ((size_t)1 << depths[t]) - 1;
+    std::vector<size_t> tidx;
+    for (size_t i : idx) tidx.push_back(i & mask);
+    std::sort(tidx.begin(), tidx.end());
+    tidx.erase(std::unique(tidx.begin(), tidx.end()), tidx.end());
+    auto rows = open_batch(rd, roots[t], widths[t], tidx, depths[t]);
+    for (size_t q = 0; q < idx.size(); q++) {
+      const size_t k = std::lower_bound(tidx.begin(), tidx.end(), idx[q] & mask) - tidx.begin();
+      for (u64 v : rows[k]) reduced[q] = e2_add(e2_mul(reduced[q], alpha_d), e2_make(v));
+    }
   }
   const u64 wK = gl_two_adic_generator(L);
   std::vector<std::pair<size_t, e2>> cur;  // (index in the current FRI domain, value)
@@ -342,15 +370,24 @@ void verify_impl(const mh_pcs_params& pp, const std::vector<DagIR>& airs, const 
   }
   // ---- constraint identity at z (verifier/mod.rs): sum over AIRs (beta-folded) == Q(z) * Z_H(z) ----
   e2 accumulated = e2_make(0);
-  size_t off_main = 0, off_aux = 0;
-  for (size_t j = 0; j < n_airs; j++) off_aux += widths[0][j];
+  size_t off_prep = 0, off_main = 0;
+  if (any_prep)
+    for (size_t w : widths[0]) off_main += w;
+  size_t off_aux = off_main;
+  for (size_t j = 0; j < n_airs; j++) off_aux += widths[g_main][j];
   size_t off_quot = off_aux;
-  for (size_t j = 0; j < n_airs; j++) off_quot += widths[1][j];
+  for (size_t j = 0; j < n_airs; j++) off_quot += widths[g_main + 1][j];
   const e2 X = e2{0, 1};  // the extension's generator: an EF column is f0 + X * f1 of its two base columns
   for (size_t j = 0; j < n_airs; j++) {
     const DagIR& air = airs[order[j]];
     const int lh = lhs[order[j]];
     std::vector<e2> mc(air.main_width), mn(air.main_width), ac(air.aux_width), an(air.aux_width), per;
+    std::vector<e2> pc(air.preprocessed_width), pn(air.preprocessed_width);
+    for (size_t c = 0; c < air.preprocessed_width; c++) {
+      pc[c] = ev[0][off_prep + c];
+      pn[c] = ev[1][off_prep + c];
+    }
+    if (air.preprocessed_width) off_prep += align8(air.preprocessed_width);
     for (size_t c = 0; c < air.main_width; c++) {
       mc[c] = ev[0][off_main + c];
       mn[c] = ev[1][off_main + c];
@@ -359,8 +396,8 @@ void verify_impl(const mh_pcs_params& pp, const std::vector<DagIR>& airs, const 
       ac[c] = e2_add(ev[0][off_aux + 2 * c], e2_mul(ev[0][off_aux + 2 * c + 1], X));
       an[c] = e2_add(ev[1][off_aux + 2 * c], e2_mul(ev[1][off_aux + 2 * c + 1], X));
     }
-    off_main += widths[0][j];
-    off_aux += widths[1][j];
+    off_main += widths[g_main][j];
+    off_aux += widths[g_main + 1][j];
     const e2 y = e2_exp_pow2(z, log_n - lh);  // the point on this instance's own domain
     const e2 van = e2_sub(e2_exp_pow2(y, lh), e2_make(1));
     const u64 wh_inv = gl_inv(gl_two_adic_generator(lh));
@@ -371,6 +408,7 @@ void verify_impl(const mh_pcs_params& pp, const std::vector<DagIR>& airs, const 
     }
     PointEnv e{};
     e.main_cur = mc.data(); e.main_next = mn.data(); e.aux_cur = ac.data(); e.aux_next = an.data();
+    e.prep_cur = pc.data(); e.prep_next = pn.data();
     e.periodic = per.data(); e.randomness = randomness.data(); e.aux_values = aux_values[j].data();
     e.publics = publics.data();
     e.is_first = e2_mul(van, e2_inv(e2_sub(y, e2_make(1))));        // domain.rs:518-531
@@ -406,8 +444,8 @@ void verify_impl(const mh_pcs_params& pp, const std::vector<DagIR>& airs, const 
 extern "C" int mh_verify(const mh_pcs_params* params, int n_airs, const uint64_t* const* air_blobs, const size_t* air_blob_words,
                          const uint8_t* log_trace_heights, const uint64_t* public_values, size_t n_public_values,
                          const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe, const uint64_t* fields,
-                         size_t n_fields, const uint64_t* commitments, size_t n_commitments, uint64_t digest[4], char* err,
-                         size_t err_cap) {
+                         size_t n_fields, const uint64_t* commitments, size_t n_commitments, const uint64_t* preprocessed_root,
+                         uint64_t digest[4], char* err, size_t err_cap) {
   auto fail = [&](int code, const char* msg) {
     if (err && err_cap) {
       strncpy(err, msg, err_cap - 1);
@@ -432,7 +470,11 @@ extern "C" int mh_verify(const mh_pcs_params* params, int n_airs, const uint64_t
     for (size_t i = 0; i < n_pre_observe; i++) rd.ch.observe(pre_observe[i]);
     rd.f = fields; rd.nf = n_fields;
     rd.c = commitments; rd.nc = n_commitments;
-    verify_impl(*params, airs, lhs, std::vector<u64>(public_values, public_values + n_public_values), rd, digest);
+    u64 proot[4];
+    if (preprocessed_root)
+      for (int i = 0; i < 4; i++) proot[i] = gl_canon(preprocessed_root[i]);
+    verify_impl(*params, airs, lhs, std::vector<u64>(public_values, public_values + n_public_values), preprocessed_root ? proot : nullptr,
+                rd, digest);
     if (err && err_cap) err[0] = 0;
     return MH_OK;
   } catch (const MhError& e) {

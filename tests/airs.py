@@ -210,7 +210,7 @@ def logup_trace(log_n, seed=3, valid=True):
 
 
 # ------------------------------------------------------------------------------------------------
-def prep_air(log_n, seed=13):
+def prep_air(log_n, seed=13, num_public=0):
     """An AIR with PREPROCESSED columns (fixed circuit data committed at setup, crates/lifted-stark/src/preprocessed.rs):
     S (a 0/1 selector) and T (a table).  Main columns a, c, d:  a' = S ? a + T : a * c  (degree 3 with the selector),
     d = T_next (reads the preprocessed column's next row).  One all-zero EF aux column (the protocol wants one)."""
@@ -218,7 +218,7 @@ def prep_air(log_n, seed=13):
     rng = np.random.default_rng(seed)
     S = rng.integers(0, 2, n, dtype=np.uint64)
     T = rng.integers(0, P, n, dtype=np.uint64)
-    b = dag.AirBuilder(3, aux_width=1, num_randomness=1, num_aux_values=0, preprocessed_width=2)
+    b = dag.AirBuilder(3, aux_width=1, num_randomness=1, num_aux_values=0, num_public=num_public, preprocessed_width=2)
     a0, a1, c0, d0 = b.main(0), b.main(0, 1), b.main(1), b.main(2)
     s, t, t_next = b.preprocessed(0), b.preprocessed(1), b.preprocessed(1, 1)
     b.assert_zero(b.is_transition() * (s * (a1 - a0 - t) + (b.const(1) - s) * (a1 - a0 * c0)))

@@ -21,10 +21,25 @@ def ctx():
     c.close()
 
 
+def attach_preprocessed(ctx, airs_, dairs, traces, params):
+    """Setup (crates/lifted-stark/src/preprocessed.rs Preprocessed::build): commit the preprocessed matrices of the AIRs
+    that declare some, in proof order, and point each DeviceAir at its matrix.  Returns the commitment or None."""
+    pkg = load_package()
+    order = sorted(range(len(airs_)), key=lambda i: (traces[i].shape[0], i))
+    with_prep = [i for i in order if airs_[i].preprocessed is not None]
+    if not with_prep:
+        return None
+    com = pkg.commit_traces(ctx, [ctx.upload_trace(airs_[i].preprocessed) for i in with_prep], params["log_blowup"])
+    for k, i in enumerate(with_prep):
+        dairs[i].attach_preprocessed(com.tree(), k)
+    return com.root()
+
+
 def gpu_prove(ctx, airs_, traces, publics, params):
     pkg = load_package()
     dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
     dtr = [ctx.upload_trace(t) for t in traces]
+    prep_root = attach_preprocessed(ctx, airs_, dairs, traces, params)
     need_cb = any(a.build_aux is not None for a in airs_)
 
     def aux_builder(idx, rnd):
@@ -33,8 +48,8 @@ def gpu_prove(ctx, airs_, traces, publics, params):
             return np.zeros((traces[idx].shape[0], 2 * a.aux_width), dtype=np.uint64), [0] * (2 * a.num_aux_values)
         return a.build_aux(traces[idx], rnd[:a.num_randomness])
 
-    return pkg.prove(ctx, dairs, dtr, publics, params, ob.challenger_state(), ob.protocol_pre_observe(params, publics),
-                     aux_builder if need_cb else None)
+    return pkg.prove(ctx, dairs, dtr, publics, params, ob.challenger_state(),
+                     ob.protocol_pre_observe(params, publics, preprocessed_root=prep_root), aux_builder if need_cb else None)
 
 
 def check_same(ctx, airs_, traces, publics, params):
@@ -54,8 +69,10 @@ def check_same(ctx, airs_, traces, publics, params):
     assert ok, msg
     # the product's own host verifier (mh_verify) agrees with the oracle's
     pkg = load_package()
-    ok2, dig2 = pkg.verify(airs_, got.log_trace_heights, publics, params, ob.challenger_state(), ob.protocol_pre_observe(params, publics),
-                           got.fields, got.commitments)
+    root = ob.preprocessed_commitment(airs_, got.log_trace_heights, params)
+    ok2, dig2 = pkg.verify(airs_, got.log_trace_heights, publics, params, ob.challenger_state(),
+                           ob.protocol_pre_observe(params, publics, preprocessed_root=root), got.fields, got.commitments,
+                           preprocessed_root=root)
     assert ok2, dig2
     assert (dig2 == got.digest).all()
     return got
@@ -389,3 +406,52 @@ def test_two_contexts_prove_concurrently():
         for got in results[i]:
             assert (got.fields == expect[i].fields).all() and (got.commitments == expect[i].commitments).all()
             assert (got.digest == expect[i].digest).all()
+
+
+# ---- preprocessed (setup-committed) columns ------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["alone", "shorter_than_max", "taller_than_others", "two_preprocessed_airs", "compiled"])
+def test_preprocessed_columns(ctx, case, monkeypatch):
+    """crates/lifted-stark/src/preprocessed.rs + the [preprocessed?, main, aux, quotient] group order: device proofs equal
+    the oracle's; the setup tree may be shorter than the max domain (query indices fold onto it by their low bits)."""
+    t7, pub7 = A.fib_trace(7)
+    t5, pub5 = A.fib_trace(5)
+    a5, tr5 = A.prep_air(5)
+    a8, tr8 = A.prep_air(8)
+    a6, tr6 = A.prep_air(6, seed=3)
+    a5p, tr5p = A.prep_air(5, num_public=3)
+    a8p, tr8p = A.prep_air(8, num_public=3)
+    if case == "alone":
+        airs_, traces, pub = [a5], [tr5()], []
+    elif case == "shorter_than_max":
+        airs_, traces, pub = [A.fib_air(), a5p], [t7, tr5p()], pub7
+    elif case == "taller_than_others":
+        airs_, traces, pub = [a8p, A.fib_air()], [tr8p(), t5], pub5
+    elif case == "two_preprocessed_airs":
+        airs_, traces, pub = [a8, a6], [tr8(), tr6()], []
+    else:  # the same through the compiled constraint kernels
+        monkeypatch.setenv("MH_JIT", "1")
+        monkeypatch.setenv("MH_JIT_CHUNK", "16")
+        airs_, traces, pub = [a8, a6], [tr8(), tr6()], []
+    got = check_same(ctx, airs_, traces, pub, FAST)
+    assert got.fields.size > 0
+
+
+def test_preprocessed_setup_mistakes_are_rejected(ctx):
+    pkg = load_package()
+    a5, tr5 = A.prep_air(5)
+    d = pkg.DeviceAir(ctx, a5)
+    t = ctx.upload_trace(tr5())
+    args = ([d], [t], [], FAST, ob.challenger_state(), ob.protocol_pre_observe(FAST, []))
+    with pytest.raises(pkg.MidenHipError, match="preprocessed"):
+        pkg.prove(ctx, *args)  # nothing attached
+    wrong_height = pkg.commit_traces(ctx, [ctx.upload_trace(A.prep_air(6)[0].preprocessed)], FAST["log_blowup"])
+    d.attach_preprocessed(wrong_height.tree(), 0)
+    with pytest.raises(pkg.MidenHipError, match="height"):
+        pkg.prove(ctx, *args)
+    wrong_blowup = pkg.commit_traces(ctx, [ctx.upload_trace(a5.preprocessed)], FAST["log_blowup"] - 1)
+    d.attach_preprocessed(wrong_blowup.tree(), 0)
+    with pytest.raises(pkg.MidenHipError, match="blowup"):
+        pkg.prove(ctx, *args)
+    plain = pkg.DeviceAir(ctx, A.fib_air())
+    with pytest.raises(pkg.MidenHipError):
+        plain.attach_preprocessed(wrong_blowup.tree(), 0)  # this AIR declares no preprocessed columns

@@ -18,10 +18,12 @@ def cases():
     yield "alone_arity4", [air], [tr()], [], PRM4
     t, pub = A.fib_trace(7)
     # the preprocessed AIR is the SHORTER instance: its tree has fewer levels than the max domain (virtual lifting)
-    yield "shorter_than_max", [A.fib_air(), air], [t, tr()], pub, PRM4
+    air3, tr3 = A.prep_air(5, num_public=3)
+    yield "shorter_than_max", [A.fib_air(), air3], [t, tr3()], pub, PRM4
     air8, tr8 = A.prep_air(8)
+    air8p, tr8p = A.prep_air(8, num_public=3)
     t5, pub5 = A.fib_trace(5)
-    yield "taller_than_others", [air8, A.fib_air()], [tr8(), t5], pub5, PRM4
+    yield "taller_than_others", [air8p, A.fib_air()], [tr8p(), t5], pub5, PRM4
     air6, tr6 = A.prep_air(6, seed=3)
     yield "two_preprocessed_airs", [air8, air6], [tr8(), tr6()], [], PRM4
 

@@ -26,10 +26,18 @@ def cases():
     yield "logup", [air], [A.logup_trace(5)], [], SMALL
     t1, pub1 = A.fib_trace(7)
     yield "multi", [A.periodic_air(3), A.fib_air()], [A.periodic_trace(5), t1], pub1, ARITY4
+    pair, ptr_ = A.prep_air(5)
+    yield "preprocessed", [pair], [ptr_()], [], ARITY4
+    pair3, ptr3 = A.prep_air(5, num_public=3)
+    yield "preprocessed_shorter_than_max", [A.fib_air(), pair3], [t1, ptr3()], pub1, ARITY4
+    pair8, ptr8 = A.prep_air(8)
+    yield "two_preprocessed", [pair8, pair], [ptr8(), ptr_()], [], ARITY4
 
 
 def product_verify(airs_, lhs, pub, prm, fields, commits):
-    return pkg.verify(airs_, lhs, pub, prm, ob.challenger_state(), ob.protocol_pre_observe(prm, pub), fields, commits)
+    root = ob.preprocessed_commitment(airs_, lhs, prm)  # setup data (None without preprocessed columns)
+    return pkg.verify(airs_, lhs, pub, prm, ob.challenger_state(), ob.protocol_pre_observe(prm, pub, preprocessed_root=root), fields,
+                      commits, preprocessed_root=root)
 
 
 @pytest.mark.parametrize("name,airs_,traces,pub,prm", list(cases()), ids=[c[0] for c in cases()])
@@ -81,3 +89,22 @@ def test_unsatisfied_constraints_are_rejected():
     ok, msg = product_verify(airs_, proof["log_heights"], pub, prm, proof["fields"], proof["commitments"])
     assert not ok and "quotient identity" in msg
     assert not ob.verify(airs_, proof["log_heights"], pub, proof, prm)[0]
+
+
+def test_preprocessed_commitment_is_checked():
+    air, tr = A.prep_air(5)
+    proof = ob.prove([air], [tr()], [], ARITY4)
+    lhs, f, c = proof["log_heights"], proof["fields"], proof["commitments"]
+    root = proof["preprocessed_root"]
+    pre = ob.protocol_pre_observe(ARITY4, [], preprocessed_root=root)
+    assert pkg.verify([air], lhs, [], ARITY4, ob.challenger_state(), pre, f, c, preprocessed_root=root)[0]
+    # missing / wrong setup commitment
+    assert not pkg.verify([air], lhs, [], ARITY4, ob.challenger_state(), pre, f, c, preprocessed_root=None)[0]
+    wrong = root.copy()
+    wrong[0] = (int(wrong[0]) + 1) % A.P
+    assert not pkg.verify([air], lhs, [], ARITY4, ob.challenger_state(), pre, f, c, preprocessed_root=wrong)[0]
+    # a commitment given for AIRs that have no preprocessed columns
+    t, pub = A.fib_trace(6)
+    p2 = ob.prove([A.fib_air()], [t], pub, ARITY4)
+    assert not pkg.verify([A.fib_air()], p2["log_heights"], pub, ARITY4, ob.challenger_state(), ob.protocol_pre_observe(ARITY4, pub),
+                          p2["fields"], p2["commitments"], preprocessed_root=root)[0]

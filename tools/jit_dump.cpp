@@ -10,7 +10,7 @@ int main(int argc, char** argv) {
   try {
     DagIR ir = dag_parse((const u64*)raw.data(), raw.size() / 8);
     size_t gates = 0;
-    for (size_t i = 0; i < ir.nodes.size(); i++) gates += ir.live[i] && ir.nodes[i].op >= DOP_ADD;
+    for (size_t i = 0; i < ir.nodes.size(); i++) gates += ir.live[i] && dag_is_gate(ir.nodes[i].op);
     printf("nodes %zu, live gates %zu, constraints %zu\n", ir.nodes.size(), gates, ir.cons.size());
     jit_program_build(nullptr, ir);
   } catch (const std::exception& e) {
