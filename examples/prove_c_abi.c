@@ -78,6 +78,22 @@ int main(int argc, char** argv) {
   printf("rows 2^%d width %zu aux %zu: %zu fields, %zu commitments, %zu bytes\n", log_n, width, aux, mh_proof_num_fields(proof),
          mh_proof_num_commitments(proof), mh_proof_serialize(proof, NULL, 0));
   printf("digest %016" PRIx64 " %016" PRIx64 " %016" PRIx64 " %016" PRIx64 "\n", d[0], d[1], d[2], d[3]);
+  /* ---- and check it with the library's host-only verifier (no GPU involved) ---- */
+  {
+    const uint64_t* blobs[1] = {blob};
+    const size_t blob_words[1] = {w};
+    const uint8_t heights[1] = {(uint8_t)log_n};
+    uint64_t vdigest[4];
+    char why[256];
+    int rc = mh_verify(&params, 1, blobs, blob_words, heights, NULL, 0, state, pre, 11, mh_proof_fields(proof),
+                       mh_proof_num_fields(proof), mh_proof_commitments(proof), mh_proof_num_commitments(proof), NULL, vdigest, why,
+                       sizeof why);
+    if (rc != MH_OK || vdigest[0] != d[0] || vdigest[3] != d[3]) {
+      fprintf(stderr, "mh_verify: %s\n", rc != MH_OK ? why : "digest mismatch");
+      return 1;
+    }
+    printf("verified\n");
+  }
   mh_proof_free(proof);
   mh_trace_free(trace);
   mh_air_free(air);

@@ -53,3 +53,4 @@ def test_c_program_proves_and_matches_oracle(tmp_path):
     assert got == [int(x) for x in exp["digest"]], out
     nf = int(re.search(r"(\d+) fields", out).group(1))
     assert nf == exp["fields"].size
+    assert "verified" in out
