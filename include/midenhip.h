@@ -36,6 +36,8 @@ typedef struct mh_proof mh_proof; /* host-resident proof: transcript fields + co
 /* ---- context ------------------------------------------------------------------------------ */
 int mh_ctx_create(int device_id, mh_ctx** out);
 void mh_ctx_destroy(mh_ctx* ctx);
+/* Release the device buffers the context keeps pooled between proofs (freed automatically on OOM and at destroy). */
+int mh_ctx_trim(mh_ctx* ctx);
 const char* mh_last_error(const mh_ctx* ctx);
 int mh_device_count(void);
 

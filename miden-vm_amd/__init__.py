@@ -20,7 +20,7 @@ P = 0xFFFFFFFF00000001
 u64p = C.POINTER(C.c_uint64)
 
 EXPORTS = [
-    "mh_ctx_create", "mh_ctx_destroy", "mh_last_error", "mh_device_count", "mh_prof_enable", "mh_prof_reset",
+    "mh_ctx_create", "mh_ctx_destroy", "mh_ctx_trim", "mh_last_error", "mh_device_count", "mh_prof_enable", "mh_prof_reset",
     "mh_prof_get", "mh_prof_dump", "mh_poseidon2_permute", "mh_poseidon2_register_rate", "mh_coset_lde_batch", "mh_trace_upload", "mh_trace_free",
     "mh_commit_traces", "mh_tree_free", "mh_tree_root", "mh_tree_log_height", "mh_tree_open", "mh_tree_download_lde",
     "mh_tree_download_layers", "mh_air_load", "mh_air_free", "mh_air_log_quotient_degree", "mh_air_compiled_chunks", "mh_prove", "mh_proof_free",
@@ -154,6 +154,10 @@ class Ctx:
         self.check(self.lib.mh_coset_lde_batch(self.h, _ptr(m), log_n, C.c_size_t(w), added_bits,
                                                C.c_uint64(int(shift)), _ptr(out)))
         return out
+
+    def trim(self):
+        """Release the device buffers pooled between proofs."""
+        self.check(self.lib.mh_ctx_trim(self.h))
 
     def upload_trace(self, matrix):
         return Trace(self, matrix)

@@ -74,6 +74,17 @@ void mh_ctx_destroy(mh_ctx* c) {
   delete c;
 }
 
+// Give the cached device buffers of this context back to the driver (a proof keeps its ~2x LDE-sized working
+// set pooled between calls so that the next proof does not pay hipMalloc / hipFree).
+int mh_ctx_trim(mh_ctx* c) {
+  MH_TRY(c)
+  MH_REQUIRE(c, "null ctx");
+  HIP_CHECK(hipSetDevice(c->device));
+  c->sync();
+  c->pool.trim();
+  MH_CATCH
+}
+
 const char* mh_last_error(const mh_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 
 int mh_prof_enable(mh_ctx* c, int on) {

@@ -142,6 +142,13 @@ def test_tiny_traces(ctx, log_n):
     check_same(ctx, [A.fib_air()], [t], pub, dict(FAST, log_final_degree=0, log_folding_arity=1))
 
 
+def test_ctx_trim_keeps_working(ctx):
+    a = check_same(ctx, [dag.dummy_miden_air(11, 2)], [A.dummy_trace(8, 11)], [], FAST)
+    ctx.trim()
+    b = check_same(ctx, [dag.dummy_miden_air(11, 2)], [A.dummy_trace(8, 11)], [], FAST)
+    assert (a.fields == b.fields).all()
+
+
 def test_many_proofs_one_ctx_pool_reuse(ctx):
     # alternate sizes on one ctx: the buffer pool must never hand out a buffer that is still in use
     air = dag.dummy_miden_air(11, 2)
