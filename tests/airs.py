@@ -238,3 +238,65 @@ def prep_air(log_n, seed=13, num_public=0):
         return m
 
     return air, trace
+
+
+# ------------------------------------------------------------------------------------------------
+def random_air(seed, width=6, aux_width=2, n_constraints=12, max_degree=4, with_preprocessed=False, log_n=None):
+    """A random constraint system touching EVERY node kind in random base/extension mixtures (main / aux / periodic /
+    public / selector / randomness / aux-value / preprocessed leaves; ADD, SUB, MUL, NEG over base-base, base-ext, ext-base
+    and ext-ext operands).  Like synthetic_big_air the constraints are not satisfied by a random trace: proofs are
+    deterministic and must be bit-identical between the oracle, the interpreter and the compiled kernels."""
+    rng = np.random.default_rng(seed)
+    pw = 2 if with_preprocessed else 0
+    b = dag.AirBuilder(width, aux_width=aux_width, num_randomness=2, num_aux_values=2, num_public=2, periodic=PERIODIC_COLS,
+                       preprocessed_width=pw)
+
+    def leaf():
+        k = int(rng.integers(0, 10 if with_preprocessed else 9))
+        if k == 0:
+            return b.main(int(rng.integers(0, width)), int(rng.integers(0, 2)))
+        if k == 1:
+            return b.aux(int(rng.integers(0, aux_width)), int(rng.integers(0, 2)))
+        if k == 2:
+            return b.periodic_value(int(rng.integers(0, 2)))
+        if k == 3:
+            return b.public(int(rng.integers(0, 2)))
+        if k == 4:
+            return [b.is_first_row, b.is_last_row, b.is_transition][int(rng.integers(0, 3))]()
+        if k == 5:
+            return b.randomness(int(rng.integers(0, 2)))
+        if k == 6:
+            return b.aux_value(int(rng.integers(0, 2)))
+        if k == 7:
+            return b.const(int(rng.integers(0, P, dtype=np.uint64)))
+        if k == 8:
+            return b.main(int(rng.integers(0, width)))
+        return b.preprocessed(int(rng.integers(0, pw)), int(rng.integers(0, 2)))
+
+    def expr(depth):
+        if depth == 0 or rng.random() < 0.25:
+            return leaf()
+        op = int(rng.integers(0, 4))
+        x = expr(depth - 1)
+        if op == 3:
+            return -x
+        y = expr(depth - 1)
+        if op == 0:
+            return x + y
+        if op == 1:
+            return x - y
+        return x * y if x.deg + y.deg <= max_degree else x + y
+
+    for _ in range(n_constraints):
+        e = expr(4)
+        (b.assert_zero_ext if e.ext else b.assert_zero)(e)
+
+    def build_aux(main, randomness):
+        n = main.shape[0]
+        r2 = np.random.default_rng(seed + 1000)
+        return r2.integers(0, P, (n, 2 * aux_width), dtype=np.uint64), [int(x) for x in r2.integers(0, P, 4, dtype=np.uint64)]
+
+    prep = None
+    if with_preprocessed:
+        prep = np.random.default_rng(seed + 2000).integers(0, P, (1 << log_n, pw), dtype=np.uint64)
+    return dag.Air(b, build_aux, f"random:{seed}", preprocessed=prep)

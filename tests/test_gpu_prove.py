@@ -462,3 +462,34 @@ def test_preprocessed_setup_mistakes_are_rejected(ctx):
     plain = pkg.DeviceAir(ctx, A.fib_air())
     with pytest.raises(pkg.MidenHipError):
         plain.attach_preprocessed(wrong_blowup.tree(), 0)  # this AIR declares no preprocessed columns
+
+
+# ---- random constraint systems: oracle == interpreter == compiled kernels -------------------------------------------
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
+def test_random_constraint_systems(ctx, seed, monkeypatch):
+    """tests/airs.py random_air: every DAG node kind in random base/extension mixtures (seed 3 and 5 with preprocessed
+    columns).  The transcript must be bit-identical between the oracle, the device interpreter and the compiled chunk
+    kernels (the random constraints do not hold, so no verifier accepts -- parity, not validity, is the property here)."""
+    pkg = load_package()
+    log_n = 6 + seed % 3
+    air = A.random_air(seed, with_preprocessed=seed in (3, 5), log_n=log_n)
+    trace = A.dummy_trace(log_n, 6, seed=seed)
+    pub = [5, 7]
+    exp = ob.prove([air], [trace], pub, FAST)
+    root = exp["preprocessed_root"]
+    pre = ob.protocol_pre_observe(FAST, pub, preprocessed_root=root)
+
+    def aux_builder(idx, rnd):
+        return air.build_aux(trace, rnd)
+
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MH_JIT", mode)
+        monkeypatch.setenv("MH_JIT_CHUNK", "24")
+        dair = pkg.DeviceAir(ctx, air)
+        assert (dair.compiled_chunks > 0) == (mode == "1")
+        attach_preprocessed(ctx, [air], [dair], [trace], FAST)
+        got = pkg.prove(ctx, [dair], [ctx.upload_trace(trace)], pub, FAST, ob.challenger_state(), pre, aux_builder)
+        nf = min(got.fields.size, exp["fields"].size)
+        bad = np.nonzero(got.fields[:nf] != exp["fields"][:nf])[0]
+        assert bad.size == 0 and got.fields.size == exp["fields"].size, f"MH_JIT={mode}: first differing field {bad[:1]}"
+        assert (got.commitments == exp["commitments"]).all() and (got.digest == exp["digest"]).all()
