@@ -24,6 +24,14 @@ def test_library_exports_every_declared_symbol():
     assert sorted(pkg.EXPORTS) == syms
 
 
+def test_rust_sys_declarations_cover_the_header():
+    """bindings/rust/midenhip_sys.rs (the -sys layer of INTEGRATION.md's shim; uncompiled here, no Rust toolchain) must
+    declare exactly the header's symbols."""
+    src = open(os.path.join(ROOT, "bindings", "rust", "midenhip_sys.rs")).read()
+    rs = sorted(set(re.findall(r"pub fn (mh_[a-z0-9_]+)\s*\(", src)))
+    assert rs == header_symbols()
+
+
 def test_no_cpu_fallback():
     pkg = load_package()
     lib = pkg.load_library()
