@@ -89,3 +89,27 @@ def test_lookup_shape_mismatch_is_rejected(ctx):
     dair = pkg.DeviceAir(ctx, dag.dummy_miden_air(9, 2))
     with pytest.raises(pkg.MidenHipError):
         dair.attach_lookup(pkg.DeviceLookup(ctx, lookup))
+
+
+def test_lookup_on_one_air_of_several(ctx):
+    """Two instances: the LogUp AIR (aux trace built on the device) next to an ordinary AIR whose aux trace still comes
+    from the host callback -- the callback must be asked for the second one only."""
+    pkg = load_package()
+    air, lookup = A.logup_air()
+    main = A.logup_trace(6, seed=5)
+    per = A.periodic_air(0)
+    per_trace = A.periodic_trace(8)
+    airs_, traces = [air, per], [main, per_trace]
+    exp = ob.prove(airs_, traces, [], FAST)
+    dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+    dairs[0].attach_lookup(pkg.DeviceLookup(ctx, lookup))
+    asked = []
+
+    def aux_builder(idx, rnd):
+        asked.append(idx)
+        return airs_[idx].build_aux(traces[idx], rnd[:airs_[idx].num_randomness])
+
+    got = pkg.prove(ctx, dairs, [ctx.upload_trace(t) for t in traces], [], FAST, ob.challenger_state(),
+                    ob.protocol_pre_observe(FAST, []), aux_builder)
+    assert asked == [1]
+    assert (got.fields == exp["fields"]).all() and (got.commitments == exp["commitments"]).all() and (got.digest == exp["digest"]).all()

@@ -246,6 +246,7 @@ def staged_prove(ctx, airs_, traces, publics, params, device_grind=True):
     dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
     dtr = [ctx.upload_trace(t) for t in traces]
     need_cb = any(a.build_aux is not None for a in airs_)
+    prep_root = attach_preprocessed(ctx, airs_, dairs, traces, params)
 
     def aux_builder(idx, rnd):
         a = airs_[idx]
@@ -254,7 +255,7 @@ def staged_prove(ctx, airs_, traces, publics, params, device_grind=True):
         return a.build_aux(traces[idx], rnd[:a.num_randomness])
 
     ch = ob.Challenger(ob.challenger_state())
-    ch.observe(ob.protocol_pre_observe(params, publics))
+    ch.observe(ob.protocol_pre_observe(params, publics, preprocessed_root=prep_root))
     ch.observe([len(airs_)] + [int(t.shape[0]).bit_length() - 1 for t in traces])
     fields, commits = [], []
 
@@ -305,16 +306,20 @@ def staged_prove(ctx, airs_, traces, publics, params, device_grind=True):
     return np.array(fields, dtype=np.uint64), np.array(commits, dtype=np.uint64).reshape(-1, 4), ch.finalize()
 
 
-@pytest.mark.parametrize("case", ["fib", "multi", "prod"])
+@pytest.mark.parametrize("case", ["fib", "multi", "prod", "preprocessed"])
 def test_staged_session_equals_mh_prove(ctx, case):
-    if case == "fib":
+    if case == "preprocessed":  # a setup tree shorter than the max domain + an ordinary AIR
+        t7, pub = A.fib_trace(7)
+        a5, tr5 = A.prep_air(5, num_public=3)
+        airs_, traces, params = [A.fib_air(), a5], [t7, tr5()], FAST
+    elif case == "fib":
         t, pub = A.fib_trace(7)
         airs_, traces, params = [A.fib_air()], [t], FAST
     elif case == "multi":
         airs_, traces, params = [A.periodic_air(0), dag.dummy_miden_air(9, 2)], [A.periodic_trace(9), A.dummy_trace(6, 9)], FAST
     else:
         airs_, traces, params = [dag.dummy_miden_air(51, 8)], [A.dummy_trace(12, 51)], ob.PROD_PARAMS
-    pub = pub if case == "fib" else []
+    pub = pub if case in ("fib", "preprocessed") else []
     one = gpu_prove(ctx, airs_, traces, pub, params)
     f, c, d = staged_prove(ctx, airs_, traces, pub, params)
     assert f.size == one.fields.size and (f == one.fields).all()
