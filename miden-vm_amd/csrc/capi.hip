@@ -70,6 +70,7 @@ void mh_ctx_destroy(mh_ctx* c) {
     c->tw_fwd.clear(); c->tw_inv.clear(); c->tables.clear(); c->table_index.clear();
   }
   c->pool.trim();
+  if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

@@ -1,5 +1,6 @@
 // Context plumbing: stream, profiler (HIP events on the private stream), sync.
 #include "ctx.hpp"
+#include <cstring>
 
 thread_local DevPool* g_dev_pool = nullptr;
 
@@ -42,3 +43,16 @@ void mh_ctx::prof_resolve() {
 }
 
 void mh_ctx::sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
+
+void mh_ctx::d2h(void* dst_host, const void* src_dev, size_t bytes) {
+  if (!bytes) return;
+  if (bytes > PINNED_BYTES) {
+    HIP_CHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, stream));
+    sync();
+    return;
+  }
+  if (!pinned) HIP_CHECK(hipHostMalloc(&pinned, PINNED_BYTES, hipHostMallocDefault));
+  HIP_CHECK(hipMemcpyAsync(pinned, src_dev, bytes, hipMemcpyDeviceToHost, stream));
+  sync();
+  memcpy(dst_host, pinned, bytes);
+}

@@ -141,6 +141,11 @@ struct mh_ctx {
   void prof_end();
   void prof_resolve();
   void sync();
+  // Blocking device-to-host copy of a small result (roots, opened rows, partial sums) through a page-locked bounce
+  // buffer: a straight DMA instead of the runtime's staged copy into pageable memory (~40 us less per call).
+  void d2h(void* dst_host, const void* src_dev, size_t bytes);
+  void* pinned = nullptr;
+  static constexpr size_t PINNED_BYTES = 1 << 20;
   const u64* twiddles(int log_n, bool inverse);
 };
 

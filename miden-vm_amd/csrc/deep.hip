@@ -108,8 +108,7 @@ void deep_ood_eval_matrix(mh_ctx* c, const LdeMatrix& m, int log_blowup, e2 y0, 
                        w1.u(), partial.u(), chunks);
   }
   std::vector<u64> host(m.width * chunks * 4);
-  HIP_CHECK(hipMemcpyAsync(host.data(), partial.p, host.size() * 8, hipMemcpyDeviceToHost, c->stream));
-  HIP_CHECK(hipStreamSynchronize(c->stream));
+  c->d2h(host.data(), partial.p, host.size() * 8);
   // scaling s(y) = ((y/g)^n - 1)/n
   const u64 g_inv = gl_inv(g), n_inv = gl_inv((u64)n % GL_P);
   e2 s0 = e2_mulf(e2_sub(e2_exp_pow2(e2_mulf(y0, g_inv), log_n), e2_make(1)), n_inv);

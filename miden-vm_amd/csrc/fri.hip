@@ -187,8 +187,7 @@ u64 fri_grind(mh_ctx* c, const u64 st[12], const u64* in, int n_in, int bits) {
     a.base = base;
     hipLaunchKernelGGL(k_grind, dim3((unsigned)(window / 256)), dim3(256), 0, c->stream, a);
     unsigned long long got = 0;
-    HIP_CHECK(hipMemcpyAsync(&got, best.p, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->d2h(&got, best.p, 8);
     if (got != ~0ULL) return (u64)got;
   }
 }

@@ -207,8 +207,7 @@ void lmcs_compress_layers(mh_ctx* c, mh_tree* t) {
                            t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
     }
   }
-  HIP_CHECK(hipMemcpyAsync(t->root, t->nodes.u() + 4 * t->layer_off[0], 32, hipMemcpyDeviceToHost, c->stream));
-  HIP_CHECK(hipStreamSynchronize(c->stream));
+  c->d2h(t->root, t->nodes.u() + 4 * t->layer_off[0], 32);
 }
 
 void lmcs_build_tree(mh_ctx* c, mh_tree* t) {
@@ -356,8 +355,7 @@ void lmcs_open(mh_ctx* c, const mh_tree* t, const std::vector<size_t>& idx, size
   hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const u64* const*)dptrs.p, dout.u(), n);
   if (distributed) dist->all_reduce_sum(c, dout.u(), n);
   std::vector<u64> host(n);
-  HIP_CHECK(hipMemcpyAsync(host.data(), dout.p, n * 8, hipMemcpyDeviceToHost, c->stream));
-  HIP_CHECK(hipStreamSynchronize(c->stream));
+  c->d2h(host.data(), dout.p, n * 8);
   for (auto& cf : cap_fill)
     for (int k = 0; k < 4; k++) host[cf.first + k] = cf.second[k];
   fields.assign(host.begin(), host.begin() + n_fields);

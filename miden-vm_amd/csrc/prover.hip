@@ -493,8 +493,7 @@ struct mh_session {
     const size_t fpd = (size_t)1 << log_fpd;
     const size_t n_loc = (size_t)1 << (log_rows + cb_loc);
     std::vector<u64> host(2 * n_loc);
-    HIP_CHECK(hipMemcpyAsync(host.data(), layer.p, n_loc * 16, hipMemcpyDeviceToHost, c->stream));
-    c->sync();
+    c->d2h(host.data(), layer.p, n_loc * 16);
     std::vector<e2> vals(fpd);
     u64 s_shift = 1;
     if (sharded) {
