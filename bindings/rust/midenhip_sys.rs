@@ -95,11 +95,11 @@ unsafe extern "C" {
     pub fn mh_air_free(air: *mut mh_air);
     pub fn mh_air_log_quotient_degree(air: *const mh_air) -> c_int;
     pub fn mh_air_compiled_chunks(air: *const mh_air) -> c_int;
-    pub fn mh_air_attach_preprocessed(air: *mut mh_air, tree: *const mh_tree, matrix_index: c_int) -> c_int;
+    pub fn mh_air_attach_preprocessed(air: *mut mh_air, tree: *const mh_tree, matrix_index: c_int, raw: *const mh_trace) -> c_int;
     pub fn mh_air_attach_lookup(air: *mut mh_air, l: *const mh_lookup) -> c_int;
     pub fn mh_lookup_load(ctx: *mut mh_ctx, blob: *const u64, n_words: usize, out: *mut *mut mh_lookup) -> c_int;
     pub fn mh_lookup_free(l: *mut mh_lookup);
-    pub fn mh_lookup_build_aux(ctx: *mut mh_ctx, l: *const mh_lookup, main_trace: *const mh_trace, randomness: *const u64, n_randomness: usize, aux_out: *mut *mut mh_trace, acc_final: *mut u64) -> c_int;
+    pub fn mh_lookup_build_aux(ctx: *mut mh_ctx, l: *const mh_lookup, main_trace: *const mh_trace, preprocessed: *const mh_trace, randomness: *const u64, n_randomness: usize, aux_out: *mut *mut mh_trace, acc_final: *mut u64) -> c_int;
     // ---- proofs ----
     pub fn mh_prove(ctx: *mut mh_ctx, params: *const mh_pcs_params, n_airs: c_int, airs: *const *mut mh_air, traces: *const *mut mh_trace, public_values: *const u64, n_public_values: usize, challenger_state: *const u64, pre_observe: *const u64, n_pre_observe: usize, aux_builder: mh_aux_builder, user: *mut c_void, out: *mut *mut mh_proof) -> c_int;
     pub fn mh_prove_sharded(ctx: *mut mh_ctx, comm: *const mh_comm, params: *const mh_pcs_params, n_airs: c_int, airs: *const *mut mh_air, traces: *const *mut mh_trace, public_values: *const u64, n_public_values: usize, challenger_state: *const u64, pre_observe: *const u64, n_pre_observe: usize, aux_builder: mh_aux_builder, user: *mut c_void, out: *mut *mut mh_proof) -> c_int;

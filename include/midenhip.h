@@ -146,13 +146,15 @@ int mh_air_compiled_chunks(const mh_air* air);
  * the proving blowup; its root is observed by the caller right after the protocol parameters and before the statement
  * (prover/mod.rs:282-286), i.e. it belongs in `pre_observe`.  Each such AIR is then pointed at its matrix of that tree;
  * proofs open the tree first (`[preprocessed?, main, aux, quotient]`).  The tree must outlive the proofs. */
-int mh_air_attach_preprocessed(mh_air* air, const mh_tree* tree, int matrix_index); /* tree = NULL detaches */
+int mh_air_attach_preprocessed(mh_air* air, const mh_tree* tree, int matrix_index, const mh_trace* raw);
+/* tree = NULL detaches.  `raw` = the uploaded preprocessed matrix itself (trace domain); only needed when a lookup
+ * program attached to the same AIR reads preprocessed columns (table lookups), NULL otherwise. */
 
 /* ---- LogUp aux trace on the device -------------------------------------------------------------------------
  * Replaces `build_logup_aux_trace` (air/src/lookup/aux_builder.rs:49-96) for an AIR whose bus messages are
  * exported as a lookup program: the "MHLKP001" blob = the constraint-DAG blob's header (w[2] = number of aux EF
- * columns, w[4] = w[5] = w[7] = 0, w[9] ignored), periodic tables and node list (ops CONST, MAIN, PERIODIC,
- * RANDOMNESS, ADD, SUB, MUL, NEG), followed per aux column by: count, then `count` pairs (multiplicity node id,
+ * columns, w[4] = w[5] = w[7] = 0, w[9] ignored, w[10] = preprocessed width), periodic tables and node list (ops CONST,
+ * MAIN, PREPROCESSED, PERIODIC, RANDOMNESS, ADD, SUB, MUL, NEG), followed per aux column by: count, then `count` pairs (multiplicity node id,
  * denominator node id).  Semantics (aux_builder.rs:202-258): f_c(r) = sum_j m_j(r) / d_j(r) over the fractions
  * of column c with m_j(r) != 0;  aux[r][c >= 1] = f_c(r);  aux[r][0] = sum_{r' < r} sum_c f_c(r');  the one
  * aux value = the sum over all rows (`committed_finals`).  A zero denominator is MH_ERR_INVALID.
@@ -163,8 +165,8 @@ int mh_lookup_load(mh_ctx* ctx, const uint64_t* blob, size_t n_words, mh_lookup*
 void mh_lookup_free(mh_lookup* l);
 int mh_air_attach_lookup(mh_air* air, const mh_lookup* l); /* l = NULL detaches */
 /* Stand-alone: aux trace (device resident, 2 * num_cols base columns) + accumulator final of `main_trace`. */
-int mh_lookup_build_aux(mh_ctx* ctx, const mh_lookup* l, const mh_trace* main_trace, const uint64_t* randomness,
-                        size_t n_randomness, mh_trace** aux_out, uint64_t acc_final[2]);
+int mh_lookup_build_aux(mh_ctx* ctx, const mh_lookup* l, const mh_trace* main_trace, const mh_trace* preprocessed /* or NULL */,
+                        const uint64_t* randomness, size_t n_randomness, mh_trace** aux_out, uint64_t acc_final[2]);
 /* Copy a device trace back as a row-major [2^log_n][width] matrix (tests). */
 int mh_trace_download(mh_ctx* ctx, const mh_trace* t, uint64_t* rowmajor_out);
 

@@ -330,10 +330,12 @@ class DeviceAir:
         self.compiled_chunks = int(ctx.lib.mh_air_compiled_chunks(h))
         self._lookup = None
 
-    def attach_preprocessed(self, tree, matrix_index):
-        """Point this AIR at its preprocessed LDE: matrix `matrix_index` of the setup-time LmcsTree (None detaches)."""
-        self.ctx.check(self.ctx.lib.mh_air_attach_preprocessed(self.h, tree.h if tree is not None else None, C.c_int(matrix_index)))
-        self._prep_tree = tree
+    def attach_preprocessed(self, tree, matrix_index, raw=None):
+        """Point this AIR at its preprocessed LDE: matrix `matrix_index` of the setup-time LmcsTree (None detaches);
+        raw = the uploaded preprocessed Trace itself, needed only when an attached lookup program reads it."""
+        self.ctx.check(self.ctx.lib.mh_air_attach_preprocessed(self.h, tree.h if tree is not None else None, C.c_int(matrix_index),
+                                                              raw.h if raw is not None else None))
+        self._prep_tree, self._prep_raw = tree, raw
 
     def attach_lookup(self, dev_lookup):
         """Build this AIR's LogUp aux trace on the device during proofs (None detaches)."""
@@ -364,12 +366,13 @@ class DeviceLookup:
         self.h = h
         ctx._children.add(self)
 
-    def build_aux(self, main_trace, randomness):
+    def build_aux(self, main_trace, randomness, preprocessed=None):
         """-> (aux Trace on the device [n, 2 * num_cols], (c0, c1) accumulator final)."""
         rnd = _arr([int(x) for r in randomness for x in r] or [0])
         h = C.c_void_p()
         fin = np.zeros(2, dtype=np.uint64)
-        self.ctx.check(self.ctx.lib.mh_lookup_build_aux(self.ctx.h, self.h, main_trace.h, _ptr(rnd), C.c_size_t(len(randomness)),
+        self.ctx.check(self.ctx.lib.mh_lookup_build_aux(self.ctx.h, self.h, main_trace.h, preprocessed.h if preprocessed is not None else None,
+                                                        _ptr(rnd), C.c_size_t(len(randomness)),
                                                         C.byref(h), _ptr(fin)))
         return Trace.from_handle(self.ctx, h, main_trace.log_n, 2 * self.lookup.num_cols), (int(fin[0]), int(fin[1]))
 

@@ -211,7 +211,7 @@ mh_lookup* mh_lookup::load(mh_ctx* ctx, const u64* w, size_t n) {
   const size_t tail = pos + 2 * n_nodes;
   std::vector<u64> blob(w, w + tail);
   blob[0] = DAG_MAGIC;
-  blob[2] = 0; blob[4] = 0; blob[5] = 0; blob[7] = 0; blob[10] = 0;
+  blob[2] = 0; blob[4] = 0; blob[5] = 0; blob[7] = 0;  // [10] (preprocessed width) is kept: bus messages may read tables
   std::unique_ptr<mh_lookup> lk(new mh_lookup());
   lk->ctx = ctx;
   size_t p = tail;
@@ -233,6 +233,7 @@ mh_lookup* mh_lookup::load(mh_ctx* ctx, const u64* w, size_t n) {
                "lookup blob: row selectors have no meaning in a bus message");
   ir.outputs = true;
   lk->main_width = ir.main_width;
+  lk->preprocessed_width = ir.preprocessed_width;
   lk->num_cols = n_cols;
   lk->num_randomness = ir.num_randomness;
   lk->periodic = ir.periodic;

@@ -68,6 +68,7 @@ struct mh_air {
   // the setup-time tree holding this AIR's preprocessed LDE, and its matrix index there (mh_air_attach_preprocessed)
   const mh_tree* prep_tree = nullptr;
   int prep_index = -1;
+  const struct mh_trace* prep_raw = nullptr;  // the preprocessed matrix itself (trace domain): read by lookup programs
   int log_quotient_degree = 0;
   std::vector<std::vector<u64>> periodic;
   size_t n_constraints = 0;
@@ -94,7 +95,7 @@ struct mh_air {
 static const u64 LOOKUP_MAGIC = 0x4d484c4b50303031ULL;  // "MHLKP001"
 struct mh_lookup {
   mh_ctx* ctx;
-  size_t main_width = 0, num_cols = 0, num_randomness = 0;
+  size_t main_width = 0, num_cols = 0, num_randomness = 0, preprocessed_width = 0;
   std::vector<std::vector<u64>> periodic;
   std::vector<uint32_t> col_count;  // fractions of column c
   std::vector<char> out_ext;        // per output (m_0, d_0, m_1, d_1, ...): EF-valued?

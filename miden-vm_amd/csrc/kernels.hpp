@@ -119,4 +119,5 @@ u64 fri_grind(mh_ctx* c, const u64 st[12], const u64* in, int n_in, int bits);
 
 // logup.hip
 struct mh_lookup;
-mh_trace* lookup_build_aux(mh_ctx* c, const mh_lookup* lk, const mh_trace* main, const std::vector<e2>& randomness, e2* acc_final);
+mh_trace* lookup_build_aux(mh_ctx* c, const mh_lookup* lk, const mh_trace* main, const mh_trace* prep, const std::vector<e2>& randomness,
+                           e2* acc_final);

@@ -131,8 +131,11 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_add_offsets(u64* __restrict__ o
 }
 
 // Build the aux trace of `lk` over `main` with the lookup challenges `randomness` (EF pairs).
-mh_trace* lookup_build_aux(mh_ctx* c, const mh_lookup* lk, const mh_trace* main, const std::vector<e2>& randomness, e2* acc_final) {
+mh_trace* lookup_build_aux(mh_ctx* c, const mh_lookup* lk, const mh_trace* main, const mh_trace* prep, const std::vector<e2>& randomness,
+                           e2* acc_final) {
   MH_REQUIRE(main->width == lk->main_width, "lookup program was exported for a different trace width");
+  MH_REQUIRE(!lk->preprocessed_width || (prep && prep->width == lk->preprocessed_width && prep->log_n == main->log_n),
+             "lookup program reads preprocessed columns: the preprocessed matrix (same height as the trace) is required");
   MH_REQUIRE(randomness.size() >= lk->num_randomness, "not enough lookup challenges");
   const int log_n = main->log_n;
   const size_t n = (size_t)1 << log_n;
@@ -161,6 +164,7 @@ mh_trace* lookup_build_aux(mh_ctx* c, const mh_lookup* lk, const mh_trace* main,
   JitArgs j{};
   j.main_lde = main->cols.u();  // the trace itself: one "coset", B = 1
   j.aux_lde = main->cols.u();   // never read (a lookup program has no aux inputs)
+  j.prep_lde = lk->preprocessed_width ? prep->cols.u() : nullptr;  // the preprocessed matrix itself, same layout
   j.acc = planes.u();
   j.periodic = dblob.u();
   j.periodic_rows = (u32)prow;

@@ -285,7 +285,8 @@ struct mh_session {
       aux_vals[i].assign(a->num_aux_values, e2_make(0));
       if (a->lookup) {  // LogUp aux trace built on the device from the AIR's lookup program; value = acc_final
         e2 fin;
-        aux_tr[i].reset(lookup_build_aux(c, a->lookup, traces[i], randomness, &fin));
+        MH_REQUIRE(!a->lookup->preprocessed_width || a->prep_raw, "the lookup program reads preprocessed columns: attach the preprocessed matrix too");
+        aux_tr[i].reset(lookup_build_aux(c, a->lookup, traces[i], a->prep_raw, randomness, &fin));
         aux_vals[i][0] = fin;
       } else if (cb) {
         std::vector<u64> host(n * w, 0), vals(2 * std::max<size_t>(1, a->num_aux_values), 0);
@@ -696,11 +697,14 @@ int mh_air_attach_lookup(mh_air* a, const mh_lookup* l) {
     MH_REQUIRE(l->num_cols == a->aux_width, "lookup program and AIR disagree on the number of aux columns");
     MH_REQUIRE(a->num_aux_values == 1, "a LogUp AIR commits exactly one aux value (the accumulator's final)");
     MH_REQUIRE(l->num_randomness <= a->num_randomness, "lookup program needs more challenges than the AIR samples");
+    MH_REQUIRE(l->preprocessed_width == 0 || l->preprocessed_width == a->preprocessed_width,
+               "lookup program and AIR disagree on the preprocessed width");
   }
   a->lookup = l;
   MH_CATCH
 }
-int mh_lookup_build_aux(mh_ctx* c, const mh_lookup* l, const mh_trace* main_trace, const uint64_t* randomness, size_t n_randomness,
+int mh_lookup_build_aux(mh_ctx* c, const mh_lookup* l, const mh_trace* main_trace, const mh_trace* preprocessed, const uint64_t* randomness,
+                        size_t n_randomness,
                         mh_trace** aux_out, uint64_t acc_final[2]) {
   MH_TRY(c)
   MH_REQUIRE(c && l && main_trace && aux_out && acc_final && (randomness || !n_randomness), "null argument");
@@ -708,7 +712,7 @@ int mh_lookup_build_aux(mh_ctx* c, const mh_lookup* l, const mh_trace* main_trac
   std::vector<e2> rnd;
   for (size_t i = 0; i < n_randomness; i++) rnd.push_back(e2{gl_canon(randomness[2 * i]), gl_canon(randomness[2 * i + 1])});
   e2 fin;
-  *aux_out = lookup_build_aux(c, l, main_trace, rnd, &fin);
+  *aux_out = lookup_build_aux(c, l, main_trace, preprocessed, rnd, &fin);
   acc_final[0] = fin.c0;
   acc_final[1] = fin.c1;
   MH_CATCH
@@ -726,7 +730,7 @@ int mh_trace_download(mh_ctx* c, const mh_trace* t, uint64_t* rowmajor_out) {
   MH_CATCH
 }
 
-int mh_air_attach_preprocessed(mh_air* a, const mh_tree* tree, int matrix_index) {
+int mh_air_attach_preprocessed(mh_air* a, const mh_tree* tree, int matrix_index, const mh_trace* raw) {
   MH_TRY(a ? a->ctx : nullptr)
   MH_REQUIRE(a, "null argument");
   if (tree) {
@@ -735,8 +739,10 @@ int mh_air_attach_preprocessed(mh_air* a, const mh_tree* tree, int matrix_index)
     MH_REQUIRE(tree->mats[matrix_index].width == a->preprocessed_width, "preprocessed matrix width differs from the AIR's declaration");
     MH_REQUIRE(tree->mats[matrix_index].log_cosets == tree->log_blowup, "the preprocessed tree must hold every coset (single-GPU commitment)");
   }
+  if (tree && raw) MH_REQUIRE(raw->width == a->preprocessed_width, "preprocessed matrix width differs from the AIR's declaration");
   a->prep_tree = tree;
   a->prep_index = tree ? matrix_index : -1;
+  a->prep_raw = tree ? raw : nullptr;
   MH_CATCH
 }
 int mh_air_compiled_chunks(const mh_air* a) { return a ? (int)jit_program_chunks(a->jit) : -1; }

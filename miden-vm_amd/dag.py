@@ -184,8 +184,9 @@ class LookupBuilder(AirBuilder):
     columns and the lookup challenges.  Reference analogue: `LookupAir::eval` on a `ProverLookupBuilder`
     (air/src/lookup/prover.rs), whose pushes `(m, d)` per column are what build_lookup_fractions collects."""
 
-    def __init__(self, main_width, num_cols, num_randomness=2, periodic=()):
-        super().__init__(main_width, aux_width=0, num_randomness=num_randomness, periodic=periodic)
+    def __init__(self, main_width, num_cols, num_randomness=2, periodic=(), preprocessed_width=0):
+        super().__init__(main_width, aux_width=0, num_randomness=num_randomness, periodic=periodic,
+                         preprocessed_width=preprocessed_width)
         self.num_cols = num_cols
         self.columns = [[] for _ in range(num_cols)]
 
@@ -199,7 +200,8 @@ class LookupBuilder(AirBuilder):
         self.columns[col].append((m.id, d.id))
 
     def blob(self):
-        w = [LOOKUP_MAGIC, self.main_width, self.num_cols, self.num_randomness, 0, 0, len(self.periodic), 0, len(self.nodes), 0, 0, 0]
+        w = [LOOKUP_MAGIC, self.main_width, self.num_cols, self.num_randomness, 0, 0, len(self.periodic), 0, len(self.nodes), 0,
+             self.preprocessed_width, 0]
         for col in self.periodic:
             w.append(len(col))
             w.extend(col)
@@ -216,4 +218,5 @@ class LookupBuilder(AirBuilder):
 class Lookup:
     def __init__(self, builder, name="lookup"):
         self.name, self.main_width, self.num_cols, self.num_randomness = name, builder.main_width, builder.num_cols, builder.num_randomness
+        self.preprocessed_width = builder.preprocessed_width
         self.blob = builder.blob()

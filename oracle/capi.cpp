@@ -210,13 +210,14 @@ void orc_ch_finalize(void* h, uint64_t digest[4]) {
 
 // ---- LogUp aux trace (oracle/lookup.hpp) ----
 int orc_lookup_build_aux(const uint64_t* blob, size_t n_words, const uint64_t* main_rowmajor, int log_n, const uint64_t* randomness,
-                         size_t n_rand, uint64_t* aux_rowmajor, uint64_t acc_final[2], char* err, size_t errcap) {
+                         size_t n_rand, uint64_t* aux_rowmajor, uint64_t acc_final[2], char* err, size_t errcap,
+                         const uint64_t* preprocessed_rowmajor /* or NULL */) {
   try {
     Lookup lk = Lookup::parse(blob, n_words);
     std::vector<E2> rnd;
     for (size_t i = 0; i < n_rand; i++) rnd.push_back(E2{randomness[2 * i] % P, randomness[2 * i + 1] % P});
     rnd.resize(std::max(rnd.size(), lk.dag.num_randomness), e2(0));
-    E2 f = lookup_build_aux(lk, main_rowmajor, (size_t)1 << log_n, rnd.data(), aux_rowmajor);
+    E2 f = lookup_build_aux(lk, main_rowmajor, preprocessed_rowmajor, (size_t)1 << log_n, rnd.data(), aux_rowmajor);
     acc_final[0] = f.c0;
     acc_final[1] = f.c1;
     return 0;

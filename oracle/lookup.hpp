@@ -37,7 +37,7 @@ struct Lookup {
     need(tail <= n);
     std::vector<uint64_t> hdr(w, w + tail);
     hdr[0] = DAG_MAGIC;
-    hdr[2] = 0; hdr[4] = 0; hdr[5] = 0; hdr[7] = 0; hdr[9] = 0;
+    hdr[2] = 0; hdr[4] = 0; hdr[5] = 0; hdr[7] = 0; hdr[9] = 0;  // hdr[10] = preprocessed width stays
     Lookup l;
     l.dag = Air::parse(hdr.data(), hdr.size());
     l.num_cols = w[2];
@@ -58,8 +58,10 @@ struct Lookup {
 };
 
 // main: row-major [n][main_width]; aux_out: row-major [n][2 * num_cols]; returns acc_final.
-static inline E2 lookup_build_aux(const Lookup& lk, const uint64_t* main, size_t n, const E2* randomness, uint64_t* aux_out) {
-  const size_t w = lk.dag.main_width, nc = lk.num_cols;
+static inline E2 lookup_build_aux(const Lookup& lk, const uint64_t* main, const uint64_t* prep /* [n][preprocessed_width] or null */, size_t n,
+                                  const E2* randomness, uint64_t* aux_out) {
+  const size_t w = lk.dag.main_width, nc = lk.num_cols, pw = lk.dag.preprocessed_width;
+  if (pw && !prep) throw std::runtime_error("lookup program reads preprocessed columns but none were supplied");
   std::vector<E2> val(lk.dag.nodes.size());
   std::vector<E2> per_row(nc);
   E2 running = e2(0);
@@ -72,6 +74,7 @@ static inline E2 lookup_build_aux(const Lookup& lk, const uint64_t* main, size_t
       switch (nd.op) {
         case OP_CONST: v = e2(nd.c % P); break;
         case OP_MAIN: v = e2((nd.b ? nxt : cur)[nd.a] % P); break;
+        case OP_PREPROCESSED: v = e2(prep[((r + nd.b) % n) * pw + nd.a] % P); break;
         case OP_PERIODIC: v = e2(lk.dag.periodic[nd.a][r % lk.dag.periodic[nd.a].size()] % P); break;
         case OP_RANDOMNESS: v = randomness[nd.a]; break;
         case OP_ADD: v = eadd(val[nd.a], val[nd.b]); break;

@@ -300,3 +300,49 @@ def random_air(seed, width=6, aux_width=2, n_constraints=12, max_degree=4, with_
     if with_preprocessed:
         prep = np.random.default_rng(seed + 2000).integers(0, P, (1 << log_n, pw), dtype=np.uint64)
     return dag.Air(b, build_aux, f"random:{seed}", preprocessed=prep)
+
+
+# ------------------------------------------------------------------------------------------------
+def range_air(log_n, seed=23):
+    """A table lookup, the canonical LogUp + preprocessed pairing: the table T is a PREPROCESSED column (fixed circuit
+    data), the main trace holds looked-up values V (each in T) and the multiplicities M; the bus
+    sum_r 1/(alpha + V_r) - M_r/(alpha + T_r) balances iff every V is in the table.
+    Returns (Air, Lookup, trace_fn): constraint DAG, lookup program (it reads the preprocessed column), trace builder."""
+    n = 1 << log_n
+    rng = np.random.default_rng(seed)
+    table = rng.permutation(np.arange(1, 4 * n, 4, dtype=np.uint64))[:n]  # n distinct values
+
+    def denoms(b):
+        r0, r1 = b.randomness(0), b.randomness(1)
+        return r0 + b.main(0) + r1 * 2, r0 + b.preprocessed(0) + r1 * 2, b.main(1)
+
+    b = dag.AirBuilder(2, aux_width=1, num_randomness=2, num_aux_values=1, preprocessed_width=1)
+    dV, dT, M = denoms(b)
+    acc, acc_next = b.aux(0), b.aux(0, 1)
+    own = dT - M * dV
+    b.assert_zero_ext(b.is_transition() * ((acc_next - acc) * dV * dT - own))
+    b.assert_zero_ext(b.is_first_row() * acc)
+    b.assert_zero_ext(b.is_last_row() * ((b.aux_value(0) - acc) * dV * dT - own))
+    lb = dag.LookupBuilder(2, num_cols=1, num_randomness=2, preprocessed_width=1)
+    dV, dT, M = denoms(lb)
+    lb.fraction(0, 1, dV)
+    lb.fraction(0, -M, dT)
+    lookup = dag.Lookup(lb, "range")
+    prep = table.reshape(n, 1)
+
+    def build_aux(main, randomness):
+        import oracle_binding as ob
+        aux, fin = ob.lookup_build_aux(lookup, main, randomness, preprocessed=prep)
+        return aux, [int(fin[0]), int(fin[1])]
+
+    def trace(seed2=29, valid=True):
+        r2 = np.random.default_rng(seed2)
+        picks = r2.integers(0, n, n)
+        m = np.zeros((n, 2), dtype=np.uint64)
+        m[:, 0] = table[picks]
+        m[:, 1] = np.bincount(picks, minlength=n).astype(np.uint64)
+        if not valid:
+            m[3, 0] = 2  # not in the table (all entries are 1 mod 4)
+        return m
+
+    return dag.Air(b, build_aux, f"range:{log_n}", preprocessed=prep), lookup, trace

@@ -257,7 +257,7 @@ def verify(airs, log_heights, publics, proof, params=PROD_PARAMS, init_state=Non
     return (True, digest) if rc == 0 else (False, err.value.decode())
 
 
-def lookup_build_aux(lookup, main, randomness):
+def lookup_build_aux(lookup, main, randomness, preprocessed=None):
     """oracle/lookup.hpp: (aux[n, 2 * num_cols] uint64, acc_final[2]) of a dag.Lookup over a row-major main trace."""
     m = arr(main)
     n = m.shape[0]
@@ -268,7 +268,8 @@ def lookup_build_aux(lookup, main, randomness):
     err = C.create_string_buffer(512)
     L = lib()
     rc = L.orc_lookup_build_aux(ptr(blob), C.c_size_t(blob.size), ptr(m), C.c_int(n.bit_length() - 1), ptr(rnd),
-                                C.c_size_t(len(randomness)), ptr(aux), ptr(fin), err, C.c_size_t(512))
+                                C.c_size_t(len(randomness)), ptr(aux), ptr(fin), err, C.c_size_t(512),
+                                ptr(arr(preprocessed)) if preprocessed is not None else None)
     if rc != 0:
         raise RuntimeError("oracle lookup_build_aux failed: " + err.value.decode())
     return aux, fin

@@ -113,3 +113,44 @@ def test_lookup_on_one_air_of_several(ctx):
                     ob.protocol_pre_observe(FAST, []), aux_builder)
     assert asked == [1]
     assert (got.fields == exp["fields"]).all() and (got.commitments == exp["commitments"]).all() and (got.digest == exp["digest"]).all()
+
+
+@pytest.mark.parametrize("log_n,valid", [(5, True), (9, False), (14, True)])
+def test_table_lookup_reads_preprocessed_column_on_the_device(ctx, log_n, valid):
+    pkg = load_package()
+    air, lookup, trace = A.range_air(log_n)
+    main = trace(valid=valid)
+    dl = pkg.DeviceLookup(ctx, lookup)
+    aux_dev, fin = dl.build_aux(ctx.upload_trace(main), RND, preprocessed=ctx.upload_trace(air.preprocessed))
+    aux, exp_fin = ob.lookup_build_aux(lookup, main, RND, preprocessed=air.preprocessed)
+    assert (aux_dev.download() == aux).all()
+    assert fin == (int(exp_fin[0]), int(exp_fin[1])) and (fin == (0, 0)) == valid
+    with pytest.raises(pkg.MidenHipError, match="preprocessed"):
+        dl.build_aux(ctx.upload_trace(main), RND)  # the table is required
+
+
+def test_range_check_proof_all_on_device(ctx):
+    """Preprocessed table + lookup program + compiled constraints: setup commits the table, the proof builds the aux
+    trace on the device from main and preprocessed columns; equal to the oracle's proof and accepted by both verifiers."""
+    pkg = load_package()
+    log_n = 8
+    air, lookup, trace = A.range_air(log_n)
+    main = trace()
+    exp = ob.prove([air], [main], [], FAST)
+    dair = pkg.DeviceAir(ctx, air)
+    raw = ctx.upload_trace(air.preprocessed)
+    com = pkg.commit_traces(ctx, [raw], FAST["log_blowup"])
+    assert list(com.root()) == [int(x) for x in exp["preprocessed_root"]]
+    dair.attach_preprocessed(com.tree(), 0, raw=raw)
+    dair.attach_lookup(pkg.DeviceLookup(ctx, lookup))
+    pre = ob.protocol_pre_observe(FAST, [], preprocessed_root=com.root())
+    got = pkg.prove(ctx, [dair], [ctx.upload_trace(main)], [], FAST, ob.challenger_state(), pre, None)
+    assert (got.fields == exp["fields"]).all() and (got.commitments == exp["commitments"]).all() and (got.digest == exp["digest"]).all()
+    ok, msg = ob.verify([air], [log_n], [], {"fields": got.fields, "commitments": got.commitments}, FAST)
+    assert ok, msg
+    ok2, dig = pkg.verify([air], [log_n], [], FAST, ob.challenger_state(), pre, got.fields, got.commitments, preprocessed_root=com.root())
+    assert ok2 and (dig == got.digest).all()
+    # without the raw table the lookup program cannot run
+    dair.attach_preprocessed(com.tree(), 0)
+    with pytest.raises(pkg.MidenHipError, match="preprocessed"):
+        pkg.prove(ctx, [dair], [ctx.upload_trace(main)], [], FAST, ob.challenger_state(), pre, None)

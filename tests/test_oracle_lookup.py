@@ -63,3 +63,26 @@ def test_logup_air_oracle_prove_verify():
     proof = ob.prove([air], [main], [], params)
     ok, msg = ob.verify([air], [5], [], proof, params)
     assert ok, msg
+
+
+def test_table_lookup_into_a_preprocessed_column():
+    """range_air: the lookup program reads a PREPROCESSED column; the bus balances iff every value is in the table,
+    and the whole thing proves and verifies (oracle prover / oracle verifier / the product's mh_verify)."""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    air, lookup, trace = A.range_air(5)
+    rnd = [(1234567, 89), (777, 3)]
+    aux, fin = ob.lookup_build_aux(lookup, trace(), rnd, preprocessed=air.preprocessed)
+    assert (int(fin[0]), int(fin[1])) == (0, 0) and (aux[0, :2] == 0).all()
+    _, fin_bad = ob.lookup_build_aux(lookup, trace(valid=False), rnd, preprocessed=air.preprocessed)
+    assert (int(fin_bad[0]), int(fin_bad[1])) != (0, 0)
+    params = dict(log_blowup=2, log_folding_arity=1, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=1, num_queries=6,
+                  query_pow_bits=2)
+    proof = ob.prove([air], [trace()], [], params)
+    ok, msg = ob.verify([air], [5], [], proof, params)
+    assert ok, msg
+    root = proof["preprocessed_root"]
+    ok2, dig = pkg.verify([air], [5], [], params, ob.challenger_state(), ob.protocol_pre_observe(params, [], preprocessed_root=root),
+                          proof["fields"], proof["commitments"], preprocessed_root=root)
+    assert ok2 and (dig == proof["digest"]).all()
+    assert (proof["fields"][:2] == 0).all()  # the committed accumulator final: balanced
