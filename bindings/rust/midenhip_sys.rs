@@ -102,6 +102,7 @@ unsafe extern "C" {
     pub fn mh_lookup_build_aux(ctx: *mut mh_ctx, l: *const mh_lookup, main_trace: *const mh_trace, preprocessed: *const mh_trace, randomness: *const u64, n_randomness: usize, aux_out: *mut *mut mh_trace, acc_final: *mut u64) -> c_int;
     // ---- proofs ----
     pub fn mh_prove(ctx: *mut mh_ctx, params: *const mh_pcs_params, n_airs: c_int, airs: *const *mut mh_air, traces: *const *mut mh_trace, public_values: *const u64, n_public_values: usize, challenger_state: *const u64, pre_observe: *const u64, n_pre_observe: usize, aux_builder: mh_aux_builder, user: *mut c_void, out: *mut *mut mh_proof) -> c_int;
+    pub fn mh_commit_traces_sharded(ctx: *mut mh_ctx, comm: *const mh_comm, n_traces: c_int, traces: *const *mut mh_trace, log_blowup: c_int, out: *mut *mut mh_tree, root: *mut u64) -> c_int;
     pub fn mh_prove_sharded(ctx: *mut mh_ctx, comm: *const mh_comm, params: *const mh_pcs_params, n_airs: c_int, airs: *const *mut mh_air, traces: *const *mut mh_trace, public_values: *const u64, n_public_values: usize, challenger_state: *const u64, pre_observe: *const u64, n_pre_observe: usize, aux_builder: mh_aux_builder, user: *mut c_void, out: *mut *mut mh_proof) -> c_int;
     pub fn mh_session_begin(ctx: *mut mh_ctx, comm: *const mh_comm, params: *const mh_pcs_params, n_airs: c_int, airs: *const *mut mh_air, traces: *const *mut mh_trace, public_values: *const u64, n_public_values: usize, out: *mut *mut mh_session) -> c_int;
     pub fn mh_session_free(s: *mut mh_session);

@@ -210,6 +210,10 @@ typedef struct mh_comm {
   int (*all_gather)(void* user, const void* send_dev, void* recv_dev, size_t bytes_per_rank);
   int (*all_reduce_sum_u64)(void* user, uint64_t* buf_dev, size_t n);
 } mh_comm;
+/* mh_commit_traces for one rank of a sharded prover (every rank calls it with the same traces): the setup commitment
+ * of preprocessed matrices for mh_prove_sharded / sharded sessions.  Same root as mh_commit_traces. */
+int mh_commit_traces_sharded(mh_ctx* ctx, const mh_comm* comm, int n_traces, mh_trace* const* traces, int log_blowup,
+                             mh_tree** out, uint64_t root[4]);
 int mh_prove_sharded(mh_ctx* ctx, const mh_comm* comm, const mh_pcs_params* params, int n_airs, mh_air* const* airs,
                      mh_trace* const* traces, const uint64_t* public_values, size_t n_public_values,
                      const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe,

@@ -229,7 +229,6 @@ struct mh_session {
       if (!a->preprocessed_width) continue;
       MH_REQUIRE(a->prep_tree, "AIR declares preprocessed columns but no preprocessed tree is attached");
       MH_REQUIRE(!prep_tree || prep_tree == a->prep_tree, "all AIRs must share one preprocessed tree");
-      MH_REQUIRE(!dist.on(), "sharded proofs with preprocessed columns are not supported");
       prep_tree = a->prep_tree;
       MH_REQUIRE(a->prep_index == n_prep, "preprocessed matrices must be committed in proof order (ascending height, ties by instance)");
       MH_REQUIRE((size_t)a->prep_index < prep_tree->mats.size(), "preprocessed matrix index out of range");
@@ -240,6 +239,8 @@ struct mh_session {
     }
     if (prep_tree) {
       MH_REQUIRE(prep_tree->log_blowup == lb, "preprocessed tree was committed under a different blowup");
+      MH_REQUIRE(prep_tree->shard_logG == dist.logG && (!dist.on() || prep_tree->shard_rank == dist.rank),
+                 "preprocessed tree was committed for a different sharding (use mh_commit_traces_sharded with the same communicator)");
       MH_REQUIRE((int)prep_tree->mats.size() == n_prep, "preprocessed tree holds matrices no AIR declares");
     }
     rounds = fri_num_rounds(pp, L);
@@ -534,7 +535,7 @@ struct mh_session {
     for (size_t i : idx) MH_REQUIRE(i < ((size_t)1 << L), "query index out of range");
     if (prep_tree) {  // a tree shorter than the max domain is virtually lifted: indices fold by their low bits
       std::vector<size_t> pidx(idx);
-      const size_t mask = ((size_t)1 << prep_tree->log_height) - 1;
+      const size_t mask = ((size_t)1 << (prep_tree->log_height + prep_tree->shard_logG)) - 1;  // full depth (a rank stores a subtree)
       for (auto& i : pidx) i &= mask;
       std::sort(pidx.begin(), pidx.end());
       pidx.erase(std::unique(pidx.begin(), pidx.end()), pidx.end());
@@ -737,7 +738,6 @@ int mh_air_attach_preprocessed(mh_air* a, const mh_tree* tree, int matrix_index,
     MH_REQUIRE(a->preprocessed_width > 0, "this AIR declares no preprocessed columns");
     MH_REQUIRE(matrix_index >= 0 && (size_t)matrix_index < tree->mats.size(), "preprocessed matrix index out of range");
     MH_REQUIRE(tree->mats[matrix_index].width == a->preprocessed_width, "preprocessed matrix width differs from the AIR's declaration");
-    MH_REQUIRE(tree->mats[matrix_index].log_cosets == tree->log_blowup, "the preprocessed tree must hold every coset (single-GPU commitment)");
   }
   if (tree && raw) MH_REQUIRE(raw->width == a->preprocessed_width, "preprocessed matrix width differs from the AIR's declaration");
   a->prep_tree = tree;
@@ -820,6 +820,34 @@ int mh_merkle_cap_root(const uint64_t* subroots, int world, uint64_t root[4]) {
   }
   memcpy(root, cur.data(), 32);
   return MH_OK;
+}
+
+// commit_traces for one rank of a sharded prover: the setup-time commitment of preprocessed matrices when proofs are
+// sharded (same root as mh_commit_traces; this rank keeps its cosets and its slice of the tree).
+int mh_commit_traces_sharded(mh_ctx* c, const mh_comm* comm, int n_traces, mh_trace* const* traces, int log_blowup, mh_tree** out,
+                             uint64_t root[4]) {
+  MH_TRY(c)
+  MH_REQUIRE(c && comm && traces && out && n_traces > 0, "null/empty argument");
+  MH_REQUIRE(log_blowup >= 0 && log_blowup <= 8, "bad log_blowup");
+  MH_REQUIRE(comm->world >= 1 && (comm->world & (comm->world - 1)) == 0 && comm->rank >= 0 && comm->rank < comm->world,
+             "world must be a power of two and 0 <= rank < world");
+  MH_REQUIRE(comm->world == 1 || (comm->all_to_all && comm->all_gather && comm->all_reduce_sum_u64), "missing collective callbacks");
+  HIP_CHECK(hipSetDevice(c->device));
+  Dist d;
+  if (comm->world > 1) {
+    d.comm = comm; d.rank = comm->rank; d.world = comm->world;
+    while ((1 << d.logG) < d.world) d.logG++;
+    MH_REQUIRE(d.logG <= log_blowup, "more ranks than cosets");
+  }
+  std::vector<const mh_trace*> v;
+  for (int i = 0; i < n_traces; i++) {
+    MH_REQUIRE(traces[i] && traces[i]->log_n >= d.logG, "null trace / trace shorter than the number of ranks");
+    v.push_back(traces[i]);
+  }
+  std::unique_ptr<mh_tree> t(commit_traces_dist(c, v, log_blowup, d));
+  if (root) memcpy(root, t->root, 32);
+  *out = t.release();
+  MH_CATCH
 }
 
 int mh_prove(mh_ctx* c, const mh_pcs_params* params, int n_airs, mh_air* const* airs, mh_trace* const* traces,

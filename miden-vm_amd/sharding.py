@@ -181,6 +181,17 @@ class TorchComm:
         return self._wrap(go)
 
 
+def commit_traces_sharded(pkg, ctx, comm, traces, log_blowup):
+    """mh_commit_traces_sharded: this rank's part of the commitment (e.g. the preprocessed setup tree of a sharded prover)."""
+    n = len(traces)
+    arr = (C.c_void_p * n)(*[t.h for t in traces])
+    h = C.c_void_p()
+    root = np.zeros(4, dtype=np.uint64)
+    ctx.check(ctx.lib.mh_commit_traces_sharded(ctx.h, C.byref(comm.struct), n, arr, log_blowup, C.byref(h),
+                                               root.ctypes.data_as(C.POINTER(C.c_uint64))))
+    return pkg.Committed(pkg.LmcsTree(ctx, h, [t.width for t in traces], [t.log_n for t in traces], log_blowup))
+
+
 def prove_sharded(pkg, ctx, comm, airs, traces, public_values, params, challenger_state, pre_observe, aux_builder=None):
     """mh_prove_sharded: same arguments as pkg.prove plus the communicator; every rank gets the proof."""
     n = len(airs)

@@ -70,6 +70,11 @@ def _prove_worker(rank, world, port, case, ret):
         elif case == "miden_small":
             airs_, traces, pub, prm = [dag.dummy_miden_air(11, 2)], [A.dummy_trace(6, 11)], [], dict(
                 log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=5, query_pow_bits=3)
+        elif case == "range_preprocessed":  # preprocessed table (sharded setup tree) + device-built LogUp aux
+            rair, rlookup, rtrace = A.range_air(7)
+            airs_, traces, pub = [rair], [rtrace()], []
+            prm = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=6,
+                       query_pow_bits=3)
         elif case == "logup_compiled":  # compiled constraint kernels + device-built LogUp aux trace on every rank
             os.environ["MH_JIT"] = "1"
             os.environ["MH_JIT_CHUNK"] = "24"
@@ -85,6 +90,16 @@ def _prove_worker(rank, world, port, case, ret):
         dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
         dtr = [ctx.upload_trace(t) for t in traces]
         need_cb = any(a.build_aux is not None for a in airs_)
+        prep_root = None
+        comm = sharding.TorchComm(rank, world)
+        if case == "range_preprocessed":
+            raw = ctx.upload_trace(rair.preprocessed)
+            com1 = pkg.commit_traces(ctx, [raw], prm["log_blowup"])                              # single-GPU tree (reference run)
+            comS = sharding.commit_traces_sharded(pkg, ctx, comm, [raw], prm["log_blowup"])      # this rank's part
+            assert list(com1.root()) == list(comS.root())
+            prep_root = com1.root()
+            lk = pkg.DeviceLookup(ctx, rlookup)
+            need_cb = False
         if case == "logup_compiled":
             assert dairs[0].compiled_chunks > 1
             dairs[0].attach_lookup(pkg.DeviceLookup(ctx, lookup))
@@ -96,9 +111,13 @@ def _prove_worker(rank, world, port, case, ret):
                 return np.zeros((traces[idx].shape[0], 2 * a.aux_width), dtype=np.uint64), [0] * (2 * a.num_aux_values)
             return a.build_aux(traces[idx], rnd[:a.num_randomness])
 
-        st, pre = ob.challenger_state(), ob.protocol_pre_observe(prm, pub)
-        comm = sharding.TorchComm(rank, world)
+        st, pre = ob.challenger_state(), ob.protocol_pre_observe(prm, pub, preprocessed_root=prep_root)
+        if case == "range_preprocessed":
+            dairs[0].attach_lookup(lk)
+            dairs[0].attach_preprocessed(comS.tree(), 0, raw=raw)
         got = sharding.prove_sharded(pkg, ctx, comm, dairs, dtr, pub, prm, st, pre, aux_builder if need_cb else None)
+        if case == "range_preprocessed":
+            dairs[0].attach_preprocessed(com1.tree(), 0, raw=raw)
         ref = pkg.prove(ctx, dairs, dtr, pub, prm, st, pre, aux_builder if need_cb else None)
         same = (got.fields.size == ref.fields.size and (got.fields == ref.fields).all()
                 and got.commitments.shape == ref.commitments.shape and (got.commitments == ref.commitments).all()
@@ -116,7 +135,7 @@ def _prove_worker(rank, world, port, case, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case", [(2, "miden_small"), (8, "miden_small"), (2, "multi"), (2, "logup_compiled"), (4, "miden"),
+@pytest.mark.parametrize("world,case", [(2, "miden_small"), (8, "miden_small"), (2, "multi"), (2, "logup_compiled"), (2, "range_preprocessed"), (4, "miden"),
                                         (8, "miden")])
 def test_sharded_proof_equals_single_gpu_proof(world, case):
     port = 29500 + (os.getpid() + 31 * world + len(case)) % 2000
