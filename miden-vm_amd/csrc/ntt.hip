@@ -436,19 +436,40 @@ void ntt_inverse_dif_inplace(mh_ctx* c, u64* cols, size_t n_cols, int log_n) {
 // Coset tables: for each output coset z (base s_z): lo[z][x] = s_z^x (x < 2^lb),
 // hi[z][y] = s_z^(y * 2^lb) * post_scale (y < 2^(log_n - lb)).
 struct CosetTables {
-  DevBuf lo, hi;
+  const u64* lo;
+  const u64* hi;
   int lb;
 };
-static CosetTables make_coset_tables(mh_ctx* c, int log_n, const std::vector<u64>& bases, u64 post_scale) {
+// Built once per (size, set of cosets) and kept in the context: a proof re-uses the same ten sets every time
+// (main/aux LDE, one per quotient chunk), 160 tiny launches per proof otherwise.
+static CosetTables coset_tables(mh_ctx* c, int log_n, const std::vector<u64>& bases, u64 post_scale) {
   CosetTables t;
   t.lb = (log_n + 1) / 2;
-  size_t nlo = (size_t)1 << t.lb, nhi = (size_t)1 << (log_n - t.lb);
-  t.lo.alloc(bases.size() * nlo * 8);
-  t.hi.alloc(bases.size() * nhi * 8);
-  for (size_t z = 0; z < bases.size(); z++) {
-    fill_powers(c, t.lo.u() + z * nlo, nlo, bases[z], 1);
-    fill_powers(c, t.hi.u() + z * nhi, nhi, gl_exp_pow2(bases[z], t.lb), post_scale);
+  const size_t nlo = (size_t)1 << t.lb, nhi = (size_t)1 << (log_n - t.lb);
+  u64 h = 0xcbf29ce484222325ULL ^ (u64)log_n;
+  for (u64 b : bases) h = (h ^ b) * 0x100000001b3ULL + (h >> 29);
+  h = (h ^ post_scale) * 0x100000001b3ULL;
+  const std::string key = "coset:" + std::to_string(log_n) + ":" + std::to_string(bases.size()) + ":" + std::to_string(h);
+  auto it = c->tables.find(key);
+  if (it == c->tables.end()) {
+    DevBuf b((bases.size() * (nlo + nhi)) * 8);
+    for (size_t z = 0; z < bases.size(); z++) {
+      fill_powers(c, b.u() + z * nlo, nlo, bases[z], 1);
+      fill_powers(c, b.u() + bases.size() * nlo + z * nhi, nhi, gl_exp_pow2(bases[z], t.lb), post_scale);
+    }
+    // keep the exact key material so that a hash collision cannot hand back another set's table
+    std::vector<size_t> ident(bases.begin(), bases.end());
+    ident.push_back((size_t)post_scale);
+    c->table_index[key] = ident;
+    it = c->tables.emplace(key, std::move(b)).first;
+  } else {
+    const std::vector<size_t>& ident = c->table_index[key];
+    bool same = ident.size() == bases.size() + 1 && ident.back() == (size_t)post_scale;
+    for (size_t z = 0; same && z < bases.size(); z++) same = ident[z] == (size_t)bases[z];
+    MH_REQUIRE(same, "internal: coset table key collision");
   }
+  t.lo = it->second.u();
+  t.hi = it->second.u() + bases.size() * nlo;
   return t;
 }
 
@@ -460,7 +481,7 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
   size_t N = (size_t)1 << log_n;
   size_t nz = bases.size();
   u64 n_inv = gl_inv((u64)N % GL_P);
-  CosetTables t = make_coset_tables(c, log_n, bases, n_inv);
+  const CosetTables t = coset_tables(c, log_n, bases, n_inv);
   auto plan = plan_passes(log_n);
   const NttPlanes tw = ntt_planes(c, log_n, false, plan);
   for (size_t i = 0; i < plan.size(); i++) {
@@ -471,7 +492,7 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
     if (i == 0) {
       a.src = coef_br;
       a.src_col_stride = N;
-      a.scale_lo = t.lo.u(); a.scale_hi = t.hi.u(); a.lb = t.lb;
+      a.scale_lo = t.lo; a.scale_hi = t.hi; a.lb = t.lb;
       a.scale_lo_z = (size_t)1 << t.lb;
       a.scale_hi_z = (size_t)1 << (log_n - t.lb);
     } else {
@@ -492,8 +513,6 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
       launch_pass(c, a, n_cols * nz, 1);
     }
   }
-  // the tables must outlive the kernels that read them
-  HIP_CHECK(hipStreamSynchronize(c->stream));
 }
 
 // LDE of column-major columns: evaluations on a*H (natural) -> evaluations on b_z*H for all z.
