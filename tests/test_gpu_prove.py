@@ -498,3 +498,11 @@ def test_random_constraint_systems(ctx, seed, monkeypatch):
         bad = np.nonzero(got.fields[:nf] != exp["fields"][:nf])[0]
         assert bad.size == 0 and got.fields.size == exp["fields"].size, f"MH_JIT={mode}: first differing field {bad[:1]}"
         assert (got.commitments == exp["commitments"]).all() and (got.digest == exp["digest"]).all()
+
+
+def test_miden_bench_cli_default_parameters(ctx):
+    """benches/miden-bench/src/cli.rs:7-8 defaults (100 queries, 16 DEEP PoW bits) instead of the production set: many
+    duplicate query indices on a small domain, a 16-bit device grind in the DEEP phase."""
+    prm = dict(log_blowup=3, log_folding_arity=2, log_final_degree=7, folding_pow_bits=4, deep_pow_bits=16, num_queries=100,
+               query_pow_bits=16)
+    check_same(ctx, [dag.dummy_miden_air(51, 8)], [A.dummy_trace(9, 51, seed=31)], [], prm)
