@@ -23,6 +23,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def synth_trace(rng, log_n, width):
     """DummyMidenAir trace shape (crates/lifted-stark/src/testing/airs/miden.rs:105-124): column 0
     all-zero, the rest uniform in [0, p).  Seeded numpy PCG64 (SmallRng is not reproducible here)."""
@@ -46,7 +56,7 @@ def cpu_baseline_commit(log_n_sample, widths, log_blowup):
         ob.commit_traces([t], log_blowup)
     dt = time.perf_counter() - t0
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {"value": (1 << log_n_sample) / dt, "unit": "trace rows/s", "cores": cores, "kind": "port",
+    return {"value": (1 << log_n_sample) / dt, "unit": "trace rows/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"oracle commit_traces (coset LDE x{1 << log_blowup} + LMCS) of 2^{log_n_sample} x {widths} "
                       f"in {dt:.2f} s, OpenMP {cores} threads"}
 
@@ -169,7 +179,10 @@ class ProveRunner:
         cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
         return {"value": (1 << log_s) / dt, "unit": "trace rows/s", "cores": cores, "kind": "port",
                 "sample": f"CPU restatement (oracle/, OpenMP {cores} threads) proving miden:{log_s}:51:8 with the same "
-                          f"parameters in {dt:.2f} s"}
+                          f"parameters in {dt:.2f} s",
+                "cpu_model": cpu_model(),
+                "note": "a plain restatement, not the reference's tuned Rayon/AVX prover (unbuildable here: no Rust); the "
+                        "reference publishes 152 k rows/s for this configuration on a 64-thread EPYC 9R45 (README.md:151)"}
 
 
 def sharded_prove_probe(pkg, ctx, args, rank, world, runner):
