@@ -15,7 +15,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmidenhip.so")
+LIB_PATH = os.environ.get("MIDENHIP_LIB") or os.path.join(_HERE, "lib", "libmidenhip.so")  # override: experiment builds only
 P = 0xFFFFFFFF00000001
 u64p = C.POINTER(C.c_uint64)
 

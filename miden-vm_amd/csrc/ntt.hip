@@ -22,6 +22,17 @@
 #include "kernels.hpp"
 #include "poseidon2_fast.cuh"
 
+// Field multiplications of the passes: the asm form of poseidon2_fast.cuh (volatile statements, in interleaved
+// groups) or the compiler-scheduled C form.  Measured per 2^20-row proof: see DESIGN.md section 3.
+#ifndef NTT_ASM_MUL
+#define NTT_ASM_MUL 0
+#endif
+#if P2F_ASM && NTT_ASM_MUL
+#define NTT_MUL1 p2f_mul
+#else
+#define NTT_MUL1 p2f_mul_c
+#endif
+
 // LDS tile of a pass: 2^12 elements (34 KB with padding, 256 threads, 4 workgroups per CU) up to 2^20-point
 // transforms; 2^14 elements (136 KB, 1024 threads, one workgroup per CU -- the same 4 waves per SIMD) beyond, so
 // that 2^21 and 2^22 still take two passes over HBM instead of three.
@@ -191,10 +202,36 @@ __device__ __forceinline__ void ntt_dft_regs(u64 (&x)[1 << G], bool dif) {
         if (!(e & (1 << m))) ntt_bfly_dif(x[e], x[e | (1 << m)], (W16 * (8 >> m) * (e & ((1 << m) - 1))) % 192);
   }
 }
+// x[e] *= tw[(e - 1) << s | gm] for e = OFF .. OFF + K - 1: the table twiddles of a round, multiplied in interleaved
+// groups of <= 5 products (p2f_mulN); consecutive lanes = consecutive gm: coalesced loads
+template <int K, int OFF>
+__device__ __forceinline__ void ntt_tw_mul(u64* x, const u64* __restrict__ tw, int s, u32 gm) {
+  if constexpr (K > 0) {
+    constexpr int C = K >= 5 ? 5 : K;
+    u64 a[C], b[C];
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      a[i] = x[OFF + i];
+      b[i] = tw[((size_t)(OFF + i - 1) << s) | gm];
+    }
+#if P2F_ASM && NTT_ASM_MUL
+    p2f_mulN<C>(a, a, b);
 #else
+#pragma unroll
+    for (int i = 0; i < C; i++) a[i] = p2f_mul_c(a[i], b[i]);
+#endif
+#pragma unroll
+    for (int i = 0; i < C; i++) x[OFF + i] = a[i];
+    ntt_tw_mul<K - C, OFF + C>(x, tw, s, gm);
+  }
+}
+#else
+template <int K, int OFF>
+__device__ void ntt_tw_mul(u64* x, const u64* __restrict__ tw, int s, u32 gm);
 template <int G, bool INV>
 __device__ void ntt_dft_regs(u64 (&x)[1 << G], bool dif);
 __device__ u64 ntt_canon(u64 t);
+__device__ u64 p2f_mul_c(u64 a, u64 b);
 #endif
 
 #ifndef NTT16_OCC
@@ -215,19 +252,9 @@ __device__ __forceinline__ void ntt_round(const NttPassArgs& a, u64* lds, int st
     u64 x[1 << G];
 #pragma unroll
     for (int e = 0; e < (1 << G); e++) x[e] = lds[ntt_pad(l0 | ((u32)e << b0))];
-    if (!INV && s > 0) {
-#pragma unroll
-      for (int e = 1; e < (1 << G); e++) {
-        x[e] = p2f_mul(x[e], tw[((size_t)(e - 1) << s) | gm]);  // consecutive lanes = consecutive gm: coalesced
-      }
-    }
+    if (!INV && s > 0) ntt_tw_mul<(1 << G) - 1, 1>(x, tw, s, gm);
     ntt_dft_regs<G, INV>(x, INV);
-    if (INV && s > 0) {
-#pragma unroll
-      for (int e = 1; e < (1 << G); e++) {
-        x[e] = p2f_mul(x[e], tw[((size_t)(e - 1) << s) | gm]);
-      }
-    }
+    if (INV && s > 0) ntt_tw_mul<(1 << G) - 1, 1>(x, tw, s, gm);
     if (dst_direct) {
 #pragma unroll
       for (int e = 0; e < (1 << G); e++) {
@@ -261,9 +288,9 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
     u64 v = src[g];
     if (a.scale_lo) {
       u32 k = bitrev32((u32)g, a.log_n);
-      u64 sc = p2f_mul(a.scale_lo[blockIdx.z * a.scale_lo_z + (k & ((1u << a.lb) - 1))],
-                       a.scale_hi[blockIdx.z * a.scale_hi_z + (k >> a.lb)]);
-      v = p2f_mul(v, sc);
+      u64 sc = NTT_MUL1(a.scale_lo[blockIdx.z * a.scale_lo_z + (k & ((1u << a.lb) - 1))],
+                        a.scale_hi[blockIdx.z * a.scale_hi_z + (k >> a.lb)]);
+      v = NTT_MUL1(v, sc);
     }
     lds[ntt_pad(l)] = v;
   }

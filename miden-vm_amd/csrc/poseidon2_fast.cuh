@@ -22,6 +22,13 @@ namespace p2c {
 #include "p2_fast_constants.inc"
 }
 
+#ifndef P2F_ASM
+#define P2F_ASM 1  // 1: multiplication with SGPR carry chains in inline asm; 0: plain C (see p2f_mul)
+#endif
+#ifndef P2F_GROUP
+#define P2F_GROUP 4  // S-boxes of an external round interleaved per asm block
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__)
 
 // acc + x * K as ONE v_mad_u64_u32 (32x32+64).  Inline asm because LLVM re-associates the C form
@@ -43,7 +50,21 @@ __device__ __forceinline__ u32 lo32(u64 x) { return (u32)x; }
 __device__ __forceinline__ u32 hi32(u64 x) { return (u32)(x >> 32); }
 
 // a*b mod p for ANY a, b < 2^64; result is some representative < 2^64 (not canonical).
-__device__ __forceinline__ u64 p2f_mul(u64 a, u64 b) {
+//
+// Two forms (P2F_ASM, default 1):
+//  * P2F_ASM = 0: plain C.  hipcc turns it into ~23 VALU instructions: every 32 -> 64-bit zero extension is a
+//    v_mov into an even-aligned pair, every carry a v_cmp_lt_u64 + v_cndmask + 64-bit add.
+//  * P2F_ASM = 1: 13 VALU + 2 SALU.  Carries never become vector values: v_mad_u64_u32's own carry-out and
+//    v_add_co / v_addc_co / v_subb_co chains hand them over in SGPR pairs, the two flag combinations run on the
+//    scalar unit, and the partial sums are written straight into the halves of the register pair the next
+//    v_mad_u64_u32 accumulates (no moves):
+//        p00 = a0*b0;  m = a0*b1;  m += a1*b0 (carry cm);  w1 = p00.hi + m.lo (k1);  acc.lo = m.hi + k1 (k2);
+//        acc.hi = cm|k2;  hi = a1*b1 + acc;  lo = {p00.lo, w1}
+//        t = hi.lo*(2^32-1) + lo (c1);   r = t - hi.hi + (c1 - borrow)*(2^32-1)   [2^64 = 2^32-1, 2^96 = -1 mod p]
+//    gfx950 needs 2 wait states between a VALU that writes an SGPR and a VALU that reads it; the statements are
+//    `asm volatile` (kept in program order), N independent products are interleaved stage by stage so that for
+//    N >= 3 the distance is there by construction, and N = 1, 2 insert the missing s_nop themselves.
+__device__ __forceinline__ u64 p2f_mul_c(u64 a, u64 b) {
   const u32 a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
   const u64 p00 = (u64)a0 * b0;
   const u64 m = (u64)a0 * b1 + (p00 >> 32);
@@ -57,16 +78,136 @@ __device__ __forceinline__ u64 p2f_mul(u64 a, u64 b) {
   r -= (t < x3) ? GL_EPS : 0;
   return r;
 }
-// (A hand-scheduled x^7 -- VCC carry chains, even-aligned register pairs with standing zeros, 17 VALU
-// per multiplication instead of 25, two multiplications interleaved to cover the VCC wait states --
-// was measured at 2.86-2.92 G perm/s vs 2.93 for this compiler-scheduled form: the saved instructions
-// were 4-byte v_mov's, the added carry ops are 8-byte VOP3 encodings that issue ~1.5x slower, so it
-// was dropped.)
+#define P2F_A asm volatile
+// wait states still missing between stage k of product i and stage k+1 of the same product (N-1 instructions lie between)
+#define P2F_GAP()                      \
+  do {                                 \
+    if (N == 1) P2F_A("s_nop 1");      \
+    else if (N == 2) P2F_A("s_nop 0"); \
+  } while (0)
+// v_mad_u64_u32 always writes a carry-out pair.  Where it is not needed it goes to one of eight fixed scratch pairs,
+// rotating between neighbouring statements: hipcc separates two inline-asm statements that touch a common
+// register by an s_nop (its dst-forwarding rule cannot see inside the asm), and it would hand every dead carry the
+// same pair.
+#define P2F_SCR(i, PRE, POST, ...)                                                  \
+  do {                                                                              \
+    switch ((i) & 7) {                                                              \
+      case 0: P2F_A(PRE "s[84:85]" POST : __VA_ARGS__ : "s84", "s85"); break;        \
+      case 1: P2F_A(PRE "s[86:87]" POST : __VA_ARGS__ : "s86", "s87"); break;        \
+      case 2: P2F_A(PRE "s[88:89]" POST : __VA_ARGS__ : "s88", "s89"); break;        \
+      case 3: P2F_A(PRE "s[90:91]" POST : __VA_ARGS__ : "s90", "s91"); break;        \
+      case 4: P2F_A(PRE "s[92:93]" POST : __VA_ARGS__ : "s92", "s93"); break;        \
+      case 5: P2F_A(PRE "s[94:95]" POST : __VA_ARGS__ : "s94", "s95"); break;        \
+      case 6: P2F_A(PRE "s[96:97]" POST : __VA_ARGS__ : "s96", "s97"); break;        \
+      default: P2F_A(PRE "s[98:99]" POST : __VA_ARGS__ : "s98", "s99"); break;       \
+    }                                                                               \
+  } while (0)
+#define P2F_MAD0(i, D, X, Y) P2F_SCR(i, "v_mad_u64_u32 %0, ", ", %1, %2, 0", "=v"(D) : "v"(X), "v"(Y))
+#define P2F_MADA(i, D, X, Y, ACC) P2F_SCR(i, "v_mad_u64_u32 %0, ", ", %1, %2, %3", "=v"(D) : "v"(X), "v"(Y), "v"(ACC))
+#define P2F_CARRY_IN(i, OP, D, X, C) P2F_SCR(i, OP " %0, ", ", %1, 0, %2", "=v"(D) : "v"(X), "s"(C))
+template <int N>
+__device__ __forceinline__ void p2f_mulN(u64 (&r)[N], const u64 (&a)[N], const u64 (&b)[N]) {
+  u64 p00[N], m[N], hi[N], t[N];
+  u64 cm[N], k1[N], k2[N], k3[N], c1[N], bb[N], bw[N], c3[N];  // SGPR pairs: lane masks of carries
+  u32 w1[N], accl[N], acch[N], rl[N], rh[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) P2F_MAD0(i, p00[i], lo32(a[i]), lo32(b[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++) P2F_MAD0(i, m[i], lo32(a[i]), hi32(b[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++) P2F_A("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m[i]), "=s"(cm[i]) : "v"(hi32(a[i])), "v"(lo32(b[i])), "0"(m[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++) P2F_A("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(w1[i]), "=s"(k1[i]) : "v"(hi32(p00[i])), "v"(lo32(m[i])));
+  P2F_GAP();
+#pragma unroll
+  for (int i = 0; i < N; i++) P2F_A("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(accl[i]), "=s"(k2[i]) : "v"(hi32(m[i])), "s"(k1[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++)  // cm and k2 exclude each other (a carried m leaves m.hi <= 2^32 - 5)
+    k3[i] = cm[i] | k2[i];  // scalar unit
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const u32 zero = 0;
+    P2F_CARRY_IN(i, "v_addc_co_u32_e64", acch[i], zero, k3[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const u64 acc = ((u64)acch[i] << 32) | accl[i];
+    P2F_MADA(i, hi[i], hi32(a[i]), hi32(b[i]), acc);
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const u64 lo = ((u64)w1[i] << 32) | lo32(p00[i]);
+    P2F_A("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t[i]), "=s"(c1[i]) : "v"(lo32(hi[i])), "v"(lo));
+  }
+  P2F_GAP();
+  // V = t + c1*(2^32 - 1) - x3 (mod 2^64): low word t.lo - x3 - c1, high word t.hi + c1 - borrow
+#pragma unroll
+  for (int i = 0; i < N; i++) P2F_A("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(rl[i]), "=s"(bb[i]) : "v"(lo32(t[i])), "v"(hi32(hi[i])), "s"(c1[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++) P2F_CARRY_IN(i, "v_addc_co_u32_e64", rh[i], hi32(t[i]), c1[i]);
+  if (N == 1) P2F_A("s_nop 0");
+#pragma unroll
+  for (int i = 0; i < N; i++) P2F_A("v_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh[i]), "=s"(bw[i]) : "0"(rh[i]), "s"(bb[i]));
+  P2F_GAP();
+  // V < 0 (bw): the wrapped value is >= 2^64 - 2^32; subtract 2^32 - 1 once more: lo += 1 (carry c3), hi -= 1 - c3
+#pragma unroll
+  for (int i = 0; i < N; i++) P2F_A("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rl[i]), "=s"(c3[i]) : "0"(rl[i]), "s"(bw[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++) k3[i] = bw[i] & ~c3[i];  // scalar unit
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    P2F_CARRY_IN(i, "v_subb_co_u32_e64", rh[i], rh[i], k3[i]);
+    r[i] = ((u64)rh[i] << 32) | rl[i];
+  }
+}
+#undef P2F_GAP
+#undef P2F_SCR
+#undef P2F_MAD0
+#undef P2F_MADA
+#undef P2F_CARRY_IN
+__device__ __forceinline__ u64 p2f_mul(u64 a, u64 b) {
+#if P2F_ASM
+  u64 r[1];
+  const u64 x[1] = {a}, y[1] = {b};
+  p2f_mulN<1>(r, x, y);
+  return r[0];
+#else
+  return p2f_mul_c(a, b);
+#endif
+}
 __device__ __forceinline__ u64 p2f_sbox(u64 x) {
+#if P2F_ASM
+  const u64 x2 = p2f_mul(x, x);
+  u64 q[2];
+  const u64 qa[2] = {x2, x2}, qb[2] = {x, x2};
+  p2f_mulN<2>(q, qa, qb);  // x^3, x^4
+  return p2f_mul(q[0], q[1]);
+#else
   const u64 x2 = p2f_mul(x, x);
   const u64 x3 = p2f_mul(x2, x);
   const u64 x4 = p2f_mul(x2, x2);
   return p2f_mul(x3, x4);
+#endif
+}
+// S-box layer of an external round: the 12 S-boxes are independent; P2F_GROUP of them run interleaved.
+__device__ __forceinline__ void p2f_sbox12(u64 s[12]) {
+#if P2F_ASM
+#pragma unroll
+  for (int g = 0; g < 12; g += P2F_GROUP) {
+    u64 x[P2F_GROUP], x2[P2F_GROUP], x3[P2F_GROUP];
+#pragma unroll
+    for (int i = 0; i < P2F_GROUP; i++) x[i] = s[g + i];
+    p2f_mulN<P2F_GROUP>(x2, x, x);
+    p2f_mulN<P2F_GROUP>(x3, x2, x);
+    p2f_mulN<P2F_GROUP>(x, x2, x2);
+    p2f_mulN<P2F_GROUP>(x2, x3, x);
+#pragma unroll
+    for (int i = 0; i < P2F_GROUP; i++) s[g + i] = x2[i];
+  }
+#else
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = p2f_sbox(s[i]);
+#endif
 }
 // x + c for any x < 2^64 and canonical c
 __device__ __forceinline__ u64 p2f_add_canon(u64 x, u64 c) {
@@ -133,8 +274,7 @@ __device__ __forceinline__ void p2f_permute(u64 s[12]) {
   p2f_external(s, p2c::P2_ARK_EXT_INITIAL);
 #pragma unroll 1
   for (int r = 0; r < 4; r++) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = p2f_sbox(s[i]);
+    p2f_sbox12(s);
     // linear layer, then the NEXT round's constants (the last one is internal round 0: element 0 only)
     if (r < 3) {
       p2f_external(s, p2c::P2_ARK_EXT_INITIAL + 12 * (r + 1));
@@ -199,14 +339,28 @@ __device__ __forceinline__ void p2f_permute(u64 s[12]) {
     }
   }
   // leave the scaled domain (factor 8^22) and add the first terminal round constants
-  s[0] = p2f_add_canon(p2f_mul(t0, p2c::P2F_DESCALE), p2c::P2_ARK_EXT_TERMINAL[0]);
+  s[0] = t0;
 #pragma unroll
-  for (int i = 1; i < 12; i++)
-    s[i] = p2f_add_canon(p2f_mul(p2f_fold_signed(L[i], H[i]), p2c::P2F_DESCALE), p2c::P2_ARK_EXT_TERMINAL[i]);
+  for (int i = 1; i < 12; i++) s[i] = p2f_fold_signed(L[i], H[i]);
+#if P2F_ASM
+#pragma unroll
+  for (int g = 0; g < 12; g += 4) {
+    u64 x[4], k[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { x[i] = s[g + i]; k[i] = p2c::P2F_DESCALE; }
+    p2f_mulN<4>(x, x, k);
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[g + i] = x[i];
+  }
+#else
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = p2f_mul(s[i], p2c::P2F_DESCALE);
+#endif
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = p2f_add_canon(s[i], p2c::P2_ARK_EXT_TERMINAL[i]);
 #pragma unroll 1
   for (int r = 0; r < 4; r++) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = p2f_sbox(s[i]);
+    p2f_sbox12(s);
     if (r < 3) {
       p2f_external(s, p2c::P2_ARK_EXT_TERMINAL + 12 * (r + 1));
     } else {
@@ -221,6 +375,8 @@ __device__ __forceinline__ void p2f_permute(u64 s[12]) {
 // host pass: kernels are only parsed, never code-generated
 __device__ void p2f_permute(u64 s[12]);
 __device__ u64 p2f_mul(u64 a, u64 b);
+__device__ u64 p2f_sbox(u64 x);
+__device__ void p2f_sbox12(u64 s[12]);
 __device__ u32 lo32(u64 x);
 __device__ u32 hi32(u64 x);
 #endif  // __HIP_DEVICE_COMPILE__
