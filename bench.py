@@ -131,17 +131,16 @@ class ProveRunner:
 
     def __init__(self, pkg, ctx, args, rank, world):
         import numpy as np
-        import oracle_binding as ob  # only for the shared constants / pre-observe framing (no oracle compute)
-        from miden_vm_amd import dag
+        from miden_vm_amd import dag, protocol
         self.pkg, self.ctx, self.args, self.rank, self.world = pkg, ctx, args, rank, world
         self.log_n = args.log_n
         self.air = dag.dummy_miden_air(51, 8)
         self.dair = pkg.DeviceAir(ctx, self.air)
         rng = np.random.default_rng(1 + rank)
         self.trace = ctx.upload_trace(synth_trace(rng, self.log_n, 51))
-        self.params = dict(ob.PROD_PARAMS)
-        self.state = ob.challenger_state()
-        self.pre = ob.protocol_pre_observe(self.params, [])
+        self.params = dict(protocol.PROD_PARAMS)
+        self.state = protocol.challenger_state()
+        self.pre = protocol.protocol_pre_observe(self.params, [])
         self.proof = None
 
     def step(self):

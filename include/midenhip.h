@@ -276,6 +276,30 @@ int mh_verify(const mh_pcs_params* params, int n_airs, const uint64_t* const* ai
               const uint64_t* fields, size_t n_fields, const uint64_t* commitments, size_t n_commitments,
               const uint64_t* preprocessed_root /* [4]: the setup commitment, NULL if no AIR has preprocessed columns */,
               uint64_t digest[4], char* err, size_t err_cap);
+/* Statement::eval_external (crates/lifted-air/src/statement.rs:94-108; MultiAir::eval_external, crates/lifted-air/src/air.rs:247-287):
+ * the statement's cross-AIR assertions, checked by the reference verifier as its step 11 (crates/lifted-stark/src/verifier/mod.rs:
+ * 488-501, ExternalAssertionFailed) and by its prover before the aux commitment is used (prover/mod.rs:383-399).  The AIRs of this
+ * library are data (constraint DAGs); a statement-level hook is code, so it is a callback: it receives the shared challenges
+ * (n_randomness EF values), every instance's committed aux values and the log heights, all in INSTANCE order, writes one EF value
+ * (c0, c1) per assertion into assertions_out (room for `cap`) and returns their number, or a negative value for the reference's
+ * ReductionError.  mh_verify_ex rejects the proof unless every value is zero.  mh_verify == mh_verify_ex(external = NULL) verifies a
+ * statement WITHOUT cross-AIR assertions (the default MultiAir): a caller whose statement has some -- every LogUp / bus statement,
+ * e.g. Miden's "sum of the committed finals plus boundary corrections = 0" (air/src/lib.rs:854-1000) -- MUST use mh_verify_ex;
+ * with mh_verify the bus balance is unchecked.  On the proving side the same check belongs in the `mh_aux_builder` callback /
+ * after mh_session_commit_aux, which hand the aux values to the caller for exactly this purpose. */
+typedef int (*mh_external_assertions)(void* user, const uint64_t* randomness, size_t n_randomness, const uint64_t* const* aux_values,
+                                      const size_t* n_aux_values, const uint8_t* log_trace_heights, int n_airs, uint64_t* assertions_out,
+                                      size_t cap);
+int mh_verify_ex(const mh_pcs_params* params, int n_airs, const uint64_t* const* air_blobs, const size_t* air_blob_words,
+                 const uint8_t* log_trace_heights, const uint64_t* public_values, size_t n_public_values,
+                 const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe, const uint64_t* fields,
+                 size_t n_fields, const uint64_t* commitments, size_t n_commitments, const uint64_t* preprocessed_root,
+                 mh_external_assertions external, void* external_user, uint64_t digest[4], char* err, size_t err_cap);
+/* A ready-made mh_external_assertions: one assertion, the sum over the instances of their aux value 0 (the LogUp accumulator
+ * final, `committed_finals` of air/src/lookup/aux_builder.rs) -- the balance of a bus statement with no boundary corrections. */
+int mh_external_logup_balance(void* user, const uint64_t* randomness, size_t n_randomness, const uint64_t* const* aux_values,
+                              const size_t* n_aux_values, const uint8_t* log_trace_heights, int n_airs, uint64_t* assertions_out,
+                              size_t cap);
 void mh_proof_free(mh_proof* p);
 size_t mh_proof_num_fields(const mh_proof* p);
 size_t mh_proof_num_commitments(const mh_proof* p);
@@ -286,6 +310,10 @@ size_t mh_proof_num_traces(const mh_proof* p);
 const uint8_t* mh_proof_log_trace_heights(const mh_proof* p);
 /* Serialise StarkProofData; returns the byte length needed (writes only if cap is large enough). */
 size_t mh_proof_serialize(const mh_proof* p, uint8_t* out, size_t cap);
+/* The inverse: StarkProofData bytes -> proof (what verifier/src/lib.rs:320-330 does first; 64 MiB limit).  MH_ERR_INVALID on
+ * truncated input, trailing bytes, oversized length prefixes or non-canonical field elements.  The digest is not part of
+ * StarkProofData and comes back zeroed (mh_verify recomputes it). */
+int mh_proof_deserialize(const uint8_t* bytes, size_t len, mh_proof** out);
 
 #ifdef __cplusplus
 }

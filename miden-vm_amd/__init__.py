@@ -31,6 +31,7 @@ EXPORTS = [
     "mh_session_commit_quotient", "mh_session_ood_point_ok", "mh_session_ood", "mh_session_deep", "mh_session_fri_commit",
     "mh_session_fri_fold", "mh_session_fri_final", "mh_session_open", "mh_grind",
     "mh_host_alloc", "mh_host_free", "mh_verify", "mh_trace_from_device", "mh_lookup_load", "mh_lookup_free", "mh_air_attach_lookup", "mh_air_attach_preprocessed", "mh_lookup_build_aux", "mh_trace_download",
+    "mh_verify_ex", "mh_external_logup_balance", "mh_proof_deserialize",
 ]
 
 _lib = None
@@ -405,6 +406,18 @@ class Proof:
         lib.mh_proof_free(h)
 
 
+def proof_from_bytes(data):
+    """mh_proof_deserialize (host only): StarkProofData bytes -> Proof (digest zeroed); raises MidenHipError on malformed input."""
+    lib = load_library()
+    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\0")
+    h = C.c_void_p()
+    lib.mh_proof_deserialize.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    rc = lib.mh_proof_deserialize(buf, C.c_size_t(len(data)), C.byref(h))
+    if rc != 0:
+        raise MidenHipError(f"mh_proof_deserialize failed ({rc}): malformed StarkProofData bytes")
+    return Proof(lib, h)
+
+
 def prove(ctx, airs, traces, public_values, params, challenger_state, pre_observe, aux_builder=None):
     """airs: list of DeviceAir, traces: list of Trace (instance order).  aux_builder: None (all-zero aux
     traces, DummyMidenAir) or a Python callable (instance_idx, randomness[(c0,c1)...]) ->
@@ -563,10 +576,34 @@ def grind(ctx, state, pending, bits):
     return int(w.value)
 
 
+EXTERNAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.POINTER(C.c_uint64)),
+                          C.POINTER(C.c_size_t), C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint64), C.c_size_t)
+
+
+def external_callback(fn):
+    """Wrap a Python function (randomness[(c0,c1)], aux_values[instance][(c0,c1)], log_heights) -> [(c0,c1), ...] as an
+    mh_external_assertions callback (Statement::eval_external, see midenhip.h).  Raising = ReductionError."""
+    def raw(_user, rnd, n_rnd, aux, n_aux, lhs, n_airs, out, cap):
+        try:
+            r = [(int(rnd[2 * i]), int(rnd[2 * i + 1])) for i in range(n_rnd)]
+            av = [[(int(aux[i][2 * k]), int(aux[i][2 * k + 1])) for k in range(n_aux[i])] for i in range(n_airs)]
+            vals = fn(r, av, [int(lhs[i]) for i in range(n_airs)])
+            if len(vals) > cap:
+                return -1
+            for k, (a, b) in enumerate(vals):
+                out[2 * k], out[2 * k + 1] = int(a), int(b)
+            return len(vals)
+        except Exception:
+            return -1
+    return EXTERNAL_FN(raw)
+
+
 def verify(airs, log_trace_heights, public_values, params, challenger_state, pre_observe, fields, commitments,
-           preprocessed_root=None):
-    """mh_verify (host only, no GPU): airs = dag.Air objects in instance order; preprocessed_root = the setup commitment when
-    some AIR has preprocessed columns (it must also be in pre_observe).  Returns (ok, digest or message)."""
+           preprocessed_root=None, external=None):
+    """mh_verify / mh_verify_ex (host only, no GPU): airs = dag.Air objects in instance order; preprocessed_root = the setup
+    commitment when some AIR has preprocessed columns (it must also be in pre_observe); external = the statement's cross-AIR
+    assertions: an EXTERNAL_FN / external_callback(...) object, or the string "logup_balance" for the library's
+    mh_external_logup_balance.  Returns (ok, digest or message)."""
     lib = load_library()
     n = len(airs)
     blobs = [_arr(a.blob) for a in airs]
@@ -580,7 +617,13 @@ def verify(airs, log_trace_heights, public_values, params, challenger_state, pre
     digest = np.zeros(4, dtype=np.uint64)
     err = C.create_string_buffer(512)
     proot = _arr(preprocessed_root) if preprocessed_root is not None else None
-    rc = lib.mh_verify(C.byref(p), C.c_int(n), bp, bl, lh, _ptr(pub), C.c_size_t(len(public_values)), _ptr(st), _ptr(pre),
-                       C.c_size_t(len(pre_observe)), _ptr(f), C.c_size_t(f.size), _ptr(c), C.c_size_t(c.size // 4),
-                       _ptr(proot) if proot is not None else None, _ptr(digest), err, C.c_size_t(512))
+    if external is None:
+        rc = lib.mh_verify(C.byref(p), C.c_int(n), bp, bl, lh, _ptr(pub), C.c_size_t(len(public_values)), _ptr(st), _ptr(pre),
+                           C.c_size_t(len(pre_observe)), _ptr(f), C.c_size_t(f.size), _ptr(c), C.c_size_t(c.size // 4),
+                           _ptr(proot) if proot is not None else None, _ptr(digest), err, C.c_size_t(512))
+    else:
+        ext = C.cast(lib.mh_external_logup_balance, EXTERNAL_FN) if external == "logup_balance" else external
+        rc = lib.mh_verify_ex(C.byref(p), C.c_int(n), bp, bl, lh, _ptr(pub), C.c_size_t(len(public_values)), _ptr(st), _ptr(pre),
+                              C.c_size_t(len(pre_observe)), _ptr(f), C.c_size_t(f.size), _ptr(c), C.c_size_t(c.size // 4),
+                              _ptr(proot) if proot is not None else None, ext, None, _ptr(digest), err, C.c_size_t(512))
     return (True, digest) if rc == 0 else (False, err.value.decode())

@@ -25,7 +25,10 @@ DagIR dag_parse(const u64* w, size_t n) {
     ir.periodic.emplace_back(w + pos, w + pos + len);
     pos += len;
   }
-  MH_REQUIRE(n_nodes < ((size_t)1 << 28) && pos + 2 * n_nodes + n_cons <= n, "constraint DAG blob: truncated");
+  // subtraction form: none of the header counts can wrap the comparison
+  MH_REQUIRE(n_nodes < ((size_t)1 << 28) && 2 * n_nodes <= n - pos && n_cons <= n - pos - 2 * n_nodes, "constraint DAG blob: truncated");
+  MH_REQUIRE(ir.num_randomness <= 65536 && ir.num_aux_values <= 65536 && ir.num_public <= ((size_t)1 << 20) && n_periodic <= 65536,
+             "constraint DAG blob: implausible header counts");
   std::vector<DagNode>& nodes = ir.nodes;
   nodes.resize(n_nodes);
   for (size_t i = 0; i < n_nodes; i++) {

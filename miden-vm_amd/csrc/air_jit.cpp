@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <mutex>
 #include <set>
@@ -77,6 +78,7 @@ struct Chunk {
   std::string src;
   std::vector<char> code;
   std::string log;
+  bool from_cache = false, no_cache = false;
 };
 
 // ---- on-disk cache of compiled chunks: an AIR is fixed per application, its kernels are compiled once ----
@@ -98,7 +100,7 @@ std::string cache_dir() {
   for (size_t i = 1; i <= dir.size(); i++)  // mkdir -p
     if (i == dir.size() || dir[i] == '/') {
       cmd_path = dir.substr(0, i);
-      (void)mkdir(cmd_path.c_str(), 0755);
+      (void)mkdir(cmd_path.c_str(), 0700);  // code objects are loaded from here: private to the user
     }
   return dir;
 }
@@ -114,17 +116,38 @@ std::string cache_key(const std::string& src) {
   snprintf(buf, sizeof buf, "gfx950-rtc%d.%d-%016llx%016llx.co", ver_major, ver_minor, (unsigned long long)h1, (unsigned long long)h2);
   return buf;
 }
+// Entry = "MHJC0001" | u64 payload length | u64 FNV-1a of the payload | payload.  A truncated or damaged entry (crash,
+// full disk) fails the check and is treated as absent.
+u64 cache_sum(const std::vector<char>& code) {
+  u64 h = 0xcbf29ce484222325ULL;
+  for (unsigned char ch : code) h = (h ^ ch) * 0x100000001b3ULL;
+  return h;
+}
 bool cache_load(const std::string& path, std::vector<char>& code) {
   std::ifstream f(path, std::ios::binary);
   if (!f) return false;
-  code.assign((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-  return code.size() > 64;
+  std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  u64 len = 0, sum = 0;
+  if (raw.size() < 24 + 64 || memcmp(raw.data(), "MHJC0001", 8) != 0) return false;
+  memcpy(&len, raw.data() + 8, 8);
+  memcpy(&sum, raw.data() + 16, 8);
+  if (len != raw.size() - 24) return false;
+  code.assign(raw.begin() + 24, raw.end());
+  if (cache_sum(code) != sum) {
+    code.clear();
+    return false;
+  }
+  return true;
 }
 void cache_store(const std::string& path, const std::vector<char>& code) {
   const std::string tmp = path + ".tmp" + std::to_string((unsigned long long)getpid());
   {
     std::ofstream f(tmp, std::ios::binary);
     if (!f) return;
+    const u64 len = code.size(), sum = cache_sum(code);
+    f.write("MHJC0001", 8);
+    f.write((const char*)&len, 8);
+    f.write((const char*)&sum, 8);
     f.write(code.data(), (std::streamsize)code.size());
     if (!f) return;
   }
@@ -423,17 +446,22 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
   // ---- compile the chunks in parallel (cached on disk by source hash) ----
   const std::string cdir = cache_dir();
   std::atomic<size_t> next{0};
+  size_t n_limit = n_chunks;  // workers take chunk indices below this bound
   std::atomic<bool> failed{false};
   std::string first_error;
   std::mutex err_mu;
   auto worker = [&]() {
     for (;;) {
       const size_t ci = next.fetch_add(1);
-      if (ci >= n_chunks || failed.load()) return;
+      if (ci >= n_limit || failed.load()) return;
       Chunk& ch = chunks[ci];
       try {
         const std::string cpath = cdir.empty() ? "" : cdir + "/" + cache_key(ch.src);
-        if (!cpath.empty() && cache_load(cpath, ch.code)) continue;
+        if (!cpath.empty() && !ch.no_cache && cache_load(cpath, ch.code)) {
+          ch.from_cache = true;
+          continue;
+        }
+        ch.from_cache = false;
         hiprtcProgram prog;
         hiprtc_check(hiprtcCreateProgram(&prog, ch.src.c_str(), "mh_jit_chunk.hip", 0, nullptr, nullptr), "create");
         const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
@@ -471,11 +499,30 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
   prog->n_spill = n_spill;
   try {
     for (size_t ci = 0; ci < n_chunks; ci++) {
-      hipModule_t m;
-      HIP_CHECK(hipModuleLoadData(&m, chunks[ci].code.data()));
+      hipModule_t m = nullptr;
+      hipFunction_t f = nullptr;
+      hipError_t e = hipModuleLoadData(&m, chunks[ci].code.data());
+      if (e == hipSuccess) e = hipModuleGetFunction(&f, m, "mh_jit_chunk");
+      if (e != hipSuccess && chunks[ci].from_cache) {
+        // a cached code object the runtime refuses (stale toolchain, damaged beyond the checksum): drop the entry,
+        // compile this chunk again and load the fresh code
+        (void)hipGetLastError();
+        if (m) (void)hipModuleUnload(m);
+        m = nullptr;
+        if (!cdir.empty()) (void)remove((cdir + "/" + cache_key(chunks[ci].src)).c_str());
+        chunks[ci].no_cache = true;
+        next.store(ci);
+        n_limit = ci + 1;
+        worker();
+        if (failed.load()) throw MhError(MH_ERR_INTERNAL, first_error);
+        HIP_CHECK(hipModuleLoadData(&m, chunks[ci].code.data()));
+        e = hipModuleGetFunction(&f, m, "mh_jit_chunk");
+      }
+      if (e != hipSuccess) {
+        if (m) (void)hipModuleUnload(m);
+        HIP_CHECK(e);
+      }
       prog->modules.push_back(m);
-      hipFunction_t f;
-      HIP_CHECK(hipModuleGetFunction(&f, m, "mh_jit_chunk"));
       prog->fns.push_back(f);
     }
   } catch (...) {

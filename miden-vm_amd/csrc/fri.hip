@@ -1,7 +1,7 @@
 // K9 / K10 / K11 / K14: FRI folding, per-round commitments and proof-of-work grinding, gfx950.
 //
 // Replaces crates/lifted-stark/src/pcs/fri/prover.rs:93-242 (FriPolys::new),
-// pcs/fri/fold/arity4.rs:46-121 and arity2.rs (fold_evals), and the PoW search of
+// pcs/fri/fold/arity4.rs:46-121, arity2.rs and arity8.rs:35-138 (fold_evals), and the PoW search of
 // crates/stark-transcript/src/prover.rs:140-144 (p3 `grind`, external).
 //
 // Layout: a FRI layer of n = Nl*C points is stored coset-major like every LDE here:
@@ -61,7 +61,7 @@ struct FoldArgs {
   const u64* tw_inv;     // w_Nl^(-k), k < Nl/2   (Nl = rows per coset of the INPUT layer)
   const u64* coset_inv;  // [C] w_n^(-j)
   e2 beta;
-  u64 w4, inv_arity;
+  u64 w4, w8_inv, inv_arity;
 };
 __global__ __launch_bounds__(256) void k_fri_fold(FoldArgs a) {
   const int log_q = a.log_rows - a.log_arity;
@@ -77,6 +77,45 @@ __global__ __launch_bounds__(256) void k_fri_fold(FoldArgs a) {
   if (a.log_arity == 1) {
     e2 y0 = ld_e2(a.ev, base), y1 = ld_e2(a.ev, base + ((size_t)1 << log_q));
     res = e2_add(e2_add(y0, y1), e2_mul(e2_sub(y0, y1), x));
+  } else if (a.log_arity == 3) {
+    // fold/arity8.rs: the interpolant of the 8 values on s*<w_8> at beta.  The values are read in NATURAL order
+    // (y_m = f(s w_8^m) = row r0 + m*Nl/8 of this coset), so the inverse DFT runs as three DIF stages and leaves
+    // 8*c_k at position bitrev(k); sum_k c_k x^k is then Horner over the bit-reversed positions.
+    e2 y[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) y[m] = ld_e2(a.ev, base + ((size_t)m << log_q));
+    const u64 wi1 = a.w8_inv, wi2 = gl_mul(wi1, wi1), wi3 = gl_mul(wi2, wi1);  // w_8^-1, w_8^-2 = w_4^-1, w_8^-3
+#pragma unroll
+    for (int m = 0; m < 4; m++) {  // span 4, twiddle w_8^-m on the difference
+      const e2 u = y[m], v = y[m + 4];
+      y[m] = e2_add(u, v);
+      const e2 d = e2_sub(u, v);
+      y[m + 4] = m == 0 ? d : e2_mulf(d, m == 1 ? wi1 : (m == 2 ? wi2 : wi3));
+    }
+#pragma unroll
+    for (int h = 0; h < 8; h += 4)
+#pragma unroll
+      for (int m = 0; m < 2; m++) {  // span 2, twiddle w_4^-m
+        const e2 u = y[h + m], v = y[h + m + 2];
+        y[h + m] = e2_add(u, v);
+        const e2 d = e2_sub(u, v);
+        y[h + m + 2] = m == 0 ? d : e2_mulf(d, wi2);
+      }
+#pragma unroll
+    for (int h = 0; h < 8; h += 2) {
+      const e2 u = y[h], v = y[h + 1];
+      y[h] = e2_add(u, v);
+      y[h + 1] = e2_sub(u, v);
+    }
+    // position p holds 8*c_{bitrev3(p)}: c0..c7 = y[0], y[4], y[2], y[6], y[1], y[5], y[3], y[7]
+    res = y[7];
+    res = e2_add(e2_mul(res, x), y[3]);
+    res = e2_add(e2_mul(res, x), y[5]);
+    res = e2_add(e2_mul(res, x), y[1]);
+    res = e2_add(e2_mul(res, x), y[6]);
+    res = e2_add(e2_mul(res, x), y[2]);
+    res = e2_add(e2_mul(res, x), y[4]);
+    res = e2_add(e2_mul(res, x), y[0]);
   } else {
     e2 y0 = ld_e2(a.ev, base), y1 = ld_e2(a.ev, base + ((size_t)1 << log_q)), y2 = ld_e2(a.ev, base + ((size_t)2 << log_q)),
        y3 = ld_e2(a.ev, base + ((size_t)3 << log_q));
@@ -105,7 +144,7 @@ void fri_leaf_hash(mh_ctx* c, const u64* ev, int log_rows, int cbits, int log_ar
 }
 
 void fri_fold(mh_ctx* c, const u64* ev, int log_rows, int cbits, int cbits_global, size_t coset0, int log_arity, e2 beta, u64* out) {
-  MH_REQUIRE(log_arity == 1 || log_arity == 2, "FRI folding arity must be 2 or 4");
+  MH_REQUIRE(log_arity >= 1 && log_arity <= 3, "FRI folding arity must be 2, 4 or 8");
   MH_REQUIRE(log_rows >= log_arity, "internal: FRI layer too short for a coset-major fold");
   const int logn = log_rows + cbits_global;  // size of the whole layer
   const size_t C = (size_t)1 << cbits;       // cosets stored here
@@ -124,6 +163,7 @@ void fri_fold(mh_ctx* c, const u64* ev, int log_rows, int cbits, int cbits_globa
   a.coset_inv = d.u();
   a.beta = beta;
   a.w4 = gl_two_adic_generator(2);
+  a.w8_inv = gl_inv(gl_two_adic_generator(3));
   a.inv_arity = gl_inv((u64)1 << log_arity);
   const size_t total = (size_t)1 << (log_rows + cbits - log_arity);
   {
@@ -170,7 +210,7 @@ __global__ __launch_bounds__(256) void k_grind(GrindArgs a) {
 
 // Returns the smallest witness >= 0 accepted by `check_witness` for the given challenger snapshot.
 u64 fri_grind(mh_ctx* c, const u64 st[12], const u64* in, int n_in, int bits) {
-  MH_REQUIRE(bits > 0 && bits < 32 && n_in >= 0 && n_in < 8, "bad grind request");
+  MH_REQUIRE(bits > 0 && bits <= 32 && n_in >= 0 && n_in < 8, "bad grind request");
   DevBuf best(8);
   GrindArgs a{};
   for (int i = 0; i < 12; i++) a.st[i] = st[i];

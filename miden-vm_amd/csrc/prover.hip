@@ -39,6 +39,7 @@ mh_trace* trace_upload(mh_ctx* c, const u64* rowmajor, int log_n, size_t width) 
   size_t n = (size_t)1 << log_n;
   std::unique_ptr<mh_trace> t(new mh_trace());
   t->ctx = c; t->log_n = log_n; t->width = width;
+  if (width == 0) return t.release();
   DevBuf staging(n * width * 8);
   t->cols.alloc(n * width * 8);
   HIP_CHECK(hipMemcpyAsync(staging.p, rowmajor, n * width * 8, hipMemcpyHostToDevice, c->stream));
@@ -55,7 +56,7 @@ mh_trace* trace_zeros(mh_ctx* c, int log_n, size_t width) {
   std::unique_ptr<mh_trace> t(new mh_trace());
   t->ctx = c; t->log_n = log_n; t->width = width;
   t->cols.alloc(n * width * 8);
-  HIP_CHECK(hipMemsetAsync(t->cols.p, 0, n * width * 8, c->stream));
+  if (width) HIP_CHECK(hipMemsetAsync(t->cols.p, 0, n * width * 8, c->stream));
   return t.release();
 }
 
@@ -92,6 +93,7 @@ LdeMatrix lde_trace_cosets(mh_ctx* c, const mh_trace* tr, int lb, size_t first, 
   MH_REQUIRE(count > 0 && (count & (count - 1)) == 0 && first + count <= ((size_t)1 << lb), "coset range out of bounds");
   m.coset0 = first;
   while (((size_t)1 << m.log_cosets) < count) m.log_cosets++;
+  if (tr->width == 0) return m;  // an AIR without aux columns still owns a (width-0) slot of the aux tree
   m.lde.alloc(N * count * tr->width * 8);
   DevBuf scratch(N * tr->width * 8);
   std::vector<u64> all = coset_shifts(tr->log_n, lb);
@@ -181,8 +183,11 @@ struct mh_session {
     MH_REQUIRE(n_airs > 0 && n_airs <= 256, "need between 1 and 256 AIR instances");
     lb = pp.log_blowup;
     MH_REQUIRE(lb > 0 && lb <= 8, "log_blowup must be in 1..8");
-    MH_REQUIRE(pp.log_folding_arity == 1 || pp.log_folding_arity == 2, "FRI folding arity must be 2 or 4");
+    MH_REQUIRE(pp.log_folding_arity >= 1 && pp.log_folding_arity <= 3, "FRI folding arity must be 2, 4 or 8");
     MH_REQUIRE(pp.num_queries > 0, "num_queries must be > 0");
+    for (int b : {pp.deep_pow_bits, pp.folding_pow_bits, pp.query_pow_bits})
+      MH_REQUIRE(b >= 0 && b <= 32, "proof-of-work bits must be in 0..32 (sample_bits reads the low 32 bits of a sample)");
+    MH_REQUIRE(pp.log_final_degree >= 0 && pp.log_final_degree <= 32, "log_final_degree must be in 0..32");
     MH_REQUIRE(pp.log_final_degree + lb >= pp.log_folding_arity - 1, "final degree unreachable by fixed-arity folding");
     // ---- trust boundary (prover/mod.rs:199-214) ----
     lhs.resize(n_airs);
@@ -192,7 +197,6 @@ struct mh_session {
       MH_REQUIRE(airs_in[i]->num_public == n_publics, "AIR expects a different number of public values");
       MH_REQUIRE(traces_in[i]->log_n >= 1, "trace needs at least 2 rows");
       MH_REQUIRE(((size_t)1 << traces_in[i]->log_n) >= airs_in[i]->max_period(), "trace shorter than a periodic column");
-      MH_REQUIRE(airs_in[i]->aux_width > 0, "AIR must declare at least one aux column");
       lhs[i] = traces_in[i]->log_n;
       airs.push_back(airs_in[i]);
       traces.push_back(traces_in[i]);
@@ -401,6 +405,7 @@ struct mh_session {
     for (size_t i = 0; i < mats.size(); i++) {
       const int lift = log_N - mats[i]->log_n;
       std::vector<e2> o0, o1;
+      if (mats[i]->width == 0) continue;
       deep_ood_eval_matrix(c, *mats[i], lb, e2_exp_pow2(z, lift), e2_exp_pow2(z_next, lift), o0, o1);
       for (size_t k = 0; k < o0.size(); k++) {
         ev0[coef_off[i] + k] = o0[k];
@@ -1003,7 +1008,7 @@ int mh_session_open(mh_session* s, const uint64_t* indices, size_t n_indices, mh
 int mh_grind(mh_ctx* c, const uint64_t state[12], const uint64_t* pending, size_t n_pending, int bits, uint64_t* witness) {
   MH_TRY(c)
   MH_REQUIRE(c && state && witness && (pending || !n_pending), "null argument");
-  MH_REQUIRE(n_pending < 8 && bits >= 0 && bits <= 40, "pending input must be shorter than the rate; bits in 0..40");
+  MH_REQUIRE(n_pending < 8 && bits >= 0 && bits <= 32, "pending input must be shorter than the rate; bits in 0..32");
   HIP_CHECK(hipSetDevice(c->device));
   HostTranscript tr;
   for (int i = 0; i < 12; i++) tr.ch.st[i] = gl_canon(state[i]);
@@ -1023,8 +1028,11 @@ size_t mh_proof_num_traces(const mh_proof* p) { return p ? p->log_trace_heights.
 const uint8_t* mh_proof_log_trace_heights(const mh_proof* p) { return p ? p->log_trace_heights.data() : nullptr; }
 
 // StarkProofData { log_trace_heights: Vec<u8>, transcript: { fields: Vec<Felt>, commitments: Vec<[Felt;4]> } }
-// (crates/lifted-stark/src/proof.rs:58-63) in bincode-style framing: u64 LE length prefixes, u64 LE felts.
-// PARITY UNPINNED: the reference frames with wincode 0.5.5 (external); see DESIGN.md.
+// (crates/lifted-stark/src/proof.rs:58-63; TranscriptData: crates/stark-transcript/src/data.rs:8-14) as the reference's
+// wincode::config::Configuration::default() + serde-wincode SerdeCompat writes it (prover/src/lib.rs:347-353): wincode 0.5.5
+// (external, Cargo.lock) is the bincode-compatible fixed-width little-endian encoding -- a Vec is a u64 LE length followed by
+// its elements, a u8 is one byte, a Felt (serde newtype over p3 Goldilocks) its canonical u64 LE, a commitment [Felt; 4] four
+// of those without a length.  PARITY UNPINNED against reference bytes until tools/ref_fixtures has been run.
 size_t mh_proof_serialize(const mh_proof* p, uint8_t* out, size_t cap) {
   if (!p) return 0;
   const size_t need = 8 + p->log_trace_heights.size() + 8 + 8 * p->fields.size() + 8 + 8 * p->commitments.size();
@@ -1043,6 +1051,42 @@ size_t mh_proof_serialize(const mh_proof* p, uint8_t* out, size_t cap) {
   put64(p->commitments.size() / 4);
   memcpy(o, p->commitments.data(), 8 * p->commitments.size());
   return need;
+}
+
+// The inverse of mh_proof_serialize (what the reference's verifier entry point does with the bytes before anything else:
+// verifier/src/lib.rs:320-330, crates/test-utils/src/recursive_verifier.rs:84-96, both under a 64 MiB limit).  Rejects
+// truncated input, trailing bytes, length prefixes that do not fit the input and non-canonical field elements (serde's
+// Goldilocks deserialiser refuses values >= p).  The digest is not part of StarkProofData: it comes back zeroed.
+int mh_proof_deserialize(const uint8_t* bytes, size_t len, mh_proof** out) {
+  if (!bytes || !out || len > ((size_t)64 << 20)) return MH_ERR_INVALID;
+  size_t pos = 0;
+  auto get64 = [&](u64& v) {
+    if (len - pos < 8) return false;
+    memcpy(&v, bytes + pos, 8);
+    pos += 8;
+    return true;
+  };
+  std::unique_ptr<mh_proof> p(new mh_proof());
+  memset(p->digest, 0, sizeof p->digest);
+  u64 n = 0;
+  if (!get64(n) || n > len - pos || n == 0 || n > 256) return MH_ERR_INVALID;
+  p->log_trace_heights.assign(bytes + pos, bytes + pos + n);
+  pos += n;
+  if (!get64(n) || n > (len - pos) / 8) return MH_ERR_INVALID;
+  p->fields.resize(n);
+  memcpy(p->fields.data(), bytes + pos, 8 * n);
+  pos += 8 * n;
+  if (!get64(n) || n > (len - pos) / 32) return MH_ERR_INVALID;
+  p->commitments.resize(4 * n);
+  memcpy(p->commitments.data(), bytes + pos, 32 * n);
+  pos += 32 * n;
+  if (pos != len) return MH_ERR_INVALID;
+  for (u64 v : p->fields)
+    if (v >= GL_P) return MH_ERR_INVALID;
+  for (u64 v : p->commitments)
+    if (v >= GL_P) return MH_ERR_INVALID;
+  *out = p.release();
+  return MH_OK;
 }
 
 }  // extern "C"

@@ -127,13 +127,25 @@ int fri_rounds(const mh_pcs_params& p, int log_lde) {
   return (steps + p.log_folding_arity - 1) / p.log_folding_arity;
 }
 
-// One folding step on an opened row (fri/fold/mod.rs:113-180, arity4.rs:46-121): the row holds the evaluations on
+// One folding step on an opened row (fri/fold/mod.rs:113-180, arity2.rs, arity4.rs:46-121, arity8.rs:35-138): the row holds the evaluations on
 // the coset s * <w_arity> in bit-reversed order; the result is the interpolant's value at beta.
 e2 fold_row(const e2* y, int log_arity, u64 s_inv, e2 beta) {
   const e2 x = e2_mulf(beta, s_inv);
   if (log_arity == 1) {
     const e2 r = e2_add(e2_add(y[0], y[1]), e2_mul(e2_sub(y[0], y[1]), x));
     return e2_mulf(r, gl_inv(2));
+  }
+  if (log_arity == 3) {
+    // fold/arity8.rs as a plain interpolation: c_k = (1/8) sum_m f(s w^m) w^(-mk), result sum_k c_k x^k.
+    // The row is bit-reversed: position p holds f(s w^bitrev(p)).
+    const u64 wi = gl_inv(gl_two_adic_generator(3));
+    e2 acc = e2_make(0);
+    for (int k = 7; k >= 0; k--) {
+      e2 ck = e2_make(0);
+      for (u32 p = 0; p < 8; p++) ck = e2_add(ck, e2_mulf(y[p], gl_pow(wi, (u64)bitrev32(p, 3) * (u64)k)));
+      acc = e2_add(e2_mul(acc, x), ck);
+    }
+    return e2_mulf(acc, gl_inv(8));
   }
   const e2 y0 = y[0], y2 = y[1], y1 = y[2], y3 = y[3];
   const u64 w4 = gl_two_adic_generator(2);
@@ -197,10 +209,14 @@ e2 periodic_at(const std::vector<u64>& col, e2 y) {
 }
 
 void verify_impl(const mh_pcs_params& pp, const std::vector<DagIR>& airs, const std::vector<int>& lhs, const std::vector<u64>& publics,
-                 const u64* prep_root, Reader& rd, u64 digest[4]) {
+                 const u64* prep_root, Reader& rd, mh_external_assertions external, void* external_user, u64 digest[4]) {
   const size_t n_airs = airs.size();
   const int lb = pp.log_blowup, la = pp.log_folding_arity;
-  if (lb < 1 || lb > 8 || (la != 1 && la != 2) || pp.num_queries < 1) throw Reject("unsupported PCS parameters");
+  if (lb < 1 || lb > 8 || la < 1 || la > 3 || pp.num_queries < 1) throw Reject("unsupported PCS parameters");
+  // sample_bits works on the low 32 bits of a sample (random_coin.masm sample_bits): more PoW bits cannot be checked
+  for (int b : {pp.deep_pow_bits, pp.folding_pow_bits, pp.query_pow_bits})
+    if (b < 0 || b > 32) throw Reject("proof-of-work bits must be in 0..32");
+  if (pp.log_final_degree < 0 || pp.log_final_degree > 32) throw Reject("log_final_degree must be in 0..32");
   for (size_t i = 0; i < n_airs; i++) {
     if (lhs[i] < 1) throw Reject("trace too small");
     size_t pmax = 0;
@@ -346,7 +362,7 @@ void verify_impl(const mh_pcs_params& pp, const std::vector<DagIR>& airs, const 
       const size_t row = kv.first & mask;
       const size_t pos = bitrev32((u32)(kv.first >> logf), la);
       const size_t q = std::lower_bound(ridx.begin(), ridx.end(), row) - ridx.begin();
-      e2 y[4];
+      e2 y[8];
       for (size_t k = 0; k < arity; k++) y[k] = e2{rows[q][2 * k], rows[q][2 * k + 1]};
       if (!e2_eq(y[pos], kv.second)) throw Reject("FRI round " + std::to_string(r) + ": opened row disagrees with the folded value");
       const e2 folded = fold_row(y, la, gl_pow(gen_inv, row), fri_betas[r]);
@@ -416,6 +432,25 @@ void verify_impl(const mh_pcs_params& pp, const std::vector<DagIR>& airs, const 
     e.is_transition = e2_sub(y, e2_make(wh_inv));
     accumulated = e2_add(e2_mul(accumulated, beta), fold_constraints(air, e, alpha));
   }
+  // ---- external assertions (verifier/mod.rs:488-501): Statement::eval_external over the challenges, the aux values
+  // back in INSTANCE order and the log heights; every assertion value must be zero ----
+  if (external) {
+    std::vector<std::vector<u64>> flat(n_airs);
+    for (size_t j = 0; j < n_airs; j++)
+      for (e2 v : aux_values[j]) { flat[order[j]].push_back(v.c0); flat[order[j]].push_back(v.c1); }
+    std::vector<const u64*> ptrs(n_airs);
+    std::vector<size_t> cnt(n_airs);
+    std::vector<uint8_t> lh8(n_airs);
+    for (size_t i = 0; i < n_airs; i++) { ptrs[i] = flat[i].data(); cnt[i] = flat[i].size() / 2; lh8[i] = (uint8_t)lhs[i]; }
+    std::vector<u64> rflat;
+    for (e2 r : randomness) { rflat.push_back(r.c0); rflat.push_back(r.c1); }
+    const size_t cap = 256;
+    std::vector<u64> out(2 * cap, 0);
+    const int k = external(external_user, rflat.data(), randomness.size(), ptrs.data(), cnt.data(), lh8.data(), (int)n_airs, out.data(), cap);
+    if (k < 0 || (size_t)k > cap) throw Reject("external assertions could not be evaluated (ReductionError)");
+    for (int a = 0; a < k; a++)
+      if (gl_canon(out[2 * a]) || gl_canon(out[2 * a + 1])) throw Reject("external assertion " + std::to_string(a) + " failed");
+  }
   {  // reconstruct_quotient (domain.rs:773-794): barycentric recombination of the D chunk openings
     const u64 wD = gl_two_adic_generator(logD);
     const e2 u = e2_exp_pow2(e2_mulf(z, g_inv), log_n);
@@ -441,11 +476,11 @@ void verify_impl(const mh_pcs_params& pp, const std::vector<DagIR>& airs, const 
 
 }  // namespace
 
-extern "C" int mh_verify(const mh_pcs_params* params, int n_airs, const uint64_t* const* air_blobs, const size_t* air_blob_words,
-                         const uint8_t* log_trace_heights, const uint64_t* public_values, size_t n_public_values,
-                         const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe, const uint64_t* fields,
-                         size_t n_fields, const uint64_t* commitments, size_t n_commitments, const uint64_t* preprocessed_root,
-                         uint64_t digest[4], char* err, size_t err_cap) {
+static int verify_entry(const mh_pcs_params* params, int n_airs, const uint64_t* const* air_blobs, const size_t* air_blob_words,
+                        const uint8_t* log_trace_heights, const uint64_t* public_values, size_t n_public_values,
+                        const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe, const uint64_t* fields,
+                        size_t n_fields, const uint64_t* commitments, size_t n_commitments, const uint64_t* preprocessed_root,
+                        mh_external_assertions external, void* external_user, uint64_t digest[4], char* err, size_t err_cap) {
   auto fail = [&](int code, const char* msg) {
     if (err && err_cap) {
       strncpy(err, msg, err_cap - 1);
@@ -474,7 +509,7 @@ extern "C" int mh_verify(const mh_pcs_params* params, int n_airs, const uint64_t
     if (preprocessed_root)
       for (int i = 0; i < 4; i++) proot[i] = gl_canon(preprocessed_root[i]);
     verify_impl(*params, airs, lhs, std::vector<u64>(public_values, public_values + n_public_values), preprocessed_root ? proot : nullptr,
-                rd, digest);
+                rd, external, external_user, digest);
     if (err && err_cap) err[0] = 0;
     return MH_OK;
   } catch (const MhError& e) {
@@ -483,3 +518,40 @@ extern "C" int mh_verify(const mh_pcs_params* params, int n_airs, const uint64_t
     return fail(MH_ERR_INTERNAL, e.what());
   }
 }
+
+extern "C" {
+int mh_verify(const mh_pcs_params* params, int n_airs, const uint64_t* const* air_blobs, const size_t* air_blob_words,
+              const uint8_t* log_trace_heights, const uint64_t* public_values, size_t n_public_values, const uint64_t challenger_state[12],
+              const uint64_t* pre_observe, size_t n_pre_observe, const uint64_t* fields, size_t n_fields, const uint64_t* commitments,
+              size_t n_commitments, const uint64_t* preprocessed_root, uint64_t digest[4], char* err, size_t err_cap) {
+  return verify_entry(params, n_airs, air_blobs, air_blob_words, log_trace_heights, public_values, n_public_values, challenger_state,
+                      pre_observe, n_pre_observe, fields, n_fields, commitments, n_commitments, preprocessed_root, nullptr, nullptr, digest,
+                      err, err_cap);
+}
+int mh_verify_ex(const mh_pcs_params* params, int n_airs, const uint64_t* const* air_blobs, const size_t* air_blob_words,
+                 const uint8_t* log_trace_heights, const uint64_t* public_values, size_t n_public_values,
+                 const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe, const uint64_t* fields,
+                 size_t n_fields, const uint64_t* commitments, size_t n_commitments, const uint64_t* preprocessed_root,
+                 mh_external_assertions external, void* external_user, uint64_t digest[4], char* err, size_t err_cap) {
+  return verify_entry(params, n_airs, air_blobs, air_blob_words, log_trace_heights, public_values, n_public_values, challenger_state,
+                      pre_observe, n_pre_observe, fields, n_fields, commitments, n_commitments, preprocessed_root, external, external_user,
+                      digest, err, err_cap);
+}
+// The cross-AIR assertion of a LogUp statement without boundary corrections: the committed accumulator finals
+// (aux value 0 of every instance that has one) sum to zero.
+int mh_external_logup_balance(void* user, const uint64_t* randomness, size_t n_randomness, const uint64_t* const* aux_values,
+                              const size_t* n_aux_values, const uint8_t* log_trace_heights, int n_airs, uint64_t* assertions_out,
+                              size_t cap) {
+  (void)user; (void)randomness; (void)n_randomness; (void)log_trace_heights;
+  if (!assertions_out || cap < 1 || n_airs < 0 || (n_airs && (!aux_values || !n_aux_values))) return -1;
+  u64 s0 = 0, s1 = 0;
+  for (int i = 0; i < n_airs; i++)
+    if (n_aux_values[i]) {
+      s0 = gl_add(s0, gl_canon(aux_values[i][0]));
+      s1 = gl_add(s1, gl_canon(aux_values[i][1]));
+    }
+  assertions_out[0] = s0;
+  assertions_out[1] = s1;
+  return 1;
+}
+}  // extern "C"

@@ -162,12 +162,14 @@ class Air:
         self.build_aux = build_aux
 
 
-def dummy_miden_air(width, num_aux_cols, num_public=0):
+def dummy_miden_air(width, num_aux_cols, num_public=0, num_aux_values=None):
     """DummyMidenAir (crates/lifted-stark/src/testing/airs/miden.rs:36-95): one degree-9 constraint
     local[0]*...*local[8] == 0 (folded from ONE exactly as the reference does), `num_aux_cols` EF aux
-    columns that are all zero, 2 randomness elements, aux values = zeros."""
+    columns that are all zero, 2 randomness elements, aux values = zeros (one per aux column, as the reference's dummy;
+    `num_aux_values=1` gives the real Miden AIRs' shape: one committed LogUp final per instance, air/src/lib.rs:666-669)."""
     assert width >= 9
-    b = AirBuilder(width, aux_width=num_aux_cols, num_randomness=2, num_aux_values=num_aux_cols, num_public=num_public)
+    b = AirBuilder(width, aux_width=num_aux_cols, num_randomness=2,
+                   num_aux_values=num_aux_cols if num_aux_values is None else num_aux_values, num_public=num_public)
     prod = b.const(1)
     for j in range(9):
         prod = prod * b.main(j)

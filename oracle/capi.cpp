@@ -156,9 +156,12 @@ int orc_prove(const int params[7], int n_airs, const uint64_t* const* dags, cons
 int orc_verify(const int params[7], int n_airs, const uint64_t* const* dags, const size_t* dag_lens, const int* log_heights,
                const uint64_t* publics, size_t n_publics, const uint64_t init_state[12], const uint64_t* pre_observe,
                size_t n_pre, const uint64_t* fields, size_t n_fields, const uint64_t* commits, size_t n_commits,
-               uint64_t digest[4], char* err, size_t errcap, const uint64_t* preprocessed_root /* [4] or NULL */) {
+               uint64_t digest[4], char* err, size_t errcap, const uint64_t* preprocessed_root /* [4] or NULL */,
+               ExternalAssertions external /* or NULL */, void* external_user) {
   try {
     VerifierInput in;
+    in.external = external;
+    in.external_user = external_user;
     in.params = make_params(params);
     Proof p;
     for (int i = 0; i < n_airs; i++) {
@@ -179,6 +182,20 @@ int orc_verify(const int params[7], int n_airs, const uint64_t* const* dags, con
     return 0;
   } catch (const std::exception& e) {
     set_err(err, errcap, e.what());
+    return 1;
+  }
+}
+
+// fold_evals (crates/lifted-stark/src/pcs/fri/fold/mod.rs:70-84): one bit-reversed row of 2^log_arity EF values -> g(s^arity)
+int orc_fri_fold_row(const uint64_t* y_flat, int log_arity, uint64_t s_inv, const uint64_t beta[2], uint64_t out[2]) {
+  try {
+    std::vector<E2> y((size_t)1 << log_arity);
+    for (size_t i = 0; i < y.size(); i++) y[i] = E2{y_flat[2 * i] % P, y_flat[2 * i + 1] % P};
+    const E2 r = fri_fold_row(y.data(), log_arity, s_inv % P, E2{beta[0] % P, beta[1] % P});
+    out[0] = r.c0;
+    out[1] = r.c1;
+    return 0;
+  } catch (const std::exception&) {
     return 1;
   }
 }

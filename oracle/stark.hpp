@@ -12,7 +12,7 @@
 //   PCS open ............. crates/lifted-stark/src/pcs/prover.rs:34-101
 //   DEEP ................. crates/lifted-stark/src/pcs/deep/prover.rs:54-315, interpolate.rs:87-204
 //   FRI .................. crates/lifted-stark/src/pcs/fri/prover.rs:93-269, fold/arity4.rs:46-121,
-//                          fold/arity2.rs, fri/mod.rs:80-115
+//                          fold/arity2.rs, fold/arity8.rs:35-138, fri/mod.rs:80-115
 //   verifier ............. crates/lifted-stark/src/verifier/mod.rs, pcs/verifier.rs,
 //                          pcs/deep/verifier.rs, pcs/fri/verifier.rs, lmcs/config.rs:172-211
 // Every field operation is exact, so any evaluation order yields the reference's values; what
@@ -39,6 +39,10 @@ struct PcsParams {
 // build_aux_trace callback (crates/lifted-air/src/air.rs LiftedAir::build_aux_trace): fills the
 // flattened EF aux trace (n x 2*aux_width, row-major) and 2*num_aux_values felts. Non-zero = abort.
 typedef int (*AuxBuilder)(void* user, int instance_idx, const uint64_t* randomness, uint64_t* aux_out, uint64_t* aux_values_out);
+// Statement::eval_external as a callback: writes (c0, c1) per assertion, returns their number (<= cap) or < 0 on error.
+typedef int (*ExternalAssertions)(void* user, const uint64_t* randomness, size_t n_randomness, const uint64_t* const* aux_values,
+                                  const size_t* n_aux_values, const uint8_t* log_trace_heights, int n_airs, uint64_t* assertions_out,
+                                  size_t cap);
 
 struct Proof {
   std::vector<uint8_t> log_trace_heights;  // instance order
@@ -116,7 +120,25 @@ static inline E2 fri_fold_row(const E2* y, int log_arity, uint64_t s_inv, E2 bet
     E2 r = eadd(sum, emul(diff, x));
     return emulf(r, finv(2));
   }
-  if (log_arity != 2) throw std::runtime_error("oracle: only FRI arity 2 and 4 are restated");
+  if (log_arity == 3) {
+    // fold/arity8.rs:35-138: size-8 inverse FFT (DIT, bit-reversed input, unscaled) -> 8 * coefficients of f(sX),
+    // then sum c_i x^i at x = beta / s, divided by 8.
+    const uint64_t w8 = two_adic_generator(3), w4 = two_adic_generator(2);
+    const uint64_t w8_3 = fmul(w4, w8), w8_5 = fmul(w8_3, w4), w8_6 = fmul(w8_3, w8_3), w8_7 = fmul(w8_6, w8);
+    const uint64_t w4_inv = w8_6, i1 = w8_7, i2 = w8_6, i3 = w8_5;
+    // row = [y0, y4, y2, y6, y1, y5, y3, y7]
+    const E2 y0 = y[0], y4 = y[1], y2 = y[2], y6 = y[3], y1 = y[4], y5 = y[5], y3 = y[6], y7 = y[7];
+    auto tf = [](E2 a, E2 b, E2& s, E2& d) { s = eadd(a, b); d = esub(a, b); };
+    auto dit = [](E2 a, E2 b, uint64_t tw, E2& s, E2& d) { const E2 t = emulf(b, tw); s = eadd(a, t); d = esub(a, t); };
+    E2 a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7, c[8];
+    tf(y0, y4, a0, a1); tf(y2, y6, a2, a3); tf(y1, y5, a4, a5); tf(y3, y7, a6, a7);
+    tf(a0, a2, b0, b2); dit(a1, a3, w4_inv, b1, b3); tf(a4, a6, b4, b6); dit(a5, a7, w4_inv, b5, b7);
+    tf(b0, b4, c[0], c[4]); dit(b1, b5, i1, c[1], c[5]); dit(b2, b6, i2, c[2], c[6]); dit(b3, b7, i3, c[3], c[7]);
+    E2 acc = c[7];
+    for (int i = 6; i >= 0; i--) acc = eadd(emul(acc, x), c[i]);
+    return emulf(acc, finv(8));
+  }
+  if (log_arity != 2) throw std::runtime_error("oracle: FRI arity must be 2, 4 or 8");
   // row = [y0, y2, y1, y3] (bit-reversed)
   E2 y0 = y[0], y2 = y[1], y1 = y[2], y3 = y[3];
   uint64_t w = two_adic_generator(2);
@@ -405,7 +427,8 @@ static inline Proof prove(ProverInput& in) {
   std::vector<OpenMat> mats;
   for (size_t k = 0; k < prep_lde.size(); k++) mats.push_back({prep_lde[k].data(), prep_lde[k].size() / prep_w[k], prep_w[k]});  // group order: [preprocessed?, main, aux, quotient]
   for (size_t j = 0; j < n_airs; j++) mats.push_back({main_lde[j].data(), main_lde[j].size() / main_w[j], main_w[j]});
-  for (size_t j = 0; j < n_airs; j++) mats.push_back({aux_lde[j].data(), aux_lde[j].size() / aux_w[j], aux_w[j]});
+  for (size_t j = 0; j < n_airs; j++)  // an AIR without aux columns keeps a width-0 slot of the height of its main LDE
+    mats.push_back({aux_lde[j].data(), aux_w[j] ? aux_lde[j].size() / aux_w[j] : main_lde[j].size() / main_w[j], aux_w[j]});
   mats.push_back({quot_lde.data(), NB, 2 * D});
   size_t W = 0;
   for (auto& m : mats) W += align8(m.w);
@@ -627,6 +650,11 @@ struct VerifierInput {
   Challenger challenger;  // preprocessed commitment (if any) already observed, like the statement
   bool has_preprocessed = false;
   Digest preprocessed_root{};
+  // Statement::eval_external (crates/lifted-air/src/statement.rs:94-108): cross-AIR assertions over the challenges,
+  // the aux values and the log heights, all in INSTANCE order; every returned value must be zero
+  // (verifier/mod.rs:488-501).  Null = the default MultiAir (no assertions).
+  ExternalAssertions external = nullptr;
+  void* external_user = nullptr;
 };
 
 static inline Digest verify(const VerifierInput& in, const Proof& proof) {
@@ -844,6 +872,24 @@ static inline Digest verify(const VerifierInput& in, const Proof& proof) {
     EvalEnvExt em{mc.data(), mn.data(), pc.data(), pn.data()};
     E2 folded = dag_fold(air, e, &em, alpha, scratch);
     accumulated = eadd(emul(accumulated, beta), folded);
+  }
+  // external assertions (verifier/mod.rs:488-501): aux values back in instance order
+  if (in.external) {
+    std::vector<std::vector<uint64_t>> flat(n_airs);
+    for (size_t j = 0; j < n_airs; j++)
+      for (E2 v : aux_values[j]) { flat[order[j]].push_back(v.c0); flat[order[j]].push_back(v.c1); }
+    std::vector<const uint64_t*> ptrs(n_airs);
+    std::vector<size_t> cnt(n_airs);
+    std::vector<uint8_t> lh8(n_airs);
+    for (size_t i = 0; i < n_airs; i++) { ptrs[i] = flat[i].data(); cnt[i] = flat[i].size() / 2; lh8[i] = (uint8_t)lhs[i]; }
+    std::vector<uint64_t> rflat;
+    for (E2 r : randomness) { rflat.push_back(r.c0); rflat.push_back(r.c1); }
+    std::vector<uint64_t> out(2 * 64, 0);
+    const int k = in.external(in.external_user, rflat.data(), randomness.size(), ptrs.data(), cnt.data(), lh8.data(), (int)n_airs,
+                              out.data(), 64);
+    if (k < 0 || k > 64) throw VerifyError("external assertions could not be evaluated");
+    for (int a = 0; a < k; a++)
+      if (out[2 * a] % P || out[2 * a + 1] % P) throw VerifyError("external assertion " + std::to_string(a) + " failed");
   }
   // reconstruct_quotient (domain.rs:773-794)
   {

@@ -10,6 +10,9 @@ Vectors:
   4. ACE_CIRCUIT_REGISTRY_LEAVES ... air/src/config.rs:126-175 (leaves 6,7 = hash_elements([0xace,i]))
   5. EMPTY_SUBTREES ................ crates/crypto/src/merkle/empty_roots.rs:49-.. (chain of merge(x,x))
   6. Poseidon2 constants ........... .../poseidon2/constants.rs:18-211 (cross-check of p2_constants.inc)
+  7. MASM recursive-verifier layout  crates/lib/core/asm/stark/constants.masm (quotient recomposition constants, FRI
+     parameters, sizes of the OOD / aux-boundary / trace-row regions, per-AIR widths) and the production PCS parameters
+     of air/src/config.rs:54-67: a second in-tree witness of how a Miden proof's streams are laid out.
 """
 import json, os, re
 REF = "/root/reference"
@@ -46,6 +49,30 @@ def main():
         return [int(x, 16) for x in re.findall(r"0x[0-9a-fA-F]+", m.group(1))]
     out["p2_constants"] = {k: hexblock(k) for k in ("MAT_DIAG", "ARK_EXT_INITIAL", "ARK_INT", "ARK_EXT_TERMINAL")}
     out["root_2_32"] = int(re.search(r"const ROOT_UNITY = (\d+)", open(f"{REF}/crates/lib/core/asm/stark/constants.masm").read()).group(1))
+    masm = open(f"{REF}/crates/lib/core/asm/stark/constants.masm").read()
+    def mconst(name):
+        return int(re.search(r"^const %s = (\d+)" % name, masm, re.M).group(1))
+    m = {k.lower(): mconst(k) for k in ("BLOWUP_FACTOR", "BLOWUP_FACTOR_LOG", "QUOTIENT_SHIFT_RATIO", "QUOTIENT_FIRST_SHIFT",
+                                        "QUOTIENT_FIRST_WEIGHT", "LOG_FINAL_DEGREE", "FRI_FOLD_ARITY", "NUM_AUX_TRACE_COEFS")}
+    m["ood_region_felts"] = mconst("AUX_BUS_BOUNDARY_PTR") - mconst("OOD_EVALUATIONS_PTR")
+    m["aux_boundary_region_felts"] = mconst("AUXILIARY_ACE_INPUTS_PTR") - mconst("AUX_BUS_BOUNDARY_PTR")
+    mm = re.search(r"main\s+= aligned\((\d+)\) \+ aligned\((\d+)\) \+ aligned\((\d+)\)", masm)
+    m["main_widths"] = [int(x) for x in mm.groups()]
+    mm = re.search(r"aux coords = aligned\((\d+) \* 2\) \+ aligned\((\d+) \* 2\) \+ aligned\((\d+) \* 2\)", masm)
+    m["aux_widths_ef"] = [int(x) for x in mm.groups()]
+    mm = re.search(r"quot\s+= (\d+) chunks \* 2 coordinates", masm)
+    m["quotient_chunks"] = int(mm.group(1))
+    mm = re.search(r"total per row = (\d+) EF slots = (\d+) felts", masm)
+    m["ood_row_ef_slots"], m["ood_row_felts"] = int(mm.group(1)), int(mm.group(2))
+    mm = re.search(r"The row therefore occupies (\d+) field\s*\n?##\s*elements", masm)
+    m["trace_row_felts"] = int(mm.group(1))
+    mm = re.search(r"maximal degree of the remainder polynomial\s*\n## that we allow is (\d+)", masm)
+    m["max_remainder_degree"] = int(mm.group(1))
+    out["masm_layout"] = m
+    pcs = {}
+    for k in ("LOG_BLOWUP", "LOG_FOLDING_ARITY", "LOG_FINAL_DEGREE", "FOLDING_POW_BITS", "DEEP_POW_BITS", "NUM_QUERIES", "QUERY_POW_BITS"):
+        pcs[k.lower()] = int(re.search(r"const %s: \w+ = (\d+);" % k, cfg).group(1))
+    out["pcs_params"] = pcs
     with open(os.path.join(HERE, "kat.json"), "w") as f:
         json.dump(out, f, indent=0)
     print("wrote kat.json:", {k: (len(v) if hasattr(v, '__len__') else v) for k, v in out.items()})

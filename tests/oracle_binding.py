@@ -138,33 +138,14 @@ def commit_traces(traces, log_blowup, indices=(), alignment=8, want_lde=False):
 # ---- whole protocol (oracle/stark.hpp) -----------------------------------------------------------
 AUX_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, u64p, u64p, u64p)
 
-# production PCS parameters (air/src/config.rs:54-67): blowup 8, arity 4, final degree 2^7,
-# folding PoW 4, DEEP PoW 12, 27 queries, query PoW 16
-PROD_PARAMS = dict(log_blowup=3, log_folding_arity=2, log_final_degree=7, folding_pow_bits=4, deep_pow_bits=12,
-                   num_queries=27, query_pow_bits=16)
-# RELATION_DIGEST (air/src/config.rs:93-98), pinned by tests/golden/kat.json
-PARAM_ORDER = ("log_blowup", "log_folding_arity", "log_final_degree", "folding_pow_bits", "deep_pow_bits", "num_queries",
-               "query_pow_bits")
+# protocol constants and pre-observe framing live in the product package (pure data, no oracle dependency there)
+from __graft_entry__ import load_package as _load_package
+_load_package()
+from miden_vm_amd.protocol import PROD_PARAMS, PARAM_ORDER, protocol_pre_observe, challenger_state  # noqa: E402,F401
 
 
 def params_array(p):
     return (C.c_int * 7)(*[int(p[k]) for k in PARAM_ORDER])
-
-
-def protocol_pre_observe(p, publics, aux_inputs=(), preprocessed_root=None):
-    """observe_protocol_params (air/src/config.rs:188-198), then the preprocessed commitment when there is one
-    (crates/lifted-stark/src/prover/mod.rs:282-286), then the default statement framing
-    (crates/lifted-air/src/air.rs:307-324)."""
-    pre = [p["num_queries"], p["query_pow_bits"], p["deep_pow_bits"], p["folding_pow_bits"], p["log_blowup"],
-           p["log_final_degree"], 1 << p["log_folding_arity"], 0]
-    if preprocessed_root is not None:
-        pre += [int(x) for x in preprocessed_root]
-    pre += [len(publics)] + [int(x) for x in publics] + [0, len(aux_inputs)] + [int(x) for x in aux_inputs]
-    return pre
-
-
-def challenger_state(relation_digest=(0, 0, 0, 0)):
-    return [0] * 8 + [int(x) for x in relation_digest]
 
 
 def make_aux_callback(airs, traces):
@@ -236,8 +217,9 @@ def prove(airs, traces, publics, params=PROD_PARAMS, init_state=None, pre_observ
             "log_heights": [int(x) for x in lhs], "preprocessed_root": prep_root}
 
 
-def verify(airs, log_heights, publics, proof, params=PROD_PARAMS, init_state=None, pre_observe=None):
-    """Returns (ok, message_or_digest)."""
+def verify(airs, log_heights, publics, proof, params=PROD_PARAMS, init_state=None, pre_observe=None, external=None):
+    """Returns (ok, message_or_digest).  external = a ctypes callback with the mh_external_assertions signature
+    (Statement::eval_external), or None for a statement without cross-AIR assertions."""
     n = len(airs)
     blobs, dag_ptrs, dag_lens = _air_arrays(airs)
     lhs = (C.c_int * n)(*[int(x) for x in log_heights])
@@ -253,7 +235,7 @@ def verify(airs, log_heights, publics, proof, params=PROD_PARAMS, init_state=Non
     L.orc_verify.restype = C.c_int
     rc = L.orc_verify(params_array(params), C.c_int(n), dag_ptrs, dag_lens, lhs, ptr(pub), C.c_size_t(len(publics)), ptr(st),
                       ptr(pre), C.c_size_t(pre.size), ptr(f), C.c_size_t(f.size), ptr(c), C.c_size_t(c.size // 4),
-                      ptr(digest), err, C.c_size_t(512), ptr(arr(prep_root)) if prep_root is not None else None)
+                      ptr(digest), err, C.c_size_t(512), ptr(arr(prep_root)) if prep_root is not None else None, external, None)
     return (True, digest) if rc == 0 else (False, err.value.decode())
 
 

@@ -1,0 +1,99 @@
+"""CPU: FRI folding arity 8 (crates/lifted-stark/src/pcs/fri/fold/arity8.rs:35-138; reachable through miden-bench's
+`--log-folding-arity 3`).  The reference's own structural tests restated (fold/mod.rs:217-300: fold_evals of a degree < arity
+polynomial's coset evaluations, bit-reversed, recovers f(beta)), then whole proofs: the oracle prover's arity-8 proofs are
+accepted by both verifiers (the product's mh_verify folds by plain interpolation, the oracle by the reference's ifft8
+butterflies -- two independent restatements), tampering is rejected."""
+import ctypes as C
+import numpy as np
+import pytest
+import oracle_binding as ob
+import airs as A
+from __graft_entry__ import load_package
+
+pkg = load_package()
+P = ob.P
+ARITY8 = dict(log_blowup=3, log_folding_arity=3, log_final_degree=1, folding_pow_bits=1, deep_pow_bits=2, num_queries=5, query_pow_bits=3)
+
+
+def emul(a, b):
+    return ((a[0] * b[0] + 7 * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def horner(coeffs, x):  # coeffs ascending, EF coefficients, EF point
+    acc = (0, 0)
+    for c in reversed(coeffs):
+        acc = emul(acc, x)
+        acc = ((acc[0] + c[0]) % P, (acc[1] + c[1]) % P)
+    return acc
+
+
+def bitrev(i, bits):
+    return int(format(i, f"0{bits}b")[::-1], 2) if bits else 0
+
+
+def rnd(rng, lo=0):
+    return int(rng.integers(lo, P, dtype=np.uint64))
+
+
+def fold_row(y, log_arity, s_inv, beta):
+    L = ob.lib()
+    flat = np.array([v for e in y for v in e], dtype=np.uint64)
+    b = np.array(beta, dtype=np.uint64)
+    out = np.zeros(2, dtype=np.uint64)
+    L.orc_fri_fold_row.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]
+    assert L.orc_fri_fold_row(flat.ctypes.data, log_arity, C.c_uint64(s_inv), b.ctypes.data, out.ctypes.data) == 0
+    return (int(out[0]), int(out[1]))
+
+
+@pytest.mark.parametrize("log_arity", [1, 2, 3])
+def test_fold_recovers_f_of_beta(log_arity):
+    # fold/mod.rs:262-300 test_fold_correctness: evals on s*<w> in bit-reversed order of a random polynomial of degree arity-1
+    rng = np.random.default_rng(100 + log_arity)
+    arity = 1 << log_arity
+    for _ in range(8):
+        poly = [(rnd(rng), rnd(rng)) for _ in range(arity)]
+        beta = (rnd(rng), rnd(rng))
+        s = rnd(rng, 1)
+        w = int(ob.lib().orc_two_adic_generator(log_arity))
+        pts = [s * pow(w, bitrev(i, log_arity), P) % P for i in range(arity)]
+        y = [horner(poly, (x, 0)) for x in pts]
+        assert fold_row(y, log_arity, pow(s, P - 2, P), beta) == horner(poly, beta)
+
+
+def test_arity8_whole_proofs_and_tamper():
+    t, pub = A.fib_trace(7)
+    cases = [("fib", [A.fib_air()], [t], pub), ("periodic", [A.periodic_air(0)], [A.periodic_trace(6)], []),
+             ("multi", [A.periodic_air(3), A.fib_air()], [A.periodic_trace(5), t], pub)]
+    for name, airs_, traces, pubs in cases:
+        proof = ob.prove(airs_, traces, pubs, ARITY8)
+        lhs = proof["log_heights"]
+        ok, dig = ob.verify(airs_, lhs, pubs, proof, ARITY8)
+        assert ok, (name, dig)
+        ok2, dig2 = pkg.verify(airs_, lhs, pubs, ARITY8, ob.challenger_state(), ob.protocol_pre_observe(ARITY8, pubs), proof["fields"],
+                               proof["commitments"])
+        assert ok2 and (dig2 == proof["digest"]).all(), (name, dig2)
+    # the last case again, tampered in the FRI part of the stream (openings are at the end of `fields`)
+    f = proof["fields"]
+    rng = np.random.default_rng(3)
+    rejected = 0
+    for pos in rng.integers(f.size // 2, f.size, 24):
+        bad = f.copy()
+        bad[pos] = (int(bad[pos]) + 1) % P
+        a = pkg.verify(airs_, lhs, pubs, ARITY8, ob.challenger_state(), ob.protocol_pre_observe(ARITY8, pubs), bad, proof["commitments"])[0]
+        b = ob.verify(airs_, lhs, pubs, {"fields": bad, "commitments": proof["commitments"]}, ARITY8)[0]
+        assert a == b
+        rejected += not a
+    assert rejected == 24
+
+
+def test_fri_round_counts_arity8():
+    # fri/mod.rs:80-115: rounds = ceil((log_lde - (log_final_degree + log_blowup)) / log_arity); the final polynomial is cut
+    # to whatever the last full fold leaves
+    p = dict(ARITY8)
+    t, pub = A.fib_trace(9)
+    proof = ob.prove([A.fib_air()], [t], pub, p)
+    # log_lde 12, log_max_final 4 -> 8 steps / 3 = 3 rounds (12 -> 9 -> 6 -> 3): 3 FRI commitments + 3 trace trees
+    n_roots = 3 + 3
+    assert proof["commitments"].shape[0] >= n_roots
+    ok, _ = ob.verify([A.fib_air()], proof["log_heights"], pub, proof, p)
+    assert ok

@@ -1,0 +1,84 @@
+"""GPU parity cases added in round 2 (run with -m gpu): FRI arity 8, AIRs without aux columns, the device proof through the
+structured parser and the byte round trip, a full transcript compare at 2^16 rows with the production parameters, the full
+Miden shape (three AIRs), and the coset LDE at the pass shapes above 2^20 (big-tile plan at 2^21/2^22, three-pass plan
+at 2^23) against the oracle."""
+import json, os
+import numpy as np
+import pytest
+import oracle_binding as ob
+import airs as A
+import proof_parser as pp
+from __graft_entry__ import load_package
+from miden_vm_amd import dag
+from test_gpu_prove import check_same, gpu_prove, FAST
+from test_external_assertions import no_aux_air, no_aux_trace
+
+pytestmark = pytest.mark.gpu
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
+ARITY8 = dict(log_blowup=3, log_folding_arity=3, log_final_degree=1, folding_pow_bits=1, deep_pow_bits=2, num_queries=5, query_pow_bits=3)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    pkg = load_package()
+    c = pkg.Ctx(0)
+    yield c
+    c.close()
+
+
+def test_fri_arity8(ctx):
+    # fold/arity8.rs; miden-bench --log-folding-arity 3
+    t, pub = A.fib_trace(7)
+    check_same(ctx, [A.fib_air()], [t], pub, ARITY8)
+    check_same(ctx, [dag.dummy_miden_air(11, 2)], [A.dummy_trace(9, 11)], [], dict(ARITY8, log_final_degree=3, num_queries=9))
+    t1, pub1 = A.fib_trace(8)
+    check_same(ctx, [A.periodic_air(3), A.fib_air()], [A.periodic_trace(5), t1], pub1, ARITY8)
+    # tiny: fewer rows than the arity in the last layers
+    t2, pub2 = A.fib_trace(2)
+    check_same(ctx, [A.fib_air()], [t2], pub2, dict(ARITY8, log_final_degree=0))
+
+
+def test_air_without_aux_columns(ctx):
+    check_same(ctx, [no_aux_air()], [no_aux_trace(6)], [], dict(FAST, log_blowup=2))
+    check_same(ctx, [dag.dummy_miden_air(9, 1), no_aux_air()], [A.dummy_trace(6, 9), no_aux_trace(5)], [], FAST)
+    check_same(ctx, [no_aux_air(), dag.dummy_miden_air(9, 1)], [no_aux_trace(7), A.dummy_trace(6, 9)], [], FAST)
+
+
+def test_device_proof_parses_and_round_trips(ctx):
+    pkg = load_package()
+    t1, pub1 = A.fib_trace(8)
+    airs_, traces = [A.periodic_air(3), A.fib_air()], [A.periodic_trace(5), t1]
+    got = gpu_prove(ctx, airs_, traces, pub1, FAST)
+    parsed = pp.parse(airs_, got.log_trace_heights, pub1, FAST, got.fields, got.commitments)
+    assert parsed["digest"] == [int(x) for x in got.digest]
+    assert got.bytes == pp.serialize(got.log_trace_heights, got.fields, got.commitments)
+    back = pkg.proof_from_bytes(got.bytes)
+    assert back.log_trace_heights == got.log_trace_heights and (back.fields == got.fields).all()
+    assert (back.commitments == got.commitments).all() and back.bytes == got.bytes
+
+
+def test_full_miden_shape(ctx):
+    # three AIRs of the real widths (51/22/16 main, 4/3/1 EF aux, one final each), production parameters
+    m = KAT["masm_layout"]
+    airs_ = [dag.dummy_miden_air(w, a, num_aux_values=1) for w, a in zip(m["main_widths"], m["aux_widths_ef"])]
+    traces = [A.dummy_trace(h, w, seed=3 + i) for i, (h, w) in enumerate(zip((12, 11, 10), m["main_widths"]))]
+    got = check_same(ctx, airs_, traces, [], ob.PROD_PARAMS)
+    parsed = pp.parse(airs_, got.log_trace_heights, [], ob.PROD_PARAMS, got.fields, got.commitments)
+    assert parsed["sizes"]["ood_felts"] == m["ood_region_felts"]
+
+
+def test_full_transcript_at_2_16_production_params(ctx):
+    # every transcript field, commitment and the digest, GPU vs oracle, at 2^16 rows x 51 columns + 8 EF aux
+    check_same(ctx, [dag.dummy_miden_air(51, 8)], [A.dummy_trace(16, 51)], [], ob.PROD_PARAMS)
+
+
+@pytest.mark.parametrize("log_n", [21, 22, 23])
+def test_coset_lde_matches_oracle_big_plans(ctx, log_n):
+    rng = np.random.default_rng(log_n)
+    t = rng.integers(0, ob.P, (1 << log_n, 1), dtype=np.uint64)
+    added = 1  # blowup 2 keeps the oracle's share of the test short; the pass plan depends on log_n only
+    shift = int(ob.lib().orc_canonical_lde_shift(log_n + added))
+    got = ctx.coset_lde_batch(t, added, shift)
+    exp = ob.coset_lde_bitrev(t, added, shift)
+    assert got.shape == exp.shape
+    assert (got == exp).all()
