@@ -1,24 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- trace rows/s of the MI355X proving hot path (BASELINE.json metric).
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches one
-rank per GPU with torch.distributed.run.  One JSON line on rank 0.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches one rank per GPU with
+torch.distributed.run.  One JSON line on rank 0.
 
-A "step" = one pass of the hot path over one synthetic trace that is already resident in HBM:
-  workload "commit"  (BASELINE.json configs[1], "NTT+Poseidon2 Merkle only"): commit_traces of the
-      2^20 x 51 main trace and of the 2^20 x 16 (8 EF) aux trace = coset LDE x8 + LMCS tree each
-      (reference: crates/lifted-stark/src/prover/commit.rs:142-180 called at prover/mod.rs:330-341
-      and :403-414);
-  workload "prove"   the whole `prove` of crates/lifted-stark/src/prover/mod.rs:230-578 on the
-      `miden:20:51:8` synthetic AIR (benches/miden-bench), when libmidenhip exports it.
-value = rows of the trace / seconds per step, whole job.  The CPU oracle is used ONLY for the
-`cpu_baseline` leg (a bounded sample), never inside the timed GPU region.
+A "step" = one complete proof (`prove`, crates/lifted-stark/src/prover/mod.rs:230-578) of the miden-bench synthetic instance
+`miden:LOG_N:51:8` (benches/miden-bench: DummyMidenAir, 51 main columns + 8 EF aux columns) with the production PCS
+parameters (air/src/config.rs:54-67) and the Poseidon2 LMCS + challenger, the trace already resident in HBM.
+
+  N = 1   LOG_N = 20 (BASELINE.json configs[1], the configuration the metric is quoted on), one GPU.
+  N > 1   ONE proof of LOG_N = 24 (configs[3]) sharded by cosets over the N GPUs: `mh_prove_sharded` with the communicator
+          inside the library (csrc/comm_rccl.cpp: RCCL collectives on the prover's own stream), "scaling": "strong" -- the
+          north-star scenario.  value = 2^24 rows / seconds per proof.  If the in-library RCCL communicator cannot be set
+          up on the node, the torch.distributed communicator is used; if no sharded proof can be made at all, the line
+          falls back to N independent proofs and says so ("scaling": "weak", config.fallback).
+
+value = rows of the proved trace / seconds per step, whole job.  The CPU oracle is used ONLY for the `cpu_baseline` leg (a
+bounded sample), never inside the timed GPU region.  Extra keys on the N = 1 line: `h2d_inclusive` (SURVEY.md section 8(d):
+the same proof with the host->device upload of the trace inside the timed region) and `miden_shape` (the full Miden VM
+shape: three AIRs of widths 51/22/16 with 4/3/1 EF aux columns, the published reference figure's neighbour).
 """
 import argparse, json, os, sys, time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -34,8 +39,8 @@ def cpu_model():
 
 
 def synth_trace(rng, log_n, width):
-    """DummyMidenAir trace shape (crates/lifted-stark/src/testing/airs/miden.rs:105-124): column 0
-    all-zero, the rest uniform in [0, p).  Seeded numpy PCG64 (SmallRng is not reproducible here)."""
+    """DummyMidenAir trace shape (crates/lifted-stark/src/testing/airs/miden.rs:105-124): column 0 all-zero, the rest uniform
+    in [0, p).  Seeded numpy PCG64 (SmallRng is not reproducible here)."""
     import numpy as np
     P = 0xFFFFFFFF00000001
     t = rng.integers(0, P, (1 << log_n, width), dtype=np.uint64)
@@ -43,101 +48,17 @@ def synth_trace(rng, log_n, width):
     return t
 
 
-def cpu_baseline_commit(log_n_sample, widths, log_blowup):
-    """Oracle (CPU restatement, OpenMP) timed on a bounded sample of the same workload."""
-    import numpy as np
-    import oracle_binding as ob
-    rng = np.random.default_rng(1)
-    traces = [synth_trace(rng, log_n_sample, w) for w in widths]
-    ob.use_fast_library(True)
-    ob.lib()
-    t0 = time.perf_counter()
-    for t in traces:
-        ob.commit_traces([t], log_blowup)
-    dt = time.perf_counter() - t0
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {"value": (1 << log_n_sample) / dt, "unit": "trace rows/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-            "sample": f"oracle commit_traces (coset LDE x{1 << log_blowup} + LMCS) of 2^{log_n_sample} x {widths} "
-                      f"in {dt:.2f} s, OpenMP {cores} threads"}
-
-
-class CommitRunner:
-    """BASELINE.json configs[1]: LDE + LMCS commitment of the main and aux traces (K1-K3)."""
-    WIDTHS = (51, 16)  # main width, aux width in base felts (8 EF)
-    LOG_BLOWUP = 3
-
-    def __init__(self, pkg, ctx, args, rank, world):
-        import numpy as np
-        self.pkg, self.ctx, self.args, self.rank, self.world = pkg, ctx, args, rank, world
-        rng = np.random.default_rng(1 + rank)
-        self.log_n = args.log_n
-        self.traces = [ctx.upload_trace(synth_trace(rng, self.log_n, w)) for w in self.WIDTHS]
-        self.roots = None
-
-    def step(self):
-        roots = []
-        for t in self.traces:
-            com = self.pkg.commit_traces(self.ctx, [t], self.LOG_BLOWUP)
-            roots.append(com.root())
-            com.tree().free()
-        self.roots = roots
-
-    def rows_per_step(self):
-        return (1 << self.log_n) * self.world  # every rank commits its own trace (independent proofs)
-
-    def leaf_permutations_per_step(self):
-        return (8 << self.log_n) * (7 + 2)  # ceil(51/8) + ceil(16/8) sponge permutations per LDE row
-
-    def scaling(self):
-        return "weak"
-
-    def config(self):
-        return {"workload": f"configs[1]: synthetic 2^{self.log_n}-row trace, NTT+Poseidon2 Merkle only: commit_traces("
-                            f"main 2^{self.log_n}x51) + commit_traces(aux 2^{self.log_n}x16), blowup 8, Poseidon2 LMCS",
-                "log_trace_rows": self.log_n, "main_width": 51, "aux_width_base": 16, "log_blowup": 3,
-                "parallelism": "1 GPU" if self.world == 1 else f"{self.world} independent replicas (one trace per GPU)"}
-
-    def roofline(self, prof):
-        # dominant kernel = the leaf sponge (k_leaf_absorb); algorithmic bytes per launch are
-        # attributed inside libmidenhip (LDE bytes read once + 32 B digest written per leaf).
-        name = max(prof, key=lambda k: prof[k]["ms"]) if prof else None
-        if not name:
-            return None
-        e = prof[name]
-        ach = (e["bytes"] / 1e9) / (e["ms"] / 1e3)
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this build (profiles/), if present
-        traffic = None
-        try:
-            t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_leaf_absorb.json")))
-            if name == "lmcs_leaf_absorb" and abs(t["hbm_bytes_per_launch"] / (e["bytes"] / max(1, e["count"])) - 1) < 0.5:
-                traffic = t["hbm_bytes_per_launch"]
-        except Exception:
-            pass
-        return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                "avg_launch_ms": e["ms"] / max(1, e["count"]), "alg_bytes_per_launch": e["bytes"] / max(1, e["count"]),
-                "note": "Poseidon2 hashing is integer-ALU bound (no 64-bit multiplier on CDNA4); see DESIGN.md for the "
-                        "int-op roofline"}
-
-    def cpu_baseline(self):
-        return cpu_baseline_commit(self.args.cpu_log_n, list(self.WIDTHS), self.LOG_BLOWUP)
-
-
 class ProveRunner:
-    """The whole proof (`prove`, crates/lifted-stark/src/prover/mod.rs:230-578) of the miden-bench
-    synthetic instance `miden:LOG_N:51:8` (benches/miden-bench/src/main.rs, DummyMidenAir 51 columns +
-    8 EF aux columns) with the production PCS parameters (air/src/config.rs:54-67: blowup 8, FRI arity 4,
-    final degree 2^7, 27 queries, PoW 4/12/16) and Poseidon2 LMCS + challenger."""
+    """One GPU, one proof of miden:LOG_N:51:8 per step."""
 
-    def __init__(self, pkg, ctx, args, rank, world):
+    def __init__(self, pkg, ctx, log_n, seed):
         import numpy as np
         from miden_vm_amd import dag, protocol
-        self.pkg, self.ctx, self.args, self.rank, self.world = pkg, ctx, args, rank, world
-        self.log_n = args.log_n
+        self.pkg, self.ctx, self.log_n = pkg, ctx, log_n
         self.air = dag.dummy_miden_air(51, 8)
         self.dair = pkg.DeviceAir(ctx, self.air)
-        rng = np.random.default_rng(1 + rank)
-        self.trace = ctx.upload_trace(synth_trace(rng, self.log_n, 51))
+        self.host_trace = synth_trace(np.random.default_rng(seed), log_n, 51)
+        self.trace = ctx.upload_trace(self.host_trace)
         self.params = dict(protocol.PROD_PARAMS)
         self.state = protocol.challenger_state()
         self.pre = protocol.protocol_pre_observe(self.params, [])
@@ -146,74 +67,117 @@ class ProveRunner:
     def step(self):
         self.proof = self.pkg.prove(self.ctx, [self.dair], [self.trace], [], self.params, self.state, self.pre, None)
 
-    def rows_per_step(self):
-        return (1 << self.log_n) * self.world
-
-    def scaling(self):
-        return "weak"
-
-    def config(self):
-        return {"workload": f"full proof of miden:{self.log_n}:51:8 (DummyMidenAir 2^{self.log_n} x 51 + 8 EF aux), 96-bit "
-                            "production PCS params (blowup 8, FRI arity 4, 27 queries, PoW 4/12/16), Poseidon2 LMCS; "
-                            "trace resident in HBM, transcript on host",
-                "log_trace_rows": self.log_n, "main_width": 51, "aux_width_ef": 8, "log_blowup": 3,
-                "proof_bytes": len(self.proof.bytes) if self.proof else None,
-                "parallelism": "1 GPU" if self.world == 1 else f"{self.world} independent proofs (one trace per GPU)"}
-
-    roofline = CommitRunner.roofline
+    def step_with_upload(self, pinned):
+        t = self.ctx.upload_trace(pinned)  # H2D copy + on-device transpose, then the same proof
+        self.proof = self.pkg.prove(self.ctx, [self.dair], [t], [], self.params, self.state, self.pre, None)
+        t.free()
 
     def leaf_permutations_per_step(self):
-        return (8 << self.log_n) * (7 + 2 + 2)  # main 51, aux 16, quotient 16 columns
+        return (8 << self.log_n) * (7 + 2 + 2)  # main 51, aux 16, quotient 16 columns, 8 felts per permutation
 
-    def cpu_baseline(self):
+
+class ShardedRunner:
+    """N GPUs, ONE proof of miden:LOG_N:51:8 per step, sharded by cosets (every rank holds the trace: same seed)."""
+
+    def __init__(self, pkg, ctx, log_n, comm):
         import numpy as np
-        import oracle_binding as ob
-        log_s = self.args.cpu_log_n
-        t = synth_trace(np.random.default_rng(1), log_s, 51)
-        ob.use_fast_library(True)  # ORACLE_FAST build: same results, no 128-bit division per multiplication
-        ob.lib()
-        t0 = time.perf_counter()
-        ob.prove([self.air], [t], [], self.params)
-        dt = time.perf_counter() - t0
-        cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-        return {"value": (1 << log_s) / dt, "unit": "trace rows/s", "cores": cores, "kind": "port",
-                "sample": f"CPU restatement (oracle/, OpenMP {cores} threads) proving miden:{log_s}:51:8 with the same "
-                          f"parameters in {dt:.2f} s",
-                "cpu_model": cpu_model(),
-                "note": "a plain restatement, not the reference's tuned Rayon/AVX prover (unbuildable here: no Rust); the "
-                        "reference publishes 152 k rows/s for this configuration on a 64-thread EPYC 9R45 (README.md:151)"}
+        from miden_vm_amd import dag, protocol, sharding
+        self.pkg, self.ctx, self.log_n, self.comm, self.sharding = pkg, ctx, log_n, comm, sharding
+        self.air = dag.dummy_miden_air(51, 8)
+        self.dair = pkg.DeviceAir(ctx, self.air)
+        self.trace = ctx.upload_trace(synth_trace(np.random.default_rng(7), log_n, 51))
+        self.params = dict(protocol.PROD_PARAMS)
+        self.state = protocol.challenger_state()
+        self.pre = protocol.protocol_pre_observe(self.params, [])
+        self.proof = None
+
+    def step(self):
+        self.proof = self.sharding.prove_sharded(self.pkg, self.ctx, self.comm, [self.dair], [self.trace], [], self.params, self.state,
+                                                 self.pre, None)
 
 
-def sharded_prove_probe(pkg, ctx, args, rank, world, runner):
-    """Strong scaling: ONE proof of the same miden:LOG_N:51:8 instance sharded by cosets over all ranks
-    (mh_prove_sharded + miden-vm_amd/sharding.py; digest all-to-alls, subroot / quotient-coefficient
-    all-gathers and opening all-reduces over RCCL).  Every rank holds the same trace (same seed)."""
+def roofline(prof, pmc_file):
+    """Dominant kernel of the timed region: algorithmic bytes per launch (attributed inside the library next to the launch)
+    over the average launch duration (HIP events on the library's stream)."""
+    if not prof:
+        return None
+    name = max((k for k in prof if not k.startswith("comm_")), key=lambda k: prof[k]["ms"])
+    e = prof[name]
+    ach = (e["bytes"] / 1e9) / (e["ms"] / 1e3)
+    traffic = None
+    try:  # HBM bytes per launch from the committed rocprofv3 PMC passes of this build (profiles/), if they describe this kernel
+        t = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+        if t.get("kernel") == name and abs(t["hbm_bytes_per_launch"] / (e["bytes"] / max(1, e["count"])) - 1) < 0.5:
+            traffic = t["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": traffic, "avg_launch_ms": e["ms"] / max(1, e["count"]), "alg_bytes_per_launch": e["bytes"] / max(1, e["count"]),
+            "note": "Poseidon2 hashing is integer-VALU bound (no 64-bit multiplier on CDNA4): see roofline_valu and DESIGN.md section 3"}
+
+
+def valu_roofline(ctx, prof, perms, steps):
+    """The bound the hash kernels actually live on: VALU issue.  peak = SIMDs x shader clock x 64 lanes / issue cycles of ONE
+    permutation's counted minimal instruction sequence: 506 field multiplications (480 S-box + 22
+    round-scale + ... ) of 13 VALU instructions at the 4 issue cycles measured for v_mad_u64_u32 and the carry-chain VOP3
+    forms, plus 3500 linear-layer instructions (one per 64-bit add/shift-add of the wide representation, folds included) at
+    the 2.5 cycles their instruction mix measures.  The clock is the one s_memtime reports under this load
+    (tools/permbench).  A hardware figure: the register-only rate of our own code is reported next to it, not used as peak."""
+    out = {"kernel": "lmcs_leaf_absorb", "bound": "valu", "unit": "Gperm/s"}
+    ach = perms / (prof["lmcs_leaf_absorb"]["ms"] / steps * 1e-3)
+    out["achieved"] = ach / 1e9
+    try:
+        out["register_rate"] = ctx.poseidon2_register_rate() / 1e9
+    except Exception as e:  # pragma: no cover
+        out["register_rate_error"] = repr(e)[:120]
+    N_MUL, MUL_VALU, MUL_CYCLES, LIN_VALU, LIN_CYCLES, SIMDS, CLOCK_GHZ = 506, 13, 4.0, 3500, 2.5, 1024, 2.24
+    cycles = N_MUL * MUL_VALU * MUL_CYCLES + LIN_VALU * LIN_CYCLES
+    out["peak"] = SIMDS * CLOCK_GHZ * 64 / cycles
+    out["frac"] = out["achieved"] / out["peak"]
+    out["peak_basis"] = (f"{SIMDS} SIMDs x {CLOCK_GHZ} GHz x 64 lanes / ({N_MUL} mul x {MUL_VALU} VALU x {MUL_CYCLES:.0f} cyc + "
+                         f"{LIN_VALU} linear VALU x {LIN_CYCLES} cyc = {cycles:.0f} issue cycles per wave-permutation)")
+    return out
+
+
+def cpu_baseline(runner, cpu_log_n):
     import numpy as np
-    import torch
-    import torch.distributed as dist
-    from miden_vm_amd import sharding
-    trace = ctx.upload_trace(synth_trace(np.random.default_rng(7), args.log_n, 51))
-    comm = sharding.TorchComm(rank, world)
-
-    def once():
-        return sharding.prove_sharded(pkg, ctx, comm, [runner.dair], [trace], [], runner.params, runner.state, runner.pre, None)
-
-    proof = once()
-    dist.barrier()
-    torch.cuda.synchronize()
-    reps = 3
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    t = synth_trace(np.random.default_rng(1), cpu_log_n, 51)
+    ob.use_fast_library(True)  # ORACLE_FAST build: same results, no 128-bit division per multiplication
+    ob.lib()
     t0 = time.perf_counter()
-    for _ in range(reps):
-        proof = once()
-    dist.barrier()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    trace.free()
-    return {"workload": f"one proof of miden:{args.log_n}:51:8 sharded by cosets over {world} GPUs (strong scaling)",
-            "ms_per_proof": float(tt.item()) * 1e3, "rows_per_s": (1 << args.log_n) / float(tt.item()),
-            "proof_bytes": len(proof.bytes), "digest": [int(x) for x in proof.digest]}
+    ob.prove([runner.air], [t], [], runner.params)
+    dt = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": (1 << cpu_log_n) / dt, "unit": "trace rows/s", "cores": cores, "kind": "port",
+            "sample": f"CPU restatement (oracle/, OpenMP {cores} threads) proving miden:{cpu_log_n}:51:8 with the same parameters in {dt:.2f} s",
+            "cpu_model": cpu_model(),
+            "note": "a plain C++ restatement, not the reference's Rayon/AVX prover (unbuildable here: no Rust).  The reference's only "
+                    "published figure (README.md:151, 64-thread EPYC 9R45, ~152 k rows/s) is for a different instance: the blake3 "
+                    "example with all three Miden AIRs (89 main + 16 aux columns, real constraints), whose neighbour here is the "
+                    "`miden_shape` key, not this DummyMidenAir workload"}
+
+
+def miden_shape_probe(pkg, ctx, steps=3):
+    """The full Miden VM shape at 2^20 rows for every AIR (SURVEY.md section 8 sizes): main widths 51/22/16, aux 4/3/1 EF, one
+    LogUp final per AIR, degree-9 stand-in constraints (the real constraint DAGs need the Rust exporter)."""
+    import numpy as np
+    from miden_vm_amd import dag, protocol
+    shapes = ((51, 4), (22, 3), (16, 1))
+    airs = [pkg.DeviceAir(ctx, dag.dummy_miden_air(w, a, num_aux_values=1)) for w, a in shapes]
+    traces = [ctx.upload_trace(synth_trace(np.random.default_rng(11 + i), 20, w)) for i, (w, _) in enumerate(shapes)]
+    prm, st = dict(protocol.PROD_PARAMS), protocol.challenger_state()
+    pre = protocol.protocol_pre_observe(prm, [])
+    pkg.prove(ctx, airs, traces, [], prm, st, pre, None)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof = pkg.prove(ctx, airs, traces, [], prm, st, pre, None)
+    dt = (time.perf_counter() - t0) / steps
+    for t in traces:
+        t.free()
+    return {"workload": "three AIRs at 2^20 rows: main 51/22/16, aux 4/3/1 EF (89 + 16 base columns), production parameters",
+            "ms_per_proof": dt * 1e3, "rows_per_s": (1 << 20) / dt, "proof_bytes": len(proof.bytes)}
 
 
 def main():
@@ -221,11 +185,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--log-n", type=int, default=20)
-    ap.add_argument("--workload", default="auto", choices=["auto", "commit", "prove"])
+    ap.add_argument("--log-n", type=int, default=20, help="rows of the single-GPU instance (N = 1)")
+    ap.add_argument("--shard-log-n", type=int, default=int(os.environ.get("MIDEN_BENCH_SHARD_LOG_N", "24")),
+                    help="rows of the ONE proof sharded over the GPUs (N > 1)")
+    ap.add_argument("--comm", default=os.environ.get("MIDEN_BENCH_COMM", "rccl"), choices=["rccl", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-sharded-probe", action="store_true")
-    ap.add_argument("--cpu-log-n", type=int, default=16)
+    ap.add_argument("--no-extras", action="store_true", help="skip the h2d_inclusive and miden_shape probes")
+    ap.add_argument("--cpu-log-n", type=int, default=18)
     args = ap.parse_args()
 
     import numpy as np
@@ -241,9 +207,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    # MIDEN_BENCH_BACKEND=gloo lets several ranks share the GPUs of a small test box (RCCL refuses two
-    # ranks on one device); the driver's multi-GPU runs use the default nccl (= RCCL over xGMI).
-    backend = os.environ.get("MIDEN_BENCH_BACKEND", "nccl")
+    # Control plane (rendezvous, barriers, the max over ranks, handing the RCCL id around): torch.distributed over gloo.  The
+    # DATA path of a sharded proof is RCCL inside libmidenhip (or, with --comm torch, torch.distributed callbacks).
+    # MIDEN_BENCH_BACKEND=nccl makes torch use its own RCCL for the control plane as well.
+    backend = os.environ.get("MIDEN_BENCH_BACKEND", "gloo")
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     if world > 1:
@@ -252,14 +219,47 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    ctx = pkg.Ctx(dev_index)
-    workload = "prove" if args.workload in ("auto", "prove") else "commit"
-    runner = (ProveRunner if workload == "prove" else CommitRunner)(pkg, ctx, args, rank, world)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def all_ok(flag):
+        if world == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    ctx = pkg.Ctx(dev_index)
+    mode, comm, comm_name, fallback = "single", None, None, None
+    if world > 1:
+        from miden_vm_amd import sharding
+        for choice in ([args.comm] + (["torch"] if args.comm == "rccl" else [])):
+            try:
+                comm = sharding.RcclComm(ctx, rank, world) if choice == "rccl" else sharding.TorchComm(rank, world)
+                sharding.comm_selftest(ctx, comm)
+                trial = ShardedRunner(pkg, ctx, 12, comm)  # a small sharded proof before the big trace is built
+                trial.step()
+                ok = trial.proof is not None
+                trial.trace.free()
+            except Exception as e:
+                ok = False
+                fallback = (fallback or "") + f"{choice}: {repr(e)[:160]}; "
+            if all_ok(ok):
+                mode, comm_name = "sharded", choice
+                break
+            comm = None
+        if mode != "sharded":
+            mode = "replicas"
+
+    if mode == "sharded":
+        runner = ShardedRunner(pkg, ctx, args.shard_log_n, comm)
+        log_n, rows_per_step, scaling = args.shard_log_n, 1 << args.shard_log_n, "strong"
+    else:
+        runner = ProveRunner(pkg, ctx, args.log_n, 1 + rank)
+        log_n, rows_per_step = args.log_n, (1 << args.log_n) * world
+        scaling = "weak"
 
     for _ in range(args.warmup):
         runner.step()
@@ -278,8 +278,13 @@ def main():
     prof = ctx.prof()
     ctx.prof_enable(False)
 
-    ms_per_step = dt / args.steps * 1e3
-    rows_per_step = runner.rows_per_step()  # whole job (all ranks)
+    if mode == "sharded":
+        par = f"one proof sharded by cosets over {world} GPUs (in-library RCCL collectives)" if comm_name == "rccl" else \
+              f"one proof sharded by cosets over {world} GPUs (torch.distributed communicator)"
+    elif world > 1:
+        par = f"{world} independent proofs (one trace per GPU): sharded proving could not be set up"
+    else:
+        par = "1 GPU"
     out = {
         "metric": "trace rows/sec proved (2^20-row trace, 96-bit sec)",
         "value": rows_per_step / (dt / args.steps),
@@ -287,53 +292,59 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
+        "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": runner.scaling(),
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "u64 (Goldilocks field, p = 2^64 - 2^32 + 1)",
-        "data": "synthetic (DummyMidenAir-shaped trace, numpy PCG64 seed 1)",
-        "config": runner.config(),
+        "data": "synthetic (DummyMidenAir-shaped trace, numpy PCG64)",
+        "config": {"workload": f"full proof of miden:{log_n}:51:8 (DummyMidenAir 2^{log_n} x 51 + 8 EF aux), 96-bit production PCS "
+                               "params (blowup 8, FRI arity 4, 27 queries, PoW 4/12/16), Poseidon2 LMCS; trace resident in HBM, "
+                               "transcript on host",
+                   "log_trace_rows": log_n, "main_width": 51, "aux_width_ef": 8, "log_blowup": 3,
+                   "proof_bytes": len(runner.proof.bytes) if runner.proof else None, "parallelism": par},
     }
-    out["roofline"] = runner.roofline(prof)
-    # the honest bound for the hash kernels: permutations/s against the register-only rate of the
-    # same permutation code (VALU ceiling), measured live on this GPU
+    if fallback:
+        out["config"]["fallback"] = fallback
+    out["roofline"] = roofline(prof, "r02_pmc_leaf_absorb.json")
     try:
-        peak = ctx.poseidon2_register_rate()
-        perms = runner.leaf_permutations_per_step()
-        ach = perms / (prof["lmcs_leaf_absorb"]["ms"] / args.steps * 1e-3)
-        out["roofline_valu"] = {"kernel": "lmcs_leaf_absorb", "bound": "valu", "achieved": ach / 1e9, "peak": peak / 1e9,
-                                "unit": "Gperm/s", "frac": ach / peak}
+        perms = (8 << log_n) * (7 + 2 + 2) // (world if mode == "sharded" else 1)  # per rank
+        out["roofline_valu"] = valu_roofline(ctx, prof, perms, args.steps)
     except Exception as e:
         out["roofline_valu"] = {"error": repr(e)[:200]}
     out["kernels"] = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["count"] / args.steps,
                           "alg_GBps": (v["bytes"] / 1e9) / (v["ms"] / 1e3) if v["ms"] > 0 else None}
                       for k, v in prof.items()}
+    if world == 1 and not args.no_extras:
+        try:  # the same proof with the trace upload inside the timed region (page-locked source buffer)
+            pin, owner = pkg.pinned_array(ctx.lib, runner.host_trace.shape)
+            pin[:] = runner.host_trace
+            runner.step_with_upload(pin)
+            barrier()
+            t1 = time.perf_counter()
+            n_h2d = max(3, min(args.steps, 10))
+            for _ in range(n_h2d):
+                runner.step_with_upload(pin)
+            barrier()
+            d = (time.perf_counter() - t1) / n_h2d
+            out["h2d_inclusive"] = {"value": (1 << log_n) / d, "unit": "trace rows/s", "ms_per_step": d * 1e3, "steps": n_h2d,
+                                    "upload_bytes": int(runner.host_trace.nbytes),
+                                    "note": "mh_trace_upload (H2D from mh_host_alloc memory + on-device transpose) inside the timed region"}
+            del pin, owner
+        except Exception as e:
+            out["h2d_inclusive"] = {"error": repr(e)[:200]}
+        try:
+            out["miden_shape"] = miden_shape_probe(pkg, ctx)
+        except Exception as e:
+            out["miden_shape"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = runner.cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(runner, args.cpu_log_n)
     elif rank == 0:
         out["cpu_baseline"] = None
-    if world > 1 and workload == "prove" and not args.no_sharded_probe:
-        # Extra (not part of `value`): ONE proof sharded over all ranks -- the path with real exchange
-        # steps.  A watchdog guarantees the main line is printed even if a collective misbehaves.
-        import threading
-        done = threading.Event()
-
-        def watchdog():
-            if not done.wait(240.0):
-                if rank == 0:
-                    out["sharded_prove"] = {"error": "timed out after 240 s"}
-                    print(json.dumps(out), flush=True)
-                os._exit(0)
-
-        threading.Thread(target=watchdog, daemon=True).start()
-        try:
-            out["sharded_prove"] = sharded_prove_probe(pkg, ctx, args, rank, world, runner)
-        except Exception as e:  # never lose the main line to the probe
-            out["sharded_prove"] = {"error": repr(e)[:300]}
-        done.set()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if comm is not None and hasattr(comm, "close"):
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -45,6 +45,8 @@ pub struct mh_comm {
     pub all_to_all: Option<unsafe extern "C" fn(user: *mut c_void, send_dev: *const c_void, recv_dev: *mut c_void, bytes_per_peer: usize) -> c_int>,
     pub all_gather: Option<unsafe extern "C" fn(user: *mut c_void, send_dev: *const c_void, recv_dev: *mut c_void, bytes_per_rank: usize) -> c_int>,
     pub all_reduce_sum_u64: Option<unsafe extern "C" fn(user: *mut c_void, buf_dev: *mut u64, n: usize) -> c_int>,
+    /// 0: host-synchronous callbacks; 1: enqueue on the ctx's stream (the library's own RCCL communicator)
+    pub stream_ordered: c_int,
 }
 
 #[repr(C)]
@@ -126,6 +128,10 @@ unsafe extern "C" {
     pub fn mh_verify_ex(params: *const mh_pcs_params, n_airs: c_int, air_blobs: *const *const u64, air_blob_words: *const usize, log_trace_heights: *const u8, public_values: *const u64, n_public_values: usize, challenger_state: *const u64, pre_observe: *const u64, n_pre_observe: usize, fields: *const u64, n_fields: usize, commitments: *const u64, n_commitments: usize, preprocessed_root: *const u64, external: mh_external_assertions, external_user: *mut c_void, digest: *mut u64, err: *mut c_char, err_cap: usize) -> c_int;
     pub fn mh_external_logup_balance(user: *mut c_void, randomness: *const u64, n_randomness: usize, aux_values: *const *const u64, n_aux_values: *const usize, log_trace_heights: *const u8, n_airs: c_int, assertions_out: *mut u64, cap: usize) -> c_int;
     pub fn mh_proof_deserialize(bytes: *const u8, len: usize, out: *mut *mut mh_proof) -> c_int;
+    pub fn mh_rccl_unique_id(id: *mut u8) -> c_int;
+    pub fn mh_comm_create_rccl(ctx: *mut mh_ctx, id: *const u8, rank: c_int, world: c_int, out: *mut *mut mh_comm) -> c_int;
+    pub fn mh_comm_destroy(comm: *mut mh_comm);
+    pub fn mh_comm_selftest(ctx: *mut mh_ctx, comm: *const mh_comm) -> c_int;
     pub fn mh_proof_free(p: *mut mh_proof);
     pub fn mh_proof_num_fields(p: *const mh_proof) -> usize;
     pub fn mh_proof_num_commitments(p: *const mh_proof) -> usize;

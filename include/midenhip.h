@@ -200,8 +200,8 @@ int mh_prove(mh_ctx* ctx, const mh_pcs_params* params, int n_airs, mh_air* const
  *   all_gather  (subtree roots; quotient-chunk coefficients; a FRI layer once it has fewer rows per
  *                coset than ranks),
  *   all_reduce_sum_u64 (query openings: every value is contributed by exactly one rank).
- * Each callback returns 0 on success; the library synchronises its stream before calling and expects the
- * collective to be complete on return.  world must be a power of two <= min(2^log_blowup, quotient
+ * Each callback returns 0 on success; unless `stream_ordered` is set the library synchronises its stream before calling
+ * and expects the collective to be complete on return.  world must be a power of two <= min(2^log_blowup, quotient
  * degree); every AIR of the proof must share one quotient degree. */
 typedef struct mh_comm {
   int rank, world;
@@ -209,7 +209,22 @@ typedef struct mh_comm {
   int (*all_to_all)(void* user, const void* send_dev, void* recv_dev, size_t bytes_per_peer);
   int (*all_gather)(void* user, const void* send_dev, void* recv_dev, size_t bytes_per_rank);
   int (*all_reduce_sum_u64)(void* user, uint64_t* buf_dev, size_t n);
+  /* 0: host-synchronous callbacks (the contract above: stream synchronised before the call, complete on return);
+   * 1: the callbacks ENQUEUE on the ctx's stream and return at once (mh_comm_create_rccl): no host synchronisation. */
+  int stream_ordered;
 } mh_comm;
+/* ---- the communicator inside the library: RCCL over xGMI ------------------------------------------------------
+ * One process + one ctx per GPU.  Rank 0 calls mh_rccl_unique_id and hands the 128 bytes to every rank (by whatever
+ * started the ranks); every rank calls mh_comm_create_rccl with its ctx (ncclCommInitRank: collective, blocks until all
+ * `world` ranks arrive).  The returned mh_comm runs the three collectives as RCCL calls on the ctx's own stream and on the
+ * library's own device buffers (leaf-digest all-to-all = grouped ncclSend/ncclRecv, ncclAllGather, ncclAllReduce(sum, u64)).
+ * RCCL is opened lazily from $MH_RCCL_LIB, $ROCM_PATH/lib/librccl.so.1 or /opt/rocm/lib/librccl.so.1.
+ * mh_comm_selftest moves known patterns through all three collectives of ANY mh_comm and checks them (every rank calls it). */
+#define MH_RCCL_ID_BYTES 128
+int mh_rccl_unique_id(uint8_t id[MH_RCCL_ID_BYTES]);
+int mh_comm_create_rccl(mh_ctx* ctx, const uint8_t id[MH_RCCL_ID_BYTES], int rank, int world, mh_comm** out);
+void mh_comm_destroy(mh_comm* comm); /* communicators made by mh_comm_create_rccl */
+int mh_comm_selftest(mh_ctx* ctx, const mh_comm* comm);
 /* mh_commit_traces for one rank of a sharded prover (every rank calls it with the same traces): the setup commitment
  * of preprocessed matrices for mh_prove_sharded / sharded sessions.  Same root as mh_commit_traces. */
 int mh_commit_traces_sharded(mh_ctx* ctx, const mh_comm* comm, int n_traces, mh_trace* const* traces, int log_blowup,

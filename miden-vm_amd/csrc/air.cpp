@@ -101,6 +101,20 @@ mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
   const std::vector<char>& live = ir.live;
   const size_t n_nodes = nodes.size(), n_cons = cons.size();
   air->n_constraints = n_cons;
+  {  // distinct LDE columns the live part of the DAG reads: the algorithmic traffic of the constraint evaluation
+    std::vector<char> m(ir.main_width, 0), a(ir.aux_width, 0), pc(ir.preprocessed_width, 0);
+    for (size_t i = 0; i < n_nodes; i++) {
+      if (!live[i]) continue;
+      if (nodes[i].op == DOP_MAIN) m[nodes[i].a] = 1;
+      else if (nodes[i].op == DOP_AUX) a[nodes[i].a] = 1;
+      else if (nodes[i].op == DOP_PREP) pc[nodes[i].a] = 1;
+    }
+    size_t t = 0;
+    for (char x : m) t += x;
+    for (char x : pc) t += x;
+    for (char x : a) t += 2 * x;  // an EF aux column is two base columns
+    air->touched_base_columns = t;
+  }
 
   // constraints attached to each node, in emission order
   std::vector<std::vector<uint32_t>> folds(n_nodes);

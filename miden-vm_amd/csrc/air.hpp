@@ -72,6 +72,7 @@ struct mh_air {
   int log_quotient_degree = 0;
   std::vector<std::vector<u64>> periodic;
   size_t n_constraints = 0;
+  size_t touched_base_columns = 0;  // distinct main/preprocessed columns + 2 per aux column the live DAG reads
   bool uses_first_last = false;
   std::vector<AirIns> code;
   uint32_t n_slots = 0;

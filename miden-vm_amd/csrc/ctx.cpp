@@ -15,15 +15,16 @@ hipEvent_t mh_ctx::get_event() {
   return e;
 }
 
-void mh_ctx::prof_begin(const char* name, double bytes) {
-  Pending p{name, get_event(), get_event(), bytes};
+size_t mh_ctx::prof_begin(const char* name, double bytes) {
+  Pending p{name, get_event(), get_event(), bytes, false};
   HIP_CHECK(hipEventRecord(p.a, stream));
   pending.push_back(p);
+  return pending.size() - 1;
 }
 
-void mh_ctx::prof_end() {
-  // close the most recent open scope (scopes do not nest across kernels in practice)
-  HIP_CHECK(hipEventRecord(pending.back().b, stream));
+void mh_ctx::prof_end(size_t slot) {
+  HIP_CHECK(hipEventRecord(pending[slot].b, stream));
+  pending[slot].closed = true;
 }
 
 void mh_ctx::prof_resolve() {
@@ -31,6 +32,11 @@ void mh_ctx::prof_resolve() {
   HIP_CHECK(hipStreamSynchronize(stream));
   for (auto& p : pending) {
     float ms = 0;
+    if (!p.closed) {  // a scope left by an exception: nothing to measure
+      event_pool.push_back(p.a);
+      event_pool.push_back(p.b);
+      continue;
+    }
     HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
     auto& e = prof[p.name];
     e.ms += ms;

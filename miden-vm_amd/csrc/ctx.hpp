@@ -126,7 +126,7 @@ struct mh_ctx {
   std::string err;
   // profiler
   bool prof_on = false;
-  struct Pending { std::string name; hipEvent_t a, b; double bytes; };
+  struct Pending { std::string name; hipEvent_t a, b; double bytes; bool closed; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> event_pool;
   std::map<std::string, ProfEntry> prof;
@@ -137,8 +137,8 @@ struct mh_ctx {
   std::map<std::string, std::vector<size_t>> table_index;  // host-side offsets into `tables` entries
 
   hipEvent_t get_event();
-  void prof_begin(const char* name, double bytes);
-  void prof_end();
+  size_t prof_begin(const char* name, double bytes);  // returns the scope's slot: scopes may nest
+  void prof_end(size_t slot);
   void prof_resolve();
   void sync();
   // Blocking device-to-host copy of a small result (roots, opened rows, partial sums) through a page-locked bounce
@@ -161,10 +161,11 @@ struct PoolScope {
 // RAII helper: time everything launched on ctx->stream within the scope under `name`.
 struct ProfScope {
   mh_ctx* c;
+  size_t slot = (size_t)-1;
   ProfScope(mh_ctx* ctx, const char* name, double bytes = 0) : c(ctx) {
-    if (c->prof_on) c->prof_begin(name, bytes);
+    if (c->prof_on) slot = c->prof_begin(name, bytes);
   }
   ~ProfScope() {
-    if (c->prof_on) c->prof_end();
+    if (slot != (size_t)-1 && slot < c->pending.size()) c->prof_end(slot);
   }
 };

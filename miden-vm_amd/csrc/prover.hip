@@ -61,26 +61,31 @@ mh_trace* trace_zeros(mh_ctx* c, int log_n, size_t width) {
 }
 
 // ---- collectives of a sharded proof ------------------------------------------------------------------
+// Host-synchronous communicators (callbacks of a host layer) get a drained stream and must finish before returning;
+// the in-library RCCL communicator (comm_rccl.cpp, stream_ordered) enqueues on c->stream and needs neither.
 void Dist::all_to_all(mh_ctx* c, const void* send, void* recv, size_t bytes_per_peer) const {
-  c->sync();
   if (!on()) {
-    HIP_CHECK(hipMemcpy(recv, send, bytes_per_peer, hipMemcpyDeviceToDevice));
+    HIP_CHECK(hipMemcpyAsync(recv, send, bytes_per_peer, hipMemcpyDeviceToDevice, c->stream));
     return;
   }
-  MH_REQUIRE(comm->all_to_all(comm->user, send, recv, bytes_per_peer) == 0, "all_to_all callback failed");
+  if (!comm->stream_ordered) c->sync();
+  ProfScope ps(c, "comm_all_to_all", (double)bytes_per_peer * world);
+  MH_REQUIRE(comm->all_to_all(comm->user, send, recv, bytes_per_peer) == 0, "all_to_all failed: " + c->err);
 }
 void Dist::all_gather(mh_ctx* c, const void* send, void* recv, size_t bytes_per_rank) const {
-  c->sync();
   if (!on()) {
-    HIP_CHECK(hipMemcpy(recv, send, bytes_per_rank, hipMemcpyDeviceToDevice));
+    HIP_CHECK(hipMemcpyAsync(recv, send, bytes_per_rank, hipMemcpyDeviceToDevice, c->stream));
     return;
   }
-  MH_REQUIRE(comm->all_gather(comm->user, send, recv, bytes_per_rank) == 0, "all_gather callback failed");
+  if (!comm->stream_ordered) c->sync();
+  ProfScope ps(c, "comm_all_gather", (double)bytes_per_rank * world);
+  MH_REQUIRE(comm->all_gather(comm->user, send, recv, bytes_per_rank) == 0, "all_gather failed: " + c->err);
 }
 void Dist::all_reduce_sum(mh_ctx* c, u64* buf, size_t n) const {
   if (!on()) return;
-  c->sync();
-  MH_REQUIRE(comm->all_reduce_sum_u64(comm->user, buf, n) == 0, "all_reduce callback failed");
+  if (!comm->stream_ordered) c->sync();
+  ProfScope ps(c, "comm_all_reduce", (double)n * 8);
+  MH_REQUIRE(comm->all_reduce_sum_u64(comm->user, buf, n) == 0, "all_reduce failed: " + c->err);
 }
 
 // LDE of one uploaded trace into coset-major layout on the canonical shift of its own LDE order;
@@ -350,13 +355,16 @@ struct mh_session {
     DevBuf gathered;
     const u64* coef = acc.u();
     {
-      ProfScope ps(c, "lde", (double)(1 + B_loc) * N * 2 * D * 8.0);
+      ProfScope ps(c, "lde", (double)N * 2 * D_loc * 8.0);
       ntt_inverse_dif_inplace(c, acc.u(), 2 * D_loc, log_N);
-      if (dist.on()) {
-        gathered.alloc(2 * D * N * 8);
-        dist.all_gather(c, acc.u(), gathered.p, 2 * D_loc * N * 8);
-        coef = gathered.u();
-      }
+    }
+    if (dist.on()) {
+      gathered.alloc(2 * D * N * 8);
+      dist.all_gather(c, acc.u(), gathered.p, 2 * D_loc * N * 8);
+      coef = gathered.u();
+    }
+    {
+      ProfScope ps(c, "lde", (double)B_loc * N * 2 * D * 8.0);
       for (size_t t = 0; t < D; t++) {
         const u64 in_inv = gl_inv(gl_mul(g, gl_pow(wJ, t)));
         std::vector<u64> bases(B_loc);

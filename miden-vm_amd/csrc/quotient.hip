@@ -309,7 +309,7 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
     j.log_n = log_n; j.log_cosets = main.log_cosets; j.log_d = log_d; j.log_dl = log_dl;
     j.jc_shift = log_blowup - log_d;
     j.t0 = (u32)t0;
-    ProfScope ps(c, "quotient_eval", (double)n * D * (8.0 * (air->main_width + 2 * air->aux_width) + 16.0));
+    ProfScope ps(c, "quotient_eval", (double)n * D * (8.0 * air->touched_base_columns + 16.0));
     jit_quotient_run(c, air->jit, j, n * D);
     hipLaunchKernelGGL(k_quot_finish, dim3((unsigned)((n * D + 255) / 256)), dim3(256), 0, c->stream, acc_out, dblob.u() + o_tab, log_n,
                        log_dl, acc_in, log_n_prev, beta);
@@ -343,8 +343,8 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
   if (lds > 64 * 1024)
     HIP_CHECK(hipFuncSetAttribute((const void*)k_eval_quotient, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   {
-    // algorithmic bytes: every main/aux column the program touches is read once, 16 B written
-    ProfScope ps(c, "quotient_eval", (double)n * D * (8.0 * (air->main_width + 2 * air->aux_width) + 16.0));
+    // algorithmic bytes: every main/aux/preprocessed column the live DAG touches is read once, 16 B written
+    ProfScope ps(c, "quotient_eval", (double)n * D * (8.0 * air->touched_base_columns + 16.0));
     hipLaunchKernelGGL(k_eval_quotient, dim3((unsigned)((n * D + T - 1) / T)), dim3(T), lds, c->stream, a);
   }
   HIP_CHECK(hipStreamSynchronize(c->stream));  // tables die with this scope

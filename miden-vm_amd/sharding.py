@@ -114,7 +114,8 @@ class MhComm(C.Structure):
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("user", C.c_void_p),
                 ("all_to_all", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)),
                 ("all_gather", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)),
-                ("all_reduce_sum_u64", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t))]
+                ("all_reduce_sum_u64", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)),
+                ("stream_ordered", C.c_int)]  # 0: these host-synchronous callbacks; 1: the library's own RCCL communicator
 
 
 class TorchComm:
@@ -127,7 +128,7 @@ class TorchComm:
         self.staged = world > 1 and dist.get_backend(group) == "gloo"
         a2a_t, ag_t, ar_t = (MhComm._fields_[3][1], MhComm._fields_[4][1], MhComm._fields_[5][1])
         self._cbs = (a2a_t(self._all_to_all), ag_t(self._all_gather), ar_t(self._all_reduce))
-        self.struct = MhComm(rank, world, None, *self._cbs)
+        self.struct = MhComm(rank, world, None, *self._cbs, 0)
 
     def _wrap(self, fn):
         try:
@@ -179,6 +180,48 @@ class TorchComm:
                 dist.all_reduce(tt, op=dist.ReduceOp.SUM, group=self.group)
                 t.copy_(tt)
         return self._wrap(go)
+
+
+class RcclComm:
+    """The communicator INSIDE the library (csrc/comm_rccl.cpp, mh_comm_create_rccl): RCCL collectives on the ctx's own
+    stream and buffers, nothing of the data path passes through Python or torch.  torch.distributed (any backend) is
+    used once, to hand rank 0's 128-byte RCCL id to the other ranks."""
+
+    def __init__(self, ctx, rank, world, group=None):
+        lib = ctx.lib
+        self.ctx, self.rank, self.world = ctx, rank, world
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            rc = lib.mh_rccl_unique_id(ident)
+            if rc != 0:
+                raise RuntimeError("mh_rccl_unique_id failed: RCCL not available")
+        if world > 1:
+            t = torch.tensor(list(ident), dtype=torch.uint8)
+            if dist.get_backend(group) == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=0, group=group)
+            ident = (C.c_uint8 * 128)(*[int(x) for x in t.cpu().tolist()])
+        h = C.POINTER(MhComm)()
+        lib.mh_comm_create_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.POINTER(MhComm))]
+        ctx.check(lib.mh_comm_create_rccl(ctx.h, ident, rank, world, C.byref(h)))
+        self._h = h
+        self.struct = h.contents
+
+    def selftest(self):
+        self.ctx.lib.mh_comm_selftest.argtypes = [C.c_void_p, C.POINTER(MhComm)]
+        self.ctx.check(self.ctx.lib.mh_comm_selftest(self.ctx.h, self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx.lib.mh_comm_destroy.argtypes = [C.POINTER(MhComm)]
+            self.ctx.lib.mh_comm_destroy(self._h)
+            self._h = None
+
+
+def comm_selftest(ctx, comm):
+    """mh_comm_selftest on any communicator object of this module (every rank calls it)."""
+    ctx.lib.mh_comm_selftest.argtypes = [C.c_void_p, C.POINTER(MhComm)]
+    ctx.check(ctx.lib.mh_comm_selftest(ctx.h, C.byref(comm.struct)))
 
 
 def commit_traces_sharded(pkg, ctx, comm, traces, log_blowup):
