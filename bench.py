@@ -101,7 +101,7 @@ def roofline(prof, pmc_file):
     over the average launch duration (HIP events on the library's stream)."""
     if not prof:
         return None
-    name = max((k for k in prof if not k.startswith("comm_")), key=lambda k: prof[k]["ms"])
+    name = max((k for k in prof if not k.startswith(("comm_", "span:"))), key=lambda k: prof[k]["ms"])
     e = prof[name]
     ach = (e["bytes"] / 1e9) / (e["ms"] / 1e3)
     traffic = None
@@ -314,7 +314,9 @@ def main():
         out["roofline_valu"] = {"error": repr(e)[:200]}
     out["kernels"] = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["count"] / args.steps,
                           "alg_GBps": (v["bytes"] / 1e9) / (v["ms"] / 1e3) if v["ms"] > 0 else None}
-                      for k, v in prof.items()}
+                      for k, v in prof.items() if not k.startswith("span:")}
+    # the same timings under the reference's tracing span names, stage spans included
+    out["spans"] = {k[5:]: round(v["ms"] / args.steps, 4) for k, v in prof.items() if k.startswith("span:")}
     if world == 1 and not args.no_extras:
         try:  # the same proof with the trace upload inside the timed region (page-locked source buffer)
             pin, owner = pkg.pinned_array(ctx.lib, runner.host_trace.shape)

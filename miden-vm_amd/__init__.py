@@ -131,7 +131,7 @@ class Ctx:
         self.check(self.lib.mh_prof_dump(self.h, buf, C.c_size_t(len(buf))))
         out = {}
         for line in buf.value.decode().splitlines():
-            name, ms, by, cnt = line.split()
+            name, ms, by, cnt = line.rsplit(None, 3)  # span names contain blanks
             out[name] = {"ms": float(ms), "bytes": float(by), "count": int(cnt)}
         return out
 

@@ -123,6 +123,21 @@ int mh_prof_dump(mh_ctx* c, char* buf, size_t cap) {
     snprintf(line, sizeof line, "%s %.6f %.0f %ld\n", kv.first.c_str(), kv.second.ms, kv.second.bytes, kv.second.count);
     s += line;
   }
+  // The reference's tracing span names (commit.rs:172, lifted_tree.rs:229/263, quotient.rs:185,
+  // deep/prover.rs:214, interpolate.rs:133, fri/prover.rs:164-183, stark-transcript grind) as aliases of the kernel classes, so
+  // that a consumer of the reference's span schema (tracing-forest, blake3-bench's SpanRecorder) finds the same keys.  The
+  // protocol stages themselves are recorded under "span:<reference name>" by the session (prover.hip).
+  static const char* const alias[][2] = {{"lde", "span:LDE"}, {"lmcs_leaf_absorb", "span:hash leaves"}, {"lmcs_compress", "span:compress tree layers"},
+                                         {"quotient_eval", "span:eval_instance"}, {"deep_ood_eval", "span:batch_eval_lifted"},
+                                         {"deep_assemble", "span:DEEP reduce + assemble"}, {"grind", "span:DEEP grind + FRI folding grind + query grind"},
+                                         {"transpose_in", "span:trace upload (no reference span: the CPU prover has none)"}};
+  for (auto& al : alias) {
+    auto it = c->prof.find(al[0]);
+    if (it == c->prof.end()) continue;
+    char line[256];
+    snprintf(line, sizeof line, "%s %.6f %.0f %ld\n", al[1], it->second.ms, it->second.bytes, it->second.count);
+    s += line;
+  }
   size_t n = std::min(cap - 1, s.size());
   memcpy(buf, s.data(), n);
   buf[n] = 0;
@@ -252,7 +267,7 @@ int mh_tree_download_lde(mh_ctx* c, const mh_tree* t, int mat, uint64_t* out) {
   const LdeMatrix& m = t->mats[mat];
   size_t total = (((size_t)1 << m.log_n) << t->log_blowup) * m.width;
   DevBuf tmp(total * 8);
-  hipLaunchKernelGGL(k_lde_to_reference_layout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, m.lde.u(),
+  MH_LAUNCH(k_lde_to_reference_layout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, m.lde.u(),
                      tmp.u(), m.log_n, t->log_blowup, m.width);
   HIP_CHECK(hipMemcpyAsync(out, tmp.p, total * 8, hipMemcpyDeviceToHost, c->stream));
   c->sync();
@@ -289,7 +304,7 @@ int mh_coset_lde_batch(mh_ctx* c, const uint64_t* rowmajor, int log_n, size_t wi
   u64 x = gl_canon(shift);
   for (auto& v : shifts) { v = x; x = gl_mul(x, wk); }
   lde_columns(c, cols.u(), width, log_n, 1, shifts, lde.u(), scratch.u());
-  hipLaunchKernelGGL(k_lde_to_reference_layout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, lde.u(), tmp.u(),
+  MH_LAUNCH(k_lde_to_reference_layout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, lde.u(), tmp.u(),
                      log_n, added_bits, width);
   HIP_CHECK(hipMemcpyAsync(out, tmp.p, total * 8, hipMemcpyDeviceToHost, c->stream));
   c->sync();

@@ -32,6 +32,17 @@ struct MhError : std::runtime_error {
                         std::to_string(__LINE__));                                               \
   } while (0)
 
+// Every kernel launch goes through this: a bad launch configuration (grid of 0, too much LDS, an unset attribute) is reported
+// HERE with file and line, not at the next synchronisation under somebody else's name.
+#define MH_LAUNCH(...)                                                                                             \
+  do {                                                                                                             \
+    hipLaunchKernelGGL(__VA_ARGS__);                                                                               \
+    hipError_t _le = hipGetLastError();                                                                            \
+    if (_le != hipSuccess)                                                                                         \
+      throw MhError(MH_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(_le) + " at " + __FILE__ + ":" + \
+                                    std::to_string(__LINE__));                                                     \
+  } while (0)
+
 #define MH_REQUIRE(cond, msg)                                        \
   do {                                                               \
     if (!(cond)) throw MhError(MH_ERR_INVALID, std::string(msg));    \
@@ -135,6 +146,7 @@ struct mh_ctx {
   // coset-scale tables keyed by (log_n, log_blowup, kind)
   std::map<std::string, DevBuf> tables;
   std::map<std::string, std::vector<size_t>> table_index;  // host-side offsets into `tables` entries
+  bool ntt_big_lds_attr = false;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this ctx's device
 
   hipEvent_t get_event();
   size_t prof_begin(const char* name, double bytes);  // returns the scope's slot: scopes may nest

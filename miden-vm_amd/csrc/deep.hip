@@ -103,8 +103,8 @@ void deep_ood_eval_matrix(mh_ctx* c, const LdeMatrix& m, int log_blowup, e2 y0, 
   DevBuf partial(m.width * chunks * 32);
   {
     ProfScope ps(c, "deep_ood_eval", (double)n * 8.0 * m.width + 64.0 * n);
-    hipLaunchKernelGGL(k_bary_weights, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, c->stream, tw, log_n, g, y0, y1, w0.u(), w1.u());
-    hipLaunchKernelGGL(k_ood_partial, dim3(chunks, (unsigned)m.width), dim3(256), 0, c->stream, m.lde.u(), log_n, m.log_cosets, w0.u(),
+    MH_LAUNCH(k_bary_weights, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, c->stream, tw, log_n, g, y0, y1, w0.u(), w1.u());
+    MH_LAUNCH(k_ood_partial, dim3(chunks, (unsigned)m.width), dim3(256), 0, c->stream, m.lde.u(), log_n, m.log_cosets, w0.u(),
                        w1.u(), partial.u(), chunks);
   }
   std::vector<u64> host(m.width * chunks * 4);
@@ -303,7 +303,7 @@ void deep_assemble(mh_ctx* c, const std::vector<const LdeMatrix*>& mats, const s
   a.z0 = z0; a.z1 = z1; a.fred0 = fred0; a.fred1 = fred1; a.beta = beta; a.out = out;
   {
     ProfScope ps(c, "deep_assemble", bytes);
-    hipLaunchKernelGGL(k_deep_assemble, dim3((unsigned)((N + 256 * DEEP_PTS - 1) / (256 * DEEP_PTS)), (unsigned)B), dim3(256), 0, c->stream, a);
+    MH_LAUNCH(k_deep_assemble, dim3((unsigned)((N + 256 * DEEP_PTS - 1) / (256 * DEEP_PTS)), (unsigned)B), dim3(256), 0, c->stream, a);
   }
   HIP_CHECK(hipStreamSynchronize(c->stream));
 }

@@ -139,7 +139,7 @@ __global__ void k_fri_to_natural(const u64* ev, u64* out, int log_rows, int cbit
 void fri_leaf_hash(mh_ctx* c, const u64* ev, int log_rows, int cbits, int log_arity, u64* digests) {
   const size_t leaves = (size_t)1 << (log_rows - log_arity + cbits);
   ProfScope ps(c, "fri_leaf_hash", (double)leaves * (16.0 * (1 << log_arity) + 32.0));
-  hipLaunchKernelGGL(k_fri_leaf_hash, dim3((unsigned)((leaves + 255) / 256)), dim3(256), 0, c->stream, ev, log_rows, cbits, log_arity,
+  MH_LAUNCH(k_fri_leaf_hash, dim3((unsigned)((leaves + 255) / 256)), dim3(256), 0, c->stream, ev, log_rows, cbits, log_arity,
                      digests);
 }
 
@@ -168,14 +168,14 @@ void fri_fold(mh_ctx* c, const u64* ev, int log_rows, int cbits, int cbits_globa
   const size_t total = (size_t)1 << (log_rows + cbits - log_arity);
   {
     ProfScope ps(c, "fri_fold", (double)total * 16.0 * ((1 << log_arity) + 1));
-    hipLaunchKernelGGL(k_fri_fold, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, a);
+    MH_LAUNCH(k_fri_fold, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, a);
   }
   HIP_CHECK(hipStreamSynchronize(c->stream));
 }
 
 void fri_to_natural(mh_ctx* c, const u64* ev, int log_rows, int cbits, u64* out) {
   const size_t total = (size_t)1 << (log_rows + cbits);
-  hipLaunchKernelGGL(k_fri_to_natural, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, ev, out, log_rows, cbits);
+  MH_LAUNCH(k_fri_to_natural, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, ev, out, log_rows, cbits);
 }
 
 // ---- proof-of-work grinding ------------------------------------------------------------------------
@@ -225,7 +225,7 @@ u64 fri_grind(mh_ctx* c, const u64 st[12], const u64* in, int n_in, int bits) {
     unsigned long long init = ~0ULL;
     HIP_CHECK(hipMemcpyAsync(best.p, &init, 8, hipMemcpyHostToDevice, c->stream));
     a.base = base;
-    hipLaunchKernelGGL(k_grind, dim3((unsigned)(window / 256)), dim3(256), 0, c->stream, a);
+    MH_LAUNCH(k_grind, dim3((unsigned)(window / 256)), dim3(256), 0, c->stream, a);
     unsigned long long got = 0;
     c->d2h(&got, best.p, 8);
     if (got != ~0ULL) return (u64)got;

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_permute_soa(u64* st, size_t n) {
 
 void poseidon2_permute_device(mh_ctx* c, u64* states_soa, size_t n) {
   if (!n) return;
-  hipLaunchKernelGGL(k_permute_soa, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, states_soa, n);
+  MH_LAUNCH(k_permute_soa, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, states_soa, n);
 }
 
 // Register-only permutation chain: the VALU ceiling the hash kernels are measured against (bench.py).
@@ -59,11 +59,11 @@ double poseidon2_register_rate(mh_ctx* c) {
   const int blocks = 2048, iters = 64;  // 8 waves per SIMD x 64 permutations: ~12 ms per launch
   DevBuf out((size_t)blocks * 256 * 8);
   hipEvent_t a = c->get_event(), b = c->get_event();
-  hipLaunchKernelGGL(k_perm_rate, dim3(blocks), dim3(256), 0, c->stream, out.u(), iters, 1ULL);  // warm-up (clocks)
+  MH_LAUNCH(k_perm_rate, dim3(blocks), dim3(256), 0, c->stream, out.u(), iters, 1ULL);  // warm-up (clocks)
   double best = 0;
   for (int rep = 0; rep < 3; rep++) {
     HIP_CHECK(hipEventRecord(a, c->stream));
-    hipLaunchKernelGGL(k_perm_rate, dim3(blocks), dim3(256), 0, c->stream, out.u(), iters, 12345ULL + rep);
+    MH_LAUNCH(k_perm_rate, dim3(blocks), dim3(256), 0, c->stream, out.u(), iters, 12345ULL + rep);
     HIP_CHECK(hipEventRecord(b, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     float ms = 0;
@@ -200,10 +200,10 @@ void lmcs_compress_layers(mh_ctx* c, mh_tree* t) {
       int cbits_child = (d + 1) - (t->log_height - lb);  // coset bits of the child layer
       int log_n_coset = cbits_child > 0 ? (t->log_height - lb) : -1;
       if (n_out <= COMPRESS_LANES_MAX_NODES)
-        hipLaunchKernelGGL(k_compress_lanes, dim3((unsigned)((n_out * 16 + 255) / 256)), dim3(256), 0, c->stream,
+        MH_LAUNCH(k_compress_lanes, dim3((unsigned)((n_out * 16 + 255) / 256)), dim3(256), 0, c->stream,
                            t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
       else
-        hipLaunchKernelGGL(k_compress, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream,
+        MH_LAUNCH(k_compress, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream,
                            t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
     }
   }
@@ -261,7 +261,7 @@ void lmcs_hash_leaves(mh_ctx* c, const std::vector<LdeMatrix>& mats, int lb, u64
     if (state_in) bytes += 96.0 * leaves;
     {
       ProfScope ps(c, "lmcs_leaf_absorb", bytes);
-      hipLaunchKernelGGL(k_leaf_absorb, dim3((unsigned)((leaves + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0,
+      MH_LAUNCH(k_leaf_absorb, dim3((unsigned)((leaves + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0,
                          c->stream, a);
     }
     state_in = a.state_out;
@@ -352,7 +352,7 @@ void lmcs_open(mh_ctx* c, const mh_tree* t, const std::vector<size_t>& idx, size
   if (!n) return;
   DevBuf dptrs(n * 8), dout(n * 8);
   HIP_CHECK(hipMemcpyAsync(dptrs.p, ptrs.data(), n * 8, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const u64* const*)dptrs.p, dout.u(), n);
+  MH_LAUNCH(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const u64* const*)dptrs.p, dout.u(), n);
   if (distributed) dist->all_reduce_sum(c, dout.u(), n);
   std::vector<u64> host(n);
   c->d2h(host.data(), dout.p, n * 8);
@@ -380,7 +380,7 @@ void lmcs_build_sharded(mh_ctx* c, mh_tree* t, const Dist& dist, const u64* loca
   MH_REQUIRE(G > 0 && lbl >= 0 && log_rows >= G, "internal: bad sharded tree shape");
   const size_t local = (size_t)1 << (lbl + log_rows);
   DevBuf packed(local * 32);
-  hipLaunchKernelGGL(k_repack_digests, dim3((unsigned)((local + 255) / 256)), dim3(256), 0, c->stream,
+  MH_LAUNCH(k_repack_digests, dim3((unsigned)((local + 255) / 256)), dim3(256), 0, c->stream,
                      (const ulonglong2*)local_digests, (ulonglong2*)packed.p, lbl, log_rows, G);
   lmcs_alloc_layers(t, log_rows - G + lb);
   dist.all_to_all(c, packed.p, lmcs_leaf_layer(t), (local >> G) * 32);

@@ -184,12 +184,12 @@ mh_trace* lookup_build_aux(mh_ctx* c, const mh_lookup* lk, const mh_trace* main,
     LogupArgs a{};
     a.planes = planes.u(); a.col_count = (const u32*)dcount.p; a.out_ext = (const unsigned char*)dext.p;
     a.num_cols = (u32)lk->num_cols; a.log_n = log_n; a.aux = aux->cols.u(); a.totals = totals.u(); a.err = (u32*)derr.p;
-    hipLaunchKernelGGL(k_logup_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+    MH_LAUNCH(k_logup_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, a);
     // column 0 (planes 0 and 1 of the aux trace) = exclusive prefix sums of the row totals
-    hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)tiles, 2), dim3(SCAN_T), 0, c->stream, totals.u(), aux->cols.u(), tile_sums.u(), n, n, n,
+    MH_LAUNCH(k_scan_tiles, dim3((unsigned)tiles, 2), dim3(SCAN_T), 0, c->stream, totals.u(), aux->cols.u(), tile_sums.u(), n, n, n,
                        tiles);
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(2), dim3(SCAN_T), 0, c->stream, tile_sums.u(), tiles, grand.u());
-    hipLaunchKernelGGL(k_scan_add_offsets, dim3((unsigned)tiles, 2), dim3(SCAN_T), 0, c->stream, aux->cols.u(), tile_sums.u(), n, n, tiles);
+    MH_LAUNCH(k_scan_tile_sums, dim3(2), dim3(SCAN_T), 0, c->stream, tile_sums.u(), tiles, grand.u());
+    MH_LAUNCH(k_scan_add_offsets, dim3((unsigned)tiles, 2), dim3(SCAN_T), 0, c->stream, aux->cols.u(), tile_sums.u(), n, n, tiles);
   }
   u64 fin[2];
   u32 err = 0;

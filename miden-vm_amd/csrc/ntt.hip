@@ -67,7 +67,7 @@ static void fill_powers(mh_ctx* c, u64* out, size_t n, u64 base, u64 scale) {
     b = gl_sqr(b);
   }
   if (n == 0) return;
-  hipLaunchKernelGGL(k_fill_powers, dim3((n + 255) / 256), dim3(256), 0, c->stream, out, n, t, scale);
+  MH_LAUNCH(k_fill_powers, dim3((n + 255) / 256), dim3(256), 0, c->stream, out, n, t, scale);
 }
 
 const u64* mh_ctx::twiddles(int log_n, bool inverse) {
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_transpose_rm_to_cm(const u64* __restric
 
 void launch_transpose_rm_to_cm(mh_ctx* c, const u64* in, u64* out, size_t n, size_t w) {
   dim3 grid((unsigned)((n + 31) / 32), (unsigned)((w + 31) / 32));
-  hipLaunchKernelGGL(k_transpose_rm_to_cm, grid, dim3(256), 0, c->stream, in, out, n, w);
+  MH_LAUNCH(k_transpose_rm_to_cm, grid, dim3(256), 0, c->stream, in, out, n, w);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -120,6 +120,7 @@ struct NttPassArgs {
   const u64* scale_hi;                                  //   scale_lo[z][k & m] * scale_hi[z][k >> lb], k = bitrev(pos)
   int lb;
   size_t scale_lo_z, scale_hi_z;
+  u32 n_z;                                              // output cosets produced per workgroup (first pass of a coset LDE), else 1
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -281,15 +282,20 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
   const size_t hi = tile >> lo_bits;
   const size_t gbase = (hi << (a.s_lo + a.r_bits)) | (lo0 << a.cb);
   const u64* src = a.src + (size_t)blockIdx.y * a.src_col_stride;
-  u64* dst = a.dst + (size_t)blockIdx.y * a.dst_col_stride + (size_t)blockIdx.z * a.dst_z_stride;
+  // The first pass of a coset LDE reads one coefficient tile and produces it on every output coset: the workgroup
+  // loops over the cosets itself (n_z > 1), so the tile comes from HBM once and from this XCD's L2 afterwards --
+  // with the cosets spread over grid.z the same tile was fetched by up to n_z workgroups on different XCDs.
+  for (u32 z = 0; z < a.n_z; z++) {
+  const u32 zc = blockIdx.z * a.n_z + z;
+  u64* dst = a.dst + (size_t)blockIdx.y * a.dst_col_stride + (size_t)zc * a.dst_z_stride;
+  if (z) __syncthreads();  // the previous coset's last round still reads the tile
 
   for (u32 l = threadIdx.x; l < tile_n; l += THREADS) {
     size_t g = gbase | ((size_t)(l >> a.cb) << a.s_lo) | (l & cb_mask);
     u64 v = src[g];
     if (a.scale_lo) {
       u32 k = bitrev32((u32)g, a.log_n);
-      u64 sc = NTT_MUL1(a.scale_lo[blockIdx.z * a.scale_lo_z + (k & ((1u << a.lb) - 1))],
-                        a.scale_hi[blockIdx.z * a.scale_hi_z + (k >> a.lb)]);
+      u64 sc = NTT_MUL1(a.scale_lo[zc * a.scale_lo_z + (k & ((1u << a.lb) - 1))], a.scale_hi[zc * a.scale_hi_z + (k >> a.lb)]);
       v = NTT_MUL1(v, sc);
     }
     lds[ntt_pad(l)] = v;
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
   const int n_rounds = n16 + (rem ? 1 : 0);
   if (n_rounds == 0) {  // a 1-point transform: only the scaling above
     if (threadIdx.x == 0) dst[gbase] = ntt_canon(lds[0]);
-    return;
+    continue;
   }
   for (int i = 0; i < n_rounds; i++) {
     // round i of a DIT pass covers [st, st+g); a DIF pass runs the same rounds in reverse order
@@ -323,6 +329,7 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
     }
     if (!direct) __syncthreads();
   }
+  }  // cosets
 }
 
 struct PassPlan {
@@ -411,7 +418,7 @@ static NttPlanes ntt_planes(mh_ctx* c, int log_n, bool inverse, const std::vecto
         const int s = plan[i].s_lo + rounds[k].first, G = rounds[k].second;
         if (s == 0) continue;
         const size_t cnt = (size_t)((1 << G) - 1) << s;
-        hipLaunchKernelGGL(k_fill_round_plane, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, b.u() + off[i * 4 + k], s, G,
+        MH_LAUNCH(k_fill_round_plane, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, b.u() + off[i * 4 + k], s, G,
                            log_n, t);
       }
     }
@@ -423,33 +430,44 @@ static NttPlanes ntt_planes(mh_ctx* c, int log_n, bool inverse, const std::vecto
 
 static void launch_pass(mh_ctx* c, NttPassArgs a, size_t n_cols, size_t n_z) {
   size_t tiles = (size_t)1 << (a.log_n - a.r_bits - a.cb);
-  dim3 grid((unsigned)tiles, (unsigned)n_cols, (unsigned)n_z);
+  // the workgroup loops over the output cosets; they are spread over grid.z only as far as it takes to fill the chip
+  // (a quotient chunk is 2 columns: 512 workgroups at 2^20 otherwise)
+  size_t zsplit = 1;
+  while (zsplit < n_z && tiles * n_cols * zsplit < 4096) zsplit *= 2;
+  a.n_z = (u32)(n_z / zsplit);
+  dim3 grid((unsigned)tiles, (unsigned)n_cols, (unsigned)zsplit);
   const int T = ntt_tile_log(a.log_n);
   const size_t lds = ntt_lds_bytes(T);
   if (T == NTT_TILE_LOG) {
-    if (a.dif) hipLaunchKernelGGL((k_ntt16_pass<true, NTT_THREADS>), grid, dim3(NTT_THREADS), lds, c->stream, a);
-    else hipLaunchKernelGGL((k_ntt16_pass<false, NTT_THREADS>), grid, dim3(NTT_THREADS), lds, c->stream, a);
+    if (a.dif) MH_LAUNCH((k_ntt16_pass<true, NTT_THREADS>), grid, dim3(NTT_THREADS), lds, c->stream, a);
+    else MH_LAUNCH((k_ntt16_pass<false, NTT_THREADS>), grid, dim3(NTT_THREADS), lds, c->stream, a);
   } else {
-    static bool once = false;  // > 64 KB of dynamic LDS must be requested per kernel
-    if (!once) {
+    if (!c->ntt_big_lds_attr) {  // > 64 KB of dynamic LDS must be requested per kernel AND per device: a flag of the ctx, not of the process
       HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt16_pass<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       HIP_CHECK(hipFuncSetAttribute((const void*)k_ntt16_pass<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      once = true;
+      c->ntt_big_lds_attr = true;
     }
-    if (a.dif) hipLaunchKernelGGL((k_ntt16_pass<true, 1024>), grid, dim3(1024), lds, c->stream, a);
-    else hipLaunchKernelGGL((k_ntt16_pass<false, 1024>), grid, dim3(1024), lds, c->stream, a);
+    if (a.dif) MH_LAUNCH((k_ntt16_pass<true, 1024>), grid, dim3(1024), lds, c->stream, a);
+    else MH_LAUNCH((k_ntt16_pass<false, 1024>), grid, dim3(1024), lds, c->stream, a);
   }
 }
 
 // In-place inverse DFT (unscaled: result = N * coefficients) of `n_cols` contiguous columns of
 // length 2^log_n: natural-order evaluations in, BIT-REVERSED coefficients out.
-void ntt_inverse_dif_inplace(mh_ctx* c, u64* cols, size_t n_cols, int log_n) {
-  if (log_n == 0) return;
+void ntt_inverse_dif_inplace(mh_ctx* c, u64* cols, size_t n_cols, int log_n) { ntt_inverse_dif(c, cols, cols, n_cols, log_n); }
+
+// The same, reading `src` and leaving the result in `dst` (the first pass moves the data: no copy is needed before an
+// in-place transform of a buffer that must stay intact).  src == dst: in place.
+void ntt_inverse_dif(mh_ctx* c, const u64* src, u64* dst, size_t n_cols, int log_n) {
+  if (log_n == 0) {
+    if (src != dst) HIP_CHECK(hipMemcpyAsync(dst, src, n_cols * 8, hipMemcpyDeviceToDevice, c->stream));
+    return;
+  }
   auto plan = plan_passes(log_n);
   const NttPlanes tw = ntt_planes(c, log_n, true, plan);
   for (int i = (int)plan.size() - 1; i >= 0; i--) {
     NttPassArgs a{};
-    a.src = cols; a.dst = cols;
+    a.src = (i == (int)plan.size() - 1) ? src : dst; a.dst = dst;
     a.src_col_stride = a.dst_col_stride = (size_t)1 << log_n;
     a.dst_z_stride = 0;
     a.log_n = log_n; a.s_lo = plan[i].s_lo; a.r_bits = plan[i].r_bits; a.cb = plan[i].cb;
@@ -545,9 +563,7 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
 // LDE of column-major columns: evaluations on a*H (natural) -> evaluations on b_z*H for all z.
 void lde_columns(mh_ctx* c, const u64* cols_in, size_t n_cols, int log_n, u64 in_shift, const std::vector<u64>& out_shifts,
                  u64* out, u64* scratch /* n_cols * N */) {
-  size_t N = (size_t)1 << log_n;
-  HIP_CHECK(hipMemcpyAsync(scratch, cols_in, n_cols * N * 8, hipMemcpyDeviceToDevice, c->stream));
-  ntt_inverse_dif_inplace(c, scratch, n_cols, log_n);
+  ntt_inverse_dif(c, cols_in, scratch, n_cols, log_n);
   u64 a_inv = gl_inv(in_shift);
   std::vector<u64> bases;
   for (u64 b : out_shifts) bases.push_back(gl_mul(b, a_inv));

@@ -80,10 +80,13 @@ __device__ __forceinline__ u64 p2f_mul_c(u64 a, u64 b) {
 }
 #define P2F_A asm volatile
 // wait states still missing between stage k of product i and stage k+1 of the same product (N-1 instructions lie between)
-#define P2F_GAP()                      \
-  do {                                 \
-    if (N == 1) P2F_A("s_nop 1");      \
-    else if (N == 2) P2F_A("s_nop 0"); \
+#ifndef P2F_GAP_NOPS
+#define P2F_GAP_NOPS 1  // 0: experiment only (tools/permbench_nogap): rely on the compiler's own s_nop between asm statements
+#endif
+#define P2F_GAP()                                          \
+  do {                                                     \
+    if (P2F_GAP_NOPS && N == 1) P2F_A("s_nop 1");          \
+    else if (P2F_GAP_NOPS && N == 2) P2F_A("s_nop 0");     \
   } while (0)
 // v_mad_u64_u32 always writes a carry-out pair.  Where it is not needed it goes to one of eight fixed scratch pairs,
 // rotating between neighbouring statements: hipcc separates two inline-asm statements that touch a common
@@ -145,7 +148,7 @@ __device__ __forceinline__ void p2f_mulN(u64 (&r)[N], const u64 (&a)[N], const u
   for (int i = 0; i < N; i++) P2F_A("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(rl[i]), "=s"(bb[i]) : "v"(lo32(t[i])), "v"(hi32(hi[i])), "s"(c1[i]));
 #pragma unroll
   for (int i = 0; i < N; i++) P2F_CARRY_IN(i, "v_addc_co_u32_e64", rh[i], hi32(t[i]), c1[i]);
-  if (N == 1) P2F_A("s_nop 0");
+  if (P2F_GAP_NOPS && N == 1) P2F_A("s_nop 0");
 #pragma unroll
   for (int i = 0; i < N; i++) P2F_A("v_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh[i]), "=s"(bw[i]) : "0"(rh[i]), "s"(bb[i]));
   P2F_GAP();

@@ -272,6 +272,7 @@ struct mh_session {
   // ---- 1. main commitment ----
   void commit_main(u64 root[4]) {
     expect(1, "commit_main");
+    ProfScope span(c, "span:commit to main traces");  // prover/mod.rs:339
     std::vector<const mh_trace*> po;
     for (int j = 0; j < n_airs; j++) po.push_back(traces[order[j]]);
     main_tree.reset(commit_traces_dist(c, po, lb, dist));
@@ -282,6 +283,7 @@ struct mh_session {
   // aux_values_out: the aux values in PROOF order, flattened EF, exactly as they enter the transcript.
   void commit_aux(const std::vector<e2>& rnd, mh_aux_builder cb, void* user, u64 root[4], std::vector<e2>& aux_values_out) {
     expect(2, "commit_aux");
+    ProfScope span(c, "span:build aux traces + commit to aux traces");  // prover/mod.rs:355, :412
     MH_REQUIRE(rnd.size() == max_rand, "wrong number of randomness elements");
     randomness = rnd;
     std::vector<u64> rand_flat;
@@ -320,6 +322,7 @@ struct mh_session {
   // ---- 4. + 5. constraint evaluation, accumulation, quotient commitment ----
   void commit_quotient(e2 alpha, e2 beta, u64 root[4]) {
     expect(3, "commit_quotient");
+    ProfScope span(c, "span:evaluate constraints + commit to quotient poly chunks");  // prover/mod.rs:445, :542
     DevBuf acc;
     int log_n_prev = 0;
     for (int j = 0; j < n_airs; j++) {
@@ -394,6 +397,7 @@ struct mh_session {
   // ---- 7a. OOD evaluations at z and z*w_H: all trees, all matrices, aligned to 8 columns ----
   void ood(e2 zp) {
     expect(4, "ood");
+    ProfScope span(c, "span:evaluate at OOD points");  // pcs/deep/prover.rs:88
     MH_REQUIRE(ood_point_ok(zp), "OOD point lies on the trace domain or the LDE coset");
     z = zp;
     z_next = e2_mulf(z, gl_two_adic_generator(log_N));
@@ -425,6 +429,7 @@ struct mh_session {
   // ---- 7b. DEEP quotient ----
   void deep(e2 alpha_d, e2 beta_d) {
     expect(5, "deep");
+    ProfScope span(c, "span:DEEP quotient");  // pcs/prover.rs:57
     e2 fred0 = e2_make(0), fred1 = e2_make(0);
     for (size_t i = 0; i < W; i++) {
       fred0 = e2_add(e2_mul(fred0, alpha_d), ev0[i]);
@@ -446,6 +451,7 @@ struct mh_session {
   // ---- 8. FRI: commit the current layer, then fold it ----
   void fri_commit(u64 root[4]) {
     expect(6, "fri_commit");
+    ProfScope span(c, "span:FRI round commit");  // pcs/fri/prover.rs:164
     MH_REQUIRE((int)fri_trees.size() < rounds && !round_committed, "no FRI round left to commit");
     const int la = pp.log_folding_arity;
     if (sharded && log_rows - la < dist.logG) {
@@ -487,6 +493,7 @@ struct mh_session {
   }
   void fri_fold_round(e2 fb) {
     expect(6, "fri_fold");
+    ProfScope span(c, "span:FRI fold");  // pcs/fri/prover.rs:183
     MH_REQUIRE(round_committed, "fold before the round's commitment");
     const int la = pp.log_folding_arity;
     DevBuf next(((size_t)1 << (log_rows + cb_loc - la)) * 16);
@@ -502,6 +509,7 @@ struct mh_session {
   // returned in descending degree order.
   void fri_final(std::vector<e2>& desc) {
     expect(6, "fri_final");
+    ProfScope span(c, "span:idft final poly");  // pcs/fri/prover.rs:231
     MH_REQUIRE((int)fri_trees.size() == rounds && !round_committed, "FRI rounds not finished");
     const int logn_f = log_rows + cbits;
     const int log_fpd = std::max(0, logn_f - lb);
@@ -543,6 +551,7 @@ struct mh_session {
   // ---- 9. openings of every tree at the sampled domain indices, in transcript (hint) order ----
   void open(std::vector<size_t> idx, std::vector<u64>& fields, std::vector<u64>& commitments) {
     expect(7, "open");
+    ProfScope span(c, "span:query phase");  // pcs/prover.rs:89
     std::sort(idx.begin(), idx.end());
     idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
     for (size_t i : idx) MH_REQUIRE(i < ((size_t)1 << L), "query index out of range");

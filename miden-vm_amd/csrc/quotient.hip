@@ -292,7 +292,7 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
     inv_first.alloc(n * D * 8);
     inv_last.alloc(n * D * 8);
     ProfScope ps(c, "quotient_selectors", 16.0 * n * D);
-    hipLaunchKernelGGL(k_selector_inverses, dim3((unsigned)((n * D + 1023) / 1024)), dim3(256), 0, c->stream, tw, dblob.u() + o_tab,
+    MH_LAUNCH(k_selector_inverses, dim3((unsigned)((n * D + 1023) / 1024)), dim3(256), 0, c->stream, tw, dblob.u() + o_tab,
                        log_n, log_dl, wh_inv, inv_first.u(), inv_last.u());
   }
   if (air->jit) {  // compiled chunks: large constraint systems
@@ -311,7 +311,7 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
     j.t0 = (u32)t0;
     ProfScope ps(c, "quotient_eval", (double)n * D * (8.0 * air->touched_base_columns + 16.0));
     jit_quotient_run(c, air->jit, j, n * D);
-    hipLaunchKernelGGL(k_quot_finish, dim3((unsigned)((n * D + 255) / 256)), dim3(256), 0, c->stream, acc_out, dblob.u() + o_tab, log_n,
+    MH_LAUNCH(k_quot_finish, dim3((unsigned)((n * D + 255) / 256)), dim3(256), 0, c->stream, acc_out, dblob.u() + o_tab, log_n,
                        log_dl, acc_in, log_n_prev, beta);
     HIP_CHECK(hipStreamSynchronize(c->stream));
     return;
@@ -345,7 +345,7 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
   {
     // algorithmic bytes: every main/aux/preprocessed column the live DAG touches is read once, 16 B written
     ProfScope ps(c, "quotient_eval", (double)n * D * (8.0 * air->touched_base_columns + 16.0));
-    hipLaunchKernelGGL(k_eval_quotient, dim3((unsigned)((n * D + T - 1) / T)), dim3(T), lds, c->stream, a);
+    MH_LAUNCH(k_eval_quotient, dim3((unsigned)((n * D + T - 1) / T)), dim3(T), lds, c->stream, a);
   }
   HIP_CHECK(hipStreamSynchronize(c->stream));  // tables die with this scope
 }
@@ -389,7 +389,7 @@ void quotient_upsample_accumulate(mh_ctx* c, const u64* q_small, int log_n, int 
   const int ab = log_d - log_dj;
   MH_REQUIRE(ab > 0, "internal: nothing to upsample");
   DevBuf nat(2 * nd * 8), scratch(2 * nd * 8), lde((2 * nd << ab) * 8);
-  hipLaunchKernelGGL(k_quot_to_natural, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, c->stream, q_small, nat.u(), log_n, log_dj);
+  MH_LAUNCH(k_quot_to_natural, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, c->stream, q_small, nat.u(), log_n, log_dj);
   // evaluations on g_j * <w_{n Dj}>  ->  on g_j * w_{n D}^u * <w_{n Dj}>, u < 2^ab
   const u64 gj = gl_lde_shift(log_n + log_blowup), w = gl_two_adic_generator(log_n + log_d);
   std::vector<u64> outs((size_t)1 << ab);
@@ -400,7 +400,7 @@ void quotient_upsample_accumulate(mh_ctx* c, const u64* q_small, int log_n, int 
   }
   lde_columns(c, nat.u(), 2, log_n + log_dj, gj, outs, lde.u(), scratch.u());
   const size_t total = n << log_d;
-  hipLaunchKernelGGL(k_quot_regroup_accumulate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, lde.u(), log_n, log_dj,
+  MH_LAUNCH(k_quot_regroup_accumulate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, lde.u(), log_n, log_dj,
                      log_d, acc_in, log_n_prev, beta, acc_out);
   HIP_CHECK(hipStreamSynchronize(c->stream));
 }
