@@ -1,0 +1,72 @@
+"""The real Miden VM AIRs as constraint-DAG blobs (tools/ref_fixtures/src/bin/export_dag.rs writes tests/golden/miden_air_*.dag
+from the reference's symbolic builder; needs a Rust toolchain, so the files are absent from this repository and every test
+here SKIPS LOUDLY until a maintainer has run tools/ref_fixtures/run.sh).  With them: the header matches the MASM verifier's
+widths, and -- on a GPU -- the device prover (compiled chunks) and the oracle produce the same transcript for a random trace
+(the constraints are not satisfied by a random trace: prover-side parity only)."""
+import glob, json, os
+import numpy as np
+import pytest
+import oracle_binding as ob
+import airs as A
+from __graft_entry__ import load_package
+
+pkg = load_package()
+HERE = os.path.dirname(os.path.abspath(__file__))
+BLOBS = sorted(glob.glob(os.path.join(HERE, "golden", "miden_air_*.dag")))
+KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
+NO_BLOBS = ("NO MIDEN AIR BLOBS: tests/golden/miden_air_*.dag are absent (they need a Rust toolchain: run tools/ref_fixtures/run.sh "
+            "<miden-vm checkout>); the constraint kernels have only seen DummyMidenAir and synthetic DAGs")
+
+
+class BlobAir:
+    """Just enough of dag.Air for the oracle/product bindings: a blob and its header fields."""
+
+    def __init__(self, words):
+        self.blob = np.asarray(words, dtype=np.uint64)
+        w = [int(x) for x in self.blob[:12]]
+        assert w[0] == 0x4d48444147303031
+        (self.main_width, self.aux_width, self.num_randomness, self.num_aux_values, self.num_public, _np, self.log_quotient_degree, self.n_nodes,
+         self.n_constraints, self.preprocessed_width) = w[1:11]
+        self.build_aux, self.preprocessed, self.name = None, None, "miden"
+
+
+def load(path):
+    return BlobAir(np.fromfile(path, dtype="<u8"))
+
+
+def test_blob_reader_on_a_stand_in():
+    # the reader itself, on a blob made by the Python exporter (so that a failure with real blobs is about the blobs)
+    from miden_vm_amd import dag
+    ref = dag.dummy_miden_air(51, 4, num_aux_values=1)
+    air = BlobAir(ref.blob)
+    assert (air.main_width, air.aux_width, air.num_aux_values, air.num_randomness, air.log_quotient_degree) == (51, 4, 1, 2, 3)
+
+
+@pytest.mark.parametrize("path", BLOBS or [None], ids=[os.path.basename(p) for p in BLOBS] or ["absent"])
+def test_blob_headers_match_the_masm_layout(path):
+    if path is None:
+        pytest.skip(NO_BLOBS)
+    m = KAT["masm_layout"]
+    i = int(os.path.basename(path)[len("miden_air_"):-len(".dag")])
+    air = load(path)
+    assert air.main_width == m["main_widths"][i] and air.aux_width == m["aux_widths_ef"][i]
+    assert air.num_aux_values == 1 and air.num_randomness == m["num_aux_trace_coefs"]
+    assert 1 << air.log_quotient_degree == m["quotient_chunks"]
+
+
+@pytest.mark.gpu
+def test_device_and_oracle_agree_on_the_real_airs():
+    if len(BLOBS) != 3:
+        pytest.skip(NO_BLOBS)
+    airs_ = [load(p) for p in BLOBS]
+    traces = [A.dummy_trace(h, a.main_width, seed=40 + i) for i, (h, a) in enumerate(zip((8, 7, 6), airs_))]
+    pub = [0] * airs_[0].num_public
+    prm = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=5, query_pow_bits=3)
+    exp = ob.prove(airs_, traces, pub, prm)
+    ctx = pkg.Ctx(0)
+    try:
+        got = pkg.prove(ctx, [pkg.DeviceAir(ctx, a) for a in airs_], [ctx.upload_trace(t) for t in traces], pub, prm, ob.challenger_state(),
+                        ob.protocol_pre_observe(prm, pub), None)
+        assert (got.fields == exp["fields"]).all() and (got.commitments == exp["commitments"]).all() and (got.digest == exp["digest"]).all()
+    finally:
+        ctx.close()
