@@ -28,6 +28,10 @@ pub struct mh_pcs_params {
 }
 
 /// LiftedAir::build_aux_trace as a callback (prover/mod.rs:355-381); non-zero aborts the proof.
+#[repr(C)]
+pub struct mh_local_fabric {
+    _private: [u8; 0],
+}
 pub type mh_aux_builder = Option<
     unsafe extern "C" fn(user: *mut c_void, instance_idx: c_int, randomness: *const u64, aux_out: *mut u64, aux_values_out: *mut u64) -> c_int,
 >;
@@ -131,6 +135,9 @@ unsafe extern "C" {
     pub fn mh_rccl_unique_id(id: *mut u8) -> c_int;
     pub fn mh_comm_create_rccl(ctx: *mut mh_ctx, id: *const u8, rank: c_int, world: c_int, out: *mut *mut mh_comm) -> c_int;
     pub fn mh_comm_destroy(comm: *mut mh_comm);
+    pub fn mh_local_fabric_create(world: c_int) -> *mut mh_local_fabric;
+    pub fn mh_local_fabric_destroy(f: *mut mh_local_fabric);
+    pub fn mh_comm_create_local(ctx: *mut mh_ctx, f: *mut mh_local_fabric, rank: c_int, out: *mut *mut mh_comm) -> c_int;
     pub fn mh_comm_selftest(ctx: *mut mh_ctx, comm: *const mh_comm) -> c_int;
     pub fn mh_proof_free(p: *mut mh_proof);
     pub fn mh_proof_num_fields(p: *const mh_proof) -> usize;

@@ -223,7 +223,15 @@ typedef struct mh_comm {
 #define MH_RCCL_ID_BYTES 128
 int mh_rccl_unique_id(uint8_t id[MH_RCCL_ID_BYTES]);
 int mh_comm_create_rccl(mh_ctx* ctx, const uint8_t id[MH_RCCL_ID_BYTES], int rank, int world, mh_comm** out);
-void mh_comm_destroy(mh_comm* comm); /* communicators made by mh_comm_create_rccl */
+void mh_comm_destroy(mh_comm* comm); /* communicators made by mh_comm_create_rccl or mh_comm_create_local */
+/* The same collectives between the contexts of ONE process (one thread + one ctx per rank; ranks on different GPUs use peer
+ * copies over xGMI, ranks sharing a GPU plain device copies): create one fabric, then every rank's thread calls
+ * mh_comm_create_local (collective: returns when all `world` ranks have joined).  Stream ordered like the RCCL communicator.
+ * No RCCL, no launcher: the shape for a host that drives all GPUs of a node from one process. */
+typedef struct mh_local_fabric mh_local_fabric;
+mh_local_fabric* mh_local_fabric_create(int world);
+void mh_local_fabric_destroy(mh_local_fabric* f); /* after every rank's communicator has been destroyed */
+int mh_comm_create_local(mh_ctx* ctx, mh_local_fabric* f, int rank, mh_comm** out);
 int mh_comm_selftest(mh_ctx* ctx, const mh_comm* comm);
 /* mh_commit_traces for one rank of a sharded prover (every rank calls it with the same traces): the setup commitment
  * of preprocessed matrices for mh_prove_sharded / sharded sessions.  Same root as mh_commit_traces. */

@@ -33,6 +33,7 @@ EXPORTS = [
     "mh_host_alloc", "mh_host_free", "mh_verify", "mh_trace_from_device", "mh_lookup_load", "mh_lookup_free", "mh_air_attach_lookup", "mh_air_attach_preprocessed", "mh_lookup_build_aux", "mh_trace_download",
     "mh_verify_ex", "mh_external_logup_balance", "mh_proof_deserialize",
     "mh_rccl_unique_id", "mh_comm_create_rccl", "mh_comm_destroy", "mh_comm_selftest",
+    "mh_local_fabric_create", "mh_local_fabric_destroy", "mh_comm_create_local",
 ]
 
 _lib = None

@@ -158,8 +158,13 @@ int mh_comm_create_rccl(mh_ctx* c, const uint8_t id[MH_RCCL_ID_BYTES], int rank,
   }
 }
 
+extern "C" void mh_comm_destroy_local(mh_comm* comm);  // comm_local.cpp (a no-op for other communicators)
 void mh_comm_destroy(mh_comm* comm) {
-  if (!comm || comm->all_to_all != rccl_all_to_all) return;  // only communicators made by mh_comm_create_rccl
+  if (!comm) return;
+  if (comm->all_to_all != rccl_all_to_all) {  // only communicators made by this library
+    mh_comm_destroy_local(comm);
+    return;
+  }
   RcclComm* rc = static_cast<RcclComm*>(comm->user);
   (void)hipSetDevice(rc->ctx->device);
   (void)hipStreamSynchronize(rc->ctx->stream);

@@ -218,6 +218,46 @@ class RcclComm:
             self._h = None
 
 
+class LocalFabric:
+    """mh_local_fabric: the meeting point of the ranks of ONE process (one thread + one ctx per rank)."""
+
+    def __init__(self, lib, world):
+        lib.mh_local_fabric_create.restype = C.c_void_p
+        lib.mh_local_fabric_create.argtypes = [C.c_int]
+        lib.mh_local_fabric_destroy.argtypes = [C.c_void_p]
+        self.lib, self.world = lib, world
+        self.h = lib.mh_local_fabric_create(world)
+        if not self.h:
+            raise RuntimeError("mh_local_fabric_create failed (world must be a power of two)")
+
+    def close(self):
+        if self.h:
+            self.lib.mh_local_fabric_destroy(self.h)
+            self.h = None
+
+
+class LocalComm:
+    """mh_comm_create_local: this thread's rank of a LocalFabric (collective: returns when every rank has joined)."""
+
+    def __init__(self, ctx, fabric, rank):
+        self.ctx, self.rank, self.world = ctx, rank, fabric.world
+        h = C.POINTER(MhComm)()
+        ctx.lib.mh_comm_create_local.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.POINTER(MhComm))]
+        ctx.check(ctx.lib.mh_comm_create_local(ctx.h, fabric.h, rank, C.byref(h)))
+        self._h = h
+        self.struct = h.contents
+
+    def selftest(self):
+        self.ctx.lib.mh_comm_selftest.argtypes = [C.c_void_p, C.POINTER(MhComm)]
+        self.ctx.check(self.ctx.lib.mh_comm_selftest(self.ctx.h, self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx.lib.mh_comm_destroy.argtypes = [C.POINTER(MhComm)]
+            self.ctx.lib.mh_comm_destroy(self._h)
+            self._h = None
+
+
 def comm_selftest(ctx, comm):
     """mh_comm_selftest on any communicator object of this module (every rank calls it)."""
     ctx.lib.mh_comm_selftest.argtypes = [C.c_void_p, C.POINTER(MhComm)]

@@ -210,3 +210,86 @@ def test_rccl_communicator_world2_when_two_devices_are_visible():
     ret = mgr.dict()
     mp.spawn(_selftest_worker, args=(2, port, "rccl", ret), nprocs=2, join=True)
     assert all(ret.get(r) for r in range(2)), dict(ret)
+
+
+# ---- stream-ordered communicators with more than one rank: thread ranks of one process (csrc/comm_local.cpp) -----------
+def _thread_ranks(world, body):
+    """Run body(rank, ctx, comm) on `world` threads, one ctx each (all on GPU 0 of the test box), joined by a LocalFabric."""
+    import threading
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from miden_vm_amd import sharding
+    fabric = sharding.LocalFabric(pkg.load_library(), world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            ctx = pkg.Ctx(0)
+            comm = sharding.LocalComm(ctx, fabric, rank)
+            try:
+                results[rank] = body(pkg, sharding, rank, ctx, comm)
+            finally:
+                comm.close()
+                ctx.close()
+        except Exception as e:  # pragma: no cover
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    fabric.close()
+    assert not errors, errors
+    return results
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_local_communicator_selftest(world):
+    res = _thread_ranks(world, lambda pkg, sharding, rank, ctx, comm: (comm.selftest(), comm.struct.stream_ordered)[1])
+    assert res == [1] * world
+
+
+@pytest.mark.parametrize("world,case", [(2, "miden_small"), (4, "miden"), (8, "miden"), (2, "multi")])
+def test_sharded_proof_through_a_stream_ordered_communicator(world, case):
+    """The sharded prover with a STREAM-ORDERED communicator and several ranks (what the RCCL communicator is on a multi-GPU
+    node): no host synchronisation around the collectives.  Every rank's proof must equal the single-GPU proof."""
+    import oracle_binding as ob
+    import airs as A
+    from miden_vm_amd import dag
+    if case == "miden":
+        airs_, traces, pub, prm = [dag.dummy_miden_air(51, 8)], [A.dummy_trace(10, 51)], [], ob.PROD_PARAMS
+    elif case == "miden_small":
+        airs_, traces, pub, prm = [dag.dummy_miden_air(11, 2)], [A.dummy_trace(6, 11)], [], dict(
+            log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=5, query_pow_bits=3)
+    else:
+        t1, pub = A.fib_trace(8)
+        airs_, traces = [A.periodic_air(3), A.fib_air()], [A.periodic_trace(6), t1]
+        prm = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=6, query_pow_bits=3)
+    st, pre = ob.challenger_state(), ob.protocol_pre_observe(prm, pub)
+    need_cb = any(a.build_aux is not None for a in airs_)
+
+    def aux_builder(idx, rnd):
+        a = airs_[idx]
+        if a.build_aux is None:
+            return np.zeros((traces[idx].shape[0], 2 * a.aux_width), dtype=np.uint64), [0] * (2 * a.num_aux_values)
+        return a.build_aux(traces[idx], rnd[:a.num_randomness])
+
+    def body(pkg, sharding, rank, ctx, comm):
+        dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+        dtr = [ctx.upload_trace(t) for t in traces]
+        got = sharding.prove_sharded(pkg, ctx, comm, dairs, dtr, pub, prm, st, pre, aux_builder if need_cb else None)
+        got2 = sharding.prove_sharded(pkg, ctx, comm, dairs, dtr, pub, prm, st, pre, aux_builder if need_cb else None)  # buffers reused
+        ref = pkg.prove(ctx, dairs, dtr, pub, prm, st, pre, aux_builder if need_cb else None) if rank == 0 else None
+        return got, got2, ref
+
+    res = _thread_ranks(world, body)
+    ref = res[0][2]
+    for got, got2, _ in res:
+        for g in (got, got2):
+            assert g.fields.size == ref.fields.size and (g.fields == ref.fields).all()
+            assert (g.commitments == ref.commitments).all() and (g.digest == ref.digest).all()
+    ok, msg = ob.verify(airs_, ref.log_trace_heights, pub, {"fields": ref.fields, "commitments": ref.commitments}, prm)
+    assert ok, msg
