@@ -3,12 +3,13 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/final
+rm -rf $O
 mkdir -p $O
-python bench.py --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err
+python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 tail -c 400 $O/bench.json
-rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/kt.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C -d $O/pmc_$C -o pmc --output-format csv -- python bench.py --steps 3 --warmup 0 --no-cpu-baseline > $O/pmc_$C.log 2>&1
+  rocprofv3 --pmc $C -d $O/pmc_$C -o pmc --output-format csv -- python bench.py --steps 3 --warmup 0 --no-cpu-baseline --no-extras > $O/pmc_$C.log 2>&1
 done
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_VALU -d $O/pmc_SQ -o pmc --output-format csv -- python bench.py --steps 3 --warmup 0 --no-cpu-baseline > $O/pmc_SQ.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_VALU -d $O/pmc_SQ -o pmc --output-format csv -- python bench.py --steps 3 --warmup 0 --no-cpu-baseline --no-extras > $O/pmc_SQ.log 2>&1
 ls -R $O | head -40

@@ -3,10 +3,10 @@
 import csv, collections, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O = os.path.join(ROOT, "gpurun_out", "final")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
 out = []
-out.append("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline   (4 proofs of miden:20:51:8; ns)")
-out.append("# (k_perm_rate = the register-only Poseidon2 calibration of bench.py's roofline_valu.peak; it runs once, outside the timed region)")
+out.append("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras   (4 proofs of miden:20:51:8; ns)")
+out.append("# (k_perm_rate = the register-only Poseidon2 rate bench.py reports next to roofline_valu; it runs once, outside the timed region)")
 out.append(open(os.path.join(O, "kt", "kt_kernel_stats.csv")).read().strip())
 
 
@@ -34,16 +34,21 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["SQ_INSTS_VALU"])[:8]:
     w = max(1.0, v["SQ_WAVES"])
     out.append(f"{k},{disp[k]},{int(w)},{v['SQ_INSTS_VALU']:.3e},{v['SQ_INSTS_VALU'] / w:.0f},{v['SQ_ACTIVE_INST_VALU'] / max(1, v['SQ_BUSY_CYCLES']):.3f},"
                f"{v['SQ_WAIT_INST_ANY'] / max(1, v['SQ_WAVE_CYCLES']):.3f},{v['SQ_WAIT_ANY'] / max(1, v['SQ_WAVE_CYCLES']):.3f}")
+la_sq = agg.get("k_leaf_absorb")
+if la_sq:
+    perms = 3 * (8 << 20) * 11  # three proofs in the pass, 8 * 2^20 leaves, 7 + 2 + 2 permutations per leaf
+    out.append(f"# k_leaf_absorb: SQ_INSTS_VALU per permutation = {la_sq['SQ_INSTS_VALU'] * 64 / perms:.0f} wave-instructions x 64 lanes / {perms} permutations "
+               f"= {la_sq['SQ_INSTS_VALU'] / (perms / 64):.0f} VALU instructions per permutation (loads/stores and address arithmetic of the kernel included)")
 bench = open(os.path.join(O, "bench.json")).read().strip().splitlines()[-1]
-out.append("# bench line (same build, un-profiled, python bench.py --steps 10 --warmup 3):")
+out.append("# bench line (same build, un-profiled, python bench.py --steps 20 --warmup 5):")
 out.append(bench)
 open(os.path.join(ROOT, "profiles", f"{tag}_rocprof.txt"), "w").write("\n".join(out) + "\n")
 la = per_launch.get("k_leaf_absorb", {})
 if la:
-    j = {"kernel": "k_leaf_absorb", "fetch_size_kb_per_launch": la["FETCH_SIZE"], "write_size_kb_per_launch": la["WRITE_SIZE"],
+    j = {"kernel": "lmcs_leaf_absorb", "device_kernel": "k_leaf_absorb", "fetch_size_kb_per_launch": la["FETCH_SIZE"], "write_size_kb_per_launch": la["WRITE_SIZE"],
          "fetch_correction": 2.0, "hbm_bytes_per_launch": (2.0 * la["FETCH_SIZE"] + la["WRITE_SIZE"]) * 1024,
          "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, averaged over the 3 leaf-absorb launches of a proof "
                  "(main, aux, quotient); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts wide coalesced reads at half)",
          "source": f"profiles/{tag}_rocprof.txt"}
-    json.dump(j, open(os.path.join(ROOT, "profiles", "r01_pmc_leaf_absorb.json"), "w"), indent=1)
+    json.dump(j, open(os.path.join(ROOT, "profiles", tag.split("_")[0] + "_pmc_leaf_absorb.json"), "w"), indent=1)
 print("\n".join(out[-3:])[:1500])
