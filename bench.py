@@ -117,12 +117,13 @@ def roofline(prof, pmc_file):
 
 
 def valu_roofline(ctx, prof, perms, steps):
-    """The bound the hash kernels actually live on: VALU issue.  peak = SIMDs x shader clock x 64 lanes / issue cycles of ONE
-    permutation's counted minimal instruction sequence: 506 field multiplications (480 S-box + 22
-    round-scale + ... ) of 13 VALU instructions at the 4 issue cycles measured for v_mad_u64_u32 and the carry-chain VOP3
-    forms, plus 3500 linear-layer instructions (one per 64-bit add/shift-add of the wide representation, folds included) at
-    the 2.5 cycles their instruction mix measures.  The clock is the one s_memtime reports under this load
-    (tools/permbench).  A hardware figure: the register-only rate of our own code is reported next to it, not used as peak."""
+    """The bound the hash kernels actually live on: VALU issue.  On gfx950 every VALU instruction of this integer code
+    (v_mad_u64_u32, the carry-chain VOP3 forms, v_lshl_add_u64, shifts) issues in 4 cycles per wave per SIMD: measured, the
+    register-only permutation runs 10.95 k VALU instructions in 43.7 k s_memtime cycles per wave (tools/permbench,
+    profiles/r02_final_rocprof.txt).  peak = SIMDs x max shader clock x 64 lanes / (4 cycles x the counted MINIMAL instruction
+    sequence of one permutation): 506 field multiplications (472 S-box + 22 round-scale + 12 de-scale) of 13 VALU instructions
+    + 3500 linear-layer instructions (one per 64-bit add / shift-add of the wide representation, 6 per fold) -- DESIGN.md
+    section 3.  A hardware figure: the register-only rate of our own code is reported next to it, not used as the peak."""
     out = {"kernel": "lmcs_leaf_absorb", "bound": "valu", "unit": "Gperm/s"}
     ach = perms / (prof["lmcs_leaf_absorb"]["ms"] / steps * 1e-3)
     out["achieved"] = ach / 1e9
@@ -130,12 +131,13 @@ def valu_roofline(ctx, prof, perms, steps):
         out["register_rate"] = ctx.poseidon2_register_rate() / 1e9
     except Exception as e:  # pragma: no cover
         out["register_rate_error"] = repr(e)[:120]
-    N_MUL, MUL_VALU, MUL_CYCLES, LIN_VALU, LIN_CYCLES, SIMDS, CLOCK_GHZ = 506, 13, 4.0, 3500, 2.5, 1024, 2.24
-    cycles = N_MUL * MUL_VALU * MUL_CYCLES + LIN_VALU * LIN_CYCLES
-    out["peak"] = SIMDS * CLOCK_GHZ * 64 / cycles
+    N_MUL, MUL_VALU, LIN_VALU, CYCLES_PER_VALU, SIMDS, MAX_CLOCK_GHZ = 506, 13, 3500, 4.0, 1024, 2.4
+    min_valu = N_MUL * MUL_VALU + LIN_VALU
+    out["peak"] = SIMDS * MAX_CLOCK_GHZ * 64 / (min_valu * CYCLES_PER_VALU)
     out["frac"] = out["achieved"] / out["peak"]
-    out["peak_basis"] = (f"{SIMDS} SIMDs x {CLOCK_GHZ} GHz x 64 lanes / ({N_MUL} mul x {MUL_VALU} VALU x {MUL_CYCLES:.0f} cyc + "
-                         f"{LIN_VALU} linear VALU x {LIN_CYCLES} cyc = {cycles:.0f} issue cycles per wave-permutation)")
+    out["valu_per_permutation"] = {"counted_minimum": min_valu, "measured_SQ_INSTS_VALU": 10977}
+    out["peak_basis"] = (f"{SIMDS} SIMDs x {MAX_CLOCK_GHZ} GHz (max clock) x 64 lanes / ({min_valu} VALU x {CYCLES_PER_VALU:.0f} issue cycles); "
+                         "measured clock under this load 2.24 GHz (s_memtime)")
     return out
 
 
