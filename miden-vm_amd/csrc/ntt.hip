@@ -22,13 +22,17 @@
 #include "kernels.hpp"
 #include "poseidon2_fast.cuh"
 
-// Field multiplications of the passes: the asm form of poseidon2_fast.cuh (volatile statements, in interleaved
-// groups) or the compiler-scheduled C form.  Measured per 2^20-row proof: see DESIGN.md section 3.
+// Field multiplications of the passes (table twiddles, coset scale): 0 = the compiler-scheduled C form (~23 VALU),
+// 1 = the volatile interleaved asm form of the hash kernels (pins the schedule: table loads are no longer hoisted, VGPRs
+// 119 -> 150+; LDE 11.5 -> 12.7 ms), 2 = the same 13-instruction product as NON-volatile statements that carry their own
+// wait states (108-111 VGPRs, LDE 11.12 -> 10.87 ms per 2^20-row proof).  Default 2.
 #ifndef NTT_ASM_MUL
-#define NTT_ASM_MUL 0
+#define NTT_ASM_MUL 2
 #endif
-#if P2F_ASM && NTT_ASM_MUL
+#if P2F_ASM && NTT_ASM_MUL == 1
 #define NTT_MUL1 p2f_mul
+#elif P2F_ASM && NTT_ASM_MUL == 2
+#define NTT_MUL1 p2f_mul_nv  // non-volatile statements: the compiler keeps its freedom to hoist loads and interleave
 #else
 #define NTT_MUL1 p2f_mul_c
 #endif
@@ -215,11 +219,11 @@ __device__ __forceinline__ void ntt_tw_mul(u64* x, const u64* __restrict__ tw, i
       a[i] = x[OFF + i];
       b[i] = tw[((size_t)(OFF + i - 1) << s) | gm];
     }
-#if P2F_ASM && NTT_ASM_MUL
+#if P2F_ASM && NTT_ASM_MUL == 1
     p2f_mulN<C>(a, a, b);
 #else
 #pragma unroll
-    for (int i = 0; i < C; i++) a[i] = p2f_mul_c(a[i], b[i]);
+    for (int i = 0; i < C; i++) a[i] = NTT_MUL1(a[i], b[i]);
 #endif
 #pragma unroll
     for (int i = 0; i < C; i++) x[OFF + i] = a[i];
