@@ -37,7 +37,43 @@ FI u64 gl_reduce128(u64 hi, u64 lo) {
   if (r < t1) r += GL_EPS;
   return r >= GL_P ? r - GL_P : r;
 }
-FI u64 gl_mul(u64 a, u64 b) { return gl_reduce128(__umul64hi(a, b), a * b); }
+FI u64 gl_mul_c(u64 a, u64 b) { return gl_reduce128(__umul64hi(a, b), a * b); }
+#ifndef MH_JIT_ASM_MUL
+#define MH_JIT_ASM_MUL 0
+#endif
+#if MH_JIT_ASM_MUL
+// the 13-instruction SGPR-carry-chain product of poseidon2_fast.cuh (p2f_mul_nv: non-volatile statements carrying their own
+// wait states), canonicalised on exit -- an experiment switch (-DMH_JIT_ASM_MUL=1 through $MH_JIT_FLAGS), see DESIGN.md section 3
+FI u32 jlo(u64 x) { return (u32)x; }
+FI u32 jhi(u64 x) { return (u32)(x >> 32); }
+FI u64 gl_mul(u64 a, u64 b) {
+  u64 p00, m, hi, t, d0, d1, d2, d3, d4, d5, cm, k1, k2, c1, bb, bw, c3;
+  u32 w1, accl, acch, rl, rh;
+  const u32 zero = 0;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p00), "=s"(d0) : "v"(jlo(a)), "v"(jlo(b)));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(m), "=s"(d1) : "v"(jlo(a)), "v"(jhi(b)));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m), "=s"(cm) : "v"(jhi(a)), "v"(jlo(b)), "0"(m));
+  asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(w1), "=s"(k1) : "v"(jhi(p00)), "v"(jlo(m)));
+  asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(accl), "=s"(k2) : "v"(jhi(m)), "s"(k1));
+  const u64 k3 = cm | k2;
+  asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(acch), "=s"(d2) : "v"(zero), "s"(k3));
+  const u64 acc = ((u64)acch << 32) | accl;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(hi), "=s"(d3) : "v"(jhi(a)), "v"(jhi(b)), "v"(acc));
+  const u64 lo = ((u64)w1 << 32) | jlo(p00);
+  asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t), "=s"(c1) : "v"(jlo(hi)), "v"(lo));
+  asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(rl), "=s"(bb) : "v"(jlo(t)), "v"(jhi(hi)), "s"(c1));
+  asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh), "=s"(d4) : "v"(jhi(t)), "s"(c1));
+  asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh), "=s"(bw) : "0"(rh), "s"(bb));
+  asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rl), "=s"(c3) : "0"(rl), "s"(bw));
+  const u64 mk = bw & ~c3;
+  asm("v_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh), "=s"(d5) : "0"(rh), "s"(mk));
+  const u64 r = ((u64)rh << 32) | rl;
+  const u64 u = r + GL_EPS;  // r >= p  <=>  r + eps carries out of 64 bits
+  return u < r ? u : r;
+}
+#else
+FI u64 gl_mul(u64 a, u64 b) { return gl_mul_c(a, b); }
+#endif
 struct e2 { u64 c0, c1; };
 FI u64 gl_mul7(u64 a) { u64 a2 = gl_add(a, a), a4 = gl_add(a2, a2), a8 = gl_add(a4, a4); return gl_sub(a8, a); }
 FI e2 e2_add(e2 a, e2 b) { return {gl_add(a.c0, b.c0), gl_add(a.c1, b.c1)}; }
@@ -104,8 +140,10 @@ std::string cache_dir() {
     }
   return dir;
 }
-std::string cache_key(const std::string& src) {
+std::string cache_key(const std::string& src_only) {
   u64 h1 = 0xcbf29ce484222325ULL, h2 = 0x9ae16a3b2f90404fULL;  // two FNV-1a style streams
+  const char* extra = getenv("MH_JIT_FLAGS");
+  const std::string src = src_only + (extra ? std::string("\n//flags:") + extra : std::string());
   for (unsigned char ch : src) {
     h1 = (h1 ^ ch) * 0x100000001b3ULL;
     h2 = (h2 ^ ch) * 0x9e3779b97f4a7c15ULL + 0x7f4a7c15ULL;
@@ -464,8 +502,10 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
         ch.from_cache = false;
         hiprtcProgram prog;
         hiprtc_check(hiprtcCreateProgram(&prog, ch.src.c_str(), "mh_jit_chunk.hip", 0, nullptr, nullptr), "create");
-        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-        const hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+        // $MH_JIT_FLAGS: one extra compiler option for experiments (e.g. -DMH_JIT_ASM_MUL=1); it is part of the cache key
+        const char* extra = getenv("MH_JIT_FLAGS");
+        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", extra && *extra ? extra : "-DMH_JIT_DEFAULT"};
+        const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
         if (r != HIPRTC_SUCCESS) {
           size_t ls = 0;
           hiprtcGetProgramLogSize(prog, &ls);
