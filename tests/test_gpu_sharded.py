@@ -252,7 +252,7 @@ def test_local_communicator_selftest(world):
     assert res == [1] * world
 
 
-@pytest.mark.parametrize("world,case", [(2, "miden_small"), (4, "miden"), (8, "miden"), (2, "multi")])
+@pytest.mark.parametrize("world,case", [(2, "miden_small"), (4, "miden"), (8, "miden"), (2, "multi"), (8, "miden18"), (2, "miden20")])
 def test_sharded_proof_through_a_stream_ordered_communicator(world, case):
     """The sharded prover with a STREAM-ORDERED communicator and several ranks (what the RCCL communicator is on a multi-GPU
     node): no host synchronisation around the collectives.  Every rank's proof must equal the single-GPU proof."""
@@ -261,6 +261,8 @@ def test_sharded_proof_through_a_stream_ordered_communicator(world, case):
     from miden_vm_amd import dag
     if case == "miden":
         airs_, traces, pub, prm = [dag.dummy_miden_air(51, 8)], [A.dummy_trace(10, 51)], [], ob.PROD_PARAMS
+    elif case in ("miden18", "miden20"):  # bench-sized shards: every NTT pass shape and the real collective sizes
+        airs_, traces, pub, prm = [dag.dummy_miden_air(51, 8)], [A.dummy_trace(int(case[5:]), 51)], [], ob.PROD_PARAMS
     elif case == "miden_small":
         airs_, traces, pub, prm = [dag.dummy_miden_air(11, 2)], [A.dummy_trace(6, 11)], [], dict(
             log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=5, query_pow_bits=3)
