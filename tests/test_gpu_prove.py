@@ -239,7 +239,7 @@ def test_rejects_bad_shapes(ctx):
 
 
 # ---- staged session: the caller owns the transcript (here: the oracle's challenger) ------------------
-def staged_prove(ctx, airs_, traces, publics, params, device_grind=True):
+def staged_prove(ctx, airs_, traces, publics, params, device_grind=True, comm=None):
     """Drive mh_session_* with an external challenger in the order of SURVEY.md Appendix A; returns
     (fields, commitments[k][4], digest) exactly as a host-side ProverTranscript would record them."""
     pkg = load_package()
@@ -276,7 +276,7 @@ def staged_prove(ctx, airs_, traces, publics, params, device_grind=True):
             w = ch.grind(bits)
         fields.append(w)
 
-    s = pkg.Session(ctx, dairs, dtr, publics, params)
+    s = pkg.Session(ctx, dairs, dtr, publics, params, comm=comm)
     sh = s.shape
     send_commitment(s.commit_main())
     rnd = [ch.sample_ef() for _ in range(sh.num_randomness)]

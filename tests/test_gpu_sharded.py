@@ -295,3 +295,31 @@ def test_sharded_proof_through_a_stream_ordered_communicator(world, case):
             assert (g.commitments == ref.commitments).all() and (g.digest == ref.digest).all()
     ok, msg = ob.verify(airs_, ref.log_trace_heights, pub, {"fields": ref.fields, "commitments": ref.commitments}, prm)
     assert ok, msg
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_staged_session_with_a_host_owned_transcript(world):
+    """mh_session_* with a communicator: every rank's host keeps its own copy of the (deterministic) transcript -- here the
+    oracle's challenger object, standing in for p3's DuplexChallenger in the Rust shim -- and drives its shard of the device
+    stages; all ranks must end with the proof mh_prove makes on one GPU."""
+    import oracle_binding as ob
+    import airs as A
+    from miden_vm_amd import dag
+    from test_gpu_prove import staged_prove, gpu_prove
+    t1, pub = A.fib_trace(8)
+    cases = [([dag.dummy_miden_air(51, 8)], [A.dummy_trace(12, 51)], [], ob.PROD_PARAMS),
+             ([A.periodic_air(3), A.fib_air()], [A.periodic_trace(6), t1], pub,
+              dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=6, query_pow_bits=3))]
+    for airs_, traces, pubs, prm in cases:
+        if world > 1 << min(a.log_quotient_degree for a in airs_):
+            continue  # a proof shards over at most min(blowup, quotient degree) ranks
+
+        def body(pkg, sharding, rank, ctx, comm):
+            f, c, d = staged_prove(ctx, airs_, traces, pubs, prm, comm=comm.struct)
+            ref = gpu_prove(ctx, airs_, traces, pubs, prm) if rank == 0 else None
+            return f, c, d, ref
+        res = _thread_ranks(world, body)
+        ref = res[0][3]
+        for f, c, d, _ in res:
+            assert f.size == ref.fields.size and (f == ref.fields).all()
+            assert (c == ref.commitments).all() and (d == ref.digest).all()
