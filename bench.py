@@ -18,7 +18,8 @@ parameters (air/src/config.rs:54-67) and the Poseidon2 LMCS + challenger, the tr
 value = rows of the proved trace / seconds per step, whole job.  The CPU oracle is used ONLY for the `cpu_baseline` leg (a
 bounded sample), never inside the timed GPU region.  Extra keys on the N = 1 line: `h2d_inclusive` (SURVEY.md section 8(d):
 the same proof with the host->device upload of the trace inside the timed region) and `miden_shape` (the full Miden VM
-shape: three AIRs of widths 51/22/16 with 4/3/1 EF aux columns, the published reference figure's neighbour).
+shape: three AIRs of widths 51/22/16 with 4/3/1 EF aux columns, the published reference figure's neighbour) and `in_flight`
+(three proofs in flight on the one GPU, one context per proving thread: service throughput, not the headline).
 """
 import argparse, json, os, sys, time
 
@@ -141,6 +142,42 @@ def valu_roofline(ctx, prof, perms, steps):
     return out
 
 
+def in_flight_probe(pkg, log_n, device, k=3, steps=4):
+    """Service throughput: k proofs in flight on the one GPU, each proving thread with its own context (its own HIP stream).
+    The latency-bound stretches of one proof (tree tops of a few waves, FRI tail, Fiat-Shamir round trips) are filled by the
+    kernels of the others.  NOT the headline: `value` stays the rate of one proof at a time."""
+    import threading
+    ctxs = [pkg.Ctx(device) for _ in range(k)]
+    runners = [ProveRunner(pkg, c, log_n, 11 + i) for i, c in enumerate(ctxs)]
+    for r in runners:
+        r.step()
+    bar = threading.Barrier(k + 1)
+
+    def work(r):
+        bar.wait()
+        for _ in range(steps):
+            r.step()
+        bar.wait()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in runners]
+    for t in th:
+        t.start()
+    bar.wait()
+    t0 = time.perf_counter()
+    bar.wait()
+    dt = time.perf_counter() - t0
+    for t in th:
+        t.join()
+    for r in runners:
+        r.trace.free()
+        r.dair.free()
+    for c in ctxs:
+        c.close()
+    return {"proofs_in_flight": k, "proofs": k * steps, "value": k * steps * (1 << log_n) / dt, "unit": "trace rows/s",
+            "ms_per_proof_amortised": dt / (k * steps) * 1e3,
+            "note": "k proving threads, one context (HIP stream) each, same GPU; every proof is a complete independent proof"}
+
+
 def cpu_baseline(runner, cpu_log_n):
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -192,7 +229,7 @@ def main():
                     help="rows of the ONE proof sharded over the GPUs (N > 1)")
     ap.add_argument("--comm", default=os.environ.get("MIDEN_BENCH_COMM", "rccl"), choices=["rccl", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the h2d_inclusive and miden_shape probes")
+    ap.add_argument("--no-extras", action="store_true", help="skip the h2d_inclusive, miden_shape and in_flight probes")
     ap.add_argument("--cpu-log-n", type=int, default=18)
     args = ap.parse_args()
 
@@ -341,6 +378,10 @@ def main():
             out["miden_shape"] = miden_shape_probe(pkg, ctx)
         except Exception as e:
             out["miden_shape"] = {"error": repr(e)[:200]}
+        try:
+            out["in_flight"] = in_flight_probe(pkg, log_n, dev_index)
+        except Exception as e:
+            out["in_flight"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(runner, args.cpu_log_n)
     elif rank == 0:

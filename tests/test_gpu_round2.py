@@ -82,3 +82,41 @@ def test_coset_lde_matches_oracle_big_plans(ctx, log_n):
     exp = ob.coset_lde_bitrev(t, added, shift)
     assert got.shape == exp.shape
     assert (got == exp).all()
+
+
+def test_contexts_are_reentrant_across_proving_threads():
+    """SURVEY.md section 8(b) threading contract: one ctx per proving thread, no global state, re-entrant across contexts.
+    Three threads prove different instances at the same time on the one GPU (their kernels overlap on three streams); every
+    proof must be byte-identical to the oracle's, several rounds in a row."""
+    import threading
+    pkg = load_package()
+    t_fib, pub_fib = A.fib_trace(9)
+    jobs = [([A.fib_air()], [t_fib], pub_fib, FAST),
+            ([dag.dummy_miden_air(13, 2)], [A.dummy_trace(12, 13)], [], FAST),
+            ([A.periodic_air(3), A.fib_air()], [A.periodic_trace(6), A.fib_trace(8)[0]], A.fib_trace(8)[1], dict(FAST, log_blowup=2))]
+    expected = [ob.prove(*j) for j in jobs]
+    ctxs = [pkg.Ctx(0) for _ in jobs]
+    results, errors = [[] for _ in jobs], []
+    bar = threading.Barrier(len(jobs))
+
+    def work(i):
+        try:
+            bar.wait()
+            for _ in range(4):
+                results[i].append(gpu_prove(ctxs[i], *jobs[i]))
+        except Exception as e:  # pragma: no cover
+            errors.append((i, repr(e)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for c in ctxs:
+        c.close()
+    assert not errors, errors
+    for i, exp in enumerate(expected):
+        assert len(results[i]) == 4
+        for got in results[i]:
+            assert (got.fields == exp["fields"]).all() and (got.commitments == exp["commitments"]).all(), f"job {i} differs under concurrency"
+            assert [int(x) for x in got.digest] == [int(x) for x in exp["digest"]]
