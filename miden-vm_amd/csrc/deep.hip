@@ -128,7 +128,9 @@ void deep_ood_eval_matrix(mh_ctx* c, const LdeMatrix& m, int log_blowup, e2 y0, 
 }
 
 // ---- DEEP reduce + assemble ----------------------------------------------------------------------
-static constexpr int DEEP_MAX_MATS = 24;
+// one descriptor per committed matrix travels in the kernel arguments (4 KB): a chiplet-stack statement of twelve AIRs
+// (precompiles-prover/src/session/prove.rs) commits 12 x {main, aux, quotient} + its setup matrices
+static constexpr int DEEP_MAX_MATS = 128;
 static constexpr unsigned DEEP_FLUSH = 128;
 static constexpr int DEEP_PTS = 2;  // points per lane (they share one Fermat inversion); more costs occupancy
 struct DeepMat {

@@ -346,3 +346,52 @@ def range_air(log_n, seed=23):
         return m
 
     return dag.Air(b, build_aux, f"range:{log_n}", preprocessed=prep), lookup, trace
+
+
+# ------------------------------------------------------------------------------------------------
+def bus_air(sign, extra_cols=0, tag=3):
+    """One side of a CROSS-AIR LogUp bus (precompiles-prover/src/session/prove.rs: twelve chiplet AIRs whose sigma finals must
+    sum to zero, closed by MultiAir::eval_external).  Main column 0 = the message; aux column 0 = the running sum of
+    sign / (r0 + tag * r1 + V), its final the AIR's one aux value.  The per-row constraints hold for ANY trace; whether the
+    senders' and receivers' multisets agree is visible only in the sum of the finals over the AIRs.
+    Returns (Air, Lookup)."""
+    w = 1 + extra_cols
+    s = sign % P
+
+    def denom(b):
+        return b.randomness(0) + b.randomness(1) * tag + b.main(0)
+
+    b = dag.AirBuilder(w, aux_width=1, num_randomness=2, num_aux_values=1, num_public=0)
+    d = denom(b)
+    acc, acc_next = b.aux(0), b.aux(0, 1)
+    b.assert_zero_ext(b.is_transition() * ((acc_next - acc) * d - s))
+    b.assert_zero_ext(b.is_first_row() * acc)
+    b.assert_zero_ext(b.is_last_row() * ((b.aux_value(0) - acc) * d - s))
+    for c in range(1, w):  # filler columns take part in a constraint so that they are live
+        b.assert_zero(b.main(c) * b.main(c) - b.main(c) * b.main(c))
+    lb = dag.LookupBuilder(w, num_cols=1, num_randomness=2)
+    lb.fraction(0, lb.const(s), denom(lb))
+    lookup = dag.Lookup(lb, f"bus{sign:+d}")
+
+    def build_aux(main, randomness):
+        import oracle_binding as ob
+        aux, fin = ob.lookup_build_aux(lookup, main, randomness)
+        return aux, [int(fin[0]), int(fin[1])]
+
+    return dag.Air(b, build_aux, f"bus{sign:+d}:{w}"), lookup
+
+
+def bus_traces(log_n, extra_cols=(0, 0, 0), seed=23, valid=True):
+    """A sender of 2^log_n messages and two receivers of half of them each (in shuffled order)."""
+    rng = np.random.default_rng(seed)
+    n = 1 << log_n
+    msgs = rng.integers(0, P, n, dtype=np.uint64)
+    perm = rng.permutation(n)
+    out = []
+    for k, part in enumerate((msgs, msgs[perm[:n // 2]], msgs[perm[n // 2:]])):
+        t = rng.integers(0, P, (part.size, 1 + extra_cols[k]), dtype=np.uint64)
+        t[:, 0] = part
+        out.append(t)
+    if not valid:
+        out[2][3, 0] = (int(out[2][3, 0]) + 1) % P
+    return out

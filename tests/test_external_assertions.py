@@ -155,3 +155,23 @@ def test_dag_blob_header_counts_cannot_wrap():
         ok, msg = pkg.verify([fake], proof["log_heights"], pub, SMALL, ob.challenger_state(), ob.protocol_pre_observe(SMALL, pub),
                              proof["fields"], proof["commitments"])
         assert not ok and "constraint DAG blob" in msg, (word, msg)
+
+
+def test_cross_air_bus_is_closed_by_the_sum_of_finals():
+    """The chiplet-stack shape of precompiles-prover/src/session/prove.rs: every AIR's own constraints hold, the senders' and
+    receivers' sigma finals cancel only ACROSS the AIRs (different heights), and only eval_external sees that."""
+    s, _ = A.bus_air(+1)
+    r1, _ = A.bus_air(-1, 1)
+    r2, _ = A.bus_air(-1, 2)
+    airs_ = [s, r1, r2]
+    for valid in (True, False):
+        proof = ob.prove(airs_, A.bus_traces(6, (0, 1, 2), valid=valid), [], SMALL)
+        lhs = proof["log_heights"]
+        assert lhs == [6, 5, 5]
+        finals = [(int(proof["fields"][2 * i]), int(proof["fields"][2 * i + 1])) for i in range(3)]
+        assert all(f != (0, 0) for f in finals)  # no AIR balances on its own
+        assert ob.verify(airs_, lhs, [], proof, SMALL)[0] and product_verify(airs_, lhs, SMALL, proof)[0]
+        ok, msg = product_verify(airs_, lhs, SMALL, proof, external="logup_balance")
+        assert ok == valid, msg
+        ok_o, _ = ob.verify(airs_, lhs, [], proof, SMALL, external=pkg.external_callback(sum_finals))
+        assert ok_o == valid

@@ -120,3 +120,43 @@ def test_contexts_are_reentrant_across_proving_threads():
         for got in results[i]:
             assert (got.fields == exp["fields"]).all() and (got.commitments == exp["commitments"]).all(), f"job {i} differs under concurrency"
             assert [int(x) for x in got.digest] == [int(x) for x in exp["digest"]]
+
+
+def test_chiplet_stack_shape_twelve_instances(ctx):
+    """The second client of the backend (precompiles-prover/src/session/prove.rs): twelve
+    heterogeneous AIRs in ONE proof -- a cross-AIR LogUp bus (one sender, two receivers of half its height, aux columns
+    built on the device from lookup programs), three AIRs with preprocessed columns in one setup tree, AIRs without aux
+    columns, wide filler AIRs -- heights 2^4..2^9, closed by the sum-of-finals external assertion."""
+    pkg = load_package()
+    from test_gpu_prove import attach_preprocessed
+    prm = FAST  # DummyMidenAir is of degree 9: blowup 8
+    bus = [A.bus_air(+1), A.bus_air(-1, 1), A.bus_air(-1, 2)]
+    preps = [A.prep_air(5, seed=31), A.prep_air(7, seed=32), A.prep_air(4, seed=33)]
+    airs_ = [bus[0][0], preps[0][0], no_aux_air(), dag.dummy_miden_air(9, 1), bus[1][0], preps[1][0], no_aux_air(),
+             dag.dummy_miden_air(21, 3), bus[2][0], preps[2][0], no_aux_air(), dag.dummy_miden_air(12, 2)]
+    bt = A.bus_traces(9, (0, 1, 2))
+    traces = [bt[0], preps[0][1](), no_aux_trace(6), A.dummy_trace(8, 9), bt[1], preps[1][1](), no_aux_trace(4, seed=5),
+              A.dummy_trace(5, 21), bt[2], preps[2][1](), no_aux_trace(9, seed=6), A.dummy_trace(7, 12)]
+    assert len(airs_) == 12
+    exp = ob.prove(airs_, traces, [], prm)  # host-built aux columns
+    dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+    for k, i in enumerate((0, 4, 8)):
+        dairs[i].attach_lookup(pkg.DeviceLookup(ctx, bus[k][1]))
+    prep_root = attach_preprocessed(ctx, airs_, dairs, traces, prm)
+    asked = []
+
+    def aux_builder(idx, rnd):  # only for the AIRs without a lookup program: all-zero aux columns
+        asked.append(idx)
+        a = airs_[idx]
+        return np.zeros((traces[idx].shape[0], 2 * a.aux_width), dtype=np.uint64), [0] * (2 * a.num_aux_values)
+
+    got = pkg.prove(ctx, dairs, [ctx.upload_trace(t) for t in traces], [], prm, ob.challenger_state(),
+                    ob.protocol_pre_observe(prm, [], preprocessed_root=prep_root), aux_builder)
+    assert not set(asked) & {0, 4, 8}
+    assert got.log_trace_heights == exp["log_heights"]
+    assert (got.commitments == exp["commitments"]).all() and (got.fields == exp["fields"]).all()
+    assert [int(x) for x in got.digest] == [int(x) for x in exp["digest"]]
+    root = ob.preprocessed_commitment(airs_, got.log_trace_heights, prm)
+    ok, msg = pkg.verify(airs_, got.log_trace_heights, [], prm, ob.challenger_state(), ob.protocol_pre_observe(prm, [], preprocessed_root=root),
+                         got.fields, got.commitments, preprocessed_root=root, external="logup_balance")
+    assert ok, msg
