@@ -395,3 +395,19 @@ def bus_traces(log_n, extra_cols=(0, 0, 0), seed=23, valid=True):
     if not valid:
         out[2][3, 0] = (int(out[2][3, 0]) + 1) % P
     return out
+
+
+def chiplet_stack_statement(log_bus=9):
+    """Twelve heterogeneous instances in the shape of precompiles-prover/src/session/prove.rs (ChipletAir): a cross-AIR
+    LogUp bus (sender + two receivers of half its height), three AIRs with preprocessed columns, three without aux columns,
+    three wide DummyMidenAir fillers; heights 2^4 .. 2^log_bus.  Returns (airs, traces, {instance index: Lookup})."""
+    import oracle_binding as ob  # noqa: F401
+    from test_external_assertions import no_aux_air, no_aux_trace
+    bus = [bus_air(+1), bus_air(-1, 1), bus_air(-1, 2)]
+    preps = [prep_air(5, seed=31), prep_air(7, seed=32), prep_air(4, seed=33)]
+    airs_ = [bus[0][0], preps[0][0], no_aux_air(), dag.dummy_miden_air(9, 1), bus[1][0], preps[1][0], no_aux_air(),
+             dag.dummy_miden_air(21, 3), bus[2][0], preps[2][0], no_aux_air(), dag.dummy_miden_air(12, 2)]
+    bt = bus_traces(log_bus, (0, 1, 2))
+    traces = [bt[0], preps[0][1](), no_aux_trace(6), dummy_trace(8, 9), bt[1], preps[1][1](), no_aux_trace(4, seed=5),
+              dummy_trace(5, 21), bt[2], preps[2][1](), no_aux_trace(log_bus, seed=6), dummy_trace(7, 12)]
+    return airs_, traces, {0: bus[0][1], 4: bus[1][1], 8: bus[2][1]}

@@ -175,3 +175,30 @@ def test_cross_air_bus_is_closed_by_the_sum_of_finals():
         assert ok == valid, msg
         ok_o, _ = ob.verify(airs_, lhs, [], proof, SMALL, external=pkg.external_callback(sum_finals))
         assert ok_o == valid
+
+
+def test_twelve_instance_statement_host_side():
+    """The chiplet-stack statement of tests/airs.py through the host-only entry points: oracle proof, product verifier with
+    the setup commitment and the sum-of-finals assertion, structured parser, byte round trip."""
+    import proof_parser as pp
+    prm = dict(SMALL, log_blowup=3)
+    airs_, traces, _ = A.chiplet_stack_statement(log_bus=7)
+    proof = ob.prove(airs_, traces, [], prm)
+    lhs = proof["log_heights"]
+    assert len(lhs) == 12 and len(set(lhs)) >= 4
+    root = ob.preprocessed_commitment(airs_, lhs, prm)
+    pre = ob.protocol_pre_observe(prm, [], preprocessed_root=root)
+    ok, dig = pkg.verify(airs_, lhs, [], prm, ob.challenger_state(), pre, proof["fields"], proof["commitments"], preprocessed_root=root,
+                         external="logup_balance")
+    assert ok and (dig == proof["digest"]).all(), dig
+    data = pp.serialize(lhs, proof["fields"], proof["commitments"])
+    back = pkg.proof_from_bytes(data)
+    assert back.log_trace_heights == lhs and (back.fields == proof["fields"]).all() and (back.commitments == proof["commitments"]).all()
+    # one receiver misses a message: every per-AIR check still passes, the statement's assertion does not
+    traces[8] = traces[8].copy()
+    traces[8][1, 0] = (int(traces[8][1, 0]) + 1) % P
+    bad = ob.prove(airs_, traces, [], prm)
+    args = (airs_, lhs, [], prm, ob.challenger_state(), pre, bad["fields"], bad["commitments"])
+    assert pkg.verify(*args, preprocessed_root=root)[0]
+    ok, msg = pkg.verify(*args, preprocessed_root=root, external="logup_balance")
+    assert not ok and "external assertion 0 failed" in msg

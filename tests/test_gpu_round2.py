@@ -130,18 +130,12 @@ def test_chiplet_stack_shape_twelve_instances(ctx):
     pkg = load_package()
     from test_gpu_prove import attach_preprocessed
     prm = FAST  # DummyMidenAir is of degree 9: blowup 8
-    bus = [A.bus_air(+1), A.bus_air(-1, 1), A.bus_air(-1, 2)]
-    preps = [A.prep_air(5, seed=31), A.prep_air(7, seed=32), A.prep_air(4, seed=33)]
-    airs_ = [bus[0][0], preps[0][0], no_aux_air(), dag.dummy_miden_air(9, 1), bus[1][0], preps[1][0], no_aux_air(),
-             dag.dummy_miden_air(21, 3), bus[2][0], preps[2][0], no_aux_air(), dag.dummy_miden_air(12, 2)]
-    bt = A.bus_traces(9, (0, 1, 2))
-    traces = [bt[0], preps[0][1](), no_aux_trace(6), A.dummy_trace(8, 9), bt[1], preps[1][1](), no_aux_trace(4, seed=5),
-              A.dummy_trace(5, 21), bt[2], preps[2][1](), no_aux_trace(9, seed=6), A.dummy_trace(7, 12)]
+    airs_, traces, lookups = A.chiplet_stack_statement()
     assert len(airs_) == 12
     exp = ob.prove(airs_, traces, [], prm)  # host-built aux columns
     dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
-    for k, i in enumerate((0, 4, 8)):
-        dairs[i].attach_lookup(pkg.DeviceLookup(ctx, bus[k][1]))
+    for i, lk in lookups.items():
+        dairs[i].attach_lookup(pkg.DeviceLookup(ctx, lk))
     prep_root = attach_preprocessed(ctx, airs_, dairs, traces, prm)
     asked = []
 
