@@ -25,6 +25,7 @@ import argparse, json, os, sys, time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL, cross-process buffers)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -273,22 +274,51 @@ def main():
     ctx = pkg.Ctx(dev_index)
     mode, comm, comm_name, fallback = "single", None, None, None
     if world > 1:
+        import threading
         from miden_vm_amd import sharding
-        for choice in ([args.comm] + (["torch"] if args.comm == "rccl" else [])):
+        own_gpu = torch.cuda.device_count() >= world  # one GPU per rank (the driver's node) or ranks sharing a device (test box)
+        choices = [args.comm] + (["torch"] if args.comm == "rccl" else [])
+        if "torch" in choices and own_gpu and backend != "nccl":
+            choices.insert(choices.index("torch"), "torch-nccl")  # torch's own RCCL before the host-staged gloo path
+        for choice in choices:
+            box = {}
+
+            def attempt():
+                try:
+                    torch.cuda.set_device(dev_index)  # the current device is per thread
+                    if choice == "rccl":
+                        c_ = sharding.RcclComm(ctx, rank, world)
+                    elif choice == "torch-nccl":
+                        c_ = sharding.TorchComm(rank, world, group=box["group"])
+                    else:
+                        c_ = sharding.TorchComm(rank, world)
+                    box["comm"] = c_
+                    sharding.comm_selftest(ctx, c_)
+                    trial = ShardedRunner(pkg, ctx, 12, c_)  # a small sharded proof before the big trace is built
+                    trial.step()
+                    box["ok"] = trial.proof is not None
+                    trial.trace.free()
+                except Exception as e:
+                    box["err"] = repr(e)[:160]
+
             try:
-                comm = sharding.RcclComm(ctx, rank, world) if choice == "rccl" else sharding.TorchComm(rank, world)
-                sharding.comm_selftest(ctx, comm)
-                trial = ShardedRunner(pkg, ctx, 12, comm)  # a small sharded proof before the big trace is built
-                trial.step()
-                ok = trial.proof is not None
-                trial.trace.free()
+                if choice == "torch-nccl":
+                    box["group"] = dist.new_group(backend="nccl")  # collective call: made by every rank, outside the watchdog
+                # watchdog: a communicator that hangs while coming up (not one that fails) must not hang the bench -- the attempt
+                # runs on its own thread, the ranks agree on the outcome over the control plane, a stuck thread is abandoned
+                th = threading.Thread(target=attempt, daemon=True)
+                th.start()
+                th.join(timeout=float(os.environ.get("MIDEN_BENCH_COMM_TIMEOUT", "240")))
+                if th.is_alive():
+                    box["err"] = "timed out"
             except Exception as e:
-                ok = False
-                fallback = (fallback or "") + f"{choice}: {repr(e)[:160]}; "
+                box["err"] = repr(e)[:160]
+            ok = bool(box.get("ok")) and "err" not in box
+            if not ok:
+                fallback = (fallback or "") + f"{choice}: {box.get('err', 'no proof')}; "
             if all_ok(ok):
-                mode, comm_name = "sharded", choice
+                mode, comm_name, comm = "sharded", choice, box["comm"]
                 break
-            comm = None
         if mode != "sharded":
             mode = "replicas"
 
@@ -318,8 +348,9 @@ def main():
     ctx.prof_enable(False)
 
     if mode == "sharded":
-        par = f"one proof sharded by cosets over {world} GPUs (in-library RCCL collectives)" if comm_name == "rccl" else \
-              f"one proof sharded by cosets over {world} GPUs (torch.distributed communicator)"
+        how = {"rccl": "in-library RCCL collectives", "torch-nccl": "torch.distributed communicator, torch's RCCL",
+               "torch": "torch.distributed communicator, host-staged"}[comm_name]
+        par = f"one proof sharded by cosets over {world} GPUs ({how})"
     elif world > 1:
         par = f"{world} independent proofs (one trace per GPU): sharded proving could not be set up"
     else:
