@@ -660,8 +660,9 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
   s.open(idx, f, cm);
   tr.hint_fields(f);
   tr.hint_commitments(cm);
-  // finalize (CanFinalizeDigest, external): flush pending input, squeeze 4 felts
-  if (!tr.ch.in.empty()) tr.ch.duplexing();
+  // finalize (CanFinalizeDigest, external; "unconditionally applies a final state transition before extracting the
+  // digest", crates/stark-transcript/src/prover.rs:31-35): one more duplexing whatever is buffered, then 4 felts
+  tr.ch.duplexing();
   for (int i = 0; i < 4; i++) proof.digest[i] = tr.ch.st[i];
   for (int i = 0; i < n_airs; i++) proof.log_trace_heights.push_back((uint8_t)s.lhs[i]);
   proof.fields = std::move(tr.fields);

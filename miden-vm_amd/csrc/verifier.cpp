@@ -470,7 +470,7 @@ void verify_impl(const mh_pcs_params& pp, const std::vector<DagIR>& airs, const 
     if (!e2_eq(accumulated, e2_mul(qz, van))) throw Reject("constraints do not vanish on the trace domain (quotient identity)");
   }
   if (rd.pf != rd.nf || rd.pc != rd.nc) throw Reject("trailing data in the transcript");
-  if (!rd.ch.in.empty()) rd.ch.duplexing();
+  rd.ch.duplexing();  // CanFinalizeDigest: "unconditionally applies a final state transition" (stark-transcript/src/prover.rs:31-35)
   for (int i = 0; i < 4; i++) digest[i] = rd.ch.st[i];
 }
 

@@ -10,7 +10,8 @@
 //   * ProverTranscript / VerifierTranscript: crates/stark-transcript/src/prover.rs:116-145,
 //     verifier.rs (fields + commitments streams; send = record + observe, hint = record only).
 // PARITY UNPINNED: the PoW witness search order of `grind` and `finalize()` are external code with
-// no in-tree restatement; this oracle takes the smallest witness and squeezes state[0..4].
+// no in-tree restatement; this oracle takes the smallest witness; finalize = one unconditional duplexing (the only
+// in-tree statement about it: stark-transcript/src/prover.rs:31-35) and state[0..4].
 #pragma once
 #include "poseidon2.hpp"
 #include <algorithm>
@@ -92,7 +93,7 @@ struct Challenger {
     }
   }
   Digest finalize() {
-    if (!in.empty()) duplexing();
+    duplexing();  // unconditional: crates/stark-transcript/src/prover.rs:31-35
     return Digest{st[0], st[1], st[2], st[3]};
   }
 };
