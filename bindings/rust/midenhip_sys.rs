@@ -72,6 +72,10 @@ unsafe extern "C" {
     pub fn mh_ctx_trim(ctx: *mut mh_ctx) -> c_int;
     pub fn mh_last_error(ctx: *const mh_ctx) -> *const c_char;
     pub fn mh_device_count() -> c_int;
+    /// MH_LMCS_POSEIDON2 = 0, MH_LMCS_BLAKE3 = 1 (the hasher of mh_commit_traces / mh_tree_open on this context)
+    pub fn mh_ctx_set_lmcs(ctx: *mut mh_ctx, lmcs: c_int) -> c_int;
+    pub fn mh_ctx_get_lmcs(ctx: *const mh_ctx) -> c_int;
+    pub fn mh_blake3(data: *const u8, n: usize, out32: *mut u8);
     pub fn mh_prof_enable(ctx: *mut mh_ctx, on: c_int) -> c_int;
     pub fn mh_prof_reset(ctx: *mut mh_ctx) -> c_int;
     pub fn mh_prof_get(ctx: *mut mh_ctx, name: *const c_char, ms: *mut c_double, bytes: *mut c_double, count: *mut c_long) -> c_int;

@@ -78,6 +78,20 @@ void* mh_host_alloc(size_t bytes);
 void mh_host_free(void* p);
 
 /* ---- commitments (K1-K3) -------------------------------------------------------------------- */
+/* The commitment scheme's hasher (the reference's StarkConfig::Lmcs, air/src/config.rs:212-305).  MH_LMCS_POSEIDON2 (default):
+ * StatefulSponge leaves + TruncatedPermutation nodes.  MH_LMCS_BLAKE3: the Blake3_256 configuration's LMCS (config.rs:275-289,
+ * ProvingOptions::default()): leaf = chain over the matrices of blake3(state || row felts as 8 LE bytes each) from a zero
+ * state (crates/stateful-hasher/src/chaining.rs:32-50, alignment 1), node = blake3(left || right); a digest travels as
+ * four uint64_t = its 32 bytes little-endian.  It applies to mh_commit_traces / mh_commit_traces_sharded / mh_tree_open
+ * on this context.  The protocol entry points (mh_prove, mh_session_*, mh_verify) are built for the Poseidon2
+ * configuration and refuse a context set to another hasher. */
+#define MH_LMCS_POSEIDON2 0
+#define MH_LMCS_BLAKE3 1
+int mh_ctx_set_lmcs(mh_ctx* ctx, int lmcs);
+int mh_ctx_get_lmcs(const mh_ctx* ctx);
+/* blake3(data) (host only; unit-parity entry point, like mh_poseidon2_permute) */
+void mh_blake3(const uint8_t* data, size_t n, uint8_t out32[32]);
+
 /* commit_traces (crates/lifted-stark/src/prover/commit.rs:142-180): per trace (proof order =
  * ascending height) coset-LDE by 2^log_blowup on the canonical shift of ITS lde order, then the
  * aligned LMCS tree (Lmcs::build_aligned_tree, lmcs/config.rs:125-137).  root = 4 felts. */

@@ -31,7 +31,7 @@ EXPORTS = [
     "mh_session_commit_quotient", "mh_session_ood_point_ok", "mh_session_ood", "mh_session_deep", "mh_session_fri_commit",
     "mh_session_fri_fold", "mh_session_fri_final", "mh_session_open", "mh_grind",
     "mh_host_alloc", "mh_host_free", "mh_verify", "mh_trace_from_device", "mh_lookup_load", "mh_lookup_free", "mh_air_attach_lookup", "mh_air_attach_preprocessed", "mh_lookup_build_aux", "mh_trace_download",
-    "mh_verify_ex", "mh_external_logup_balance", "mh_proof_deserialize",
+    "mh_verify_ex", "mh_external_logup_balance", "mh_proof_deserialize", "mh_ctx_set_lmcs", "mh_ctx_get_lmcs", "mh_blake3",
     "mh_rccl_unique_id", "mh_comm_create_rccl", "mh_comm_destroy", "mh_comm_selftest",
     "mh_local_fabric_create", "mh_local_fabric_destroy", "mh_comm_create_local",
 ]
@@ -161,6 +161,13 @@ class Ctx:
     def trim(self):
         """Release the device buffers pooled between proofs."""
         self.check(self.lib.mh_ctx_trim(self.h))
+
+    LMCS = {"poseidon2": 0, "blake3": 1}
+
+    def set_lmcs(self, name):
+        """mh_ctx_set_lmcs: the commitment scheme's hasher for commit_traces / tree openings on this context ("poseidon2" |
+        "blake3" = the reference's default Blake3_256 configuration, air/src/config.rs:275-289)."""
+        self.check(self.lib.mh_ctx_set_lmcs(self.h, self.LMCS[name]))
 
     def upload_trace(self, matrix):
         return Trace(self, matrix)
@@ -629,3 +636,13 @@ def verify(airs, log_trace_heights, public_values, params, challenger_state, pre
                               C.c_size_t(len(pre_observe)), _ptr(f), C.c_size_t(f.size), _ptr(c), C.c_size_t(c.size // 4),
                               _ptr(proot) if proot is not None else None, ext, None, _ptr(digest), err, C.c_size_t(512))
     return (True, digest) if rc == 0 else (False, err.value.decode())
+
+
+def blake3(data):
+    """mh_blake3 (host only): the 32-byte BLAKE3 digest of `data`."""
+    lib = load_library()
+    data = bytes(data)
+    out = C.create_string_buffer(32)
+    lib.mh_blake3.restype = None
+    lib.mh_blake3(data, C.c_size_t(len(data)), out)
+    return out.raw

@@ -3,6 +3,7 @@
 #include "ctx.hpp"
 #include "gl.cuh"
 #include "kernels.hpp"
+#include "blake3.cuh"
 #include <algorithm>
 #include <cstring>
 #include <memory>
@@ -38,6 +39,18 @@ int mh_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+
+int mh_ctx_set_lmcs(mh_ctx* c, int lmcs) {
+  if (!c) return MH_ERR_INVALID;
+  if (lmcs != MH_LMCS_POSEIDON2 && lmcs != MH_LMCS_BLAKE3) {
+    c->err = "unknown LMCS hasher id";
+    return MH_ERR_INVALID;
+  }
+  c->lmcs = lmcs;
+  return 0;
+}
+int mh_ctx_get_lmcs(const mh_ctx* c) { return c ? c->lmcs : -1; }
+void mh_blake3(const uint8_t* data, size_t n, uint8_t out32[32]) { b3::hash_bytes(data, n, out32); }
 
 int mh_ctx_create(int device_id, mh_ctx** out) {
   if (!out) return MH_ERR_INVALID;

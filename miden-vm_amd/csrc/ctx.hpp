@@ -146,6 +146,7 @@ struct mh_ctx {
   // coset-scale tables keyed by (log_n, log_blowup, kind)
   std::map<std::string, DevBuf> tables;
   std::map<std::string, std::vector<size_t>> table_index;  // host-side offsets into `tables` entries
+  int lmcs = 0;  // MH_LMCS_POSEIDON2 / MH_LMCS_BLAKE3: the commitment scheme's hasher (StarkConfig::Lmcs), mh_ctx_set_lmcs
   bool ntt_big_lds_attr = false;  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this ctx's device
 
   hipEvent_t get_event();

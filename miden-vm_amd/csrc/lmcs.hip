@@ -17,9 +17,11 @@
 //   A lifted (shorter) matrix contributes row r mod N_m of coset j (i mod B*N_m).
 // One sponge per lane, state in VGPRs; Poseidon2 is integer-ALU bound.
 #include "ctx.hpp"
+#include "../../include/midenhip.h"
 #include "kernels.hpp"
 #include "poseidon2_fast.cuh"
 #include "poseidon2_lanes.cuh"
+#include "blake3.cuh"
 #include "gl.cuh"
 #include <algorithm>
 #include <cstring>
@@ -127,6 +129,87 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_absorb(LeafArgs a) {
   }
 }
 
+// ---- Blake3 LMCS (mh_ctx_set_lmcs(MH_LMCS_BLAKE3)): same launch structure, the state is the 32-byte digest itself ----
+// One thread per leaf; per matrix one hash of  state || row  (chaining.rs:32-50).  Block 0 = the state and the first four
+// felts, every later block eight felts (coalesced column reads, as in k_leaf_absorb); state_in / state_out / digest_out
+// are all [leaves][4] u64 (a digest = its 32 bytes little-endian).
+__global__ __launch_bounds__(LEAF_THREADS) void k_leaf_absorb_b3(LeafArgs a) {
+  const size_t leaves = (size_t)1 << (a.log_n + a.log_blowup);
+  const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (q >= leaves) return;
+  const size_t j = q >> a.log_n, r = q & (((size_t)1 << a.log_n) - 1);
+  uint32_t st[8];
+  if (a.state_in) {
+    const size_t qi = (j << a.log_n_prev) + (r & (((size_t)1 << a.log_n_prev) - 1));
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const u64 v = a.state_in[4 * qi + i];
+      st[2 * i] = (uint32_t)v;
+      st[2 * i + 1] = (uint32_t)(v >> 32);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; i++) st[i] = 0;
+  }
+  const size_t col_stride = leaves;
+#pragma unroll 1
+  for (int mi = 0; mi < a.n_mats; mi++) {
+    const u64* base = a.m[mi].data + q;
+    const u32 w = a.m[mi].width;
+    const u32 total = 32 + 8 * w;                 // message bytes
+    const u32 n_blocks = (total + 63) / 64;
+    b3::Stream h;
+    h.init();
+    uint32_t m[16];
+#pragma unroll 1
+    for (u32 b = 0; b < n_blocks; b++) {
+      // words [16b, 16b + 16) of the message: words 0..7 = the state, then two words per felt
+      const int f0 = (int)(8 * b) - 4;  // first felt of this block (block 0: felts 0..3 sit in words 8..15)
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int f = f0 + k;
+        u64 v = 0;
+        if (f >= 0 && (u32)f < w) v = base[(size_t)f * col_stride];
+        m[2 * k] = (uint32_t)v;
+        m[2 * k + 1] = (uint32_t)(v >> 32);
+      }
+      if (b == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) m[k] = st[k];
+      }
+      if (b + 1 < n_blocks) h.block(m);
+      else h.finish(m, total - 64 * b, st);
+    }
+  }
+  u64* o = (a.digest_out ? a.digest_out : a.state_out) + 4 * q;
+#pragma unroll
+  for (int i = 0; i < 4; i++) o[i] = (u64)st[2 * i] | ((u64)st[2 * i + 1] << 32);
+}
+__global__ __launch_bounds__(256) void k_compress_b3(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out, int log_n_coset) {
+  const size_t q = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (q >= n_out) return;
+  size_t l, rgt;
+  if (log_n_coset >= 0) {
+    const size_t N = (size_t)1 << log_n_coset;
+    const size_t jp = q >> log_n_coset, r = q & (N - 1);
+    l = ((2 * jp) << log_n_coset) + r;
+    rgt = l + N;
+  } else {
+    l = 2 * q;
+    rgt = l + 1;
+  }
+  uint32_t a[8], b[8], o[8];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const u64 x = in[4 * l + i], y = in[4 * rgt + i];
+    a[2 * i] = (uint32_t)x; a[2 * i + 1] = (uint32_t)(x >> 32);
+    b[2 * i] = (uint32_t)y; b[2 * i + 1] = (uint32_t)(y >> 32);
+  }
+  b3::compress_pair(a, b, o);
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[4 * q + i] = (u64)o[2 * i] | ((u64)o[2 * i + 1] << 32);
+}
+
 // out[q] = compress(in[left(q)], in[left(q) + sib]) ; coset phase: left = (2j')*N + r, sib = N;
 // natural phase: left = 2q, sib = 1.
 __global__ __launch_bounds__(256) void k_compress(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out, int log_n_coset) {
@@ -199,7 +282,10 @@ void lmcs_compress_layers(mh_ctx* c, mh_tree* t) {
       size_t n_out = (size_t)1 << d;
       int cbits_child = (d + 1) - (t->log_height - lb);  // coset bits of the child layer
       int log_n_coset = cbits_child > 0 ? (t->log_height - lb) : -1;
-      if (n_out <= COMPRESS_LANES_MAX_NODES)
+      if (c->lmcs == MH_LMCS_BLAKE3)
+        MH_LAUNCH(k_compress_b3, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream,
+                           t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
+      else if (n_out <= COMPRESS_LANES_MAX_NODES)
         MH_LAUNCH(k_compress_lanes, dim3((unsigned)((n_out * 16 + 255) / 256)), dim3(256), 0, c->stream,
                            t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
       else
@@ -253,7 +339,7 @@ void lmcs_hash_leaves(mh_ctx* c, const std::vector<LdeMatrix>& mats, int lb, u64
       a.state_out = nullptr;
       bytes += 32.0 * leaves;
     } else {
-      outbuf.alloc(leaves * 12 * 8);
+      outbuf.alloc(leaves * 12 * 8);  // (the Blake3 state uses the first 4 words per leaf of it)
       a.state_out = outbuf.u();
       a.digest_out = nullptr;
       bytes += 96.0 * leaves;
@@ -261,8 +347,11 @@ void lmcs_hash_leaves(mh_ctx* c, const std::vector<LdeMatrix>& mats, int lb, u64
     if (state_in) bytes += 96.0 * leaves;
     {
       ProfScope ps(c, "lmcs_leaf_absorb", bytes);
-      MH_LAUNCH(k_leaf_absorb, dim3((unsigned)((leaves + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0,
-                         c->stream, a);
+      if (c->lmcs == MH_LMCS_BLAKE3)
+        MH_LAUNCH(k_leaf_absorb_b3, dim3((unsigned)((leaves + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0, c->stream, a);
+      else
+        MH_LAUNCH(k_leaf_absorb, dim3((unsigned)((leaves + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0,
+                           c->stream, a);
     }
     state_in = a.state_out;
     log_n_prev = ln;
@@ -395,8 +484,14 @@ void lmcs_build_sharded(mh_ctx* c, mh_tree* t, const Dist& dist, const u64* loca
     for (size_t p = 0; p < ((size_t)1 << d); p++) {
       u64 st[12] = {0};
       const u64* l = t->cap.data() + 4 * ((((size_t)2) << d) - 1 + 2 * p);
-      for (int k = 0; k < 8; k++) st[k] = l[k];
-      p2_permute(st);
+      if (c->lmcs == MH_LMCS_BLAKE3) {
+        uint8_t dg[32];
+        b3::hash_bytes(reinterpret_cast<const uint8_t*>(l), 64, dg);  // little-endian host: a digest's u64s are its bytes
+        memcpy(st, dg, 32);
+      } else {
+        for (int k = 0; k < 8; k++) st[k] = l[k];
+        p2_permute(st);
+      }
       memcpy(t->cap.data() + 4 * ((((size_t)1) << d) - 1 + p), st, 32);
     }
   memcpy(t->root, t->cap.data(), 32);

@@ -185,6 +185,8 @@ struct mh_session {
   void begin(mh_ctx* ctx, const mh_pcs_params& params, int n, mh_air* const* airs_in, mh_trace* const* traces_in,
              const u64* publics_in, size_t n_publics, const Dist& d) {
     c = ctx; pp = params; dist = d; n_airs = n;
+    MH_REQUIRE(c->lmcs == MH_LMCS_POSEIDON2,
+               "the protocol entry points are built for the Poseidon2 configuration: this context's LMCS is set to another hasher");
     MH_REQUIRE(n_airs > 0 && n_airs <= 256, "need between 1 and 256 AIR instances");
     lb = pp.log_blowup;
     MH_REQUIRE(lb > 0 && lb <= 8, "log_blowup must be in 1..8");

@@ -8,6 +8,7 @@
 #include "lmcs.hpp"
 #include "stark.hpp"
 #include "lookup.hpp"
+#include "blake3.hpp"
 #include <cstring>
 #include <cstdio>
 
@@ -38,6 +39,7 @@ void orc_permute(uint64_t* states, size_t n) {
 }
 void orc_hash_elements(const uint64_t* in, size_t n, uint64_t out[4]) { hash_elements(in, n, out); }
 void orc_compress(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]) { compress(l, r, out); }
+void orc_blake3(const uint8_t* data, size_t n, uint8_t out[32]) { b3::hash(data, n, out); }
 void orc_sponge_absorb(uint64_t state[12], const uint64_t* in, size_t n) { sponge_absorb(state, in, n); }
 
 void orc_naive_dft(const uint64_t* in, size_t n, int inverse, uint64_t* out) {
@@ -55,11 +57,13 @@ void orc_coset_lde_bitrev(const uint64_t* m, size_t n, size_t w, int added_bits,
 
 // LMCS over already bit-reversed row-major matrices (ascending heights).
 // layers_out (optional): all digest layers bottom(leaf, domain order)-up concatenated: 2H-1 digests.
+static int g_lmcs_hash = LMCS_POSEIDON2;  // orc_set_lmcs: the hasher orc_lmcs_build / orc_commit_traces use (tests are serial)
+void orc_set_lmcs(int hash) { g_lmcs_hash = hash; }
 void orc_lmcs_build(int n_mats, const uint64_t* const* ptrs, const size_t* heights, const size_t* widths,
                     uint64_t root_out[4], uint64_t* layers_out) {
   std::vector<Mat> mats;
   for (int i = 0; i < n_mats; i++) mats.push_back(Mat{ptrs[i], heights[i], widths[i]});
-  LmcsTree t = lmcs_build(mats);
+  LmcsTree t = lmcs_build(mats, g_lmcs_hash);
   Digest r = t.root();
   memcpy(root_out, r.data(), 32);
   if (layers_out) {
@@ -88,7 +92,7 @@ void orc_commit_traces(int n_mats, const uint64_t* const* ptrs, const int* log_h
     mats.push_back(Mat{ldes[i].data(), n << log_blowup, widths[i]});
     if (lde_out && lde_out[i]) memcpy(lde_out[i], ldes[i].data(), ldes[i].size() * 8);
   }
-  LmcsTree t = lmcs_build(mats);
+  LmcsTree t = lmcs_build(mats, g_lmcs_hash);
   Digest r = t.root();
   memcpy(root_out, r.data(), 32);
   if (n_idx) {

@@ -10,8 +10,10 @@
 // roots, digests, opened rows and sibling lists.
 #pragma once
 #include "poseidon2.hpp"
+#include "blake3.hpp"
 #include <algorithm>
 #include <array>
+#include <cstring>
 #include <vector>
 
 namespace oracle {
@@ -30,7 +32,65 @@ struct LmcsTree {
   Digest root() const { return layers[0][0]; }
 };
 
-static inline LmcsTree lmcs_build(const std::vector<Mat>& mats) {
+// The Blake3 LMCS of air/src/config.rs:275-289 (LmcsConfig<Felt, u8, ChainingHasher<Blake3Hasher>,
+// CompressionFunctionFromHasher<Blake3Hasher, 2, 32>>): per-leaf state = a 32-byte digest, zero at first
+// (StatefulHasher::hash_rows, stateful-hasher/src/lib.rs: State::default()); absorbing a row =
+// blake3(state || felts as canonical u64 little-endian bytes) (chaining.rs:32-50; the byte encoding is pinned by
+// crates/crypto/src/hash/blake/tests.rs:24-34); node = blake3(left || right).  Lifting duplicates states exactly as for
+// the sponge (lifted_tree.rs:363-417 is generic in the hasher).  A Digest holds the 32 bytes as four little-endian u64.
+enum { LMCS_POSEIDON2 = 0, LMCS_BLAKE3 = 1 };
+static inline Digest b3_absorb(const Digest& st, const uint64_t* row, size_t w) {
+  std::vector<uint8_t> msg(32 + 8 * w);
+  memcpy(msg.data(), st.data(), 32);          // little-endian host
+  memcpy(msg.data() + 32, row, 8 * w);
+  Digest out;
+  b3::hash(msg.data(), msg.size(), reinterpret_cast<uint8_t*>(out.data()));
+  return out;
+}
+static inline Digest b3_compress(const Digest& l, const Digest& r) {
+  uint8_t msg[64];
+  memcpy(msg, l.data(), 32);
+  memcpy(msg + 32, r.data(), 32);
+  Digest out;
+  b3::hash(msg, 64, reinterpret_cast<uint8_t*>(out.data()));
+  return out;
+}
+static inline LmcsTree lmcs_build_b3(const std::vector<Mat>& mats) {
+  LmcsTree t;
+  t.leaves = mats;
+  size_t H = mats.back().h;
+  int lgH = log2_strict(H);
+  std::vector<Digest> st(H, Digest{0, 0, 0, 0}), scratch(H);
+  size_t active = mats.front().h;
+  for (const Mat& m : mats) {
+    if (m.h > active) {
+      size_t f = m.h / active;
+      for (size_t i = 0; i < active; i++)
+        for (size_t k = 0; k < f; k++) scratch[i * f + k] = st[i];
+      std::swap(st, scratch);
+    }
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < (long)m.h; r++) st[r] = b3_absorb(st[r], m.v + (size_t)r * m.w, m.w);
+    active = m.h;
+  }
+  std::vector<Digest> cur(H);
+  for (size_t i = 0; i < H; i++) cur[i] = st[bitrev((uint32_t)i, lgH)];
+  std::vector<std::vector<Digest>> up;
+  up.push_back(cur);
+  while (up.back().size() > 1) {
+    const auto& prev = up.back();
+    std::vector<Digest> next(prev.size() / 2);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)next.size(); i++) next[i] = b3_compress(prev[2 * i], prev[2 * i + 1]);
+    up.push_back(std::move(next));
+  }
+  std::reverse(up.begin(), up.end());
+  t.layers = std::move(up);
+  return t;
+}
+
+static inline LmcsTree lmcs_build(const std::vector<Mat>& mats, int hash = LMCS_POSEIDON2) {
+  if (hash == LMCS_BLAKE3) return lmcs_build_b3(mats);
   LmcsTree t;
   t.leaves = mats;
   size_t H = mats.back().h;

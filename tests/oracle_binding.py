@@ -96,6 +96,18 @@ def coset_lde_bitrev(m, added_bits, shift):
     return out
 
 
+def set_lmcs(name):
+    """The hasher lmcs_build / commit_traces use: "poseidon2" (default) or "blake3" (air/src/config.rs:275-289)."""
+    lib().orc_set_lmcs(C.c_int({"poseidon2": 0, "blake3": 1}[name]))
+
+
+def blake3(data):
+    data = bytes(data)
+    out = C.create_string_buffer(32)
+    lib().orc_blake3(data, C.c_size_t(len(data)), out)
+    return out.raw
+
+
 def lmcs_build(mats, want_layers=False):
     """mats: list of 2-D uint64 arrays, bit-reversed row order, ascending heights."""
     mats = [arr(m) for m in mats]

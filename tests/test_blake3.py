@@ -1,0 +1,106 @@
+"""BLAKE3 and the Blake3 LMCS (the reference's default configuration: ProvingOptions::default() = HashFunction::Blake3_256,
+air/src/config.rs:275-289).  CPU: the oracle's and the product's host BLAKE3 against tests/golden/blake3.json (digests made
+with the BLAKE3 team's C implementation as shipped in LLVM, tests/golden/make_blake3_golden.py) and the chaining-hasher
+leaf / pair-hash node semantics spelled out by hand.  GPU (-m gpu): mh_commit_traces with MH_LMCS_BLAKE3 against the oracle:
+root, every digest layer, opened rows (alignment 1) and sibling lists, single and lifted (mixed-height) batches, widths
+that cross block and chunk boundaries."""
+import json, os
+import numpy as np
+import pytest
+import oracle_binding as ob
+from __graft_entry__ import load_package
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "blake3.json")))
+P = ob.P
+
+
+def pattern(n):
+    return bytes(i % 251 for i in range(n))
+
+
+def test_blake3_golden_vectors_oracle_and_product():
+    pkg = load_package()
+    assert ob.blake3(b"abc").hex() == GOLD["abc"] == pkg.blake3(b"abc").hex()
+    for c in GOLD["cases"]:
+        d = pattern(c["len"])
+        assert ob.blake3(d).hex() == c["hash"], c["len"]
+        assert pkg.blake3(d).hex() == c["hash"], c["len"]
+
+
+def digest_bytes(d):
+    return np.asarray(d, dtype="<u8").tobytes()
+
+
+def test_blake3_lmcs_semantics_by_hand():
+    """leaf = chain over the matrices of H(state || row felts LE), zero state first (stateful-hasher/src/chaining.rs:32-50);
+    node = H(left || right); lifting repeats the shorter matrix's state (lifted_tree.rs:363-417)."""
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, P, (4, 3), dtype=np.uint64)   # bit-reversed row order, as the LMCS stores them
+    b = rng.integers(0, P, (8, 5), dtype=np.uint64)
+    ob.set_lmcs("blake3")
+    try:
+        root, layers = ob.lmcs_build([a, b], want_layers=True)
+    finally:
+        ob.set_lmcs("poseidon2")
+
+    def bitrev(i, bits):
+        return int(format(i, f"0{bits}b")[::-1], 2)
+    leaves = []
+    for i in range(8):  # domain index i <- physical row bitrev(i); the 4-row matrix is lifted: physical row r >> 1
+        r = bitrev(i, 3)
+        st = ob.blake3(bytes(32) + a[r >> 1].astype("<u8").tobytes())
+        st = ob.blake3(st + b[r].astype("<u8").tobytes())
+        leaves.append(st)
+    assert [digest_bytes(layers[i]) for i in range(8)] == leaves
+    l4 = [ob.blake3(leaves[2 * i] + leaves[2 * i + 1]) for i in range(4)]
+    l2 = [ob.blake3(l4[0] + l4[1]), ob.blake3(l4[2] + l4[3])]
+    assert digest_bytes(root) == ob.blake3(l2[0] + l2[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["one", "lifted", "wide", "many"])
+def test_device_blake3_commitment_equals_oracle(case):
+    pkg = load_package()
+    ctx = pkg.Ctx(0)
+    rng = np.random.default_rng(11)
+    shapes = {"one": [(6, 5)], "lifted": [(4, 3), (6, 9), (6, 4), (8, 51)], "wide": [(5, 124), (5, 125), (5, 260)],
+              "many": [(3, 1)] + [(7, w) for w in range(1, 12)]}[case]   # (log_n, width): 124 felts = exactly one chunk
+    traces = [rng.integers(0, P, (1 << ln, w), dtype=np.uint64) for ln, w in shapes]
+    lb = 2
+    H = (1 << shapes[-1][0]) << lb
+    idx = sorted(set(int(x) for x in rng.integers(0, H, 9))) + [0, H - 1]
+    ob.set_lmcs("blake3")
+    try:
+        exp = ob.commit_traces(traces, lb, indices=idx, alignment=1)
+    finally:
+        ob.set_lmcs("poseidon2")
+    ctx.set_lmcs("blake3")
+    com = pkg.commit_traces(ctx, [ctx.upload_trace(t) for t in traces], lb)
+    assert (com.root() == exp["root"]).all()
+    f, c = com.tree().prove_batch(idx, alignment=1)
+    assert (f == exp["fields"]).all() and (c == exp["commitments"]).all()
+    # every digest layer, through the oracle's own LDE (bit-reversed rows) of the same traces
+    ob.set_lmcs("blake3")
+    try:
+        ldes = ob.commit_traces(traces, lb, want_lde=True)["ldes"]
+        _, layers = ob.lmcs_build(ldes, want_layers=True)
+    finally:
+        ob.set_lmcs("poseidon2")
+    assert (com.tree().download_layers() == layers).all()
+    # a Poseidon2 commitment of the same data is something else, and the protocol entry points refuse this context
+    ctx.set_lmcs("poseidon2")
+    assert not (pkg.commit_traces(ctx, [ctx.upload_trace(t) for t in traces], lb).root() == exp["root"]).all()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_protocol_entry_points_refuse_a_blake3_context():
+    import airs as A
+    pkg = load_package()
+    ctx = pkg.Ctx(0)
+    ctx.set_lmcs("blake3")
+    t, pub = A.fib_trace(5)
+    prm = dict(log_blowup=2, log_folding_arity=1, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=1, num_queries=6, query_pow_bits=2)
+    with pytest.raises(pkg.MidenHipError, match="Poseidon2 configuration"):
+        pkg.prove(ctx, [pkg.DeviceAir(ctx, A.fib_air())], [ctx.upload_trace(t)], pub, prm, ob.challenger_state(), ob.protocol_pre_observe(prm, pub), None)
+    ctx.close()
