@@ -12,7 +12,9 @@
 // in query openings.
 // s_inv for row i0 is w_n^(-i0) (fri/prover.rs:117-142: the coset shift is deliberately ignored).
 #include "gl.cuh"
+#include "../../include/midenhip.h"
 #include "kernels.hpp"
+#include "blake3.cuh"
 #include "poseidon2_fast.cuh"
 
 __device__ __forceinline__ e2 ld_e2(const u64* p, size_t idx) {
@@ -51,6 +53,38 @@ __global__ __launch_bounds__(256) void k_fri_leaf_hash(const u64* __restrict__ e
   ulonglong2* o = reinterpret_cast<ulonglong2*>(digests + 4 * s);
   o[0] = make_ulonglong2(st[0], st[1]);
   o[1] = make_ulonglong2(st[2], st[3]);
+}
+
+// Blake3 LMCS (air/src/config.rs:275-289): leaf = blake3(32 zero bytes || the row's 2 * arity felts, 8 LE bytes each)
+__global__ __launch_bounds__(256) void k_fri_leaf_hash_b3(const u64* __restrict__ ev, int log_rows, int cbits, int log_arity,
+                                                          u64* __restrict__ digests) {
+  const int log_q = log_rows - log_arity;
+  const size_t leaves = (size_t)1 << (log_q + cbits);
+  const size_t s = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (s >= leaves) return;
+  const size_t j = s >> log_q, r0 = s & (((size_t)1 << log_q) - 1);
+  const u32 arity = 1u << log_arity;
+  const u32 total = 32 + 16 * arity, n_blocks = (total + 63) / 64;  // <= 160 bytes: one chunk
+  b3::Stream h;
+  h.init();
+  uint32_t m[16], out[8];
+#pragma unroll 1
+  for (u32 b = 0; b < n_blocks; b++) {
+    // words [16b, 16b + 16): words 0..7 = the zero state, then four words per EF element (position p)
+    const int p0 = (int)(4 * b) - 2;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int pp = p0 + k;
+      e2 v = e2_make(0);
+      if (pp >= 0 && (u32)pp < arity) v = ld_e2(ev, (j << log_rows) + r0 + ((size_t)fri_row_pos((u32)pp, log_arity) << log_q));
+      m[4 * k] = (uint32_t)v.c0; m[4 * k + 1] = (uint32_t)(v.c0 >> 32);
+      m[4 * k + 2] = (uint32_t)v.c1; m[4 * k + 3] = (uint32_t)(v.c1 >> 32);
+    }
+    if (b + 1 < n_blocks) h.block(m);
+    else h.finish(m, total - 64 * b, out);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) digests[4 * s + i] = (u64)out[2 * i] | ((u64)out[2 * i + 1] << 32);
 }
 
 // ---- fold ----------------------------------------------------------------------------------------
@@ -139,8 +173,11 @@ __global__ void k_fri_to_natural(const u64* ev, u64* out, int log_rows, int cbit
 void fri_leaf_hash(mh_ctx* c, const u64* ev, int log_rows, int cbits, int log_arity, u64* digests) {
   const size_t leaves = (size_t)1 << (log_rows - log_arity + cbits);
   ProfScope ps(c, "fri_leaf_hash", (double)leaves * (16.0 * (1 << log_arity) + 32.0));
-  MH_LAUNCH(k_fri_leaf_hash, dim3((unsigned)((leaves + 255) / 256)), dim3(256), 0, c->stream, ev, log_rows, cbits, log_arity,
-                     digests);
+  if (c->lmcs == MH_LMCS_BLAKE3)
+    MH_LAUNCH(k_fri_leaf_hash_b3, dim3((unsigned)((leaves + 255) / 256)), dim3(256), 0, c->stream, ev, log_rows, cbits, log_arity, digests);
+  else
+    MH_LAUNCH(k_fri_leaf_hash, dim3((unsigned)((leaves + 255) / 256)), dim3(256), 0, c->stream, ev, log_rows, cbits, log_arity,
+                       digests);
 }
 
 void fri_fold(mh_ctx* c, const u64* ev, int log_rows, int cbits, int cbits_global, size_t coset0, int log_arity, e2 beta, u64* out) {

@@ -185,8 +185,6 @@ struct mh_session {
   void begin(mh_ctx* ctx, const mh_pcs_params& params, int n, mh_air* const* airs_in, mh_trace* const* traces_in,
              const u64* publics_in, size_t n_publics, const Dist& d) {
     c = ctx; pp = params; dist = d; n_airs = n;
-    MH_REQUIRE(c->lmcs == MH_LMCS_POSEIDON2,
-               "the protocol entry points are built for the Poseidon2 configuration: this context's LMCS is set to another hasher");
     MH_REQUIRE(n_airs > 0 && n_airs <= 256, "need between 1 and 256 AIR instances");
     lb = pp.log_blowup;
     MH_REQUIRE(lb > 0 && lb <= 8, "log_blowup must be in 1..8");
@@ -257,11 +255,14 @@ struct mh_session {
     rounds = fri_num_rounds(pp, L);
     stage = 1;
   }
+  // aligned_len(w, lmcs.alignment()) (util/align.rs:7-13): 8 for the sponge, 1 for the chaining hasher of the Blake3 LMCS
+  size_t alignment() const { return c->lmcs == MH_LMCS_BLAKE3 ? 1 : 8; }
+  size_t al(size_t w) const { return c->lmcs == MH_LMCS_BLAKE3 ? w : align8(w); }
   size_t ood_width() const {
     size_t w = 0;
     for (int i = 0; i < n_airs; i++)
-      w += align8(airs[i]->main_width) + align8(2 * airs[i]->aux_width) + (airs[i]->preprocessed_width ? align8(airs[i]->preprocessed_width) : 0);
-    return w + align8(2 * D);
+      w += al(airs[i]->main_width) + al(2 * airs[i]->aux_width) + (airs[i]->preprocessed_width ? al(airs[i]->preprocessed_width) : 0);
+    return w + al(2 * D);
   }
   size_t num_aux_values() const {
     size_t k = 0;
@@ -412,7 +413,7 @@ struct mh_session {
     W = 0;
     for (auto* m : mats) {
       coef_off.push_back((u32)W);
-      W += align8(m->width);
+      W += al(m->width);
     }
     ev0.assign(W, e2_make(0));
     ev1.assign(W, e2_make(0));
@@ -564,13 +565,13 @@ struct mh_session {
       std::sort(pidx.begin(), pidx.end());
       pidx.erase(std::unique(pidx.begin(), pidx.end()), pidx.end());
       std::vector<u64> f, cm;
-      lmcs_open(c, prep_tree, pidx, 8, f, cm, &dist);
+      lmcs_open(c, prep_tree, pidx, alignment(), f, cm, &dist);
       fields.insert(fields.end(), f.begin(), f.end());
       commitments.insert(commitments.end(), cm.begin(), cm.end());
     }
     for (const mh_tree* t : {main_tree.get(), aux_tree.get(), quot_tree.get()}) {
       std::vector<u64> f, cm;
-      lmcs_open(c, t, idx, 8, f, cm, &dist);
+      lmcs_open(c, t, idx, alignment(), f, cm, &dist);
       fields.insert(fields.end(), f.begin(), f.end());
       commitments.insert(commitments.end(), cm.begin(), cm.end());
     }
@@ -614,6 +615,10 @@ static void do_grind(mh_ctx* c, HostTranscript& tr, int bits) {
 static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* const* airs_in, mh_trace* const* traces_in,
                        const u64* publics_in, size_t n_publics, const u64 init_state[12], const u64* pre_observe, size_t n_pre,
                        mh_aux_builder cb, void* user, mh_proof& proof, const Dist& dist) {
+  // the one-shot prover owns the transcript, and the library's challenger is the duplex sponge of the Poseidon2 (algebraic)
+  // configuration; the Blake3 configuration goes through the staged session, where the host owns the challenger
+  MH_REQUIRE(c->lmcs == MH_LMCS_POSEIDON2,
+             "mh_prove is built for the Poseidon2 configuration: with another LMCS hasher use the staged session (host-owned transcript)");
   mh_session s;
   s.begin(c, pp, n_airs, airs_in, traces_in, publics_in, n_publics, dist);
   HostTranscript tr;

@@ -57,13 +57,12 @@ void orc_coset_lde_bitrev(const uint64_t* m, size_t n, size_t w, int added_bits,
 
 // LMCS over already bit-reversed row-major matrices (ascending heights).
 // layers_out (optional): all digest layers bottom(leaf, domain order)-up concatenated: 2H-1 digests.
-static int g_lmcs_hash = LMCS_POSEIDON2;  // orc_set_lmcs: the hasher orc_lmcs_build / orc_commit_traces use (tests are serial)
-void orc_set_lmcs(int hash) { g_lmcs_hash = hash; }
+void orc_set_lmcs(int hash) { g_lmcs = hash; }  // the configuration of every later call (tests are serial)
 void orc_lmcs_build(int n_mats, const uint64_t* const* ptrs, const size_t* heights, const size_t* widths,
                     uint64_t root_out[4], uint64_t* layers_out) {
   std::vector<Mat> mats;
   for (int i = 0; i < n_mats; i++) mats.push_back(Mat{ptrs[i], heights[i], widths[i]});
-  LmcsTree t = lmcs_build(mats, g_lmcs_hash);
+  LmcsTree t = lmcs_build(mats);
   Digest r = t.root();
   memcpy(root_out, r.data(), 32);
   if (layers_out) {
@@ -92,7 +91,7 @@ void orc_commit_traces(int n_mats, const uint64_t* const* ptrs, const int* log_h
     mats.push_back(Mat{ldes[i].data(), n << log_blowup, widths[i]});
     if (lde_out && lde_out[i]) memcpy(lde_out[i], ldes[i].data(), ldes[i].size() * 8);
   }
-  LmcsTree t = lmcs_build(mats, g_lmcs_hash);
+  LmcsTree t = lmcs_build(mats);
   Digest r = t.root();
   memcpy(root_out, r.data(), 32);
   if (n_idx) {
@@ -110,7 +109,7 @@ void orc_commit_traces(int n_mats, const uint64_t* const* ptrs, const int* log_h
 // ---- whole-protocol entry points (stark.hpp) ----------------------------------------------------
 static Challenger make_challenger(const uint64_t init_state[12], const uint64_t* pre_observe, size_t n_pre) {
   Challenger c;
-  for (int i = 0; i < 12; i++) c.st[i] = init_state[i];
+  c.init(init_state);
   for (size_t i = 0; i < n_pre; i++) c.observe(pre_observe[i]);
   return c;
 }
@@ -207,7 +206,9 @@ int orc_fri_fold_row(const uint64_t* y_flat, int log_arity, uint64_t s_inv, cons
 // ---- the duplex challenger as an object (tests drive the staged device session with it) ----------
 void* orc_ch_new(const uint64_t state[12]) {
   Challenger* c = new Challenger();
-  for (int i = 0; i < 12; i++) c->st[i] = state[i] % P;
+  uint64_t st[12];
+  for (int i = 0; i < 12; i++) st[i] = state[i] % P;
+  c->init(st);
   return c;
 }
 void orc_ch_free(void* h) { delete (Challenger*)h; }

@@ -14,8 +14,10 @@
 // in-tree statement about it: stark-transcript/src/prover.rs:31-35) and state[0..4].
 #pragma once
 #include "poseidon2.hpp"
+#include "lmcs.hpp"
 #include <algorithm>
 #include <array>
+#include <cstring>
 #include <stdexcept>
 #include <vector>
 
@@ -23,11 +25,28 @@ namespace oracle {
 
 typedef std::array<uint64_t, 4> Digest;
 
+// mode LMCS_BLAKE3: SerializingChallenger64<Felt, HashChallenger<u8, Blake3Hasher, 32>> (air/src/config.rs:291-303), both
+// external (p3-challenger 0.6.2) and with NO in-tree mirror -- PARITY UNPINNED, restated from the published crate:
+//   HashChallenger: observe(byte) clears the output buffer and appends to the input buffer; sampling from an empty output
+//     buffer flushes: output = hash(input), input := output (chaining); sample = output.pop() (from the END);
+//   SerializingChallenger64: observe(felt) = its canonical u64 as 8 little-endian bytes (a 32-byte digest is observed byte
+//     by byte = the same as its four little-endian u64s); sample = u64 from 8 sampled bytes (first sampled = lowest),
+//     rejected and redrawn when >= p; sample_bits = low bits of such a u64 without rejection; grind/check_witness =
+//     observe(witness), sample_bits(bits) == 0.
+// The configuration starts from an empty input buffer and observes RELATION_DIGEST first (config.rs:301-302): here the
+// capacity words st[8..12] of the initial state (where the sponge configuration keeps that digest) are observed.
 struct Challenger {
+  int mode = LMCS_POSEIDON2;
   uint64_t st[12];
   std::vector<uint64_t> in, out;
-  Challenger() {
+  std::vector<uint8_t> bin, bout;  // byte mode
+  Challenger() : mode(g_lmcs) {
     for (auto& x : st) x = 0;
+  }
+  void init(const uint64_t init_state[12]) {
+    for (int i = 0; i < 12; i++) st[i] = init_state[i];
+    if (mode == LMCS_BLAKE3)
+      for (int i = 8; i < 12; i++) observe(st[i]);
   }
   void duplexing() {
     size_t k = in.size();
@@ -40,7 +59,27 @@ struct Challenger {
     p2_permute(st);
     out.assign(st, st + 8);
   }
+  void flush_bytes() {
+    uint8_t d[32];
+    b3::hash(bin.data(), bin.size(), d);
+    bout.assign(d, d + 32);
+    bin.assign(d, d + 32);
+  }
+  uint64_t sample_u64_bytes() {
+    uint64_t v = 0;
+    for (int i = 0; i < 8; i++) {
+      if (bout.empty()) flush_bytes();
+      v |= (uint64_t)bout.back() << (8 * i);
+      bout.pop_back();
+    }
+    return v;
+  }
   void observe(uint64_t x) {
+    if (mode == LMCS_BLAKE3) {
+      bout.clear();
+      for (int i = 0; i < 8; i++) bin.push_back((uint8_t)(x >> (8 * i)));
+      return;
+    }
     out.clear();
     in.push_back(x);
     if (in.size() == 8) duplexing();
@@ -49,6 +88,12 @@ struct Challenger {
     for (uint64_t x : d) observe(x);
   }
   uint64_t sample() {
+    if (mode == LMCS_BLAKE3) {
+      for (;;) {
+        uint64_t v = sample_u64_bytes();
+        if (v < P) return v;
+      }
+    }
     if (!in.empty() || out.empty()) duplexing();
     uint64_t x = out.back();
     out.pop_back();
@@ -59,7 +104,10 @@ struct Challenger {
     uint64_t c1 = sample();
     return E2{c0, c1};
   }
-  size_t sample_bits(int bits) { return (size_t)((sample() & 0xFFFFFFFFULL) & (((uint64_t)1 << bits) - 1)); }
+  size_t sample_bits(int bits) {
+    if (mode == LMCS_BLAKE3) return (size_t)(sample_u64_bytes() & (((uint64_t)1 << bits) - 1));
+    return (size_t)((sample() & 0xFFFFFFFFULL) & (((uint64_t)1 << bits) - 1));
+  }
   bool check_witness(int bits, uint64_t w) {
     if (bits == 0) return w == 0;
     observe(w);
@@ -68,6 +116,15 @@ struct Challenger {
   // check_witness on a stack copy of the state (no heap traffic): exactly one duplexing happens
   // between observe(w) and the sampled bits, whether the buffer fills up (8) or not.
   bool trial(int bits, uint64_t w) const {
+    if (mode == LMCS_BLAKE3) {
+      std::vector<uint8_t> m(bin);
+      for (int i = 0; i < 8; i++) m.push_back((uint8_t)(w >> (8 * i)));
+      uint8_t d[32];
+      b3::hash(m.data(), m.size(), d);
+      uint64_t v = 0;
+      for (int i = 0; i < 8; i++) v |= (uint64_t)d[31 - i] << (8 * i);
+      return (v & (((uint64_t)1 << bits) - 1)) == 0;
+    }
     uint64_t s[12];
     for (int i = 0; i < 12; i++) s[i] = st[i];
     size_t k = in.size() + 1;
@@ -93,6 +150,12 @@ struct Challenger {
     }
   }
   Digest finalize() {
+    if (mode == LMCS_BLAKE3) {  // one unconditional state transition (stark-transcript/src/prover.rs:31-35), then the digest
+      flush_bytes();
+      Digest d;
+      memcpy(d.data(), bout.data(), 32);
+      return d;
+    }
     duplexing();  // unconditional: crates/stark-transcript/src/prover.rs:31-35
     return Digest{st[0], st[1], st[2], st[3]};
   }

@@ -1,6 +1,6 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see gl.hpp header).
 //
-// Lifted Matrix Commitment Scheme (LMCS) with the Poseidon2 sponge, restating
+// Lifted Matrix Commitment Scheme (LMCS) with the Poseidon2 sponge (and, g_lmcs, the Blake3 chaining hasher), restating
 //   crates/lifted-stark/src/lmcs/lifted_tree.rs:202-284 (build_with_alignment),
 //   :363-417 (build_leaf_states_upsampled), :427-461 (absorb_matrix),
 //   :472-511 (compress_uniform), :326-341 (collect_rows), :155-180 (prove_batch),
@@ -39,6 +39,12 @@ struct LmcsTree {
 // crates/crypto/src/hash/blake/tests.rs:24-34); node = blake3(left || right).  Lifting duplicates states exactly as for
 // the sponge (lifted_tree.rs:363-417 is generic in the hasher).  A Digest holds the 32 bytes as four little-endian u64.
 enum { LMCS_POSEIDON2 = 0, LMCS_BLAKE3 = 1 };
+// The STARK configuration the oracle restates (test infrastructure: one setting for the process, orc_set_lmcs): the LMCS
+// hasher, and with it the row alignment (Alignable::ALIGNMENT: 8 for the sponge, 1 for the chaining hasher,
+// chaining.rs:161-169 -- every aligned width of the protocol follows lmcs.alignment(), proof.rs:268, deep/prover.rs:133)
+// and the challenger (duplex sponge / serializing hash challenger, air/src/config.rs:224,291-292).
+inline int g_lmcs = LMCS_POSEIDON2;
+static inline size_t lmcs_alignment() { return g_lmcs == LMCS_BLAKE3 ? 1 : 8; }
 static inline Digest b3_absorb(const Digest& st, const uint64_t* row, size_t w) {
   std::vector<uint8_t> msg(32 + 8 * w);
   memcpy(msg.data(), st.data(), 32);          // little-endian host
@@ -89,8 +95,8 @@ static inline LmcsTree lmcs_build_b3(const std::vector<Mat>& mats) {
   return t;
 }
 
-static inline LmcsTree lmcs_build(const std::vector<Mat>& mats, int hash = LMCS_POSEIDON2) {
-  if (hash == LMCS_BLAKE3) return lmcs_build_b3(mats);
+static inline LmcsTree lmcs_build(const std::vector<Mat>& mats) {
+  if (g_lmcs == LMCS_BLAKE3) return lmcs_build_b3(mats);
   LmcsTree t;
   t.leaves = mats;
   size_t H = mats.back().h;

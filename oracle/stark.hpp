@@ -51,7 +51,11 @@ struct Proof {
   Digest digest;
 };
 
-static inline size_t align8(size_t w) { return (w + 7) / 8 * 8; }
+// aligned_len(w, lmcs.alignment()) (util/align.rs:7-13); the name is from the sponge configuration, where the alignment is 8
+static inline size_t align8(size_t w) {
+  const size_t a = lmcs_alignment();
+  return (w + a - 1) / a * a;
+}
 
 static inline void batch_inverse(std::vector<uint64_t>& v) {
   size_t n = v.size();
@@ -558,14 +562,14 @@ static inline Proof prove(ProverInput& in) {
     pidx.erase(std::unique(pidx.begin(), pidx.end()), pidx.end());
     std::vector<uint64_t> f;
     std::vector<Digest> c;
-    lmcs_prove_batch(*prep_tree, pidx, 8, f, c);
+    lmcs_prove_batch(*prep_tree, pidx, lmcs_alignment(), f, c);
     ch.hint_fields(f);
     ch.hint_commitments(c);
   }
   for (const LmcsTree* t : {&main_tree, &aux_tree, &quot_tree}) {
     std::vector<uint64_t> f;
     std::vector<Digest> c;
-    lmcs_prove_batch(*t, idx, 8, f, c);
+    lmcs_prove_batch(*t, idx, lmcs_alignment(), f, c);
     ch.hint_fields(f);
     ch.hint_commitments(c);
   }
@@ -610,13 +614,22 @@ static inline std::map<size_t, std::vector<uint64_t>> lmcs_verify_batch(Verifier
   for (size_t i : sorted_idx) {
     std::vector<uint64_t> r(tot);
     for (auto& x : r) x = ch.hint_field();
-    uint64_t st[12] = {0};
     size_t off = 0;
-    for (size_t w : aligned_widths) {
-      sponge_absorb(st, r.data() + off, w);
-      off += w;
+    if (g_lmcs == LMCS_BLAKE3) {
+      Digest st{0, 0, 0, 0};
+      for (size_t w : aligned_widths) {
+        st = b3_absorb(st, r.data() + off, w);
+        off += w;
+      }
+      level[i] = st;
+    } else {
+      uint64_t st[12] = {0};
+      for (size_t w : aligned_widths) {
+        sponge_absorb(st, r.data() + off, w);
+        off += w;
+      }
+      level[i] = Digest{st[0], st[1], st[2], st[3]};
     }
-    level[i] = Digest{st[0], st[1], st[2], st[3]};
     rows[i] = std::move(r);
   }
   for (int d = depth; d > 0; d--) {
@@ -633,7 +646,8 @@ static inline std::map<size_t, std::vector<uint64_t>> lmcs_verify_batch(Verifier
         it = nx;
       }
       Digest parent;
-      if (node & 1) compress(other.data(), me.data(), parent.data());
+      if (g_lmcs == LMCS_BLAKE3) parent = (node & 1) ? b3_compress(other, me) : b3_compress(me, other);
+      else if (node & 1) compress(other.data(), me.data(), parent.data());
       else compress(me.data(), other.data(), parent.data());
       next[node >> 1] = parent;
     }

@@ -94,13 +94,78 @@ def test_device_blake3_commitment_equals_oracle(case):
 
 
 @pytest.mark.gpu
-def test_protocol_entry_points_refuse_a_blake3_context():
+def test_one_shot_prover_refuses_a_blake3_context():
     import airs as A
     pkg = load_package()
     ctx = pkg.Ctx(0)
     ctx.set_lmcs("blake3")
     t, pub = A.fib_trace(5)
     prm = dict(log_blowup=2, log_folding_arity=1, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=1, num_queries=6, query_pow_bits=2)
-    with pytest.raises(pkg.MidenHipError, match="Poseidon2 configuration"):
+    with pytest.raises(pkg.MidenHipError, match="Poseidon2 configuration"):  # the one-shot prover owns a duplex-sponge transcript
         pkg.prove(ctx, [pkg.DeviceAir(ctx, A.fib_air())], [ctx.upload_trace(t)], pub, prm, ob.challenger_state(), ob.protocol_pre_observe(prm, pub), None)
     ctx.close()
+
+
+# ---- the whole Blake3 configuration (ProvingOptions::default()): alignment 1, byte challenger, staged boundary --------------
+SMALL = dict(log_blowup=2, log_folding_arity=1, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=1, num_queries=6, query_pow_bits=2)
+FAST = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=5, query_pow_bits=3)
+
+
+def blake3_cases():
+    import airs as A
+    from miden_vm_amd import dag
+    t, pub = A.fib_trace(6)
+    t7, pub7 = A.fib_trace(7)
+    a5, tr5 = A.prep_air(5, num_public=3)
+    return {"fib": ([A.fib_air()], [t], pub, SMALL),
+            "multi": ([A.periodic_air(3), A.fib_air()], [A.periodic_trace(5), t7], pub7, FAST),
+            "logup": ([A.logup_air()[0]], [A.logup_trace(5)], [], SMALL),
+            "dummy_arity8": ([dag.dummy_miden_air(11, 2)], [A.dummy_trace(7, 11)], [], dict(FAST, log_folding_arity=3, log_final_degree=1)),
+            "preprocessed": ([A.fib_air(), a5], [t7, tr5()], pub7, FAST)}
+
+
+@pytest.mark.parametrize("name", ["fib", "multi", "logup", "dummy_arity8", "preprocessed"])
+def test_oracle_blake3_configuration_proves_and_verifies(name):
+    """Oracle only: the same statement under both configurations; the Blake3 one carries unpadded rows (alignment 1:
+    stateful-hasher/src/chaining.rs:161-169, proof.rs:268) and a byte challenger; its verifier accepts the proof and
+    rejects a tampered one; a proof of one configuration is not a proof of the other."""
+    airs_, traces, pub, prm = blake3_cases()[name]
+    p2 = ob.prove(airs_, traces, pub, prm)
+    ob.set_lmcs("blake3")
+    try:
+        p = ob.prove(airs_, traces, pub, prm)
+        assert ob.verify(airs_, p["log_heights"], pub, p, prm)[0]
+        bad = dict(p)
+        bad["fields"] = p["fields"].copy()
+        bad["fields"][7] = (int(bad["fields"][7]) + 1) % P
+        assert not ob.verify(airs_, p["log_heights"], pub, bad, prm)[0]
+        assert not ob.verify(airs_, p2["log_heights"], pub, p2, prm)[0]
+    finally:
+        ob.set_lmcs("poseidon2")
+    assert p["fields"].size < p2["fields"].size  # no zero padding of opened rows and OOD blocks
+    assert not ob.verify(airs_, p["log_heights"], pub, p, prm)[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["fib", "multi", "logup", "dummy_arity8", "preprocessed"])
+def test_device_blake3_configuration_through_the_staged_session(name):
+    """The device prover under the Blake3 configuration through the staged boundary (the host owns the transcript -- in the
+    reference's shim that is p3's SerializingChallenger64, here the oracle's restatement of it): every commitment, OOD value,
+    final polynomial and opening hint equals the oracle prover's, and the oracle verifier accepts the transcript."""
+    from test_gpu_prove import staged_prove
+    pkg = load_package()
+    airs_, traces, pub, prm = blake3_cases()[name]
+    ctx = pkg.Ctx(0)
+    ob.set_lmcs("blake3")
+    try:
+        ctx.set_lmcs("blake3")
+        exp = ob.prove(airs_, traces, pub, prm)
+        f, c, d = staged_prove(ctx, airs_, traces, pub, prm, device_grind=False)
+        assert c.shape == exp["commitments"].shape and (c == exp["commitments"]).all()
+        assert f.size == exp["fields"].size and (f == exp["fields"]).all()
+        assert (d == exp["digest"]).all()
+        ok, msg = ob.verify(airs_, exp["log_heights"], pub, {"fields": f, "commitments": c}, prm)
+        assert ok, msg
+    finally:
+        ob.set_lmcs("poseidon2")
+        ctx.close()
