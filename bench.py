@@ -19,7 +19,8 @@ value = rows of the proved trace / seconds per step, whole job.  The CPU oracle 
 bounded sample), never inside the timed GPU region.  Extra keys on the N = 1 line: `h2d_inclusive` (SURVEY.md section 8(d):
 the same proof with the host->device upload of the trace inside the timed region) and `miden_shape` (the full Miden VM
 shape: three AIRs of widths 51/22/16 with 4/3/1 EF aux columns, the published reference figure's neighbour) and `in_flight`
-(three proofs in flight on the one GPU, one context per proving thread: service throughput, not the headline).
+(three proofs in flight on the one GPU, one context per proving thread: service throughput, not the headline) and
+`blake3_config` (the device stages of a proof under the reference's default Blake3_256 configuration, staged session).
 """
 import argparse, json, os, sys, time
 
@@ -177,6 +178,55 @@ def in_flight_probe(pkg, log_n, device, k=3, steps=4):
     return {"proofs_in_flight": k, "proofs": k * steps, "value": k * steps * (1 << log_n) / dt, "unit": "trace rows/s",
             "ms_per_proof_amortised": dt / (k * steps) * 1e3,
             "note": "k proving threads, one context (HIP stream) each, same GPU; every proof is a complete independent proof"}
+
+
+def session_stages_probe(pkg, ctx, log_n, lmcs, steps=3):
+    """Device time of ONE proof's stages through the staged session (mh_session_*) under an LMCS hasher, with the challenges
+    drawn from a PRNG instead of a transcript: what the GPU does for a proof of the Blake3 configuration (the reference's
+    ProvingOptions::default(); its byte challenger and PoW search stay with the host shim and are not in this figure),
+    next to the same drive under the Poseidon2 configuration."""
+    import numpy as np
+    from miden_vm_amd import dag, protocol
+    P = 0xFFFFFFFF00000001
+    ctx.set_lmcs(lmcs)
+    try:
+        air = pkg.DeviceAir(ctx, dag.dummy_miden_air(51, 8))
+        tr = ctx.upload_trace(synth_trace(np.random.default_rng(3), log_n, 51))
+        prm = dict(protocol.PROD_PARAMS)
+        rng = np.random.default_rng(4)
+
+        def ef():
+            return (int(rng.integers(0, P, dtype=np.uint64)), int(rng.integers(0, P, dtype=np.uint64)))
+
+        def one():
+            s = pkg.Session(ctx, [air], [tr], [], prm)
+            sh = s.shape
+            s.commit_main()
+            s.commit_aux([ef() for _ in range(sh.num_randomness)], None)
+            s.commit_quotient(ef(), ef())
+            z = ef()
+            while not s.ood_point_ok(z):
+                z = ef()
+            s.ood(z)
+            s.deep(ef(), ef())
+            for _ in range(sh.num_fri_rounds):
+                s.fri_commit()
+                s.fri_fold(ef())
+            s.fri_final()
+            hints = s.open([int(x) for x in rng.integers(0, 1 << sh.log_lde_height, prm["num_queries"])])
+            s.free()
+            return len(hints.fields) * 8 + len(hints.commitments) * 32
+
+        one()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            nbytes = one()
+        dt = (time.perf_counter() - t0) / steps
+        tr.free()
+        air.free()
+    finally:
+        ctx.set_lmcs("poseidon2")
+    return {"lmcs": lmcs, "ms_per_proof": dt * 1e3, "rows_per_s": (1 << log_n) / dt, "opening_hint_bytes": int(nbytes)}
 
 
 def cpu_baseline(runner, cpu_log_n):
@@ -413,6 +463,13 @@ def main():
             out["in_flight"] = in_flight_probe(pkg, log_n, dev_index)
         except Exception as e:
             out["in_flight"] = {"error": repr(e)[:200]}
+        try:  # the reference's DEFAULT configuration (Blake3_256) through the staged boundary, next to the same drive with Poseidon2
+            out["blake3_config"] = {"note": "staged session (mh_session_*), challenges from a PRNG: device stages of one proof; the "
+                                            "host shim's challenger and PoW search are not included",
+                                    "blake3": session_stages_probe(pkg, ctx, log_n, "blake3"),
+                                    "poseidon2": session_stages_probe(pkg, ctx, log_n, "poseidon2")}
+        except Exception as e:
+            out["blake3_config"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(runner, args.cpu_log_n)
     elif rank == 0:
