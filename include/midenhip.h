@@ -82,14 +82,17 @@ void mh_host_free(void* p);
  * StatefulSponge leaves + TruncatedPermutation nodes.  MH_LMCS_BLAKE3: the Blake3_256 configuration's LMCS (config.rs:275-289,
  * ProvingOptions::default()): leaf = chain over the matrices of blake3(state || row felts as 8 LE bytes each) from a zero
  * state (crates/stateful-hasher/src/chaining.rs:32-50, alignment 1), node = blake3(left || right); a digest travels as
- * four uint64_t = its 32 bytes little-endian.  It applies to everything this context commits and opens: mh_commit_traces,
+ * four uint64_t = its 32 bytes little-endian.  MH_LMCS_KECCAK: the Keccak configuration's LMCS (config.rs:307-353): the
+ * overwrite-mode sponge over 64-bit lanes with Keccak-f[1600] (25 lanes, 17 felts as canonical u64 per permutation, digest =
+ * lanes 0..3; alignment 17), node = one permutation over left || right in a zero state.  It applies to everything this context commits and opens: mh_commit_traces,
  * mh_commit_traces_sharded, mh_tree_open and the staged session mh_session_* -- there the row alignment follows the hasher
- * (lmcs.alignment(): 8 for the sponge, 1 for the chaining hasher; OOD blocks and opened rows are then unpadded) and the FRI
+ * (lmcs.alignment(): the sponge's rate, 8 or 17; 1 for the chaining hasher: OOD blocks and opened rows are then unpadded) and the FRI
  * leaves use it too, so a host shim that owns the Blake3 configuration's challenger (p3 SerializingChallenger64 over a
  * HashChallenger) proves under HashFunction::Blake3_256 through the session.  The one-shot mh_prove / mh_prove_sharded own a
  * duplex-sponge transcript and mh_verify its verifier: they are the Poseidon2 configuration only and say so. */
 #define MH_LMCS_POSEIDON2 0
 #define MH_LMCS_BLAKE3 1
+#define MH_LMCS_KECCAK 2
 int mh_ctx_set_lmcs(mh_ctx* ctx, int lmcs);
 int mh_ctx_get_lmcs(const mh_ctx* ctx);
 /* blake3(data) (host only; unit-parity entry point, like mh_poseidon2_permute) */

@@ -162,7 +162,7 @@ class Ctx:
         """Release the device buffers pooled between proofs."""
         self.check(self.lib.mh_ctx_trim(self.h))
 
-    LMCS = {"poseidon2": 0, "blake3": 1}
+    LMCS = {"poseidon2": 0, "blake3": 1, "keccak": 2}
 
     def set_lmcs(self, name):
         """mh_ctx_set_lmcs: the commitment scheme's hasher for commit_traces / tree openings on this context ("poseidon2" |

@@ -15,6 +15,7 @@
 #include "../../include/midenhip.h"
 #include "kernels.hpp"
 #include "blake3.cuh"
+#include "keccak.cuh"
 #include "poseidon2_fast.cuh"
 
 __device__ __forceinline__ e2 ld_e2(const u64* p, size_t idx) {
@@ -85,6 +86,31 @@ __global__ __launch_bounds__(256) void k_fri_leaf_hash_b3(const u64* __restrict_
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) digests[4 * s + i] = (u64)out[2 * i] | ((u64)out[2 * i + 1] << 32);
+}
+
+// Keccak LMCS: the sponge over the row's 2 * arity <= 16 felts = one permutation of (felts, zeros)
+__global__ __launch_bounds__(256) void k_fri_leaf_hash_kk(const u64* __restrict__ ev, int log_rows, int cbits, int log_arity,
+                                                          u64* __restrict__ digests) {
+  const int log_q = log_rows - log_arity;
+  const size_t leaves = (size_t)1 << (log_q + cbits);
+  const size_t s = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (s >= leaves) return;
+  const size_t j = s >> log_q, r0 = s & (((size_t)1 << log_q) - 1);
+  const u32 arity = 1u << log_arity;
+  uint64_t st[25];
+#pragma unroll
+  for (int i = 0; i < 25; i++) st[i] = 0;
+#pragma unroll
+  for (u32 p = 0; p < 8; p++) {
+    if (p < arity) {
+      const e2 v = ld_e2(ev, (j << log_rows) + r0 + ((size_t)fri_row_pos(p, log_arity) << log_q));
+      st[2 * p] = v.c0;
+      st[2 * p + 1] = v.c1;
+    }
+  }
+  kk::f1600(st);
+#pragma unroll
+  for (int i = 0; i < 4; i++) digests[4 * s + i] = st[i];
 }
 
 // ---- fold ----------------------------------------------------------------------------------------
@@ -173,7 +199,9 @@ __global__ void k_fri_to_natural(const u64* ev, u64* out, int log_rows, int cbit
 void fri_leaf_hash(mh_ctx* c, const u64* ev, int log_rows, int cbits, int log_arity, u64* digests) {
   const size_t leaves = (size_t)1 << (log_rows - log_arity + cbits);
   ProfScope ps(c, "fri_leaf_hash", (double)leaves * (16.0 * (1 << log_arity) + 32.0));
-  if (c->lmcs == MH_LMCS_BLAKE3)
+  if (c->lmcs == MH_LMCS_KECCAK)
+    MH_LAUNCH(k_fri_leaf_hash_kk, dim3((unsigned)((leaves + 255) / 256)), dim3(256), 0, c->stream, ev, log_rows, cbits, log_arity, digests);
+  else if (c->lmcs == MH_LMCS_BLAKE3)
     MH_LAUNCH(k_fri_leaf_hash_b3, dim3((unsigned)((leaves + 255) / 256)), dim3(256), 0, c->stream, ev, log_rows, cbits, log_arity, digests);
   else
     MH_LAUNCH(k_fri_leaf_hash, dim3((unsigned)((leaves + 255) / 256)), dim3(256), 0, c->stream, ev, log_rows, cbits, log_arity,

@@ -255,9 +255,13 @@ struct mh_session {
     rounds = fri_num_rounds(pp, L);
     stage = 1;
   }
-  // aligned_len(w, lmcs.alignment()) (util/align.rs:7-13): 8 for the sponge, 1 for the chaining hasher of the Blake3 LMCS
-  size_t alignment() const { return c->lmcs == MH_LMCS_BLAKE3 ? 1 : 8; }
-  size_t al(size_t w) const { return c->lmcs == MH_LMCS_BLAKE3 ? w : align8(w); }
+  // aligned_len(w, lmcs.alignment()) (util/align.rs:7-13): the sponge's rate -- 8 (Poseidon2), 17 (Keccak) -- or 1 for the chaining
+  // hasher of the Blake3 LMCS
+  size_t alignment() const { return c->lmcs == MH_LMCS_BLAKE3 ? 1 : (c->lmcs == MH_LMCS_KECCAK ? 17 : 8); }
+  size_t al(size_t w) const {
+    const size_t a = alignment();
+    return (w + a - 1) / a * a;
+  }
   size_t ood_width() const {
     size_t w = 0;
     for (int i = 0; i < n_airs; i++)

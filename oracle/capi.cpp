@@ -9,6 +9,7 @@
 #include "stark.hpp"
 #include "lookup.hpp"
 #include "blake3.hpp"
+#include "keccak.hpp"
 #include <cstring>
 #include <cstdio>
 
@@ -39,6 +40,8 @@ void orc_permute(uint64_t* states, size_t n) {
 }
 void orc_hash_elements(const uint64_t* in, size_t n, uint64_t out[4]) { hash_elements(in, n, out); }
 void orc_compress(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]) { compress(l, r, out); }
+void orc_keccak_f1600(uint64_t st[25]) { kk::f1600(st); }
+void orc_keccak256(const uint8_t* data, size_t n, int pad, uint8_t out[32]) { kk::hash256(data, n, (uint8_t)pad, out); }
 void orc_blake3(const uint8_t* data, size_t n, uint8_t out[32]) { b3::hash(data, n, out); }
 void orc_sponge_absorb(uint64_t state[12], const uint64_t* in, size_t n) { sponge_absorb(state, in, n); }
 

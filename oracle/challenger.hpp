@@ -25,7 +25,8 @@ namespace oracle {
 
 typedef std::array<uint64_t, 4> Digest;
 
-// mode LMCS_BLAKE3: SerializingChallenger64<Felt, HashChallenger<u8, Blake3Hasher, 32>> (air/src/config.rs:291-303), both
+// modes LMCS_BLAKE3 / LMCS_KECCAK: SerializingChallenger64<Felt, HashChallenger<u8, Blake3Hasher | Keccak256Hash, 32>>
+// (air/src/config.rs:291-303, 334-353; Keccak256Hash = Keccak-256 with the original 0x01 padding, p3-keccak), both
 // external (p3-challenger 0.6.2) and with NO in-tree mirror -- PARITY UNPINNED, restated from the published crate:
 //   HashChallenger: observe(byte) clears the output buffer and appends to the input buffer; sampling from an empty output
 //     buffer flushes: output = hash(input), input := output (chaining); sample = output.pop() (from the END);
@@ -45,7 +46,7 @@ struct Challenger {
   }
   void init(const uint64_t init_state[12]) {
     for (int i = 0; i < 12; i++) st[i] = init_state[i];
-    if (mode == LMCS_BLAKE3)
+    if (bytes())
       for (int i = 8; i < 12; i++) observe(st[i]);
   }
   void duplexing() {
@@ -59,9 +60,14 @@ struct Challenger {
     p2_permute(st);
     out.assign(st, st + 8);
   }
+  bool bytes() const { return mode != LMCS_POSEIDON2; }
+  void hash_bytes(const uint8_t* p, size_t n, uint8_t d[32]) const {
+    if (mode == LMCS_KECCAK) kk::hash256(p, n, 0x01, d);
+    else b3::hash(p, n, d);
+  }
   void flush_bytes() {
     uint8_t d[32];
-    b3::hash(bin.data(), bin.size(), d);
+    hash_bytes(bin.data(), bin.size(), d);
     bout.assign(d, d + 32);
     bin.assign(d, d + 32);
   }
@@ -75,7 +81,7 @@ struct Challenger {
     return v;
   }
   void observe(uint64_t x) {
-    if (mode == LMCS_BLAKE3) {
+    if (bytes()) {
       bout.clear();
       for (int i = 0; i < 8; i++) bin.push_back((uint8_t)(x >> (8 * i)));
       return;
@@ -88,7 +94,7 @@ struct Challenger {
     for (uint64_t x : d) observe(x);
   }
   uint64_t sample() {
-    if (mode == LMCS_BLAKE3) {
+    if (bytes()) {
       for (;;) {
         uint64_t v = sample_u64_bytes();
         if (v < P) return v;
@@ -105,7 +111,7 @@ struct Challenger {
     return E2{c0, c1};
   }
   size_t sample_bits(int bits) {
-    if (mode == LMCS_BLAKE3) return (size_t)(sample_u64_bytes() & (((uint64_t)1 << bits) - 1));
+    if (bytes()) return (size_t)(sample_u64_bytes() & (((uint64_t)1 << bits) - 1));
     return (size_t)((sample() & 0xFFFFFFFFULL) & (((uint64_t)1 << bits) - 1));
   }
   bool check_witness(int bits, uint64_t w) {
@@ -116,11 +122,11 @@ struct Challenger {
   // check_witness on a stack copy of the state (no heap traffic): exactly one duplexing happens
   // between observe(w) and the sampled bits, whether the buffer fills up (8) or not.
   bool trial(int bits, uint64_t w) const {
-    if (mode == LMCS_BLAKE3) {
+    if (bytes()) {
       std::vector<uint8_t> m(bin);
       for (int i = 0; i < 8; i++) m.push_back((uint8_t)(w >> (8 * i)));
       uint8_t d[32];
-      b3::hash(m.data(), m.size(), d);
+      hash_bytes(m.data(), m.size(), d);
       uint64_t v = 0;
       for (int i = 0; i < 8; i++) v |= (uint64_t)d[31 - i] << (8 * i);
       return (v & (((uint64_t)1 << bits) - 1)) == 0;
@@ -150,7 +156,7 @@ struct Challenger {
     }
   }
   Digest finalize() {
-    if (mode == LMCS_BLAKE3) {  // one unconditional state transition (stark-transcript/src/prover.rs:31-35), then the digest
+    if (bytes()) {  // one unconditional state transition (stark-transcript/src/prover.rs:31-35), then the digest
       flush_bytes();
       Digest d;
       memcpy(d.data(), bout.data(), 32);

@@ -11,6 +11,7 @@
 #pragma once
 #include "poseidon2.hpp"
 #include "blake3.hpp"
+#include "keccak.hpp"
 #include <algorithm>
 #include <array>
 #include <cstring>
@@ -38,13 +39,13 @@ struct LmcsTree {
 // blake3(state || felts as canonical u64 little-endian bytes) (chaining.rs:32-50; the byte encoding is pinned by
 // crates/crypto/src/hash/blake/tests.rs:24-34); node = blake3(left || right).  Lifting duplicates states exactly as for
 // the sponge (lifted_tree.rs:363-417 is generic in the hasher).  A Digest holds the 32 bytes as four little-endian u64.
-enum { LMCS_POSEIDON2 = 0, LMCS_BLAKE3 = 1 };
+enum { LMCS_POSEIDON2 = 0, LMCS_BLAKE3 = 1, LMCS_KECCAK = 2 };
 // The STARK configuration the oracle restates (test infrastructure: one setting for the process, orc_set_lmcs): the LMCS
 // hasher, and with it the row alignment (Alignable::ALIGNMENT: 8 for the sponge, 1 for the chaining hasher,
 // chaining.rs:161-169 -- every aligned width of the protocol follows lmcs.alignment(), proof.rs:268, deep/prover.rs:133)
 // and the challenger (duplex sponge / serializing hash challenger, air/src/config.rs:224,291-292).
 inline int g_lmcs = LMCS_POSEIDON2;
-static inline size_t lmcs_alignment() { return g_lmcs == LMCS_BLAKE3 ? 1 : 8; }
+static inline size_t lmcs_alignment() { return g_lmcs == LMCS_BLAKE3 ? 1 : (g_lmcs == LMCS_KECCAK ? 17 : 8); }
 static inline Digest b3_absorb(const Digest& st, const uint64_t* row, size_t w) {
   std::vector<uint8_t> msg(32 + 8 * w);
   memcpy(msg.data(), st.data(), 32);          // little-endian host
@@ -95,8 +96,72 @@ static inline LmcsTree lmcs_build_b3(const std::vector<Mat>& mats) {
   return t;
 }
 
+// The Keccak LMCS of air/src/config.rs:307-353: SerializingStatefulSponge<StatefulSponge<KeccakF, 25, 17, 4>> -- the same
+// overwrite-mode sponge as the algebraic one (stateful-hasher/src/field_sponge.rs:41-64 is generic in the item type), over u64
+// lanes: felts enter as their canonical u64 (serializing_sponge.rs:60-75), 17 per permutation, digest = lanes 0..3; alignment 17
+// (field_sponge.rs:70, serializing_sponge.rs:163-199: lcm(8, 17 * 8) / 8).  Node = PaddingFreeSponge<KeccakF, 25, 17, 4> over
+// the 8 lanes of left || right (p3-symmetric: overwrite the first lanes of a zero state, permute once, lanes 0..3).
+static inline void keccak_absorb(uint64_t st[25], const uint64_t* in, size_t n) {
+  size_t pos = 0;
+  while (pos < n) {
+    size_t k = std::min<size_t>(17, n - pos);
+    for (size_t i = 0; i < k; i++) st[i] = in[pos + i];
+    for (size_t i = k; i < 17; i++) st[i] = 0;
+    kk::f1600(st);
+    pos += k;
+  }
+}
+static inline Digest keccak_compress(const Digest& l, const Digest& r) {
+  uint64_t st[25] = {0};
+  for (int i = 0; i < 4; i++) {
+    st[i] = l[i];
+    st[4 + i] = r[i];
+  }
+  kk::f1600(st);
+  return Digest{st[0], st[1], st[2], st[3]};
+}
+static inline LmcsTree lmcs_build_keccak(const std::vector<Mat>& mats) {
+  LmcsTree t;
+  t.leaves = mats;
+  size_t H = mats.back().h;
+  int lgH = log2_strict(H);
+  typedef std::array<uint64_t, 25> St;
+  std::vector<St> st(H), scratch(H);
+  for (auto& s : st) s.fill(0);
+  size_t active = mats.front().h;
+  for (const Mat& m : mats) {
+    if (m.h > active) {
+      size_t f = m.h / active;
+      for (size_t i = 0; i < active; i++)
+        for (size_t k = 0; k < f; k++) scratch[i * f + k] = st[i];
+      std::swap(st, scratch);
+    }
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < (long)m.h; r++) keccak_absorb(st[r].data(), m.v + (size_t)r * m.w, m.w);
+    active = m.h;
+  }
+  std::vector<Digest> cur(H);
+  for (size_t i = 0; i < H; i++) {
+    const St& s = st[bitrev((uint32_t)i, lgH)];
+    cur[i] = Digest{s[0], s[1], s[2], s[3]};
+  }
+  std::vector<std::vector<Digest>> up;
+  up.push_back(cur);
+  while (up.back().size() > 1) {
+    const auto& prev = up.back();
+    std::vector<Digest> next(prev.size() / 2);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)next.size(); i++) next[i] = keccak_compress(prev[2 * i], prev[2 * i + 1]);
+    up.push_back(std::move(next));
+  }
+  std::reverse(up.begin(), up.end());
+  t.layers = std::move(up);
+  return t;
+}
+
 static inline LmcsTree lmcs_build(const std::vector<Mat>& mats) {
   if (g_lmcs == LMCS_BLAKE3) return lmcs_build_b3(mats);
+  if (g_lmcs == LMCS_KECCAK) return lmcs_build_keccak(mats);
   LmcsTree t;
   t.leaves = mats;
   size_t H = mats.back().h;

@@ -622,6 +622,13 @@ static inline std::map<size_t, std::vector<uint64_t>> lmcs_verify_batch(Verifier
         off += w;
       }
       level[i] = st;
+    } else if (g_lmcs == LMCS_KECCAK) {
+      uint64_t st[25] = {0};
+      for (size_t w : aligned_widths) {
+        keccak_absorb(st, r.data() + off, w);
+        off += w;
+      }
+      level[i] = Digest{st[0], st[1], st[2], st[3]};
     } else {
       uint64_t st[12] = {0};
       for (size_t w : aligned_widths) {
@@ -647,6 +654,7 @@ static inline std::map<size_t, std::vector<uint64_t>> lmcs_verify_batch(Verifier
       }
       Digest parent;
       if (g_lmcs == LMCS_BLAKE3) parent = (node & 1) ? b3_compress(other, me) : b3_compress(me, other);
+      else if (g_lmcs == LMCS_KECCAK) parent = (node & 1) ? keccak_compress(other, me) : keccak_compress(me, other);
       else if (node & 1) compress(other.data(), me.data(), parent.data());
       else compress(me.data(), other.data(), parent.data());
       next[node >> 1] = parent;

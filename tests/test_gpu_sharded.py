@@ -325,23 +325,23 @@ def test_sharded_staged_session_with_a_host_owned_transcript(world):
             assert (c == ref.commitments).all() and (d == ref.digest).all()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_commitment_with_the_blake3_lmcs(world):
-    """mh_commit_traces_sharded with MH_LMCS_BLAKE3: the digest all-to-all, the per-rank subtrees and the host-side cap give
+@pytest.mark.parametrize("world,lmcs", [(2, "blake3"), (4, "blake3"), (2, "keccak"), (4, "keccak")])
+def test_sharded_commitment_with_the_byte_hash_lmcs(world, lmcs):
+    """mh_commit_traces_sharded with MH_LMCS_BLAKE3 / MH_LMCS_KECCAK: the digest all-to-all, the per-rank subtrees and the host-side cap give
     the oracle's root on every rank (thread ranks, stream-ordered communicator)."""
     import numpy as np
     import oracle_binding as ob
     rng = np.random.default_rng(3)
     traces = [rng.integers(0, ob.P, (1 << 5, 7), dtype=np.uint64), rng.integers(0, ob.P, (1 << 7, 13), dtype=np.uint64)]
     lb = 3
-    ob.set_lmcs("blake3")
+    ob.set_lmcs(lmcs)
     try:
         exp = ob.commit_traces(traces, lb)
     finally:
         ob.set_lmcs("poseidon2")
 
     def body(pkg, sharding, rank, ctx, comm):
-        ctx.set_lmcs("blake3")
+        ctx.set_lmcs(lmcs)
         com = sharding.commit_traces_sharded(pkg, ctx, comm, [ctx.upload_trace(t) for t in traces], lb)
         return com.root().copy()
 
