@@ -20,7 +20,8 @@ bounded sample), never inside the timed GPU region.  Extra keys on the N = 1 lin
 the same proof with the host->device upload of the trace inside the timed region) and `miden_shape` (the full Miden VM
 shape: three AIRs of widths 51/22/16 with 4/3/1 EF aux columns, the published reference figure's neighbour) and `in_flight`
 (three proofs in flight on the one GPU, one context per proving thread: service throughput, not the headline) and
-`blake3_config` (the device stages of a proof under the reference's default Blake3_256 configuration, staged session).
+`hash_configs` (the device stages of a proof under the reference's default Blake3_256 configuration and under Keccak, staged
+session).
 """
 import argparse, json, os, sys, time
 
@@ -463,13 +464,15 @@ def main():
             out["in_flight"] = in_flight_probe(pkg, log_n, dev_index)
         except Exception as e:
             out["in_flight"] = {"error": repr(e)[:200]}
-        try:  # the reference's DEFAULT configuration (Blake3_256) through the staged boundary, next to the same drive with Poseidon2
-            out["blake3_config"] = {"note": "staged session (mh_session_*), challenges from a PRNG: device stages of one proof; the "
-                                            "host shim's challenger and PoW search are not included",
-                                    "blake3": session_stages_probe(pkg, ctx, log_n, "blake3"),
-                                    "poseidon2": session_stages_probe(pkg, ctx, log_n, "poseidon2")}
+        try:  # the reference's other configurations (Blake3_256 = its DEFAULT, Keccak) through the staged boundary, next to the
+            # same drive with Poseidon2
+            out["hash_configs"] = {"note": "staged session (mh_session_*), challenges from a PRNG: device stages of one proof; the "
+                                           "host shim's challenger and PoW search are not included",
+                                   "blake3": session_stages_probe(pkg, ctx, log_n, "blake3"),
+                                   "keccak": session_stages_probe(pkg, ctx, log_n, "keccak"),
+                                   "poseidon2": session_stages_probe(pkg, ctx, log_n, "poseidon2")}
         except Exception as e:
-            out["blake3_config"] = {"error": repr(e)[:200]}
+            out["hash_configs"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(runner, args.cpu_log_n)
     elif rank == 0:

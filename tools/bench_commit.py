@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[1] ("NTT + Merkle only"): mh_commit_traces of the 2^LOG_N x 51 main trace (coset LDE x 8 + LMCS tree)
-with the Poseidon2 LMCS and with the Blake3 LMCS (the reference's default configuration), trace resident in HBM.
+with the Poseidon2 LMCS, the Blake3 LMCS (the reference's default configuration) and the Keccak LMCS, trace resident in HBM.
 
     python tools/bench_commit.py [--log-n 20] [--width 51] [--steps 5]
 """
@@ -22,7 +22,7 @@ def main():
     pkg = load_package()
     ctx = pkg.Ctx(0)
     tr = ctx.upload_trace(bench.synth_trace(np.random.default_rng(1), a.log_n, a.width))
-    for lmcs in ("poseidon2", "blake3"):
+    for lmcs in ("poseidon2", "blake3", "keccak"):
         ctx.set_lmcs(lmcs)
         pkg.commit_traces(ctx, [tr], 3).tree().free()
         ctx.prof_enable(True)
