@@ -385,6 +385,9 @@ void lmcs_hash_leaves(mh_ctx* c, const std::vector<LdeMatrix>& mats, int lb, u64
     a.n_mats = 0;
     double bytes = 0;
     while (i < nm && mats[i].log_n == ln && a.n_mats < LEAF_MAX_MATS) {
+      // a row is one BLAKE3 message of 32 + 8 * width bytes; b3::Stream keeps at most 2^MAX_STACK chunks of 1 KiB on its stack
+      MH_REQUIRE(c->lmcs != MH_LMCS_BLAKE3 || mats[i].width <= (((size_t)1024 << b3::MAX_STACK) - 32) / 8,
+                 "matrix too wide for the Blake3 LMCS (a row must fit 256 KiB)");
       a.m[a.n_mats].data = mats[i].lde.u();
       a.m[a.n_mats].width = (u32)mats[i].width;
       bytes += (double)mats[i].width * 8.0 * (double)((size_t)1 << (ln + lb));
