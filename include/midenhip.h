@@ -84,15 +84,20 @@ void mh_host_free(void* p);
  * state (crates/stateful-hasher/src/chaining.rs:32-50, alignment 1), node = blake3(left || right); a digest travels as
  * four uint64_t = its 32 bytes little-endian.  MH_LMCS_KECCAK: the Keccak configuration's LMCS (config.rs:307-353): the
  * overwrite-mode sponge over 64-bit lanes with Keccak-f[1600] (25 lanes, 17 felts as canonical u64 per permutation, digest =
- * lanes 0..3; alignment 17), node = one permutation over left || right in a zero state.  It applies to everything this context commits and opens: mh_commit_traces,
+ * lanes 0..3; alignment 17), node = one permutation over left || right in a zero state.  MH_LMCS_RPO / MH_LMCS_RPX: the
+ * other two ALGEBRAIC configurations (config.rs:224-245): the Poseidon2 LMCS and duplex challenger with the Rescue Prime
+ * permutations (crates/crypto/src/hash/algebraic_sponge/rescue/); for them the one-shot mh_prove, mh_grind and mh_verify_lmcs
+ * work as for Poseidon2.  It applies to everything this context commits and opens: mh_commit_traces,
  * mh_commit_traces_sharded, mh_tree_open and the staged session mh_session_* -- there the row alignment follows the hasher
  * (lmcs.alignment(): the sponge's rate, 8 or 17; 1 for the chaining hasher: OOD blocks and opened rows are then unpadded) and the FRI
  * leaves use it too, so a host shim that owns the Blake3 configuration's challenger (p3 SerializingChallenger64 over a
- * HashChallenger) proves under HashFunction::Blake3_256 through the session.  The one-shot mh_prove / mh_prove_sharded own a
- * duplex-sponge transcript and mh_verify its verifier: they are the Poseidon2 configuration only and say so. */
+ * HashChallenger) proves under HashFunction::Blake3_256 / Keccak through the session.  The one-shot mh_prove / mh_prove_sharded
+ * own a duplex-sponge transcript and mh_verify* is its verifier: the algebraic configurations only, and they say so. */
 #define MH_LMCS_POSEIDON2 0
 #define MH_LMCS_BLAKE3 1
 #define MH_LMCS_KECCAK 2
+#define MH_LMCS_RPO 3
+#define MH_LMCS_RPX 4
 int mh_ctx_set_lmcs(mh_ctx* ctx, int lmcs);
 int mh_ctx_get_lmcs(const mh_ctx* ctx);
 /* blake3(data) (host only; unit-parity entry point, like mh_poseidon2_permute) */
@@ -338,6 +343,13 @@ int mh_verify_ex(const mh_pcs_params* params, int n_airs, const uint64_t* const*
                  const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe, const uint64_t* fields,
                  size_t n_fields, const uint64_t* commitments, size_t n_commitments, const uint64_t* preprocessed_root,
                  mh_external_assertions external, void* external_user, uint64_t digest[4], char* err, size_t err_cap);
+/* mh_verify_ex for an algebraic configuration other than Poseidon2: lmcs = MH_LMCS_POSEIDON2 | MH_LMCS_RPO | MH_LMCS_RPX
+ * (HashFunction::Rpo256 / Rpx256, prover/src/lib.rs:268-300). */
+int mh_verify_lmcs(int lmcs, const mh_pcs_params* params, int n_airs, const uint64_t* const* air_blobs, const size_t* air_blob_words,
+                   const uint8_t* log_trace_heights, const uint64_t* public_values, size_t n_public_values,
+                   const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe, const uint64_t* fields,
+                   size_t n_fields, const uint64_t* commitments, size_t n_commitments, const uint64_t* preprocessed_root,
+                   mh_external_assertions external, void* external_user, uint64_t digest[4], char* err, size_t err_cap);
 /* A ready-made mh_external_assertions: one assertion, the sum over the instances of their aux value 0 (the LogUp accumulator
  * final, `committed_finals` of air/src/lookup/aux_builder.rs) -- the balance of a bus statement with no boundary corrections. */
 int mh_external_logup_balance(void* user, const uint64_t* randomness, size_t n_randomness, const uint64_t* const* aux_values,

@@ -31,7 +31,7 @@ EXPORTS = [
     "mh_session_commit_quotient", "mh_session_ood_point_ok", "mh_session_ood", "mh_session_deep", "mh_session_fri_commit",
     "mh_session_fri_fold", "mh_session_fri_final", "mh_session_open", "mh_grind",
     "mh_host_alloc", "mh_host_free", "mh_verify", "mh_trace_from_device", "mh_lookup_load", "mh_lookup_free", "mh_air_attach_lookup", "mh_air_attach_preprocessed", "mh_lookup_build_aux", "mh_trace_download",
-    "mh_verify_ex", "mh_external_logup_balance", "mh_proof_deserialize", "mh_ctx_set_lmcs", "mh_ctx_get_lmcs", "mh_blake3",
+    "mh_verify_ex", "mh_external_logup_balance", "mh_proof_deserialize", "mh_ctx_set_lmcs", "mh_ctx_get_lmcs", "mh_blake3", "mh_verify_lmcs",
     "mh_rccl_unique_id", "mh_comm_create_rccl", "mh_comm_destroy", "mh_comm_selftest",
     "mh_local_fabric_create", "mh_local_fabric_destroy", "mh_comm_create_local",
 ]
@@ -162,7 +162,7 @@ class Ctx:
         """Release the device buffers pooled between proofs."""
         self.check(self.lib.mh_ctx_trim(self.h))
 
-    LMCS = {"poseidon2": 0, "blake3": 1, "keccak": 2}
+    LMCS = {"poseidon2": 0, "blake3": 1, "keccak": 2, "rpo": 3, "rpx": 4}
 
     def set_lmcs(self, name):
         """mh_ctx_set_lmcs: the commitment scheme's hasher for commit_traces / tree openings on this context ("poseidon2" |
@@ -608,7 +608,7 @@ def external_callback(fn):
 
 
 def verify(airs, log_trace_heights, public_values, params, challenger_state, pre_observe, fields, commitments,
-           preprocessed_root=None, external=None):
+           preprocessed_root=None, external=None, lmcs="poseidon2"):
     """mh_verify / mh_verify_ex (host only, no GPU): airs = dag.Air objects in instance order; preprocessed_root = the setup
     commitment when some AIR has preprocessed columns (it must also be in pre_observe); external = the statement's cross-AIR
     assertions: an EXTERNAL_FN / external_callback(...) object, or the string "logup_balance" for the library's
@@ -626,7 +626,13 @@ def verify(airs, log_trace_heights, public_values, params, challenger_state, pre
     digest = np.zeros(4, dtype=np.uint64)
     err = C.create_string_buffer(512)
     proot = _arr(preprocessed_root) if preprocessed_root is not None else None
-    if external is None:
+    if lmcs != "poseidon2":  # mh_verify_lmcs: the other algebraic configurations ("rpo", "rpx")
+        ext = C.cast(lib.mh_external_logup_balance, EXTERNAL_FN) if external == "logup_balance" else external
+        rc = lib.mh_verify_lmcs(C.c_int(Ctx.LMCS[lmcs]), C.byref(p), C.c_int(n), bp, bl, lh, _ptr(pub), C.c_size_t(len(public_values)),
+                                _ptr(st), _ptr(pre), C.c_size_t(len(pre_observe)), _ptr(f), C.c_size_t(f.size), _ptr(c),
+                                C.c_size_t(c.size // 4), _ptr(proot) if proot is not None else None,
+                                ext if ext is not None else C.cast(None, EXTERNAL_FN), None, _ptr(digest), err, C.c_size_t(512))
+    elif external is None:
         rc = lib.mh_verify(C.byref(p), C.c_int(n), bp, bl, lh, _ptr(pub), C.c_size_t(len(public_values)), _ptr(st), _ptr(pre),
                            C.c_size_t(len(pre_observe)), _ptr(f), C.c_size_t(f.size), _ptr(c), C.c_size_t(c.size // 4),
                            _ptr(proot) if proot is not None else None, _ptr(digest), err, C.c_size_t(512))

@@ -42,7 +42,7 @@ int mh_device_count(void) {
 
 int mh_ctx_set_lmcs(mh_ctx* c, int lmcs) {
   if (!c) return MH_ERR_INVALID;
-  if (lmcs != MH_LMCS_POSEIDON2 && lmcs != MH_LMCS_BLAKE3 && lmcs != MH_LMCS_KECCAK) {
+  if (lmcs < MH_LMCS_POSEIDON2 || lmcs > MH_LMCS_RPX) {
     c->err = "unknown LMCS hasher id";
     return MH_ERR_INVALID;
   }

@@ -1,4 +1,4 @@
-// Host-side Fiat-Shamir: duplex challenger over Poseidon2 and the prover transcript.
+// Host-side Fiat-Shamir: duplex challenger over an algebraic permutation (Poseidon2; RPO / RPX) and the prover transcript.
 //
 // In the reference these live on the host as well: p3-challenger 0.6.2 `DuplexChallenger`
 // (semantics mirrored in-tree by crates/lib/core/asm/stark/random_coin.masm:103-303, :944-975) and
@@ -6,13 +6,14 @@
 // GPU (fri.hip k_grind): the device searches a window of witnesses in parallel and the host
 // replays the smallest hit, so the transcript is a pure function of the inputs.
 #pragma once
-#include "poseidon2.cuh"
+#include "rescue.cuh"
 #include <array>
 #include <vector>
 
 typedef std::array<u64, 4> Digest4;
 
 struct HostChallenger {
+  int hash = 0;  // MH_LMCS_* id of the algebraic configuration: which permutation the sponge uses (0 Poseidon2, 3 RPO, 4 RPX)
   u64 st[12];
   std::vector<u64> in, out;
   HostChallenger() {
@@ -26,7 +27,7 @@ struct HostChallenger {
       st[8] = gl_add(st[8], (u64)k);
       in.clear();
     }
-    p2_permute(st);
+    alg_permute(hash, st);
     out.assign(st, st + 8);
   }
   void observe(u64 x) {

@@ -16,6 +16,7 @@
 #include "kernels.hpp"
 #include "blake3.cuh"
 #include "keccak.cuh"
+#include "rescue.cuh"
 #include "poseidon2_fast.cuh"
 
 __device__ __forceinline__ e2 ld_e2(const u64* p, size_t idx) {
@@ -86,6 +87,33 @@ __global__ __launch_bounds__(256) void k_fri_leaf_hash_b3(const u64* __restrict_
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) digests[4 * s + i] = (u64)out[2 * i] | ((u64)out[2 * i + 1] << 32);
+}
+
+// RPO / RPX: k_fri_leaf_hash with the Rescue permutations
+__global__ __launch_bounds__(256) void k_fri_leaf_hash_alg(const u64* __restrict__ ev, int log_rows, int cbits, int log_arity,
+                                                           u64* __restrict__ digests, int lmcs) {
+  const int log_q = log_rows - log_arity;
+  const size_t leaves = (size_t)1 << (log_q + cbits);
+  const size_t s = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (s >= leaves) return;
+  const size_t j = s >> log_q, r0 = s & (((size_t)1 << log_q) - 1);
+  const u32 arity = 1u << log_arity;
+  u64 st[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) st[i] = 0;
+#pragma unroll 1
+  for (u32 p0 = 0; p0 < arity; p0 += 4) {
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+      e2 v = e2_make(0);
+      if (p0 + k < arity) v = ld_e2(ev, (j << log_rows) + r0 + ((size_t)fri_row_pos(p0 + k, log_arity) << log_q));
+      st[2 * k] = (p0 + k < arity) ? v.c0 : 0;
+      st[2 * k + 1] = (p0 + k < arity) ? v.c1 : 0;
+    }
+    alg_permute(lmcs, st);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) digests[4 * s + i] = st[i];
 }
 
 // Keccak LMCS: the sponge over the row's 2 * arity <= 16 felts = one permutation of (felts, zeros)
@@ -199,7 +227,10 @@ __global__ void k_fri_to_natural(const u64* ev, u64* out, int log_rows, int cbit
 void fri_leaf_hash(mh_ctx* c, const u64* ev, int log_rows, int cbits, int log_arity, u64* digests) {
   const size_t leaves = (size_t)1 << (log_rows - log_arity + cbits);
   ProfScope ps(c, "fri_leaf_hash", (double)leaves * (16.0 * (1 << log_arity) + 32.0));
-  if (c->lmcs == MH_LMCS_KECCAK)
+  if (c->lmcs == MH_LMCS_RPO || c->lmcs == MH_LMCS_RPX)
+    MH_LAUNCH(k_fri_leaf_hash_alg, dim3((unsigned)((leaves + 255) / 256)), dim3(256), 0, c->stream, ev, log_rows, cbits, log_arity, digests,
+                       c->lmcs);
+  else if (c->lmcs == MH_LMCS_KECCAK)
     MH_LAUNCH(k_fri_leaf_hash_kk, dim3((unsigned)((leaves + 255) / 256)), dim3(256), 0, c->stream, ev, log_rows, cbits, log_arity, digests);
   else if (c->lmcs == MH_LMCS_BLAKE3)
     MH_LAUNCH(k_fri_leaf_hash_b3, dim3((unsigned)((leaves + 255) / 256)), dim3(256), 0, c->stream, ev, log_rows, cbits, log_arity, digests);
@@ -273,6 +304,23 @@ __global__ __launch_bounds__(256) void k_grind(GrindArgs a) {
   if (((x & 0xFFFFFFFFULL) & (((u64)1 << a.bits) - 1)) == 0) atomicMin(a.best, (unsigned long long)w);
 }
 
+__global__ __launch_bounds__(256) void k_grind_alg(GrindArgs a, int lmcs) {
+  const u64 w = a.base + blockIdx.x * (u64)256 + threadIdx.x;
+  if (w >= GL_P) return;
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = a.st[i];
+  const int k = a.n_in + 1;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u64 v = (i < a.n_in) ? a.in[i] : (i == a.n_in ? w : 0);
+    s[i] = (i < k) ? v : 0;
+  }
+  s[8] = gl_add(s[8], (u64)k);
+  alg_permute(lmcs, s);
+  if (((s[7] & 0xFFFFFFFFULL) & (((u64)1 << a.bits) - 1)) == 0) atomicMin(a.best, (unsigned long long)w);
+}
+
 // Returns the smallest witness >= 0 accepted by `check_witness` for the given challenger snapshot.
 u64 fri_grind(mh_ctx* c, const u64 st[12], const u64* in, int n_in, int bits) {
   MH_REQUIRE(bits > 0 && bits <= 32 && n_in >= 0 && n_in < 8, "bad grind request");
@@ -290,7 +338,10 @@ u64 fri_grind(mh_ctx* c, const u64 st[12], const u64* in, int n_in, int bits) {
     unsigned long long init = ~0ULL;
     HIP_CHECK(hipMemcpyAsync(best.p, &init, 8, hipMemcpyHostToDevice, c->stream));
     a.base = base;
-    MH_LAUNCH(k_grind, dim3((unsigned)(window / 256)), dim3(256), 0, c->stream, a);
+    if (c->lmcs == MH_LMCS_RPO || c->lmcs == MH_LMCS_RPX)
+      MH_LAUNCH(k_grind_alg, dim3((unsigned)(window / 256)), dim3(256), 0, c->stream, a, c->lmcs);
+    else
+      MH_LAUNCH(k_grind, dim3((unsigned)(window / 256)), dim3(256), 0, c->stream, a);
     unsigned long long got = 0;
     c->d2h(&got, best.p, 8);
     if (got != ~0ULL) return (u64)got;

@@ -23,6 +23,7 @@
 #include "poseidon2_lanes.cuh"
 #include "blake3.cuh"
 #include "keccak.cuh"
+#include "rescue.cuh"
 #include "gl.cuh"
 #include <algorithm>
 #include <cstring>
@@ -211,6 +212,69 @@ __global__ __launch_bounds__(256) void k_compress_b3(const u64* __restrict__ in,
   for (int i = 0; i < 4; i++) out[4 * q + i] = (u64)o[2 * i] | ((u64)o[2 * i + 1] << 32);
 }
 
+// ---- RPO / RPX (MH_LMCS_RPO, MH_LMCS_RPX): the sponge and the compression of the Poseidon2 LMCS with the Rescue permutations
+// (rescue.cuh; plain arithmetic, one state per lane -- supported, not tuned) ----
+__global__ __launch_bounds__(LEAF_THREADS) void k_leaf_absorb_alg(LeafArgs a, int lmcs) {
+  const size_t leaves = (size_t)1 << (a.log_n + a.log_blowup);
+  const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (q >= leaves) return;
+  const size_t j = q >> a.log_n, r = q & (((size_t)1 << a.log_n) - 1);
+  u64 s[12];
+  if (a.state_in) {
+    const size_t leaves_prev = (size_t)1 << (a.log_n_prev + a.log_blowup);
+    const size_t qi = (j << a.log_n_prev) + (r & (((size_t)1 << a.log_n_prev) - 1));
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = a.state_in[i * leaves_prev + qi];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+  }
+  const size_t col_stride = leaves;
+#pragma unroll 1
+  for (int mi = 0; mi < a.n_mats; mi++) {
+    const u64* base = a.m[mi].data + q;
+    const u32 w = a.m[mi].width;
+#pragma unroll 1
+    for (u32 c0 = 0; c0 < w; c0 += 8) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) s[k] = (c0 + k < w) ? base[(size_t)(c0 + k) * col_stride] : 0;
+      alg_permute(lmcs, s);
+    }
+  }
+  if (a.digest_out) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) a.digest_out[4 * q + i] = s[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; i++) a.state_out[i * leaves + q] = s[i];
+  }
+}
+__global__ __launch_bounds__(256) void k_compress_alg(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out, int log_n_coset,
+                                                      int lmcs) {
+  const size_t q = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (q >= n_out) return;
+  size_t l, rgt;
+  if (log_n_coset >= 0) {
+    const size_t N = (size_t)1 << log_n_coset;
+    const size_t jp = q >> log_n_coset, r = q & (N - 1);
+    l = ((2 * jp) << log_n_coset) + r;
+    rgt = l + N;
+  } else {
+    l = 2 * q;
+    rgt = l + 1;
+  }
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    s[i] = in[4 * l + i];
+    s[4 + i] = in[4 * rgt + i];
+    s[8 + i] = 0;
+  }
+  alg_permute(lmcs, s);
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[4 * q + i] = s[i];
+}
+
 // ---- Keccak LMCS (MH_LMCS_KECCAK): the sponge of k_leaf_absorb with Keccak-f[1600], 25 lanes, rate 17 ----
 __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_absorb_kk(LeafArgs a) {
   const size_t leaves = (size_t)1 << (a.log_n + a.log_blowup);
@@ -343,7 +407,10 @@ void lmcs_compress_layers(mh_ctx* c, mh_tree* t) {
       size_t n_out = (size_t)1 << d;
       int cbits_child = (d + 1) - (t->log_height - lb);  // coset bits of the child layer
       int log_n_coset = cbits_child > 0 ? (t->log_height - lb) : -1;
-      if (c->lmcs == MH_LMCS_KECCAK)
+      if (c->lmcs == MH_LMCS_RPO || c->lmcs == MH_LMCS_RPX)
+        MH_LAUNCH(k_compress_alg, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream,
+                           t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset, c->lmcs);
+      else if (c->lmcs == MH_LMCS_KECCAK)
         MH_LAUNCH(k_compress_kk, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream,
                            t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
       else if (c->lmcs == MH_LMCS_BLAKE3)
@@ -414,7 +481,10 @@ void lmcs_hash_leaves(mh_ctx* c, const std::vector<LdeMatrix>& mats, int lb, u64
     if (state_in) bytes += 96.0 * leaves;
     {
       ProfScope ps(c, "lmcs_leaf_absorb", bytes);
-      if (c->lmcs == MH_LMCS_KECCAK)
+      if (c->lmcs == MH_LMCS_RPO || c->lmcs == MH_LMCS_RPX)
+        MH_LAUNCH(k_leaf_absorb_alg, dim3((unsigned)((leaves + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0, c->stream, a,
+                           c->lmcs);
+      else if (c->lmcs == MH_LMCS_KECCAK)
         MH_LAUNCH(k_leaf_absorb_kk, dim3((unsigned)((leaves + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0, c->stream, a);
       else if (c->lmcs == MH_LMCS_BLAKE3)
         MH_LAUNCH(k_leaf_absorb_b3, dim3((unsigned)((leaves + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0, c->stream, a);
@@ -561,7 +631,7 @@ void lmcs_build_sharded(mh_ctx* c, mh_tree* t, const Dist& dist, const u64* loca
         memcpy(st, dg, 32);
       } else {
         for (int k = 0; k < 8; k++) st[k] = l[k];
-        p2_permute(st);
+        alg_permute(c->lmcs, st);
       }
       memcpy(t->cap.data() + 4 * ((((size_t)1) << d) - 1 + p), st, 32);
     }

@@ -621,11 +621,13 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
                        mh_aux_builder cb, void* user, mh_proof& proof, const Dist& dist) {
   // the one-shot prover owns the transcript, and the library's challenger is the duplex sponge of the Poseidon2 (algebraic)
   // configuration; the Blake3 configuration goes through the staged session, where the host owns the challenger
-  MH_REQUIRE(c->lmcs == MH_LMCS_POSEIDON2,
-             "mh_prove is built for the Poseidon2 configuration: with another LMCS hasher use the staged session (host-owned transcript)");
+  MH_REQUIRE(c->lmcs == MH_LMCS_POSEIDON2 || c->lmcs == MH_LMCS_RPO || c->lmcs == MH_LMCS_RPX,
+             "mh_prove is built for the algebraic configurations (Poseidon2 configuration, RPO, RPX): with a byte hasher use the staged "
+             "session (host-owned transcript)");
   mh_session s;
   s.begin(c, pp, n_airs, airs_in, traces_in, publics_in, n_publics, dist);
   HostTranscript tr;
+  tr.ch.hash = c->lmcs;
   for (int i = 0; i < 12; i++) tr.ch.st[i] = gl_canon(init_state[i]);
   for (size_t i = 0; i < n_pre; i++) tr.ch.observe(pre_observe[i]);
   tr.ch.observe((u64)n_airs);  // order.rs:154-163
@@ -1040,6 +1042,8 @@ int mh_grind(mh_ctx* c, const uint64_t state[12], const uint64_t* pending, size_
   MH_REQUIRE(n_pending < 8 && bits >= 0 && bits <= 32, "pending input must be shorter than the rate; bits in 0..32");
   HIP_CHECK(hipSetDevice(c->device));
   HostTranscript tr;
+  tr.ch.hash = c->lmcs;
+  MH_REQUIRE(c->lmcs == MH_LMCS_POSEIDON2 || c->lmcs == MH_LMCS_RPO || c->lmcs == MH_LMCS_RPX, "mh_grind searches the duplex sponge's witness: algebraic configurations only");
   for (int i = 0; i < 12; i++) tr.ch.st[i] = gl_canon(state[i]);
   for (size_t i = 0; i < n_pending; i++) tr.ch.in.push_back(gl_canon(pending[i]));
   do_grind(c, tr, bits);

@@ -66,6 +66,8 @@ struct Reader {
 };
 
 size_t align8(size_t w) { return (w + 7) / 8 * 8; }
+// the algebraic configuration being verified (MH_LMCS_POSEIDON2 / _RPO / _RPX): set per call, per thread
+thread_local int t_hash = 0;
 
 // Overwrite-mode sponge over whole (already aligned / short) rows: crates/stateful-hasher/src/field_sponge.rs:41-59.
 void absorb(u64 st[12], const u64* v, size_t n) {
@@ -73,12 +75,12 @@ void absorb(u64 st[12], const u64* v, size_t n) {
     const size_t k = std::min<size_t>(8, n - off);
     for (size_t i = 0; i < k; i++) st[i] = v[off + i];
     for (size_t i = k; i < 8; i++) st[i] = 0;
-    p2_permute(st);
+    alg_permute(t_hash, st);
   }
 }
 Digest4 compress2(const Digest4& l, const Digest4& r) {
   u64 st[12] = {l[0], l[1], l[2], l[3], r[0], r[1], r[2], r[3], 0, 0, 0, 0};
-  p2_permute(st);
+  alg_permute(t_hash, st);
   return Digest4{st[0], st[1], st[2], st[3]};
 }
 
@@ -476,7 +478,7 @@ void verify_impl(const mh_pcs_params& pp, const std::vector<DagIR>& airs, const 
 
 }  // namespace
 
-static int verify_entry(const mh_pcs_params* params, int n_airs, const uint64_t* const* air_blobs, const size_t* air_blob_words,
+static int verify_entry(int lmcs, const mh_pcs_params* params, int n_airs, const uint64_t* const* air_blobs, const size_t* air_blob_words,
                         const uint8_t* log_trace_heights, const uint64_t* public_values, size_t n_public_values,
                         const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe, const uint64_t* fields,
                         size_t n_fields, const uint64_t* commitments, size_t n_commitments, const uint64_t* preprocessed_root,
@@ -500,7 +502,11 @@ static int verify_entry(const mh_pcs_params* params, int n_airs, const uint64_t*
       airs.push_back(dag_parse(air_blobs[i], air_blob_words[i]));
       lhs.push_back(log_trace_heights[i]);
     }
+    MH_REQUIRE(lmcs == MH_LMCS_POSEIDON2 || lmcs == MH_LMCS_RPO || lmcs == MH_LMCS_RPX,
+               "mh_verify covers the algebraic configurations (Poseidon2, RPO, RPX): duplex-sponge transcript, sponge LMCS");
+    t_hash = lmcs;
     Reader rd;
+    rd.ch.hash = lmcs;
     for (int i = 0; i < 12; i++) rd.ch.st[i] = gl_canon(challenger_state[i]);
     for (size_t i = 0; i < n_pre_observe; i++) rd.ch.observe(pre_observe[i]);
     rd.f = fields; rd.nf = n_fields;
@@ -524,7 +530,7 @@ int mh_verify(const mh_pcs_params* params, int n_airs, const uint64_t* const* ai
               const uint8_t* log_trace_heights, const uint64_t* public_values, size_t n_public_values, const uint64_t challenger_state[12],
               const uint64_t* pre_observe, size_t n_pre_observe, const uint64_t* fields, size_t n_fields, const uint64_t* commitments,
               size_t n_commitments, const uint64_t* preprocessed_root, uint64_t digest[4], char* err, size_t err_cap) {
-  return verify_entry(params, n_airs, air_blobs, air_blob_words, log_trace_heights, public_values, n_public_values, challenger_state,
+  return verify_entry(MH_LMCS_POSEIDON2, params, n_airs, air_blobs, air_blob_words, log_trace_heights, public_values, n_public_values, challenger_state,
                       pre_observe, n_pre_observe, fields, n_fields, commitments, n_commitments, preprocessed_root, nullptr, nullptr, digest,
                       err, err_cap);
 }
@@ -533,9 +539,18 @@ int mh_verify_ex(const mh_pcs_params* params, int n_airs, const uint64_t* const*
                  const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe, const uint64_t* fields,
                  size_t n_fields, const uint64_t* commitments, size_t n_commitments, const uint64_t* preprocessed_root,
                  mh_external_assertions external, void* external_user, uint64_t digest[4], char* err, size_t err_cap) {
-  return verify_entry(params, n_airs, air_blobs, air_blob_words, log_trace_heights, public_values, n_public_values, challenger_state,
-                      pre_observe, n_pre_observe, fields, n_fields, commitments, n_commitments, preprocessed_root, external, external_user,
-                      digest, err, err_cap);
+  return verify_entry(MH_LMCS_POSEIDON2, params, n_airs, air_blobs, air_blob_words, log_trace_heights, public_values, n_public_values,
+                      challenger_state, pre_observe, n_pre_observe, fields, n_fields, commitments, n_commitments, preprocessed_root,
+                      external, external_user, digest, err, err_cap);
+}
+int mh_verify_lmcs(int lmcs, const mh_pcs_params* params, int n_airs, const uint64_t* const* air_blobs, const size_t* air_blob_words,
+                   const uint8_t* log_trace_heights, const uint64_t* public_values, size_t n_public_values,
+                   const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe, const uint64_t* fields,
+                   size_t n_fields, const uint64_t* commitments, size_t n_commitments, const uint64_t* preprocessed_root,
+                   mh_external_assertions external, void* external_user, uint64_t digest[4], char* err, size_t err_cap) {
+  return verify_entry(lmcs, params, n_airs, air_blobs, air_blob_words, log_trace_heights, public_values, n_public_values,
+                      challenger_state, pre_observe, n_pre_observe, fields, n_fields, commitments, n_commitments, preprocessed_root,
+                      external, external_user, digest, err, err_cap);
 }
 // The cross-AIR assertion of a LogUp statement without boundary corrections: the committed accumulator finals
 // (aux value 0 of every instance that has one) sum to zero.

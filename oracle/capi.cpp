@@ -60,7 +60,14 @@ void orc_coset_lde_bitrev(const uint64_t* m, size_t n, size_t w, int added_bits,
 
 // LMCS over already bit-reversed row-major matrices (ascending heights).
 // layers_out (optional): all digest layers bottom(leaf, domain order)-up concatenated: 2H-1 digests.
-void orc_set_lmcs(int hash) { g_lmcs = hash; }  // the configuration of every later call (tests are serial)
+void orc_set_lmcs(int hash) {  // the configuration of every later call (tests are serial)
+  g_lmcs = hash;
+  g_alg_perm = (hash == LMCS_RPO || hash == LMCS_RPX) ? hash : 0;
+}
+void orc_rescue_permute(int which, uint64_t st[12]) {
+  if (which == LMCS_RPX) rpx_permute(st);
+  else rpo_permute(st);
+}
 void orc_lmcs_build(int n_mats, const uint64_t* const* ptrs, const size_t* heights, const size_t* widths,
                     uint64_t root_out[4], uint64_t* layers_out) {
   std::vector<Mat> mats;

@@ -57,10 +57,10 @@ struct Challenger {
       st[8] = fadd(st[8], (uint64_t)k);
       in.clear();
     }
-    p2_permute(st);
+    alg_permute(st);
     out.assign(st, st + 8);
   }
-  bool bytes() const { return mode != LMCS_POSEIDON2; }
+  bool bytes() const { return mode == LMCS_BLAKE3 || mode == LMCS_KECCAK; }
   void hash_bytes(const uint8_t* p, size_t n, uint8_t d[32]) const {
     if (mode == LMCS_KECCAK) kk::hash256(p, n, 0x01, d);
     else b3::hash(p, n, d);
@@ -136,7 +136,7 @@ struct Challenger {
     size_t k = in.size() + 1;
     for (size_t i = 0; i < 8; i++) s[i] = i < in.size() ? in[i] : (i == in.size() ? w : 0);
     s[8] = fadd(s[8], (uint64_t)k);
-    p2_permute(s);
+    alg_permute(s);
     return ((s[7] & 0xFFFFFFFFULL) & (((uint64_t)1 << bits) - 1)) == 0;
   }
   uint64_t grind(int bits) {

@@ -39,7 +39,7 @@ struct LmcsTree {
 // blake3(state || felts as canonical u64 little-endian bytes) (chaining.rs:32-50; the byte encoding is pinned by
 // crates/crypto/src/hash/blake/tests.rs:24-34); node = blake3(left || right).  Lifting duplicates states exactly as for
 // the sponge (lifted_tree.rs:363-417 is generic in the hasher).  A Digest holds the 32 bytes as four little-endian u64.
-enum { LMCS_POSEIDON2 = 0, LMCS_BLAKE3 = 1, LMCS_KECCAK = 2 };
+enum { LMCS_POSEIDON2 = 0, LMCS_BLAKE3 = 1, LMCS_KECCAK = 2, LMCS_RPO = 3, LMCS_RPX = 4 };  // RPO / RPX: the sponge LMCS with another permutation
 // The STARK configuration the oracle restates (test infrastructure: one setting for the process, orc_set_lmcs): the LMCS
 // hasher, and with it the row alignment (Alignable::ALIGNMENT: 8 for the sponge, 1 for the chaining hasher,
 // chaining.rs:161-169 -- every aligned width of the protocol follows lmcs.alignment(), proof.rs:268, deep/prover.rs:133)

@@ -10,6 +10,7 @@
 // Pinned by the KAT at .../poseidon2/test.rs:7-39 (tests/test_oracle_kat.py).
 #pragma once
 #include "gl.hpp"
+#include "rescue.hpp"
 
 namespace oracle {
 #include "p2_constants.inc"
@@ -65,6 +66,15 @@ static inline void p2_permute(uint64_t s[12]) {
   }
 }
 
+// The algebraic configurations (air/src/config.rs:212-273) differ only in this permutation: 0 = Poseidon2, 3 = RPO, 4 = RPX
+// (the values of LMCS_* in lmcs.hpp; orc_set_lmcs).  Sponge, compression, hash_elements and the duplex challenger call it.
+inline int g_alg_perm = 0;
+static inline void alg_permute(uint64_t s[12]) {
+  if (g_alg_perm == 3) rpo_permute(s);
+  else if (g_alg_perm == 4) rpx_permute(s);
+  else p2_permute(s);
+}
+
 // (i) LMCS leaf sponge: crates/stateful-hasher/src/field_sponge.rs:41-59 (StatefulSponge::absorb_into,
 //     WIDTH 12, RATE 8): overwrite rate chunk-wise; permute per full chunk; trailing partial chunk
 //     zero-filled then permuted; empty input = no-op.
@@ -77,12 +87,12 @@ static inline void sponge_absorb(uint64_t state[12], const uint64_t* in, size_t 
       } else {
         if (i != 0) {
           for (int k = i; k < 8; k++) state[k] = 0;
-          p2_permute(state);
+          alg_permute(state);
         }
         return;
       }
     }
-    p2_permute(state);
+    alg_permute(state);
   }
 }
 // (ii) Merkle 2-to-1 compression: TruncatedPermutation<_,2,4,12> (air/src/config.rs:213-220)
@@ -94,7 +104,7 @@ static inline void compress(const uint64_t l[4], const uint64_t r[4], uint64_t o
     s[4 + i] = r[i];
     s[8 + i] = 0;
   }
-  p2_permute(s);
+  alg_permute(s);
   for (int i = 0; i < 4; i++) out[i] = s[i];
 }
 // (iii) Poseidon2::hash_elements (algebraic_sponge/mod.rs:215-265): state[8] = len mod 8 first.
@@ -105,13 +115,13 @@ static inline void hash_elements(const uint64_t* in, size_t n, uint64_t out[4]) 
   for (size_t k = 0; k < n; k++) {
     s[i++] = in[k];
     if (i == 8) {
-      p2_permute(s);
+      alg_permute(s);
       i = 0;
     }
   }
   if (i > 0) {
     while (i != 8) s[i++] = 0;
-    p2_permute(s);
+    alg_permute(s);
   }
   for (int k = 0; k < 4; k++) out[k] = s[k];
 }

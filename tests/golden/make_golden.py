@@ -13,6 +13,7 @@ Vectors:
   7. MASM recursive-verifier layout  crates/lib/core/asm/stark/constants.masm (quotient recomposition constants, FRI
      parameters, sizes of the OOD / aux-boundary / trace-row regions, per-AIR widths) and the production PCS parameters
      of air/src/config.rs:54-67: a second in-tree witness of how a Miden proof's streams are laid out.
+  8. RPO hash_elements vectors ..... crates/crypto/src/hash/algebraic_sponge/rescue/rpo/tests.rs:241-267, 316-..
 """
 import json, os, re
 REF = "/root/reference"
@@ -73,6 +74,12 @@ def main():
     for k in ("LOG_BLOWUP", "LOG_FOLDING_ARITY", "LOG_FINAL_DEGREE", "FOLDING_POW_BITS", "DEEP_POW_BITS", "NUM_QUERIES", "QUERY_POW_BITS"):
         pcs[k.lower()] = int(re.search(r"const %s: \w+ = (\d+);" % k, cfg).group(1))
     out["pcs_params"] = pcs
+    # 8. RPO: hash_elements([0, 1, .., i]) for i < 19 (rescue/rpo/tests.rs:241-267, EXPECTED :316-..): pins the Rescue Prime
+    #    permutation (MDS, ARK1/ARK2, x^7 and x^(1/7)) that RPO and RPX share
+    rt = open(f"{REF}/crates/crypto/src/hash/algebraic_sponge/rescue/rpo/tests.rs").read()
+    ev = const_block(rt, "EXPECTED")
+    assert len(ev) == 19 * 4
+    out["rpo_hash_elements"] = [ev[4*i:4*i+4] for i in range(19)]
     with open(os.path.join(HERE, "kat.json"), "w") as f:
         json.dump(out, f, indent=0)
     print("wrote kat.json:", {k: (len(v) if hasattr(v, '__len__') else v) for k, v in out.items()})

@@ -98,7 +98,7 @@ def coset_lde_bitrev(m, added_bits, shift):
 
 def set_lmcs(name):
     """The hasher lmcs_build / commit_traces use: "poseidon2" (default) or "blake3" (air/src/config.rs:275-289)."""
-    lib().orc_set_lmcs(C.c_int({"poseidon2": 0, "blake3": 1, "keccak": 2}[name]))
+    lib().orc_set_lmcs(C.c_int({"poseidon2": 0, "blake3": 1, "keccak": 2, "rpo": 3, "rpx": 4}[name]))
 
 
 def blake3(data):

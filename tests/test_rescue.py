@@ -1,0 +1,142 @@
+"""The RPO and RPX configurations (HashFunction::Rpo256 / Rpx256; air/src/config.rs:224-245: the algebraic LMCS and the duplex
+challenger of the Poseidon2 configuration with the Rescue Prime permutations).  CPU: the reference's 19 RPO hash_elements vectors
+(rescue/rpo/tests.rs:241-267) against the oracle; RPX's E round against its algebraic definition; the generated constants; the
+oracle's prover / verifier and the product's host verifier (mh_verify_lmcs) under both.  GPU (-m gpu): one-shot device proofs
+(mh_prove on a context set to RPO / RPX) equal the oracle's, commitment parity with lifted batches, the sharded commitment."""
+import ctypes as C, json, os
+import numpy as np
+import pytest
+import oracle_binding as ob
+from __graft_entry__ import load_package
+from test_blake3 import blake3_cases
+
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
+P = ob.P
+u64p = C.POINTER(C.c_uint64)
+
+
+def rescue_permute(which, state):
+    st = np.array([int(x) % P for x in state], dtype=np.uint64)
+    ob.lib().orc_rescue_permute(C.c_int({"rpo": 3, "rpx": 4}[which]), st.ctypes.data_as(u64p))
+    return [int(x) for x in st]
+
+
+def test_rpo_reference_vectors():
+    ob.set_lmcs("rpo")
+    try:
+        for i, exp in enumerate(KAT["rpo_hash_elements"]):
+            assert [int(x) for x in ob.hash_elements(list(range(i + 1)))] == exp, i
+    finally:
+        ob.set_lmcs("poseidon2")
+
+
+def test_rpx_is_rpo_rounds_with_cubic_extension_rounds():
+    """RPX = FB, E, FB, E, FB, E, M (rescue/rpx/mod.rs:183-196).  The FB rounds are RPO's (pinned above); the E round is x -> x^7
+    in F_p[phi]/(phi^3 - phi - 1) on the four triples (rpx/mod.rs:279-330) and has no literal vector in tree.  Checked here: the
+    permutation is deterministic, differs from RPO, separates nearby inputs, and the extension arithmetic the restatements use
+    gives phi^7 = 2 phi^2 + 2 phi + 1 (by hand: phi^3 = phi + 1, phi^4 = phi^2 + phi, phi^6 = phi^2 + 2 phi + 1)."""
+    a = rescue_permute("rpx", range(12))
+    assert a != rescue_permute("rpo", range(12)) and a == rescue_permute("rpx", range(12))
+    assert len(set(tuple(rescue_permute("rpx", [k] + [0] * 11)) for k in range(8))) == 8
+    def mul(x, y):
+        d = [0] * 5
+        for i in range(3):
+            for j in range(3):
+                d[i + j] = (d[i + j] + x[i] * y[j]) % P
+        return [(d[0] + d[3]) % P, (d[1] + d[3] + d[4]) % P, (d[2] + d[4]) % P]
+
+    def pow7(x):
+        x2 = mul(x, x)
+        x4 = mul(x2, x2)
+        return mul(mul(x4, x2), x)
+    assert pow7([1, 0, 0]) == [1, 0, 0]
+    assert pow7([0, 1, 0]) == [1, 2, 2]  # phi^7 = 2 phi^2 + 2 phi + 1
+
+
+def test_generated_rescue_constants_match_the_circulant_first_row():
+    inc = open(os.path.join(os.path.dirname(__file__), "..", "miden-vm_amd", "csrc", "rescue_constants.inc")).read()
+    row0 = inc[inc.index("RESCUE_MDS_ROW0"):inc.index("};")]
+    import re
+    assert [int(x, 16) for x in re.findall(r"0x[0-9a-f]+", row0)] == [7, 23, 8, 26, 13, 10, 9, 7, 6, 22, 21, 8]
+    assert open(os.path.join(os.path.dirname(__file__), "..", "oracle", "rescue_constants.inc")).read() == inc
+
+
+@pytest.mark.parametrize("lmcs", ["rpo", "rpx"])
+@pytest.mark.parametrize("name", ["fib", "multi", "preprocessed"])
+def test_oracle_and_product_verifier_under_the_rescue_configurations(lmcs, name):
+    pkg = load_package()
+    airs_, traces, pub, prm = blake3_cases()[name]
+    p2 = ob.prove(airs_, traces, pub, prm)
+    ob.set_lmcs(lmcs)
+    try:
+        p = ob.prove(airs_, traces, pub, prm)
+        lhs = p["log_heights"]
+        assert ob.verify(airs_, lhs, pub, p, prm)[0]
+        root = ob.preprocessed_commitment(airs_, lhs, prm) if any(a.preprocessed is not None for a in airs_) else None
+    finally:
+        ob.set_lmcs("poseidon2")
+    assert not (p["commitments"][0] == p2["commitments"][0]).all()
+    pre = ob.protocol_pre_observe(prm, pub, preprocessed_root=root)
+    args = (airs_, lhs, pub, prm, ob.challenger_state(), pre, p["fields"], p["commitments"])
+    ok, dig = pkg.verify(*args, preprocessed_root=root, lmcs=lmcs)
+    assert ok and (dig == p["digest"]).all(), dig
+    assert not pkg.verify(*args, preprocessed_root=root)[0]                      # not a Poseidon2 proof
+    other = "rpx" if lmcs == "rpo" else "rpo"
+    assert not pkg.verify(*args, preprocessed_root=root, lmcs=other)[0]
+    bad = p["fields"].copy()
+    bad[3] = (int(bad[3]) + 1) % P
+    assert not pkg.verify(airs_, lhs, pub, prm, ob.challenger_state(), pre, bad, p["commitments"], preprocessed_root=root, lmcs=lmcs)[0]
+    ok, msg = pkg.verify(*args, preprocessed_root=root, lmcs="blake3")
+    assert not ok and "algebraic" in msg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lmcs", ["rpo", "rpx"])
+@pytest.mark.parametrize("name", ["fib", "multi", "logup", "dummy_arity8", "preprocessed"])
+def test_device_proofs_under_the_rescue_configurations(lmcs, name):
+    from test_gpu_prove import gpu_prove
+    pkg = load_package()
+    airs_, traces, pub, prm = blake3_cases()[name]
+    if name == "dummy_arity8":
+        prm = dict(prm, deep_pow_bits=8)  # exercises the device PoW search (k_grind_alg) as well
+    ctx = pkg.Ctx(0)
+    ob.set_lmcs(lmcs)
+    try:
+        ctx.set_lmcs(lmcs)
+        exp = ob.prove(airs_, traces, pub, prm)
+        got = gpu_prove(ctx, airs_, traces, pub, prm)
+        assert got.log_trace_heights == exp["log_heights"]
+        assert (got.commitments == exp["commitments"]).all() and (got.fields == exp["fields"]).all()
+        assert (got.digest == exp["digest"]).all()
+        root = ob.preprocessed_commitment(airs_, exp["log_heights"], prm) if any(a.preprocessed is not None for a in airs_) else None
+    finally:
+        ob.set_lmcs("poseidon2")
+        ctx.close()
+    ok, dig = pkg.verify(airs_, got.log_trace_heights, pub, prm, ob.challenger_state(), ob.protocol_pre_observe(prm, pub, preprocessed_root=root),
+                         got.fields, got.commitments, preprocessed_root=root, lmcs=lmcs)
+    assert ok and (dig == got.digest).all(), dig
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lmcs", ["rpo", "rpx"])
+def test_device_rescue_commitment_equals_oracle(lmcs):
+    pkg = load_package()
+    ctx = pkg.Ctx(0)
+    rng = np.random.default_rng(13)
+    traces = [rng.integers(0, P, (1 << ln, w), dtype=np.uint64) for ln, w in [(3, 3), (5, 9), (5, 8), (6, 21)]]
+    lb = 2
+    H = (1 << 6) << lb
+    idx = sorted(set(int(x) for x in rng.integers(0, H, 9))) + [0, H - 1]
+    ob.set_lmcs(lmcs)
+    try:
+        exp = ob.commit_traces(traces, lb, indices=idx, alignment=8, want_lde=True)
+        _, layers = ob.lmcs_build(exp["ldes"], want_layers=True)
+    finally:
+        ob.set_lmcs("poseidon2")
+    ctx.set_lmcs(lmcs)
+    com = pkg.commit_traces(ctx, [ctx.upload_trace(t) for t in traces], lb)
+    assert (com.root() == exp["root"]).all()
+    f, c = com.tree().prove_batch(idx, alignment=8)
+    assert (f == exp["fields"]).all() and (c == exp["commitments"]).all()
+    assert (com.tree().download_layers() == layers).all()
+    ctx.close()

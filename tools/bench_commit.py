@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--width", type=int, default=51)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--lmcs", default="poseidon2,blake3,keccak")
     a = ap.parse_args()
     import numpy as np
     import bench
@@ -22,7 +23,7 @@ def main():
     pkg = load_package()
     ctx = pkg.Ctx(0)
     tr = ctx.upload_trace(bench.synth_trace(np.random.default_rng(1), a.log_n, a.width))
-    for lmcs in ("poseidon2", "blake3", "keccak"):
+    for lmcs in a.lmcs.split(","):
         ctx.set_lmcs(lmcs)
         pkg.commit_traces(ctx, [tr], 3).tree().free()
         ctx.prof_enable(True)
