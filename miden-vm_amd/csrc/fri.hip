@@ -16,8 +16,9 @@
 #include "kernels.hpp"
 #include "blake3.cuh"
 #include "keccak.cuh"
-#include "rescue.cuh"
 #include "poseidon2_fast.cuh"
+#define RESCUE_FAST 1  // S-boxes through p2f_mulN (poseidon2_fast.cuh is included above)
+#include "rescue.cuh"
 
 __device__ __forceinline__ e2 ld_e2(const u64* p, size_t idx) {
   const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(p + 2 * idx);

@@ -23,6 +23,7 @@
 #include "poseidon2_lanes.cuh"
 #include "blake3.cuh"
 #include "keccak.cuh"
+#define RESCUE_FAST 1  // S-boxes through p2f_mulN (poseidon2_fast.cuh is included above)
 #include "rescue.cuh"
 #include "gl.cuh"
 #include <algorithm>

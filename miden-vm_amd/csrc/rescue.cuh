@@ -112,9 +112,101 @@ GL_HD void rpx_permute(u64 s[12]) {
 
 }  // namespace rescue
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RESCUE_FAST)
+// Device fast path (the hash kernels of lmcs.hip / fri.hip define RESCUE_FAST after including poseidon2_fast.cuh): the S-boxes of
+// four state elements at a time through the 13-instruction product with SGPR carry chains (p2f_mulN<4>: stage-interleaved, no
+// wait-state padding).  Values between the layers are any 64-bit representative; the MDS layer works on 32-bit halves of
+// whatever it is given, constants are added with p2f_add_canon, the state is canonicalised once at the end.
+namespace rescue {
+__device__ __forceinline__ void mul4(u64 (&r)[4], const u64 (&a)[4], const u64 (&b)[4]) { p2f_mulN<4>(r, a, b); }
+__device__ __forceinline__ void sqr4_n(u64 (&x)[4], int n) {
+#pragma unroll 1
+  for (int i = 0; i < n; i++) mul4(x, x, x);
+}
+__device__ __forceinline__ void pow7_x4(u64 (&x)[4]) {
+  u64 x2[4], x4[4], x6[4];
+  mul4(x2, x, x);
+  mul4(x4, x2, x2);
+  mul4(x6, x4, x2);
+  mul4(x, x6, x);
+}
+__device__ __forceinline__ void inv_pow7_x4(u64 (&x)[4]) {  // the chain of inv_pow7 above on four elements
+  u64 t1[4], t2[4], t3[4], t4[4], t5[4], t6[4], t7[4], a[4], b[4];
+  mul4(t1, x, x);
+  mul4(t2, t1, t1);
+#pragma unroll
+  for (int i = 0; i < 4; i++) t3[i] = t2[i];
+  sqr4_n(t3, 3); mul4(t3, t3, t2);
+#pragma unroll
+  for (int i = 0; i < 4; i++) t4[i] = t3[i];
+  sqr4_n(t4, 6); mul4(t4, t4, t3);
+#pragma unroll
+  for (int i = 0; i < 4; i++) t5[i] = t4[i];
+  sqr4_n(t5, 12); mul4(t5, t5, t4);
+#pragma unroll
+  for (int i = 0; i < 4; i++) t6[i] = t5[i];
+  sqr4_n(t6, 6); mul4(t6, t6, t3);
+#pragma unroll
+  for (int i = 0; i < 4; i++) t7[i] = t6[i];
+  sqr4_n(t7, 31); mul4(t7, t7, t6);
+  mul4(a, t7, t7); mul4(a, a, t6); sqr4_n(a, 2);
+  mul4(b, t1, t2); mul4(b, b, x);
+  mul4(x, a, b);
+}
+__device__ __forceinline__ void fb_round_fast(u64 s[12], int r) {
+  mds(s);  // canonical out
+#pragma unroll
+  for (int g = 0; g < 12; g += 4) {
+    u64 x[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = gl_add(s[g + i], RESCUE_ARK1[12 * r + g + i]);
+    pow7_x4(x);
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[g + i] = x[i];
+  }
+  mds(s);
+#pragma unroll 1
+  for (int g = 0; g < 12; g += 4) {
+    u64 x[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = gl_add(s[g + i], RESCUE_ARK2[12 * r + g + i]);
+    inv_pow7_x4(x);
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[g + i] = x[i];
+  }
+}
+__device__ __forceinline__ void canon12(u64 s[12]) {
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
+}
+__device__ __forceinline__ void rpo_permute_fast(u64 s[12]) {
+#pragma unroll 1
+  for (int r = 0; r < 7; r++) fb_round_fast(s, r);
+  canon12(s);
+}
+__device__ __forceinline__ void rpx_permute_fast(u64 s[12]) {
+#pragma unroll 1
+  for (int r = 0; r < 6; r += 2) {
+    fb_round_fast(s, r);
+    canon12(s);  // the E round runs on canonical values (plain extension arithmetic)
+    ext_round(s, r + 1);
+  }
+  mds(s);
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], RESCUE_ARK1[72 + i]);
+}
+}  // namespace rescue
+#endif
+
 // The permutation of an algebraic configuration by its MH_LMCS_* id (0 Poseidon2, 3 RPO, 4 RPX)
 GL_HD void alg_permute(int lmcs, u64 s[12]) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RESCUE_FAST)
+  if (lmcs == 3) rescue::rpo_permute_fast(s);
+  else if (lmcs == 4) rescue::rpx_permute_fast(s);
+  else p2_permute(s);
+#else
   if (lmcs == 3) rescue::rpo_permute(s);
   else if (lmcs == 4) rescue::rpx_permute(s);
   else p2_permute(s);
+#endif
 }
