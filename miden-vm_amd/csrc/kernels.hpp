@@ -48,6 +48,7 @@ struct mh_tree {
   mh_ctx* ctx;
   int log_blowup;  // number of coset bits in the leaf layer layout (may be 0)
   int log_height;  // tree depth L (leaves = 2^L)
+  int lmcs = 0;    // MH_LMCS_* hasher the layers were built with (the context's, at build time)
   std::vector<LdeMatrix> mats;
   // FRI round trees (fri.hip) commit one EF layer instead of LDE matrices: rows are rebuilt from it
   DevBuf fri_layer;      // EF pairs, coset-major [2^fri_log_cosets][2^fri_log_rows] (this rank's cosets)

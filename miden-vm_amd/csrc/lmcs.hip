@@ -400,6 +400,7 @@ void lmcs_alloc_layers(mh_tree* t, int log_height) {
 u64* lmcs_leaf_layer(mh_tree* t) { return t->nodes.u() + 4 * t->layer_off[t->log_height]; }
 
 void lmcs_compress_layers(mh_ctx* c, mh_tree* t) {
+  t->lmcs = c->lmcs;
   const int lb = t->log_blowup;
   const size_t H = (size_t)1 << t->log_height;
   {

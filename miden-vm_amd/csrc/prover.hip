@@ -185,6 +185,7 @@ struct mh_session {
   void begin(mh_ctx* ctx, const mh_pcs_params& params, int n, mh_air* const* airs_in, mh_trace* const* traces_in,
              const u64* publics_in, size_t n_publics, const Dist& d) {
     c = ctx; pp = params; dist = d; n_airs = n;
+    lmcs0 = c->lmcs;
     MH_REQUIRE(n_airs > 0 && n_airs <= 256, "need between 1 and 256 AIR instances");
     lb = pp.log_blowup;
     MH_REQUIRE(lb > 0 && lb <= 8, "log_blowup must be in 1..8");
@@ -251,6 +252,7 @@ struct mh_session {
       MH_REQUIRE(prep_tree->shard_logG == dist.logG && (!dist.on() || prep_tree->shard_rank == dist.rank),
                  "preprocessed tree was committed for a different sharding (use mh_commit_traces_sharded with the same communicator)");
       MH_REQUIRE((int)prep_tree->mats.size() == n_prep, "preprocessed tree holds matrices no AIR declares");
+      MH_REQUIRE(prep_tree->lmcs == c->lmcs, "the preprocessed (setup) tree was committed with another LMCS hasher than this context's");
     }
     rounds = fri_num_rounds(pp, L);
     stage = 1;
@@ -274,7 +276,11 @@ struct mh_session {
     return k;
   }
   size_t final_poly_len() const { return (size_t)1 << std::max(0, L - rounds * pp.log_folding_arity - lb); }
-  void expect(int s, const char* what) { MH_REQUIRE(stage == s, std::string("session call out of protocol order: ") + what); }
+  int lmcs0 = 0;  // the context's LMCS hasher when the session began: one configuration per proof
+  void expect(int s, const char* what) {
+    MH_REQUIRE(stage == s, std::string("session call out of protocol order: ") + what);
+    MH_REQUIRE(c->lmcs == lmcs0, "the context's LMCS hasher changed during the session");
+  }
 
   // ---- 1. main commitment ----
   void commit_main(u64 root[4]) {

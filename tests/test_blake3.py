@@ -169,3 +169,28 @@ def test_device_blake3_configuration_through_the_staged_session(name):
     finally:
         ob.set_lmcs("poseidon2")
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_one_configuration_per_session():
+    """A session is one proof under one StarkConfig: switching the context's hasher in the middle, or attaching a setup tree
+    committed under another hasher, is refused with a message."""
+    import airs as A
+    from test_gpu_prove import attach_preprocessed
+    pkg = load_package()
+    ctx = pkg.Ctx(0)
+    t, pub = A.fib_trace(5)
+    s = pkg.Session(ctx, [pkg.DeviceAir(ctx, A.fib_air())], [ctx.upload_trace(t)], pub, FAST)
+    s.commit_main()
+    ctx.set_lmcs("blake3")
+    with pytest.raises(pkg.MidenHipError, match="changed during the session"):
+        s.commit_aux([(1, 2), (3, 4)], None)
+    ctx.set_lmcs("poseidon2")
+    s.free()
+    a5, tr5 = A.prep_air(5)
+    d = pkg.DeviceAir(ctx, a5)
+    attach_preprocessed(ctx, [a5], [d], [tr5()], FAST)  # committed under Poseidon2
+    ctx.set_lmcs("keccak")
+    with pytest.raises(pkg.MidenHipError, match="another LMCS hasher"):
+        pkg.Session(ctx, [d], [ctx.upload_trace(tr5())], [], FAST)
+    ctx.close()
