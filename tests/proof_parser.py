@@ -75,8 +75,12 @@ class Streams:
         return w
 
 
-def parse(airs, log_heights, publics, params, fields, commitments, preprocessed_root=None, init_state=None, aux_inputs=()):
-    """-> dict with the named pieces of StarkProof + PcsProof, `digest`, and `sizes` (felts / commitments per section)."""
+def parse(airs, log_heights, publics, params, fields, commitments, preprocessed_root=None, init_state=None, aux_inputs=(), alignment=8):
+    """-> dict with the named pieces of StarkProof + PcsProof, `digest`, and `sizes` (felts / commitments per section).
+    alignment = lmcs.alignment() of the configuration (proof.rs:268): 8 (Poseidon2 / RPO / RPX), 1 (Blake3), 17 (Keccak); the
+    challenger is the oracle's for the configuration set with ob.set_lmcs."""
+    def align(w, a=alignment):
+        return (w + a - 1) // a * a
     n = len(airs)
     order = sorted(range(n), key=lambda i: (log_heights[i], i))            # order.rs: stable by (height, instance)
     lb, la = params["log_blowup"], params["log_folding_arity"]

@@ -134,3 +134,26 @@ def test_proof_bytes_round_trip_and_malformed_inputs():
     for b in bad:
         with pytest.raises(pkg.MidenHipError):
             pkg.proof_from_bytes(b)
+
+
+@pytest.mark.parametrize("lmcs,alignment", [("blake3", 1), ("keccak", 17), ("rpo", 8), ("rpx", 8)])
+def test_parser_consumes_the_other_configurations(lmcs, alignment):
+    """The same parser over proofs of the other four StarkConfigs: only lmcs.alignment() (proof.rs:268) and the challenger
+    change; every felt and commitment is consumed and the digest reproduced."""
+    import airs as A
+    t7, pub7 = A.fib_trace(7)
+    a5, tr5 = A.prep_air(5, num_public=3)
+    prm = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=5, query_pow_bits=3)
+    airs_, traces = [A.periodic_air(3), A.fib_air(), a5], [A.periodic_trace(5), t7, tr5()]
+    ob.set_lmcs(lmcs)
+    try:
+        proof = ob.prove(airs_, traces, pub7, prm)
+        root = ob.preprocessed_commitment(airs_, proof["log_heights"], prm)
+        parsed = pp.parse(airs_, proof["log_heights"], pub7, prm, proof["fields"], proof["commitments"], preprocessed_root=root,
+                          alignment=alignment)
+        assert parsed["digest"] == [int(x) for x in proof["digest"]]
+        with pytest.raises(AssertionError):  # the wrong alignment cannot consume the streams exactly
+            pp.parse(airs_, proof["log_heights"], pub7, prm, proof["fields"], proof["commitments"], preprocessed_root=root,
+                     alignment=8 if alignment != 8 else 1)
+    finally:
+        ob.set_lmcs("poseidon2")
