@@ -7,17 +7,67 @@
 // replays the smallest hit, so the transcript is a pure function of the inputs.
 #pragma once
 #include "rescue.cuh"
+#include "blake3.cuh"
+#include "keccak.cuh"
 #include <array>
+#include <cstring>
 #include <vector>
 
 typedef std::array<u64, 4> Digest4;
 
+// Byte configurations (hash = MH_LMCS_BLAKE3 = 1 / MH_LMCS_KECCAK = 2; air/src/config.rs:291-303, 334-353):
+// SerializingChallenger64<Felt, HashChallenger<u8, Blake3Hasher | Keccak256Hash, 32>> -- p3-challenger 0.6.2, external, no in-tree
+// mirror (parity unpinned), restated from the published crate:
+//   observe(felt)  = clear the output buffer, append the felt's canonical u64 as 8 little-endian bytes to the input buffer
+//                    (a 32-byte digest is observed byte by byte = its four little-endian u64s);
+//   flush          = output := hash(input); input := output (the chaining value);   sample byte = output.pop() (from the END),
+//                    flushing first when the output buffer is empty;
+//   sample felt    = u64 from 8 sampled bytes (first sampled = lowest byte), redrawn while >= p;   sample_bits = the low bits of
+//                    such a u64 (no redraw);   check_witness = observe(witness), sample_bits(bits) == 0.
+// The configuration observes RELATION_DIGEST before anything else (config.rs:301-302): init_from_state() observes the capacity
+// words st[8..12] of the state the caller hands over (where the sponge configurations keep that digest).
 struct HostChallenger {
-  int hash = 0;  // MH_LMCS_* id of the algebraic configuration: which permutation the sponge uses (0 Poseidon2, 3 RPO, 4 RPX)
+  int hash = 0;  // MH_LMCS_* id of the configuration: 0 Poseidon2, 3 RPO, 4 RPX (duplex sponge); 1 Blake3, 2 Keccak (byte hash)
   u64 st[12];
   std::vector<u64> in, out;
+  std::vector<uint8_t> bin, bout;
   HostChallenger() {
     for (auto& x : st) x = 0;
+  }
+  bool bytes() const { return hash == 1 || hash == 2; }
+  void init_from_state(const u64 state[12]) {
+    for (int i = 0; i < 12; i++) st[i] = gl_canon(state[i]);
+    if (bytes())
+      for (int i = 8; i < 12; i++) observe(st[i]);
+  }
+  void hash_bytes(const uint8_t* p, size_t n, uint8_t d[32]) const {
+    if (hash == 2) kk::hash256(p, n, 0x01, d);
+    else b3::hash_bytes(p, n, d);
+  }
+  void flush_bytes() {
+    uint8_t d[32];
+    hash_bytes(bin.data(), bin.size(), d);
+    bout.assign(d, d + 32);
+    bin.assign(d, d + 32);
+  }
+  u64 sample_u64_bytes() {
+    u64 v = 0;
+    for (int i = 0; i < 8; i++) {
+      if (bout.empty()) flush_bytes();
+      v |= (u64)bout.back() << (8 * i);
+      bout.pop_back();
+    }
+    return v;
+  }
+  // the transcript digest (CanFinalizeDigest): one unconditional state transition, then 4 felts / 32 bytes
+  void finalize(u64 digest[4]) {
+    if (bytes()) {
+      flush_bytes();
+      memcpy(digest, bout.data(), 32);
+      return;
+    }
+    duplexing();
+    for (int i = 0; i < 4; i++) digest[i] = st[i];
   }
   void duplexing() {
     size_t k = in.size();
@@ -31,14 +81,32 @@ struct HostChallenger {
     out.assign(st, st + 8);
   }
   void observe(u64 x) {
+    if (bytes()) {
+      bout.clear();
+      const u64 v = gl_canon(x);
+      for (int i = 0; i < 8; i++) bin.push_back((uint8_t)(v >> (8 * i)));
+      return;
+    }
     out.clear();
     in.push_back(gl_canon(x));
     if (in.size() == 8) duplexing();
   }
   void observe_digest(const u64 d[4]) {
+    if (bytes()) {  // 32 raw bytes: the words of a byte digest are not field elements
+      bout.clear();
+      for (int i = 0; i < 4; i++)
+        for (int k = 0; k < 8; k++) bin.push_back((uint8_t)(d[i] >> (8 * k)));
+      return;
+    }
     for (int i = 0; i < 4; i++) observe(d[i]);
   }
   u64 sample() {
+    if (bytes()) {
+      for (;;) {
+        const u64 v = sample_u64_bytes();
+        if (v < GL_P) return v;
+      }
+    }
     if (!in.empty() || out.empty()) duplexing();
     u64 x = out.back();
     out.pop_back();
@@ -49,7 +117,10 @@ struct HostChallenger {
     u64 c1 = sample();
     return e2{c0, c1};
   }
-  size_t sample_bits(int bits) { return (size_t)((sample() & 0xFFFFFFFFULL) & (((u64)1 << bits) - 1)); }
+  size_t sample_bits(int bits) {
+    if (bytes()) return (size_t)(sample_u64_bytes() & (((u64)1 << bits) - 1));
+    return (size_t)((sample() & 0xFFFFFFFFULL) & (((u64)1 << bits) - 1));
+  }
   bool check_witness(int bits, u64 w) {
     if (bits == 0) return w == 0;
     observe(w);

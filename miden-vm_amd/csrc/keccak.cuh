@@ -65,4 +65,56 @@ KK_HD void compress_pair(const uint64_t l[4], const uint64_t r[4], uint64_t out[
   for (int i = 0; i < 4; i++) out[i] = a[i];
 }
 
+// Keccak sponge hash, rate 136 bytes, 32-byte digest; pad = 0x01 (Keccak-256: the challenger's Keccak256Hash) or 0x06 (SHA3-256).
+// XOR-absorbing, FIPS 202 section 4 (unlike the overwrite-mode LMCS sponge above).  Host side (challenger, verifier).
+struct Sponge256 {
+  uint64_t st[25];
+  uint8_t buf[136];
+  uint32_t fill;
+  KK_HD void init() {
+    for (int i = 0; i < 25; i++) st[i] = 0;
+    fill = 0;
+  }
+  KK_HD void absorb_block(const uint8_t* b) {
+    for (int i = 0; i < 17; i++) {
+      uint64_t w = 0;
+      for (int k = 0; k < 8; k++) w |= (uint64_t)b[8 * i + k] << (8 * k);
+      st[i] ^= w;
+    }
+    f1600(st);
+  }
+  KK_HD void update(const uint8_t* p, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+      buf[fill++] = p[i];
+      if (fill == 136) {
+        absorb_block(buf);
+        fill = 0;
+      }
+    }
+  }
+  KK_HD void finish(uint8_t pad, uint8_t out32[32]) {
+    for (uint32_t i = fill; i < 136; i++) buf[i] = 0;
+    buf[fill] ^= pad;
+    buf[135] ^= 0x80;
+    absorb_block(buf);
+    for (int i = 0; i < 4; i++)
+      for (int k = 0; k < 8; k++) out32[8 * i + k] = (uint8_t)(st[i] >> (8 * k));
+  }
+};
+KK_HD void hash256(const uint8_t* p, size_t n, uint8_t pad, uint8_t out32[32]) {
+  Sponge256 s;
+  s.init();
+  s.update(p, n);
+  s.finish(pad, out32);
+}
+// the overwrite-mode sponge of the Keccak LMCS over whole rows (field_sponge.rs:41-64 with WIDTH 25, RATE 17)
+KK_HD void lmcs_absorb(uint64_t st[25], const uint64_t* v, size_t n) {
+  for (size_t off = 0; off < n; off += 17) {
+    const size_t k = n - off < 17 ? n - off : 17;
+    for (size_t i = 0; i < k; i++) st[i] = v[off + i];
+    for (size_t i = k; i < 17; i++) st[i] = 0;
+    f1600(st);
+  }
+}
+
 }  // namespace kk

@@ -634,7 +634,7 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
   s.begin(c, pp, n_airs, airs_in, traces_in, publics_in, n_publics, dist);
   HostTranscript tr;
   tr.ch.hash = c->lmcs;
-  for (int i = 0; i < 12; i++) tr.ch.st[i] = gl_canon(init_state[i]);
+  tr.ch.init_from_state(init_state);
   for (size_t i = 0; i < n_pre; i++) tr.ch.observe(pre_observe[i]);
   tr.ch.observe((u64)n_airs);  // order.rs:154-163
   for (int i = 0; i < n_airs; i++) tr.ch.observe((u64)s.lhs[i]);
@@ -681,8 +681,7 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
   tr.hint_commitments(cm);
   // finalize (CanFinalizeDigest, external; "unconditionally applies a final state transition before extracting the
   // digest", crates/stark-transcript/src/prover.rs:31-35): one more duplexing whatever is buffered, then 4 felts
-  tr.ch.duplexing();
-  for (int i = 0; i < 4; i++) proof.digest[i] = tr.ch.st[i];
+  tr.ch.finalize(proof.digest);
   for (int i = 0; i < n_airs; i++) proof.log_trace_heights.push_back((uint8_t)s.lhs[i]);
   proof.fields = std::move(tr.fields);
   for (auto& d : tr.commitments) proof.commitments.insert(proof.commitments.end(), d.begin(), d.end());

@@ -40,7 +40,7 @@ struct Reader {
     Digest4 d;
     for (int i = 0; i < 4; i++) {
       d[i] = c[4 * pc + i];
-      if (d[i] >= GL_P) throw Reject("non-canonical digest element");
+      if (!ch.bytes() && d[i] >= GL_P) throw Reject("non-canonical digest element");  // a byte digest's words are not felts
     }
     pc++;
     return d;
@@ -65,9 +65,14 @@ struct Reader {
   }
 };
 
-size_t align8(size_t w) { return (w + 7) / 8 * 8; }
-// the algebraic configuration being verified (MH_LMCS_POSEIDON2 / _RPO / _RPX): set per call, per thread
+// the configuration being verified (MH_LMCS_*): set per call, per thread
 thread_local int t_hash = 0;
+// aligned_len(w, lmcs.alignment()) (util/align.rs:7-13, proof.rs:268): the sponge's rate -- 8, or 17 for Keccak -- and 1 for the
+// chaining hasher of the Blake3 LMCS.  (The name dates from the Poseidon2 configuration.)
+size_t align8(size_t w) {
+  const size_t a = t_hash == MH_LMCS_BLAKE3 ? 1 : (t_hash == MH_LMCS_KECCAK ? 17 : 8);
+  return (w + a - 1) / a * a;
+}
 
 // Overwrite-mode sponge over whole (already aligned / short) rows: crates/stateful-hasher/src/field_sponge.rs:41-59.
 void absorb(u64 st[12], const u64* v, size_t n) {
@@ -79,8 +84,53 @@ void absorb(u64 st[12], const u64* v, size_t n) {
   }
 }
 Digest4 compress2(const Digest4& l, const Digest4& r) {
+  if (t_hash == MH_LMCS_BLAKE3) {  // blake3(left || right)
+    uint8_t msg[64], d[32];
+    memcpy(msg, l.data(), 32);
+    memcpy(msg + 32, r.data(), 32);
+    b3::hash_bytes(msg, 64, d);
+    Digest4 o;
+    memcpy(o.data(), d, 32);
+    return o;
+  }
+  if (t_hash == MH_LMCS_KECCAK) {
+    Digest4 o;
+    kk::compress_pair(l.data(), r.data(), o.data());
+    return o;
+  }
   u64 st[12] = {l[0], l[1], l[2], l[3], r[0], r[1], r[2], r[3], 0, 0, 0, 0};
   alg_permute(t_hash, st);
+  return Digest4{st[0], st[1], st[2], st[3]};
+}
+// leaf digest of one opened index: the rows of the tree's matrices, each already of its aligned width
+Digest4 leaf_digest(const u64* row, const std::vector<size_t>& widths) {
+  size_t off = 0;
+  if (t_hash == MH_LMCS_BLAKE3) {  // chaining hasher: state := blake3(state || row bytes), zero state first (chaining.rs:32-50)
+    Digest4 st{0, 0, 0, 0};
+    for (size_t w : widths) {
+      std::vector<uint8_t> msg(32 + 8 * w);
+      memcpy(msg.data(), st.data(), 32);
+      if (w) memcpy(msg.data() + 32, row + off, 8 * w);
+      uint8_t d[32];
+      b3::hash_bytes(msg.data(), msg.size(), d);
+      memcpy(st.data(), d, 32);
+      off += w;
+    }
+    return st;
+  }
+  if (t_hash == MH_LMCS_KECCAK) {
+    u64 st[25] = {0};
+    for (size_t w : widths) {
+      kk::lmcs_absorb(st, row + off, w);
+      off += w;
+    }
+    return Digest4{st[0], st[1], st[2], st[3]};
+  }
+  u64 st[12] = {0};
+  for (size_t w : widths) {
+    absorb(st, row + off, w);
+    off += w;
+  }
   return Digest4{st[0], st[1], st[2], st[3]};
 }
 
@@ -94,13 +144,7 @@ std::vector<std::vector<u64>> open_batch(Reader& rd, const Digest4& root, const 
   std::vector<std::pair<size_t, Digest4>> level;
   for (size_t q = 0; q < idx.size(); q++) {
     for (auto& x : rows[q]) x = rd.hint_field();
-    u64 st[12] = {0};
-    size_t off = 0;
-    for (size_t w : widths) {
-      absorb(st, rows[q].data() + off, w);
-      off += w;
-    }
-    level.push_back({idx[q], Digest4{st[0], st[1], st[2], st[3]}});
+    level.push_back({idx[q], leaf_digest(rows[q].data(), widths)});
   }
   for (int d = depth; d > 0; d--) {
     std::vector<std::pair<size_t, Digest4>> up;
@@ -472,8 +516,7 @@ void verify_impl(const mh_pcs_params& pp, const std::vector<DagIR>& airs, const 
     if (!e2_eq(accumulated, e2_mul(qz, van))) throw Reject("constraints do not vanish on the trace domain (quotient identity)");
   }
   if (rd.pf != rd.nf || rd.pc != rd.nc) throw Reject("trailing data in the transcript");
-  rd.ch.duplexing();  // CanFinalizeDigest: "unconditionally applies a final state transition" (stark-transcript/src/prover.rs:31-35)
-  for (int i = 0; i < 4; i++) digest[i] = rd.ch.st[i];
+  rd.ch.finalize(digest);  // CanFinalizeDigest: "unconditionally applies a final state transition" (stark-transcript/src/prover.rs:31-35)
 }
 
 }  // namespace
@@ -502,12 +545,11 @@ static int verify_entry(int lmcs, const mh_pcs_params* params, int n_airs, const
       airs.push_back(dag_parse(air_blobs[i], air_blob_words[i]));
       lhs.push_back(log_trace_heights[i]);
     }
-    MH_REQUIRE(lmcs == MH_LMCS_POSEIDON2 || lmcs == MH_LMCS_RPO || lmcs == MH_LMCS_RPX,
-               "mh_verify covers the algebraic configurations (Poseidon2, RPO, RPX): duplex-sponge transcript, sponge LMCS");
+    MH_REQUIRE(lmcs >= MH_LMCS_POSEIDON2 && lmcs <= MH_LMCS_RPX, "unknown LMCS hasher id");
     t_hash = lmcs;
     Reader rd;
     rd.ch.hash = lmcs;
-    for (int i = 0; i < 12; i++) rd.ch.st[i] = gl_canon(challenger_state[i]);
+    rd.ch.init_from_state(challenger_state);
     for (size_t i = 0; i < n_pre_observe; i++) rd.ch.observe(pre_observe[i]);
     rd.f = fields; rd.nf = n_fields;
     rd.c = commitments; rd.nc = n_commitments;

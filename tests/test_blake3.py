@@ -146,6 +146,43 @@ def test_oracle_blake3_configuration_proves_and_verifies(name):
     assert not ob.verify(airs_, p["log_heights"], pub, p, prm)[0]
 
 
+@pytest.mark.parametrize("lmcs", ["blake3", "keccak"])
+@pytest.mark.parametrize("name", ["fib", "multi", "logup", "dummy_arity8", "preprocessed"])
+def test_product_verifier_under_the_byte_hash_configurations(lmcs, name):
+    """mh_verify_lmcs with the product's own restatement of the byte challenger (csrc/challenger.hpp), of the chaining-hasher /
+    Keccak-sponge leaves and of the alignment rule: accepts the oracle prover's proofs, reproduces the digest, rejects tampering
+    and proofs of other configurations."""
+    pkg = load_package()
+    airs_, traces, pub, prm = blake3_cases()[name]
+    ob.set_lmcs(lmcs)
+    try:
+        p = ob.prove(airs_, traces, pub, prm)
+        lhs = p["log_heights"]
+        root = ob.preprocessed_commitment(airs_, lhs, prm) if any(a.preprocessed is not None for a in airs_) else None
+    finally:
+        ob.set_lmcs("poseidon2")
+    pre = ob.protocol_pre_observe(prm, pub, preprocessed_root=root)
+    args = (airs_, lhs, pub, prm, ob.challenger_state(), pre, p["fields"], p["commitments"])
+    ok, dig = pkg.verify(*args, preprocessed_root=root, lmcs=lmcs)
+    assert ok and (dig == p["digest"]).all(), dig
+    for other in ("poseidon2", "rpo", "keccak" if lmcs == "blake3" else "blake3"):
+        assert not pkg.verify(*args, preprocessed_root=root, lmcs=other)[0]
+    rng = np.random.default_rng(1)
+    for pos in list(rng.integers(0, p["fields"].size, 12)) + [0, p["fields"].size - 1]:
+        bad = p["fields"].copy()
+        bad[pos] = (int(bad[pos]) + 1) % P
+        ok_p = pkg.verify(airs_, lhs, pub, prm, ob.challenger_state(), pre, bad, p["commitments"], preprocessed_root=root, lmcs=lmcs)[0]
+        ob.set_lmcs(lmcs)
+        try:
+            ok_o = ob.verify(airs_, lhs, pub, {"fields": bad, "commitments": p["commitments"]}, prm)[0]
+        finally:
+            ob.set_lmcs("poseidon2")
+        assert ok_p == ok_o
+    badc = p["commitments"].copy()
+    badc[1, 2] ^= np.uint64(1)
+    assert not pkg.verify(airs_, lhs, pub, prm, ob.challenger_state(), pre, p["fields"], badc, preprocessed_root=root, lmcs=lmcs)[0]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["fib", "multi", "logup", "dummy_arity8", "preprocessed"])
 def test_device_blake3_configuration_through_the_staged_session(name):

@@ -86,8 +86,7 @@ def test_oracle_and_product_verifier_under_the_rescue_configurations(lmcs, name)
     bad = p["fields"].copy()
     bad[3] = (int(bad[3]) + 1) % P
     assert not pkg.verify(airs_, lhs, pub, prm, ob.challenger_state(), pre, bad, p["commitments"], preprocessed_root=root, lmcs=lmcs)[0]
-    ok, msg = pkg.verify(*args, preprocessed_root=root, lmcs="blake3")
-    assert not ok and "algebraic" in msg
+    assert not pkg.verify(*args, preprocessed_root=root, lmcs="blake3")[0]       # nor a byte-hash one
 
 
 @pytest.mark.gpu
