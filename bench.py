@@ -20,8 +20,7 @@ bounded sample), never inside the timed GPU region.  Extra keys on the N = 1 lin
 the same proof with the host->device upload of the trace inside the timed region) and `miden_shape` (the full Miden VM
 shape: three AIRs of widths 51/22/16 with 4/3/1 EF aux columns, the published reference figure's neighbour) and `in_flight`
 (three proofs in flight on the one GPU, one context per proving thread: service throughput, not the headline) and
-`hash_configs` (the device stages of a proof under the reference's default Blake3_256 configuration and under Keccak, staged
-session).
+`hash_configs` (the same proof under the reference's other hash functions: Blake3_256 = its default, Keccak, RPO, RPX).
 """
 import argparse, json, os, sys, time
 
@@ -181,53 +180,24 @@ def in_flight_probe(pkg, log_n, device, k=3, steps=4):
             "note": "k proving threads, one context (HIP stream) each, same GPU; every proof is a complete independent proof"}
 
 
-def session_stages_probe(pkg, ctx, log_n, lmcs, steps=3):
-    """Device time of ONE proof's stages through the staged session (mh_session_*) under an LMCS hasher, with the challenges
-    drawn from a PRNG instead of a transcript: what the GPU does for a proof of the Blake3 configuration (the reference's
-    ProvingOptions::default(); its byte challenger and PoW search stay with the host shim and are not in this figure),
-    next to the same drive under the Poseidon2 configuration."""
-    import numpy as np
-    from miden_vm_amd import dag, protocol
-    P = 0xFFFFFFFF00000001
-    ctx.set_lmcs(lmcs)
+def hash_config_probe(pkg, device, log_n, lmcs, steps=5):
+    """A complete proof (mh_prove: transcript, PoW search and openings included) of the bench instance under another of the
+    reference's five StarkConfigs (air/src/config.rs:212-353; HashFunction::Blake3_256 is ProvingOptions::default())."""
+    ctx = pkg.Ctx(device)
     try:
-        air = pkg.DeviceAir(ctx, dag.dummy_miden_air(51, 8))
-        tr = ctx.upload_trace(synth_trace(np.random.default_rng(3), log_n, 51))
-        prm = dict(protocol.PROD_PARAMS)
-        rng = np.random.default_rng(4)
-
-        def ef():
-            return (int(rng.integers(0, P, dtype=np.uint64)), int(rng.integers(0, P, dtype=np.uint64)))
-
-        def one():
-            s = pkg.Session(ctx, [air], [tr], [], prm)
-            sh = s.shape
-            s.commit_main()
-            s.commit_aux([ef() for _ in range(sh.num_randomness)], None)
-            s.commit_quotient(ef(), ef())
-            z = ef()
-            while not s.ood_point_ok(z):
-                z = ef()
-            s.ood(z)
-            s.deep(ef(), ef())
-            for _ in range(sh.num_fri_rounds):
-                s.fri_commit()
-                s.fri_fold(ef())
-            s.fri_final()
-            hints = s.open([int(x) for x in rng.integers(0, 1 << sh.log_lde_height, prm["num_queries"])])
-            s.free()
-            return len(hints.fields) * 8 + len(hints.commitments) * 32
-
-        one()
+        ctx.set_lmcs(lmcs)
+        r = ProveRunner(pkg, ctx, log_n, 21)
+        r.step()
         t0 = time.perf_counter()
         for _ in range(steps):
-            nbytes = one()
+            r.step()
         dt = (time.perf_counter() - t0) / steps
-        tr.free()
-        air.free()
+        nbytes = len(r.proof.bytes)
+        r.trace.free()
+        r.dair.free()
     finally:
-        ctx.set_lmcs("poseidon2")
-    return {"lmcs": lmcs, "ms_per_proof": dt * 1e3, "rows_per_s": (1 << log_n) / dt, "opening_hint_bytes": int(nbytes)}
+        ctx.close()
+    return {"ms_per_proof": dt * 1e3, "rows_per_s": (1 << log_n) / dt, "proof_bytes": nbytes}
 
 
 def cpu_baseline(runner, cpu_log_n):
@@ -464,13 +434,13 @@ def main():
             out["in_flight"] = in_flight_probe(pkg, log_n, dev_index)
         except Exception as e:
             out["in_flight"] = {"error": repr(e)[:200]}
-        try:  # the reference's other configurations (Blake3_256 = its DEFAULT, Keccak) through the staged boundary, next to the
-            # same drive with Poseidon2
-            out["hash_configs"] = {"note": "staged session (mh_session_*), challenges from a PRNG: device stages of one proof; the "
-                                           "host shim's challenger and PoW search are not included",
-                                   "blake3": session_stages_probe(pkg, ctx, log_n, "blake3"),
-                                   "keccak": session_stages_probe(pkg, ctx, log_n, "keccak"),
-                                   "poseidon2": session_stages_probe(pkg, ctx, log_n, "poseidon2")}
+        try:  # the same proof under the reference's other StarkConfigs (Blake3_256 = its DEFAULT ProvingOptions)
+            out["hash_configs"] = {"note": "mh_prove of the same instance on a context set to another LMCS hasher / challenger "
+                                           "(mh_ctx_set_lmcs); rpo / rpx at 2^16 rows (Rescue Prime is supported, not tuned)",
+                                   "blake3": hash_config_probe(pkg, dev_index, log_n, "blake3"),
+                                   "keccak": hash_config_probe(pkg, dev_index, log_n, "keccak"),
+                                   "rpo_2p16": hash_config_probe(pkg, dev_index, min(log_n, 16), "rpo", steps=2),
+                                   "rpx_2p16": hash_config_probe(pkg, dev_index, min(log_n, 16), "rpx", steps=2)}
         except Exception as e:
             out["hash_configs"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -86,13 +86,15 @@ void mh_host_free(void* p);
  * overwrite-mode sponge over 64-bit lanes with Keccak-f[1600] (25 lanes, 17 felts as canonical u64 per permutation, digest =
  * lanes 0..3; alignment 17), node = one permutation over left || right in a zero state.  MH_LMCS_RPO / MH_LMCS_RPX: the
  * other two ALGEBRAIC configurations (config.rs:224-245): the Poseidon2 LMCS and duplex challenger with the Rescue Prime
- * permutations (crates/crypto/src/hash/algebraic_sponge/rescue/); for them the one-shot mh_prove, mh_grind and mh_verify_lmcs
- * work as for Poseidon2.  It applies to everything this context commits and opens: mh_commit_traces,
- * mh_commit_traces_sharded, mh_tree_open and the staged session mh_session_* -- there the row alignment follows the hasher
- * (lmcs.alignment(): the sponge's rate, 8 or 17; 1 for the chaining hasher: OOD blocks and opened rows are then unpadded) and the FRI
- * leaves use it too, so a host shim that owns the Blake3 configuration's challenger (p3 SerializingChallenger64 over a
- * HashChallenger) proves under HashFunction::Blake3_256 / Keccak through the session.  The one-shot mh_prove / mh_prove_sharded
- * own a duplex-sponge transcript and mh_verify* is its verifier: the algebraic configurations only, and they say so. */
+ * permutations (crates/crypto/src/hash/algebraic_sponge/rescue/).
+ * The setting is the context's StarkConfig: it applies to everything the context commits, opens and proves -- mh_commit_traces,
+ * mh_commit_traces_sharded, mh_tree_open, mh_prove / mh_prove_sharded and the staged session.  The row alignment follows the
+ * hasher (lmcs.alignment(): the sponge's rate, 8 or 17; 1 for the chaining hasher: OOD blocks and opened rows are then
+ * unpadded), the FRI leaves use it, and so does the challenger of the one-shot prover: the duplex sponge over the configuration's
+ * permutation (Poseidon2, RPO, RPX) or, for Blake3 and Keccak, the library's restatement of p3's SerializingChallenger64 over a
+ * HashChallenger (external code with no in-tree mirror: a shim that wants p3's own keeps the transcript on the host and drives
+ * mh_session_*, which never sees a challenger).  mh_verify / mh_verify_ex are the Poseidon2 configuration; mh_verify_lmcs takes
+ * the id.  mh_grind is the duplex sponge's PoW search (algebraic configurations). */
 #define MH_LMCS_POSEIDON2 0
 #define MH_LMCS_BLAKE3 1
 #define MH_LMCS_KECCAK 2
@@ -343,8 +345,7 @@ int mh_verify_ex(const mh_pcs_params* params, int n_airs, const uint64_t* const*
                  const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe, const uint64_t* fields,
                  size_t n_fields, const uint64_t* commitments, size_t n_commitments, const uint64_t* preprocessed_root,
                  mh_external_assertions external, void* external_user, uint64_t digest[4], char* err, size_t err_cap);
-/* mh_verify_ex for an algebraic configuration other than Poseidon2: lmcs = MH_LMCS_POSEIDON2 | MH_LMCS_RPO | MH_LMCS_RPX
- * (HashFunction::Rpo256 / Rpx256, prover/src/lib.rs:268-300). */
+/* mh_verify_ex under any of the five configurations: lmcs = MH_LMCS_* (prover/src/lib.rs:246-300 dispatches the same five). */
 int mh_verify_lmcs(int lmcs, const mh_pcs_params* params, int n_airs, const uint64_t* const* air_blobs, const size_t* air_blob_words,
                    const uint8_t* log_trace_heights, const uint64_t* public_values, size_t n_public_values,
                    const uint64_t challenger_state[12], const uint64_t* pre_observe, size_t n_pre_observe, const uint64_t* fields,

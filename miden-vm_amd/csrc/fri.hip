@@ -11,6 +11,7 @@
 // writes one; the reference's bit-reversed row [y0,y2,y1,y3] is rebuilt only in the leaf hash and
 // in query openings.
 // s_inv for row i0 is w_n^(-i0) (fri/prover.rs:117-142: the coset shift is deliberately ignored).
+#include <cstring>
 #include "gl.cuh"
 #include "../../include/midenhip.h"
 #include "kernels.hpp"
@@ -320,6 +321,118 @@ __global__ __launch_bounds__(256) void k_grind_alg(GrindArgs a, int lmcs) {
   s[8] = gl_add(s[8], (u64)k);
   alg_permute(lmcs, s);
   if (((s[7] & 0xFFFFFFFFULL) & (((u64)1 << a.bits) - 1)) == 0) atomicMin(a.best, (unsigned long long)w);
+}
+
+// ---- PoW search for the byte challengers (Blake3 / Keccak configurations) ----
+// check_witness = observe(w): input := prefix || w (8 LE bytes); sample_bits: output = hash(input), the sampled u64 is built from
+// the digest's LAST eight bytes, last byte lowest (HashChallenger pops from the end) = bswap64 of digest bytes 24..31.
+// The host hashes every block that lies wholly inside the prefix once; a trial costs the last one or two blocks.
+struct GrindB3Args {
+  b3::Stream pre;       // after the full 64-byte blocks of the prefix
+  uint8_t tail[64];     // the rest of the prefix (tail_len < 64 bytes)
+  uint32_t tail_len;
+  int bits;
+  u64 base;
+  unsigned long long* best;
+};
+__global__ __launch_bounds__(256) void k_grind_b3(GrindB3Args a) {
+  const u64 w = a.base + blockIdx.x * (u64)256 + threadIdx.x;
+  if (w >= GL_P) return;
+  uint8_t buf[128];
+#pragma unroll 1
+  for (int i = 0; i < 128; i++) buf[i] = 0;
+  for (uint32_t i = 0; i < a.tail_len; i++) buf[i] = a.tail[i];
+  for (int k = 0; k < 8; k++) buf[a.tail_len + k] = (uint8_t)(w >> (8 * k));
+  const uint32_t n = a.tail_len + 8;
+  b3::Stream h = a.pre;
+  uint32_t m[16], out[8];
+  auto words = [&](const uint8_t* p) {
+    for (int i = 0; i < 16; i++) m[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
+  };
+  if (n <= 64) {
+    words(buf);
+    h.finish(m, n, out);
+  } else {
+    words(buf);
+    h.block(m);
+    words(buf + 64);
+    h.finish(m, n - 64, out);
+  }
+  const u64 x = (u64)out[6] | ((u64)out[7] << 32);
+  const u64 v = __builtin_bswap64(x);
+  if ((v & (((u64)1 << a.bits) - 1)) == 0) atomicMin(a.best, (unsigned long long)w);
+}
+struct GrindKkArgs {
+  u64 st[25];           // after the full 136-byte blocks of the prefix
+  uint8_t tail[136];
+  uint32_t tail_len;    // < 136
+  int bits;
+  u64 base;
+  unsigned long long* best;
+};
+__global__ __launch_bounds__(256) void k_grind_kk(GrindKkArgs a) {
+  const u64 w = a.base + blockIdx.x * (u64)256 + threadIdx.x;
+  if (w >= GL_P) return;
+  kk::Sponge256 s;
+  for (int i = 0; i < 25; i++) s.st[i] = a.st[i];
+  for (uint32_t i = 0; i < a.tail_len; i++) s.buf[i] = a.tail[i];
+  s.fill = a.tail_len;
+  uint8_t wb[8], d[32];
+  for (int k = 0; k < 8; k++) wb[k] = (uint8_t)(w >> (8 * k));
+  s.update(wb, 8);
+  s.finish(0x01, d);
+  u64 v = 0;
+  for (int i = 0; i < 8; i++) v |= (u64)d[31 - i] << (8 * i);
+  if ((v & (((u64)1 << a.bits) - 1)) == 0) atomicMin(a.best, (unsigned long long)w);
+}
+u64 fri_grind_bytes(mh_ctx* c, int lmcs, const std::vector<uint8_t>& prefix, int bits) {
+  MH_REQUIRE(bits > 0 && bits <= 32 && (lmcs == MH_LMCS_BLAKE3 || lmcs == MH_LMCS_KECCAK), "bad byte-challenger grind request");
+  DevBuf best(8);
+  GrindB3Args ab{};
+  GrindKkArgs ak{};
+  if (lmcs == MH_LMCS_BLAKE3) {
+    ab.pre.init();
+    const size_t k = prefix.size() / 64;
+    for (size_t b = 0; b < k; b++) {
+      uint32_t m[16];
+      for (int i = 0; i < 16; i++) {
+        const uint8_t* p = prefix.data() + 64 * b + 4 * i;
+        m[i] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+      }
+      ab.pre.block(m);
+    }
+    ab.tail_len = (uint32_t)(prefix.size() - 64 * k);
+    memcpy(ab.tail, prefix.data() + 64 * k, ab.tail_len);
+    ab.bits = bits;
+    ab.best = (unsigned long long*)best.p;
+  } else {
+    kk::Sponge256 s;
+    s.init();
+    const size_t k = prefix.size() / 136;
+    s.update(prefix.data(), 136 * k);  // full blocks only: fill stays 0
+    for (int i = 0; i < 25; i++) ak.st[i] = s.st[i];
+    ak.tail_len = (uint32_t)(prefix.size() - 136 * k);
+    memcpy(ak.tail, prefix.data() + 136 * k, ak.tail_len);
+    ak.bits = bits;
+    ak.best = (unsigned long long*)best.p;
+  }
+  u64 window = (u64)1 << (bits + 2);
+  if (window < 65536) window = 65536;
+  ProfScope ps(c, "grind", 0);
+  for (u64 base = 0;; base += window) {
+    unsigned long long init = ~0ULL;
+    HIP_CHECK(hipMemcpyAsync(best.p, &init, 8, hipMemcpyHostToDevice, c->stream));
+    if (lmcs == MH_LMCS_BLAKE3) {
+      ab.base = base;
+      MH_LAUNCH(k_grind_b3, dim3((unsigned)(window / 256)), dim3(256), 0, c->stream, ab);
+    } else {
+      ak.base = base;
+      MH_LAUNCH(k_grind_kk, dim3((unsigned)(window / 256)), dim3(256), 0, c->stream, ak);
+    }
+    unsigned long long got = 0;
+    c->d2h(&got, best.p, 8);
+    if (got != ~0ULL) return (u64)got;
+  }
 }
 
 // Returns the smallest witness >= 0 accepted by `check_witness` for the given challenger snapshot.

@@ -118,6 +118,8 @@ void fri_leaf_hash(mh_ctx* c, const u64* ev, int log_rows, int cbits, int log_ar
 void fri_fold(mh_ctx* c, const u64* ev, int log_rows, int cbits, int cbits_global, size_t coset0, int log_arity, e2 beta, u64* out);
 void fri_to_natural(mh_ctx* c, const u64* ev, int log_rows, int cbits, u64* out);
 u64 fri_grind(mh_ctx* c, const u64 st[12], const u64* in, int n_in, int bits);
+// byte challengers (Blake3 / Keccak): smallest w with sample_bits(bits) == 0 after observing it; prefix = the input buffer
+u64 fri_grind_bytes(mh_ctx* c, int lmcs, const std::vector<uint8_t>& prefix, int bits);
 
 // logup.hip
 struct mh_lookup;

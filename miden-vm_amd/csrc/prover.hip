@@ -616,7 +616,8 @@ static void do_grind(mh_ctx* c, HostTranscript& tr, int bits) {
       }
     }
   }
-  u64 w = fri_grind(c, tr.ch.st, tr.ch.in.data(), (int)tr.ch.in.size(), bits);
+  u64 w = tr.ch.bytes() ? fri_grind_bytes(c, tr.ch.hash, tr.ch.bin, bits)
+                        : fri_grind(c, tr.ch.st, tr.ch.in.data(), (int)tr.ch.in.size(), bits);
   MH_REQUIRE(tr.ch.check_witness(bits, w), "internal: device PoW witness rejected by the host challenger");
   tr.fields.push_back(w);
 }
@@ -627,9 +628,9 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
                        mh_aux_builder cb, void* user, mh_proof& proof, const Dist& dist) {
   // the one-shot prover owns the transcript, and the library's challenger is the duplex sponge of the Poseidon2 (algebraic)
   // configuration; the Blake3 configuration goes through the staged session, where the host owns the challenger
-  MH_REQUIRE(c->lmcs == MH_LMCS_POSEIDON2 || c->lmcs == MH_LMCS_RPO || c->lmcs == MH_LMCS_RPX,
-             "mh_prove is built for the algebraic configurations (Poseidon2 configuration, RPO, RPX): with a byte hasher use the staged "
-             "session (host-owned transcript)");
+  // every configuration of air/src/config.rs: the duplex sponge over the context's permutation, or -- Blake3, Keccak -- the
+  // library's restatement of p3's serializing hash challenger (challenger.hpp; unpinned: a shim that wants p3's own keeps the
+  // transcript on the host and drives the staged session instead)
   mh_session s;
   s.begin(c, pp, n_airs, airs_in, traces_in, publics_in, n_publics, dist);
   HostTranscript tr;

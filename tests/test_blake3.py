@@ -94,16 +94,30 @@ def test_device_blake3_commitment_equals_oracle(case):
 
 
 @pytest.mark.gpu
-def test_one_shot_prover_refuses_a_blake3_context():
-    import airs as A
+@pytest.mark.parametrize("lmcs", ["blake3", "keccak"])
+@pytest.mark.parametrize("name", ["fib", "multi", "dummy_arity8", "preprocessed"])
+def test_one_shot_device_proofs_under_the_byte_hash_configurations(lmcs, name):
+    """mh_prove on a context set to Blake3 / Keccak: the library's own byte challenger (host) and PoW search (k_grind_b3 /
+    k_grind_kk: more than 5 bits) -- the proof equals the oracle prover's and passes the product verifier."""
+    from test_gpu_prove import gpu_prove
     pkg = load_package()
+    airs_, traces, pub, prm = blake3_cases()[name]
+    prm = dict(prm, deep_pow_bits=9, query_pow_bits=7)
     ctx = pkg.Ctx(0)
-    ctx.set_lmcs("blake3")
-    t, pub = A.fib_trace(5)
-    prm = dict(log_blowup=2, log_folding_arity=1, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=1, num_queries=6, query_pow_bits=2)
-    with pytest.raises(pkg.MidenHipError, match="Poseidon2 configuration"):  # the one-shot prover owns a duplex-sponge transcript
-        pkg.prove(ctx, [pkg.DeviceAir(ctx, A.fib_air())], [ctx.upload_trace(t)], pub, prm, ob.challenger_state(), ob.protocol_pre_observe(prm, pub), None)
-    ctx.close()
+    ob.set_lmcs(lmcs)
+    try:
+        ctx.set_lmcs(lmcs)
+        exp = ob.prove(airs_, traces, pub, prm)
+        got = gpu_prove(ctx, airs_, traces, pub, prm)
+        assert (got.commitments == exp["commitments"]).all() and got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all()
+        assert (got.digest == exp["digest"]).all()
+        root = ob.preprocessed_commitment(airs_, exp["log_heights"], prm) if any(a.preprocessed is not None for a in airs_) else None
+    finally:
+        ob.set_lmcs("poseidon2")
+        ctx.close()
+    ok, dig = pkg.verify(airs_, got.log_trace_heights, pub, prm, ob.challenger_state(), ob.protocol_pre_observe(prm, pub, preprocessed_root=root),
+                         got.fields, got.commitments, preprocessed_root=root, lmcs=lmcs)
+    assert ok and (dig == got.digest).all(), dig
 
 
 # ---- the whole Blake3 configuration (ProvingOptions::default()): alignment 1, byte challenger, staged boundary --------------
