@@ -348,3 +348,34 @@ def test_sharded_commitment_with_the_byte_hash_lmcs(world, lmcs):
     roots = _thread_ranks(world, body)
     for r in roots:
         assert (r == exp["root"]).all()
+
+
+@pytest.mark.parametrize("world,lmcs", [(2, "blake3"), (2, "keccak"), (2, "rpx")])
+def test_sharded_proof_under_the_other_configurations(world, lmcs):
+    """mh_prove_sharded on contexts set to another StarkConfig: every rank's proof equals the oracle prover's proof of that
+    configuration (digest all-to-all, per-rank subtrees, host cap, openings with the configuration's alignment, each rank running
+    the same host challenger)."""
+    import oracle_binding as ob
+    import airs as A
+    t1, pub = A.fib_trace(8)
+    airs_, traces = [A.periodic_air(3), A.fib_air()], [A.periodic_trace(6), t1]
+    prm = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=7, num_queries=6, query_pow_bits=3)
+    st, pre = ob.challenger_state(), ob.protocol_pre_observe(prm, pub)
+    ob.set_lmcs(lmcs)
+    try:
+        exp = ob.prove(airs_, traces, pub, prm)
+    finally:
+        ob.set_lmcs("poseidon2")
+
+    def aux_builder(idx, rnd):
+        return airs_[idx].build_aux(traces[idx], rnd[:airs_[idx].num_randomness])
+
+    def body(pkg, sharding, rank, ctx, comm):
+        ctx.set_lmcs(lmcs)
+        dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+        dtr = [ctx.upload_trace(t) for t in traces]
+        return sharding.prove_sharded(pkg, ctx, comm, dairs, dtr, pub, prm, st, pre, aux_builder)
+
+    for got in _thread_ranks(world, body):
+        assert got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all()
+        assert (got.commitments == exp["commitments"]).all() and (got.digest == exp["digest"]).all()
