@@ -95,7 +95,7 @@ def test_device_blake3_commitment_equals_oracle(case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("lmcs", ["blake3", "keccak"])
-@pytest.mark.parametrize("name", ["fib", "multi", "dummy_arity8", "preprocessed"])
+@pytest.mark.parametrize("name", ["multi", "preprocessed"])
 def test_one_shot_device_proofs_under_the_byte_hash_configurations(lmcs, name):
     """mh_prove on a context set to Blake3 / Keccak: the library's own byte challenger (host) and PoW search (k_grind_b3 /
     k_grind_kk: more than 5 bits) -- the proof equals the oracle prover's and passes the product verifier."""
