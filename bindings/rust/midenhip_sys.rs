@@ -132,6 +132,7 @@ unsafe extern "C" {
     pub fn mh_session_fri_final(s: *mut mh_session, coeffs_out: *mut u64) -> c_int;
     pub fn mh_session_open(s: *mut mh_session, indices: *const u64, n_indices: usize, out: *mut *mut mh_proof) -> c_int;
     pub fn mh_grind(ctx: *mut mh_ctx, state: *const u64, pending: *const u64, n_pending: usize, bits: c_int, witness: *mut u64) -> c_int;
+    pub fn mh_grind_bytes(ctx: *mut mh_ctx, input: *const u8, n_input: usize, bits: c_int, witness: *mut u64) -> c_int;
     pub fn mh_verify(params: *const mh_pcs_params, n_airs: c_int, air_blobs: *const *const u64, air_blob_words: *const usize, log_trace_heights: *const u8, public_values: *const u64, n_public_values: usize, challenger_state: *const u64, pre_observe: *const u64, n_pre_observe: usize, fields: *const u64, n_fields: usize, commitments: *const u64, n_commitments: usize, preprocessed_root: *const u64, digest: *mut u64, err: *mut c_char, err_cap: usize) -> c_int;
     pub fn mh_verify_ex(params: *const mh_pcs_params, n_airs: c_int, air_blobs: *const *const u64, air_blob_words: *const usize, log_trace_heights: *const u8, public_values: *const u64, n_public_values: usize, challenger_state: *const u64, pre_observe: *const u64, n_pre_observe: usize, fields: *const u64, n_fields: usize, commitments: *const u64, n_commitments: usize, preprocessed_root: *const u64, external: mh_external_assertions, external_user: *mut c_void, digest: *mut u64, err: *mut c_char, err_cap: usize) -> c_int;
     /// mh_verify_ex for MH_LMCS_RPO (3) / MH_LMCS_RPX (4) / MH_LMCS_POSEIDON2 (0)

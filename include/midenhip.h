@@ -314,6 +314,12 @@ int mh_session_open(mh_session* s, const uint64_t* indices, size_t n_indices, mh
 /* GrindingChallenger::grind on the device: `state` = the sponge state, `pending` = felts observed since the
  * last permutation (< 8).  Returns the smallest witness; the caller replays check_witness on its challenger. */
 int mh_grind(mh_ctx* ctx, const uint64_t state[12], const uint64_t* pending, size_t n_pending, int bits, uint64_t* witness);
+/* The same search for the byte challengers of the Blake3 / Keccak configurations (context set accordingly): `input` = the hash
+ * challenger's input buffer as it stands before the witness is observed (the chaining value of the last flush followed by every
+ * byte observed since); returns the smallest felt w such that, after observing w as 8 little-endian bytes, the u64 built from the
+ * LAST eight digest bytes (last byte lowest: HashChallenger pops from the end) has `bits` low zero bits.  The caller replays
+ * check_witness on its own challenger. */
+int mh_grind_bytes(mh_ctx* ctx, const uint8_t* input, size_t n_input, int bits, uint64_t* witness);
 /* ---- verifier (host only: no GPU, no ctx) ---------------------------------------------------------------------
  * Replays a proof against the AIRs' constraint-DAG blobs: crates/lifted-stark/src/verifier/mod.rs (flow, constraint
  * identity), pcs/verifier.rs + lmcs/config.rs:172-211 (openings), pcs/deep/verifier.rs, pcs/fri/verifier.rs.

@@ -31,7 +31,7 @@ EXPORTS = [
     "mh_session_commit_quotient", "mh_session_ood_point_ok", "mh_session_ood", "mh_session_deep", "mh_session_fri_commit",
     "mh_session_fri_fold", "mh_session_fri_final", "mh_session_open", "mh_grind",
     "mh_host_alloc", "mh_host_free", "mh_verify", "mh_trace_from_device", "mh_lookup_load", "mh_lookup_free", "mh_air_attach_lookup", "mh_air_attach_preprocessed", "mh_lookup_build_aux", "mh_trace_download",
-    "mh_verify_ex", "mh_external_logup_balance", "mh_proof_deserialize", "mh_ctx_set_lmcs", "mh_ctx_get_lmcs", "mh_blake3", "mh_verify_lmcs",
+    "mh_verify_ex", "mh_external_logup_balance", "mh_proof_deserialize", "mh_ctx_set_lmcs", "mh_ctx_get_lmcs", "mh_blake3", "mh_verify_lmcs", "mh_grind_bytes",
     "mh_rccl_unique_id", "mh_comm_create_rccl", "mh_comm_destroy", "mh_comm_selftest",
     "mh_local_fabric_create", "mh_local_fabric_destroy", "mh_comm_create_local",
 ]
@@ -642,6 +642,14 @@ def verify(airs, log_trace_heights, public_values, params, challenger_state, pre
                               C.c_size_t(len(pre_observe)), _ptr(f), C.c_size_t(f.size), _ptr(c), C.c_size_t(c.size // 4),
                               _ptr(proot) if proot is not None else None, ext, None, _ptr(digest), err, C.c_size_t(512))
     return (True, digest) if rc == 0 else (False, err.value.decode())
+
+
+def grind_bytes(ctx, input_bytes, bits):
+    """mh_grind_bytes: device PoW search for a hash challenger whose input buffer holds `input_bytes` (Blake3 / Keccak context)."""
+    data = bytes(input_bytes)
+    w = C.c_uint64(0)
+    ctx.check(ctx.lib.mh_grind_bytes(ctx.h, data, C.c_size_t(len(data)), C.c_int(bits), C.byref(w)))
+    return int(w.value)
 
 
 def blake3(data):

@@ -1057,6 +1057,21 @@ int mh_grind(mh_ctx* c, const uint64_t state[12], const uint64_t* pending, size_
   MH_CATCH
 }
 
+int mh_grind_bytes(mh_ctx* c, const uint8_t* input, size_t n_input, int bits, uint64_t* witness) {
+  MH_TRY(c)
+  MH_REQUIRE(c && witness && (input || !n_input), "null argument");
+  MH_REQUIRE(bits >= 0 && bits <= 32, "bits in 0..32");
+  MH_REQUIRE(c->lmcs == MH_LMCS_BLAKE3 || c->lmcs == MH_LMCS_KECCAK, "mh_grind_bytes searches a hash challenger's witness: Blake3 / Keccak contexts");
+  HIP_CHECK(hipSetDevice(c->device));
+  if (bits == 0) {
+    *witness = 0;
+  } else {
+    std::vector<uint8_t> prefix(input, input + n_input);
+    *witness = fri_grind_bytes(c, c->lmcs, prefix, bits);
+  }
+  MH_CATCH
+}
+
 void mh_proof_free(mh_proof* p) { delete p; }
 size_t mh_proof_num_fields(const mh_proof* p) { return p ? p->fields.size() : 0; }
 size_t mh_proof_num_commitments(const mh_proof* p) { return p ? p->commitments.size() / 4 : 0; }

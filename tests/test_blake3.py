@@ -245,3 +245,36 @@ def test_one_configuration_per_session():
     with pytest.raises(pkg.MidenHipError, match="another LMCS hasher"):
         pkg.Session(ctx, [d], [ctx.upload_trace(tr5())], [], FAST)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lmcs", ["blake3", "keccak"])
+def test_device_pow_search_for_hash_challengers(lmcs):
+    """mh_grind_bytes against a plain Python search: input buffers shorter than a block, across block / chunk / rate boundaries."""
+    import ctypes as C
+    pkg = load_package()
+    ctx = pkg.Ctx(0)
+    ctx.set_lmcs(lmcs)
+    rng = np.random.default_rng(8)
+
+    def digest(data):
+        if lmcs == "blake3":
+            return ob.blake3(data)
+        out = C.create_string_buffer(32)
+        ob.lib().orc_keccak256(data, C.c_size_t(len(data)), 1, out)
+        return out.raw
+
+    for n, bits in [(32, 9), (55, 7), (56, 8), (57, 6), (63, 10), (64, 9), (127, 8), (128, 11), (136, 9), (200, 8), (1016, 9), (1030, 10), (4400, 12)]:
+        data = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        w = 0
+        while True:
+            d = digest(data + w.to_bytes(8, "little"))
+            if int.from_bytes(d[24:32][::-1], "little") & ((1 << bits) - 1) == 0:
+                break
+            w += 1
+        assert pkg.grind_bytes(ctx, data, bits) == w, (n, bits)
+    assert pkg.grind_bytes(ctx, b"abc", 0) == 0
+    ctx.set_lmcs("poseidon2")
+    with pytest.raises(pkg.MidenHipError, match="hash challenger"):
+        pkg.grind_bytes(ctx, b"abc", 4)
+    ctx.close()
