@@ -1137,8 +1137,8 @@ int mh_proof_deserialize(const uint8_t* bytes, size_t len, mh_proof** out) {
   if (pos != len) return MH_ERR_INVALID;
   for (u64 v : p->fields)
     if (v >= GL_P) return MH_ERR_INVALID;
-  for (u64 v : p->commitments)
-    if (v >= GL_P) return MH_ERR_INVALID;
+  // commitments are 32 opaque bytes here: [Felt; 4] in the algebraic configurations (the verifier rejects a non-canonical word
+  // there), [u8; 32] / [u64; 4] under Blake3 / Keccak -- the same framing
   *out = p.release();
   return MH_OK;
 }

@@ -31,7 +31,7 @@ def split_bytes(data):
 
 
 def instance(fx, d=None):
-    name = os.path.basename(fx)[len("ref_"):-len(".json")]
+    name = os.path.basename(fx)[len("ref_"):-len(".json")].split("@")[0]  # ref_<case>[@<hasher>].json
     d = d if d is not None else json.load(open(fx))
     insts = CASES[name]
     assert [list(x[:3]) for x in insts] == d["instances"], "fixture was made from different instances than fixture_cases.json"
@@ -47,6 +47,27 @@ def state_and_pre():
     return ob.challenger_state(KAT["relation_digest"]), ob.protocol_pre_observe(ob.PROD_PARAMS, [])
 
 
+ALIGNMENT = {"poseidon2": 8, "rpo": 8, "rpx": 8, "blake3": 1, "keccak": 17}
+
+
+def lmcs_of(d):
+    return d.get("lmcs", "poseidon2")
+
+
+class configuration:
+    """with configuration(d): the oracle restates the fixture's StarkConfig (ob.set_lmcs) for the duration."""
+
+    def __init__(self, d):
+        self.lmcs = lmcs_of(d)
+
+    def __enter__(self):
+        ob.set_lmcs(self.lmcs)
+        return self.lmcs
+
+    def __exit__(self, *a):
+        ob.set_lmcs("poseidon2")
+
+
 def compare(d, lhs, fields, commitments, digest, airs_):
     ref_bytes = bytes.fromhex(d["proof_bytes_hex"])
     r_lhs, r_fields, r_commits = split_bytes(ref_bytes)
@@ -60,7 +81,8 @@ def compare(d, lhs, fields, commitments, digest, airs_):
     assert [int(x) for x in digest] == d["digest"]
     assert pp.serialize(lhs, fields, commitments) == ref_bytes  # the framing itself (wincode) byte for byte
     st, pre = state_and_pre()
-    parsed = pp.parse(airs_, lhs, [], ob.PROD_PARAMS, r_fields, r_commits, init_state=st)
+    with configuration(d) as lmcs:
+        parsed = pp.parse(airs_, lhs, [], ob.PROD_PARAMS, r_fields, r_commits, init_state=st, alignment=ALIGNMENT[lmcs])
     assert [list(x) for x in parsed["randomness"]] == d["randomness"]
     assert list(parsed["alpha"]) == d["alpha"] and list(parsed["beta"]) == d["beta"] and list(parsed["z"]) == d["z"]
     assert parsed["digest"] == d["digest"]
@@ -78,21 +100,25 @@ def test_fixture_inputs_are_reproducible():
     assert {k: [list(x) for x in v] for k, v in mi.CASES.items()} == CASES
 
 
-def test_fixture_consumer_self_check():
+@pytest.mark.parametrize("lmcs", ["poseidon2", "blake3", "keccak", "rpo", "rpx"])
+def test_fixture_consumer_self_check(lmcs):
     """The comparison code itself, run on a stand-in fixture assembled from the ORACLE's proof (never written to disk, never a
-    golden): when real fixtures arrive, a failure is then a parity finding, not a bug in this file."""
+    golden): when real fixtures arrive, a failure is then a parity finding, not a bug in this file.  One stand-in per
+    StarkConfig the kit can dump (--hasher)."""
     name = "miden_6_11_2"
     insts = CASES[name]
     airs_ = [dag.dummy_miden_air(w, aux) for (_, w, aux, _) in insts]
     traces = [A.dummy_trace(lh, w, seed=seed) for (lh, w, _, seed) in insts]
     st, pre = state_and_pre()
-    proof = ob.prove(airs_, traces, [], ob.PROD_PARAMS, init_state=st, pre_observe=pre)
-    parsed = pp.parse(airs_, proof["log_heights"], [], ob.PROD_PARAMS, proof["fields"], proof["commitments"], init_state=st)
-    d = dict(instances=[list(x[:3]) for x in insts], params=dict(ob.PROD_PARAMS),
+    with configuration({"lmcs": lmcs}):
+        proof = ob.prove(airs_, traces, [], ob.PROD_PARAMS, init_state=st, pre_observe=pre)
+        parsed = pp.parse(airs_, proof["log_heights"], [], ob.PROD_PARAMS, proof["fields"], proof["commitments"], init_state=st,
+                          alignment=ALIGNMENT[lmcs])
+    d = dict(lmcs=lmcs, instances=[list(x[:3]) for x in insts], params=dict(ob.PROD_PARAMS),
              proof_bytes_hex=pp.serialize(proof["log_heights"], proof["fields"], proof["commitments"]).hex(),
              digest=[int(x) for x in proof["digest"]], randomness=[list(x) for x in parsed["randomness"]], alpha=list(parsed["alpha"]),
              beta=list(parsed["beta"]), z=list(parsed["z"]))
-    d2, airs2, traces2 = instance("ref_" + name + ".json", d)
+    d2, airs2, traces2 = instance("ref_" + name + "@" + lmcs + ".json", d)
     compare(d2, proof["log_heights"], proof["fields"], proof["commitments"], proof["digest"], airs2)
     bad = proof["fields"].copy()
     bad[5] = (int(bad[5]) + 1) % ob.P
@@ -106,11 +132,12 @@ def test_oracle_reproduces_reference_proof_bytes(fx):
         pytest.skip(NO_FIXTURES)
     d, airs_, traces = instance(fx)
     st, pre = state_and_pre()
-    proof = ob.prove(airs_, traces, [], ob.PROD_PARAMS, init_state=st, pre_observe=pre)
+    with configuration(d):
+        proof = ob.prove(airs_, traces, [], ob.PROD_PARAMS, init_state=st, pre_observe=pre)
     compare(d, proof["log_heights"], proof["fields"], proof["commitments"], proof["digest"], airs_)
     # and the product's host verifier accepts the reference's bytes
     lhs, f, c = split_bytes(bytes.fromhex(d["proof_bytes_hex"]))
-    ok, dig = pkg.verify(airs_, lhs, [], ob.PROD_PARAMS, st, pre, f, c)
+    ok, dig = pkg.verify(airs_, lhs, [], ob.PROD_PARAMS, st, pre, f, c, lmcs=lmcs_of(d))
     assert ok and [int(x) for x in dig] == d["digest"], dig
 
 
@@ -123,6 +150,7 @@ def test_device_reproduces_reference_proof_bytes(fx):
     st, pre = state_and_pre()
     ctx = pkg.Ctx(0)
     try:
+        ctx.set_lmcs(lmcs_of(d))
         got = pkg.prove(ctx, [pkg.DeviceAir(ctx, a) for a in airs_], [ctx.upload_trace(t) for t in traces], [], ob.PROD_PARAMS, st, pre, None)
         compare(d, got.log_trace_heights, got.fields, got.commitments, got.digest, airs_)
         assert got.bytes == bytes.fromhex(d["proof_bytes_hex"])  # mh_proof_serialize == the reference's wincode bytes

@@ -17,6 +17,7 @@ CASES = {
     "miden_shape_10_9_8": [(10, 51, 4, 3), (9, 22, 3, 4), (8, 16, 1, 5)],
     "miden_mixed_order": [(9, 16, 1, 5), (7, 51, 4, 3), (9, 22, 3, 4)],
 }
+OTHER_HASHERS_FOR = ("miden_6_11_2", "miden_shape_10_9_8")
 
 
 def main():
@@ -31,6 +32,10 @@ def main():
             A.dummy_trace(lh, w, seed=seed).astype("<u8").tofile(path)
             specs.append(f"{lh}:{w}:{aux}:{path}")
         lines.append(f"cargo run --release -p midenhip-fixtures -- {os.path.join(out, 'ref_' + name + '.json')} " + " ".join(specs))
+        if name in OTHER_HASHERS_FOR:  # the other four StarkConfigs of prove_stark on a couple of cases: ref_<case>@<hasher>.json
+            for h in ("blake3", "keccak", "rpo", "rpx"):
+                lines.append(f"cargo run --release -p midenhip-fixtures -- --hasher {h} "
+                             f"{os.path.join(out, 'ref_' + name + '@' + h + '.json')} " + " ".join(specs))
     json.dump(CASES, open(os.path.join(out, "cases.json"), "w"))
     print("\n".join(lines))
 

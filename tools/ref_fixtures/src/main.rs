@@ -1,13 +1,18 @@
 //! Dump one proof of the reference lifted-STARK prover for the libmidenhip parity tests.
 //!
 //! The instance is the miden-bench synthetic one (`DummyMidenAir`, benches/miden-bench/src/lifted.rs:110-162) but proved
-//! exactly the way `miden_prover::prove_stark` does it (prover/src/lib.rs:317-355): Miden's production Poseidon2
-//! configuration `config::poseidon2_config(config::pcs_params(), RELATION_DIGEST)`, `observe_protocol_params` on the
+//! exactly the way `miden_prover::prove_stark` does it (prover/src/lib.rs:317-355): one of Miden's five production
+//! configurations, e.g. `config::poseidon2_config(config::pcs_params(), RELATION_DIGEST)`, `observe_protocol_params` on the
 //! challenger, empty public values / aux inputs, wincode framing of `StarkProofData`.  The traces are NOT generated here:
 //! they are read from the little-endian u64 row-major files tools/ref_fixtures/make_inputs.py wrote, so that both sides
 //! prove the same matrices.
 //!
-//! usage: midenhip-fixtures OUT.json  LOG_HEIGHT:WIDTH:AUX_COLS:TRACE.bin  [LOG_HEIGHT:WIDTH:AUX_COLS:TRACE.bin ...]
+//! usage: midenhip-fixtures [--hasher poseidon2|blake3|keccak|rpo|rpx] OUT.json  LOG_HEIGHT:WIDTH:AUX_COLS:TRACE.bin  [...]
+//!
+//! --hasher selects the StarkConfig exactly as `prove_miden_vm_execution_trace` does (prover/src/lib.rs:246-300); the JSON then
+//! carries "lmcs": "<hasher>".  Commitments and the digest are written as FOUR u64 WORDS: the canonical values of a `[Felt; 4]`
+//! (algebraic configurations), the little-endian words of a `[u8; 32]` (Blake3), the lanes of a `[u64; 4]` (Keccak) -- the
+//! container libmidenhip and the oracle use for all of them.
 //!
 //! OUT.json: { "instances": [[log_h, width, aux], ...], "params": {...}, "proof_bytes_hex": "...", "digest": [4 u64],
 //!             "randomness": [[c0,c1],...], "alpha": [c0,c1], "beta": [c0,c1], "z": [c0,c1],
@@ -80,14 +85,32 @@ fn felts(v: &[Felt]) -> String {
     s
 }
 
+fn u64s(v: &[u64]) -> String {
+    let mut s = String::from("[");
+    for (i, x) in v.iter().enumerate() {
+        if i > 0 {
+            s.push(',');
+        }
+        write!(s, "{x}").unwrap();
+    }
+    s.push(']');
+    s
+}
+
 fn ef(x: QuadFelt) -> String {
     use miden_crypto::stark::air::BasedVectorSpace; // p3_field::BasedVectorSpace (re-exported with p3-air's prelude)
     felts(<QuadFelt as BasedVectorSpace<Felt>>::as_basis_coefficients_slice(&x))
 }
 
 fn main() {
-    let args: Vec<String> = env::args().collect();
-    assert!(args.len() >= 3, "usage: midenhip-fixtures OUT.json LOG_H:WIDTH:AUX:TRACE.bin ...");
+    let mut args: Vec<String> = env::args().collect();
+    let mut hasher = String::from("poseidon2");
+    if args.len() > 2 && args[1] == "--hasher" {
+        hasher = args[2].clone();
+        args.drain(1..3);
+    }
+    assert!(args.len() >= 3, "usage: midenhip-fixtures [--hasher H] OUT.json LOG_H:WIDTH:AUX:TRACE.bin ...");
+    let params0 = config::pcs_params();
     let mut airs = Vec::new();
     let mut traces = Vec::new();
     let mut inst_json = String::from("[");
@@ -107,61 +130,80 @@ fn main() {
     }
     inst_json.push(']');
 
-    // exactly prove_stark (prover/src/lib.rs:326-353)
-    let params = config::pcs_params();
-    let cfg = config::poseidon2_config(params, RELATION_DIGEST);
-    let mut challenger = cfg.challenger();
-    config::observe_protocol_params(&mut challenger);
-    let statement = Statement::new(Multi { airs }, Vec::new(), Vec::new()).expect("statement");
-    let prover_statement = ProverStatement::new(statement, traces).expect("prover statement");
-    let output: StarkOutput<Felt, QuadFelt, _> =
-        ProverInstance::new(&cfg, &prover_statement, None).expect("instance").prove(challenger).expect("prove");
-    let bytes = <SerdeCompat<StarkProofData<Felt, QuadFelt, _>> as wincode::config::Serialize<_>>::serialize(
-        &output.proof,
-        wincode::config::Configuration::default(),
-    )
-    .expect("serialize");
+    // exactly prove_stark (prover/src/lib.rs:326-353), once per configuration type: a macro instead of a function generic in the
+    // StarkConfig (its associated commitment and digest types differ: [Felt; 4], [u8; 32], [u64; 4])
+    macro_rules! run {
+        ($name:literal, $cfg:expr, $words:expr) => {{
+            let cfg = $cfg;
+            let mut challenger = cfg.challenger();
+            config::observe_protocol_params(&mut challenger);
+            let statement = Statement::new(Multi { airs }, Vec::new(), Vec::new()).expect("statement");
+            let prover_statement = ProverStatement::new(statement, traces).expect("prover statement");
+            let output: StarkOutput<Felt, QuadFelt, _> =
+                ProverInstance::new(&cfg, &prover_statement, None).expect("instance").prove(challenger).expect("prove");
+            let bytes = <SerdeCompat<StarkProofData<Felt, QuadFelt, _>> as wincode::config::Serialize<_>>::serialize(
+                &output.proof,
+                wincode::config::Configuration::default(),
+            )
+            .expect("serialize");
 
-    // the structured view (proof.rs:214-420) for the sampled challenges, and the verifier's verdict
-    let mut vch = cfg.challenger();
-    config::observe_protocol_params(&mut vch);
-    let vinst = VerifierInstance::new(&cfg, prover_statement.statement(), None).expect("verifier instance");
-    let (stark, digest2) = StarkProof::from_data(&vinst, &output.proof, vch.clone()).expect("parse");
-    assert_eq!(output.digest, digest2);
-    let digest3 = vinst.verify(&output.proof, vch).expect("verify");
-    assert_eq!(output.digest, digest3);
+            // the structured view (proof.rs:214-420) for the sampled challenges, and the verifier's verdict
+            let mut vch = cfg.challenger();
+            config::observe_protocol_params(&mut vch);
+            let vinst = VerifierInstance::new(&cfg, prover_statement.statement(), None).expect("verifier instance");
+            let (stark, digest2) = StarkProof::from_data(&vinst, &output.proof, vch.clone()).expect("parse");
+            assert_eq!(output.digest, digest2);
+            let digest3 = vinst.verify(&output.proof, vch).expect("verify");
+            assert_eq!(output.digest, digest3);
 
-    let mut hex = String::with_capacity(2 * bytes.len());
-    for b in &bytes {
-        write!(hex, "{b:02x}").unwrap();
+            let mut hex = String::with_capacity(2 * bytes.len());
+            for b in &bytes {
+                write!(hex, "{b:02x}").unwrap();
+            }
+            let words = $words;
+            let digest: [u64; 4] = words(output.digest.into());
+            let main_c: [u64; 4] = words(stark.main_commit.into());
+            let aux_c: [u64; 4] = words(stark.aux_commit.into());
+            let quot_c: [u64; 4] = words(stark.quotient_commit.into());
+            let mut rnd = String::from("[");
+            for (i, r) in stark.randomness.iter().enumerate() {
+                if i > 0 {
+                    rnd.push(',');
+                }
+                rnd.push_str(&ef(*r));
+            }
+            rnd.push(']');
+            let json = format!(
+                "{{\"lmcs\":\"{}\",\"instances\":{inst_json},\"params\":{{\"log_blowup\":3,\"log_folding_arity\":{},\"log_final_degree\":7,\"folding_pow_bits\":{},\"deep_pow_bits\":{},\"num_queries\":27,\"query_pow_bits\":16}},\
+                 \"proof_bytes_hex\":\"{hex}\",\"digest\":{},\"randomness\":{rnd},\"alpha\":{},\"beta\":{},\"z\":{},\
+                 \"main_commit\":{},\"aux_commit\":{},\"quotient_commit\":{}}}\n",
+                $name,
+                config::LOG_FOLDING_ARITY,
+                config::FOLDING_POW_BITS,
+                config::DEEP_POW_BITS,
+                u64s(&digest),
+                ef(stark.alpha),
+                ef(stark.beta),
+                ef(stark.z),
+                u64s(&main_c),
+                u64s(&aux_c),
+                u64s(&quot_c),
+            );
+
+            json
+        }};
     }
-    let digest: [Felt; 4] = output.digest.into();
-    let main_c: [Felt; 4] = stark.main_commit.into();
-    let aux_c: [Felt; 4] = stark.aux_commit.into();
-    let quot_c: [Felt; 4] = stark.quotient_commit.into();
-    let mut rnd = String::from("[");
-    for (i, r) in stark.randomness.iter().enumerate() {
-        if i > 0 {
-            rnd.push(',');
-        }
-        rnd.push_str(&ef(*r));
-    }
-    rnd.push(']');
-    let json = format!(
-        "{{\"instances\":{inst_json},\"params\":{{\"log_blowup\":3,\"log_folding_arity\":{},\"log_final_degree\":7,\"folding_pow_bits\":{},\"deep_pow_bits\":{},\"num_queries\":27,\"query_pow_bits\":16}},\
-         \"proof_bytes_hex\":\"{hex}\",\"digest\":{},\"randomness\":{rnd},\"alpha\":{},\"beta\":{},\"z\":{},\
-         \"main_commit\":{},\"aux_commit\":{},\"quotient_commit\":{}}}\n",
-        config::LOG_FOLDING_ARITY,
-        config::FOLDING_POW_BITS,
-        config::DEEP_POW_BITS,
-        felts(&digest),
-        ef(stark.alpha),
-        ef(stark.beta),
-        ef(stark.z),
-        felts(&main_c),
-        felts(&aux_c),
-        felts(&quot_c),
-    );
+    let felt_words = |d: [Felt; 4]| d.map(|x| x.as_canonical_u64());
+    let byte_words = |d: [u8; 32]| core::array::from_fn::<u64, 4, _>(|i| u64::from_le_bytes(d[8 * i..8 * i + 8].try_into().unwrap()));
+    let lane_words = |d: [u64; 4]| d;
+    let json: String = match hasher.as_str() {
+        "poseidon2" => run!("poseidon2", config::poseidon2_config(params0, RELATION_DIGEST), felt_words),
+        "rpo" => run!("rpo", config::rpo_config(params0, RELATION_DIGEST), felt_words),
+        "rpx" => run!("rpx", config::rpx_config(params0, RELATION_DIGEST), felt_words),
+        "blake3" => run!("blake3", config::blake3_256_config(params0, RELATION_DIGEST), byte_words),
+        "keccak" => run!("keccak", config::keccak_config(params0, RELATION_DIGEST), lane_words),
+        other => panic!("unknown --hasher {other}"),
+    };
     fs::write(&args[1], json).expect("write");
-    eprintln!("wrote {} ({} proof bytes)", args[1], bytes.len());
+    eprintln!("wrote {} ({hasher})", args[1]);
 }
