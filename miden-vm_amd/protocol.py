@@ -25,3 +25,38 @@ def protocol_pre_observe(p, publics, aux_inputs=(), preprocessed_root=None):
 def challenger_state(relation_digest=(0, 0, 0, 0)):
     """The prototype challenger (air/src/config.rs:255-273): RELATION_DIGEST in the sponge capacity, state[8..12]."""
     return [0] * 8 + [int(x) for x in relation_digest]
+
+
+# ---- the host-side mirror of miden_prover's options and dispatch (prover/src/proving_options.rs, prover/src/lib.rs:246-300) ----
+class HashFunction:
+    """core/src/proof.rs:31-42, same names and discriminants."""
+    Blake3_256, Rpo256, Rpx256, Poseidon2, Keccak = 0x01, 0x02, 0x03, 0x04, 0x05
+    LMCS = {0x01: "blake3", 0x02: "rpo", 0x03: "rpx", 0x04: "poseidon2", 0x05: "keccak"}  # -> mh_ctx_set_lmcs
+
+
+class ProvingOptions:
+    """prover/src/proving_options.rs:10-46: the hash function is the only knob; the default is Blake3_256."""
+
+    def __init__(self, hash_fn=HashFunction.Blake3_256):
+        assert hash_fn in HashFunction.LMCS, "unknown hash function"
+        self._hash_fn = hash_fn
+
+    @classmethod
+    def with_96_bit_security(cls, hash_fn):
+        return cls(hash_fn)
+
+    def hash_fn(self):
+        return self._hash_fn
+
+
+def prove_stark(pkg, ctx, options, airs, traces, public_values, relation_digest, aux_builder=None):
+    """miden_prover::prove_stark behind `prove_miden_vm_execution_trace`'s match on options.hash_fn() (prover/src/lib.rs:246-355):
+    config = <hash>_config(pcs_params(), RELATION_DIGEST); challenger = config.challenger(); observe_protocol_params; prove;
+    -> StarkProofData bytes.  `airs` / `traces`: DeviceAir / Trace lists in instance order (core, chiplets, poseidon2)."""
+    ctx.set_lmcs(HashFunction.LMCS[options.hash_fn()])
+    try:
+        proof = pkg.prove(ctx, airs, traces, public_values, PROD_PARAMS, challenger_state(relation_digest),
+                          protocol_pre_observe(PROD_PARAMS, public_values), aux_builder)
+    finally:
+        ctx.set_lmcs("poseidon2")
+    return proof.bytes

@@ -154,3 +154,32 @@ def test_chiplet_stack_shape_twelve_instances(ctx):
     ok, msg = pkg.verify(airs_, got.log_trace_heights, [], prm, ob.challenger_state(), ob.protocol_pre_observe(prm, [], preprocessed_root=root),
                          got.fields, got.commitments, preprocessed_root=root, external="logup_balance")
     assert ok, msg
+
+
+def test_prove_stark_mirror_with_default_options(ctx):
+    """miden-vm_amd/protocol.py mirrors the reference's entry point: `prove_stark(ProvingOptions::default(), ..)` proves under
+    Blake3_256 (prover/src/proving_options.rs:42-46); the bytes are the oracle prover's for that configuration and every other
+    HashFunction gives different bytes that its own verifier accepts."""
+    pkg = load_package()
+    from miden_vm_amd import protocol
+    airs_ = [dag.dummy_miden_air(51, 4, num_aux_values=1), dag.dummy_miden_air(22, 3, num_aux_values=1), dag.dummy_miden_air(16, 1, num_aux_values=1)]
+    traces = [A.dummy_trace(7, 51, seed=1), A.dummy_trace(8, 22, seed=2), A.dummy_trace(6, 16, seed=3)]
+    dairs, dtr = [pkg.DeviceAir(ctx, a) for a in airs_], [ctx.upload_trace(t) for t in traces]
+    rd = KAT["relation_digest"]
+    assert protocol.ProvingOptions().hash_fn() == protocol.HashFunction.Blake3_256
+    seen = set()
+    for hf in (protocol.HashFunction.Blake3_256, protocol.HashFunction.Poseidon2, protocol.HashFunction.Keccak):
+        data = protocol.prove_stark(pkg, ctx, protocol.ProvingOptions(hf), dairs, dtr, [], rd)
+        lmcs = protocol.HashFunction.LMCS[hf]
+        ob.set_lmcs(lmcs)
+        try:
+            exp = ob.prove(airs_, traces, [], ob.PROD_PARAMS, init_state=ob.challenger_state(rd), pre_observe=ob.protocol_pre_observe(ob.PROD_PARAMS, []))
+        finally:
+            ob.set_lmcs("poseidon2")
+        assert data == pp.serialize(exp["log_heights"], exp["fields"], exp["commitments"]), lmcs
+        p = pkg.proof_from_bytes(data)
+        ok, _ = pkg.verify(airs_, p.log_trace_heights, [], ob.PROD_PARAMS, ob.challenger_state(rd), ob.protocol_pre_observe(ob.PROD_PARAMS, []),
+                           p.fields, p.commitments, lmcs=lmcs)
+        assert ok
+        seen.add(data)
+    assert len(seen) == 3
