@@ -64,6 +64,13 @@ pub struct mh_session_shape_t {
     pub final_poly_len: usize,
 }
 
+/// mh_ctx_set_lmcs / mh_verify_lmcs: the StarkConfig (air/src/config.rs:212-353) by its hash function
+pub const MH_LMCS_POSEIDON2: c_int = 0;
+pub const MH_LMCS_BLAKE3: c_int = 1;
+pub const MH_LMCS_KECCAK: c_int = 2;
+pub const MH_LMCS_RPO: c_int = 3;
+pub const MH_LMCS_RPX: c_int = 4;
+
 #[link(name = "midenhip")]
 unsafe extern "C" {
     // ---- context ----

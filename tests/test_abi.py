@@ -50,3 +50,18 @@ def test_product_never_touches_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp", ".cuh", ".h", "Makefile")):
                 src = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in src.lower(), (dp, f)
+
+
+def test_configuration_ids_agree_everywhere():
+    """MH_LMCS_* in the header, the Rust -sys constants, the ctypes layer and the reference's HashFunction mirror name the same five
+    configurations with the same numbers."""
+    h = open(os.path.join(ROOT, "include", "midenhip.h")).read()
+    ids = {k: int(v) for k, v in re.findall(r"#define MH_LMCS_([A-Z0-9]+) (\d+)", h)}
+    assert ids == {"POSEIDON2": 0, "BLAKE3": 1, "KECCAK": 2, "RPO": 3, "RPX": 4}
+    rs = open(os.path.join(ROOT, "bindings", "rust", "midenhip_sys.rs")).read()
+    assert {k: int(v) for k, v in re.findall(r"pub const MH_LMCS_([A-Z0-9]+): c_int = (\d+);", rs)} == ids
+    pkg = load_package()
+    assert {k.upper(): v for k, v in pkg.Ctx.LMCS.items()} == ids
+    from miden_vm_amd import protocol
+    assert set(protocol.HashFunction.LMCS.values()) == set(pkg.Ctx.LMCS)
+    assert protocol.HashFunction.LMCS[protocol.ProvingOptions().hash_fn()] == "blake3"
