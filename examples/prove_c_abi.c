@@ -29,9 +29,13 @@ static uint64_t node(uint64_t op, uint64_t a, uint64_t b) { return op | (a << 8)
 int main(int argc, char** argv) {
   const int log_n = argc > 1 ? atoi(argv[1]) : 12;
   const size_t width = argc > 2 ? (size_t)atoi(argv[2]) : 51, aux = argc > 3 ? (size_t)atoi(argv[3]) : 8;
+  /* the StarkConfig by its hash function (ProvingOptions of the reference): 0 Poseidon2, 1 Blake3_256 (its default), 2 Keccak,
+   * 3 Rpo256, 4 Rpx256 */
+  const int lmcs = argc > 4 ? atoi(argv[4]) : MH_LMCS_POSEIDON2;
   const size_t n = (size_t)1 << log_n;
   mh_ctx* ctx = NULL;
   CHECK(mh_ctx_create(0, &ctx));
+  CHECK(mh_ctx_set_lmcs(ctx, lmcs));
 
   /* ---- the AIR as data: header, 1 CONST + 9 MAIN leaves + 9 MUL gates, one constraint ---- */
   uint64_t blob[12 + 2 * 19 + 1];
@@ -85,11 +89,11 @@ int main(int argc, char** argv) {
     const uint8_t heights[1] = {(uint8_t)log_n};
     uint64_t vdigest[4];
     char why[256];
-    int rc = mh_verify(&params, 1, blobs, blob_words, heights, NULL, 0, state, pre, 11, mh_proof_fields(proof),
-                       mh_proof_num_fields(proof), mh_proof_commitments(proof), mh_proof_num_commitments(proof), NULL, vdigest, why,
-                       sizeof why);
+    int rc = mh_verify_lmcs(lmcs, &params, 1, blobs, blob_words, heights, NULL, 0, state, pre, 11, mh_proof_fields(proof),
+                            mh_proof_num_fields(proof), mh_proof_commitments(proof), mh_proof_num_commitments(proof), NULL, NULL, NULL,
+                            vdigest, why, sizeof why);
     if (rc != MH_OK || vdigest[0] != d[0] || vdigest[3] != d[3]) {
-      fprintf(stderr, "mh_verify: %s\n", rc != MH_OK ? why : "digest mismatch");
+      fprintf(stderr, "mh_verify_lmcs: %s\n", rc != MH_OK ? why : "digest mismatch");
       return 1;
     }
     printf("verified\n");

@@ -42,14 +42,19 @@ def test_header_is_plain_c_and_example_links(tmp_path):
 
 
 @pytest.mark.gpu
-def test_c_program_proves_and_matches_oracle(tmp_path):
+@pytest.mark.parametrize("lmcs", ["poseidon2", "blake3"])
+def test_c_program_proves_and_matches_oracle(tmp_path, lmcs):
     exe = build_example(tmp_path)
     log_n, width, aux = 9, 11, 2
-    out = subprocess.check_output([exe, str(log_n), str(width), str(aux)], text=True)
+    out = subprocess.check_output([exe, str(log_n), str(width), str(aux), str({"poseidon2": 0, "blake3": 1}[lmcs])], text=True)
     m = re.search(r"digest ([0-9a-f]{16}) ([0-9a-f]{16}) ([0-9a-f]{16}) ([0-9a-f]{16})", out)
     assert m, out
     got = [int(g, 16) for g in m.groups()]
-    exp = ob.prove([dag.dummy_miden_air(width, aux)], [lcg_trace(log_n, width)], [], ob.PROD_PARAMS)
+    ob.set_lmcs(lmcs)
+    try:
+        exp = ob.prove([dag.dummy_miden_air(width, aux)], [lcg_trace(log_n, width)], [], ob.PROD_PARAMS)
+    finally:
+        ob.set_lmcs("poseidon2")
     assert got == [int(x) for x in exp["digest"]], out
     nf = int(re.search(r"(\d+) fields", out).group(1))
     assert nf == exp["fields"].size
