@@ -213,6 +213,33 @@ __global__ __launch_bounds__(256) void k_compress_b3(const u64* __restrict__ in,
   for (int i = 0; i < 4; i++) out[4 * q + i] = (u64)o[2 * i] | ((u64)o[2 * i + 1] << 32);
 }
 
+// The top of a Blake3 tree in ONE launch: levels d_start .. 0 (<= 256 nodes each, natural order) by one workgroup, a barrier
+// between levels.  A node is one 64-byte block (~0.7 k instructions): at these sizes a level is all launch latency, 8-9 launches
+// per tree, 10 trees per proof.  Layer d starts at digest (2^(L+1) - 2^(d+1)) of the node array (lmcs_alloc_layers).
+__global__ __launch_bounds__(256) void k_compress_b3_top(u64* nodes, int log_height, int d_start) {
+  const size_t two_l1 = (size_t)2 << log_height;
+  for (int d = d_start; d >= 0; d--) {
+    const size_t n_out = (size_t)1 << d;
+    const u64* in = nodes + 4 * (two_l1 - ((size_t)2 << (d + 1)));
+    u64* out = nodes + 4 * (two_l1 - ((size_t)2 << d));
+    const size_t q = threadIdx.x;
+    if (q < n_out) {
+      uint32_t a[8], b[8], o[8];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const u64 x = in[8 * q + i], y = in[8 * q + 4 + i];
+        a[2 * i] = (uint32_t)x; a[2 * i + 1] = (uint32_t)(x >> 32);
+        b[2 * i] = (uint32_t)y; b[2 * i + 1] = (uint32_t)(y >> 32);
+      }
+      b3::compress_pair(a, b, o);
+#pragma unroll
+      for (int i = 0; i < 4; i++) out[4 * q + i] = (u64)o[2 * i] | ((u64)o[2 * i + 1] << 32);
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
 // ---- RPO / RPX (MH_LMCS_RPO, MH_LMCS_RPX): the sponge and the compression of the Poseidon2 LMCS with the Rescue permutations
 // (rescue.cuh; plain arithmetic, one state per lane -- supported, not tuned) ----
 __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_absorb_alg(LeafArgs a, int lmcs) {
@@ -415,7 +442,10 @@ void lmcs_compress_layers(mh_ctx* c, mh_tree* t) {
       else if (c->lmcs == MH_LMCS_KECCAK)
         MH_LAUNCH(k_compress_kk, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream,
                            t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
-      else if (c->lmcs == MH_LMCS_BLAKE3)
+      else if (c->lmcs == MH_LMCS_BLAKE3 && n_out <= 256 && log_n_coset < 0) {
+        MH_LAUNCH(k_compress_b3_top, dim3(1), dim3(256), 0, c->stream, t->nodes.u(), t->log_height, d);
+        break;  // that launch went down to the root
+      } else if (c->lmcs == MH_LMCS_BLAKE3)
         MH_LAUNCH(k_compress_b3, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream,
                            t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
       else if (n_out <= COMPRESS_LANES_MAX_NODES)
