@@ -278,3 +278,25 @@ def test_device_pow_search_for_hash_challengers(lmcs):
     with pytest.raises(pkg.MidenHipError, match="hash challenger"):
         pkg.grind_bytes(ctx, b"abc", 4)
     ctx.close()
+
+
+def test_blake3_random_inputs_against_llvm_when_present():
+    """Beyond the committed vectors: where the image ships LLVM's copy of the official C implementation (libLLVM-15), 300 random
+    byte strings of random lengths (0 .. 9000) through the oracle's and the product's BLAKE3 against it.  Skips elsewhere."""
+    import ctypes as C
+    try:
+        L = C.CDLL("/usr/lib/x86_64-linux-gnu/libLLVM-15.so.1")
+        L.llvm_blake3_hasher_init
+    except (OSError, AttributeError):
+        pytest.skip("no libLLVM-15 with llvm_blake3_* in this image")
+    pkg = load_package()
+    rng = np.random.default_rng(99)
+    for _ in range(300):
+        n = int(rng.integers(0, 9000))
+        data = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        st = C.create_string_buffer(4096)
+        L.llvm_blake3_hasher_init(st)
+        L.llvm_blake3_hasher_update(st, data, C.c_size_t(n))
+        out = C.create_string_buffer(32)
+        L.llvm_blake3_hasher_finalize(st, out, C.c_size_t(32))
+        assert ob.blake3(data) == out.raw == pkg.blake3(data), n
