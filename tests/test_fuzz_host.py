@@ -56,6 +56,42 @@ CHILD = textwrap.dedent('''
         # a damaged word may leave the AIR's meaning intact (the unused payload word of a gate, a width inside the same
         # 8-column alignment, a dead node): most are rejected, none may crash
         assert n_rejected >= 0.6 * n_total
+    elif mode.startswith("proof:"):
+        # damaged transcripts through the verifier of every configuration (its own challenger, leaf hashing and alignment)
+        lmcs = mode.split(":")[1]
+        t, pub = A.fib_trace(6)
+        a5, tr5 = A.prep_air(5, num_public=3)
+        airs_, traces = [A.periodic_air(3), A.fib_air(), a5], [A.periodic_trace(5), t, tr5()]
+        ob.set_lmcs(lmcs)
+        proof = ob.prove(airs_, traces, pub, PRM)
+        root = ob.preprocessed_commitment(airs_, proof["log_heights"], PRM)
+        ob.set_lmcs("poseidon2")
+        pre = ob.protocol_pre_observe(PRM, pub, preprocessed_root=root)
+        lhs, f0, c0 = proof["log_heights"], proof["fields"], proof["commitments"]
+        assert pkg.verify(airs_, lhs, pub, PRM, ob.challenger_state(), pre, f0, c0, preprocessed_root=root, lmcs=lmcs)[0]
+        n_rej = 0
+        for it in range(250):
+            f, c, h = f0.copy(), c0.copy(), list(lhs)
+            kind = int(rng.integers(0, 7))
+            if kind == 0:
+                f = f[:int(rng.integers(0, f.size))]
+            elif kind == 1:
+                c = c[:int(rng.integers(0, c.shape[0]))]
+            elif kind == 2:
+                f = np.concatenate([f, rng.integers(0, 2**63, int(rng.integers(1, 20)), dtype=np.uint64)])
+            elif kind == 3:
+                c[int(rng.integers(0, c.shape[0])), int(rng.integers(0, 4))] = np.uint64(int(rng.integers(0, 2**63)) * 2 + 1)
+            elif kind == 4:
+                f[int(rng.integers(0, f.size))] = np.uint64(2**64 - 1 - int(rng.integers(0, 2**32)))   # non-canonical felt
+            elif kind == 5:
+                h[int(rng.integers(0, len(h)))] = int(rng.integers(0, 40))
+            else:
+                for _ in range(3):
+                    f[int(rng.integers(0, f.size))] = np.uint64(int(rng.integers(0, 2**63)))
+            ok, _ = pkg.verify(airs_, h, pub, PRM, ob.challenger_state(), pre, f, c, preprocessed_root=root, lmcs=lmcs)
+            n_rej += not ok
+        print("proof", lmcs, n_rej)
+        assert n_rej >= 240  # (a damaged height equal to the old one, or a rewritten felt equal to the old one, changes nothing)
     else:
         import proof_parser as pp
         t, pub = A.fib_trace(6)
@@ -99,3 +135,12 @@ def test_damaged_constraint_blobs_are_rejected_not_crashed():
 def test_damaged_proof_bytes_are_rejected_not_crashed():
     out = run_child("bytes", 2)
     assert "bytes" in out
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("lmcs", ["poseidon2", "blake3", "keccak", "rpo"])
+def test_damaged_transcripts_are_rejected_not_crashed(lmcs):
+    out = run_child("proof:" + lmcs, 3)
+    assert "proof " + lmcs in out
