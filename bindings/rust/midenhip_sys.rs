@@ -111,6 +111,7 @@ unsafe extern "C" {
     pub fn mh_shard_leaf_digests(s: *mut mh_shard, n_digests: *mut usize) -> *mut u64;
     pub fn mh_shard_build_subtree(ctx: *mut mh_ctx, s: *mut mh_shard, digests_device: *const u64, subroot: *mut u64) -> c_int;
     pub fn mh_merkle_cap_root(subroots: *const u64, world: c_int, root: *mut u64) -> c_int;
+    pub fn mh_merkle_cap_root_lmcs(lmcs: c_int, subroots: *const u64, world: c_int, root: *mut u64) -> c_int;
     // ---- AIRs, lookups ----
     pub fn mh_air_load(ctx: *mut mh_ctx, blob: *const u64, n_words: usize, out: *mut *mut mh_air) -> c_int;
     pub fn mh_air_free(air: *mut mh_air);
@@ -151,6 +152,7 @@ unsafe extern "C" {
     pub fn mh_comm_destroy(comm: *mut mh_comm);
     pub fn mh_local_fabric_create(world: c_int) -> *mut mh_local_fabric;
     pub fn mh_local_fabric_destroy(f: *mut mh_local_fabric);
+    pub fn mh_local_fabric_abort(f: *mut mh_local_fabric);
     pub fn mh_comm_create_local(ctx: *mut mh_ctx, f: *mut mh_local_fabric, rank: c_int, out: *mut *mut mh_comm) -> c_int;
     pub fn mh_comm_selftest(ctx: *mut mh_ctx, comm: *const mh_comm) -> c_int;
     pub fn mh_proof_free(p: *mut mh_proof);

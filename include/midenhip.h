@@ -144,8 +144,10 @@ void mh_shard_free(mh_shard* s);
 uint64_t* mh_shard_leaf_digests(mh_shard* s, size_t* n_digests);
 /* digests_device: DEVICE pointer to the exchanged digests [B][N/world] x 4 felts. */
 int mh_shard_build_subtree(mh_ctx* ctx, mh_shard* s, const uint64_t* digests_device, uint64_t subroot[4]);
-/* Host only (no GPU needed): Merkle root over `world` subroots given in rank order. */
+/* Host only (no GPU needed): Merkle root over `world` subroots given in rank order, Poseidon2 nodes ... */
 int mh_merkle_cap_root(const uint64_t* subroots, int world, uint64_t root[4]);
+/* ... and under any LMCS hasher (MH_LMCS_*): the one the context of mh_shard_commit_leaves / mh_shard_build_subtree was set to. */
+int mh_merkle_cap_root_lmcs(int lmcs, const uint64_t* subroots, int world, uint64_t root[4]);
 
 /* ---- AIRs as data: the constraint DAG blob "MHDAG001" ------------------------------------------ */
 /* The Rust side captures `air.eval` once on a symbolic builder (the route of
@@ -259,6 +261,10 @@ typedef struct mh_local_fabric mh_local_fabric;
 mh_local_fabric* mh_local_fabric_create(int world);
 void mh_local_fabric_destroy(mh_local_fabric* f); /* after every rank's communicator has been destroyed */
 int mh_comm_create_local(mh_ctx* ctx, mh_local_fabric* f, int rank, mh_comm** out);
+/* Marks the fabric dead and wakes every rank waiting in a collective (they return an error).  Call it from a rank's error path
+ * -- a failed session step, a rank that will never reach the next collective -- so that its peers do not block for ever.  A failed
+ * mh_comm_create_local and a failed collective do this themselves.  Sticky: create a new fabric to continue. */
+void mh_local_fabric_abort(mh_local_fabric* f);
 int mh_comm_selftest(mh_ctx* ctx, const mh_comm* comm);
 /* mh_commit_traces for one rank of a sharded prover (every rank calls it with the same traces): the setup commitment
  * of preprocessed matrices for mh_prove_sharded / sharded sessions.  Same root as mh_commit_traces. */

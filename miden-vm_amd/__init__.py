@@ -26,14 +26,14 @@ EXPORTS = [
     "mh_tree_download_layers", "mh_air_load", "mh_air_free", "mh_air_log_quotient_degree", "mh_air_compiled_chunks", "mh_prove", "mh_proof_free",
     "mh_proof_num_fields", "mh_proof_num_commitments", "mh_proof_fields", "mh_proof_commitments", "mh_proof_digest",
     "mh_proof_num_traces", "mh_proof_log_trace_heights", "mh_proof_serialize", "mh_shard_commit_leaves", "mh_shard_free",
-    "mh_shard_leaf_digests", "mh_shard_build_subtree", "mh_merkle_cap_root", "mh_prove_sharded", "mh_commit_traces_sharded",
+    "mh_shard_leaf_digests", "mh_shard_build_subtree", "mh_merkle_cap_root", "mh_merkle_cap_root_lmcs", "mh_prove_sharded", "mh_commit_traces_sharded",
     "mh_session_begin", "mh_session_free", "mh_session_shape", "mh_session_commit_main", "mh_session_commit_aux",
     "mh_session_commit_quotient", "mh_session_ood_point_ok", "mh_session_ood", "mh_session_deep", "mh_session_fri_commit",
     "mh_session_fri_fold", "mh_session_fri_final", "mh_session_open", "mh_grind",
     "mh_host_alloc", "mh_host_free", "mh_verify", "mh_trace_from_device", "mh_lookup_load", "mh_lookup_free", "mh_air_attach_lookup", "mh_air_attach_preprocessed", "mh_lookup_build_aux", "mh_trace_download",
     "mh_verify_ex", "mh_external_logup_balance", "mh_proof_deserialize", "mh_ctx_set_lmcs", "mh_ctx_get_lmcs", "mh_blake3", "mh_verify_lmcs", "mh_grind_bytes",
     "mh_rccl_unique_id", "mh_comm_create_rccl", "mh_comm_destroy", "mh_comm_selftest",
-    "mh_local_fabric_create", "mh_local_fabric_destroy", "mh_comm_create_local",
+    "mh_local_fabric_create", "mh_local_fabric_destroy", "mh_local_fabric_abort", "mh_comm_create_local",
 ]
 
 _lib = None
@@ -101,6 +101,7 @@ class Ctx:
         if rc != 0:
             raise MidenHipError(f"mh_ctx_create failed with code {rc}")
         self.h = h
+        self.lmcs_id = 0
         self._children = weakref.WeakSet()  # device objects that must be freed before the ctx
 
     def check(self, rc):
@@ -168,6 +169,7 @@ class Ctx:
         """mh_ctx_set_lmcs: the commitment scheme's hasher for commit_traces / tree openings on this context ("poseidon2" |
         "blake3" = the reference's default Blake3_256 configuration, air/src/config.rs:275-289)."""
         self.check(self.lib.mh_ctx_set_lmcs(self.h, self.LMCS[name]))
+        self.lmcs_id = self.LMCS[name]
 
     def upload_trace(self, matrix):
         return Trace(self, matrix)

@@ -19,7 +19,8 @@
 namespace b3 {
 
 enum : uint32_t { CHUNK_START = 1, CHUNK_END = 2, PARENT = 4, ROOT = 8 };
-static constexpr int MAX_STACK = 8;  // chaining values of completed subtrees: messages up to 2^8 chunks = 256 KB
+static constexpr int MAX_STACK = 8;   // device streams: chaining values of completed subtrees, messages up to 2^8 chunks = 256 KiB
+static constexpr int HOST_STACK = 54;  // host streams: any message the specification allows (2^64 bytes = 2^54 chunks)
 
 B3_HD uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 B3_HD uint32_t iv(int i) {
@@ -87,9 +88,10 @@ B3_HD void parent_cv(const uint32_t l[8], const uint32_t r[8], uint32_t out[8], 
 
 // Streaming hasher over 64-byte blocks handed in as 16 little-endian words.  The caller says which block is the last one
 // of the message (and its length in bytes); chunk boundaries (16 blocks) and the tree above them are handled here.
-struct Stream {
+template <int STACK>
+struct StreamT {
   uint32_t cv[8];
-  uint32_t stack[MAX_STACK][8];
+  uint32_t stack[STACK][8];
   int sp;
   uint32_t chunk, blk_in_chunk;
   B3_HD void init() {
@@ -148,10 +150,12 @@ struct Stream {
     sp = 0;
   }
 };
+using Stream = StreamT<MAX_STACK>;      // kernels (rows of at most 256 KiB: checked where leaves are hashed) and kernel arguments
+using HostStream = StreamT<HOST_STACK>;  // host: transcripts, verifier leaves, mh_blake3 -- no length limit
 
-// plain byte-string hash (host side: the cap of a sharded tree, the verifier, tests)
+// plain byte-string hash (host side: the cap of a sharded tree, the challenger, the verifier, tests); any length
 inline void hash_bytes(const uint8_t* p, size_t n, uint8_t out32[32]) {
-  Stream s;
+  HostStream s;
   s.init();
   size_t off = 0;
   uint32_t m[16];

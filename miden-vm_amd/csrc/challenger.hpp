@@ -91,6 +91,17 @@ struct HostChallenger {
     in.push_back(gl_canon(x));
     if (in.size() == 8) duplexing();
   }
+  // A word of the statement framing observed before the proof starts (protocol parameters, public values, a setup
+  // commitment: prover/mod.rs:252-286).  Felts are canonical by contract; a byte configuration's setup commitment is four
+  // words that are NOT felts and goes in as its raw bytes, exactly as the reference observes the 32-byte digest.
+  void observe_framing(u64 x) {
+    if (bytes()) {
+      bout.clear();
+      for (int i = 0; i < 8; i++) bin.push_back((uint8_t)(x >> (8 * i)));
+      return;
+    }
+    observe(x);
+  }
   void observe_digest(const u64 d[4]) {
     if (bytes()) {  // 32 raw bytes: the words of a byte digest are not field elements
       bout.clear();

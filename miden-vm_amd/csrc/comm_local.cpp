@@ -25,16 +25,26 @@ struct mh_local_fabric {
   std::vector<void*> recv;
   std::vector<hipEvent_t> ready, done;
   std::vector<int> joined;
-  void barrier() {
+  // false = the fabric has been aborted (a rank failed or left): nobody waits for that rank any more
+  bool barrier() {
     std::unique_lock<std::mutex> lk(mu);
+    if (failed) return false;
     const unsigned long g = generation;
     if (++arrived == world) {
       arrived = 0;
       generation++;
       cv.notify_all();
     } else {
-      cv.wait(lk, [&] { return generation != g; });
+      cv.wait(lk, [&] { return generation != g || failed; });
     }
+    return !failed;
+  }
+  void abort() {  // sticky: a fabric that lost a rank is dead; waiting ranks wake up and report an error
+    {
+      std::lock_guard<std::mutex> g(mu);
+      failed = true;
+    }
+    cv.notify_all();
   }
 };
 
@@ -62,6 +72,11 @@ void copy_from_peer(LocalComm* lc, int p, void* dst, const void* src, size_t byt
   else HIP_CHECK(hipMemcpyPeerAsync(dst, lc->ctx->device, src, f->ctx[p]->device, bytes, lc->ctx->stream));
 }
 
+int fail_aborted(LocalComm* lc) {
+  if (lc->ctx->err.empty()) lc->ctx->err = "local fabric aborted: another rank failed or left the collective";
+  return 1;
+}
+
 // common frame: publish, barrier, body (enqueue copies), done event, barrier, wait for the peers' done events
 template <class Body>
 int collective(LocalComm* lc, const void* send, void* recv, Body body) {
@@ -77,24 +92,22 @@ int collective(LocalComm* lc, const void* send, void* recv, Body body) {
   }
   f->send[r] = send;
   f->recv[r] = recv;
-  if (rc) f->failed = true;
-  f->barrier();
-  if (!f->failed) {
-    try {
-      body();
-      HIP_CHECK(hipEventRecord(f->done[r], lc->ctx->stream));
-    } catch (const std::exception& e) {
-      lc->ctx->err = e.what();
-      f->failed = true;
-    }
+  if (rc) f->abort();
+  if (!f->barrier()) return fail_aborted(lc);
+  try {
+    body();
+    HIP_CHECK(hipEventRecord(f->done[r], lc->ctx->stream));
+  } catch (const std::exception& e) {
+    lc->ctx->err = e.what();
+    f->abort();
   }
-  f->barrier();
-  if (f->failed) return 1;
+  if (!f->barrier()) return fail_aborted(lc);
   try {
     for (int p = 0; p < f->world; p++)
       if (p != r) HIP_CHECK(hipStreamWaitEvent(lc->ctx->stream, f->done[p], 0));  // my buffers have been read
   } catch (const std::exception& e) {
     lc->ctx->err = e.what();
+    f->abort();
     return 1;
   }
   return 0;
@@ -126,7 +139,7 @@ int local_all_reduce(void* user, uint64_t* buf, size_t n) {
     }
   } catch (const std::exception& e) {
     lc->ctx->err = e.what();
-    lc->f->failed = true;
+    lc->f->abort();
   }
   // gather every rank's vector into the staging area; the sum overwrites `buf` only after all peers have read it
   const int rc = collective(lc, buf, buf, [&] {
@@ -159,6 +172,9 @@ mh_local_fabric* mh_local_fabric_create(int world) {
   return f;
 }
 void mh_local_fabric_destroy(mh_local_fabric* f) { delete f; }
+void mh_local_fabric_abort(mh_local_fabric* f) {
+  if (f) f->abort();
+}
 
 int mh_comm_create_local(mh_ctx* c, mh_local_fabric* f, int rank, mh_comm** out) {
   if (!c || !f || !out || rank < 0 || rank >= f->world) return MH_ERR_INVALID;
@@ -172,7 +188,8 @@ int mh_comm_create_local(mh_ctx* c, mh_local_fabric* f, int rank, mh_comm** out)
       HIP_CHECK(hipEventCreateWithFlags(&f->ready[rank], hipEventDisableTiming));
       HIP_CHECK(hipEventCreateWithFlags(&f->done[rank], hipEventDisableTiming));
     }
-    f->barrier();  // every rank has joined: peers' contexts and events are known from here on
+    // every rank has joined: peers' contexts and events are known from here on
+    MH_REQUIRE(f->barrier(), "local fabric aborted while ranks were joining");
     for (int p = 0; p < f->world; p++)
       if (f->ctx[p]->device != c->device) {
         int can = 0;
@@ -197,9 +214,11 @@ int mh_comm_create_local(mh_ctx* c, mh_local_fabric* f, int rank, mh_comm** out)
     return MH_OK;
   } catch (const MhError& e) {
     c->err = e.what();
+    f->abort();  // the other ranks must not wait for this one
     return e.code;
   } catch (const std::exception& e) {
     c->err = e.what();
+    f->abort();
     return MH_ERR_INTERNAL;
   }
 }

@@ -391,6 +391,9 @@ u64 fri_grind_bytes(mh_ctx* c, int lmcs, const std::vector<uint8_t>& prefix, int
   GrindB3Args ab{};
   GrindKkArgs ak{};
   if (lmcs == MH_LMCS_BLAKE3) {
+    // the device stream (a kernel argument) keeps MAX_STACK chaining values: fewer than 2^MAX_STACK chunks of 1 KiB
+    MH_REQUIRE(prefix.size() + 8 <= ((size_t)1024 << b3::MAX_STACK) - 1024,
+               "Blake3 PoW search: more than 255 KiB observed since the last sample (device stream stack)");
     ab.pre.init();
     const size_t k = prefix.size() / 64;
     for (size_t b = 0; b < k; b++) {

@@ -88,6 +88,7 @@ void lmcs_open(mh_ctx* c, const mh_tree* t, const std::vector<size_t>& sorted_un
 // Sharded tree build: local leaf digests [2^lbl][2^log_rows] -> all-to-all -> subtree over this rank's
 // row range -> all-gather of subroots -> cap on the host.  t->log_blowup = global coset bits.
 void lmcs_build_sharded(mh_ctx* c, mh_tree* t, const Dist& dist, const u64* local_digests, int log_rows);
+void lmcs_host_compress(int lmcs, const u64* pair, u64* out);
 std::vector<std::pair<int, size_t>> lmcs_missing_siblings(const std::vector<size_t>& sorted_unique_idx, int depth);
 
 // ---- prover.hip (commit helpers shared with the C ABI) -------------------------------------------

@@ -635,6 +635,23 @@ __global__ void k_repack_digests(const ulonglong2* __restrict__ in, ulonglong2* 
   out[2 * o + 1] = in[2 * q + 1];
 }
 
+// One 2-to-1 node on the HOST under hasher `lmcs` (MH_LMCS_*): pair = left || right (8 words), out = 4 words.  Byte
+// digests (Blake3, Keccak) are never canonicalised: their words are not field elements.
+void lmcs_host_compress(int lmcs, const u64* pair, u64* out) {
+  u64 st[12] = {0};
+  if (lmcs == MH_LMCS_KECCAK) {
+    kk::compress_pair(pair, pair + 4, st);
+  } else if (lmcs == MH_LMCS_BLAKE3) {
+    uint8_t dg[32];
+    b3::hash_bytes(reinterpret_cast<const uint8_t*>(pair), 64, dg);  // little-endian host: a digest's u64s are its bytes
+    memcpy(st, dg, 32);
+  } else {
+    for (int k = 0; k < 8; k++) st[k] = pair[k];
+    alg_permute(lmcs, st);
+  }
+  memcpy(out, st, 32);
+}
+
 void lmcs_build_sharded(mh_ctx* c, mh_tree* t, const Dist& dist, const u64* local_digests, int log_rows) {
   const int G = dist.logG, lb = t->log_blowup, lbl = lb - G;
   MH_REQUIRE(G > 0 && lbl >= 0 && log_rows >= G, "internal: bad sharded tree shape");
@@ -653,19 +670,8 @@ void lmcs_build_sharded(mh_ctx* c, mh_tree* t, const Dist& dist, const u64* loca
   HIP_CHECK(hipStreamSynchronize(c->stream));
   for (int d = G - 1; d >= 0; d--)
     for (size_t p = 0; p < ((size_t)1 << d); p++) {
-      u64 st[12] = {0};
       const u64* l = t->cap.data() + 4 * ((((size_t)2) << d) - 1 + 2 * p);
-      if (c->lmcs == MH_LMCS_KECCAK) {
-        kk::compress_pair(l, l + 4, st);
-      } else if (c->lmcs == MH_LMCS_BLAKE3) {
-        uint8_t dg[32];
-        b3::hash_bytes(reinterpret_cast<const uint8_t*>(l), 64, dg);  // little-endian host: a digest's u64s are its bytes
-        memcpy(st, dg, 32);
-      } else {
-        for (int k = 0; k < 8; k++) st[k] = l[k];
-        alg_permute(c->lmcs, st);
-      }
-      memcpy(t->cap.data() + 4 * ((((size_t)1) << d) - 1 + p), st, 32);
+      lmcs_host_compress(c->lmcs, l, t->cap.data() + 4 * ((((size_t)1) << d) - 1 + p));
     }
   memcpy(t->root, t->cap.data(), 32);
   t->shard_logG = G;

@@ -436,6 +436,7 @@ static void launch_pass(mh_ctx* c, NttPassArgs a, size_t n_cols, size_t n_z) {
   size_t tiles = (size_t)1 << (a.log_n - a.r_bits - a.cb);
   // the workgroup loops over the output cosets; they are spread over grid.z only as far as it takes to fill the chip
   // (a quotient chunk is 2 columns: 512 workgroups at 2^20 otherwise)
+  MH_REQUIRE(n_z >= 1 && (n_z & (n_z - 1)) == 0, "internal: the number of output cosets of a pass must be a power of two");
   size_t zsplit = 1;
   while (zsplit < n_z && tiles * n_cols * zsplit < 4096) zsplit *= 2;
   a.n_z = (u32)(n_z / zsplit);

@@ -636,7 +636,7 @@ static void prove_impl(mh_ctx* c, const mh_pcs_params& pp, int n_airs, mh_air* c
   HostTranscript tr;
   tr.ch.hash = c->lmcs;
   tr.ch.init_from_state(init_state);
-  for (size_t i = 0; i < n_pre; i++) tr.ch.observe(pre_observe[i]);
+  for (size_t i = 0; i < n_pre; i++) tr.ch.observe_framing(pre_observe[i]);
   tr.ch.observe((u64)n_airs);  // order.rs:154-163
   for (int i = 0; i < n_airs; i++) tr.ch.observe((u64)s.lhs[i]);
 
@@ -846,22 +846,24 @@ int mh_shard_build_subtree(mh_ctx* c, mh_shard* s, const uint64_t* digests_devic
   s->subtree = std::move(t);
   MH_CATCH
 }
-// Root of the cap: `world` subtree roots (rank order = domain order) -> the commitment (host only).
-int mh_merkle_cap_root(const uint64_t* subroots, int world, uint64_t root[4]) {
-  if (!subroots || !root || world < 1 || (world & (world - 1))) return MH_ERR_INVALID;
+// Root of the cap: `world` subtree roots (rank order = domain order) -> the commitment (host only), under the hasher the
+// subtrees were built with (MH_LMCS_*; mh_shard_commit_leaves / mh_shard_build_subtree follow the context's).
+int mh_merkle_cap_root_lmcs(int lmcs, const uint64_t* subroots, int world, uint64_t root[4]) {
+  if (!subroots || !root || world < 1 || (world & (world - 1)) || lmcs < 0 || lmcs > MH_LMCS_RPX) return MH_ERR_INVALID;
   std::vector<u64> cur(subroots, subroots + 4 * (size_t)world);
+  const bool felts = lmcs != MH_LMCS_BLAKE3 && lmcs != MH_LMCS_KECCAK;
+  if (felts)
+    for (auto& x : cur) x = gl_canon(x);
   for (int n = world; n > 1; n >>= 1) {
     std::vector<u64> next(4 * (size_t)(n / 2));
-    for (int i = 0; i < n / 2; i++) {
-      u64 st[12] = {0};
-      for (int k = 0; k < 4; k++) { st[k] = gl_canon(cur[8 * i + k]); st[4 + k] = gl_canon(cur[8 * i + 4 + k]); }
-      p2_permute(st);
-      for (int k = 0; k < 4; k++) next[4 * i + k] = st[k];
-    }
+    for (int i = 0; i < n / 2; i++) lmcs_host_compress(lmcs, cur.data() + 8 * i, next.data() + 4 * i);
     cur.swap(next);
   }
   memcpy(root, cur.data(), 32);
   return MH_OK;
+}
+int mh_merkle_cap_root(const uint64_t* subroots, int world, uint64_t root[4]) {
+  return mh_merkle_cap_root_lmcs(MH_LMCS_POSEIDON2, subroots, world, root);
 }
 
 // commit_traces for one rank of a sharded prover: the setup-time commitment of preprocessed matrices when proofs are

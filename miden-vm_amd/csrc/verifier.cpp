@@ -550,12 +550,12 @@ static int verify_entry(int lmcs, const mh_pcs_params* params, int n_airs, const
     Reader rd;
     rd.ch.hash = lmcs;
     rd.ch.init_from_state(challenger_state);
-    for (size_t i = 0; i < n_pre_observe; i++) rd.ch.observe(pre_observe[i]);
+    for (size_t i = 0; i < n_pre_observe; i++) rd.ch.observe_framing(pre_observe[i]);
     rd.f = fields; rd.nf = n_fields;
     rd.c = commitments; rd.nc = n_commitments;
     u64 proot[4];
     if (preprocessed_root)
-      for (int i = 0; i < 4; i++) proot[i] = gl_canon(preprocessed_root[i]);
+      for (int i = 0; i < 4; i++) proot[i] = rd.ch.bytes() ? preprocessed_root[i] : gl_canon(preprocessed_root[i]);  // byte digests are not felts
     verify_impl(*params, airs, lhs, std::vector<u64>(public_values, public_values + n_public_values), preprocessed_root ? proot : nullptr,
                 rd, external, external_user, digest);
     if (err && err_cap) err[0] = 0;

@@ -49,14 +49,32 @@ class ProvingOptions:
         return self._hash_fn
 
 
-def prove_stark(pkg, ctx, options, airs, traces, public_values, relation_digest, aux_builder=None):
+def miden_statement_pre_observe(p, public_values, aux_inputs, kernel_h):
+    """The framing of a REAL Miden statement: observe_protocol_params, then `MidenMultiAir::observe` (air/src/lib.rs:817-849),
+    a rate-aligned schedule of six 8-felt blocks: [kernel_H | program_hash] [deferred_root | 0 0 0 0] [stack inputs (16)]
+    [stack outputs (16)].  `public_values` = the 32 stack-io felts (NUM_PUBLIC_VALUES, air/src/lib.rs:271); `aux_inputs` =
+    program_hash (4) | deferred_root (4) | kernel digests...; `kernel_h` = hash_elements of the kernel-digest felts
+    (hash_kernel_digests, air/src/lib.rs:946-961) -- computed by the caller, whose Rust side owns that hash."""
+    assert len(public_values) == 32 and len(aux_inputs) >= 8 and len(kernel_h) == 4
+    pre = protocol_pre_observe(p, [])[:8]
+    pre += [int(x) for x in kernel_h] + [int(x) for x in aux_inputs[0:4]]
+    pre += [int(x) for x in aux_inputs[4:8]] + [0, 0, 0, 0]
+    return pre + [int(x) for x in public_values]
+
+
+def prove_stark(pkg, ctx, options, airs, traces, public_values, relation_digest, aux_builder=None, pre_observe=None):
     """miden_prover::prove_stark behind `prove_miden_vm_execution_trace`'s match on options.hash_fn() (prover/src/lib.rs:246-355):
     config = <hash>_config(pcs_params(), RELATION_DIGEST); challenger = config.challenger(); observe_protocol_params; prove;
-    -> StarkProofData bytes.  `airs` / `traces`: DeviceAir / Trace lists in instance order (core, chiplets, poseidon2)."""
+    -> StarkProofData bytes.  `airs` / `traces`: DeviceAir / Trace lists in instance order (core, chiplets, poseidon2).
+
+    Statement framing: by DEFAULT this helper frames the statement the way the default `MultiAir::observe` does
+    (crates/lifted-air/src/air.rs:307-324: len, inputs, 0, 0) -- right for the DummyMidenAir fixtures of benches/miden-bench, NOT
+    for the real Miden statement, whose `MidenMultiAir` overrides `observe`: pass `pre_observe=miden_statement_pre_observe(..)`
+    for that (the aux inputs enter the transcript only through it; the proof system itself never reads them)."""
     ctx.set_lmcs(HashFunction.LMCS[options.hash_fn()])
     try:
-        proof = pkg.prove(ctx, airs, traces, public_values, PROD_PARAMS, challenger_state(relation_digest),
-                          protocol_pre_observe(PROD_PARAMS, public_values), aux_builder)
+        pre = pre_observe if pre_observe is not None else protocol_pre_observe(PROD_PARAMS, public_values)
+        proof = pkg.prove(ctx, airs, traces, public_values, PROD_PARAMS, challenger_state(relation_digest), pre, aux_builder)
     finally:
         ctx.set_lmcs("poseidon2")
     return proof.bytes

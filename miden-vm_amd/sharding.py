@@ -57,13 +57,14 @@ def gather_subroots(subroot, world, group=None, device="cpu"):
     return torch.stack(out).cpu().numpy().view(np.uint64)
 
 
-def cap_root(lib, subroots):
+def cap_root(lib, subroots, lmcs=0):
+    """Root over the ranks' subroots under LMCS hasher `lmcs` (MH_LMCS_*: the id of the context the subtrees were built on)."""
     s = np.ascontiguousarray(subroots, dtype=np.uint64)
     root = np.zeros(4, dtype=np.uint64)
     u64p = C.POINTER(C.c_uint64)
-    rc = lib.mh_merkle_cap_root(s.ctypes.data_as(u64p), C.c_int(s.shape[0]), root.ctypes.data_as(u64p))
+    rc = lib.mh_merkle_cap_root_lmcs(C.c_int(int(lmcs)), s.ctypes.data_as(u64p), C.c_int(s.shape[0]), root.ctypes.data_as(u64p))
     if rc != 0:
-        raise RuntimeError("mh_merkle_cap_root failed")
+        raise RuntimeError("mh_merkle_cap_root_lmcs failed")
     return root
 
 
@@ -95,7 +96,7 @@ class ShardedCommit:
         self.ctx.check(lib.mh_shard_build_subtree(self.ctx.h, self.h, C.c_void_p(mine.data_ptr()),
                                                   sub.ctypes.data_as(C.POINTER(C.c_uint64))))
         subs = gather_subroots(sub, self.world, self.group, device="cuda")
-        return cap_root(lib, subs)
+        return cap_root(lib, subs, getattr(self.ctx, "lmcs_id", 0))
 
     def free(self):
         if getattr(self, "h", None):
@@ -229,6 +230,13 @@ class LocalFabric:
         self.h = lib.mh_local_fabric_create(world)
         if not self.h:
             raise RuntimeError("mh_local_fabric_create failed (world must be a power of two)")
+
+    def abort(self):
+        """mh_local_fabric_abort: call from a rank's error path so that the peers waiting in a collective return an error
+        instead of blocking for ever."""
+        if self.h:
+            self.lib.mh_local_fabric_abort.argtypes = [C.c_void_p]
+            self.lib.mh_local_fabric_abort(self.h)
 
     def close(self):
         if self.h:

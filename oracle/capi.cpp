@@ -64,6 +64,14 @@ void orc_set_lmcs(int hash) {  // the configuration of every later call (tests a
   g_lmcs = hash;
   g_alg_perm = (hash == LMCS_RPO || hash == LMCS_RPX) ? hash : 0;
 }
+// the 2-to-1 node function of the configuration set by orc_set_lmcs (lifted_tree.rs:472-511 compress_uniform's `compress`)
+void orc_lmcs_compress(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]) {
+  Digest a{l[0], l[1], l[2], l[3]}, b{r[0], r[1], r[2], r[3]}, o;
+  if (g_lmcs == LMCS_BLAKE3) o = b3_compress(a, b);
+  else if (g_lmcs == LMCS_KECCAK) o = keccak_compress(a, b);
+  else compress(l, r, o.data());
+  memcpy(out, o.data(), 32);
+}
 void orc_rescue_permute(int which, uint64_t st[12]) {
   if (which == LMCS_RPX) rpx_permute(st);
   else rpo_permute(st);
@@ -256,6 +264,54 @@ int orc_lookup_build_aux(const uint64_t* blob, size_t n_words, const uint64_t* m
   } catch (const std::exception& e) {
     set_err(err, errcap, e.what());
     return 1;
+  }
+}
+
+// ---- row-by-row constraint check on concrete values (crates/lifted-stark/src/debug.rs:147-232 check_single_trace) ----
+// Every constraint of the DAG is evaluated on every row window (next row wraps around) with is_first / is_last /
+// is_transition as 0/1 values and periodic columns indexed by row % period.  Returns the number of (row, constraint) pairs
+// that are non-zero; the first one is written to first_bad = {row, constraint index}.  -1 on malformed input.
+long orc_check_constraints(const uint64_t* blob, size_t n_words, const uint64_t* main_rowmajor, int log_n,
+                           const uint64_t* aux_rowmajor /* [n][2*aux_width] or NULL */, const uint64_t* aux_values,
+                           const uint64_t* publics, const uint64_t* randomness, const uint64_t* preprocessed_rowmajor,
+                           uint64_t first_bad[2], char* err, size_t errcap) {
+  try {
+    Air air = Air::parse(blob, n_words);
+    size_t n = (size_t)1 << log_n, w = air.main_width, aw = air.aux_width, pw = air.preprocessed_width;
+    if (aw && !aux_rowmajor) throw std::runtime_error("aux trace missing");
+    if (pw && !preprocessed_rowmajor) throw std::runtime_error("preprocessed trace missing");
+    std::vector<E2> rnd(air.num_randomness), av(air.num_aux_values);
+    for (size_t i = 0; i < rnd.size(); i++) rnd[i] = E2{randomness[2 * i] % P, randomness[2 * i + 1] % P};
+    for (size_t i = 0; i < av.size(); i++) av[i] = E2{aux_values[2 * i] % P, aux_values[2 * i + 1] % P};
+    long bad = 0;
+    std::vector<E2> scratch, ac(aw), an(aw), per(air.periodic.size());
+    for (size_t r = 0; r < n; r++) {
+      size_t rn = (r + 1) % n;
+      for (size_t c = 0; c < aw; c++) {
+        ac[c] = E2{aux_rowmajor[(r * aw + c) * 2], aux_rowmajor[(r * aw + c) * 2 + 1]};
+        an[c] = E2{aux_rowmajor[(rn * aw + c) * 2], aux_rowmajor[(rn * aw + c) * 2 + 1]};
+      }
+      for (size_t c = 0; c < per.size(); c++) per[c] = e2(air.periodic[c][r % air.periodic[c].size()] % P);
+      EvalEnv e;
+      e.main_cur = main_rowmajor + r * w; e.main_next = main_rowmajor + rn * w;
+      e.prep_cur = pw ? preprocessed_rowmajor + r * pw : nullptr; e.prep_next = pw ? preprocessed_rowmajor + rn * pw : nullptr;
+      e.aux_cur = ac.data(); e.aux_next = an.data();
+      e.publics = publics; e.periodic = per.data();
+      e.is_first = e2(r == 0); e.is_last = e2(r == n - 1); e.is_transition = e2(r != n - 1);
+      e.randomness = rnd.data(); e.aux_values = av.data();
+      dag_fold(air, e, nullptr, e2(0), scratch);  // fills scratch with every node's value
+      for (size_t k = 0; k < air.constraints.size(); k++) {
+        E2 v = scratch[air.constraints[k]];
+        if (v.c0 != 0 || v.c1 != 0) {
+          if (bad == 0) { first_bad[0] = r; first_bad[1] = k; }
+          bad++;
+        }
+      }
+    }
+    return bad;
+  } catch (const std::exception& e) {
+    set_err(err, errcap, e.what());
+    return -1;
   }
 }
 

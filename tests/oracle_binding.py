@@ -269,6 +269,28 @@ def lookup_build_aux(lookup, main, randomness, preprocessed=None):
     return aux, fin
 
 
+def check_constraints(air, main, aux=None, aux_values=(), publics=(), randomness=(), preprocessed=None):
+    """crates/lifted-stark/src/debug.rs check_single_trace on concrete values: -> (number of non-zero (row, constraint)
+    pairs, first such pair or None)."""
+    m = arr(main)
+    n = m.shape[0]
+    blob = arr(air.blob)
+    rnd = arr([int(x) % P for r in randomness for x in r] or [0])
+    av = arr([int(x) % P for x in aux_values] or [0])
+    pub = arr(list(publics) or [0])
+    first = np.zeros(2, dtype=np.uint64)
+    err = C.create_string_buffer(512)
+    L = lib()
+    L.orc_check_constraints.restype = C.c_long
+    a = arr(aux) if aux is not None else None
+    rc = L.orc_check_constraints(ptr(blob), C.c_size_t(blob.size), ptr(m), C.c_int(n.bit_length() - 1),
+                                 ptr(a) if a is not None else None, ptr(av), ptr(pub), ptr(rnd),
+                                 ptr(arr(preprocessed)) if preprocessed is not None else None, ptr(first), err, C.c_size_t(512))
+    if rc < 0:
+        raise RuntimeError("oracle check_constraints failed: " + err.value.decode())
+    return int(rc), ((int(first[0]), int(first[1])) if rc else None)
+
+
 class Challenger:
     """oracle::Challenger (DuplexChallenger restatement) as an object, for driving a staged proof."""
 

@@ -300,3 +300,13 @@ def test_blake3_random_inputs_against_llvm_when_present():
         out = C.create_string_buffer(32)
         L.llvm_blake3_hasher_finalize(st, out, C.c_size_t(32))
         assert ob.blake3(data) == out.raw == pkg.blake3(data), n
+
+
+def test_host_blake3_has_no_length_limit():
+    """The host stream keeps 54 chaining values (any message the specification allows); the device stream's 8 are guarded where
+    leaves are hashed and where the PoW prefix is handed to the kernel.  Lengths whose chunk counts have 9 and more set bits
+    (511 KiB+: past the old 8-entry stack) against the oracle's independent, vector-backed implementation."""
+    pkg = load_package()
+    for n in (511 * 1024, 511 * 1024 + 1, 512 * 1024 + 77, 1023 * 1024 + 5, (1 << 21) - 1024 + 3):
+        d = pattern(n)
+        assert pkg.blake3(d) == ob.blake3(d), n

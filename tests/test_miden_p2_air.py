@@ -1,0 +1,148 @@
+"""CPU tests of the first real Miden AIR on this backend, `Poseidon2PermutationAir` (miden-vm_amd/miden_air.py, restating
+air/src/constraints/poseidon2_permutation/{mod,state,columns}.rs + lookup/poseidon2_permutation_air.rs).
+
+Reference anchors: the trace is generated with the permutation the reference's KAT pins (poseidon2/test.rs:7-39): cycle
+input [0..11] must put the KAT output on row 15; the hand-ported constraints vanish on every row of the generated trace
+(the reference's own `check_constraints` debug pass, crates/lifted-stark/src/debug.rs:147-232, restated in the oracle) and
+fail on any one-cell perturbation; periodic-column tests follow columns.rs:253-337."""
+import json, os
+import numpy as np
+import pytest
+import oracle_binding as ob
+from __graft_entry__ import load_package
+
+load_package()
+from miden_vm_amd import miden_air as MA, dag  # noqa: E402
+
+P = dag.P
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
+RND = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
+FAST = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=5,
+            query_pow_bits=3)
+
+
+def p2_air():
+    return MA.poseidon2_permutation_air(host_aux=ob.lookup_build_aux)
+
+
+def requests(k, seed=7):
+    rng = np.random.default_rng(seed)
+    st = rng.integers(0, P, (k, 12), dtype=np.uint64)
+    st[0] = np.arange(12, dtype=np.uint64)  # the KAT input
+    return st, rng.integers(1, 5, k, dtype=np.uint64)
+
+
+def test_numpy_goldilocks_matches_python_ints():
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, P, 4096, dtype=np.uint64)
+    b = rng.integers(0, P, 4096, dtype=np.uint64)
+    a[:4] = [0, P - 1, P - 1, 1 << 32]
+    b[:4] = [P - 1, P - 1, 1, (1 << 32) - 1]
+    assert [int(x) for x in MA.gl_mul(a, b)] == [int(x) * int(y) % P for x, y in zip(a, b)]
+    assert [int(x) for x in MA.gl_add(a, b)] == [(int(x) + int(y)) % P for x, y in zip(a, b)]
+
+
+def test_periodic_columns_follow_the_reference_schedule():
+    # columns.rs:253-337: selectors boolean + exclusive, none on row 15; ark rows = the round constants
+    per = MA.periodic_columns()
+    assert len(per) == 16 and all(len(c) == 16 for c in per)
+    for r in range(16):
+        sel = [per[i][r] for i in range(4)]
+        assert all(s in (0, 1) for s in sel) and sum(sel) == (0 if r == 15 else 1)
+    for lane in range(12):
+        ark = per[4 + lane]
+        assert [ark[r] for r in range(4)] == [MA.ARK_EXT_INITIAL[r][lane] for r in range(4)]
+        assert [ark[11 + r] for r in range(4)] == [MA.ARK_EXT_TERMINAL[r][lane] for r in range(4)]
+        for t in range(7):
+            assert ark[4 + t] == (MA.ARK_INT[3 * t + lane] if lane < 3 else 0)
+        assert ark[15] == 0
+
+
+def test_trace_row15_is_the_reference_kat_output():
+    st, mult = requests(3)
+    tr = MA.poseidon2_permutation_trace(7, st, mult)
+    assert tr.shape == (128, 16)
+    exp = [int(x, 16) if isinstance(x, str) else int(x) for x in KAT["permutation_kat"]["output"]]
+    assert [int(x) for x in tr[15, MA.COL_STATE:MA.COL_STATE + 12]] == exp
+    # every cycle's row 15 is the oracle permutation of its row 0; ids are consecutive, padding cycles have multiplicity 0
+    for c in range(8):
+        out = ob.permute(tr[16 * c, 3:15])[0]
+        assert (tr[16 * c + 15, 3:15] == out).all()
+        assert (tr[16 * c:16 * c + 16, 15] == c).all()
+        assert int(tr[16 * c, 0]) == (int(mult[c]) if c < 3 else 0) == int(tr[16 * c + 15, 0])
+
+
+def test_constraints_vanish_on_the_generated_trace_and_fail_on_perturbations():
+    air, lookup = p2_air()
+    assert air.main_width == 16 and air.aux_width == 1 and air.num_randomness == 2 and air.num_aux_values == 1
+    assert air.log_quotient_degree == 3 and air.blob[9] == 58 + 3  # 58 base + 3 extension constraints
+    st, mult = requests(5)
+    tr = MA.poseidon2_permutation_trace(7, st, mult)
+    aux, fin = ob.lookup_build_aux(lookup, tr, RND)
+    assert ob.check_constraints(air, tr, aux, fin, randomness=RND) == (0, None)
+    rng = np.random.default_rng(3)
+    for _ in range(40):  # one-cell perturbations of the main trace (aux rebuilt honestly: the main constraints must catch it)
+        r, c = int(rng.integers(0, 128)), int(rng.integers(0, 16))
+        bad = tr.copy()
+        bad[r, c] = (int(bad[r, c]) + 1 + int(rng.integers(0, 1000))) % P
+        aux_b, fin_b = ob.lookup_build_aux(lookup, bad, RND)
+        nbad, first = ob.check_constraints(air, bad, aux_b, fin_b, randomness=RND)
+        assert nbad > 0, f"perturbing cell ({r}, {c}) went unnoticed"
+    # a wrong aux cell / a wrong committed final break the three LogUp constraints (indices 58..60)
+    aux_b = aux.copy()
+    aux_b[40, 0] = (int(aux_b[40, 0]) + 1) % P
+    nbad, first = ob.check_constraints(air, tr, aux_b, fin, randomness=RND)
+    assert nbad > 0 and first[1] >= 58
+    nbad, first = ob.check_constraints(air, tr, aux, [(int(fin[0]) + 1) % P, int(fin[1])], randomness=RND)
+    assert (nbad, first) == (1, (127, 60))
+
+
+def test_perm_link_final_is_the_sum_of_the_removed_requests():
+    # poseidon2_permutation_air.rs:23-29: row 0 removes the input request, row 15 the output request, `multiplicity` times
+    _, lookup = p2_air()
+    st, mult = requests(4)
+    tr = MA.poseidon2_permutation_trace(7, st, mult)
+    _, fin = ob.lookup_build_aux(lookup, tr, RND)
+
+    def emul(a, b):
+        return ((a[0] * b[0] + 7 * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+    def einv(a):
+        out = np.zeros(2, dtype=np.uint64)
+        ob.lib().orc_einv(ob.ptr(ob.arr(list(a))), ob.ptr(out))
+        return (int(out[0]), int(out[1]))
+
+    alpha, beta = RND
+    pw = [(1, 0)]
+    for _ in range(16):
+        pw.append(emul(pw[-1], beta))
+    total = (0, 0)
+    for c in range(4):
+        for row, bus in ((0, MA.BUS_HASHER_PERM_LINK_INPUT), (15, MA.BUS_HASHER_PERM_LINK_OUTPUT)):
+            d = ((alpha[0] + pw[16][0] * (bus + 1) + c) % P, (alpha[1] + pw[16][1] * (bus + 1)) % P)
+            for i in range(12):
+                s = int(tr[16 * c + row, 3 + i])
+                d = ((d[0] + pw[2 + i][0] * s) % P, (d[1] + pw[2 + i][1] * s) % P)
+            inv = einv(d)
+            m = (P - int(mult[c])) % P
+            total = ((total[0] + inv[0] * m) % P, (total[1] + inv[1] * m) % P)
+    assert (int(fin[0]), int(fin[1])) == total
+
+
+def test_oracle_proves_and_verifies_the_real_air():
+    air, _ = p2_air()
+    st, mult = requests(5)
+    tr = MA.poseidon2_permutation_trace(7, st, mult)
+    proof = ob.prove([air], [tr], [], FAST)
+    ok, msg = ob.verify([air], [7], [], proof, FAST)
+    assert ok, msg
+    pkg = load_package()
+    ok2, dig = pkg.verify([air], [7], [], FAST, ob.challenger_state(), ob.protocol_pre_observe(FAST, []), proof["fields"],
+                          proof["commitments"])
+    assert ok2 and (dig == proof["digest"]).all()
+    bad = tr.copy()
+    bad[37, 5] = (int(bad[37, 5]) + 1) % P  # an unsatisfied trace: the proof is produced but no verifier accepts it
+    proof_b = ob.prove([air], [bad], [], FAST)
+    assert not ob.verify([air], [7], [], proof_b, FAST)[0]
+    assert not pkg.verify([air], [7], [], FAST, ob.challenger_state(), ob.protocol_pre_observe(FAST, []), proof_b["fields"],
+                          proof_b["commitments"])[0]
