@@ -69,6 +69,17 @@ int mh_coset_lde_batch(mh_ctx* ctx, const uint64_t* rowmajor, int log_n, size_t 
 /* Upload a host row-major RowMajorMatrix<Felt> (values, width) of height 2^log_n: one H2D copy +
  * an on-device transpose to column-major; canonicalises felts. */
 int mh_trace_upload(mh_ctx* ctx, const uint64_t* rowmajor, int log_n, size_t width, mh_trace** out);
+/* The same without blocking: returns as soon as the copy is enqueued.  The DMA and the transpose run on the context's COPY
+ * stream, under whatever the compute stream is doing; every consumer of the trace (mh_prove, mh_session_*, mh_commit_traces,
+ * mh_lookup_build_aux, mh_trace_download) orders itself after the upload on the GPU, no host wait.  Start the uploads of all
+ * the matrices of a statement in proof order (ascending height, ties by instance index), then call mh_prove: the LDE and the leaf
+ * sponges of matrix k run while matrices k+1.. are still on the PCIe link; only the first matrix's copy is exposed.  `rowmajor`
+ * should be page-locked (mh_host_alloc) -- pageable memory makes the copy synchronous -- and must stay valid and unmodified
+ * until the proof has been made (or mh_trace_wait has returned).  Reference: prover/src/lib.rs:317-355 hands over host
+ * RowMajorMatrix values. */
+int mh_trace_upload_async(mh_ctx* ctx, const uint64_t* rowmajor, int log_n, size_t width, mh_trace** out);
+/* Blocks until the upload of `t` has landed (the host buffer may be reused) and releases its landing buffer. */
+int mh_trace_wait(mh_ctx* ctx, mh_trace* t);
 /* The same for a row-major matrix that is already in device memory (a GPU trace generator): no PCIe traffic. */
 int mh_trace_from_device(mh_ctx* ctx, const uint64_t* device_rowmajor, int log_n, size_t width, mh_trace** out);
 void mh_trace_free(mh_trace* t);

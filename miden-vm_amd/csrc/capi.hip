@@ -75,6 +75,7 @@ int mh_ctx_create(int device_id, mh_ctx** out) {
 void mh_ctx_destroy(mh_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
@@ -85,6 +86,7 @@ void mh_ctx_destroy(mh_ctx* c) {
   c->pool.trim();
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   delete c;
 }
 
@@ -189,6 +191,25 @@ int mh_trace_upload(mh_ctx* c, const uint64_t* rowmajor, int log_n, size_t width
   MH_REQUIRE(log_n >= 0 && log_n <= 29 && width > 0, "bad trace shape");
   HIP_CHECK(hipSetDevice(c->device));
   *out = trace_upload(c, rowmajor, log_n, width);
+  MH_CATCH
+}
+int mh_trace_upload_async(mh_ctx* c, const uint64_t* rowmajor, int log_n, size_t width, mh_trace** out) {
+  MH_TRY(c)
+  MH_REQUIRE(c && rowmajor && out, "null argument");
+  MH_REQUIRE(log_n >= 0 && log_n <= 29 && width > 0, "bad trace shape");
+  HIP_CHECK(hipSetDevice(c->device));
+  *out = trace_upload_async(c, rowmajor, log_n, width);
+  MH_CATCH
+}
+int mh_trace_wait(mh_ctx* c, mh_trace* t) {
+  MH_TRY(c)
+  MH_REQUIRE(c && t, "null argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  if (t->ready) HIP_CHECK(hipEventSynchronize(t->ready));
+  {
+    PoolScope ps(c);
+    t->staging.release();  // the DMA has landed and been transposed: the landing buffer goes back to the pool
+  }
   MH_CATCH
 }
 // A trace that already lives in device memory (row-major, any stream-ordered producer finished): transposed and

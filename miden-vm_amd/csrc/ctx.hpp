@@ -134,6 +134,7 @@ struct mh_ctx {
   int device = 0;
   DevPool pool;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // mh_trace_upload_async: DMA copies + transposes that run under the proof's kernels (created on first use)
   std::string err;
   // profiler
   bool prof_on = false;

@@ -4,7 +4,7 @@
 #include <vector>
 
 // ---- ntt.hip ---------------------------------------------------------------------------------
-void launch_transpose_rm_to_cm(mh_ctx* c, const u64* in_rowmajor, u64* out_colmajor, size_t n, size_t w);
+void launch_transpose_rm_to_cm(mh_ctx* c, const u64* in_rowmajor, u64* out_colmajor, size_t n, size_t w, hipStream_t stream = nullptr);  // null: the compute stream
 void ntt_inverse_dif_inplace(mh_ctx* c, u64* cols, size_t n_cols, int log_n);
 void ntt_inverse_dif(mh_ctx* c, const u64* src, u64* dst, size_t n_cols, int log_n);  // src == dst: in place
 void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n, const std::vector<u64>& bases, u64* out);
@@ -18,7 +18,19 @@ struct mh_trace {
   int log_n;
   size_t width;
   DevBuf cols;  // [width][N]
+  // mh_trace_upload_async: the H2D copy + transpose run on the context's copy stream; `ready` is recorded behind them.  Every
+  // consumer on the compute stream orders itself after it with trace_wait_ready() (a stream-side wait, no host block).
+  hipEvent_t ready = nullptr;
+  DevBuf staging;  // the row-major landing buffer of the DMA, released once the trace has been consumed
+  ~mh_trace() {
+    if (ready) {
+      (void)hipEventSynchronize(ready);  // the copy stream may still be writing cols / reading staging
+      (void)hipEventDestroy(ready);
+    }
+  }
 };
+// Order everything enqueued on c->stream from here on after the trace's upload (no-op for a synchronously uploaded trace).
+void trace_wait_ready(mh_ctx* c, const mh_trace* t);
 
 // A committed (LDE'd) matrix: coset-major column-major: lde[(c*B + j)*N + r] = f_c(shift*w_K^j*w_H^r)
 // = evaluation at natural index i = r*B + j of the max-domain-lifted polynomial.
@@ -94,6 +106,7 @@ std::vector<std::pair<int, size_t>> lmcs_missing_siblings(const std::vector<size
 // ---- prover.hip (commit helpers shared with the C ABI) -------------------------------------------
 std::vector<u64> coset_shifts(int log_n, int lb);  // g*w_K^j, j < 2^lb, for the canonical shift of order log_n+lb
 mh_trace* trace_upload(mh_ctx* c, const u64* rowmajor, int log_n, size_t width);
+mh_trace* trace_upload_async(mh_ctx* c, const u64* rowmajor, int log_n, size_t width);
 mh_trace* trace_zeros(mh_ctx* c, int log_n, size_t width);
 mh_tree* commit_traces(mh_ctx* c, const std::vector<const mh_trace*>& traces, int log_blowup);
 // LDE of `tr` onto the cosets [first, first + count) only of the 2^lb cosets (count a power of two)

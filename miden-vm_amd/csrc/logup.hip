@@ -160,6 +160,8 @@ mh_trace* lookup_build_aux(mh_ctx* c, const mh_lookup* lk, const mh_trace* main,
   HIP_CHECK(hipMemcpyAsync(dext.p, lk->out_ext.data(), lk->out_ext.size(), hipMemcpyHostToDevice, c->stream));
   HIP_CHECK(hipMemsetAsync(derr.p, 0, 4, c->stream));
 
+  trace_wait_ready(c, main);
+  trace_wait_ready(c, prep);
   DevBuf planes(4 * K * n * 8);  // outputs m_j, d_j: two planes each
   JitArgs j{};
   j.main_lde = main->cols.u();  // the trace itself: one "coset", B = 1

@@ -106,9 +106,9 @@ __global__ __launch_bounds__(256) void k_transpose_rm_to_cm(const u64* __restric
   }
 }
 
-void launch_transpose_rm_to_cm(mh_ctx* c, const u64* in, u64* out, size_t n, size_t w) {
+void launch_transpose_rm_to_cm(mh_ctx* c, const u64* in, u64* out, size_t n, size_t w, hipStream_t stream) {
   dim3 grid((unsigned)((n + 31) / 32), (unsigned)((w + 31) / 32));
-  MH_LAUNCH(k_transpose_rm_to_cm, grid, dim3(256), 0, c->stream, in, out, n, w);
+  MH_LAUNCH(k_transpose_rm_to_cm, grid, dim3(256), 0, stream ? stream : c->stream, in, out, n, w);
 }
 
 // ---------------------------------------------------------------------------------------------

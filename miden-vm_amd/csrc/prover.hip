@@ -51,6 +51,35 @@ mh_trace* trace_upload(mh_ctx* c, const u64* rowmajor, int log_n, size_t width) 
   return t.release();
 }
 
+// The same without blocking the caller and without occupying the compute stream: the DMA copy and the transpose go to the
+// context's copy stream, `ready` is recorded behind them, and every consumer orders itself after it on the GPU
+// (trace_wait_ready).  With several traces in flight -- the three matrices of a Miden statement -- the LDE and leaf sponges of
+// matrix k run while matrices k+1.. are still on the PCIe link; the first matrix of the proof order is the only exposed copy.
+// (A single row-major matrix cannot be split further: column windows of a row-major host buffer move at 16-36 GB/s, the PCIe
+// read-tag limit for 64-216 B segments, tools/h2dbench, and every column NTT needs all rows.)
+mh_trace* trace_upload_async(mh_ctx* c, const u64* rowmajor, int log_n, size_t width) {
+  size_t n = (size_t)1 << log_n;
+  std::unique_ptr<mh_trace> t(new mh_trace());
+  t->ctx = c; t->log_n = log_n; t->width = width;
+  if (width == 0) return t.release();
+  if (!c->copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  t->staging.alloc(n * width * 8);
+  t->cols.alloc(n * width * 8);
+  // pooled buffers: whatever the compute stream still does with their previous contents comes first
+  hipEvent_t fence = c->get_event();
+  HIP_CHECK(hipEventRecord(fence, c->stream));
+  HIP_CHECK(hipStreamWaitEvent(c->copy_stream, fence, 0));
+  c->event_pool.push_back(fence);
+  HIP_CHECK(hipMemcpyAsync(t->staging.p, rowmajor, n * width * 8, hipMemcpyHostToDevice, c->copy_stream));
+  launch_transpose_rm_to_cm(c, t->staging.u(), t->cols.u(), n, width, c->copy_stream);
+  HIP_CHECK(hipEventCreateWithFlags(&t->ready, hipEventDisableTiming));
+  HIP_CHECK(hipEventRecord(t->ready, c->copy_stream));
+  return t.release();
+}
+void trace_wait_ready(mh_ctx* c, const mh_trace* t) {
+  if (t && t->ready) HIP_CHECK(hipStreamWaitEvent(c->stream, t->ready, 0));
+}
+
 mh_trace* trace_zeros(mh_ctx* c, int log_n, size_t width) {
   size_t n = (size_t)1 << log_n;
   std::unique_ptr<mh_trace> t(new mh_trace());
@@ -99,6 +128,7 @@ LdeMatrix lde_trace_cosets(mh_ctx* c, const mh_trace* tr, int lb, size_t first, 
   m.coset0 = first;
   while (((size_t)1 << m.log_cosets) < count) m.log_cosets++;
   if (tr->width == 0) return m;  // an AIR without aux columns still owns a (width-0) slot of the aux tree
+  trace_wait_ready(c, tr);
   m.lde.alloc(N * count * tr->width * 8);
   DevBuf scratch(N * tr->width * 8);
   std::vector<u64> all = coset_shifts(tr->log_n, lb);
@@ -766,6 +796,7 @@ int mh_trace_download(mh_ctx* c, const mh_trace* t, uint64_t* rowmajor_out) {
   HIP_CHECK(hipSetDevice(c->device));
   const size_t n = (size_t)1 << t->log_n;
   std::vector<u64> cm(n * t->width);
+  trace_wait_ready(c, t);
   HIP_CHECK(hipMemcpyAsync(cm.data(), t->cols.p, cm.size() * 8, hipMemcpyDeviceToHost, c->stream));
   c->sync();
   for (size_t col = 0; col < t->width; col++)

@@ -133,3 +133,38 @@ def test_miden_shape_with_the_real_poseidon2_air(ctx, fast_oracle):
     assert (got.digest == exp["digest"]).all()
     ok, msg = ob.verify(airs_, got.log_trace_heights, [], {"fields": got.fields, "commitments": got.commitments}, ob.PROD_PARAMS)
     assert ok, msg
+
+
+def test_async_uploads_give_the_same_proof(ctx):
+    """mh_trace_upload_async (copy stream + ready event) against the synchronous upload: same proof bytes, for one matrix and
+    for a three-matrix statement whose uploads overlap the first matrix's LDE; the trace downloads back intact and the lookup
+    program (which reads the raw trace, not the LDE) waits for its upload too."""
+    pkg = load_package()
+    p2, lookup = MA.poseidon2_permutation_air()
+    airs_ = [dag.dummy_miden_air(51, 4, num_aux_values=1), dag.dummy_miden_air(22, 3, num_aux_values=1), p2]
+    host = [A.dummy_trace(15, 51, seed=3), A.dummy_trace(13, 22, seed=4), p2_statement(14, 300)]
+    pins = []
+    for t in host:
+        a, owner = pkg.pinned_array(ctx.lib, t.shape)
+        a[:] = t
+        pins.append((a, owner))
+    pre = ob.protocol_pre_observe(ob.PROD_PARAMS, [])
+
+    def prove(traces):
+        dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+        dairs[2].attach_lookup(pkg.DeviceLookup(ctx, lookup))
+        return pkg.prove(ctx, dairs, traces, [], ob.PROD_PARAMS, ob.challenger_state(), pre, None)
+
+    ref = prove([ctx.upload_trace(t) for t in host])
+    for _ in range(3):
+        up = [pkg.Trace.upload_async(ctx, a) for a, _ in pins]
+        got = prove(up)
+        assert got.bytes == ref.bytes
+        assert (up[1].download() == host[1]).all()
+        up[0].wait()
+        for t in up:
+            t.free()
+    t = pkg.Trace.upload_async(ctx, pins[2][0])  # a trace that is freed without ever being consumed
+    t.free()
+    t = pkg.Trace.upload_async(ctx, pins[0][0])
+    assert (t.download() == host[0]).all()
