@@ -222,3 +222,112 @@ class Lookup:
         self.name, self.main_width, self.num_cols, self.num_randomness = name, builder.main_width, builder.num_cols, builder.num_randomness
         self.preprocessed_width = builder.preprocessed_width
         self.blob = builder.blob()
+
+
+# ---- the LogUp aux builder of an AIR, derived from its constraint DAG ---------------------------------------------------------
+def parse_air_blob(blob):
+    """-> dict(header fields, periodic, nodes [(op, a, b, c)], constraints) of an "MHDAG001" blob."""
+    w = [int(x) for x in blob]
+    assert w[0] == MAGIC, "not a constraint-DAG blob"
+    hdr = dict(main_width=w[1], aux_width=w[2], num_randomness=w[3], num_aux_values=w[4], num_public=w[5], log_quotient_degree=w[7],
+               preprocessed_width=w[10])
+    pos, periodic = 12, []
+    for _ in range(w[6]):
+        n = w[pos]
+        periodic.append(w[pos + 1:pos + 1 + n])
+        pos += 1 + n
+    nodes = []
+    for i in range(w[8]):
+        x = w[pos + 2 * i]
+        nodes.append((x & 0xFF, (x >> 8) & 0xFFFFFFF, x >> 36, w[pos + 2 * i + 1]))
+    pos += 2 * w[8]
+    return dict(hdr, periodic=periodic, nodes=nodes, constraints=w[pos:pos + w[9]])
+
+
+def lookup_from_constraints(air_blob, name="derived"):
+    """The lookup program of a LogUp AIR recovered from its CONSTRAINTS -- no separate bus-message exporter.
+
+    The reference's constraint-path adapter (air/src/lookup/constraint.rs:133-196) emits, per aux column, exactly one transition
+    constraint that contains the column's cross-multiplied fraction sum (V, U):
+        column 0 (accumulator):   is_transition * (U * (acc_next[0] - sum_i acc[i]) - V)
+        column i > 0 (fraction):  is_transition * (U * acc[i] - V)
+    and on every row V / U = sum_j m_j / d_j, the value `build_logup_aux_trace` (air/src/lookup/aux_builder.rs:49-96, 202-258)
+    gets by summing the prover-path fractions one by one: field arithmetic is exact, so the aux trace built from ONE fraction
+    (V, U) per column is bit-identical to the reference's (and needs one EF inversion per row and column instead of one per
+    interaction).  This walks the DAG blob -- the Python exporter's or export_dag.rs's -- finds those constraints by shape, and
+    re-emits the U and V sub-DAGs as an "MHLKP001" program.  Raises ValueError when the aux columns are not all matched (an AIR
+    whose aux trace is not a LogUp accumulator keeps the host `build_aux_trace` callback)."""
+    a = parse_air_blob(air_blob)
+    nodes = a["nodes"]
+
+    def is_leaf(i, op, x=None, y=None):
+        n = nodes[i]
+        return n[0] == op and (x is None or n[1] == x) and (y is None or n[2] == y)
+
+    def sum_terms(i):  # leaves of an ADD tree
+        return sum_terms(nodes[i][1]) + sum_terms(nodes[i][2]) if nodes[i][0] == OP_ADD else [i]
+
+    found = {}
+    for k in a["constraints"]:
+        n = nodes[k]
+        if n[0] != OP_MUL:
+            continue
+        inner = n[2] if is_leaf(n[1], OP_IS_TRANSITION) else (n[1] if is_leaf(n[2], OP_IS_TRANSITION) else None)
+        if inner is None or nodes[inner][0] != OP_SUB:
+            continue
+        p, v = nodes[inner][1], nodes[inner][2]
+        cands = [(None, p)]  # U folded away (U = 1): the product is q itself
+        if nodes[p][0] == OP_MUL:
+            cands = [(nodes[p][1], nodes[p][2]), (nodes[p][2], nodes[p][1])] + cands
+        for u, q in cands:
+            col = None
+            if nodes[q][0] == OP_AUX and nodes[q][2] == 0 and nodes[q][1] > 0:
+                col = nodes[q][1]
+            elif nodes[q][0] == OP_SUB and is_leaf(nodes[q][1], OP_AUX, 0, 1):
+                terms = sum_terms(nodes[q][2])
+                if all(nodes[t][0] == OP_AUX and nodes[t][2] == 0 for t in terms) and sorted(nodes[t][1] for t in terms) == list(range(a["aux_width"])):
+                    col = 0
+            if col is not None and col not in found:
+                found[col] = (u, v)
+                break
+    if sorted(found) != list(range(a["aux_width"])) or not found:
+        raise ValueError(f"not a LogUp AIR in the reference's constraint shape: matched aux columns {sorted(found)} of {a['aux_width']}")
+
+    lb = LookupBuilder(a["main_width"], num_cols=a["aux_width"], num_randomness=a["num_randomness"], periodic=a["periodic"],
+                       preprocessed_width=a["preprocessed_width"])
+    memo = {}
+
+    def copy(i):
+        if i in memo:
+            return memo[i]
+        op, x, y, c = nodes[i]
+        if op == OP_CONST:
+            e = lb.const(c)
+        elif op == OP_MAIN:
+            e = lb.main(x, y)
+        elif op == OP_PREPROCESSED:
+            e = lb.preprocessed(x, y)
+        elif op == OP_PERIODIC:
+            e = lb.periodic_value(x)
+        elif op == OP_RANDOMNESS:
+            e = lb.randomness(x)
+        elif op in (OP_ADD, OP_SUB, OP_MUL):
+            l, r = copy(x), copy(y)
+            e = l + r if op == OP_ADD else (l - r if op == OP_SUB else l * r)
+        elif op == OP_NEG:
+            e = -copy(x)
+        else:
+            raise ValueError(f"a bus message reads a leaf of kind {op} (aux / public / selector): not a lookup program")
+        memo[i] = e
+        return e
+
+    import sys
+    limit = sys.getrecursionlimit()
+    sys.setrecursionlimit(max(limit, 4 * len(nodes) + 1000))  # deep chains in exported DAGs
+    try:
+        for col in range(a["aux_width"]):
+            u, v = found[col]
+            lb.fraction(col, copy(v), copy(u) if u is not None else lb.const(1))
+    finally:
+        sys.setrecursionlimit(limit)
+    return Lookup(lb, name)

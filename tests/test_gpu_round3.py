@@ -168,3 +168,22 @@ def test_async_uploads_give_the_same_proof(ctx):
     t.free()
     t = pkg.Trace.upload_async(ctx, pins[0][0])
     assert (t.download() == host[0]).all()
+
+
+def test_device_aux_from_the_lookup_program_derived_from_the_constraints(ctx):
+    """dag.lookup_from_constraints (one (V, U) fraction per aux column, read off the accumulator's transition constraint):
+    the device aux column equals the oracle's evaluation of the hand-written program, and the proof made with it is the
+    oracle's proof."""
+    pkg = load_package()
+    air, hand = MA.poseidon2_permutation_air(host_aux=ob.lookup_build_aux)
+    derived = dag.lookup_from_constraints(air.blob)
+    tr = p2_statement(11, 100)
+    rnd = [(123456789012345, 987654321), (55555, 2**63 + 17)]
+    aux_dev, fin = pkg.DeviceLookup(ctx, derived).build_aux(ctx.upload_trace(tr), rnd)
+    aux, exp_fin = ob.lookup_build_aux(hand, tr, rnd)
+    assert (aux_dev.download() == aux).all() and fin == (int(exp_fin[0]), int(exp_fin[1]))
+    exp = ob.prove([air], [tr], [], FAST)
+    dair = pkg.DeviceAir(ctx, air)
+    dair.attach_lookup(pkg.DeviceLookup(ctx, derived))
+    got = pkg.prove(ctx, [dair], [ctx.upload_trace(tr)], [], FAST, ob.challenger_state(), ob.protocol_pre_observe(FAST, []), None)
+    assert (got.fields == exp["fields"]).all() and (got.commitments == exp["commitments"]).all() and (got.digest == exp["digest"]).all()

@@ -70,3 +70,26 @@ def test_device_and_oracle_agree_on_the_real_airs():
         assert (got.fields == exp["fields"]).all() and (got.commitments == exp["commitments"]).all() and (got.digest == exp["digest"]).all()
     finally:
         ctx.close()
+
+
+def test_real_air_blobs_yield_their_lookup_programs():
+    """dag.lookup_from_constraints on the exported blobs: every aux column of the three real AIRs is a LogUp column in the
+    constraint-path shape (air/src/lookup/constraint.rs:133-196), so the device aux builder needs no second exporter; the
+    Poseidon2 permutation blob must give the same aux trace as the hand-ported program (miden-vm_amd/miden_air.py)."""
+    if len(BLOBS) != 3:
+        pytest.skip(NO_BLOBS)
+    from miden_vm_amd import dag, miden_air as MA
+    for p in BLOBS:
+        air = load(p)
+        lk = dag.lookup_from_constraints(air.blob)
+        assert lk.num_cols == air.aux_width
+    p2 = load(BLOBS[2])
+    _, hand = MA.poseidon2_permutation_air()
+    rng = np.random.default_rng(2)
+    tr = MA.poseidon2_permutation_trace(7, rng.integers(0, ob.P, (5, 12), dtype=np.uint64), rng.integers(1, 4, 5, dtype=np.uint64))
+    rnd = [(11, 22), (33, 44)]
+    a1, f1 = ob.lookup_build_aux(dag.lookup_from_constraints(p2.blob), tr, rnd)
+    a2, f2 = ob.lookup_build_aux(hand, tr, rnd)
+    assert (a1 == a2).all() and (f1 == f2).all()
+    # and the exported constraints themselves vanish on the KAT-pinned trace
+    assert ob.check_constraints(p2, tr, a1, f1, randomness=rnd) == (0, None)

@@ -146,3 +146,23 @@ def test_oracle_proves_and_verifies_the_real_air():
     assert not ob.verify([air], [7], [], proof_b, FAST)[0]
     assert not pkg.verify([air], [7], [], FAST, ob.challenger_state(), ob.protocol_pre_observe(FAST, []), proof_b["fields"],
                           proof_b["commitments"])[0]
+
+
+def test_lookup_program_derived_from_the_constraint_dag():
+    """dag.lookup_from_constraints: the (V, U) pair inside the accumulator's transition constraint IS the aux builder
+    (lookup/constraint.rs:133-196 vs aux_builder.rs:202-258: V / U = sum of the row's fractions).  The derived one-fraction
+    program gives the same aux column and final as the hand-written two-fraction program, cell for cell."""
+    air, lookup = p2_air()
+    derived = dag.lookup_from_constraints(air.blob)
+    assert derived.num_cols == 1 and derived.main_width == 16
+    st, mult = requests(6)
+    tr = MA.poseidon2_permutation_trace(8, st, mult)
+    aux1, fin1 = ob.lookup_build_aux(lookup, tr, RND)
+    aux2, fin2 = ob.lookup_build_aux(derived, tr, RND)
+    assert (aux1 == aux2).all() and (fin1 == fin2).all()
+    assert ob.check_constraints(air, tr, aux2, fin2, randomness=RND) == (0, None)
+    # AIRs whose aux columns are not LogUp accumulators in that shape are refused
+    import airs as A
+    for other in (A.fib_air(), dag.dummy_miden_air(11, 2)):
+        with pytest.raises(ValueError):
+            dag.lookup_from_constraints(other.blob)

@@ -14,9 +14,12 @@
 use std::{collections::HashMap, env, fs, rc::Rc};
 
 use miden_air::MidenMultiAir;
-use miden_core::{Felt, field::QuadFelt};
+use miden_core::{
+    Felt,
+    field::{BasedVectorSpace, QuadFelt},
+};
 use miden_crypto::stark::air::{
-    BasedVectorSpace, LiftedAir, MultiAir,
+    LiftedAir, MultiAir,
     symbolic::{
         BaseEntry, BaseLeaf, ExtEntry, ExtLeaf, SymbolicAirBuilder, SymbolicExpression, SymbolicExpressionExt,
     },

@@ -98,7 +98,7 @@ fn u64s(v: &[u64]) -> String {
 }
 
 fn ef(x: QuadFelt) -> String {
-    use miden_crypto::stark::air::BasedVectorSpace; // p3_field::BasedVectorSpace (re-exported with p3-air's prelude)
+    use miden_core::field::BasedVectorSpace; // p3_field's trait, re-exported by miden-field -> miden-crypto::field -> miden-core::field
     felts(<QuadFelt as BasedVectorSpace<Felt>>::as_basis_coefficients_slice(&x))
 }
 
