@@ -105,7 +105,7 @@ def roofline(prof, pmc_file):
     over the average launch duration (HIP events on the library's stream)."""
     if not prof:
         return None
-    name = max((k for k in prof if not k.startswith(("comm_", "span:"))), key=lambda k: prof[k]["ms"])
+    name = max((k for k in prof if not k.startswith(("comm_", "span:")) and k != "lde_intt"), key=lambda k: prof[k]["ms"])  # lde_intt is nested in lde
     e = prof[name]
     ach = (e["bytes"] / 1e9) / (e["ms"] / 1e3)
     traffic = None
@@ -442,6 +442,19 @@ def main():
     }
     if fallback:
         out["config"]["fallback"] = fallback
+    if mode == "sharded":
+        # the measured split of this rank's time next to the model of DESIGN.md section 5 (miden-vm_amd/sharding.py), so that the
+        # line can be read against a prediction: sharded kernels, the replicated inverse transforms, collectives
+        from miden_vm_amd import sharding as _sh
+        per = lambda k: prof.get(k, {}).get("ms", 0.0) / args.steps
+        comm = {k: round(per(k), 3) for k in prof if k.startswith("comm_")}
+        out["sharded_breakdown"] = {
+            "comm_ms": comm, "comm_calls_per_proof": {k: prof[k]["count"] / args.steps for k in prof if k.startswith("comm_")},
+            "replicated_intt_ms": round(per("lde_intt"), 3), "ood_ms": round(per("deep_ood_eval"), 3),
+            "kernel_ms": round(sum(per(k) for k in prof if not k.startswith(("comm_", "span:")) and k != "lde_intt"), 3),
+            "model": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in _sh.predict_sharded_ms(world, log_n).items()},
+            "model_note": "per-rank ms predicted from the single-GPU spans of profiles/r02_config_shapes.txt (2^24: 840 ms) with "
+                          "60 GB/s per xGMI link and direction; replicated = inverse NTTs + host-serial tree tops / transcript"}
     out["roofline"] = roofline(prof, "r02_pmc_leaf_absorb.json")
     try:
         perms = (8 << log_n) * (7 + 2 + 2) // (world if mode == "sharded" else 1)  # per rank

@@ -85,8 +85,16 @@ __global__ __launch_bounds__(256) void k_ood_partial(const u64* lde, int log_n, 
 }
 
 // evals_out[k][col] (EF) for one matrix; y_k = z_k^(lift) supplied by the caller.
-void deep_ood_eval_matrix(mh_ctx* c, const LdeMatrix& m, int log_blowup, e2 y0, e2 y1, std::vector<e2>& out0, std::vector<e2>& out1) {
+// Only columns [col_begin, col_end) are evaluated (the others come back as zero): a rank of a sharded proof evaluates its
+// share of the columns -- on its own first coset -- and the ranks add their vectors up.
+void deep_ood_eval_matrix(mh_ctx* c, const LdeMatrix& m, int log_blowup, e2 y0, e2 y1, std::vector<e2>& out0, std::vector<e2>& out1,
+                          size_t col_begin, size_t col_end) {
   const int log_n = m.log_n;
+  if (col_end > m.width) col_end = m.width;
+  out0.assign(m.width, e2_make(0));
+  out1.assign(m.width, e2_make(0));
+  if (col_begin >= col_end) return;
+  const size_t ncol = col_end - col_begin;
   const size_t n = (size_t)1 << log_n;
   // any coset of H determines the polynomial: use the first one this rank stores
   // (shift g_m * w_{K_m}^coset0; coset 0 on a single GPU, as the reference does)
@@ -100,30 +108,28 @@ void deep_ood_eval_matrix(mh_ctx* c, const LdeMatrix& m, int log_blowup, e2 y0, 
     tw = one.u();
   }
   const unsigned chunks = (unsigned)((n + OOD_ROWS_PER_BLOCK - 1) / OOD_ROWS_PER_BLOCK);
-  DevBuf partial(m.width * chunks * 32);
+  DevBuf partial(ncol * chunks * 32);
   {
-    ProfScope ps(c, "deep_ood_eval", (double)n * 8.0 * m.width + 64.0 * n);
+    ProfScope ps(c, "deep_ood_eval", (double)n * 8.0 * ncol + 64.0 * n);
     MH_LAUNCH(k_bary_weights, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, c->stream, tw, log_n, g, y0, y1, w0.u(), w1.u());
-    MH_LAUNCH(k_ood_partial, dim3(chunks, (unsigned)m.width), dim3(256), 0, c->stream, m.lde.u(), log_n, m.log_cosets, w0.u(),
-                       w1.u(), partial.u(), chunks);
+    MH_LAUNCH(k_ood_partial, dim3(chunks, (unsigned)ncol), dim3(256), 0, c->stream, m.lde.u() + ((col_begin << m.log_cosets) << log_n), log_n,
+                       m.log_cosets, w0.u(), w1.u(), partial.u(), chunks);
   }
-  std::vector<u64> host(m.width * chunks * 4);
+  std::vector<u64> host(ncol * chunks * 4);
   c->d2h(host.data(), partial.p, host.size() * 8);
   // scaling s(y) = ((y/g)^n - 1)/n
   const u64 g_inv = gl_inv(g), n_inv = gl_inv((u64)n % GL_P);
   e2 s0 = e2_mulf(e2_sub(e2_exp_pow2(e2_mulf(y0, g_inv), log_n), e2_make(1)), n_inv);
   e2 s1 = e2_mulf(e2_sub(e2_exp_pow2(e2_mulf(y1, g_inv), log_n), e2_make(1)), n_inv);
-  out0.assign(m.width, e2_make(0));
-  out1.assign(m.width, e2_make(0));
-  for (size_t col = 0; col < m.width; col++) {
+  for (size_t col = 0; col < ncol; col++) {
     e2 a0 = e2_make(0), a1 = e2_make(0);
     for (unsigned ch = 0; ch < chunks; ch++) {
       const u64* p = host.data() + (col * chunks + ch) * 4;
       a0 = e2_add(a0, e2{p[0], p[1]});
       a1 = e2_add(a1, e2{p[2], p[3]});
     }
-    out0[col] = e2_mul(a0, s0);
-    out1[col] = e2_mul(a1, s1);
+    out0[col_begin + col] = e2_mul(a0, s0);
+    out1[col_begin + col] = e2_mul(a1, s1);
   }
 }
 

@@ -123,7 +123,8 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
 void quotient_upsample_accumulate(mh_ctx* c, const u64* q_small, int log_n, int log_blowup, int log_dj, int log_d, const u64* acc_in,
                                   int log_n_prev, e2 beta, u64* acc_out);
 // ---- deep.hip ----------------------------------------------------------------------------------
-void deep_ood_eval_matrix(mh_ctx* c, const LdeMatrix& m, int log_blowup, e2 y0, e2 y1, std::vector<e2>& out0, std::vector<e2>& out1);
+void deep_ood_eval_matrix(mh_ctx* c, const LdeMatrix& m, int log_blowup, e2 y0, e2 y1, std::vector<e2>& out0, std::vector<e2>& out1,
+                          size_t col_begin = 0, size_t col_end = (size_t)-1);
 void deep_assemble(mh_ctx* c, const std::vector<const LdeMatrix*>& mats, const std::vector<uint32_t>& coef_off, int log_n, int log_blowup,
                    const std::vector<e2>& negc, e2 z0, e2 z1, e2 fred0, e2 fred1, e2 beta, u64* out);
 // ---- fri.hip -----------------------------------------------------------------------------------

@@ -568,7 +568,10 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
 // LDE of column-major columns: evaluations on a*H (natural) -> evaluations on b_z*H for all z.
 void lde_columns(mh_ctx* c, const u64* cols_in, size_t n_cols, int log_n, u64 in_shift, const std::vector<u64>& out_shifts,
                  u64* out, u64* scratch /* n_cols * N */) {
-  ntt_inverse_dif(c, cols_in, scratch, n_cols, log_n);
+  {
+    ProfScope ps(c, "lde_intt", 16.0 * (double)n_cols * (double)((size_t)1 << log_n));  // nested in "lde": the part every rank of a sharded proof repeats
+    ntt_inverse_dif(c, cols_in, scratch, n_cols, log_n);
+  }
   u64 a_inv = gl_inv(in_shift);
   std::vector<u64> bases;
   for (u64 b : out_shifts) bases.push_back(gl_mul(b, a_inv));

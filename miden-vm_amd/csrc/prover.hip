@@ -461,10 +461,32 @@ struct mh_session {
       const int lift = log_N - mats[i]->log_n;
       std::vector<e2> o0, o1;
       if (mats[i]->width == 0) continue;
-      deep_ood_eval_matrix(c, *mats[i], lb, e2_exp_pow2(z, lift), e2_exp_pow2(z_next, lift), o0, o1);
+      // sharded proof: every rank holds every column (on its own cosets), so the columns of a matrix are split between the ranks
+      // and the vectors added up below -- the barycentric sums are not repeated G times
+      size_t cb = 0, ce = mats[i]->width;
+      if (dist.on()) {
+        const size_t per = (mats[i]->width + dist.world - 1) / dist.world;
+        cb = std::min(mats[i]->width, per * dist.rank);
+        ce = std::min(mats[i]->width, cb + per);
+      }
+      deep_ood_eval_matrix(c, *mats[i], lb, e2_exp_pow2(z, lift), e2_exp_pow2(z_next, lift), o0, o1, cb, ce);
       for (size_t k = 0; k < o0.size(); k++) {
         ev0[coef_off[i] + k] = o0[k];
         ev1[coef_off[i] + k] = o1[k];
+      }
+    }
+    if (dist.on() && W) {  // every slot was computed by exactly one rank: a plain sum puts the full vectors on every rank
+      std::vector<u64> flat(4 * W);
+      for (size_t i = 0; i < W; i++) {
+        flat[4 * i] = ev0[i].c0; flat[4 * i + 1] = ev0[i].c1; flat[4 * i + 2] = ev1[i].c0; flat[4 * i + 3] = ev1[i].c1;
+      }
+      DevBuf d(flat.size() * 8);
+      HIP_CHECK(hipMemcpyAsync(d.p, flat.data(), flat.size() * 8, hipMemcpyHostToDevice, c->stream));
+      dist.all_reduce_sum(c, d.u(), flat.size());
+      c->d2h(flat.data(), d.p, flat.size() * 8);
+      for (size_t i = 0; i < W; i++) {
+        ev0[i] = e2{flat[4 * i], flat[4 * i + 1]};
+        ev1[i] = e2{flat[4 * i + 2], flat[4 * i + 3]};
       }
     }
     stage = 5;

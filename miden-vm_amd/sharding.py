@@ -314,3 +314,54 @@ def prove_sharded(pkg, ctx, comm, airs, traces, public_values, params, challenge
                                        C.c_size_t(len(public_values)), st.ctypes.data_as(u64p), pre.ctypes.data_as(u64p),
                                        C.c_size_t(len(pre_observe)), c_cb, None, C.byref(h)))
     return pkg.Proof(ctx.lib, h)
+
+
+# ---- a time model of the coset-sharded proof: what the first measured scaling line is read against --------
+# Single-GPU kernel classes of ONE proof of miden:24:51:8 on an MI355X, ms (profiles/r02_config_shapes.txt, configs[3]).
+SINGLE_GPU_MS_2P24 = {"lmcs_leaf_absorb": 405.66, "lde": 245.32, "lmcs_compress": 126.53, "deep_assemble": 30.69, "fri_leaf_hash": 12.73,
+                      "deep_ood_eval": 11.35, "total": 840.0}
+XGMI_GBS_PER_LINK_DIR = 60.0   # achievable per direction per link (MI355X: 7 links x ~153 GB/s bidirectional peak per GPU, point to point)
+HOST_SERIAL_MS = 3.3            # ~10 tree tops of one wave per level (2.5), grinding (0.2), ~30 transcript round trips (0.6)
+
+
+def predict_sharded_ms(world, log_n=24, main_width=51, aux_base_width=16, quotient_base_width=16, log_blowup=3, arity_log=2,
+                       single=None, link_gbs=XGMI_GBS_PER_LINK_DIR):
+    """Per-rank time of one proof sharded by cosets over `world` GPUs of a fully connected xGMI node, from single-GPU spans.
+
+      sharded terms / G   leaf sponges, forward coset NTTs, subtree compression, constraint evaluation, DEEP, FRI hashing + folds
+                          the OOD evaluation (columns split between the ranks, each on its own first coset; one small all-reduce)
+      replicated terms    the iNTT of the main and aux traces (1/9 of their LDE: every rank needs all coefficients), the
+                          host-serial part
+      collectives         per tree one all-to-all of 32-byte leaf digests (each rank keeps 1/G of what it hashed), the all-gather
+                          of the quotient chunk coefficients (16 B x N per chunk, D = B chunks), FRI layers and openings (small);
+                          a rank talks to each peer over ONE link, all links at once: time = bytes per peer / link rate
+    Returns dict(ms, speedup, terms...)."""
+    s = dict(single or SINGLE_GPU_MS_2P24)
+    scale = (1 << log_n) / float(1 << 24) if single is None else 1.0
+    for k in s:
+        s[k] *= scale
+    G = world
+    cols = main_width + aux_base_width + quotient_base_width
+    intt = s["lde"] * (main_width + aux_base_width) / cols / (1 + (1 << log_blowup))  # replicated inverse transforms
+    replicated = intt + HOST_SERIAL_MS
+    sharded = s["total"] - replicated
+    N, B = 1 << log_n, 1 << log_blowup
+    # digest all-to-all: a rank hashed B*N/G leaves, sends 32 B of each but its own share: one message of B*N/G^2 digests per peer.
+    # Trees: main, aux, quotient (B*N leaves each) + FRI rounds (B*N / arity^(r+1) leaves in round r): a geometric tail.
+    tree_equiv = 3.0 + sum((0.5 ** (arity_log * (r + 1))) for r in range(8))
+    a2a_ms = 0.0 if G == 1 else tree_equiv * (32.0 * B * N / (G * G)) / (link_gbs * 1e6)
+    # quotient coefficients: every rank needs all D = B chunks (16 B * N each); it holds D/G of them, receives D/G from each peer
+    gather_ms = 0.0 if G == 1 else (16.0 * N * B / G) / (link_gbs * 1e6)
+    ms = sharded / G + replicated + a2a_ms + gather_ms
+    return {"world": G, "ms": ms, "speedup": s["total"] / ms, "sharded_ms": sharded / G, "replicated_ms": replicated,
+            "replicated_intt_ms": intt, "host_serial_ms": HOST_SERIAL_MS,
+            "digest_all_to_all_ms": a2a_ms, "chunk_all_gather_ms": gather_ms, "link_gbs": link_gbs}
+
+
+def expected_collectives(world, n_trees_full=3, n_fri_rounds=8):
+    """Call counts of a sharded proof, for reading `comm_*` launch counts: per tree one all-to-all + one all-gather of subroots
+    (FRI trees too while their layers are still sharded), one all-gather of quotient chunks, one all-reduce per opened tree."""
+    if world == 1:
+        return {"all_to_all": 0, "all_gather": 0, "all_reduce": 0}
+    return {"all_to_all": n_trees_full + n_fri_rounds, "all_gather": n_trees_full + n_fri_rounds + 1 + n_fri_rounds,
+            "all_reduce": n_trees_full + n_fri_rounds + 1}  # + the OOD evaluation vectors

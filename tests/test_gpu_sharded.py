@@ -235,6 +235,7 @@ def _thread_ranks(world, body):
                 ctx.close()
         except Exception as e:  # pragma: no cover
             errors.append((rank, repr(e)))
+            fabric.abort()  # the peers must not wait for this rank in their next collective
 
     threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     for t in threads:
@@ -379,3 +380,80 @@ def test_sharded_proof_under_the_other_configurations(world, lmcs):
     for got in _thread_ranks(world, body):
         assert got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all()
         assert (got.commitments == exp["commitments"]).all() and (got.digest == exp["digest"]).all()
+
+
+def test_a_failing_rank_does_not_hang_its_peers():
+    """mh_local_fabric_abort (csrc/comm_local.cpp): rank 1 fails before its first collective; the other ranks, already waiting
+    in theirs, come back with an error instead of blocking for ever."""
+    import threading, time
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from miden_vm_amd import sharding
+    world = 4
+    fabric = sharding.LocalFabric(pkg.load_library(), world)
+    outcome = [None] * world
+
+    def run(rank):
+        ctx = pkg.Ctx(0)
+        comm = sharding.LocalComm(ctx, fabric, rank)  # collective: all four join
+        try:
+            if rank == 1:
+                time.sleep(0.3)  # let the others enter the collective first
+                raise RuntimeError("this rank's session failed")
+            comm.selftest()
+            outcome[rank] = "finished"
+        except RuntimeError as e:
+            outcome[rank] = "own failure" if rank == 1 else "error"
+            if rank == 1:
+                fabric.abort()
+        except pkg.MidenHipError as e:
+            outcome[rank] = "error: " + str(e)[:60]
+        finally:
+            comm.close()
+            ctx.close()
+
+    th = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=60)
+    assert not any(t.is_alive() for t in th), "a rank is still blocked in a collective"
+    fabric.close()
+    assert outcome[1] == "own failure" and all(o and o.startswith("error") for i, o in enumerate(outcome) if i != 1), outcome
+
+
+def test_collective_counts_and_bytes_of_a_world8_proof():
+    """The call counts and byte volumes of a sharded proof (thread ranks on the one GPU) against the model of DESIGN.md
+    section 5 / sharding.expected_collectives: per tree one digest all-to-all + one subroot all-gather, one chunk all-gather,
+    one all-reduce per opened tree + one for the OOD vectors."""
+    import oracle_binding as ob
+    import airs as A
+    from miden_vm_amd import dag
+    world, log_n = 8, 14
+    air, trace, prm = dag.dummy_miden_air(51, 8), A.dummy_trace(log_n, 51), ob.PROD_PARAMS
+    st, pre = ob.challenger_state(), ob.protocol_pre_observe(prm, [])
+
+    def body(pkg, sharding, rank, ctx, comm):
+        dair, dtr = pkg.DeviceAir(ctx, air), ctx.upload_trace(trace)
+        sharding.prove_sharded(pkg, ctx, comm, [dair], [dtr], [], prm, st, pre, None)
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        sharding.prove_sharded(pkg, ctx, comm, [dair], [dtr], [], prm, st, pre, None)
+        prof = ctx.prof()
+        ctx.prof_enable(False)
+        return {k: (v["count"], v["bytes"]) for k, v in prof.items() if k.startswith("comm_") or k in ("lde_intt", "deep_ood_eval")}
+
+    res = _thread_ranks(world, body)
+    N, B = 1 << log_n, 8
+    for r in res:
+        assert r == res[0]
+        n_a2a, bytes_a2a = r["comm_all_to_all"]
+        # main, aux, quotient trees: B*N/G leaf digests of 32 B per rank each; FRI trees add a geometric tail (< 1/3 of one tree)
+        full = 3 * 32 * B * N / world
+        assert full <= bytes_a2a <= full * (1 + 1 / 3 + 0.01), (bytes_a2a, full)
+        assert n_a2a >= 3
+        n_ag, bytes_ag = r["comm_all_gather"]
+        assert bytes_ag >= 16 * N * B  # the quotient chunk coefficients: 16 B x N per chunk, all D = B chunks on every rank
+        assert r["comm_all_reduce"][0] >= 4  # three opened trees + FRI rounds + the OOD vectors
+        assert r["lde_intt"][0] >= 2 and r["deep_ood_eval"][0] == 3  # replicated inverse transforms; OOD once per matrix
