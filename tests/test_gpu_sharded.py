@@ -447,7 +447,8 @@ def test_collective_counts_and_bytes_of_a_world8_proof():
     res = _thread_ranks(world, body)
     N, B = 1 << log_n, 8
     for r in res:
-        assert r == res[0]
+        # the collectives are the same on every rank; the OOD column shares differ (51 columns over 8 ranks)
+        assert {k: v for k, v in r.items() if k != "deep_ood_eval"} == {k: v for k, v in res[0].items() if k != "deep_ood_eval"}
         n_a2a, bytes_a2a = r["comm_all_to_all"]
         # main, aux, quotient trees: B*N/G leaf digests of 32 B per rank each; FRI trees add a geometric tail (< 1/3 of one tree)
         full = 3 * 32 * B * N / world
