@@ -258,7 +258,7 @@ def miden_shape_probe(pkg, ctx, steps=3):
                        "Poseidon2PermutationAir (aux column from its lookup program, on the device)",
            "ms_per_proof": dt * 1e3, "rows_per_s": (1 << 20) / dt, "proof_bytes": len(proof.bytes), "verifies": bool(ok),
            "quotient_eval_ms": prof.get("quotient_eval", {}).get("ms", 0) / steps, "logup_aux_ms": prof.get("logup_aux", {}).get("ms", 0) / steps,
-           "p2_air_compiled_chunks": airs[2].compiled_chunks}
+           "p2_air_compiled_chunks": airs[2].compiled_chunks, "p2_air_chunk_max_vgprs": airs[2].compiled_max_vgprs}
     try:
         pins = []
         for t in host:

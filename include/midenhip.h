@@ -180,6 +180,8 @@ int mh_air_log_quotient_degree(const mh_air* air);
  * under $MH_JIT_CACHE_DIR or ~/.cache/midenhip); 0 = small DAG, evaluated by the generic interpreter kernel.
  * MH_JIT=0 / MH_JIT=1 in the environment force either path (both are bit-identical). */
 int mh_air_compiled_chunks(const mh_air* air);
+/* Largest VGPR count over those kernels (their occupancy is 512 / VGPRs waves per SIMD); 0 when nothing was compiled. */
+int mh_air_compiled_max_vgprs(const mh_air* air);
 /* Preprocessed columns (fixed circuit data committed once at setup: crates/lifted-stark/src/preprocessed.rs; blob word
  * [10] = preprocessed width, DAG op 14 PREPROCESSED(a = col, b = row offset)).  Setup = mh_commit_traces of the
  * preprocessed matrices of the AIRs that declare some, in PROOF order (ascending height, ties by instance index), with

@@ -23,7 +23,7 @@ EXPORTS = [
     "mh_ctx_create", "mh_ctx_destroy", "mh_ctx_trim", "mh_last_error", "mh_device_count", "mh_prof_enable", "mh_prof_reset",
     "mh_prof_get", "mh_prof_dump", "mh_poseidon2_permute", "mh_poseidon2_register_rate", "mh_coset_lde_batch", "mh_trace_upload", "mh_trace_upload_async", "mh_trace_wait", "mh_trace_free",
     "mh_commit_traces", "mh_tree_free", "mh_tree_root", "mh_tree_log_height", "mh_tree_open", "mh_tree_download_lde",
-    "mh_tree_download_layers", "mh_air_load", "mh_air_free", "mh_air_log_quotient_degree", "mh_air_compiled_chunks", "mh_prove", "mh_proof_free",
+    "mh_tree_download_layers", "mh_air_load", "mh_air_free", "mh_air_log_quotient_degree", "mh_air_compiled_chunks", "mh_air_compiled_max_vgprs", "mh_prove", "mh_proof_free",
     "mh_proof_num_fields", "mh_proof_num_commitments", "mh_proof_fields", "mh_proof_commitments", "mh_proof_digest",
     "mh_proof_num_traces", "mh_proof_log_trace_heights", "mh_proof_serialize", "mh_shard_commit_leaves", "mh_shard_free",
     "mh_shard_leaf_digests", "mh_shard_build_subtree", "mh_merkle_cap_root", "mh_merkle_cap_root_lmcs", "mh_prove_sharded", "mh_commit_traces_sharded",
@@ -358,6 +358,8 @@ class DeviceAir:
         ctx._children.add(self)
         ctx.lib.mh_air_compiled_chunks.argtypes = [C.c_void_p]
         self.compiled_chunks = int(ctx.lib.mh_air_compiled_chunks(h))
+        ctx.lib.mh_air_compiled_max_vgprs.argtypes = [C.c_void_p]
+        self.compiled_max_vgprs = int(ctx.lib.mh_air_compiled_max_vgprs(h))
         self._lookup = None
 
     def attach_preprocessed(self, tree, matrix_index, raw=None):

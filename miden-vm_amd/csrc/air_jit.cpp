@@ -211,6 +211,16 @@ void jit_program_free(JitProgram* p) {
   delete p;
 }
 size_t jit_program_chunks(const JitProgram* p) { return p ? p->fns.size() : 0; }
+// Largest VGPR count over the compiled chunks (what bounds their occupancy: 512 / VGPRs waves per SIMD on gfx950); 0 = none / unknown.
+int jit_program_max_vgprs(const JitProgram* p) {
+  int mx = 0;
+  if (p)
+    for (hipFunction_t f : p->fns) {
+      int v = 0;
+      if (hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_NUM_REGS, f) == hipSuccess && v > mx) mx = v;
+    }
+  return mx;
+}
 
 JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
   const int mode = ir.outputs ? 1 : env_int("MH_JIT", -1);  // 0: never, 1: always, default: large DAGs only

@@ -38,3 +38,4 @@ static_assert(sizeof(JitArgs) == 14 * 8 + 4 * 8 + 7 * 4 + 4, "JitArgs layout is 
 // Runs every chunk over all `total` points of the quotient coset(s); a.q0 / q_count / spill are filled here.
 void jit_quotient_run(mh_ctx* c, const JitProgram* p, JitArgs a, size_t total);
 size_t jit_program_chunks(const JitProgram* p);
+int jit_program_max_vgprs(const JitProgram* p);

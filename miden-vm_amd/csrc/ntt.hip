@@ -21,6 +21,7 @@
 #include "gl.cuh"
 #include "kernels.hpp"
 #include "poseidon2_fast.cuh"
+#include <utility>
 
 // Field multiplications of the passes (table twiddles, coset scale): 0 = the compiler-scheduled C form (~23 VALU),
 // 1 = the volatile interleaved asm form of the hash kernels (pins the schedule: table loads are no longer hoisted, VGPRs
@@ -189,9 +190,179 @@ __device__ __forceinline__ void ntt_bfly_dif(u64& a, u64& b, int E) {
   a = s;
   b = E % 96 ? ntt_mul_pow2(d, E % 96) : d;
 }
+// ---- the forward (DIT) register DFT with hand-placed carry chains (NTT_ASM_BFLY, default 1) ----------------------------------
+// The C butterflies above cost hipcc ~14 VALU instructions without a shift and ~30 with one (every carry a v_cmp_lt_u64 +
+// v_cndmask pair, every 32 -> 64-bit composition a v_mov / v_or); a radix-16 round spent 870 of its ~1130 VALU instructions
+// there.  Here a stage's 2^(G-1) butterflies run as ONE stage-interleaved sequence of single-instruction asm statements, the way
+// p2f_mulN interleaves products (carries live in SGPR pairs, N >= 4 independent chains give every carry its 2 wait states):
+//   shifted butterfly:  X = b * 2^(E mod 96) laid out as lo64 + h0 * 2^64 + h1 * 2^96   (3-4 instructions, prelude in C)
+//                       r = lo + h0 * eps - h1  (the 6-instruction tail of the field multiplication: 1 mad + carry fix-ups)
+//   every butterfly:    t = canonical(r or b) (4), a + t (4), a - t (4); E >= 96 (2^96 = -1) swaps the two outputs.
+// 12 VALU for a plain butterfly, 21-22 for a shifted one: ~545 per radix-16 round instead of 870.
+#ifndef NTT_ASM_BFLY
+#define NTT_ASM_BFLY 1
+#endif
+#define NTT_A asm volatile
+// carry-outs nobody reads rotate through fixed scratch SGPR pairs (hipcc separates asm statements that share a register by s_nop)
+#define NTT_DEAD(i, TXT_PRE, TXT_POST, ...)                                          \
+  do {                                                                              \
+    switch ((i) & 3) {                                                              \
+      case 0: NTT_A(TXT_PRE "s[84:85]" TXT_POST : __VA_ARGS__ : "s84", "s85"); break; \
+      case 1: NTT_A(TXT_PRE "s[86:87]" TXT_POST : __VA_ARGS__ : "s86", "s87"); break; \
+      case 2: NTT_A(TXT_PRE "s[88:89]" TXT_POST : __VA_ARGS__ : "s88", "s89"); break; \
+      default: NTT_A(TXT_PRE "s[90:91]" TXT_POST : __VA_ARGS__ : "s90", "s91"); break; \
+    }                                                                               \
+  } while (0)
+// r[i] = lo[i] + h0[i] * 2^64 + h1[i] * 2^96 (mod p), any representative  [i < N, stage-interleaved]
+template <int N>
+__device__ __forceinline__ void ntt_reduce128N(u64 (&r)[N], const u64 (&lo)[N], const u32 (&h0)[N], const u32 (&h1)[N]) {
+  u64 t[N], c1[N], bb[N], bw[N], c3[N], k3[N];
+  u32 rl[N], rh[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) NTT_A("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t[i]), "=s"(c1[i]) : "v"(h0[i]), "v"(lo[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++) NTT_A("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(rl[i]), "=s"(bb[i]) : "v"(lo32(t[i])), "v"(h1[i]), "s"(c1[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++) NTT_DEAD(i, "v_addc_co_u32_e64 %0, ", ", %1, 0, %2", "=v"(rh[i]) : "v"(hi32(t[i])), "s"(c1[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++) NTT_A("v_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh[i]), "=s"(bw[i]) : "0"(rh[i]), "s"(bb[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++) NTT_A("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rl[i]), "=s"(c3[i]) : "0"(rl[i]), "s"(bw[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++) k3[i] = bw[i] & ~c3[i];  // scalar unit
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    NTT_DEAD(i, "v_subb_co_u32_e64 %0, ", ", %1, 0, %2", "=v"(rh[i]) : "0"(rh[i]), "s"(k3[i]));
+    r[i] = ((u64)rh[i] << 32) | rl[i];
+  }
+}
+// (a[i], t[i]) <- (a[i] + t[i], a[i] - t[i]) for any representatives a[i], t[i] < 2^64; results are representatives < 2^64
+template <int N>
+__device__ __forceinline__ void ntt_bfly_tailN(u64 (&a)[N], u64 (&t)[N]) {
+  u32 u0[N], u1[N], t0[N], t1[N], s0[N], s1[N], d0[N], d1[N];
+  u64 c0[N], c1[N], ca[N], cb[N], bs[N], ks[N], b0[N], b1[N], cd[N], kd[N];
+  // t <- canonical(t):  t >= p  <=>  t + eps carries out of 64 bits, and then t - p = t + eps (mod 2^64) = (t.lo - 1, 0)
+#pragma unroll
+  for (int i = 0; i < N; i++) NTT_A("v_add_co_u32_e64 %0, %1, %2, -1" : "=v"(u0[i]), "=s"(c0[i]) : "v"(lo32(t[i])));
+#pragma unroll
+  for (int i = 0; i < N; i++) NTT_A("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(u1[i]), "=s"(c1[i]) : "v"(hi32(t[i])), "s"(c0[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++) NTT_A("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(t0[i]) : "v"(lo32(t[i])), "v"(u0[i]), "s"(c1[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++) NTT_A("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(t1[i]) : "v"(hi32(t[i])), "v"(u1[i]), "s"(c1[i]));
+  // s = a + t: a carry out of 64 bits is worth eps = 2^32 - 1: lo -= 1 (borrow bs), hi += 1 - bs; cannot carry again (t < p)
+#pragma unroll
+  for (int i = 0; i < N; i++) NTT_A("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(s0[i]), "=s"(ca[i]) : "v"(lo32(a[i])), "v"(t0[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++) NTT_A("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(s1[i]), "=s"(cb[i]) : "v"(hi32(a[i])), "v"(t1[i]), "s"(ca[i]));
+  // d = a - t: a borrow is worth -eps: lo += 1 (carry cd), hi -= 1 - cd; cannot borrow again (t < p)
+#pragma unroll
+  for (int i = 0; i < N; i++) NTT_A("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(d0[i]), "=s"(b0[i]) : "v"(lo32(a[i])), "v"(t0[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++) NTT_A("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(d1[i]), "=s"(b1[i]) : "v"(hi32(a[i])), "v"(t1[i]), "s"(b0[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++) NTT_A("v_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(s0[i]), "=s"(bs[i]) : "0"(s0[i]), "s"(cb[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++) NTT_A("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(d0[i]), "=s"(cd[i]) : "0"(d0[i]), "s"(b1[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    ks[i] = cb[i] & ~bs[i];  // scalar unit
+    kd[i] = b1[i] & ~cd[i];
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) NTT_DEAD(i, "v_addc_co_u32_e64 %0, ", ", %1, 0, %2", "=v"(s1[i]) : "0"(s1[i]), "s"(ks[i]));
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    NTT_DEAD(i + 2, "v_subb_co_u32_e64 %0, ", ", %1, 0, %2", "=v"(d1[i]) : "0"(d1[i]), "s"(kd[i]));
+    a[i] = ((u64)s1[i] << 32) | s0[i];
+    t[i] = ((u64)d1[i] << 32) | d0[i];
+  }
+}
+// b * 2^S (S = 32 q + r in (0, 96)) as lo + h0 * 2^64 + h1 * 2^96:  y = b << r = (y0, y1, y2), y2 < 2^r;
+//   q = 0: (y0, y1 | y2, 0);  q = 1: (0, y0 | y1, y2);  q = 2: y0 * 2^64 + y1 * 2^96 + y2 * 2^128, and 2^128 = -2^32 mod p:
+//   p - y2 * 2^32 = (1, ~y2) as 32-bit words (y2 < 2^31), so (1, ~y2 | y0, y1).
+template <int S>
+__device__ __forceinline__ void ntt_shift_parts(u64 b, u64& lo, u32& h0, u32& h1) {
+  constexpr int q = S >> 5, r = S & 31;
+  const u32 b0 = lo32(b), b1 = hi32(b);
+  const u32 y0 = r ? (b0 << r) : b0;
+  const u32 y1 = r ? __builtin_amdgcn_alignbit(b1, b0, 32 - r) : b1;
+  const u32 y2 = r ? (b1 >> (32 - r)) : 0u;
+  if constexpr (q == 0) {
+    lo = ((u64)y1 << 32) | y0; h0 = y2; h1 = 0;
+  } else if constexpr (q == 1) {
+    lo = (u64)y0 << 32; h0 = y1; h1 = y2;
+  } else {
+    lo = ((u64)(~y2) << 32) | 1u; h0 = y0; h1 = y1;
+  }
+}
+// exponent of 2 in the twiddle of butterfly (e, e | 1 << m) of the forward DIT (position bit m = stage m; w_16 = 2^156)
+__host__ __device__ constexpr int ntt_fwd_exp(int m, int e) { return (156 * (8 >> m) * (e & ((1 << m) - 1))) % 192; }
+__host__ __device__ constexpr int ntt_bfly_lo(int m, int k) { return ((k >> m) << (m + 1)) | (k & ((1 << m) - 1)); }  // k-th index without bit m
+__host__ __device__ constexpr bool ntt_bfly_shifted(int m, int k) { return (ntt_fwd_exp(m, ntt_bfly_lo(m, k)) % 96) != 0; }
+__host__ __device__ constexpr int ntt_shift_slot(int m, int k) {  // shifted butterflies of stage m in front of butterfly k
+  int n = 0;
+  for (int i = 0; i < k; i++) n += ntt_bfly_shifted(m, i);
+  return n;
+}
+// Butterfly K (and the following ones) of stage M: operands into the interleaved arrays / results back into x.
+template <int H, int M, int K>
+struct NttBfly {
+  static constexpr int E = ntt_bfly_lo(M, K), EX = ntt_fwd_exp(M, E), SLOT = ntt_shift_slot(M, K);
+  static constexpr bool SH = (EX % 96) != 0;
+  __device__ __forceinline__ static void pre(const u64* x, u64* a, u64* t, u64* lo, u32* h0, u32* h1) {
+    a[K] = x[E];
+    if constexpr (SH) ntt_shift_parts<EX % 96>(x[E | (1 << M)], lo[SLOT], h0[SLOT], h1[SLOT]);
+    else t[K] = x[E | (1 << M)];
+    if constexpr (K + 1 < H) NttBfly<H, M, K + 1>::pre(x, a, t, lo, h0, h1);
+  }
+  __device__ __forceinline__ static void mid(u64* t, const u64* r) {
+    if constexpr (SH) t[K] = r[SLOT];
+    if constexpr (K + 1 < H) NttBfly<H, M, K + 1>::mid(t, r);
+  }
+  __device__ __forceinline__ static void post(u64* x, const u64* a, const u64* t) {
+    if constexpr (EX >= 96) {  // 2^96 = -1: the twiddle was negated, the two outputs trade places
+      x[E] = t[K];
+      x[E | (1 << M)] = a[K];
+    } else {
+      x[E] = a[K];
+      x[E | (1 << M)] = t[K];
+    }
+    if constexpr (K + 1 < H) NttBfly<H, M, K + 1>::post(x, a, t);
+  }
+};
+template <int G, int M>
+__device__ __forceinline__ void ntt_fwd_stage(u64 (&x)[1 << G]) {
+  constexpr int H = 1 << (G - 1);
+  constexpr int NS = ntt_shift_slot(M, H);  // shifted butterflies in this stage: 0, H/2, 3H/4, 7H/8
+  u64 a[H], t[H];
+  u64 lo[NS ? NS : 1], r[NS ? NS : 1];
+  u32 h0[NS ? NS : 1], h1[NS ? NS : 1];
+  NttBfly<H, M, 0>::pre(x, a, t, lo, h0, h1);
+  if constexpr (NS > 0) {
+    ntt_reduce128N<NS>(r, lo, h0, h1);
+    NttBfly<H, M, 0>::mid(t, r);
+  }
+  ntt_bfly_tailN<H>(a, t);
+  NttBfly<H, M, 0>::post(x, a, t);
+}
+template <int G, int M = 0>
+__device__ __forceinline__ void ntt_fwd_dft_asm(u64 (&x)[1 << G]) {
+  if constexpr (M < G) {
+    ntt_fwd_stage<G, M>(x);
+    ntt_fwd_dft_asm<G, M + 1>(x);
+  }
+}
+
 // 2^G-point DFT on registers; position bit m is stage m.  DIT: bit-reversed in, natural out; DIF: the transpose.
 template <int G, bool INV>
 __device__ __forceinline__ void ntt_dft_regs(u64 (&x)[1 << G], bool dif) {
+#if P2F_ASM && NTT_ASM_BFLY
+  if constexpr (!INV && G >= 3) {  // the forward passes (8/9 of an LDE); 4 or 8 butterflies per stage keep every carry 2 wait states away
+    ntt_fwd_dft_asm<G>(x);
+    return;
+  }
+#endif
   constexpr int W16 = INV ? 36 : 156;  // log2 of w_16 in the transform direction
   if (!dif) {
 #pragma unroll

@@ -841,6 +841,7 @@ int mh_air_attach_preprocessed(mh_air* a, const mh_tree* tree, int matrix_index,
   MH_CATCH
 }
 int mh_air_compiled_chunks(const mh_air* a) { return a ? (int)jit_program_chunks(a->jit) : -1; }
+int mh_air_compiled_max_vgprs(const mh_air* a) { return a ? jit_program_max_vgprs(a->jit) : -1; }
 
 // ---- coset-sharded commitment (one process per GPU) -------------------------
 struct mh_shard {

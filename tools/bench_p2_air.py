@@ -35,7 +35,7 @@ for jit in ("1", "0"):
         proof = pkg.prove(ctx, [dair], [dtr], [], prm, st, pre, None)
     dt = (time.perf_counter() - t0) / steps
     prof = ctx.prof(); ctx.prof_enable(False)
-    out = {"air": "Poseidon2PermutationAir", "log_n": log_n, "MH_JIT": jit, "compiled_chunks": dair.compiled_chunks, "ms_per_proof": dt * 1e3,
+    out = {"air": "Poseidon2PermutationAir", "log_n": log_n, "MH_JIT": jit, "compiled_chunks": dair.compiled_chunks, "max_vgprs": dair.compiled_max_vgprs, "ms_per_proof": dt * 1e3,
            "rows_per_s": (1 << log_n) / dt, "kernels_ms": {k_: round(v["ms"] / steps, 3) for k_, v in prof.items() if not k_.startswith("span:") and v["ms"] / steps > 0.05}}
     print(json.dumps(out))
     dtr.free(); dair.free()
