@@ -452,10 +452,12 @@ def main():
             "comm_ms": comm, "comm_calls_per_proof": {k: prof[k]["count"] / args.steps for k in prof if k.startswith("comm_")},
             "replicated_intt_ms": round(per("lde_intt"), 3), "ood_ms": round(per("deep_ood_eval"), 3),
             "kernel_ms": round(sum(per(k) for k in prof if not k.startswith(("comm_", "span:")) and k != "lde_intt"), 3),
-            "model": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in _sh.predict_sharded_ms(world, log_n).items()},
+            # the model scales the 2^24 single-GPU spans linearly: meaningful for large proofs only (fixed latencies dominate small ones)
+            "model": ({k: (round(v, 2) if isinstance(v, float) else v) for k, v in _sh.predict_sharded_ms(world, log_n).items()}
+                      if log_n >= 22 else None),
             "model_note": "per-rank ms predicted from the single-GPU spans of profiles/r02_config_shapes.txt (2^24: 840 ms) with "
                           "60 GB/s per xGMI link and direction; replicated = inverse NTTs + host-serial tree tops / transcript"}
-    out["roofline"] = roofline(prof, "r02_pmc_leaf_absorb.json")
+    out["roofline"] = roofline(prof, "r03_pmc_leaf_absorb.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_leaf_absorb.json")) else "r02_pmc_leaf_absorb.json")
     try:
         perms = (8 << log_n) * (7 + 2 + 2) // (world if mode == "sharded" else 1)  # per rank
         out["roofline_valu"] = valu_roofline(ctx, prof, perms, args.steps)

@@ -331,6 +331,50 @@ struct NttBfly {
     if constexpr (K + 1 < H) NttBfly<H, M, K + 1>::post(x, a, t);
   }
 };
+// Interleave at most NTT_ILV chains at a time: every live carry is an SGPR pair, eight butterflies at once (24+ pairs next to the
+// kernel's own scalars) made hipcc spill SGPRs into VGPR lanes (v_writelane / v_readlane in the round loop).
+#ifndef NTT_ILV
+#define NTT_ILV 4
+#endif
+template <int N>
+__device__ __forceinline__ void ntt_tail_split(u64 (&a)[N], u64 (&t)[N]) {
+  if constexpr (N <= NTT_ILV) {
+    ntt_bfly_tailN<N>(a, t);
+  } else {
+    constexpr int A = NTT_ILV, B = N - NTT_ILV;
+    u64 a0[A], t0[A], a1[B], t1[B];
+#pragma unroll
+    for (int i = 0; i < A; i++) { a0[i] = a[i]; t0[i] = t[i]; }
+#pragma unroll
+    for (int i = 0; i < B; i++) { a1[i] = a[A + i]; t1[i] = t[A + i]; }
+    ntt_bfly_tailN<A>(a0, t0);
+    ntt_tail_split<B>(a1, t1);
+#pragma unroll
+    for (int i = 0; i < A; i++) { a[i] = a0[i]; t[i] = t0[i]; }
+#pragma unroll
+    for (int i = 0; i < B; i++) { a[A + i] = a1[i]; t[A + i] = t1[i]; }
+  }
+}
+template <int N>
+__device__ __forceinline__ void ntt_reduce_split(u64 (&r)[N], const u64 (&lo)[N], const u32 (&h0)[N], const u32 (&h1)[N]) {
+  if constexpr (N <= NTT_ILV) {
+    ntt_reduce128N<N>(r, lo, h0, h1);
+  } else {
+    constexpr int A = (N >= 2 * NTT_ILV || N - NTT_ILV >= 3) ? NTT_ILV : N - 3, B = N - A;  // never leave a tail of fewer than 3 chains
+    u64 r0[A], lo0[A], r1[B], lo1[B];
+    u32 p0[A], q0[A], p1[B], q1[B];
+#pragma unroll
+    for (int i = 0; i < A; i++) { lo0[i] = lo[i]; p0[i] = h0[i]; q0[i] = h1[i]; }
+#pragma unroll
+    for (int i = 0; i < B; i++) { lo1[i] = lo[A + i]; p1[i] = h0[A + i]; q1[i] = h1[A + i]; }
+    ntt_reduce128N<A>(r0, lo0, p0, q0);
+    ntt_reduce_split<B>(r1, lo1, p1, q1);
+#pragma unroll
+    for (int i = 0; i < A; i++) r[i] = r0[i];
+#pragma unroll
+    for (int i = 0; i < B; i++) r[A + i] = r1[i];
+  }
+}
 template <int G, int M>
 __device__ __forceinline__ void ntt_fwd_stage(u64 (&x)[1 << G]) {
   constexpr int H = 1 << (G - 1);
@@ -340,10 +384,10 @@ __device__ __forceinline__ void ntt_fwd_stage(u64 (&x)[1 << G]) {
   u32 h0[NS ? NS : 1], h1[NS ? NS : 1];
   NttBfly<H, M, 0>::pre(x, a, t, lo, h0, h1);
   if constexpr (NS > 0) {
-    ntt_reduce128N<NS>(r, lo, h0, h1);
+    ntt_reduce_split<NS>(r, lo, h0, h1);
     NttBfly<H, M, 0>::mid(t, r);
   }
-  ntt_bfly_tailN<H>(a, t);
+  ntt_tail_split<H>(a, t);
   NttBfly<H, M, 0>::post(x, a, t);
 }
 template <int G, int M = 0>
