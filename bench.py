@@ -135,13 +135,22 @@ def valu_roofline(ctx, prof, perms, steps):
         out["register_rate"] = ctx.poseidon2_register_rate() / 1e9
     except Exception as e:  # pragma: no cover
         out["register_rate_error"] = repr(e)[:120]
-    N_MUL, MUL_VALU, LIN_VALU, CYCLES_PER_VALU, SIMDS, MAX_CLOCK_GHZ = 506, 13, 3500, 4.0, 1024, 2.4
+    # Issue cost per instruction class (tools/instbench, profiles/r01_microbench.txt, relative to each other): v_mad_u64_u32, the VOP3
+    # carry-chain forms (v_add_co / v_addc_co / v_subb_co with SGPR carries), v_lshl_add_u64 and 64-bit shifts all cost the same slot
+    # (1.86-2.00 ns in the microbenchmark = the 4 cycles the permutation measures: 10.95 k instructions in 43.7 k cycles); only
+    # carry-less 32-bit VOP1/VOP2 (v_mov, v_cndmask, v_and, v_add_u32) are cheaper (1.26 ns = 0.65 of a slot).  The permutation's
+    # dynamic mix (ISA of k_compress, per section x trip count): 4.3 % plain, the rest in the 4-cycle class.
+    N_MUL, MUL_VALU, LIN_VALU, SIMDS, MAX_CLOCK_GHZ = 506, 13, 3500, 1024, 2.4
+    CYC_WIDE, CYC_PLAIN, PLAIN_SHARE = 4.0, 2.6, 0.043
     min_valu = N_MUL * MUL_VALU + LIN_VALU
-    out["peak"] = SIMDS * MAX_CLOCK_GHZ * 64 / (min_valu * CYCLES_PER_VALU)
+    cycles = min_valu * ((1 - PLAIN_SHARE) * CYC_WIDE + PLAIN_SHARE * CYC_PLAIN)
+    out["peak"] = SIMDS * MAX_CLOCK_GHZ * 64 / cycles
     out["frac"] = out["achieved"] / out["peak"]
-    out["valu_per_permutation"] = {"counted_minimum": min_valu, "measured_SQ_INSTS_VALU": 10977}
-    out["peak_basis"] = (f"{SIMDS} SIMDs x {MAX_CLOCK_GHZ} GHz (max clock) x 64 lanes / ({min_valu} VALU x {CYCLES_PER_VALU:.0f} issue cycles); "
-                         "measured clock under this load 2.24 GHz (s_memtime)")
+    out["valu_per_permutation"] = {"counted_minimum": min_valu, "measured_SQ_INSTS_VALU": 10977,
+                                   "issue_cycles_by_class": {"mad_u64_u32 / carry-chain VOP3 / 64-bit add, shift": CYC_WIDE, "plain 32-bit VOP1/VOP2": CYC_PLAIN},
+                                   "plain_share_of_dynamic_mix": PLAIN_SHARE}
+    out["peak_basis"] = (f"{SIMDS} SIMDs x {MAX_CLOCK_GHZ} GHz (max clock) x 64 lanes / ({min_valu} VALU: {100 * (1 - PLAIN_SHARE):.1f} % at {CYC_WIDE:.0f} issue "
+                         f"cycles, {100 * PLAIN_SHARE:.1f} % at {CYC_PLAIN}); measured clock under this load 2.24-2.35 GHz (s_memtime)")
     return out
 
 
