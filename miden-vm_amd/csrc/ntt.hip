@@ -457,10 +457,23 @@ __device__ u64 p2f_mul_c(u64 a, u64 b);
 #ifndef NTT16_OCC
 #define NTT16_OCC
 #endif
-static size_t ntt_lds_bytes(int tile_log) { return (((size_t)1 << tile_log) + ((size_t)1 << (tile_log - 4))) * 8; }  // one pad element per 16
-__device__ __forceinline__ u32 ntt_pad(u32 l) { return l + (l >> 4); }
+// LDS placement of tile element l.  NTT_SWZ = 1 (default, the 2^12 tile): XOR swizzle l ^ ((l >> 4) & 31) -- conflict-free for the
+// three access shapes of a pass (element stride 1 / 16 / 256 between a thread's sixteen values, consecutive lanes = consecutive
+// low bits: every group of 32 lanes covers all 32 bank pairs) and for the linear tile load, in EXACTLY 32 KB: five workgroups share
+// a CU's 160 KB (the padded tile, 34 KB, allowed four).  The 2^14 tile (one workgroup per CU anyway) keeps one pad element per 16.
+#ifndef NTT_SWZ
+#define NTT_SWZ 1
+#endif
+static size_t ntt_lds_bytes(int tile_log) {
+  if (NTT_SWZ && tile_log == NTT_TILE_LOG) return ((size_t)1 << tile_log) * 8;
+  return (((size_t)1 << tile_log) + ((size_t)1 << (tile_log - 4))) * 8;
+}
+template <bool SWZ>
+__device__ __forceinline__ u32 ntt_pad(u32 l) {
+  return SWZ ? (l ^ ((l >> 4) & 31u)) : (l + (l >> 4));
+}
 
-template <int G, bool INV>
+template <int G, bool INV, bool SWZ>
 __device__ __forceinline__ void ntt_round(const NttPassArgs& a, u64* lds, int st, u32 tile_n, size_t lo0, u64* dst_direct,
                                           size_t gbase, const u64* __restrict__ tw) {
   const int b0 = st + a.cb, s = a.s_lo + st;
@@ -471,7 +484,7 @@ __device__ __forceinline__ void ntt_round(const NttPassArgs& a, u64* lds, int st
     const u32 gm = (((l0 >> a.cb) & ((1u << st) - 1)) << a.s_lo) | ((u32)lo0 << a.cb) | (l0 & cb_mask);
     u64 x[1 << G];
 #pragma unroll
-    for (int e = 0; e < (1 << G); e++) x[e] = lds[ntt_pad(l0 | ((u32)e << b0))];
+    for (int e = 0; e < (1 << G); e++) x[e] = lds[ntt_pad<SWZ>(l0 | ((u32)e << b0))];
     if (!INV && s > 0) ntt_tw_mul<(1 << G) - 1, 1>(x, tw, s, gm);
     ntt_dft_regs<G, INV>(x, INV);
     if (INV && s > 0) ntt_tw_mul<(1 << G) - 1, 1>(x, tw, s, gm);
@@ -483,7 +496,7 @@ __device__ __forceinline__ void ntt_round(const NttPassArgs& a, u64* lds, int st
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < (1 << G); e++) lds[ntt_pad(l0 | ((u32)e << b0))] = x[e];
+      for (int e = 0; e < (1 << G); e++) lds[ntt_pad<SWZ>(l0 | ((u32)e << b0))] = x[e];
     }
   }
 }
@@ -492,6 +505,7 @@ __device__ __forceinline__ void ntt_round(const NttPassArgs& a, u64* lds, int st
 template <bool INV, int THREADS>
 __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a) {
   extern __shared__ u64 lds[];
+  constexpr bool SWZ = NTT_SWZ && THREADS == NTT_THREADS;  // the 2^12 tile
   const int tile_log = a.r_bits + a.cb;
   const u32 tile_n = 1u << tile_log;
   const u32 cb_mask = (1u << a.cb) - 1;
@@ -517,7 +531,7 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
       u64 sc = NTT_MUL1(a.scale_lo[zc * a.scale_lo_z + (k & ((1u << a.lb) - 1))], a.scale_hi[zc * a.scale_hi_z + (k >> a.lb)]);
       v = NTT_MUL1(v, sc);
     }
-    lds[ntt_pad(l)] = v;
+    lds[ntt_pad<SWZ>(l)] = v;
   }
   __syncthreads();
   // stage groups: as many radix-16 rounds as fit, the remainder (1..3 stages) in one smaller round.
@@ -541,10 +555,10 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
     }
     u64* direct = (i == n_rounds - 1) ? dst : nullptr;
     switch (g) {
-      case 4: ntt_round<4, INV>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri]); break;
-      case 3: ntt_round<3, INV>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri]); break;
-      case 2: ntt_round<2, INV>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri]); break;
-      default: ntt_round<1, INV>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri]); break;
+      case 4: ntt_round<4, INV, SWZ>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri]); break;
+      case 3: ntt_round<3, INV, SWZ>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri]); break;
+      case 2: ntt_round<2, INV, SWZ>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri]); break;
+      default: ntt_round<1, INV, SWZ>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri]); break;
     }
     if (!direct) __syncthreads();
   }
