@@ -425,14 +425,14 @@ __device__ __forceinline__ void ntt_dft_regs(u64 (&x)[1 << G], bool dif) {
 // x[e] *= tw[(e - 1) << s | gm] for e = OFF .. OFF + K - 1: the table twiddles of a round, multiplied in interleaved
 // groups of <= 5 products (p2f_mulN); consecutive lanes = consecutive gm: coalesced loads
 template <int K, int OFF>
-__device__ __forceinline__ void ntt_tw_mul(u64* x, const u64* __restrict__ tw, int s, u32 gm) {
+__device__ __forceinline__ void ntt_tw_mul(u64* x, const u64* __restrict__ tw, int s) {
   if constexpr (K > 0) {
     constexpr int C = K >= 5 ? 5 : K;
     u64 a[C], b[C];
 #pragma unroll
     for (int i = 0; i < C; i++) {
       a[i] = x[OFF + i];
-      b[i] = tw[((size_t)(OFF + i - 1) << s) | gm];
+      b[i] = tw[(size_t)(OFF + i - 1) << s];  // tw already points at this thread's column gm of the plane: a wave-uniform offset per element
     }
 #if P2F_ASM && NTT_ASM_MUL == 1
     p2f_mulN<C>(a, a, b);
@@ -442,12 +442,12 @@ __device__ __forceinline__ void ntt_tw_mul(u64* x, const u64* __restrict__ tw, i
 #endif
 #pragma unroll
     for (int i = 0; i < C; i++) x[OFF + i] = a[i];
-    ntt_tw_mul<K - C, OFF + C>(x, tw, s, gm);
+    ntt_tw_mul<K - C, OFF + C>(x, tw, s);
   }
 }
 #else
 template <int K, int OFF>
-__device__ void ntt_tw_mul(u64* x, const u64* __restrict__ tw, int s, u32 gm);
+__device__ void ntt_tw_mul(u64* x, const u64* __restrict__ tw, int s);
 template <int G, bool INV>
 __device__ void ntt_dft_regs(u64 (&x)[1 << G], bool dif);
 __device__ u64 ntt_canon(u64 t);
@@ -482,21 +482,29 @@ __device__ __forceinline__ void ntt_round(const NttPassArgs& a, u64* lds, int st
     const u32 low = q & ((1u << b0) - 1);
     const u32 l0 = ((q >> b0) << (b0 + G)) | low;
     const u32 gm = (((l0 >> a.cb) & ((1u << st) - 1)) << a.s_lo) | ((u32)lo0 << a.cb) | (l0 & cb_mask);
+    // LDS slot of element e: the swizzle is linear over XOR and l0, e << b0 have no bit in common, so
+    // slot(l0 | e << b0) = slot(l0) ^ slot(e << b0): one per-thread value and sixteen wave-uniform ones (scalar unit), one
+    // v_xor per access instead of the shift / and / or chain of the generic form (~4 VALU x 32 accesses per round)
+    const u32 p0 = ntt_pad<SWZ>(l0);
     u64 x[1 << G];
 #pragma unroll
-    for (int e = 0; e < (1 << G); e++) x[e] = lds[ntt_pad<SWZ>(l0 | ((u32)e << b0))];
-    if (!INV && s > 0) ntt_tw_mul<(1 << G) - 1, 1>(x, tw, s, gm);
+    for (int e = 0; e < (1 << G); e++) x[e] = lds[SWZ ? (p0 ^ ntt_pad<true>((u32)e << b0)) : ntt_pad<false>(l0 | ((u32)e << b0))];
+    if (!INV && s > 0) ntt_tw_mul<(1 << G) - 1, 1>(x, tw + gm, s);
     ntt_dft_regs<G, INV>(x, INV);
-    if (INV && s > 0) ntt_tw_mul<(1 << G) - 1, 1>(x, tw, s, gm);
+    if (INV && s > 0) ntt_tw_mul<(1 << G) - 1, 1>(x, tw + gm, s);
     if (dst_direct) {
+      // global index of element e: b0 >= cb, so e << b0 lands above the tile's contiguous bits: index = index(l0) + (e << (st + s_lo))
+      u64* p = dst_direct + (gbase | ((size_t)(l0 >> a.cb) << a.s_lo) | (l0 & cb_mask));
+      if (a.canon_out) {  // decided once per round, not per element
 #pragma unroll
-      for (int e = 0; e < (1 << G); e++) {
-        const u32 l = l0 | ((u32)e << b0);
-        dst_direct[gbase | ((size_t)(l >> a.cb) << a.s_lo) | (l & cb_mask)] = a.canon_out ? ntt_canon(x[e]) : x[e];
+        for (int e = 0; e < (1 << G); e++) p[(size_t)e << s] = ntt_canon(x[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < (1 << G); e++) p[(size_t)e << s] = x[e];
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < (1 << G); e++) lds[ntt_pad<SWZ>(l0 | ((u32)e << b0))] = x[e];
+      for (int e = 0; e < (1 << G); e++) lds[SWZ ? (p0 ^ ntt_pad<true>((u32)e << b0)) : ntt_pad<false>(l0 | ((u32)e << b0))] = x[e];
     }
   }
 }
@@ -523,15 +531,43 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
   u64* dst = a.dst + (size_t)blockIdx.y * a.dst_col_stride + (size_t)zc * a.dst_z_stride;
   if (z) __syncthreads();  // the previous coset's last round still reads the tile
 
-  for (u32 l = threadIdx.x; l < tile_n; l += THREADS) {
-    size_t g = gbase | ((size_t)(l >> a.cb) << a.s_lo) | (l & cb_mask);
-    u64 v = src[g];
-    if (a.scale_lo) {
-      u32 k = bitrev32((u32)g, a.log_n);
-      u64 sc = NTT_MUL1(a.scale_lo[zc * a.scale_lo_z + (k & ((1u << a.lb) - 1))], a.scale_hi[zc * a.scale_hi_z + (k >> a.lb)]);
-      v = NTT_MUL1(v, sc);
+  constexpr int LOG_T = THREADS == 256 ? 8 : 10;
+  if (tile_n == 16u * THREADS && a.cb <= LOG_T) {
+    // full tile: element i of this thread is l = tid + i * THREADS; THREADS >= 2^cb, so i * THREADS lands above the contiguous bits:
+    // global index = index(tid) + (i << (LOG_T - cb + s_lo)), LDS slot = slot(tid) ^ slot(i * THREADS) (linear swizzle)
+    const u32 tid = threadIdx.x;
+    const size_t g0 = gbase | ((size_t)(tid >> a.cb) << a.s_lo) | (tid & cb_mask);
+    const int shg = LOG_T - a.cb + a.s_lo;
+    const u32 p0 = ntt_pad<SWZ>(tid);
+    // four elements at a time: all sixteen in flight (plus their scale-table loads) cost 200 VGPRs
+#pragma unroll 1
+    for (int c = 0; c < 16; c += 4) {
+      u64 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = src[g0 + ((size_t)(c + j) << shg)];
+      if (a.scale_lo) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const u32 k = bitrev32((u32)(g0 + ((size_t)(c + j) << shg)), a.log_n);
+          const u64 sc = NTT_MUL1(a.scale_lo[zc * a.scale_lo_z + (k & ((1u << a.lb) - 1))], a.scale_hi[zc * a.scale_hi_z + (k >> a.lb)]);
+          v[j] = NTT_MUL1(v[j], sc);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        lds[SWZ ? (p0 ^ ntt_pad<true>((u32)(c + j) * THREADS)) : ntt_pad<false>(tid + (u32)(c + j) * THREADS)] = v[j];
     }
-    lds[ntt_pad<SWZ>(l)] = v;
+  } else {
+    for (u32 l = threadIdx.x; l < tile_n; l += THREADS) {
+      size_t g = gbase | ((size_t)(l >> a.cb) << a.s_lo) | (l & cb_mask);
+      u64 v = src[g];
+      if (a.scale_lo) {
+        u32 k = bitrev32((u32)g, a.log_n);
+        u64 sc = NTT_MUL1(a.scale_lo[zc * a.scale_lo_z + (k & ((1u << a.lb) - 1))], a.scale_hi[zc * a.scale_hi_z + (k >> a.lb)]);
+        v = NTT_MUL1(v, sc);
+      }
+      lds[ntt_pad<SWZ>(l)] = v;
+    }
   }
   __syncthreads();
   // stage groups: as many radix-16 rounds as fit, the remainder (1..3 stages) in one smaller round.
