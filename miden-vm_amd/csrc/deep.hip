@@ -138,6 +138,9 @@ void deep_ood_eval_matrix(mh_ctx* c, const LdeMatrix& m, int log_blowup, e2 y0, 
 // (precompiles-prover/src/session/prove.rs) commits 12 x {main, aux, quotient} + its setup matrices
 static constexpr int DEEP_MAX_MATS = 128;
 static constexpr unsigned DEEP_FLUSH = 128;
+#ifndef DEEP_UNROLL
+#define DEEP_UNROLL 2  // columns per trip of the dot-product loop (loads in flight per lane = DEEP_UNROLL x DEEP_PTS)
+#endif
 static constexpr int DEEP_PTS = 2;  // points per lane (they share one Fermat inversion); more costs occupancy
 struct DeepMat {
   const u64* lde;
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void k_deep_assemble(DeepArgs a) {
     const size_t nm_mask = ((size_t)1 << m.log_n) - 1;
     const u64* colp = m.lde + (j << m.log_n);
     const size_t cstride = (size_t)1 << (m.log_n + a.log_blowup);
-#pragma unroll 2
+#pragma unroll DEEP_UNROLL
     for (u32 cidx = 0; cidx < m.width; cidx++) {
       const u64 cf0 = a.negc[2 * (m.coef_off + cidx)], cf1 = a.negc[2 * (m.coef_off + cidx) + 1];
       u32 al[2][4];
