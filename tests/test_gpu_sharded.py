@@ -253,14 +253,23 @@ def test_local_communicator_selftest(world):
     assert res == [1] * world
 
 
-@pytest.mark.parametrize("world,case", [(2, "miden_small"), (4, "miden"), (8, "miden"), (2, "multi"), (8, "miden18"), (2, "miden20")])
+@pytest.mark.parametrize("world,case", [(2, "miden_small"), (4, "miden"), (8, "miden"), (2, "multi"), (8, "miden18"), (2, "miden20"),
+                                        (4, "p2air"), (8, "p2air")])
 def test_sharded_proof_through_a_stream_ordered_communicator(world, case):
     """The sharded prover with a STREAM-ORDERED communicator and several ranks (what the RCCL communicator is on a multi-GPU
     node): no host synchronisation around the collectives.  Every rank's proof must equal the single-GPU proof."""
     import oracle_binding as ob
     import airs as A
     from miden_vm_amd import dag
-    if case == "miden":
+    lookups = {}
+    if case == "p2air":  # the real Poseidon2 permutation AIR (16 periodic columns, compiled chunks, aux column from its lookup program) next to a stand-in core
+        from miden_vm_amd import miden_air as MA
+        p2, lk = MA.poseidon2_permutation_air(host_aux=ob.lookup_build_aux)
+        rng = np.random.default_rng(4)
+        airs_ = [dag.dummy_miden_air(51, 4, num_aux_values=1), p2]
+        traces = [A.dummy_trace(12, 51, seed=2), MA.poseidon2_permutation_trace(11, rng.integers(0, ob.P, (60, 12), dtype=np.uint64), rng.integers(1, 4, 60, dtype=np.uint64))]
+        pub, prm, lookups = [], ob.PROD_PARAMS, {1: lk}
+    elif case == "miden":
         airs_, traces, pub, prm = [dag.dummy_miden_air(51, 8)], [A.dummy_trace(10, 51)], [], ob.PROD_PARAMS
     elif case in ("miden18", "miden20"):  # bench-sized shards: every NTT pass shape and the real collective sizes
         airs_, traces, pub, prm = [dag.dummy_miden_air(51, 8)], [A.dummy_trace(int(case[5:]), 51)], [], ob.PROD_PARAMS
@@ -282,6 +291,8 @@ def test_sharded_proof_through_a_stream_ordered_communicator(world, case):
 
     def body(pkg, sharding, rank, ctx, comm):
         dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+        for i, lk in lookups.items():
+            dairs[i].attach_lookup(pkg.DeviceLookup(ctx, lk))
         dtr = [ctx.upload_trace(t) for t in traces]
         got = sharding.prove_sharded(pkg, ctx, comm, dairs, dtr, pub, prm, st, pre, aux_builder if need_cb else None)
         got2 = sharding.prove_sharded(pkg, ctx, comm, dairs, dtr, pub, prm, st, pre, aux_builder if need_cb else None)  # buffers reused
