@@ -331,3 +331,183 @@ def lookup_from_constraints(air_blob, name="derived"):
     finally:
         sys.setrecursionlimit(limit)
     return Lookup(lb, name)
+
+
+# ---- the reference's closure-based lookup API, both adapters at once ------------------------------------------------------------
+class LogUp:
+    """`LookupBuilder` of air/src/lookup/builder.rs:103-183 over a dag.AirBuilder, playing BOTH of the reference's adapters in one
+    walk: the constraint path (lookup/constraint.rs: `(V, U)` running pairs per group / batch / column, the three constraints per
+    column emitted when the column closes) and the prover path (lookup/prover.rs: `(flag * multiplicity, denominator)` fractions per
+    column, collected into an "MHLKP001" program).  An AIR's `lookup_eval` is written once against it:
+
+        lk = dag.LogUp(b, max_message_width=16, num_bus_ids=25)         # Challenges::new (lookup/challenges.rs:48-70)
+        with lk.column() as col:                                         # LookupBuilder::next_column
+            with col.group() as g:                                       # LookupColumn::group: mutually exclusive flags
+                g.insert(flag, multiplicity, lambda ch: ch.encode(bus, [..]))   # LookupGroup::insert / add / remove
+                with g.batch(flag) as bt:                                # LookupGroup::batch: simultaneous interactions
+                    bt.add(lambda ch: ...); bt.insert(m, lambda ch: ...)
+        lookup = lk.finish()                                             # -> dag.Lookup (prover path), constraints are in b
+
+    `message(ch)` receives the Challenges of whichever side is being built and returns the encoded denominator."""
+
+    class Challenges:
+        def __init__(self, bld, max_message_width, num_bus_ids):
+            alpha, beta = bld.randomness(0), bld.randomness(1)
+            self.alpha = alpha
+            self.beta_powers = [bld.const(1)]
+            for _ in range(1, max_message_width):
+                self.beta_powers.append(self.beta_powers[-1] * beta)
+            gamma = self.beta_powers[-1] * beta
+            self.bus_prefix = [alpha + gamma * (i + 1) for i in range(num_bus_ids)]
+
+        def encode(self, bus, elems):  # Challenges::encode (challenges.rs:75-97)
+            acc = self.bus_prefix[bus]
+            for i, e in enumerate(elems):
+                acc = acc + self.beta_powers[i] * e
+            return acc
+
+        def inner_product_at(self, offset, elems):  # challenges.rs:104-121
+            acc = None
+            for i, e in enumerate(elems):
+                t = self.beta_powers[offset + i] * e
+                acc = t if acc is None else acc + t
+            return acc
+
+    def __init__(self, builder, max_message_width, num_bus_ids, prover_builder=None):
+        self.b = builder
+        self.lb = prover_builder if prover_builder is not None else LookupBuilder(
+            builder.main_width, num_cols=builder.aux_width, num_randomness=builder.num_randomness, periodic=builder.periodic,
+            preprocessed_width=builder.preprocessed_width)
+        self.ch_c = LogUp.Challenges(self.b, max_message_width, num_bus_ids)
+        self.ch_p = LogUp.Challenges(self.lb, max_message_width, num_bus_ids)
+        self.column_idx = 0
+
+    def mirror(self, f):
+        """An expression written once, built on both sides: f(builder) -> Expr."""
+        return f(self.b), f(self.lb)
+
+    class _Batch:
+        def __init__(self, lk, col, flag):
+            self.lk, self.col, self.flag = lk, col, flag
+            self.n, self.d = lk.b.const(0), lk.b.const(1)
+
+        def __enter__(self):
+            return self
+
+        def _push(self, mult_pair, message):
+            v = message(self.lk.ch_c)
+            d_prev = self.d
+            mc, mp = mult_pair
+            self.n = self.n * v + (d_prev * mc if mc is not None else d_prev)  # ConstraintBatch::insert: N <- N v + m D
+            self.d = self.d * v
+            fp = self.flag[1]
+            self.lk.lb.fraction(self.col, fp * mp if mp is not None else fp, message(self.lk.ch_p))
+
+        def add(self, message):
+            self._push((None, None), message)
+
+        def remove(self, message):
+            self._push((self.lk.b.const(P - 1), self.lk.lb.const(P - 1)), message)
+
+        def insert(self, multiplicity, message):
+            self._push(multiplicity, message)
+
+        def __exit__(self, *exc):
+            return False
+
+    class _Group:
+        def __init__(self, lk, col):
+            self.lk, self.col = lk, col
+            self.u, self.v = lk.b.const(1), lk.b.const(0)
+
+        def __enter__(self):
+            return self
+
+        def insert(self, flag, multiplicity, message):
+            """flag, multiplicity: (constraint-side Expr, prover-side Expr) pairs from LogUp.mirror."""
+            one = self.lk.b.const(1)
+            d = message(self.lk.ch_c)
+            self.u = self.u + (d - one) * flag[0]           # ConstraintGroup::insert (constraint.rs:333-347)
+            self.v = self.v + flag[0] * multiplicity[0]
+            self.lk.lb.fraction(self.col, flag[1] * multiplicity[1], message(self.lk.ch_p))
+
+        def add(self, flag, message):
+            one = self.lk.b.const(1)
+            d = message(self.lk.ch_c)
+            self.u = self.u + (d - one) * flag[0]
+            self.v = self.v + flag[0]
+            self.lk.lb.fraction(self.col, flag[1], message(self.lk.ch_p))
+
+        def remove(self, flag, message):
+            one = self.lk.b.const(1)
+            d = message(self.lk.ch_c)
+            self.u = self.u + (d - one) * flag[0]
+            self.v = self.v - flag[0]
+            self.lk.lb.fraction(self.col, self.lk.lb.const(0) - flag[1], message(self.lk.ch_p))
+
+        def batch(self, flag):
+            bt = LogUp._Batch(self.lk, self.col, flag)
+            grp = self
+
+            class _Ctx:
+                def __enter__(self_inner):
+                    return bt
+
+                def __exit__(self_inner, *exc):
+                    one = grp.lk.b.const(1)
+                    grp.u = grp.u + (bt.d - one) * flag[0]   # ConstraintGroup::batch (constraint.rs:349-366)
+                    grp.v = grp.v + bt.n * flag[0]
+                    return False
+
+            return _Ctx()
+
+        def __exit__(self, *exc):
+            return False
+
+    class _Column:
+        def __init__(self, lk, idx):
+            self.lk, self.idx = lk, idx
+            self.u, self.v = lk.b.const(1), lk.b.const(0)
+
+        def __enter__(self):
+            return self
+
+        def group(self):
+            g = LogUp._Group(self.lk, self.idx)
+            col = self
+
+            class _Ctx:
+                def __enter__(self_inner):
+                    return g
+
+                def __exit__(self_inner, *exc):  # ConstraintColumn::fold_group (constraint.rs:226-229)
+                    col.v = col.v * g.u + g.v * col.u
+                    col.u = col.u * g.u
+                    return False
+
+            return _Ctx()
+
+        def __exit__(self, *exc):  # the tail of ConstraintLookupBuilder::next_column (constraint.rs:150-196)
+            b, i = self.lk.b, self.idx
+            if i == 0:
+                acc, acc_next = b.aux(0), b.aux(0, 1)
+                total = acc
+                for k in range(1, b.aux_width):
+                    total = total + b.aux(k)
+                b.assert_zero_ext(b.is_first_row() * acc)
+                b.assert_zero_ext(b.is_transition() * (self.u * (acc_next - total) - self.v))
+                b.assert_zero_ext(b.is_last_row() * (acc - b.aux_value(0)))
+            else:
+                cur = b.aux(i)
+                b.assert_zero_ext(b.is_transition() * (self.u * cur - self.v))
+                b.assert_zero_ext(b.is_last_row() * cur)
+            return False
+
+    def column(self):
+        c = LogUp._Column(self, self.column_idx)
+        self.column_idx += 1
+        return c
+
+    def finish(self, name="lookup"):
+        assert self.column_idx == self.b.aux_width, "every aux column needs its next_column call"
+        return Lookup(self.lb, name)

@@ -166,31 +166,26 @@ def _constraints(b):
     b.assert_zero(b.is_transition() * (cycle_end * (perm_id_next - (perm_id + one))))
 
 
-def _perm_link(b):
-    """(flag_row0, flag_row15, multiplicity, denominator_input, denominator_output) of the perm-link bus
-    (poseidon2_permutation_air.rs:31-76) over any builder with main / periodic_value / randomness / const."""
-    alpha, beta = b.randomness(0), b.randomness(1)
-    powers = [b.const(1)]
-    for _ in range(1, MIDEN_MAX_MESSAGE_WIDTH):
-        powers.append(powers[-1] * beta)
-    gamma = powers[-1] * beta
-    prefix = {bus: alpha + gamma * (bus + 1) for bus in (BUS_HASHER_PERM_LINK_INPUT, BUS_HASHER_PERM_LINK_OUTPUT)}
-    per = [b.periodic_value(i) for i in range(4)]
-    f_row0 = per[0]
-    f_row15 = b.const(1) - (per[0] + per[1] + per[2] + per[3])
-    mult = b.const(0) - b.main(COL_WITNESS)
-    state = [b.main(COL_STATE + i) for i in range(STATE_WIDTH)]
-    perm_id = b.main(COL_PERM_ID)
+def _emit_perm_link(lk):
+    """emit_poseidon2_permutation_lookup_columns (constraints/lookup/poseidon2_permutation_air.rs:31-76), written once against the
+    closure API (dag.LogUp plays the constraint-path and the prover-path adapter in the same walk)."""
+    def parts(b):
+        per = [b.periodic_value(i) for i in range(4)]
+        return dict(f_row0=per[0], f_row15=b.const(1) - (per[0] + per[1] + per[2] + per[3]), mult=b.const(0) - b.main(COL_WITNESS),
+                    state=[b.main(COL_STATE + i) for i in range(STATE_WIDTH)], perm_id=b.main(COL_PERM_ID))
 
-    def encode(bus):  # messages.rs:859-868
-        acc = prefix[bus] + perm_id
-        inner = None
-        for i, s in enumerate(state):
-            term = powers[HASHER_PERM_LINK_STATE_OFFSET + i] * s
-            inner = term if inner is None else inner + term
-        return acc + inner
+    pc, pp = parts(lk.b), parts(lk.lb)
 
-    return f_row0, f_row15, mult, encode(BUS_HASHER_PERM_LINK_INPUT), encode(BUS_HASHER_PERM_LINK_OUTPUT)
+    def message(bus):  # HasherPermLinkMsg::encode (messages.rs:855-870): bus_prefix[bus] + perm_id + <beta^(2..), state>
+        def enc(ch):
+            side = pc if ch is lk.ch_c else pp
+            return ch.bus_prefix[bus] + side["perm_id"] + ch.inner_product_at(HASHER_PERM_LINK_STATE_OFFSET, side["state"])
+        return enc
+
+    with lk.column() as col:
+        with col.group() as g:
+            g.insert((pc["f_row0"], pp["f_row0"]), (pc["mult"], pp["mult"]), message(BUS_HASHER_PERM_LINK_INPUT))
+            g.insert((pc["f_row15"], pp["f_row15"]), (pc["mult"], pp["mult"]), message(BUS_HASHER_PERM_LINK_OUTPUT))
 
 
 def poseidon2_permutation_air(host_aux=None):
@@ -199,27 +194,10 @@ def poseidon2_permutation_air(host_aux=None):
     that keeps the reference's build_logup_aux_trace on the CPU, or a test's CPU checker)."""
     b = dag.AirBuilder(NUM_COLS, aux_width=1, num_randomness=2, num_aux_values=1, num_public=0, periodic=periodic_columns())
     _constraints(b)
-    # ConstraintLookupBuilder (lookup/constraint.rs): one column, one group, two inserts
-    f0, f15, mult, d_in, d_out = _perm_link(b)
-    one = b.const(1)
-    u_g = one + (d_in - one) * f0       # ConstraintGroup::insert: U_g += (v - 1) * flag
-    v_g = f0 * mult                     #                          V_g += flag * multiplicity
-    u_g = u_g + (d_out - one) * f15
-    v_g = v_g + f15 * mult
-    zero = b.const(0)
-    v = zero * u_g + v_g * one          # fold_group on (V, U) = (0, 1): V <- V U_g + V_g U, U <- U U_g
-    u = one * u_g
-    acc, acc_next = b.aux(0), b.aux(0, 1)
-    b.assert_zero_ext(b.is_first_row() * acc)
-    b.assert_zero_ext(b.is_transition() * (u * (acc_next - acc) - v))
-    b.assert_zero_ext(b.is_last_row() * (acc - b.aux_value(0)))
+    lk = dag.LogUp(b, MIDEN_MAX_MESSAGE_WIDTH, NUM_BUS_IDS)  # ConstraintLookupBuilder::new(builder, &MidenAir::Poseidon2Permutation)
+    _emit_perm_link(lk)
+    lookup = lk.finish("poseidon2_perm_link")
     assert b.max_degree == 8 and b.log_quotient_degree() == 3  # ConstraintDegrees { base: 8, ext: 3 }, air/src/lib.rs:690
-
-    lb = dag.LookupBuilder(NUM_COLS, num_cols=1, num_randomness=2, periodic=periodic_columns())
-    f0, f15, mult, d_in, d_out = _perm_link(lb)
-    lb.fraction(0, f0 * mult, d_in)
-    lb.fraction(0, f15 * mult, d_out)
-    lookup = dag.Lookup(lb, "poseidon2_perm_link")
 
     build_aux = None
     if host_aux is not None:
@@ -227,6 +205,60 @@ def poseidon2_permutation_air(host_aux=None):
             aux, fin = host_aux(lookup, main, randomness)
             return aux, [int(fin[0]), int(fin[1])]
     return dag.Air(b, build_aux, "poseidon2_permutation"), lookup
+
+
+def perm_link_controller_air(host_aux=None):
+    """The OTHER side of the perm-link bus, reduced to what the bus needs: the hasher controller of the chiplets AIR adds
+    `+1 / encode(Input, perm_id, state)` on its input rows and `+1 / encode(Output, ..)` on its output rows
+    (constraints/lookup/buses/wiring.rs:165-190).  This stand-in holds one request per row -- perm_id | input state | output state
+    | multiplicity (26 columns) -- and adds both messages with that multiplicity in one batch; its committed final plus the
+    Poseidon2 permutation AIR's must vanish (`MultiAir::eval_external`, here mh_external_logup_balance).  Not a Miden AIR: the
+    request columns are unconstrained; it exists to close the real bus in tests."""
+    w = 1 + 12 + 12 + 1
+    b = dag.AirBuilder(w, aux_width=1, num_randomness=2, num_aux_values=1, num_public=0)
+    lk = dag.LogUp(b, MIDEN_MAX_MESSAGE_WIDTH, NUM_BUS_IDS)
+
+    def parts(bb):
+        return dict(perm_id=bb.main(0), s_in=[bb.main(1 + i) for i in range(12)], s_out=[bb.main(13 + i) for i in range(12)], mult=bb.main(25),
+                    one=bb.const(1))
+
+    pc, pp = parts(b), parts(lk.lb)
+
+    def message(bus, key):
+        def enc(ch):
+            side = pc if ch is lk.ch_c else pp
+            return ch.bus_prefix[bus] + side["perm_id"] + ch.inner_product_at(HASHER_PERM_LINK_STATE_OFFSET, side[key])
+        return enc
+
+    with lk.column() as col:
+        with col.group() as g:
+            with g.batch((pc["one"], pp["one"])) as bt:
+                bt.insert((pc["mult"], pp["mult"]), message(BUS_HASHER_PERM_LINK_INPUT, "s_in"))
+                bt.insert((pc["mult"], pp["mult"]), message(BUS_HASHER_PERM_LINK_OUTPUT, "s_out"))
+    lookup = lk.finish("perm_link_controller")
+    build_aux = None
+    if host_aux is not None:
+        def build_aux(main, randomness):
+            aux, fin = host_aux(lookup, main, randomness)
+            return aux, [int(fin[0]), int(fin[1])]
+    return dag.Air(b, build_aux, "perm_link_controller"), lookup
+
+
+def perm_link_controller_trace(p2_trace, log_n):
+    """One row per cycle of a Poseidon2 permutation trace (requests first, then zero-multiplicity rows; the last row carries no
+    request: the accumulator's last-row constraint assumes a silent last row)."""
+    n = 1 << log_n
+    cycles = p2_trace.shape[0] // HASH_CYCLE_LEN
+    t = np.zeros((n, 26), dtype=np.uint64)
+    k = min(cycles, n - 1)
+    rows0 = p2_trace[0::HASH_CYCLE_LEN][:k]
+    rows15 = p2_trace[15::HASH_CYCLE_LEN][:k]
+    assert (p2_trace[0::HASH_CYCLE_LEN][k:, COL_WITNESS] == 0).all(), "requests beyond the controller's height"
+    t[:k, 0] = rows0[:, COL_PERM_ID]
+    t[:k, 1:13] = rows0[:, COL_STATE:COL_STATE + 12]
+    t[:k, 13:25] = rows15[:, COL_STATE:COL_STATE + 12]
+    t[:k, 25] = rows0[:, COL_WITNESS]
+    return t
 
 
 # ---- u64 Goldilocks arithmetic on numpy arrays (trace generation only) -----------------------------------------------------

@@ -187,3 +187,34 @@ def test_device_aux_from_the_lookup_program_derived_from_the_constraints(ctx):
     dair.attach_lookup(pkg.DeviceLookup(ctx, derived))
     got = pkg.prove(ctx, [dair], [ctx.upload_trace(tr)], [], FAST, ob.challenger_state(), ob.protocol_pre_observe(FAST, []), None)
     assert (got.fields == exp["fields"]).all() and (got.commitments == exp["commitments"]).all() and (got.digest == exp["digest"]).all()
+
+
+def test_perm_link_bus_closes_on_the_device(ctx):
+    """Both sides of the real perm-link bus proved on the GPU, both aux columns built on the device from lookup programs (the
+    controller's derived back from its constraints): the proof equals the oracle's, and the cross-AIR LogUp assertion
+    (mh_verify_ex + mh_external_logup_balance) accepts it and rejects an unbalanced statement."""
+    pkg = load_package()
+    p2, lk_p2 = MA.poseidon2_permutation_air(host_aux=ob.lookup_build_aux)
+    ctl, _ = MA.perm_link_controller_air(host_aux=ob.lookup_build_aux)
+    lk_ctl = dag.lookup_from_constraints(ctl.blob)
+    tr_p2 = p2_statement(10, 40)
+    tr_ctl = MA.perm_link_controller_trace(tr_p2, 7)
+    airs_ = [p2, ctl]
+    pre, st = ob.protocol_pre_observe(FAST, []), ob.challenger_state()
+
+    def prove(traces):
+        dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+        dairs[0].attach_lookup(pkg.DeviceLookup(ctx, lk_p2))
+        dairs[1].attach_lookup(pkg.DeviceLookup(ctx, lk_ctl))
+        return pkg.prove(ctx, dairs, [ctx.upload_trace(t) for t in traces], [], FAST, st, pre, None)
+
+    got = prove([tr_p2, tr_ctl])
+    exp = ob.prove(airs_, [tr_p2, tr_ctl], [], FAST)
+    assert (got.fields == exp["fields"]).all() and (got.commitments == exp["commitments"]).all() and (got.digest == exp["digest"]).all()
+    ok, msg = pkg.verify(airs_, [10, 7], [], FAST, st, pre, got.fields, got.commitments, external="logup_balance")
+    assert ok, msg
+    bad = tr_ctl.copy()
+    bad[5, 25] = (int(bad[5, 25]) + 1) % ob.P
+    gb = prove([tr_p2, bad])
+    assert pkg.verify(airs_, [10, 7], [], FAST, st, pre, gb.fields, gb.commitments)[0]
+    assert not pkg.verify(airs_, [10, 7], [], FAST, st, pre, gb.fields, gb.commitments, external="logup_balance")[0]

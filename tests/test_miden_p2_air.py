@@ -166,3 +166,36 @@ def test_lookup_program_derived_from_the_constraint_dag():
     for other in (A.fib_air(), dag.dummy_miden_air(11, 2)):
         with pytest.raises(ValueError):
             dag.lookup_from_constraints(other.blob)
+
+
+def test_perm_link_bus_closes_across_airs():
+    """The real bus, both sides: the Poseidon2 permutation AIR removes what a controller-side AIR adds
+    (constraints/lookup/buses/wiring.rs:165-190 reduced to one request per row, miden_air.perm_link_controller_air), so the two
+    committed finals sum to zero -- the cross-AIR assertion of `MultiAir::eval_external` (mh_verify_ex + mh_external_logup_balance)
+    accepts; with one multiplicity changed on one side every per-row constraint still holds, the plain verifier still accepts,
+    and the cross-AIR assertion rejects.  The controller's constraints come from the batch branch of the closure API
+    (dag.LogUp: ConstraintBatch N <- N v + m D), and its lookup program can be derived back from them."""
+    pkg = load_package()
+    p2, lk_p2 = p2_air()
+    ctl, lk_ctl = MA.perm_link_controller_air(host_aux=ob.lookup_build_aux)
+    st, mult = requests(9)
+    tr_p2 = MA.poseidon2_permutation_trace(8, st, mult)          # 16 cycles: 9 requests + padding
+    tr_ctl = MA.perm_link_controller_trace(tr_p2, 5)             # 32 rows: 16 cycles, then silence
+    aux_c, fin_c = ob.lookup_build_aux(lk_ctl, tr_ctl, RND)
+    aux_p, fin_p = ob.lookup_build_aux(lk_p2, tr_p2, RND)
+    assert ob.check_constraints(ctl, tr_ctl, aux_c, fin_c, randomness=RND) == (0, None)
+    assert (int(fin_c[0]) + int(fin_p[0])) % P == 0 and (int(fin_c[1]) + int(fin_p[1])) % P == 0
+    derived = dag.lookup_from_constraints(ctl.blob)
+    aux_d, fin_d = ob.lookup_build_aux(derived, tr_ctl, RND)
+    assert (aux_d == aux_c).all() and (fin_d == fin_c).all()
+    airs_, traces = [p2, ctl], [tr_p2, tr_ctl]
+    pre, stt = ob.protocol_pre_observe(FAST, []), ob.challenger_state()
+    proof = ob.prove(airs_, traces, [], FAST)
+    ok, msg = pkg.verify(airs_, [8, 5], [], FAST, stt, pre, proof["fields"], proof["commitments"], external="logup_balance")
+    assert ok, msg
+    bad = tr_ctl.copy()
+    bad[2, 25] = (int(bad[2, 25]) + 1) % P  # the controller claims one more use of request 2
+    proof_b = ob.prove(airs_, [tr_p2, bad], [], FAST)
+    assert pkg.verify(airs_, [8, 5], [], FAST, stt, pre, proof_b["fields"], proof_b["commitments"])[0]  # per-row constraints hold
+    ok, msg = pkg.verify(airs_, [8, 5], [], FAST, stt, pre, proof_b["fields"], proof_b["commitments"], external="logup_balance")
+    assert not ok
