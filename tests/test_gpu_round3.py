@@ -5,7 +5,8 @@
   crates/lifted-stark/src/testing/airs/miden.rs:36-54,105-124) -- and at the other BASELINE shapes the oracle reaches in about
   a minute on the GPU box's host cores: the config-2 mixed-height shape (2^18 x 51 / 2^20 x 22), config-5 parameters
   (blowup 16) at 2^18 rows.
-* The coset LDE at 2^21 rows with width 3 and blowup 8: the n_z = 8 coset loop of the first forward pass compared directly.
+* The coset LDE at 2^21 / 2^22 / 2^23 rows with blowup 8: the n_z = 8 coset loop of the first forward pass compared directly, on the
+  big-tile two-pass plan and on the three-pass plan.
 * The first real Miden AIR, Poseidon2PermutationAir (miden-vm_amd/miden_air.py): device proof == oracle proof, through the
   interpreter and through the hiprtc-compiled chunks, aux column built on the device from the perm-link lookup program.
 """
@@ -53,10 +54,12 @@ def test_full_transcript_config5_blowup16_at_2_18(ctx, fast_oracle):
     check_same(ctx, [dag.dummy_miden_air(16, 1)], [A.dummy_trace(18, 16, seed=9)], [], prm)
 
 
-def test_coset_lde_2_21_width3_blowup8(ctx, fast_oracle):
-    rng = np.random.default_rng(21)
-    t = rng.integers(0, ob.P, (1 << 21, 3), dtype=np.uint64)
-    shift = int(ob.lib().orc_canonical_lde_shift(24))
+@pytest.mark.parametrize("log_n,width", [(21, 3), (22, 2), (23, 1)])
+def test_coset_lde_big_plans_blowup8(ctx, fast_oracle, log_n, width):
+    # 2^21 / 2^22: the big-tile two-pass plan, 2^23: the three-pass plan -- each with the n_z = 8 coset loop of the first forward pass
+    rng = np.random.default_rng(log_n)
+    t = rng.integers(0, ob.P, (1 << log_n, width), dtype=np.uint64)
+    shift = int(ob.lib().orc_canonical_lde_shift(log_n + 3))
     got = ctx.coset_lde_batch(t, 3, shift)
     exp = ob.coset_lde_bitrev(t, 3, shift)
     assert got.shape == exp.shape and (got == exp).all()
