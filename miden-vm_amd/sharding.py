@@ -317,9 +317,10 @@ def prove_sharded(pkg, ctx, comm, airs, traces, public_values, params, challenge
 
 
 # ---- a time model of the coset-sharded proof: what the first measured scaling line is read against --------
-# Single-GPU kernel classes of ONE proof of miden:24:51:8 on an MI355X, ms (profiles/r02_config_shapes.txt, configs[3]).
-SINGLE_GPU_MS_2P24 = {"lmcs_leaf_absorb": 405.66, "lde": 245.32, "lmcs_compress": 126.53, "deep_assemble": 30.69, "fri_leaf_hash": 12.73,
-                      "deep_ood_eval": 11.35, "total": 840.0}
+# Single-GPU kernel classes of ONE proof of miden:24:51:8 on an MI355X, ms (profiles/r03_config_shapes.txt, configs[3]); lde_intt (the
+# inverse transforms of main + aux + quotient chunks, nested in lde) is measured, the main + aux share of it is what every rank repeats.
+SINGLE_GPU_MS_2P24 = {"lmcs_leaf_absorb": 408.26, "lde": 191.51, "lde_intt": 18.42, "lmcs_compress": 127.5, "deep_assemble": 30.37,
+                      "fri_leaf_hash": 12.96, "deep_ood_eval": 11.3, "total": 789.7}
 XGMI_GBS_PER_LINK_DIR = 60.0   # achievable per direction per link (MI355X: 7 links x ~153 GB/s bidirectional peak per GPU, point to point)
 HOST_SERIAL_MS = 3.3            # ~10 tree tops of one wave per level (2.5), grinding (0.2), ~30 transcript round trips (0.6)
 
@@ -342,7 +343,10 @@ def predict_sharded_ms(world, log_n=24, main_width=51, aux_base_width=16, quotie
         s[k] *= scale
     G = world
     cols = main_width + aux_base_width + quotient_base_width
-    intt = s["lde"] * (main_width + aux_base_width) / cols / (1 + (1 << log_blowup))  # replicated inverse transforms
+    if "lde_intt" in s:  # measured inverse transforms: the main + aux share is replicated (the quotient chunks' are sharded)
+        intt = s["lde_intt"] * (main_width + aux_base_width) / cols
+    else:
+        intt = s["lde"] * (main_width + aux_base_width) / cols / (1 + (1 << log_blowup))
     replicated = intt + HOST_SERIAL_MS
     sharded = s["total"] - replicated
     N, B = 1 << log_n, 1 << log_blowup
