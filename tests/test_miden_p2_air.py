@@ -199,3 +199,15 @@ def test_perm_link_bus_closes_across_airs():
     assert pkg.verify(airs_, [8, 5], [], FAST, stt, pre, proof_b["fields"], proof_b["commitments"])[0]  # per-row constraints hold
     ok, msg = pkg.verify(airs_, [8, 5], [], FAST, stt, pre, proof_b["fields"], proof_b["commitments"], external="logup_balance")
     assert not ok
+
+
+def test_committed_blobs_are_current():
+    """miden-vm_amd/blobs/poseidon2_permutation.{dag,lkp} (tools/export_p2_air.py): what a Rust / C host loads with mh_air_load /
+    mh_lookup_load -- byte-identical to what miden_air.py generates, parse under the oracle's and the product's blob readers."""
+    air, lookup = MA.poseidon2_permutation_air()
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "miden-vm_amd", "blobs")
+    dag_words = np.fromfile(os.path.join(root, "poseidon2_permutation.dag"), dtype="<u8")
+    lkp_words = np.fromfile(os.path.join(root, "poseidon2_permutation.lkp"), dtype="<u8")
+    assert (dag_words == air.blob).all() and (lkp_words == lookup.blob).all(), "run tools/export_p2_air.py"
+    parsed = dag.parse_air_blob(dag_words)
+    assert parsed["main_width"] == 16 and parsed["aux_width"] == 1 and len(parsed["constraints"]) == 61 and len(parsed["periodic"]) == 16
