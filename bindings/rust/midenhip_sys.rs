@@ -128,6 +128,9 @@ unsafe extern "C" {
     // ---- proofs ----
     pub fn mh_prove(ctx: *mut mh_ctx, params: *const mh_pcs_params, n_airs: c_int, airs: *const *mut mh_air, traces: *const *mut mh_trace, public_values: *const u64, n_public_values: usize, challenger_state: *const u64, pre_observe: *const u64, n_pre_observe: usize, aux_builder: mh_aux_builder, user: *mut c_void, out: *mut *mut mh_proof) -> c_int;
     pub fn mh_commit_traces_sharded(ctx: *mut mh_ctx, comm: *const mh_comm, n_traces: c_int, traces: *const *mut mh_trace, log_blowup: c_int, out: *mut *mut mh_tree, root: *mut u64) -> c_int;
+    pub fn mh_prove_host(ctx: *mut mh_ctx, params: *const mh_pcs_params, n_airs: c_int, airs: *const *mut mh_air, traces_rowmajor: *const *const u64,
+                         log_heights: *const c_int, public_values: *const u64, n_public_values: usize, challenger_state: *const u64,
+                         pre_observe: *const u64, n_pre_observe: usize, aux_builder: mh_aux_builder, user: *mut c_void, out: *mut *mut mh_proof) -> c_int;
     pub fn mh_prove_sharded(ctx: *mut mh_ctx, comm: *const mh_comm, params: *const mh_pcs_params, n_airs: c_int, airs: *const *mut mh_air, traces: *const *mut mh_trace, public_values: *const u64, n_public_values: usize, challenger_state: *const u64, pre_observe: *const u64, n_pre_observe: usize, aux_builder: mh_aux_builder, user: *mut c_void, out: *mut *mut mh_proof) -> c_int;
     pub fn mh_session_begin(ctx: *mut mh_ctx, comm: *const mh_comm, params: *const mh_pcs_params, n_airs: c_int, airs: *const *mut mh_air, traces: *const *mut mh_trace, public_values: *const u64, n_public_values: usize, out: *mut *mut mh_session) -> c_int;
     pub fn mh_session_free(s: *mut mh_session);

@@ -234,6 +234,12 @@ typedef int (*mh_aux_builder)(void* user, int instance_idx, const uint64_t* rand
 int mh_prove(mh_ctx* ctx, const mh_pcs_params* params, int n_airs, mh_air* const* airs, mh_trace* const* traces,
              const uint64_t* public_values, size_t n_public_values, const uint64_t challenger_state[12],
              const uint64_t* pre_observe, size_t n_pre_observe, mh_aux_builder aux_builder, void* user, mh_proof** out);
+/* The shape of prove_stark itself (prover/src/lib.rs:317-355): HOST row-major matrices in (instance order; page-locked memory from
+ * mh_host_alloc for full overlap), proof out.  The library starts every upload at once in proof order and proves: matrix k + 1 is on
+ * the PCIe link while matrix k is extended and hashed.  Equivalent to mh_trace_upload_async x n, mh_prove, mh_trace_free x n. */
+int mh_prove_host(mh_ctx* ctx, const mh_pcs_params* params, int n_airs, mh_air* const* airs, const uint64_t* const* traces_rowmajor,
+                  const int* log_heights, const uint64_t* public_values, size_t n_public_values, const uint64_t challenger_state[12],
+                  const uint64_t* pre_observe, size_t n_pre_observe, mh_aux_builder aux_builder, void* user, mh_proof** out);
 /* One proof sharded over `world` GPUs (one process + one ctx per GPU, all ranks call this with the same
  * arguments and traces; every rank returns the same proof).  The coset-major layout makes every pass over
  * LDE-sized data local to a rank's cosets; what crosses ranks goes through these three collectives on

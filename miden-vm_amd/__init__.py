@@ -23,7 +23,7 @@ EXPORTS = [
     "mh_ctx_create", "mh_ctx_destroy", "mh_ctx_trim", "mh_last_error", "mh_device_count", "mh_prof_enable", "mh_prof_reset",
     "mh_prof_get", "mh_prof_dump", "mh_poseidon2_permute", "mh_poseidon2_register_rate", "mh_coset_lde_batch", "mh_trace_upload", "mh_trace_upload_async", "mh_trace_wait", "mh_trace_free",
     "mh_commit_traces", "mh_tree_free", "mh_tree_root", "mh_tree_log_height", "mh_tree_open", "mh_tree_download_lde",
-    "mh_tree_download_layers", "mh_air_load", "mh_air_free", "mh_air_log_quotient_degree", "mh_air_compiled_chunks", "mh_air_compiled_max_vgprs", "mh_prove", "mh_proof_free",
+    "mh_tree_download_layers", "mh_air_load", "mh_air_free", "mh_air_log_quotient_degree", "mh_air_compiled_chunks", "mh_air_compiled_max_vgprs", "mh_prove", "mh_prove_host", "mh_proof_free",
     "mh_proof_num_fields", "mh_proof_num_commitments", "mh_proof_fields", "mh_proof_commitments", "mh_proof_digest",
     "mh_proof_num_traces", "mh_proof_log_trace_heights", "mh_proof_serialize", "mh_shard_commit_leaves", "mh_shard_free",
     "mh_shard_leaf_digests", "mh_shard_build_subtree", "mh_merkle_cap_root", "mh_merkle_cap_root_lmcs", "mh_prove_sharded", "mh_commit_traces_sharded",
@@ -479,6 +479,25 @@ def prove(ctx, airs, traces, public_values, params, challenger_state, pre_observ
     p = params if isinstance(params, PcsParams) else PcsParams.from_dict(params)
     ctx.check(ctx.lib.mh_prove(ctx.h, C.byref(p), C.c_int(n), a_arr, t_arr, _ptr(pub), C.c_size_t(len(public_values)),
                                _ptr(st), _ptr(pre), C.c_size_t(len(pre_observe)), c_cb, None, C.byref(h)))
+    return Proof(ctx.lib, h)
+
+
+def prove_host(ctx, airs, host_traces, public_values, params, challenger_state, pre_observe, aux_builder=None):
+    """mh_prove_host: `host_traces` = row-major uint64 matrices in HOST memory (pinned_array for full overlap), instance order.
+    The uploads run inside the call, overlapped with the proof (matrix k + 1 lands under matrix k's LDE and leaf sponges)."""
+    n = len(airs)
+    a_arr = (C.c_void_p * n)(*[a.h for a in airs])
+    mats = [m if (m.dtype == np.uint64 and m.flags["C_CONTIGUOUS"]) else _arr(m) for m in host_traces]
+    t_arr = (u64p * n)(*[_ptr(m) for m in mats])
+    lhs = (C.c_int * n)(*[int(m.shape[0]).bit_length() - 1 for m in mats])
+    for m, a in zip(mats, airs):
+        assert m.ndim == 2 and m.shape[1] == a.air.main_width and 1 << (int(m.shape[0]).bit_length() - 1) == m.shape[0]
+    pub, st, pre = _arr(list(public_values) or [0]), _arr(challenger_state), _arr(list(pre_observe) or [0])
+    c_cb = _aux_callback(aux_builder, max(a.air.num_randomness for a in airs))
+    h = C.c_void_p()
+    p = params if isinstance(params, PcsParams) else PcsParams.from_dict(params)
+    ctx.check(ctx.lib.mh_prove_host(ctx.h, C.byref(p), C.c_int(n), a_arr, t_arr, lhs, _ptr(pub), C.c_size_t(len(public_values)), _ptr(st),
+                                    _ptr(pre), C.c_size_t(len(pre_observe)), c_cb, None, C.byref(h)))
     return Proof(ctx.lib, h)
 
 

@@ -62,3 +62,15 @@ void mh_ctx::d2h(void* dst_host, const void* src_dev, size_t bytes) {
   sync();
   memcpy(dst_host, pinned, bytes);
 }
+
+void* mh_ctx::host_take(size_t bytes) {
+  for (size_t i = 0; i < host_pool.size(); i++)
+    if (host_pool[i].second >= bytes && host_pool[i].second <= 2 * bytes + 4096) {
+      void* p = host_pool[i].first;
+      host_pool.erase(host_pool.begin() + i);
+      return p;
+    }
+  void* p = nullptr;
+  HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+  return p;
+}

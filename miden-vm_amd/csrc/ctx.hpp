@@ -160,6 +160,10 @@ struct mh_ctx {
   void d2h(void* dst_host, const void* src_dev, size_t bytes);
   void* pinned = nullptr;
   static constexpr size_t PINNED_BYTES = 1 << 20;
+  // page-locked scratch for host-built aux traces (the aux_builder callback writes into it, the DMA reads it): kept between proofs
+  std::vector<std::pair<void*, size_t>> host_pool;
+  void* host_take(size_t bytes);
+  void host_give(void* p, size_t bytes) { host_pool.emplace_back(p, bytes); }
   const u64* twiddles(int log_n, bool inverse);
 };
 

@@ -333,6 +333,16 @@ struct mh_session {
     for (e2 r : randomness) { rand_flat.push_back(r.c0); rand_flat.push_back(r.c1); }
     if (rand_flat.empty()) rand_flat.push_back(0);
     std::vector<std::unique_ptr<mh_trace>> aux_tr(n_airs);
+    // host-built aux traces land in page-locked scratch and upload on the copy stream: the callback of instance i + 1 runs (on the
+    // CPU) while instance i's matrix is on the PCIe link, and the LDE of instance i does not wait for the later uploads
+    struct HostScratch {
+      mh_ctx* c;
+      std::vector<std::pair<void*, size_t>> bufs;
+      ~HostScratch() {
+        if (!bufs.empty() && c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);  // error paths: the DMA may still be reading
+        for (auto& b : bufs) c->host_give(b.first, b.second);
+      }
+    } scratch{c, {}};
     aux_vals.assign(n_airs, {});
     for (int i = 0; i < n_airs; i++) {
       const mh_air* a = airs[i];
@@ -344,11 +354,15 @@ struct mh_session {
         aux_tr[i].reset(lookup_build_aux(c, a->lookup, traces[i], a->prep_raw, randomness, &fin));
         aux_vals[i][0] = fin;
       } else if (cb) {
-        std::vector<u64> host(n * w, 0), vals(2 * std::max<size_t>(1, a->num_aux_values), 0);
-        int rc = cb(user, i, rand_flat.data(), host.data(), vals.data());
+        std::vector<u64> vals(2 * std::max<size_t>(1, a->num_aux_values), 0);
+        const size_t bytes = std::max<size_t>(8, n * w * 8);
+        u64* host = static_cast<u64*>(c->host_take(bytes));
+        scratch.bufs.emplace_back(host, bytes);
+        memset(host, 0, n * w * 8);
+        int rc = cb(user, i, rand_flat.data(), host, vals.data());
         MH_REQUIRE(rc == 0, "aux trace builder / external assertion failed");
         for (size_t k = 0; k < a->num_aux_values; k++) aux_vals[i][k] = e2{gl_canon(vals[2 * k]), gl_canon(vals[2 * k + 1])};
-        aux_tr[i].reset(trace_upload(c, host.data(), lhs[i], w));
+        aux_tr[i].reset(w ? trace_upload_async(c, host, lhs[i], w) : trace_upload(c, host, lhs[i], w));
       } else {
         aux_tr[i].reset(trace_zeros(c, lhs[i], w));  // DummyMidenAir::build_aux_trace (testing/airs/miden.rs:79-89)
       }
@@ -958,6 +972,33 @@ int mh_prove(mh_ctx* c, const mh_pcs_params* params, int n_airs, mh_air* const* 
   HIP_CHECK(hipSetDevice(c->device));
   std::unique_ptr<mh_proof> p(new mh_proof());
   prove_impl(c, *params, n_airs, airs, traces, public_values, n_public_values, challenger_state, pre_observe, n_pre_observe,
+             aux_builder, user, *p, Dist{});
+  *out = p.release();
+  MH_CATCH
+}
+
+// prove_stark's shape exactly (prover/src/lib.rs:317-355): HOST RowMajorMatrix values in, proof out.  The uploads are started in
+// proof order (ascending height, ties by instance index: the order the matrices are extended and absorbed in), so matrix k + 1
+// is on the PCIe link while matrix k is extended and hashed; the traces are freed before returning.
+int mh_prove_host(mh_ctx* c, const mh_pcs_params* params, int n_airs, mh_air* const* airs, const uint64_t* const* traces_rowmajor,
+                  const int* log_heights, const uint64_t* public_values, size_t n_public_values, const uint64_t challenger_state[12],
+                  const uint64_t* pre_observe, size_t n_pre_observe, mh_aux_builder aux_builder, void* user, mh_proof** out) {
+  MH_TRY(c)
+  MH_REQUIRE(c && params && airs && traces_rowmajor && log_heights && challenger_state && out, "null argument");
+  MH_REQUIRE(n_airs > 0 && n_airs <= 256, "need between 1 and 256 AIR instances");
+  MH_REQUIRE(public_values || !n_public_values, "null public values");
+  MH_REQUIRE(pre_observe || !n_pre_observe, "null pre_observe");
+  HIP_CHECK(hipSetDevice(c->device));
+  std::vector<int> order(n_airs);
+  std::iota(order.begin(), order.end(), 0);
+  for (int i = 0; i < n_airs; i++) MH_REQUIRE(airs[i] && traces_rowmajor[i] && log_heights[i] >= 0 && log_heights[i] <= 29, "bad trace argument");
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return log_heights[a] < log_heights[b]; });
+  std::vector<std::unique_ptr<mh_trace>> owned(n_airs);
+  for (int i : order) owned[i].reset(trace_upload_async(c, traces_rowmajor[i], log_heights[i], airs[i]->main_width));
+  std::vector<mh_trace*> tr(n_airs);
+  for (int i = 0; i < n_airs; i++) tr[i] = owned[i].get();
+  std::unique_ptr<mh_proof> p(new mh_proof());
+  prove_impl(c, *params, n_airs, airs, tr.data(), public_values, n_public_values, challenger_state, pre_observe, n_pre_observe,
              aux_builder, user, *p, Dist{});
   *out = p.release();
   MH_CATCH

@@ -167,6 +167,12 @@ def test_async_uploads_give_the_same_proof(ctx):
         up[0].wait()
         for t in up:
             t.free()
+    # mh_prove_host: the same with the uploads inside the call (instance order in, proof order inside), pinned and pageable sources
+    for mats in ([a for a, _ in pins], host):
+        dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+        dairs[2].attach_lookup(pkg.DeviceLookup(ctx, lookup))
+        got = pkg.prove_host(ctx, dairs, mats, [], ob.PROD_PARAMS, ob.challenger_state(), pre, None)
+        assert got.bytes == ref.bytes
     t = pkg.Trace.upload_async(ctx, pins[2][0])  # a trace that is freed without ever being consumed
     t.free()
     t = pkg.Trace.upload_async(ctx, pins[0][0])
