@@ -64,9 +64,8 @@ int main(int argc, char** argv) {
       x = x * 6364136223846793005ULL + 1442695040888963407ULL;
       rows[r * width + c] = c == 0 ? 0 : x % GL_P;
     }
-  mh_trace* trace = NULL;
-  CHECK(mh_trace_upload(ctx, rows, log_n, width, &trace));
-  mh_host_free(rows);
+  /* the matrix stays on the host: mh_prove_host uploads it on the copy stream inside the call (prove_stark's own shape:
+   * host RowMajorMatrix values in, proof out) */
 
   /* ---- prove: production parameters (air/src/config.rs:54-67); the challenger starts from the all-zero sponge and
    * has observed the protocol parameters and an empty statement (config.rs:188-198, lifted-air/src/air.rs:307-324) ---- */
@@ -74,9 +73,11 @@ int main(int argc, char** argv) {
   const uint64_t state[12] = {0};
   const uint64_t pre[11] = {27, 16, 12, 4, 3, 7, 4, 0, /*n publics*/ 0, 0, /*n aux inputs*/ 0};
   mh_air* airs[1] = {air};
-  mh_trace* traces[1] = {trace};
+  const uint64_t* host_traces[1] = {rows};
+  const int log_heights[1] = {log_n};
   mh_proof* proof = NULL;
-  CHECK(mh_prove(ctx, &params, 1, airs, traces, NULL, 0, state, pre, 11, NULL, NULL, &proof));
+  CHECK(mh_prove_host(ctx, &params, 1, airs, host_traces, log_heights, NULL, 0, state, pre, 11, NULL, NULL, &proof));
+  mh_host_free(rows);
 
   const uint64_t* d = mh_proof_digest(proof);
   printf("rows 2^%d width %zu aux %zu: %zu fields, %zu commitments, %zu bytes\n", log_n, width, aux, mh_proof_num_fields(proof),
@@ -99,7 +100,6 @@ int main(int argc, char** argv) {
     printf("verified\n");
   }
   mh_proof_free(proof);
-  mh_trace_free(trace);
   mh_air_free(air);
   mh_ctx_destroy(ctx);
   return 0;
