@@ -89,7 +89,8 @@ class ShardedRunner:
         self.pkg, self.ctx, self.log_n, self.comm, self.sharding = pkg, ctx, log_n, comm, sharding
         self.air = dag.dummy_miden_air(51, 8)
         self.dair = pkg.DeviceAir(ctx, self.air)
-        self.trace = ctx.upload_trace(synth_trace(np.random.default_rng(7), log_n, 51))
+        # every rank holds the (same, seeded) host matrix; each moves 1/N of its rows over its own PCIe link, the rest arrives over xGMI
+        self.trace = sharding.upload_trace_sharded(pkg, ctx, comm, synth_trace(np.random.default_rng(7), log_n, 51))
         self.params = dict(protocol.PROD_PARAMS)
         self.state = protocol.challenger_state()
         self.pre = protocol.protocol_pre_observe(self.params, [])

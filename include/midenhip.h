@@ -261,6 +261,11 @@ typedef struct mh_comm {
    * 1: the callbacks ENQUEUE on the ctx's stream and return at once (mh_comm_create_rccl): no host synchronisation. */
   int stream_ordered;
 } mh_comm;
+/* The trace of a sharded proof: every rank uploads only its 1/world of the ROWS (a contiguous slice of the row-major host matrix)
+ * over its own PCIe link, the slices are all-gathered over the communicator and each rank transposes the whole.  Collective: every
+ * rank calls it with the same shape; `rowmajor` must be readable by every rank (threads of one process, or a shared mapping), a
+ * rank reads only its slice.  The result is an ordinary mh_trace (the full matrix on every rank: the inverse NTT needs all rows). */
+int mh_trace_upload_sharded(mh_ctx* ctx, const mh_comm* comm, const uint64_t* rowmajor, int log_n, size_t width, mh_trace** out);
 /* ---- the communicator inside the library: RCCL over xGMI ------------------------------------------------------
  * One process + one ctx per GPU.  Rank 0 calls mh_rccl_unique_id and hands the 128 bytes to every rank (by whatever
  * started the ranks); every rank calls mh_comm_create_rccl with its ctx (ncclCommInitRank: collective, blocks until all

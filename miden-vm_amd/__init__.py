@@ -26,7 +26,7 @@ EXPORTS = [
     "mh_tree_download_layers", "mh_air_load", "mh_air_free", "mh_air_log_quotient_degree", "mh_air_compiled_chunks", "mh_air_compiled_max_vgprs", "mh_prove", "mh_prove_host", "mh_proof_free",
     "mh_proof_num_fields", "mh_proof_num_commitments", "mh_proof_fields", "mh_proof_commitments", "mh_proof_digest",
     "mh_proof_num_traces", "mh_proof_log_trace_heights", "mh_proof_serialize", "mh_shard_commit_leaves", "mh_shard_free",
-    "mh_shard_leaf_digests", "mh_shard_build_subtree", "mh_merkle_cap_root", "mh_merkle_cap_root_lmcs", "mh_prove_sharded", "mh_commit_traces_sharded",
+    "mh_shard_leaf_digests", "mh_shard_build_subtree", "mh_merkle_cap_root", "mh_merkle_cap_root_lmcs", "mh_prove_sharded", "mh_commit_traces_sharded", "mh_trace_upload_sharded",
     "mh_session_begin", "mh_session_free", "mh_session_shape", "mh_session_commit_main", "mh_session_commit_aux",
     "mh_session_commit_quotient", "mh_session_ood_point_ok", "mh_session_ood", "mh_session_deep", "mh_session_fri_commit",
     "mh_session_fri_fold", "mh_session_fri_final", "mh_session_open", "mh_grind",

@@ -936,6 +936,43 @@ int mh_merkle_cap_root(const uint64_t* subroots, int world, uint64_t root[4]) {
 
 // commit_traces for one rank of a sharded prover: the setup-time commitment of preprocessed matrices when proofs are
 // sharded (same root as mh_commit_traces; this rank keeps its cosets and its slice of the tree).
+// The trace of a sharded proof without G full uploads: every rank moves only its 1/G of the ROWS over its own PCIe link (a
+// contiguous slice of the row-major host matrix: full DMA rate), the slices are all-gathered over xGMI, and each
+// rank transposes the assembled matrix.  At 2^24 x 51 on 8 GPUs: 0.85 GB of PCIe + 6 GB of xGMI receives per rank instead of 6.8 GB
+// of PCIe each (all eight links of the host at once).  `rowmajor` must be readable by every rank (threads of one process, or a
+// shared mapping); a rank only reads its own slice.
+int mh_trace_upload_sharded(mh_ctx* c, const mh_comm* comm, const uint64_t* rowmajor, int log_n, size_t width, mh_trace** out) {
+  MH_TRY(c)
+  MH_REQUIRE(c && comm && rowmajor && out, "null argument");
+  MH_REQUIRE(log_n >= 0 && log_n <= 29 && width > 0, "bad trace shape");
+  MH_REQUIRE(comm->world >= 1 && (comm->world & (comm->world - 1)) == 0 && comm->rank >= 0 && comm->rank < comm->world,
+             "world must be a power of two and 0 <= rank < world");
+  HIP_CHECK(hipSetDevice(c->device));
+  const size_t n = (size_t)1 << log_n;
+  if (comm->world == 1 || n < (size_t)comm->world) {
+    *out = trace_upload(c, rowmajor, log_n, width);
+  } else {
+    MH_REQUIRE(comm->all_gather, "missing all_gather callback");
+    Dist d;
+    d.comm = comm; d.rank = comm->rank; d.world = comm->world;
+    while ((1 << d.logG) < d.world) d.logG++;
+    const size_t rows = n / comm->world, slice = rows * width * 8;
+    std::unique_ptr<mh_trace> t(new mh_trace());
+    t->ctx = c; t->log_n = log_n; t->width = width;
+    DevBuf mine(slice), full(n * width * 8);
+    t->cols.alloc(n * width * 8);
+    HIP_CHECK(hipMemcpyAsync(mine.p, rowmajor + (size_t)comm->rank * rows * width, slice, hipMemcpyHostToDevice, c->stream));
+    d.all_gather(c, mine.p, full.p, slice);  // rank order = row order
+    {
+      ProfScope ps(c, "transpose_in", 16.0 * n * width);
+      launch_transpose_rm_to_cm(c, full.u(), t->cols.u(), n, width);
+    }
+    c->sync();
+    *out = t.release();
+  }
+  MH_CATCH
+}
+
 int mh_commit_traces_sharded(mh_ctx* c, const mh_comm* comm, int n_traces, mh_trace* const* traces, int log_blowup, mh_tree** out,
                              uint64_t root[4]) {
   MH_TRY(c)

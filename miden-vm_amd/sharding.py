@@ -272,6 +272,18 @@ def comm_selftest(ctx, comm):
     ctx.check(ctx.lib.mh_comm_selftest(ctx.h, C.byref(comm.struct)))
 
 
+def upload_trace_sharded(pkg, ctx, comm, matrix):
+    """mh_trace_upload_sharded: this rank uploads its 1/world of the rows, the slices are all-gathered (collective)."""
+    m = np.ascontiguousarray(matrix, dtype=np.uint64)
+    n, w = m.shape
+    log_n = int(n).bit_length() - 1
+    assert 1 << log_n == n
+    h = C.c_void_p()
+    ctx.check(ctx.lib.mh_trace_upload_sharded(ctx.h, C.byref(comm.struct), m.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int(log_n),
+                                              C.c_size_t(w), C.byref(h)))
+    return pkg.Trace.from_handle(ctx, h, log_n, w)
+
+
 def commit_traces_sharded(pkg, ctx, comm, traces, log_blowup):
     """mh_commit_traces_sharded: this rank's part of the commitment (e.g. the preprocessed setup tree of a sharded prover)."""
     n = len(traces)

@@ -469,3 +469,29 @@ def test_collective_counts_and_bytes_of_a_world8_proof():
         assert bytes_ag >= 16 * N * B  # the quotient chunk coefficients: 16 B x N per chunk, all D = B chunks on every rank
         assert r["comm_all_reduce"][0] >= 4  # three opened trees + FRI rounds + the OOD vectors
         assert r["lde_intt"][0] >= 2 and r["deep_ood_eval"][0] == 3  # replicated inverse transforms; OOD once per matrix
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_trace_upload(world):
+    """mh_trace_upload_sharded: every rank uploads 1/world of the rows, the slices are all-gathered: each rank ends up with the
+    whole matrix (canonicalised, column-major on the device) and proves from it exactly as from a plain upload."""
+    import oracle_binding as ob
+    import airs as A
+    from miden_vm_amd import dag
+    air, host, prm = dag.dummy_miden_air(13, 2), A.dummy_trace(10, 13, seed=12), ob.PROD_PARAMS
+    host[5, 3] = np.uint64(ob.P + 5)  # a non-canonical felt in memory: canonicalised on the way in
+    st, pre = ob.challenger_state(), ob.protocol_pre_observe(prm, [])
+    canon = host % np.uint64(ob.P)
+
+    def body(pkg, sharding, rank, ctx, comm):
+        t = sharding.upload_trace_sharded(pkg, ctx, comm, host)
+        back = t.download()
+        dair = pkg.DeviceAir(ctx, air)
+        got = sharding.prove_sharded(pkg, ctx, comm, [dair], [t], [], prm, st, pre, None)
+        ref = pkg.prove(ctx, [dair], [ctx.upload_trace(host)], [], prm, st, pre, None) if rank == 0 else None
+        return back, got, ref
+
+    res = _thread_ranks(world, body)
+    for back, got, _ in res:
+        assert (back == canon).all()
+        assert got.bytes == res[0][2].bytes
