@@ -425,14 +425,14 @@ __device__ __forceinline__ void ntt_dft_regs(u64 (&x)[1 << G], bool dif) {
 // x[e] *= tw[(e - 1) << s | gm] for e = OFF .. OFF + K - 1: the table twiddles of a round, multiplied in interleaved
 // groups of <= 5 products (p2f_mulN); consecutive lanes = consecutive gm: coalesced loads
 template <int K, int OFF>
-__device__ __forceinline__ void ntt_tw_mul(u64* x, const u64* __restrict__ tw, int s) {
+__device__ __forceinline__ void ntt_tw_mul(u64* x, const u64* __restrict__ tw, int s, u32 gm) {
   if constexpr (K > 0) {
     constexpr int C = K >= 5 ? 5 : K;
     u64 a[C], b[C];
 #pragma unroll
     for (int i = 0; i < C; i++) {
       a[i] = x[OFF + i];
-      b[i] = tw[(size_t)(OFF + i - 1) << s];  // tw already points at this thread's column gm of the plane: a wave-uniform offset per element
+      b[i] = (tw + ((size_t)(OFF + i - 1) << s))[gm];  // wave-uniform row pointer + the thread's column
     }
 #if P2F_ASM && NTT_ASM_MUL == 1
     p2f_mulN<C>(a, a, b);
@@ -442,12 +442,12 @@ __device__ __forceinline__ void ntt_tw_mul(u64* x, const u64* __restrict__ tw, i
 #endif
 #pragma unroll
     for (int i = 0; i < C; i++) x[OFF + i] = a[i];
-    ntt_tw_mul<K - C, OFF + C>(x, tw, s);
+    ntt_tw_mul<K - C, OFF + C>(x, tw, s, gm);
   }
 }
 #else
 template <int K, int OFF>
-__device__ void ntt_tw_mul(u64* x, const u64* __restrict__ tw, int s);
+__device__ void ntt_tw_mul(u64* x, const u64* __restrict__ tw, int s, u32 gm);
 template <int G, bool INV>
 __device__ void ntt_dft_regs(u64 (&x)[1 << G], bool dif);
 __device__ u64 ntt_canon(u64 t);
@@ -473,38 +473,50 @@ __device__ __forceinline__ u32 ntt_pad(u32 l) {
   return SWZ ? (l ^ ((l >> 4) & 31u)) : (l + (l >> 4));
 }
 
-template <int G, bool INV, bool SWZ>
+// B0: the LDS bit position of the element index e in this round (= st + cb) when it is 0, 4 or 8 -- every round of the 2^20 plan --
+// else -1 (decided at run time).  With B0 known at compile time the LDS byte address of element e is the thread's pre-scaled
+// address XOR a LITERAL (B0 = 0, 4: one v_xor, no scalar registers), or, for B0 = 8, one of two pre-computed addresses plus an
+// immediate offset in the ds instruction (the swizzle touches bit 4 only: slot = (p0 ^ ((e & 1) << 4)) + (e << 8)): no VALU at all.
+template <int G, bool INV, bool SWZ, int B0>
 __device__ __forceinline__ void ntt_round(const NttPassArgs& a, u64* lds, int st, u32 tile_n, size_t lo0, u64* dst_direct,
                                           size_t gbase, const u64* __restrict__ tw) {
-  const int b0 = st + a.cb, s = a.s_lo + st;
+  const int b0 = B0 >= 0 ? B0 : st + a.cb, s = a.s_lo + st;
   const u32 cb_mask = (1u << a.cb) - 1;
+  constexpr bool FAST = SWZ && B0 >= 0;
   for (u32 q = threadIdx.x; q < (tile_n >> G); q += blockDim.x) {
     const u32 low = q & ((1u << b0) - 1);
     const u32 l0 = ((q >> b0) << (b0 + G)) | low;
     const u32 gm = (((l0 >> a.cb) & ((1u << st) - 1)) << a.s_lo) | ((u32)lo0 << a.cb) | (l0 & cb_mask);
     // LDS slot of element e: the swizzle is linear over XOR and l0, e << b0 have no bit in common, so
-    // slot(l0 | e << b0) = slot(l0) ^ slot(e << b0): one per-thread value and sixteen wave-uniform ones (scalar unit), one
-    // v_xor per access instead of the shift / and / or chain of the generic form (~4 VALU x 32 accesses per round)
+    // slot(l0 | e << b0) = slot(l0) ^ slot(e << b0)
     const u32 p0 = ntt_pad<SWZ>(l0);
+    char* const ldsb = reinterpret_cast<char*>(lds);
+    const u32 pb = p0 * 8u, pb1 = (p0 ^ 16u) * 8u;  // byte addresses (pb1: B0 = 8, odd e)
+    auto slot = [&](int e) -> u64* {
+      if constexpr (FAST && B0 == 8) return reinterpret_cast<u64*>(ldsb + ((e & 1) ? pb1 : pb) + ((u32)e << 11));
+      else if constexpr (FAST) return reinterpret_cast<u64*>(ldsb + (pb ^ (ntt_pad<true>((u32)e << B0) * 8u)));
+      else return lds + (SWZ ? (p0 ^ ntt_pad<true>((u32)e << b0)) : ntt_pad<false>(l0 | ((u32)e << b0)));
+    };
     u64 x[1 << G];
 #pragma unroll
-    for (int e = 0; e < (1 << G); e++) x[e] = lds[SWZ ? (p0 ^ ntt_pad<true>((u32)e << b0)) : ntt_pad<false>(l0 | ((u32)e << b0))];
-    if (!INV && s > 0) ntt_tw_mul<(1 << G) - 1, 1>(x, tw + gm, s);
+    for (int e = 0; e < (1 << G); e++) x[e] = *slot(e);
+    if (!INV && s > 0) ntt_tw_mul<(1 << G) - 1, 1>(x, tw, s, gm);
     ntt_dft_regs<G, INV>(x, INV);
-    if (INV && s > 0) ntt_tw_mul<(1 << G) - 1, 1>(x, tw + gm, s);
+    if (INV && s > 0) ntt_tw_mul<(1 << G) - 1, 1>(x, tw, s, gm);
     if (dst_direct) {
-      // global index of element e: b0 >= cb, so e << b0 lands above the tile's contiguous bits: index = index(l0) + (e << (st + s_lo))
-      u64* p = dst_direct + (gbase | ((size_t)(l0 >> a.cb) << a.s_lo) | (l0 & cb_mask));
+      // global index of element e: b0 >= cb, so e << b0 lands above the tile's contiguous bits: index = index(l0) + (e << (st + s_lo)).
+      // A wave-uniform base pointer per element + one 32-bit per-thread index: the scalar-base form of global_store, no address VALU.
+      const u32 tix = (u32)(gbase | ((size_t)(l0 >> a.cb) << a.s_lo) | (l0 & cb_mask));
       if (a.canon_out) {  // decided once per round, not per element
 #pragma unroll
-        for (int e = 0; e < (1 << G); e++) p[(size_t)e << s] = ntt_canon(x[e]);
+        for (int e = 0; e < (1 << G); e++) (dst_direct + ((size_t)e << s))[tix] = ntt_canon(x[e]);
       } else {
 #pragma unroll
-        for (int e = 0; e < (1 << G); e++) p[(size_t)e << s] = x[e];
+        for (int e = 0; e < (1 << G); e++) (dst_direct + ((size_t)e << s))[tix] = x[e];
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < (1 << G); e++) lds[SWZ ? (p0 ^ ntt_pad<true>((u32)e << b0)) : ntt_pad<false>(l0 | ((u32)e << b0))] = x[e];
+      for (int e = 0; e < (1 << G); e++) *slot(e) = x[e];
     }
   }
 }
@@ -536,7 +548,7 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
     // full tile: element i of this thread is l = tid + i * THREADS; THREADS >= 2^cb, so i * THREADS lands above the contiguous bits:
     // global index = index(tid) + (i << (LOG_T - cb + s_lo)), LDS slot = slot(tid) ^ slot(i * THREADS) (linear swizzle)
     const u32 tid = threadIdx.x;
-    const size_t g0 = gbase | ((size_t)(tid >> a.cb) << a.s_lo) | (tid & cb_mask);
+    const u32 g0 = (u32)(gbase | ((size_t)(tid >> a.cb) << a.s_lo) | (tid & cb_mask));
     const int shg = LOG_T - a.cb + a.s_lo;
     const u32 p0 = ntt_pad<SWZ>(tid);
     // four elements at a time: all sixteen in flight (plus their scale-table loads) cost 200 VGPRs
@@ -544,11 +556,11 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
     for (int c = 0; c < 16; c += 4) {
       u64 v[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) v[j] = src[g0 + ((size_t)(c + j) << shg)];
+      for (int j = 0; j < 4; j++) v[j] = (src + ((size_t)(c + j) << shg))[g0];  // wave-uniform base + the thread's index
       if (a.scale_lo) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const u32 k = bitrev32((u32)(g0 + ((size_t)(c + j) << shg)), a.log_n);
+          const u32 k = bitrev32(g0 + ((u32)(c + j) << shg), a.log_n);
           const u64 sc = NTT_MUL1(a.scale_lo[zc * a.scale_lo_z + (k & ((1u << a.lb) - 1))], a.scale_hi[zc * a.scale_hi_z + (k >> a.lb)]);
           v[j] = NTT_MUL1(v[j], sc);
         }
@@ -590,12 +602,16 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
       g = 4;
     }
     u64* direct = (i == n_rounds - 1) ? dst : nullptr;
-    switch (g) {
-      case 4: ntt_round<4, INV, SWZ>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri]); break;
-      case 3: ntt_round<3, INV, SWZ>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri]); break;
-      case 2: ntt_round<2, INV, SWZ>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri]); break;
-      default: ntt_round<1, INV, SWZ>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri]); break;
-    }
+    const int b0 = st + a.cb;
+#define NTT_ROUND(GG, BB) ntt_round<GG, INV, SWZ, BB>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri])
+    if (g == 4 && b0 == 0) NTT_ROUND(4, 0);
+    else if (g == 4 && b0 == 4) NTT_ROUND(4, 4);
+    else if (g == 4 && b0 == 8) NTT_ROUND(4, 8);
+    else if (g == 4) NTT_ROUND(4, -1);
+    else if (g == 3) NTT_ROUND(3, -1);
+    else if (g == 2) NTT_ROUND(2, -1);
+    else NTT_ROUND(1, -1);
+#undef NTT_ROUND
     if (!direct) __syncthreads();
   }
   }  // cosets
