@@ -221,7 +221,7 @@ def cpu_baseline(runner, cpu_log_n):
     t0 = time.perf_counter()
     ob.prove([runner.air], [t], [], runner.params)
     dt = time.perf_counter() - t0
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    cores = ob.omp_threads()
     return {"value": (1 << cpu_log_n) / dt, "unit": "trace rows/s", "cores": cores, "kind": "port",
             "sample": f"CPU restatement (oracle/, OpenMP {cores} threads) proving miden:{cpu_log_n}:51:8 with the same parameters in {dt:.2f} s",
             "cpu_model": cpu_model(),

@@ -141,7 +141,10 @@ static constexpr unsigned DEEP_FLUSH = 128;
 #ifndef DEEP_UNROLL
 #define DEEP_UNROLL 2  // columns per trip of the dot-product loop (loads in flight per lane = DEEP_UNROLL x DEEP_PTS)
 #endif
-static constexpr int DEEP_PTS = 2;  // points per lane (they share one Fermat inversion); more costs occupancy
+#ifndef DEEP_PTS_N
+#define DEEP_PTS_N 1  // measured: 1 point per lane 1.69 ms, 2 points 1.96 ms, 4 points 3.12 ms (occupancy beats the shared inversion)
+#endif
+static constexpr int DEEP_PTS = DEEP_PTS_N;  // points per lane (they share one Fermat inversion); more costs occupancy
 struct DeepMat {
   const u64* lde;
   u32 width, coef_off;  // coef_off: index of this matrix's first column in the aligned coefficient list

@@ -21,13 +21,41 @@ def use_fast_library(on=True):
 _so_name = "liboracle.so"
 
 
+def usable_cpus():
+    """Cores this process may really burn: the affinity mask capped by the cgroup CPU quota.  A container that shows 256 CPUs
+    under a 16-core quota turns 256 spinning OpenMP threads into seconds of throttling per parallel region."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def omp_threads():
+    return int(os.environ.get("OMP_NUM_THREADS", 0)) or usable_cpus()
+
+
 def lib():
     global _lib
     if _lib is None:
         so = os.path.join(ROOT, "oracle", _so_name)
         if not os.path.exists(so):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+        os.environ.setdefault("OMP_NUM_THREADS", str(omp_threads()))
         _lib = C.CDLL(so)
+        try:  # libgomp may have read the environment before this module set it (torch loads it first)
+            C.CDLL("libgomp.so.1").omp_set_num_threads(omp_threads())
+        except OSError:
+            pass
         for name in ("orc_fmul", "orc_fadd", "orc_fsub", "orc_fpow"):
             getattr(_lib, name).restype = C.c_uint64
             getattr(_lib, name).argtypes = [C.c_uint64, C.c_uint64]
