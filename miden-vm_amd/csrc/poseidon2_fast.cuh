@@ -263,6 +263,7 @@ __device__ __forceinline__ u64 p2f_fold_signed(u64 L, u64 H) {
 
 // out = circ(2*M4, M4, M4) * s (+ rc), s given as 64-bit values; result folded back to 64 bits.
 // M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]]  (poseidon2/mod.rs:233-281)
+template <bool RC>
 __device__ __forceinline__ void p2f_external(u64 s[12], const unsigned long long* rc) {
   u64 oL[12], oH[12];
 #pragma unroll
@@ -289,7 +290,7 @@ __device__ __forceinline__ void p2f_external(u64 s[12], const unsigned long long
 #pragma unroll
     for (int i = l; i < 12; i += 4) {
       u64 L = oL[i] + stL, H = oH[i] + stH;
-      if (rc) {
+      if (RC) {  // a template flag: as a run-time test of the pointer it became four v_cndmask per element
         L += rc[i] & 0xFFFFFFFFULL;
         H += rc[i] >> 32;
       }
@@ -300,15 +301,15 @@ __device__ __forceinline__ void p2f_external(u64 s[12], const unsigned long long
 
 __device__ __forceinline__ void p2f_permute(u64 s[12]) {
   // initial linear layer + round constants of external round 0
-  p2f_external(s, p2c::P2_ARK_EXT_INITIAL);
+  p2f_external<true>(s, p2c::P2_ARK_EXT_INITIAL);
 #pragma unroll 1
   for (int r = 0; r < 4; r++) {
     p2f_sbox12(s);
     // linear layer, then the NEXT round's constants (the last one is internal round 0: element 0 only)
     if (r < 3) {
-      p2f_external(s, p2c::P2_ARK_EXT_INITIAL + 12 * (r + 1));
+      p2f_external<true>(s, p2c::P2_ARK_EXT_INITIAL + 12 * (r + 1));
     } else {
-      p2f_external(s, nullptr);
+      p2f_external<false>(s, nullptr);
     }
   }
   // ---- internal rounds in the 8^r-scaled domain ----
@@ -319,46 +320,69 @@ __device__ __forceinline__ void p2f_permute(u64 s[12]) {
     L[i] = p2f_zmul<1>(lo32(s[i]));
     H[i] = p2f_zmul<1>(hi32(s[i]));
   }
-#pragma unroll 1
-  for (int r = 0; r < 22; r++) {
-    // y = 8^r * (s0 + rc)^7
-    const u64 y = p2f_mul(p2f_sbox(t0), p2c::P2F_INT_K[r]);
-    u64 sL = p2f_mad<1>(L[1], lo32(y)), sH = p2f_mad<1>(H[1], hi32(y));
-#pragma unroll
-    for (int i = 2; i < 12; i++) {
-      sL += L[i];
-      sH += H[i];
-    }
-    const u64 s8L = sL << 3, s8H = sH << 3;
-    // element 0: -16*y + 8*sum (+ the next round's scaled constant), folded for the next S-box
-    {
-      u64 nL = s8L - p2f_zmul<16>(lo32(y)), nH = s8H - p2f_zmul<16>(hi32(y));
-      if (r < 21) {
-        const u64 rc = p2c::P2F_ARK_INT_SCALED[r + 1];
-        nL += rc & 0xFFFFFFFFULL;
-        nH += rc >> 32;
-      }
-      t0 = p2f_fold_signed(nL, nH);
-    }
+  // Rounds come in pairs.  A 64-bit subtraction is two VALU instructions (v_sub_co + v_subb) plus the shift, an addition with
+  // the shift folded in is one (v_lshl_add_u64), and the S-box is odd, so the elements with a negative diagonal entry (6, 7, 8,
+  // 10) and element 0 are carried NEGATED through every odd round: the even round forms -(s8 - k x) = (x << k) + (-s8) and
+  // -(new s0) = 16 y + (-s8) - rc, the odd round reads v = -x, y' = -y and forms s8 - k x = (v << k) + s8, new s0 = 16 y' + s8 + rc,
+  // the sum being (positive elements) - (y' + negated elements).  17 instructions fewer per round, same values mod p.
 #define P2F_UPD(i, EXPR_L, EXPR_H) \
   {                                \
     const u64 xl = L[i], xh = H[i]; \
     L[i] = EXPR_L;                 \
     H[i] = EXPR_H;                 \
   }
-    P2F_UPD(1, (xl << 3) + s8L, (xh << 3) + s8H)                                  //   8
-    P2F_UPD(2, (xl << 4) + s8L, (xh << 4) + s8H)                                  //  16
-    P2F_UPD(3, (xl << 2) + s8L, (xh << 2) + s8H)                                  //   4
-    P2F_UPD(4, (((xl << 1) + xl) << 3) + s8L, (((xh << 1) + xh) << 3) + s8H)      //  24
-    P2F_UPD(5, ((xl << 1) << 4) + s8L, ((xh << 1) << 4) + s8H)                    //  32
-    P2F_UPD(6, s8L - (xl << 2), s8H - (xh << 2))                                  //  -4
-    P2F_UPD(7, s8L - (((xl << 1) + xl) << 3), s8H - (((xh << 1) + xh) << 3))      // -24
-    P2F_UPD(8, s8L - (xl << 5), s8H - (xh << 5))                                  // -32
-    P2F_UPD(9, (xl << 1) + s8L, (xh << 1) + s8H)                                  //   2
-    P2F_UPD(10, s8L - (xl << 1), s8H - (xh << 1))                                 //  -2
-    P2F_UPD(11, xl + s8L, xh + s8H)                                               //   1
-#undef P2F_UPD
-    if ((r & 3) == 3) {  // parts have grown by <= 7 bits per round from < 2^32: refold before 2^61
+#define P2F_UPD_POS(AL, AH)                                                         \
+  P2F_UPD(1, (xl << 3) + AL, (xh << 3) + AH)                         /*   8 */      \
+  P2F_UPD(2, (xl << 4) + AL, (xh << 4) + AH)                         /*  16 */      \
+  P2F_UPD(3, (xl << 2) + AL, (xh << 2) + AH)                         /*   4 */      \
+  P2F_UPD(4, (((xl << 1) + xl) << 3) + AL, (((xh << 1) + xh) << 3) + AH) /* 24 */   \
+  P2F_UPD(5, (xl << 5) + AL, (xh << 5) + AH)                         /*  32 */      \
+  P2F_UPD(9, (xl << 1) + AL, (xh << 1) + AH)                         /*   2 */      \
+  P2F_UPD(11, xl + AL, xh + AH)                                      /*   1 */
+  // diagonal -4, -24, -32, -2: B = -s8 while the element is true (result negated), B = s8 while it is negated (result true)
+#define P2F_UPD_NEG(BL, BH)                                                         \
+  P2F_UPD(6, (xl << 2) + BL, (xh << 2) + BH)                                        \
+  P2F_UPD(7, (((xl << 1) + xl) << 3) + BL, (((xh << 1) + xh) << 3) + BH)            \
+  P2F_UPD(8, (xl << 5) + BL, (xh << 5) + BH)                                        \
+  P2F_UPD(10, (xl << 1) + BL, (xh << 1) + BH)
+#pragma unroll 1
+  for (int r = 0; r < 22; r += 2) {
+    {  // ---- even round r: every value true on entry
+      // y = 8^r * (s0 + rc)^7
+      const u64 y = p2f_mul(p2f_sbox(t0), p2c::P2F_INT_K[r]);
+      u64 sL = p2f_mad<1>(L[1], lo32(y)), sH = p2f_mad<1>(H[1], hi32(y));
+#pragma unroll
+      for (int i = 2; i < 12; i++) {
+        sL += L[i];
+        sH += H[i];
+      }
+      const u64 s8L = sL << 3, s8H = sH << 3;
+      u64 n8L = 0 - s8L, n8H = 0 - s8H;
+      asm("" : "+v"(n8L), "+v"(n8H));  // opaque: LLVM otherwise turns (x << k) + (0 - s8) back into a shift and a subtraction
+      // -(element 0) = 16*y - 8*sum - (round r + 1's scaled constant), folded for the next S-box
+      const u64 nrc = GL_P - p2c::P2F_ARK_INT_SCALED[r + 1];
+      t0 = p2f_fold_signed(p2f_mad<16>(n8L, lo32(y)) + (nrc & 0xFFFFFFFFULL), p2f_mad<16>(n8H, hi32(y)) + (nrc >> 32));
+      P2F_UPD_POS(s8L, s8H)
+      P2F_UPD_NEG(n8L, n8H)
+    }
+    {  // ---- odd round r + 1: element 0 and elements 6, 7, 8, 10 negated on entry, true on exit
+      const u64 y = p2f_mul(p2f_sbox(t0), p2c::P2F_INT_K[r + 1]);  // = -(8^(r+1) * (s0 + rc)^7)
+      const u64 pL = L[1] + L[2] + L[3] + L[4] + L[5] + L[9] + L[11], pH = H[1] + H[2] + H[3] + H[4] + H[5] + H[9] + H[11];
+      u64 qL = p2f_mad<1>(L[6], lo32(y)) + L[7] + L[8] + L[10], qH = p2f_mad<1>(H[6], hi32(y)) + H[7] + H[8] + H[10];
+      asm("" : "+v"(qL), "+v"(qH));  // one subtraction of the finished sum (LLVM otherwise subtracts term by term)
+      const u64 s8L = (pL - qL) << 3, s8H = (pH - qH) << 3;
+      // element 0: -16*(true y) + 8*sum (+ the next round's scaled constant)
+      u64 nL = p2f_mad<16>(s8L, lo32(y)), nH = p2f_mad<16>(s8H, hi32(y));
+      if (r + 1 < 21) {
+        const u64 rc = p2c::P2F_ARK_INT_SCALED[r + 2];
+        nL += rc & 0xFFFFFFFFULL;
+        nH += rc >> 32;
+      }
+      t0 = p2f_fold_signed(nL, nH);
+      P2F_UPD_POS(s8L, s8H)
+      P2F_UPD_NEG(s8L, s8H)
+    }
+    if ((r & 3) == 2) {  // parts have grown by <= 7 bits per round from < 2^32: refold every 4 rounds, before 2^61
 #pragma unroll
       for (int i = 1; i < 12; i++) {
         const u64 v = p2f_fold_signed(L[i], H[i]);
@@ -367,6 +391,9 @@ __device__ __forceinline__ void p2f_permute(u64 s[12]) {
       }
     }
   }
+#undef P2F_UPD_POS
+#undef P2F_UPD_NEG
+#undef P2F_UPD
   // leave the scaled domain (factor 8^22) and add the first terminal round constants
   s[0] = t0;
 #pragma unroll
@@ -391,9 +418,9 @@ __device__ __forceinline__ void p2f_permute(u64 s[12]) {
   for (int r = 0; r < 4; r++) {
     p2f_sbox12(s);
     if (r < 3) {
-      p2f_external(s, p2c::P2_ARK_EXT_TERMINAL + 12 * (r + 1));
+      p2f_external<true>(s, p2c::P2_ARK_EXT_TERMINAL + 12 * (r + 1));
     } else {
-      p2f_external(s, nullptr);
+      p2f_external<false>(s, nullptr);
     }
   }
 #pragma unroll
