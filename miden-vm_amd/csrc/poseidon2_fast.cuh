@@ -12,9 +12,13 @@
 //     modular fix-up, small-constant products are free (mad / shift-add);
 //   * one fold back to 64 bits per element per S-box (2^64 = 2^32 - 1 mod p);
 //   * the 22 internal rounds keep elements 1..11 wide across rounds; the fractional diagonal
-//     [-2,1,2,1/2,3,4,-1/2,-3,-4,1/4,-1/4,1/8] is cleared by carrying the whole state scaled by 8^r
+//     [-2,1,2,1/2,3,4,-1/2,-3,-4,1/4,-1/4,1/8] is cleared by carrying the whole state scaled by c_r = 2 * 8^r
 //     (integer diagonal [-16,8,16,4,24,32,-4,-24,-32,2,-2,1]); the S-box of round r then costs one
-//     extra multiplication by the constant 8^(-6r), and wide values are refolded every 4 rounds.
+//     extra multiplication by the constant c_r^(-6), and wide values are refolded every 4 rounds;
+//   * the diagonal pairs (+k, -k) -- elements (3,6), (4,7), (5,8), (9,10) -- are carried as h = (x_i + x_j)/2, whose
+//     two-step recurrence h(r+1) = k^2 h(r-1) + 8*sum is ONE shift-add per part and round (no 64-bit subtraction, which is
+//     two instructions plus the shift), and the sum reads one value per pair; tests/test_p2_fast_schedule.py checks the algebra
+//     on exact integers, tools/p2_pair_bounds.py the magnitudes.  10 953 -> 10 120 VALU instructions per permutation.
 #pragma once
 #include "poseidon2.cuh"
 
@@ -312,105 +316,120 @@ __device__ __forceinline__ void p2f_permute(u64 s[12]) {
       p2f_external<false>(s, nullptr);
     }
   }
-  // ---- internal rounds in the 8^r-scaled domain ----
-  u64 t0 = p2f_add_canon(s[0], p2c::P2F_ARK_INT_SCALED[0]);
-  u64 L[12], H[12];  // [0] unused
+  // ---- internal rounds, all values scaled by c_r = 2 * 8^r ----
+  // X' = 8 * (diag * X + sum), integer diagonal [-16, 8, 16, 4, 24, 32, -4, -24, -32, 2, -2, 1].  Elements (3,6), (4,7), (5,8),
+  // (9,10) have diagonals (+k, -k): with h = (X_i + X_j) / 2 and b = X_i - X_j one round is h' = (k/2) b + s8, b' = 2 k h, so
+  //     h(r+1) = k^2 * h(r-1) + s8(r)          (s8 = 8 * sum; the sum needs only 2 h per pair)
+  // is all a round does for a pair -- one shift-add per part instead of two shifts, an addition and a subtraction -- and after the
+  // last round X_i = h(22) + k h(21), X_j = h(22) - k h(21).  The factor 2 in c_r makes h(0) = x_i + x_j an integer sum.
+  // Round 0 takes the TRUE state (its constants: P2G_ARK[0] = ark_0, P2G_K[0] = c_0 = 2).
+  u64 t0 = p2f_add_canon(s[0], p2c::P2G_ARK[0]);
+  u64 X1L, X1H, X2L, X2H, X11L, X11H;
+  u64 AL[4], AH[4], BL[4], BH[4];  // pair q: A = h(even round), B = h(odd round)
+  {
+    const u64 y = p2f_mul(p2f_sbox(t0), p2c::P2G_K[0]);
+    u64 RL = p2f_zmul<1>(lo32(s[1])), RH = p2f_zmul<1>(hi32(s[1]));
 #pragma unroll
-  for (int i = 1; i < 12; i++) {
-    L[i] = p2f_zmul<1>(lo32(s[i]));
-    H[i] = p2f_zmul<1>(hi32(s[i]));
+    for (int i = 2; i < 12; i++) {
+      RL = p2f_mad<1>(RL, lo32(s[i]));
+      RH = p2f_mad<1>(RH, hi32(s[i]));
+    }
+    // sum = y + 2 * (x_1 + ... + x_11);  element 0: -16 y + 8 sum = 8 * (2 R - y)
+    const u64 s8L = p2f_mad<1>(RL << 1, lo32(y)) << 3, s8H = p2f_mad<1>(RH << 1, hi32(y)) << 3;
+    {
+      const u64 rc = p2c::P2G_ARK[1];
+      t0 = p2f_fold_signed((((RL << 1) - (u64)lo32(y)) << 3) + (rc & 0xFFFFFFFFULL), (((RH << 1) - (u64)hi32(y)) << 3) + (rc >> 32));
+    }
+    X1L = p2f_mad<16>(s8L, lo32(s[1])), X1H = p2f_mad<16>(s8H, hi32(s[1]));     // 8 * (2 x)
+    X2L = p2f_mad<32>(s8L, lo32(s[2])), X2H = p2f_mad<32>(s8H, hi32(s[2]));     // 16 * (2 x)
+    X11L = p2f_mad<2>(s8L, lo32(s[11])), X11H = p2f_mad<2>(s8H, hi32(s[11]));   // 1 * (2 x)
+#define P2G_PAIR0(q, i, j, K)                                                         \
+  AL[q] = p2f_mad<1>(p2f_zmul<1>(lo32(s[i])), lo32(s[j]));                            \
+  AH[q] = p2f_mad<1>(p2f_zmul<1>(hi32(s[i])), hi32(s[j]));                            \
+  BL[q] = p2f_mad<K>(s8L, lo32(s[i])) - p2f_zmul<K>(lo32(s[j]));                      \
+  BH[q] = p2f_mad<K>(s8H, hi32(s[i])) - p2f_zmul<K>(hi32(s[j]));
+    P2G_PAIR0(0, 3, 6, 4)
+    P2G_PAIR0(1, 4, 7, 24)
+    P2G_PAIR0(2, 5, 8, 32)
+    P2G_PAIR0(3, 9, 10, 2)
+#undef P2G_PAIR0
   }
-  // Rounds come in pairs.  A 64-bit subtraction is two VALU instructions (v_sub_co + v_subb) plus the shift, an addition with
-  // the shift folded in is one (v_lshl_add_u64), and the S-box is odd, so the elements with a negative diagonal entry (6, 7, 8,
-  // 10) and element 0 are carried NEGATED through every odd round: the even round forms -(s8 - k x) = (x << k) + (-s8) and
-  // -(new s0) = 16 y + (-s8) - rc, the odd round reads v = -x, y' = -y and forms s8 - k x = (v << k) + s8, new s0 = 16 y' + s8 + rc,
-  // the sum being (positive elements) - (y' + negated elements).  17 instructions fewer per round, same values mod p.
-#define P2F_UPD(i, EXPR_L, EXPR_H) \
-  {                                \
-    const u64 xl = L[i], xh = H[i]; \
-    L[i] = EXPR_L;                 \
-    H[i] = EXPR_H;                 \
+  // round r: C = h(r), P = h(r - 1) -> P = h(r + 1)
+#define P2G_ROUND(r, CL, CH, PL, PH, HAS_RC)                                                             \
+  {                                                                                                       \
+    const u64 y = p2f_mul(p2f_sbox(t0), p2c::P2G_K[r]);                                                   \
+    const u64 RL = ((CL[0] + CL[1] + CL[2] + CL[3]) << 1) + X1L + X2L + X11L;                             \
+    const u64 RH = ((CH[0] + CH[1] + CH[2] + CH[3]) << 1) + X1H + X2H + X11H;                             \
+    const u64 s8L = p2f_mad<1>(RL, lo32(y)) << 3, s8H = p2f_mad<1>(RH, hi32(y)) << 3;                     \
+    {                                                                                                     \
+      u64 nL = (RL - (u64)lo32(y)) << 3, nH = (RH - (u64)hi32(y)) << 3; /* -16 y + 8 (R + y) */           \
+      if (HAS_RC) {                                                                                       \
+        const u64 rc = p2c::P2G_ARK[(r) + 1];                                                             \
+        nL += rc & 0xFFFFFFFFULL;                                                                         \
+        nH += rc >> 32;                                                                                   \
+      }                                                                                                   \
+      t0 = p2f_fold_signed(nL, nH);                                                                       \
+    }                                                                                                     \
+    X1L = (X1L << 3) + s8L, X1H = (X1H << 3) + s8H;                                                       \
+    X2L = (X2L << 4) + s8L, X2H = (X2H << 4) + s8H;                                                       \
+    X11L += s8L, X11H += s8H;                                                                             \
+    PL[0] = (PL[0] << 4) + s8L, PH[0] = (PH[0] << 4) + s8H;                               /* 4^2 */       \
+    PL[1] = ((((PL[1] << 3) + PL[1]) << 2) << 4) + s8L, PH[1] = ((((PH[1] << 3) + PH[1]) << 2) << 4) + s8H; /* 24^2 = 9 * 64 */ \
+    PL[2] = ((PL[2] << 6) << 4) + s8L, PH[2] = ((PH[2] << 6) << 4) + s8H;                 /* 32^2 */      \
+    PL[3] = (PL[3] << 2) + s8L, PH[3] = (PH[3] << 2) + s8H;                               /* 2^2 */       \
   }
-#define P2F_UPD_POS(AL, AH)                                                         \
-  P2F_UPD(1, (xl << 3) + AL, (xh << 3) + AH)                         /*   8 */      \
-  P2F_UPD(2, (xl << 4) + AL, (xh << 4) + AH)                         /*  16 */      \
-  P2F_UPD(3, (xl << 2) + AL, (xh << 2) + AH)                         /*   4 */      \
-  P2F_UPD(4, (((xl << 1) + xl) << 3) + AL, (((xh << 1) + xh) << 3) + AH) /* 24 */   \
-  P2F_UPD(5, (xl << 5) + AL, (xh << 5) + AH)                         /*  32 */      \
-  P2F_UPD(9, (xl << 1) + AL, (xh << 1) + AH)                         /*   2 */      \
-  P2F_UPD(11, xl + AL, xh + AH)                                      /*   1 */
-  // diagonal -4, -24, -32, -2: B = -s8 while the element is true (result negated), B = s8 while it is negated (result true)
-#define P2F_UPD_NEG(BL, BH)                                                         \
-  P2F_UPD(6, (xl << 2) + BL, (xh << 2) + BH)                                        \
-  P2F_UPD(7, (((xl << 1) + xl) << 3) + BL, (((xh << 1) + xh) << 3) + BH)            \
-  P2F_UPD(8, (xl << 5) + BL, (xh << 5) + BH)                                        \
-  P2F_UPD(10, (xl << 1) + BL, (xh << 1) + BH)
+#define P2G_REFOLD(L_, H_)                        \
+  {                                               \
+    const u64 v = p2f_fold_signed(L_, H_);        \
+    L_ = p2f_zmul<1>(lo32(v));                    \
+    H_ = p2f_zmul<1>(hi32(v));                    \
+  }
 #pragma unroll 1
-  for (int r = 0; r < 22; r += 2) {
-    {  // ---- even round r: every value true on entry
-      // y = 8^r * (s0 + rc)^7
-      const u64 y = p2f_mul(p2f_sbox(t0), p2c::P2F_INT_K[r]);
-      u64 sL = p2f_mad<1>(L[1], lo32(y)), sH = p2f_mad<1>(H[1], hi32(y));
+  for (int r = 1; r < 22; r += 2) {
+    P2G_ROUND(r, BL, BH, AL, AH, r < 21)
+    if ((r & 3) == 3) {  // parts < 2^32 grow to < 2^60.5 in four rounds (tools/p2_pair_bounds.py): refold before 2^61
+      P2G_REFOLD(X1L, X1H)
+      P2G_REFOLD(X2L, X2H)
+      P2G_REFOLD(X11L, X11H)
 #pragma unroll
-      for (int i = 2; i < 12; i++) {
-        sL += L[i];
-        sH += H[i];
-      }
-      const u64 s8L = sL << 3, s8H = sH << 3;
-      u64 n8L = 0 - s8L, n8H = 0 - s8H;
-      asm("" : "+v"(n8L), "+v"(n8H));  // opaque: LLVM otherwise turns (x << k) + (0 - s8) back into a shift and a subtraction
-      // -(element 0) = 16*y - 8*sum - (round r + 1's scaled constant), folded for the next S-box
-      const u64 nrc = GL_P - p2c::P2F_ARK_INT_SCALED[r + 1];
-      t0 = p2f_fold_signed(p2f_mad<16>(n8L, lo32(y)) + (nrc & 0xFFFFFFFFULL), p2f_mad<16>(n8H, hi32(y)) + (nrc >> 32));
-      P2F_UPD_POS(s8L, s8H)
-      P2F_UPD_NEG(n8L, n8H)
-    }
-    {  // ---- odd round r + 1: element 0 and elements 6, 7, 8, 10 negated on entry, true on exit
-      const u64 y = p2f_mul(p2f_sbox(t0), p2c::P2F_INT_K[r + 1]);  // = -(8^(r+1) * (s0 + rc)^7)
-      const u64 pL = L[1] + L[2] + L[3] + L[4] + L[5] + L[9] + L[11], pH = H[1] + H[2] + H[3] + H[4] + H[5] + H[9] + H[11];
-      u64 qL = p2f_mad<1>(L[6], lo32(y)) + L[7] + L[8] + L[10], qH = p2f_mad<1>(H[6], hi32(y)) + H[7] + H[8] + H[10];
-      asm("" : "+v"(qL), "+v"(qH));  // one subtraction of the finished sum (LLVM otherwise subtracts term by term)
-      const u64 s8L = (pL - qL) << 3, s8H = (pH - qH) << 3;
-      // element 0: -16*(true y) + 8*sum (+ the next round's scaled constant)
-      u64 nL = p2f_mad<16>(s8L, lo32(y)), nH = p2f_mad<16>(s8H, hi32(y));
-      if (r + 1 < 21) {
-        const u64 rc = p2c::P2F_ARK_INT_SCALED[r + 2];
-        nL += rc & 0xFFFFFFFFULL;
-        nH += rc >> 32;
-      }
-      t0 = p2f_fold_signed(nL, nH);
-      P2F_UPD_POS(s8L, s8H)
-      P2F_UPD_NEG(s8L, s8H)
-    }
-    if ((r & 3) == 2) {  // parts have grown by <= 7 bits per round from < 2^32: refold every 4 rounds, before 2^61
-#pragma unroll
-      for (int i = 1; i < 12; i++) {
-        const u64 v = p2f_fold_signed(L[i], H[i]);
-        L[i] = p2f_zmul<1>(lo32(v));
-        H[i] = p2f_zmul<1>(hi32(v));
+      for (int q = 0; q < 4; q++) {
+        P2G_REFOLD(AL[q], AH[q])
+        P2G_REFOLD(BL[q], BH[q])
       }
     }
+    if (r + 1 < 22) P2G_ROUND(r + 1, AL, AH, BL, BH, true)
   }
-#undef P2F_UPD_POS
-#undef P2F_UPD_NEG
-#undef P2F_UPD
-  // leave the scaled domain (factor 8^22) and add the first terminal round constants
+#undef P2G_ROUND
+#undef P2G_REFOLD
+  // A = h(22), B = h(21): back to the elements, out of the scaled domain (factor c_22), then the first terminal round constants
   s[0] = t0;
-#pragma unroll
-  for (int i = 1; i < 12; i++) s[i] = p2f_fold_signed(L[i], H[i]);
+  s[1] = p2f_fold_signed(X1L, X1H);
+  s[2] = p2f_fold_signed(X2L, X2H);
+  s[11] = p2f_fold_signed(X11L, X11H);
+#define P2G_UNPAIR(q, i, j, KL, KH)                         \
+  {                                                         \
+    const u64 kL = KL, kH = KH;                             \
+    s[i] = p2f_fold_signed(AL[q] + kL, AH[q] + kH);         \
+    s[j] = p2f_fold_signed(AL[q] - kL, AH[q] - kH);         \
+  }
+  P2G_UNPAIR(0, 3, 6, BL[0] << 2, BH[0] << 2)
+  P2G_UNPAIR(1, 4, 7, ((BL[1] << 1) + BL[1]) << 3, ((BH[1] << 1) + BH[1]) << 3)
+  P2G_UNPAIR(2, 5, 8, BL[2] << 5, BH[2] << 5)
+  P2G_UNPAIR(3, 9, 10, BL[3] << 1, BH[3] << 1)
+#undef P2G_UNPAIR
 #if P2F_ASM
 #pragma unroll
   for (int g = 0; g < 12; g += 4) {
     u64 x[4], k[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) { x[i] = s[g + i]; k[i] = p2c::P2F_DESCALE; }
+    for (int i = 0; i < 4; i++) { x[i] = s[g + i]; k[i] = p2c::P2G_DESCALE; }
     p2f_mulN<4>(x, x, k);
 #pragma unroll
     for (int i = 0; i < 4; i++) s[g + i] = x[i];
   }
 #else
 #pragma unroll
-  for (int i = 0; i < 12; i++) s[i] = p2f_mul(s[i], p2c::P2F_DESCALE);
+  for (int i = 0; i < 12; i++) s[i] = p2f_mul(s[i], p2c::P2G_DESCALE);
 #endif
 #pragma unroll
   for (int i = 0; i < 12; i++) s[i] = p2f_add_canon(s[i], p2c::P2_ARK_EXT_TERMINAL[i]);
