@@ -112,17 +112,30 @@ __device__ __forceinline__ u64 p2f_mul_c(u64 a, u64 b) {
 #define P2F_MAD0(i, D, X, Y) P2F_SCR(i, "v_mad_u64_u32 %0, ", ", %1, %2, 0", "=v"(D) : "v"(X), "v"(Y))
 #define P2F_MADA(i, D, X, Y, ACC) P2F_SCR(i, "v_mad_u64_u32 %0, ", ", %1, %2, %3", "=v"(D) : "v"(X), "v"(Y), "v"(ACC))
 #define P2F_CARRY_IN(i, OP, D, X, C) P2F_SCR(i, OP " %0, ", ", %1, 0, %2", "=v"(D) : "v"(X), "s"(C))
-template <int N>
+// the same with the second factor in scalar registers (a wave-uniform constant: no v_mov of its halves into VGPRs)
+#define P2F_MAD0S(i, D, X, Y) P2F_SCR(i, "v_mad_u64_u32 %0, ", ", %1, %2, 0", "=v"(D) : "v"(X), "s"(Y))
+#define P2F_MADAS(i, D, X, Y, ACC) P2F_SCR(i, "v_mad_u64_u32 %0, ", ", %1, %2, %3", "=v"(D) : "v"(X), "s"(Y), "v"(ACC))
+// BS: every b[i] is wave-uniform (a table constant); it is read from SGPRs
+template <int N, bool BS = false>
 __device__ __forceinline__ void p2f_mulN(u64 (&r)[N], const u64 (&a)[N], const u64 (&b)[N]) {
   u64 p00[N], m[N], hi[N], t[N];
   u64 cm[N], k1[N], k2[N], k3[N], c1[N], bb[N], bw[N], c3[N];  // SGPR pairs: lane masks of carries
   u32 w1[N], accl[N], acch[N], rl[N], rh[N];
 #pragma unroll
-  for (int i = 0; i < N; i++) P2F_MAD0(i, p00[i], lo32(a[i]), lo32(b[i]));
+  for (int i = 0; i < N; i++) {
+    if constexpr (BS) P2F_MAD0S(i, p00[i], lo32(a[i]), lo32(b[i]));
+    else P2F_MAD0(i, p00[i], lo32(a[i]), lo32(b[i]));
+  }
 #pragma unroll
-  for (int i = 0; i < N; i++) P2F_MAD0(i, m[i], lo32(a[i]), hi32(b[i]));
+  for (int i = 0; i < N; i++) {
+    if constexpr (BS) P2F_MAD0S(i, m[i], lo32(a[i]), hi32(b[i]));
+    else P2F_MAD0(i, m[i], lo32(a[i]), hi32(b[i]));
+  }
 #pragma unroll
-  for (int i = 0; i < N; i++) P2F_A("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m[i]), "=s"(cm[i]) : "v"(hi32(a[i])), "v"(lo32(b[i])), "0"(m[i]));
+  for (int i = 0; i < N; i++) {
+    if constexpr (BS) P2F_A("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m[i]), "=s"(cm[i]) : "v"(hi32(a[i])), "s"(lo32(b[i])), "0"(m[i]));
+    else P2F_A("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m[i]), "=s"(cm[i]) : "v"(hi32(a[i])), "v"(lo32(b[i])), "0"(m[i]));
+  }
 #pragma unroll
   for (int i = 0; i < N; i++) P2F_A("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(w1[i]), "=s"(k1[i]) : "v"(hi32(p00[i])), "v"(lo32(m[i])));
   P2F_GAP();
@@ -139,7 +152,8 @@ __device__ __forceinline__ void p2f_mulN(u64 (&r)[N], const u64 (&a)[N], const u
 #pragma unroll
   for (int i = 0; i < N; i++) {
     const u64 acc = ((u64)acch[i] << 32) | accl[i];
-    P2F_MADA(i, hi[i], hi32(a[i]), hi32(b[i]), acc);
+    if constexpr (BS) P2F_MADAS(i, hi[i], hi32(a[i]), hi32(b[i]), acc);
+    else P2F_MADA(i, hi[i], hi32(a[i]), hi32(b[i]), acc);
   }
 #pragma unroll
   for (int i = 0; i < N; i++) {
@@ -171,6 +185,8 @@ __device__ __forceinline__ void p2f_mulN(u64 (&r)[N], const u64 (&a)[N], const u
 #undef P2F_SCR
 #undef P2F_MAD0
 #undef P2F_MADA
+#undef P2F_MAD0S
+#undef P2F_MADAS
 #undef P2F_CARRY_IN
 // The same 13-instruction product with NON-volatile statements, each carry consumer carrying its own 2 wait states: for
 // code whose schedule must stay free (loads hoisted above the products, independent products interleaved by the compiler:
@@ -206,6 +222,17 @@ __device__ __forceinline__ u64 p2f_mul(u64 a, u64 b) {
   return r[0];
 #else
   return p2f_mul_c(a, b);
+#endif
+}
+// a * k for a wave-uniform k
+__device__ __forceinline__ u64 p2f_mul_k(u64 a, u64 k) {
+#if P2F_ASM
+  u64 r[1];
+  const u64 x[1] = {a}, y[1] = {k};
+  p2f_mulN<1, true>(r, x, y);
+  return r[0];
+#else
+  return p2f_mul_c(a, k);
 #endif
 }
 __device__ __forceinline__ u64 p2f_sbox(u64 x) {
@@ -327,7 +354,7 @@ __device__ __forceinline__ void p2f_permute(u64 s[12]) {
   u64 X1L, X1H, X2L, X2H, X11L, X11H;
   u64 AL[4], AH[4], BL[4], BH[4];  // pair q: A = h(even round), B = h(odd round)
   {
-    const u64 y = p2f_mul(p2f_sbox(t0), p2c::P2G_K[0]);
+    const u64 y = p2f_mul_k(p2f_sbox(t0), p2c::P2G_K[0]);
     u64 RL = p2f_zmul<1>(lo32(s[1])), RH = p2f_zmul<1>(hi32(s[1]));
 #pragma unroll
     for (int i = 2; i < 12; i++) {
@@ -357,7 +384,7 @@ __device__ __forceinline__ void p2f_permute(u64 s[12]) {
   // round r: C = h(r), P = h(r - 1) -> P = h(r + 1)
 #define P2G_ROUND(r, CL, CH, PL, PH, HAS_RC)                                                             \
   {                                                                                                       \
-    const u64 y = p2f_mul(p2f_sbox(t0), p2c::P2G_K[r]);                                                   \
+    const u64 y = p2f_mul_k(p2f_sbox(t0), p2c::P2G_K[r]);                                                   \
     const u64 RL = ((CL[0] + CL[1] + CL[2] + CL[3]) << 1) + X1L + X2L + X11L;                             \
     const u64 RH = ((CH[0] + CH[1] + CH[2] + CH[3]) << 1) + X1H + X2H + X11H;                             \
     const u64 s8L = p2f_mad<1>(RL, lo32(y)) << 3, s8H = p2f_mad<1>(RH, hi32(y)) << 3;                     \
@@ -374,7 +401,12 @@ __device__ __forceinline__ void p2f_permute(u64 s[12]) {
     X2L = (X2L << 4) + s8L, X2H = (X2H << 4) + s8H;                                                       \
     X11L += s8L, X11H += s8H;                                                                             \
     PL[0] = (PL[0] << 4) + s8L, PH[0] = (PH[0] << 4) + s8H;                               /* 4^2 */       \
-    PL[1] = ((((PL[1] << 3) + PL[1]) << 2) << 4) + s8L, PH[1] = ((((PH[1] << 3) + PH[1]) << 2) << 4) + s8H; /* 24^2 = 9 * 64 */ \
+    {                                                                           /* 24^2 = 9 * 64 */       \
+      u64 uL, uH; /* 9 h as ONE shift-add: from C, LLVM makes it a 64 x 32-bit product (two mads and two moves per part) */ \
+      asm("v_lshl_add_u64 %0, %1, 3, %1" : "=v"(uL) : "v"(PL[1]));                                        \
+      asm("v_lshl_add_u64 %0, %1, 3, %1" : "=v"(uH) : "v"(PH[1]));                                        \
+      PL[1] = ((uL << 2) << 4) + s8L, PH[1] = ((uH << 2) << 4) + s8H;                                     \
+    }                                                                                                     \
     PL[2] = ((PL[2] << 6) << 4) + s8L, PH[2] = ((PH[2] << 6) << 4) + s8H;                 /* 32^2 */      \
     PL[3] = (PL[3] << 2) + s8L, PH[3] = (PH[3] << 2) + s8H;                               /* 2^2 */       \
   }
@@ -451,6 +483,7 @@ __device__ __forceinline__ void p2f_permute(u64 s[12]) {
 __device__ void p2f_permute(u64 s[12]);
 __device__ u64 p2f_mul(u64 a, u64 b);
 __device__ u64 p2f_mul_nv(u64 a, u64 b);
+__device__ u64 p2f_mul_k(u64 a, u64 k);
 __device__ u64 p2f_sbox(u64 x);
 __device__ void p2f_sbox12(u64 s[12]);
 __device__ u32 lo32(u64 x);
