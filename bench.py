@@ -121,14 +121,14 @@ def roofline(prof, pmc_file):
             "note": "Poseidon2 hashing is integer-VALU bound (no 64-bit multiplier on CDNA4): see roofline_valu and DESIGN.md section 3"}
 
 
-def valu_roofline(ctx, prof, perms, steps):
+def valu_roofline(ctx, prof, perms, steps, pmc_json=None):
     """The bound the hash kernels actually live on: VALU issue.  On gfx950 every VALU instruction of this integer code
-    (v_mad_u64_u32, the carry-chain VOP3 forms, v_lshl_add_u64, shifts) issues in 4 cycles per wave per SIMD: measured, the
-    register-only permutation runs 10.95 k VALU instructions in 43.7 k s_memtime cycles per wave (tools/permbench,
-    profiles/r02_final_rocprof.txt).  peak = SIMDs x max shader clock x 64 lanes / (4 cycles x the counted MINIMAL instruction
-    sequence of one permutation): 506 field multiplications (472 S-box + 22 round-scale + 12 de-scale) of 13 VALU instructions
-    + 3500 linear-layer instructions (one per 64-bit add / shift-add of the wide representation, 6 per fold) -- DESIGN.md
-    section 3.  A hardware figure: the register-only rate of our own code is reported next to it, not used as the peak."""
+    (v_mad_u64_u32, the carry-chain VOP3 forms, v_lshl_add_u64, shifts) issues in 4 cycles per wave per SIMD (tools/permbench,
+    tools/instbench).  peak = SIMDs x max shader clock x 64 lanes / (issue cycles of the instruction sequence of one permutation):
+    506 field multiplications (472 S-box + 22 round-scale + 12 de-scale) of 13 VALU instructions + the linear layers as they
+    stand in the ISA of p2f_permute (counted per basic block x trip count: DESIGN.md section 3).  It is the ceiling of THIS
+    instruction sequence -- a shorter sequence raises it (round 3 went 10 953 -> 9 967) -- so the register-only rate of the code
+    and the instruction count are reported next to it."""
     out = {"kernel": "lmcs_leaf_absorb", "bound": "valu", "unit": "Gperm/s"}
     ach = perms / (prof["lmcs_leaf_absorb"]["ms"] / steps * 1e-3)
     out["achieved"] = ach / 1e9
@@ -138,19 +138,23 @@ def valu_roofline(ctx, prof, perms, steps):
         out["register_rate_error"] = repr(e)[:120]
     # Issue cost per instruction class (tools/instbench, profiles/r01_microbench.txt, relative to each other): v_mad_u64_u32, the VOP3
     # carry-chain forms (v_add_co / v_addc_co / v_subb_co with SGPR carries), v_lshl_add_u64 and 64-bit shifts all cost the same slot
-    # (1.86-2.00 ns in the microbenchmark = the 4 cycles the permutation measures: 10.95 k instructions in 43.7 k cycles); only
-    # carry-less 32-bit VOP1/VOP2 (v_mov, v_cndmask, v_and, v_add_u32) are cheaper (1.26 ns = 0.65 of a slot).  The permutation's
-    # dynamic mix (ISA of k_compress, per section x trip count): 4.3 % plain, the rest in the 4-cycle class.
-    N_MUL, MUL_VALU, LIN_VALU, SIMDS, MAX_CLOCK_GHZ = 506, 13, 3500, 1024, 2.4
-    CYC_WIDE, CYC_PLAIN, PLAIN_SHARE = 4.0, 2.6, 0.043
-    min_valu = N_MUL * MUL_VALU + LIN_VALU
-    cycles = min_valu * ((1 - PLAIN_SHARE) * CYC_WIDE + PLAIN_SHARE * CYC_PLAIN)
+    # (1.86-2.00 ns in the microbenchmark = the 4 cycles the permutation measures); only carry-less 32-bit VOP1/VOP2 (v_mov,
+    # v_cndmask, v_and, v_add_u32) are cheaper (1.26 ns = 0.65 of a slot): 2.4 % of the dynamic mix (cndmask of the folds and of the final canonicalisation).
+    N_MUL, MUL_VALU, LIN_VALU, SIMDS, MAX_CLOCK_GHZ = 506, 13, 3389, 1024, 2.4
+    CYC_WIDE, CYC_PLAIN, PLAIN_SHARE = 4.0, 2.6, 0.024
+    isa_valu = N_MUL * MUL_VALU + LIN_VALU
+    cycles = isa_valu * ((1 - PLAIN_SHARE) * CYC_WIDE + PLAIN_SHARE * CYC_PLAIN)
     out["peak"] = SIMDS * MAX_CLOCK_GHZ * 64 / cycles
     out["frac"] = out["achieved"] / out["peak"]
-    out["valu_per_permutation"] = {"counted_minimum": min_valu, "measured_SQ_INSTS_VALU": 10977,
+    measured = None
+    try:
+        measured = json.load(open(os.path.join(ROOT, "profiles", pmc_json))).get("valu_per_permutation_SQ_INSTS_VALU") if pmc_json else None
+    except (OSError, ValueError):
+        pass
+    out["valu_per_permutation"] = {"isa_count_p2f_permute": isa_valu, "round2_isa_count": 10953, "measured_SQ_INSTS_VALU_leaf_kernel": measured,
                                    "issue_cycles_by_class": {"mad_u64_u32 / carry-chain VOP3 / 64-bit add, shift": CYC_WIDE, "plain 32-bit VOP1/VOP2": CYC_PLAIN},
                                    "plain_share_of_dynamic_mix": PLAIN_SHARE}
-    out["peak_basis"] = (f"{SIMDS} SIMDs x {MAX_CLOCK_GHZ} GHz (max clock) x 64 lanes / ({min_valu} VALU: {100 * (1 - PLAIN_SHARE):.1f} % at {CYC_WIDE:.0f} issue "
+    out["peak_basis"] = (f"{SIMDS} SIMDs x {MAX_CLOCK_GHZ} GHz (max clock) x 64 lanes / ({isa_valu} VALU: {100 * (1 - PLAIN_SHARE):.1f} % at {CYC_WIDE:.0f} issue "
                          f"cycles, {100 * PLAIN_SHARE:.1f} % at {CYC_PLAIN}); measured clock under this load 2.24-2.35 GHz (s_memtime)")
     return out
 
@@ -467,10 +471,11 @@ def main():
                       if log_n >= 22 else None),
             "model_note": "per-rank ms predicted from the single-GPU spans of profiles/r03_config_shapes.txt (2^24: 790 ms) with "
                           "60 GB/s per xGMI link and direction; replicated = inverse NTTs + host-serial tree tops / transcript"}
-    out["roofline"] = roofline(prof, "r03_pmc_leaf_absorb.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_leaf_absorb.json")) else "r02_pmc_leaf_absorb.json")
+    pmc_json = "r03_pmc_leaf_absorb.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_leaf_absorb.json")) else "r02_pmc_leaf_absorb.json"
+    out["roofline"] = roofline(prof, pmc_json)
     try:
         perms = (8 << log_n) * (7 + 2 + 2) // (world if mode == "sharded" else 1)  # per rank
-        out["roofline_valu"] = valu_roofline(ctx, prof, perms, args.steps)
+        out["roofline_valu"] = valu_roofline(ctx, prof, perms, args.steps, pmc_json)
     except Exception as e:
         out["roofline_valu"] = {"error": repr(e)[:200]}
     out["kernels"] = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["count"] / args.steps,
