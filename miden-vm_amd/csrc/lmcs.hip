@@ -426,13 +426,36 @@ void lmcs_alloc_layers(mh_tree* t, int log_height) {
 }
 u64* lmcs_leaf_layer(mh_tree* t) { return t->nodes.u() + 4 * t->layer_off[t->log_height]; }
 
+// The top levels of a tree (5 by default) are finished on the host: the level of 2^5 nodes comes back in the copy that
+// fetched the root anyway, 31 compressions cost the host ~1.5 us each, and a level of < 32 nodes costs the
+// device a whole lone-wave permutation (17.6 us with a state spread over 16 lanes) whatever its size.  The nodes go back into
+// the layer buffer as kernel arguments (openings read sibling digests from it), asynchronously.
+static constexpr int LMCS_HOST_TOP_MAX = 6;
+static int lmcs_host_top_levels() {
+  static const int v = [] {
+    const char* e = getenv("MH_HOST_TOP");  // experiments: 0 (off) .. 6
+    const int x = e ? atoi(e) : 5;  // measured at 2^20: 0 / 3 / 4 / 5 / 6 levels -> 49.6 / 49.0 / 48.8 / 48.7 / 49.0 ms per proof
+    return x < 0 ? 0 : (x > LMCS_HOST_TOP_MAX ? LMCS_HOST_TOP_MAX : x);
+  }();
+  return v;
+}
+struct TopNodes {
+  u64 w[4 * ((1 << LMCS_HOST_TOP_MAX) - 1)];
+};
+__global__ void k_store_top(TopNodes top, u64* __restrict__ dst, int n_words) {
+  if ((int)threadIdx.x < n_words) dst[threadIdx.x] = top.w[threadIdx.x];
+}
+
 void lmcs_compress_layers(mh_ctx* c, mh_tree* t) {
   t->lmcs = c->lmcs;
   const int lb = t->log_blowup;
   const size_t H = (size_t)1 << t->log_height;
+  // levels [0, host_top) on the host: only natural-order levels (above the coset phase); Blake3 has its one-launch top
+  const int want = lmcs_host_top_levels();
+  const int host_top = (c->lmcs != MH_LMCS_BLAKE3 && t->log_height - lb >= want && t->log_height > want) ? want : 0;
   {
     ProfScope ps(c, "lmcs_compress", 96.0 * (double)H);
-    for (int d = t->log_height - 1; d >= 0; d--) {
+    for (int d = t->log_height - 1; d >= host_top; d--) {
       size_t n_out = (size_t)1 << d;
       int cbits_child = (d + 1) - (t->log_height - lb);  // coset bits of the child layer
       int log_n_coset = cbits_child > 0 ? (t->log_height - lb) : -1;
@@ -456,7 +479,23 @@ void lmcs_compress_layers(mh_ctx* c, mh_tree* t) {
                            t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
     }
   }
-  c->d2h(t->root, t->nodes.u() + 4 * t->layer_off[0], 32);
+  if (!host_top) {
+    c->d2h(t->root, t->nodes.u() + 4 * t->layer_off[0], 32);
+    return;
+  }
+  u64 level[4 << LMCS_HOST_TOP_MAX];
+  c->d2h(level, t->nodes.u() + 4 * t->layer_off[host_top], (size_t)32 << host_top);
+  // layers host_top - 1 .. 0 lie one after the other at the end of the node buffer (lmcs_alloc_layers): the same order in `top`
+  TopNodes top;
+  const u64* child = level;
+  size_t off = 0;
+  for (int d = host_top - 1; d >= 0; d--) {
+    for (size_t q = 0; q < ((size_t)1 << d); q++) lmcs_host_compress(c->lmcs, child + 8 * q, top.w + off + 4 * q);
+    child = top.w + off;
+    off += (size_t)4 << d;
+  }
+  memcpy(t->root, top.w + off - 4, 32);
+  MH_LAUNCH(k_store_top, dim3(1), dim3(256), 0, c->stream, top, t->nodes.u() + 4 * t->layer_off[host_top - 1], (int)off);
 }
 
 void lmcs_build_tree(mh_ctx* c, mh_tree* t) {
