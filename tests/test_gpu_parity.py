@@ -32,6 +32,9 @@ def test_poseidon2_kat_and_random(ctx):
     s[0] = 0
     s[1] = P - 1
     s[2, :] = np.uint64(0xFFFFFFFFFFFFFFFF)  # non-canonical input is canonicalised
+    # states drawn from the corners of the 32-bit halves (the device schedule adds 32-bit parts lazily: carries, borrows, folds)
+    corners = np.array([0, 1, P - 1, P - 2, 0xFFFFFFFF, 0x100000000, 0xFFFFFFFF00000000, 0xFFFFFFFE00000001, 0x7FFFFFFF80000000], dtype=np.uint64)
+    s[3:2003] = corners[rng.integers(0, len(corners), (2000, 12))]
     exp_in = s.copy()
     exp_in[2, :] = np.uint64(0xFFFFFFFFFFFFFFFF - P)
     assert (ctx.poseidon2_permute(s) == ob.permute(exp_in)).all()
