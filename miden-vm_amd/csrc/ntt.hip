@@ -46,7 +46,13 @@ static constexpr int NTT_TILE_LOG_BIG = 14;
 static constexpr int NTT_THREADS = 256;
 // (measured, LDE per proof: 2^22 three-AIR shape 69.4 -> 63.2 ms with the big tile; at 2^24 the 10-stage strided
 // pass it implies -- 128 B segments, 1024 rows -- loses to three small-tile passes, 289.7 vs 259.6 ms)
-static int ntt_tile_log(int log_n) { return log_n > 20 && log_n <= 22 ? NTT_TILE_LOG_BIG : NTT_TILE_LOG; }
+static int ntt_tile_log(int log_n) {
+  static const int big_max = [] {
+    const char* e = getenv("MH_NTT_BIG_MAX");  // experiments: the largest log_n that uses the 2^14 tile
+    return e ? atoi(e) : 22;
+  }();
+  return log_n > 20 && log_n <= big_max ? NTT_TILE_LOG_BIG : NTT_TILE_LOG;
+}
 
 // ---------------------------------------------------------------------------------------------
 // twiddle table: tw[k] = w^k, k < n_half, given w^(2^i) in pw[]
