@@ -390,7 +390,13 @@ __global__ __launch_bounds__(256) void k_compress(const u64* __restrict__ in, u6
 
 // Same compression with one state element per lane (16 lanes per node): the low-latency form for the
 // small layers near the root (poseidon2_lanes.cuh).
-static constexpr size_t COMPRESS_LANES_MAX_NODES = 8192;
+static size_t compress_lanes_max_nodes() {
+  static const size_t v = [] {
+    const char* e = getenv("MH_LANES_MAX_NODES");  // experiments
+    return e ? (size_t)atol(e) : (size_t)8192;
+  }();
+  return v;
+}
 __global__ __launch_bounds__(256) void k_compress_lanes(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out, int log_n_coset) {
   const size_t node = (blockIdx.x * (size_t)256 + threadIdx.x) >> 4;
   const int g = threadIdx.x & 15;
@@ -471,7 +477,7 @@ void lmcs_compress_layers(mh_ctx* c, mh_tree* t) {
       } else if (c->lmcs == MH_LMCS_BLAKE3)
         MH_LAUNCH(k_compress_b3, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream,
                            t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
-      else if (n_out <= COMPRESS_LANES_MAX_NODES)
+      else if (n_out <= compress_lanes_max_nodes())
         MH_LAUNCH(k_compress_lanes, dim3((unsigned)((n_out * 16 + 255) / 256)), dim3(256), 0, c->stream,
                            t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
       else
