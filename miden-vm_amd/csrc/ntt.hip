@@ -557,6 +557,16 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
     const u32 g0 = (u32)(gbase | ((size_t)(tid >> a.cb) << a.s_lo) | (tid & cb_mask));
     const int shg = LOG_T - a.cb + a.s_lo;
     const u32 p0 = ntt_pad<SWZ>(tid);
+    if (THREADS == NTT_THREADS && !a.scale_lo) {  // (the 1024-thread kernel has 128 VGPRs: it would spill)
+      // no scale (every pass but the first of a coset LDE): all sixteen loads in flight -- the strided passes are short of bytes in
+      // flight, not of issue slots (pass 1 of the 2^20 plan: 3.3 TB/s with four at a time)
+      u64 v[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) v[j] = (src + ((size_t)j << shg))[g0];
+#pragma unroll
+      for (int j = 0; j < 16; j++)
+        lds[SWZ ? (p0 ^ ntt_pad<true>((u32)j * THREADS)) : ntt_pad<false>(tid + (u32)j * THREADS)] = v[j];
+    } else
     // four elements at a time: all sixteen in flight (plus their scale-table loads) cost 200 VGPRs
 #pragma unroll 1
     for (int c = 0; c < 16; c += 4) {
