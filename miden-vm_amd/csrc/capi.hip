@@ -76,6 +76,7 @@ void mh_ctx_destroy(mh_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+  if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
@@ -88,6 +89,7 @@ void mh_ctx_destroy(mh_ctx* c) {
   for (auto& hp : c->host_pool) (void)hipHostFree(hp.first);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
   delete c;
 }
 

@@ -7,9 +7,12 @@
 void launch_transpose_rm_to_cm(mh_ctx* c, const u64* in_rowmajor, u64* out_colmajor, size_t n, size_t w, hipStream_t stream = nullptr);  // null: the compute stream
 void ntt_inverse_dif_inplace(mh_ctx* c, u64* cols, size_t n_cols, int log_n);
 void ntt_inverse_dif(mh_ctx* c, const u64* src, u64* dst, size_t n_cols, int log_n);  // src == dst: in place
-void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n, const std::vector<u64>& bases, u64* out);
+void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n, const std::vector<u64>& bases, u64* out, size_t out_col_stride = 0);
 void lde_columns(mh_ctx* c, const u64* cols_in, size_t n_cols, int log_n, u64 in_shift, const std::vector<u64>& out_shifts,
                  u64* out, u64* scratch);
+void lde_coefficients(mh_ctx* c, const u64* cols_in, size_t n_cols, int log_n, u64* coef_br);
+void lde_forward_group(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n, u64 in_shift, const std::vector<u64>& group_shifts,
+                       u64* out, size_t out_col_stride);
 
 // ---- device-resident objects -------------------------------------------------------------------
 // A trace matrix as uploaded: column-major, natural row order, canonical felts.
@@ -91,6 +94,9 @@ double poseidon2_register_rate(mh_ctx* c);  // permutations/s with the state hel
 void lmcs_build_tree(mh_ctx* c, mh_tree* t);
 // Pieces of the above for trees whose leaf digests come from another kernel (FRI rounds):
 void lmcs_hash_leaves(mh_ctx* c, const std::vector<LdeMatrix>& mats, int lb, u64* digests);
+// the leaves [q_begin, q_begin + q_count) only (a group of cosets of a tree whose matrices all have one height)
+void lmcs_hash_leaves_range(mh_ctx* c, const std::vector<LdeMatrix>& mats, int lb, u64* digests, size_t q_begin, size_t q_count);
+bool lmcs_leaves_rangeable(mh_ctx* c, const std::vector<LdeMatrix>& mats);
 void lmcs_alloc_layers(mh_tree* t, int log_height);  // sets log_height, layer_off, nodes
 u64* lmcs_leaf_layer(mh_tree* t);                     // device pointer of the leaf digest layer
 void lmcs_compress_layers(mh_ctx* c, mh_tree* t);     // leaf layer -> root (copies root to host)

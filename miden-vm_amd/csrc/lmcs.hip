@@ -93,12 +93,13 @@ struct LeafArgs {
   int log_n_prev;
   u64* state_out;        // [12][B * 2^log_n] or null
   u64* digest_out;       // [B * 2^log_n][4] or null
+  size_t q_begin, q_count;  // the leaves this launch hashes; q_count = 0: all of them
 };
 
 __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_absorb(LeafArgs a) {
   const size_t leaves = (size_t)1 << (a.log_n + a.log_blowup);
-  const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (q >= leaves) return;
+  const size_t q = a.q_begin + blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (q >= (a.q_count ? a.q_begin + a.q_count : leaves)) return;
   const size_t j = q >> a.log_n, r = q & (((size_t)1 << a.log_n) - 1);
   u64 s[12];
   if (a.state_in) {
@@ -138,8 +139,8 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_absorb(LeafArgs a) {
 // are all [leaves][4] u64 (a digest = its 32 bytes little-endian).
 __global__ __launch_bounds__(LEAF_THREADS) void k_leaf_absorb_b3(LeafArgs a) {
   const size_t leaves = (size_t)1 << (a.log_n + a.log_blowup);
-  const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (q >= leaves) return;
+  const size_t q = a.q_begin + blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (q >= (a.q_count ? a.q_begin + a.q_count : leaves)) return;
   const size_t j = q >> a.log_n, r = q & (((size_t)1 << a.log_n) - 1);
   uint32_t st[8];
   if (a.state_in) {
@@ -509,6 +510,39 @@ void lmcs_build_tree(mh_ctx* c, mh_tree* t) {
   lmcs_alloc_layers(t, t->mats.back().log_n + t->log_blowup);
   lmcs_hash_leaves(c, t->mats, t->log_blowup, lmcs_leaf_layer(t));
   lmcs_compress_layers(c, t);
+}
+
+// One launch over the leaves [q_begin, q_begin + q_count): every matrix has the same height (no state chained between launches) and
+// the hasher's leaf kernel takes a range (Poseidon2, Blake3).
+bool lmcs_leaves_rangeable(mh_ctx* c, const std::vector<LdeMatrix>& mats) {
+  if (mats.empty() || mats.size() > (size_t)LEAF_MAX_MATS) return false;
+  if (c->lmcs != MH_LMCS_POSEIDON2 && c->lmcs != MH_LMCS_BLAKE3) return false;
+  for (const LdeMatrix& m : mats)
+    if (m.log_n != mats[0].log_n || m.log_cosets != mats[0].log_cosets) return false;
+  return true;
+}
+void lmcs_hash_leaves_range(mh_ctx* c, const std::vector<LdeMatrix>& mats, int lb, u64* digests, size_t q_begin, size_t q_count) {
+  MH_REQUIRE(lmcs_leaves_rangeable(c, mats), "internal: leaves cannot be hashed by ranges");
+  LeafArgs a{};
+  double bytes = 32.0 * (double)q_count;
+  for (const LdeMatrix& m : mats) {
+    MH_REQUIRE(c->lmcs != MH_LMCS_BLAKE3 || m.width <= (((size_t)1024 << b3::MAX_STACK) - 32) / 8,
+               "matrix too wide for the Blake3 LMCS (a row must fit 256 KiB)");
+    a.m[a.n_mats].data = m.lde.u();
+    a.m[a.n_mats].width = (u32)m.width;
+    bytes += (double)m.width * 8.0 * (double)q_count;
+    a.n_mats++;
+  }
+  a.log_blowup = lb;
+  a.log_n = mats[0].log_n;
+  a.digest_out = digests;
+  a.q_begin = q_begin;
+  a.q_count = q_count;
+  MH_REQUIRE(q_count > 0 && q_begin + q_count <= ((size_t)1 << (a.log_n + lb)), "internal: leaf range out of bounds");
+  ProfScope ps(c, "lmcs_leaf_absorb", bytes);
+  const dim3 grid((unsigned)((q_count + LEAF_THREADS - 1) / LEAF_THREADS));
+  if (c->lmcs == MH_LMCS_BLAKE3) MH_LAUNCH(k_leaf_absorb_b3, grid, dim3(LEAF_THREADS), 0, c->stream, a);
+  else MH_LAUNCH(k_leaf_absorb, grid, dim3(LEAF_THREADS), 0, c->stream, a);
 }
 
 // Leaf digests of a group of LDE matrices holding 2^lb cosets each (all cosets, or one rank's share

@@ -132,6 +132,7 @@ struct NttPassArgs {
   int lb;
   size_t scale_lo_z, scale_hi_z;
   u32 n_z;                                              // output cosets produced per workgroup (first pass of a coset LDE), else 1
+  size_t src_z_stride;                                  // 0: every coset reads the same source (first pass); else the source of coset z is src + z * src_z_stride
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -540,13 +541,14 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
   const size_t lo0 = tile & ((1u << lo_bits) - 1);
   const size_t hi = tile >> lo_bits;
   const size_t gbase = (hi << (a.s_lo + a.r_bits)) | (lo0 << a.cb);
-  const u64* src = a.src + (size_t)blockIdx.y * a.src_col_stride;
+  const u64* src0 = a.src + (size_t)blockIdx.y * a.src_col_stride;
   // The first pass of a coset LDE reads one coefficient tile and produces it on every output coset: the workgroup
   // loops over the cosets itself (n_z > 1), so the tile comes from HBM once and from this XCD's L2 afterwards --
   // with the cosets spread over grid.z the same tile was fetched by up to n_z workgroups on different XCDs.
   for (u32 z = 0; z < a.n_z; z++) {
   const u32 zc = blockIdx.z * a.n_z + z;
   u64* dst = a.dst + (size_t)blockIdx.y * a.dst_col_stride + (size_t)zc * a.dst_z_stride;
+  const u64* src = src0 + (size_t)zc * a.src_z_stride;
   if (z) __syncthreads();  // the previous coset's last round still reads the tile
 
   constexpr int LOG_T = THREADS == 256 ? 8 : 10;
@@ -729,13 +731,13 @@ static NttPlanes ntt_planes(mh_ctx* c, int log_n, bool inverse, const std::vecto
   return NttPlanes{it->second.u(), c->table_index[key]};
 }
 
-static void launch_pass(mh_ctx* c, NttPassArgs a, size_t n_cols, size_t n_z) {
+static void launch_pass(mh_ctx* c, NttPassArgs a, size_t n_cols, size_t n_z, bool one_coset_per_workgroup = false) {
   size_t tiles = (size_t)1 << (a.log_n - a.r_bits - a.cb);
   // the workgroup loops over the output cosets; they are spread over grid.z only as far as it takes to fill the chip
   // (a quotient chunk is 2 columns: 512 workgroups at 2^20 otherwise)
   MH_REQUIRE(n_z >= 1 && (n_z & (n_z - 1)) == 0, "internal: the number of output cosets of a pass must be a power of two");
   size_t zsplit = 1;
-  while (zsplit < n_z && tiles * n_cols * zsplit < 4096) zsplit *= 2;
+  while (zsplit < n_z && (one_coset_per_workgroup || tiles * n_cols * zsplit < 4096)) zsplit *= 2;
   a.n_z = (u32)(n_z / zsplit);
   dim3 grid((unsigned)tiles, (unsigned)n_cols, (unsigned)zsplit);
   const int T = ntt_tile_log(a.log_n);
@@ -823,10 +825,13 @@ static CosetTables coset_tables(mh_ctx* c, int log_n, const std::vector<u64>& ba
 // Forward coset evaluation: `coef_br` holds, per column, N*coefficients in bit-reversed order
 // (output of ntt_inverse_dif_inplace).  For every output coset z, out[(col*n_z + z)*N + r] =
 // sum_k c_k * bases[z]^k * w_N^(r k)   (1/N folded into the table).
+// out_col_stride != 0: the cosets are a GROUP of a wider coset-major matrix -- `out` points at the group's first coset of column 0,
+// consecutive columns lie out_col_stride apart (e.g. 8 N for blowup 8 while bases.size() = 2).
 void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n, const std::vector<u64>& bases,
-                        u64* out) {
+                        u64* out, size_t out_col_stride) {
   size_t N = (size_t)1 << log_n;
   size_t nz = bases.size();
+  const bool grouped = out_col_stride != 0 && out_col_stride != nz * N;
   u64 n_inv = gl_inv((u64)N % GL_P);
   const CosetTables t = coset_tables(c, log_n, bases, n_inv);
   auto plan = plan_passes(log_n);
@@ -834,7 +839,7 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
   for (size_t i = 0; i < plan.size(); i++) {
     NttPassArgs a{};
     a.dst = out;
-    a.dst_col_stride = nz * N;
+    a.dst_col_stride = grouped ? out_col_stride : nz * N;
     a.dst_z_stride = N;
     if (i == 0) {
       a.src = coef_br;
@@ -854,6 +859,10 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
     a.canon_out = i + 1 == plan.size();
     if (i == 0) {
       launch_pass(c, a, n_cols, nz);
+    } else if (grouped) {  // in place, one workgroup per (tile, column, coset): the columns of the group are not contiguous
+      a.src_col_stride = out_col_stride;
+      a.src_z_stride = N;
+      launch_pass(c, a, n_cols, nz, true);
     } else {
       a.dst_col_stride = N;
       a.dst_z_stride = 0;
@@ -873,4 +882,18 @@ void lde_columns(mh_ctx* c, const u64* cols_in, size_t n_cols, int log_n, u64 in
   std::vector<u64> bases;
   for (u64 b : out_shifts) bases.push_back(gl_mul(b, a_inv));
   ntt_forward_cosets(c, scratch, n_cols, log_n, bases, out);
+}
+
+// The two halves of lde_columns, for a caller that pipelines the forward transforms by groups of output cosets (commit_traces):
+// coefficients once, then each group into its place of the full coset-major matrix (`out` = first coset of the group, column 0).
+void lde_coefficients(mh_ctx* c, const u64* cols_in, size_t n_cols, int log_n, u64* coef_br) {
+  ProfScope ps(c, "lde_intt", 16.0 * (double)n_cols * (double)((size_t)1 << log_n));
+  ntt_inverse_dif(c, cols_in, coef_br, n_cols, log_n);
+}
+void lde_forward_group(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n, u64 in_shift, const std::vector<u64>& group_shifts,
+                       u64* out, size_t out_col_stride) {
+  const u64 a_inv = gl_inv(in_shift);
+  std::vector<u64> bases;
+  for (u64 b : group_shifts) bases.push_back(gl_mul(b, a_inv));
+  ntt_forward_cosets(c, coef_br, n_cols, log_n, bases, out, out_col_stride);
 }

@@ -139,9 +139,113 @@ LdeMatrix lde_trace_cosets(mh_ctx* c, const mh_trace* tr, int lb, size_t first, 
 }
 static LdeMatrix lde_trace(mh_ctx* c, const mh_trace* tr, int lb) { return lde_trace_cosets(c, tr, lb, 0, (size_t)1 << lb); }
 
+// ---- commit_traces with the forward transforms pipelined under the leaf hashing, by groups of cosets -------------------------
+// A leaf is one row of ONE coset, so the leaves of cosets [0, k) can be hashed as soon as those cosets exist: the forward NTTs of the
+// next group run on a second stream meanwhile.  The strided NTT pass is short of HBM bandwidth and issues only 60-75 % of its wall
+// time; the Poseidon2 sponge is pure VALU issue (and the Blake3 one pure HBM streaming next to a VALU-bound NTT): their waves share
+// the SIMDs (4 sponge waves + 1 NTT wave fit a SIMD's registers) and fill each other's stalls.  Only when every matrix of the tree
+// has one height (no sponge state carried between launches).  An option (MH_PIPELINE, below), not the default.
+struct StreamSwap {
+  mh_ctx* c;
+  hipStream_t prev;
+  StreamSwap(mh_ctx* ctx, hipStream_t s) : c(ctx), prev(ctx->stream) { c->stream = s; }
+  ~StreamSwap() { c->stream = prev; }
+};
+// MH_PIPELINE: unset / 0 = off (the default); 1 = geometric groups of cosets 1, 1, 2, 4, ... ; n >= 2 = n equal groups.
+// Measured at 2^20 rows (same box, ms per proof, off / 4 groups): Poseidon2 48.31 / 47.80, 49.25 / 48.33 on another box (2 groups 48.70,
+// 8 groups 49.07, geometric 48.01 vs 48.27); three proofs in flight 44.3 / 42.3; Blake3 15.64 / 15.79; three matrices uploaded inside
+// the proof 80.3 / 85.3 (the coefficient pass waits for every upload).  A gain of 1-2 % for one proof of one matrix, at the price of
+// per-kernel times that no longer add up (both kernels are stretched while they share the SIMDs): off unless asked for.
+static int pipeline_mode() {
+  static const int v = [] {
+    const char* e = getenv("MH_PIPELINE");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+static std::vector<std::pair<size_t, size_t>> pipeline_groups(int lb) {  // (first coset, count), counts powers of two
+  std::vector<std::pair<size_t, size_t>> g;
+  const size_t B = (size_t)1 << lb;
+  const int mode = pipeline_mode();
+  if (mode <= 0 || B < 2) return g;
+  if (mode == 1) {
+    g.emplace_back(0, 1);
+    for (size_t z = 1; z < B; z *= 2) g.emplace_back(z, z);
+    return g;
+  }
+  size_t n = (size_t)mode;
+  while (n > B) n >>= 1;
+  if (n < 2 || (n & (n - 1))) return {};
+  for (size_t i = 0; i < n; i++) g.emplace_back(i * (B / n), B / n);
+  return g;
+}
+static bool commit_traces_pipelined(mh_ctx* c, mh_tree* t, const std::vector<const mh_trace*>& traces, int lb) {
+  if (traces.empty()) return false;
+  const std::vector<std::pair<size_t, size_t>> groups = pipeline_groups(lb);
+  if (groups.empty()) return false;
+  const int log_n = traces[0]->log_n;
+  if (log_n < 17) return false;  // small proofs live on launch latencies: nothing to hide, more launches to pay
+  for (const mh_trace* tr : traces)
+    if (tr->log_n != log_n || tr->width == 0) return false;
+  if (c->lmcs != MH_LMCS_POSEIDON2 && c->lmcs != MH_LMCS_BLAKE3) return false;
+  if (traces.size() > 8) return false;
+  MH_REQUIRE(log_n + lb <= 32, "LDE order exceeds the field's two-adicity");
+  const size_t N = (size_t)1 << log_n, B = (size_t)1 << lb;
+  for (const mh_trace* tr : traces) {
+    LdeMatrix m;
+    m.log_n = log_n; m.width = tr->width; m.log_cosets = lb; m.coset0 = 0;
+    m.lde.alloc(N * B * tr->width * 8);
+    t->mats.push_back(std::move(m));
+  }
+  if (!lmcs_leaves_rangeable(c, t->mats)) {
+    t->mats.clear();
+    return false;
+  }
+  if (!c->side_stream) HIP_CHECK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+  const std::vector<u64> shifts = coset_shifts(log_n, lb);
+  std::vector<DevBuf> coef(traces.size());
+  std::vector<hipEvent_t> done;
+  hipEvent_t fence = c->get_event();
+  HIP_CHECK(hipEventRecord(fence, c->stream));  // the side stream starts after everything already queued (and so after the pool's last users)
+  try {
+    {
+      StreamSwap sw(c, c->side_stream);
+      HIP_CHECK(hipStreamWaitEvent(c->stream, fence, 0));
+      for (size_t i = 0; i < traces.size(); i++) {
+        trace_wait_ready(c, traces[i]);
+        coef[i].alloc(N * traces[i]->width * 8);
+        ProfScope ps(c, "lde", (double)N * traces[i]->width * 8.0);
+        lde_coefficients(c, traces[i]->cols.u(), traces[i]->width, log_n, coef[i].u());
+      }
+      for (const auto& g : groups) {
+        const std::vector<u64> mine(shifts.begin() + g.first, shifts.begin() + g.first + g.second);
+        for (size_t i = 0; i < traces.size(); i++) {
+          ProfScope ps(c, "lde", (double)g.second * N * traces[i]->width * 8.0);
+          lde_forward_group(c, coef[i].u(), traces[i]->width, log_n, 1, mine, t->mats[i].lde.u() + g.first * N, B * N);
+        }
+        done.push_back(c->get_event());
+        HIP_CHECK(hipEventRecord(done.back(), c->stream));
+      }
+    }
+    lmcs_alloc_layers(t, log_n + lb);
+    for (size_t k = 0; k < groups.size(); k++) {
+      HIP_CHECK(hipStreamWaitEvent(c->stream, done[k], 0));
+      lmcs_hash_leaves_range(c, t->mats, lb, lmcs_leaf_layer(t), groups[k].first * N, groups[k].second * N);
+    }
+    lmcs_compress_layers(c, t);  // ends with a blocking copy of the root: both streams are idle when the coefficient buffers go back to the pool
+  } catch (...) {
+    (void)hipStreamSynchronize(c->side_stream);  // the side stream may still read the coefficient buffers this frame is about to free
+    throw;
+  }
+  c->event_pool.push_back(fence);
+  for (hipEvent_t e : done) c->event_pool.push_back(e);
+  return true;
+}
+
 mh_tree* commit_traces(mh_ctx* c, const std::vector<const mh_trace*>& traces, int log_blowup) {
   std::unique_ptr<mh_tree> t(new mh_tree());
   t->ctx = c; t->log_blowup = log_blowup;
+  if (commit_traces_pipelined(c, t.get(), traces, log_blowup)) return t.release();
   for (const mh_trace* tr : traces) t->mats.push_back(lde_trace(c, tr, log_blowup));
   lmcs_build_tree(c, t.get());
   return t.release();

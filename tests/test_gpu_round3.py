@@ -227,3 +227,44 @@ def test_perm_link_bus_closes_on_the_device(ctx):
     gb = prove([tr_p2, bad])
     assert pkg.verify(airs_, [10, 7], [], FAST, st, pre, gb.fields, gb.commitments)[0]
     assert not pkg.verify(airs_, [10, 7], [], FAST, st, pre, gb.fields, gb.commitments, external="logup_balance")[0]
+
+
+# ---- the coset-group pipeline of commit_traces (MH_PIPELINE, an option): same proof as the default path ------------------------
+_PIPE_CHILD = r"""
+import sys, hashlib
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import numpy as np
+from __graft_entry__ import load_package
+pkg = load_package()
+from miden_vm_amd import dag, protocol
+ctx = pkg.Ctx(0)
+ctx.set_lmcs({lmcs!r})
+rng = np.random.default_rng(77)
+P = 0xFFFFFFFF00000001
+traces = [rng.integers(0, P, (1 << 17, w), dtype=np.uint64) for w in (19, 11)]
+for t in traces:
+    t[:, 0] = 0
+airs = [dag.dummy_miden_air(19, 2), dag.dummy_miden_air(11, 1)]
+dairs = [pkg.DeviceAir(ctx, a) for a in airs]
+dtr = [ctx.upload_trace(t) for t in traces]
+params = dict(protocol.PROD_PARAMS)
+proof = pkg.prove(ctx, dairs, dtr, [], params, protocol.challenger_state(), protocol.protocol_pre_observe(params, []), None)
+print("DIGEST", hashlib.sha256(proof.fields.tobytes() + proof.commitments.tobytes()).hexdigest())
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lmcs", ["poseidon2", "blake3"])
+@pytest.mark.parametrize("mode", ["4", "1"])
+def test_pipelined_commit_gives_the_same_proof(lmcs, mode):
+    """Two matrices of one height, 2^17 rows (the smallest size the pipeline takes), Poseidon2 and Blake3: the proof with the
+    forward NTTs pipelined under the leaf hashing (four equal / geometric coset groups) equals the default path's, byte for byte."""
+    import os, subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _PIPE_CHILD.format(root=ROOT, tests=os.path.join(ROOT, "tests"), lmcs=lmcs)
+    outs = []
+    for env_mode in ("0", mode):
+        env = dict(os.environ, MH_PIPELINE=env_mode)
+        out = subprocess.check_output([sys.executable, "-c", code], env=env, text=True, timeout=600)
+        outs.append([l for l in out.splitlines() if l.startswith("DIGEST")][0])
+    assert outs[0] == outs[1]
