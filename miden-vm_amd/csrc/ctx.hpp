@@ -160,6 +160,7 @@ struct mh_ctx {
   // buffer: a straight DMA instead of the runtime's staged copy into pageable memory (~40 us less per call).
   void d2h(void* dst_host, const void* src_dev, size_t bytes);
   void* pinned = nullptr;
+  void* pinned_top = nullptr;  // lmcs_compress_layers: the tree top computed on the host, on its way back to the device
   static constexpr size_t PINNED_BYTES = 1 << 20;
   // page-locked scratch for host-built aux traces (the aux_builder callback writes into it, the DMA reads it): kept between proofs
   std::vector<std::pair<void*, size_t>> host_pool;

@@ -107,6 +107,11 @@ void lmcs_open(mh_ctx* c, const mh_tree* t, const std::vector<size_t>& sorted_un
 // row range -> all-gather of subroots -> cap on the host.  t->log_blowup = global coset bits.
 void lmcs_build_sharded(mh_ctx* c, mh_tree* t, const Dist& dist, const u64* local_digests, int log_rows);
 void lmcs_host_compress(int lmcs, const u64* pair, u64* out);
+// one tree level on the host: out[q] = compress(children[2q], children[2q + 1]), q < n_out (natural order); eight nodes per call of
+// the AVX-512 Poseidon2 (p2_host_simd.cpp) where the CPU has it, the scalar code otherwise
+void lmcs_host_compress_level(int lmcs, const u64* children, size_t n_out, u64* out);
+bool p2_host_simd_available();
+void p2_host_compress8(const u64* pairs, int n, u64* out);
 std::vector<std::pair<int, size_t>> lmcs_missing_siblings(const std::vector<size_t>& sorted_unique_idx, int depth);
 
 // ---- prover.hip (commit helpers shared with the C ABI) -------------------------------------------

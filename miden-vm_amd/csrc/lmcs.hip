@@ -433,24 +433,20 @@ void lmcs_alloc_layers(mh_tree* t, int log_height) {
 }
 u64* lmcs_leaf_layer(mh_tree* t) { return t->nodes.u() + 4 * t->layer_off[t->log_height]; }
 
-// The top levels of a tree (5 by default) are finished on the host: the level of 2^5 nodes comes back in the copy that
-// fetched the root anyway, 31 compressions cost the host ~1.5 us each, and a level of < 32 nodes costs the
-// device a whole lone-wave permutation (17.6 us with a state spread over 16 lanes) whatever its size.  The nodes go back into
-// the layer buffer as kernel arguments (openings read sibling digests from it), asynchronously.
-static constexpr int LMCS_HOST_TOP_MAX = 6;
-static int lmcs_host_top_levels() {
-  static const int v = [] {
-    const char* e = getenv("MH_HOST_TOP");  // experiments: 0 (off) .. 6
-    const int x = e ? atoi(e) : 5;  // measured at 2^20: 0 / 3 / 4 / 5 / 6 levels -> 49.6 / 49.0 / 48.8 / 48.7 / 49.0 ms per proof
-    return x < 0 ? 0 : (x > LMCS_HOST_TOP_MAX ? LMCS_HOST_TOP_MAX : x);
+// The top levels of a tree are finished on the host: the level of 2^k nodes comes back in the copy that fetched the root anyway, the
+// host compresses it with eight nodes per AVX-512 permutation (p2_host_simd.cpp; ~2 us per eight nodes, scalar ~2 us per node), and a
+// level of a few hundred nodes costs the device a lone-wave permutation (17.6 us with a state spread over 16 lanes) whatever its
+// size.  The nodes go back into the layer buffer (openings read sibling digests from it) with an asynchronous copy from a page-locked
+// buffer of the context.
+static constexpr int LMCS_HOST_TOP_MAX = 10;
+static int lmcs_host_top_levels(int lmcs) {
+  static const int forced = [] {
+    const char* e = getenv("MH_HOST_TOP");  // experiments: 0 (off) .. 10, every hasher
+    const int x = e ? atoi(e) : -1;
+    return x > LMCS_HOST_TOP_MAX ? LMCS_HOST_TOP_MAX : x;
   }();
-  return v;
-}
-struct TopNodes {
-  u64 w[4 * ((1 << LMCS_HOST_TOP_MAX) - 1)];
-};
-__global__ void k_store_top(TopNodes top, u64* __restrict__ dst, int n_words) {
-  if ((int)threadIdx.x < n_words) dst[threadIdx.x] = top.w[threadIdx.x];
+  if (forced >= 0) return forced;
+  return lmcs == MH_LMCS_POSEIDON2 && p2_host_simd_available() ? 6 : 5;  // scalar host compressions: five levels (31 nodes)
 }
 
 void lmcs_compress_layers(mh_ctx* c, mh_tree* t) {
@@ -458,7 +454,7 @@ void lmcs_compress_layers(mh_ctx* c, mh_tree* t) {
   const int lb = t->log_blowup;
   const size_t H = (size_t)1 << t->log_height;
   // levels [0, host_top) on the host: only natural-order levels (above the coset phase); Blake3 has its one-launch top
-  const int want = lmcs_host_top_levels();
+  const int want = lmcs_host_top_levels(c->lmcs);
   const int host_top = (c->lmcs != MH_LMCS_BLAKE3 && t->log_height - lb >= want && t->log_height > want) ? want : 0;
   {
     ProfScope ps(c, "lmcs_compress", 96.0 * (double)H);
@@ -490,19 +486,23 @@ void lmcs_compress_layers(mh_ctx* c, mh_tree* t) {
     c->d2h(t->root, t->nodes.u() + 4 * t->layer_off[0], 32);
     return;
   }
-  u64 level[4 << LMCS_HOST_TOP_MAX];
-  c->d2h(level, t->nodes.u() + 4 * t->layer_off[host_top], (size_t)32 << host_top);
+  // page-locked: [level read back: 2^host_top nodes][the host_top layers above it: 2^host_top - 1 nodes]
+  const size_t n_level = (size_t)1 << host_top;
+  if (!c->pinned_top) HIP_CHECK(hipHostMalloc(&c->pinned_top, ((size_t)64 << LMCS_HOST_TOP_MAX), hipHostMallocDefault));
+  u64* level = static_cast<u64*>(c->pinned_top);
+  u64* top = level + 4 * n_level;
+  c->d2h(level, t->nodes.u() + 4 * t->layer_off[host_top], 32 * n_level);
   // layers host_top - 1 .. 0 lie one after the other at the end of the node buffer (lmcs_alloc_layers): the same order in `top`
-  TopNodes top;
   const u64* child = level;
   size_t off = 0;
   for (int d = host_top - 1; d >= 0; d--) {
-    for (size_t q = 0; q < ((size_t)1 << d); q++) lmcs_host_compress(c->lmcs, child + 8 * q, top.w + off + 4 * q);
-    child = top.w + off;
+    lmcs_host_compress_level(c->lmcs, child, (size_t)1 << d, top + off);
+    child = top + off;
     off += (size_t)4 << d;
   }
-  memcpy(t->root, top.w + off - 4, 32);
-  MH_LAUNCH(k_store_top, dim3(1), dim3(256), 0, c->stream, top, t->nodes.u() + 4 * t->layer_off[host_top - 1], (int)off);
+  memcpy(t->root, top + off - 4, 32);
+  // the buffer is written again only after the next tree's blocking read-back on this stream: this copy has completed by then
+  HIP_CHECK(hipMemcpyAsync(t->nodes.u() + 4 * t->layer_off[host_top - 1], top, off * 8, hipMemcpyHostToDevice, c->stream));
 }
 
 void lmcs_build_tree(mh_ctx* c, mh_tree* t) {
@@ -729,6 +729,20 @@ void lmcs_host_compress(int lmcs, const u64* pair, u64* out) {
     alg_permute(lmcs, st);
   }
   memcpy(out, st, 32);
+}
+
+void lmcs_host_compress_level(int lmcs, const u64* children, size_t n_out, u64* out) {
+  size_t q = 0;
+  if (lmcs == MH_LMCS_POSEIDON2 && p2_host_simd_available()) {
+    for (; q < n_out; q += 8) {
+      const int n = (int)std::min<size_t>(8, n_out - q);
+      u64 pairs[64];
+      for (int j = 0; j < 8 * n; j++) pairs[j] = gl_canon(children[8 * q + j]);
+      p2_host_compress8(pairs, n, out + 4 * q);
+    }
+    return;
+  }
+  for (; q < n_out; q++) lmcs_host_compress(lmcs, children + 8 * q, out + 4 * q);
 }
 
 void lmcs_build_sharded(mh_ctx* c, mh_tree* t, const Dist& dist, const u64* local_digests, int log_rows) {

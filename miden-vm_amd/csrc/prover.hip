@@ -1028,7 +1028,7 @@ int mh_merkle_cap_root_lmcs(int lmcs, const uint64_t* subroots, int world, uint6
     for (auto& x : cur) x = gl_canon(x);
   for (int n = world; n > 1; n >>= 1) {
     std::vector<u64> next(4 * (size_t)(n / 2));
-    for (int i = 0; i < n / 2; i++) lmcs_host_compress(lmcs, cur.data() + 8 * i, next.data() + 4 * i);
+    lmcs_host_compress_level(lmcs, cur.data(), (size_t)(n / 2), next.data());
     cur.swap(next);
   }
   memcpy(root, cur.data(), 32);
