@@ -103,6 +103,14 @@ void lmcs_compress_layers(mh_ctx* c, mh_tree* t);     // leaf layer -> root (cop
 // Gather opened rows (aligned, per sorted unique index) and missing siblings.
 void lmcs_open(mh_ctx* c, const mh_tree* t, const std::vector<size_t>& sorted_unique_idx, size_t alignment,
                std::vector<u64>& fields, std::vector<u64>& commitments, const Dist* dist = nullptr);
+// the same in three steps, so that the openings of several trees share one gather, one read-back and (sharded) one all-reduce
+struct OpenPlan {
+  size_t first = 0, n_fields = 0, n = 0;                     // this tree's slice of the gather list: rows, then sibling digests
+  std::vector<std::pair<size_t, const u64*>> cap_fill;       // (offset in the slice, host digest of the sharded tree's cap)
+};
+OpenPlan lmcs_open_plan(const mh_tree* t, const std::vector<size_t>& idx, size_t alignment, const Dist* dist, std::vector<const u64*>& ptrs);
+void lmcs_open_run(mh_ctx* c, const std::vector<const u64*>& ptrs, const Dist* dist, std::vector<u64>& host);
+void lmcs_open_take(const OpenPlan& plan, std::vector<u64>& host, std::vector<u64>& fields, std::vector<u64>& commitments);
 // Sharded tree build: local leaf digests [2^lbl][2^log_rows] -> all-to-all -> subtree over this rank's
 // row range -> all-gather of subroots -> cap on the host.  t->log_blowup = global coset bits.
 void lmcs_build_sharded(mh_ctx* c, mh_tree* t, const Dist& dist, const u64* local_digests, int log_rows);

@@ -633,17 +633,20 @@ __global__ void k_gather(const u64* const* __restrict__ ptrs, u64* __restrict__ 
   if (k < n) out[k] = ptrs[k] ? *ptrs[k] : 0;
 }
 
-void lmcs_open(mh_ctx* c, const mh_tree* t, const std::vector<size_t>& idx, size_t alignment, std::vector<u64>& fields,
-               std::vector<u64>& commitments, const Dist* dist) {
+// The gather list of one tree's opening, appended to `ptrs` (one device pointer per opened word, null = not stored on this rank /
+// filled from the host-side cap): first the rows, then the missing sibling digests bottom-up (tree_indices.rs:185-240).
+OpenPlan lmcs_open_plan(const mh_tree* t, const std::vector<size_t>& idx, size_t alignment, const Dist* dist,
+                        std::vector<const u64*>& ptrs) {
   // Sharded proofs: every opened value lives on exactly one rank (rows: the rank that stores the coset;
   // tree nodes: the rank whose row range covers them; the cap: known to all).  Each rank gathers what
   // it owns, leaves zeros elsewhere, and one all-reduce (sum) assembles the identical answer everywhere.
+  OpenPlan plan;
+  plan.first = ptrs.size();
   const bool distributed = dist && dist->on();
   const bool i_contribute = !distributed || t->shard_logG > 0 || dist->rank == 0;  // unsharded tree in a sharded proof: rank 0
   const int lb = t->log_blowup, G = t->shard_logG;
   const int full_height = t->log_height + G;
   const size_t Bm = ((size_t)1 << lb) - 1;
-  std::vector<const u64*> ptrs;
   for (size_t i : idx) {
     MH_REQUIRE(i < ((size_t)1 << full_height), "opening index out of range");
     size_t j = i & Bm, r = i >> lb;
@@ -669,14 +672,13 @@ void lmcs_open(mh_ctx* c, const mh_tree* t, const std::vector<size_t>& idx, size
       for (size_t k = m.width; k < padded; k++) ptrs.push_back(nullptr);
     }
   }
-  const size_t n_fields = ptrs.size();
+  plan.n_fields = ptrs.size() - plan.first;
   auto sib = lmcs_missing_siblings(idx, full_height);
-  std::vector<std::pair<size_t, const u64*>> cap_fill;  // (output position, host digest)
   for (auto& s : sib) {
     const int d = s.first;
     const size_t p = s.second;
     if (G > 0 && d <= G) {
-      cap_fill.emplace_back(ptrs.size(), t->cap.data() + 4 * ((((size_t)1) << d) - 1 + p));
+      plan.cap_fill.emplace_back(ptrs.size() - plan.first, t->cap.data() + 4 * ((((size_t)1) << d) - 1 + p));
       for (int k = 0; k < 4; k++) ptrs.push_back(nullptr);
       continue;
     }
@@ -685,20 +687,47 @@ void lmcs_open(mh_ctx* c, const mh_tree* t, const std::vector<size_t>& idx, size
     const u64* q = t->nodes.u() + 4 * (t->layer_off[d - G] + t->node_slot(d - G, pl));
     for (int k = 0; k < 4; k++) ptrs.push_back(mine ? q + k : nullptr);
   }
+  plan.n = ptrs.size() - plan.first;
+  return plan;
+}
+
+// ONE gather (and, in a sharded proof, one all-reduce) for the gather lists of any number of trees: host[i] = *ptrs[i] (0 for null).
+// The query phase opens ten trees: per tree this was a pageable upload of the list, a kernel and a blocking read-back.
+void lmcs_open_run(mh_ctx* c, const std::vector<const u64*>& ptrs, const Dist* dist, std::vector<u64>& host) {
   const size_t n = ptrs.size();
-  fields.clear();
-  commitments.clear();
+  host.assign(n, 0);
   if (!n) return;
   DevBuf dptrs(n * 8), dout(n * 8);
-  HIP_CHECK(hipMemcpyAsync(dptrs.p, ptrs.data(), n * 8, hipMemcpyHostToDevice, c->stream));
-  MH_LAUNCH(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const u64* const*)dptrs.p, dout.u(), n);
-  if (distributed) dist->all_reduce_sum(c, dout.u(), n);
-  std::vector<u64> host(n);
-  c->d2h(host.data(), dout.p, n * 8);
-  for (auto& cf : cap_fill)
-    for (int k = 0; k < 4; k++) host[cf.first + k] = cf.second[k];
-  fields.assign(host.begin(), host.begin() + n_fields);
-  commitments.assign(host.begin() + n_fields, host.end());
+  void* staged = c->host_take(n * 8);  // page-locked: the upload is a plain DMA
+  memcpy(staged, ptrs.data(), n * 8);
+  try {
+    HIP_CHECK(hipMemcpyAsync(dptrs.p, staged, n * 8, hipMemcpyHostToDevice, c->stream));
+    MH_LAUNCH(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const u64* const*)dptrs.p, dout.u(), n);
+    if (dist && dist->on()) dist->all_reduce_sum(c, dout.u(), n);
+    c->d2h(host.data(), dout.p, n * 8);  // blocking: the staged list has been read
+  } catch (...) {
+    (void)hipStreamSynchronize(c->stream);
+    c->host_give(staged, n * 8);
+    throw;
+  }
+  c->host_give(staged, n * 8);
+}
+
+// A tree's slice of the gathered words -> its opened rows and sibling digests (cap digests from the host copy of the cap).
+void lmcs_open_take(const OpenPlan& plan, std::vector<u64>& host, std::vector<u64>& fields, std::vector<u64>& commitments) {
+  for (auto& cf : plan.cap_fill)
+    for (int k = 0; k < 4; k++) host[plan.first + cf.first + k] = cf.second[k];
+  fields.assign(host.begin() + plan.first, host.begin() + plan.first + plan.n_fields);
+  commitments.assign(host.begin() + plan.first + plan.n_fields, host.begin() + plan.first + plan.n);
+}
+
+void lmcs_open(mh_ctx* c, const mh_tree* t, const std::vector<size_t>& idx, size_t alignment, std::vector<u64>& fields,
+               std::vector<u64>& commitments, const Dist* dist) {
+  std::vector<const u64*> ptrs;
+  const OpenPlan plan = lmcs_open_plan(t, idx, alignment, dist, ptrs);
+  std::vector<u64> host;
+  lmcs_open_run(c, ptrs, dist, host);
+  lmcs_open_take(plan, host, fields, commitments);
 }
 
 // [2^lbl][2^log_rows] digests -> [G][2^lbl][rows/G]: the block of every destination rank contiguous

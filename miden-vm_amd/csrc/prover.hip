@@ -738,23 +738,18 @@ struct mh_session {
     std::sort(idx.begin(), idx.end());
     idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
     for (size_t i : idx) MH_REQUIRE(i < ((size_t)1 << L), "query index out of range");
+    // every tree's gather list first, then ONE gather / read-back (/ all-reduce) for all of them
+    std::vector<const u64*> ptrs;
+    std::vector<OpenPlan> plans;
     if (prep_tree) {  // a tree shorter than the max domain is virtually lifted: indices fold by their low bits
       std::vector<size_t> pidx(idx);
       const size_t mask = ((size_t)1 << (prep_tree->log_height + prep_tree->shard_logG)) - 1;  // full depth (a rank stores a subtree)
       for (auto& i : pidx) i &= mask;
       std::sort(pidx.begin(), pidx.end());
       pidx.erase(std::unique(pidx.begin(), pidx.end()), pidx.end());
-      std::vector<u64> f, cm;
-      lmcs_open(c, prep_tree, pidx, alignment(), f, cm, &dist);
-      fields.insert(fields.end(), f.begin(), f.end());
-      commitments.insert(commitments.end(), cm.begin(), cm.end());
+      plans.push_back(lmcs_open_plan(prep_tree, pidx, alignment(), &dist, ptrs));
     }
-    for (const mh_tree* t : {main_tree.get(), aux_tree.get(), quot_tree.get()}) {
-      std::vector<u64> f, cm;
-      lmcs_open(c, t, idx, alignment(), f, cm, &dist);
-      fields.insert(fields.end(), f.begin(), f.end());
-      commitments.insert(commitments.end(), cm.begin(), cm.end());
-    }
+    for (const mh_tree* t : {main_tree.get(), aux_tree.get(), quot_tree.get()}) plans.push_back(lmcs_open_plan(t, idx, alignment(), &dist, ptrs));
     int depth = L;
     for (auto& t : fri_trees) {
       depth -= pp.log_folding_arity;
@@ -762,8 +757,13 @@ struct mh_session {
       for (auto& i : idx) i &= mask;
       std::sort(idx.begin(), idx.end());
       idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
+      plans.push_back(lmcs_open_plan(t.get(), idx, 1, &dist, ptrs));
+    }
+    std::vector<u64> host;
+    lmcs_open_run(c, ptrs, &dist, host);
+    for (const OpenPlan& plan : plans) {
       std::vector<u64> f, cm;
-      lmcs_open(c, t.get(), idx, 1, f, cm, &dist);
+      lmcs_open_take(plan, host, f, cm);
       fields.insert(fields.end(), f.begin(), f.end());
       commitments.insert(commitments.end(), cm.begin(), cm.end());
     }

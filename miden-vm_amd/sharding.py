@@ -376,8 +376,9 @@ def predict_sharded_ms(world, log_n=24, main_width=51, aux_base_width=16, quotie
 
 def expected_collectives(world, n_trees_full=3, n_fri_rounds=8):
     """Call counts of a sharded proof, for reading `comm_*` launch counts: per tree one all-to-all + one all-gather of subroots
-    (FRI trees too while their layers are still sharded), one all-gather of quotient chunks, one all-reduce per opened tree."""
+    (FRI trees too while their layers are still sharded), one all-gather of quotient chunks, one all-reduce for the OOD evaluation
+    vectors and ONE for the openings of all trees (their gather lists are concatenated: lmcs_open_run)."""
     if world == 1:
         return {"all_to_all": 0, "all_gather": 0, "all_reduce": 0}
     return {"all_to_all": n_trees_full + n_fri_rounds, "all_gather": n_trees_full + n_fri_rounds + 1 + n_fri_rounds,
-            "all_reduce": n_trees_full + n_fri_rounds + 1}  # + the OOD evaluation vectors
+            "all_reduce": 2}
