@@ -87,6 +87,7 @@ void mh_ctx_destroy(mh_ctx* c) {
   c->pool.trim();
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->pinned_top) (void)hipHostFree(c->pinned_top);
+  if (c->ring) (void)hipHostFree(c->ring);
   for (auto& hp : c->host_pool) (void)hipHostFree(hp.first);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);

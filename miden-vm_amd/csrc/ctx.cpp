@@ -63,6 +63,24 @@ void mh_ctx::d2h(void* dst_host, const void* src_dev, size_t bytes) {
   memcpy(dst_host, pinned, bytes);
 }
 
+void mh_ctx::h2d(void* dst_dev, const void* src_host, size_t bytes) {
+  if (!bytes) return;
+  if (bytes > RING_BYTES / 4) {  // big blocks: the runtime's own path (blocking for pageable sources)
+    HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, stream));
+    return;
+  }
+  if (!ring) HIP_CHECK(hipHostMalloc(&ring, RING_BYTES, hipHostMallocDefault));
+  const size_t need = (bytes + 63) & ~(size_t)63;
+  if (ring_pos + need > RING_BYTES) {  // wrap: copies still in flight may read the start of the ring
+    sync();
+    ring_pos = 0;
+  }
+  void* slot = static_cast<char*>(ring) + ring_pos;
+  ring_pos += need;
+  memcpy(slot, src_host, bytes);
+  HIP_CHECK(hipMemcpyAsync(dst_dev, slot, bytes, hipMemcpyHostToDevice, stream));
+}
+
 void* mh_ctx::host_take(size_t bytes) {
   for (size_t i = 0; i < host_pool.size(); i++)
     if (host_pool[i].second >= bytes && host_pool[i].second <= 2 * bytes + 4096) {

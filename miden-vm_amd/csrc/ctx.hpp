@@ -159,6 +159,13 @@ struct mh_ctx {
   // Blocking device-to-host copy of a small result (roots, opened rows, partial sums) through a page-locked bounce
   // buffer: a straight DMA instead of the runtime's staged copy into pageable memory (~40 us less per call).
   void d2h(void* dst_host, const void* src_dev, size_t bytes);
+  // Asynchronous host-to-device copy of a small parameter block (challenge powers, OOD points, program constants) through a
+  // page-locked ring: from pageable memory the runtime stages the bytes itself and the GPU idles ~25 us per copy (kernel trace: ~15
+  // such copies per proof).  The source may be reused as soon as the call returns.
+  void h2d(void* dst_dev, const void* src_host, size_t bytes);
+  void* ring = nullptr;
+  size_t ring_pos = 0;
+  static constexpr size_t RING_BYTES = 4 << 20;
   void* pinned = nullptr;
   void* pinned_top = nullptr;  // lmcs_compress_layers: the tree top computed on the host, on its way back to the device
   static constexpr size_t PINNED_BYTES = 1 << 20;

@@ -104,7 +104,7 @@ void deep_ood_eval_matrix(mh_ctx* c, const LdeMatrix& m, int log_blowup, e2 y0, 
   if (!tw) {
     one.alloc(8);
     u64 v = 1;
-    HIP_CHECK(hipMemcpyAsync(one.p, &v, 8, hipMemcpyHostToDevice, c->stream));
+    c->h2d(one.p, &v, 8);
     tw = one.u();
   }
   const unsigned chunks = (unsigned)((n + OOD_ROWS_PER_BLOCK - 1) / OOD_ROWS_PER_BLOCK);
@@ -297,12 +297,12 @@ void deep_assemble(mh_ctx* c, const std::vector<const LdeMatrix*>& mats, const s
     x = gl_mul(x, wK);
   }
   DevBuf dblob(blob.size() * 8), one;
-  HIP_CHECK(hipMemcpyAsync(dblob.p, blob.data(), blob.size() * 8, hipMemcpyHostToDevice, c->stream));
+  c->h2d(dblob.p, blob.data(), blob.size() * 8);
   const u64* tw = log_n ? c->twiddles(log_n, false) : nullptr;
   if (!tw) {
     one.alloc(8);
     u64 v = 1;
-    HIP_CHECK(hipMemcpyAsync(one.p, &v, 8, hipMemcpyHostToDevice, c->stream));
+    c->h2d(one.p, &v, 8);
     tw = one.u();
   }
   DeepArgs a{};

@@ -254,7 +254,7 @@ void fri_fold(mh_ctx* c, const u64* ev, int log_rows, int cbits, int cbits_globa
     x = gl_mul(x, wn_inv);
   }
   DevBuf d(C * 8);
-  HIP_CHECK(hipMemcpyAsync(d.p, ci.data(), C * 8, hipMemcpyHostToDevice, c->stream));
+  c->h2d(d.p, ci.data(), C * 8);
   FoldArgs a{};
   a.ev = ev; a.out = out; a.log_rows = log_rows; a.cbits = cbits; a.log_arity = log_arity;
   a.tw_inv = log_rows ? c->twiddles(log_rows, true) : nullptr;
@@ -424,7 +424,7 @@ u64 fri_grind_bytes(mh_ctx* c, int lmcs, const std::vector<uint8_t>& prefix, int
   ProfScope ps(c, "grind", 0);
   for (u64 base = 0;; base += window) {
     unsigned long long init = ~0ULL;
-    HIP_CHECK(hipMemcpyAsync(best.p, &init, 8, hipMemcpyHostToDevice, c->stream));
+    c->h2d(best.p, &init, 8);
     if (lmcs == MH_LMCS_BLAKE3) {
       ab.base = base;
       MH_LAUNCH(k_grind_b3, dim3((unsigned)(window / 256)), dim3(256), 0, c->stream, ab);
@@ -453,7 +453,7 @@ u64 fri_grind(mh_ctx* c, const u64 st[12], const u64* in, int n_in, int bits) {
   ProfScope ps(c, "grind", 0);
   for (u64 base = 0;; base += window) {
     unsigned long long init = ~0ULL;
-    HIP_CHECK(hipMemcpyAsync(best.p, &init, 8, hipMemcpyHostToDevice, c->stream));
+    c->h2d(best.p, &init, 8);
     a.base = base;
     if (c->lmcs == MH_LMCS_RPO || c->lmcs == MH_LMCS_RPX)
       MH_LAUNCH(k_grind_alg, dim3((unsigned)(window / 256)), dim3(256), 0, c->stream, a, c->lmcs);

@@ -698,19 +698,10 @@ void lmcs_open_run(mh_ctx* c, const std::vector<const u64*>& ptrs, const Dist* d
   host.assign(n, 0);
   if (!n) return;
   DevBuf dptrs(n * 8), dout(n * 8);
-  void* staged = c->host_take(n * 8);  // page-locked: the upload is a plain DMA
-  memcpy(staged, ptrs.data(), n * 8);
-  try {
-    HIP_CHECK(hipMemcpyAsync(dptrs.p, staged, n * 8, hipMemcpyHostToDevice, c->stream));
-    MH_LAUNCH(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const u64* const*)dptrs.p, dout.u(), n);
-    if (dist && dist->on()) dist->all_reduce_sum(c, dout.u(), n);
-    c->d2h(host.data(), dout.p, n * 8);  // blocking: the staged list has been read
-  } catch (...) {
-    (void)hipStreamSynchronize(c->stream);
-    c->host_give(staged, n * 8);
-    throw;
-  }
-  c->host_give(staged, n * 8);
+  c->h2d(dptrs.p, ptrs.data(), n * 8);  // through the page-locked ring: a plain DMA
+  MH_LAUNCH(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const u64* const*)dptrs.p, dout.u(), n);
+  if (dist && dist->on()) dist->all_reduce_sum(c, dout.u(), n);
+  c->d2h(host.data(), dout.p, n * 8);
 }
 
 // A tree's slice of the gathered words -> its opened rows and sibling digests (cap digests from the host copy of the cap).

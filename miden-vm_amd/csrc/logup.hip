@@ -155,9 +155,9 @@ mh_trace* lookup_build_aux(mh_ctx* c, const mh_lookup* lk, const mh_trace* main,
   }
   if (blob.empty()) blob.push_back(0);
   DevBuf dblob(blob.size() * 8), dcount(lk->col_count.size() * 4), dext(lk->out_ext.size()), derr(4);
-  HIP_CHECK(hipMemcpyAsync(dblob.p, blob.data(), blob.size() * 8, hipMemcpyHostToDevice, c->stream));
-  HIP_CHECK(hipMemcpyAsync(dcount.p, lk->col_count.data(), lk->col_count.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIP_CHECK(hipMemcpyAsync(dext.p, lk->out_ext.data(), lk->out_ext.size(), hipMemcpyHostToDevice, c->stream));
+  c->h2d(dblob.p, blob.data(), blob.size() * 8);
+  c->h2d(dcount.p, lk->col_count.data(), lk->col_count.size() * 4);
+  c->h2d(dext.p, lk->out_ext.data(), lk->out_ext.size());
   HIP_CHECK(hipMemsetAsync(derr.p, 0, 4, c->stream));
 
   trace_wait_ready(c, main);

@@ -599,7 +599,7 @@ struct mh_session {
         flat[4 * i] = ev0[i].c0; flat[4 * i + 1] = ev0[i].c1; flat[4 * i + 2] = ev1[i].c0; flat[4 * i + 3] = ev1[i].c1;
       }
       DevBuf d(flat.size() * 8);
-      HIP_CHECK(hipMemcpyAsync(d.p, flat.data(), flat.size() * 8, hipMemcpyHostToDevice, c->stream));
+      c->h2d(d.p, flat.data(), flat.size() * 8);
       dist.all_reduce_sum(c, d.u(), flat.size());
       c->d2h(flat.data(), d.p, flat.size() * 8);
       for (size_t i = 0; i < W; i++) {

@@ -277,13 +277,13 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
   };
   const size_t o_tab = put(tab), o_ap = put(apow), o_pt = put(ptab), o_pub = put(pub), o_rnd = put(rnd), o_av = put(av);
   DevBuf dblob(blob.size() * 8);
-  HIP_CHECK(hipMemcpyAsync(dblob.p, blob.data(), blob.size() * 8, hipMemcpyHostToDevice, c->stream));
+  c->h2d(dblob.p, blob.data(), blob.size() * 8);
   const u64* tw = log_n ? c->twiddles(log_n, false) : nullptr;
   DevBuf one;
   if (!tw) {  // n = 1: a one-entry table holding w^0
     one.alloc(8);
     u64 v = 1;
-    HIP_CHECK(hipMemcpyAsync(one.p, &v, 8, hipMemcpyHostToDevice, c->stream));
+    c->h2d(one.p, &v, 8);
     tw = one.u();
   }
   const u64 wh_inv = gl_inv(gl_two_adic_generator(log_n));
