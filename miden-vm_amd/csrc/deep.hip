@@ -87,50 +87,101 @@ __global__ __launch_bounds__(256) void k_ood_partial(const u64* lde, int log_n, 
 // evals_out[k][col] (EF) for one matrix; y_k = z_k^(lift) supplied by the caller.
 // Only columns [col_begin, col_end) are evaluated (the others come back as zero): a rank of a sharded proof evaluates its
 // share of the columns -- on its own first coset -- and the ranks add their vectors up.
+// All matrices of a statement in ONE pass over the host: every job's kernels are queued, the partial sums of all of them come back
+// in one blocking copy (per matrix that was a round trip of ~45 us), and matrices that share (height, coset, points) share one
+// set of barycentric weights (at 2^20 rows: three matrices, one k_bary_weights instead of three).
+void deep_ood_eval_batch(mh_ctx* c, std::vector<OodJob>& jobs, int log_blowup) {
+  struct Weights {
+    int log_n;
+    size_t coset0;
+    e2 y0, y1;
+    DevBuf w0, w1;
+  };
+  std::vector<std::unique_ptr<Weights>> weights;
+  struct Slot {
+    size_t off = 0, ncol = 0;
+    unsigned chunks = 0;
+  };
+  std::vector<Slot> slots(jobs.size());
+  size_t total = 0;
+  for (size_t k = 0; k < jobs.size(); k++) {
+    OodJob& j = jobs[k];
+    const LdeMatrix& m = *j.m;
+    if (j.col_end > m.width) j.col_end = m.width;
+    j.out0.assign(m.width, e2_make(0));
+    j.out1.assign(m.width, e2_make(0));
+    if (j.col_begin >= j.col_end) continue;
+    const size_t n = (size_t)1 << m.log_n;
+    slots[k].ncol = j.col_end - j.col_begin;
+    slots[k].chunks = (unsigned)((n + OOD_ROWS_PER_BLOCK - 1) / OOD_ROWS_PER_BLOCK);
+    slots[k].off = total;
+    total += slots[k].ncol * slots[k].chunks * 4;
+  }
+  if (!total) return;
+  DevBuf partial(total * 8), one;
+  for (size_t k = 0; k < jobs.size(); k++) {
+    if (!slots[k].ncol) continue;
+    const OodJob& j = jobs[k];
+    const LdeMatrix& m = *j.m;
+    const int log_n = m.log_n;
+    const size_t n = (size_t)1 << log_n;
+    // any coset of H determines the polynomial: use the first one this rank stores
+    // (shift g_m * w_{K_m}^coset0; coset 0 on a single GPU, as the reference does)
+    const u64 g = gl_mul(gl_lde_shift(log_n + log_blowup), gl_pow(gl_two_adic_generator(log_n + log_blowup), m.coset0));
+    const u64* tw = log_n ? c->twiddles(log_n, false) : nullptr;
+    if (!tw) {
+      if (!one.p) {
+        one.alloc(8);
+        u64 v = 1;
+        c->h2d(one.p, &v, 8);
+      }
+      tw = one.u();
+    }
+    ProfScope ps(c, "deep_ood_eval", (double)n * 8.0 * slots[k].ncol + 64.0 * n);
+    Weights* w = nullptr;
+    for (auto& cand : weights)
+      if (cand->log_n == log_n && cand->coset0 == m.coset0 && e2_eq(cand->y0, j.y0) && e2_eq(cand->y1, j.y1)) w = cand.get();
+    if (!w) {
+      weights.emplace_back(new Weights{log_n, m.coset0, j.y0, j.y1, DevBuf(n * 16), DevBuf(n * 16)});
+      w = weights.back().get();
+      MH_LAUNCH(k_bary_weights, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, c->stream, tw, log_n, g, j.y0, j.y1, w->w0.u(), w->w1.u());
+    }
+    MH_LAUNCH(k_ood_partial, dim3(slots[k].chunks, (unsigned)slots[k].ncol), dim3(256), 0, c->stream,
+              m.lde.u() + ((j.col_begin << m.log_cosets) << log_n), log_n, m.log_cosets, w->w0.u(), w->w1.u(), partial.u() + slots[k].off,
+              slots[k].chunks);
+  }
+  std::vector<u64> host(total);
+  c->d2h(host.data(), partial.p, total * 8);
+  for (size_t k = 0; k < jobs.size(); k++) {
+    if (!slots[k].ncol) continue;
+    OodJob& j = jobs[k];
+    const LdeMatrix& m = *j.m;
+    const int log_n = m.log_n;
+    const size_t n = (size_t)1 << log_n;
+    const u64 g = gl_mul(gl_lde_shift(log_n + log_blowup), gl_pow(gl_two_adic_generator(log_n + log_blowup), m.coset0));
+    // scaling s(y) = ((y/g)^n - 1)/n
+    const u64 g_inv = gl_inv(g), n_inv = gl_inv((u64)n % GL_P);
+    const e2 s0 = e2_mulf(e2_sub(e2_exp_pow2(e2_mulf(j.y0, g_inv), log_n), e2_make(1)), n_inv);
+    const e2 s1 = e2_mulf(e2_sub(e2_exp_pow2(e2_mulf(j.y1, g_inv), log_n), e2_make(1)), n_inv);
+    for (size_t col = 0; col < slots[k].ncol; col++) {
+      e2 a0 = e2_make(0), a1 = e2_make(0);
+      for (unsigned ch = 0; ch < slots[k].chunks; ch++) {
+        const u64* p = host.data() + slots[k].off + (col * slots[k].chunks + ch) * 4;
+        a0 = e2_add(a0, e2{p[0], p[1]});
+        a1 = e2_add(a1, e2{p[2], p[3]});
+      }
+      j.out0[j.col_begin + col] = e2_mul(a0, s0);
+      j.out1[j.col_begin + col] = e2_mul(a1, s1);
+    }
+  }
+}
 void deep_ood_eval_matrix(mh_ctx* c, const LdeMatrix& m, int log_blowup, e2 y0, e2 y1, std::vector<e2>& out0, std::vector<e2>& out1,
                           size_t col_begin, size_t col_end) {
-  const int log_n = m.log_n;
-  if (col_end > m.width) col_end = m.width;
-  out0.assign(m.width, e2_make(0));
-  out1.assign(m.width, e2_make(0));
-  if (col_begin >= col_end) return;
-  const size_t ncol = col_end - col_begin;
-  const size_t n = (size_t)1 << log_n;
-  // any coset of H determines the polynomial: use the first one this rank stores
-  // (shift g_m * w_{K_m}^coset0; coset 0 on a single GPU, as the reference does)
-  const u64 g = gl_mul(gl_lde_shift(log_n + log_blowup), gl_pow(gl_two_adic_generator(log_n + log_blowup), m.coset0));
-  DevBuf w0(n * 16), w1(n * 16), one;
-  const u64* tw = log_n ? c->twiddles(log_n, false) : nullptr;
-  if (!tw) {
-    one.alloc(8);
-    u64 v = 1;
-    c->h2d(one.p, &v, 8);
-    tw = one.u();
-  }
-  const unsigned chunks = (unsigned)((n + OOD_ROWS_PER_BLOCK - 1) / OOD_ROWS_PER_BLOCK);
-  DevBuf partial(ncol * chunks * 32);
-  {
-    ProfScope ps(c, "deep_ood_eval", (double)n * 8.0 * ncol + 64.0 * n);
-    MH_LAUNCH(k_bary_weights, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, c->stream, tw, log_n, g, y0, y1, w0.u(), w1.u());
-    MH_LAUNCH(k_ood_partial, dim3(chunks, (unsigned)ncol), dim3(256), 0, c->stream, m.lde.u() + ((col_begin << m.log_cosets) << log_n), log_n,
-                       m.log_cosets, w0.u(), w1.u(), partial.u(), chunks);
-  }
-  std::vector<u64> host(ncol * chunks * 4);
-  c->d2h(host.data(), partial.p, host.size() * 8);
-  // scaling s(y) = ((y/g)^n - 1)/n
-  const u64 g_inv = gl_inv(g), n_inv = gl_inv((u64)n % GL_P);
-  e2 s0 = e2_mulf(e2_sub(e2_exp_pow2(e2_mulf(y0, g_inv), log_n), e2_make(1)), n_inv);
-  e2 s1 = e2_mulf(e2_sub(e2_exp_pow2(e2_mulf(y1, g_inv), log_n), e2_make(1)), n_inv);
-  for (size_t col = 0; col < ncol; col++) {
-    e2 a0 = e2_make(0), a1 = e2_make(0);
-    for (unsigned ch = 0; ch < chunks; ch++) {
-      const u64* p = host.data() + (col * chunks + ch) * 4;
-      a0 = e2_add(a0, e2{p[0], p[1]});
-      a1 = e2_add(a1, e2{p[2], p[3]});
-    }
-    out0[col_begin + col] = e2_mul(a0, s0);
-    out1[col_begin + col] = e2_mul(a1, s1);
-  }
+  std::vector<OodJob> jobs(1);
+  jobs[0].m = &m; jobs[0].y0 = y0; jobs[0].y1 = y1; jobs[0].col_begin = col_begin; jobs[0].col_end = col_end;
+  deep_ood_eval_batch(c, jobs, log_blowup);
+  out0.swap(jobs[0].out0);
+  out1.swap(jobs[0].out1);
 }
 
 // ---- DEEP reduce + assemble ----------------------------------------------------------------------

@@ -142,6 +142,13 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
 void quotient_upsample_accumulate(mh_ctx* c, const u64* q_small, int log_n, int log_blowup, int log_dj, int log_d, const u64* acc_in,
                                   int log_n_prev, e2 beta, u64* acc_out);
 // ---- deep.hip ----------------------------------------------------------------------------------
+struct OodJob {
+  const LdeMatrix* m = nullptr;
+  e2 y0, y1;                            // the two evaluation points, already lifted to this matrix's height
+  size_t col_begin = 0, col_end = ~(size_t)0;
+  std::vector<e2> out0, out1;           // per column (zero outside [col_begin, col_end))
+};
+void deep_ood_eval_batch(mh_ctx* c, std::vector<OodJob>& jobs, int log_blowup);
 void deep_ood_eval_matrix(mh_ctx* c, const LdeMatrix& m, int log_blowup, e2 y0, e2 y1, std::vector<e2>& out0, std::vector<e2>& out1,
                           size_t col_begin = 0, size_t col_end = (size_t)-1);
 void deep_assemble(mh_ctx* c, const std::vector<const LdeMatrix*>& mats, const std::vector<uint32_t>& coef_off, int log_n, int log_blowup,

@@ -575,10 +575,9 @@ struct mh_session {
     }
     ev0.assign(W, e2_make(0));
     ev1.assign(W, e2_make(0));
+    std::vector<OodJob> jobs(mats.size());
     for (size_t i = 0; i < mats.size(); i++) {
       const int lift = log_N - mats[i]->log_n;
-      std::vector<e2> o0, o1;
-      if (mats[i]->width == 0) continue;
       // sharded proof: every rank holds every column (on its own cosets), so the columns of a matrix are split between the ranks
       // and the vectors added up below -- the barycentric sums are not repeated G times
       size_t cb = 0, ce = mats[i]->width;
@@ -587,12 +586,18 @@ struct mh_session {
         cb = std::min(mats[i]->width, per * dist.rank);
         ce = std::min(mats[i]->width, cb + per);
       }
-      deep_ood_eval_matrix(c, *mats[i], lb, e2_exp_pow2(z, lift), e2_exp_pow2(z_next, lift), o0, o1, cb, ce);
-      for (size_t k = 0; k < o0.size(); k++) {
-        ev0[coef_off[i] + k] = o0[k];
-        ev1[coef_off[i] + k] = o1[k];
-      }
+      jobs[i].m = mats[i];
+      jobs[i].y0 = e2_exp_pow2(z, lift);
+      jobs[i].y1 = e2_exp_pow2(z_next, lift);
+      jobs[i].col_begin = cb;
+      jobs[i].col_end = ce;
     }
+    deep_ood_eval_batch(c, jobs, lb);  // one read-back for all matrices
+    for (size_t i = 0; i < mats.size(); i++)
+      for (size_t k = 0; k < jobs[i].out0.size(); k++) {
+        ev0[coef_off[i] + k] = jobs[i].out0[k];
+        ev1[coef_off[i] + k] = jobs[i].out1[k];
+      }
     if (dist.on() && W) {  // every slot was computed by exactly one rank: a plain sum puts the full vectors on every rank
       std::vector<u64> flat(4 * W);
       for (size_t i = 0; i < W; i++) {
