@@ -258,14 +258,16 @@ def miden_shape_probe(pkg, ctx, steps=3):
     proof = pkg.prove(ctx, airs, traces, [], prm, st, pre, None)
     ok, _ = pkg.verify([dag.dummy_miden_air(51, 4, num_aux_values=1), dag.dummy_miden_air(22, 3, num_aux_values=1), p2], [20, 20, 20], [], prm, st, pre,
                        proof.fields, proof.commitments)
-    ctx.prof_enable(True)
-    ctx.prof_reset()
     t0 = time.perf_counter()
     for _ in range(steps):
         proof = pkg.prove(ctx, airs, traces, [], prm, st, pre, None)
     dt = (time.perf_counter() - t0) / steps
+    ctx.prof_enable(True)  # the two kernel classes reported below: one more proof, outside the timing (event records cost ~0.7 ms per proof here)
+    ctx.prof_reset()
+    proof = pkg.prove(ctx, airs, traces, [], prm, st, pre, None)
     prof = ctx.prof()
     ctx.prof_enable(False)
+    prof = {k: dict(v, ms=v["ms"] * steps) for k, v in prof.items()}  # the expressions below divide by `steps`
     for t in traces:
         t.free()
     out = {"workload": "three AIRs at 2^20 rows: main 51/22/16, aux 4/3/1 EF (89 + 16 base columns), production parameters; third AIR = the real "
@@ -412,6 +414,11 @@ def main():
 
     for _ in range(args.warmup):
         runner.step()
+    # Timed region: HIP events around the DOMINANT kernel class only.  An event record is a barrier packet on the stream; with
+    # every class and span recorded (~130 scopes per proof) a 2^20-row proof is 0.5 ms slower (47.7 vs 47.2 ms).  The full
+    # per-class breakdown (`kernels`, `spans`, `sharded_breakdown`) comes from a second, untimed pass right after.
+    DOMINANT = "lmcs_leaf_absorb"
+    ctx.prof_filter(DOMINANT)
     ctx.prof_enable(True)
     ctx.prof_reset()
     barrier()
@@ -424,6 +431,15 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    prof_timed = ctx.prof()
+    ctx.prof_filter(None)
+    ctx.prof_reset()
+    bd_steps = max(1, min(args.steps, 2 if mode == "sharded" else 5))
+    t_bd = time.perf_counter()
+    for _ in range(bd_steps):
+        runner.step()
+    barrier()
+    bd_ms = (time.perf_counter() - t_bd) / bd_steps * 1e3
     prof = ctx.prof()
     ctx.prof_enable(False)
 
@@ -460,10 +476,10 @@ def main():
         # the measured split of this rank's time next to the model of DESIGN.md section 5 (miden-vm_amd/sharding.py), so that the
         # line can be read against a prediction: sharded kernels, the replicated inverse transforms, collectives
         from miden_vm_amd import sharding as _sh
-        per = lambda k: prof.get(k, {}).get("ms", 0.0) / args.steps
+        per = lambda k: prof.get(k, {}).get("ms", 0.0) / bd_steps
         comm = {k: round(per(k), 3) for k in prof if k.startswith("comm_")}
         out["sharded_breakdown"] = {
-            "comm_ms": comm, "comm_calls_per_proof": {k: prof[k]["count"] / args.steps for k in prof if k.startswith("comm_")},
+            "comm_ms": comm, "comm_calls_per_proof": {k: prof[k]["count"] / bd_steps for k in prof if k.startswith("comm_")},
             "replicated_intt_ms": round(per("lde_intt"), 3), "ood_ms": round(per("deep_ood_eval"), 3),
             "kernel_ms": round(sum(per(k) for k in prof if not k.startswith(("comm_", "span:")) and k != "lde_intt"), 3),
             # the model scales the 2^24 single-GPU spans linearly: meaningful for large proofs only (fixed latencies dominate small ones)
@@ -472,17 +488,27 @@ def main():
             "model_note": "per-rank ms predicted from the single-GPU spans of profiles/r03_config_shapes.txt (2^24: 744 ms) with "
                           "60 GB/s per xGMI link and direction; replicated = inverse NTTs + host-serial tree tops / transcript"}
     pmc_json = "r03_pmc_leaf_absorb.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_leaf_absorb.json")) else "r02_pmc_leaf_absorb.json"
-    out["roofline"] = roofline(prof, pmc_json)
+    # the dominant class of the full pass must be the one the timed region recorded; if a configuration moves it, say so and fall back
+    full_dom = max((k for k in prof if not k.startswith(("comm_", "span:")) and k != "lde_intt"), key=lambda k: prof[k]["ms"]) if prof else None
+    live = prof_timed if (DOMINANT in prof_timed and full_dom == DOMINANT) else prof
+    live_steps = args.steps if live is prof_timed else bd_steps
+    out["roofline"] = roofline(live, pmc_json)
+    if out["roofline"] is not None:
+        out["roofline"]["measured_over"] = ("the timed region" if live is prof_timed else
+                                            f"the untimed breakdown pass (dominant class here is {full_dom}, not {DOMINANT})")
     try:
         perms = (8 << log_n) * (7 + 2 + 2) // (world if mode == "sharded" else 1)  # per rank
-        out["roofline_valu"] = valu_roofline(ctx, prof, perms, args.steps, pmc_json)
+        out["roofline_valu"] = valu_roofline(ctx, live, perms, live_steps, pmc_json)
     except Exception as e:
         out["roofline_valu"] = {"error": repr(e)[:200]}
-    out["kernels"] = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["count"] / args.steps,
+    out["breakdown_pass"] = {"steps": bd_steps, "ms_per_step_with_every_class_recorded": bd_ms,
+                             "note": "kernels / spans / sharded_breakdown: a second, untimed pass with every kernel class and span recorded "
+                                     "(event records are barrier packets: ~0.5 ms per 2^20-row proof); the timed region records the dominant class only"}
+    out["kernels"] = {k: {"ms_per_step": v["ms"] / bd_steps, "launches_per_step": v["count"] / bd_steps,
                           "alg_GBps": (v["bytes"] / 1e9) / (v["ms"] / 1e3) if v["ms"] > 0 else None}
                       for k, v in prof.items() if not k.startswith("span:")}
     # the same timings under the reference's tracing span names, stage spans included
-    out["spans"] = {k[5:]: round(v["ms"] / args.steps, 4) for k, v in prof.items() if k.startswith("span:")}
+    out["spans"] = {k[5:]: round(v["ms"] / bd_steps, 4) for k, v in prof.items() if k.startswith("span:")}
     if world == 1 and not args.no_extras:
         try:  # the same proof with the trace upload inside the timed region (page-locked source buffer)
             pin, owner = pkg.pinned_array(ctx.lib, runner.host_trace.shape)

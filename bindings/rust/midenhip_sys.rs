@@ -84,6 +84,7 @@ unsafe extern "C" {
     pub fn mh_ctx_get_lmcs(ctx: *const mh_ctx) -> c_int;
     pub fn mh_blake3(data: *const u8, n: usize, out32: *mut u8);
     pub fn mh_prof_enable(ctx: *mut mh_ctx, on: c_int) -> c_int;
+    pub fn mh_prof_filter(ctx: *mut mh_ctx, name: *const c_char) -> c_int;
     pub fn mh_prof_reset(ctx: *mut mh_ctx) -> c_int;
     pub fn mh_prof_get(ctx: *mut mh_ctx, name: *const c_char, ms: *mut c_double, bytes: *mut c_double, count: *mut c_long) -> c_int;
     pub fn mh_prof_dump(ctx: *mut mh_ctx, buf: *mut c_char, cap: usize) -> c_int;

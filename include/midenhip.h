@@ -44,6 +44,10 @@ int mh_device_count(void);
 /* Kernel profiler: HIP events recorded on the ctx's private stream around each kernel class.
  * mh_prof_get returns accumulated milliseconds, attributed algorithmic bytes and launch count. */
 int mh_prof_enable(mh_ctx* ctx, int on);
+/* Restrict the profiler to ONE kernel class (e.g. "lmcs_leaf_absorb"); NULL or "" = every class and span again.  An event
+ * record is a barrier packet on the stream: recording every class costs a 2^20-row proof ~0.5 ms (a proof has ~130 scopes),
+ * one class ~10 us. */
+int mh_prof_filter(mh_ctx* ctx, const char* name);
 int mh_prof_reset(mh_ctx* ctx);
 int mh_prof_get(mh_ctx* ctx, const char* name, double* ms, double* bytes, long* count);
 /* writes up to cap bytes of a '\n'-separated "name ms bytes count" listing */

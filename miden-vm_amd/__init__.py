@@ -20,7 +20,7 @@ P = 0xFFFFFFFF00000001
 u64p = C.POINTER(C.c_uint64)
 
 EXPORTS = [
-    "mh_ctx_create", "mh_ctx_destroy", "mh_ctx_trim", "mh_last_error", "mh_device_count", "mh_prof_enable", "mh_prof_reset",
+    "mh_ctx_create", "mh_ctx_destroy", "mh_ctx_trim", "mh_last_error", "mh_device_count", "mh_prof_enable", "mh_prof_filter", "mh_prof_reset",
     "mh_prof_get", "mh_prof_dump", "mh_poseidon2_permute", "mh_poseidon2_register_rate", "mh_coset_lde_batch", "mh_trace_upload", "mh_trace_upload_async", "mh_trace_wait", "mh_trace_free",
     "mh_commit_traces", "mh_tree_free", "mh_tree_root", "mh_tree_log_height", "mh_tree_open", "mh_tree_download_lde",
     "mh_tree_download_layers", "mh_air_load", "mh_air_free", "mh_air_log_quotient_degree", "mh_air_compiled_chunks", "mh_air_compiled_max_vgprs", "mh_prove", "mh_prove_host", "mh_proof_free",
@@ -124,6 +124,11 @@ class Ctx:
     # ---- profiler ----
     def prof_enable(self, on=True):
         self.check(self.lib.mh_prof_enable(self.h, int(on)))
+
+    def prof_filter(self, name=None):
+        """mh_prof_filter: record only this kernel class (None: everything).  Event records are barrier packets: the full
+        profile costs a 2^20-row proof ~0.5 ms."""
+        self.check(self.lib.mh_prof_filter(self.h, name.encode() if name else None))
 
     def prof_reset(self):
         self.check(self.lib.mh_prof_reset(self.h))

@@ -115,6 +115,13 @@ int mh_prof_enable(mh_ctx* c, int on) {
   c->prof_on = on != 0;
   MH_CATCH
 }
+int mh_prof_filter(mh_ctx* c, const char* name) {
+  MH_TRY(c)
+  MH_REQUIRE(c, "null ctx");
+  c->prof_resolve();
+  c->prof_only = name ? name : "";
+  MH_CATCH
+}
 int mh_prof_reset(mh_ctx* c) {
   MH_TRY(c)
   MH_REQUIRE(c, "null ctx");

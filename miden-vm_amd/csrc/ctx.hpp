@@ -139,6 +139,7 @@ struct mh_ctx {
   std::string err;
   // profiler
   bool prof_on = false;
+  std::string prof_only;  // mh_prof_filter: the one scope name that is recorded ("" = all)
   struct Pending { std::string name; hipEvent_t a, b; double bytes; bool closed; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> event_pool;
@@ -190,7 +191,7 @@ struct ProfScope {
   mh_ctx* c;
   size_t slot = (size_t)-1;
   ProfScope(mh_ctx* ctx, const char* name, double bytes = 0) : c(ctx) {
-    if (c->prof_on) slot = c->prof_begin(name, bytes);
+    if (c->prof_on && (c->prof_only.empty() || c->prof_only == name)) slot = c->prof_begin(name, bytes);
   }
   ~ProfScope() {
     if (slot != (size_t)-1 && slot < c->pending.size()) c->prof_end(slot);
