@@ -120,6 +120,7 @@ void lmcs_host_compress(int lmcs, const u64* pair, u64* out);
 void lmcs_host_compress_level(int lmcs, const u64* children, size_t n_out, u64* out);
 bool p2_host_simd_available();
 void p2_host_compress8(const u64* pairs, int n, u64* out);
+void p2_host_permute8(u64* states /* [8][12] */);
 std::vector<std::pair<int, size_t>> lmcs_missing_siblings(const std::vector<size_t>& sorted_unique_idx, int depth);
 
 // ---- prover.hip (commit helpers shared with the C ABI) -------------------------------------------

@@ -123,6 +123,19 @@ bool p2_host_simd_available() {
   return ok;
 }
 
+// Eight full permutations: states[j][0..12) canonical in, canonical out.  Call only when p2_host_simd_available().
+P2V_TARGET void p2_host_permute8(u64* states) {
+  alignas(64) u64 lanes[12][8];
+  for (int j = 0; j < 8; j++)
+    for (int k = 0; k < 12; k++) lanes[k][j] = states[12 * j + k];
+  v8 s[12];
+  for (int k = 0; k < 12; k++) s[k] = _mm512_load_si512(lanes[k]);
+  permute8(s);
+  for (int k = 0; k < 12; k++) _mm512_store_si512(lanes[k], s[k]);
+  for (int j = 0; j < 8; j++)
+    for (int k = 0; k < 12; k++) states[12 * j + k] = lanes[k][j];
+}
+
 // out[j] = compress(pairs[j]) for j < n <= 8: pairs = n x (left || right) canonical words, out = n x 4 words.
 // Call only when p2_host_simd_available().
 P2V_TARGET void p2_host_compress8(const u64* pairs, int n, u64* out) {

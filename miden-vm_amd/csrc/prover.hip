@@ -781,6 +781,33 @@ static void do_grind(mh_ctx* c, HostTranscript& tr, int bits) {
     tr.fields.push_back(0);
     return;
   }
+  if (bits <= 5 && tr.ch.hash == MH_LMCS_POSEIDON2 && p2_host_simd_available()) {
+    // A trial is ONE permutation whose input differs from the next trial's in the witness word only (observe(w), then the duplexing
+    // that sample_bits or the full rate triggers; the sampled word is st[7]): eight trials per AVX-512 permutation, smallest hit first
+    // -- the same witness the scalar loop finds.  ~16 trials per FRI round, seven rounds per proof.
+    HostChallenger& ch = tr.ch;
+    const size_t k = ch.in.size() + 1;  // rate words after observing the witness: 1..8
+    u64 base[12];
+    for (int i = 0; i < 12; i++) base[i] = ch.st[i];
+    for (size_t i = 0; i + 1 < k; i++) base[i] = ch.in[i];
+    for (size_t i = k; i < 8; i++) base[i] = 0;
+    base[8] = gl_add(base[8], (u64)k);
+    const u64 mask = ((u64)1 << bits) - 1;
+    for (u64 w0 = 0;; w0 += 8) {
+      u64 states[8][12];
+      for (int j = 0; j < 8; j++) {
+        memcpy(states[j], base, 96);
+        states[j][k - 1] = w0 + (u64)j;
+      }
+      p2_host_permute8(&states[0][0]);
+      for (int j = 0; j < 8; j++)
+        if (((states[j][7] & 0xFFFFFFFFULL) & mask) == 0) {
+          MH_REQUIRE(ch.check_witness(bits, w0 + (u64)j), "internal: vectorised PoW witness rejected by the challenger");
+          tr.fields.push_back(w0 + (u64)j);
+          return;
+        }
+    }
+  }
   if (bits <= 5) {  // ~2^bits trials: cheaper on the host than one kernel launch + round trip
     for (u64 w = 0;; w++) {
       HostChallenger trial = tr.ch;
