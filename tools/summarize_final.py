@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O = os.path.join(ROOT, "gpurun_out", "final")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
 out = []
-out.append("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras   (4 proofs of miden:20:51:8; ns)")
+out.append("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras   (7 proofs of miden:20:51:8: 1 warm-up, 3 timed, 3 of the breakdown pass; ns)")
 out.append("# (k_perm_rate = the register-only Poseidon2 rate bench.py reports next to roofline_valu; it runs once, outside the timed region)")
 out.append(open(os.path.join(O, "kt", "kt_kernel_stats.csv")).read().strip())
 
@@ -24,12 +24,12 @@ def pmc(name):
 per_launch = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg, disp = pmc(c)
-    out.append(f"# rocprofv3 --pmc {c} (its own pass, 3 proofs), unit KB as reported\nkernel,dispatches,sum_KB,per_dispatch_KB")
+    out.append(f"# rocprofv3 --pmc {c} (its own pass, bench.py --steps 3 --warmup 0: 6 proofs), unit KB as reported\nkernel,dispatches,sum_KB,per_dispatch_KB")
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][c])[:10]:
         out.append(f"{k},{disp[k]},{v[c]:.0f},{v[c] / disp[k]:.1f}")
         per_launch.setdefault(k, {})[c] = v[c] / disp[k]
 agg, disp = pmc("SQ")
-out.append("# rocprofv3 --pmc SQ_* (own pass, 3 proofs)\nkernel,dispatches,waves,valu_insts,valu_per_wave,SQ_ACTIVE_INST_VALU/SQ_BUSY_CYCLES(raw ratio: compare kernels with each other),wait_inst_any/wave_cycles,wait_any/wave_cycles")
+out.append("# rocprofv3 --pmc SQ_* (own pass, 6 proofs)\nkernel,dispatches,waves,valu_insts,valu_per_wave,SQ_ACTIVE_INST_VALU/SQ_BUSY_CYCLES(raw ratio: compare kernels with each other),wait_inst_any/wave_cycles,wait_any/wave_cycles")
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["SQ_INSTS_VALU"])[:8]:
     w = max(1.0, v["SQ_WAVES"])
     out.append(f"{k},{disp[k]},{int(w)},{v['SQ_INSTS_VALU']:.3e},{v['SQ_INSTS_VALU'] / w:.0f},{v['SQ_ACTIVE_INST_VALU'] / max(1, v['SQ_BUSY_CYCLES']):.3f},"
@@ -37,8 +37,9 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["SQ_INSTS_VALU"])[:8]:
 la_sq = agg.get("k_leaf_absorb")
 valu_per_perm = None
 if la_sq:
-    valu_per_perm = la_sq['SQ_INSTS_VALU'] / (3 * (8 << 20) * 11 / 64)
-    perms = 3 * (8 << 20) * 11  # three proofs in the pass, 8 * 2^20 leaves, 7 + 2 + 2 permutations per leaf
+    n_proofs = disp["k_leaf_absorb"] // 3  # three leaf launches per proof (main, aux, quotient)
+    valu_per_perm = la_sq['SQ_INSTS_VALU'] / (n_proofs * (8 << 20) * 11 / 64)
+    perms = n_proofs * (8 << 20) * 11  # the proofs of the pass, 8 * 2^20 leaves, 7 + 2 + 2 permutations per leaf
     out.append(f"# k_leaf_absorb: SQ_INSTS_VALU per permutation = {la_sq['SQ_INSTS_VALU'] * 64 / perms:.0f} wave-instructions x 64 lanes / {perms} permutations "
                f"= {la_sq['SQ_INSTS_VALU'] / (perms / 64):.0f} VALU instructions per permutation (loads/stores and address arithmetic of the kernel included)")
 bench = open(os.path.join(O, "bench.json")).read().strip().splitlines()[-1]
