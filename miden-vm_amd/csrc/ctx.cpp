@@ -71,8 +71,10 @@ void mh_ctx::h2d(void* dst_dev, const void* src_host, size_t bytes) {
   }
   if (!ring) HIP_CHECK(hipHostMalloc(&ring, RING_BYTES, hipHostMallocDefault));
   const size_t need = (bytes + 63) & ~(size_t)63;
-  if (ring_pos + need > RING_BYTES) {  // wrap: copies still in flight may read the start of the ring
+  if (ring_pos + need > RING_BYTES) {  // wrap (every few hundred proofs): copies still in flight on any stream of this context may read the start of the ring
     sync();
+    if (side_stream) HIP_CHECK(hipStreamSynchronize(side_stream));
+    if (copy_stream) HIP_CHECK(hipStreamSynchronize(copy_stream));
     ring_pos = 0;
   }
   void* slot = static_cast<char*>(ring) + ring_pos;
