@@ -485,7 +485,7 @@ def main():
             # the model scales the 2^24 single-GPU spans linearly: meaningful for large proofs only (fixed latencies dominate small ones)
             "model": ({k: (round(v, 2) if isinstance(v, float) else v) for k, v in _sh.predict_sharded_ms(world, log_n).items()}
                       if log_n >= 22 else None),
-            "model_note": "per-rank ms predicted from the single-GPU spans of profiles/r03_config_shapes.txt (2^24: 744 ms) with "
+            "model_note": "per-rank ms predicted from the single-GPU spans of profiles/r03_config_shapes.txt (2^24: 739 ms) with "
                           "60 GB/s per xGMI link and direction; replicated = inverse NTTs + host-serial tree tops / transcript"}
     pmc_json = "r03_pmc_leaf_absorb.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_leaf_absorb.json")) else "r02_pmc_leaf_absorb.json"
     # the dominant class of the full pass must be the one the timed region recorded; if a configuration moves it, say so and fall back

@@ -331,8 +331,8 @@ def prove_sharded(pkg, ctx, comm, airs, traces, public_values, params, challenge
 # ---- a time model of the coset-sharded proof: what the first measured scaling line is read against --------
 # Single-GPU kernel classes of ONE proof of miden:24:51:8 on an MI355X, ms (profiles/r03_config_shapes.txt, configs[3]); lde_intt (the
 # inverse transforms of main + aux + quotient chunks, nested in lde) is measured, the main + aux share of it is what every rank repeats.
-SINGLE_GPU_MS_2P24 = {"lmcs_leaf_absorb": 380.45, "lde": 190.55, "lde_intt": 18.42, "lmcs_compress": 118.3, "deep_assemble": 23.06,
-                      "fri_leaf_hash": 12.93, "deep_ood_eval": 11.3, "total": 743.9}
+SINGLE_GPU_MS_2P24 = {"lmcs_leaf_absorb": 379.64, "lde": 189.71, "lde_intt": 18.0, "lmcs_compress": 117.35, "deep_assemble": 23.16,
+                      "fri_leaf_hash": 12.13, "deep_ood_eval": 11.3, "total": 739.4}
 XGMI_GBS_PER_LINK_DIR = 60.0   # achievable per direction per link (MI355X: 7 links x ~153 GB/s bidirectional peak per GPU, point to point)
 HOST_SERIAL_MS = 3.3            # ~10 tree tops of one wave per level (2.5), grinding (0.2), ~30 transcript round trips (0.6)
 
