@@ -95,6 +95,7 @@ unsafe extern "C" {
     // ---- traces ----
     pub fn mh_trace_upload(ctx: *mut mh_ctx, rowmajor: *const u64, log_n: c_int, width: usize, out: *mut *mut mh_trace) -> c_int;
     pub fn mh_trace_upload_async(ctx: *mut mh_ctx, rowmajor: *const u64, log_n: c_int, width: usize, out: *mut *mut mh_trace) -> c_int;
+    pub fn mh_trace_upload_cols_async(ctx: *mut mh_ctx, colmajor: *const u64, log_n: c_int, width: usize, out: *mut *mut mh_trace) -> c_int;
     pub fn mh_trace_wait(ctx: *mut mh_ctx, t: *mut mh_trace) -> c_int;
     pub fn mh_trace_from_device(ctx: *mut mh_ctx, device_rowmajor: *const u64, log_n: c_int, width: usize, out: *mut *mut mh_trace) -> c_int;
     pub fn mh_trace_download(ctx: *mut mh_ctx, t: *const mh_trace, rowmajor_out: *mut u64) -> c_int;

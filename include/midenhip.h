@@ -82,6 +82,11 @@ int mh_trace_upload(mh_ctx* ctx, const uint64_t* rowmajor, int log_n, size_t wid
  * until the proof has been made (or mh_trace_wait has returned).  Reference: prover/src/lib.rs:317-355 hands over host
  * RowMajorMatrix values. */
 int mh_trace_upload_async(mh_ctx* ctx, const uint64_t* rowmajor, int log_n, size_t width, mh_trace** out);
+/* The same for a COLUMN-major host matrix, colmajor[c * 2^log_n + r] (a trace builder that writes columns: SURVEY 8(f) #4).
+ * Every column is one contiguous copy and there is no transpose, so ONE matrix pipelines too: the columns go up in groups of
+ * eight, and the LDE of a group starts when that group has landed -- the exposed part of the upload is the first group.  (A
+ * row-major matrix cannot be split like this: its column windows move at 16-36 GB/s.)  Same lifetime rules as above. */
+int mh_trace_upload_cols_async(mh_ctx* ctx, const uint64_t* colmajor, int log_n, size_t width, mh_trace** out);
 /* Blocks until the upload of `t` has landed (the host buffer may be reused) and releases its landing buffer. */
 int mh_trace_wait(mh_ctx* ctx, mh_trace* t);
 /* The same for a row-major matrix that is already in device memory (a GPU trace generator): no PCIe traffic. */

@@ -21,7 +21,7 @@ u64p = C.POINTER(C.c_uint64)
 
 EXPORTS = [
     "mh_ctx_create", "mh_ctx_destroy", "mh_ctx_trim", "mh_last_error", "mh_device_count", "mh_prof_enable", "mh_prof_filter", "mh_prof_reset",
-    "mh_prof_get", "mh_prof_dump", "mh_poseidon2_permute", "mh_poseidon2_register_rate", "mh_coset_lde_batch", "mh_trace_upload", "mh_trace_upload_async", "mh_trace_wait", "mh_trace_free",
+    "mh_prof_get", "mh_prof_dump", "mh_poseidon2_permute", "mh_poseidon2_register_rate", "mh_coset_lde_batch", "mh_trace_upload", "mh_trace_upload_async", "mh_trace_upload_cols_async", "mh_trace_wait", "mh_trace_free",
     "mh_commit_traces", "mh_tree_free", "mh_tree_root", "mh_tree_log_height", "mh_tree_open", "mh_tree_download_lde",
     "mh_tree_download_layers", "mh_air_load", "mh_air_free", "mh_air_log_quotient_degree", "mh_air_compiled_chunks", "mh_air_compiled_max_vgprs", "mh_prove", "mh_prove_host", "mh_proof_free",
     "mh_proof_num_fields", "mh_proof_num_commitments", "mh_proof_fields", "mh_proof_commitments", "mh_proof_digest",
@@ -229,6 +229,21 @@ class Trace:
         ctx.check(ctx.lib.mh_trace_upload_async(ctx.h, _ptr(m), log_n, C.c_size_t(w), C.byref(h)))
         t = cls.from_handle(ctx, h, log_n, w)
         t._source = m  # keeps the host buffer alive as long as the trace
+        return t
+
+    @classmethod
+    def upload_cols_async(cls, ctx, pinned_colmajor):
+        """mh_trace_upload_cols_async: `pinned_colmajor` is the TRANSPOSED matrix, shape (width, 2^log_n), C-contiguous (a pinned_array):
+        columns go up in groups of eight, the LDE of a group starts when it has landed."""
+        m = pinned_colmajor
+        assert m.dtype == np.uint64 and m.flags["C_CONTIGUOUS"] and m.ndim == 2
+        w, n = m.shape
+        log_n = int(n).bit_length() - 1
+        assert 1 << log_n == n, "trace height must be a power of two"
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mh_trace_upload_cols_async(ctx.h, _ptr(m), log_n, C.c_size_t(w), C.byref(h)))
+        t = cls.from_handle(ctx, h, log_n, w)
+        t._source = m
         return t
 
     def wait(self):

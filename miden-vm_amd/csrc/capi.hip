@@ -213,6 +213,14 @@ int mh_trace_upload_async(mh_ctx* c, const uint64_t* rowmajor, int log_n, size_t
   *out = trace_upload_async(c, rowmajor, log_n, width);
   MH_CATCH
 }
+int mh_trace_upload_cols_async(mh_ctx* c, const uint64_t* colmajor, int log_n, size_t width, mh_trace** out) {
+  MH_TRY(c)
+  MH_REQUIRE(c && colmajor && out, "null argument");
+  MH_REQUIRE(log_n >= 0 && log_n <= 29 && width > 0, "bad trace shape");
+  HIP_CHECK(hipSetDevice(c->device));
+  *out = trace_upload_cols_async(c, colmajor, log_n, width);
+  MH_CATCH
+}
 int mh_trace_wait(mh_ctx* c, mh_trace* t) {
   MH_TRY(c)
   MH_REQUIRE(c && t, "null argument");

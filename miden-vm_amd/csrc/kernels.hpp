@@ -25,15 +25,20 @@ struct mh_trace {
   // consumer on the compute stream orders itself after it with trace_wait_ready() (a stream-side wait, no host block).
   hipEvent_t ready = nullptr;
   DevBuf staging;  // the row-major landing buffer of the DMA, released once the trace has been consumed
+  // mh_trace_upload_cols_async (a COLUMN-major host matrix): the columns arrive in groups of `col_group`; group g is complete behind
+  // col_ready[g] (`ready` = the last of them), so the LDE of group g runs while group g + 1 is still on the PCIe link.
+  size_t col_group = 0;
+  std::vector<hipEvent_t> col_ready;
   ~mh_trace() {
-    if (ready) {
-      (void)hipEventSynchronize(ready);  // the copy stream may still be writing cols / reading staging
-      (void)hipEventDestroy(ready);
-    }
+    if (ready) (void)hipEventSynchronize(ready);  // the copy stream may still be writing cols / reading staging
+    for (hipEvent_t e : col_ready)
+      if (e != ready) (void)hipEventDestroy(e);
+    if (ready) (void)hipEventDestroy(ready);
   }
 };
 // Order everything enqueued on c->stream from here on after the trace's upload (no-op for a synchronously uploaded trace).
 void trace_wait_ready(mh_ctx* c, const mh_trace* t);
+mh_trace* trace_upload_cols_async(mh_ctx* c, const u64* colmajor, int log_n, size_t width);
 
 // A committed (LDE'd) matrix: coset-major column-major: lde[(c*B + j)*N + r] = f_c(shift*w_K^j*w_H^r)
 // = evaluation at natural index i = r*B + j of the max-domain-lifted polynomial.

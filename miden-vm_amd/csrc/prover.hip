@@ -76,6 +76,37 @@ mh_trace* trace_upload_async(mh_ctx* c, const u64* rowmajor, int log_n, size_t w
   HIP_CHECK(hipEventRecord(t->ready, c->copy_stream));
   return t.release();
 }
+// A COLUMN-major host matrix ([width][2^log_n], e.g. a trace builder that writes columns: SURVEY 8(f) #4): every column is one
+// contiguous 8 * N-byte DMA, there is no transpose, and the matrix CAN be pipelined -- groups of eight columns, one event each; the
+// LDE of a group (lde_trace_cosets) waits for that group only.  Values are canonicalised in place behind the copy.
+__global__ void k_canon_inplace(u64* p, size_t n) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < n) p[i] = gl_canon(p[i]);
+}
+mh_trace* trace_upload_cols_async(mh_ctx* c, const u64* colmajor, int log_n, size_t width) {
+  const size_t n = (size_t)1 << log_n;
+  std::unique_ptr<mh_trace> t(new mh_trace());
+  t->ctx = c; t->log_n = log_n; t->width = width;
+  if (width == 0) return t.release();
+  if (!c->copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  t->cols.alloc(n * width * 8);
+  hipEvent_t fence = c->get_event();  // pooled buffer: whatever the compute stream still does with its previous contents comes first
+  HIP_CHECK(hipEventRecord(fence, c->stream));
+  HIP_CHECK(hipStreamWaitEvent(c->copy_stream, fence, 0));
+  c->event_pool.push_back(fence);
+  t->col_group = 8;
+  for (size_t g0 = 0; g0 < width; g0 += t->col_group) {
+    const size_t gc = std::min(t->col_group, width - g0), words = gc * n;
+    HIP_CHECK(hipMemcpyAsync(t->cols.u() + g0 * n, colmajor + g0 * n, words * 8, hipMemcpyHostToDevice, c->copy_stream));
+    MH_LAUNCH(k_canon_inplace, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, c->copy_stream, t->cols.u() + g0 * n, words);
+    hipEvent_t e = nullptr;
+    HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    t->col_ready.push_back(e);
+    HIP_CHECK(hipEventRecord(e, c->copy_stream));
+  }
+  t->ready = t->col_ready.back();
+  return t.release();
+}
 void trace_wait_ready(mh_ctx* c, const mh_trace* t) {
   if (t && t->ready) HIP_CHECK(hipStreamWaitEvent(c->stream, t->ready, 0));
 }
@@ -128,12 +159,21 @@ LdeMatrix lde_trace_cosets(mh_ctx* c, const mh_trace* tr, int lb, size_t first, 
   m.coset0 = first;
   while (((size_t)1 << m.log_cosets) < count) m.log_cosets++;
   if (tr->width == 0) return m;  // an AIR without aux columns still owns a (width-0) slot of the aux tree
-  trace_wait_ready(c, tr);
   m.lde.alloc(N * count * tr->width * 8);
   DevBuf scratch(N * tr->width * 8);
   std::vector<u64> all = coset_shifts(tr->log_n, lb);
   std::vector<u64> mine(all.begin() + first, all.begin() + first + count);
   ProfScope ps(c, "lde", (double)(1 + count) * N * tr->width * 8.0);
+  if (tr->col_group && !tr->col_ready.empty()) {
+    // a column-major upload still in flight: extend each group of columns as soon as it has landed
+    for (size_t g = 0, g0 = 0; g0 < tr->width; g++, g0 += tr->col_group) {
+      const size_t gc = std::min(tr->col_group, tr->width - g0);
+      HIP_CHECK(hipStreamWaitEvent(c->stream, tr->col_ready[g], 0));
+      lde_columns(c, tr->cols.u() + g0 * N, gc, tr->log_n, 1, mine, m.lde.u() + g0 * count * N, scratch.u() + g0 * N);
+    }
+    return m;
+  }
+  trace_wait_ready(c, tr);
   lde_columns(c, tr->cols.u(), tr->width, tr->log_n, 1, mine, m.lde.u(), scratch.u());
   return m;
 }

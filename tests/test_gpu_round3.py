@@ -268,3 +268,31 @@ def test_pipelined_commit_gives_the_same_proof(lmcs, mode):
         out = subprocess.check_output([sys.executable, "-c", code], env=env, text=True, timeout=600)
         outs.append([l for l in out.splitlines() if l.startswith("DIGEST")][0])
     assert outs[0] == outs[1]
+
+
+@pytest.mark.gpu
+def test_column_major_upload_pipelines_and_proves_the_same(ctx):
+    """mh_trace_upload_cols_async: a COLUMN-major host matrix goes up in groups of eight columns, the LDE of a group waits for that
+    group only; the committed matrix and the proof equal those of the row-major upload (51 columns: seven groups, the last one
+    short; a non-canonical cell is canonicalised on the way)."""
+    pkg = load_package()
+    rng = np.random.default_rng(31)
+    P = 0xFFFFFFFF00000001
+    log_n = 12
+    host = rng.integers(0, P, (1 << log_n, 51), dtype=np.uint64)
+    host[:, 0] = 0
+    host[5, 3] = 7
+    cm, _owner = pkg.pinned_array(ctx.lib, (51, 1 << log_n))
+    cm[:] = host.T
+    cm[3, 5] = np.uint64(7 + P)  # the same felt, non-canonical in memory (only felts below 2^32 - 1 have a second representative)
+    t_cols = pkg.Trace.upload_cols_async(ctx, cm)
+    t_rows = ctx.upload_trace(host)
+    assert (t_cols.download() == host).all()
+    air = dag.dummy_miden_air(51, 8)
+    dair = pkg.DeviceAir(ctx, air)
+    prm, st = dict(ob.PROD_PARAMS), ob.challenger_state()
+    pre = ob.protocol_pre_observe(prm, [])
+    t_cols2 = pkg.Trace.upload_cols_async(ctx, cm)  # proved while (possibly) still in flight
+    a = pkg.prove(ctx, [dair], [t_cols2], [], prm, st, pre, None)
+    b = pkg.prove(ctx, [dair], [t_rows], [], prm, st, pre, None)
+    assert (a.fields == b.fields).all() and (a.commitments == b.commitments).all()
