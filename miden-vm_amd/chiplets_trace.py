@@ -1,0 +1,517 @@
+"""Trace generator for the chiplets AIR (miden-vm_amd/chiplets_air.py): the five chiplet sections + padding, laid out as
+`Chiplets::fill_trace` does (processor/src/trace/chiplets/mod.rs:159-254), and the Poseidon2 permutation requests that go to the
+separate permutation AIR.
+
+What is restated (file:line of the reference):
+
+* section order, selector prefix columns, `chip_clk` = row + 1, padding rows `s0..s4 = 1`: processor/src/trace/chiplets/mod.rs:159-254,
+  `ChipletTraceFragment` (processor/src/trace/utils.rs:86-179: `prefix_one_cols`, payload at `col_start`, clock in the last column);
+* hasher controller: processor/src/trace/chiplets/hasher/mod.rs:118-470 (`permute`, `hash_control_block`, `hash_basic_block` with
+  RESPAN batches, `build_merkle_root`, `update_merkle_root`, `append_controller_permutation`, `verify_merkle_path`, the
+  permutation-request table with shared ids and multiplicities, padding to CONTROLLER_TRACE_ALIGNMENT = 8), rows
+  hasher/trace.rs:214-277; selector constants air/src/trace/chiplets/hasher.rs:53-66.  (Memoised replays of a block hash,
+  hasher/mod.rs:404-431, produce the same rows as hashing it again; not modelled);
+* bitwise: processor/src/trace/chiplets/bitwise/mod.rs:103-160 (8 rows per op, 4 bits per row from the most significant);
+* memory: processor/src/trace/chiplets/memory/mod.rs:225-330 and segment.rs (accesses sorted by ctx, word address, clock; the
+  word after the operation; delta limbs; `d_inv`; `is_same_ctx_and_addr`; the two word-address limbs), range-check requests
+  memory/mod.rs:170-222;
+* ACE: processor/src/trace/chiplets/ace/trace.rs:40-291, instruction.rs:30-48, processor/src/execution/operations/eval_circuit.rs:54-118;
+* kernel ROM: processor/src/trace/chiplets/kernel_rom/mod.rs:28-110 (one row per kernel procedure, sorted by digest bytes).
+
+`core_requests` lists, for a generated trace, the messages the CORE AIR would put on the chiplets / range-check buses for it
+(air/src/constraints/lookup/buses/chiplet_requests.rs and the range table, buses/block_stack_and_range_logcap.rs): the numeric mirror
+of the response encoders, used by the tests' bus stand-in (miden_statement.bus_standin_air) to close the statement.
+"""
+import numpy as np
+from . import miden_air as MA
+from . import chiplets_air as CA
+
+P = MA.P
+LINEAR_HASH, MP_VERIFY, MR_UPDATE_OLD, MR_UPDATE_NEW = (1, 0, 0), (1, 0, 1), (1, 1, 0), (1, 1, 1)
+RETURN_HASH, RETURN_STATE = (0, 0, 0), (0, 0, 1)
+CONTROLLER_TRACE_ALIGNMENT = 8
+OP_CYCLE_LEN = 8
+BITWISE_AND, BITWISE_XOR = 0, 1
+
+
+# ---- Poseidon2 on Python ints (sequential hasher operations; the vectorised form lives in miden_air) ---------------------------
+def permute(state):
+    """The reference permutation (crates/crypto/src/hash/algebraic_sponge/poseidon2/mod.rs:22-37), pinned by the KAT through
+    tests/test_chiplets_air.py."""
+    s = [int(x) % P for x in state]
+
+    def ext(s, rc):
+        return [x % P for x in MA._matmul_external([pow(s[i] + rc[i], 7, P) for i in range(12)])]
+
+    s = [x % P for x in MA._matmul_external(s)]
+    for r in range(4):
+        s = ext(s, MA.ARK_EXT_INITIAL[r])
+    for r in range(22):
+        s[0] = pow(s[0] + MA.ARK_INT[r], 7, P)
+        s = [x % P for x in MA._matmul_internal(s, MA.MAT_DIAG)]
+    for r in range(4):
+        s = ext(s, MA.ARK_EXT_TERMINAL[r])
+    return s
+
+
+def hash_elements(xs):
+    """Poseidon2::hash_elements (crates/crypto/src/hash/algebraic_sponge/mod.rs:215-265): capacity[0] = len mod 8, zero padding,
+    empty input -> zero digest."""
+    xs = [int(x) % P for x in xs]
+    if not xs:
+        return [0, 0, 0, 0]
+    s = [0] * 12
+    s[8] = len(xs) % 8
+    for i in range(0, len(xs), 8):
+        chunk = xs[i:i + 8]
+        s[0:8] = chunk + [0] * (8 - len(chunk)) if len(chunk) < 8 else chunk
+        s = permute(s)
+    return s[0:4]
+
+
+def merge(a, b, domain=0):
+    return permute(list(a) + list(b) + [0, domain, 0, 0])[0:4]
+
+
+class Hasher:
+    def __init__(self):
+        self.rows = []            # (selectors, state, node_index, mrupdate_id, is_boundary, direction_bit, perm_id)
+        self.perm_map, self.perm_requests = {}, []   # state -> id; [state, multiplicity]
+        self.mrupdate_id = 0
+
+    def next_row_addr(self):
+        return len(self.rows) + 1
+
+    def _record_perm_request(self, state):
+        key = tuple(state)
+        if key in self.perm_map:
+            self.perm_requests[self.perm_map[key]][1] += 1
+            return self.perm_map[key]
+        self.perm_map[key] = len(self.perm_requests)
+        self.perm_requests.append([list(state), 1])
+        return self.perm_map[key]
+
+    def _append_permutation(self, init_sel, final_sel, state, in_idx, out_idx, bnd_in, bnd_out, dir_in, dir_out):
+        state = [int(x) % P for x in state]
+        pid = self._record_perm_request(state)
+        self.rows.append((init_sel, state, in_idx, self.mrupdate_id, bnd_in, dir_in, pid))
+        out = permute(state)
+        self.rows.append((final_sel, out, out_idx, self.mrupdate_id, bnd_out, dir_out, pid))
+        return out
+
+    def permute(self, state):                                            # HPERM
+        addr = self.next_row_addr()
+        return addr, self._append_permutation(LINEAR_HASH, RETURN_STATE, state, 0, 0, 1, 1, 0, 0)
+
+    def hash_control_block(self, h1, h2, domain):
+        addr = self.next_row_addr()
+        out = self._append_permutation(LINEAR_HASH, RETURN_HASH, list(h1) + list(h2) + [0, domain, 0, 0], 0, 0, 1, 1, 0, 0)
+        return addr, out[0:4]
+
+    def hash_basic_block(self, batches):
+        """`batches`: the 8-felt op-group words of the block's op batches (one permutation each, RESPAN between them)."""
+        addr = self.next_row_addr()
+        st = list(batches[0]) + [0, 0, 0, 0]
+        if len(batches) == 1:
+            return addr, self._append_permutation(LINEAR_HASH, RETURN_HASH, st, 0, 0, 1, 1, 0, 0)[0:4]
+        st = self._append_permutation(LINEAR_HASH, RETURN_STATE, st, 0, 0, 1, 0, 0, 0)
+        for batch in batches[1:-1]:
+            st = self._append_permutation(LINEAR_HASH, RETURN_STATE, list(batch) + st[8:12], 0, 0, 0, 0, 0, 0)
+        out = self._append_permutation(LINEAR_HASH, RETURN_HASH, list(batches[-1]) + st[8:12], 0, 0, 0, 1, 0, 0)
+        return addr, out[0:4]
+
+    def _verify_merkle_path(self, value, path, index, main_sel):
+        assert path and (index >> len(path)) == 0
+        root, depth = list(value), len(path)
+        for i, sibling in enumerate(path):
+            is_last = i == depth - 1
+            b_i = index & 1
+            state = (root + list(sibling) if b_i == 0 else list(sibling) + root) + [0, 0, 0, 0]
+            b_next = 0 if is_last else (index >> 1) & 1
+            out = self._append_permutation(main_sel, RETURN_HASH if is_last else RETURN_STATE, state, index, index >> 1,
+                                           1 if i == 0 else 0, 1 if is_last else 0, b_i, b_next)
+            root, index = out[0:4], index >> 1
+        return root
+
+    def build_merkle_root(self, value, path, index):                      # MPVERIFY
+        addr = self.next_row_addr()
+        return addr, self._verify_merkle_path(value, path, index, MP_VERIFY)
+
+    def update_merkle_root(self, old_value, new_value, path, index):      # MRUPDATE
+        self.mrupdate_id += 1
+        addr = self.next_row_addr()
+        old_root = self._verify_merkle_path(old_value, path, index, MR_UPDATE_OLD)
+        new_root = self._verify_merkle_path(new_value, path, index, MR_UPDATE_NEW)
+        return addr, old_root, new_root
+
+    def section(self):
+        """-> uint64 [len, 20] controller rows incl. the padding to a multiple of 8."""
+        n = len(self.rows)
+        total = -(-n // CONTROLLER_TRACE_ALIGNMENT) * CONTROLLER_TRACE_ALIGNMENT
+        out = np.zeros((total, 20), dtype=np.uint64)
+        for r, (sel, state, idx, mid, bnd, dbit, pid) in enumerate(self.rows):
+            out[r, 0:3] = sel
+            out[r, 3:15] = state
+            out[r, 15:20] = (idx, mid, bnd, dbit, pid)
+        out[n:, 1] = 1                         # padding selectors [0, 1, 0]
+        out[n:, 16] = self.mrupdate_id
+        return out
+
+
+class Bitwise:
+    def __init__(self):
+        self.ops = []
+
+    def u32and(self, a, b):
+        self.ops.append((BITWISE_AND, int(a), int(b)))
+        return int(a) & int(b)
+
+    def u32xor(self, a, b):
+        self.ops.append((BITWISE_XOR, int(a), int(b)))
+        return int(a) ^ int(b)
+
+    def section(self):
+        out = np.zeros((len(self.ops) * OP_CYCLE_LEN, 13), dtype=np.uint64)
+        for k, (op, a, b) in enumerate(self.ops):
+            assert 0 <= a < 1 << 32 and 0 <= b < 1 << 32
+            result = 0
+            for i, off in enumerate(range(28, -1, -4)):
+                prev = result
+                aa, ba = a >> off, b >> off
+                r4 = ((aa & ba) if op == BITWISE_AND else (aa ^ ba)) & 0xF
+                result = (result << 4) | r4
+                out[k * 8 + i] = [op, aa, ba] + [(aa >> j) & 1 for j in range(4)] + [(ba >> j) & 1 for j in range(4)] + [prev, result]
+        return out
+
+
+class Memory:
+    def __init__(self):
+        self.trace = {}   # ctx -> {word_addr -> [(clk, is_read, is_word, idx, word)]}
+        self.num_rows = 0
+
+    def _addr_trace(self, ctx, addr):
+        idx = addr % 4
+        return self.trace.setdefault(int(ctx), {}).setdefault(addr - idx, []), idx
+
+    def read(self, ctx, addr, clk):
+        t, idx = self._addr_trace(ctx, int(addr))
+        word = list(t[-1][4]) if t else [0, 0, 0, 0]
+        assert not (t and t[-1][0] == clk and not t[-1][1]), "read after write in the same cycle"
+        t.append((int(clk), 1, 0, idx, word))
+        self.num_rows += 1
+        return word[idx]
+
+    def read_word(self, ctx, addr, clk):
+        assert addr % 4 == 0
+        t, _ = self._addr_trace(ctx, int(addr))
+        word = list(t[-1][4]) if t else [0, 0, 0, 0]
+        assert not (t and t[-1][0] == clk and not t[-1][1]), "read after write in the same cycle"
+        t.append((int(clk), 1, 1, 0, word))
+        self.num_rows += 1
+        return word
+
+    def write(self, ctx, addr, clk, value):
+        t, idx = self._addr_trace(ctx, int(addr))
+        assert not (t and t[-1][0] == clk), "two accesses with a write in the same cycle"
+        word = list(t[-1][4]) if t else [0, 0, 0, 0]
+        word[idx] = int(value) % P
+        t.append((int(clk), 0, 0, idx, word))
+        self.num_rows += 1
+
+    def write_word(self, ctx, addr, clk, word):
+        assert addr % 4 == 0
+        t, _ = self._addr_trace(ctx, int(addr))
+        assert not (t and t[-1][0] == clk), "two accesses with a write in the same cycle"
+        t.append((int(clk), 0, 1, 0, [int(x) % P for x in word]))
+        self.num_rows += 1
+
+    def section(self):
+        """-> uint64 [rows, 17]: MemoryCols (15) + the two word-address limbs."""
+        out = np.zeros((self.num_rows, 17), dtype=np.uint64)
+        r, prev = 0, None
+        deltas = []
+        for ctx in sorted(self.trace):
+            for addr in sorted(self.trace[ctx]):
+                for clk, is_read, is_word, idx, word in self.trace[ctx][addr]:
+                    if prev is None:
+                        prev = (ctx, addr, (clk - 1) % P)
+                    if prev[0] != ctx:
+                        delta = ctx - prev[0]
+                    elif prev[1] != addr:
+                        delta = addr - prev[1]
+                    else:
+                        delta = (clk - prev[2]) % P
+                    assert 0 <= delta < 1 << 32
+                    same = 1 if (prev[0] == ctx and prev[1] == addr) else 0
+                    widx = addr // 4
+                    out[r] = [is_read, is_word, ctx, addr, idx & 1, idx >> 1, clk] + list(word) + [delta & 0xFFFF, delta >> 16, 0, same,
+                                                                                               widx & 0xFFFF, widx >> 16]
+                    deltas.append(delta)
+                    prev = (ctx, addr, clk)
+                    r += 1
+        for i, d in enumerate(deltas):
+            out[i, 13] = pow(d, P - 2, P) if d else 0
+        return out
+
+
+def encode_ace_instruction(id_l, id_r, op):
+    """instruction.rs: id_l | id_r << 30 | op << 60 with op = 0 (sub), 1 (mul), 2 (add)."""
+    return id_l | (id_r << 30) | ({"sub": 0, "mul": 1, "add": 2}[op] << 60)
+
+
+def _qmul(a, b):
+    return ((a[0] * b[0] + 7 * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+class Ace:
+    def __init__(self):
+        self.evals = {}   # clk -> rows
+
+    def eval_circuit(self, memory, ctx, ptr, clk, num_vars, num_eval):
+        """eval_circuit_impl: READ rows consume words (two wires each), EVAL rows one instruction element each; the last wire must
+        be zero.  Returns the rows of this evaluation (16 columns each)."""
+        assert num_vars % 2 == 0 and num_vars > 0 and num_eval % 4 == 0 and num_eval > 0
+        n_read = num_vars // 2
+        num_wires = 2 * n_read + num_eval
+        wires, id_next = [], num_wires - 1
+        reads, evals = [], []
+
+        def insert(v):
+            nonlocal id_next
+            wires.append([v, 0])
+            wid = id_next
+            id_next -= 1
+            return wid
+
+        def read_value(wid):
+            w = wires[num_wires - wid - 1]
+            w[1] += 1
+            return w[0]
+
+        for _ in range(n_read):
+            word = memory.read_word(ctx, ptr, clk)
+            v0, v1 = (word[0], word[1]), (word[2], word[3])
+            id0 = insert(v0)
+            id1 = insert(v1)
+            reads.append((ptr, id0, v0, id1, v1))
+            ptr += 4
+        for _ in range(num_eval):
+            ins = memory.read(ctx, ptr, clk)
+            id_l, id_r, opc = ins & ((1 << 30) - 1), (ins >> 30) & ((1 << 30) - 1), ins >> 60
+            vl, vr = read_value(id_l), read_value(id_r)
+            if opc == 0:
+                v0, eval_op = ((vl[0] - vr[0]) % P, (vl[1] - vr[1]) % P), P - 1
+            elif opc == 1:
+                v0, eval_op = _qmul(vl, vr), 0
+            else:
+                assert opc == 2
+                v0, eval_op = ((vl[0] + vr[0]) % P, (vl[1] + vr[1]) % P), 1
+            id0 = insert(v0)
+            evals.append((ptr, eval_op, id0, v0, id_l, vl, id_r, vr))
+            ptr += 1
+        assert wires[-1][0] == (0, 0), "circuit does not evaluate to zero"
+        rows = np.zeros((n_read + num_eval, 16), dtype=np.uint64)
+        mult = iter(m for _, m in wires)
+        for i, (p_, id0, v0, id1, v1) in enumerate(reads):
+            m0 = next(mult)
+            m1 = next(mult)
+            rows[i] = [1 if i == 0 else 0, 0, ctx, p_, clk, 0, id0, v0[0], v0[1], id1, v1[0], v1[1], num_eval - 1, 0, m1, m0]
+        for i, (p_, eval_op, id0, v0, id1, v1, id2, v2) in enumerate(evals):
+            rows[n_read + i] = [0, 1, ctx, p_, clk, eval_op, id0, v0[0], v0[1], id1, v1[0], v1[1], id2, v2[0], v2[1], next(mult)]
+        self.evals[int(clk)] = rows
+        return rows
+
+    def section(self):
+        rows = [self.evals[c] for c in sorted(self.evals)]
+        return np.concatenate(rows) if rows else np.zeros((0, 16), dtype=np.uint64)
+
+
+class KernelRom:
+    def __init__(self, proc_hashes=()):
+        def key(d):   # ProcHashBytes: the canonical little-endian bytes of the four felts, compared lexicographically
+            return b"".join(int(x).to_bytes(8, "little") for x in d)
+        self.procs = {key(d): [[int(x) % P for x in d], 0] for d in proc_hashes}
+        self._key = key
+
+    def access_proc(self, digest):
+        self.procs[self._key(digest)][1] += 1
+
+    def digests(self):
+        """The kernel digests in trace order = the order of `aux_inputs[8..]` that balances the INIT removes."""
+        return [self.procs[k][0] for k in sorted(self.procs)]
+
+    def section(self):
+        out = np.zeros((len(self.procs), 5), dtype=np.uint64)
+        for r, k in enumerate(sorted(self.procs)):
+            out[r] = [self.procs[k][1]] + self.procs[k][0]
+        return out
+
+
+class Chiplets:
+    def __init__(self, kernel_proc_hashes=()):
+        self.hasher, self.bitwise, self.memory, self.ace = Hasher(), Bitwise(), Memory(), Ace()
+        self.kernel_rom = KernelRom(kernel_proc_hashes)
+
+    def trace_len(self):
+        h = -(-len(self.hasher.rows) // 8) * 8
+        return h + len(self.bitwise.ops) * 8 + self.memory.num_rows + sum(len(r) for r in self.ace.evals.values()) + len(self.kernel_rom.procs) + 1
+
+    def poseidon2_trace_len(self):
+        return (len(self.hasher.perm_requests) + 1) * MA.HASH_CYCLE_LEN
+
+    def into_traces(self, log_n=None, log_n_p2=None):
+        """-> (chiplets trace [2^log_n, 22], Poseidon2 permutation trace [2^log_n_p2, 16])."""
+        need, need_p2 = self.trace_len(), self.poseidon2_trace_len()
+        log_n = max(6, (need - 1).bit_length()) if log_n is None else log_n          # MIN_TRACE_LEN = 64
+        log_n_p2 = max(6, (need_p2 - 1).bit_length()) if log_n_p2 is None else log_n_p2
+        n = 1 << log_n
+        assert need <= n and need_p2 <= 1 << log_n_p2
+        t = np.zeros((n, CA.NUM_CHIPLETS_COLS), dtype=np.uint64)
+        row = 0
+        for col_start, prefix_ones, sec in ((1, 0, self.hasher.section()), (2, 1, self.bitwise.section()), (3, 2, self.memory.section()),
+                                            (4, 3, self.ace.section()), (5, 4, self.kernel_rom.section())):
+            k = sec.shape[0]
+            t[row:row + k, 0:prefix_ones] = 1
+            t[row:row + k, col_start:col_start + sec.shape[1]] = sec
+            row += k
+        t[row:, 0:5] = 1                                                       # fill_padding_rows
+        t[:, CA.CHIP_CLK] = np.arange(1, n + 1, dtype=np.uint64)
+        states = np.array([s for s, _ in self.hasher.perm_requests], dtype=np.uint64).reshape(-1, 12)
+        mults = np.array([m for _, m in self.hasher.perm_requests], dtype=np.uint64)
+        p2 = MA.poseidon2_permutation_trace(log_n_p2, states, mults)
+        return t, p2
+
+
+# ---- what the Core AIR would request for a chiplets trace (numeric mirror of the response encoders) ------------------------------
+def core_requests(trace):
+    """-> list of (bus, multiplicity, fields): the messages whose sum cancels the chiplets AIR's OPEN buses for `trace`:
+    * column 0 (responses, buses/chiplet_responses.rs): every response is requested once by the decoder / stack
+      (buses/chiplet_requests.rs) -> multiplicity -1; a kernel-ROM CALL response with multiplicity m is requested m times;
+      the kernel-ROM INIT removes are balanced by the statement's boundary correction, not by the Core AIR;
+    * column 1: the five range-check removes of every memory row are added by the range table
+      (buses/block_stack_and_range_logcap.rs) -> multiplicity +1 each.  The sibling table, the ACE memory reads and the ACE
+      wires close inside the chiplets AIR, the perm-link against the permutation AIR."""
+    out = []
+    n = trace.shape[0]
+    t = [[int(x) for x in row] for row in trace]
+    # the ACE chiplet's own memory reads (hash_kernel.rs:170-213): requested by the chiplets AIR itself, not by the Core AIR
+    ace_reads = {}
+    for row in t:
+        if row[0:4] == [1, 1, 1, 0]:
+            key = (row[6], row[7], row[8], 1 - row[5])   # ctx, ptr, clk, is_word (READ rows read words, EVAL rows elements)
+            ace_reads[key] = ace_reads.get(key, 0) + 1
+    for r in range(n):
+        row = t[r]
+        nxt = t[(r + 1) % n]
+        s = row[0:5]
+        clk = row[CA.CHIP_CLK]
+        if s[0] == 0:                                        # hasher controller
+            hs0, hs1, hs2 = row[1:4]
+            st, idx, bnd = row[4:16], row[16], row[18]
+            if hs0 == 1:
+                if (hs1, hs2) == (0, 0):
+                    if bnd:
+                        out.append((CA.BUS_HASHER_LINEAR_HASH_INIT, -1, [clk, 0] + st))
+                    else:
+                        out.append((CA.BUS_HASHER_ABSORPTION, -1, [clk, 0] + st[0:8]))
+                elif bnd:
+                    bit = (idx - 2 * nxt[16]) % P
+                    word = [((1 - bit) * st[i] + bit * st[4 + i]) % P for i in range(4)]
+                    bus = {(0, 1): CA.BUS_HASHER_MERKLE_VERIFY_INIT, (1, 0): CA.BUS_HASHER_MERKLE_OLD_INIT, (1, 1): CA.BUS_HASHER_MERKLE_NEW_INIT}[(hs1, hs2)]
+                    out.append((bus, -1, [clk, idx] + word))
+            elif hs1 == 0:
+                if hs2 == 0:
+                    out.append((CA.BUS_HASHER_RETURN_HASH, -1, [clk, idx] + st[0:4]))
+                elif bnd:
+                    out.append((CA.BUS_HASHER_RETURN_STATE, -1, [clk, 0] + st))
+        elif s[1] == 0:                                      # bitwise: responds on the last row of a cycle
+            if r % 8 == 7:
+                out.append((CA.BUS_BITWISE, -1, [row[2], row[3], row[4], row[14]]))
+        elif s[2] == 0:                                      # memory
+            m = row[3:20]
+            is_read, is_word, ctx, waddr, idx0, idx1, mclk = m[0:7]
+            word = m[7:11]
+            addr = waddr + 2 * idx1 + idx0
+            for v in (m[11], m[12], m[15], m[16], 4 * m[16]):
+                out.append((CA.BUS_RANGE_CHECK, 1, [v]))
+            if is_read and ace_reads.get((ctx, addr, mclk, is_word), 0):
+                ace_reads[(ctx, addr, mclk, is_word)] -= 1
+                continue
+            if is_word:
+                out.append((CA.BUS_MEMORY_READ_WORD if is_read else CA.BUS_MEMORY_WRITE_WORD, -1, [ctx, addr, mclk] + word))
+            else:
+                out.append((CA.BUS_MEMORY_READ_ELEMENT if is_read else CA.BUS_MEMORY_WRITE_ELEMENT, -1, [ctx, addr, mclk, word[2 * idx1 + idx0]]))
+        elif s[3] == 0:                                      # ACE: the init message on start rows
+            a = row[4:20]
+            if a[0] == 1:
+                num_eval = a[12] + 1
+                out.append((CA.BUS_ACE_INIT, -1, [a[4], a[2], a[3], (a[6] + 1 - num_eval) % P, num_eval]))
+        elif s[4] == 0:                                      # kernel ROM: CALL with the syscall multiplicity
+            if row[5]:
+                out.append((CA.BUS_KERNEL_ROM_CALL, -row[5], row[6:10]))
+    return out
+
+
+# ---- a mixed workload (tests, benches) ---------------------------------------------------------------------------------------------
+def sample_chiplets(seed=0, n_hperm=3, n_hash=2, n_blocks=2, merkle_depth=3, n_mrupdate=1, n_bitwise=5, n_mem=12, ace=True, kernel_procs=2,
+                    syscalls=(2, 0)):
+    """A small program's worth of chiplet activity touching every section and every hasher operation kind."""
+    rng = np.random.default_rng(seed)
+
+    def felt():
+        return int(rng.integers(0, P, dtype=np.uint64))
+
+    def word():
+        return [int(x) for x in rng.integers(0, P, 4, dtype=np.uint64)]
+
+    procs = [word() for _ in range(kernel_procs)]
+    c = Chiplets(procs)
+    for _ in range(n_hperm):
+        c.hasher.permute([int(x) for x in rng.integers(0, P, 12, dtype=np.uint64)])
+    for _ in range(n_hash):
+        c.hasher.hash_control_block(word(), word(), int(rng.integers(0, 64)))
+    for k in range(n_blocks):
+        c.hasher.hash_basic_block([[int(x) for x in rng.integers(0, P, 8, dtype=np.uint64)] for _ in range(1 + k * 2)])
+    if merkle_depth:
+        leaf, path = word(), [word() for _ in range(merkle_depth)]
+        index = int(rng.integers(0, 1 << merkle_depth))
+        c.hasher.build_merkle_root(leaf, path, index)
+        for _ in range(n_mrupdate):
+            c.hasher.update_merkle_root(leaf, word(), path, index)
+    if n_hperm:
+        c.hasher.permute(c.hasher.perm_requests[0][0])          # a repeated input state: shared perm id, multiplicity 2
+    for k in range(n_bitwise):
+        a, b = int(rng.integers(0, 1 << 32)), int(rng.integers(0, 1 << 32))
+        (c.bitwise.u32and if k % 2 == 0 else c.bitwise.u32xor)(a, b)
+    clk = 1
+    for k in range(n_mem):
+        ctx = int(rng.integers(0, 2)) * 3
+        addr = int(rng.integers(0, 6)) * 4 + (1 << 18) * int(rng.integers(0, 2))
+        kind = k % 4
+        if kind == 0:
+            c.memory.write_word(ctx, addr, clk, word())
+        elif kind == 1:
+            c.memory.write(ctx, addr + int(rng.integers(0, 4)), clk, felt())
+        elif kind == 2:
+            c.memory.read_word(ctx, addr, clk)
+        else:
+            c.memory.read(ctx, addr + int(rng.integers(0, 4)), clk)
+        clk += 1 + int(rng.integers(0, 3))
+    if ace:
+        # circuit (x0 * x1 - x2) + 0 ... over 4 variables and 4 gates, evaluating to zero: x2 = x0 * x1, x3 = 0
+        ctx, ptr = 0, 1 << 10
+        x0, x1 = (felt(), felt()), (felt(), felt())
+        x2 = _qmul(x0, x1)
+        c.memory.write_word(ctx, ptr, clk, [x0[0], x0[1], x1[0], x1[1]])
+        c.memory.write_word(ctx, ptr + 4, clk + 1, [x2[0], x2[1], 0, 0])
+        # wires: ids 7, 6 (x0, x1), 5, 4 (x2, x3 = 0); gates get ids 3, 2, 1, 0
+        ins = [encode_ace_instruction(7, 6, "mul"),     # id 3 = x0 * x1
+               encode_ace_instruction(3, 5, "sub"),     # id 2 = x0 x1 - x2 = 0
+               encode_ace_instruction(2, 4, "add"),     # id 1 = 0 + x3 = 0
+               encode_ace_instruction(1, 2, "mul")]     # id 0 = 0
+        c.memory.write_word(ctx, ptr + 8, clk + 2, ins)
+        c.ace.eval_circuit(c.memory, ctx, ptr, clk + 3, 4, 4)
+    for d, k in zip(procs, syscalls):
+        for _ in range(k):
+            c.kernel_rom.access_proc(d)
+    return c

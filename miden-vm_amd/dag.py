@@ -26,14 +26,31 @@ class Expr:
     def _lift(self, o):
         return o if isinstance(o, Expr) else self.b.const(o)
 
+    def _const(self):
+        """The value of a constant node, else None (x * 1, x + 0, x * 0 and constant pairs are folded: same values, fewer gates)."""
+        n = self.b.nodes[self.id]
+        return n[3] if n[0] == OP_CONST else None
+
     def __add__(self, o):
         o = self._lift(o)
+        a, c = self._const(), o._const()
+        if a is not None and c is not None:
+            return self.b.const(a + c)
+        if c == 0:
+            return self
+        if a == 0:
+            return o
         return self.b._node(OP_ADD, self.id, o.id, 0, max(self.deg, o.deg), self.ext or o.ext)
 
     __radd__ = __add__
 
     def __sub__(self, o):
         o = self._lift(o)
+        a, c = self._const(), o._const()
+        if a is not None and c is not None:
+            return self.b.const(a - c)
+        if c == 0:
+            return self
         return self.b._node(OP_SUB, self.id, o.id, 0, max(self.deg, o.deg), self.ext or o.ext)
 
     def __rsub__(self, o):
@@ -41,6 +58,15 @@ class Expr:
 
     def __mul__(self, o):
         o = self._lift(o)
+        a, c = self._const(), o._const()
+        if a is not None and c is not None:
+            return self.b.const(a * c)
+        if c == 1:
+            return self
+        if a == 1:
+            return o
+        if c == 0 or a == 0:
+            return self.b.const(0)
         return self.b._node(OP_MUL, self.id, o.id, 0, self.deg + o.deg, self.ext or o.ext)
 
     __rmul__ = __mul__
@@ -60,6 +86,7 @@ class AirBuilder:
         self.nodes = []        # (op, a, b, const)
         self.constraints = []  # node ids in emission order
         self.max_degree = 0
+        self.declared_degree = None  # LiftedAir::constraint_degree when the AIR declares it (air/src/lib.rs:686-692)
         self._cache = {}
 
     def _node(self, op, a, b, c, deg, ext):
@@ -127,7 +154,9 @@ class AirBuilder:
     # ---- lowering ----
     def log_quotient_degree(self):
         """crates/lifted-stark/src/domain.rs:585-598: ceil(log2(max(1, degree - 1)))."""
-        chunks = max(1, self.max_degree - 1)
+        degree = self.max_degree if self.declared_degree is None else self.declared_degree
+        assert degree >= self.max_degree, "declared constraint degree below the degree of an emitted constraint"
+        chunks = max(1, degree - 1)
         return (chunks - 1).bit_length()
 
     def blob(self):

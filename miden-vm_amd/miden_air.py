@@ -188,11 +188,12 @@ def _emit_perm_link(lk):
             g.insert((pc["f_row15"], pp["f_row15"]), (pc["mult"], pp["mult"]), message(BUS_HASHER_PERM_LINK_OUTPUT))
 
 
-def poseidon2_permutation_air(host_aux=None):
-    """-> (dag.Air, dag.Lookup).  The product path attaches the Lookup to the DeviceAir (the aux column is built on the GPU);
+def poseidon2_permutation_air(host_aux=None, num_public=0):
+    """-> (dag.Air, dag.Lookup).  `num_public` = 32 inside the Miden statement (every `MidenAir` declares NUM_PUBLIC_VALUES,
+    air/src/lib.rs:660-662; this AIR reads none of them), 0 for the stand-alone instance.  The product path attaches the Lookup to the DeviceAir (the aux column is built on the GPU);
     `host_aux(lookup, main, randomness) -> (aux, final)` gives the Air a host-side `build_aux_trace` callback instead (a caller
     that keeps the reference's build_logup_aux_trace on the CPU, or a test's CPU checker)."""
-    b = dag.AirBuilder(NUM_COLS, aux_width=1, num_randomness=2, num_aux_values=1, num_public=0, periodic=periodic_columns())
+    b = dag.AirBuilder(NUM_COLS, aux_width=1, num_randomness=2, num_aux_values=1, num_public=num_public, periodic=periodic_columns())
     _constraints(b)
     lk = dag.LogUp(b, MIDEN_MAX_MESSAGE_WIDTH, NUM_BUS_IDS)  # ConstraintLookupBuilder::new(builder, &MidenAir::Poseidon2Permutation)
     _emit_perm_link(lk)

@@ -14,6 +14,9 @@ Vectors:
      parameters, sizes of the OOD / aux-boundary / trace-row regions, per-AIR widths) and the production PCS parameters
      of air/src/config.rs:54-67: a second in-tree witness of how a Miden proof's streams are laid out.
   8. RPO hash_elements vectors ..... crates/crypto/src/hash/algebraic_sponge/rescue/rpo/tests.rs:241-267, 316-..
+  9. AIR column layouts ............ air/src/constraints/snapshots/*_col_map_layout.snap (insta snapshots of the #[repr(C)] column
+     structs: core, chiplets, hasher controller, bitwise, memory, ACE (+ read / eval overlays), kernel ROM) and the LogUp bus ids
+     air/src/constraints/lookup/messages.rs:55-107 -- what the hand-ported AIRs' column tables are held to.
 """
 import json, os, re
 REF = "/root/reference"
@@ -80,6 +83,44 @@ def main():
     ev = const_block(rt, "EXPECTED")
     assert len(ev) == 19 * 4
     out["rpo_hash_elements"] = [ev[4*i:4*i+4] for i in range(19)]
+    # 9. column-layout snapshots and bus ids
+    import glob
+    layouts = {}
+    for path in sorted(glob.glob(f"{REF}/air/src/constraints/snapshots/*_col_map_layout.snap")):
+        name = re.search(r"tests__(\w+)_col_map_layout", path).group(1)
+        body = open(path).read().split("---")[-1]
+        flat = {}
+        # `field: 3,`, `field: [3, 4,],`, `field: QuadFeltExpr(7, 8,),`, nested struct names are prefixes
+        stack = []
+        for line in body.splitlines():
+            line = line.strip()
+            mm = re.match(r"(\w+): (\w+) \{$", line) or re.match(r"^(\w+) \{$", line)
+            if mm:
+                stack.append(mm.group(1) if mm.lastindex == 2 else "")
+                continue
+            if line.startswith("}"):
+                stack and stack.pop()
+                continue
+            mm = re.match(r"(\w+): (\d+),$", line)
+            if mm:
+                flat[".".join([x for x in stack if x] + [mm.group(1)])] = int(mm.group(2))
+                continue
+            mm = re.match(r"(\w+): (\[|QuadFeltExpr\()$", line)
+            if mm:
+                stack.append("@" + mm.group(1))
+                flat[".".join([x for x in stack[:-1] if x] + [mm.group(1)])] = []
+                continue
+            mm = re.match(r"(\d+),$", line)
+            if mm and stack and stack[-1].startswith("@"):
+                flat[".".join([x for x in stack[:-1] if x] + [stack[-1][1:]])].append(int(mm.group(1)))
+                continue
+            if line in ("],", "),"):
+                stack.pop()
+        layouts[name] = flat
+    out["col_maps"] = layouts
+    msg = open(f"{REF}/air/src/constraints/lookup/messages.rs").read()
+    enum = msg[msg.index("pub enum BusId"):msg.index("impl BusId")]
+    out["bus_ids"] = {k: int(v) for k, v in re.findall(r"(\w+) = (\d+),", enum)}
     with open(os.path.join(HERE, "kat.json"), "w") as f:
         json.dump(out, f, indent=0)
     print("wrote kat.json:", {k: (len(v) if hasattr(v, '__len__') else v) for k, v in out.items()})

@@ -3,6 +3,7 @@
 (miden-vm_amd/miden_air.py) as little-endian u64 files a non-Python host loads with mh_air_load / mh_lookup_load:
 
     miden-vm_amd/blobs/poseidon2_permutation.dag     miden-vm_amd/blobs/poseidon2_permutation.lkp
+    miden-vm_amd/blobs/chiplets.dag                  miden-vm_amd/blobs/chiplets.lkp      (ChipletsAir, miden-vm_amd/chiplets_air.py)
 
 tests/test_miden_p2_air.py::test_committed_blobs_are_current keeps them equal to what the module generates."""
 import os, sys
@@ -10,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 load_package()
-from miden_vm_amd import miden_air
+from miden_vm_amd import miden_air, chiplets_air
 
 air, lookup = miden_air.poseidon2_permutation_air()
 out = os.path.join(ROOT, "miden-vm_amd", "blobs")
@@ -18,3 +19,9 @@ os.makedirs(out, exist_ok=True)
 air.blob.astype("<u8").tofile(os.path.join(out, "poseidon2_permutation.dag"))
 lookup.blob.astype("<u8").tofile(os.path.join(out, "poseidon2_permutation.lkp"))
 print(f"constraint DAG: {air.blob.size} words ({int(air.blob[8])} nodes, {int(air.blob[9])} constraints); lookup program: {lookup.blob.size} words")
+
+# the chiplets AIR (miden-vm_amd/chiplets_air.py): chiplets.dag / chiplets.lkp
+air, lookup = chiplets_air.chiplets_air()
+air.blob.astype("<u8").tofile(os.path.join(out, "chiplets.dag"))
+lookup.blob.astype("<u8").tofile(os.path.join(out, "chiplets.lkp"))
+print(f"chiplets constraint DAG: {air.blob.size} words ({int(air.blob[8])} nodes, {int(air.blob[9])} constraints); lookup program: {lookup.blob.size} words")
