@@ -201,6 +201,105 @@ def in_flight_probe(pkg, log_n, device, k=3, steps=4):
             "note": "k proving threads, one context (HIP stream) each, same GPU; every proof is a complete independent proof"}
 
 
+def in_flight_h2d_probe(pkg, log_n, device, k=3, steps=6):
+    """The service loop with EVERY proof's host->device upload inside the timed region: k proving threads, each with its own
+    context and its own page-locked host trace (the reference's hand-over: a host RowMajorMatrix, prover/src/lib.rs:317-355).  A
+    thread keeps TWO traces in flight: the upload of proof j+1 (mh_trace_upload_async: DMA + transpose on the context's copy stream)
+    is issued before mh_prove of proof j, so the 7.5 ms DMA rides under proof j's kernels (the SDMA engine does not slow a VALU-bound
+    kernel, profiles/r03_h2dbench.txt); `steps` uploads and `steps` proofs per thread lie inside the timed region, the first upload
+    of every thread exposed."""
+    import threading
+    ctxs = [pkg.Ctx(device) for _ in range(k)]
+    runners = [ProveRunner(pkg, c, log_n, 31 + i) for i, c in enumerate(ctxs)]
+    pins = []
+    for r in runners:
+        r.trace.free()
+        pin, owner = pkg.pinned_array(r.ctx.lib, r.host_trace.shape)
+        pin[:] = r.host_trace
+        pins.append((pin, owner))
+        r.step_with_upload(pin)
+    bar = threading.Barrier(k + 1)
+
+    def work(r, pin):
+        bar.wait()
+        nxt = pkg.Trace.upload_async(r.ctx, pin)
+        for i in range(steps):
+            cur, nxt = nxt, (pkg.Trace.upload_async(r.ctx, pin) if i + 1 < steps else None)
+            r.proof = pkg.prove(r.ctx, [r.dair], [cur], [], r.params, r.state, r.pre, None)
+            cur.free()
+        bar.wait()
+
+    th = [threading.Thread(target=work, args=(r, p[0])) for r, p in zip(runners, pins)]
+    for t in th:
+        t.start()
+    bar.wait()
+    t0 = time.perf_counter()
+    bar.wait()
+    dt = time.perf_counter() - t0
+    for t in th:
+        t.join()
+    for r in runners:
+        r.dair.free()
+    for c in ctxs:
+        c.close()
+    return {"proofs_in_flight": k, "proofs": k * steps, "value": k * steps * (1 << log_n) / dt, "unit": "trace rows/s",
+            "ms_per_proof_amortised": dt / (k * steps) * 1e3, "upload_bytes_per_proof": int(runners[0].host_trace.nbytes),
+            "note": "every proof = upload of its 2^%d x 51 row-major host trace (page-locked) + transpose + complete proof, all inside the "
+                    "timed region; k proving threads, one context each, same GPU; per thread the upload of proof j+1 is in flight under "
+                    "proof j" % log_n}
+
+
+def chiplets_air_probe(pkg, ctx, log_n=20, steps=3):
+    """The real ChipletsAir alone at 2^log_n rows (production parameters, aux columns on the device): what a real multi-chiplet
+    constraint system costs on the compiled constraint path -- quotient_eval_ms, chunks, VGPRs, logup_aux_ms -- and what loading it
+    costs (hiprtc cold = empty cache directory, cached = code objects from disk)."""
+    import shutil, tempfile
+    from miden_vm_amd import dag, protocol, chiplets_air, chiplets_trace
+    air, _ = chiplets_air.chiplets_air(num_public=0)
+    lookup = dag.lookup_from_constraints(air.blob)
+    tmp = tempfile.mkdtemp(prefix="mh_jit_cold_")
+    old = os.environ.get("MH_JIT_CACHE_DIR")
+    try:
+        os.environ["MH_JIT_CACHE_DIR"] = tmp
+        t0 = time.perf_counter()
+        d0, l0 = pkg.DeviceAir(ctx, air), pkg.DeviceLookup(ctx, lookup)
+        cold = time.perf_counter() - t0
+        d0.free()
+        t0 = time.perf_counter()
+        dair, dlk = pkg.DeviceAir(ctx, air), pkg.DeviceLookup(ctx, lookup)
+        cached = time.perf_counter() - t0
+    finally:
+        if old is None:
+            os.environ.pop("MH_JIT_CACHE_DIR", None)
+        else:
+            os.environ["MH_JIT_CACHE_DIR"] = old
+        shutil.rmtree(tmp, ignore_errors=True)
+    dair.attach_lookup(dlk)
+    trace, _ = chiplets_trace.bulk_chiplets(log_n, log_n, seed=2)
+    dtr = ctx.upload_trace(trace)
+    prm, st = dict(protocol.PROD_PARAMS), protocol.challenger_state()
+    pre = protocol.protocol_pre_observe(prm, [])
+    proof = pkg.prove(ctx, [dair], [dtr], [], prm, st, pre, None)
+    ok, _ = pkg.verify([air], [log_n], [], prm, st, pre, proof.fields, proof.commitments)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof = pkg.prove(ctx, [dair], [dtr], [], prm, st, pre, None)
+    dt = (time.perf_counter() - t0) / steps
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    pkg.prove(ctx, [dair], [dtr], [], prm, st, pre, None)
+    prof = ctx.prof()
+    ctx.prof_enable(False)
+    out = {"workload": f"ChipletsAir alone, 2^{log_n} x 22 + 3 EF aux, production parameters, bulk workload (hasher / bitwise / memory / kernel ROM)",
+           "constraints": int(air.blob[9]), "dag_nodes": int(air.blob[8]), "ms_per_proof": dt * 1e3, "rows_per_s": (1 << log_n) / dt, "verifies": bool(ok),
+           "quotient_eval_ms": prof.get("quotient_eval", {}).get("ms", 0), "logup_aux_ms": prof.get("logup_aux", {}).get("ms", 0),
+           "compiled_chunks": dair.compiled_chunks, "chunk_max_vgprs": dair.compiled_max_vgprs,
+           "jit_cold_s": cold, "jit_cached_ms": cached * 1e3}
+    dtr.free()
+    dair.free()
+    return out
+
+
 def hash_config_probe(pkg, device, log_n, lmcs, steps=5):
     """A complete proof (mh_prove: transcript, PoW search and openings included) of the bench instance under another of the
     reference's five StarkConfigs (air/src/config.rs:212-353; HashFunction::Blake3_256 is ProvingOptions::default())."""
@@ -243,27 +342,30 @@ def cpu_baseline(runner, cpu_log_n):
 
 def miden_shape_probe(pkg, ctx, steps=3):
     """The full Miden VM statement shape at 2^20 rows for every AIR (SURVEY.md section 8 sizes): main widths 51/22/16, aux 4/3/1
-    EF, one LogUp final per AIR.  Core and chiplets are degree-9 stand-ins (their constraint DAGs need the Rust exporter); the
-    THIRD instance is the real Poseidon2PermutationAir (miden-vm_amd/miden_air.py: 61 constraints of degree 8, 16 periodic
-    columns, the perm-link bus as a lookup program -- its aux column is built on the device).  Timed twice: traces resident, and
-    with the three host matrices uploaded inside the timed region (mh_trace_upload_async in proof order: matrices 2 and 3 land
-    under the LDE + leaf sponges of matrix 1)."""
+    EF, one LogUp final per AIR.  Core is a degree-9 stand-in (the core AIR is not ported yet); the SECOND instance is the real
+    ChipletsAir (miden-vm_amd/chiplets_air.py: 113 + 7 constraints of degree <= 9, 2 periodic columns, three LogUp columns) on a
+    bulk workload (chiplets_trace.bulk_chiplets), the THIRD the real Poseidon2PermutationAir (miden-vm_amd/miden_air.py: 61
+    constraints of degree 8, 16 periodic columns) holding exactly the permutations the chiplets trace requests; both AIRs' aux
+    columns are built on the device from the lookup programs derived from their constraint DAGs.  Timed twice: traces resident,
+    and with the three host matrices uploaded inside the timed region (mh_trace_upload_async in proof order: matrices 2 and 3
+    land under the LDE + leaf sponges of matrix 1)."""
     import numpy as np
-    from miden_vm_amd import dag, protocol, miden_air
-    p2, lookup = miden_air.poseidon2_permutation_air()
-    airs = [pkg.DeviceAir(ctx, dag.dummy_miden_air(51, 4, num_aux_values=1)), pkg.DeviceAir(ctx, dag.dummy_miden_air(22, 3, num_aux_values=1)),
-            pkg.DeviceAir(ctx, p2)]
-    airs[2].attach_lookup(pkg.DeviceLookup(ctx, lookup))
-    rng = np.random.default_rng(5)
-    k = (1 << 20) // 16 - 1
-    host = [synth_trace(np.random.default_rng(11), 20, 51), synth_trace(np.random.default_rng(12), 20, 22),
-            miden_air.poseidon2_permutation_trace(20, rng.integers(0, miden_air.P, (k, 12), dtype=np.uint64), rng.integers(1, 4, k, dtype=np.uint64))]
+    from miden_vm_amd import dag, protocol, miden_air, chiplets_air, chiplets_trace
+    p2, _ = miden_air.poseidon2_permutation_air()
+    ch, _ = chiplets_air.chiplets_air(num_public=0)
+    host_airs = [dag.dummy_miden_air(51, 4, num_aux_values=1), ch, p2]
+    t0 = time.perf_counter()
+    airs = [pkg.DeviceAir(ctx, a) for a in host_airs]
+    for i in (1, 2):
+        airs[i].attach_lookup(pkg.DeviceLookup(ctx, dag.lookup_from_constraints(host_airs[i].blob)))
+    air_load_s = time.perf_counter() - t0
+    tr_ch, tr_p2 = chiplets_trace.bulk_chiplets(20, 20, seed=5)
+    host = [synth_trace(np.random.default_rng(11), 20, 51), tr_ch, tr_p2]
     traces = [ctx.upload_trace(t) for t in host]
     prm, st = dict(protocol.PROD_PARAMS), protocol.challenger_state()
     pre = protocol.protocol_pre_observe(prm, [])
     proof = pkg.prove(ctx, airs, traces, [], prm, st, pre, None)
-    ok, _ = pkg.verify([dag.dummy_miden_air(51, 4, num_aux_values=1), dag.dummy_miden_air(22, 3, num_aux_values=1), p2], [20, 20, 20], [], prm, st, pre,
-                       proof.fields, proof.commitments)
+    ok, _ = pkg.verify(host_airs, [20, 20, 20], [], prm, st, pre, proof.fields, proof.commitments)
     t0 = time.perf_counter()
     for _ in range(steps):
         proof = pkg.prove(ctx, airs, traces, [], prm, st, pre, None)
@@ -276,11 +378,14 @@ def miden_shape_probe(pkg, ctx, steps=3):
     prof = {k: dict(v, ms=v["ms"] * steps) for k, v in prof.items()}  # the expressions below divide by `steps`
     for t in traces:
         t.free()
-    out = {"workload": "three AIRs at 2^20 rows: main 51/22/16, aux 4/3/1 EF (89 + 16 base columns), production parameters; third AIR = the real "
-                       "Poseidon2PermutationAir (aux column from its lookup program, on the device)",
+    out = {"workload": "three AIRs at 2^20 rows: main 51/22/16, aux 4/3/1 EF (89 + 16 base columns), production parameters; second AIR = the real "
+                       "ChipletsAir, third = the real Poseidon2PermutationAir (aux columns from the lookup programs derived from their "
+                       "constraint DAGs, on the device); core = a degree-9 stand-in",
            "ms_per_proof": dt * 1e3, "rows_per_s": (1 << 20) / dt, "proof_bytes": len(proof.bytes), "verifies": bool(ok),
            "quotient_eval_ms": prof.get("quotient_eval", {}).get("ms", 0) / steps, "logup_aux_ms": prof.get("logup_aux", {}).get("ms", 0) / steps,
-           "p2_air_compiled_chunks": airs[2].compiled_chunks, "p2_air_chunk_max_vgprs": airs[2].compiled_max_vgprs}
+           "p2_air_compiled_chunks": airs[2].compiled_chunks, "p2_air_chunk_max_vgprs": airs[2].compiled_max_vgprs,
+           "chiplets_air_compiled_chunks": airs[1].compiled_chunks, "chiplets_air_chunk_max_vgprs": airs[1].compiled_max_vgprs,
+           "air_load_s": air_load_s}
     try:
         pins = []
         for t in host:
@@ -416,7 +521,9 @@ def main():
     else:
         runner = ProveRunner(pkg, ctx, args.log_n, 1 + rank)
         log_n, rows_per_step = args.log_n, (1 << args.log_n) * world
-        scaling = "weak"
+        # N = 1 is the first point of the strong-scaling series the N > 1 lines continue (one proof sharded over the GPUs; a single
+        # MI355X proves 2^24 rows at the same rows/s as 2^20); independent replicas after a fallback are weak scaling
+        scaling = "strong" if world == 1 else "weak"
 
     for _ in range(args.warmup):
         runner.step()
@@ -554,9 +661,18 @@ def main():
         except Exception as e:
             out["miden_shape"] = {"error": repr(e)[:200]}
         try:
+            out["chiplets_air"] = chiplets_air_probe(pkg, ctx)
+        except Exception as e:
+            out["chiplets_air"] = {"error": repr(e)[:200]}
+        try:
             out["in_flight"] = in_flight_probe(pkg, log_n, dev_index)
         except Exception as e:
             out["in_flight"] = {"error": repr(e)[:200]}
+        try:
+            out["in_flight_h2d"] = in_flight_h2d_probe(pkg, log_n, dev_index)
+            out["pipelined_h2d"] = in_flight_h2d_probe(pkg, log_n, dev_index, k=1, steps=8)
+        except Exception as e:
+            out["in_flight_h2d"] = {"error": repr(e)[:200]}
         try:  # the same proof under the reference's other StarkConfigs (Blake3_256 = its DEFAULT ProvingOptions)
             out["hash_configs"] = {"note": "mh_prove of the same instance on a context set to another LMCS hasher / challenger "
                                            "(mh_ctx_set_lmcs); rpo / rpx at 2^16 rows (Rescue Prime is supported, not tuned)",

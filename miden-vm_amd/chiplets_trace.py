@@ -515,3 +515,136 @@ def sample_chiplets(seed=0, n_hperm=3, n_hash=2, n_blocks=2, merkle_depth=3, n_m
         for _ in range(k):
             c.kernel_rom.access_proc(d)
     return c
+
+
+# ---- a large synthetic workload, vectorised (benches and full-size GPU tests) ------------------------------------------------------
+def bulk_chiplets(log_n, log_n_p2=None, seed=0, merkle_depth=8):
+    """-> (chiplets trace [2^log_n, 22], Poseidon2 permutation trace [2^log_n_p2, 16]) with the section mix of a hash-heavy
+    program: the permutation AIR's cycles all used (2 controller rows each: HPERMs, 2-to-1 hashes, Merkle path verifications of
+    `merkle_depth` levels), half of the rows bitwise cycles, a quarter memory accesses (per word: word write, element write, word
+    read, element read), no ACE rows, two kernel procedures, padding.  Same row semantics as the sequential classes above
+    (checked against them and by the constraint checker in tests/test_chiplets_air.py)."""
+    rng = np.random.default_rng(seed)
+    n = 1 << log_n
+    log_n_p2 = log_n if log_n_p2 is None else log_n_p2
+    n_perm = min((1 << log_n_p2) // MA.HASH_CYCLE_LEN - 1, n // 16)
+    n_paths = n_perm // (3 * merkle_depth)
+    n_merkle = n_paths * merkle_depth
+    n_hperm = (n_perm - n_merkle) // 2
+    n_hash = n_perm - n_merkle - n_hperm
+
+    def felts(*shape):
+        return rng.integers(0, P, shape, dtype=np.uint64)
+
+    # ---- hasher controller: [HPERMs | 2-to-1 hashes | Merkle paths], two rows per permutation ----
+    sel_in = np.zeros((n_perm, 3), dtype=np.uint64)
+    sel_out = np.zeros((n_perm, 3), dtype=np.uint64)
+    st_in = np.zeros((n_perm, 12), dtype=np.uint64)
+    meta_in = np.zeros((n_perm, 4), dtype=np.uint64)    # node_index, mrupdate_id, is_boundary, direction_bit
+    meta_out = np.zeros((n_perm, 4), dtype=np.uint64)
+    sel_in[:, 0] = 1
+    a, b_ = n_hperm, n_hperm + n_hash
+    st_in[:a] = felts(a, 12)
+    sel_out[:a, 2] = 1                                   # RETURN_STATE
+    meta_in[:a, 2] = meta_out[:a, 2] = 1
+    st_in[a:b_, 0:8] = felts(n_hash, 8)
+    st_in[a:b_, 9] = rng.integers(0, 64, n_hash, dtype=np.uint64)   # the control-block domain
+    meta_in[a:b_, 2] = meta_out[a:b_, 2] = 1
+    st_out = np.zeros((n_perm, 12), dtype=np.uint64)
+    st_out[:b_] = MA.permute_batch(st_in[:b_])
+    if n_paths:
+        index = rng.integers(0, 1 << merkle_depth, n_paths, dtype=np.uint64)
+        root = felts(n_paths, 4)
+        rows = b_ + np.arange(n_paths) * merkle_depth
+        sel_in[b_:, 2] = 1                               # MP_VERIFY = [1, 0, 1]
+        for lvl in range(merkle_depth):
+            r = rows + lvl
+            sib = felts(n_paths, 4)
+            bit = index & np.uint64(1)
+            left = np.where(bit[:, None] == 0, root, sib)
+            right = np.where(bit[:, None] == 0, sib, root)
+            st_in[r, 0:4], st_in[r, 4:8] = left, right
+            out = MA.permute_batch(st_in[r])
+            st_out[r] = out
+            last = lvl == merkle_depth - 1
+            meta_in[r, 0], meta_in[r, 2], meta_in[r, 3] = index, 1 if lvl == 0 else 0, bit
+            index = index >> np.uint64(1)
+            meta_out[r, 0], meta_out[r, 2], meta_out[r, 3] = index, 1 if last else 0, 0 if last else (index & np.uint64(1))
+            sel_out[r, 2] = 0 if last else 1             # RETURN_HASH on the last level, RETURN_STATE before
+            root = out[:, 0:4]
+    h_rows = 2 * n_perm
+    h_len = -(-h_rows // 8) * 8
+    t = np.zeros((n, CA.NUM_CHIPLETS_COLS), dtype=np.uint64)
+    perm_id = np.arange(n_perm, dtype=np.uint64)
+    for off, sel, st, meta in ((0, sel_in, st_in, meta_in), (1, sel_out, st_out, meta_out)):
+        t[off:h_rows:2, 1:4] = sel
+        t[off:h_rows:2, 4:16] = st
+        t[off:h_rows:2, 16:20] = meta
+        t[off:h_rows:2, 20] = perm_id
+    t[h_rows:h_len, 2] = 1                               # controller padding rows [0, 1, 0]
+    # ---- bitwise ----
+    n_bw = (n // 2) // 8
+    row = h_len
+    op = rng.integers(0, 2, n_bw, dtype=np.uint64)
+    av, bv = rng.integers(0, 1 << 32, n_bw, dtype=np.uint64), rng.integers(0, 1 << 32, n_bw, dtype=np.uint64)
+    result = np.zeros(n_bw, dtype=np.uint64)
+    for i, off in enumerate(range(28, -1, -4)):
+        rr = slice(row + i, row + 8 * n_bw, 8)
+        aa, ba = av >> np.uint64(off), bv >> np.uint64(off)
+        r4 = np.where(op == 0, aa & ba, aa ^ ba) & np.uint64(0xF)
+        t[rr, 13] = result
+        result = (result << np.uint64(4)) | r4
+        t[rr, 0], t[rr, 2], t[rr, 3], t[rr, 4], t[rr, 14] = 1, op, aa, ba, result
+        for j in range(4):
+            t[rr, 5 + j], t[rr, 9 + j] = (aa >> np.uint64(j)) & np.uint64(1), (ba >> np.uint64(j)) & np.uint64(1)
+    row += 8 * n_bw
+    # ---- memory: per word [write_word, write element, read_word, read element], words sorted by (ctx, address) ----
+    n_words = (n // 4) // 4
+    words_per_ctx = max(1, n_words // 4)
+    g = np.arange(n_words)
+    ctx = (g // words_per_ctx).astype(np.uint64) * np.uint64(3)
+    waddr = ((g % words_per_ctx).astype(np.uint64) * np.uint64(5) + np.uint64(1)) * np.uint64(4)
+    clk0 = rng.integers(1, 1 << 20, n_words, dtype=np.uint64)
+    dclk = rng.integers(1, 1 << 10, (n_words, 3), dtype=np.uint64)
+    clk = np.stack([clk0, clk0 + dclk[:, 0], clk0 + dclk[:, 0] + dclk[:, 1], clk0 + dclk.sum(axis=1)], axis=1)
+    w0 = felts(n_words, 4)
+    idx_w, idx_r = rng.integers(0, 4, n_words), rng.integers(0, 4, n_words)
+    w1 = w0.copy()
+    w1[g, idx_w] = felts(n_words)
+    m = np.zeros((n_words, 4, 17), dtype=np.uint64)
+    m[:, :, 2], m[:, :, 3], m[:, :, 6] = ctx[:, None], waddr[:, None], clk
+    m[:, 0, 1], m[:, 0, 7:11] = 1, w0                                        # write_word
+    m[:, 1, 4], m[:, 1, 5], m[:, 1, 7:11] = idx_w & 1, idx_w >> 1, w1        # write element
+    m[:, 2, 0], m[:, 2, 1], m[:, 2, 7:11] = 1, 1, w1                         # read_word
+    m[:, 3, 0], m[:, 3, 4], m[:, 3, 5], m[:, 3, 7:11] = 1, idx_r & 1, idx_r >> 1, w1   # read element
+    m = m.reshape(n_words * 4, 17)
+    pc, pa, pk = np.roll(m[:, 2], 1), np.roll(m[:, 3], 1), np.roll(m[:, 6], 1)
+    pc[0], pa[0], pk[0] = m[0, 2], m[0, 3], m[0, 6] - np.uint64(1)
+    delta = np.where(pc != m[:, 2], m[:, 2] - pc, np.where(pa != m[:, 3], m[:, 3] - pa, m[:, 6] - pk))
+    m[:, 11], m[:, 12] = delta & np.uint64(0xFFFF), delta >> np.uint64(16)
+    m[:, 14] = ((pc == m[:, 2]) & (pa == m[:, 3])).astype(np.uint64)
+    # d_inv: batch inversion by the product tree trick on Python ints would be slow; Fermat through gl_mul square-and-multiply
+    inv = np.ones_like(delta)
+    base, e = delta.copy(), P - 2
+    while e:
+        if e & 1:
+            inv = MA.gl_mul(inv, base)
+        base = MA.gl_mul(base, base)
+        e >>= 1
+    m[:, 13] = np.where(delta == 0, np.uint64(0), inv)
+    widx = m[:, 3] // np.uint64(4)
+    m[:, 15], m[:, 16] = widx & np.uint64(0xFFFF), widx >> np.uint64(16)
+    k = m.shape[0]
+    t[row:row + k, 0:2] = 1
+    t[row:row + k, 3:20] = m
+    row += k
+    # ---- kernel ROM (two procedures) and padding ----
+    for d, mult in ((felts(4), 3), (felts(4), 0)):
+        t[row, 0:4] = 1
+        t[row, 5], t[row, 6:10] = mult, d
+        row += 1
+    assert row < n
+    t[row:, 0:5] = 1
+    t[:, CA.CHIP_CLK] = np.arange(1, n + 1, dtype=np.uint64)
+    p2 = MA.poseidon2_permutation_trace(log_n_p2, st_in, np.ones(n_perm, dtype=np.uint64))
+    return t, p2

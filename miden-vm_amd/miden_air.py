@@ -307,6 +307,19 @@ class _V:
         return _V(gl_mul(self.v, o.v if isinstance(o, _V) else np.uint64(int(o) % P)))
 
 
+def permute_batch(states):
+    """The Poseidon2 permutation of every row of `states` [k, 12] (vectorised; the same round functions as the trace generator)."""
+    st = [_V(np.ascontiguousarray(states[:, i], dtype=np.uint64) % _P) for i in range(12)]
+    st = _matmul_external(st)
+    for r in range(4):
+        st = _matmul_external([_pow7(st[i] + ARK_EXT_INITIAL[r][i]) for i in range(12)])
+    for r in range(22):
+        st = _matmul_internal([_pow7(st[0] + ARK_INT[r])] + st[1:], MAT_DIAG)
+    for r in range(4):
+        st = _matmul_external([_pow7(st[i] + ARK_EXT_TERMINAL[r][i]) for i in range(12)])
+    return np.stack([x.v for x in st], axis=1)
+
+
 def poseidon2_permutation_trace(log_n, states=None, multiplicities=None):
     """fill_poseidon2_permutation_trace (processor/src/trace/chiplets/hasher/trace.rs:361-408): one 16-row cycle per request
     (`states[k]` = 12 input felts, `multiplicities[k]`), then zero-state zero-multiplicity padding cycles; perm ids 0, 1, 2, ..
