@@ -296,6 +296,26 @@ def chiplets_air_probe(pkg, ctx, log_n=20, steps=3):
            "compiled_chunks": dair.compiled_chunks, "chunk_max_vgprs": dair.compiled_max_vgprs,
            "jit_cold_s": cold, "jit_cached_ms": cached * 1e3}
     dtr.free()
+    try:  # the hand-over of a trace builder that writes columns: the generator fills page-locked column-major memory
+        cols, _owner = pkg.pinned_array(ctx.lib, (22, 1 << log_n))
+        chiplets_trace.bulk_chiplets(log_n, log_n, seed=2, out_cols=cols)
+        rows, _owner2 = pkg.pinned_array(ctx.lib, (1 << log_n, 22))
+        rows[:] = cols.T
+
+        def run(upload, src):
+            t = upload(ctx, src)
+            pkg.prove(ctx, [dair], [t], [], prm, st, pre, None)
+            t.free()
+
+        for name, upload, src in (("h2d_inclusive_colmajor_producer_ms", pkg.Trace.upload_cols_async, cols),
+                                  ("h2d_inclusive_rowmajor_ms", pkg.Trace.upload_async, rows)):
+            run(upload, src)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                run(upload, src)
+            out[name] = (time.perf_counter() - t0) / steps * 1e3
+    except Exception as e:
+        out["h2d_error"] = repr(e)[:200]
     dair.free()
     return out
 

@@ -518,12 +518,17 @@ def sample_chiplets(seed=0, n_hperm=3, n_hash=2, n_blocks=2, merkle_depth=3, n_m
 
 
 # ---- a large synthetic workload, vectorised (benches and full-size GPU tests) ------------------------------------------------------
-def bulk_chiplets(log_n, log_n_p2=None, seed=0, merkle_depth=8):
+def bulk_chiplets(log_n, log_n_p2=None, seed=0, merkle_depth=8, out_cols=None):
     """-> (chiplets trace [2^log_n, 22], Poseidon2 permutation trace [2^log_n_p2, 16]) with the section mix of a hash-heavy
     program: the permutation AIR's cycles all used (2 controller rows each: HPERMs, 2-to-1 hashes, Merkle path verifications of
     `merkle_depth` levels), half of the rows bitwise cycles, a quarter memory accesses (per word: word write, element write, word
     read, element read), no ACE rows, two kernel procedures, padding.  Same row semantics as the sequential classes above
-    (checked against them and by the constraint checker in tests/test_chiplets_air.py)."""
+    (checked against them and by the constraint checker in tests/test_chiplets_air.py).
+
+    The generator WRITES COLUMNS: its backing store is column-major [22][2^log_n] -- `out_cols`, e.g. page-locked memory from
+    mh_host_alloc, when given -- and the returned trace is the transposed view of it.  That is the hand-over
+    mh_trace_upload_cols_async pipelines (every column one contiguous DMA, no transpose on the device; SURVEY 8(f) #4: a trace
+    builder that writes columns instead of `generate_core_trace_row_major`, processor/src/trace/parallel/mod.rs:157)."""
     rng = np.random.default_rng(seed)
     n = 1 << log_n
     log_n_p2 = log_n if log_n_p2 is None else log_n_p2
@@ -574,7 +579,11 @@ def bulk_chiplets(log_n, log_n_p2=None, seed=0, merkle_depth=8):
             root = out[:, 0:4]
     h_rows = 2 * n_perm
     h_len = -(-h_rows // 8) * 8
-    t = np.zeros((n, CA.NUM_CHIPLETS_COLS), dtype=np.uint64)
+    if out_cols is None:
+        out_cols = np.zeros((CA.NUM_CHIPLETS_COLS, n), dtype=np.uint64)
+    assert out_cols.shape == (CA.NUM_CHIPLETS_COLS, n) and out_cols.dtype == np.uint64 and out_cols.flags["C_CONTIGUOUS"]
+    out_cols[:] = 0
+    t = out_cols.T                                       # [n, 22] view: every `t[rows, col] = ..` below lands in column `col`
     perm_id = np.arange(n_perm, dtype=np.uint64)
     for off, sel, st, meta in ((0, sel_in, st_in, meta_in), (1, sel_out, st_out, meta_out)):
         t[off:h_rows:2, 1:4] = sel

@@ -162,3 +162,31 @@ def test_miden_shape_2p20_with_both_real_airs_verifies(ctx):
     bad[777_777, 3] = (int(bad[777_777, 3]) + 1) % ob.P
     gb = pkg.prove(ctx, dairs, [ctx.upload_trace(traces[0]), ctx.upload_trace(bad), ctx.upload_trace(tp2)], [], prm, st, pre, None)
     assert not pkg.verify(airs_, [20, 20, 20], [], prm, st, pre, gb.fields, gb.commitments)[0]
+
+
+def test_column_major_trace_producer_feeds_the_pipelined_upload(ctx):
+    """a trace builder that writes COLUMNS (chiplets_trace.bulk_chiplets fills a column-major page-locked buffer)
+    handed over with mh_trace_upload_cols_async (eight columns per DMA, the LDE of a group starts when it has landed): the proof
+    equals the one from the row-major hand-over, and the uploaded matrix downloads back intact."""
+    pkg = load_package()
+    air, _ = CA.chiplets_air(num_public=0)
+    lookup = dag.lookup_from_constraints(air.blob)
+    log_n = 13
+    cols, _owner = pkg.pinned_array(ctx.lib, (CA.NUM_CHIPLETS_COLS, 1 << log_n))
+    tr, _ = CT.bulk_chiplets(log_n, 12, seed=8, out_cols=cols)
+    assert tr.base is cols or np.shares_memory(tr, cols)
+    rows = np.ascontiguousarray(tr)
+    t_cols = pkg.Trace.upload_cols_async(ctx, cols)
+    assert (t_cols.download() == rows).all()
+    prm, st = dict(ob.PROD_PARAMS), ob.challenger_state()
+    pre = ob.protocol_pre_observe(prm, [])
+
+    def prove(trace):
+        dair = pkg.DeviceAir(ctx, air)
+        dair.attach_lookup(pkg.DeviceLookup(ctx, lookup))
+        return pkg.prove(ctx, [dair], [trace], [], prm, st, pre, None)
+
+    a = prove(pkg.Trace.upload_cols_async(ctx, cols))
+    b = prove(ctx.upload_trace(rows))
+    assert a.bytes == b.bytes
+    assert pkg.verify([air], [log_n], [], prm, st, pre, a.fields, a.commitments)[0]
