@@ -146,7 +146,7 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
                               const std::vector<u64>& publics, const std::vector<e2>& randomness, const std::vector<e2>& aux_values,
                               e2 alpha, const u64* acc_in, int log_n_prev, e2 beta, u64* acc_out);
 void quotient_upsample_accumulate(mh_ctx* c, const u64* q_small, int log_n, int log_blowup, int log_dj, int log_d, const u64* acc_in,
-                                  int log_n_prev, e2 beta, u64* acc_out);
+                                  int log_n_prev, e2 beta, u64* acc_out, size_t t_first, size_t n_local);
 // ---- deep.hip ----------------------------------------------------------------------------------
 struct OodJob {
   const LdeMatrix* m = nullptr;

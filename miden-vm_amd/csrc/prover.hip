@@ -335,7 +335,20 @@ struct mh_session {
   std::vector<u64> publics;
   std::vector<int> lhs, order;      // log heights (instance order), proof order -> instance index
   int lb = 0, log_N = 0, L = 0, logD = 0, lbl = 0;
-  size_t N = 0, D = 0, B_loc = 0, coset0 = 0, D_loc = 0;
+  size_t N = 0, D = 0, B_loc = 0, coset0 = 0, D_loc = 0, D_slot = 1;
+  // chunks of a 2^log_d-coset quotient domain that live on this rank, and the first of them
+  size_t chunks_on_rank(int log_d) const {
+    if (log_d >= dist.logG) return (size_t)1 << (log_d - dist.logG);
+    return (dist.rank & ((1 << (dist.logG - log_d)) - 1)) == 0 ? 1 : 0;
+  }
+  size_t first_chunk_on_rank(int log_d) const {
+    return log_d >= dist.logG ? ((size_t)dist.rank << (log_d - dist.logG)) : ((size_t)dist.rank >> (dist.logG - log_d));
+  }
+  // where chunk t of a 2^log_d-chunk set sits in a buffer all-gathered with `slot` chunks per rank
+  size_t gathered_chunk(int log_d, size_t slot, size_t t) const {
+    if (log_d >= dist.logG) return t;  // rank r contributed chunks r * slot ..: the natural order
+    return (t << (dist.logG - log_d)) * slot;
+  }
   size_t max_rand = 0;
   int stage = 0;                    // protocol position, enforced on every call
   std::unique_ptr<mh_tree> main_tree, aux_tree, quot_tree;
@@ -394,16 +407,17 @@ struct mh_session {
     D = (size_t)1 << logD;
     publics.assign(publics_in, publics_in + n_publics);
     if (dist.on()) {
-      MH_REQUIRE(dist.logG <= lb && dist.logG <= logD, "more ranks than cosets / quotient chunks");
-      for (int i = 0; i < n_airs; i++) {
-        MH_REQUIRE(airs[i]->log_quotient_degree == logD, "sharded proofs need one quotient degree for every AIR");
-        MH_REQUIRE(lhs[i] >= dist.logG, "trace shorter than the number of ranks");
-      }
+      MH_REQUIRE(dist.logG <= lb, "more ranks than cosets");
+      for (int i = 0; i < n_airs; i++) MH_REQUIRE(lhs[i] >= dist.logG, "trace shorter than the number of ranks");
     }
     lbl = lb - dist.logG;  // coset bits stored on this rank
     B_loc = (size_t)1 << lbl;
     coset0 = (size_t)dist.rank * B_loc;
-    D_loc = D >> dist.logG;  // quotient chunks owned by this rank
+    // quotient chunks owned by this rank: chunk t IS the LDE coset t * B / D.  G <= D: D / G chunks per rank; G > D: the
+    // chunk lives on rank t * G / D, the ranks in between own none (they idle through constraint evaluation, contribute an empty slot to
+    // the chunk gather and transform all D chunks onto their cosets like everybody else)
+    D_loc = chunks_on_rank(logD);
+    D_slot = std::max<size_t>(1, D >> dist.logG);
     // ---- preprocessed columns (crates/lifted-stark/src/preprocessed.rs validate_preprocessed): every AIR that
     // declares some must point at ONE setup tree whose matrices are those AIRs' LDEs in proof order ----
     prep_of.assign(n_airs, -1);
@@ -529,17 +543,37 @@ struct mh_session {
     for (int j = 0; j < n_airs; j++) {
       const mh_air* a = airs[order[j]];
       const int ln = lhs[order[j]];
-      DevBuf out(((size_t)2 * D_loc << ln) * 8);
+      DevBuf out(std::max<size_t>(8, ((size_t)2 * D_loc << ln) * 8));
       std::vector<e2> rnd(randomness.begin(), randomness.begin() + a->num_randomness);
       const int logDj = a->log_quotient_degree;
+      const LdeMatrix* prep = prep_of[j] >= 0 ? &prep_tree->mats[prep_of[j]] : nullptr;
       if (logDj == logD) {
-        quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], prep_of[j] >= 0 ? &prep_tree->mats[prep_of[j]] : nullptr, lb, logD, publics, rnd, aux_vals[order[j]], alpha,
-                                 j ? acc.u() : nullptr, log_n_prev, beta, out.u());
-      } else {  // native coset of n*Dj points, then upsample to n*D (prover/mod.rs:520-528); single GPU only
+        if (D_loc)
+          quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], prep, lb, logD, publics, rnd, aux_vals[order[j]], alpha,
+                                   j ? acc.u() : nullptr, log_n_prev, beta, out.u());
+      } else {
+        // native coset of n * Dj points, then upsample to n * D (prover/mod.rs:520-528).  Sharded: the Dj native chunks are the LDE
+        // cosets t' * B / Dj, each evaluated by the rank that stores it; every rank gets all of them (16 B * n per chunk), runs the
+        // small LDE of the upsample itself (two columns of n * Dj) and keeps the batch chunks it owns
+        const size_t dj_loc = chunks_on_rank(logDj), dj_slot = std::max<size_t>(1, ((size_t)1 << logDj) >> dist.logG);
+        const size_t chunk_words = (size_t)2 << ln;
+        DevBuf mine(dj_slot * chunk_words * 8);
+        if (dj_loc)
+          quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], prep, lb, logDj, publics, rnd, aux_vals[order[j]], alpha,
+                                   nullptr, 0, beta, mine.u());
         DevBuf small(((size_t)2 << (logDj + ln)) * 8);
-        quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], prep_of[j] >= 0 ? &prep_tree->mats[prep_of[j]] : nullptr, lb, logDj, publics, rnd, aux_vals[order[j]], alpha,
-                                 nullptr, 0, beta, small.u());
-        quotient_upsample_accumulate(c, small.u(), ln, lb, logDj, logD, j ? acc.u() : nullptr, log_n_prev, beta, out.u());
+        if (dist.on()) {
+          DevBuf all((size_t)dist.world * dj_slot * chunk_words * 8);
+          dist.all_gather(c, mine.u(), all.p, dj_slot * chunk_words * 8);
+          for (size_t t = 0; t < ((size_t)1 << logDj); t++)
+            HIP_CHECK(hipMemcpyAsync(small.u() + t * chunk_words, all.u() + gathered_chunk(logDj, dj_slot, t) * chunk_words, chunk_words * 8,
+                                     hipMemcpyDeviceToDevice, c->stream));
+          c->sync();
+        } else {
+          small = std::move(mine);
+        }
+        quotient_upsample_accumulate(c, small.u(), ln, lb, logDj, logD, j ? acc.u() : nullptr, log_n_prev, beta, out.u(),
+                                     first_chunk_on_rank(logD), D_loc);
       }
       acc = std::move(out);
       log_n_prev = ln;
@@ -556,15 +590,21 @@ struct mh_session {
     const u64 g = gl_lde_shift(L);
     const u64 wJ = gl_two_adic_generator(log_N + logD);
     const std::vector<u64> all_outs = coset_shifts(log_N, lb);
-    DevBuf gathered;
+    DevBuf gathered, slot_buf;
     const u64* coef = acc.u();
-    {
+    if (D_loc) {
       ProfScope ps(c, "lde", (double)N * 2 * D_loc * 8.0);
       ntt_inverse_dif_inplace(c, acc.u(), 2 * D_loc, log_N);
     }
     if (dist.on()) {
-      gathered.alloc(2 * D * N * 8);
-      dist.all_gather(c, acc.u(), gathered.p, 2 * D_loc * N * 8);
+      const u64* mine = acc.u();
+      if (!D_loc) {  // a rank without a chunk still fills its slot of the gather
+        slot_buf.alloc(2 * D_slot * N * 8);
+        HIP_CHECK(hipMemsetAsync(slot_buf.p, 0, 2 * D_slot * N * 8, c->stream));
+        mine = slot_buf.u();
+      }
+      gathered.alloc((size_t)dist.world * 2 * D_slot * N * 8);
+      dist.all_gather(c, mine, gathered.p, 2 * D_slot * N * 8);
       coef = gathered.u();
     }
     {
@@ -573,7 +613,8 @@ struct mh_session {
         const u64 in_inv = gl_inv(gl_mul(g, gl_pow(wJ, t)));
         std::vector<u64> bases(B_loc);
         for (size_t zc = 0; zc < B_loc; zc++) bases[zc] = gl_mul(all_outs[coset0 + zc], in_inv);
-        ntt_forward_cosets(c, coef + 2 * t * N, 2, log_N, bases, qm.lde.u() + 2 * t * B_loc * N);
+        const size_t src_chunk = dist.on() ? gathered_chunk(logD, D_slot, t) : t;
+        ntt_forward_cosets(c, coef + 2 * src_chunk * N, 2, log_N, bases, qm.lde.u() + 2 * t * B_loc * N);
       }
     }
     quot_tree->mats.push_back(std::move(qm));

@@ -201,9 +201,11 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
                "preprocessed matrix does not match the AIR / trace shape");
   // this rank stores 2^log_cosets of the 2^log_blowup cosets: it evaluates the quotient cosets among them
   const int G = log_blowup - main.log_cosets;
-  MH_REQUIRE(G >= 0 && log_d >= G && aux.log_cosets == main.log_cosets && aux.coset0 == main.coset0,
-             "quotient degree smaller than the number of ranks");
-  const int log_dl = log_d - G;
+  MH_REQUIRE(G >= 0 && aux.log_cosets == main.log_cosets && aux.coset0 == main.coset0, "internal: main / aux shard shapes differ");
+  // more ranks than quotient cosets (log_d < G): coset t lives on the rank whose first LDE coset is t * B / D -- that rank evaluates
+  // it (one local quotient coset = its local LDE coset 0), the others hold none and must not get here (quotient_rank_owns)
+  MH_REQUIRE(log_d >= G || (main.coset0 & ((B >> log_d) - 1)) == 0, "internal: this rank holds no quotient coset of this AIR");
+  const int log_dl = std::max(0, log_d - G);
   const size_t D = (size_t)1 << log_dl;  // local quotient cosets
   const size_t t0 = main.coset0 >> (log_blowup - log_d);
   const int L = log_n + log_blowup;
@@ -364,27 +366,29 @@ __global__ void k_quot_to_natural(const u64* __restrict__ q_small, u64* __restri
   nat[n * Dj + i] = q_small[((2 * tp + 1) << log_n) + r];
 }
 __global__ void k_quot_regroup_accumulate(const u64* __restrict__ lde, int log_n, int log_dj, int log_d, const u64* __restrict__ acc_in,
-                                          int log_n_prev, e2 beta, u64* __restrict__ acc_out) {
+                                          int log_n_prev, e2 beta, u64* __restrict__ acc_out, size_t t_first, size_t n_local) {
   const size_t n = (size_t)1 << log_n;
   const int ab = log_d - log_dj;
   const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (q >= (n << log_d)) return;
-  const size_t t = q >> log_n, r = q & (n - 1);
+  if (q >= (n_local << log_n)) return;
+  const size_t tl = q >> log_n, r = q & (n - 1);  // tl: chunk index on this rank (acc_in / acc_out planes), t: in the batch
+  const size_t t = t_first + tl;
   const size_t tp = t >> ab, u = t & (((size_t)1 << ab) - 1);
   const size_t nd = n << log_dj;                       // column length of the small coset
   const size_t src = (u * nd) + (r << log_dj) + tp;    // column e at offset e * 2^ab * nd
   e2 v = e2{lde[src], lde[((size_t)1 << ab) * nd + src]};
   if (acc_in) {
     const size_t n_prev = (size_t)1 << log_n_prev, rp = r & (n_prev - 1);
-    e2 old = e2{acc_in[((2 * t) << log_n_prev) + rp], acc_in[((2 * t + 1) << log_n_prev) + rp]};
+    e2 old = e2{acc_in[((2 * tl) << log_n_prev) + rp], acc_in[((2 * tl + 1) << log_n_prev) + rp]};
     v = e2_add(e2_mul(old, beta), v);
   }
-  acc_out[((2 * t) << log_n) + r] = v.c0;
-  acc_out[((2 * t + 1) << log_n) + r] = v.c1;
+  acc_out[((2 * tl) << log_n) + r] = v.c0;
+  acc_out[((2 * tl + 1) << log_n) + r] = v.c1;
 }
 
+// Output: the `n_local` batch chunks t_first .. t_first + n_local - 1 (a sharded proof: this rank's chunks; else all 2^log_d).
 void quotient_upsample_accumulate(mh_ctx* c, const u64* q_small, int log_n, int log_blowup, int log_dj, int log_d, const u64* acc_in,
-                                  int log_n_prev, e2 beta, u64* acc_out) {
+                                  int log_n_prev, e2 beta, u64* acc_out, size_t t_first, size_t n_local) {
   const size_t n = (size_t)1 << log_n, nd = n << log_dj;
   const int ab = log_d - log_dj;
   MH_REQUIRE(ab > 0, "internal: nothing to upsample");
@@ -399,8 +403,10 @@ void quotient_upsample_accumulate(mh_ctx* c, const u64* q_small, int log_n, int 
     x = gl_mul(x, w);
   }
   lde_columns(c, nat.u(), 2, log_n + log_dj, gj, outs, lde.u(), scratch.u());
-  const size_t total = n << log_d;
-  MH_LAUNCH(k_quot_regroup_accumulate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, lde.u(), log_n, log_dj,
-                     log_d, acc_in, log_n_prev, beta, acc_out);
+  MH_REQUIRE(t_first + n_local <= ((size_t)1 << log_d), "internal: chunk range");
+  const size_t total = n * n_local;
+  if (total)
+    MH_LAUNCH(k_quot_regroup_accumulate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, lde.u(), log_n, log_dj,
+                       log_d, acc_in, log_n_prev, beta, acc_out, t_first, n_local);
   HIP_CHECK(hipStreamSynchronize(c->stream));
 }

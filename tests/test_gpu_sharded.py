@@ -254,7 +254,11 @@ def test_local_communicator_selftest(world):
 
 
 @pytest.mark.parametrize("world,case", [(2, "miden_small"), (4, "miden"), (8, "miden"), (2, "multi"), (8, "miden18"), (2, "miden20"),
-                                        (4, "p2air"), (8, "p2air")])
+                                        (4, "p2air"), (8, "p2air"),
+                                        # round 4: more ranks than quotient chunks (D = 2: chunk t lives on rank t * G / 2, the others
+                                        # idle through constraint evaluation), mixed per-AIR quotient degrees (D_j in {2, 2, 8}: native
+                                        # chunks gathered, upsampled on every rank), both instance orders; the real chiplets AIR
+                                        (4, "multi"), (8, "multi"), (2, "mixed"), (4, "mixed"), (8, "mixed"), (4, "mixed_rev"), (8, "chiplets")])
 def test_sharded_proof_through_a_stream_ordered_communicator(world, case):
     """The sharded prover with a STREAM-ORDERED communicator and several ranks (what the RCCL communicator is on a multi-GPU
     node): no host synchronisation around the collectives.  Every rank's proof must equal the single-GPU proof."""
@@ -269,6 +273,20 @@ def test_sharded_proof_through_a_stream_ordered_communicator(world, case):
         airs_ = [dag.dummy_miden_air(51, 4, num_aux_values=1), p2]
         traces = [A.dummy_trace(12, 51, seed=2), MA.poseidon2_permutation_trace(11, rng.integers(0, ob.P, (60, 12), dtype=np.uint64), rng.integers(1, 4, 60, dtype=np.uint64))]
         pub, prm, lookups = [], ob.PROD_PARAMS, {1: lk}
+    elif case in ("mixed", "mixed_rev"):  # test_gpu_prove.py::test_mixed_quotient_degrees, sharded
+        tf, pub = A.fib_trace(7)
+        airs_ = [A.periodic_air(3), A.fib_air(), dag.dummy_miden_air(11, 2, num_public=3)]
+        traces = [A.periodic_trace(5), tf, A.dummy_trace(6, 11)]
+        if case == "mixed_rev":
+            airs_, traces = airs_[::-1], traces[::-1]
+        prm = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=6, query_pow_bits=3)
+    elif case == "chiplets":  # the real ChipletsAir + Poseidon2 permutation AIR, aux columns from the derived lookup programs on every rank
+        from miden_vm_amd import miden_air as MA, chiplets_air as CA, chiplets_trace as CT
+        ch, _ = CA.chiplets_air(host_aux=ob.lookup_build_aux, num_public=0)
+        p2, _ = MA.poseidon2_permutation_air(host_aux=ob.lookup_build_aux)
+        tr, tp2 = CT.bulk_chiplets(11, 10, seed=6)
+        airs_, traces, pub, prm = [ch, p2], [np.ascontiguousarray(tr), tp2], [], ob.PROD_PARAMS
+        lookups = {0: dag.lookup_from_constraints(ch.blob), 1: dag.lookup_from_constraints(p2.blob)}
     elif case == "miden":
         airs_, traces, pub, prm = [dag.dummy_miden_air(51, 8)], [A.dummy_trace(10, 51)], [], ob.PROD_PARAMS
     elif case in ("miden18", "miden20"):  # bench-sized shards: every NTT pass shape and the real collective sizes
@@ -281,7 +299,7 @@ def test_sharded_proof_through_a_stream_ordered_communicator(world, case):
         airs_, traces = [A.periodic_air(3), A.fib_air()], [A.periodic_trace(6), t1]
         prm = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=6, query_pow_bits=3)
     st, pre = ob.challenger_state(), ob.protocol_pre_observe(prm, pub)
-    need_cb = any(a.build_aux is not None for a in airs_)
+    need_cb = any(a.build_aux is not None and i not in lookups for i, a in enumerate(airs_))
 
     def aux_builder(idx, rnd):
         a = airs_[idx]
