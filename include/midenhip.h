@@ -258,8 +258,10 @@ int mh_prove_host(mh_ctx* ctx, const mh_pcs_params* params, int n_airs, mh_air* 
  *                coset than ranks),
  *   all_reduce_sum_u64 (query openings: every value is contributed by exactly one rank).
  * Each callback returns 0 on success; unless `stream_ordered` is set the library synchronises its stream before calling
- * and expects the collective to be complete on return.  world must be a power of two <= min(2^log_blowup, quotient
- * degree); every AIR of the proof must share one quotient degree. */
+ * and expects the collective to be complete on return.  world must be a power of two <= 2^log_blowup and <= the shortest trace.
+ * Any mix of per-AIR quotient degrees is accepted (an AIR's native quotient chunks are gathered with all_gather and upsampled on
+ * every rank), and world may exceed the number of quotient chunks D: chunk t then lives on rank t * world / D, the other ranks
+ * idle through constraint evaluation (if D < B only world * D / B ranks hold quotient-coset rows). */
 typedef struct mh_comm {
   int rank, world;
   void* user;
