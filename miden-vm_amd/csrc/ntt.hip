@@ -132,6 +132,8 @@ struct NttPassArgs {
   int lb;
   size_t scale_lo_z, scale_hi_z;
   u32 n_z;                                              // output cosets produced per workgroup (first pass of a coset LDE), else 1
+  const u64* scale_full;                                // optional, instead of scale_lo/hi: the whole product table [z][pos] (one load, one product)
+  int col_fastest;                                      // grid = (columns, tiles): neighbouring workgroups share a tile's twiddle / scale slices
   size_t src_z_stride;                                  // 0: every coset reads the same source (first pass); else the source of coset z is src + z * src_z_stride
 };
 
@@ -536,18 +538,19 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
   const int tile_log = a.r_bits + a.cb;
   const u32 tile_n = 1u << tile_log;
   const u32 cb_mask = (1u << a.cb) - 1;
-  const u32 tile = blockIdx.x;
+  const u32 tile = a.col_fastest ? blockIdx.y : blockIdx.x;
+  const u32 col_id = a.col_fastest ? blockIdx.x : blockIdx.y;
   const int lo_bits = a.s_lo - a.cb;
   const size_t lo0 = tile & ((1u << lo_bits) - 1);
   const size_t hi = tile >> lo_bits;
   const size_t gbase = (hi << (a.s_lo + a.r_bits)) | (lo0 << a.cb);
-  const u64* src0 = a.src + (size_t)blockIdx.y * a.src_col_stride;
+  const u64* src0 = a.src + (size_t)col_id * a.src_col_stride;
   // The first pass of a coset LDE reads one coefficient tile and produces it on every output coset: the workgroup
   // loops over the cosets itself (n_z > 1), so the tile comes from HBM once and from this XCD's L2 afterwards --
   // with the cosets spread over grid.z the same tile was fetched by up to n_z workgroups on different XCDs.
   for (u32 z = 0; z < a.n_z; z++) {
   const u32 zc = blockIdx.z * a.n_z + z;
-  u64* dst = a.dst + (size_t)blockIdx.y * a.dst_col_stride + (size_t)zc * a.dst_z_stride;
+  u64* dst = a.dst + (size_t)col_id * a.dst_col_stride + (size_t)zc * a.dst_z_stride;
   const u64* src = src0 + (size_t)zc * a.src_z_stride;
   if (z) __syncthreads();  // the previous coset's last round still reads the tile
 
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
     const u32 g0 = (u32)(gbase | ((size_t)(tid >> a.cb) << a.s_lo) | (tid & cb_mask));
     const int shg = LOG_T - a.cb + a.s_lo;
     const u32 p0 = ntt_pad<SWZ>(tid);
-    if (THREADS == NTT_THREADS && !a.scale_lo) {  // (the 1024-thread kernel has 128 VGPRs: it would spill)
+    if (THREADS == NTT_THREADS && !a.scale_lo && !a.scale_full) {  // (the 1024-thread kernel has 128 VGPRs: it would spill)
       // no scale (every pass but the first of a coset LDE): all sixteen loads in flight -- the strided passes are short of bytes in
       // flight, not of issue slots (pass 1 of the 2^20 plan: 3.3 TB/s with four at a time)
       u64 v[16];
@@ -575,7 +578,11 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
       u64 v[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) v[j] = (src + ((size_t)(c + j) << shg))[g0];  // wave-uniform base + the thread's index
-      if (a.scale_lo) {
+      if (a.scale_full) {
+        const u64* sf = a.scale_full + ((size_t)zc << a.log_n);
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = NTT_MUL1(v[j], (sf + ((size_t)(c + j) << shg))[g0]);
+      } else if (a.scale_lo) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const u32 k = bitrev32(g0 + ((u32)(c + j) << shg), a.log_n);
@@ -591,7 +598,9 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
     for (u32 l = threadIdx.x; l < tile_n; l += THREADS) {
       size_t g = gbase | ((size_t)(l >> a.cb) << a.s_lo) | (l & cb_mask);
       u64 v = src[g];
-      if (a.scale_lo) {
+      if (a.scale_full) {
+        v = NTT_MUL1(v, a.scale_full[((size_t)zc << a.log_n) + g]);
+      } else if (a.scale_lo) {
         u32 k = bitrev32((u32)g, a.log_n);
         u64 sc = NTT_MUL1(a.scale_lo[zc * a.scale_lo_z + (k & ((1u << a.lb) - 1))], a.scale_hi[zc * a.scale_hi_z + (k >> a.lb)]);
         v = NTT_MUL1(v, sc);
@@ -739,7 +748,9 @@ static void launch_pass(mh_ctx* c, NttPassArgs a, size_t n_cols, size_t n_z, boo
   size_t zsplit = 1;
   while (zsplit < n_z && (one_coset_per_workgroup || tiles * n_cols * zsplit < 4096)) zsplit *= 2;
   a.n_z = (u32)(n_z / zsplit);
-  dim3 grid((unsigned)tiles, (unsigned)n_cols, (unsigned)zsplit);
+  static const int colfast = [] { const char* e = getenv("MH_NTT_COLFAST"); return e ? atoi(e) : 1; }();
+  a.col_fastest = (colfast && tiles <= 65535) ? 1 : 0;
+  dim3 grid(a.col_fastest ? (unsigned)n_cols : (unsigned)tiles, a.col_fastest ? (unsigned)tiles : (unsigned)n_cols, (unsigned)zsplit);
   const int T = ntt_tile_log(a.log_n);
   const size_t lds = ntt_lds_bytes(T);
   if (T == NTT_TILE_LOG) {
@@ -822,6 +833,35 @@ static CosetTables coset_tables(mh_ctx* c, int log_n, const std::vector<u64>& ba
   return t;
 }
 
+// The whole coset-scale table [z][pos] = lo[z][k & m] * hi[z][k >> lb], k = bitrev(pos): one load and one product per element in the
+// first forward pass instead of two loads and two products.  8 B per LDE element (64 MB at 2^20 rows, blowup 8): worth it for the
+// many-column trace LDEs only.  Measured at 2^20 x (51 + 16) columns (round 4, ms of LDE per proof): two-level tables 8.70, full table
+// 8.22, full table + column-fastest grid (the 256 KB slice of a tile is shared by neighbouring workgroups in L2) 8.08; the
+// column-fastest grid alone 8.72.  MH_NTT_FULLSCALE=0 / MH_NTT_COLFAST=0 restore the round-3 path.
+__global__ void k_fill_scale_full(u64* out, const u64* lo, const u64* hi, int log_n, int lb, size_t lo_z, size_t hi_z) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t n = (size_t)1 << log_n;
+  const size_t z = blockIdx.y;
+  if (i >= n) return;
+  const u32 k = bitrev32((u32)i, log_n);
+  out[z * n + i] = gl_mul(lo[z * lo_z + (k & ((1u << lb) - 1))], hi[z * hi_z + (k >> lb)]);
+}
+static const u64* coset_scale_full(mh_ctx* c, int log_n, const std::vector<u64>& bases, u64 post_scale, const CosetTables& t) {
+  u64 h = 0xcbf29ce484222325ULL ^ (u64)log_n;
+  for (u64 b : bases) h = (h ^ b) * 0x100000001b3ULL + (h >> 29);
+  h = (h ^ post_scale) * 0x100000001b3ULL;
+  const std::string key = "cosetfull:" + std::to_string(log_n) + ":" + std::to_string(bases.size()) + ":" + std::to_string(h);
+  auto it = c->tables.find(key);
+  if (it == c->tables.end()) {
+    const size_t n = (size_t)1 << log_n;
+    DevBuf b(bases.size() * n * 8);
+    MH_LAUNCH(k_fill_scale_full, dim3((unsigned)((n + 255) / 256), (unsigned)bases.size()), dim3(256), 0, c->stream, b.u(), t.lo, t.hi, log_n,
+              t.lb, (size_t)1 << t.lb, (size_t)1 << (log_n - t.lb));
+    it = c->tables.emplace(key, std::move(b)).first;
+  }
+  return it->second.u();
+}
+
 // Forward coset evaluation: `coef_br` holds, per column, N*coefficients in bit-reversed order
 // (output of ntt_inverse_dif_inplace).  For every output coset z, out[(col*n_z + z)*N + r] =
 // sum_k c_k * bases[z]^k * w_N^(r k)   (1/N folded into the table).
@@ -847,6 +887,8 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
       a.scale_lo = t.lo; a.scale_hi = t.hi; a.lb = t.lb;
       a.scale_lo_z = (size_t)1 << t.lb;
       a.scale_hi_z = (size_t)1 << (log_n - t.lb);
+      static const int fullscale = [] { const char* e = getenv("MH_NTT_FULLSCALE"); return e ? atoi(e) : 1; }();
+      if (fullscale && n_cols >= 16 && log_n >= 12 && log_n <= 24) a.scale_full = coset_scale_full(c, log_n, bases, n_inv, t);
     } else {
       // in place inside each coset block: fold z into the source stride
       a.src = out;
