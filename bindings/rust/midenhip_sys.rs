@@ -122,6 +122,7 @@ unsafe extern "C" {
     pub fn mh_air_log_quotient_degree(air: *const mh_air) -> c_int;
     pub fn mh_air_compiled_chunks(air: *const mh_air) -> c_int;
     pub fn mh_air_compiled_max_vgprs(air: *const mh_air) -> c_int;
+    pub fn mh_jit_precompile(blob: *const u64, n_words: usize, n_chunks: *mut c_int) -> c_int;
     pub fn mh_air_attach_preprocessed(air: *mut mh_air, tree: *const mh_tree, matrix_index: c_int, raw: *const mh_trace) -> c_int;
     pub fn mh_air_attach_lookup(air: *mut mh_air, l: *const mh_lookup) -> c_int;
     pub fn mh_lookup_load(ctx: *mut mh_ctx, blob: *const u64, n_words: usize, out: *mut *mut mh_lookup) -> c_int;

@@ -189,6 +189,11 @@ int mh_air_log_quotient_degree(const mh_air* air);
  * under $MH_JIT_CACHE_DIR or ~/.cache/midenhip); 0 = small DAG, evaluated by the generic interpreter kernel.
  * MH_JIT=0 / MH_JIT=1 in the environment force either path (both are bit-identical). */
 int mh_air_compiled_chunks(const mh_air* air);
+/* Offline precompilation, host only (no GPU, no context): compiles the chunk kernels of a constraint-DAG blob or of a lookup program
+ * ("MHLKP001") for gfx950 into the cache directory ($MH_JIT_CACHE_DIR, else ~/.cache/midenhip), where a later mh_air_load /
+ * mh_lookup_load finds them -- a prover service ships the directory and never runs hiprtc on the request path (measured for the
+ * chiplets AIR: 5.7 s cold, 3 ms from the cache).  *n_chunks = kernels of the program (0: small DAG, interpreted). */
+int mh_jit_precompile(const uint64_t* blob, size_t n_words, int* n_chunks);
 /* Largest VGPR count over those kernels (their occupancy is 512 / VGPRs waves per SIMD); 0 when nothing was compiled. */
 int mh_air_compiled_max_vgprs(const mh_air* air);
 /* Preprocessed columns (fixed circuit data committed once at setup: crates/lifted-stark/src/preprocessed.rs; blob word

@@ -23,7 +23,7 @@ EXPORTS = [
     "mh_ctx_create", "mh_ctx_destroy", "mh_ctx_trim", "mh_last_error", "mh_device_count", "mh_prof_enable", "mh_prof_filter", "mh_prof_reset",
     "mh_prof_get", "mh_prof_dump", "mh_poseidon2_permute", "mh_poseidon2_register_rate", "mh_coset_lde_batch", "mh_trace_upload", "mh_trace_upload_async", "mh_trace_upload_cols_async", "mh_trace_wait", "mh_trace_free",
     "mh_commit_traces", "mh_tree_free", "mh_tree_root", "mh_tree_log_height", "mh_tree_open", "mh_tree_download_lde",
-    "mh_tree_download_layers", "mh_air_load", "mh_air_free", "mh_air_log_quotient_degree", "mh_air_compiled_chunks", "mh_air_compiled_max_vgprs", "mh_prove", "mh_prove_host", "mh_proof_free",
+    "mh_tree_download_layers", "mh_air_load", "mh_air_free", "mh_air_log_quotient_degree", "mh_air_compiled_chunks", "mh_air_compiled_max_vgprs", "mh_jit_precompile", "mh_prove", "mh_prove_host", "mh_proof_free",
     "mh_proof_num_fields", "mh_proof_num_commitments", "mh_proof_fields", "mh_proof_commitments", "mh_proof_digest",
     "mh_proof_num_traces", "mh_proof_log_trace_heights", "mh_proof_serialize", "mh_shard_commit_leaves", "mh_shard_free",
     "mh_shard_leaf_digests", "mh_shard_build_subtree", "mh_merkle_cap_root", "mh_merkle_cap_root_lmcs", "mh_prove_sharded", "mh_commit_traces_sharded", "mh_trace_upload_sharded",
@@ -35,6 +35,11 @@ EXPORTS = [
     "mh_rccl_unique_id", "mh_comm_create_rccl", "mh_comm_destroy", "mh_comm_selftest",
     "mh_local_fabric_create", "mh_local_fabric_destroy", "mh_local_fabric_abort", "mh_comm_create_local",
 ]
+
+# the in-tree cache of precompiled constraint kernels (filled by __graft_entry__.build() / tools/jit_precompile.py); $MH_JIT_CACHE_DIR wins
+_JIT_CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "jit_cache")
+if os.path.isdir(_JIT_CACHE):
+    os.environ.setdefault("MH_JIT_CACHE_DIR", _JIT_CACHE)
 
 _lib = None
 
@@ -703,6 +708,28 @@ def verify(airs, log_trace_heights, public_values, params, challenger_state, pre
                               C.c_size_t(len(pre_observe)), _ptr(f), C.c_size_t(f.size), _ptr(c), C.c_size_t(c.size // 4),
                               _ptr(proot) if proot is not None else None, ext, None, _ptr(digest), err, C.c_size_t(512))
     return (True, digest) if rc == 0 else (False, err.value.decode())
+
+
+def jit_precompile(blob, cache_dir=None):
+    """mh_jit_precompile (host only, no GPU): compile the chunk kernels of an AIR / lookup blob into the cache directory.
+    -> number of chunk kernels."""
+    lib = load_library()
+    b = _arr(blob)
+    k = C.c_int(0)
+    old = os.environ.get("MH_JIT_CACHE_DIR")
+    if cache_dir is not None:
+        os.environ["MH_JIT_CACHE_DIR"] = cache_dir
+    try:
+        rc = lib.mh_jit_precompile(_ptr(b), C.c_size_t(b.size), C.byref(k))
+    finally:
+        if cache_dir is not None:
+            if old is None:
+                os.environ.pop("MH_JIT_CACHE_DIR", None)
+            else:
+                os.environ["MH_JIT_CACHE_DIR"] = old
+    if rc != 0:
+        raise MidenHipError(f"mh_jit_precompile failed: {rc}")
+    return int(k.value)
 
 
 def grind_bytes(ctx, input_bytes, bits):

@@ -1,5 +1,6 @@
 // Constraint-DAG blob -> interpreter program (see air.hpp).
 #include "air.hpp"
+#include "air_jit.hpp"
 #include "gl.cuh"
 #include <algorithm>
 #include <cstring>
@@ -213,6 +214,24 @@ mh_air* mh_air::load(mh_ctx* ctx, const u64* w, size_t n) {
 }
 
 // ---- lookup blob -> DagIR in output mode -> compiled kernels ----------------------------------------------
+// Offline precompilation (no GPU, no context): the chunk kernels of a constraint-DAG blob ("MHDAG001") or of a lookup program
+// ("MHLKP001") are compiled by hiprtc into the cache directory, where mh_air_load / mh_lookup_load find them.
+int jit_precompile_blob(const u64* w, size_t n) {
+  MH_REQUIRE(n >= 12, "blob too short");
+  struct Flag {
+    Flag() { g_jit_compile_only = true; g_jit_last_chunks = 0; }
+    ~Flag() { g_jit_compile_only = false; }
+  } flag;
+  if (w[0] == LOOKUP_MAGIC) {
+    mh_lookup* lk = mh_lookup::load(nullptr, w, n);  // compile-only: returns before anything touches the device
+    delete lk;
+  } else {
+    DagIR ir = dag_parse(w, n);
+    jit_program_build(nullptr, ir);
+  }
+  return g_jit_last_chunks;
+}
+
 mh_lookup* mh_lookup::load(mh_ctx* ctx, const u64* w, size_t n) {
   MH_REQUIRE(n >= 12 && w[0] == LOOKUP_MAGIC, "lookup blob: bad magic / too short");
   // Same header / periodic / node sections as a constraint DAG (no aux columns, publics or aux values); the
@@ -256,6 +275,6 @@ mh_lookup* mh_lookup::load(mh_ctx* ctx, const u64* w, size_t n) {
   lk->periodic = ir.periodic;
   for (uint32_t id : ir.cons) lk->out_ext.push_back(ir.nodes[id].ext ? 1 : 0);
   lk->jit = jit_program_build(ctx, ir);
-  MH_REQUIRE(lk->jit, "internal: lookup program was not compiled");
+  MH_REQUIRE(lk->jit || g_jit_compile_only, "internal: lookup program was not compiled");
   return lk.release();
 }

@@ -105,3 +105,5 @@ struct mh_lookup {
   size_t n_fractions() const { return out_ext.size() / 2; }
   static mh_lookup* load(mh_ctx* c, const u64* w, size_t n);
 };
+
+int jit_precompile_blob(const u64* w, size_t n);  // -> number of chunk kernels compiled into / found in the cache (no GPU)

@@ -222,6 +222,9 @@ int jit_program_max_vgprs(const JitProgram* p) {
   return mx;
 }
 
+thread_local bool g_jit_compile_only = false;
+thread_local int g_jit_last_chunks = 0;
+
 JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
   const int mode = ir.outputs ? 1 : env_int("MH_JIT", -1);  // 0: never, 1: always, default: large DAGs only
   if (mode == 0) return nullptr;
@@ -490,6 +493,7 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
     }
   }
   if (env_int("MH_JIT_NO_COMPILE", 0)) return nullptr;  // source generation only (tools, no GPU)
+  const bool compile_only = g_jit_compile_only;           // mh_jit_precompile: fill the cache, load nothing (no GPU needed)
 
   // ---- compile the chunks in parallel (cached on disk by source hash) ----
   const std::string cdir = cache_dir();
@@ -544,6 +548,10 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
     for (auto& t : th) t.join();
   }
   if (failed.load()) throw MhError(MH_ERR_INTERNAL, first_error);
+  if (compile_only) {
+    g_jit_last_chunks = (int)n_chunks;
+    return nullptr;
+  }
   std::unique_ptr<JitProgram> prog(new JitProgram());
   prog->ctx = ctx;
   prog->n_spill = n_spill;

@@ -39,3 +39,8 @@ static_assert(sizeof(JitArgs) == 14 * 8 + 4 * 8 + 7 * 4 + 4, "JitArgs layout is 
 void jit_quotient_run(mh_ctx* c, const JitProgram* p, JitArgs a, size_t total);
 size_t jit_program_chunks(const JitProgram* p);
 int jit_program_max_vgprs(const JitProgram* p);
+
+// mh_jit_precompile: while set (per thread), jit_program_build compiles the chunks into the cache directory and returns null without
+// touching the GPU; g_jit_last_chunks = the number of chunks of the last such call.
+extern thread_local bool g_jit_compile_only;
+extern thread_local int g_jit_last_chunks;

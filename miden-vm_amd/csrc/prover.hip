@@ -1001,6 +1001,18 @@ void mh_air_free(mh_air* a) {
   delete a;
 }
 int mh_air_log_quotient_degree(const mh_air* a) { return a ? a->log_quotient_degree : -1; }
+int mh_jit_precompile(const uint64_t* blob, size_t n_words, int* n_chunks) {
+  try {
+    if (!blob) return MH_ERR_INVALID;
+    const int k = jit_precompile_blob(blob, n_words);
+    if (n_chunks) *n_chunks = k;
+    return MH_OK;
+  } catch (const MhError& e) {
+    return e.code;
+  } catch (const std::exception&) {
+    return MH_ERR_INTERNAL;
+  }
+}
 // ---- LogUp lookup programs -----------------------------------------------------------------------------
 int mh_lookup_load(mh_ctx* c, const uint64_t* blob, size_t n_words, mh_lookup** out) {
   MH_TRY(c)

@@ -358,3 +358,18 @@ def test_committed_blobs_are_current():
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "miden-vm_amd", "blobs")
     assert (np.fromfile(os.path.join(root, "chiplets.dag"), dtype="<u8") == air.blob).all(), "run tools/export_p2_air.py"
     assert (np.fromfile(os.path.join(root, "chiplets.lkp"), dtype="<u8") == lookup.blob).all(), "run tools/export_p2_air.py"
+
+
+def test_offline_precompile_fills_the_cache_without_a_gpu(tmp_path):
+    """mh_jit_precompile: hiprtc compiles the chiplets AIR's constraint chunks and its derived lookup program for gfx950 with no
+    GPU and no context; a second call finds the code objects (what mh_air_load does on the GPU box)."""
+    import time
+    air, _ = CA.chiplets_air()
+    d = str(tmp_path)
+    k = pkg.jit_precompile(air.blob, d)
+    assert k >= 2 and len(os.listdir(d)) == k
+    t0 = time.perf_counter()
+    assert pkg.jit_precompile(air.blob, d) == k and time.perf_counter() - t0 < 0.5
+    kl = pkg.jit_precompile(dag.lookup_from_constraints(air.blob).blob, d)
+    assert kl >= 1 and len(os.listdir(d)) == k + kl
+    assert pkg.jit_precompile(dag.dummy_miden_air(11, 2).blob, d) == 0     # small DAG: interpreted, nothing to compile

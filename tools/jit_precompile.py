@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Offline precompilation of the constraint / lookup kernels (mh_jit_precompile: hiprtc for gfx950, no GPU needed):
+
+    python tools/jit_precompile.py <cache_dir> [blob files ...]
+
+Without blob files: the AIRs this repository ships (ChipletsAir, Poseidon2PermutationAir, the tests' bus stand-in), their
+hand-written lookup programs and the ones derived from their constraint DAGs.  A prover service points MH_JIT_CACHE_DIR at the
+directory and never compiles on the request path (mh_air_load of the chiplets AIR: 5.7 s cold, 3 ms from the cache)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from __graft_entry__ import load_package
+
+
+def shipped_blobs():
+    from miden_vm_amd import dag, miden_air, chiplets_air, miden_statement
+    out = []
+    for name, (air, lookup) in (("chiplets", chiplets_air.chiplets_air()), ("chiplets_nopub", chiplets_air.chiplets_air(num_public=0)),
+                                ("poseidon2_permutation", miden_air.poseidon2_permutation_air()),
+                                ("poseidon2_permutation_pub32", miden_air.poseidon2_permutation_air(num_public=32)),
+                                ("bus_standin", miden_statement.bus_standin_air())):
+        out += [(name + ".dag", air.blob), (name + ".lkp", lookup.blob), (name + ".derived.lkp", dag.lookup_from_constraints(air.blob).blob)]
+    return out
+
+
+def main():
+    pkg = load_package()
+    cache = sys.argv[1]
+    os.makedirs(cache, exist_ok=True)
+    blobs = [(p, np.fromfile(p, dtype="<u8")) for p in sys.argv[2:]] or shipped_blobs()
+    for name, blob in blobs:
+        t0 = time.perf_counter()
+        k = pkg.jit_precompile(blob, cache)
+        print(f"{name}: {k} kernels, {time.perf_counter() - t0:.2f} s")
+
+
+if __name__ == "__main__":
+    main()
