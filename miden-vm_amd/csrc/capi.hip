@@ -63,6 +63,7 @@ int mh_ctx_create(int device_id, mh_ctx** out) {
     HIP_CHECK(hipSetDevice(device_id));
     c->device = device_id;
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->primary_stream = c->stream;
   } catch (const std::exception& e) {
     fprintf(stderr, "mh_ctx_create: %s\n", e.what());
     delete c;
@@ -103,6 +104,11 @@ int mh_ctx_trim(mh_ctx* c) {
   HIP_CHECK(hipSetDevice(c->device));
   c->sync();
   c->pool.trim();
+  // page-locked aux scratch (host_take / host_give) is cached per size class: a long-lived context proving varied shapes would keep
+  // every class for ever
+  if (c->copy_stream) HIP_CHECK(hipStreamSynchronize(c->copy_stream));
+  for (auto& b : c->host_pool) (void)hipHostFree(b.first);
+  c->host_pool.clear();
   MH_CATCH
 }
 

@@ -73,6 +73,7 @@ void mh_ctx::h2d(void* dst_dev, const void* src_host, size_t bytes) {
   const size_t need = (bytes + 63) & ~(size_t)63;
   if (ring_pos + need > RING_BYTES) {  // wrap (every few hundred proofs): copies still in flight on any stream of this context may read the start of the ring
     sync();
+    if (primary_stream && primary_stream != stream) HIP_CHECK(hipStreamSynchronize(primary_stream));  // `stream` may be swapped to the side stream
     if (side_stream) HIP_CHECK(hipStreamSynchronize(side_stream));
     if (copy_stream) HIP_CHECK(hipStreamSynchronize(copy_stream));
     ring_pos = 0;

@@ -134,6 +134,7 @@ struct mh_ctx {
   int device = 0;
   DevPool pool;
   hipStream_t stream = nullptr;
+  hipStream_t primary_stream = nullptr;  // = stream at creation; `stream` is swapped to the side stream inside commit_traces_pipelined
   hipStream_t side_stream = nullptr;  // commit_traces: forward NTTs of the next coset group under the leaf sponges of the previous one (created on first use)
   hipStream_t copy_stream = nullptr;  // mh_trace_upload_async: DMA copies + transposes that run under the proof's kernels (created on first use)
   std::string err;

@@ -24,13 +24,15 @@ struct mh_trace {
   // mh_trace_upload_async: the H2D copy + transpose run on the context's copy stream; `ready` is recorded behind them.  Every
   // consumer on the compute stream orders itself after it with trace_wait_ready() (a stream-side wait, no host block).
   hipEvent_t ready = nullptr;
-  DevBuf staging;  // the row-major landing buffer of the DMA, released once the trace has been consumed
+  mutable DevBuf staging;  // the row-major landing buffer of the DMA: back to the pool when the first consumer has ordered itself after `ready`
   // mh_trace_upload_cols_async (a COLUMN-major host matrix): the columns arrive in groups of `col_group`; group g is complete behind
   // col_ready[g] (`ready` = the last of them), so the LDE of group g runs while group g + 1 is still on the PCIe link.
   size_t col_group = 0;
   std::vector<hipEvent_t> col_ready;
   ~mh_trace() {
-    if (ready) (void)hipEventSynchronize(ready);  // the copy stream may still be writing cols / reading staging
+    // the copy stream may still be writing cols / reading staging -- also when an upload failed half-way (`ready` not recorded yet)
+    if (ready) (void)hipEventSynchronize(ready);
+    else if ((staging.p || !col_ready.empty()) && ctx && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (hipEvent_t e : col_ready)
       if (e != ready) (void)hipEventDestroy(e);
     if (ready) (void)hipEventDestroy(ready);

@@ -103,12 +103,16 @@ mh_trace* trace_upload_cols_async(mh_ctx* c, const u64* colmajor, int log_n, siz
     HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     t->col_ready.push_back(e);
     HIP_CHECK(hipEventRecord(e, c->copy_stream));
+    t->ready = e;  // always the last RECORDED event: a failure further down leaves a trace whose destructor still waits for the copies
   }
-  t->ready = t->col_ready.back();
   return t.release();
 }
 void trace_wait_ready(mh_ctx* c, const mh_trace* t) {
-  if (t && t->ready) HIP_CHECK(hipStreamWaitEvent(c->stream, t->ready, 0));
+  if (!t || !t->ready) return;
+  HIP_CHECK(hipStreamWaitEvent(c->stream, t->ready, 0));
+  // the transpose that read the landing buffer lies before `ready`, and whoever takes the buffer from the pool next runs on this
+  // stream (or fences its copy stream on it): the row-major copy does not have to live as long as the trace (2^24 x 51: 6.8 GB)
+  if (t->staging.p && c == t->ctx) t->staging.release();
 }
 
 mh_trace* trace_zeros(mh_ctx* c, int log_n, size_t width) {
@@ -275,6 +279,8 @@ static bool commit_traces_pipelined(mh_ctx* c, mh_tree* t, const std::vector<con
     lmcs_compress_layers(c, t);  // ends with a blocking copy of the root: both streams are idle when the coefficient buffers go back to the pool
   } catch (...) {
     (void)hipStreamSynchronize(c->side_stream);  // the side stream may still read the coefficient buffers this frame is about to free
+    c->event_pool.push_back(fence);
+    for (hipEvent_t e : done) c->event_pool.push_back(e);
     throw;
   }
   c->event_pool.push_back(fence);
