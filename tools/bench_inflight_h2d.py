@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """k proofs in flight on one GPU, every proof's host->device upload inside its step (bench.in_flight_h2d_probe), stand-alone for
-profiling:  rocprofv3 --kernel-trace --memory-copy-trace -d out -o t --output-format csv -- python tools/bench_inflight_h2d.py [k=3] [steps=4]
+profiling:  rocprofv3 --kernel-trace --memory-copy-trace -d out -o t --output-format csv -- python tools/bench_inflight_h2d.py [k=3] [steps=4] [log_n=20]
 and, with `--analyse out_dir`, the overlap report of such a run: how much of every big upload lies under kernels of the other
 contexts, and how long the small transcript copies of the other proofs waited behind it."""
 import os, sys, json, glob, csv
@@ -50,6 +50,7 @@ if __name__ == "__main__":
     pkg = load_package()
     k = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-    print(json.dumps(bench.in_flight_h2d_probe(pkg, 20, 0, k=k, steps=steps)))
-    print(json.dumps(bench.in_flight_h2d_probe(pkg, 20, 0, k=1, steps=2 * steps)))
-    print(json.dumps(bench.in_flight_probe(pkg, 20, 0, k=k, steps=steps)))
+    log_n = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+    print(json.dumps(bench.in_flight_h2d_probe(pkg, log_n, 0, k=k, steps=steps)), flush=True)
+    print(json.dumps(bench.in_flight_h2d_probe(pkg, log_n, 0, k=1, steps=2 * steps)), flush=True)
+    print(json.dumps(bench.in_flight_probe(pkg, log_n, 0, k=k, steps=steps)), flush=True)
