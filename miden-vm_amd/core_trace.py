@@ -1,0 +1,503 @@
+"""A small Miden VM executor that builds the CORE trace (system | decoder | stack | range: 51 columns) of a program together with the
+chiplet activity it causes -- the trace side of miden-vm_amd/core_air.py.  It covers straight-line blocks and the control-flow
+nodes JOIN / SPLIT / LOOP with a working subset of the instruction set (field, boolean, comparison, stack manipulation, u32
+arithmetic and bitwise, memory, HPERM, MPVERIFY / MRUPDATE, EVALCIRCUIT); procedure calls (CALL / SYSCALL / DYN / DYNCALL) and the
+advice-driven / FRI / Horner / stream operations are not executed here (their constraints are in the AIR, gated off by the flags).
+
+What is restated (file:line of the reference):
+
+* operation batching: core/src/mast/node/basic_block_node/op_batch.rs:248-372 (`OpBatchAccumulator`: groups of 9 opcodes of 7 bits,
+  immediates in the following group slots, NOOP padding, batches of 8 groups padded to a power of two), `batch_ops` /
+  `batch_and_hash_ops` (mod.rs:680-747: block digest = hash_elements of every batch's 8 group slots), `num_op_groups` (:166-169);
+* node digests: JOIN / SPLIT / LOOP = hash of the two child words with the opcode as the domain (core/src/mast/node/{join,split,
+  loop}_node.rs: DOMAIN), computed by the hasher chiplet (`hash_control_block`, processor/src/trace/chiplets/hasher/mod.rs:133-160);
+* decoder rows: processor/src/trace/parallel/tracer/trace_row.rs:43-140 (control-flow rows, SPAN / RESPAN rows with the batch
+  flags, operation rows with h0 = rest of the group, h1 = parent address, helpers in h2..h7), :142-236 (basic blocks, RESPAN bumps
+  the block address by 2), :240-415 (JOIN / SPLIT / LOOP / REPEAT / END rows), :418-446 (op bits, the two extra columns),
+  group counting processor/src/trace/parallel/core_trace_fragment/mod.rs:46-134; END flags trace_state.rs:378-420; the do-while LOOP
+  of processor/src/execution/loop.rs:24-160 (LOOP enters the body unconditionally, REPEAT / END pop the condition);
+* a row holds the state BEFORE its operation (trace_row.rs:420-436: system and stack columns are those stored by the previous
+  call); `clk` = row index, overflow bookkeeping b0 = depth, b1 = address (clk) of the top overflow entry, h0 = 1 / (b0 - 16);
+* helper registers per operation: processor/src/tracer.rs:491-640;
+* range table: processor/src/trace/range/mod.rs:17-215 (values 0 and 65535 always present, bridge rows in steps of 3^k, the table
+  sits at the END of the core trace, padding rows (0, 0) in front of it).
+"""
+import numpy as np
+from . import chiplets_trace as CT
+from . import core_air as CO
+from . import chiplets_air as CA
+
+P = CT.P
+OPC = CO.OPC
+GROUP_SIZE, BATCH_SIZE = 9, 8
+
+
+# ---- program nodes -----------------------------------------------------------------------------------------------------------------
+class Span:
+    def __init__(self, ops):
+        """ops: [(name,) or (name, immediate)] -- names of core_air.OPC; only PUSH carries an immediate."""
+        self.ops = [(o,) if isinstance(o, str) else tuple(o) for o in ops]
+        self.batches = batch_ops(self.ops)
+        groups = [g for b in self.batches for g in b["groups"]]
+        self.digest = CT.hash_elements(groups)
+
+
+class Join:
+    def __init__(self, first, second):
+        self.first, self.second = first, second
+        self.digest = CT.merge(first.digest, second.digest, OPC["JOIN"])
+
+
+class Split:
+    def __init__(self, on_true, on_false):
+        self.on_true, self.on_false = on_true, on_false
+        self.digest = CT.merge(on_true.digest, on_false.digest, OPC["SPLIT"])
+
+
+class Loop:
+    def __init__(self, body):
+        self.body = body
+        self.digest = CT.merge(body.digest, [0, 0, 0, 0], OPC["LOOP"])
+
+
+# ---- OpBatchAccumulator (op_batch.rs:248-372) ----------------------------------------------------------------------------------------
+class _Acc:
+    INVALID = BATCH_SIZE * GROUP_SIZE + 1
+
+    def __init__(self):
+        self.ops, self.indptr, self.padding, self.groups = [], [0] * (BATCH_SIZE + 1), [False] * BATCH_SIZE, [0] * BATCH_SIZE
+        self.group, self.op_idx, self.group_idx, self.next_group_idx = 0, 0, 0, 1
+
+    @staticmethod
+    def imm(op):
+        return op[1] if op[0] == "PUSH" else None
+
+    def can_accept(self, op):
+        if self.imm(op) is not None:
+            return self.next_group_idx < BATCH_SIZE if self.op_idx < GROUP_SIZE - 1 else self.next_group_idx + 1 < BATCH_SIZE
+        return self.op_idx < GROUP_SIZE or self.next_group_idx < BATCH_SIZE
+
+    def add_op(self, op):
+        if self.op_idx == GROUP_SIZE:
+            self.finalize_group()
+        if self.imm(op) is not None:
+            if self.op_idx == GROUP_SIZE - 1:
+                self.finalize_group()
+            self.groups[self.next_group_idx] = int(self.imm(op)) % P
+            self.indptr[self.next_group_idx] = self.INVALID
+            self.next_group_idx += 1
+        self.push_op(op)
+
+    def push_op(self, op):
+        self.group |= OPC[op[0]] << (7 * self.op_idx)
+        self.ops.append(op)
+        self.op_idx += 1
+
+    def pad_if_needed(self):
+        if self.op_idx == 0 or (self.ops and self.imm(self.ops[-1]) is not None):
+            self.push_op(("NOOP",))
+            self.padding[self.group_idx] = True
+
+    def finalize_indptr(self):
+        self.indptr[self.next_group_idx] = len(self.ops)
+        k = self.next_group_idx - 1
+        while k >= self.group_idx and self.indptr[k] == self.INVALID:
+            self.indptr[k] = len(self.ops)
+            k -= 1
+
+    def finalize_group(self):
+        self.pad_if_needed()
+        self.groups[self.group_idx] = self.group
+        self.finalize_indptr()
+        self.group_idx = self.next_group_idx
+        self.next_group_idx = self.group_idx + 1
+        self.op_idx, self.group = 0, 0
+
+    def into_batch(self):
+        num_groups = self.next_group_idx
+        target = 1 << (num_groups - 1).bit_length()
+        for _ in range(num_groups, target):
+            self.finalize_group()
+        if self.group != 0 or self.op_idx != 0:
+            self.groups[self.group_idx] = self.group
+        self.pad_if_needed()
+        self.finalize_indptr()
+        for i in range(self.next_group_idx, BATCH_SIZE + 1):
+            self.indptr[i] = len(self.ops)
+        return dict(ops=self.ops, indptr=self.indptr, groups=self.groups, num_groups=self.next_group_idx)
+
+
+def batch_ops(ops):
+    batches, acc = [], _Acc()
+    for op in ops:
+        if not acc.can_accept(op):
+            batches.append(acc.into_batch())
+            acc = _Acc()
+        acc.add_op(op)
+    if acc.ops:
+        batches.append(acc.into_batch())
+    assert batches, "a basic block holds at least one operation"
+    return batches
+
+
+def op_batch_flags(num_groups):   # air/src/trace/decoder: OP_BATCH_{8,4,2,1}_GROUPS
+    return {8: (1, 0, 0), 4: (0, 1, 0), 2: (0, 0, 1), 1: (0, 1, 1)}[min(num_groups, 8)]
+
+
+# ---- the machine -----------------------------------------------------------------------------------------------------------------------
+def _inv(x):
+    return pow(int(x) % P, P - 2, P) if int(x) % P else 0
+
+
+def _u16_limbs(x):
+    return [x & 0xFFFF, (x >> 16) & 0xFFFF]
+
+
+class CoreVM:
+    def __init__(self, stack_inputs=(), kernel_proc_hashes=()):
+        self.chiplets = CT.Chiplets(kernel_proc_hashes)
+        init = [int(x) % P for x in stack_inputs] + [0] * (16 - len(stack_inputs))
+        assert len(init) == 16
+        self.stack_inputs = list(init)
+        self.top, self.overflow = list(init), []          # overflow: [(value, clk of the push)]
+        self.rows = []
+        self.range_lookups = {0: 0, 65535: 0}
+        self.ctx, self.fn_hash = 0, [0, 0, 0, 0]
+
+    # -- rows --
+    @property
+    def clk(self):
+        return len(self.rows)
+
+    def _row(self, opcode, addr, hasher, in_span=0, group_count=0, op_index=0, batch_flags=(0, 0, 0)):
+        r = [0] * CO.NUM_CORE_COLS
+        r[CO.CLK], r[CO.CTX] = self.clk, self.ctx
+        for i in range(4):
+            r[CO.FN_HASH[i]] = self.fn_hash[i]
+        r[CO.DEC_ADDR] = addr
+        for i in range(7):
+            r[CO.DEC_OP_BITS[i]] = (opcode >> i) & 1
+        for i in range(8):
+            r[CO.DEC_HASHER[i]] = int(hasher[i]) % P
+        r[CO.DEC_IN_SPAN], r[CO.DEC_GROUP_COUNT], r[CO.DEC_OP_INDEX] = in_span, group_count, op_index
+        for i in range(3):
+            r[CO.DEC_BATCH_FLAGS[i]] = batch_flags[i]
+        b6, b5, b4 = (opcode >> 6) & 1, (opcode >> 5) & 1, (opcode >> 4) & 1
+        r[CO.DEC_EXTRA[0]], r[CO.DEC_EXTRA[1]] = b6 * (1 - b5) * b4, b6 * b5
+        for i in range(16):
+            r[CO.STACK_TOP[i]] = self.top[i]
+        depth = 16 + len(self.overflow)
+        r[CO.STACK_B0], r[CO.STACK_B1] = depth, (self.overflow[-1][1] if self.overflow else 0)
+        r[CO.STACK_H0] = _inv(depth - 16)
+        self.rows.append(r)
+
+    # -- stack primitives --
+    def _shift_right(self, new_top_value):
+        """Push: s15 goes to the overflow table under the current clk (the clk of the row being executed)."""
+        self.overflow.append((self.top[15], self.clk - 1))
+        self.top = [int(new_top_value) % P] + self.top[:15]
+
+    def _shift_left(self, new_prefix, start):
+        """The first `start` positions are consumed and replaced by `new_prefix` (len = start - 1); positions start.. move up by one;
+        s15 comes from the overflow table (or 0)."""
+        incoming = self.overflow.pop()[0] if self.overflow else 0
+        self.top = [int(x) % P for x in new_prefix] + self.top[start:] + [incoming]
+        assert len(self.top) == 16
+
+    def _range_check(self, values):
+        for v in values:
+            assert 0 <= v < 1 << 16
+            self.range_lookups[v] = self.range_lookups.get(v, 0) + 1
+
+    # -- operations: returns the six user-op helper registers --
+    def _exec(self, name, imm):
+        s, clk = self.top, self.clk - 1            # the row of this operation has just been written
+        H = [0] * 6
+        if name == "NOOP":
+            pass
+        elif name == "PAD":
+            self._shift_right(0)
+        elif name == "PUSH":
+            self._shift_right(imm)
+        elif name == "DROP":
+            self._shift_left([], 1)
+        elif name.startswith("DUP"):
+            self._shift_right(s[int(name[3:])])
+        elif name == "CLK":
+            self._shift_right(clk)
+        elif name == "SDEPTH":
+            self._shift_right(16 + len(self.overflow))
+        elif name == "SWAP":
+            self.top = [s[1], s[0]] + s[2:]
+        elif name.startswith("MOVUP"):
+            k = int(name[5:])
+            self.top = [s[k]] + s[:k] + s[k + 1:]
+        elif name.startswith("MOVDN"):
+            k = int(name[5:])
+            self.top = s[1:k + 1] + [s[0]] + s[k + 1:]
+        elif name == "SWAPW":
+            self.top = s[4:8] + s[0:4] + s[8:]
+        elif name == "SWAPW2":
+            self.top = s[8:12] + s[4:8] + s[0:4] + s[12:]
+        elif name == "SWAPW3":
+            self.top = s[12:16] + s[4:12] + s[0:4]
+        elif name == "SWAPDW":
+            self.top = s[8:16] + s[0:8]
+        elif name == "ADD":
+            self._shift_left([(s[0] + s[1]) % P], 2)
+        elif name == "MUL":
+            self._shift_left([s[0] * s[1] % P], 2)
+        elif name == "NEG":
+            self.top = [(P - s[0]) % P] + s[1:]
+        elif name == "INV":
+            assert s[0] != 0
+            self.top = [_inv(s[0])] + s[1:]
+        elif name == "INCR":
+            self.top = [(s[0] + 1) % P] + s[1:]
+        elif name == "NOT":
+            assert s[0] in (0, 1)
+            self.top = [1 - s[0]] + s[1:]
+        elif name == "AND":
+            assert s[0] in (0, 1) and s[1] in (0, 1)
+            self._shift_left([s[0] & s[1]], 2)
+        elif name == "OR":
+            assert s[0] in (0, 1) and s[1] in (0, 1)
+            self._shift_left([s[0] | s[1]], 2)
+        elif name == "EQ":
+            H[0] = _inv(s[0] - s[1])
+            self._shift_left([1 if s[0] == s[1] else 0], 2)
+        elif name == "EQZ":
+            H[0] = _inv(s[0])
+            self.top = [1 if s[0] == 0 else 0] + s[1:]
+        elif name == "ASSERT":
+            assert s[0] == 1, "ASSERT failed"
+            self._shift_left([], 1)
+        elif name == "CSWAP":
+            assert s[0] in (0, 1)
+            a, b = (s[2], s[1]) if s[0] else (s[1], s[2])
+            self._shift_left([a, b], 3)
+        elif name == "CSWAPW":
+            assert s[0] in (0, 1)
+            w0, w1 = (s[5:9], s[1:5]) if s[0] else (s[1:5], s[5:9])
+            self._shift_left(w0 + w1, 9)
+        elif name == "EXPACC":
+            # [bit, base, acc, exp] -> [exp & 1, base^2, acc * (bit' ? base : 1), exp >> 1]
+            base, acc, e = s[1], s[2], s[3]
+            bit = e & 1
+            val = base if bit else 1
+            H[0] = val
+            self.top = [bit, base * base % P, acc * val % P, e >> 1] + s[4:]
+        elif name == "EXT2MUL":
+            b0, b1, a0, a1 = s[0:4]
+            self.top = [b0, b1, (a0 * b0 + 7 * a1 * b1) % P, (a0 * b1 + a1 * b0) % P] + s[4:]
+        elif name in ("U32ADD", "U32ADD3", "U32MUL", "U32MADD", "U32SPLIT", "U32SUB", "U32DIV", "U32ASSERT2"):
+            if name == "U32SPLIT":
+                v = s[0]
+                lo, hi = v & 0xFFFFFFFF, v >> 32
+                H[0:4] = _u16_limbs(lo) + _u16_limbs(hi)
+                H[4] = _inv(0xFFFFFFFF - hi)
+                self.top = [hi] + s[1:]
+                self._shift_right(lo)
+            elif name in ("U32ADD", "U32ADD3"):
+                n = 2 if name == "U32ADD" else 3
+                assert all(x < 1 << 32 for x in s[0:n])
+                v = sum(s[0:n])
+                lo, hi = v & 0xFFFFFFFF, v >> 32
+                H[0:4] = _u16_limbs(lo) + _u16_limbs(hi)
+                if n == 2:
+                    self.top = [lo, hi] + s[2:]
+                else:
+                    self._shift_left([lo, hi], 3)
+            elif name in ("U32MUL", "U32MADD"):
+                n = 2 if name == "U32MUL" else 3
+                assert all(x < 1 << 32 for x in s[0:n])
+                v = s[0] * s[1] + (s[2] if n == 3 else 0)
+                lo, hi = v & 0xFFFFFFFF, v >> 32
+                H[0:4] = _u16_limbs(lo) + _u16_limbs(hi)
+                H[4] = _inv(0xFFFFFFFF - hi)
+                if n == 2:
+                    self.top = [lo, hi] + s[2:]
+                else:
+                    self._shift_left([lo, hi], 3)
+            elif name == "U32SUB":
+                assert s[0] < 1 << 32 and s[1] < 1 << 32
+                d = s[1] - s[0]
+                borrow, diff = (1, d + (1 << 32)) if d < 0 else (0, d)
+                H[0:2] = _u16_limbs(diff)
+                self.top = [borrow, diff] + s[2:]
+            elif name == "U32DIV":
+                assert s[0] < 1 << 32 and s[1] < 1 << 32 and s[0] != 0
+                q, r = divmod(s[1], s[0])
+                H[0:4] = _u16_limbs(s[1] - q) + _u16_limbs(s[0] - r - 1)
+                self.top = [r, q] + s[2:]
+            else:  # U32ASSERT2
+                assert s[0] < 1 << 32 and s[1] < 1 << 32
+                H[0:4] = _u16_limbs(s[1]) + _u16_limbs(s[0])
+            self._range_check(H[0:4])
+        elif name in ("U32AND", "U32XOR"):
+            r = (self.chiplets.bitwise.u32and if name == "U32AND" else self.chiplets.bitwise.u32xor)(s[0], s[1])
+            self._shift_left([r], 2)
+        elif name == "MLOAD":
+            self.top = [self.chiplets.memory.read(self.ctx, s[0], clk)] + s[1:]
+        elif name == "MSTORE":
+            self.chiplets.memory.write(self.ctx, s[0], clk, s[1])
+            self._shift_left([], 1)
+        elif name == "MLOADW":
+            w = self.chiplets.memory.read_word(self.ctx, s[0], clk)
+            self._shift_left(w, 5)
+        elif name == "MSTOREW":
+            self.chiplets.memory.write_word(self.ctx, s[0], clk, s[1:5])
+            self._shift_left([], 1)
+        elif name == "HPERM":
+            addr, out = self.chiplets.hasher.permute(s[0:12])
+            H[0] = addr
+            self.top = out + s[12:]
+        elif name == "MPVERIFY":
+            node, depth, index, root = s[0:4], s[4], s[5], s[6:10]
+            path = self.advice_paths[(tuple(root), index, depth)]
+            addr, got = self.chiplets.hasher.build_merkle_root(node, path, index)
+            assert got == root, "MPVERIFY: wrong root"
+            H[0] = addr
+        elif name == "MRUPDATE":
+            old, depth, index, root, new = s[0:4], s[4], s[5], s[6:10], s[10:14]
+            path = self.advice_paths[(tuple(root), index, depth)]
+            addr, old_root, new_root = self.chiplets.hasher.update_merkle_root(old, new, path, index)
+            assert old_root == root, "MRUPDATE: wrong root"
+            H[0] = addr
+            self.top = new_root + s[4:]
+        elif name == "EVALCIRCUIT":
+            self.chiplets.ace.eval_circuit(self.chiplets.memory, self.ctx, s[0], clk, s[1], s[2])
+        else:
+            raise NotImplementedError(f"operation {name} is not executed by this VM")
+        return H
+
+    # -- nodes --
+    def run(self, node, parent_addr=0, is_loop_body=0):
+        if isinstance(node, Span):
+            self._run_span(node, parent_addr, is_loop_body)
+        elif isinstance(node, Join):
+            addr, dig = self.chiplets.hasher.hash_control_block(node.first.digest, node.second.digest, OPC["JOIN"])
+            assert dig == node.digest
+            self._row(OPC["JOIN"], parent_addr, node.first.digest + node.second.digest)
+            self.run(node.first, addr)
+            self.run(node.second, addr)
+            self._row(OPC["END"], addr, node.digest + [is_loop_body, 0, 0, 0])
+        elif isinstance(node, Split):
+            addr, dig = self.chiplets.hasher.hash_control_block(node.on_true.digest, node.on_false.digest, OPC["SPLIT"])
+            assert dig == node.digest
+            self._row(OPC["SPLIT"], parent_addr, node.on_true.digest + node.on_false.digest)
+            cond = self.top[0]
+            assert cond in (0, 1)
+            self._shift_left([], 1)
+            self.run(node.on_true if cond else node.on_false, addr)
+            self._row(OPC["END"], addr, node.digest + [is_loop_body, 0, 0, 0])
+        elif isinstance(node, Loop):
+            addr, dig = self.chiplets.hasher.hash_control_block(node.body.digest, [0, 0, 0, 0], OPC["LOOP"])
+            assert dig == node.digest
+            self._row(OPC["LOOP"], parent_addr, node.body.digest + [0, 0, 0, 0])
+            while True:                                    # do-while: the body runs, then its condition sits on the stack
+                self.run(node.body, addr, is_loop_body=1)
+                if self.top[0] == 1:
+                    self._row(OPC["REPEAT"], addr, node.body.digest + [1, 0, 0, 0])
+                    self._shift_left([], 1)
+                else:
+                    assert self.top[0] == 0, "loop condition must be binary"
+                    self._row(OPC["END"], addr, node.digest + [is_loop_body, 1, 0, 0])
+                    self._shift_left([], 1)
+                    break
+        else:
+            raise TypeError(node)
+
+    def _run_span(self, node, parent_addr, is_loop_body):
+        batches = node.batches
+        addr, dig = self.chiplets.hasher.hash_basic_block([b["groups"] for b in batches])
+        assert dig == node.digest
+        total = (len(batches) - 1) * BATCH_SIZE + (1 << (batches[-1]["num_groups"] - 1).bit_length())
+        group_count = total
+        cur_addr = addr
+        for bi, batch in enumerate(batches):
+            left_here = sum(b["num_groups"] for b in batches[bi:])
+            if bi == 0:
+                self._row(OPC["SPAN"], parent_addr, batch["groups"], group_count=group_count, batch_flags=op_batch_flags(left_here))
+            else:
+                self._row(OPC["RESPAN"], cur_addr, batch["groups"], group_count=group_count, batch_flags=op_batch_flags(left_here))
+                cur_addr += 2
+            group_count -= 1                               # the batch's first group starts decoding
+            ops, indptr, groups = batch["ops"], batch["indptr"], batch["groups"]
+            prev_group = 0
+            for k, op in enumerate(ops):
+                g = max(i for i in range(batch["num_groups"]) if indptr[i] <= k and k < indptr[i + 1])
+                idx_in_group = k - indptr[g]
+                if g != prev_group:                        # a new op group starts: the groups up to it (immediates included) are consumed
+                    group_count = (total - sum((1 << (b["num_groups"] - 1).bit_length()) for b in batches[:bi])) - (g + 1)
+                    prev_group = g
+                rest = groups[g] >> (7 * (idx_in_group + 1))
+                # helpers are known only after executing: write the row with placeholders, run the op, patch the helpers in
+                self._row(OPC[op[0]], cur_addr, [rest, parent_addr, 0, 0, 0, 0, 0, 0], in_span=1, group_count=group_count, op_index=idx_in_group)
+                row = self.rows[-1]
+                H = self._exec(op[0], op[1] if len(op) > 1 else None)
+                for i in range(6):
+                    row[CO.DEC_HASHER[2 + i]] = int(H[i]) % P
+                if op[0] == "PUSH":
+                    group_count -= 1
+        assert group_count == 0, group_count
+        self._row(OPC["END"], cur_addr, node.digest + [is_loop_body, 0, 0, 0])
+
+    # -- finish --
+    def finish(self, log_n=None):
+        """HALT rows up to a power-of-two height, the range table at the end; -> dict(core, chiplets, poseidon2, public_values,
+        program rows)."""
+        assert len(self.overflow) == 0, "the program must leave the stack at depth 16"
+        n_prog = len(self.rows)
+        self.chiplets.memory_range_checks(self.range_lookups)
+        table = range_table(self.range_lookups)
+        need = max(n_prog + 1, len(table))
+        log_n = max(6, (need - 1).bit_length()) if log_n is None else log_n
+        n = 1 << log_n
+        assert need <= n
+        while len(self.rows) < n:
+            self._row(OPC["HALT"], 0, [0] * 8)
+        core = np.array(self.rows, dtype=np.uint64)
+        core[n - len(table):, CO.RANGE_M] = [m for m, _ in table]
+        core[n - len(table):, CO.RANGE_V] = [v for _, v in table]
+        return core
+
+
+def range_table(lookups):
+    """RangeChecker::emit_table_rows (range/mod.rs:61-75, 120-145): [(multiplicity, value)], ending with (0, 65535)."""
+    rows, prev = [], 0
+    for value in sorted(lookups):
+        gap, pv, stride = value - prev, prev, 3 ** 7
+        while gap != stride:
+            if gap > stride:
+                gap -= stride
+                pv += stride
+                rows.append((0, pv))
+            else:
+                stride //= 3
+        rows.append((lookups[value], value))
+        prev = value
+    rows.append((0, 65535))
+    return rows
+
+
+def _memory_range_checks(self, lookups):
+    """Memory::append_range_checks (memory/mod.rs:170-222): the two delta limbs and w0, w1, 4 * w1 of every memory row."""
+    sec = self.memory.section()
+    for r in sec:
+        for v in (int(r[11]), int(r[12]), int(r[15]), int(r[16]), 4 * int(r[16])):
+            lookups[v] = lookups.get(v, 0) + 1
+
+
+CT.Chiplets.memory_range_checks = _memory_range_checks
+
+
+def prove_inputs(vm, program, log_n=None):
+    """Run `program` to completion: -> dict(core, chiplets, poseidon2, public_values, aux_inputs, program_hash)."""
+    vm.run(program)
+    outputs = list(vm.top)
+    core = vm.finish(log_n)
+    chiplets, p2 = vm.chiplets.into_traces()
+    kernel = [x for d in vm.chiplets.kernel_rom.digests() for x in d]
+    return dict(core=core, chiplets=chiplets, poseidon2=p2, public_values=vm.stack_inputs + outputs,
+                aux_inputs=list(program.digest) + [0, 0, 0, 0] + kernel, program_hash=list(program.digest))

@@ -121,6 +121,9 @@ def main():
     msg = open(f"{REF}/air/src/constraints/lookup/messages.rs").read()
     enum = msg[msg.index("pub enum BusId"):msg.index("impl BusId")]
     out["bus_ids"] = {k: int(v) for k, v in re.findall(r"(\w+) = (\d+),", enum)}
+    # 10. the VM's opcodes (core/src/operations/mod.rs:29-129)
+    ops_src = open(f"{REF}/core/src/operations/mod.rs").read()
+    out["opcodes"] = {k: int(v.replace("_", ""), 2) for k, v in re.findall(r"pub const (\w+): u8\s*= 0b([01_]+);", ops_src)}
     with open(os.path.join(HERE, "kat.json"), "w") as f:
         json.dump(out, f, indent=0)
     print("wrote kat.json:", {k: (len(v) if hasattr(v, '__len__') else v) for k, v in out.items()})

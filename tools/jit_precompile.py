@@ -14,9 +14,9 @@ from __graft_entry__ import load_package
 
 
 def shipped_blobs():
-    from miden_vm_amd import dag, miden_air, chiplets_air, miden_statement
+    from miden_vm_amd import dag, miden_air, chiplets_air, miden_statement, core_air
     out = []
-    for name, (air, lookup) in (("chiplets", chiplets_air.chiplets_air()), ("chiplets_nopub", chiplets_air.chiplets_air(num_public=0)),
+    for name, (air, lookup) in (("core", core_air.core_air()), ("chiplets", chiplets_air.chiplets_air()), ("chiplets_nopub", chiplets_air.chiplets_air(num_public=0)),
                                 ("poseidon2_permutation", miden_air.poseidon2_permutation_air()),
                                 ("poseidon2_permutation_pub32", miden_air.poseidon2_permutation_air(num_public=32)),
                                 ("bus_standin", miden_statement.bus_standin_air())):
