@@ -501,3 +501,22 @@ def prove_inputs(vm, program, log_n=None):
     kernel = [x for d in vm.chiplets.kernel_rom.digests() for x in d]
     return dict(core=core, chiplets=chiplets, poseidon2=p2, public_values=vm.stack_inputs + outputs,
                 aux_inputs=list(program.digest) + [0, 0, 0, 0] + kernel, program_hash=list(program.digest))
+
+
+def bench_program(iters):
+    """A loop of `iters` iterations over a hash / u32 / memory mix (about 100 core rows, 70 chiplet rows and one fresh Poseidon2
+    permutation per iteration): the workload of the bench's `miden_real` key and of the full-size GPU tests.  Stack at loop entry:
+    [counter, x, y, ...]."""
+    body = Span([
+        "DUP1", "DUP3", "U32AND", "DROP", "DUP1", "DUP3", "U32XOR", "MOVDN2", "SWAP", "DROP",           # y <- x ^ y
+        "DUP1", ("PUSH", 0x9E3779B9), "U32ADD", "DROP", "MOVDN2", "SWAP", "DROP",                        # x <- x + golden ratio (mod 2^32)
+        "DUP1", "DUP3", "U32MUL", "DROP", "DROP", "DUP1", "DUP3", "U32AND", "DROP", "DUP2", "DUP2", "U32XOR", "DROP",
+        "DUP1", ("PUSH", 0xFF00FF00), "U32AND", "DROP", "DUP2", ("PUSH", 0x0F0F0F0F), "U32XOR", "DROP",
+        "DUP1", ("PUSH", 7), "U32DIV", "DROP", "DROP", "DUP2", "DUP2", "U32SUB", "DROP", "DROP",
+        "DUP0", ("PUSH", 4), "MUL", "DUP2", "SWAP", "MSTORE", "DROP",                                      # mem[4 * counter] <- x
+        "DUP0", ("PUSH", 4), "MUL", "MLOAD", "DROP",
+        "DUP0", ("PUSH", 4), "MUL", ("PUSH", 1 << 20), "ADD", "PAD", "PAD", "DUP5", "DUP5", "MOVUP4", "MSTOREW", "DROP", "DROP", "DROP", "DROP",
+        "PAD", "PAD", "PAD", "PAD", "DUP4", "DUP6", "DUP7", "DUP7", "DUP11", "DUP13", "DUP15", "DUP15", "HPERM",  # state holds counter, x, y
+        "DROP", "DROP", "DROP", "DROP", "DROP", "DROP", "DROP", "DROP", "DROP", "DROP", "DROP", "DROP",
+        ("PUSH", 1), "NEG", "ADD", "DUP0", "EQZ", "NOT"])                                                 # counter -= 1; repeat while != 0
+    return Join(Span([("PUSH", 0x1234), ("PUSH", 0xABCDEF), ("PUSH", iters)]), Join(Loop(body), Span(["DROP", "DROP", "DROP"])))

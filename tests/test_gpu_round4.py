@@ -14,7 +14,7 @@ import pytest
 import oracle_binding as ob
 import airs as A
 from __graft_entry__ import load_package
-from miden_vm_amd import dag, protocol, miden_air as MA, chiplets_air as CA, chiplets_trace as CT, miden_statement as MS
+from miden_vm_amd import dag, protocol, miden_air as MA, chiplets_air as CA, chiplets_trace as CT, miden_statement as MS, core_air as CO, core_trace as CV
 from test_gpu_prove import FAST
 
 pytestmark = pytest.mark.gpu
@@ -190,3 +190,63 @@ def test_column_major_trace_producer_feeds_the_pipelined_upload(ctx):
     b = prove(ctx.upload_trace(rows))
     assert a.bytes == b.bytes
     assert pkg.verify([air], [log_n], [], prm, st, pre, a.fields, a.commitments)[0]
+
+
+# ---- the complete Miden statement: CoreAir + ChipletsAir + Poseidon2PermutationAir over one executed program -----------------------
+def real_statement(program, stack_inputs=tuple(range(1, 17)), host_aux=True):
+    aux = ob.lookup_build_aux if host_aux else None
+    core, _ = CO.core_air(host_aux=aux)
+    ch, _ = CA.chiplets_air(host_aux=aux)
+    p2, _ = MA.poseidon2_permutation_air(host_aux=aux, num_public=32)
+    r = CV.prove_inputs(CV.CoreVM(stack_inputs=stack_inputs), program)
+    return [core, ch, p2], [r["core"], r["chiplets"], r["poseidon2"]], r
+
+
+def device_prove(ctx, airs_, traces, pub, prm, stt, pre):
+    pkg = load_package()
+    dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+    for d, a in zip(dairs, airs_):
+        d.attach_lookup(pkg.DeviceLookup(ctx, dag.lookup_from_constraints(a.blob)))
+    return dairs, pkg.prove(ctx, dairs, [ctx.upload_trace(t) for t in traces], pub, prm, stt, pre, never)
+
+
+@pytest.mark.parametrize("jit", ["0", "1"])
+def test_real_miden_statement_device_proof_equals_oracle(ctx, jit, monkeypatch):
+    """A program with every control-flow node and every executed instruction (tests/test_core_air.py::big_program), the reference's
+    statement framing, all eight aux columns built on the device: the proof equals the oracle's bit for bit through the interpreter
+    and through the compiled chunks; the statement's external assertion accepts it; a forged output is refused."""
+    import test_core_air as TC
+    pkg = load_package()
+    monkeypatch.setenv("MH_JIT", jit)
+    airs_, traces, r = real_statement(TC.big_program())
+    pub, aux_inputs = r["public_values"], r["aux_inputs"]
+    lhs = [int(t.shape[0]).bit_length() - 1 for t in traces]
+    pre = MS.statement_pre_observe(FAST, pub, aux_inputs)
+    stt = protocol.challenger_state(KAT["relation_digest"])
+    exp = ob.prove(airs_, traces, pub, FAST, init_state=stt, pre_observe=pre)
+    dairs, got = device_prove(ctx, airs_, traces, pub, FAST, stt, pre)
+    assert (dairs[0].compiled_chunks > 0) == (jit == "1")
+    same(got, exp)
+    ext = MS.external_assertions(pkg, pub, aux_inputs)
+    ok, dig = pkg.verify(airs_, lhs, pub, FAST, stt, pre, got.fields, got.commitments, external=ext)
+    assert ok and (dig == got.digest).all(), dig
+    assert ob.verify(airs_, lhs, pub, {"fields": got.fields, "commitments": got.commitments}, FAST, init_state=stt, pre_observe=pre, external=ext)[0]
+    pv = list(pub)
+    pv[17] = (pv[17] + 1) % ob.P
+    assert not pkg.verify(airs_, lhs, pv, FAST, stt, MS.statement_pre_observe(FAST, pv, aux_inputs), got.fields, got.commitments, external=ext)[0]
+
+
+def test_real_miden_statement_production_params(ctx, fast_oracle):
+    """The loop workload of the bench (core 2^15, chiplets 2^14, Poseidon2 2^12 rows), production parameters: device == oracle."""
+    pkg = load_package()
+    airs_, traces, r = real_statement(CV.bench_program(150), stack_inputs=tuple(range(16)))
+    pub, aux_inputs = r["public_values"], r["aux_inputs"]
+    prm = dict(ob.PROD_PARAMS)
+    pre = MS.statement_pre_observe(prm, pub, aux_inputs)
+    stt = protocol.challenger_state(KAT["relation_digest"])
+    exp = ob.prove(airs_, traces, pub, prm, init_state=stt, pre_observe=pre)
+    dairs, got = device_prove(ctx, airs_, traces, pub, prm, stt, pre)
+    same(got, exp)
+    lhs = [int(t.shape[0]).bit_length() - 1 for t in traces]
+    ok, dig = pkg.verify(airs_, lhs, pub, prm, stt, pre, got.fields, got.commitments, external=MS.external_assertions(pkg, pub, aux_inputs))
+    assert ok, dig
