@@ -320,7 +320,7 @@ def chiplets_air_probe(pkg, ctx, log_n=20, steps=3):
     return out
 
 
-def miden_real_probe(pkg, ctx, iters=9400, steps=3):
+def miden_real_probe(pkg, ctx, iters=9250, steps=3):
     """THE Miden statement, no stand-ins: CoreAir + ChipletsAir + Poseidon2PermutationAir (miden-vm_amd/{core,chiplets,miden}_air.py) over
     the traces of ONE executed program -- a loop over a hash / u32 / memory mix run by the small VM of miden-vm_amd/core_trace.py --
     with the reference's statement framing (RELATION_DIGEST, observe_protocol_params, `MidenMultiAir::observe`), production parameters,

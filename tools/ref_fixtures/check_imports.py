@@ -7,7 +7,9 @@ across workspace crates).  A moved or renamed item fails here instead of on the 
     python tools/ref_fixtures/check_imports.py [/path/to/miden-vm]      (default /root/reference)
 
 What it cannot see: items of crates outside the workspace (Plonky3, wincode: reported as "external"), trait-method
-resolution, generics.  It is a path check, not a type check.
+resolution, generics.  Beyond paths it compares, for the calls on the `prove_stark` path (SIGNATURES), the number of arguments at
+the kits' call sites and a fragment of each parameter type with the reference's declarations: a hand-made type check of the
+calls that matter, not a compiler.
 """
 import os
 import re
@@ -269,6 +271,25 @@ class Workspace:
                     return rel
         return None
 
+    def method_params(self, type_name, method):
+        """Parameter list (without the receiver) of `fn method` inside an `impl ... Type` / `trait Type` block: [(name, type text)]."""
+        pat = re.compile(r"\b(?:impl|trait)\b[^{;]*\b" + re.escape(type_name) + r"\b[^{;]*\{")
+        want = re.compile(r"\bfn\s+" + re.escape(method) + r"\b\s*(?:<[^(]*>)?\s*\(")
+        for rel, s in self.sources().items():
+            if type_name not in s:
+                continue
+            for m in pat.finditer(s):
+                depth, i = 1, m.end()
+                while i < len(s) and depth:
+                    depth += s[i] == "{"
+                    depth -= s[i] == "}"
+                    i += 1
+                f = want.search(s[m.end():i])
+                if f:
+                    body = s[m.end() + f.end():i]
+                    return [a for a in split_args(body[:close_paren(body)]) if not re.match(r"^(&\s*)?(mut\s+)?self\b", a)]
+        return None
+
     def find_field(self, struct, field):
         pat = re.compile(r"\bstruct\s+" + re.escape(struct) + r"\b[^{;]*\{")
         want = re.compile(r"\bpub\s+" + re.escape(field) + r"\s*:")
@@ -284,6 +305,47 @@ class Workspace:
                 if want.search(s[m.end():i]):
                     return rel
         return None
+
+
+def close_paren(s):
+    """Index of the `)` closing a list whose `(` has just been consumed."""
+    depth = 1
+    for i, c in enumerate(s):
+        depth += c in "([{"
+        depth -= c in ")]}"
+        if depth == 0:
+            return i
+    return len(s)
+
+
+def split_args(s):
+    """Top-level comma-separated pieces (generics' `<,>` count as nesting when balanced)."""
+    out, depth, angle, start = [], 0, 0, 0
+    for i, c in enumerate(s):
+        if c in "([{":
+            depth += 1
+        elif c in ")]}":
+            depth -= 1
+        elif c == "<":
+            angle += 1
+        elif c == ">" and angle and s[i - 1] != "-" and s[i - 1] != "=":
+            angle -= 1
+        elif c == "," and depth == 0 and angle == 0:
+            out.append(s[start:i].strip())
+            start = i + 1
+    out.append(s[start:].strip())
+    return [a for a in out if a]
+
+
+def kit_calls(kit_src, type_name, method):
+    """Argument lists of every `Type::method(..)` / `Type::<..>::method(..)` / `.method(..)` call in the kits."""
+    pats = [r"\b" + re.escape(type_name) + r"(?:::<[^(]*>)?::" + re.escape(method) + r"\s*\(", r"\." + re.escape(method) + r"\s*\("]
+    out = []
+    for k, pat in enumerate(pats):
+        for m in re.finditer(pat, kit_src):
+            body = kit_src[m.end():]
+            out.append((k == 0, split_args(body[:close_paren(body)])))
+    return out
 
 
 def kit_uses(src):
@@ -313,6 +375,24 @@ FIELDS = [("StarkProof", "main_commit"), ("StarkProof", "aux_commit"), ("StarkPr
           ("Challenges", "alpha"), ("Challenges", "beta_powers"), ("Challenges", "bus_prefix")]
 CONFIG_ITEMS = ["pcs_params", "poseidon2_config", "rpo_config", "rpx_config", "blake3_256_config", "keccak_config",
                 "observe_protocol_params", "RELATION_DIGEST", "LOG_FOLDING_ARITY", "FOLDING_POW_BITS", "DEEP_POW_BITS"]
+
+
+# Type-level check, one step beyond paths: (type, fn, UFCS?) -> the number of arguments at every call site of the kits must equal the
+# number of parameters of the reference's declaration (receiver excluded; a `Trait::method(&obj, ..)` call passes it explicitly),
+# and for the prove_stark-path calls the reference's parameter TYPES must contain the given fragments.
+SIGNATURES = [
+    ("Statement", "new", ["", "Vec<F>", "Vec<F>"]),                         # (multi_air, air_inputs, aux_inputs)   statement.rs
+    ("ProverStatement", "new", ["Statement<", "Vec<RowMajorMatrix<F>>"]),   # (statement, traces)
+    ("ProverInstance", "new", ["&'a SC", "&'a ProverStatement<", "Option<&'a Preprocessed<"]),
+    ("ProverInstance", "prove", ["SC::Challenger"]),
+    ("VerifierInstance", "new", ["&'a SC", "&'a Statement<", "Option<"]),
+    ("VerifierInstance", "verify", ["&StarkProofData<", "SC::Challenger"]),
+    ("StarkProof", "from_data", ["&VerifierInstance<", "&StarkProofData<", "SC::Challenger"]),
+    ("DummyMidenAir", "new", ["usize", "usize"]),
+    ("MidenMultiAir", "new", []),
+]
+CONFIG_SIGNATURES = {"pcs_params": 0, "observe_protocol_params": 1, "poseidon2_config": 2, "rpo_config": 2, "rpx_config": 2,
+                     "blake3_256_config": 2, "keccak_config": 2}
 
 
 # Calls into crates OUTSIDE the workspace (p3-air 0.6.2's symbolic builder, wincode): their definitions cannot be seen, but the
@@ -377,6 +457,37 @@ def check(ref, kit_dir):
         report.append(("precedent", pat, ("in reference" if found else "NOT IN REFERENCE") + ("" if used else " (unused by the kits)")))
         if used and not found:
             problems.append(f"external API pattern /{pat}/ is used by the kits but nowhere in the reference")
+    for t, meth, want in SIGNATURES:
+        params = ws.method_params(t, meth)
+        report.append(("signature", f"{t}::{meth}", "(" + ", ".join(params or []) + ")" if params is not None else "NOT FOUND"))
+        if params is None:
+            problems.append(f"cannot find the declaration of {t}::{meth}")
+            continue
+        if len(params) != len(want):
+            problems.append(f"{t}::{meth} takes {len(params)} parameter(s) in the reference, the kits assume {len(want)}: {params}")
+        for prm, frag in zip(params, want):
+            if frag and frag.replace(" ", "") not in prm.replace(" ", ""):
+                problems.append(f"{t}::{meth}: parameter `{prm}` does not mention `{frag}`")
+        calls = [args for ufcs, args in kit_calls(kit_src, t, meth) if ufcs] or \
+                ([args for ufcs, args in kit_calls(kit_src, t, meth)] if meth not in ("new",) else [])
+        for args in calls:
+            if len(args) != len(want):
+                problems.append(f"a kit calls {t}::{meth} with {len(args)} argument(s) {args}, the reference declares {len(params)}")
+        report.append(("call sites", f"{t}::{meth}", str(len(calls))))
+    cfg_src = ws.sources().get(os.path.join("air", "src", "config.rs"), "")
+    for fn_name, n in CONFIG_SIGNATURES.items():
+        m = re.search(r"\bpub\s+fn\s+" + fn_name + r"\b\s*(?:<[^(]*>)?\s*\(", cfg_src)
+        if not m:
+            problems.append(f"air/src/config.rs has no `pub fn {fn_name}`")
+            continue
+        params = split_args(cfg_src[m.end():][:close_paren(cfg_src[m.end():])])
+        report.append(("signature", f"config::{fn_name}", "(" + ", ".join(params) + ")"))
+        if len(params) != n:
+            problems.append(f"config::{fn_name} takes {len(params)} parameter(s), the kits assume {n}")
+        for mm in re.finditer(r"config::" + fn_name + r"\s*\(", kit_src):
+            args = split_args(kit_src[mm.end():][:close_paren(kit_src[mm.end():])])
+            if len(args) != n:
+                problems.append(f"a kit calls config::{fn_name} with {len(args)} argument(s)")
     for s, fld in FIELDS:
         where = ws.find_field(s, fld)
         report.append(("field", f"{s}.{fld}", where or "NOT FOUND"))

@@ -10,8 +10,12 @@
 //!     -> OUT_DIR/miden_air_0.dag, miden_air_1.dag, miden_air_2.dag      (little-endian u64 words)
 //!
 //! Blob layout (include/midenhip.h): 12 header words, periodic columns, nodes {op | a << 8 | b << 36, const}, constraint ids.
-//! Never compiled here (no Rust toolchain in the build image); it uses only what ace-codegen's pipeline.rs / lower.rs use.
-use std::{collections::HashMap, env, fs, rc::Rc};
+//! Never compiled here (no Rust toolchain in the build image); it uses only what ace-codegen's pipeline.rs / lower.rs use:
+//! `SymbolicAirBuilder::<F, EF>::new(AirLayout)`, `air.eval(&mut builder)`, `constraint_layout()` (`base_indices`, `ext_indices`),
+//! `base_constraints()`, `extension_constraints()` (pipeline.rs:103-107), the `Leaf / Add / Sub / Mul / Neg {x, y, ..}` shapes and
+//! the `BaseLeaf / BaseEntry / ExtLeaf / ExtEntry` variants (lower.rs:113-196), `degree_multiple()` (crates/lifted-air/src/air.rs:157-163),
+//! `AirLayout`'s seven fields (pipeline.rs:93-101).
+use std::{collections::HashMap, env, fs, ops::Deref};
 
 use miden_air::MidenMultiAir;
 use miden_core::{
@@ -19,7 +23,7 @@ use miden_core::{
     field::{BasedVectorSpace, QuadFelt},
 };
 use miden_crypto::stark::air::{
-    LiftedAir, MultiAir,
+    BaseAir, LiftedAir, MultiAir,
     symbolic::{
         BaseEntry, BaseLeaf, ExtEntry, ExtLeaf, SymbolicAirBuilder, SymbolicExpression, SymbolicExpressionExt,
     },
@@ -86,8 +90,9 @@ impl Dag {
             },
         }
     }
-    fn base_rc(&mut self, e: &Rc<SymbolicExpression<Felt>>) -> u64 {
-        let key = Rc::as_ptr(e) as usize;
+    // the children are shared pointers (`Arc` in p3-air 0.6, `Rc` before): anything that derefs to the expression, keyed by address
+    fn base_rc<P: Deref<Target = SymbolicExpression<Felt>>>(&mut self, e: &P) -> u64 {
+        let key = (&**e) as *const SymbolicExpression<Felt> as usize;
         if let Some(&id) = self.seen_base.get(&key) {
             return id;
         }
@@ -95,7 +100,7 @@ impl Dag {
         self.seen_base.insert(key, id);
         id
     }
-    fn base_bin(&mut self, op: u64, x: &Rc<SymbolicExpression<Felt>>, y: &Rc<SymbolicExpression<Felt>>) -> u64 {
+    fn base_bin<P: Deref<Target = SymbolicExpression<Felt>>>(&mut self, op: u64, x: &P, y: &P) -> u64 {
         let (a, b) = (self.base_rc(x), self.base_rc(y));
         self.node(op, a, b, 0)
     }
@@ -125,8 +130,8 @@ impl Dag {
             },
         }
     }
-    fn ext_rc(&mut self, e: &Rc<SymbolicExpressionExt<Felt, QuadFelt>>) -> u64 {
-        let key = Rc::as_ptr(e) as usize;
+    fn ext_rc<P: Deref<Target = SymbolicExpressionExt<Felt, QuadFelt>>>(&mut self, e: &P) -> u64 {
+        let key = (&**e) as *const SymbolicExpressionExt<Felt, QuadFelt> as usize;
         if let Some(&id) = self.seen_ext.get(&key) {
             return id;
         }
@@ -134,12 +139,7 @@ impl Dag {
         self.seen_ext.insert(key, id);
         id
     }
-    fn ext_bin(
-        &mut self,
-        op: u64,
-        x: &Rc<SymbolicExpressionExt<Felt, QuadFelt>>,
-        y: &Rc<SymbolicExpressionExt<Felt, QuadFelt>>,
-    ) -> u64 {
+    fn ext_bin<P: Deref<Target = SymbolicExpressionExt<Felt, QuadFelt>>>(&mut self, op: u64, x: &P, y: &P) -> u64 {
         let (a, b) = (self.ext_rc(x), self.ext_rc(y));
         self.node(op, a, b, 0)
     }
@@ -151,7 +151,7 @@ fn log2_ceil(x: usize) -> u64 {
 
 fn export<A: LiftedAir<Felt, QuadFelt>>(air: &A) -> Vec<u64> {
     let layout = air.air_layout();
-    let periodic = air.periodic_columns();
+    let periodic: Vec<Vec<Felt>> = BaseAir::<Felt>::periodic_columns(air); // air/src/lib.rs:643 (`&self -> Vec<Vec<Felt>>`)
     let mut builder = SymbolicAirBuilder::<Felt, QuadFelt>::new(air.air_layout());
     air.eval(&mut builder);
     let cl = builder.constraint_layout();
@@ -194,7 +194,7 @@ fn export<A: LiftedAir<Felt, QuadFelt>>(air: &A) -> Vec<u64> {
         layout.preprocessed_width as u64,
         0,
     ];
-    for col in &periodic {
+    for col in periodic.iter() {
         w.push(col.len() as u64);
         w.extend(col.iter().map(|x| x.as_canonical_u64()));
     }

@@ -10,7 +10,7 @@
 //! usage: midenhip-fixtures [--hasher poseidon2|blake3|keccak|rpo|rpx] OUT.json  LOG_HEIGHT:WIDTH:AUX_COLS:TRACE.bin  [...]
 //!
 //! --hasher selects the StarkConfig exactly as `prove_miden_vm_execution_trace` does (prover/src/lib.rs:246-300); the JSON then
-//! carries "lmcs": "<hasher>".  Commitments and the digest are written as FOUR u64 WORDS: the canonical values of a `[Felt; 4]`
+//! carries "lmcs": "<hasher>".  Commitments and the digest are written as u64 WORDS (four, for every configuration the consumer knows): the canonical values of a `[Felt; 4]`
 //! (algebraic configurations), the little-endian words of a `[u8; 32]` (Blake3), the lanes of a `[u64; 4]` (Keccak) -- the
 //! container libmidenhip and the oracle use for all of them.
 //!
@@ -24,52 +24,64 @@ use miden_air::config::{self, RELATION_DIGEST};
 use miden_core::{Felt, field::QuadFelt, utils::RowMajorMatrix};
 use miden_crypto::stark::{
     ProverInstance, StarkConfig, VerifierInstance,
-    air::{BaseAir, LiftedAir, LiftedAirBuilder, MultiAir, ProverStatement, Statement},
+    air::{MultiAir, ProverStatement, Statement},
     proof::{StarkOutput, StarkProof, StarkProofData},
 };
 use miden_lifted_stark::testing::airs::miden::DummyMidenAir;
+use p3_symmetric::Hash;
 use serde_wincode::SerdeCompat;
 
-struct Dummy(DummyMidenAir);
-
-impl BaseAir<Felt> for Dummy {
-    fn width(&self) -> usize {
-        BaseAir::<Felt>::width(&self.0)
-    }
-}
-
-impl LiftedAir<Felt, QuadFelt> for Dummy {
-    fn num_randomness(&self) -> usize {
-        LiftedAir::<Felt, QuadFelt>::num_randomness(&self.0)
-    }
-    fn aux_width(&self) -> usize {
-        LiftedAir::<Felt, QuadFelt>::aux_width(&self.0)
-    }
-    fn num_aux_values(&self) -> usize {
-        LiftedAir::<Felt, QuadFelt>::num_aux_values(&self.0)
-    }
-    fn build_aux_trace(
-        &self,
-        main: &RowMajorMatrix<Felt>,
-        air_inputs: &[Felt],
-        aux_inputs: &[Felt],
-        challenges: &[QuadFelt],
-    ) -> (RowMajorMatrix<QuadFelt>, Vec<QuadFelt>) {
-        LiftedAir::<Felt, QuadFelt>::build_aux_trace(&self.0, main, air_inputs, aux_inputs, challenges)
-    }
-    fn eval<AB: LiftedAirBuilder<F = Felt>>(&self, builder: &mut AB) {
-        LiftedAir::<Felt, QuadFelt>::eval(&self.0, builder)
-    }
-}
-
+// Type-level notes (checked by reading the reference, not by a compiler -- there is none in the build image):
+//  * `DummyMidenAir` implements `BaseAir<F>` and `LiftedAir<F, EF>` itself (crates/lifted-stark/src/testing/airs/miden.rs:60-100),
+//    so it is the `MultiAir::Air` directly -- exactly one AIR type, as `BenchMultiAir` has (benches/miden-bench/src/lifted.rs:92-103);
+//  * `Statement::new(multi_air, air_inputs, aux_inputs)`, `ProverStatement::new(statement, traces)`,
+//    `ProverInstance::new(&cfg, &prover_statement, None)?.prove(challenger)` -> `StarkOutput { digest, proof }`
+//    (crates/lifted-stark/src/prover/mod.rs:139-159, proof.rs:115-120; call shape of prover/src/lib.rs:326-353);
+//  * `VerifierInstance::new(&cfg, &statement, None)?.verify(&proof, challenger)` -> digest (verifier/mod.rs:106-130);
+//  * `StarkProof::from_data(&verifier_instance, &proof, challenger)` -> `(StarkProof, digest)` with the public fields
+//    `main_commit`, `randomness`, `aux_commit`, `alpha`, `beta`, `quotient_commit`, `z` (proof.rs:151-180, 221-225);
+//  * the LMCS commitment is `p3_symmetric::Hash<F, W, DIGEST>` (lmcs/config.rs:89), `Into<[W; DIGEST]>` as
+//    crates/test-utils/src/recursive_verifier.rs:397-399 uses it; the transcript digest is `CanFinalizeDigest::Digest` of the
+//    challenger (proof.rs:110-111), a p3-challenger 0.6 type this kit has never seen: `Words` below accepts an array of any
+//    length over Felt / u8 / u64 or a `Hash` of those, and the consumer checks the length.
 struct Multi {
-    airs: Vec<Dummy>,
+    airs: Vec<DummyMidenAir>,
 }
 
 impl MultiAir<Felt, QuadFelt> for Multi {
-    type Air = Dummy;
+    type Air = DummyMidenAir;
     fn airs(&self) -> &[Self::Air] {
         &self.airs
+    }
+}
+
+/// u64 words of a commitment or digest: canonical values of felts, little-endian words of bytes, lanes as they are.
+trait Words {
+    fn words(&self) -> Vec<u64>;
+}
+impl<const N: usize> Words for [Felt; N] {
+    fn words(&self) -> Vec<u64> {
+        self.iter().map(|x| x.as_canonical_u64()).collect()
+    }
+}
+impl<const N: usize> Words for [u8; N] {
+    fn words(&self) -> Vec<u64> {
+        self.chunks_exact(8).map(|c| u64::from_le_bytes(c.try_into().unwrap())).collect()
+    }
+}
+impl<const N: usize> Words for [u64; N] {
+    fn words(&self) -> Vec<u64> {
+        self.to_vec()
+    }
+}
+impl<F, W, const N: usize> Words for Hash<F, W, N>
+where
+    Hash<F, W, N>: Clone + Into<[W; N]>,
+    [W; N]: Words,
+{
+    fn words(&self) -> Vec<u64> {
+        let a: [W; N] = self.clone().into();
+        a.words()
     }
 }
 
@@ -122,7 +134,7 @@ fn main() {
         let values: Vec<Felt> =
             raw.chunks_exact(8).map(|c| Felt::new_unchecked(u64::from_le_bytes(c.try_into().unwrap()))).collect();
         traces.push(RowMajorMatrix::new(values, width));
-        airs.push(Dummy(DummyMidenAir::new(width, aux)));
+        airs.push(DummyMidenAir::new(width, aux));
         if k > 0 {
             inst_json.push(',');
         }
@@ -133,7 +145,7 @@ fn main() {
     // exactly prove_stark (prover/src/lib.rs:326-353), once per configuration type: a macro instead of a function generic in the
     // StarkConfig (its associated commitment and digest types differ: [Felt; 4], [u8; 32], [u64; 4])
     macro_rules! run {
-        ($name:literal, $cfg:expr, $words:expr) => {{
+        ($name:literal, $cfg:expr) => {{
             let cfg = $cfg;
             let mut challenger = cfg.challenger();
             config::observe_protocol_params(&mut challenger);
@@ -148,23 +160,24 @@ fn main() {
             .expect("serialize");
 
             // the structured view (proof.rs:214-420) for the sampled challenges, and the verifier's verdict
+            let vinst = VerifierInstance::new(&cfg, prover_statement.statement(), None).expect("verifier instance");
             let mut vch = cfg.challenger();
             config::observe_protocol_params(&mut vch);
-            let vinst = VerifierInstance::new(&cfg, prover_statement.statement(), None).expect("verifier instance");
-            let (stark, digest2) = StarkProof::from_data(&vinst, &output.proof, vch.clone()).expect("parse");
-            assert_eq!(output.digest, digest2);
+            let (stark, digest2) = StarkProof::from_data(&vinst, &output.proof, vch).expect("parse");
+            let mut vch = cfg.challenger();
+            config::observe_protocol_params(&mut vch);
             let digest3 = vinst.verify(&output.proof, vch).expect("verify");
-            assert_eq!(output.digest, digest3);
+            let digest = output.digest.words();
+            assert_eq!(digest, digest2.words());
+            assert_eq!(digest, digest3.words());
 
             let mut hex = String::with_capacity(2 * bytes.len());
             for b in &bytes {
                 write!(hex, "{b:02x}").unwrap();
             }
-            let words = $words;
-            let digest: [u64; 4] = words(output.digest.into());
-            let main_c: [u64; 4] = words(stark.main_commit.into());
-            let aux_c: [u64; 4] = words(stark.aux_commit.into());
-            let quot_c: [u64; 4] = words(stark.quotient_commit.into());
+            let main_c = stark.main_commit.words();
+            let aux_c = stark.aux_commit.words();
+            let quot_c = stark.quotient_commit.words();
             let mut rnd = String::from("[");
             for (i, r) in stark.randomness.iter().enumerate() {
                 if i > 0 {
@@ -193,15 +206,12 @@ fn main() {
             json
         }};
     }
-    let felt_words = |d: [Felt; 4]| d.map(|x| x.as_canonical_u64());
-    let byte_words = |d: [u8; 32]| core::array::from_fn::<u64, 4, _>(|i| u64::from_le_bytes(d[8 * i..8 * i + 8].try_into().unwrap()));
-    let lane_words = |d: [u64; 4]| d;
     let json: String = match hasher.as_str() {
-        "poseidon2" => run!("poseidon2", config::poseidon2_config(params0, RELATION_DIGEST), felt_words),
-        "rpo" => run!("rpo", config::rpo_config(params0, RELATION_DIGEST), felt_words),
-        "rpx" => run!("rpx", config::rpx_config(params0, RELATION_DIGEST), felt_words),
-        "blake3" => run!("blake3", config::blake3_256_config(params0, RELATION_DIGEST), byte_words),
-        "keccak" => run!("keccak", config::keccak_config(params0, RELATION_DIGEST), lane_words),
+        "poseidon2" => run!("poseidon2", config::poseidon2_config(params0, RELATION_DIGEST)),
+        "rpo" => run!("rpo", config::rpo_config(params0, RELATION_DIGEST)),
+        "rpx" => run!("rpx", config::rpx_config(params0, RELATION_DIGEST)),
+        "blake3" => run!("blake3", config::blake3_256_config(params0, RELATION_DIGEST)),
+        "keccak" => run!("keccak", config::keccak_config(params0, RELATION_DIGEST)),
         other => panic!("unknown --hasher {other}"),
     };
     fs::write(&args[1], json).expect("write");
