@@ -249,6 +249,38 @@ def in_flight_h2d_probe(pkg, log_n, device, k=3, steps=6):
                     "proof j" % log_n}
 
 
+def jit_load_probe(pkg, ctx):
+    """mh_air_load of the three real Miden AIRs: cold (empty cache directory: hiprtc compiles every chunk) and cached (code objects
+    from disk).  A prover service runs tools/jit_precompile.py at build time (mh_jit_precompile needs no GPU), so its request path
+    only ever sees the cached figure."""
+    import shutil, tempfile
+    from miden_vm_amd import miden_air, chiplets_air, core_air
+    out = {}
+    old = os.environ.get("MH_JIT_CACHE_DIR")
+    for name, air in (("poseidon2_permutation", miden_air.poseidon2_permutation_air(num_public=32)[0]), ("chiplets", chiplets_air.chiplets_air()[0]),
+                      ("core", core_air.core_air()[0])):
+        tmp = tempfile.mkdtemp(prefix="mh_jit_cold_")
+        try:
+            os.environ["MH_JIT_CACHE_DIR"] = tmp
+            t0 = time.perf_counter()
+            d = pkg.DeviceAir(ctx, air)
+            cold = time.perf_counter() - t0
+            d.free()
+            t0 = time.perf_counter()
+            d = pkg.DeviceAir(ctx, air)
+            cached = time.perf_counter() - t0
+            out[name] = {"dag_nodes": int(air.blob[8]), "constraints": int(air.blob[9]), "chunks": d.compiled_chunks, "max_vgprs": d.compiled_max_vgprs,
+                         "jit_cold_s": round(cold, 2), "jit_cached_ms": round(cached * 1e3, 2)}
+            d.free()
+        finally:
+            if old is None:
+                os.environ.pop("MH_JIT_CACHE_DIR", None)
+            else:
+                os.environ["MH_JIT_CACHE_DIR"] = old
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def chiplets_air_probe(pkg, ctx, log_n=20, steps=3):
     """The real ChipletsAir alone at 2^log_n rows (production parameters, aux columns on the device): what a real multi-chiplet
     constraint system costs on the compiled constraint path -- quotient_eval_ms, chunks, VGPRs, logup_aux_ms -- and what loading it
@@ -320,7 +352,7 @@ def chiplets_air_probe(pkg, ctx, log_n=20, steps=3):
     return out
 
 
-def miden_real_probe(pkg, ctx, iters=9250, steps=3):
+def miden_real_probe(pkg, ctx, iters=9250, steps=3, lmcs="poseidon2", inputs=None):
     """THE Miden statement, no stand-ins: CoreAir + ChipletsAir + Poseidon2PermutationAir (miden-vm_amd/{core,chiplets,miden}_air.py) over
     the traces of ONE executed program -- a loop over a hash / u32 / memory mix run by the small VM of miden-vm_amd/core_trace.py --
     with the reference's statement framing (RELATION_DIGEST, observe_protocol_params, `MidenMultiAir::observe`), production parameters,
@@ -329,8 +361,10 @@ def miden_real_probe(pkg, ctx, iters=9250, steps=3):
     import json as _json
     from miden_vm_amd import dag, protocol, miden_air, chiplets_air, core_air, core_trace, miden_statement
     t0 = time.perf_counter()
-    r = core_trace.prove_inputs(core_trace.CoreVM(stack_inputs=list(range(16))), core_trace.bench_program(iters))
+    r = inputs if inputs is not None else core_trace.prove_inputs(core_trace.CoreVM(stack_inputs=list(range(16))), core_trace.bench_program(iters))
     gen_s = time.perf_counter() - t0
+    if lmcs != "poseidon2":
+        ctx.set_lmcs(lmcs)
     host_airs = [core_air.core_air()[0], chiplets_air.chiplets_air()[0], miden_air.poseidon2_permutation_air(num_public=32)[0]]
     host = [r["core"], r["chiplets"], r["poseidon2"]]
     lhs = [int(t.shape[0]).bit_length() - 1 for t in host]
@@ -347,7 +381,7 @@ def miden_real_probe(pkg, ctx, iters=9250, steps=3):
     pre = miden_statement.statement_pre_observe(prm, pub, aux_inputs)
     proof = pkg.prove(ctx, airs, traces, pub, prm, st, pre, None)
     ok, _ = pkg.verify(host_airs, lhs, pub, prm, st, pre, proof.fields, proof.commitments,
-                       external=miden_statement.external_assertions(pkg, pub, aux_inputs))
+                       external=miden_statement.external_assertions(pkg, pub, aux_inputs), lmcs=lmcs)
     t0 = time.perf_counter()
     for _ in range(steps):
         proof = pkg.prove(ctx, airs, traces, pub, prm, st, pre, None)
@@ -362,7 +396,7 @@ def miden_real_probe(pkg, ctx, iters=9250, steps=3):
     rows = 1 << max(lhs)
     return {"workload": f"the real Miden statement (CoreAir 51 + 4 EF, ChipletsAir 22 + 3 EF, Poseidon2PermutationAir 16 + 1 EF) of a loop of {iters} "
                         "iterations (u32 / bitwise / memory / HPERM mix), production parameters",
-            "log_trace_heights": lhs, "ms_per_proof": dt * 1e3, "rows_per_s": rows / dt, "proof_bytes": len(proof.bytes),
+            "lmcs": lmcs, "log_trace_heights": lhs, "ms_per_proof": dt * 1e3, "rows_per_s": rows / dt, "proof_bytes": len(proof.bytes),
             "verifies_with_eval_external": bool(ok), "constraints": [int(a.blob[9]) for a in host_airs],
             "compiled_chunks": [a.compiled_chunks for a in airs], "chunk_max_vgprs": [a.compiled_max_vgprs for a in airs],
             "kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items() if not k.startswith("span:") and v["ms"] > 0.05},
@@ -734,9 +768,20 @@ def main():
         except Exception as e:
             out["miden_shape"] = {"error": repr(e)[:200]}
         try:
-            out["miden_real"] = miden_real_probe(pkg, ctx)
+            from miden_vm_amd import core_trace as _ct
+            real_inputs = _ct.prove_inputs(_ct.CoreVM(stack_inputs=list(range(16))), _ct.bench_program(9250))
+            out["miden_real"] = miden_real_probe(pkg, ctx, inputs=real_inputs)
+            c3 = pkg.Ctx(dev_index)
+            try:  # ProvingOptions::default() = Blake3_256: the configuration the reference's published figure is quoted on
+                out["miden_real_blake3"] = miden_real_probe(pkg, c3, inputs=real_inputs, lmcs="blake3")
+            finally:
+                c3.close()
         except Exception as e:
             out["miden_real"] = {"error": repr(e)[:300]}
+        try:
+            out["jit_load"] = jit_load_probe(pkg, ctx)
+        except Exception as e:
+            out["jit_load"] = {"error": repr(e)[:200]}
         try:
             out["chiplets_air"] = chiplets_air_probe(pkg, ctx)
         except Exception as e:

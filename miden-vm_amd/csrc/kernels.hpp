@@ -7,7 +7,8 @@
 void launch_transpose_rm_to_cm(mh_ctx* c, const u64* in_rowmajor, u64* out_colmajor, size_t n, size_t w, hipStream_t stream = nullptr);  // null: the compute stream
 void ntt_inverse_dif_inplace(mh_ctx* c, u64* cols, size_t n_cols, int log_n);
 void ntt_inverse_dif(mh_ctx* c, const u64* src, u64* dst, size_t n_cols, int log_n);  // src == dst: in place
-void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n, const std::vector<u64>& bases, u64* out, size_t out_col_stride = 0);
+void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n, const std::vector<u64>& bases, u64* out, size_t out_col_stride = 0,
+                        size_t group_cols = 0);
 void lde_columns(mh_ctx* c, const u64* cols_in, size_t n_cols, int log_n, u64 in_shift, const std::vector<u64>& out_shifts,
                  u64* out, u64* scratch);
 void lde_coefficients(mh_ctx* c, const u64* cols_in, size_t n_cols, int log_n, u64* coef_br);

@@ -135,6 +135,9 @@ struct NttPassArgs {
   const u64* scale_full;                                // optional, instead of scale_lo/hi: the whole product table [z][pos] (one load, one product)
   int col_fastest;                                      // grid = (columns, tiles): neighbouring workgroups share a tile's twiddle / scale slices
   size_t src_z_stride;                                  // 0: every coset reads the same source (first pass); else the source of coset z is src + z * src_z_stride
+  u32 group_cols, group_z;                              // group_cols > 0: columns come in groups with their OWN coset shifts (quotient chunks):
+                                                        //   the scale row of (column, coset z) is (column / group_cols) * group_z + z
+  const u64* step;                                      // MODE 1 (first pass, cosets in geometric progression): [pos] = (base_{z+1} / base_z)^k, k = bitrev(pos)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -486,6 +489,9 @@ __device__ __forceinline__ u32 ntt_pad(u32 l) {
 // else -1 (decided at run time).  With B0 known at compile time the LDS byte address of element e is the thread's pre-scaled
 // address XOR a LITERAL (B0 = 0, 4: one v_xor, no scalar registers), or, for B0 = 8, one of two pre-computed addresses plus an
 // immediate offset in the ds instruction (the swizzle touches bit 4 only: slot = (p0 ^ ((e & 1) << 4)) + (e << 8)): no VALU at all.
+// (Streaming stores for the output of a pass -- __builtin_nontemporal_store -- were measured in round 4: the forward passes do not
+// change, the inverse transform gets 0.4 ms slower per 51 columns: its output is the next kernel's input and came from the cache.)
+#define NTT_STORE(p, v) (*(p) = (v))
 template <int G, bool INV, bool SWZ, int B0>
 __device__ __forceinline__ void ntt_round(const NttPassArgs& a, u64* lds, int st, u32 tile_n, size_t lo0, u64* dst_direct,
                                           size_t gbase, const u64* __restrict__ tw) {
@@ -518,10 +524,10 @@ __device__ __forceinline__ void ntt_round(const NttPassArgs& a, u64* lds, int st
       const u32 tix = (u32)(gbase | ((size_t)(l0 >> a.cb) << a.s_lo) | (l0 & cb_mask));
       if (a.canon_out) {  // decided once per round, not per element
 #pragma unroll
-        for (int e = 0; e < (1 << G); e++) (dst_direct + ((size_t)e << s))[tix] = ntt_canon(x[e]);
+        for (int e = 0; e < (1 << G); e++) NTT_STORE((dst_direct + ((size_t)e << s)) + tix, ntt_canon(x[e]));
       } else {
 #pragma unroll
-        for (int e = 0; e < (1 << G); e++) (dst_direct + ((size_t)e << s))[tix] = x[e];
+        for (int e = 0; e < (1 << G); e++) NTT_STORE((dst_direct + ((size_t)e << s)) + tix, x[e]);
       }
     } else {
 #pragma unroll
@@ -531,7 +537,12 @@ __device__ __forceinline__ void ntt_round(const NttPassArgs& a, u64* lds, int st
 }
 
 // INV: the inverse transform, always run as DIF (natural in, bit-reversed out); forward = DIT.
-template <bool INV, int THREADS>
+// MODE 1 = the first pass of a coset LDE whose coset shifts are a geometric progression (they are: shift * w^j): the thread keeps its
+// sixteen SCALED coefficients in registers over the coset loop and moves them from coset z to z + 1 with one product by step[pos]
+// (an 8 MB table at 2^20 that every column and every coset of a tile shares) -- instead of re-reading the tile and one row of the
+// [z][pos] table (64 MB at 2^20, blowup 8) per coset, which was 0.8 ms of the 2.5 ms of this pass on 51 columns (round 4: skipping the
+// table load made the pass that much faster, skipping the tile re-read changed nothing: it hits L2).
+template <bool INV, int THREADS, int MODE = 0>
 __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a) {
   extern __shared__ u64 lds[];
   constexpr bool SWZ = NTT_SWZ && THREADS == NTT_THREADS;  // the 2^12 tile
@@ -548,8 +559,10 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
   // The first pass of a coset LDE reads one coefficient tile and produces it on every output coset: the workgroup
   // loops over the cosets itself (n_z > 1), so the tile comes from HBM once and from this XCD's L2 afterwards --
   // with the cosets spread over grid.z the same tile was fetched by up to n_z workgroups on different XCDs.
+  u64 raw[MODE == 1 ? 16 : 1];
   for (u32 z = 0; z < a.n_z; z++) {
   const u32 zc = blockIdx.z * a.n_z + z;
+  const u32 srow = a.group_cols ? (col_id / a.group_cols) * a.group_z + zc : zc;  // row of the scale tables
   u64* dst = a.dst + (size_t)col_id * a.dst_col_stride + (size_t)zc * a.dst_z_stride;
   const u64* src = src0 + (size_t)zc * a.src_z_stride;
   if (z) __syncthreads();  // the previous coset's last round still reads the tile
@@ -562,6 +575,41 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
     const u32 g0 = (u32)(gbase | ((size_t)(tid >> a.cb) << a.s_lo) | (tid & cb_mask));
     const int shg = LOG_T - a.cb + a.s_lo;
     const u32 p0 = ntt_pad<SWZ>(tid);
+    if constexpr (MODE == 1) {
+      if (z == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) raw[j] = (src + ((size_t)j << shg))[g0];
+        if (a.scale_full) {
+          const u64* sf = a.scale_full + ((size_t)srow << a.log_n);
+#pragma unroll
+          for (int c = 0; c < 16; c += 4) {
+            u64 t[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) t[j] = (sf + ((size_t)(c + j) << shg))[g0];
+#pragma unroll
+            for (int j = 0; j < 4; j++) raw[c + j] = NTT_MUL1(raw[c + j], t[j]);
+          }
+        } else {  // few columns (quotient chunks): the first coset from the two-level tables, no [z][pos] table is built for them
+#pragma unroll 4
+          for (int j = 0; j < 16; j++) {
+            const u32 k = bitrev32(g0 + ((u32)j << shg), a.log_n);
+            const u64 sc = NTT_MUL1(a.scale_lo[srow * a.scale_lo_z + (k & ((1u << a.lb) - 1))], a.scale_hi[srow * a.scale_hi_z + (k >> a.lb)]);
+            raw[j] = NTT_MUL1(raw[j], sc);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 16; c += 8) {
+          u64 t[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) t[j] = (a.step + ((size_t)(c + j) << shg))[g0];
+#pragma unroll
+          for (int j = 0; j < 8; j++) raw[c + j] = NTT_MUL1(raw[c + j], t[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 16; j++) lds[p0 ^ ntt_pad<true>((u32)j * THREADS)] = raw[j];
+    } else
     if (THREADS == NTT_THREADS && !a.scale_lo && !a.scale_full) {  // (the 1024-thread kernel has 128 VGPRs: it would spill)
       // no scale (every pass but the first of a coset LDE): all sixteen loads in flight -- the strided passes are short of bytes in
       // flight, not of issue slots (pass 1 of the 2^20 plan: 3.3 TB/s with four at a time)
@@ -579,14 +627,14 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
 #pragma unroll
       for (int j = 0; j < 4; j++) v[j] = (src + ((size_t)(c + j) << shg))[g0];  // wave-uniform base + the thread's index
       if (a.scale_full) {
-        const u64* sf = a.scale_full + ((size_t)zc << a.log_n);
+        const u64* sf = a.scale_full + ((size_t)srow << a.log_n);
 #pragma unroll
         for (int j = 0; j < 4; j++) v[j] = NTT_MUL1(v[j], (sf + ((size_t)(c + j) << shg))[g0]);
       } else if (a.scale_lo) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const u32 k = bitrev32(g0 + ((u32)(c + j) << shg), a.log_n);
-          const u64 sc = NTT_MUL1(a.scale_lo[zc * a.scale_lo_z + (k & ((1u << a.lb) - 1))], a.scale_hi[zc * a.scale_hi_z + (k >> a.lb)]);
+          const u64 sc = NTT_MUL1(a.scale_lo[srow * a.scale_lo_z + (k & ((1u << a.lb) - 1))], a.scale_hi[srow * a.scale_hi_z + (k >> a.lb)]);
           v[j] = NTT_MUL1(v[j], sc);
         }
       }
@@ -599,10 +647,10 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
       size_t g = gbase | ((size_t)(l >> a.cb) << a.s_lo) | (l & cb_mask);
       u64 v = src[g];
       if (a.scale_full) {
-        v = NTT_MUL1(v, a.scale_full[((size_t)zc << a.log_n) + g]);
+        v = NTT_MUL1(v, a.scale_full[((size_t)srow << a.log_n) + g]);
       } else if (a.scale_lo) {
         u32 k = bitrev32((u32)g, a.log_n);
-        u64 sc = NTT_MUL1(a.scale_lo[zc * a.scale_lo_z + (k & ((1u << a.lb) - 1))], a.scale_hi[zc * a.scale_hi_z + (k >> a.lb)]);
+        u64 sc = NTT_MUL1(a.scale_lo[srow * a.scale_lo_z + (k & ((1u << a.lb) - 1))], a.scale_hi[srow * a.scale_hi_z + (k >> a.lb)]);
         v = NTT_MUL1(v, sc);
       }
       lds[ntt_pad<SWZ>(l)] = v;
@@ -755,6 +803,8 @@ static void launch_pass(mh_ctx* c, NttPassArgs a, size_t n_cols, size_t n_z, boo
   const size_t lds = ntt_lds_bytes(T);
   if (T == NTT_TILE_LOG) {
     if (a.dif) MH_LAUNCH((k_ntt16_pass<true, NTT_THREADS>), grid, dim3(NTT_THREADS), lds, c->stream, a);
+    else if (a.step && a.n_z > 1 && NTT_SWZ && a.r_bits + a.cb == NTT_TILE_LOG && a.cb == 0)
+      MH_LAUNCH((k_ntt16_pass<false, NTT_THREADS, 1>), grid, dim3(NTT_THREADS), lds, c->stream, a);
     else MH_LAUNCH((k_ntt16_pass<false, NTT_THREADS>), grid, dim3(NTT_THREADS), lds, c->stream, a);
   } else {
     if (!c->ntt_big_lds_attr) {  // > 64 KB of dynamic LDS must be requested per kernel AND per device: a flag of the ctx, not of the process
@@ -867,10 +917,15 @@ static const u64* coset_scale_full(mh_ctx* c, int log_n, const std::vector<u64>&
 // sum_k c_k * bases[z]^k * w_N^(r k)   (1/N folded into the table).
 // out_col_stride != 0: the cosets are a GROUP of a wider coset-major matrix -- `out` points at the group's first coset of column 0,
 // consecutive columns lie out_col_stride apart (e.g. 8 N for blowup 8 while bases.size() = 2).
+// group_cols != 0: the columns come in n_cols / group_cols groups, each with its OWN coset shifts (the chunks of the quotient, whose
+// coefficients belong to different input cosets): bases = [group][z], all groups in one pair of launches instead of one pair each
+// (a quotient chunk is 2 columns: 512 workgroups per launch at 2^20 rows, 43-55 us per column against 36-44 in a 16-column launch).
 void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n, const std::vector<u64>& bases,
-                        u64* out, size_t out_col_stride) {
+                        u64* out, size_t out_col_stride, size_t group_cols) {
   size_t N = (size_t)1 << log_n;
-  size_t nz = bases.size();
+  const size_t n_groups = group_cols ? n_cols / group_cols : 1;
+  MH_REQUIRE(n_groups >= 1 && (!group_cols || n_cols % group_cols == 0) && bases.size() % n_groups == 0, "internal: coset groups");
+  size_t nz = bases.size() / n_groups;
   const bool grouped = out_col_stride != 0 && out_col_stride != nz * N;
   u64 n_inv = gl_inv((u64)N % GL_P);
   const CosetTables t = coset_tables(c, log_n, bases, n_inv);
@@ -888,7 +943,19 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
       a.scale_lo_z = (size_t)1 << t.lb;
       a.scale_hi_z = (size_t)1 << (log_n - t.lb);
       static const int fullscale = [] { const char* e = getenv("MH_NTT_FULLSCALE"); return e ? atoi(e) : 1; }();
-      if (fullscale && n_cols >= 16 && log_n >= 12 && log_n <= 24) a.scale_full = coset_scale_full(c, log_n, bases, n_inv, t);
+      a.group_cols = (u32)group_cols; a.group_z = (u32)nz;
+      if (fullscale && !group_cols && n_cols >= 16 && log_n >= 12 && log_n <= 24) a.scale_full = coset_scale_full(c, log_n, bases, n_inv, t);
+      static const int geo = [] { const char* e = getenv("MH_NTT_STEP"); return e ? atoi(e) : 1; }();
+      if (geo && nz > 1 && log_n >= NTT_TILE_LOG && log_n <= 24) {  // bases[z + 1] = bases[z] * ratio for every z?
+        const u64 ratio = gl_mul(bases[1], gl_inv(bases[0]));
+        bool geometric = true;
+        for (size_t g = 0; g < n_groups; g++)
+          for (size_t z = 0; z + 1 < nz; z++) geometric = geometric && gl_mul(bases[g * nz + z], ratio) == bases[g * nz + z + 1];
+        if (geometric) {
+          const std::vector<u64> rb{ratio};
+          a.step = coset_scale_full(c, log_n, rb, 1, coset_tables(c, log_n, rb, 1));
+        }
+      }
     } else {
       // in place inside each coset block: fold z into the source stride
       a.src = out;

@@ -615,12 +615,22 @@ struct mh_session {
     }
     {
       ProfScope ps(c, "lde", (double)B_loc * N * 2 * D * 8.0);
+      std::vector<u64> bases(D * B_loc);
+      bool contiguous = true;  // chunk t's coefficients lie at 2 t N (always, unless a gather put them in rank order)
       for (size_t t = 0; t < D; t++) {
         const u64 in_inv = gl_inv(gl_mul(g, gl_pow(wJ, t)));
-        std::vector<u64> bases(B_loc);
-        for (size_t zc = 0; zc < B_loc; zc++) bases[zc] = gl_mul(all_outs[coset0 + zc], in_inv);
-        const size_t src_chunk = dist.on() ? gathered_chunk(logD, D_slot, t) : t;
-        ntt_forward_cosets(c, coef + 2 * src_chunk * N, 2, log_N, bases, qm.lde.u() + 2 * t * B_loc * N);
+        for (size_t zc = 0; zc < B_loc; zc++) bases[t * B_loc + zc] = gl_mul(all_outs[coset0 + zc], in_inv);
+        contiguous = contiguous && (dist.on() ? gathered_chunk(logD, D_slot, t) : t) == t;
+      }
+      static const int grouped = [] { const char* e = getenv("MH_QUOTIENT_LDE_GROUPED"); return e ? atoi(e) : 1; }();
+      if (grouped && contiguous && D > 1) {  // all chunks in one pair of launches, every chunk with its own coset shifts
+        ntt_forward_cosets(c, coef, 2 * D, log_N, bases, qm.lde.u(), 0, 2);
+      } else {
+        for (size_t t = 0; t < D; t++) {
+          const size_t src_chunk = dist.on() ? gathered_chunk(logD, D_slot, t) : t;
+          const std::vector<u64> bt(bases.begin() + t * B_loc, bases.begin() + (t + 1) * B_loc);
+          ntt_forward_cosets(c, coef + 2 * src_chunk * N, 2, log_N, bt, qm.lde.u() + 2 * t * B_loc * N);
+        }
       }
     }
     quot_tree->mats.push_back(std::move(qm));
