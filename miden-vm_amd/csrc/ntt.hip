@@ -54,6 +54,17 @@ static int ntt_tile_log(int log_n) {
   return log_n > 20 && log_n <= big_max ? NTT_TILE_LOG_BIG : NTT_TILE_LOG;
 }
 
+// Layout of a coefficient vector between the inverse and the forward transform (internal to this file and to its two callers):
+// bit-reversed order, and -- when the contiguous pass works on full 2^12 tiles -- every tile ROTATED: element l of the tile sits at
+// position (l & 15) << 8 | l >> 4.  The last round of the inverse leaves thread q with elements 16 q .. 16 q + 15 and the first round
+// of the forward transform wants exactly those: with the rotation the inverse's final stores are coalesced (position e * 256 + q;
+// they were 8-byte stores 128 B apart) and the forward's tile load (position tid + 256 j) IS round one's register set -- no LDS round
+// trip, no barrier before the first butterflies.  The scale tables of the first forward pass are built in the same order.
+static bool ntt_coef_rot(int log_n) {
+  static const int on = [] { const char* e = getenv("MH_NTT_ROT"); return e ? atoi(e) : 1; }();
+  return on && log_n >= NTT_TILE_LOG && ntt_tile_log(log_n) == NTT_TILE_LOG;
+}
+
 // ---------------------------------------------------------------------------------------------
 // twiddle table: tw[k] = w^k, k < n_half, given w^(2^i) in pw[]
 struct PowTable {
@@ -135,6 +146,8 @@ struct NttPassArgs {
   const u64* scale_full;                                // optional, instead of scale_lo/hi: the whole product table [z][pos] (one load, one product)
   int col_fastest;                                      // grid = (columns, tiles): neighbouring workgroups share a tile's twiddle / scale slices
   size_t src_z_stride;                                  // 0: every coset reads the same source (first pass); else the source of coset z is src + z * src_z_stride
+  int rot;                                              // contiguous pass on rotated coefficient tiles (ntt_coef_rot): inverse = its stores, forward = its loads
+  int direct_first;                                     // forward strided pass, cb = 4, r_bits a multiple of 4 and >= 8: the first round loads from HBM
   u32 group_cols, group_z;                              // group_cols > 0: columns come in groups with their OWN coset shifts (quotient chunks):
                                                         //   the scale row of (column, coset z) is (column / group_cols) * group_z + z
   const u64* step;                                      // MODE 1 (first pass, cosets in geometric progression): [pos] = (base_{z+1} / base_z)^k, k = bitrev(pos)
@@ -494,7 +507,8 @@ __device__ __forceinline__ u32 ntt_pad(u32 l) {
 #define NTT_STORE(p, v) (*(p) = (v))
 template <int G, bool INV, bool SWZ, int B0>
 __device__ __forceinline__ void ntt_round(const NttPassArgs& a, u64* lds, int st, u32 tile_n, size_t lo0, u64* dst_direct,
-                                          size_t gbase, const u64* __restrict__ tw) {
+                                          size_t gbase, const u64* __restrict__ tw, const u64* __restrict__ src_direct = nullptr,
+                                          const u64* xin = nullptr) {
   const int b0 = B0 >= 0 ? B0 : st + a.cb, s = a.s_lo + st;
   const u32 cb_mask = (1u << a.cb) - 1;
   constexpr bool FAST = SWZ && B0 >= 0;
@@ -513,12 +527,29 @@ __device__ __forceinline__ void ntt_round(const NttPassArgs& a, u64* lds, int st
       else return lds + (SWZ ? (p0 ^ ntt_pad<true>((u32)e << b0)) : ntt_pad<false>(l0 | ((u32)e << b0)));
     };
     u64 x[1 << G];
+    if (xin) {  // the thread's registers already hold this round's values (first forward pass on rotated tiles)
+#pragma unroll
+      for (int e = 0; e < (1 << G); e++) x[e] = xin[e];
+    } else if (src_direct) {
+      // the first round of a strided pass takes its sixteen values straight from HBM: they are the elements l0 | e << b0 of the tile,
+      // rows (l0 >> cb) + e of 2^cb consecutive elements each -- the same 128-byte segments the staged tile load moved, without the
+      // LDS round trip and without the barrier (every wave starts its butterflies when ITS loads have landed)
+      const u32 six = (u32)(gbase | ((size_t)(l0 >> a.cb) << a.s_lo) | (l0 & cb_mask));
+#pragma unroll
+      for (int e = 0; e < (1 << G); e++) x[e] = (src_direct + ((size_t)e << s))[six];
+    } else {
 #pragma unroll
     for (int e = 0; e < (1 << G); e++) x[e] = *slot(e);
+    }
     if (!INV && s > 0) ntt_tw_mul<(1 << G) - 1, 1>(x, tw, s, gm);
     ntt_dft_regs<G, INV>(x, INV);
     if (INV && s > 0) ntt_tw_mul<(1 << G) - 1, 1>(x, tw, s, gm);
-    if (dst_direct) {
+    if (INV && dst_direct && a.rot && b0 == 0 && G == 4) {
+      // rotated coefficient tile: element 16 q + e of the tile goes to position e * 256 + q
+      const u32 rix = (u32)gbase + (l0 >> 4);
+#pragma unroll
+      for (int e = 0; e < (1 << G); e++) NTT_STORE((dst_direct + ((size_t)e << 8)) + rix, a.canon_out ? ntt_canon(x[e]) : x[e]);
+    } else if (dst_direct) {
       // global index of element e: b0 >= cb, so e << b0 lands above the tile's contiguous bits: index = index(l0) + (e << (st + s_lo)).
       // A wave-uniform base pointer per element + one 32-bit per-thread index: the scalar-base form of global_store, no address VALU.
       const u32 tix = (u32)(gbase | ((size_t)(l0 >> a.cb) << a.s_lo) | (l0 & cb_mask));
@@ -568,7 +599,12 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
   if (z) __syncthreads();  // the previous coset's last round still reads the tile
 
   constexpr int LOG_T = THREADS == 256 ? 8 : 10;
-  if (tile_n == 16u * THREADS && a.cb <= LOG_T) {
+  // no staging of the tile when the first round executed can load its own values in whole segments: the forward strided pass of
+  // whole radix-16 rounds (pass 1 of the 2^20 plan: element bit 4 of the tile, 128-byte segments) and every full-tile pass of the
+  // inverse transform (DIF starts with the top four bits: element stride 256 = the very pattern of the staged load)
+  const bool direct_first = MODE == 0 && THREADS == NTT_THREADS && a.direct_first && tile_n == 16u * THREADS;
+  if (direct_first) {
+  } else if (tile_n == 16u * THREADS && a.cb <= LOG_T) {
     // full tile: element i of this thread is l = tid + i * THREADS; THREADS >= 2^cb, so i * THREADS lands above the contiguous bits:
     // global index = index(tid) + (i << (LOG_T - cb + s_lo)), LDS slot = slot(tid) ^ slot(i * THREADS) (linear swizzle)
     const u32 tid = threadIdx.x;
@@ -592,7 +628,7 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
         } else {  // few columns (quotient chunks): the first coset from the two-level tables, no [z][pos] table is built for them
 #pragma unroll 4
           for (int j = 0; j < 16; j++) {
-            const u32 k = bitrev32(g0 + ((u32)j << shg), a.log_n);
+            const u32 k = bitrev32(a.rot ? (g0 - tid) + ((tid << 4) | (u32)j) : g0 + ((u32)j << shg), a.log_n);
             const u64 sc = NTT_MUL1(a.scale_lo[srow * a.scale_lo_z + (k & ((1u << a.lb) - 1))], a.scale_hi[srow * a.scale_hi_z + (k >> a.lb)]);
             raw[j] = NTT_MUL1(raw[j], sc);
           }
@@ -607,8 +643,10 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
           for (int j = 0; j < 8; j++) raw[c + j] = NTT_MUL1(raw[c + j], t[j]);
         }
       }
+      if (!a.rot) {
 #pragma unroll
-      for (int j = 0; j < 16; j++) lds[p0 ^ ntt_pad<true>((u32)j * THREADS)] = raw[j];
+        for (int j = 0; j < 16; j++) lds[p0 ^ ntt_pad<true>((u32)j * THREADS)] = raw[j];
+      }
     } else
     if (THREADS == NTT_THREADS && !a.scale_lo && !a.scale_full) {  // (the 1024-thread kernel has 128 VGPRs: it would spill)
       // no scale (every pass but the first of a coset LDE): all sixteen loads in flight -- the strided passes are short of bytes in
@@ -633,11 +671,15 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
       } else if (a.scale_lo) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const u32 k = bitrev32(g0 + ((u32)(c + j) << shg), a.log_n);
+          const u32 k = bitrev32(a.rot ? (g0 - tid) + ((tid << 4) | (u32)(c + j)) : g0 + ((u32)(c + j) << shg), a.log_n);
           const u64 sc = NTT_MUL1(a.scale_lo[srow * a.scale_lo_z + (k & ((1u << a.lb) - 1))], a.scale_hi[srow * a.scale_hi_z + (k >> a.lb)]);
           v[j] = NTT_MUL1(v[j], sc);
         }
       }
+      if (a.rot) {  // position tid + 256 (c + j) holds element 16 tid + c + j of the tile
+#pragma unroll
+        for (int j = 0; j < 4; j++) lds[ntt_pad<SWZ>((tid << 4) | (u32)(c + j))] = v[j];
+      } else
 #pragma unroll
       for (int j = 0; j < 4; j++)
         lds[SWZ ? (p0 ^ ntt_pad<true>((u32)(c + j) * THREADS)) : ntt_pad<false>(tid + (u32)(c + j) * THREADS)] = v[j];
@@ -656,7 +698,8 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
       lds[ntt_pad<SWZ>(l)] = v;
     }
   }
-  __syncthreads();
+  const bool regs_first = MODE == 1 && a.rot;  // round one runs on `raw` itself
+  if (!direct_first && !regs_first) __syncthreads();
   // stage groups: as many radix-16 rounds as fit, the remainder (1..3 stages) in one smaller round.
   // DIT ascends (small group first keeps the last, directly-stored round wide); DIF descends.
   const int rem = a.r_bits & 3, n16 = a.r_bits >> 2;
@@ -679,7 +722,9 @@ __global__ __launch_bounds__(THREADS) NTT16_OCC void k_ntt16_pass(NttPassArgs a)
     u64* direct = (i == n_rounds - 1) ? dst : nullptr;
     const int b0 = st + a.cb;
 #define NTT_ROUND(GG, BB) ntt_round<GG, INV, SWZ, BB>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri])
-    if (g == 4 && b0 == 0) NTT_ROUND(4, 0);
+    if (direct_first && i == 0) ntt_round<4, INV, SWZ, INV ? 8 : 4>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri], src);
+    else if (regs_first && i == 0) ntt_round<4, INV, SWZ, 0>(a, lds, st, tile_n, lo0, direct, gbase, a.tw_round[ri], nullptr, raw);
+    else if (g == 4 && b0 == 0) NTT_ROUND(4, 0);
     else if (g == 4 && b0 == 4) NTT_ROUND(4, 4);
     else if (g == 4 && b0 == 8) NTT_ROUND(4, 8);
     else if (g == 4) NTT_ROUND(4, -1);
@@ -839,6 +884,9 @@ void ntt_inverse_dif(mh_ctx* c, const u64* src, u64* dst, size_t n_cols, int log
     a.dif = 1; a.scale_lo = nullptr; a.scale_hi = nullptr;
     for (int k = 0; k < 4; k++) a.tw_round[k] = tw.base + tw.off[i * 4 + k];
     a.canon_out = 0;  // the coefficients only feed the forward passes' multiplications
+    static const int direct = [] { const char* e = getenv("MH_NTT_DIRECT"); return e ? atoi(e) : 1; }();
+    a.direct_first = direct && NTT_SWZ && a.r_bits >= 4 && a.r_bits + a.cb == NTT_TILE_LOG;
+    a.rot = i == 0 && ntt_coef_rot(log_n);
     launch_pass(c, a, n_cols, 1);
   }
 }
@@ -888,25 +936,27 @@ static CosetTables coset_tables(mh_ctx* c, int log_n, const std::vector<u64>& ba
 // many-column trace LDEs only.  Measured at 2^20 x (51 + 16) columns (round 4, ms of LDE per proof): two-level tables 8.70, full table
 // 8.22, full table + column-fastest grid (the 256 KB slice of a tile is shared by neighbouring workgroups in L2) 8.08; the
 // column-fastest grid alone 8.72.  MH_NTT_FULLSCALE=0 / MH_NTT_COLFAST=0 restore the round-3 path.
-__global__ void k_fill_scale_full(u64* out, const u64* lo, const u64* hi, int log_n, int lb, size_t lo_z, size_t hi_z) {
+__global__ void k_fill_scale_full(u64* out, const u64* lo, const u64* hi, int log_n, int lb, size_t lo_z, size_t hi_z, int rot) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   const size_t n = (size_t)1 << log_n;
   const size_t z = blockIdx.y;
   if (i >= n) return;
-  const u32 k = bitrev32((u32)i, log_n);
+  const u32 il = rot ? (((u32)i & ~4095u) | (((u32)i & 255u) << 4) | (((u32)i >> 8) & 15u)) : (u32)i;  // position -> element (ntt_coef_rot)
+  const u32 k = bitrev32(il, log_n);
   out[z * n + i] = gl_mul(lo[z * lo_z + (k & ((1u << lb) - 1))], hi[z * hi_z + (k >> lb)]);
 }
 static const u64* coset_scale_full(mh_ctx* c, int log_n, const std::vector<u64>& bases, u64 post_scale, const CosetTables& t) {
+  const int rot = ntt_coef_rot(log_n) ? 1 : 0;
   u64 h = 0xcbf29ce484222325ULL ^ (u64)log_n;
   for (u64 b : bases) h = (h ^ b) * 0x100000001b3ULL + (h >> 29);
   h = (h ^ post_scale) * 0x100000001b3ULL;
-  const std::string key = "cosetfull:" + std::to_string(log_n) + ":" + std::to_string(bases.size()) + ":" + std::to_string(h);
+  const std::string key = "cosetfull:" + std::to_string(log_n) + ":" + std::to_string(bases.size()) + ":" + std::to_string(h) + (rot ? ":rot" : "");
   auto it = c->tables.find(key);
   if (it == c->tables.end()) {
     const size_t n = (size_t)1 << log_n;
     DevBuf b(bases.size() * n * 8);
     MH_LAUNCH(k_fill_scale_full, dim3((unsigned)((n + 255) / 256), (unsigned)bases.size()), dim3(256), 0, c->stream, b.u(), t.lo, t.hi, log_n,
-              t.lb, (size_t)1 << t.lb, (size_t)1 << (log_n - t.lb));
+              t.lb, (size_t)1 << t.lb, (size_t)1 << (log_n - t.lb), rot);
     it = c->tables.emplace(key, std::move(b)).first;
   }
   return it->second.u();
@@ -944,6 +994,7 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
       a.scale_hi_z = (size_t)1 << (log_n - t.lb);
       static const int fullscale = [] { const char* e = getenv("MH_NTT_FULLSCALE"); return e ? atoi(e) : 1; }();
       a.group_cols = (u32)group_cols; a.group_z = (u32)nz;
+      a.rot = ntt_coef_rot(log_n);
       if (fullscale && !group_cols && n_cols >= 16 && log_n >= 12 && log_n <= 24) a.scale_full = coset_scale_full(c, log_n, bases, n_inv, t);
       static const int geo = [] { const char* e = getenv("MH_NTT_STEP"); return e ? atoi(e) : 1; }();
       if (geo && nz > 1 && log_n >= NTT_TILE_LOG && log_n <= 24) {  // bases[z + 1] = bases[z] * ratio for every z?
@@ -966,6 +1017,8 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
     a.dif = 0;
     for (int k = 0; k < 4; k++) a.tw_round[k] = tw.base + tw.off[i * 4 + k];
     a.canon_out = i + 1 == plan.size();
+    static const int direct = [] { const char* e = getenv("MH_NTT_DIRECT"); return e ? atoi(e) : 1; }();
+    a.direct_first = direct && i > 0 && NTT_SWZ && a.cb == 4 && a.r_bits >= 8 && a.r_bits % 4 == 0 && a.r_bits + a.cb == NTT_TILE_LOG;
     if (i == 0) {
       launch_pass(c, a, n_cols, nz);
     } else if (grouped) {  // in place, one workgroup per (tile, column, coset): the columns of the group are not contiguous
@@ -973,9 +1026,16 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
       a.src_z_stride = N;
       launch_pass(c, a, n_cols, nz, true);
     } else {
-      a.dst_col_stride = N;
-      a.dst_z_stride = 0;
-      launch_pass(c, a, n_cols * nz, 1);
+      static const int zloop = [] { const char* e = getenv("MH_NTT_ZLOOP"); return e ? atoi(e) : 1; }();
+      if (zloop && nz > 1) {  // the workgroup walks the cosets of its (tile, column): 1/nz of the workgroup launches
+        a.src_col_stride = nz * N;
+        a.src_z_stride = N;
+        launch_pass(c, a, n_cols, nz);
+      } else {
+        a.dst_col_stride = N;
+        a.dst_z_stride = 0;
+        launch_pass(c, a, n_cols * nz, 1);
+      }
     }
   }
 }
