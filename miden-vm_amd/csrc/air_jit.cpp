@@ -88,6 +88,36 @@ FI e2 e2_mul(e2 a, e2 b) {
   return {gl_add(a0b0, gl_mul7(a1b1)), gl_sub(gl_sub(cross, a0b0), a1b1)};
 }
 FI e2 e2_mulf(e2 a, u64 b) { return {gl_mul(a.c0, b), gl_mul(a.c1, b)}; }
+// The alpha fold with the modular reduction delayed to the end of the chunk: alpha^k is uniform, so it is cut into 16-bit limbs
+// (scalar unit), a constraint value into 32-bit halves, and the 48-bit partial products are summed by weight 2^(16 j) in plain 64-bit
+// accumulators -- 8 v_mad_u64_u32 per (base value, alpha component) instead of a modular multiplication and a modular addition;
+// < 2^14 folds per chunk keep every accumulator below 2^64.  MH_JIT_FOLD=0 (flag) selects the former per-constraint form.
+#ifndef MH_JIT_FOLD
+#define MH_JIT_FOLD 1
+#endif
+struct fold_acc { u64 w0, w1, w2, w3, w4, w5; };
+// acc + a * x as ONE v_mad_u64_u32 with the uniform limb in an SGPR; inline asm because LLVM reassociates the C form of these sums
+// (every product of the chunk then stays live to the end: 512 VGPRs and scratch)
+FI void fold_mad(u64& acc, u32 a, u32 x) {
+  u64 d, cy;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "s"(a), "v"(x), "v"(acc));
+  acc = d;
+}
+FI void fold_limbs(fold_acc& f, u64 alpha, u64 x) {
+  const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+  const u32 a0 = (u32)alpha & 0xffffu, a1 = ((u32)alpha) >> 16, a2 = (u32)(alpha >> 32) & 0xffffu, a3 = (u32)(alpha >> 48);
+  fold_mad(f.w0, a0, x0); fold_mad(f.w1, a1, x0); fold_mad(f.w2, a2, x0); fold_mad(f.w3, a3, x0);
+  fold_mad(f.w2, a0, x1); fold_mad(f.w3, a1, x1); fold_mad(f.w4, a2, x1); fold_mad(f.w5, a3, x1);
+}
+FI u64 fold_value(const fold_acc& f) {  // sum_j w_j 2^(16 j) mod p, canonical
+  u64 r = gl_reduce128(0, f.w0);
+  r = gl_add(r, gl_reduce128(f.w1 >> 48, f.w1 << 16));
+  r = gl_add(r, gl_reduce128(f.w2 >> 32, f.w2 << 32));
+  r = gl_add(r, gl_reduce128(f.w3 >> 16, f.w3 << 48));
+  r = gl_add(r, gl_reduce128(f.w4, 0));
+  r = gl_add(r, gl_mul_c(gl_reduce128(f.w5 >> 48, f.w5 << 16), GL_EPS));  // 2^80 = 2^16 * (2^64 mod p)
+  return r;
+}
 struct JitArgs {
   const u64* main_lde; const u64* aux_lde; const u64* prep_lde; u64* spill; u64* acc; const u64* tw; const u64* coset_tab;
   const u64* inv_first; const u64* inv_last; const u64* periodic; const u64* publics; const u64* randomness;
@@ -288,23 +318,98 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
     if (lo < seq.size()) chunks.push_back({lo, seq.size(), {}, {}, {}});
   }
   const size_t n_chunks = chunks.size();
-  // ---- values crossing chunk boundaries -> spill slots (one u64 plane each), reused once dead ----
-  std::vector<int32_t> def_chunk(nodes.size(), -1), last_use(nodes.size(), -1);
+  // ---- what each chunk evaluates, and which values cross chunk boundaries ----
+  // A value defined in an earlier chunk is either RECOMPUTED in the chunk that needs it (its cone down to cells / constants / values
+  // this chunk already holds is cheap: operation flags, small sums -- a spilled value costs an 8-byte store and an 8-byte load per
+  // point and reader, the constraint kernels of the real AIRs are bound by exactly that traffic) or LOADED from an HBM spill plane
+  // (then, and only then, its defining chunk stores it).  $MH_JIT_RECOMP = the largest cone, in estimated VALU instructions, that is
+  // recomputed (0: spill everything, the former behaviour).
+  std::vector<int32_t> def_chunk(nodes.size(), -1);
   for (size_t ci = 0; ci < n_chunks; ci++)
     for (size_t i = chunks[ci].ev_lo; i < chunks[ci].ev_hi; i++)
       if (seq[i].fold_k < 0) def_chunk[seq[i].node] = (int32_t)ci;
-  for (size_t ci = 0; ci < n_chunks; ci++)
-    for (size_t i = chunks[ci].ev_lo; i < chunks[ci].ev_hi; i++) {
-      const DagNode& nd = nodes[seq[i].node];
-      auto use = [&](uint32_t id) {
-        if (interior(id)) last_use[id] = std::max(last_use[id], (int32_t)ci);
+  const int recomp_max = env_int("MH_JIT_RECOMP", 250);
+  auto valu_cost = [&](uint32_t id) -> int {  // rough VALU instructions of one gate
+    const DagNode& nd = nodes[id];
+    const bool ea = nodes[nd.a].ext, eb = nd.op != DOP_NEG && nodes[nd.b].ext;
+    if (nd.op == DOP_MUL) return ea && eb ? 80 : (ea || eb ? 44 : 22);
+    return (ea || eb) ? 12 : 6;
+  };
+  struct Item {
+    uint32_t node;
+    int32_t fold_k;  // -1: compute the node, >= 0: fold / output k, -2: load the node from its spill plane
+  };
+  std::vector<std::vector<Item>> items(n_chunks);
+  std::vector<char> spilled(nodes.size(), 0);
+  std::vector<int32_t> last_load(nodes.size(), -1);
+  size_t n_recomputed = 0;
+  {
+    std::vector<int32_t> mat(nodes.size(), -1);   // chunk in which the value was last materialised
+    std::vector<int32_t> seen(nodes.size(), -1);  // scratch of the cone walks (stamp)
+    int32_t stamp = 0;
+    std::vector<uint32_t> cone;
+    for (size_t ci = 0; ci < n_chunks; ci++) {
+      auto have = [&](uint32_t u) { return !interior(u) || mat[u] == (int32_t)ci; };
+      auto load = [&](uint32_t u) {
+        spilled[u] = 1;
+        last_load[u] = (int32_t)ci;
+        mat[u] = (int32_t)ci;
+        items[ci].push_back({u, -2});
       };
-      if (seq[i].fold_k >= 0) use(seq[i].node);
-      else {
-        use(nd.a);
-        if (nd.op != DOP_NEG) use(nd.b);
+      // make `u` (defined in an earlier chunk) available here
+      auto ensure = [&](uint32_t u) {
+        if (have(u)) return;
+        if (spilled[u] || recomp_max <= 0) { load(u); return; }
+        // the cone of u down to what this chunk holds or can load: post-order, cost
+        stamp++;
+        cone.clear();
+        long cst = 0;
+        std::vector<std::pair<uint32_t, int>> dfs;
+        dfs.push_back({u, 0});
+        while (!dfs.empty()) {
+          auto& [id, ph] = dfs.back();
+          if (seen[id] == stamp) { dfs.pop_back(); continue; }
+          const DagNode& nd = nodes[id];
+          if (ph == 0) {
+            ph = 1;
+            if (interior(nd.a) && mat[nd.a] != (int32_t)ci && !spilled[nd.a] && seen[nd.a] != stamp) { dfs.push_back({nd.a, 0}); continue; }
+          }
+          if (ph == 1) {
+            ph = 2;
+            if (nd.op != DOP_NEG && interior(nd.b) && mat[nd.b] != (int32_t)ci && !spilled[nd.b] && seen[nd.b] != stamp) { dfs.push_back({nd.b, 0}); continue; }
+          }
+          seen[id] = stamp;
+          cone.push_back(id);
+          cst += valu_cost(id);
+          dfs.pop_back();
+          if (cst > recomp_max) break;
+        }
+        if (cst > recomp_max) { load(u); return; }
+        for (uint32_t id : cone) {
+          const DagNode& nd = nodes[id];
+          if (interior(nd.a) && mat[nd.a] != (int32_t)ci) load(nd.a);  // a spilled value inside the cone
+          if (nd.op != DOP_NEG && interior(nd.b) && mat[nd.b] != (int32_t)ci) load(nd.b);
+          mat[id] = (int32_t)ci;
+          items[ci].push_back({id, -1});
+          n_recomputed++;
+        }
+      };
+      for (size_t i = chunks[ci].ev_lo; i < chunks[ci].ev_hi; i++) {
+        const uint32_t id = seq[i].node;
+        const DagNode& nd = nodes[id];
+        if (seq[i].fold_k >= 0) {
+          ensure(id);
+          items[ci].push_back({id, seq[i].fold_k});
+          continue;
+        }
+        ensure(nd.a);
+        if (nd.op != DOP_NEG) ensure(nd.b);
+        mat[id] = (int32_t)ci;
+        items[ci].push_back({id, -1});
       }
     }
+  }
+  // spill planes (one u64 plane per base value, two per EF value), reused once the last reader has run
   std::vector<int32_t> slot(nodes.size(), -1);
   size_t n_spill = 0;
   {
@@ -314,9 +419,8 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
       for (size_t i = chunks[ci].ev_lo; i < chunks[ci].ev_hi; i++) {
         if (seq[i].fold_k >= 0) continue;
         const uint32_t id = seq[i].node;
-        if (last_use[id] <= (int32_t)ci) continue;
+        if (!spilled[id]) continue;
         const int need = nodes[id].ext ? 2 : 1;
-        // ext values take two consecutive fresh or two separately recycled planes: keep it simple, (s, s+1)
         uint32_t s;
         if (need == 1 && !free_slots.empty()) {
           s = free_slots.back();
@@ -326,7 +430,7 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
           n_spill += need;
         }
         slot[id] = (int32_t)s;
-        dies[last_use[id]].push_back(id);
+        dies[last_load[id]].push_back(id);
       }
       for (uint32_t id : dies[ci]) {
         free_slots.push_back((uint32_t)slot[id]);
@@ -334,11 +438,23 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
       }
     }
   }
+  if (env_int("MH_JIT_STATS", 0)) {
+    size_t n_loads = 0, n_stores = 0;
+    for (size_t ci = 0; ci < n_chunks; ci++)
+      for (const Item& it : items[ci]) n_loads += it.fold_k == -2 ? (nodes[it.node].ext ? 2 : 1) : 0;
+    for (size_t i = 0; i < nodes.size(); i++) n_stores += spilled[i] ? (nodes[i].ext ? 2 : 1) : 0;
+    fprintf(stderr, "[mh jit] %zu chunks, %zu gates, %zu recomputed, spill planes %zu, per point: %zu spill loads, %zu spill stores\n", n_chunks,
+            seq.size(), n_recomputed, n_spill, n_loads, n_stores);
+  }
   // ---- source per chunk ----
+  const bool lazy_loads = env_int("MH_JIT_LAZY", 1) != 0;
   char buf[256];
   for (size_t ci = 0; ci < n_chunks; ci++) {
     Chunk& ch = chunks[ci];
     std::ostringstream decl, body;
+    // cells, periodic values and spilled values are read where they are first used (the live ranges start there: ~90 VGPRs and five
+    // waves per SIMD instead of ~230 and two, for the chunks of the core AIR), or all at the top of the kernel (MH_JIT_LAZY=0)
+    std::ostringstream& ld = lazy_loads ? body : decl;
     std::set<std::string> declared;
     bool need_x = false, need_fl = false;
     auto ref = [&](uint32_t id) -> std::string {
@@ -354,7 +470,7 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
           if (declared.insert(name).second) {
             snprintf(buf, sizeof buf, "  const u64 %s = a.main_lde[((%uull * B + jc) << a.log_n) + %s];\n", name.c_str(), nd.a,
                      nd.b ? "rn" : "r");
-            decl << buf;
+            ld << buf;
           }
           return name;
         case DOP_AUX:
@@ -363,9 +479,9 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
           if (declared.insert(name).second) {
             const char* rr = nd.b ? "rn" : "r";
             snprintf(buf, sizeof buf, "  const e2 %s = {a.aux_lde[((%uull * B + jc) << a.log_n) + %s], ", name.c_str(), 2 * nd.a, rr);
-            decl << buf;
+            ld << buf;
             snprintf(buf, sizeof buf, "a.aux_lde[((%uull * B + jc) << a.log_n) + %s]};\n", 2 * nd.a + 1, rr);
-            decl << buf;
+            ld << buf;
           }
           return name;
         case DOP_PREP:
@@ -374,7 +490,7 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
           if (declared.insert(name).second) {
             snprintf(buf, sizeof buf, "  const u64 %s = a.prep_lde[((%uull * B + jc) << a.log_n) + %s];\n", name.c_str(), nd.a,
                      nd.b ? "rn" : "r");
-            decl << buf;
+            ld << buf;
           }
           return name;
         case DOP_PUBLIC:
@@ -386,7 +502,7 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
           if (declared.insert(name).second) {
             snprintf(buf, sizeof buf, "  const u64 %s = a.periodic[%uull * a.periodic_rows + ((r * D + a.t0 + t) %% a.periodic_rows)];\n",
                      name.c_str(), nd.a);
-            decl << buf;
+            ld << buf;
           }
           return name;
         case DOP_IS_FIRST: need_fl = true; return "sel_first";
@@ -401,26 +517,26 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
         default: break;
       }
       snprintf(buf, sizeof buf, "v%u", id);
-      name = buf;
-      if (def_chunk[id] != (int32_t)ci && declared.insert(name).second) {  // produced by an earlier chunk
-        if (nd.ext)
-          snprintf(buf, sizeof buf, "  const e2 %s = {a.spill[%dull * a.spill_stride + qb], a.spill[%dull * a.spill_stride + qb]};\n",
-                   name.c_str(), slot[id], slot[id] + 1);
-        else
-          snprintf(buf, sizeof buf, "  const u64 %s = a.spill[%dull * a.spill_stride + qb];\n", name.c_str(), slot[id]);
-        decl << buf;
-      }
-      return name;
+      return buf;  // computed, recomputed or loaded earlier in this chunk (items)
     };
     bool any_fold = false;
-    for (size_t i = ch.ev_lo; i < ch.ev_hi; i++) {
-      const uint32_t id = seq[i].node;
+    for (const Item& it : items[ci]) {
+      const uint32_t id = it.node;
       const DagNode& nd = nodes[id];
-      if (seq[i].fold_k >= 0) {
+      if (it.fold_k == -2) {  // produced by an earlier chunk: from its spill plane(s)
+        if (nd.ext)
+          snprintf(buf, sizeof buf, "  const e2 v%u = {a.spill[%dull * a.spill_stride + qb], a.spill[%dull * a.spill_stride + qb]};\n", id,
+                   slot[id], slot[id] + 1);
+        else
+          snprintf(buf, sizeof buf, "  const u64 v%u = a.spill[%dull * a.spill_stride + qb];\n", id, slot[id]);
+        ld << buf;
+        continue;
+      }
+      if (it.fold_k >= 0) {
         any_fold = true;
         const std::string x = ref(id);
         if (ir.outputs) {  // output k -> planes 2k (c0) and 2k+1 (c1, EF outputs only), rows r (single coset)
-          const int k = seq[i].fold_k;
+          const int k = it.fold_k;
           if (nd.ext)
             body << "  a.acc[(" << 2 * k << "ull << a.log_n) + r] = " << x << ".c0; a.acc[(" << 2 * k + 1 << "ull << a.log_n) + r] = " << x
                  << ".c1;\n";
@@ -428,8 +544,18 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
             body << "  a.acc[(" << 2 * k << "ull << a.log_n) + r] = " << x << ";\n";
           continue;
         }
-        snprintf(buf, sizeof buf, "e2{a.alpha_pows[%d], a.alpha_pows[%d]}", 2 * seq[i].fold_k, 2 * seq[i].fold_k + 1);
+        snprintf(buf, sizeof buf, "e2{a.alpha_pows[%d], a.alpha_pows[%d]}", 2 * it.fold_k, 2 * it.fold_k + 1);
+        body << "#if MH_JIT_FOLD\n";
+        if (nd.ext)
+          body << "  { const u64 al0 = a.alpha_pows[" << 2 * it.fold_k << "], al1 = a.alpha_pows[" << 2 * it.fold_k + 1 << "], al7 = gl_mul7(al1);\n"
+               << "    fold_limbs(f0, al0, " << x << ".c0); fold_limbs(f0, al7, " << x << ".c1); fold_limbs(f1, al0, " << x
+               << ".c1); fold_limbs(f1, al1, " << x << ".c0); }\n";
+        else
+          body << "  fold_limbs(f0, a.alpha_pows[" << 2 * it.fold_k << "], " << x << "); fold_limbs(f1, a.alpha_pows[" << 2 * it.fold_k + 1
+               << "], " << x << ");\n";
+        body << "#else\n";
         body << "  acc = e2_add(acc, " << (nd.ext ? "e2_mul(" : "e2_mulf(") << buf << ", " << x << "));\n";
+        body << "#endif\n";
         continue;
       }
       const std::string A = ref(nd.a);
@@ -451,7 +577,7 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
                                                                                                      : "gl_mul(" + A + ", " + Bv + ")";
       }
       body << "  const " << (nd.ext ? "e2" : "u64") << " v" << id << " = " << rhs << ";\n";
-      if (last_use[id] > (int32_t)ci) {
+      if (spilled[id] && def_chunk[id] == (int32_t)ci) {
         if (nd.ext)
           body << "  a.spill[" << slot[id] << "ull * a.spill_stride + qb] = v" << id << ".c0; a.spill[" << slot[id] + 1
                << "ull * a.spill_stride + qb] = v" << id << ".c1;\n";
@@ -477,7 +603,8 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
     if (need_fl)
       src << "  const u64 sel_first = gl_mul(a.coset_tab[Dl + t], a.inv_first[q]);\n"
              "  const u64 sel_last = gl_mul(a.coset_tab[Dl + t], a.inv_last[q]);\n";
-    src << "  e2 acc = {0, 0}; (void)acc;\n" << decl.str() << body.str();
+    src << "  e2 acc = {0, 0}; (void)acc;\n  fold_acc f0 = {0, 0, 0, 0, 0, 0}, f1 = {0, 0, 0, 0, 0, 0}; (void)f0; (void)f1;\n" << decl.str() << body.str();
+    if (!ir.outputs && any_fold) src << "#if MH_JIT_FOLD\n  acc = {fold_value(f0), fold_value(f1)};\n#endif\n";
     if (!ir.outputs && (any_fold || ci == 0)) {
       src << "  u64* p0 = a.acc + (((2 * t) << a.log_n) + r);\n  u64* p1 = a.acc + (((2 * t + 1) << a.log_n) + r);\n";
       if (ci == 0) src << "  *p0 = acc.c0; *p1 = acc.c1;\n";

@@ -996,7 +996,10 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
       a.group_cols = (u32)group_cols; a.group_z = (u32)nz;
       a.rot = ntt_coef_rot(log_n);
       if (fullscale && !group_cols && n_cols >= 16 && log_n >= 12 && log_n <= 24) a.scale_full = coset_scale_full(c, log_n, bases, n_inv, t);
-      static const int geo = [] { const char* e = getenv("MH_NTT_STEP"); return e ? atoi(e) : 1; }();
+      // the geometric stepping of the scaled coefficients (registers over the coset loop, one shared 8 MB step table) is off by default:
+      // since the strided pass stopped staging through LDS (first-round register loads) the full [z][pos] table is the faster form
+      // again (2^20 x 51 + 8 EF: lde 7.77 vs 8.25 ms, proof 46.0 vs 46.25 ms, three alternating runs on one box; gpurun_out/nttexp.txt)
+      static const int geo = [] { const char* e = getenv("MH_NTT_STEP"); return e ? atoi(e) : 0; }();
       if (geo && nz > 1 && log_n >= NTT_TILE_LOG && log_n <= 24) {  // bases[z + 1] = bases[z] * ratio for every z?
         const u64 ratio = gl_mul(bases[1], gl_inv(bases[0]));
         bool geometric = true;

@@ -402,7 +402,14 @@ class LogUp:
                 acc = t if acc is None else acc + t
             return acc
 
-    def __init__(self, builder, max_message_width, num_bus_ids, prover_builder=None):
+    def __init__(self, builder, max_message_width, num_bus_ids, prover_builder=None, closing="dead_last_row", num_logup_cols=None):
+        """closing = "dead_last_row": the VM's adapter (air/src/lookup/constraint.rs: the last row is reserved, `acc[last] = aux_value`,
+        fraction columns vanish there); "sigma_last_row": the precompile prover's (precompiles-prover/src/logup/constraint.rs:213-270:
+        the running sum closes on the LIVE last row against sigma = aux_value(0), fraction columns are ungated on every row);
+        num_logup_cols < aux_width leaves trailing (register) aux columns out of the running sum."""
+        assert closing in ("dead_last_row", "sigma_last_row")
+        self.closing = closing
+        self.num_logup_cols = builder.aux_width if num_logup_cols is None else num_logup_cols
         self.b = builder
         self.lb = prover_builder if prover_builder is not None else LookupBuilder(
             builder.main_width, num_cols=builder.aux_width, num_randomness=builder.num_randomness, periodic=builder.periodic,
@@ -518,6 +525,18 @@ class LogUp:
 
         def __exit__(self, *exc):  # the tail of ConstraintLookupBuilder::next_column (constraint.rs:150-196)
             b, i = self.lk.b, self.idx
+            if self.lk.closing == "sigma_last_row":  # CyclicConstraintLookupBuilder::next_column
+                if i == 0:
+                    acc, acc_next, sigma = b.aux(0), b.aux(0, 1), b.aux_value(0)
+                    total = acc
+                    for k in range(1, self.lk.num_logup_cols):
+                        total = total + b.aux(k)
+                    b.assert_zero_ext(b.is_first_row() * acc)
+                    b.assert_zero_ext(b.is_transition() * (self.u * (acc_next - total) - self.v))
+                    b.assert_zero_ext(b.is_last_row() * (self.u * (sigma - total) - self.v))
+                else:
+                    b.assert_zero_ext(self.u * b.aux(i) - self.v)
+                return False
             if i == 0:
                 acc, acc_next = b.aux(0), b.aux(0, 1)
                 total = acc
@@ -538,5 +557,5 @@ class LogUp:
         return c
 
     def finish(self, name="lookup"):
-        assert self.column_idx == self.b.aux_width, "every aux column needs its next_column call"
+        assert self.column_idx == self.num_logup_cols, "every LogUp aux column needs its next_column call"
         return Lookup(self.lb, name)

@@ -1,0 +1,118 @@
+"""GPU parity of the second client (run with -m gpu): the precompile prover's session statement over its real preprocessed AIR
+(`BytePairLutAir`, 2^16 rows, four verifier-known columns committed at setup), the group table (`EcGroupsAir`) and the requests of
+the unported chiplets (miden-vm_amd/precompile_airs.py; precompiles-prover/src/session/prove.rs:300-333 `prove_stark_with_config`:
+`ProverInstance::new(config, statement, Some(preprocessed))`).
+
+Device proof == oracle proof bit for bit with the aux columns of all three AIRs built ON THE DEVICE by their lookup programs (the
+table's reads the preprocessed matrix next to the multiplicities: the reference's combined `[preprocessed ++ main]` window), through the
+interpreter and the compiled chunks; the statement closes only through `ChipletMultiAir::eval_external`; production parameters and a
+Keccak-sized request load at full table height verify through both verifiers."""
+import numpy as np
+import pytest
+import oracle_binding as ob
+from __graft_entry__ import load_package
+from miden_vm_amd import dag, protocol, precompile_airs as PA
+from test_gpu_prove import FAST
+
+pytestmark = pytest.mark.gpu
+P = dag.P
+ROOT = [71, 72, 73, 74]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    pkg = load_package()
+    c = pkg.Ctx(0)
+    yield c
+    c.close()
+
+
+def host_aux(lookup, main, randomness, preprocessed=None):
+    return ob.lookup_build_aux(lookup, main, randomness, preprocessed)
+
+
+def session(n_ops, log_req, seed=5):
+    rng = np.random.default_rng(seed)
+    ledger = PA.BytePairLutRequires()
+    reqs = PA.keccak_like_requests(rng, n_ops, ledger)
+    while len(reqs) < (1 << log_req):  # fill the requirer to its last row (which fires)
+        ledger.require_range16(0xffff)
+        reqs.append((PA.BUS_RANGE16, 1, [0xffff]))
+    pairs = [PA.requirer_air(host_aux), PA.byte_pair_lut_air(host_aux), PA.ec_groups_air(host_aux)]
+    traces = [PA.requirer_trace(reqs, log_req), PA.byte_pair_lut_trace(ledger), PA.ec_groups_trace()]
+    return [p[0] for p in pairs], [p[1] for p in pairs], traces
+
+
+def never(idx, rnd):
+    raise AssertionError("host aux builder called for an AIR with a lookup program")
+
+
+def device_prove(ctx, airs_, lookups, traces, params):
+    """Setup = commit the table once (Preprocessed::build), then the session's proof with every aux column from the device."""
+    pkg = load_package()
+    dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+    raw = ctx.upload_trace(airs_[1].preprocessed)
+    com = pkg.commit_traces(ctx, [raw], params["log_blowup"])
+    dairs[1].attach_preprocessed(com.tree(), 0, raw=raw)
+    for d, lk in zip(dairs, lookups):
+        d.attach_lookup(pkg.DeviceLookup(ctx, lk))
+    st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
+    pre = protocol.protocol_pre_observe(params, ROOT, preprocessed_root=com.root())
+    got = pkg.prove(ctx, dairs, [ctx.upload_trace(t) for t in traces], ROOT, params, st, pre, never)
+    return got, com.root(), st, pre
+
+
+@pytest.mark.parametrize("jit", ["0", "1"])
+def test_precompile_session_device_proof_equals_oracle(ctx, jit, monkeypatch):
+    pkg = load_package()
+    monkeypatch.setenv("MH_JIT", jit)
+    if jit == "1":
+        monkeypatch.setenv("MH_JIT_CHUNK", "24")  # several chunks even for these small constraint systems
+    airs_, lookups, traces = session(42, 9)
+    exp = ob.prove(airs_, traces, ROOT, FAST, init_state=protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST))
+    got, root, st, pre = device_prove(ctx, airs_, lookups, traces, FAST)
+    assert list(root) == [int(x) for x in exp["preprocessed_root"]]
+    assert (got.commitments == exp["commitments"]).all()
+    assert got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all()
+    assert (got.digest == exp["digest"]).all()
+    assert got.log_trace_heights == [9, 16, 3]
+    ok, msg = ob.verify(airs_, got.log_trace_heights, ROOT, {"fields": got.fields, "commitments": got.commitments}, FAST,
+                        external=PA.external_assertions(pkg))
+    assert ok, msg
+    ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, FAST, st, pre, got.fields, got.commitments, preprocessed_root=root,
+                          external=PA.external_assertions(pkg))
+    assert ok2 and (dig == got.digest).all()
+    # the sigma sum alone (no boundary consume of the fixed curve group) must not close
+    bal = pkg.external_callback(lambda rnd, av, lhs: [(sum(v[0][0] for v in av) % P, sum(v[0][1] for v in av) % P)])
+    ok3, _ = pkg.verify(airs_, got.log_trace_heights, ROOT, FAST, st, pre, got.fields, got.commitments, preprocessed_root=root, external=bal)
+    assert not ok3
+
+
+def test_device_aux_of_the_table_equals_the_oracle_cell_for_cell(ctx):
+    """The table's lookup program reads `[preprocessed ++ main]`: aux column 0 = running sum, column 1 = the Xor + Range16 fraction of
+    the row, sigma = the full residue (the last row, (255, 255), fires)."""
+    pkg = load_package()
+    airs_, lookups, traces = session(300, 12)
+    rnd = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
+    assert int(traces[1][-1, 2]) > 0  # range16 multiplicity of 0xffff
+    dl = pkg.DeviceLookup(ctx, lookups[1])
+    aux_dev, fin = dl.build_aux(ctx.upload_trace(traces[1]), rnd, preprocessed=ctx.upload_trace(airs_[1].preprocessed))
+    aux, exp_fin = ob.lookup_build_aux(lookups[1], traces[1], rnd, preprocessed=airs_[1].preprocessed)
+    assert (aux_dev.download() == aux).all()
+    assert fin == (int(exp_fin[0]), int(exp_fin[1])) and fin != (0, 0)
+
+
+def test_precompile_session_production_params_keccak_sized_load(ctx):
+    """`precompile_pcs_params()` (= the VM's production parameters), 2^16 requests (~5 400 Keccak-round-row equivalents) against the
+    full table: verify-only (the oracle needs minutes for this size), both verifiers, through `eval_external`."""
+    pkg = load_package()
+    airs_, lookups, traces = session(5400, 16, seed=9)
+    prm = dict(protocol.PROD_PARAMS)
+    got, root, st, pre = device_prove(ctx, airs_, lookups, traces, prm)
+    assert got.log_trace_heights == [16, 16, 3]
+    ok, msg = ob.verify(airs_, got.log_trace_heights, ROOT, {"fields": got.fields, "commitments": got.commitments}, prm,
+                        init_state=st, pre_observe=pre, external=PA.external_assertions(pkg))
+    assert ok, msg
+    ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, preprocessed_root=root,
+                          external=PA.external_assertions(pkg))
+    assert ok2 and (dig == got.digest).all()

@@ -1,0 +1,174 @@
+"""CPU tests of the second client's AIRs (miden-vm_amd/precompile_airs.py restating precompiles-prover/src/primitives/byte_pair_lut.rs,
+ec/groups.rs, logup/constraint.rs -- the natural last-row sigma closing --, relations.rs and session/prove.rs `eval_external`).
+
+Anchors held here: the preprocessed table equals `preprocessed_table()`'s definition row for row (lex order, !a & b, a ^ b); the
+constraints vanish on generated traces under the reference's `check_constraints` pass (crates/lifted-stark/src/debug.rs, restated in the
+oracle) -- INCLUDING a firing last row, which the VM's adapter forbids and this one is built for -- and fail on one-cell perturbations;
+sigma = the full LogUp residue of the AIR; the statement [requirer, byte-pair table, group table] closes only through `eval_external`
+(sigma sum + the verifier's fixed `EcGroup` consume), the oracle proves it with the precompile PCS parameters and both verifiers accept;
+dropped requests, a forged table multiplicity and a missing boundary correction are rejected."""
+import numpy as np
+import pytest
+import oracle_binding as ob
+from __graft_entry__ import load_package
+
+pkg = load_package()
+from miden_vm_amd import precompile_airs as PA, dag, protocol  # noqa: E402
+
+P = dag.P
+RND = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
+FAST = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=5,
+            query_pow_bits=3)
+ROOT = [71, 72, 73, 74]  # the session's public transcript root (4 felts, logup/mod.rs:131): declared by every chiplet, read by none here
+
+
+def host_aux(lookup, main, randomness, preprocessed=None):
+    return ob.lookup_build_aux(lookup, main, randomness, preprocessed)
+
+
+@pytest.fixture(scope="module")
+def airs():
+    return dict(bpl=PA.byte_pair_lut_air(host_aux), groups=PA.ec_groups_air(host_aux), req=PA.requirer_air(host_aux))
+
+
+@pytest.fixture(scope="module")
+def session(airs):
+    """[requirer 2^9 rows (every row fires, the last one too), byte-pair table 2^16, group table 2^3]"""
+    rng = np.random.default_rng(5)
+    ledger = PA.BytePairLutRequires()
+    reqs = PA.keccak_like_requests(rng, 42, ledger)  # 42 * 12 = 504 requests
+    reqs += [(PA.BUS_RANGE16, 1, [0xffff])] * 8       # -> 512: the requirer's last row fires; table row 0xffff gets multiplicity 8
+    for _ in range(8):
+        ledger.require_range16(0xffff)
+    assert len(reqs) == 512
+    traces = [PA.requirer_trace(reqs, 9), PA.byte_pair_lut_trace(ledger), PA.ec_groups_trace()]
+    return [airs["req"][0], airs["bpl"][0], airs["groups"][0]], traces
+
+
+def sigma_of(air_lookup, trace):
+    air, lookup = air_lookup
+    aux, fin = ob.lookup_build_aux(lookup, trace, RND, air.preprocessed)
+    return aux, (int(fin[0]), int(fin[1]))
+
+
+def test_preprocessed_table_is_the_lex_enumeration():
+    t = PA.byte_pair_preprocessed()
+    assert t.shape == (1 << 16, 4)
+    for idx in (0, 1, 255, 256, 0x1234, 0xabcd, 0xffff):
+        a, b = idx >> 8, idx & 0xff
+        assert list(t[idx]) == [a, b, (~a & 0xff) & b, a ^ b]
+    assert int(t[:, 2].max()) < 256 and int(t[:, 3].max()) < 256
+    # BytePairOp::apply_u64 commutes with the byte split (require_logic64, byte_pair_lut.rs:233-256)
+    led = PA.BytePairLutRequires()
+    x, y = 0x0123456789abcdef, 0xfedcba9876543210
+    assert led.require_logic64(PA.OP_XOR, x, y) == x ^ y and led.require_logic64(PA.OP_ANDNOT, x, y) == (~x & y) & ((1 << 64) - 1)
+    assert int(led.counts.sum()) == 16
+    led.require_range16(0xbeef)
+    assert led.counts[(0xef << 8) | 0xbe, 2] == 1  # w = a + 256 b: the LSB byte is the table's `a`
+
+
+def test_shapes_follow_the_reference_declarations(airs):
+    bpl, groups = airs["bpl"][0], airs["groups"][0]
+    h = dag.parse_air_blob(bpl.blob)
+    assert (h["main_width"], h["aux_width"], h["num_randomness"], h["num_aux_values"], h["num_public"]) == (3, 2, 2, 1, 4)
+    assert bpl.preprocessed.shape == (1 << 16, 4)
+    assert h["log_quotient_degree"] == 1      # "every closing constraint stays at degree <= 3 -> lqd 1"
+    g = dag.parse_air_blob(groups.blob)
+    assert (g["main_width"], g["aux_width"], g["num_aux_values"], g["num_public"]) == (6, 1, 1, 4)
+    assert len(h["constraints"]) == 4 and len(g["constraints"]) == 2 + 3   # col 0: first / transition / last, col 1: one ungated
+
+
+def test_constraints_vanish_and_perturbations_are_caught(airs, session):
+    _, traces = session
+    for key, t in zip(("req", "bpl", "groups"), traces):
+        air = airs[key][0]
+        aux, sig = sigma_of(airs[key], t)
+        bad, first = ob.check_constraints(air, t, aux, list(sig), ROOT, RND, air.preprocessed)
+        assert bad == 0, (key, first)
+        # sigma is the FULL residue: the last row's interaction is inside it (the VM's adapter would leave it out)
+        wrong = ((sig[0] + 1) % P, sig[1])
+        bad, first = ob.check_constraints(air, t, aux, list(wrong), ROOT, RND, air.preprocessed)
+        assert bad == 1 and first[0] == t.shape[0] - 1, (key, bad, first)
+    # a forged table multiplicity changes the fractions: the committed aux no longer satisfies the column equations
+    t = traces[1].copy()
+    aux, sig = sigma_of(airs["bpl"], traces[1])
+    t[0x1234, 1] = (int(t[0x1234, 1]) + 1) % P
+    bad, _ = ob.check_constraints(airs["bpl"][0], t, aux, list(sig), ROOT, RND, airs["bpl"][0].preprocessed)
+    assert bad >= 1
+    # the group table's pointer chain is ungated: pads included
+    g = traces[2].copy()
+    g[5, 0] = 99
+    aux, sig = sigma_of(airs["groups"], g)
+    bad, _ = ob.check_constraints(airs["groups"][0], g, aux, list(sig), ROOT, RND)
+    assert bad == 2  # rows 4 and 5 of the transition constraint
+
+
+def test_last_row_fires_in_the_requirer(airs, session):
+    _, traces = session
+    t = traces[0]
+    assert int(t[-1, 0]) == 1  # multiplicity 1 on the last row
+    aux, sig = sigma_of(airs["req"], t)
+    quiet = t.copy()
+    quiet[-1, 0] = 0
+    _, sig_q = sigma_of(airs["req"], quiet)
+    assert sig != sig_q
+
+
+def test_sigmas_close_through_eval_external_only(airs, session):
+    _, traces = session
+    sig = [[sigma_of(airs[k], t)[1]] for k, t in zip(("req", "bpl", "groups"), traces)]
+    assert PA.eval_external(RND, sig) == [(0, 0)]
+    s = (sum(x[0][0] for x in sig) % P, sum(x[0][1] for x in sig) % P)
+    assert s != (0, 0)                       # the verifier's fixed EcGroup consume is part of the identity
+    assert PA.eval_external(RND, sig[:2]) != [(0, 0)]
+    # requirer + table alone balance (the table provides exactly what was requested)
+    assert ((sig[0][0][0] + sig[1][0][0]) % P, (sig[0][0][1] + sig[1][0][1]) % P) == (0, 0)
+
+
+def _prove_verify(air_list, traces, params, tamper=None):
+    proof = ob.prove(air_list, traces, ROOT, params, init_state=protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST))
+    root = proof["preprocessed_root"]
+    pre = protocol.protocol_pre_observe(params, ROOT, preprocessed_root=root)
+    lhs = proof["log_heights"]
+    ext_o = PA.external_assertions(pkg)
+    ok_o, msg_o = ob.verify(air_list, lhs, ROOT, proof, params, external=ext_o)
+    ok_p, msg_p = pkg.verify(air_list, lhs, ROOT, params, protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST), pre, proof["fields"],
+                             proof["commitments"], preprocessed_root=root, external=PA.external_assertions(pkg))
+    return proof, (ok_o, msg_o), (ok_p, msg_p)
+
+
+def test_the_session_statement_proves_and_verifies(session):
+    air_list, traces = session
+    proof, (ok_o, msg_o), (ok_p, msg_p) = _prove_verify(air_list, traces, FAST)
+    assert ok_o, msg_o
+    assert ok_p, msg_p
+    assert proof["log_heights"] == [9, 16, 3] and proof["preprocessed_root"] is not None
+    # without the statement's external assertions the proof of the three AIRs alone is fine (every AIR is locally sound) ...
+    ok, _ = ob.verify(air_list, proof["log_heights"], ROOT, proof, FAST)
+    assert ok
+    # ... and the plain balance (sigma sum without the boundary consume) does not close
+    bal = pkg.external_callback(lambda rnd, av, lhs: [(sum(v[0][0] for v in av) % P, sum(v[0][1] for v in av) % P)])
+    ok, _ = ob.verify(air_list, proof["log_heights"], ROOT, proof, FAST, external=bal)
+    assert not ok
+
+
+def test_dropped_request_and_forged_multiplicity_are_rejected(airs, session):
+    air_list, traces = session
+    t_req = traces[0].copy()
+    t_req[17, 0] = 0  # one request dropped: the table still provides it
+    _, (ok_o, _), (ok_p, _) = _prove_verify(air_list, [t_req, traces[1], traces[2]], FAST)
+    assert not ok_o and not ok_p
+    t_bpl = traces[1].copy()
+    t_bpl[0x00ff, 0] = (int(t_bpl[0x00ff, 0]) + 1) % P  # one more AndNot provide than was requested
+    _, (ok_o, _), (ok_p, _) = _prove_verify(air_list, [traces[0], t_bpl, traces[2]], FAST)
+    assert not ok_o and not ok_p
+    t_g = traces[2].copy()
+    t_g[0, 5] = 2  # the group row claims two readers, only the verifier's boundary consume exists
+    _, (ok_o, _), (ok_p, _) = _prove_verify(air_list, [traces[0], traces[1], t_g], FAST)
+    assert not ok_o and not ok_p
+
+
+def test_precompile_pcs_params_are_the_vm_production_parameters():
+    # stark_config.rs:64-75 `precompile_pcs_params` mirrors miden_air::config::pcs_params
+    assert protocol.PROD_PARAMS == dict(log_blowup=3, log_folding_arity=2, log_final_degree=7, folding_pow_bits=4, deep_pow_bits=12,
+                                        num_queries=27, query_pow_bits=16)
