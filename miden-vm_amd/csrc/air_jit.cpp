@@ -328,7 +328,7 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
   for (size_t ci = 0; ci < n_chunks; ci++)
     for (size_t i = chunks[ci].ev_lo; i < chunks[ci].ev_hi; i++)
       if (seq[i].fold_k < 0) def_chunk[seq[i].node] = (int32_t)ci;
-  const int recomp_max = env_int("MH_JIT_RECOMP", 250);
+  const int recomp_max = env_int("MH_JIT_RECOMP", 160);
   auto valu_cost = [&](uint32_t id) -> int {  // rough VALU instructions of one gate
     const DagNode& nd = nodes[id];
     const bool ea = nodes[nd.a].ext, eb = nd.op != DOP_NEG && nodes[nd.b].ext;
