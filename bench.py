@@ -352,6 +352,58 @@ def chiplets_air_probe(pkg, ctx, log_n=20, steps=3):
     return out
 
 
+def precompile_session_probe(pkg, ctx, n_perms=80, steps=3):
+    """The second client (precompiles-prover/src/session/prove.rs): n_perms Keccak-f[1600] permutations through the real KeccakRoundAir
+    (two lanes, 68 columns + 20 EF LogUp columns + 10 periodic), the real BytePairLutAir (2^16 rows, four PREPROCESSED columns committed at
+    setup), the group table and the sponge side of the memory bus (miden-vm_amd/precompile_airs.py); production parameters
+    (`precompile_pcs_params`), every aux column built on the device, verified through `ChipletMultiAir::eval_external`."""
+    import numpy as np
+    from miden_vm_amd import protocol, precompile_airs as PA
+    rng = np.random.default_rng(3)
+    states = [[int(x) for x in rng.integers(0, 1 << 63, 25)] for _ in range(n_perms)]
+    t0 = time.perf_counter()
+    ledger = PA.BytePairLutRequires()
+    trace, mem = PA.keccak_round_trace(states, ledger)
+    pairs = [PA.keccak_round_air(), PA.byte_pair_lut_air(), PA.ec_groups_air(), PA.requirer_air()]
+    host = [trace, PA.byte_pair_lut_trace(ledger), PA.ec_groups_trace(), PA.requirer_trace(PA.sponge_side_requests(states, mem))]
+    gen_s = time.perf_counter() - t0
+    airs_h = [p_[0] for p_ in pairs]
+    prm = dict(protocol.PROD_PARAMS)
+    root_pub = [71, 72, 73, 74]
+    t0 = time.perf_counter()
+    dairs = [pkg.DeviceAir(ctx, a) for a in airs_h]
+    raw = ctx.upload_trace(airs_h[1].preprocessed)
+    com = pkg.commit_traces(ctx, [raw], prm["log_blowup"])   # setup: Preprocessed::build, once per configuration
+    dairs[1].attach_preprocessed(com.tree(), 0, raw=raw)
+    for d, (_, lk) in zip(dairs, pairs):
+        d.attach_lookup(pkg.DeviceLookup(ctx, lk))
+    setup_s = time.perf_counter() - t0
+    st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
+    pre = protocol.protocol_pre_observe(prm, root_pub, preprocessed_root=com.root())
+    traces = [ctx.upload_trace(t) for t in host]
+    proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    ok, _ = pkg.verify(airs_h, proof.log_trace_heights, root_pub, prm, st, pre, proof.fields, proof.commitments, preprocessed_root=com.root(),
+                       external=PA.external_assertions(pkg))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    dt = (time.perf_counter() - t0) / steps
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    prof = ctx.prof()
+    ctx.prof_enable(False)
+    for t in traces:
+        t.free()
+    return {"workload": f"precompile session: {n_perms} Keccak-f permutations (KeccakRoundAir 68 + 20 EF aux, BytePairLutAir 3 + 2 EF aux + 4 preprocessed, "
+                        "EcGroupsAir, sponge side of the memory bus), production parameters, aux columns on the device",
+            "log_trace_heights": proof.log_trace_heights, "ms_per_proof": dt * 1e3, "keccak_permutations_per_s": n_perms / dt,
+            "proof_bytes": len(proof.bytes), "verifies_with_eval_external": bool(ok),
+            "compiled_chunks": [a.compiled_chunks for a in dairs], "chunk_max_vgprs": [a.compiled_max_vgprs for a in dairs],
+            "kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items() if not k.startswith("span:") and v["ms"] > 0.05},
+            "trace_generation_s": gen_s, "setup_s": setup_s}
+
+
 def miden_real_probe(pkg, ctx, iters=9250, steps=3, lmcs="poseidon2", inputs=None):
     """THE Miden statement, no stand-ins: CoreAir + ChipletsAir + Poseidon2PermutationAir (miden-vm_amd/{core,chiplets,miden}_air.py) over
     the traces of ONE executed program -- a loop over a hash / u32 / memory mix run by the small VM of miden-vm_amd/core_trace.py --
@@ -786,6 +838,10 @@ def main():
             out["chiplets_air"] = chiplets_air_probe(pkg, ctx)
         except Exception as e:
             out["chiplets_air"] = {"error": repr(e)[:200]}
+        try:
+            out["precompile_session"] = precompile_session_probe(pkg, ctx)
+        except Exception as e:
+            out["precompile_session"] = {"error": repr(e)[:300]}
         try:
             # the service-level probes run in a process of their own (tools/bench_inflight_h2d.py, no torch in it): measured in THIS
             # process, which also hosts PyTorch's HIP runtime, the same loops lose the copy / kernel overlap (k = 1 with its uploads

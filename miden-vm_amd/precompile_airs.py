@@ -1,19 +1,27 @@
 """The second client of the backend: AIRs of the precompile prover (`precompiles-prover/src`), hand-ported against `dag.AirBuilder`
 like the VM's three AIRs, and the statement layer of its session (`precompiles-prover/src/session/prove.rs`).
 
-What is here: the one AIR of the chiplet stack with PREPROCESSED columns and a fixed height --
-`BytePairLutAir` (`primitives/byte_pair_lut.rs`: the 2^16-row `(a, b, !a & b, a ^ b)` table committed once, three witness
-multiplicity columns, two LogUp columns) --, the group table `EcGroupsAir` (`ec/groups.rs`: six columns, an ungated pointer chain,
-one LogUp column whose provides are closed by the verifier's fixed boundary consumes), the precompile prover's LogUp adapter (natural
-last-row sigma closing, `logup/constraint.rs`: `dag.LogUp(closing="sigma_last_row")`), its bus registry (`relations.rs`) and
-`ChipletMultiAir::eval_external` (`session/prove.rs:259-272`: sum of the committed sigmas + the fixed boundary correction).
+What is here: three of the twelve chiplets of `ChipletAir::all()` (session/prove.rs:104-121) --
+* `BytePairLutAir` (`primitives/byte_pair_lut.rs`): the one AIR of the stack with PREPROCESSED columns and a fixed height -- the
+  2^16-row `(a, b, !a & b, a ^ b)` table committed once, three witness multiplicity columns, two LogUp columns;
+* `KeccakRoundAir` (`hash/keccak/round/{mod,program}.rs`): its consumer -- a three-address machine `c = ROL(a OP b, s)` whose 128-slot
+  round program (ten periodic columns) runs Keccak-f[1600] rounds, two permutation lanes of 34 columns, 2 x 10 LogUp columns (Memory64
+  provide / requires, eight byte-pair requests, eight Range16 limb requests per row);
+* `EcGroupsAir` (`ec/groups.rs`): six columns, an ungated pointer chain, one LogUp column whose provides are closed by the verifier's
+  fixed boundary consumes;
+the precompile prover's LogUp adapter (natural last-row sigma closing, `logup/constraint.rs`: `dag.LogUp(closing="sigma_last_row")`),
+its bus registry (`relations.rs`) and `ChipletMultiAir::eval_external` (`session/prove.rs:259-272`: sum of the committed sigmas + the
+fixed boundary correction).
 
-What is not: the other ten chiplets (Keccak round / sponge, chunk nodes, Poseidon2 transcript, eval, uint store / add, EC point store /
-add / MSM: ~25 kLoC of the reference).  The requests they would put on the `BytePairLut` / `Range16` buses come from `requirer_air`, a
-one-interaction-per-row stand-in written against the same adapter, so that the table's multiplicities are exercised and the statement
-closes; `eval_external` therefore sums the `EcGroup` part of `fixed_boundary_correction` only (the `UintVal` part belongs to the uint
-store, which is not in this subset).  Parity is held by tests/test_precompile_airs.py and tests/test_gpu_precompile.py; the reference-side
-bytes need the exported symbolic DAGs like every other AIR here (tools/ref_fixtures)."""
+What is not: the other nine chiplets (Keccak sponge, chunk nodes, Poseidon2 transcript, eval, uint store / add, EC point store / add /
+MSM: ~25 kLoC of the reference).  What the SPONGE would put on the Memory64 bus for the permutations of a trace (initial lanes, round
+constants, the consumed outputs: `sponge_side_requests`) comes from `requirer_air`, a one-interaction-per-row stand-in written against
+the same adapter, so that the statement closes; `eval_external` sums the `EcGroup` part of `fixed_boundary_correction` only (the
+`UintVal` part belongs to the uint store).  Pinned here: the round program's operation counts (program.rs tests: 22 / 52 / 25 / 5 / 24),
+the machine computes FIPS 202 Keccak-f (checked against a plain implementation), every bus balances.  Not pinned (no Rust): the
+reference's own evaluation of the same constraints (exported symbolic DAGs, tools/ref_fixtures), and the quotient degree its symbolic
+builder assigns to the Keccak chiplet (this builder counts a periodic value as degree 1: log_quotient_degree 2, the reference's notes say 1).
+Parity of the device path is held by tests/test_precompile_airs.py and tests/test_gpu_precompile.py."""
 import numpy as np
 from . import dag
 
@@ -247,3 +255,292 @@ def eval_external(randomness, aux_values):
 
 def external_assertions(pkg):
     return pkg.external_callback(lambda rnd, aux_values, lhs: eval_external(rnd, aux_values))
+
+
+# ---- KeccakRound: the consumer of the byte-pair table (hash/keccak/round/{mod,program}.rs) --------------------------------------------
+# A three-address machine `c = ROL(a OP b, s)` over the Memory64 bus; one Keccak-f[1600] round = 128 program slots (10 periodic
+# columns), a permutation = 24 active rounds + 1 dead round = 3200 rows, two permutation lanes side by side (2 x 34 main columns,
+# 2 x 10 LogUp columns).  Every row commits its operands and result as bytes / 16-bit limbs and checks them against the table.
+ROUND_PERIOD, KR_NUM_ROUNDS, KR_NUM_LANES, KR_LANE_WIDTH = 128, 24, 2, 34
+PERM_CYCLE = (KR_NUM_ROUNDS + 1) * ROUND_PERIOD
+KR_MAIN_COLS, KR_AUX_COLS, KR_IP_BOUNDARY = KR_LANE_WIDTH * KR_NUM_LANES, 10 * KR_NUM_LANES, 25
+KR_COL_IP, KR_A, KR_B, KR_R, KR_ROT, KR_COL_ACT = 0, 1, 9, 17, 25, 33  # lane-local (mod.rs:52-96)
+PCOL_IS_XOR, PCOL_IS_ANDNOT, PCOL_IS_ROL, PCOL_BACK_A, PCOL_BACK_B, PCOL_K, PCOL_DST_MULT, PCOL_P_LAST, PCOL_IS_XORROL, PCOL_SWAP = range(10)
+OP_NOP, OP_KXOR, OP_KANDNOT, OP_ROL, OP_XORROL = range(5)
+KECCAK_RC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808a, 0x8000000080008000, 0x000000000000808b, 0x0000000080000001,
+             0x8000000080008081, 0x8000000000008009, 0x000000000000008a, 0x0000000000000088, 0x0000000080008009, 0x000000008000000a,
+             0x000000008000808b, 0x800000000000008b, 0x8000000000008089, 0x8000000000008003, 0x8000000000008002, 0x8000000000000080,
+             0x000000000000800a, 0x800000008000000a, 0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
+KECCAK_RHO = [[0, 36, 3, 41, 18], [1, 44, 10, 45, 2], [62, 6, 43, 15, 61], [28, 55, 25, 21, 56], [27, 20, 39, 8, 14]]  # RHO[x][y]
+SLOT_RC, SLOT_C_BEGIN, SLOT_D_ROL_BEGIN, SLOT_D_XOR_BEGIN, SLOT_CHI_ANDNOT_BEGIN, SLOT_CHI00, SLOT_IOTA, SLOT_CHI_XOR_BEGIN = 0, 2, 22, 27, 69, 102, 103, 104
+_SLOT_B = [32, 34, 36, 37, 38, 39, 40, 41, 43, 46, 47, 48, 49, 50, 51, 52, 54, 55, 56, 58, 61, 63, 65, 67, 68]  # program.rs:165-194
+M64 = (1 << 64) - 1
+
+
+def _rol64(x, s):
+    return ((x << s) | (x >> (64 - s))) & M64 if s else x
+
+
+def keccak_f_reference(state):
+    """FIPS 202 Keccak-f[1600] on 25 lanes, index x + 5 y (the checker of the ported round program)."""
+    s = list(state)
+    for rc in KECCAK_RC:
+        c = [s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20] for x in range(5)]
+        d = [c[(x + 4) % 5] ^ _rol64(c[(x + 1) % 5], 1) for x in range(5)]
+        s = [s[i] ^ d[i % 5] for i in range(25)]
+        bq = [0] * 25
+        for x in range(5):
+            for y in range(5):
+                bq[y + 5 * ((2 * x + 3 * y) % 5)] = _rol64(s[x + 5 * y], KECCAK_RHO[x][y])
+        s = [bq[x + 5 * y] ^ (~bq[(x + 1) % 5 + 5 * y] & M64 & bq[(x + 2) % 5 + 5 * y]) for y in range(5) for x in range(5)]
+        s[0] ^= rc
+    return s
+
+
+def keccak_round_slots():
+    """`slots()` (program.rs:262-270): per slot (op, shift, back_a, back_b, dst_mult).  Sources are ("local", slot) /
+    ("lane", x, y) = the previous round's output for lane (x, y) / None, turned into back-offsets exactly as `Source::back_off`."""
+    def slot_lane_prev(x, y):
+        return SLOT_IOTA if (x, y) == (0, 0) else SLOT_CHI_XOR_BEGIN + (x + 5 * y - 1)
+
+    def slot_c(x):
+        return SLOT_C_BEGIN + 4 * x + 3
+
+    def slot_t(x, y):
+        return SLOT_CHI_ANDNOT_BEGIN + x + 5 * y
+
+    def slot_b(x, y):
+        return _SLOT_B[x + 5 * y]
+    s = [(OP_NOP, 0, None, None, 0)] * ROUND_PERIOD
+    for x in range(5):  # theta C: five linear 4-XOR chains
+        base = SLOT_C_BEGIN + 4 * x
+        s[base] = (OP_KXOR, 0, ("lane", x, 0), ("lane", x, 1), 1)
+        s[base + 1] = (OP_KXOR, 0, ("local", base), ("lane", x, 2), 1)
+        s[base + 2] = (OP_KXOR, 0, ("local", base + 1), ("lane", x, 3), 1)
+        s[base + 3] = (OP_KXOR, 0, ("local", base + 2), ("lane", x, 4), 2)
+    for i in range(5):
+        s[SLOT_D_ROL_BEGIN + i] = (OP_ROL, 1, ("local", slot_c((i + 1) % 5)), None, 1)
+    for i in range(5):
+        s[SLOT_D_XOR_BEGIN + i] = (OP_KXOR, 0, ("local", slot_c((i + 4) % 5)), ("local", SLOT_D_ROL_BEGIN + i), 5)
+    for out_y in range(5):  # theta-apply + rho-pi, `emit_apply_rpi`
+        for out_x in range(5):
+            in_x, in_y = (3 * out_y + out_x) % 5, out_x  # pi^-1
+            rho = KECCAK_RHO[in_x][in_y]
+            a_src, d_src = ("lane", in_x, in_y), ("local", SLOT_D_XOR_BEGIN + in_x)
+            apply_a, apply_b = (d_src, a_src) if in_y == 0 else (a_src, d_src)
+            s[slot_b(out_x, out_y)] = (OP_KXOR if rho == 0 else OP_XORROL, rho, apply_a, apply_b, 3)
+    for y in range(5):
+        for x in range(5):
+            s[slot_t(x, y)] = (OP_KANDNOT, 0, ("local", slot_b((x + 1) % 5, y)), ("local", slot_b((x + 2) % 5, y)), 1)
+    s[SLOT_CHI00] = (OP_KXOR, 0, ("local", slot_t(0, 0)), ("local", slot_b(0, 0)), 1)
+    s[SLOT_IOTA] = (OP_KXOR, 0, ("local", SLOT_CHI00), ("local", SLOT_RC), 2)
+    for idx in range(1, 25):
+        x, y = idx % 5, idx // 5
+        s[SLOT_CHI_XOR_BEGIN + idx - 1] = (OP_KXOR, 0, ("local", slot_t(x, y)), ("local", slot_b(x, y)), 2)
+
+    def back(src, read_slot):
+        if src is None:
+            return 0
+        if src[0] == "local":
+            return read_slot - src[1]
+        return ROUND_PERIOD + read_slot - slot_lane_prev(src[1], src[2])
+    return [(op, sh, back(a, i), back(bsrc, i), m) for i, (op, sh, a, bsrc, m) in enumerate(s)]
+
+
+def _rol_decompose(s):  # program.rs:470-472
+    return (s - 32, 1) if s >= 32 else (s, 0)
+
+
+def keccak_round_program():
+    """`round_program()` (program.rs:481-519): the ten period-128 columns in PCOL_* order."""
+    cols = [[0] * ROUND_PERIOD for _ in range(10)]
+    for slot, (op, sh, back_a, back_b, mult) in enumerate(keccak_round_slots()):
+        is_xor, is_andnot, is_rol, is_xorrol, k, swap = {OP_NOP: (0, 0, 0, 0, 0, 0), OP_KXOR: (1, 0, 0, 0, 0, 0), OP_KANDNOT: (0, 1, 0, 0, 0, 0)}.get(op, None) or \
+            ((0, 0, 1, 0, 1 << sh, 0) if op == OP_ROL else (1, 0, 1, 1, 1 << _rol_decompose(sh)[0], _rol_decompose(sh)[1]))
+        for c, v in ((PCOL_IS_XOR, is_xor), (PCOL_IS_ANDNOT, is_andnot), (PCOL_IS_ROL, is_rol), (PCOL_IS_XORROL, is_xorrol), (PCOL_SWAP, swap),
+                     (PCOL_BACK_A, back_a), (PCOL_BACK_B, back_b), (PCOL_K, k), (PCOL_DST_MULT, mult)):
+            cols[c][slot] = v
+    cols[PCOL_P_LAST][ROUND_PERIOD - 1] = 1
+    return cols
+
+
+def _pack_le(items, base):  # utils.rs `pack_le`: Horner, LSB first
+    acc = None
+    for it in reversed(items):
+        acc = it if acc is None else acc * base + it
+    return acc
+
+
+def keccak_round_air(host_aux=None):
+    """`KeccakRoundAir::eval` (round/mod.rs:206-311) and its `LookupAir::eval` (:396-560), both lanes."""
+    from .chiplets_air import When
+    b = dag.AirBuilder(KR_MAIN_COLS, aux_width=KR_AUX_COLS, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
+                       num_public=NUM_PUBLIC_VALUES, periodic=keccak_round_program())
+    w = When(b)
+    per = [b.periodic_value(i) for i in range(10)]
+    p_last, is_xor, is_andnot, is_rol, k = per[PCOL_P_LAST], per[PCOL_IS_XOR], per[PCOL_IS_ANDNOT], per[PCOL_IS_ROL], per[PCOL_K]
+    two_32 = b.const(1 << 32)
+    for lane in range(KR_NUM_LANES):
+        base = lane * KR_LANE_WIDTH
+        ip, next_ip = b.main(base + KR_COL_IP), b.main(base + KR_COL_IP, 1)
+        act, next_act = b.main(base + KR_COL_ACT), b.main(base + KR_COL_ACT, 1)
+        if lane == 0:
+            w.when_first_row().assert_eq(ip, b.const(KR_IP_BOUNDARY))
+        w.when_transition().assert_zero(next_ip - ip - 1)
+        w.assert_bool(act)
+        w.assert_zero((1 - p_last) * (next_act - act))
+        no_logic = 1 - (is_xor + is_andnot)
+        for i in range(8):
+            w.assert_zero(no_logic * (b.main(base + KR_R + i) - b.main(base + KR_A + i)))
+        r_bytes = [b.main(base + KR_R + i) for i in range(8)]
+        rot = [b.main(base + KR_ROT + i) for i in range(8)]
+        r_lo, r_hi = _pack_le(r_bytes[:4], 256), _pack_le(r_bytes[4:], 256)
+        rol_gate = act * is_rol
+        w.assert_zero(rol_gate * ((r_lo + two_32) * k - _pack_le(rot[:4], 1 << 16)))
+        w.assert_zero(rol_gate * ((r_hi + two_32) * k - _pack_le(rot[4:], 1 << 16)))
+    lk = dag.LogUp(b, MAX_MESSAGE_WIDTH, NUM_BUS_IDS, closing="sigma_last_row")
+
+    def side(bb):
+        p = [bb.periodic_value(i) for i in range(10)]
+        return dict(bb=bb, p=p, one=bb.const(1), zero=bb.const(0))
+    sc, sp = side(lk.b), side(lk.lb)
+
+    def both(f):
+        return f(sc), f(sp)
+
+    def msg(f):
+        def m(ch):
+            bus, fields = f(sc if ch is lk.ch_c else sp)
+            return ch.encode(bus, fields)
+        return m
+
+    def frac_col(*fracs):  # logup/mod.rs frac_col!: one group, one batch with flag ONE, its fractions
+        with lk.column() as col:
+            with col.group() as g:
+                with g.batch(both(lambda s: s["one"])) as bt:
+                    for mult, message in fracs:
+                        bt.insert(mult, message)
+    for lane in range(KR_NUM_LANES):
+        base = lane * KR_LANE_WIDTH
+
+        def cells(s, off, n=8):
+            return [s["bb"].main(base + off + i) for i in range(n)]
+
+        def gates(s):
+            p = s["p"]
+            act = s["bb"].main(base + KR_COL_ACT)
+            return dict(is_active=act * (p[PCOL_IS_XOR] + p[PCOL_IS_ANDNOT] + p[PCOL_IS_ROL] - p[PCOL_IS_XORROL]),
+                        reads_b=act * (p[PCOL_IS_XOR] + p[PCOL_IS_ANDNOT]), rol_act=act * p[PCOL_IS_ROL], dst=act * p[PCOL_DST_MULT],
+                        logic_active=p[PCOL_IS_XOR] + p[PCOL_IS_ANDNOT], bpl_op=s["one"] - p[PCOL_IS_ANDNOT])
+
+        def provide_c(s):  # `memory_provide_c` / `rotated_halves` (mod.rs:322-363)
+            p = s["p"]
+            r, limb = cells(s, KR_R), cells(s, KR_ROT)
+            r_lo, r_hi = _pack_le(r[:4], 256), _pack_le(r[4:], 256)
+            two_16 = s["bb"].const(1 << 16)
+            c0, c1, c2, c3 = limb[0] + limb[6], limb[1] + limb[7], limb[2] + limb[4], limb[3] + limb[5]
+            lo = c0 + c1 * two_16 - p[PCOL_K]
+            hi = c2 + c3 * two_16 - p[PCOL_K]
+            lo_f = lo + p[PCOL_SWAP] * (hi - lo)
+            hi_f = hi + p[PCOL_SWAP] * (lo - hi)
+            return r_lo + p[PCOL_IS_ROL] * (lo_f - r_lo), r_hi + p[PCOL_IS_ROL] * (hi_f - r_hi)
+
+        def ip_of(s):
+            return s["bb"].main(base + KR_COL_IP)
+        # band col 0: the Memory64 dst provide
+        frac_col((both(lambda s: s["zero"] - gates(s)["dst"]), msg(lambda s: (BUS_MEMORY64, [ip_of(s), *provide_c(s)]))))
+        # band col 1: the src_a and src_b requires
+        frac_col((both(lambda s: gates(s)["is_active"]),
+                  msg(lambda s: (BUS_MEMORY64, [ip_of(s) - s["p"][PCOL_BACK_A], _pack_le(cells(s, KR_A)[:4], 256), _pack_le(cells(s, KR_A)[4:], 256)]))),
+                 (both(lambda s: gates(s)["reads_b"]),
+                  msg(lambda s: (BUS_MEMORY64, [ip_of(s) - s["p"][PCOL_BACK_B], _pack_le(cells(s, KR_B)[:4], 256), _pack_le(cells(s, KR_B)[4:], 256)]))))
+        # band cols 2-5: eight byte requests, two per column
+        for pair in range(4):
+            def byte_req(i):
+                return (both(lambda s: gates(s)["is_active"]),
+                        msg(lambda s: (BUS_BYTE_PAIR_LUT, [gates(s)["bpl_op"], cells(s, KR_A)[i], gates(s)["logic_active"] * cells(s, KR_B)[i], cells(s, KR_R)[i]])))
+            frac_col(byte_req(2 * pair), byte_req(2 * pair + 1))
+        # band cols 6-9: eight Range16 requests on the rotation limbs
+        for pair in range(4):
+            def limb_req(i):
+                return (both(lambda s: gates(s)["rol_act"]), msg(lambda s: (BUS_RANGE16, [cells(s, KR_ROT)[i]])))
+            frac_col(limb_req(2 * pair), limb_req(2 * pair + 1))
+    lookup = lk.finish("keccak_round")
+    return dag.Air(b, _host_aux(lookup, host_aux), "keccak_round"), lookup
+
+
+def keccak_round_trace(states, requires=None, rcs=None):
+    """`generate_trace_from_states_inner` (round/mod.rs:725-806): `states` = the initial 25-lane states of the stacked permutations,
+    contiguous blocks of permutations per lane; drives the byte-pair ledger when one is given.  The machine's address space is kept per
+    permutation (`memory[n][a]` = absolute address n * 3200 + a: the initial state at 0..24, RC[r] at 25 + 128 r, the value written by
+    program row r at 25 + r) and the 3200 program rows are stepped once for all permutations (numpy).  -> (trace, memory)."""
+    rcs = KECCAK_RC if rcs is None else rcs
+    num_perms = len(states)
+    assert num_perms >= 1
+    active = KR_NUM_ROUNDS * ROUND_PERIOD
+    ppl = -(-num_perms // KR_NUM_LANES)
+    height = max(2, 1 << (ppl * PERM_CYCLE - 1).bit_length())
+    program = keccak_round_slots()
+    u = np.uint64
+    mem = np.zeros((num_perms, KR_IP_BOUNDARY + PERM_CYCLE), dtype=np.uint64)
+    mem[:, :25] = np.array([[int(v) for v in st] for st in states], dtype=np.uint64)
+    for r in range(KR_NUM_ROUNDS):
+        mem[:, KR_IP_BOUNDARY + r * ROUND_PERIOD] = u(rcs[r])
+    cyc = np.zeros((num_perms, PERM_CYCLE, KR_LANE_WIDTH), dtype=np.uint64)  # the rows of one permutation cycle, ip filled in below
+    sh8 = (np.arange(8, dtype=np.uint64) * u(8))[None, :]
+    sh16 = (np.arange(4, dtype=np.uint64) * u(16))[None, :]
+    for r in range(PERM_CYCLE):
+        op, sh, back_a, back_b, mult = program[r % ROUND_PERIOD]
+        act = r < active
+        a = mem[:, KR_IP_BOUNDARY + r - back_a] if op != OP_NOP else np.zeros(num_perms, dtype=np.uint64)
+        bv = mem[:, KR_IP_BOUNDARY + r - back_b] if op in (OP_KXOR, OP_KANDNOT, OP_XORROL) else np.zeros(num_perms, dtype=np.uint64)
+        rv = (a ^ bv) if op in (OP_KXOR, OP_XORROL) else ((~a & bv) if op == OP_KANDNOT else a)
+        cv = ((rv << u(sh)) | (rv >> u(64 - sh))) if op in (OP_ROL, OP_XORROL) and sh else rv
+        if act and mult > 0:
+            mem[:, KR_IP_BOUNDARY + r] = cv
+        ab, bb_, rb = (a[:, None] >> sh8) & u(0xff), (bv[:, None] >> sh8) & u(0xff), (rv[:, None] >> sh8) & u(0xff)
+        cyc[:, r, KR_A:KR_A + 8], cyc[:, r, KR_B:KR_B + 8], cyc[:, r, KR_R:KR_R + 8] = ab, bb_, rb
+        if act and op != OP_NOP and requires is not None:  # require_logic64: eight byte requests per row
+            np.add.at(requires.counts, (((ab << u(8)) | bb_).astype(np.int64).ravel(), OP_ANDNOT if op == OP_KANDNOT else OP_XOR), 1)
+        if op in (OP_ROL, OP_XORROL):
+            kk = u(1 << _rol_decompose(sh)[0])
+            lo_k, hi_k = ((rv & u(0xffffffff)) + u(1 << 32)) * kk, ((rv >> u(32)) + u(1 << 32)) * kk
+            limbs = np.concatenate([(lo_k[:, None] >> sh16) & u(0xffff), (hi_k[:, None] >> sh16) & u(0xffff)], axis=1)
+            cyc[:, r, KR_ROT:KR_ROT + 8] = limbs
+            if act and requires is not None:  # require_range16: w = a + 256 b, the table row is (a << 8) | b
+                np.add.at(requires.counts, ((((limbs & u(0xff)) << u(8)) | (limbs >> u(8))).astype(np.int64).ravel(), 2), 1)
+        cyc[:, r, KR_COL_ACT] = 1 if act else 0
+    t = np.zeros((height, KR_MAIN_COLS), dtype=np.uint64)
+    for lane in range(KR_NUM_LANES):
+        base_perm = lane * ppl
+        lane_perms = min(max(num_perms - base_perm, 0), ppl)
+        cb = lane * KR_LANE_WIDTH
+        if lane_perms:
+            t[:lane_perms * PERM_CYCLE, cb:cb + KR_LANE_WIDTH] = cyc[base_perm:base_perm + lane_perms].reshape(-1, KR_LANE_WIDTH)
+        t[:, cb + KR_COL_IP] = np.arange(height, dtype=np.uint64) + u(KR_IP_BOUNDARY + base_perm * PERM_CYCLE)
+    return t, mem
+
+
+def keccak_round_outputs(memory, n):
+    """`extract_outputs`: the 25 output lanes of permutation n (the iota slot, then the chi-XOR block of round 23)."""
+    base = KR_IP_BOUNDARY + 23 * ROUND_PERIOD
+    return [int(memory[n, base + SLOT_IOTA])] + [int(memory[n, base + SLOT_CHI_XOR_BEGIN + i]) for i in range(24)]
+
+
+def sponge_side_requests(states, memory):
+    """What the Keccak SPONGE chiplet (not ported) puts on the Memory64 bus for these permutations, as `requirer` rows: it provides the
+    initial lanes (each read twice by round 0: theta's column sums and theta-apply) and RC[r] (read once by iota), and consumes the 25
+    outputs of round 23 (provided with multiplicity 2 for a next round that is the dead one)."""
+    def m64(addr, v):
+        return [addr, v & 0xffffffff, v >> 32]
+    out = []
+    for n, st in enumerate(states):
+        pb = n * PERM_CYCLE
+        for idx, v in enumerate(st):
+            out.append((BUS_MEMORY64, P - 2, m64(pb + idx, int(v))))
+        for r in range(KR_NUM_ROUNDS):
+            out.append((BUS_MEMORY64, P - 1, m64(KR_IP_BOUNDARY + pb + r * ROUND_PERIOD, KECCAK_RC[r])))
+        base = KR_IP_BOUNDARY + pb + 23 * ROUND_PERIOD
+        for slot in [SLOT_IOTA] + [SLOT_CHI_XOR_BEGIN + i for i in range(24)]:
+            out.append((BUS_MEMORY64, 2, m64(base + slot, int(memory[n, base + slot - pb]))))
+    return out

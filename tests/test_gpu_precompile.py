@@ -116,3 +116,60 @@ def test_precompile_session_production_params_keccak_sized_load(ctx):
     ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, preprocessed_root=root,
                           external=PA.external_assertions(pkg))
     assert ok2 and (dig == got.digest).all()
+
+
+# ---- with the Keccak round chiplet: the table's real consumer -------------------------------------------------------------------------
+def keccak_session(n_perms, seed=11):
+    rng = np.random.default_rng(seed)
+    states = [[0] * 25] + [[int(x) for x in rng.integers(0, 1 << 63, 25)] for _ in range(n_perms - 1)]
+    ledger = PA.BytePairLutRequires()
+    kr = PA.keccak_round_air(host_aux)
+    trace, mem = PA.keccak_round_trace(states, ledger)
+    pairs = [kr, PA.byte_pair_lut_air(host_aux), PA.ec_groups_air(host_aux), PA.requirer_air(host_aux)]
+    traces = [trace, PA.byte_pair_lut_trace(ledger), PA.ec_groups_trace(), PA.requirer_trace(PA.sponge_side_requests(states, mem))]
+    return [p[0] for p in pairs], [p[1] for p in pairs], traces
+
+
+@pytest.mark.parametrize("jit", ["0", "1"])
+def test_keccak_session_device_proof_equals_oracle(ctx, jit, monkeypatch):
+    """[KeccakRoundAir 2^13 x 68 + 20 EF aux (ten periodic columns), BytePairLutAir 2^16, EcGroupsAir, sponge side]: three permutations
+    in two lanes; 20 LogUp columns built on the device; interpreter and compiled chunks."""
+    pkg = load_package()
+    monkeypatch.setenv("MH_JIT", jit)
+    airs_, lookups, traces = keccak_session(3)
+    exp = ob.prove(airs_, traces, ROOT, FAST, init_state=protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST))
+    got, root, st, pre = device_prove(ctx, airs_, lookups, traces, FAST)
+    assert (got.commitments == exp["commitments"]).all()
+    assert got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all()
+    assert (got.digest == exp["digest"]).all()
+    assert got.log_trace_heights == [13, 16, 3, 8]
+    ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, FAST, st, pre, got.fields, got.commitments, preprocessed_root=root,
+                          external=PA.external_assertions(pkg))
+    assert ok2 and (dig == got.digest).all()
+
+
+def test_keccak_round_device_aux_equals_the_oracle(ctx):
+    pkg = load_package()
+    airs_, lookups, traces = keccak_session(5)
+    rnd = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
+    dl = pkg.DeviceLookup(ctx, lookups[0])
+    aux_dev, fin = dl.build_aux(ctx.upload_trace(traces[0]), rnd)
+    aux, exp_fin = ob.lookup_build_aux(lookups[0], traces[0], rnd)
+    assert (aux_dev.download() == aux).all()
+    assert fin == (int(exp_fin[0]), int(exp_fin[1]))
+
+
+def test_keccak_session_production_params_80_permutations(ctx):
+    """80 Keccak-f permutations (2^17 rows x 68 + 20 EF), the full table, production parameters: verify-only through both verifiers
+    and `eval_external`."""
+    pkg = load_package()
+    airs_, lookups, traces = keccak_session(80, seed=3)
+    prm = dict(protocol.PROD_PARAMS)
+    got, root, st, pre = device_prove(ctx, airs_, lookups, traces, prm)
+    assert got.log_trace_heights == [17, 16, 3, 13]
+    ok, msg = ob.verify(airs_, got.log_trace_heights, ROOT, {"fields": got.fields, "commitments": got.commitments}, prm,
+                        init_state=st, pre_observe=pre, external=PA.external_assertions(pkg))
+    assert ok, msg
+    ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, preprocessed_root=root,
+                          external=PA.external_assertions(pkg))
+    assert ok2 and (dig == got.digest).all()

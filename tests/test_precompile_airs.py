@@ -172,3 +172,110 @@ def test_precompile_pcs_params_are_the_vm_production_parameters():
     # stark_config.rs:64-75 `precompile_pcs_params` mirrors miden_air::config::pcs_params
     assert protocol.PROD_PARAMS == dict(log_blowup=3, log_folding_arity=2, log_final_degree=7, folding_pow_bits=4, deep_pow_bits=12,
                                         num_queries=27, query_pow_bits=16)
+
+
+# ---- the Keccak round chiplet: the table's real consumer -----------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def keccak(airs):
+    rng = np.random.default_rng(11)
+    states = [[0] * 25] + [[int(x) for x in rng.integers(0, 1 << 63, 25)] for _ in range(2)]  # three permutations: lanes of 2 + 1
+    ledger = PA.BytePairLutRequires()
+    kr = PA.keccak_round_air(host_aux)
+    trace, mem = PA.keccak_round_trace(states, ledger)
+    return dict(states=states, ledger=ledger, air=kr, trace=trace, mem=mem)
+
+
+def test_round_program_is_the_reference_design():
+    sl = PA.keccak_round_slots()
+    ops = [s[0] for s in sl]
+    # program.rs `op_counts_match_design`
+    assert [ops.count(o) for o in (PA.OP_NOP, PA.OP_KXOR, PA.OP_KANDNOT, PA.OP_ROL, PA.OP_XORROL)] == [22, 52, 25, 5, 24]
+    b_slots = PA._SLOT_B
+    assert len(set(b_slots)) == 25 and all(32 <= s < 69 for s in b_slots)  # `b_slot_table_unique_and_in_range`
+    cols = PA.keccak_round_program()
+    assert len(cols) == 10 and all(len(c) == 128 for c in cols)
+    assert sum(cols[PA.PCOL_P_LAST]) == 1 and cols[PA.PCOL_P_LAST][127] == 1
+    # the reduced shift stays within the bitwise bound, the half-swap takes the rest (rol_decompose)
+    assert all(k == 0 or k <= 1 << 30 for k in cols[PA.PCOL_K])
+    assert sum(cols[PA.PCOL_SWAP]) == sum(1 for (op, sh, *_r) in sl if op == PA.OP_XORROL and sh >= 32)
+    # every value the program writes is read exactly dst_mult times inside a round or by the next one: RC and the outputs aside,
+    # provides and requires cancel slot by slot
+    reads = [0] * 256
+    for i, (op, sh, ba, bb, m) in enumerate(sl):
+        if op != PA.OP_NOP:
+            reads[128 + i - ba] += 1
+        if op in (PA.OP_KXOR, PA.OP_KANDNOT, PA.OP_XORROL):
+            reads[128 + i - bb] += 1
+    for i, (op, sh, ba, bb, m) in enumerate(sl):
+        assert reads[128 + i] + reads[i] == (m if i != PA.SLOT_RC else 1), i
+
+
+def test_round_machine_computes_keccak_f(keccak):
+    assert PA.keccak_f_reference([0] * 25)[0] == 0xf1258f7940e1dde7  # FIPS 202: first lane of Keccak-f[1600] of the zero state
+    for n, st in enumerate(keccak["states"]):
+        assert PA.keccak_round_outputs(keccak["mem"], n) == PA.keccak_f_reference(st)
+    t = keccak["trace"]
+    assert t.shape == (8192, 68)                      # two permutation cycles of 3200 rows in lane 0 -> 2^13
+    assert int(t[0, 0]) == 25 and int(t[0, 34]) == 25 + 2 * 3200  # lane 1 starts at its block's address frame
+    assert int(t[3071, 33]) == 1 and int(t[3072, 33]) == 0        # the 25th round of a cycle is dead
+    assert int(t[3200:6400, 67].sum()) == 0                        # lane 1 holds one permutation: its second cycle is padding
+
+
+def test_keccak_round_constraints_and_perturbations(keccak):
+    air, lookup = keccak["air"]
+    t = keccak["trace"]
+    aux, fin = ob.lookup_build_aux(lookup, t, RND)
+    sig = [int(fin[0]), int(fin[1])]
+    assert ob.check_constraints(air, t, aux, sig, ROOT, RND) == (0, None)
+    h = dag.parse_air_blob(air.blob)
+    assert (h["main_width"], h["aux_width"], len(h["periodic"])) == (68, 20, 10)
+    assert len(h["constraints"]) == 2 * 13 + 1 + 3 + 19   # per lane 13 local, the ip boundary of lane 0; col 0: 3, the other 19 columns: 1 each
+    for row, col, delta in ((100, 0, 1),            # ip chain
+                            (200, 33, 1),           # act is constant inside a round (and boolean)
+                            (22, 17, 1),            # slot 22 is a pure ROL: r = a byte-wise
+                            (34, 25, 1),            # slot 34 rotates: the limbs are bound to (r_half + 2^32) k
+                            (128 + 36, 34 + 29, 5)):  # the same in lane 1 (slot 36 of its round 1)
+        bad_t = t.copy()
+        bad_t[row, col] = (int(bad_t[row, col]) + delta) % P
+        bad, _ = ob.check_constraints(air, bad_t, aux, sig, ROOT, RND)
+        assert bad >= 1, (row, col)
+    # a wrong result byte on an XOR row passes the local constraints (no pin there) but not the table: the fraction column changes
+    bad_t = t.copy()
+    bad_t[2, 17] = (int(bad_t[2, 17]) + 1) % 256
+    aux2, fin2 = ob.lookup_build_aux(lookup, bad_t, RND)
+    assert ob.check_constraints(air, bad_t, aux2, [int(fin2[0]), int(fin2[1])], ROOT, RND) == (0, None)
+    assert (int(fin2[0]), int(fin2[1])) != tuple(sig)
+
+
+def keccak_session(airs, keccak):
+    reqs = PA.sponge_side_requests(keccak["states"], keccak["mem"])
+    air_list = [keccak["air"][0], airs["bpl"][0], airs["groups"][0], airs["req"][0]]
+    traces = [keccak["trace"], PA.byte_pair_lut_trace(keccak["ledger"]), PA.ec_groups_trace(), PA.requirer_trace(reqs)]
+    return air_list, [keccak["air"][1], airs["bpl"][1], airs["groups"][1], airs["req"][1]], traces
+
+
+def test_keccak_rounds_balance_against_the_table_and_the_sponge_side(airs, keccak):
+    air_list, lookups, traces = keccak_session(airs, keccak)
+    sig = []
+    for a, lk, t in zip(air_list, lookups, traces):
+        _, fin = ob.lookup_build_aux(lk, t, RND, a.preprocessed)
+        sig.append([(int(fin[0]), int(fin[1]))])
+    assert PA.eval_external(RND, sig) == [(0, 0)]
+    # 3 permutations x 24 rounds x (106 rows that read `a`) x 8 bytes + 29 rotating rows x 8 limbs
+    assert int(traces[1].sum()) == 3 * 24 * (106 * 8 + 29 * 8)
+    # the Keccak chiplet alone does not balance against the table: its Memory64 traffic needs the sponge side
+    s3 = sig[:3]
+    assert PA.eval_external(RND, s3) != [(0, 0)]
+
+
+def test_keccak_session_proves_and_verifies(airs, keccak):
+    air_list, _, traces = keccak_session(airs, keccak)
+    proof, (ok_o, msg_o), (ok_p, msg_p) = _prove_verify(air_list, traces, FAST)
+    assert ok_o, msg_o
+    assert ok_p, msg_p
+    assert proof["log_heights"] == [13, 16, 3, 8]
+    # one flipped result byte in a chi row: locally fine, the table does not provide that tuple
+    t = traces[0].copy()
+    t[80, 17] ^= 1
+    _, (ok_o, _), (ok_p, _) = _prove_verify(air_list, [t] + traces[1:], FAST)
+    assert not ok_o and not ok_p

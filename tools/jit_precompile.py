@@ -21,6 +21,11 @@ def shipped_blobs():
                                 ("poseidon2_permutation_pub32", miden_air.poseidon2_permutation_air(num_public=32)),
                                 ("bus_standin", miden_statement.bus_standin_air())):
         out += [(name + ".dag", air.blob), (name + ".lkp", lookup.blob), (name + ".derived.lkp", dag.lookup_from_constraints(air.blob).blob)]
+    # the second client's AIRs (hand-written lookup programs only: their sigma-closing columns are not what lookup_from_constraints matches)
+    from miden_vm_amd import precompile_airs as PA
+    for name, (air, lookup) in (("keccak_round", PA.keccak_round_air()), ("byte_pair_lut", PA.byte_pair_lut_air()),
+                                ("ec_groups", PA.ec_groups_air()), ("requirer", PA.requirer_air())):
+        out += [(name + ".dag", air.blob), (name + ".lkp", lookup.blob)]
     return out
 
 
