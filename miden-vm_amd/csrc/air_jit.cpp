@@ -587,7 +587,8 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
     }
     std::ostringstream src;
     src << JIT_PRELUDE;
-    src << "extern \"C\" __global__ __launch_bounds__(256) void mh_jit_chunk(JitArgs a) {\n"
+    src << "#ifdef MH_JIT_WAVES\n__attribute__((amdgpu_waves_per_eu(MH_JIT_WAVES, MH_JIT_WAVES)))\n#endif\n"
+           "extern \"C\" __global__ __launch_bounds__(256) void mh_jit_chunk(JitArgs a) {\n"
            "  const u64 qb = blockIdx.x * 256ull + threadIdx.x;\n"
            "  if (qb >= a.q_count) return;\n"
            "  const u64 q = a.q0 + qb;\n"
