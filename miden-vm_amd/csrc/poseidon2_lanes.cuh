@@ -16,8 +16,10 @@
 // quad_perm for the 4-blocks, row_ror for the three 4-blocks of a 16-lane row, row_newbcast for lane 0.
 template <int CTRL>
 __device__ __forceinline__ u64 p2l_dpp(u64 v) {
-  const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)lo32(v), CTRL, 0xF, 0xF, false);
-  const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)hi32(v), CTRL, 0xF, 0xF, false);
+  // mov_dpp = update_dpp with an UNDEFINED old value: every control used here (quad_perm, row_ror, row_newbcast) gives each lane a
+  // valid source, so nothing of `old` survives and the compiler need not zero the destination first (a v_mov per 32-bit half)
+  const u32 lo = (u32)__builtin_amdgcn_mov_dpp((int)lo32(v), CTRL, 0xF, 0xF, false);
+  const u32 hi = (u32)__builtin_amdgcn_mov_dpp((int)hi32(v), CTRL, 0xF, 0xF, false);
   return ((u64)hi << 32) | lo;
 }
 #define P2L_QUAD(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
