@@ -39,7 +39,7 @@ FI u64 gl_reduce128(u64 hi, u64 lo) {
 }
 FI u64 gl_mul_c(u64 a, u64 b) { return gl_reduce128(__umul64hi(a, b), a * b); }
 #ifndef MH_JIT_ASM_MUL
-#define MH_JIT_ASM_MUL 0
+#define MH_JIT_ASM_MUL 2  // 0: plain C products, 1: the asm product everywhere, 2: for base-field gates only (measured: core AIR 19.6 / 19.9 / 18.7 ms)
 #endif
 #if MH_JIT_ASM_MUL
 // the 13-instruction SGPR-carry-chain product of poseidon2_fast.cuh (p2f_mul_nv: non-volatile statements carrying their own
@@ -82,12 +82,18 @@ FI e2 e2_neg(e2 a) { return {gl_neg(a.c0), gl_neg(a.c1)}; }
 FI e2 e2_addf(e2 a, u64 b) { return {gl_add(a.c0, b), a.c1}; }
 FI e2 e2_subf(e2 a, u64 b) { return {gl_sub(a.c0, b), a.c1}; }
 FI e2 e2_fsub(u64 a, e2 b) { return {gl_sub(a, b.c0), gl_neg(b.c1)}; }
+// MH_JIT_ASM_MUL == 2: the asm product for base-field gates only, EF products stay in C (their chunks lose with the asm form)
+#if MH_JIT_ASM_MUL == 2
+#define gl_mul_ef gl_mul_c
+#else
+#define gl_mul_ef gl_mul
+#endif
 FI e2 e2_mul(e2 a, e2 b) {
-  u64 a0b0 = gl_mul(a.c0, b.c0), a1b1 = gl_mul(a.c1, b.c1);
-  u64 cross = gl_mul(gl_add(a.c0, a.c1), gl_add(b.c0, b.c1));
+  u64 a0b0 = gl_mul_ef(a.c0, b.c0), a1b1 = gl_mul_ef(a.c1, b.c1);
+  u64 cross = gl_mul_ef(gl_add(a.c0, a.c1), gl_add(b.c0, b.c1));
   return {gl_add(a0b0, gl_mul7(a1b1)), gl_sub(gl_sub(cross, a0b0), a1b1)};
 }
-FI e2 e2_mulf(e2 a, u64 b) { return {gl_mul(a.c0, b), gl_mul(a.c1, b)}; }
+FI e2 e2_mulf(e2 a, u64 b) { return {gl_mul_ef(a.c0, b), gl_mul_ef(a.c1, b)}; }
 // The alpha fold with the modular reduction delayed to the end of the chunk: alpha^k is uniform, so it is cut into 16-bit limbs
 // (scalar unit), a constraint value into 32-bit halves, and the 48-bit partial products are summed by weight 2^(16 j) in plain 64-bit
 // accumulators -- 8 v_mad_u64_u32 per (base value, alpha component) instead of a modular multiplication and a modular addition;
@@ -264,27 +270,94 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
   for (size_t i = 0; i < nodes.size(); i++) n_gates += ir.live[i] && interior((uint32_t)i);
   if (mode != 1 && n_gates < (size_t)env_int("MH_JIT_MIN_GATES", 400)) return nullptr;
 
+  // ---- sums of (uniform EF coefficient) x (base value): LogUp message encodings `prefix + sum_i beta^i f_i` ----
+  // The coefficients depend on challenges, constants and public values only -- the same for every point --, so such a sum is the
+  // alpha fold's pattern: the coefficient is cut into 16-bit limbs on the scalar unit, the value into 32-bit halves, 8 v_mad_u64_u32
+  // per (term, component) into weight accumulators and ONE reduction per sum, instead of two modular products and two modular
+  // additions per term (72 VALU instructions -> 16, + ~130 per sum).  An EF ADD tree (through single-use ADD nodes) with at least
+  // $MH_JIT_DOT (default 3, 0 = off) such terms becomes one "dot" gate: its operands are the terms' (coefficient, value) pairs and the
+  // other addends; the ADD and MUL nodes inside are absorbed (never emitted).  Exact: the same field value, canonical on exit.
+  std::vector<char> uniform(nodes.size(), 0), absorbed(nodes.size(), 0);
+  struct Dot {
+    std::vector<std::pair<uint32_t, uint32_t>> terms;  // (uniform EF coefficient, base value)
+    std::vector<uint32_t> others;
+  };
+  std::vector<int32_t> dot_of(nodes.size(), -1);
+  std::vector<Dot> dots;
+  {
+    for (size_t i = 0; i < nodes.size(); i++) {
+      const DagNode& nd = nodes[i];
+      if (nd.op == DOP_CONST || nd.op == DOP_PUBLIC || nd.op == DOP_RANDOMNESS || nd.op == DOP_AUX_VALUE) uniform[i] = 1;
+      else if (dag_is_gate(nd.op)) uniform[i] = uniform[nd.a] && (nd.op == DOP_NEG || uniform[nd.b]);
+    }
+    const int min_terms = env_int("MH_JIT_DOT", 3);
+    std::vector<uint32_t> uses(nodes.size(), 0);
+    for (size_t i = 0; i < nodes.size(); i++)
+      if (ir.live[i] && interior((uint32_t)i)) {
+        uses[nodes[i].a]++;
+        if (nodes[i].op != DOP_NEG) uses[nodes[i].b]++;
+      }
+    for (uint32_t c : ir.cons) uses[c]++;
+    auto is_term = [&](uint32_t id, uint32_t& u, uint32_t& v) {
+      const DagNode& nd = nodes[id];
+      if (nd.op != DOP_MUL || uses[id] != 1) return false;
+      if (nodes[nd.a].ext && uniform[nd.a] && !nodes[nd.b].ext) { u = nd.a; v = nd.b; return true; }
+      if (nodes[nd.b].ext && uniform[nd.b] && !nodes[nd.a].ext) { u = nd.b; v = nd.a; return true; }
+      return false;
+    };
+    if (min_terms > 0 && !ir.outputs)
+      for (size_t h = nodes.size(); h-- > 0;) {
+        if (!ir.live[h] || absorbed[h] || nodes[h].op != DOP_ADD || !nodes[h].ext || uniform[h]) continue;
+        Dot d;
+        std::vector<uint32_t> inner, st{(uint32_t)h};
+        while (!st.empty()) {
+          const uint32_t x = st.back();
+          st.pop_back();
+          for (uint32_t c : {nodes[x].a, nodes[x].b}) {
+            uint32_t u, v;
+            if (nodes[c].op == DOP_ADD && nodes[c].ext && uses[c] == 1 && !uniform[c]) { inner.push_back(c); st.push_back(c); }
+            else if (is_term(c, u, v)) { inner.push_back(c); d.terms.push_back({u, v}); }
+            else d.others.push_back(c);
+          }
+        }
+        if ((int)d.terms.size() < min_terms) continue;
+        for (uint32_t x : inner) absorbed[x] = 1;
+        dot_of[h] = (int32_t)dots.size();
+        dots.push_back(std::move(d));
+      }
+  }
+  // the operands of a gate as the emitter sees them
+  auto ops = [&](uint32_t id, std::vector<uint32_t>& out) {
+    out.clear();
+    if (dot_of[id] >= 0) {
+      const Dot& d = dots[dot_of[id]];
+      for (uint32_t o : d.others) out.push_back(o);
+      for (auto& t : d.terms) { out.push_back(t.first); out.push_back(t.second); }
+      return;
+    }
+    out.push_back(nodes[id].a);
+    if (nodes[id].op != DOP_NEG) out.push_back(nodes[id].b);
+  };
   // ---- emission order: depth-first from each constraint in turn (a value is computed when first needed,
   // which keeps the cut sets between chunks small), the fold right after the constraint's node ----
   std::vector<Ev> seq;
   {
     std::vector<char> done(nodes.size(), 0);
-    std::vector<std::pair<uint32_t, int>> st;
+    std::vector<std::pair<uint32_t, size_t>> st;
+    std::vector<uint32_t> o;
     for (size_t k = 0; k < ir.cons.size(); k++) {
       const uint32_t root = ir.cons[k];
       if (interior(root) && !done[root]) st.push_back({root, 0});
       while (!st.empty()) {
-        auto& [id, phase] = st.back();
-        const DagNode& nd = nodes[id];
+        const uint32_t id = st.back().first;
         if (done[id]) { st.pop_back(); continue; }
-        if (phase == 0) {
-          phase = 1;
-          if (interior(nd.a) && !done[nd.a]) { st.push_back({nd.a, 0}); continue; }
+        ops(id, o);
+        bool pushed = false;
+        while (st.back().second < o.size()) {
+          const uint32_t c = o[st.back().second++];
+          if (interior(c) && !done[c]) { st.push_back({c, 0}); pushed = true; break; }
         }
-        if (phase == 1) {
-          phase = 2;
-          if (nd.op != DOP_NEG && interior(nd.b) && !done[nd.b]) { st.push_back({nd.b, 0}); continue; }
-        }
+        if (pushed) continue;
         done[id] = 1;
         seq.push_back({id, -1});
         st.pop_back();
@@ -296,6 +369,7 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
   auto cost = [&](const Ev& e) -> int {
     const DagNode& nd = nodes[e.node];
     if (e.fold_k >= 0) return nd.ext ? 3 : 2;
+    if (dot_of[e.node] >= 0) return 4 + (int)dots[dot_of[e.node]].terms.size();
     if (nd.op != DOP_MUL) return 1;
     const bool ea = nodes[nd.a].ext, eb = nodes[nd.b].ext;
     return ea && eb ? 4 : (ea || eb ? 2 : 1);
@@ -331,6 +405,7 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
   const int recomp_max = env_int("MH_JIT_RECOMP", 160);
   auto valu_cost = [&](uint32_t id) -> int {  // rough VALU instructions of one gate
     const DagNode& nd = nodes[id];
+    if (dot_of[id] >= 0) return 130 + 16 * (int)dots[dot_of[id]].terms.size() + 12 * (int)dots[dot_of[id]].others.size();
     const bool ea = nodes[nd.a].ext, eb = nd.op != DOP_NEG && nodes[nd.b].ext;
     if (nd.op == DOP_MUL) return ea && eb ? 80 : (ea || eb ? 44 : 22);
     return (ea || eb) ? 12 : 6;
@@ -364,20 +439,19 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
         stamp++;
         cone.clear();
         long cst = 0;
-        std::vector<std::pair<uint32_t, int>> dfs;
+        std::vector<std::pair<uint32_t, size_t>> dfs;
+        std::vector<uint32_t> o;
         dfs.push_back({u, 0});
         while (!dfs.empty()) {
-          auto& [id, ph] = dfs.back();
+          const uint32_t id = dfs.back().first;
           if (seen[id] == stamp) { dfs.pop_back(); continue; }
-          const DagNode& nd = nodes[id];
-          if (ph == 0) {
-            ph = 1;
-            if (interior(nd.a) && mat[nd.a] != (int32_t)ci && !spilled[nd.a] && seen[nd.a] != stamp) { dfs.push_back({nd.a, 0}); continue; }
+          ops(id, o);
+          bool pushed = false;
+          while (dfs.back().second < o.size()) {
+            const uint32_t c = o[dfs.back().second++];
+            if (interior(c) && mat[c] != (int32_t)ci && !spilled[c] && seen[c] != stamp) { dfs.push_back({c, 0}); pushed = true; break; }
           }
-          if (ph == 1) {
-            ph = 2;
-            if (nd.op != DOP_NEG && interior(nd.b) && mat[nd.b] != (int32_t)ci && !spilled[nd.b] && seen[nd.b] != stamp) { dfs.push_back({nd.b, 0}); continue; }
-          }
+          if (pushed) continue;
           seen[id] = stamp;
           cone.push_back(id);
           cst += valu_cost(id);
@@ -386,24 +460,24 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
         }
         if (cst > recomp_max) { load(u); return; }
         for (uint32_t id : cone) {
-          const DagNode& nd = nodes[id];
-          if (interior(nd.a) && mat[nd.a] != (int32_t)ci) load(nd.a);  // a spilled value inside the cone
-          if (nd.op != DOP_NEG && interior(nd.b) && mat[nd.b] != (int32_t)ci) load(nd.b);
+          ops(id, o);
+          for (uint32_t c : o)
+            if (interior(c) && mat[c] != (int32_t)ci) load(c);  // a spilled value inside the cone
           mat[id] = (int32_t)ci;
           items[ci].push_back({id, -1});
           n_recomputed++;
         }
       };
+      std::vector<uint32_t> opv;
       for (size_t i = chunks[ci].ev_lo; i < chunks[ci].ev_hi; i++) {
         const uint32_t id = seq[i].node;
-        const DagNode& nd = nodes[id];
         if (seq[i].fold_k >= 0) {
           ensure(id);
           items[ci].push_back({id, seq[i].fold_k});
           continue;
         }
-        ensure(nd.a);
-        if (nd.op != DOP_NEG) ensure(nd.b);
+        ops(id, opv);
+        for (uint32_t c : opv) ensure(c);
         mat[id] = (int32_t)ci;
         items[ci].push_back({id, -1});
       }
@@ -443,8 +517,10 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
     for (size_t ci = 0; ci < n_chunks; ci++)
       for (const Item& it : items[ci]) n_loads += it.fold_k == -2 ? (nodes[it.node].ext ? 2 : 1) : 0;
     for (size_t i = 0; i < nodes.size(); i++) n_stores += spilled[i] ? (nodes[i].ext ? 2 : 1) : 0;
-    fprintf(stderr, "[mh jit] %zu chunks, %zu gates, %zu recomputed, spill planes %zu, per point: %zu spill loads, %zu spill stores\n", n_chunks,
-            seq.size(), n_recomputed, n_spill, n_loads, n_stores);
+    size_t n_terms = 0;
+    for (const Dot& d : dots) n_terms += d.terms.size();
+    fprintf(stderr, "[mh jit] %zu chunks, %zu gates, %zu recomputed, spill planes %zu, per point: %zu spill loads, %zu spill stores; %zu dot gates with %zu terms\n",
+            n_chunks, seq.size(), n_recomputed, n_spill, n_loads, n_stores, dots.size(), n_terms);
   }
   // ---- source per chunk ----
   const bool lazy_loads = env_int("MH_JIT_LAZY", 1) != 0;
@@ -556,6 +632,25 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
         body << "#else\n";
         body << "  acc = e2_add(acc, " << (nd.ext ? "e2_mul(" : "e2_mulf(") << buf << ", " << x << "));\n";
         body << "#endif\n";
+        continue;
+      }
+      if (dot_of[id] >= 0) {
+        const Dot& d = dots[dot_of[id]];
+        body << "  fold_acc d" << id << "a = {0, 0, 0, 0, 0, 0}, d" << id << "b = {0, 0, 0, 0, 0, 0};\n";
+        for (auto& t : d.terms) {
+          const std::string U = ref(t.first), Bv = ref(t.second);
+          body << "  { const e2 cu = " << U << "; const u64 cb = " << Bv << "; fold_limbs(d" << id << "a, cu.c0, cb); fold_limbs(d" << id
+               << "b, cu.c1, cb); }\n";
+        }
+        std::string rhs = "e2{fold_value(d" + std::to_string(id) + "a), fold_value(d" + std::to_string(id) + "b)}";
+        for (uint32_t o : d.others) {
+          const std::string O = ref(o);
+          rhs = (nodes[o].ext ? "e2_add(" : "e2_addf(") + rhs + ", " + O + ")";
+        }
+        body << "  const e2 v" << id << " = " << rhs << ";\n";
+        if (spilled[id] && def_chunk[id] == (int32_t)ci)
+          body << "  a.spill[" << slot[id] << "ull * a.spill_stride + qb] = v" << id << ".c0; a.spill[" << slot[id] + 1
+               << "ull * a.spill_stride + qb] = v" << id << ".c1;\n";
         continue;
       }
       const std::string A = ref(nd.a);
