@@ -173,3 +173,48 @@ def test_keccak_session_production_params_80_permutations(ctx):
     ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, preprocessed_root=root,
                           external=PA.external_assertions(pkg))
     assert ok2 and (dig == got.digest).all()
+
+
+# ---- traces built on the device: nothing but 200 bytes per permutation crosses PCIe -------------------------------------------------
+def test_keccak_session_from_device_built_traces(ctx):
+    """examples/keccak_trace_device.hip (a client-side GPU trace generator: the three-address machine, one thread per permutation, the
+    byte-pair ledger as 64-bit atomics) builds the Keccak chiplet's and the table's main traces in HBM; `mh_trace_from_device` hands them
+    over.  They equal the host generator's matrices cell for cell, and the session's proof equals the proof from uploaded traces."""
+    import ctypes as C, os
+    pkg = load_package()
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "libkeccak_trace_device.so")
+    if not os.path.exists(so):
+        pytest.fail("examples/libkeccak_trace_device.so is missing: run __graft_entry__.build()")
+    kt = C.CDLL(so)
+    airs_, lookups, traces = keccak_session(7)   # 4 + 3 permutations in the two lanes
+    rng = np.random.default_rng(11)
+    states = np.array([[0] * 25] + [[int(x) for x in rng.integers(0, 1 << 63, 25)] for _ in range(6)], dtype=np.uint64)
+    program = np.array([[op, sh, ba, bb, m] for (op, sh, ba, bb, m) in PA.keccak_round_slots()], dtype=np.int32)
+    rcs = np.array(PA.KECCAK_RC, dtype=np.uint64)
+    tr_dev, cnt_dev, mem_dev, lg = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()
+    rc = kt.kt_keccak_round_trace(states.ctypes.data_as(C.c_void_p), C.c_int(7), rcs.ctypes.data_as(C.c_void_p), program.ctypes.data_as(C.c_void_p),
+                                  C.byref(tr_dev), C.byref(lg), C.byref(cnt_dev), C.byref(mem_dev))
+    assert rc == 0
+    try:
+        assert lg.value == 14
+        t_kr = pkg.Trace.from_device(ctx, tr_dev.value, lg.value, PA.KR_MAIN_COLS)
+        t_bpl = pkg.Trace.from_device(ctx, cnt_dev.value, 16, 3)
+        assert (t_kr.download() == traces[0]).all()
+        assert (t_bpl.download() == traces[1]).all()
+        # the machine's outputs are Keccak-f of the inputs
+        mem = np.zeros((7, 25 + 3200), dtype=np.uint64)
+        assert kt.kt_download(mem.ctypes.data_as(C.c_void_p), mem_dev, C.c_size_t(mem.size)) == 0
+        for n in range(7):
+            assert PA.keccak_round_outputs(mem, n) == PA.keccak_f_reference([int(x) for x in states[n]])
+        got_host, root, st, pre = device_prove(ctx, airs_, lookups, traces, FAST)
+        dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+        raw = ctx.upload_trace(airs_[1].preprocessed)
+        com = pkg.commit_traces(ctx, [raw], FAST["log_blowup"])
+        dairs[1].attach_preprocessed(com.tree(), 0, raw=raw)
+        for d, lk in zip(dairs, lookups):
+            d.attach_lookup(pkg.DeviceLookup(ctx, lk))
+        got = pkg.prove(ctx, dairs, [t_kr, t_bpl, ctx.upload_trace(traces[2]), ctx.upload_trace(traces[3])], ROOT, FAST, st, pre, never)
+        assert (got.digest == got_host.digest).all() and (got.fields == got_host.fields).all()
+    finally:
+        for p_ in (tr_dev, cnt_dev, mem_dev):
+            kt.kt_free(p_)
