@@ -89,6 +89,16 @@ __global__ void k_keccak_round_ip(u64* trace, size_t height, int perms_per_lane)
     trace[r * (LANE_WIDTH * NUM_LANES) + lane * LANE_WIDTH + COL_IP] = IP_BOUNDARY + (u64)lane * perms_per_lane * PERM_CYCLE + r;
 }
 
+// buffers of one call: freed again when the call fails half way
+struct KtBuffers {
+  u64 *mem = nullptr, *tr = nullptr, *cnt = nullptr, *st = nullptr, *rc = nullptr;
+  bool keep = false;
+  ~KtBuffers() {
+    (void)hipFree(st);
+    (void)hipFree(rc);
+    if (!keep) { (void)hipFree(mem); (void)hipFree(tr); (void)hipFree(cnt); }
+  }
+};
 #define KT_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 extern "C" {
@@ -105,24 +115,23 @@ int kt_keccak_round_trace(const uint64_t* states, int n_perms, const uint64_t* r
   while (height < (size_t)ppl * PERM_CYCLE) { height <<= 1; lg++; }
   Program prog;
   for (int i = 0; i < ROUND_PERIOD; i++) prog.s[i] = Slot{program[5 * i], program[5 * i + 1], program[5 * i + 2], program[5 * i + 3], program[5 * i + 4]};
-  u64 *mem = nullptr, *tr = nullptr, *cnt = nullptr, *st_dev = nullptr, *rc_dev = nullptr;
-  KT_CHECK(hipMalloc(&mem, (size_t)MEM_WORDS * n_perms * 8));
-  KT_CHECK(hipMalloc(&tr, height * LANE_WIDTH * NUM_LANES * 8));
-  KT_CHECK(hipMalloc(&cnt, (size_t)65536 * 3 * 8));
-  KT_CHECK(hipMalloc(&st_dev, (size_t)25 * n_perms * 8));
-  KT_CHECK(hipMalloc(&rc_dev, (size_t)NUM_ROUNDS * 8));
-  KT_CHECK(hipMemset(tr, 0, height * LANE_WIDTH * NUM_LANES * 8));
-  KT_CHECK(hipMemset(cnt, 0, (size_t)65536 * 3 * 8));
+  KtBuffers b;
+  KT_CHECK(hipMalloc(&b.mem, (size_t)MEM_WORDS * n_perms * 8));
+  KT_CHECK(hipMalloc(&b.tr, height * LANE_WIDTH * NUM_LANES * 8));
+  KT_CHECK(hipMalloc(&b.cnt, (size_t)65536 * 3 * 8));
+  KT_CHECK(hipMalloc(&b.st, (size_t)25 * n_perms * 8));
+  KT_CHECK(hipMalloc(&b.rc, (size_t)NUM_ROUNDS * 8));
+  KT_CHECK(hipMemset(b.tr, 0, height * LANE_WIDTH * NUM_LANES * 8));
+  KT_CHECK(hipMemset(b.cnt, 0, (size_t)65536 * 3 * 8));
   // the only host data: 25 lanes per permutation and the round constants
-  KT_CHECK(hipMemcpy(st_dev, states, (size_t)25 * n_perms * 8, hipMemcpyHostToDevice));
-  KT_CHECK(hipMemcpy(rc_dev, rcs, (size_t)NUM_ROUNDS * 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_keccak_round_ip, dim3((unsigned)((height + 255) / 256)), dim3(256), 0, 0, tr, height, ppl);
-  hipLaunchKernelGGL(k_keccak_round_trace, dim3((unsigned)n_perms), dim3(64), 0, 0, prog, st_dev, rc_dev, mem, n_perms, ppl, tr, cnt);
+  KT_CHECK(hipMemcpy(b.st, states, (size_t)25 * n_perms * 8, hipMemcpyHostToDevice));
+  KT_CHECK(hipMemcpy(b.rc, rcs, (size_t)NUM_ROUNDS * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_keccak_round_ip, dim3((unsigned)((height + 255) / 256)), dim3(256), 0, 0, b.tr, height, ppl);
+  hipLaunchKernelGGL(k_keccak_round_trace, dim3((unsigned)n_perms), dim3(64), 0, 0, prog, b.st, b.rc, b.mem, n_perms, ppl, b.tr, b.cnt);
   KT_CHECK(hipGetLastError());
   KT_CHECK(hipDeviceSynchronize());
-  (void)hipFree(st_dev);
-  (void)hipFree(rc_dev);
-  *trace_dev = (uint64_t*)tr; *log_n = lg; *counts_dev = (uint64_t*)cnt; *memory_dev = (uint64_t*)mem;
+  b.keep = true;
+  *trace_dev = (uint64_t*)b.tr; *log_n = lg; *counts_dev = (uint64_t*)b.cnt; *memory_dev = (uint64_t*)b.mem;
   return 0;
 }
 int kt_download(uint64_t* dst, const uint64_t* src_dev, size_t words) { return (int)hipMemcpy(dst, src_dev, words * 8, hipMemcpyDeviceToHost); }

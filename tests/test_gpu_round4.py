@@ -250,3 +250,36 @@ def test_real_miden_statement_production_params(ctx, fast_oracle):
     lhs = [int(t.shape[0]).bit_length() - 1 for t in traces]
     ok, dig = pkg.verify(airs_, lhs, pub, prm, stt, pre, got.fields, got.commitments, external=MS.external_assertions(pkg, pub, aux_inputs))
     assert ok, dig
+
+
+# ---- the generator's switches change the code, never the proof ----------------------------------------------------------------------
+GEN_SWITCHES = [{}, {"MH_JIT_RECOMP": "0"}, {"MH_JIT_RECOMP": "1000", "MH_JIT_CHUNK": "120"}, {"MH_JIT_LAZY": "0"}, {"MH_JIT_DOT": "0"},
+                {"MH_JIT_DOT": "2"}, {"MH_JIT_FLAGS": "-DMH_JIT_FOLD=0"}, {"MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=0"},
+                {"MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=1"}]
+
+
+@pytest.mark.parametrize("env", GEN_SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "defaults")
+def test_generator_switches_are_bit_exact(ctx, env, monkeypatch, tmp_path):
+    """csrc/air_jit.cpp: recompute-or-spill, loads at first use, delayed-reduction fold, dot gates, the asm product -- every combination
+    evaluates the same constraint values: the ChipletsAir proof (compiled chunks, aux from the derived lookup program) equals the
+    interpreter's field for field.  A fresh cache directory per case: the kernels are compiled here, on the box."""
+    pkg = load_package()
+    air, _ = CA.chiplets_air(num_public=0)
+    lookup = dag.lookup_from_constraints(air.blob)
+    trace, _ = CT.bulk_chiplets(10, 10, seed=4)
+    prm, st = dict(FAST), protocol.challenger_state()
+    pre = protocol.protocol_pre_observe(prm, [])
+
+    def prove():
+        dair = pkg.DeviceAir(ctx, air)
+        dair.attach_lookup(pkg.DeviceLookup(ctx, lookup))
+        return dair, pkg.prove(ctx, [dair], [ctx.upload_trace(trace)], [], prm, st, pre, never)
+    monkeypatch.setenv("MH_JIT", "0")
+    _, ref = prove()
+    monkeypatch.setenv("MH_JIT", "1")
+    monkeypatch.setenv("MH_JIT_CACHE_DIR", str(tmp_path))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    dair, got = prove()
+    assert dair.compiled_chunks >= 2
+    assert (got.fields == ref.fields).all() and (got.commitments == ref.commitments).all() and (got.digest == ref.digest).all()

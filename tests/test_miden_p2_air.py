@@ -211,3 +211,21 @@ def test_committed_blobs_are_current():
     assert (dag_words == air.blob).all() and (lkp_words == lookup.blob).all(), "run tools/export_p2_air.py"
     parsed = dag.parse_air_blob(dag_words)
     assert parsed["main_width"] == 16 and parsed["aux_width"] == 1 and len(parsed["constraints"]) == 61 and len(parsed["periodic"]) == 16
+
+
+# ---- the constraint-kernel generator's switches (csrc/air_jit.cpp) keep producing code that compiles ---------------------------------
+JIT_SWITCHES = [{}, {"MH_JIT_RECOMP": "0"}, {"MH_JIT_RECOMP": "1000", "MH_JIT_CHUNK": "120"}, {"MH_JIT_LAZY": "0"}, {"MH_JIT_DOT": "0"},
+                {"MH_JIT_DOT": "2"}, {"MH_JIT_FLAGS": "-DMH_JIT_FOLD=0"}, {"MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=0"},
+                {"MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=1"}, {"MH_JIT_FLAGS": "-DMH_JIT_WAVES=3"}]
+
+
+@pytest.mark.parametrize("env", JIT_SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "defaults")
+def test_generator_switches_compile_offline(env, tmp_path, monkeypatch):
+    """mh_jit_precompile (hiprtc for gfx950, no GPU) of this AIR's chunks under every generator switch: recompute-or-spill threshold,
+    chunk budget, loads at the top / at first use, dot gates, the per-constraint fold, the three forms of the product, an occupancy
+    target.  (That they all give the SAME proof is tests/test_gpu_round4.py::test_generator_switches_are_bit_exact.)"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    air, _ = MA.poseidon2_permutation_air()
+    n = load_package().jit_precompile(air.blob, str(tmp_path))
+    assert n >= 2 and len(os.listdir(str(tmp_path))) == n
