@@ -94,10 +94,10 @@ FI e2 e2_mul(e2 a, e2 b) {
   return {gl_add(a0b0, gl_mul7(a1b1)), gl_sub(gl_sub(cross, a0b0), a1b1)};
 }
 FI e2 e2_mulf(e2 a, u64 b) { return {gl_mul_ef(a.c0, b), gl_mul_ef(a.c1, b)}; }
-// The alpha fold with the modular reduction delayed to the end of the chunk: alpha^k is uniform, so it is cut into 16-bit limbs
-// (scalar unit), a constraint value into 32-bit halves, and the 48-bit partial products are summed by weight 2^(16 j) in plain 64-bit
-// accumulators -- 8 v_mad_u64_u32 per (base value, alpha component) instead of a modular multiplication and a modular addition;
-// < 2^14 folds per chunk keep every accumulator below 2^64.  MH_JIT_FOLD=0 (flag) selects the former per-constraint form.
+// The alpha fold with the modular reduction delayed to the end of the chunk: alpha^k is uniform, so it is cut into three 22-bit limbs
+// (scalar unit), a constraint value into 32-bit halves, and the 54-bit partial products are summed by weight in six plain 64-bit
+// accumulators -- 6 v_mad_u64_u32 per (base value, alpha component) instead of a modular multiplication and a modular addition;
+// < 2^9 folds per chunk keep every accumulator below 2^64.  MH_JIT_FOLD=0 (flag) selects the former per-constraint form.
 #ifndef MH_JIT_FOLD
 #define MH_JIT_FOLD 1
 #endif
@@ -109,19 +109,19 @@ FI void fold_mad(u64& acc, u32 a, u32 x) {
   asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "s"(a), "v"(x), "v"(acc));
   acc = d;
 }
-FI void fold_limbs(fold_acc& f, u64 alpha, u64 x) {
+FI void fold_limbs(fold_acc& f, u64 alpha, u64 x) {  // three 22-bit limbs of alpha x two 32-bit halves of x: 54-bit products
   const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
-  const u32 a0 = (u32)alpha & 0xffffu, a1 = ((u32)alpha) >> 16, a2 = (u32)(alpha >> 32) & 0xffffu, a3 = (u32)(alpha >> 48);
-  fold_mad(f.w0, a0, x0); fold_mad(f.w1, a1, x0); fold_mad(f.w2, a2, x0); fold_mad(f.w3, a3, x0);
-  fold_mad(f.w2, a0, x1); fold_mad(f.w3, a1, x1); fold_mad(f.w4, a2, x1); fold_mad(f.w5, a3, x1);
+  const u32 a0 = (u32)alpha & 0x3fffffu, a1 = (u32)(alpha >> 22) & 0x3fffffu, a2 = (u32)(alpha >> 44);
+  fold_mad(f.w0, a0, x0); fold_mad(f.w1, a1, x0); fold_mad(f.w2, a2, x0);
+  fold_mad(f.w3, a0, x1); fold_mad(f.w4, a1, x1); fold_mad(f.w5, a2, x1);
 }
-FI u64 fold_value(const fold_acc& f) {  // sum_j w_j 2^(16 j) mod p, canonical
+FI u64 fold_value(const fold_acc& f) {  // w0 + 2^22 w1 + 2^44 w2 + 2^32 w3 + 2^54 w4 + 2^76 w5 mod p, canonical
   u64 r = gl_reduce128(0, f.w0);
-  r = gl_add(r, gl_reduce128(f.w1 >> 48, f.w1 << 16));
-  r = gl_add(r, gl_reduce128(f.w2 >> 32, f.w2 << 32));
-  r = gl_add(r, gl_reduce128(f.w3 >> 16, f.w3 << 48));
-  r = gl_add(r, gl_reduce128(f.w4, 0));
-  r = gl_add(r, gl_mul_c(gl_reduce128(f.w5 >> 48, f.w5 << 16), GL_EPS));  // 2^80 = 2^16 * (2^64 mod p)
+  r = gl_add(r, gl_reduce128(f.w1 >> 42, f.w1 << 22));
+  r = gl_add(r, gl_reduce128(f.w2 >> 20, f.w2 << 44));
+  r = gl_add(r, gl_reduce128(f.w3 >> 32, f.w3 << 32));
+  r = gl_add(r, gl_reduce128(f.w4 >> 10, f.w4 << 54));
+  r = gl_add(r, gl_mul_c(gl_reduce128(0, f.w5), GL_EPS << 12));  // 2^76 = 2^12 (2^64 mod p)
   return r;
 }
 struct JitArgs {
@@ -272,7 +272,7 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
 
   // ---- sums of (uniform EF coefficient) x (base value): LogUp message encodings `prefix + sum_i beta^i f_i` ----
   // The coefficients depend on challenges, constants and public values only -- the same for every point --, so such a sum is the
-  // alpha fold's pattern: the coefficient is cut into 16-bit limbs on the scalar unit, the value into 32-bit halves, 8 v_mad_u64_u32
+  // alpha fold's pattern: the coefficient is cut into 22-bit limbs on the scalar unit, the value into 32-bit halves, 6 v_mad_u64_u32
   // per (term, component) into weight accumulators and ONE reduction per sum, instead of two modular products and two modular
   // additions per term (72 VALU instructions -> 16, + ~130 per sum).  An EF ADD tree (through single-use ADD nodes) with at least
   // $MH_JIT_DOT (default 3, 0 = off) such terms becomes one "dot" gate: its operands are the terms' (coefficient, value) pairs and the
@@ -320,7 +320,7 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
             else d.others.push_back(c);
           }
         }
-        if ((int)d.terms.size() < min_terms) continue;
+        if ((int)d.terms.size() < min_terms || d.terms.size() > 400) continue;  // <= 2^9 products of < 2^54 per accumulator
         for (uint32_t x : inner) absorbed[x] = 1;
         dot_of[h] = (int32_t)dots.size();
         dots.push_back(std::move(d));
@@ -596,6 +596,7 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
       return buf;  // computed, recomputed or loaded earlier in this chunk (items)
     };
     bool any_fold = false;
+    int fold_terms = 0;
     for (const Item& it : items[ci]) {
       const uint32_t id = it.node;
       const DagNode& nd = nodes[id];
@@ -629,6 +630,11 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
         else
           body << "  fold_limbs(f0, a.alpha_pows[" << 2 * it.fold_k << "], " << x << "); fold_limbs(f1, a.alpha_pows[" << 2 * it.fold_k + 1
                << "], " << x << ");\n";
+        fold_terms += nd.ext ? 2 : 1;
+        if (fold_terms >= 400) {  // keep every accumulator below 2^64: <= 2^9 products of < 2^54 between two reductions
+          body << "  acc = e2_add(acc, e2{fold_value(f0), fold_value(f1)}); f0 = {0, 0, 0, 0, 0, 0}; f1 = {0, 0, 0, 0, 0, 0};\n";
+          fold_terms = 0;
+        }
         body << "#else\n";
         body << "  acc = e2_add(acc, " << (nd.ext ? "e2_mul(" : "e2_mulf(") << buf << ", " << x << "));\n";
         body << "#endif\n";
@@ -700,7 +706,7 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
       src << "  const u64 sel_first = gl_mul(a.coset_tab[Dl + t], a.inv_first[q]);\n"
              "  const u64 sel_last = gl_mul(a.coset_tab[Dl + t], a.inv_last[q]);\n";
     src << "  e2 acc = {0, 0}; (void)acc;\n  fold_acc f0 = {0, 0, 0, 0, 0, 0}, f1 = {0, 0, 0, 0, 0, 0}; (void)f0; (void)f1;\n" << decl.str() << body.str();
-    if (!ir.outputs && any_fold) src << "#if MH_JIT_FOLD\n  acc = {fold_value(f0), fold_value(f1)};\n#endif\n";
+    if (!ir.outputs && any_fold) src << "#if MH_JIT_FOLD\n  acc = e2_add(acc, e2{fold_value(f0), fold_value(f1)});\n#endif\n";
     if (!ir.outputs && (any_fold || ci == 0)) {
       src << "  u64* p0 = a.acc + (((2 * t) << a.log_n) + r);\n  u64* p1 = a.acc + (((2 * t + 1) << a.log_n) + r);\n";
       if (ci == 0) src << "  *p0 = acc.c0; *p1 = acc.c1;\n";

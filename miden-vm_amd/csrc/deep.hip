@@ -219,9 +219,10 @@ __global__ __launch_bounds__(256) void k_deep_assemble(DeepArgs a) {
 #pragma unroll
   for (int k = 0; k < DEEP_PTS; k++) r[k] = base + (size_t)k * 256;
   // neg[k] = sum over columns of cf_col * v_col(r[k]) with the modular reduction DELAYED: cf (uniform, EF) is cut
-  // into 16-bit limbs, v into 32-bit halves, and the 48-bit partial products are summed by weight
-  // 2^0, 2^16, .., 2^80 in plain 64-bit accumulators (one v_mad_u64_u32 each, no carries); one reduction per
-  // <= DEEP_FLUSH columns.  16 multiply-adds per (column, point) instead of two modular multiplications.
+  // into THREE 22-bit limbs, v into 32-bit halves, and the 54-bit partial products are summed by weight
+  // 2^0, 2^22, 2^44 (x v.lo) and 2^32, 2^54, 2^76 (x v.hi) in plain 64-bit accumulators (one v_mad_u64_u32 each, no
+  // carries); one reduction per <= DEEP_FLUSH columns.  12 multiply-adds per (column, point) instead of two modular
+  // multiplications (16 with the four 16-bit limbs of rounds 2-3: the kernel is bound by these mads).
   e2 neg[DEEP_PTS];
   u64 w[DEEP_PTS][2][6];
 #pragma unroll
@@ -233,10 +234,11 @@ __global__ __launch_bounds__(256) void k_deep_assemble(DeepArgs a) {
       for (int i = 0; i < 6; i++) w[k][e][i] = 0;
   }
   auto flush = [&]() {
-    const u64 C[6] = {1ULL, 1ULL << 16, 1ULL << 32, 1ULL << 48, GL_EPS, GL_EPS << 16};  // 2^(16 i) mod p
+    // weights of the six accumulators mod p: 2^0, 2^22, 2^44, 2^32, 2^54, 2^76 = 2^12 (2^32 - 1)
+    const u64 C[6] = {1ULL, 1ULL << 22, 1ULL << 44, 1ULL << 32, 1ULL << 54, GL_EPS << 12};
 #pragma unroll
     for (int k = 0; k < DEEP_PTS; k++) {
-      u64 s0 = w[k][0][0], s1 = w[k][1][0];  // < 2^57: canonical
+      u64 s0 = w[k][0][0], s1 = w[k][1][0];  // < 2^61: canonical
 #pragma unroll
       for (int i = 1; i < 6; i++) {
         s0 = gl_add(s0, gl_mul(w[k][0][i], C[i]));
@@ -259,11 +261,11 @@ __global__ __launch_bounds__(256) void k_deep_assemble(DeepArgs a) {
 #pragma unroll DEEP_UNROLL
     for (u32 cidx = 0; cidx < m.width; cidx++) {
       const u64 cf0 = a.negc[2 * (m.coef_off + cidx)], cf1 = a.negc[2 * (m.coef_off + cidx) + 1];
-      u32 al[2][4];
+      u32 al[2][3];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        al[0][i] = (u32)(cf0 >> (16 * i)) & 0xFFFFu;
-        al[1][i] = (u32)(cf1 >> (16 * i)) & 0xFFFFu;
+      for (int i = 0; i < 3; i++) {
+        al[0][i] = (u32)(cf0 >> (22 * i)) & 0x3FFFFFu;
+        al[1][i] = (u32)(cf1 >> (22 * i)) & 0x3FFFFFu;
       }
 #pragma unroll
       for (int k = 0; k < DEEP_PTS; k++) {
@@ -275,16 +277,14 @@ __global__ __launch_bounds__(256) void k_deep_assemble(DeepArgs a) {
             w[k][e][0] += (u64)al[e][0] * v0;
             w[k][e][1] += (u64)al[e][1] * v0;
             w[k][e][2] += (u64)al[e][2] * v0;
-            w[k][e][3] += (u64)al[e][3] * v0;
-            w[k][e][2] += (u64)al[e][0] * v1;
-            w[k][e][3] += (u64)al[e][1] * v1;
-            w[k][e][4] += (u64)al[e][2] * v1;
-            w[k][e][5] += (u64)al[e][3] * v1;
+            w[k][e][3] += (u64)al[e][0] * v1;
+            w[k][e][4] += (u64)al[e][1] * v1;
+            w[k][e][5] += (u64)al[e][2] * v1;
           }
         }
       }
       colp += cstride;
-      if (++pending == DEEP_FLUSH) {  // 2 * DEEP_FLUSH products of < 2^48 per accumulator stay below 2^57
+      if (++pending == DEEP_FLUSH) {  // DEEP_FLUSH products of < 2^54 per accumulator stay below 2^61
         flush();
         pending = 0;
       }
