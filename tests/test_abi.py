@@ -65,3 +65,15 @@ def test_configuration_ids_agree_everywhere():
     from miden_vm_amd import protocol
     assert set(protocol.HashFunction.LMCS.values()) == set(pkg.Ctx.LMCS)
     assert protocol.HashFunction.LMCS[protocol.ProvingOptions().hash_fn()] == "blake3"
+
+
+def test_example_trace_generator_exports_its_entry_points():
+    """examples/libkeccak_trace_device.so (built by __graft_entry__.build(): a client-side GPU trace generator over the public C ABI)
+    loads without a GPU and exports what tests/test_gpu_precompile.py and bench.py call."""
+    import ctypes
+    so = os.path.join(ROOT, "examples", "libkeccak_trace_device.so")
+    if not os.path.exists(so):
+        pytest.skip("examples/ not built (run __graft_entry__.build())")
+    lib = ctypes.CDLL(so)
+    for sym in ("kt_keccak_round_trace", "kt_download", "kt_free"):
+        assert hasattr(lib, sym), sym

@@ -218,3 +218,20 @@ def test_keccak_session_from_device_built_traces(ctx):
     finally:
         for p_ in (tr_dev, cnt_dev, mem_dev):
             kt.kt_free(p_)
+
+
+def test_keccak_session_production_params_equals_oracle(ctx):
+    """The second client at `precompile_pcs_params()` (27 queries, PoW 4 / 12 / 16): device transcript == oracle transcript field for
+    field (the optimised oracle build; three permutations + the full table)."""
+    ob.use_fast_library(True)
+    try:
+        airs_, lookups, traces = keccak_session(3)
+        prm = dict(protocol.PROD_PARAMS)
+        exp = ob.prove(airs_, traces, ROOT, prm, init_state=protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST))
+        got, root, st, pre = device_prove(ctx, airs_, lookups, traces, prm)
+        assert list(root) == [int(x) for x in exp["preprocessed_root"]]
+        assert (got.commitments == exp["commitments"]).all()
+        assert got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all()
+        assert (got.digest == exp["digest"]).all()
+    finally:
+        ob.use_fast_library(False)
