@@ -3,8 +3,12 @@
 // The interpreter (quotient.hip) re-reads every trace cell each time a gate uses it; for a Miden-sized
 // system (thousands of gates over ~130 cells) that is megabytes of L2 traffic per wavefront.  Compiled
 // code keeps cells and intermediates in VGPRs.  One kernel per CHUNK of the DAG (a few hundred gates:
-// the compiler's time is super-linear in the size of a straight-line block); values that cross a chunk
-// boundary go through an HBM spill area, the alpha-fold is accumulated in the quotient buffer itself.
+// the compiler's time is super-linear in the size of a straight-line block); a value that crosses a chunk
+// boundary is recomputed in the reading chunk when its cone is cheap and goes through an HBM spill plane
+// otherwise; cells are loaded where first used; the alpha-fold and the sums of (uniform EF coefficient) x
+// (base value) of LogUp message encodings run through limb accumulators with one reduction per chunk /
+// sum; base-field products use the 13-instruction asm form.  The partial folds are accumulated in the
+// quotient buffer itself.  (DESIGN.md section 3c has the measurements behind each of these.)
 // Replaces, like the interpreter, `air.eval(&mut ProverConstraintFolder)` of
 // crates/lifted-stark/src/prover/constraints/mod.rs:244-246 + folder.rs:88-105.
 #pragma once
