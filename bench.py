@@ -884,6 +884,12 @@ def main():
                 out["miden_real_blake3"] = miden_real_probe(pkg, c3, inputs=real_inputs, lmcs="blake3")
             finally:
                 c3.close()
+            # BASELINE.json configs[0]: a ~2^16-row program, the reference's own CPU-runnable case, as a latency
+            # point of the real statement: 575 iterations of the same loop body = 2^16 core rows
+            small = _ct.prove_inputs(_ct.CoreVM(stack_inputs=list(range(16))), _ct.bench_program(575))
+            r16 = miden_real_probe(pkg, ctx, inputs=small, steps=5)
+            out["miden_real_2p16"] = {k: r16[k] for k in ("log_trace_heights", "ms_per_proof", "rows_per_s", "h2d_inclusive_ms", "proof_bytes",
+                                                           "verifies_with_eval_external", "kernels_ms")}
         except Exception as e:
             out["miden_real"] = {"error": repr(e)[:300]}
         try:
