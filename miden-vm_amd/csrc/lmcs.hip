@@ -21,6 +21,7 @@
 #include "kernels.hpp"
 #include "poseidon2_fast.cuh"
 #include "poseidon2_lanes.cuh"
+#include "poseidon2_quad.cuh"
 #include "blake3.cuh"
 #include "keccak.cuh"
 #define RESCUE_FAST 1  // S-boxes through p2f_mulN (poseidon2_fast.cuh is included above)
@@ -420,6 +421,42 @@ __global__ __launch_bounds__(256) void k_compress_lanes(const u64* __restrict__ 
   if (active && g < 4) out[4 * q + g] = s;
 }
 
+// The same compression with four lanes per node (three state elements per lane, poseidon2_quad.cuh): 16 nodes per wave, for the
+// levels between the 16-lane form (latency-optimal below ~2^13 nodes) and the state-per-lane form (throughput-optimal above ~2^15).
+static size_t compress_quad_min_nodes() {
+  static const size_t v = [] {
+    const char* e = getenv("MH_QUAD_MIN_NODES");  // experiments (measured: 2^14 .. 2^15 is where it pays, tools/exp_quad.sh)
+    return e ? (size_t)atol(e) : (size_t)16384;
+  }();
+  return v;
+}
+static size_t compress_quad_max_nodes() {
+  static const size_t v = [] {
+    const char* e = getenv("MH_QUAD_MAX_NODES");  // experiments; 0 disables the form
+    return e ? (size_t)atol(e) : (size_t)32768;
+  }();
+  return v;
+}
+__global__ __launch_bounds__(256) void k_compress_quad(const u64* __restrict__ in, u64* __restrict__ out, size_t n_out, int log_n_coset) {
+  const size_t node = (blockIdx.x * (size_t)256 + threadIdx.x) >> 2;
+  const int j = threadIdx.x & 3;
+  const bool active = node < n_out;
+  const size_t q = active ? node : 0;  // idle quads recompute node 0 (keeps every wave converged)
+  size_t l, rgt;
+  if (log_n_coset >= 0) {
+    const size_t N = (size_t)1 << log_n_coset;
+    const size_t jp = q >> log_n_coset, r = q & (N - 1);
+    l = ((2 * jp) << log_n_coset) + r;
+    rgt = l + N;
+  } else {
+    l = 2 * q;
+    rgt = l + 1;
+  }
+  u64 s[3] = {in[4 * l + j], in[4 * rgt + j], 0};  // elements j (left digest), 4 + j (right digest), 8 + j (capacity)
+  p2q_permute(s);
+  if (active) out[4 * q + j] = s[0];
+}
+
 void lmcs_alloc_layers(mh_tree* t, int log_height) {
   t->log_height = log_height;
   // layers: depth L (H nodes) first, then L-1, ..., 0
@@ -473,6 +510,9 @@ void lmcs_compress_layers(mh_ctx* c, mh_tree* t) {
         break;  // that launch went down to the root
       } else if (c->lmcs == MH_LMCS_BLAKE3)
         MH_LAUNCH(k_compress_b3, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream,
+                           t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
+      else if (n_out >= compress_quad_min_nodes() && n_out <= compress_quad_max_nodes())
+        MH_LAUNCH(k_compress_quad, dim3((unsigned)((n_out * 4 + 255) / 256)), dim3(256), 0, c->stream,
                            t->nodes.u() + 4 * t->layer_off[d + 1], t->nodes.u() + 4 * t->layer_off[d], n_out, log_n_coset);
       else if (n_out <= compress_lanes_max_nodes())
         MH_LAUNCH(k_compress_lanes, dim3((unsigned)((n_out * 16 + 255) / 256)), dim3(256), 0, c->stream,
