@@ -77,6 +77,7 @@ def test_lde_is_extension_of_trace(ctx):
     ([(5, 9), (7, 22), (8, 51)], 3),
     ([(10, 51)], 3),
     ([(4, 16), (6, 8)], 4),
+    ([(14, 3)], 3),  # 2^17 leaves: every compression form in one tree (state per lane, four lanes per state at 2^15 / 2^14, sixteen lanes, host)
 ])
 def test_commit_traces_root_layers_openings(ctx, shapes, lb):
     pkg = load_package()
