@@ -1,5 +1,5 @@
-import sys, json
-sys.path.insert(0,'/root/repo')
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from __graft_entry__ import load_package
 pkg=load_package()
