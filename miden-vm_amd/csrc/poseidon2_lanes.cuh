@@ -27,8 +27,9 @@ __device__ __forceinline__ u64 p2l_dpp(u64 v) {
 #define P2L_ROW_BCAST0 0x150
 
 // out_g = (circ(2*M4, M4, M4) * s)_g + rc_g, folded to 64 bits.  g = element index (lanes 12..15 of the
-// group idle but execute), grp0 = first lane of the 16-lane group.
-__device__ __forceinline__ u64 p2l_external(u64 s, int g, const unsigned long long* rc) {
+// group idle but execute), c = this lane's round constant (RC = false: none).
+template <bool RC>
+__device__ __forceinline__ u64 p2l_external(u64 s, int g, u64 c) {
   // lane k of a quad reads lanes k+1, k+2, k+3 (mod 4)
   const u64 x1 = p2l_dpp<P2L_QUAD(1, 2, 3, 0)>(s), x2 = p2l_dpp<P2L_QUAD(2, 3, 0, 1)>(s), x3 = p2l_dpp<P2L_QUAD(3, 0, 1, 2)>(s);
   // row k of M4 = [2, 3, 1, 1] rotated: 2*x_k + 3*x_{k+1} + x_{k+2} + x_{k+3}
@@ -39,8 +40,7 @@ __device__ __forceinline__ u64 p2l_external(u64 s, int g, const unsigned long lo
   const u64 sL = oL + p2l_dpp<P2L_ROW_ROR(4)>(oL) + p2l_dpp<P2L_ROW_ROR(8)>(oL) + p2l_dpp<P2L_ROW_ROR(12)>(oL);
   const u64 sH = oH + p2l_dpp<P2L_ROW_ROR(4)>(oH) + p2l_dpp<P2L_ROW_ROR(8)>(oH) + p2l_dpp<P2L_ROW_ROR(12)>(oH);
   u64 L = oL + sL, H = oH + sH;
-  if (rc) {
-    const u64 c = rc[g < 12 ? g : 0];
+  if (RC) {
     L += c & 0xFFFFFFFFULL;
     H += c >> 32;
   }
@@ -50,58 +50,76 @@ __device__ __forceinline__ u64 p2l_external(u64 s, int g, const unsigned long lo
 // One permutation per 16-lane group; lane g < 12 holds element g on entry and exit (canonical).
 __device__ __forceinline__ u64 p2l_permute(u64 s) {
   const int lane = threadIdx.x & 63, g = lane & 15;
-  s = p2l_external(s, g, p2c::P2_ARK_EXT_INITIAL);
-#pragma unroll 1
+  // A lone wave pays every memory latency in its dependency chain: the round constants are fetched up front (the eight external
+  // ones of this lane here, in one latency; the internal ones one round ahead, below), not where the rounds use them.
+  const int gi = g < 12 ? g : 0;
+  u64 rci[4], rct[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    rci[k] = p2c::P2_ARK_EXT_INITIAL[12 * k + gi];
+    rct[k] = p2c::P2_ARK_EXT_TERMINAL[12 * k + gi];
+  }
+  s = p2l_external<true>(s, g, rci[0]);
+#pragma unroll
   for (int r = 0; r < 4; r++) {
     s = p2f_sbox(s);
-    s = p2l_external(s, g, r < 3 ? p2c::P2_ARK_EXT_INITIAL + 12 * (r + 1) : nullptr);
+    s = r < 3 ? p2l_external<true>(s, g, rci[r + 1]) : p2l_external<false>(s, g, 0);
   }
   // ---- internal rounds, state scaled by 8^r, every lane wide; integer diagonal per lane ----
   // 8 * diag = [-16, 8, 16, 4, 24, 32, -4, -24, -32, 2, -2, 1]
-  const u32 mag_tab[16] = {16, 8, 16, 4, 24, 32, 4, 24, 32, 2, 2, 1, 0, 0, 0, 0};
+  // |8 * diag| = 16, 8, 16, 4, 24, 32, 4, 24, 32, 2, 2, 1 (0 for the idle lanes) as byte fields of two literals: a table lookup would
+  // be a memory load in the dependency chain of a lone wave
+  const u64 mag_lo = 0x1804201804100810ULL, mag_hi = 0x0000000001020220ULL;  // elements 0..7, 8..15
   const u32 neg_bits = 0x5C1;  // elements 0, 6, 7, 8, 10
-  const u64 mag = mag_tab[g];
+  const u64 mag = ((g < 8 ? mag_lo : mag_hi) >> (8 * (g & 7))) & 0xff;
   const u64 sgn = ((neg_bits >> g) & 1) ? ~(u64)0 : 0;  // all-ones where the coefficient is negative
-  u64 t0 = p2f_add_canon(s, p2c::P2F_ARK_INT_SCALED[0]);  // used from lane 0 only
+  u64 t0 = p2f_add_canon(s, p2c::P2F_ARK_INT_SCALED[0]);  // the S-box input (element 0); the same in every lane from round 1 on
+  // Element 0 enters every round as the S-box output y, so lane 0 keeps (0, 0) in (L, H) and everything that does not depend on y --
+  // the sum R of elements 1..11 over the row and the coefficient products c_i T_i -- is written BEFORE the S-box chain: the scheduler
+  // may lay those ~50 instructions into the chain's wait states.  After y: S = R + y, T_i' = 8 S + c_i T_i, and the next S-box input
+  // T_0' = 8 S - 16 y (+ round constant) comes out the same in every lane (S and y are row-uniform).
   u64 L = (g >= 1 && g < 12) ? (u64)lo32(s) : 0, H = (g >= 1 && g < 12) ? (u64)hi32(s) : 0;
+  u64 nL = 0, nH = 0;
+  u64 k_cur = p2c::P2F_INT_K[0], a_cur = p2c::P2F_ARK_INT_SCALED[1];
 #pragma unroll 1
   for (int r = 0; r < 22; r++) {
-    const u64 y = p2l_dpp<P2L_ROW_BCAST0>(p2f_mul(p2f_sbox(t0), p2c::P2F_INT_K[r]));  // lane 0's S-box output
-    if (g == 0) {
-      L = lo32(y);
-      H = hi32(y);
-    }
-    u64 sL = L, sH = H;  // sum over the 16 lanes of the row, left in every lane
+    const u64 k_nxt = p2c::P2F_INT_K[r < 21 ? r + 1 : 21], a_nxt = p2c::P2F_ARK_INT_SCALED[r < 20 ? r + 2 : 21];  // for the next round
+    u64 sL = L, sH = H;  // R: sum over the 16 lanes of the row (lane 0 and the idle lanes hold zeros), left in every lane
     sL += p2l_dpp<P2L_ROW_ROR(8)>(sL); sH += p2l_dpp<P2L_ROW_ROR(8)>(sH);
     sL += p2l_dpp<P2L_ROW_ROR(4)>(sL); sH += p2l_dpp<P2L_ROW_ROR(4)>(sH);
     sL += p2l_dpp<P2L_QUAD(2, 3, 0, 1)>(sL); sH += p2l_dpp<P2L_QUAD(2, 3, 0, 1)>(sH);
     sL += p2l_dpp<P2L_QUAD(1, 0, 3, 2)>(sL); sH += p2l_dpp<P2L_QUAD(1, 0, 3, 2)>(sH);
-    // T' = coeff * T + 8 * sum   (two's complement arithmetic on the signed wide parts)
     const u64 mL = L * mag, mH = H * mag;
-    L = (sL << 3) + ((mL ^ sgn) - sgn);
-    H = (sH << 3) + ((mH ^ sgn) - sgn);
-    if (g >= 12) { L = 0; H = 0; }
-    // lane 0: next S-box input = T_0' + scaled round constant, folded
-    u64 nL = L, nH = H;
-    if (r < 21) {
-      const u64 rc = p2c::P2F_ARK_INT_SCALED[r + 1];
-      nL += rc & 0xFFFFFFFFULL;
-      nH += rc >> 32;
-    }
-    t0 = p2f_fold_signed(nL, nH);
+    const u64 cL = (mL ^ sgn) - sgn, cH = (mH ^ sgn) - sgn;  // c_i T_i (two's complement arithmetic on the signed wide parts)
+    const u64 y = p2l_dpp<P2L_ROW_BCAST0>(p2f_mul(p2f_sbox(t0), k_cur));  // the S-box output (lane 0's; t0 is row-uniform from round 1 on)
+    const u64 yl = lo32(y), yh = hi32(y);
+    sL += yl;
+    sH += yh;
+    L = (sL << 3) + cL;  // T_i' = 8 S + c_i T_i
+    H = (sH << 3) + cH;
+    nL = (sL << 3) - (yl << 4);  // T_0' = 8 S - 16 y
+    nH = (sH << 3) - (yh << 4);
+    if (g == 0 || g >= 12) { L = 0; H = 0; }
+    if (r < 21) t0 = p2f_fold_signed(nL + (a_cur & 0xFFFFFFFFULL), nH + (a_cur >> 32));
+    k_cur = k_nxt;
+    a_cur = a_nxt;
     if ((r & 3) == 3) {  // refold the wide parts before they outgrow 2^61 (<= 7 bits per round)
       const u64 v = p2f_fold_signed(L, H);
       L = lo32(v);
       H = hi32(v);
-      if (g >= 12) { L = 0; H = 0; }
+      if (g == 0 || g >= 12) { L = 0; H = 0; }
     }
   }
+  if (g == 0) {  // element 0 after the last round
+    L = nL;
+    H = nH;
+  }
   // leave the scaled domain, first terminal round constants
-  s = p2f_add_canon(p2f_mul(p2f_fold_signed(L, H), p2c::P2F_DESCALE), p2c::P2_ARK_EXT_TERMINAL[g < 12 ? g : 0]);
-#pragma unroll 1
+  s = p2f_add_canon(p2f_mul(p2f_fold_signed(L, H), p2c::P2F_DESCALE), rct[0]);
+#pragma unroll
   for (int r = 0; r < 4; r++) {
     s = p2f_sbox(s);
-    s = p2l_external(s, g, r < 3 ? p2c::P2_ARK_EXT_TERMINAL + 12 * (r + 1) : nullptr);
+    s = r < 3 ? p2l_external<true>(s, g, rct[r + 1]) : p2l_external<false>(s, g, 0);
   }
   return gl_canon(s);
 }

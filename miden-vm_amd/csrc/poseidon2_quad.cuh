@@ -18,7 +18,7 @@
 
 // out_k = (circ(2*M4, M4, M4) * s)_(4k + j) (+ rc), folded to 64 bits; j = lane within the quad.
 template <bool RC>
-__device__ __forceinline__ void p2q_external(u64 (&s)[3], int j, const unsigned long long* rc) {
+__device__ __forceinline__ void p2q_external(u64 (&s)[3], const u64 (&c)[3]) {
   u64 oL[3], oH[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -32,9 +32,8 @@ __device__ __forceinline__ void p2q_external(u64 (&s)[3], int j, const unsigned 
   for (int k = 0; k < 3; k++) {
     u64 L = oL[k] + sL, H = oH[k] + sH;
     if (RC) {
-      const u64 c = rc[4 * k + j];
-      L += c & 0xFFFFFFFFULL;
-      H += c >> 32;
+      L += c[k] & 0xFFFFFFFFULL;
+      H += c[k] >> 32;
     }
     s[k] = p2f_fold(L, H);
   }
@@ -51,30 +50,42 @@ __device__ __forceinline__ void p2q_sbox3(u64 (&s)[3]) {
 // One permutation per quad; lane j holds elements j, 4 + j, 8 + j on entry and exit (canonical on exit).
 __device__ __forceinline__ void p2q_permute(u64 (&s)[3]) {
   const int j = threadIdx.x & 3;
-  p2q_external<true>(s, j, p2c::P2_ARK_EXT_INITIAL);
-#pragma unroll 1
+  // the 24 external round constants of this lane up front, the internal ones one round ahead: a lone wave pays every memory latency
+  // that sits in its dependency chain (poseidon2_lanes.cuh)
+  u64 rci[4][3], rct[4][3];
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      rci[r][k] = p2c::P2_ARK_EXT_INITIAL[12 * r + 4 * k + j];
+      rct[r][k] = p2c::P2_ARK_EXT_TERMINAL[12 * r + 4 * k + j];
+    }
+  p2q_external<true>(s, rci[0]);
+#pragma unroll
   for (int r = 0; r < 4; r++) {
     p2q_sbox3(s);
-    if (r < 3) p2q_external<true>(s, j, p2c::P2_ARK_EXT_INITIAL + 12 * (r + 1));
-    else p2q_external<false>(s, j, nullptr);
+    if (r < 3) p2q_external<true>(s, rci[r + 1]);
+    else p2q_external<false>(s, rci[0]);
   }
   // ---- internal rounds: state scaled by 8^r, wide parts; 8 * diag = [-16, 8, 16, 4, 24, 32, -4, -24, -32, 2, -2, 1] ----
-  const u32 mag_tab[12] = {16, 8, 16, 4, 24, 32, 4, 24, 32, 2, 2, 1};
+  const u64 mag_lo = 0x1804201804100810ULL, mag_hi = 0x0000000001020220ULL;  // |8 * diag| of elements 0..7, 8..11 as byte fields (no table load)
   const u32 neg_bits = 0x5C1;  // elements 0, 6, 7, 8, 10
   u64 mag[3], sgn[3], L[3], H[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     const int e = 4 * k + j;
-    mag[k] = mag_tab[e];
+    mag[k] = ((e < 8 ? mag_lo : mag_hi) >> (8 * (e & 7))) & 0xff;
     sgn[k] = ((neg_bits >> e) & 1) ? ~(u64)0 : 0;
     L[k] = lo32(s[k]);
     H[k] = hi32(s[k]);
   }
   u64 t0 = p2f_add_canon(s[0], p2c::P2F_ARK_INT_SCALED[0]);  // used from lane 0 only
   if (j == 0) { L[0] = 0; H[0] = 0; }
+  u64 k_cur = p2c::P2F_INT_K[0], a_cur = p2c::P2F_ARK_INT_SCALED[1];
 #pragma unroll 1
   for (int r = 0; r < 22; r++) {
-    const u64 y = p2l_dpp<P2L_QUAD(0, 0, 0, 0)>(p2f_mul(p2f_sbox(t0), p2c::P2F_INT_K[r]));  // lane 0's S-box output
+    const u64 k_nxt = p2c::P2F_INT_K[r < 21 ? r + 1 : 21], a_nxt = p2c::P2F_ARK_INT_SCALED[r < 20 ? r + 2 : 21];  // for the next round
+    const u64 y = p2l_dpp<P2L_QUAD(0, 0, 0, 0)>(p2f_mul(p2f_sbox(t0), k_cur));  // lane 0's S-box output
     if (j == 0) {
       L[0] = lo32(y);
       H[0] = hi32(y);
@@ -90,11 +101,12 @@ __device__ __forceinline__ void p2q_permute(u64 (&s)[3]) {
     }
     u64 nL = L[0], nH = H[0];  // lane 0: next S-box input = T_0' + scaled round constant, folded
     if (r < 21) {
-      const u64 rc = p2c::P2F_ARK_INT_SCALED[r + 1];
-      nL += rc & 0xFFFFFFFFULL;
-      nH += rc >> 32;
+      nL += a_cur & 0xFFFFFFFFULL;
+      nH += a_cur >> 32;
     }
     t0 = p2f_fold_signed(nL, nH);
+    k_cur = k_nxt;
+    a_cur = a_nxt;
     if ((r & 3) == 3) {  // refold the wide parts before they outgrow 2^61 (<= 7 bits per round)
 #pragma unroll
       for (int k = 0; k < 3; k++) {
@@ -106,12 +118,12 @@ __device__ __forceinline__ void p2q_permute(u64 (&s)[3]) {
   }
   // leave the scaled domain, first terminal round constants
 #pragma unroll
-  for (int k = 0; k < 3; k++) s[k] = p2f_add_canon(p2f_mul(p2f_fold_signed(L[k], H[k]), p2c::P2F_DESCALE), p2c::P2_ARK_EXT_TERMINAL[4 * k + j]);
-#pragma unroll 1
+  for (int k = 0; k < 3; k++) s[k] = p2f_add_canon(p2f_mul(p2f_fold_signed(L[k], H[k]), p2c::P2F_DESCALE), rct[0][k]);
+#pragma unroll
   for (int r = 0; r < 4; r++) {
     p2q_sbox3(s);
-    if (r < 3) p2q_external<true>(s, j, p2c::P2_ARK_EXT_TERMINAL + 12 * (r + 1));
-    else p2q_external<false>(s, j, nullptr);
+    if (r < 3) p2q_external<true>(s, rct[r + 1]);
+    else p2q_external<false>(s, rct[0]);
   }
 #pragma unroll
   for (int k = 0; k < 3; k++) s[k] = gl_canon(s[k]);
