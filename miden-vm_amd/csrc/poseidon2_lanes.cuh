@@ -1,12 +1,14 @@
 // Poseidon2 with ONE STATE ELEMENT PER LANE (16-lane groups, 12 active): the low-latency form used
 // for the small top layers of every Merkle tree.
 //
-// A one-state-per-lane permutation (poseidon2_fast.cuh) is ~16 k dependent-ish VALU instructions =
-// ~45 us for a lone wave.  The top 13 levels of a tree have fewer nodes than the chip has lanes, so each
+// A one-state-per-lane permutation (poseidon2_fast.cuh) is ~10 k dependent-ish VALU instructions =
+// ~31 us for a lone wave.  The top levels of a tree have fewer nodes than the chip has lanes, so each
 // of them costs one such latency, 10 trees per proof.  Spreading a state over 12 lanes makes the 12
 // S-boxes of a full round run side by side and turns the linear layers into a handful of cross-lane
-// reads: ~5 k instructions per permutation, same arithmetic (wide values, scaled internal rounds) and
-// bit-identical results.  Throughput per lane is 3x worse, so only layers of <= 8192 nodes use it.
+// reads: ~6.5 k issue slots per permutation, same arithmetic (wide values, scaled internal rounds) and
+// bit-identical results.  Throughput per lane is 3x worse, so only layers of <= 8192 nodes use it (2^14 / 2^15 nodes:
+// poseidon2_quad.cuh).  A lone wave also pays every MEMORY latency in its dependency chain: the round constants are fetched ahead
+// of it (p2l_permute), not where the rounds use them (-2.5 us per level).
 #pragma once
 #include "poseidon2_fast.cuh"
 
