@@ -152,3 +152,34 @@ def test_fast_build_agrees_with_reference_build():
         assert ob.lib().orc_fmul(ob.P - 1, ob.P - 1) == 1
     finally:
         ob.use_fast_library(False)
+
+
+def test_fast_build_gives_the_same_whole_proofs():
+    """The fast build (no 128-bit division in fmul / fadd / fsub) against the `% P` build on complete proofs: every transcript field,
+    commitment and the digest -- a DummyMidenAir instance at production parameters (PoW search included), a statement with selectors,
+    public values and an aux column, and a LogUp statement with a preprocessed table (EF inversions, sigma closing)."""
+    import airs as A
+    from __graft_entry__ import load_package
+    load_package()
+    from miden_vm_amd import dag, protocol, precompile_airs as PA
+    fast = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=5, query_pow_bits=3)
+
+    def host_aux(lookup, main, randomness, preprocessed=None):
+        return ob.lookup_build_aux(lookup, main, randomness, preprocessed)
+    rng = np.random.default_rng(5)
+    ledger = PA.BytePairLutRequires()
+    reqs = PA.keccak_like_requests(rng, 5, ledger)
+    pairs = [PA.requirer_air(host_aux), PA.byte_pair_lut_air(host_aux), PA.ec_groups_air(host_aux)]
+    t_fib, pub_fib = A.fib_trace(7)
+    cases = [([dag.dummy_miden_air(51, 8)], [A.dummy_trace(8, 51)], [], dict(protocol.PROD_PARAMS)),
+             ([A.fib_air()], [t_fib], pub_fib, fast),
+             ([p[0] for p in pairs], [PA.requirer_trace(reqs), PA.byte_pair_lut_trace(ledger), PA.ec_groups_trace()], [71, 72, 73, 74], fast)]
+    for airs_, traces, pub, prm in cases:
+        ref = ob.prove(airs_, traces, pub, prm)
+        ob.use_fast_library(True)
+        try:
+            got = ob.prove(airs_, traces, pub, prm)
+        finally:
+            ob.use_fast_library(False)
+        assert got["fields"].size == ref["fields"].size and (got["fields"] == ref["fields"]).all()
+        assert (got["commitments"] == ref["commitments"]).all() and (got["digest"] == ref["digest"]).all()
