@@ -414,9 +414,9 @@ __global__ __launch_bounds__(256) void k_compress_lanes(const u64* __restrict__ 
     l = 2 * q;
     rgt = l + 1;
   }
-  u64 s = 0;
-  if (g < 4) s = in[4 * l + g];
-  else if (g < 8) s = in[4 * rgt + (g - 4)];
+  // lanes 0-3: the left digest, 4-7: the right one, the rest zeros -- ONE masked load (two branches were two memory latencies in a row)
+  const u64* src = in + 4 * (g < 4 ? l : rgt) + (g & 3);
+  u64 s = g < 8 ? *src : 0;
   s = p2l_permute(s);
   if (active && g < 4) out[4 * q + g] = s;
 }
