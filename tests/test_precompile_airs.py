@@ -279,3 +279,89 @@ def test_keccak_session_proves_and_verifies(airs, keccak):
     t[80, 17] ^= 1
     _, (ok_o, _), (ok_p, _) = _prove_verify(air_list, [t] + traces[1:], FAST)
     assert not ok_o and not ok_p
+
+
+# ---- the reference's own unit tests of the byte-pair table, replayed (precompiles-prover/src/tests/byte_pair_lut.rs) -----------------
+def test_reference_unit_cases_of_the_byte_pair_table(airs):
+    # `andnot_uses_keccak_chi_convention`, `op_tags_match_relation_encoding` (:29-38)
+    led = PA.BytePairLutRequires()
+    assert led.require(PA.OP_ANDNOT, 0xf0, 0xcc) == (~0xf0 & 0xff) & 0xcc and led.require(PA.OP_XOR, 0xab, 0xcd) == 0xab ^ 0xcd
+    assert (PA.OP_ANDNOT, PA.OP_XOR) == (0, 1)
+    # `require_increments_multiplicity`, `require_range16_increments_dedicated_multiplicity` (:41-64)
+    led = PA.BytePairLutRequires()
+    led.require(PA.OP_XOR, 0xab, 0xcd)
+    assert led.counts[(0xab << 8) | 0xcd, 1] == 1
+    led.require(PA.OP_XOR, 0xab, 0xcd)
+    assert led.counts[(0xab << 8) | 0xcd, 1] == 2 and led.counts[(0xab << 8) | 0xcd, 0] == 0
+    led.require_range16(0xabcd)
+    assert led.counts[(0xcd << 8) | 0xab, 2] == 1 and led.counts[(0xcd << 8) | 0xab, 0] == 0 and led.counts[(0xcd << 8) | 0xab, 1] == 0
+    # `empty_requires_enumerates_all_pairs_with_zero_mults`, `preprocessed_table_is_correct_for_all_pairs`, `trace_height_is_fixed_at_2_pow_16`
+    table = PA.byte_pair_preprocessed()
+    a, b = np.arange(1 << 16, dtype=np.uint64) >> np.uint64(8), np.arange(1 << 16, dtype=np.uint64) & np.uint64(0xff)
+    assert (table[:, 0] == a).all() and (table[:, 1] == b).all() and (table[:, 2] == ((~a & np.uint64(0xff)) & b)).all() and (table[:, 3] == (a ^ b)).all()
+    empty = PA.byte_pair_lut_trace(PA.BytePairLutRequires())
+    assert empty.shape == (1 << 16, 3) and int(empty.sum()) == 0
+    # `trace_row_carries_results_and_multiplicities_at_lex_index` (:137-186)
+    led = PA.BytePairLutRequires()
+    led.require(PA.OP_XOR, 0x05, 0x03); led.require(PA.OP_XOR, 0x05, 0x03); led.require(PA.OP_ANDNOT, 0x05, 0x03)
+    led.require(PA.OP_ANDNOT, 0x01, 0x02); led.require_range16(0x0301)
+    t = PA.byte_pair_lut_trace(led)
+    assert list(table[0x0102, 2:]) == [0x02, 0x03] and list(t[0x0102]) == [1, 0, 0]
+    assert list(table[0x0103, 2:]) == [(~1 & 0xff) & 3, 1 ^ 3] and list(t[0x0103]) == [0, 0, 1]
+    assert list(table[0x0503, 2:]) == [0x02, 0x06] and list(t[0x0503]) == [1, 2, 0]
+    assert int(table[0x0504, 3]) == 0x05 ^ 0x04 and list(t[0x0504]) == [0, 0, 0]
+    # `build_aux_trace_matches_main_height`, `build_aux_trace_starts_at_zero`, `populate_aux_trace_exposed_residue_matches_full_sum` (:204-270):
+    # sigma = - sum of 1 / enc over every individual lookup, with the reference test's challenges alpha = (3, 7)? -> any (alpha, beta) works
+    bp_calls = [(PA.OP_XOR, 0x05, 0x03), (PA.OP_XOR, 0x05, 0x03), (PA.OP_ANDNOT, 0x05, 0x03), (PA.OP_ANDNOT, 0x10, 0x20)]
+    r16_calls = [0x0301, 0x0301, 0x2010]
+    led = PA.BytePairLutRequires()
+    for op, x, y in bp_calls:
+        led.require(op, x, y)
+    for w in r16_calls:
+        led.require_range16(w)
+    air, lookup = airs["bpl"]
+    aux, fin = ob.lookup_build_aux(lookup, PA.byte_pair_lut_trace(led), RND, air.preprocessed)
+    assert aux.shape == (1 << 16, 4) and int(aux[0, 0]) == 0 and int(aux[0, 1]) == 0   # two EF columns; the running sum starts at zero
+    total = (0, 0)
+    for op, x, y in bp_calls:
+        c = ((~x & 0xff) & y) if op == PA.OP_ANDNOT else (x ^ y)
+        inv = PA._e_inv(PA._encode(RND[0], RND[1], PA.BUS_BYTE_PAIR_LUT, [op, x, y, c]))
+        total = ((total[0] + inv[0]) % P, (total[1] + inv[1]) % P)
+    for w in r16_calls:
+        inv = PA._e_inv(PA._encode(RND[0], RND[1], PA.BUS_RANGE16, [(w & 0xff) + 256 * (w >> 8)]))
+        total = ((total[0] + inv[0]) % P, (total[1] + inv[1]) % P)
+    assert (int(fin[0]), int(fin[1])) == ((P - total[0]) % P, (P - total[1]) % P)
+    # `air_quotient_degree_matches_constraint_plan`, `num_public_values_matches_shared_root`
+    h = dag.parse_air_blob(air.blob)
+    assert h["log_quotient_degree"] == 1 and h["num_public"] == PA.NUM_PUBLIC_VALUES == 4
+
+
+# ---- the reference's own tests of the Keccak round chiplet, replayed (precompiles-prover/src/tests/keccak.rs) ------------------------
+def test_reference_unit_cases_of_the_keccak_round_chiplet():
+    kr_air, kr_lookup = PA.keccak_round_air(host_aux)
+
+    def check_local(trace):  # crate::tests::check_local: the AIR's constraints on a main trace with its own aux trace
+        aux, fin = ob.lookup_build_aux(kr_lookup, trace, RND)
+        return ob.check_constraints(kr_air, trace, aux, [int(fin[0]), int(fin[1])], ROOT, RND)
+    # `extract_output_matches_reference_keccak_zero_input` / `_canonical_test_vectors` / `_random_input` (:153-184)
+    patterned = [(i * 0x9e3779b97f4a7c15) & PA.M64 for i in range(25)]
+    rng = np.random.default_rng(0xcaca0)
+    for st in ([0] * 25, patterned, *[[int(x) for x in rng.integers(0, 1 << 63, 25)] for _ in range(3)]):
+        t, mem = PA.keccak_round_trace([st])
+        assert PA.keccak_round_outputs(mem, 0) == PA.keccak_f_reference(st)
+    # `keccak_round_constraints_hold_on_canonical_input` (:187-194): one permutation -> height next_pow2(3200) = 4096
+    t, _ = PA.keccak_round_trace([[0] * 25])
+    assert t.shape[0] == 4096 and check_local(t) == (0, None)
+    # `keccak_round_constraints_hold_on_random_input`
+    t, _ = PA.keccak_round_trace([[int(x) for x in np.random.default_rng(0xc037f).integers(0, 1 << 63, 25)]])
+    assert check_local(t) == (0, None)
+    # `keccak_round_multi_perm_oracle_and_constraints` (:214-236): three permutations, lanes of 2 + 1 -> next_pow2(2 * 3200) = 8192
+    states = [[int(x) for x in np.random.default_rng(0xc0ffee + k).integers(0, 1 << 63, 25)] for k in range(3)]
+    t, mem = PA.keccak_round_trace(states)
+    assert [PA.keccak_round_outputs(mem, n) for n in range(3)] == [PA.keccak_f_reference(s) for s in states]
+    assert t.shape[0] == 8192 and check_local(t) == (0, None)
+    # `corruption_rot_limb_breaks_rotation_decomposition_binding` (:246-256): SLOT_D_ROL_BEGIN of round 0, lane 0 is an active ROL row
+    t, _ = PA.keccak_round_trace([[0] * 25])
+    t[PA.SLOT_D_ROL_BEGIN, PA.KR_ROT] = (int(t[PA.SLOT_D_ROL_BEGIN, PA.KR_ROT]) + 1) % P
+    bad, first = check_local(t)
+    assert bad >= 1 and first[0] == PA.SLOT_D_ROL_BEGIN
