@@ -455,8 +455,9 @@ class CoreVM:
         log_n = max(6, (need - 1).bit_length()) if log_n is None else log_n
         n = 1 << log_n
         assert need <= n
-        while len(self.rows) < n:
-            self._row(OPC["HALT"], 0, [0] * 8)
+        halt_state = list(getattr(self, "program_digest", [0, 0, 0, 0])) + [0, 0, 0, 0]
+        while len(self.rows) < n:                          # HALT rows keep the root block's digest in h0..h3 (trace_row.rs: the END row's
+            self._row(OPC["HALT"], 0, halt_state)          # hasher state is carried; pinned by the reference snapshots, tests/test_ref_traces.py)
         core = np.array(self.rows, dtype=np.uint64)
         core[n - len(table):, CO.RANGE_M] = [m for m, _ in table]
         core[n - len(table):, CO.RANGE_V] = [v for _, v in table]
@@ -495,6 +496,7 @@ CT.Chiplets.memory_range_checks = _memory_range_checks
 def prove_inputs(vm, program, log_n=None):
     """Run `program` to completion: -> dict(core, chiplets, poseidon2, public_values, aux_inputs, program_hash)."""
     vm.run(program)
+    vm.program_digest = list(program.digest)
     outputs = list(vm.top)
     core = vm.finish(log_n)
     chiplets, p2 = vm.chiplets.into_traces()
