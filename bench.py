@@ -262,6 +262,7 @@ def jit_load_probe(pkg, ctx):
         tmp = tempfile.mkdtemp(prefix="mh_jit_cold_")
         try:
             os.environ["MH_JIT_CACHE_DIR"] = tmp
+            ro, os.environ["MH_JIT_CACHE_RO_DIR"] = os.environ.get("MH_JIT_CACHE_RO_DIR", ""), ""   # cold = not even the shipped kernels
             t0 = time.perf_counter()
             d = pkg.DeviceAir(ctx, air)
             cold = time.perf_counter() - t0
@@ -273,6 +274,7 @@ def jit_load_probe(pkg, ctx):
                          "jit_cold_s": round(cold, 2), "jit_cached_ms": round(cached * 1e3, 2)}
             d.free()
         finally:
+            os.environ["MH_JIT_CACHE_RO_DIR"] = ro
             if old is None:
                 os.environ.pop("MH_JIT_CACHE_DIR", None)
             else:
@@ -291,8 +293,10 @@ def chiplets_air_probe(pkg, ctx, log_n=20, steps=3):
     lookup = dag.lookup_from_constraints(air.blob)
     tmp = tempfile.mkdtemp(prefix="mh_jit_cold_")
     old = os.environ.get("MH_JIT_CACHE_DIR")
+    ro = os.environ.get("MH_JIT_CACHE_RO_DIR", "")
     try:
         os.environ["MH_JIT_CACHE_DIR"] = tmp
+        os.environ["MH_JIT_CACHE_RO_DIR"] = ""
         t0 = time.perf_counter()
         d0, l0 = pkg.DeviceAir(ctx, air), pkg.DeviceLookup(ctx, lookup)
         cold = time.perf_counter() - t0
@@ -301,6 +305,7 @@ def chiplets_air_probe(pkg, ctx, log_n=20, steps=3):
         dair, dlk = pkg.DeviceAir(ctx, air), pkg.DeviceLookup(ctx, lookup)
         cached = time.perf_counter() - t0
     finally:
+        os.environ["MH_JIT_CACHE_RO_DIR"] = ro
         if old is None:
             os.environ.pop("MH_JIT_CACHE_DIR", None)
         else:

@@ -6,7 +6,7 @@
 use core::ffi::{c_char, c_double, c_int, c_long, c_void};
 
 macro_rules! opaque { ($($n:ident),*) => { $( #[repr(C)] pub struct $n { _p: [u8; 0] } )* } }
-opaque!(mh_ctx, mh_trace, mh_tree, mh_air, mh_proof, mh_shard, mh_lookup, mh_session);
+opaque!(mh_ctx, mh_trace, mh_tree, mh_air, mh_proof, mh_shard, mh_lookup, mh_session, mh_miden);
 
 pub const MH_OK: c_int = 0;
 pub const MH_ERR_INVALID: c_int = 1;
@@ -165,6 +165,19 @@ unsafe extern "C" {
     pub fn mh_local_fabric_abort(f: *mut mh_local_fabric);
     pub fn mh_comm_create_local(ctx: *mut mh_ctx, f: *mut mh_local_fabric, rank: c_int, out: *mut *mut mh_comm) -> c_int;
     pub fn mh_comm_selftest(ctx: *mut mh_ctx, comm: *const mh_comm) -> c_int;
+    // ---- the Miden statement in the library (prove_stark's own shape, prover/src/lib.rs:317-355); a Rust shim that keeps
+    // `MidenMultiAir` on its side uses mh_prove / mh_verify_ex instead
+    pub fn mh_miden_load(ctx: *mut mh_ctx, out: *mut *mut mh_miden) -> c_int;
+    pub fn mh_miden_free(m: *mut mh_miden);
+    pub fn mh_prove_miden(ctx: *mut mh_ctx, m: *const mh_miden, hash_fn: c_int, core_rowmajor: *const u64, log_core: c_int, chiplets_rowmajor: *const u64, log_chiplets: c_int, poseidon2_rowmajor: *const u64, log_poseidon2: c_int, public_values: *const u64, aux_inputs: *const u64, n_aux_inputs: usize, out: *mut *mut mh_proof) -> c_int;
+    pub fn mh_prove_miden_traces(ctx: *mut mh_ctx, m: *const mh_miden, hash_fn: c_int, traces: *const *mut mh_trace, public_values: *const u64, aux_inputs: *const u64, n_aux_inputs: usize, out: *mut *mut mh_proof) -> c_int;
+    pub fn mh_verify_miden(hash_fn: c_int, public_values: *const u64, aux_inputs: *const u64, n_aux_inputs: usize, proof_bytes: *const u8, n_bytes: usize, digest: *mut u64, err: *mut c_char, err_cap: usize) -> c_int;
+    pub fn mh_miden_pcs_params(out: *mut mh_pcs_params);
+    pub fn mh_miden_challenger_state(state: *mut u64);
+    pub fn mh_miden_hash_kernel_digests(kernel_felts: *const u64, n_felts: usize, out: *mut u64) -> c_int;
+    pub fn mh_miden_pre_observe(params: *const mh_pcs_params, public_values: *const u64, aux_inputs: *const u64, n_aux_inputs: usize, out: *mut u64) -> c_int;
+    pub fn mh_miden_eval_external(randomness: *const u64, aux_inputs: *const u64, n_aux_inputs: usize, aux_values: *const *const u64, n_aux_values: *const usize, n_airs: c_int, out: *mut u64) -> c_int;
+    pub fn mh_miden_air_blob(which: c_int, words_out: *mut *const u64, n_words: *mut usize) -> c_int;
     pub fn mh_proof_free(p: *mut mh_proof);
     pub fn mh_proof_num_fields(p: *const mh_proof) -> usize;
     pub fn mh_proof_num_commitments(p: *const mh_proof) -> usize;

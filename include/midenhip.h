@@ -408,6 +408,47 @@ int mh_verify_lmcs(int lmcs, const mh_pcs_params* params, int n_airs, const uint
 int mh_external_logup_balance(void* user, const uint64_t* randomness, size_t n_randomness, const uint64_t* const* aux_values,
                               const size_t* n_aux_values, const uint8_t* log_trace_heights, int n_airs, uint64_t* assertions_out,
                               size_t cap);
+
+/* ---- the Miden VM statement: prove_stark's own shape (prover/src/lib.rs:317-355) --------------------------------------------------
+ * Three matrices + 32 public values + aux inputs in, proof out -- the statement layer the reference's `MidenMultiAir` adds to the
+ * proof system, in the library (csrc/miden.cpp) so that a C caller restates nothing:
+ *   - the three AIRs [CoreAir, ChipletsAir, Poseidon2PermutationAir] (air/src/lib.rs:560-650) with their LogUp lookup programs, embedded
+ *     as the blobs of miden-vm_amd/blobs (all eight aux columns are built on the device);
+ *   - `MidenMultiAir::observe` (air/src/lib.rs:805-849): [kernel_H | program_hash] [deferred_root | 0^4] [stack inputs 16] [stack
+ *     outputs 16], kernel_H = hash_kernel_digests (:946-961) = Poseidon2 hash_elements of the kernel-digest felts;
+ *   - `MidenMultiAir::eval_external` (:854-933): the three committed LogUp finals + the boundary corrections (block-hash seed,
+ *     deferred-root log, one KernelRomInit per kernel digest) must vanish -- mh_verify_miden checks it, no proof of this statement
+ *     verifies without it;
+ *   - pcs_params() and RELATION_DIGEST of air/src/config.rs:54-67, 93-98; hash_fn = MH_LMCS_* as `prove_miden_vm_execution_trace`
+ *     dispatches on ProvingOptions::hash_fn (prover/src/lib.rs:246-300).
+ * public_values: stack inputs (16) ++ stack outputs (16).  aux_inputs: program hash (4) | deferred root (4) | kernel procedure
+ * digests (4 each, at most 255).  Matrices row-major, heights 2^log_*, widths 51 / 22 / 16, canonical felts. */
+#define MH_MIDEN_NUM_PUBLIC_VALUES 32
+#define MH_MIDEN_PRE_OBSERVE_FELTS 56 /* 8 protocol parameters + the 48-felt statement schedule */
+typedef struct mh_miden mh_miden; /* the three AIRs loaded on a context, lookups attached */
+int mh_miden_load(mh_ctx* ctx, mh_miden** out);
+void mh_miden_free(mh_miden* m);
+int mh_prove_miden(mh_ctx* ctx, const mh_miden* m, int hash_fn, const uint64_t* core_rowmajor, int log_core,
+                   const uint64_t* chiplets_rowmajor, int log_chiplets, const uint64_t* poseidon2_rowmajor, int log_poseidon2,
+                   const uint64_t* public_values /* [32] */, const uint64_t* aux_inputs, size_t n_aux_inputs, mh_proof** out);
+/* the same over device-resident traces (mh_trace_upload* / mh_trace_from_device), instance order core, chiplets, poseidon2 */
+int mh_prove_miden_traces(mh_ctx* ctx, const mh_miden* m, int hash_fn, mh_trace* const traces[3], const uint64_t* public_values,
+                          const uint64_t* aux_inputs, size_t n_aux_inputs, mh_proof** out);
+/* verifier/src/lib.rs:320-330 for this statement: StarkProofData bytes -> MH_OK + the transcript digest, or MH_ERR_INVALID + reason.
+ * Host only (no context, no GPU). */
+int mh_verify_miden(int hash_fn, const uint64_t* public_values /* [32] */, const uint64_t* aux_inputs, size_t n_aux_inputs,
+                    const uint8_t* proof_bytes, size_t n_bytes, uint64_t digest[4], char* err, size_t err_cap);
+/* the pieces, for a caller that drives mh_prove / mh_session_* / mh_verify_ex itself */
+void mh_miden_pcs_params(mh_pcs_params* out);
+void mh_miden_challenger_state(uint64_t state[12]);
+int mh_miden_hash_kernel_digests(const uint64_t* kernel_felts, size_t n_felts, uint64_t out[4]);
+int mh_miden_pre_observe(const mh_pcs_params* params, const uint64_t* public_values, const uint64_t* aux_inputs, size_t n_aux_inputs,
+                         uint64_t out[MH_MIDEN_PRE_OBSERVE_FELTS]);
+/* randomness = (alpha, beta) as 4 felts; aux_values[i] = the i-th AIR's committed values (2 felts each); out = the one assertion */
+int mh_miden_eval_external(const uint64_t randomness[4], const uint64_t* aux_inputs, size_t n_aux_inputs,
+                           const uint64_t* const* aux_values, const size_t* n_aux_values, int n_airs, uint64_t out[2]);
+int mh_miden_air_blob(int which /* 0 core, 1 chiplets, 2 poseidon2 */, const uint64_t** words_out, size_t* n_words);
+
 void mh_proof_free(mh_proof* p);
 size_t mh_proof_num_fields(const mh_proof* p);
 size_t mh_proof_num_commitments(const mh_proof* p);

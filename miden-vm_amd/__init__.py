@@ -34,12 +34,16 @@ EXPORTS = [
     "mh_verify_ex", "mh_external_logup_balance", "mh_proof_deserialize", "mh_ctx_set_lmcs", "mh_ctx_get_lmcs", "mh_blake3", "mh_verify_lmcs", "mh_grind_bytes",
     "mh_rccl_unique_id", "mh_comm_create_rccl", "mh_comm_destroy", "mh_comm_selftest",
     "mh_local_fabric_create", "mh_local_fabric_destroy", "mh_local_fabric_abort", "mh_comm_create_local",
+    "mh_miden_load", "mh_miden_free", "mh_prove_miden", "mh_prove_miden_traces", "mh_verify_miden", "mh_miden_pcs_params",
+    "mh_miden_challenger_state", "mh_miden_hash_kernel_digests", "mh_miden_pre_observe", "mh_miden_eval_external", "mh_miden_air_blob",
 ]
 
 # the in-tree cache of precompiled constraint kernels (filled by __graft_entry__.build() / tools/jit_precompile.py); $MH_JIT_CACHE_DIR wins
+# It is consulted READ-ONLY ($MH_JIT_CACHE_RO_DIR): kernels this box has to compile itself (another hiprtc version, another AIR) go to
+# the user's cache ($MH_JIT_CACHE_DIR, default ~/.cache/midenhip), never into the package directory.
 _JIT_CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "jit_cache")
 if os.path.isdir(_JIT_CACHE):
-    os.environ.setdefault("MH_JIT_CACHE_DIR", _JIT_CACHE)
+    os.environ.setdefault("MH_JIT_CACHE_RO_DIR", _JIT_CACHE)
 
 _lib = None
 
@@ -708,6 +712,107 @@ def verify(airs, log_trace_heights, public_values, params, challenger_state, pre
                               C.c_size_t(len(pre_observe)), _ptr(f), C.c_size_t(f.size), _ptr(c), C.c_size_t(c.size // 4),
                               _ptr(proot) if proot is not None else None, ext, None, _ptr(digest), err, C.c_size_t(512))
     return (True, digest) if rc == 0 else (False, err.value.decode())
+
+
+# ---- the Miden VM statement in the library (csrc/miden.cpp): prove_stark's own shape, prover/src/lib.rs:317-355 ---------------------
+class Miden:
+    """mh_miden_load: the three AIRs of `MidenMultiAir` with their lookup programs on a context.  prove(core, chiplets, poseidon2,
+    public_values[32], aux_inputs) -> Proof: host row-major matrices (mh_prove_miden) or Trace objects (mh_prove_miden_traces)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mh_miden_load(ctx.h, C.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+
+    def prove(self, core, chiplets, poseidon2, public_values, aux_inputs, hash_fn="poseidon2"):
+        lib, mats = self.ctx.lib, (core, chiplets, poseidon2)
+        pv, aux = _arr([int(x) for x in public_values]), _arr([int(x) for x in aux_inputs])
+        assert pv.size == 32
+        out = C.c_void_p()
+        if all(isinstance(m, Trace) for m in mats):
+            tr = (C.c_void_p * 3)(*[m.h for m in mats])
+            rc = lib.mh_prove_miden_traces(self.ctx.h, self.h, C.c_int(Ctx.LMCS[hash_fn]), tr, _ptr(pv), _ptr(aux), C.c_size_t(aux.size), C.byref(out))
+        else:
+            hs = [np.ascontiguousarray(m, dtype=np.uint64) for m in mats]
+            lg = [int(m.shape[0]).bit_length() - 1 for m in hs]
+            assert [m.shape[1] for m in hs] == [51, 22, 16] and all(m.shape[0] == 1 << l for m, l in zip(hs, lg))
+            rc = lib.mh_prove_miden(self.ctx.h, self.h, C.c_int(Ctx.LMCS[hash_fn]), _ptr(hs[0]), C.c_int(lg[0]), _ptr(hs[1]), C.c_int(lg[1]),
+                                    _ptr(hs[2]), C.c_int(lg[2]), _ptr(pv), _ptr(aux), C.c_size_t(aux.size), C.byref(out))
+        self.ctx.check(rc)
+        return Proof(lib, out)
+
+    def free(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            self.ctx.lib.mh_miden_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def verify_miden(public_values, aux_inputs, proof_bytes, hash_fn="poseidon2"):
+    """mh_verify_miden (host only): StarkProofData bytes of a Miden proof -> (True, digest) or (False, reason)."""
+    lib = load_library()
+    pv, aux = _arr([int(x) for x in public_values]), _arr([int(x) for x in aux_inputs] or [0])
+    buf = (C.c_uint8 * max(1, len(proof_bytes))).from_buffer_copy(bytes(proof_bytes) or b"\0")
+    digest, err = np.zeros(4, dtype=np.uint64), C.create_string_buffer(512)
+    lib.mh_verify_miden.argtypes = [C.c_int, u64p, u64p, C.c_size_t, C.c_void_p, C.c_size_t, u64p, C.c_char_p, C.c_size_t]
+    rc = lib.mh_verify_miden(Ctx.LMCS[hash_fn], _ptr(pv), _ptr(aux), len(aux_inputs), buf, len(proof_bytes), _ptr(digest), err, 512)
+    return (True, digest) if rc == 0 else (False, err.value.decode())
+
+
+def miden_pre_observe(params, public_values, aux_inputs):
+    """mh_miden_pre_observe: observe_protocol_params + `MidenMultiAir::observe` (56 felts)."""
+    lib = load_library()
+    p = params if isinstance(params, PcsParams) else PcsParams.from_dict(params)
+    pv, aux, out = _arr([int(x) for x in public_values]), _arr([int(x) for x in aux_inputs] or [0]), np.zeros(56, dtype=np.uint64)
+    rc = lib.mh_miden_pre_observe(C.byref(p), _ptr(pv), _ptr(aux), C.c_size_t(len(aux_inputs)), _ptr(out))
+    if rc != 0:
+        raise MidenHipError("mh_miden_pre_observe: malformed public values / aux inputs")
+    return [int(x) for x in out]
+
+
+def miden_hash_kernel_digests(kernel_felts):
+    lib = load_library()
+    k, out = _arr([int(x) for x in kernel_felts] or [0]), np.zeros(4, dtype=np.uint64)
+    if lib.mh_miden_hash_kernel_digests(_ptr(k), C.c_size_t(len(kernel_felts)), _ptr(out)) != 0:
+        raise MidenHipError("mh_miden_hash_kernel_digests: whole words, at most 255 procedures")
+    return [int(x) for x in out]
+
+
+def miden_eval_external(randomness, aux_inputs, aux_values):
+    """mh_miden_eval_external: randomness [(a0, a1), (b0, b1)], aux_values = per AIR [(c0, c1)] -> the assertion (c0, c1), or None
+    when the library refuses the shape / meets a zero denominator."""
+    lib = load_library()
+    rnd = _arr([int(x) for pair in randomness for x in pair])
+    aux = _arr([int(x) for x in aux_inputs] or [0])
+    vals = [_arr([int(x) for pair in v for x in pair] or [0]) for v in aux_values]
+    vp = (u64p * len(vals))(*[_ptr(v) for v in vals])
+    nv = (C.c_size_t * len(vals))(*[len(v) for v in aux_values])
+    out = np.zeros(2, dtype=np.uint64)
+    rc = lib.mh_miden_eval_external(_ptr(rnd), _ptr(aux), C.c_size_t(len(aux_inputs)), vp, nv, C.c_int(len(vals)), _ptr(out))
+    return (int(out[0]), int(out[1])) if rc == 0 else None
+
+
+def miden_constants():
+    """(pcs params dict, challenger state) of the production configuration as the library holds them."""
+    lib = load_library()
+    p, st = PcsParams(), np.zeros(12, dtype=np.uint64)
+    lib.mh_miden_pcs_params(C.byref(p))
+    lib.mh_miden_challenger_state(_ptr(st))
+    return {k: int(getattr(p, k)) for k, _ in PcsParams._fields_}, [int(x) for x in st]
+
+
+def miden_air_blob(which):
+    lib = load_library()
+    w, n = u64p(), C.c_size_t()
+    assert lib.mh_miden_air_blob(C.c_int(which), C.byref(w), C.byref(n)) == 0
+    return np.ctypeslib.as_array(w, shape=(n.value,)).copy()
 
 
 def jit_precompile(blob, cache_dir=None):

@@ -37,7 +37,17 @@ FI u64 gl_reduce128(u64 hi, u64 lo) {
   if (r < t1) r += GL_EPS;
   return r >= GL_P ? r - GL_P : r;
 }
-FI u64 gl_mul_c(u64 a, u64 b) { return gl_reduce128(__umul64hi(a, b), a * b); }
+typedef unsigned __int128 u128;
+FI u64 gl_reduce128_lazy(u64 hi, u64 lo) {  // gl_reduce128 without its last line: any representative < 2^64
+  u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+  u64 t0 = lo - hi_hi;
+  if (lo < hi_hi) t0 -= GL_EPS;
+  u64 t1 = (hi_lo << 32) - hi_lo;
+  u64 r = t0 + t1;
+  if (r < t1) r += GL_EPS;
+  return r;
+}
+FI u64 gl_mul_c(u64 a, u64 b) { const u128 p = (u128)a * b; return gl_reduce128((u64)(p >> 64), (u64)p); }  // one 64 x 64 -> 128 product (four v_mad_u64_u32), not __umul64hi + a second low product
 #ifndef MH_JIT_ASM_MUL
 #define MH_JIT_ASM_MUL 2  // 0: plain C products, 1: the asm product everywhere, 2: for base-field gates only (measured: core AIR 19.6 / 19.9 / 18.7 ms)
 #endif
@@ -101,6 +111,9 @@ FI e2 e2_mulf(e2 a, u64 b) { return {gl_mul_ef(a.c0, b), gl_mul_ef(a.c1, b)}; }
 #ifndef MH_JIT_FOLD
 #define MH_JIT_FOLD 1
 #endif
+#ifndef MH_JIT_FOLDV
+#define MH_JIT_FOLDV 1  // 0: the limb-by-limb recombination of round 4
+#endif
 struct fold_acc { u64 w0, w1, w2, w3, w4, w5; };
 // acc + a * x as ONE v_mad_u64_u32 with the uniform limb in an SGPR; inline asm because LLVM reassociates the C form of these sums
 // (every product of the chunk then stays live to the end: 512 VGPRs and scratch)
@@ -115,7 +128,8 @@ FI void fold_limbs(fold_acc& f, u64 alpha, u64 x) {  // three 22-bit limbs of al
   fold_mad(f.w0, a0, x0); fold_mad(f.w1, a1, x0); fold_mad(f.w2, a2, x0);
   fold_mad(f.w3, a0, x1); fold_mad(f.w4, a1, x1); fold_mad(f.w5, a2, x1);
 }
-FI u64 fold_value(const fold_acc& f) {  // w0 + 2^22 w1 + 2^44 w2 + 2^32 w3 + 2^54 w4 + 2^76 w5 mod p, canonical
+FI u64 fold_value(const fold_acc& f) {  // w0 + 2^22 w1 + 2^44 w2 + 2^32 (w3 + 2^22 w4 + 2^44 w5) mod p, canonical
+#if MH_JIT_FOLDV == 0
   u64 r = gl_reduce128(0, f.w0);
   r = gl_add(r, gl_reduce128(f.w1 >> 42, f.w1 << 22));
   r = gl_add(r, gl_reduce128(f.w2 >> 20, f.w2 << 44));
@@ -123,16 +137,93 @@ FI u64 fold_value(const fold_acc& f) {  // w0 + 2^22 w1 + 2^44 w2 + 2^32 w3 + 2^
   r = gl_add(r, gl_reduce128(f.w4 >> 10, f.w4 << 54));
   r = gl_add(r, gl_mul_c(gl_reduce128(0, f.w5), GL_EPS << 12));  // 2^76 = 2^12 (2^64 mod p)
   return r;
+#else
+  // two 108-bit sums in 128-bit arithmetic, the upper one reduced and shifted into the lower, ONE canonical reduction (the six
+  // reductions and five modular additions of the form above were 139 VALU instructions per call)
+  const u128 lo = (u128)f.w0 + ((u128)f.w1 << 22) + ((u128)f.w2 << 44);
+  const u128 up = (u128)f.w3 + ((u128)f.w4 << 22) + ((u128)f.w5 << 44);
+  const u64 u = gl_reduce128_lazy((u64)(up >> 64), (u64)up);
+  const u128 v = lo + ((u128)u << 32);   // < 2^108 + 2^96
+  return gl_reduce128((u64)(v >> 64), (u64)v);
+#endif
 }
+// ---- any-representative ("lazy") arithmetic: MH_JIT_LAZYVAL (generator switch, default on) ----
+// Between gates a value is ANY u64 congruent to it mod p; only what leaves the chunk as a field element (the fold's accumulator, the
+// outputs of a lookup program) is canonical.  A canonicalising addition costs two compares and two selects more than the carry fix-up
+// needs, a canonicalising product a compare, a subtraction and two selects.  `_c` forms take one operand known (at code-generation
+// time) to be canonical -- a trace cell, a constant, a uniform value -- for which a single fix-up is exact:
+//   a + c, c <= p - 1:  a wrapped sum is <= 2^64 - 2^32 - 1, so + eps cannot wrap again;
+//   a - c, c <= p - 1:  a wrapped difference is >= 2^32, so - eps cannot wrap again.
+// The `_g` forms (both operands arbitrary) apply the fix-up twice.
+FI u64 lz_canon(u64 a) { return a >= GL_P ? a - GL_P : a; }
+FI u64 lz_add_c(u64 a, u64 c) { u64 s = a + c; return s < a ? s + GL_EPS : s; }
+FI u64 lz_add_g(u64 a, u64 b) { u64 s = a + b; if (s < a) { s += GL_EPS; if (s < GL_EPS) s += GL_EPS; } return s; }
+FI u64 lz_sub_c(u64 a, u64 c) { u64 d = a - c; return a < c ? d - GL_EPS : d; }
+FI u64 lz_sub_g(u64 a, u64 b) { u64 d = a - b; if (a < b) { const u64 e = d - GL_EPS; d = d < GL_EPS ? e - GL_EPS : e; } return d; }
+#define lz_reduce128 gl_reduce128_lazy
+FI u64 lz_mul_c(u64 a, u64 b) { const u128 p = (u128)a * b; return lz_reduce128((u64)(p >> 64), (u64)p); }
+#if MH_JIT_ASM_MUL
+FI u64 lz_mul_asm(u64 a, u64 b) {  // the 13 instructions of gl_mul above, without the canonicalisation behind them
+  u64 p00, m, hi, t, d0, d1, d2, d3, d4, d5, cm, k1, k2, c1, bb, bw, c3;
+  u32 w1, accl, acch, rl, rh;
+  const u32 zero = 0;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p00), "=s"(d0) : "v"(jlo(a)), "v"(jlo(b)));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(m), "=s"(d1) : "v"(jlo(a)), "v"(jhi(b)));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m), "=s"(cm) : "v"(jhi(a)), "v"(jlo(b)), "0"(m));
+  asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(w1), "=s"(k1) : "v"(jhi(p00)), "v"(jlo(m)));
+  asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(accl), "=s"(k2) : "v"(jhi(m)), "s"(k1));
+  const u64 k3 = cm | k2;
+  asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(acch), "=s"(d2) : "v"(zero), "s"(k3));
+  const u64 acc = ((u64)acch << 32) | accl;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(hi), "=s"(d3) : "v"(jhi(a)), "v"(jhi(b)), "v"(acc));
+  const u64 lo = ((u64)w1 << 32) | jlo(p00);
+  asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t), "=s"(c1) : "v"(jlo(hi)), "v"(lo));
+  asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(rl), "=s"(bb) : "v"(jlo(t)), "v"(jhi(hi)), "s"(c1));
+  asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh), "=s"(d4) : "v"(jhi(t)), "s"(c1));
+  asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh), "=s"(bw) : "0"(rh), "s"(bb));
+  asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rl), "=s"(c3) : "0"(rl), "s"(bw));
+  const u64 mk = bw & ~c3;
+  asm("v_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh), "=s"(d5) : "0"(rh), "s"(mk));
+  return ((u64)rh << 32) | rl;
+}
+#endif
+#if MH_JIT_ASM_MUL
+#define lz_mul lz_mul_asm
+#else
+#define lz_mul lz_mul_c
+#endif
+#if MH_JIT_ASM_MUL == 1
+#define lz_mul_ef lz_mul_asm
+#else
+#define lz_mul_ef lz_mul_c
+#endif
+FI u64 lz_mul7(u64 a) {  // 7 a: a 67-bit integer, top limb < 7
+  const u128 p = (u128)a * 7u;
+  const u64 t1 = (u64)(p >> 64) * GL_EPS, r = (u64)p + t1;
+  return r < t1 ? r + GL_EPS : r;
+}
+template <int CA, int CB> FI u64 lz_add(u64 a, u64 b) { return CB ? lz_add_c(a, b) : CA ? lz_add_c(b, a) : lz_add_g(a, b); }
+template <int CB> FI u64 lz_sub(u64 a, u64 b) { return CB ? lz_sub_c(a, b) : lz_sub_g(a, b); }
+template <int CA> FI u64 lz_neg(u64 a) { return CA ? GL_P - a : lz_sub_g(0, a); }   // p - 0 = p: a representative of 0
+template <int CA, int CB> FI e2 lz_e2_add(e2 a, e2 b) { return {lz_add<CA, CB>(a.c0, b.c0), lz_add<CA, CB>(a.c1, b.c1)}; }
+template <int CA, int CB> FI e2 lz_e2_sub(e2 a, e2 b) { return {lz_sub<CB>(a.c0, b.c0), lz_sub<CB>(a.c1, b.c1)}; }
+template <int CA> FI e2 lz_e2_neg(e2 a) { return {lz_neg<CA>(a.c0), lz_neg<CA>(a.c1)}; }
+template <int CA, int CB> FI e2 lz_e2_addf(e2 a, u64 b) { return {lz_add<CA, CB>(a.c0, b), a.c1}; }
+template <int CA, int CB> FI e2 lz_e2_subf(e2 a, u64 b) { return {lz_sub<CB>(a.c0, b), a.c1}; }
+template <int CA, int CB> FI e2 lz_e2_fsub(u64 a, e2 b) { return {lz_sub<CB>(a, b.c0), lz_neg<CB>(b.c1)}; }
+FI e2 lz_e2_mul(e2 a, e2 b) {  // schoolbook: four products, two general additions, one times-seven
+  return {lz_add_g(lz_mul_ef(a.c0, b.c0), lz_mul7(lz_mul_ef(a.c1, b.c1))), lz_add_g(lz_mul_ef(a.c0, b.c1), lz_mul_ef(a.c1, b.c0))};
+}
+FI e2 lz_e2_mulf(e2 a, u64 b) { return {lz_mul_ef(a.c0, b), lz_mul_ef(a.c1, b)}; }
 struct JitArgs {
   const u64* main_lde; const u64* aux_lde; const u64* prep_lde; u64* spill; u64* acc; const u64* tw; const u64* coset_tab;
   const u64* inv_first; const u64* inv_last; const u64* periodic; const u64* publics; const u64* randomness;
-  const u64* aux_values; const u64* alpha_pows;
+  const u64* aux_values; const u64* alpha_pows; const u64* uni;
   u64 wh_inv, q0, q_count, spill_stride;
   int log_n, log_cosets, log_d, log_dl, jc_shift;
   u32 t0, periodic_rows;
 };
-static_assert(sizeof(JitArgs) == 176, "JitArgs layout");
+static_assert(sizeof(JitArgs) == 184, "JitArgs layout");
 )SRC";
 
 struct Ev {
@@ -238,7 +329,9 @@ struct JitProgram {
   mh_ctx* ctx = nullptr;
   std::vector<hipModule_t> modules;
   std::vector<hipFunction_t> fns;
+  hipFunction_t fn_uni = nullptr;  // fills JitArgs::uni (null: the DAG has no uniform gate)
   size_t n_spill = 0;  // u64 slots per point crossing chunk boundaries
+  size_t n_uni = 0;    // u64 entries of the uniform table
 };
 
 void jit_program_free(JitProgram* p) {
@@ -265,9 +358,28 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
   const int mode = ir.outputs ? 1 : env_int("MH_JIT", -1);  // 0: never, 1: always, default: large DAGs only
   if (mode == 0) return nullptr;
   const std::vector<DagNode>& nodes = ir.nodes;
-  auto interior = [&](uint32_t id) { return dag_is_gate(nodes[id].op); };
+  // ---- uniform gates: no trace cell, periodic value or selector in their cone (powers of the LogUp challenges, bus prefixes, sums of
+  // public values) -- the same for every point.  They are evaluated ONCE per call by the program's uniform kernel into a table
+  // (JitArgs::uni) and are leaves for everything below: never computed per point, never spilled.  MH_JIT_UNI=0: per point, as before.
+  std::vector<char> uniform(nodes.size(), 0);
+  for (size_t i = 0; i < nodes.size(); i++) {
+    const DagNode& nd = nodes[i];
+    if (nd.op == DOP_CONST || nd.op == DOP_PUBLIC || nd.op == DOP_RANDOMNESS || nd.op == DOP_AUX_VALUE) uniform[i] = 1;
+    else if (dag_is_gate(nd.op)) uniform[i] = uniform[nd.a] && (nd.op == DOP_NEG || uniform[nd.b]);
+  }
+  const bool use_uni = env_int("MH_JIT_UNI", 1) != 0;
+  const bool lazy_vals = env_int("MH_JIT_LAZYVAL", 1) != 0;  // any-representative arithmetic between gates (prelude: lz_*)
+  std::vector<int32_t> uni_slot(nodes.size(), -1);
+  size_t n_uni = 0;
+  if (use_uni)
+    for (size_t i = 0; i < nodes.size(); i++)
+      if (ir.live[i] && dag_is_gate(nodes[i].op) && uniform[i]) {
+        uni_slot[i] = (int32_t)n_uni;
+        n_uni += nodes[i].ext ? 2 : 1;
+      }
+  auto interior = [&](uint32_t id) { return dag_is_gate(nodes[id].op) && uni_slot[id] < 0; };
   size_t n_gates = 0;
-  for (size_t i = 0; i < nodes.size(); i++) n_gates += ir.live[i] && interior((uint32_t)i);
+  for (size_t i = 0; i < nodes.size(); i++) n_gates += ir.live[i] && dag_is_gate(nodes[i].op);
   if (mode != 1 && n_gates < (size_t)env_int("MH_JIT_MIN_GATES", 400)) return nullptr;
 
   // ---- sums of (uniform EF coefficient) x (base value): LogUp message encodings `prefix + sum_i beta^i f_i` ----
@@ -277,7 +389,7 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
   // additions per term (72 VALU instructions -> 16, + ~130 per sum).  An EF ADD tree (through single-use ADD nodes) with at least
   // $MH_JIT_DOT (default 3, 0 = off) such terms becomes one "dot" gate: its operands are the terms' (coefficient, value) pairs and the
   // other addends; the ADD and MUL nodes inside are absorbed (never emitted).  Exact: the same field value, canonical on exit.
-  std::vector<char> uniform(nodes.size(), 0), absorbed(nodes.size(), 0);
+  std::vector<char> absorbed(nodes.size(), 0);
   struct Dot {
     std::vector<std::pair<uint32_t, uint32_t>> terms;  // (uniform EF coefficient, base value)
     std::vector<uint32_t> others;
@@ -285,11 +397,6 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
   std::vector<int32_t> dot_of(nodes.size(), -1);
   std::vector<Dot> dots;
   {
-    for (size_t i = 0; i < nodes.size(); i++) {
-      const DagNode& nd = nodes[i];
-      if (nd.op == DOP_CONST || nd.op == DOP_PUBLIC || nd.op == DOP_RANDOMNESS || nd.op == DOP_AUX_VALUE) uniform[i] = 1;
-      else if (dag_is_gate(nd.op)) uniform[i] = uniform[nd.a] && (nd.op == DOP_NEG || uniform[nd.b]);
-    }
     const int min_terms = env_int("MH_JIT_DOT", 3);
     std::vector<uint32_t> uses(nodes.size(), 0);
     for (size_t i = 0; i < nodes.size(); i++)
@@ -377,19 +484,69 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
   const int budget = std::max(16, env_int("MH_JIT_CHUNK", 320));
   std::vector<Chunk> chunks;
   {
-    size_t lo = 0;
-    int acc = 0;
-    for (size_t i = 0; i < seq.size(); i++) {
-      acc += cost(seq[i]);
-      // never separate a node from the fold that consumes it
-      const bool fold_next = i + 1 < seq.size() && seq[i + 1].fold_k >= 0;
-      if (acc >= budget && !fold_next) {
-        chunks.push_back({lo, i + 1, {}, {}, {}});
-        lo = i + 1;
-        acc = 0;
+    // crossing[i] = u64 words alive across a cut after seq[i]: computed at or before i, used after i.  A cut is placed where this is
+    // smallest inside a window around the budget ($MH_JIT_CUTWIN percent, 0 = cut at the budget): every crossing value is either
+    // recomputed or goes through a spill plane (16 bytes of traffic per point and word).
+    std::vector<long> crossing(seq.size() + 1, 0);
+    {
+      std::vector<long> def_pos(nodes.size(), -1), last_use(nodes.size(), -1);
+      std::vector<uint32_t> o;
+      for (size_t i = 0; i < seq.size(); i++) {
+        const uint32_t id = seq[i].node;
+        if (seq[i].fold_k >= 0) { if (interior(id)) last_use[id] = (long)i; continue; }
+        def_pos[id] = (long)i;
+        ops(id, o);
+        for (uint32_t c : o)
+          if (interior(c)) last_use[c] = (long)i;
+      }
+      std::vector<long> diff(seq.size() + 2, 0);
+      for (size_t id = 0; id < nodes.size(); id++)
+        if (def_pos[id] >= 0 && last_use[id] > def_pos[id]) {
+          const long w = nodes[id].ext ? 2 : 1;
+          diff[def_pos[id]] += w;       // alive across cuts after positions def .. last_use - 1
+          diff[last_use[id]] -= w;
+        }
+      long run = 0;
+      for (size_t i = 0; i < seq.size(); i++) { run += diff[i]; crossing[i] = run; }
+    }
+    const int win = std::max(0, env_int("MH_JIT_CUTWIN", 25));
+    const long lo_b = (long)budget * (100 - win) / 100, hi_b = (long)budget * (100 + win) / 100;
+    // dynamic programme over the cut positions: best[i] = smallest sum of crossings with a cut after seq[i - 1], every chunk's cost
+    // inside [lo_b, hi_b] (the last one from lo_b / 2); fewest crossings overall, not greedily chunk by chunk
+    const size_t S = seq.size();
+    std::vector<long> pre(S + 1, 0);
+    for (size_t i = 0; i < S; i++) pre[i + 1] = pre[i] + cost(seq[i]);
+    const long INF = 1L << 60;
+    std::vector<long> best(S + 1, INF);
+    std::vector<size_t> from(S + 1, 0);
+    best[0] = 0;
+    for (size_t i = 1; i <= S; i++) {
+      const bool fold_next = i < S && seq[i].fold_k >= 0;  // never separate a node from the fold that consumes it
+      if (fold_next) continue;
+      for (size_t j = i; j-- > 0;) {
+        const long c = pre[i] - pre[j];
+        if (c > hi_b && j + 1 < i) break;   // a single over-budget event still forms a chunk
+        if (best[j] >= INF) continue;
+        if (c < (i != S ? lo_b : lo_b / 2) && !(i == S && j == 0)) continue;  // the last chunk may be half a window short, not a stub
+        const long v = best[j] + (i < S ? crossing[i - 1] : 0);
+        if (v < best[i]) { best[i] = v; from[i] = j; }
       }
     }
-    if (lo < seq.size()) chunks.push_back({lo, seq.size(), {}, {}, {}});
+    if (best[S] >= INF) {  // no partition inside the window (degenerate budgets): cut at the budget
+      size_t lo = 0;
+      long acc = 0;
+      for (size_t i = 0; i < S; i++) {
+        acc += cost(seq[i]);
+        const bool fold_next = i + 1 < S && seq[i + 1].fold_k >= 0;
+        if (acc >= budget && !fold_next) { chunks.push_back({lo, i + 1, {}, {}, {}}); lo = i + 1; acc = 0; }
+      }
+      if (lo < S) chunks.push_back({lo, S, {}, {}, {}});
+    } else {
+      std::vector<size_t> cuts;
+      for (size_t i = S; i > 0; i = from[i]) cuts.push_back(i);
+      size_t lo = 0;
+      for (size_t k = cuts.size(); k-- > 0;) { chunks.push_back({lo, cuts[k], {}, {}, {}}); lo = cuts[k]; }
+    }
   }
   const size_t n_chunks = chunks.size();
   // ---- what each chunk evaluates, and which values cross chunk boundaries ----
@@ -402,7 +559,7 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
   for (size_t ci = 0; ci < n_chunks; ci++)
     for (size_t i = chunks[ci].ev_lo; i < chunks[ci].ev_hi; i++)
       if (seq[i].fold_k < 0) def_chunk[seq[i].node] = (int32_t)ci;
-  const int recomp_max = env_int("MH_JIT_RECOMP", 160);
+  const int recomp_max = env_int("MH_JIT_RECOMP", 250);  // round-5 sweep with the lazy generator, core AIR: 160 / 200 / 250 / 300 / 400 -> 15.6 / 15.6 / 14.5 / 15.1 / 15.3 ms
   auto valu_cost = [&](uint32_t id) -> int {  // rough VALU instructions of one gate
     const DagNode& nd = nodes[id];
     if (dot_of[id] >= 0) return 130 + 16 * (int)dots[dot_of[id]].terms.size() + 12 * (int)dots[dot_of[id]].others.size();
@@ -522,6 +679,12 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
     fprintf(stderr, "[mh jit] %zu chunks, %zu gates, %zu recomputed, spill planes %zu, per point: %zu spill loads, %zu spill stores; %zu dot gates with %zu terms\n",
             n_chunks, seq.size(), n_recomputed, n_spill, n_loads, n_stores, dots.size(), n_terms);
   }
+  // ---- which values are canonical (< p) by construction: every leaf and table entry; with lazy arithmetic no gate result is,
+  // except a dot gate without further addends (fold_value ends canonical) ----
+  std::vector<char> canon(nodes.size(), 1);
+  if (lazy_vals)
+    for (size_t i = 0; i < nodes.size(); i++)
+      if (interior((uint32_t)i)) canon[i] = dot_of[i] >= 0 && dots[dot_of[i]].others.empty();
   // ---- source per chunk ----
   const bool lazy_loads = env_int("MH_JIT_LAZY", 1) != 0;
   char buf[256];
@@ -592,6 +755,11 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
           return buf;
         default: break;
       }
+      if (uni_slot[id] >= 0) {  // a uniform gate: from the table the uniform kernel filled
+        if (nd.ext) snprintf(buf, sizeof buf, "e2{a.uni[%d], a.uni[%d]}", uni_slot[id], uni_slot[id] + 1);
+        else snprintf(buf, sizeof buf, "a.uni[%d]", uni_slot[id]);
+        return buf;
+      }
       snprintf(buf, sizeof buf, "v%u", id);
       return buf;  // computed, recomputed or loaded earlier in this chunk (items)
     };
@@ -614,11 +782,12 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
         const std::string x = ref(id);
         if (ir.outputs) {  // output k -> planes 2k (c0) and 2k+1 (c1, EF outputs only), rows r (single coset)
           const int k = it.fold_k;
+          const char* cf = canon[id] ? "" : "lz_canon";  // what leaves the program is a field element
           if (nd.ext)
-            body << "  a.acc[(" << 2 * k << "ull << a.log_n) + r] = " << x << ".c0; a.acc[(" << 2 * k + 1 << "ull << a.log_n) + r] = " << x
-                 << ".c1;\n";
+            body << "  { const e2 o = " << x << "; a.acc[(" << 2 * k << "ull << a.log_n) + r] = " << cf << "(o.c0); a.acc[(" << 2 * k + 1
+                 << "ull << a.log_n) + r] = " << cf << "(o.c1); }\n";
           else
-            body << "  a.acc[(" << 2 * k << "ull << a.log_n) + r] = " << x << ";\n";
+            body << "  a.acc[(" << 2 * k << "ull << a.log_n) + r] = " << cf << "(" << x << ");\n";
           continue;
         }
         snprintf(buf, sizeof buf, "e2{a.alpha_pows[%d], a.alpha_pows[%d]}", 2 * it.fold_k, 2 * it.fold_k + 1);
@@ -649,9 +818,16 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
                << "b, cu.c1, cb); }\n";
         }
         std::string rhs = "e2{fold_value(d" + std::to_string(id) + "a), fold_value(d" + std::to_string(id) + "b)}";
+        bool rc = true;  // the running sum is canonical so far
         for (uint32_t o : d.others) {
           const std::string O = ref(o);
-          rhs = (nodes[o].ext ? "e2_add(" : "e2_addf(") + rhs + ", " + O + ")";
+          if (lazy_vals) {
+            const std::string tp = std::string("<") + (rc ? "1" : "0") + ", " + (canon[o] ? "1" : "0") + ">(";
+            rhs = (nodes[o].ext ? "lz_e2_add" : "lz_e2_addf") + tp + rhs + ", " + O + ")";
+            rc = false;
+          } else {
+            rhs = (nodes[o].ext ? "e2_add(" : "e2_addf(") + rhs + ", " + O + ")";
+          }
         }
         body << "  const e2 v" << id << " = " << rhs << ";\n";
         if (spilled[id] && def_chunk[id] == (int32_t)ci)
@@ -662,7 +838,25 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
       const std::string A = ref(nd.a);
       const bool ea = nodes[nd.a].ext;
       std::string rhs;
-      if (nd.op == DOP_NEG) {
+      if (lazy_vals) {
+        const std::string ca = canon[nd.a] ? "1" : "0";
+        if (nd.op == DOP_NEG) {
+          rhs = (ea ? "lz_e2_neg<" : "lz_neg<") + ca + ">(" + A + ")";
+        } else {
+          const std::string Bv = ref(nd.b);
+          const bool eb = nodes[nd.b].ext;
+          const std::string cb = canon[nd.b] ? "1" : "0", tab = "<" + ca + ", " + cb + ">(", tba = "<" + cb + ", " + ca + ">(";
+          if (nd.op == DOP_ADD)
+            rhs = ea && eb ? "lz_e2_add" + tab + A + ", " + Bv + ")" : ea ? "lz_e2_addf" + tab + A + ", " + Bv + ")"
+                  : eb     ? "lz_e2_addf" + tba + Bv + ", " + A + ")" : "lz_add" + tab + A + ", " + Bv + ")";
+          else if (nd.op == DOP_SUB)
+            rhs = ea && eb ? "lz_e2_sub" + tab + A + ", " + Bv + ")" : ea ? "lz_e2_subf" + tab + A + ", " + Bv + ")"
+                  : eb     ? "lz_e2_fsub" + tab + A + ", " + Bv + ")" : "lz_sub<" + cb + ">(" + A + ", " + Bv + ")";
+          else
+            rhs = ea && eb ? "lz_e2_mul(" + A + ", " + Bv + ")" : ea ? "lz_e2_mulf(" + A + ", " + Bv + ")"
+                  : eb     ? "lz_e2_mulf(" + Bv + ", " + A + ")" : "lz_mul(" + A + ", " + Bv + ")";
+        }
+      } else if (nd.op == DOP_NEG) {
         rhs = (ea ? "e2_neg(" : "gl_neg(") + A + ")";
       } else {
         const std::string Bv = ref(nd.b);
@@ -715,8 +909,49 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
     src << "}\n";
     ch.src = src.str();
   }
+  // ---- the uniform kernel: every live uniform gate, in node order (operands precede their gate), canonical arithmetic, one lane ----
+  if (n_uni) {
+    std::ostringstream src;
+    src << JIT_PRELUDE << "extern \"C\" __global__ void mh_jit_chunk(JitArgs a) {\n  if (blockIdx.x | threadIdx.x) return;\n  u64* U = (u64*)a.uni;\n";
+    auto uref = [&](uint32_t id) -> std::string {
+      const DagNode& nd = nodes[id];
+      switch (nd.op) {
+        case DOP_CONST: snprintf(buf, sizeof buf, "0x%llxULL", (unsigned long long)nd.c); return buf;
+        case DOP_PUBLIC: snprintf(buf, sizeof buf, "a.publics[%u]", nd.a); return buf;
+        case DOP_RANDOMNESS: snprintf(buf, sizeof buf, "e2{a.randomness[%u], a.randomness[%u]}", 2 * nd.a, 2 * nd.a + 1); return buf;
+        case DOP_AUX_VALUE: snprintf(buf, sizeof buf, "e2{a.aux_values[%u], a.aux_values[%u]}", 2 * nd.a, 2 * nd.a + 1); return buf;
+        default: break;
+      }
+      snprintf(buf, sizeof buf, "u%u", id);
+      return buf;
+    };
+    for (size_t i = 0; i < nodes.size(); i++) {
+      if (uni_slot[i] < 0) continue;
+      const DagNode& nd = nodes[i];
+      const std::string A = uref(nd.a);
+      const bool ea = nodes[nd.a].ext;
+      std::string rhs;
+      if (nd.op == DOP_NEG) {
+        rhs = (ea ? "e2_neg(" : "gl_neg(") + A + ")";
+      } else {
+        const std::string Bv = uref(nd.b);
+        const bool eb = nodes[nd.b].ext;
+        const char* f2 = nd.op == DOP_ADD ? "add" : nd.op == DOP_SUB ? "sub" : "mul";
+        if (ea && eb) rhs = std::string("e2_") + f2 + "(" + A + ", " + Bv + ")";
+        else if (!ea && !eb) rhs = std::string("gl_") + f2 + (nd.op == DOP_MUL ? "_c(" : "(") + A + ", " + Bv + ")";
+        else if (nd.op == DOP_SUB) rhs = ea ? "e2_subf(" + A + ", " + Bv + ")" : "e2_fsub(" + A + ", " + Bv + ")";
+        else rhs = std::string("e2_") + f2 + "f(" + (ea ? A + ", " + Bv : Bv + ", " + A) + ")";
+      }
+      src << "  const " << (nd.ext ? "e2" : "u64") << " u" << i << " = " << rhs << ";\n";
+      if (nd.ext) src << "  U[" << uni_slot[i] << "] = u" << i << ".c0; U[" << uni_slot[i] + 1 << "] = u" << i << ".c1;\n";
+      else src << "  U[" << uni_slot[i] << "] = u" << i << ";\n";
+    }
+    src << "}\n";
+    chunks.push_back({0, 0, src.str(), {}, {}});  // compiled and cached with the chunks; launched once per call, ahead of them
+  }
+  const size_t n_kernels = chunks.size();
   if (const char* dir = getenv("MH_JIT_DUMP")) {
-    for (size_t ci = 0; ci < n_chunks; ci++) {
+    for (size_t ci = 0; ci < n_kernels; ci++) {
       std::ofstream f(std::string(dir) + "/chunk" + std::to_string(ci) + ".hip");
       f << chunks[ci].src;
     }
@@ -726,8 +961,10 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
 
   // ---- compile the chunks in parallel (cached on disk by source hash) ----
   const std::string cdir = cache_dir();
+  const char* ro_env = getenv("MH_JIT_CACHE_RO_DIR");
+  const std::string rodir = ro_env && *ro_env && cdir != ro_env && !compile_only ? ro_env : "";  // mh_jit_precompile fills ITS directory
   std::atomic<size_t> next{0};
-  size_t n_limit = n_chunks;  // workers take chunk indices below this bound
+  size_t n_limit = n_kernels;  // workers take chunk indices below this bound
   std::atomic<bool> failed{false};
   std::string first_error;
   std::mutex err_mu;
@@ -737,8 +974,11 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
       if (ci >= n_limit || failed.load()) return;
       Chunk& ch = chunks[ci];
       try {
-        const std::string cpath = cdir.empty() ? "" : cdir + "/" + cache_key(ch.src);
-        if (!cpath.empty() && !ch.no_cache && cache_load(cpath, ch.code)) {
+        const std::string key = cache_key(ch.src);
+        const std::string cpath = cdir.empty() ? "" : cdir + "/" + key;
+        // $MH_JIT_CACHE_RO_DIR: a read-only cache consulted first and never written (the kernels shipped with the package: a box whose
+        // hiprtc differs simply misses there and compiles into the writable cache, not into the package directory)
+        if (!ch.no_cache && ((!rodir.empty() && cache_load(rodir + "/" + key, ch.code)) || (!cpath.empty() && cache_load(cpath, ch.code)))) {
           ch.from_cache = true;
           continue;
         }
@@ -770,7 +1010,7 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
     }
   };
   {
-    unsigned nt = std::max(1u, std::min<unsigned>((unsigned)n_chunks, std::min(64u, std::thread::hardware_concurrency())));
+    unsigned nt = std::max(1u, std::min<unsigned>((unsigned)n_kernels, std::min(64u, std::thread::hardware_concurrency())));
     nt = (unsigned)std::max(1, env_int("MH_JIT_THREADS", (int)nt));
     std::vector<std::thread> th;
     for (unsigned i = 0; i < nt; i++) th.emplace_back(worker);
@@ -778,14 +1018,15 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
   }
   if (failed.load()) throw MhError(MH_ERR_INTERNAL, first_error);
   if (compile_only) {
-    g_jit_last_chunks = (int)n_chunks;
+    g_jit_last_chunks = (int)n_kernels;
     return nullptr;
   }
   std::unique_ptr<JitProgram> prog(new JitProgram());
   prog->ctx = ctx;
   prog->n_spill = n_spill;
+  prog->n_uni = n_uni;
   try {
-    for (size_t ci = 0; ci < n_chunks; ci++) {
+    for (size_t ci = 0; ci < n_kernels; ci++) {
       hipModule_t m = nullptr;
       hipFunction_t f = nullptr;
       hipError_t e = hipModuleLoadData(&m, chunks[ci].code.data());
@@ -810,7 +1051,8 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
         HIP_CHECK(e);
       }
       prog->modules.push_back(m);
-      prog->fns.push_back(f);
+      if (ci < n_chunks) prog->fns.push_back(f);
+      else prog->fn_uni = f;
     }
   } catch (...) {
     jit_program_free(prog.release());
@@ -820,13 +1062,20 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
 }
 
 void jit_quotient_run(mh_ctx* c, const JitProgram* p, JitArgs a, size_t total) {
-  // Points are swept in blocks of 2^21 so that the spill planes stay bounded (n_spill * 16 MB) for any trace
-  // height.  (Measured on a 6.5 k-gate system at 2^23 points: 2^16-point blocks 72 ms, 2^18 45.8, 2^20 45.3,
-  // one block 43.4 -- cache-sized blocks do not pay, launches do.)
-  const size_t block = std::min(total, (size_t)1 << std::max(10, env_int("MH_JIT_BLOCK_LOG", 21)));
+  // Points are swept in blocks so that the spill planes stay bounded (n_spill * 32 MB) for any trace height.  Cache-sized blocks do
+  // not pay: the cells and planes of a 2^17 / 2^18-point block fit the 256 MB Infinity Cache, yet the core AIR's quotient takes
+  // 19.5 / 16.8 ms against 15.6 / 14.5 / 14.3 / 14.2 ms with 2^19 / 2^21 / 2^22 / 2^23-point blocks (round 5; tails of half-filled
+  // launches cost more than the re-reads save).
+  const size_t block = std::min(total, (size_t)1 << std::max(10, env_int("MH_JIT_BLOCK_LOG", 22)));
   DevBuf spill(std::max<size_t>(1, p->n_spill) * block * 8);
   a.spill = spill.u();
   a.spill_stride = block;
+  DevBuf uni(std::max<size_t>(1, p->n_uni) * 8);
+  a.uni = uni.u();
+  if (p->fn_uni) {
+    void* params[] = {&a};
+    HIP_CHECK(hipModuleLaunchKernel(p->fn_uni, 1, 1, 1, 64, 1, 1, 0, c->stream, params, nullptr));
+  }
   for (size_t q0 = 0; q0 < total; q0 += block) {
     a.q0 = q0;
     a.q_count = std::min(block, total - q0);

@@ -31,13 +31,14 @@ struct JitArgs {
   const u64* randomness;
   const u64* aux_values;
   const u64* alpha_pows;
+  const u64* uni;       // values of the DAG's uniform gates (no trace cell in their cone), filled once per call by the program's uniform kernel
   u64 wh_inv;
   u64 q0, q_count;      // this launch covers points q0 .. q0 + q_count - 1
   u64 spill_stride;
   int log_n, log_cosets, log_d, log_dl, jc_shift;
   u32 t0, periodic_rows;
 };
-static_assert(sizeof(JitArgs) == 14 * 8 + 4 * 8 + 7 * 4 + 4, "JitArgs layout is mirrored in the generated source");
+static_assert(sizeof(JitArgs) == 15 * 8 + 4 * 8 + 7 * 4 + 4, "JitArgs layout is mirrored in the generated source");
 
 // Runs every chunk over all `total` points of the quotient coset(s); a.q0 / q_count / spill are filled here.
 void jit_quotient_run(mh_ctx* c, const JitProgram* p, JitArgs a, size_t total);

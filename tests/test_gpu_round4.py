@@ -255,12 +255,17 @@ def test_real_miden_statement_production_params(ctx, fast_oracle):
 # ---- the generator's switches change the code, never the proof ----------------------------------------------------------------------
 GEN_SWITCHES = [{}, {"MH_JIT_RECOMP": "0"}, {"MH_JIT_RECOMP": "1000", "MH_JIT_CHUNK": "120"}, {"MH_JIT_LAZY": "0"}, {"MH_JIT_DOT": "0"},
                 {"MH_JIT_DOT": "2"}, {"MH_JIT_FLAGS": "-DMH_JIT_FOLD=0"}, {"MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=0"},
-                {"MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=1"}]
+                {"MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=1"},
+                # round 5: any-representative arithmetic, the uniform-gate table, cuts placed by the dynamic programme, the one-reduction fold_value
+                {"MH_JIT_LAZYVAL": "0"}, {"MH_JIT_UNI": "0"}, {"MH_JIT_LAZYVAL": "0", "MH_JIT_UNI": "0", "MH_JIT_FLAGS": "-DMH_JIT_FOLDV=0"},
+                {"MH_JIT_CUTWIN": "0"}, {"MH_JIT_CUTWIN": "60", "MH_JIT_CHUNK": "200"}, {"MH_JIT_BLOCK_LOG": "12"},
+                {"MH_JIT_LAZYVAL": "1", "MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=0"}]
 
 
 @pytest.mark.parametrize("env", GEN_SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "defaults")
 def test_generator_switches_are_bit_exact(ctx, env, monkeypatch, tmp_path):
-    """csrc/air_jit.cpp: recompute-or-spill, loads at first use, delayed-reduction fold, dot gates, the asm product -- every combination
+    """csrc/air_jit.cpp: recompute-or-spill, loads at first use, delayed-reduction fold, dot gates, the asm product, lazy values, the
+    uniform table, the cut placement -- every combination
     evaluates the same constraint values: the ChipletsAir proof (compiled chunks, aux from the derived lookup program) equals the
     interpreter's field for field.  A fresh cache directory per case: the kernels are compiled here, on the box."""
     pkg = load_package()
@@ -278,6 +283,7 @@ def test_generator_switches_are_bit_exact(ctx, env, monkeypatch, tmp_path):
     _, ref = prove()
     monkeypatch.setenv("MH_JIT", "1")
     monkeypatch.setenv("MH_JIT_CACHE_DIR", str(tmp_path))
+    monkeypatch.setenv("MH_JIT_CACHE_RO_DIR", "")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     dair, got = prove()
