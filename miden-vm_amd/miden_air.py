@@ -370,3 +370,42 @@ def poseidon2_permutation_trace(log_n, states=None, multiplicities=None):
         st = ext_round(st, ARK_EXT_TERMINAL[r])
     write(15, st, [mult, zero, zero])
     return rows.reshape(n, NUM_COLS)
+
+
+# ---- Poseidon2 on Python ints (the statement layer's hash_kernel_digests, sequential hasher operations of the test generators) ----
+def permute(state):
+    """The reference permutation (crates/crypto/src/hash/algebraic_sponge/poseidon2/mod.rs:22-37), pinned by the KAT through
+    tests/test_chiplets_air.py."""
+    s = [int(x) % P for x in state]
+
+    def ext(s, rc):
+        return [x % P for x in _matmul_external([pow(s[i] + rc[i], 7, P) for i in range(12)])]
+
+    s = [x % P for x in _matmul_external(s)]
+    for r in range(4):
+        s = ext(s, ARK_EXT_INITIAL[r])
+    for r in range(22):
+        s[0] = pow(s[0] + ARK_INT[r], 7, P)
+        s = [x % P for x in _matmul_internal(s, MAT_DIAG)]
+    for r in range(4):
+        s = ext(s, ARK_EXT_TERMINAL[r])
+    return s
+
+
+def hash_elements(xs):
+    """Poseidon2::hash_elements (crates/crypto/src/hash/algebraic_sponge/mod.rs:215-265): capacity[0] = len mod 8, zero padding,
+    empty input -> zero digest."""
+    xs = [int(x) % P for x in xs]
+    if not xs:
+        return [0, 0, 0, 0]
+    s = [0] * 12
+    s[8] = len(xs) % 8
+    for i in range(0, len(xs), 8):
+        chunk = xs[i:i + 8]
+        s[0:8] = chunk + [0] * (8 - len(chunk)) if len(chunk) < 8 else chunk
+        s = permute(s)
+    return s[0:4]
+
+
+def merge(a, b, domain=0):
+    return permute(list(a) + list(b) + [0, domain, 0, 0])[0:4]

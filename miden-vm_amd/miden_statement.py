@@ -18,7 +18,7 @@ closes its open buses (chiplet requests, range-check table, block-hash seed, def
 import numpy as np
 from . import dag, protocol
 from . import chiplets_air as CA
-from . import chiplets_trace as CT
+from . import miden_air as MA
 
 P = dag.P
 NUM_PUBLIC_VALUES = 32                 # air/src/lib.rs:270
@@ -66,7 +66,7 @@ class Challenges:
 
 def hash_kernel_digests(kernel_felts):
     assert len(kernel_felts) % 4 == 0 and len(kernel_felts) <= MAX_NUM_KERNEL_PROCEDURES * 4
-    return CT.hash_elements(kernel_felts)
+    return MA.hash_elements(kernel_felts)
 
 
 def boundary_correction(ch, aux_inputs):

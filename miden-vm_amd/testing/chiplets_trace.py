@@ -23,8 +23,8 @@ What is restated (file:line of the reference):
 of the response encoders, used by the tests' bus stand-in (miden_statement.bus_standin_air) to close the statement.
 """
 import numpy as np
-from . import miden_air as MA
-from . import chiplets_air as CA
+from .. import miden_air as MA
+from .. import chiplets_air as CA
 
 P = MA.P
 LINEAR_HASH, MP_VERIFY, MR_UPDATE_OLD, MR_UPDATE_NEW = (1, 0, 0), (1, 0, 1), (1, 1, 0), (1, 1, 1)
@@ -34,43 +34,8 @@ OP_CYCLE_LEN = 8
 BITWISE_AND, BITWISE_XOR = 0, 1
 
 
-# ---- Poseidon2 on Python ints (sequential hasher operations; the vectorised form lives in miden_air) ---------------------------
-def permute(state):
-    """The reference permutation (crates/crypto/src/hash/algebraic_sponge/poseidon2/mod.rs:22-37), pinned by the KAT through
-    tests/test_chiplets_air.py."""
-    s = [int(x) % P for x in state]
-
-    def ext(s, rc):
-        return [x % P for x in MA._matmul_external([pow(s[i] + rc[i], 7, P) for i in range(12)])]
-
-    s = [x % P for x in MA._matmul_external(s)]
-    for r in range(4):
-        s = ext(s, MA.ARK_EXT_INITIAL[r])
-    for r in range(22):
-        s[0] = pow(s[0] + MA.ARK_INT[r], 7, P)
-        s = [x % P for x in MA._matmul_internal(s, MA.MAT_DIAG)]
-    for r in range(4):
-        s = ext(s, MA.ARK_EXT_TERMINAL[r])
-    return s
-
-
-def hash_elements(xs):
-    """Poseidon2::hash_elements (crates/crypto/src/hash/algebraic_sponge/mod.rs:215-265): capacity[0] = len mod 8, zero padding,
-    empty input -> zero digest."""
-    xs = [int(x) % P for x in xs]
-    if not xs:
-        return [0, 0, 0, 0]
-    s = [0] * 12
-    s[8] = len(xs) % 8
-    for i in range(0, len(xs), 8):
-        chunk = xs[i:i + 8]
-        s[0:8] = chunk + [0] * (8 - len(chunk)) if len(chunk) < 8 else chunk
-        s = permute(s)
-    return s[0:4]
-
-
-def merge(a, b, domain=0):
-    return permute(list(a) + list(b) + [0, domain, 0, 0])[0:4]
+# ---- Poseidon2 on Python ints: miden_air.permute / hash_elements / merge (product side: the statement layer hashes kernel digests) ----
+permute, hash_elements, merge = MA.permute, MA.hash_elements, MA.merge
 
 
 class Hasher:

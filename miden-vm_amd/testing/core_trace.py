@@ -24,8 +24,8 @@ What is restated (file:line of the reference):
 """
 import numpy as np
 from . import chiplets_trace as CT
-from . import core_air as CO
-from . import chiplets_air as CA
+from .. import core_air as CO
+from .. import chiplets_air as CA
 
 P = CT.P
 OPC = CO.OPC

@@ -67,7 +67,7 @@ SENTINEL = 9999
 
 
 def _programs():
-    from miden_vm_amd import core_trace as CV
+    from miden_vm_amd.testing import core_trace as CV
     S = CV.Span
     join = CV.Join(S(["MUL"]), CV.Join(S(["ADD"]), S(["SWAP"])))                                   # join_program, tests.rs:592-618
     split = CV.Join(S(["SWAP", "SWAP"]), CV.Split(S(["ADD"]), S(["SWAP"])))                        # split_program, :621-650
@@ -87,7 +87,7 @@ def _programs():
 def run_case_on_the_test_vm(case):
     """Execute the program of snapshot `case` (its #[case(program, fragment_size, stack_inputs)] line in tests.rs:60-318; the
     fragment size does not change the trace -- that is what the reference test asserts) on core_trace.CoreVM."""
-    from miden_vm_amd import core_trace as CV
+    from miden_vm_amd.testing import core_trace as CV
     program, stack = _programs()[case]
     vm = CV.CoreVM(stack_inputs=stack)
     return CV.prove_inputs(vm, program)

@@ -77,3 +77,13 @@ def test_example_trace_generator_exports_its_entry_points():
     lib = ctypes.CDLL(so)
     for sym in ("kt_keccak_round_trace", "kt_download", "kt_free"):
         assert hasattr(lib, sym), sym
+
+
+def test_product_never_imports_the_test_generators():
+    """miden-vm_amd/testing/ (the small VM and the chiplet trace builder: witness generators for tests and bench workloads) is not
+    part of the proving backend: no product module may import it."""
+    pkg_dir = os.path.join(ROOT, "miden-vm_amd")
+    for f in os.listdir(pkg_dir):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg_dir, f)).read()
+            assert not re.search(r"^\s*(from|import)\s+[\w.]*\b(testing|core_trace|chiplets_trace)\b", src, re.M), f

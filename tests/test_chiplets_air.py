@@ -16,7 +16,8 @@ import oracle_binding as ob
 from __graft_entry__ import load_package
 
 pkg = load_package()
-from miden_vm_amd import chiplets_air as CA, chiplets_trace as CT, miden_statement as MS, miden_air as MA, dag, protocol  # noqa: E402
+from miden_vm_amd import chiplets_air as CA, miden_statement as MS, miden_air as MA, dag, protocol  # noqa: E402
+from miden_vm_amd.testing import chiplets_trace as CT  # noqa: E402
 
 P = dag.P
 KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))

@@ -14,7 +14,8 @@ import pytest
 import oracle_binding as ob
 import airs as A
 from __graft_entry__ import load_package
-from miden_vm_amd import dag, protocol, miden_air as MA, chiplets_air as CA, chiplets_trace as CT, miden_statement as MS, core_air as CO, core_trace as CV
+from miden_vm_amd import dag, protocol, miden_air as MA, chiplets_air as CA, miden_statement as MS, core_air as CO
+from miden_vm_amd.testing import chiplets_trace as CT, core_trace as CV
 from test_gpu_prove import FAST
 
 pytestmark = pytest.mark.gpu

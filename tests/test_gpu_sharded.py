@@ -258,7 +258,12 @@ def test_local_communicator_selftest(world):
                                         # round 4: more ranks than quotient chunks (D = 2: chunk t lives on rank t * G / 2, the others
                                         # idle through constraint evaluation), mixed per-AIR quotient degrees (D_j in {2, 2, 8}: native
                                         # chunks gathered, upsampled on every rank), both instance orders; the real chiplets AIR
-                                        (4, "multi"), (8, "multi"), (2, "mixed"), (4, "mixed"), (8, "mixed"), (4, "mixed_rev"), (8, "chiplets")])
+                                        (4, "multi"), (8, "multi"), (2, "mixed"), (4, "mixed"), (8, "mixed"), (4, "mixed_rev"), (8, "chiplets"),
+                                        # round 5: the REAL three-AIR statement -- CoreAir (compiled chunks, 4 EF aux) + ChipletsAir +
+                                        # Poseidon2PermutationAir of an executed program, heights differing, `MidenMultiAir` framing, all
+                                        # eight LogUp columns built on every rank, accepted only through eval_external; and the reference
+                                        # processor's own snapshot 13 (SYSCALL, a kernel) the same way
+                                        (2, "miden_real"), (4, "miden_real"), (8, "miden_real"), (2, "ref_case13"), (8, "ref_case13")])
 def test_sharded_proof_through_a_stream_ordered_communicator(world, case):
     """The sharded prover with a STREAM-ORDERED communicator and several ranks (what the RCCL communicator is on a multi-GPU
     node): no host synchronisation around the collectives.  Every rank's proof must equal the single-GPU proof."""
@@ -281,12 +286,33 @@ def test_sharded_proof_through_a_stream_ordered_communicator(world, case):
             airs_, traces = airs_[::-1], traces[::-1]
         prm = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=6, query_pow_bits=3)
     elif case == "chiplets":  # the real ChipletsAir + Poseidon2 permutation AIR, aux columns from the derived lookup programs on every rank
-        from miden_vm_amd import miden_air as MA, chiplets_air as CA, chiplets_trace as CT
+        from miden_vm_amd import miden_air as MA, chiplets_air as CA
+        from miden_vm_amd.testing import chiplets_trace as CT
         ch, _ = CA.chiplets_air(host_aux=ob.lookup_build_aux, num_public=0)
         p2, _ = MA.poseidon2_permutation_air(host_aux=ob.lookup_build_aux)
         tr, tp2 = CT.bulk_chiplets(11, 10, seed=6)
         airs_, traces, pub, prm = [ch, p2], [np.ascontiguousarray(tr), tp2], [], ob.PROD_PARAMS
         lookups = {0: dag.lookup_from_constraints(ch.blob), 1: dag.lookup_from_constraints(p2.blob)}
+    elif case in ("miden_real", "ref_case13"):
+        import json
+        from miden_vm_amd import miden_air as MA, chiplets_air as CA, core_air as CO, miden_statement as MS, protocol
+        from miden_vm_amd.testing import core_trace as CV
+        core, _ = CO.core_air(host_aux=ob.lookup_build_aux)
+        ch, _ = CA.chiplets_air(host_aux=ob.lookup_build_aux)
+        p2, _ = MA.poseidon2_permutation_air(host_aux=ob.lookup_build_aux, num_public=32)
+        airs_ = [core, ch, p2]
+        if case == "miden_real":
+            r = CV.prove_inputs(CV.CoreVM(stack_inputs=tuple(range(16))), CV.bench_program(60))
+            traces, pub, aux_inputs = [r["core"], r["chiplets"], r["poseidon2"]], r["public_values"], r["aux_inputs"]
+            assert len({t.shape[0] for t in traces}) == 3     # three different heights
+        else:
+            import ref_traces as RT
+            c = RT.load_cases()[12]
+            traces, pub, aux_inputs = [c["core"], c["chiplets"], c["poseidon2"]], RT.public_values(c), RT.aux_inputs(c)
+        prm = ob.PROD_PARAMS
+        lookups = {i: dag.lookup_from_constraints(a.blob) for i, a in enumerate(airs_)}
+        kat = json.load(open(os.path.join(ROOT, "tests", "golden", "kat.json")))
+        statement = (protocol.challenger_state(kat["relation_digest"]), MS.statement_pre_observe(prm, pub, aux_inputs), aux_inputs)
     elif case == "miden":
         airs_, traces, pub, prm = [dag.dummy_miden_air(51, 8)], [A.dummy_trace(10, 51)], [], ob.PROD_PARAMS
     elif case in ("miden18", "miden20"):  # bench-sized shards: every NTT pass shape and the real collective sizes
@@ -299,6 +325,8 @@ def test_sharded_proof_through_a_stream_ordered_communicator(world, case):
         airs_, traces = [A.periodic_air(3), A.fib_air()], [A.periodic_trace(6), t1]
         prm = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=6, query_pow_bits=3)
     st, pre = ob.challenger_state(), ob.protocol_pre_observe(prm, pub)
+    if case in ("miden_real", "ref_case13"):
+        st, pre = statement[0], statement[1]
     need_cb = any(a.build_aux is not None and i not in lookups for i, a in enumerate(airs_))
 
     def aux_builder(idx, rnd):
@@ -323,6 +351,17 @@ def test_sharded_proof_through_a_stream_ordered_communicator(world, case):
         for g in (got, got2):
             assert g.fields.size == ref.fields.size and (g.fields == ref.fields).all()
             assert (g.commitments == ref.commitments).all() and (g.digest == ref.digest).all()
+    if case in ("miden_real", "ref_case13"):
+        from miden_vm_amd import miden_statement as MS
+        from __graft_entry__ import load_package
+        pkg = load_package()
+        ext = MS.external_assertions(pkg, pub, statement[2])
+        ok, msg = ob.verify(airs_, ref.log_trace_heights, pub, {"fields": ref.fields, "commitments": ref.commitments}, prm, init_state=st, pre_observe=pre, external=ext)
+        assert ok, msg
+        assert not pkg.verify(airs_, ref.log_trace_heights, pub, prm, st, pre, ref.fields, ref.commitments, external="logup_balance")[0]
+        ok, dig = pkg.verify_miden(pub, statement[2], ref.bytes)          # ... and through the library's own statement layer
+        assert ok and (dig == ref.digest).all(), dig
+        return
     ok, msg = ob.verify(airs_, ref.log_trace_heights, pub, {"fields": ref.fields, "commitments": ref.commitments}, prm)
     assert ok, msg
 

@@ -15,7 +15,8 @@ import proof_parser
 from __graft_entry__ import load_package
 
 pkg = load_package()
-from miden_vm_amd import core_air as CO, chiplets_air as CA, chiplets_trace as CT, miden_air as MA, miden_statement as MS, dag, protocol  # noqa: E402
+from miden_vm_amd import core_air as CO, chiplets_air as CA, miden_air as MA, miden_statement as MS, dag, protocol  # noqa: E402
+from miden_vm_amd.testing import chiplets_trace as CT  # noqa: E402
 import ref_traces as RT  # noqa: E402
 
 P = dag.P

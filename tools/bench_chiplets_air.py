@@ -9,7 +9,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from __graft_entry__ import load_package
 pkg = load_package()
-from miden_vm_amd import chiplets_air as CA, chiplets_trace as CT, dag, protocol
+from miden_vm_amd import chiplets_air as CA, dag, protocol
+from miden_vm_amd.testing import chiplets_trace as CT
 
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from __graft_entry__ import load_package
 pkg=load_package()
-from miden_vm_amd import core_trace as ct
+from miden_vm_amd.testing import core_trace as ct
 ctx=pkg.Ctx(0)
 small = ct.prove_inputs(ct.CoreVM(stack_inputs=list(range(16))), ct.bench_program(575))
 r=bench.miden_real_probe(pkg, ctx, inputs=small, steps=5)

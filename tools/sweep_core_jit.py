@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 pkg = load_package()
-from miden_vm_amd import dag, protocol, miden_air, chiplets_air, core_air, core_trace, miden_statement
+from miden_vm_amd import dag, protocol, miden_air, chiplets_air, core_air, miden_statement
+from miden_vm_amd.testing import core_trace
 
 args = sys.argv[1:]
 pre = bool(args) and args[0] == "precompile"
