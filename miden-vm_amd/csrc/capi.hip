@@ -109,6 +109,11 @@ int mh_ctx_trim(mh_ctx* c) {
   if (c->copy_stream) HIP_CHECK(hipStreamSynchronize(c->copy_stream));
   for (auto& b : c->host_pool) (void)hipHostFree(b.first);
   c->host_pool.clear();
+  // the full [z][pos] coset-scale tables of the LDE (ntt.hip coset_scale_full: 8 N bytes per output coset -- 64 MB per trace height at
+  // blowup 8, 1 GB at 2^24 rows) are rebuilt in one launch when next needed; a service that proves varied heights would otherwise
+  // accumulate gigabytes of them.  The small twiddle / coset tables stay.
+  for (auto it = c->tables.begin(); it != c->tables.end();)
+    it = it->first.rfind("cosetfull:", 0) == 0 ? c->tables.erase(it) : std::next(it);
   MH_CATCH
 }
 

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void k_compress_lanes(const u64* __restrict__ 
 // levels between the 16-lane form (latency-optimal below ~2^13 nodes) and the state-per-lane form (throughput-optimal above ~2^15).
 static size_t compress_quad_min_nodes() {
   static const size_t v = [] {
-    const char* e = getenv("MH_QUAD_MIN_NODES");  // experiments (measured: 2^14 .. 2^15 is where it pays, tools/exp_quad.sh)
+    const char* e = getenv("MH_QUAD_MIN_NODES");  // experiments (measured: 2^14 .. 2^15 is where it pays, profiles/scripts/exp_quad.sh)
     return e ? (size_t)atol(e) : (size_t)16384;
   }();
   return v;

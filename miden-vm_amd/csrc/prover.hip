@@ -110,9 +110,15 @@ mh_trace* trace_upload_cols_async(mh_ctx* c, const u64* colmajor, int log_n, siz
 void trace_wait_ready(mh_ctx* c, const mh_trace* t) {
   if (!t || !t->ready) return;
   HIP_CHECK(hipStreamWaitEvent(c->stream, t->ready, 0));
-  // the transpose that read the landing buffer lies before `ready`, and whoever takes the buffer from the pool next runs on this
-  // stream (or fences its copy stream on it): the row-major copy does not have to live as long as the trace (2^24 x 51: 6.8 GB)
-  if (t->staging.p && c == t->ctx) t->staging.release();
+  // the transpose that read the landing buffer lies before `ready`; the row-major copy does not have to live as long as the trace
+  // (2^24 x 51: 6.8 GB).  POOL INVARIANT: a buffer returned to the pool may be taken by any later allocation of this context, whose
+  // first write is ordered only against the PRIMARY stream's position at that moment -- so the buffer goes back only when the
+  // primary stream itself has passed `ready`.  Inside commit_traces_pipelined `c->stream` is the side stream: the primary stream
+  // is fenced on the event first (a wait on an already-signalled event costs nothing).
+  if (t->staging.p && c == t->ctx) {
+    if (c->stream != c->primary_stream && c->primary_stream) HIP_CHECK(hipStreamWaitEvent(c->primary_stream, t->ready, 0));
+    t->staging.release();
+  }
 }
 
 mh_trace* trace_zeros(mh_ctx* c, int log_n, size_t width) {
@@ -567,8 +573,9 @@ struct mh_session {
         if (dj_loc)
           quotient_eval_accumulate(c, a, main_tree->mats[j], aux_tree->mats[j], prep, lb, logDj, publics, rnd, aux_vals[order[j]], alpha,
                                    nullptr, 0, beta, mine.u());
-        DevBuf small(((size_t)2 << (logDj + ln)) * 8);
+        DevBuf small;
         if (dist.on()) {
+          small.alloc(((size_t)2 << (logDj + ln)) * 8);
           DevBuf all((size_t)dist.world * dj_slot * chunk_words * 8);
           dist.all_gather(c, mine.u(), all.p, dj_slot * chunk_words * 8);
           for (size_t t = 0; t < ((size_t)1 << logDj); t++)
