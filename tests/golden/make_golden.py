@@ -124,6 +124,14 @@ def main():
     # 10. the VM's opcodes (core/src/operations/mod.rs:29-129)
     ops_src = open(f"{REF}/core/src/operations/mod.rs").read()
     out["opcodes"] = {k: int(v.replace("_", ""), 2) for k, v in re.findall(r"pub const (\w+): u8\s*= 0b([01_]+);", ops_src)}
+    # 11. the recursive verifier's ACE circuit metadata (air/src/snapshots/miden_air__config__tests__relation_digest_matches_current_air.snap,
+    #     test air/src/config.rs:383-454): num_inputs / num_eval_gates / stream_len of the six proof orders + the relation digest
+    snap = open(f"{REF}/air/src/snapshots/miden_air__config__tests__relation_digest_matches_current_air.snap").read()
+    orders = re.findall(r"(constraints_eval_\w+):\n  num_inputs: (\d+)\n  num_eval_gates: (\d+)\n  stream_len: (\d+)\n  commitment: \[([^\]]*)\]", snap)
+    assert len(orders) == 6
+    out["ace_circuit_snapshot"] = {"orders": {n: {"num_inputs": int(a), "num_eval_gates": int(b), "stream_len": int(c),
+                                                   "commitment": [int(x) for x in d.split(",")]} for n, a, b, c, d in orders},
+                                   "relation_digest": [int(x) for x in re.search(r"relation_digest: \[([^\]]*)\]", snap).group(1).split(",")]}
     with open(os.path.join(HERE, "kat.json"), "w") as f:
         json.dump(out, f, indent=0)
     print("wrote kat.json:", {k: (len(v) if hasattr(v, '__len__') else v) for k, v in out.items()})

@@ -157,3 +157,61 @@ def test_parser_consumes_the_other_configurations(lmcs, alignment):
                      alignment=8 if alignment != 8 else 1)
     finally:
         ob.set_lmcs("poseidon2")
+
+
+def test_ace_circuit_snapshot_pins_the_statement_shape_and_bounds_the_constraint_system_size():
+    """The reference holds the size of its recursive verifier's ACE circuit over [CoreAir, ChipletsAir, Poseidon2PermutationAir]
+    (air/src/snapshots/miden_air__config__tests__relation_digest_matches_current_air.snap, test air/src/config.rs:383-454; circuit
+    built by air/src/ace/{recursive,multi_air}.rs over crates/ace-codegen): num_inputs 624, num_eval_gates 5208, stream_len 5792,
+    identical for the six proof orders.
+
+    EXACT part.  `num_inputs` counts READ slots + constants, and the stream holds two felts per constant and one per operation
+    (crates/ace-codegen/src/encode.rs:36-70, 98-203), so READ slots = 624 - (5792 - 5208) / 2 = 332.  The READ layout is pure
+    arithmetic over the statement's shape (layout/policy.rs:78-218 MASM policy, multi-AIR composition; per-AIR widths padded to 8
+    before concatenation, ace/multi_air.rs:188-217): the hand-ported AIRs' widths must reproduce it.
+
+    BOUNDED part (the attempt at the circuit-size pin, VERDICT round 4 next #3 ii).  The gate count of the reference circuit is the
+    number of distinct arithmetic nodes of the three constraint DAGs + two per constraint for the alpha fold + the Horner
+    evaluation of the periodic columns + the quotient recomposition and the cross-AIR fold (dag/lower.rs, quotient.rs,
+    multi_air.rs:130-160).  The same count over the hand-ported DAGs is 5173 + ~117 = ~5290 against 5208: within 1.6 %, NOT equal --
+    exact equality depends on the folding rules of p3-air's symbolic builder and of `DagBuilder` (hash-consing, 0 / 1 elision),
+    which are not in the checkout.  What this does hold: a hand-ported AIR that lost (or duplicated) a section of more than ~150
+    gates would leave the band."""
+    from miden_vm_amd import core_air as CO, chiplets_air as CA, miden_air as MA
+    snap = KAT["ace_circuit_snapshot"]
+    metas = {(o["num_inputs"], o["num_eval_gates"], o["stream_len"]) for o in snap["orders"].values()}
+    assert metas == {(624, 5208, 5792)} and snap["relation_digest"] == KAT["relation_digest"]
+    num_inputs, gates, stream = next(iter(metas))
+    airs = [CO.core_air()[0], CA.chiplets_air()[0], MA.poseidon2_permutation_air(num_public=32)[0]]
+    al = lambda x, a: (x + a - 1) // a * a                                                                      # noqa: E731
+    main_w = sum(al(a.main_width, 8) for a in airs)                          # 56 + 24 + 16
+    aux_coords = sum(al(2 * a.aux_width, 8) for a in airs)                   # 8 + 8 + 8 base coordinates
+    off = al(32, 8)                                                          # public values (QuadWord)
+    off = al(off, 2) + 2                                                     # alpha, beta
+    for _ in range(2):                                                       # current row, then next row
+        off = al(off, 4) + main_w
+        off = al(off, 4) + aux_coords
+        off = al(off, 4) + 8 * 2                                             # quotient chunks x EF coordinates
+    # layout order (policy.rs:150-161): main_curr, aux_curr, quotient_curr, main_next, aux_next, quotient_next, boundary, stark vars
+    off = al(off, 2) + sum(a.num_aux_values for a in airs)
+    off = al(off, 2) + 10 + 1 + 3 * 3                                        # 10 stark variables + fold beta + three selectors per AIR
+    off = al(off, 2)
+    assert off == 332 == num_inputs - (stream - gates) // 2, off
+    est = 0
+    for a in airs:
+        p = dag.parse_air_blob(a.blob)
+        nodes, live, st = p["nodes"], set(), list(p["constraints"])
+        while st:
+            i = st.pop()
+            if i in live:
+                continue
+            live.add(i)
+            op, x, y = nodes[i][0], nodes[i][1], nodes[i][2]
+            if op in (dag.OP_ADD, dag.OP_SUB, dag.OP_MUL):
+                st += [x, y]
+            elif op == dag.OP_NEG:
+                st.append(x)
+        est += sum(1 for i in live if nodes[i][0] in (dag.OP_ADD, dag.OP_SUB, dag.OP_MUL, dag.OP_NEG))
+        est += 2 * len(p["constraints"]) + sum(2 * (len(col) - 1) for col in p["periodic"])
+    assert est == 5173                                                       # what the ports amount to today (changes with any constraint edit)
+    assert abs(est + 117 - gates) <= 0.03 * gates
