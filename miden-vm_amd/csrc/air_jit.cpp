@@ -319,6 +319,46 @@ void cache_store(const std::string& path, const std::vector<char>& code) {
   if (rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
 }
 
+// What the compiler did with a chunk, read from its code object (ELF64): the kernel descriptor `mh_jit_chunk.kd` (64 bytes in
+// .rodata; llvm AMDGPUUsage "Kernel Descriptor") holds the private-segment (scratch) size at offset 4 and the granulated VGPR count
+// in compute_pgm_rsrc1[5:0] (units of 8 on gfx90a+).  No GPU needed: the same answer at build time (mh_jit_precompile) and at load.
+// -> false if the object cannot be parsed (then nothing is concluded from it).
+bool code_object_info(const std::vector<char>& co, unsigned* scratch_bytes, unsigned* vgprs) {
+  auto rd = [&](size_t off, int bytes) -> u64 {
+    u64 v = 0;
+    if (off + (size_t)bytes > co.size()) return 0;
+    memcpy(&v, co.data() + off, (size_t)bytes);
+    return v;
+  };
+  if (co.size() < 64 || memcmp(co.data(), "\177ELF", 4) != 0 || co[4] != 2) return false;
+  const u64 shoff = rd(0x28, 8), shentsize = rd(0x3A, 2), shnum = rd(0x3C, 2);
+  if (!shoff || shentsize < 64 || shoff + shnum * shentsize > co.size()) return false;
+  struct Sec { u64 type, addr, off, size, link, entsize; };
+  std::vector<Sec> secs(shnum);
+  for (u64 i = 0; i < shnum; i++) {
+    const size_t b = shoff + i * shentsize;
+    secs[i] = {rd(b + 4, 4), rd(b + 0x10, 8), rd(b + 0x18, 8), rd(b + 0x20, 8), rd(b + 0x28, 4), rd(b + 0x38, 8)};
+  }
+  for (const Sec& st : secs) {
+    if ((st.type != 2 && st.type != 11) || st.entsize < 24 || st.link >= shnum) continue;  // SHT_SYMTAB / SHT_DYNSYM
+    const Sec& str = secs[st.link];
+    for (u64 k = 0; k < st.size / st.entsize; k++) {
+      const size_t b = st.off + k * st.entsize;
+      const u64 name = rd(b, 4), value = rd(b + 8, 8);
+      if (str.off + name + 15 > co.size() || strncmp(co.data() + str.off + name, "mh_jit_chunk.kd", 16) != 0) continue;
+      for (const Sec& sc : secs)
+        if (sc.type == 1 && value >= sc.addr && value + 64 <= sc.addr + sc.size) {  // SHT_PROGBITS holding the descriptor
+          const size_t kd = sc.off + (value - sc.addr);
+          if (kd + 64 > co.size()) return false;
+          *scratch_bytes = (unsigned)rd(kd + 4, 4);
+          *vgprs = (unsigned)(((rd(kd + 48, 4) & 63) + 1) * 8);
+          return true;
+        }
+    }
+  }
+  return false;
+}
+
 void hiprtc_check(hiprtcResult r, const char* what) {
   if (r != HIPRTC_SUCCESS) throw MhError(MH_ERR_INTERNAL, std::string("hiprtc: ") + what + ": " + hiprtcGetErrorString(r));
 }
@@ -354,7 +394,11 @@ int jit_program_max_vgprs(const JitProgram* p) {
 thread_local bool g_jit_compile_only = false;
 thread_local int g_jit_last_chunks = 0;
 
-JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
+static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const std::vector<size_t>* forced_cuts, int depth);
+JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) { return jit_program_build_cuts(ctx, ir, nullptr, 0); }
+// forced_cuts: the chunk end positions (ascending, last = the number of events) of a retry after a chunk came back from the compiler
+// with scratch memory -- see the end of the compile step
+static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const std::vector<size_t>* forced_cuts, int depth) {
   const int mode = ir.outputs ? 1 : env_int("MH_JIT", -1);  // 0: never, 1: always, default: large DAGs only
   if (mode == 0) return nullptr;
   const std::vector<DagNode>& nodes = ir.nodes;
@@ -483,11 +527,11 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
   };
   const int budget = std::max(16, env_int("MH_JIT_CHUNK", 320));
   std::vector<Chunk> chunks;
+  std::vector<long> crossing(seq.size() + 1, 0);
   {
     // crossing[i] = u64 words alive across a cut after seq[i]: computed at or before i, used after i.  A cut is placed where this is
     // smallest inside a window around the budget ($MH_JIT_CUTWIN percent, 0 = cut at the budget): every crossing value is either
     // recomputed or goes through a spill plane (16 bytes of traffic per point and word).
-    std::vector<long> crossing(seq.size() + 1, 0);
     {
       std::vector<long> def_pos(nodes.size(), -1), last_use(nodes.size(), -1);
       std::vector<uint32_t> o;
@@ -510,7 +554,14 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
       for (size_t i = 0; i < seq.size(); i++) { run += diff[i]; crossing[i] = run; }
     }
     const int win = std::max(0, env_int("MH_JIT_CUTWIN", 25));
-    const long lo_b = (long)budget * (100 - win) / 100, hi_b = (long)budget * (100 + win) / 100;
+    // $MH_JIT_CUTK = K > 0: chunk sizes are free between 0.4 and 1.6 budgets and the programme minimises
+    //   sum over cuts (crossing words + P)  +  K * sum over chunks (cost / budget)^2
+    // -- a constraint system whose values rarely cross (Poseidon2 permutation rows, chiplet sections) is cut into MORE, smaller
+    // kernels (fewer VGPRs, more waves per SIMD, and the cuts are free), one with 40-100 words alive everywhere (the core AIR's
+    // operation flags) keeps large chunks.  K = 0: the fixed window above.
+    const long cut_k = std::max(0, env_int("MH_JIT_CUTK", 0)), cut_p = std::max(0, env_int("MH_JIT_CUTP", 10));
+    const long lo_b = cut_k ? (long)budget * 2 / 5 : (long)budget * (100 - win) / 100,
+               hi_b = cut_k ? (long)budget * 8 / 5 : (long)budget * (100 + win) / 100;
     // dynamic programme over the cut positions: best[i] = smallest sum of crossings with a cut after seq[i - 1], every chunk's cost
     // inside [lo_b, hi_b] (the last one from lo_b / 2); fewest crossings overall, not greedily chunk by chunk
     const size_t S = seq.size();
@@ -528,11 +579,15 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
         if (c > hi_b && j + 1 < i) break;   // a single over-budget event still forms a chunk
         if (best[j] >= INF) continue;
         if (c < (i != S ? lo_b : lo_b / 2) && !(i == S && j == 0)) continue;  // the last chunk may be half a window short, not a stub
-        const long v = best[j] + (i < S ? crossing[i - 1] : 0);
+        long v = best[j] + (i < S ? crossing[i - 1] + (cut_k ? cut_p : 0) : 0);
+        if (cut_k) v += cut_k * c * c / ((long)budget * budget);
         if (v < best[i]) { best[i] = v; from[i] = j; }
       }
     }
-    if (best[S] >= INF) {  // no partition inside the window (degenerate budgets): cut at the budget
+    if (forced_cuts) {
+      size_t lo = 0;
+      for (size_t e : *forced_cuts) { chunks.push_back({lo, e, {}, {}, {}}); lo = e; }
+    } else if (best[S] >= INF) {  // no partition inside the window (degenerate budgets): cut at the budget
       size_t lo = 0;
       long acc = 0;
       for (size_t i = 0; i < S; i++) {
@@ -547,6 +602,13 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
       size_t lo = 0;
       for (size_t k = cuts.size(); k-- > 0;) { chunks.push_back({lo, cuts[k], {}, {}, {}}); lo = cuts[k]; }
     }
+    if (env_int("MH_JIT_STATS", 0))
+      for (const Chunk& ch : chunks) {
+        long peak = 0;
+        for (size_t i = ch.ev_lo; i < ch.ev_hi; i++) peak = std::max(peak, crossing[i]);
+        fprintf(stderr, "[mh jit]   chunk [%zu, %zu): cost %ld, peak live words %ld, crossing at its end %ld\n", ch.ev_lo, ch.ev_hi,
+                pre[ch.ev_hi] - pre[ch.ev_lo], peak, ch.ev_hi < S ? crossing[ch.ev_hi - 1] : 0L);
+      }
   }
   const size_t n_chunks = chunks.size();
   // ---- what each chunk evaluates, and which values cross chunk boundaries ----
@@ -1017,6 +1079,44 @@ JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) {
     for (auto& t : th) t.join();
   }
   if (failed.load()) throw MhError(MH_ERR_INTERNAL, first_error);
+  // ---- a chunk the register allocator could not fit into 256 VGPRs (it then parks values in accumulation registers: 264 "VGPRs" =
+  // ONE wave per SIMD; or in scratch memory) runs several times slower than two chunks of half its size (core AIR, round 5: two
+  // 264-register chunks took the quotient from 13.4 to 18.7 ms).  Such a chunk is cut in two at the
+  // position of its middle third with the fewest crossing values, and everything is generated again (at most three times;
+  // $MH_JIT_SPLIT=0: keep what the first cut gave). ----
+  if (depth < 3 && env_int("MH_JIT_SPLIT", 1)) {
+    // the unified VGPR + AGPR budget of a chunk.  256 would still be two waves per SIMD, but a chunk AT the limit is fragile (one box of
+    // the pool ran the core AIR's 256-register chunk five times slower than the others: 3.5 ms instead of 0.65 per 2^22 points) and
+    // cutting it costs nothing: core AIR 256 / 248 / 200 / 168 -> 13.46 / 13.27 / 13.17 / 13.97 ms (round 5)
+    const int max_regs = env_int("MH_JIT_MAXREGS", 200);
+    std::vector<size_t> cuts;
+    bool any = false;
+    for (size_t ci = 0; ci < n_chunks; ci++) {
+      unsigned scratch = 0, vg = 0;
+      const size_t lo = chunks[ci].ev_lo, hi = chunks[ci].ev_hi;
+      if (code_object_info(chunks[ci].code, &scratch, &vg) && (scratch > 0 || (int)vg > max_regs) && hi - lo >= 8) {
+        size_t best_m = 0;
+        long best_x = -1;
+        for (size_t m = lo + (hi - lo) / 3; m <= lo + 2 * (hi - lo) / 3; m++) {
+          if (m <= lo || m >= hi || seq[m].fold_k >= 0) continue;  // never separate a node from the fold that consumes it
+          if (best_x < 0 || crossing[m - 1] < best_x) { best_x = crossing[m - 1]; best_m = m; }
+        }
+        if (best_m) {
+          if (env_int("MH_JIT_STATS", 0))
+            fprintf(stderr, "[mh jit] chunk %zu [%zu, %zu) does not fit 256 VGPRs (%u bytes of scratch, %u registers): cut again at %zu\n", ci, lo, hi, scratch, vg, best_m);
+          cuts.push_back(best_m);
+          any = true;
+        }
+      }
+      cuts.push_back(hi);
+    }
+    if (any) return jit_program_build_cuts(ctx, ir, &cuts, depth + 1);
+  }
+  if (env_int("MH_JIT_STATS", 0))
+    for (size_t ci = 0; ci < n_kernels; ci++) {
+      unsigned scratch = 0, vg = 0;
+      if (code_object_info(chunks[ci].code, &scratch, &vg)) fprintf(stderr, "[mh jit]   kernel %zu: %u VGPRs, %u bytes of scratch\n", ci, vg, scratch);
+    }
   if (compile_only) {
     g_jit_last_chunks = (int)n_kernels;
     return nullptr;

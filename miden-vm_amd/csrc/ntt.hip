@@ -981,6 +981,25 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
   const CosetTables t = coset_tables(c, log_n, bases, n_inv);
   auto plan = plan_passes(log_n);
   const NttPlanes tw = ntt_planes(c, log_n, false, plan);
+  // $MH_NTT_COLGROUP = k > 0: the passes run column group by column group (k columns x nz cosets through ALL passes before the next
+  // group), so that what pass i wrote is still in the 256 MB Infinity Cache when pass i + 1 reads it (2^20 rows, blowup 8: 64 MB per
+  // column -- k = 3 keeps a group at 192 MB).  0 = every pass over all columns (the inter-pass matrix, 3.4 GB for 51 columns, goes
+  // through HBM).
+  static const int colgroup = [] { const char* e = getenv("MH_NTT_COLGROUP"); return e ? atoi(e) : 0; }();
+  static thread_local bool inside = false;  // this call is one column group of an outer call
+  if (colgroup > 0 && !group_cols && !grouped && plan.size() > 1 && n_cols > (size_t)colgroup) {
+    if (!inside) {
+      inside = true;
+      try {
+        for (size_t c0 = 0; c0 < n_cols; c0 += (size_t)colgroup) {
+          const size_t k = std::min<size_t>((size_t)colgroup, n_cols - c0);
+          ntt_forward_cosets(c, coef_br + c0 * N, k, log_n, bases, out + c0 * nz * N, out_col_stride, group_cols);
+        }
+      } catch (...) { inside = false; throw; }
+      inside = false;
+      return;
+    }
+  }
   for (size_t i = 0; i < plan.size(); i++) {
     NttPassArgs a{};
     a.dst = out;
@@ -995,7 +1014,7 @@ void ntt_forward_cosets(mh_ctx* c, const u64* coef_br, size_t n_cols, int log_n,
       static const int fullscale = [] { const char* e = getenv("MH_NTT_FULLSCALE"); return e ? atoi(e) : 1; }();
       a.group_cols = (u32)group_cols; a.group_z = (u32)nz;
       a.rot = ntt_coef_rot(log_n);
-      if (fullscale && !group_cols && n_cols >= 16 && log_n >= 12 && log_n <= 24) a.scale_full = coset_scale_full(c, log_n, bases, n_inv, t);
+      if (fullscale && !group_cols && (n_cols >= 16 || inside) && log_n >= 12 && log_n <= 24) a.scale_full = coset_scale_full(c, log_n, bases, n_inv, t);
       // the geometric stepping of the scaled coefficients (registers over the coset loop, one shared 8 MB step table) is off by default:
       // since the strided pass stopped staging through LDS (first-round register loads) the full [z][pos] table is the faster form
       // again (2^20 x 51 + 8 EF: lde 7.77 vs 8.25 ms, proof 46.0 vs 46.25 ms, three alternating runs on one box; gpurun_out/nttexp.txt)

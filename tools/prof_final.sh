@@ -12,4 +12,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C -d $O/pmc_$C -o pmc --output-format csv -- python bench.py --steps 3 --warmup 0 --no-cpu-baseline --no-extras > $O/pmc_$C.log 2>&1
 done
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_VALU -d $O/pmc_SQ -o pmc --output-format csv -- python bench.py --steps 3 --warmup 0 --no-cpu-baseline --no-extras > $O/pmc_SQ.log 2>&1
-ls -R $O | head -40
+# the real statement (kernel stats) and the per-chunk view of the core AIR's constraint kernels (trace + PMC)
+rocprofv3 --kernel-trace --stats -d $O/kt_real -o kt --output-format csv -- python tools/bench_miden_real.py > $O/real.log 2>&1
+tail -1 $O/real.log | cut -c1-300
+MH_JIT_CACHE_DIR=/tmp/jc bash tools/prof_jit_core.sh r5_final > $O/jit_core.txt 2>&1
+tail -5 $O/jit_core.txt
+ls -R $O | head -60
