@@ -21,7 +21,7 @@ per = collections.defaultdict(list)
 for i, x in enumerate(q):
     per[i % n_chunks].append(x)
 out = {k: round(sum(v) / len(v), 1) for k, v in sorted(per.items())}
-print("us per chunk launch (2^21 points):", out, "sum x4 blocks = %.2f ms" % (sum(out.values()) * 4 / 1e3))
+print("us per chunk launch (largest grid of the trace = one block of the point sweep):", out, "sum per block = %.2f ms" % (sum(out.values()) / 1e3))
 open(sys.argv[1] + "/per_chunk.txt", "w").write(repr(out) + "\n")
 PY
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD"; do
