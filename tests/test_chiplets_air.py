@@ -374,3 +374,21 @@ def test_offline_precompile_fills_the_cache_without_a_gpu(tmp_path):
     kl = pkg.jit_precompile(dag.lookup_from_constraints(air.blob).blob, d)
     assert kl >= 1 and len(os.listdir(d)) == k + kl
     assert pkg.jit_precompile(dag.dummy_miden_air(11, 2).blob, d) == 0     # small DAG: interpreted, nothing to compile
+
+
+def test_chunks_above_the_register_budget_are_cut_again_without_a_gpu(tmp_path):
+    """csrc/air_jit.cpp reads the compiler's verdict on a chunk -- registers, scratch -- from the kernel descriptor inside the code
+    object (ELF), so the re-cut happens identically at build time (here: mh_jit_precompile, no GPU) and at load time.  A budget of 64
+    registers forces it: more kernels than the first cut gave, and the second call finds all of them in the cache."""
+    air, _ = CA.chiplets_air()
+    base = pkg.jit_precompile(air.blob, str(tmp_path / "a"))
+    os.environ["MH_JIT_MAXREGS"] = "64"
+    try:
+        cut = pkg.jit_precompile(air.blob, str(tmp_path / "b"))
+        assert cut > base, (base, cut)
+        assert pkg.jit_precompile(air.blob, str(tmp_path / "b")) == cut
+        os.environ["MH_JIT_SPLIT"] = "0"
+        assert pkg.jit_precompile(air.blob, str(tmp_path / "c")) == base
+    finally:
+        os.environ.pop("MH_JIT_MAXREGS", None)
+        os.environ.pop("MH_JIT_SPLIT", None)

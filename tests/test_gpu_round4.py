@@ -260,7 +260,10 @@ GEN_SWITCHES = [{}, {"MH_JIT_RECOMP": "0"}, {"MH_JIT_RECOMP": "1000", "MH_JIT_CH
                 # round 5: any-representative arithmetic, the uniform-gate table, cuts placed by the dynamic programme, the one-reduction fold_value
                 {"MH_JIT_LAZYVAL": "0"}, {"MH_JIT_UNI": "0"}, {"MH_JIT_LAZYVAL": "0", "MH_JIT_UNI": "0", "MH_JIT_FLAGS": "-DMH_JIT_FOLDV=0"},
                 {"MH_JIT_CUTWIN": "0"}, {"MH_JIT_CUTWIN": "60", "MH_JIT_CHUNK": "200"}, {"MH_JIT_BLOCK_LOG": "12"},
-                {"MH_JIT_LAZYVAL": "1", "MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=0"}]
+                {"MH_JIT_LAZYVAL": "1", "MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=0"},
+                # the register budget: every chunk above 96 / 64 registers is cut again (up to three rounds of re-cutting), or never
+                {"MH_JIT_MAXREGS": "96"}, {"MH_JIT_MAXREGS": "64", "MH_JIT_CHUNK": "500"}, {"MH_JIT_SPLIT": "0", "MH_JIT_CHUNK": "500"},
+                {"MH_JIT_CUTK": "60"}]
 
 
 @pytest.mark.parametrize("env", GEN_SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "defaults")
