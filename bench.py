@@ -521,7 +521,7 @@ def miden_real_probe(pkg, ctx, iters=9250, steps=3, lmcs="poseidon2", inputs=Non
             "compiled_chunks": [a.compiled_chunks for a in airs], "chunk_max_vgprs": [a.compiled_max_vgprs for a in airs],
             "kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items() if not k.startswith("span:") and v["ms"] > 0.05},
             "air_load_s": air_load_s,
-            **({"test_trace_generator_s": {"seconds": gen_s, "note": "Python TEST generator (tests/core_trace.py), not product: the reference's "
+            **({"test_trace_generator_s": {"seconds": gen_s, "note": "Python TEST generator (miden-vm_amd/testing/core_trace.py), not product: the reference's "
                                                                      "processor builds these matrices; excluded from every rate"}} if gen_s is not None else {}),
             # speed-ups are quoted from the H2D-inclusive time only (the metric includes the upload) and only against the
             # reference's one published figure, which is another machine, another program and the Blake3 configuration
