@@ -1,0 +1,81 @@
+"""The test VM's operation semantics against the reference processor's own outputs.
+
+tests/golden/ref_all_ops.json = the 1173 insta snapshots of `test_basic_block` (processor/src/fast/tests/all_ops.rs:12-134, extracted
+by tests/golden/make_all_ops.py): for 17 stack-input vectors ([], [1], .., [1..16], top first) x 69 operation sequences, the
+`StackOutputs` the REFERENCE processor ends with -- or the error it raises.  miden-vm_amd/testing/core_trace.py (the generator of every
+executed-program trace the AIR tests and the bench use) must end with the same stack on every sequence it can execute (65 of the
+69: MSTREAM, FRIE2F4, HORNERBASE, HORNEREXT are outside its frozen feature set) and must refuse what the reference refuses
+(non-binary operands, division by zero, unaligned word accesses, a malformed circuit).  On a third of the accepted cases the traces it
+built are also run through the three hand-ported AIRs and `eval_external`: every operation's rows, under every stack depth, satisfy the
+constraints and close the buses -- generator and constraints are held to the same reference outputs from both sides."""
+import json, os
+import numpy as np
+import pytest
+import oracle_binding as ob
+from __graft_entry__ import load_package
+
+load_package()
+from miden_vm_amd import core_air as CO, chiplets_air as CA, miden_air as MA, miden_statement as MS, dag  # noqa: E402
+from miden_vm_amd.testing import core_trace as CV  # noqa: E402
+
+P = dag.P
+DOC = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_all_ops.json")))
+RND = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
+OUTSIDE = {"MSTREAM", "FRIE2F4", "HORNERBASE", "HORNEREXT"}
+
+
+def to_vm_ops(seq):
+    out = []
+    for op in seq:
+        if op[0] == "PUSH":
+            out.append(("PUSH", op[1]))
+        else:
+            out.append(op[0])              # U32ASSERT2 carries an error code in the reference, not an operand
+    return out
+
+
+def run(case):
+    seq = DOC["sequences"][case["ops"]]
+    vm = CV.CoreVM(stack_inputs=tuple(range(1, case["inputs"] + 1)))
+    return CV.prove_inputs(vm, CV.Span(to_vm_ops(seq)))
+
+
+def test_fixture_shape():
+    assert len(DOC["sequences"]) == 69 and len(DOC["cases"]) == 17 * 69
+    assert sum("ok" in c for c in DOC["cases"]) == 1068
+    executable = [s for s in DOC["sequences"] if not ({o[0] for o in s} & OUTSIDE)]
+    assert len(executable) == 65 and all(o[0] in CO.OPC for s in executable for o in s)
+
+
+@pytest.fixture(scope="module")
+def airs():
+    return dict(core=CO.core_air(host_aux=ob.lookup_build_aux), chiplets=CA.chiplets_air(host_aux=ob.lookup_build_aux),
+                poseidon2=MA.poseidon2_permutation_air(host_aux=ob.lookup_build_aux, num_public=32))
+
+
+def test_stack_outputs_and_errors_equal_the_reference_processor(airs):
+    checked = refused = constrained = 0
+    for k, case in enumerate(DOC["cases"]):
+        seq = DOC["sequences"][case["ops"]]
+        if {o[0] for o in seq} & OUTSIDE:
+            continue
+        if "ok" in case:
+            r = run(case)
+            assert r["public_values"][16:] == case["ok"], (case, seq, r["public_values"][16:])
+            assert r["public_values"][:16] == list(range(1, case["inputs"] + 1)) + [0] * (16 - case["inputs"])
+            checked += 1
+            if k % 3 == 0:
+                fins = []
+                for key, t in (("core", r["core"]), ("chiplets", r["chiplets"]), ("poseidon2", r["poseidon2"])):
+                    air, lookup = airs[key]
+                    aux, fin = ob.lookup_build_aux(lookup, t, RND)
+                    assert ob.check_constraints(air, t, aux, fin, publics=r["public_values"], randomness=RND) == (0, None), (case, seq, key)
+                    fins.append([(int(fin[0]), int(fin[1]))])
+                assert MS.eval_external(RND, r["public_values"], r["aux_inputs"], fins, [1, 1, 1]) == [(0, 0)], (case, seq)
+                constrained += 1
+        else:
+            with pytest.raises((AssertionError, KeyError, ValueError, ZeroDivisionError, IndexError)):
+                run(case)
+            refused += 1
+    assert checked == 1068 - sum(1 for c in DOC["cases"] if "ok" in c and ({o[0] for o in DOC["sequences"][c["ops"]]} & OUTSIDE))
+    assert refused >= 80 and constrained >= 300, (checked, refused, constrained)
