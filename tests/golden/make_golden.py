@@ -132,6 +132,26 @@ def main():
     out["ace_circuit_snapshot"] = {"orders": {n: {"num_inputs": int(a), "num_eval_gates": int(b), "stream_len": int(c),
                                                    "commitment": [int(x) for x in d.split(",")]} for n, a, b, c, d in orders},
                                    "relation_digest": [int(x) for x in re.search(r"relation_digest: \[([^\]]*)\]", snap).group(1).split(",")]}
+    # 12. operation batching: the nine `batch_ops_N` cases of core/src/mast/node/basic_block_node/tests.rs:12-270 with their insta
+    #     snapshots (ops incl. padding NOOPs, indptr, padding flags, the 8 group slots, num_groups per batch)
+    bt = open(f"{REF}/core/src/mast/node/basic_block_node/tests.rs").read()
+    op_batches = []
+    for k in range(1, 10):
+        body = bt[bt.index(f"fn batch_ops_{k}()"):]
+        body = body[:body.index("batch_and_hash_ops")]
+        ops = []
+        for name, arg, _num in re.findall(r"Operation::(\w+)(?:\((ONE|Felt::new_unchecked\((\d+)\))\))?", body):
+            ops.append([name.upper(), 1 if arg == "ONE" else int(re.search(r"\d+", arg).group(0))] if arg else [name.upper()])
+        snap = open(f"{REF}/core/src/mast/node/basic_block_node/snapshots/miden_core__mast__node__basic_block_node__tests__batch_ops_{k}.snap").read()
+        batches = []
+        for b in re.findall(r"OpBatch \{(.*?)num_groups: (\d+),", snap, re.S):
+            text = b[0]
+            bops = [[n.upper(), int(a)] if a else [n.upper()] for n, a in re.findall(r"^\s{12}(\w+)(?:\(\s*(\d+),\s*\))?,?$", text[text.index("ops: ["):text.index("indptr")], re.M)]
+            nums = lambda key, nxt: [int(x) for x in re.findall(r"\d+", text[text.index(key):text.index(nxt)] if nxt else text[text.index(key):])]
+            batches.append({"ops": bops, "indptr": nums("indptr: [", "padding"), "padding": re.findall(r"true|false", text[text.index("padding: ["):text.index("groups")]),
+                            "groups": nums("groups: [", None), "num_groups": int(b[1])})
+        op_batches.append({"ops": ops, "batches": batches})
+    out["op_batches"] = op_batches
     with open(os.path.join(HERE, "kat.json"), "w") as f:
         json.dump(out, f, indent=0)
     print("wrote kat.json:", {k: (len(v) if hasattr(v, '__len__') else v) for k, v in out.items()})

@@ -276,3 +276,17 @@ def test_committed_blobs_are_current():
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "miden-vm_amd", "blobs")
     assert (np.fromfile(os.path.join(root, "core.dag"), dtype="<u8") == air.blob).all(), "run tools/export_p2_air.py"
     assert (np.fromfile(os.path.join(root, "core.lkp"), dtype="<u8") == lookup.blob).all(), "run tools/export_p2_air.py"
+
+
+def test_op_batching_equals_the_reference_snapshots():
+    """The nine `batch_ops_N` cases of core/src/mast/node/basic_block_node/tests.rs:12-270 with their insta snapshots
+    (tests/golden/kat.json `op_batches`): operations with the inserted padding NOOPs, `indptr`, the padding flags, the eight group
+    slots and `num_groups` of every batch -- what the decoder rows, the op-group table and the block digests are built from."""
+    assert len(KAT["op_batches"]) == 9
+    for case in KAT["op_batches"]:
+        ops = [tuple(o) if len(o) > 1 else (o[0],) for o in case["ops"]]
+        got = CV.batch_ops(ops)
+        assert len(got) == len(case["batches"]), case["ops"]
+        for g, e in zip(got, case["batches"]):
+            assert [list(o) for o in g["ops"]] == e["ops"], (case["ops"], g["ops"])
+            assert g["indptr"] == e["indptr"] and g["groups"] == e["groups"] and g["num_groups"] == e["num_groups"], (case["ops"], g, e)
