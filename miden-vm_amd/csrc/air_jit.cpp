@@ -1089,21 +1089,26 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
     // the pool ran the core AIR's 256-register chunk five times slower than the others: 3.5 ms instead of 0.65 per 2^22 points) and
     // cutting it costs nothing: core AIR 256 / 248 / 200 / 168 -> 13.46 / 13.27 / 13.17 / 13.97 ms (round 5)
     const int max_regs = env_int("MH_JIT_MAXREGS", 200);
+    // ... and a chunk between 168 (three waves per SIMD below it) and that budget is cut again only where the cut is cheap -- at most
+    // $MH_JIT_SOFTCROSS words alive across it: chiplets 4.42 -> 4.28 ms, Poseidon2 2.76 -> 2.53 ms with every chunk below 168, while the
+    // core AIR, whose cuts cross 40-100 words of operation flags, loses (13.17 -> 13.97 ms) and keeps its 176-184-register chunks
+    const int soft_regs = env_int("MH_JIT_SOFTREGS", 168), soft_cross = env_int("MH_JIT_SOFTCROSS", 32);
     std::vector<size_t> cuts;
     bool any = false;
     for (size_t ci = 0; ci < n_chunks; ci++) {
       unsigned scratch = 0, vg = 0;
       const size_t lo = chunks[ci].ev_lo, hi = chunks[ci].ev_hi;
-      if (code_object_info(chunks[ci].code, &scratch, &vg) && (scratch > 0 || (int)vg > max_regs) && hi - lo >= 8) {
+      if (code_object_info(chunks[ci].code, &scratch, &vg) && (scratch > 0 || (int)vg > soft_regs) && hi - lo >= 8) {
         size_t best_m = 0;
         long best_x = -1;
         for (size_t m = lo + (hi - lo) / 3; m <= lo + 2 * (hi - lo) / 3; m++) {
           if (m <= lo || m >= hi || seq[m].fold_k >= 0) continue;  // never separate a node from the fold that consumes it
           if (best_x < 0 || crossing[m - 1] < best_x) { best_x = crossing[m - 1]; best_m = m; }
         }
-        if (best_m) {
+        const bool must = scratch > 0 || (int)vg > max_regs;
+        if (best_m && (must || best_x <= soft_cross)) {
           if (env_int("MH_JIT_STATS", 0))
-            fprintf(stderr, "[mh jit] chunk %zu [%zu, %zu) does not fit 256 VGPRs (%u bytes of scratch, %u registers): cut again at %zu\n", ci, lo, hi, scratch, vg, best_m);
+            fprintf(stderr, "[mh jit] chunk %zu [%zu, %zu) is above the register budget (%u bytes of scratch, %u registers): cut again at %zu\n", ci, lo, hi, scratch, vg, best_m);
           cuts.push_back(best_m);
           any = true;
         }
