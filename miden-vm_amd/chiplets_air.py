@@ -102,16 +102,15 @@ class When:
     # constraint, the condition product a * b is never formed (FilteredAirBuilder::assert_zero multiplies by ITS condition and hands
     # the result to its parent).  The ports form a * b once and share it ((a * b) * x: 1 + k products for k constraints under the
     # same filters instead of 2 k): the same field values, hence the same proof, ~30 gates fewer over the three AIRs.
-    # P3_NESTING = True emits p3's shape instead -- used by the circuit-size comparison with the reference's ACE snapshot
+    # dag.REFERENCE_SHAPES = True emits p3's shape instead -- used by the circuit-size comparison with the reference's ACE snapshot
     # (tests/test_proof_structure.py), never by the prover.
-    P3_NESTING = False
 
     def __init__(self, b, gate=None, chain=None):
         self.b, self.gate = b, gate
         self.chain = chain if chain is not None else ([gate] if gate is not None else [])
 
     def when(self, cond):
-        if When.P3_NESTING:
+        if dag.REFERENCE_SHAPES:
             return When(self.b, cond, self.chain + [cond])
         return When(self.b, cond if self.gate is None else self.gate * cond)
 
@@ -126,7 +125,7 @@ class When:
 
     def assert_zero(self, x):
         x = x if isinstance(x, dag.Expr) else self.b.const(x)
-        if When.P3_NESTING:
+        if dag.REFERENCE_SHAPES:
             for c in reversed(self.chain):
                 x = c * x
             self.b.assert_zero(x)

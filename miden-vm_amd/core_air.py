@@ -119,20 +119,20 @@ class OpFlags:
         prefix_100 = bits[6][1] * bits[5][0] * bits[4][0]
         is_loop_end = local.is_loop
         end_loop_flag = op("END") * is_loop_end
-        no_shift_depth0 = _sum([op("NOOP"), op("U32ASSERT2"), op("MPVERIFY"), op("SPAN"), op("JOIN"), op("LOOP"), op("EMIT"), op("RESPAN"), op("HALT"),
+        no_shift_depth0 = dag.sum_array([op("NOOP"), op("U32ASSERT2"), op("MPVERIFY"), op("SPAN"), op("JOIN"), op("LOOP"), op("EMIT"), op("RESPAN"), op("HALT"),
                                 op("CALL"), op("SYSCALL"), op("END") * (one - is_loop_end), op("EVALCIRCUIT"), op("HORNERBASE"), op("HORNEREXT")])
         no_shift_depth1 = _sum(deg7[0:8]) - op("NOOP")
         u32_arith_group = prefix_100 * bits[3][0]
-        no_shift_depth4 = _sum([movup_or_movdn[1], advpopw_or_expacc, swapw2_or_swapw3, op("EXT2MUL"), op("MRUPDATE"), op("CALLER")])
+        no_shift_depth4 = dag.sum_array([movup_or_movdn[1], advpopw_or_expacc, swapw2_or_swapw3, op("EXT2MUL"), op("MRUPDATE"), op("CALLER")])
         stream_word_ops = op("MSTREAM") + op("PIPE")
         no_shift_depth8 = movup_or_movdn[5] + op("SWAPW") + stream_word_ops - op("SWAPW2")
         no_shift_depth12 = op("SWAPW2") + op("HPERM") + op("LOGDEFERRED") - stream_word_ops - op("SWAPW3")
         self.no_shift = _accumulate([no_shift_depth0, no_shift_depth1, op("SWAP") + u32_arith_group, movup_or_movdn[0], no_shift_depth4,
                                      movup_or_movdn[2], movup_or_movdn[3], movup_or_movdn[4], no_shift_depth8, movup_or_movdn[6], zero, zero,
                                      no_shift_depth12, stream_word_ops, -(op("HORNERBASE") + op("HORNEREXT")), zero])
-        all_mov_pairs = _sum(movup_or_movdn)
+        all_mov_pairs = dag.sum_array(movup_or_movdn)
         all_movdn = all_mov_pairs * bits[0][1]
-        left_shift_depth1 = _sum([op("ASSERT"), all_movdn, op("DROP"), op("MSTORE"), op("MSTOREW"), deg7[47], op("SPLIT"), op("REPEAT"), end_loop_flag,
+        left_shift_depth1 = dag.sum_array([op("ASSERT"), all_movdn, op("DROP"), op("MSTORE"), op("MSTOREW"), deg7[47], op("SPLIT"), op("REPEAT"), end_loop_flag,
                                   op("DYN"), op("DYNCALL")])
         left_shift_depth2 = _sum(deg7[32:40]) - op("ASSERT")
         left_shift_depth3 = op("CSWAP") + op("U32ADD3") + op("U32MADD") - op("MOVDN2")
@@ -145,8 +145,8 @@ class OpFlags:
         self.right_shift = prefix_011 + op("PUSH") + op("U32SPLIT")
         prefix_010 = prefix_01 * bits[4][0]
         u32_add3_madd_group = prefix_100 * bits[3][1] * bits[2][1]
-        self.left_shift = _sum([prefix_010, u32_add3_madd_group, op("SPLIT"), op("REPEAT"), end_loop_flag, op("DYN")])
-        self.control_flow = _sum([bits[3][0] * bits[2][1] * local.extra[0], bits[4][1] * local.extra[1], op("DYNCALL"), op("DYN"), op("SYSCALL"),
+        self.left_shift = dag.sum_array([prefix_010, u32_add3_madd_group, op("SPLIT"), op("REPEAT"), end_loop_flag, op("DYN")])
+        self.control_flow = dag.sum_array([bits[3][0] * bits[2][1] * local.extra[0], bits[4][1] * local.extra[1], op("DYNCALL"), op("DYN"), op("SYSCALL"),
                                   op("CALL")])
         self.overflow = (local.b0 - 16) * local.h0
         self.u32_rc_op = prefix_100                                        # LookupOpFlags::u32_rc_op (lookup_op_flags.rs:150)
@@ -159,6 +159,49 @@ class OpFlags:
         code = OPC[name]
         fam = self.deg7 if code <= 63 else (self.deg6 if code <= 79 else (self.deg5 if code <= 95 else self.deg4))
         return fam[op_index(code)]
+
+
+class LookupOpFlags:
+    """LookupOpFlags::from_main_cols (lookup/buses/lookup_op_flags.rs:155-330): the flags the LogUp buses read, built by the reference
+    a second time with product trees of their own ((b6 b5 b4) b321 b0 for the degree-7 ones, prefix' nb3' nb2' for the next-row ones,
+    a left chain for left_shift).  The same polynomials as OpFlags'; the ports' lookup side reads OpFlags unless
+    dag.REFERENCE_SHAPES asks for the reference's trees."""
+
+    def __init__(self, bb, local, nxt):
+        one = bb.const(1)
+        bits = [[one - b, b] for b in local.op_bits]
+        b32 = [bits[3][i >> 1] * bits[2][i & 1] for i in range(4)]
+        b321 = [b32[i >> 1] * bits[1][i & 1] for i in range(8)]
+        b3210 = [b321[i >> 1] * bits[0][i & 1] for i in range(16)]
+        b432 = [bits[4][i >> 2] * b32[i & 3] for i in range(8)]
+        b654_0 = bits[6][0] * bits[5][0] * bits[4][0]
+        b654_2 = bits[6][0] * bits[5][1] * bits[4][0]
+        self._f = {}
+        for prefix, names in ((b654_0, ("MLOAD",)), (b654_2, ("U32AND", "U32XOR", "MLOADW", "MSTORE", "MSTOREW"))):
+            for n in names:
+                assert (OPC[n] >> 4) == (0 if prefix is b654_0 else 2)
+                self._f[n] = prefix * b321[(OPC[n] >> 1) & 7] * bits[0][OPC[n] & 1]
+        for n in ("HPERM", "MPVERIFY", "PIPE", "MSTREAM", "SPLIT", "LOOP", "SPAN", "JOIN", "DYN", "PUSH", "DYNCALL", "EVALCIRCUIT", "LOGDEFERRED",
+                  "HORNERBASE", "HORNEREXT"):
+            self._f[n] = local.extra[0] * b3210[op_index(OPC[n])]
+        for n in ("END", "REPEAT", "RESPAN", "CALL", "SYSCALL", "MRUPDATE", "CRYPTOSTREAM"):
+            self._f[n] = b432[op_index(OPC[n])] * local.extra[1]
+        prefix = nxt.extra[1] * nxt.op_bits[4]
+        b3n, b2n = nxt.op_bits[3], nxt.op_bits[2]
+        nb3n, nb2n = one - b3n, one - b2n
+        self.end_next, self.repeat_next = prefix * nb3n * nb2n, prefix * nb3n * b2n
+        self.respan_next, self.halt_next = prefix * b3n * nb2n, prefix * b3n * b2n
+        self.u32_rc_op = bits[6][1] * bits[5][0] * bits[4][0]
+        u32split = self.u32_rc_op * b321[op_index(OPC["U32SPLIT"])]
+        prefix_01 = bits[6][0] * bits[5][1]
+        self.right_shift = prefix_01 * bits[4][1] + self._f["PUSH"] + u32split
+        u32_add3_madd_group = self.u32_rc_op * bits[3][1] * bits[2][1]
+        end_loop = self._f["END"] * local.is_loop
+        self.left_shift = prefix_01 * bits[4][0] + u32_add3_madd_group + self._f["SPLIT"] + self._f["REPEAT"] + end_loop + self._f["DYN"]
+        self.overflow = (local.b0 - 16) * local.h0
+
+    def op(self, name):
+        return self._f[name]
 
 
 # ---- system / range / public inputs -----------------------------------------------------------------------------------------------
@@ -539,10 +582,12 @@ class _Side:
     def __init__(self, bb):
         self.bb = bb
         self.local, self.next = Row(bb, 0), Row(bb, 1)
-        self.f = OpFlags(bb, self.local, self.next)
+        self.f = (LookupOpFlags if dag.REFERENCE_SHAPES else OpFlags)(bb, self.local, self.next)
 
 
 def _block_stack_simple(ch, block_id, parent_id, is_loop):
+    if dag.REFERENCE_SHAPES:   # BlockStackMsg::Simple (messages.rs:698-701): the inner product first, then the prefix
+        return ch.bus_prefix[CA.BUS_BLOCK_STACK_TABLE] + ch.inner_product_at(0, [block_id, parent_id, is_loop])
     return ch.encode(CA.BUS_BLOCK_STACK_TABLE, [block_id, parent_id, is_loop])
 
 

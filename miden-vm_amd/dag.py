@@ -15,6 +15,33 @@ MAGIC = 0x4d48444147303031  # "MHDAG001"
 (OP_CONST, OP_MAIN, OP_AUX, OP_PUBLIC, OP_PERIODIC, OP_IS_FIRST, OP_IS_LAST, OP_IS_TRANSITION, OP_RANDOMNESS,
  OP_AUX_VALUE, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_PREPROCESSED) = range(15)
 
+# The hand-ported AIRs emit each constraint as the SAME POLYNOMIAL as the reference but, in a few places, through a cheaper expression
+# tree (filters of nested `when`s multiplied once and shared; the lookup side reusing the constraint side's operation flags; ...): the
+# same values at every point, hence the same proofs, fewer gates for the evaluator.  REFERENCE_SHAPES = True makes the ports emit the
+# reference's own trees instead (the association p3-air's builders and p3-field's helpers produce) -- used only by the circuit-size
+# comparison with the reference's ACE snapshot (tests/test_proof_structure.py, tests/ace_codegen.py), never by the product.
+REFERENCE_SHAPES = False
+
+
+def sum_array(xs):
+    """`PrimeCharacteristicRing::sum_array::<N>` (p3-field): a left chain here; under REFERENCE_SHAPES p3's tree -- N <= 3 a chain,
+    4 = (x0 + x1) + (x2 + x3), 5..8 = sum4 + sum(rest), above 8 blocks of eight added up in order, then the remainder."""
+    xs = list(xs)
+    if not REFERENCE_SHAPES or len(xs) <= 3:
+        acc = xs[0]
+        for x in xs[1:]:
+            acc = acc + x
+        return acc
+    n = len(xs)
+    if n == 4:
+        return (xs[0] + xs[1]) + (xs[2] + xs[3])
+    if n <= 8:
+        return sum_array(xs[:4]) + sum_array(xs[4:])
+    acc = sum_array(xs[:8])
+    for i in range(16, n + 1, 8):
+        acc = acc + sum_array(xs[i - 8:i])
+    return acc + sum_array(xs[8 * (n // 8):]) if n & 7 else acc
+
 
 class Expr:
     """A DAG node handle with operator overloading; `deg` = degree multiple, `ext` = EF-valued."""
@@ -363,6 +390,9 @@ def lookup_from_constraints(air_blob, name="derived"):
 
 
 # ---- the reference's closure-based lookup API, both adapters at once ------------------------------------------------------------
+MINUS_ONE = object()   # the multiplicity of LookupBatch::remove on the constraint side
+
+
 class LogUp:
     """`LookupBuilder` of air/src/lookup/builder.rs:103-183 over a dag.AirBuilder, playing BOTH of the reference's adapters in one
     walk: the constraint path (lookup/constraint.rs: `(V, U)` running pairs per group / batch / column, the three constraints per
@@ -431,10 +461,16 @@ class LogUp:
             return self
 
         def _push(self, mult_pair, message):
+            mc, mp = mult_pair
+            minus_one = mc is MINUS_ONE
+            if minus_one and not REFERENCE_SHAPES:
+                mc = self.lk.b.const(P - 1)
             v = message(self.lk.ch_c)
             d_prev = self.d
-            mc, mp = mult_pair
-            self.n = self.n * v + (d_prev * mc if mc is not None else d_prev)  # ConstraintBatch::insert: N <- N v + m D
+            if minus_one and REFERENCE_SHAPES:                                 # ConstraintBatch::remove: N <- N v - D
+                self.n = self.n * v - d_prev
+            else:
+                self.n = self.n * v + (d_prev * mc if mc is not None else d_prev)  # ConstraintBatch::insert: N <- N v + m D
             self.d = self.d * v
             fp = self.flag[1]
             self.lk.lb.fraction(self.col, fp * mp if mp is not None else fp, message(self.lk.ch_p))
@@ -443,7 +479,7 @@ class LogUp:
             self._push((None, None), message)
 
         def remove(self, message):
-            self._push((self.lk.b.const(P - 1), self.lk.lb.const(P - 1)), message)
+            self._push((MINUS_ONE, self.lk.lb.const(P - 1)), message)
 
         def insert(self, multiplicity, message):
             self._push(multiplicity, message)

@@ -101,9 +101,7 @@ def _matmul_external(s):
 
 
 def _matmul_internal(s, diag):
-    total = s[0]
-    for x in s[1:]:
-        total = total + x
+    total = dag.sum_array(s)                                # E::sum_array::<STATE_WIDTH> (state.rs:156)
     return [s[i] * diag[i] + total for i in range(STATE_WIDTH)]
 
 

@@ -159,24 +159,60 @@ def test_parser_consumes_the_other_configurations(lmcs, alignment):
         ob.set_lmcs("poseidon2")
 
 
+def _eval_constraints(parsed, rng_seed):
+    """Every constraint of a parsed "MHDAG001" blob at one random point (main / aux two-row windows, public values, periodic values,
+    selectors, challenges, aux values all random): [(c0, c1)] in emission order.  A plain EF interpreter of the node list."""
+    P_ = dag.P
+    rng = np.random.default_rng(rng_seed)
+    rnd = lambda: int(rng.integers(0, P_, dtype=np.uint64))                                                     # noqa: E731
+    memo_in = {}
+
+    def leaf(key, ext=False):
+        if key not in memo_in:
+            memo_in[key] = (rnd(), rnd() if ext else 0)
+        return memo_in[key]
+
+    mul = lambda a, b: ((a[0] * b[0] + 7 * a[1] * b[1]) % P_, (a[0] * b[1] + a[1] * b[0]) % P_)                   # noqa: E731
+    vals = []
+    for op, a, b, c in parsed["nodes"]:
+        if op == dag.OP_CONST:
+            v = (c % P_, 0)
+        elif op == dag.OP_ADD:
+            v = ((vals[a][0] + vals[b][0]) % P_, (vals[a][1] + vals[b][1]) % P_)
+        elif op == dag.OP_SUB:
+            v = ((vals[a][0] - vals[b][0]) % P_, (vals[a][1] - vals[b][1]) % P_)
+        elif op == dag.OP_MUL:
+            v = mul(vals[a], vals[b])
+        elif op == dag.OP_NEG:
+            v = ((-vals[a][0]) % P_, (-vals[a][1]) % P_)
+        else:
+            v = leaf((op, a, b), ext=op in (dag.OP_AUX, dag.OP_RANDOMNESS, dag.OP_AUX_VALUE))
+        vals.append(v)
+    return [vals[i] for i in parsed["constraints"]]
+
+
 def test_ace_circuit_snapshot_pins_the_statement_shape_and_the_constraint_system_size():
     """The reference holds the size of its recursive verifier's ACE circuit over [CoreAir, ChipletsAir, Poseidon2PermutationAir]
-    (air/src/snapshots/miden_air__config__tests__relation_digest_matches_current_air.snap, test air/src/config.rs:383-454):
-    `num_inputs 624, num_eval_gates 5208, stream_len 5792`, identical for the six proof orders.  tests/ace_codegen.py restates the
-    pipeline that produces it (crates/ace-codegen: DagBuilder, lowering, periodic columns, quotient recomposition, emission, encoding;
-    air/src/ace/multi_air.rs: the three-AIR composition) and runs it over the HAND-PORTED constraint DAGs:
+    (air/src/snapshots/miden_air__config__tests__relation_digest_matches_current_air.snap, test air/src/config.rs:383-454; the same
+    numbers in crates/lib/core/asm/sys/vm/constraints_eval.masm:9-12): `num_inputs 624, num_eval_gates 5208, stream_len 5792`,
+    identical for the six proof orders.  tests/ace_codegen.py restates the pipeline that produces it (crates/ace-codegen: DagBuilder,
+    lowering, periodic columns, quotient recomposition, emission, encoding; air/src/ace/multi_air.rs: the three-AIR composition)
+    and runs it over the HAND-PORTED constraint DAGs:
 
     * READ layout: 332 slots, exact -- pure arithmetic over the statement's shape (layout/policy.rs:78-218 MASM policy, multi-AIR
       composition; per-AIR widths padded to 8, ace/multi_air.rs:188-217); the snapshot says 624 - (5792 - 5208) / 2 = 332;
     * CONSTANTS: 292 distinct values, exact -- `num_inputs` = 332 + 292 = 624 as in the snapshot.  Every constant of the three
       constraint systems, the periodic columns in their cheaper form (dense Horner coefficients / sparse Lagrange terms), the
       extension basis element and the folded constants enter this count;
-    * OPERATIONS: 5200 against 5201..5208 (the stream is padded to a multiple of 8 felts: `num_eval_gates` 5200 / `stream_len` 5784
-      here, 5208 / 5792 in the snapshot -- one padding block apart), when nested filters are emitted as p3-air emits them
-      (a * (b * x), `When.P3_NESTING`); 5171 in the ports' own, shared form.  The remaining 1..8 operations are expression-shape
-      differences that cannot be located without the reference's symbolic trees; with `assert_bool(x)` as x * (x - 1) instead of
-      (1 - x) * x the count overshoots (5214), which is what the ports' sign convention for `bool_check` rests on besides the
-      recollection of p3-field's `andn`.
+    * OPERATIONS: the stream is padded to a multiple of 8 felts, so the snapshot says 5201..5208.  The ports' own trees give 5171;
+      with every place where the ports knowingly emit a cheaper tree for the same polynomial switched to the reference's tree
+      (`dag.REFERENCE_SHAPES`: p3-air's nested filters a * (b * x); the lookup side's own operation flags, lookup_op_flags.rs;
+      ConstraintBatch::remove as N v - D; p3-field's `sum_array` tree; BlockStackMsg's inner-product-first encoding) 5187 -- all
+      of core / chiplets / Poseidon2 constraint and bus code was then re-read against the reference line by line without another
+      difference in tree shape.  The last 14..21 operations sit in what is NOT in the checkout: p3-air / p3-field 0.6.2.  One
+      candidate accounts for exactly 14: `assert_bool(x)` as x * (x - 1) (p3-air before `bool_check`) instead of (1 - x) * x
+      (`andn(x, x)`, as recollected for 0.6) gives 5201, inside the window -- recorded, not claimed.
+    The two forms are the SAME POLYNOMIALS: every constraint of every AIR takes the same value at random points in both.
     All six proof orders give the same figures, as the reference asserts for its own."""
     import ace_codegen as AC
     from miden_vm_amd import core_air as CO, chiplets_air as CA, miden_air as MA
@@ -203,13 +239,22 @@ def test_ace_circuit_snapshot_pins_the_statement_shape_and_the_constraint_system
     assert read_slots == 332 == num_inputs - (stream - gates) // 2
     own = AC.build_multi_air_circuit(airs, [0, 1, 2])
     assert (own["ops"], own["constants"]) == (5171, 292)
-    CA.When.P3_NESTING = True
+    orders = ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0))
+    bool_check = CA.When.assert_bool
+    dag.REFERENCE_SHAPES = True
     try:
-        p3 = parsed_airs()
-        sizes = {tuple(AC.build_multi_air_circuit(p3, list(order))[k] for k in ("ops", "constants", "num_eval_gates", "stream_len"))
-                 for order in ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0))}
+        ref = parsed_airs()
+        sizes = {tuple(AC.build_multi_air_circuit(ref, list(order))[k] for k in ("ops", "constants", "num_eval_gates", "stream_len")) for order in orders}
+        CA.When.assert_bool = lambda self, x: self.assert_zero(x * (x - 1))
+        alt = AC.build_multi_air_circuit(parsed_airs(), [0, 1, 2])
     finally:
-        CA.When.P3_NESTING = False
-    assert sizes == {(5200, 292, 5200, 5784)}, sizes
+        dag.REFERENCE_SHAPES = False
+        CA.When.assert_bool = bool_check
+    assert sizes == {(5187, 292, 5192, 5776)}, sizes
     assert read_slots + 292 == num_inputs                                    # exact
-    assert 0 < gates - 5200 <= 8 and stream - 5784 == 8                      # one padding block below the reference
+    assert 14 <= (gates - 7) - 5187 and gates - 5187 <= 21                   # 14..21 operations below the reference
+    assert (alt["ops"], alt["constants"], alt["num_eval_gates"], alt["stream_len"]) == (5201, 292, gates, stream)
+    for k, (a, r) in enumerate(zip(airs, ref)):                              # the same polynomials, constraint for constraint
+        assert len(a["constraints"]) == len(r["constraints"])
+        for seed in (1, 2, 3):
+            assert _eval_constraints(a, seed) == _eval_constraints(r, seed), k
