@@ -112,6 +112,7 @@ class AirBuilder:
             assert len(col) > 0 and len(col) & (len(col) - 1) == 0, "periodic column length must be a power of two"
         self.nodes = []        # (op, a, b, const)
         self.constraints = []  # node ids in emission order
+        self.constraint_degrees = []  # (degree multiple, emitted through assert_zero_ext) per constraint
         self.max_degree = 0
         self.declared_degree = None  # LiftedAir::constraint_degree when the AIR declares it (air/src/lib.rs:686-692)
         self._cache = {}
@@ -172,10 +173,12 @@ class AirBuilder:
     def assert_zero(self, e):
         assert not e.ext, "extension-valued expression: use assert_zero_ext"
         self.constraints.append(e.id)
+        self.constraint_degrees.append((e.deg, False))
         self.max_degree = max(self.max_degree, e.deg)
 
     def assert_zero_ext(self, e):
         self.constraints.append(e.id)
+        self.constraint_degrees.append((e.deg, True))
         self.max_degree = max(self.max_degree, e.deg)
 
     # ---- lowering ----
@@ -215,6 +218,7 @@ class Air:
         self.num_public = builder.num_public
         self.log_quotient_degree = builder.log_quotient_degree()
         self.blob = builder.blob()
+        self.constraint_degrees = list(builder.constraint_degrees)
         self.build_aux = build_aux
 
 
