@@ -1,7 +1,7 @@
 """The second client of the backend: AIRs of the precompile prover (`precompiles-prover/src`), hand-ported against `dag.AirBuilder`
 like the VM's three AIRs, and the statement layer of its session (`precompiles-prover/src/session/prove.rs`).
 
-What is here: three of the twelve chiplets of `ChipletAir::all()` (session/prove.rs:104-121) --
+What is here: four of the twelve chiplets of `ChipletAir::all()` (session/prove.rs:104-121) --
 * `BytePairLutAir` (`primitives/byte_pair_lut.rs`): the one AIR of the stack with PREPROCESSED columns and a fixed height -- the
   2^16-row `(a, b, !a & b, a ^ b)` table committed once, three witness multiplicity columns, two LogUp columns;
 * `KeccakRoundAir` (`hash/keccak/round/{mod,program}.rs`): its consumer -- a three-address machine `c = ROL(a OP b, s)` whose 128-slot
@@ -9,11 +9,13 @@ What is here: three of the twelve chiplets of `ChipletAir::all(
   provide / requires, eight byte-pair requests, eight Range16 limb requests per row);
 * `EcGroupsAir` (`ec/groups.rs`): six columns, an ungated pointer chain, one LogUp column whose provides are closed by the verifier's
   fixed boundary consumes;
+* `ChunkAir` (`hash/chunk/{mod,message,trace}.rs`): the hashers' input tape -- one row per 32-byte chunk, provided as four Memory64
+  lanes and absorbed as one Poseidon2 block, twelve columns, FIVE flattened LogUp columns (`frac_col!`) on three buses;
 the precompile prover's LogUp adapter (natural last-row sigma closing, `logup/constraint.rs`: `dag.LogUp(closing="sigma_last_row")`),
 its bus registry (`relations.rs`) and `ChipletMultiAir::eval_external` (`session/prove.rs:259-272`: sum of the committed sigmas + the
 fixed boundary correction).
 
-What is not: the other nine chiplets (Keccak sponge, chunk nodes, Poseidon2 transcript, eval, uint store / add, EC point store / add /
+What is not: the other eight chiplets (Keccak sponge, chunk nodes, Poseidon2 transcript, eval, uint store / add, EC point store / add /
 MSM: ~25 kLoC of the reference).  What the SPONGE would put on the Memory64 bus for the permutations of a trace (initial lanes, round
 constants, the consumed outputs: `sponge_side_requests`) comes from `requirer_air`, a one-interaction-per-row stand-in written against
 the same adapter, so that the statement closes; `eval_external` sums the `EcGroup` part of `fixed_boundary_correction` only (the
@@ -30,6 +32,7 @@ P = dag.P
 # relations.rs:52-80 (bus ids), :91 (MAX_MESSAGE_WIDTH), :78 (NUM_BUS_IDS); logup/mod.rs:103 (NUM_RANDOMNESS), :131 (NUM_PUBLIC_VALUES),
 # :146 (NUM_SIGMA_VALUES)
 BUS_BYTE_PAIR_LUT, BUS_RANGE16, BUS_MEMORY64, BUS_KECCAK_SPONGE, BUS_EC_GROUP = 0, 1, 4, 5, 14
+BUS_POSEIDON2_IN, BUS_POSEIDON2_OUT, BUS_CHUNK_CHAIN = 6, 7, 9
 MAX_MESSAGE_WIDTH, NUM_BUS_IDS = 18, 21
 NUM_RANDOMNESS, NUM_PUBLIC_VALUES, NUM_SIGMA_VALUES = 2, 4, 1
 PLACEHOLDER_RELATION_DIGEST = (0, 0, 0, 0)  # session/prove.rs:40
@@ -165,11 +168,12 @@ def ec_groups_trace(groups=None, log_n=3):
 REQUIRER_COLS = 2 + 4  # multiplicity | bus id + 1 | up to four payload felts
 
 
-def requirer_air(host_aux=None):
+def requirer_air(host_aux=None, payload=4):
     """A stand-in for the consumers of the byte-pair table (the Keccak round chiplet's byte and limb requests,
     hash/keccak/round/mod.rs:396-560): one interaction per row, multiplicity `m` on `bus_prefix[bus] + <beta^i, f_i>` with the bus id
-    as a column (the prefix is linear in it, logup/mod.rs:44-47), through the same sigma-closing adapter."""
-    b = dag.AirBuilder(REQUIRER_COLS, aux_width=1, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
+    as a column (the prefix is linear in it, logup/mod.rs:44-47), through the same sigma-closing adapter.  `payload` = the number of
+    payload columns (4: the byte-pair / Memory64 shapes; 6: Poseidon2In's `(perm_seq_id, tag, c0..c3)`)."""
+    b = dag.AirBuilder(2 + payload, aux_width=1, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
                        num_public=NUM_PUBLIC_VALUES)
     lk = dag.LogUp(b, MAX_MESSAGE_WIDTH, NUM_BUS_IDS, closing="sigma_last_row")
 
@@ -177,25 +181,26 @@ def requirer_air(host_aux=None):
         bb = lk.b if ch is lk.ch_c else lk.lb
         gamma = ch.bus_prefix[1] - ch.bus_prefix[0]
         acc = ch.alpha + gamma * bb.main(1)
-        for i in range(4):
+        for i in range(payload):
             acc = acc + ch.beta_powers[i] * bb.main(2 + i)
         return acc
     with lk.column() as col:
         with col.group() as g:
             with g.batch((lk.b.const(1), lk.lb.const(1))) as bt:
                 bt.insert((lk.b.main(0), lk.lb.main(0)), msg)
-    lookup = lk.finish("requirer")
-    return dag.Air(b, _host_aux(lookup, host_aux), "requirer"), lookup
+    name = "requirer" if payload == 4 else f"requirer{payload}"
+    lookup = lk.finish(name)
+    return dag.Air(b, _host_aux(lookup, host_aux), name), lookup
 
 
-def requirer_trace(requests, log_n=None):
+def requirer_trace(requests, log_n=None, payload=4):
     """requests = [(bus, multiplicity, fields)]; every row may fire (the sigma closing has no dead last row)."""
     log_n = max(3, (max(1, len(requests)) - 1).bit_length()) if log_n is None else log_n
     assert len(requests) <= 1 << log_n
-    t = np.zeros((1 << log_n, REQUIRER_COLS), dtype=np.uint64)
+    t = np.zeros((1 << log_n, 2 + payload), dtype=np.uint64)
     t[:, 1] = 1  # silent rows: a well-formed (nonzero) denominator with multiplicity 0
     for r, (bus, mult, fields) in enumerate(requests):
-        assert len(fields) <= 4
+        assert len(fields) <= payload
         t[r, 0], t[r, 1] = int(mult) % P, bus + 1
         t[r, 2:2 + len(fields)] = [int(x) % P for x in fields]
     return t
@@ -255,6 +260,153 @@ def eval_external(randomness, aux_values):
 
 def external_assertions(pkg):
     return pkg.external_callback(lambda rnd, aux_values, lhs: eval_external(rnd, aux_values))
+
+
+# ---- Chunk: the input-byte tape of the hashers (hash/chunk/{mod,message,trace}.rs) ------------------------------------------------------
+# One row per 32-byte chunk = 8 u32 felts = four Memory64 lanes for the downstream hasher AND one Poseidon2 absorption block
+# (`rate0 || rate1`) of the chain that content-hashes the invocation; chain heads also consume the capacity `Tag::CHUNKS` and
+# provide a `ChunkChain` tuple tying the chunk-side index to the P2 chain.  12 main columns, FIVE flattened LogUp columns
+# (`frac_col!`, logup/mod.rs:13-28: one column = one group = one batch under the flag ONE), no periodic columns.
+CHUNK_COLS, CHUNK_AUX_COLS, CHUNK_NUM_F = 12, 5, 8                      # chunk/mod.rs:55-83, :96
+COL_CHUNK_SEQ_ID, COL_PERM_SEQ_ID, COL_CHUNK_ACT, COL_IS_HEAD, COL_F_BEGIN = 0, 1, 2, 3, 4
+CHUNK_ADDR_BASE = 1 << 48                                               # hash/memory64.rs:40
+TAG_CHUNKS_WORD = (2, 0, 0, 0)                                          # Tag::CHUNKS.as_word(), core/src/deferred/node.rs:47-56, :91-93
+POSEIDON2_IN_TAG_RATE0, POSEIDON2_IN_TAG_RATE1, POSEIDON2_IN_TAG_CAP = 0, 1, 2   # transcript/poseidon2/messages.rs:19-23
+
+
+def chunk_air(host_aux=None):
+    """`ChunkAir::eval` (hash/chunk/mod.rs:149-200): `chunk_seq_id` = the row index, `perm_seq_id` + 1 inside a chain and free at chain
+    heads, `act` sticky downward, `is_head` boolean and dead on inactive rows; and its `LookupAir::eval` (:223-360): col 0 lane0 |
+    col 1 lane1 + lane2 | col 2 lane3 + rate0 | col 3 rate1 + cap | col 4 the ChunkChain emit."""
+    b = dag.AirBuilder(CHUNK_COLS, aux_width=CHUNK_AUX_COLS, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
+                       num_public=NUM_PUBLIC_VALUES)
+    loc, nxt = [b.main(c) for c in range(CHUNK_COLS)], [b.main(c, 1) for c in range(CHUNK_COLS)]
+    one = b.const(1)
+    chunk_seq_id, chunk_seq_id_next = loc[COL_CHUNK_SEQ_ID], nxt[COL_CHUNK_SEQ_ID]
+    perm_seq_id, perm_seq_id_next = loc[COL_PERM_SEQ_ID], nxt[COL_PERM_SEQ_ID]
+    act, act_next, is_head, is_head_next = loc[COL_CHUNK_ACT], nxt[COL_CHUNK_ACT], loc[COL_IS_HEAD], nxt[COL_IS_HEAD]
+    b.assert_zero(b.is_first_row() * chunk_seq_id)
+    b.assert_zero(b.is_transition() * (chunk_seq_id_next - chunk_seq_id - one))
+    b.assert_zero(b.is_transition() * ((one - is_head_next) * (perm_seq_id_next - perm_seq_id - one)))
+    b.assert_zero((one - act) * act)                                    # assert_bool(act)
+    b.assert_zero(b.is_transition() * ((one - act) * act_next))
+    b.assert_zero((one - is_head) * is_head)                            # assert_bool(is_head)
+    b.assert_zero(is_head * (one - act))
+    lk = dag.LogUp(b, MAX_MESSAGE_WIDTH, NUM_BUS_IDS, closing="sigma_last_row")
+
+    def side(ch):
+        bb = lk.b if ch is lk.ch_c else lk.lb
+        row = [bb.main(c) for c in range(CHUNK_COLS)]
+        return bb, row, row[COL_F_BEGIN:COL_F_BEGIN + CHUNK_NUM_F]
+
+    def lane(j):        # Memory64Msg { addr: CHUNK_ADDR_BASE + 4 chunk_seq_id + j, lo: f[2j], hi: f[2j + 1] } (hash/memory64.rs:55-64)
+        def msg(ch):
+            bb, row, f = side(ch)
+            addr = bb.const(CHUNK_ADDR_BASE) + bb.const(4) * row[COL_CHUNK_SEQ_ID]
+            if j:
+                addr = addr + bb.const(j)
+            return ch.encode(BUS_MEMORY64, [addr, f[2 * j], f[2 * j + 1]])
+        return msg
+
+    def p2_in(tag, which):   # Poseidon2InMsg::{rate0, rate1, cap} (transcript/poseidon2/messages.rs:43-87)
+        def msg(ch):
+            bb, row, f = side(ch)
+            c = [bb.const(x) for x in TAG_CHUNKS_WORD] if which is None else f[4 * which:4 * which + 4]
+            return ch.encode(BUS_POSEIDON2_IN, [row[COL_PERM_SEQ_ID], bb.const(tag)] + c)
+        return msg
+
+    def emit(ch):            # ChunkChainMsg (hash/chunk/message.rs)
+        _, row, _ = side(ch)
+        return ch.encode(BUS_CHUNK_CHAIN, [row[COL_CHUNK_SEQ_ID], row[COL_PERM_SEQ_ID]])
+
+    def mults(fn):
+        return fn(lk.b), fn(lk.lb)
+    neg_act = mults(lambda bb: bb.const(0) - bb.main(COL_CHUNK_ACT))
+    pos_act = mults(lambda bb: bb.main(COL_CHUNK_ACT))
+    pos_act_head = mults(lambda bb: bb.main(COL_CHUNK_ACT) * bb.main(COL_IS_HEAD))
+    neg_act_head = mults(lambda bb: bb.const(0) - bb.main(COL_CHUNK_ACT) * bb.main(COL_IS_HEAD))
+    columns = ([(neg_act, lane(0))], [(neg_act, lane(1)), (neg_act, lane(2))], [(neg_act, lane(3)), (pos_act, p2_in(POSEIDON2_IN_TAG_RATE0, 0))],
+               [(pos_act, p2_in(POSEIDON2_IN_TAG_RATE1, 1)), (pos_act_head, p2_in(POSEIDON2_IN_TAG_CAP, None))], [(neg_act_head, emit)])
+    for fractions in columns:                                           # frac_col!
+        with lk.column() as col:
+            with col.group() as g:
+                with g.batch((lk.b.const(1), lk.lb.const(1))) as bt:
+                    for mult, msg in fractions:
+                        bt.insert(mult, msg)
+    lookup = lk.finish("chunk")
+    return dag.Air(b, _host_aux(lookup, host_aux), "chunk"), lookup
+
+
+def chunks_from_bytes(data):
+    """`Node::chunks_from_bytes` (core/src/deferred/node.rs:365-374; `bytes_to_packed_u32_elements`, core/src/utils/mod.rs:136-146):
+    little-endian u32 felts, zero-padded to a non-empty multiple of 8 -> [[8 felts]]."""
+    data = bytes(data)
+    felts = [int.from_bytes(data[i:i + 4].ljust(4, b"\0"), "little") for i in range(0, len(data), 4)]
+    n_chunks = max(1, -(-len(felts) // CHUNK_NUM_F))
+    felts += [0] * (n_chunks * CHUNK_NUM_F - len(felts))
+    return [felts[i:i + CHUNK_NUM_F] for i in range(0, len(felts), CHUNK_NUM_F)]
+
+
+class ChunkRequires:
+    """`ChunkRequires` (hash/chunk/trace.rs:75-125) with the part of `Poseidon2Requires` it drives (transcript/poseidon2/trace.rs:
+    218-236: an absorption chain is laid once per DIGEST, i.e. once per chunk content -- a repeated input reuses its span and raises
+    the chain's `in_mult`): records = [(chunks, first chunk_seq_id, first perm_seq_id)]."""
+
+    def __init__(self):
+        self.records, self.next_chunk_seq, self.next_perm_seq = [], 0, 0
+        self.spans = {}          # chunk content -> (start, len, in_mult)
+
+    def require(self, data):
+        """-> (chunk_head seq, (perm span start, perm span len))"""
+        chunks = chunks_from_bytes(data)
+        key = tuple(x for c in chunks for x in c)
+        if key in self.spans:
+            start, n, mult = self.spans[key]
+            self.spans[key] = (start, n, mult + 1)
+        else:
+            start, n = self.next_perm_seq, len(chunks)
+            self.spans[key] = (start, n, 1)
+            self.next_perm_seq += n
+        head = self.next_chunk_seq
+        self.records.append((chunks, head, start))
+        self.next_chunk_seq += len(chunks)
+        return head, (start, n)
+
+
+def chunk_trace(requires, min_height=0):
+    """`generate_trace_padded_to` (hash/chunk/trace.rs:133-175): one row per chunk, then dead rows on which both counters run on."""
+    total = requires.next_chunk_seq
+    height = max(2, min_height, 1 << max(0, (total - 1).bit_length()) if total else 1)
+    t = np.zeros((height, CHUNK_COLS), dtype=np.uint64)
+    r, next_perm = 0, 0
+    for chunks, head, perm_start in requires.records:
+        assert head == r
+        for c, f in enumerate(chunks):
+            t[r, 0:4] = [r, perm_start + c, 1, int(c == 0)]
+            t[r, COL_F_BEGIN:] = f
+            r += 1
+        next_perm = perm_start + len(chunks)
+    for k in range(r, height):
+        t[k, 0], t[k, 1] = k, next_perm
+        next_perm += 1
+    return t
+
+
+def chunk_side_requests(requires):
+    """What the chiplets that are not ported put on the chunk chiplet's three buses: the downstream hasher consumes every Memory64
+    lane once, the Poseidon2 chiplet provides each absorption block (rate0, rate1, and the capacity on chain heads) once per laid
+    chain USE, the node chiplet consumes each chain's ChunkChain tuple.  -> [(bus, multiplicity, fields)] for `requirer_air(payload=6)`."""
+    out = []
+    for chunks, head, perm_start in requires.records:
+        for c, f in enumerate(chunks):
+            seq = head + c
+            for j in range(4):
+                out.append((BUS_MEMORY64, 1, [CHUNK_ADDR_BASE + 4 * seq + j, f[2 * j], f[2 * j + 1]]))
+            out.append((BUS_POSEIDON2_IN, P - 1, [perm_start + c, POSEIDON2_IN_TAG_RATE0] + f[0:4]))
+            out.append((BUS_POSEIDON2_IN, P - 1, [perm_start + c, POSEIDON2_IN_TAG_RATE1] + f[4:8]))
+        out.append((BUS_POSEIDON2_IN, P - 1, [perm_start, POSEIDON2_IN_TAG_CAP] + list(TAG_CHUNKS_WORD)))
+        out.append((BUS_CHUNK_CHAIN, 1, [head, perm_start]))
+    return out
 
 
 # ---- KeccakRound: the consumer of the byte-pair table (hash/keccak/round/{mod,program}.rs) --------------------------------------------

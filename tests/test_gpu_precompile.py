@@ -235,3 +235,67 @@ def test_keccak_session_production_params_equals_oracle(ctx):
         assert (got.digest == exp["digest"]).all()
     finally:
         ob.use_fast_library(False)
+
+
+# ---- the chunk chiplet: the hashers' input tape (hash/chunk) ---------------------------------------------------------------------------
+def chunk_session(n_invocations, max_len, seed=21):
+    """[ChunkAir, the other sides of its three buses (Memory64 consumes of the hasher, Poseidon2In provides of the P2 chiplet, ChunkChain
+    consumes of the node chiplet), EcGroupsAir]: no preprocessed AIR in this statement."""
+    rng = np.random.default_rng(seed)
+    req = PA.ChunkRequires()
+    inputs = [bytes(rng.integers(0, 256, int(rng.integers(0, max_len + 1)), dtype=np.uint8)) for _ in range(n_invocations)]
+    inputs.append(inputs[0])                                            # a repeated input: its absorption chain is reused
+    for data in inputs:
+        req.require(data)
+    pairs = [PA.chunk_air(host_aux), PA.requirer_air(host_aux, payload=6), PA.ec_groups_air(host_aux)]
+    traces = [PA.chunk_trace(req), PA.requirer_trace(PA.chunk_side_requests(req), payload=6), PA.ec_groups_trace()]
+    return [p[0] for p in pairs], [p[1] for p in pairs], traces
+
+
+def chunk_device_prove(ctx, airs_, lookups, traces, params):
+    pkg = load_package()
+    dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+    for d, lk in zip(dairs, lookups):
+        d.attach_lookup(pkg.DeviceLookup(ctx, lk))
+    st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
+    pre = protocol.protocol_pre_observe(params, ROOT)
+    return pkg.prove(ctx, dairs, [ctx.upload_trace(t) for t in traces], ROOT, params, st, pre, never), st, pre
+
+
+@pytest.mark.parametrize("jit", ["0", "1"])
+def test_chunk_session_device_proof_equals_oracle(ctx, jit, monkeypatch):
+    """ChunkAir (12 main columns, FIVE flattened LogUp columns: `frac_col!`) with every aux column built on the device; interpreter and
+    compiled chunks; the statement closes only through `eval_external`."""
+    pkg = load_package()
+    monkeypatch.setenv("MH_JIT", jit)
+    airs_, lookups, traces = chunk_session(9, 300)
+    rnd = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
+    aux_dev, fin = pkg.DeviceLookup(ctx, lookups[0]).build_aux(ctx.upload_trace(traces[0]), rnd)
+    aux, exp_fin = ob.lookup_build_aux(lookups[0], traces[0], rnd)
+    assert (aux_dev.download() == aux).all() and fin == (int(exp_fin[0]), int(exp_fin[1])) and fin != (0, 0)
+    exp = ob.prove(airs_, traces, ROOT, FAST, init_state=protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST))
+    got, st, pre = chunk_device_prove(ctx, airs_, lookups, traces, FAST)
+    assert (got.commitments == exp["commitments"]).all()
+    assert got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all()
+    assert (got.digest == exp["digest"]).all()
+    assert got.log_trace_heights == [int(t.shape[0]).bit_length() - 1 for t in traces]
+    ok, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, FAST, st, pre, got.fields, got.commitments, external=PA.external_assertions(pkg))
+    assert ok and (dig == got.digest).all()
+    bal = pkg.external_callback(lambda rnd_, av, lhs: [(sum(v[0][0] for v in av) % P, sum(v[0][1] for v in av) % P)])
+    ok3, _ = pkg.verify(airs_, got.log_trace_heights, ROOT, FAST, st, pre, got.fields, got.commitments, external=bal)
+    assert not ok3
+
+
+def test_chunk_session_production_params_one_mebibyte_of_input(ctx):
+    """35 076 chunks = 1.07 MiB of hasher input in 64 invocations (2^16 rows; 210 584 interactions on the other sides, 2^18 rows),
+    production parameters: verify-only through both verifiers."""
+    pkg = load_package()
+    airs_, lookups, traces = chunk_session(63, 32768, seed=4)
+    prm = dict(protocol.PROD_PARAMS)
+    got, st, pre = chunk_device_prove(ctx, airs_, lookups, traces, prm)
+    assert got.log_trace_heights == [16, 18, 3]
+    ok, msg = ob.verify(airs_, got.log_trace_heights, ROOT, {"fields": got.fields, "commitments": got.commitments}, prm,
+                        init_state=st, pre_observe=pre, external=PA.external_assertions(pkg))
+    assert ok, msg
+    ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, external=PA.external_assertions(pkg))
+    assert ok2 and (dig == got.digest).all()
