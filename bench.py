@@ -448,6 +448,47 @@ def precompile_session_probe(pkg, ctx, n_perms=80, steps=3):
             "trace_generation_s": gen_s, "setup_s": setup_s, "device_built_traces": dev}
 
 
+def chunk_session_probe(pkg, ctx, steps=3):
+    """The second client's chunk chiplet (precompiles-prover/src/hash/chunk: `ChunkAir`, twelve columns, five flattened LogUp columns on
+    the Memory64 / Poseidon2In / ChunkChain buses): 1.07 MiB of hasher input in 64 invocations (35 076 chunks, 2^16 rows), the other sides
+    of its buses from the one-interaction-per-row stand-in (2^18 rows), the group table; production parameters, aux columns on the device,
+    verified through `ChipletMultiAir::eval_external`."""
+    import numpy as np
+    from miden_vm_amd import protocol, precompile_airs as PA
+    rng = np.random.default_rng(4)
+    t0 = time.perf_counter()
+    req = PA.ChunkRequires()
+    inputs = [bytes(rng.integers(0, 256, int(rng.integers(0, 32769)), dtype=np.uint8)) for _ in range(63)]
+    inputs.append(inputs[0])
+    for data in inputs:
+        req.require(data)
+    pairs = [PA.chunk_air(), PA.requirer_air(payload=6), PA.ec_groups_air()]
+    host = [PA.chunk_trace(req), PA.requirer_trace(PA.chunk_side_requests(req), payload=6), PA.ec_groups_trace()]
+    gen_s = time.perf_counter() - t0
+    airs_h = [p_[0] for p_ in pairs]
+    prm = dict(protocol.PROD_PARAMS)
+    root_pub = [71, 72, 73, 74]
+    dairs = [pkg.DeviceAir(ctx, a) for a in airs_h]
+    for d, (_, lk) in zip(dairs, pairs):
+        d.attach_lookup(pkg.DeviceLookup(ctx, lk))
+    st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
+    pre = protocol.protocol_pre_observe(prm, root_pub)
+    traces = [ctx.upload_trace(t) for t in host]
+    proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    ok, _ = pkg.verify(airs_h, proof.log_trace_heights, root_pub, prm, st, pre, proof.fields, proof.commitments, external=PA.external_assertions(pkg))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    dt = (time.perf_counter() - t0) / steps
+    for t in traces:
+        t.free()
+    n_bytes = sum(len(x) for x in inputs)
+    return {"workload": "chunk session: ChunkAir 12 + 5 EF aux, the other sides of its three buses (8 + 1 EF aux), EcGroupsAir; production parameters, aux columns on the device",
+            "input_bytes": n_bytes, "chunks": req.next_chunk_seq, "log_trace_heights": proof.log_trace_heights, "ms_per_proof": dt * 1e3,
+            "input_MiB_per_s": n_bytes / dt / (1 << 20), "proof_bytes": len(proof.bytes), "verifies_with_eval_external": bool(ok),
+            "compiled_chunks": [a.compiled_chunks for a in dairs], "trace_generation_s": gen_s}
+
+
 def miden_real_probe(pkg, ctx, iters=9250, steps=3, lmcs="poseidon2", inputs=None):
     """THE Miden statement, no stand-ins: CoreAir + ChipletsAir + Poseidon2PermutationAir (miden-vm_amd/{core,chiplets,miden}_air.py) over
     the traces of ONE executed program -- a loop over a hash / u32 / memory mix run by the small VM of miden-vm_amd/core_trace.py --
@@ -985,6 +1026,10 @@ def main():
             out["precompile_session"] = precompile_session_probe(pkg, ctx)
         except Exception as e:
             out["precompile_session"] = {"error": repr(e)[:300]}
+        try:
+            out["chunk_session"] = chunk_session_probe(pkg, ctx)
+        except Exception as e:
+            out["chunk_session"] = {"error": repr(e)[:300]}
         try:
             # the service-level probes run in a process of their own (tools/bench_inflight_h2d.py, no torch in it): measured in THIS
             # process, which also hosts PyTorch's HIP runtime, the same loops lose the copy / kernel overlap (k = 1 with its uploads
