@@ -448,6 +448,59 @@ def precompile_session_probe(pkg, ctx, n_perms=80, steps=3):
             "trace_generation_s": gen_s, "setup_s": setup_s, "device_built_traces": dev}
 
 
+def chunk_poseidon2_session_probe(pkg, ctx, steps=3):
+    """Two chiplets of the second client closing each other's bus: `ChunkAir` and `Poseidon2Air` (precompiles-prover/src/transcript/poseidon2:
+    32 columns = state, three witnessed S-boxes, thirteen cube registers; sixteen periodic columns; absorption chains).  1.07 MiB of
+    hasher input in 64 invocations = 34 332 Poseidon2 permutations proven in-circuit (2^20 rows), the digests' readers and the Memory64 /
+    ChunkChain sides from the stand-in; production parameters, aux columns on the device, verified through `eval_external`.  The trace
+    generator steps through the absorption chains with the device permutation (`mh_poseidon2_permute`)."""
+    import numpy as np
+    from miden_vm_amd import protocol, precompile_airs as PA
+    rng = np.random.default_rng(4)
+    t0 = time.perf_counter()
+    ledger = PA.Poseidon2Requires()
+    req = PA.ChunkRequires(ledger)
+    inputs = [bytes(rng.integers(0, 256, int(rng.integers(0, 32769)), dtype=np.uint8)) for _ in range(63)]
+    inputs.append(inputs[0])
+    for data in inputs:
+        req.require(data)
+        ledger.require_digest(req.last)
+    p2_main, outs = PA.poseidon2_chiplet_trace(ledger, permute_batch=ctx.poseidon2_permute)
+    others = PA.chunk_side_requests(req, poseidon2_chiplet=True) + PA.poseidon2_out_requests(ledger, outs)
+    pairs = [PA.chunk_air(), PA.poseidon2_chiplet_air(), PA.requirer_air(payload=6), PA.ec_groups_air()]
+    host = [PA.chunk_trace(req), p2_main, PA.requirer_trace(others, payload=6), PA.ec_groups_trace()]
+    gen_s = time.perf_counter() - t0
+    airs_h = [p_[0] for p_ in pairs]
+    prm = dict(protocol.PROD_PARAMS)
+    root_pub = [71, 72, 73, 74]
+    dairs = [pkg.DeviceAir(ctx, a) for a in airs_h]
+    for d, (_, lk) in zip(dairs, pairs):
+        d.attach_lookup(pkg.DeviceLookup(ctx, lk))
+    st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
+    pre = protocol.protocol_pre_observe(prm, root_pub)
+    traces = [ctx.upload_trace(t) for t in host]
+    proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    ok, _ = pkg.verify(airs_h, proof.log_trace_heights, root_pub, prm, st, pre, proof.fields, proof.commitments, external=PA.external_assertions(pkg))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    dt = (time.perf_counter() - t0) / steps
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    prof = ctx.prof()
+    ctx.prof_enable(False)
+    for t in traces:
+        t.free()
+    n_bytes = sum(len(x) for x in inputs)
+    return {"workload": "chunk + Poseidon2 session: ChunkAir 12 + 5 EF aux, Poseidon2Air 32 + 3 EF aux + 16 periodic, the remaining bus sides (8 + 1 EF aux), EcGroupsAir; production parameters, aux columns on the device",
+            "input_bytes": n_bytes, "poseidon2_permutations": ledger.next_seq, "log_trace_heights": proof.log_trace_heights, "ms_per_proof": dt * 1e3,
+            "permutations_per_s": ledger.next_seq / dt, "input_MiB_per_s": n_bytes / dt / (1 << 20), "proof_bytes": len(proof.bytes),
+            "verifies_with_eval_external": bool(ok), "compiled_chunks": [a.compiled_chunks for a in dairs],
+            "kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items() if not k.startswith("span:") and v["ms"] > 0.05},
+            "trace_generation_s": gen_s}
+
+
 def chunk_session_probe(pkg, ctx, steps=3):
     """The second client's chunk chiplet (precompiles-prover/src/hash/chunk: `ChunkAir`, twelve columns, five flattened LogUp columns on
     the Memory64 / Poseidon2In / ChunkChain buses): 1.07 MiB of hasher input in 64 invocations (35 076 chunks, 2^16 rows), the other sides
@@ -1030,6 +1083,10 @@ def main():
             out["chunk_session"] = chunk_session_probe(pkg, ctx)
         except Exception as e:
             out["chunk_session"] = {"error": repr(e)[:300]}
+        try:
+            out["chunk_poseidon2_session"] = chunk_poseidon2_session_probe(pkg, ctx)
+        except Exception as e:
+            out["chunk_poseidon2_session"] = {"error": repr(e)[:300]}
         try:
             # the service-level probes run in a process of their own (tools/bench_inflight_h2d.py, no torch in it): measured in THIS
             # process, which also hosts PyTorch's HIP runtime, the same loops lose the copy / kernel overlap (k = 1 with its uploads

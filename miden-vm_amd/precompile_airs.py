@@ -1,7 +1,7 @@
 """The second client of the backend: AIRs of the precompile prover (`precompiles-prover/src`), hand-ported against `dag.AirBuilder`
 like the VM's three AIRs, and the statement layer of its session (`precompiles-prover/src/session/prove.rs`).
 
-What is here: four of the twelve chiplets of `ChipletAir::all()` (session/prove.rs:104-121) --
+What is here: five of the twelve chiplets of `ChipletAir::all()` (session/prove.rs:104-121) --
 * `BytePairLutAir` (`primitives/byte_pair_lut.rs`): the one AIR of the stack with PREPROCESSED columns and a fixed height -- the
   2^16-row `(a, b, !a & b, a ^ b)` table committed once, three witness multiplicity columns, two LogUp columns;
 * `KeccakRoundAir` (`hash/keccak/round/{mod,program}.rs`): its consumer -- a three-address machine `c = ROL(a OP b, s)` whose 128-slot
@@ -11,11 +11,14 @@ What is here: four of the twelve chiplets of `ChipletAir::all()
   fixed boundary consumes;
 * `ChunkAir` (`hash/chunk/{mod,message,trace}.rs`): the hashers' input tape -- one row per 32-byte chunk, provided as four Memory64
   lanes and absorbed as one Poseidon2 block, twelve columns, FIVE flattened LogUp columns (`frac_col!`) on three buses;
+* `Poseidon2Air` (`transcript/poseidon2/{mod,math,program,messages,trace}.rs`): the permutation chiplet that serves those
+  absorptions -- the VM's packed 16-row schedule plus thirteen cube registers per row (S-box outputs at degree 3), absorption chains
+  and per-cycle In / Out multiplicities; 32 columns, 3 LogUp columns, sixteen periodic columns, log_quotient_degree 2;
 the precompile prover's LogUp adapter (natural last-row sigma closing, `logup/constraint.rs`: `dag.LogUp(closing="sigma_last_row")`),
 its bus registry (`relations.rs`) and `ChipletMultiAir::eval_external` (`session/prove.rs:259-272`: sum of the committed sigmas + the
 fixed boundary correction).
 
-What is not: the other eight chiplets (Keccak sponge, chunk nodes, Poseidon2 transcript, eval, uint store / add, EC point store / add /
+What is not: the other seven chiplets (Keccak sponge, chunk nodes, eval, uint store / add, EC point store / add /
 MSM: ~25 kLoC of the reference).  What the SPONGE would put on the Memory64 bus for the permutations of a trace (initial lanes, round
 constants, the consumed outputs: `sponge_side_requests`) comes from `requirer_air`, a one-interaction-per-row stand-in written against
 the same adapter, so that the statement closes; `eval_external` sums the `EcGroup` part of `fixed_boundary_correction` only (the
@@ -348,25 +351,23 @@ def chunks_from_bytes(data):
 
 
 class ChunkRequires:
-    """`ChunkRequires` (hash/chunk/trace.rs:75-125) with the part of `Poseidon2Requires` it drives (transcript/poseidon2/trace.rs:
-    218-236: an absorption chain is laid once per DIGEST, i.e. once per chunk content -- a repeated input reuses its span and raises
-    the chain's `in_mult`): records = [(chunks, first chunk_seq_id, first perm_seq_id)]."""
+    """`ChunkRequires` (hash/chunk/trace.rs:75-125): every invocation's chunks are laid on the tape and absorbed through the shared
+    Poseidon2 ledger under the capacity `Tag::CHUNKS` (`p2.require_absorption(P2Cap::chunk(), rate pairs)`, :94): a repeated input
+    reuses its absorption chain.  records = [(chunks, first chunk_seq_id, first perm_seq_id)]."""
 
-    def __init__(self):
-        self.records, self.next_chunk_seq, self.next_perm_seq = [], 0, 0
-        self.spans = {}          # chunk content -> (start, len, in_mult)
+    def __init__(self, p2=None):
+        self.records, self.next_chunk_seq = [], 0
+        self.p2 = Poseidon2Requires() if p2 is None else p2
+
+    @property
+    def next_perm_seq(self):
+        return self.p2.next_seq
 
     def require(self, data):
-        """-> (chunk_head seq, (perm span start, perm span len))"""
+        """-> (chunk_head seq, (perm span start, perm span len)); `self.last` = the absorption's index in the Poseidon2 ledger."""
         chunks = chunks_from_bytes(data)
-        key = tuple(x for c in chunks for x in c)
-        if key in self.spans:
-            start, n, mult = self.spans[key]
-            self.spans[key] = (start, n, mult + 1)
-        else:
-            start, n = self.next_perm_seq, len(chunks)
-            self.spans[key] = (start, n, 1)
-            self.next_perm_seq += n
+        self.last = self.p2.require_absorption(TAG_CHUNKS_WORD, [(f[0:4], f[4:8]) for f in chunks])
+        start, n = self.p2.span(self.last)
         head = self.next_chunk_seq
         self.records.append((chunks, head, start))
         self.next_chunk_seq += len(chunks)
@@ -392,20 +393,280 @@ def chunk_trace(requires, min_height=0):
     return t
 
 
-def chunk_side_requests(requires):
-    """What the chiplets that are not ported put on the chunk chiplet's three buses: the downstream hasher consumes every Memory64
-    lane once, the Poseidon2 chiplet provides each absorption block (rate0, rate1, and the capacity on chain heads) once per laid
-    chain USE, the node chiplet consumes each chain's ChunkChain tuple.  -> [(bus, multiplicity, fields)] for `requirer_air(payload=6)`."""
+def chunk_side_requests(requires, poseidon2_chiplet=False):
+    """What the chiplets that are not ported put on the chunk chiplet's buses: the downstream hasher consumes every Memory64 lane
+    once, the node chiplet consumes each chain's ChunkChain tuple, and -- unless the Poseidon2 chiplet itself is part of the statement
+    (`poseidon2_chiplet=True`) -- the Poseidon2 chiplet provides each absorption block (rate0, rate1, the capacity on chain heads)
+    once per USE of the chain.  -> [(bus, multiplicity, fields)] for `requirer_air(payload=6)`."""
     out = []
     for chunks, head, perm_start in requires.records:
         for c, f in enumerate(chunks):
             seq = head + c
             for j in range(4):
                 out.append((BUS_MEMORY64, 1, [CHUNK_ADDR_BASE + 4 * seq + j, f[2 * j], f[2 * j + 1]]))
-            out.append((BUS_POSEIDON2_IN, P - 1, [perm_start + c, POSEIDON2_IN_TAG_RATE0] + f[0:4]))
-            out.append((BUS_POSEIDON2_IN, P - 1, [perm_start + c, POSEIDON2_IN_TAG_RATE1] + f[4:8]))
-        out.append((BUS_POSEIDON2_IN, P - 1, [perm_start, POSEIDON2_IN_TAG_CAP] + list(TAG_CHUNKS_WORD)))
+            if not poseidon2_chiplet:
+                out.append((BUS_POSEIDON2_IN, P - 1, [perm_start + c, POSEIDON2_IN_TAG_RATE0] + f[0:4]))
+                out.append((BUS_POSEIDON2_IN, P - 1, [perm_start + c, POSEIDON2_IN_TAG_RATE1] + f[4:8]))
+        if not poseidon2_chiplet:
+            out.append((BUS_POSEIDON2_IN, P - 1, [perm_start, POSEIDON2_IN_TAG_CAP] + list(TAG_CHUNKS_WORD)))
         out.append((BUS_CHUNK_CHAIN, 1, [head, perm_start]))
+    return out
+
+
+# ---- Poseidon2: the permutation chiplet of the transcript (transcript/poseidon2/{mod,math,program,messages,trace}.rs) --------------------
+# One 16-row cycle per permutation on the VM's packed schedule (row 0 init + ext, 1-3 ext, 4-10 three internal rounds per row with
+# witnessed S-box outputs, 11 int + ext, 12-14 ext, 15 the output), the SAME sixteen periodic columns as the VM's
+# Poseidon2PermutationAir.  What it adds: thirteen CUBE REGISTERS per row (x^3 of every S-box input committed, so an S-box output is
+# reg^2 x: degree 3 instead of 7 at the price of a degree-3 check reg - x^3), absorption CHAINS (`is_absorb`: the cycle inherits its
+# capacity from the previous cycle's output), and per-cycle provide multiplicities for the In side (rate0, rate1, capacity) and the
+# Out side (the digest of a chain's last cycle).  32 main columns, 3 LogUp columns, log_quotient_degree 2.
+P2_COLS, P2_AUX_COLS, P2_NUM_WITNESSES, P2_NUM_CUBE_REGS, P2_PERIOD = 32, 3, 3, 13, 16      # mod.rs:64-97, math.rs:11-13, program.rs:6
+P2C_PERM_SEQ_ID, P2C_IN_MULT, P2C_OUT_MULT, P2C_IS_ABSORB, P2C_STATE, P2C_WITNESS, P2C_CUBE = 0, 1, 2, 3, 4, 16, 19
+
+
+def _p2_sbox(x, reg):      # math.rs `sbox`: (reg^2 x, reg - x^3)
+    return reg * reg * x, reg - (x * x) * x
+
+
+def poseidon2_chiplet_air(host_aux=None):
+    """`Poseidon2Air::eval` (transcript/poseidon2/mod.rs:176-345) over the round functions of math.rs, and its `LookupAir::eval`
+    (:368-516): col 0 in_rate0 | col 1 in_rate1 + out_rate0 | col 2 in_cap."""
+    from . import miden_air as MA
+    b = dag.AirBuilder(P2_COLS, aux_width=P2_AUX_COLS, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
+                       num_public=NUM_PUBLIC_VALUES, periodic=MA.periodic_columns())
+    loc, nxt = [b.main(c) for c in range(P2_COLS)], [b.main(c, 1) for c in range(P2_COLS)]
+    one = b.const(1)
+    per = [b.periodic_value(i) for i in range(16)]
+    is_init_ext, is_ext, is_packed_int, is_int_ext = per[0:4]
+    ark = per[4:16]
+    p_last = one - is_init_ext - is_ext - is_packed_int - is_int_ext
+    state, state_next = loc[P2C_STATE:P2C_STATE + 12], nxt[P2C_STATE:P2C_STATE + 12]
+    w, regs = loc[P2C_WITNESS:P2C_WITNESS + 3], loc[P2C_CUBE:P2C_CUBE + P2_NUM_CUBE_REGS]
+    perm_seq_id, perm_seq_id_next = loc[P2C_PERM_SEQ_ID], nxt[P2C_PERM_SEQ_ID]
+    in_mult, in_mult_next, out_mult, out_mult_next = loc[P2C_IN_MULT], nxt[P2C_IN_MULT], loc[P2C_OUT_MULT], nxt[P2C_OUT_MULT]
+    is_absorb, is_absorb_next = loc[P2C_IS_ABSORB], nxt[P2C_IS_ABSORB]
+    activity = in_mult + out_mult
+    b.assert_zero(b.is_first_row() * perm_seq_id)
+    b.assert_zero(b.is_first_row() * is_absorb)
+    b.assert_zero((one - p_last) * (perm_seq_id_next - perm_seq_id))
+    b.assert_zero(b.is_transition() * (p_last * (perm_seq_id_next - perm_seq_id - one)))
+    b.assert_zero((one - p_last) * (in_mult_next - in_mult))
+    b.assert_zero((one - p_last) * (out_mult_next - out_mult))
+    b.assert_zero((one - is_absorb) * is_absorb)
+    b.assert_zero((one - p_last) * (is_absorb_next - is_absorb))
+    for i in range(8, 12):
+        b.assert_zero(p_last * is_absorb_next * (state_next[i] - state[i]))
+    diag = [b.const(v) for v in MA.MAT_DIAG]
+
+    def ext_with_cubes(inputs):
+        outs, checks = [], []
+        for i in range(12):
+            o, c = _p2_sbox(inputs[i], regs[i])
+            outs.append(o)
+            checks.append(c)
+        return MA._matmul_external(outs), checks
+
+    def emit(gate, next_state, checks_first, checks_after=()):
+        for c in checks_first:
+            b.assert_zero(gate * c)
+        for i in range(12):
+            b.assert_zero(gate * (state_next[i] - next_state[i]))
+        for c in checks_after:
+            b.assert_zero(gate * c)
+    # row 0: apply_init_plus_ext -- next-state constraints first, then the cube checks (mod.rs:262-272)
+    pre = MA._matmul_external(state)
+    expected, cubes = ext_with_cubes([pre[i] + ark[i] for i in range(12)])
+    emit(activity * is_init_ext, expected, (), cubes)
+    # rows 1-3, 12-14: apply_single_ext
+    expected, cubes = ext_with_cubes([state[i] + ark[i] for i in range(12)])
+    emit(activity * is_ext, expected, (), cubes)
+    # rows 4-10: apply_packed_internals -- witness checks, cube checks, next state
+    st, wit_checks, cube_checks = list(state), [], []
+    for k in range(3):
+        out, chk = _p2_sbox(st[0] + ark[k], regs[k])
+        wit_checks.append(w[k] - out)
+        cube_checks.append(chk)
+        st[0] = w[k]
+        st = MA._matmul_internal(st, diag)
+    emit(activity * is_packed_int, st, wit_checks + cube_checks)
+    # row 11: apply_internal_plus_ext -- the witness check, the cube checks (the internal one first), next state
+    int_out, int_chk = _p2_sbox(state[0] + b.const(MA.ARK_INT[MA.LAST_INTERNAL_ROUND_ARK_IDX]), regs[12])
+    inter = MA._matmul_internal([w[0]] + state[1:], diag)
+    expected, cubes = ext_with_cubes([inter[i] + ark[i] for i in range(12)])
+    emit(activity * is_int_ext, expected, [w[0] - int_out, int_chk] + cubes)
+    b.assert_zero((one - is_packed_int - is_int_ext) * w[0])
+    b.assert_zero((one - is_packed_int) * w[1])
+    b.assert_zero((one - is_packed_int) * w[2])
+
+    lk = dag.LogUp(b, MAX_MESSAGE_WIDTH, NUM_BUS_IDS, closing="sigma_last_row")
+
+    def side(ch):
+        bb = lk.b if ch is lk.ch_c else lk.lb
+        return bb, [bb.main(c) for c in range(P2_COLS)]
+
+    def p2_in(tag, lo):
+        def msg(ch):
+            bb, row = side(ch)
+            return ch.encode(BUS_POSEIDON2_IN, [row[P2C_PERM_SEQ_ID], bb.const(tag)] + row[P2C_STATE + lo:P2C_STATE + lo + 4])
+        return msg
+
+    def p2_out(ch):
+        _, row = side(ch)
+        return ch.encode(BUS_POSEIDON2_OUT, [row[P2C_PERM_SEQ_ID]] + row[P2C_STATE:P2C_STATE + 4])
+
+    def mults(fn):
+        return fn(lk.b), fn(lk.lb)
+
+    def sel(bb):
+        pv = [bb.periodic_value(i) for i in range(4)]
+        return pv[0], bb.const(1) - pv[0] - pv[1] - pv[2] - pv[3]
+    m_in = mults(lambda bb: sel(bb)[0] * (bb.const(0) - bb.main(P2C_IN_MULT)))
+    m_in_cap = mults(lambda bb: sel(bb)[0] * ((bb.const(0) - bb.main(P2C_IN_MULT)) * (bb.const(1) - bb.main(P2C_IS_ABSORB))))
+    m_out = mults(lambda bb: sel(bb)[1] * ((bb.const(0) - bb.main(P2C_OUT_MULT)) * (bb.const(1) - bb.main(P2C_IS_ABSORB, 1))))
+    for fractions in ([(m_in, p2_in(POSEIDON2_IN_TAG_RATE0, 0))], [(m_in, p2_in(POSEIDON2_IN_TAG_RATE1, 4)), (m_out, p2_out)],
+                      [(m_in_cap, p2_in(POSEIDON2_IN_TAG_CAP, 8))]):
+        with lk.column() as col:
+            with col.group() as g:
+                with g.batch((lk.b.const(1), lk.lb.const(1))) as bt:
+                    for mult, msg in fractions:
+                        bt.insert(mult, msg)
+    lookup = lk.finish("poseidon2_chiplet")
+    return dag.Air(b, _host_aux(lookup, host_aux), "poseidon2_chiplet"), lookup
+
+
+class Poseidon2Requires:
+    """`Poseidon2Requires` (transcript/poseidon2/trace.rs:100-215): absorption chains interned by what they absorb (the reference keys
+    them by digest; the same capacity and blocks are the same digest), each laid once on consecutive cycles; `in_mult` counts the
+    callers that consume the In-side tuples, `out_mult` the consumers of the digest."""
+
+    def __init__(self):
+        self.absorptions, self.by_content, self.next_seq = [], {}, 0      # [cap, blocks, start, in_mult, out_mult]
+        self._digests = {}
+
+    def require_absorption(self, cap, blocks):
+        """-> the absorption's index (`span(idx)`, `digest(idx)`)."""
+        blocks = [(tuple(int(x) % P for x in r0), tuple(int(x) % P for x in r1)) for r0, r1 in blocks]
+        assert blocks, "absorption needs at least one block"
+        key = (tuple(int(x) % P for x in cap), tuple(blocks))
+        idx = self.by_content.get(key)
+        if idx is not None:
+            self.absorptions[idx][3] += 1
+            return idx
+        self.absorptions.append([key[0], blocks, self.next_seq, 1, 0])
+        self.next_seq += len(blocks)
+        self.by_content[key] = len(self.absorptions) - 1
+        return len(self.absorptions) - 1
+
+    def require_digest(self, idx):
+        self.absorptions[idx][4] += 1
+        return self.span(idx)
+
+    def span(self, idx):
+        _, blocks, start, _, _ = self.absorptions[idx]
+        return start, len(blocks)
+
+    def digest(self, idx):
+        """The digest of a chain as the reference computes it next to the ledger (trace.rs:70-80): the chained permutation's first four lanes."""
+        if idx not in self._digests:
+            from . import miden_air as MA
+            cap, blocks = self.absorptions[idx][0], self.absorptions[idx][1]
+            out = None
+            for r0, r1 in blocks:
+                out = MA.permute(list(r0) + list(r1) + list(cap))
+                cap = out[8:12]
+            self._digests[idx] = out[0:4]
+        return self._digests[idx]
+
+
+def poseidon2_chiplet_trace(requires, min_height=0, permute_batch=None):
+    """`generate_trace` / `write_cycle` (transcript/poseidon2/trace.rs:217-420): the cycles of every absorption in the order they were
+    laid, then cycles that carry their perm_seq_id and nothing else.  `permute_batch([k, 12]) -> [k, 12]`: the permutation used to
+    step through the chains (default: numpy; a client with a GPU passes `Ctx.poseidon2_permute` -- a chain of n blocks is n dependent
+    calls).  -> (uint64 [height, 32], outputs [cycles, 12])."""
+    from . import miden_air as MA
+    permute_batch = MA.permute_batch if permute_batch is None else permute_batch
+    total = requires.next_seq
+    height = max(P2_PERIOD, min_height, 1 << max(0, (total * P2_PERIOD - 1).bit_length()) if total else P2_PERIOD)
+    cycles = height // P2_PERIOD
+    rows = np.zeros((cycles, P2_PERIOD, P2_COLS), dtype=np.uint64)
+    rows[:, :, P2C_PERM_SEQ_ID] = np.arange(cycles, dtype=np.uint64)[:, None]
+    init = np.zeros((total, 12), dtype=np.uint64)
+    outs = np.zeros((total, 12), dtype=np.uint64)
+    # the inputs of a chain's cycles depend on each other: step through the block index, every chain's k-th block in one batch
+    longest = max((len(a[1]) for a in requires.absorptions), default=0)
+    for a in requires.absorptions:
+        cap, blocks, start, im, om = a
+        rows[start:start + len(blocks), :, P2C_IN_MULT], rows[start:start + len(blocks), :, P2C_OUT_MULT] = im % P, om % P
+        rows[start + 1:start + len(blocks), :, P2C_IS_ABSORB] = 1
+        init[start, 8:12] = cap
+        for k, (r0, r1) in enumerate(blocks):
+            init[start + k, 0:4], init[start + k, 4:8] = r0, r1
+    for k in range(longest):
+        idx = np.array([a[2] + k for a in requires.absorptions if len(a[1]) > k], dtype=np.int64)
+        outs[idx] = permute_batch(np.ascontiguousarray(init[idx]))
+        carry = np.array([a[2] + k for a in requires.absorptions if len(a[1]) > k + 1], dtype=np.int64)
+        init[carry + 1, 8:12] = outs[carry, 8:12]
+    if total:
+        V = MA._V
+
+        def cube(x):
+            return (x * x * x).v
+        zero = np.zeros(total, dtype=np.uint64)
+
+        def write(r, st, wit, cubes):
+            for i in range(12):
+                rows[:total, r, P2C_STATE + i] = st[i].v
+            for i in range(3):
+                rows[:total, r, P2C_WITNESS + i] = wit[i]
+            for i, c in enumerate(cubes):
+                rows[:total, r, P2C_CUBE + i] = c
+
+        def ext_round(sbox_in):
+            return MA._matmul_external([MA._pow7(x) for x in sbox_in])
+        st = [V(init[:, i].copy()) for i in range(12)]
+        pre = MA._matmul_external(st)
+        sbox_in = [pre[i] + MA.ARK_EXT_INITIAL[0][i] for i in range(12)]
+        write(0, st, [zero] * 3, [cube(x) for x in sbox_in])
+        st = ext_round(sbox_in)
+        for r in (1, 2, 3):
+            sbox_in = [st[i] + MA.ARK_EXT_INITIAL[r][i] for i in range(12)]
+            write(r, st, [zero] * 3, [cube(x) for x in sbox_in])
+            st = ext_round(sbox_in)
+        for triple in range(7):
+            pre_state, wit, cubes = st, [], []
+            for j in range(3):
+                x = st[0] + MA.ARK_INT[3 * triple + j]
+                cubes.append(cube(x))
+                s0 = MA._pow7(x)
+                wit.append(s0.v)
+                st = MA._matmul_internal([s0] + st[1:], MA.MAT_DIAG)
+            write(4 + triple, pre_state, wit, cubes)
+        pre_state = st
+        w0_in = st[0] + MA.ARK_INT[MA.LAST_INTERNAL_ROUND_ARK_IDX]
+        w0 = MA._pow7(w0_in)
+        inter = MA._matmul_internal([w0] + st[1:], MA.MAT_DIAG)
+        sbox_in = [inter[i] + MA.ARK_EXT_TERMINAL[0][i] for i in range(12)]
+        write(11, pre_state, [w0.v, zero, zero], [cube(x) for x in sbox_in] + [cube(w0_in)])
+        st = ext_round(sbox_in)
+        for r in (1, 2, 3):
+            sbox_in = [st[i] + MA.ARK_EXT_TERMINAL[r][i] for i in range(12)]
+            write(11 + r, st, [zero] * 3, [cube(x) for x in sbox_in])
+            st = ext_round(sbox_in)
+        write(15, st, [zero] * 3, [])
+        assert (np.stack([x.v for x in st], axis=1) == outs).all()
+    return rows.reshape(height, P2_COLS), outs
+
+
+def poseidon2_out_requests(requires, outs=None):
+    """The consumers of the digests (`require_digest`): Poseidon2OutMsg { perm_seq_id of the chain's LAST cycle, digest } once per
+    reader -- what the node / transcript chiplets (not ported) put on the Poseidon2Out bus.  `outs` = the permutation outputs the
+    trace generator returned (else the digests are recomputed chain by chain).  -> [(bus, multiplicity, fields)]"""
+    out = []
+    for idx, (cap, blocks, start, im, om) in enumerate(requires.absorptions):
+        if om:
+            tail = start + len(blocks) - 1
+            digest = requires.digest(idx) if outs is None else [int(x) for x in outs[tail, 0:4]]
+            out.append((BUS_POSEIDON2_OUT, om, [tail] + [int(x) for x in digest]))
     return out
 
 

@@ -299,3 +299,59 @@ def test_chunk_session_production_params_one_mebibyte_of_input(ctx):
     assert ok, msg
     ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, external=PA.external_assertions(pkg))
     assert ok2 and (dig == got.digest).all()
+
+
+# ---- the Poseidon2 chiplet: the chunk chiplet's absorptions served by their real provider (transcript/poseidon2) -------------------------
+def chunk_poseidon2_session(n_invocations, max_len, seed=22, permute_batch=None):
+    """[ChunkAir, Poseidon2Air (32 columns: state, witnessed S-boxes, thirteen cube registers; sixteen periodic columns; absorption
+    chains), the remaining sides (Memory64 and ChunkChain consumes, the digests' readers on Poseidon2Out), EcGroupsAir]."""
+    rng = np.random.default_rng(seed)
+    ledger = PA.Poseidon2Requires()
+    req = PA.ChunkRequires(ledger)
+    inputs = [bytes(rng.integers(0, 256, int(rng.integers(0, max_len + 1)), dtype=np.uint8)) for _ in range(n_invocations)]
+    inputs.append(inputs[0])
+    for data in inputs:
+        req.require(data)
+        ledger.require_digest(req.last)
+    p2_main, outs = PA.poseidon2_chiplet_trace(ledger, permute_batch=permute_batch)
+    others = PA.chunk_side_requests(req, poseidon2_chiplet=True) + PA.poseidon2_out_requests(ledger, outs)
+    pairs = [PA.chunk_air(host_aux), PA.poseidon2_chiplet_air(host_aux), PA.requirer_air(host_aux, payload=6), PA.ec_groups_air(host_aux)]
+    traces = [PA.chunk_trace(req), p2_main, PA.requirer_trace(others, payload=6), PA.ec_groups_trace()]
+    return [p[0] for p in pairs], [p[1] for p in pairs], traces
+
+
+@pytest.mark.parametrize("jit", ["0", "1"])
+def test_chunk_poseidon2_session_device_proof_equals_oracle(ctx, jit, monkeypatch):
+    pkg = load_package()
+    monkeypatch.setenv("MH_JIT", jit)
+    airs_, lookups, traces = chunk_poseidon2_session(7, 300)
+    rnd = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
+    # the Poseidon2 chiplet's lookup program reads the NEXT row (is_absorb') and the periodic selectors
+    aux_dev, fin = pkg.DeviceLookup(ctx, lookups[1]).build_aux(ctx.upload_trace(traces[1]), rnd)
+    aux, exp_fin = ob.lookup_build_aux(lookups[1], traces[1], rnd)
+    assert (aux_dev.download() == aux).all() and fin == (int(exp_fin[0]), int(exp_fin[1])) and fin != (0, 0)
+    exp = ob.prove(airs_, traces, ROOT, FAST, init_state=protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST))
+    got, st, pre = chunk_device_prove(ctx, airs_, lookups, traces, FAST)
+    assert (got.commitments == exp["commitments"]).all()
+    assert got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all()
+    assert (got.digest == exp["digest"]).all()
+    assert got.log_trace_heights == [int(t.shape[0]).bit_length() - 1 for t in traces]
+    ok, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, FAST, st, pre, got.fields, got.commitments, external=PA.external_assertions(pkg))
+    assert ok and (dig == got.digest).all()
+
+
+def test_chunk_poseidon2_session_production_params_chains_stepped_on_the_device(ctx):
+    """~130 KiB of input in 64 invocations (chains of up to 128 blocks), production parameters; the trace generator steps through the
+    chains with the DEVICE permutation (`Ctx.poseidon2_permute`) and must give the numpy generator's matrix; verify-only."""
+    pkg = load_package()
+    airs_, lookups, traces = chunk_poseidon2_session(63, 4096, seed=5, permute_batch=ctx.poseidon2_permute)
+    _, _, traces_np = chunk_poseidon2_session(63, 4096, seed=5)
+    assert all((a == b).all() for a, b in zip(traces, traces_np))
+    prm = dict(protocol.PROD_PARAMS)
+    got, st, pre = chunk_device_prove(ctx, airs_, lookups, traces, prm)
+    assert got.log_trace_heights == [13, 16, 15, 3]
+    ok, msg = ob.verify(airs_, got.log_trace_heights, ROOT, {"fields": got.fields, "commitments": got.commitments}, prm,
+                        init_state=st, pre_observe=pre, external=PA.external_assertions(pkg))
+    assert ok, msg
+    ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, external=PA.external_assertions(pkg))
+    assert ok2 and (dig == got.digest).all()
