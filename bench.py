@@ -448,6 +448,61 @@ def precompile_session_probe(pkg, ctx, n_perms=80, steps=3):
             "trace_generation_s": gen_s, "setup_s": setup_s, "device_built_traces": dev}
 
 
+def keccak_hash_session_probe(pkg, ctx, steps=3):
+    """Keccak-256 of 54 inputs (up to 1.4 KiB each, 40 KiB, 323 Keccak-f permutations: the round chiplet at 2^19 rows) proven over SIX real chiplets of the second
+    client: KeccakRoundAir (the permutations), BytePairLutAir (2^16-row PREPROCESSED table), KeccakSpongeAir (pad10*1, absorb, squeeze: 67
+    columns, 24 flattened LogUp columns), ChunkAir (the input tape), Poseidon2Air (the tape's content hash), EcGroupsAir, plus what the
+    node / transcript chiplets above them put on the buses; production parameters, every aux column on the device."""
+    import numpy as np
+    from miden_vm_amd import protocol, precompile_airs as PA
+    rng = np.random.default_rng(6)
+    inputs = [b"", b"abc"] + [bytes(rng.integers(0, 256, int(rng.integers(0, 1401)), dtype=np.uint8)) for _ in range(52)]
+    t0 = time.perf_counter()
+    ledger, p2 = PA.BytePairLutRequires(), PA.Poseidon2Requires()
+    chunks = PA.ChunkRequires(p2)
+    sp = PA.SpongeRequires(chunks, ledger)
+    digests = []
+    for data in inputs:
+        o = sp.require(data)
+        p2.require_digest(o["chunk_absorption"])
+        digests.append(o["keccak_digest"])
+    kr_trace, mem = PA.keccak_round_trace(sp.perm_inputs, ledger)
+    p2_main, outs = PA.poseidon2_chiplet_trace(p2, permute_batch=ctx.poseidon2_permute)
+    others = PA.keccak_hash_side_requests(sp, mem) + PA.poseidon2_out_requests(p2, outs)
+    pairs = [PA.keccak_round_air(), PA.byte_pair_lut_air(), PA.keccak_sponge_air(), PA.chunk_air(), PA.poseidon2_chiplet_air(),
+             PA.requirer_air(payload=6), PA.ec_groups_air()]
+    host = [kr_trace, PA.byte_pair_lut_trace(ledger), PA.keccak_sponge_trace(sp), PA.chunk_trace(chunks), p2_main,
+            PA.requirer_trace(others, payload=6), PA.ec_groups_trace()]
+    gen_s = time.perf_counter() - t0
+    airs_h = [p_[0] for p_ in pairs]
+    prm = dict(protocol.PROD_PARAMS)
+    root_pub = [71, 72, 73, 74]
+    dairs = [pkg.DeviceAir(ctx, a) for a in airs_h]
+    raw = ctx.upload_trace(airs_h[1].preprocessed)
+    com = pkg.commit_traces(ctx, [raw], prm["log_blowup"])
+    dairs[1].attach_preprocessed(com.tree(), 0, raw=raw)
+    for d, (_, lk) in zip(dairs, pairs):
+        d.attach_lookup(pkg.DeviceLookup(ctx, lk))
+    st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
+    pre = protocol.protocol_pre_observe(prm, root_pub, preprocessed_root=com.root())
+    traces = [ctx.upload_trace(t) for t in host]
+    proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    ok, _ = pkg.verify(airs_h, proof.log_trace_heights, root_pub, prm, st, pre, proof.fields, proof.commitments, preprocessed_root=com.root(),
+                       external=PA.external_assertions(pkg))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    dt = (time.perf_counter() - t0) / steps
+    for t in traces:
+        t.free()
+    n_bytes = sum(len(x) for x in inputs)
+    return {"workload": "Keccak-256 hashing session: KeccakRoundAir, BytePairLutAir (preprocessed), KeccakSpongeAir 67 + 24 EF aux, ChunkAir, Poseidon2Air, the node side of the buses, EcGroupsAir; production parameters, aux columns on the device",
+            "inputs": len(inputs), "input_bytes": n_bytes, "keccak_permutations": len(sp.perm_inputs), "log_trace_heights": proof.log_trace_heights,
+            "ms_per_proof": dt * 1e3, "hashes_per_s": len(inputs) / dt, "keccak_permutations_per_s": len(sp.perm_inputs) / dt,
+            "input_KiB_per_s": n_bytes / dt / 1024, "proof_bytes": len(proof.bytes), "verifies_with_eval_external": bool(ok),
+            "keccak256_of_empty": digests[0].hex(), "compiled_chunks": [a.compiled_chunks for a in dairs], "trace_generation_s": gen_s}
+
+
 def chunk_poseidon2_session_probe(pkg, ctx, steps=3):
     """Two chiplets of the second client closing each other's bus: `ChunkAir` and `Poseidon2Air` (precompiles-prover/src/transcript/poseidon2:
     32 columns = state, three witnessed S-boxes, thirteen cube registers; sixteen periodic columns; absorption chains).  1.07 MiB of
@@ -1087,6 +1142,10 @@ def main():
             out["chunk_poseidon2_session"] = chunk_poseidon2_session_probe(pkg, ctx)
         except Exception as e:
             out["chunk_poseidon2_session"] = {"error": repr(e)[:300]}
+        try:
+            out["keccak_hash_session"] = keccak_hash_session_probe(pkg, ctx)
+        except Exception as e:
+            out["keccak_hash_session"] = {"error": repr(e)[:300]}
         try:
             # the service-level probes run in a process of their own (tools/bench_inflight_h2d.py, no torch in it): measured in THIS
             # process, which also hosts PyTorch's HIP runtime, the same loops lose the copy / kernel overlap (k = 1 with its uploads

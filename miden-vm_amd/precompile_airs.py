@@ -1,7 +1,7 @@
 """The second client of the backend: AIRs of the precompile prover (`precompiles-prover/src`), hand-ported against `dag.AirBuilder`
 like the VM's three AIRs, and the statement layer of its session (`precompiles-prover/src/session/prove.rs`).
 
-What is here: five of the twelve chiplets of `ChipletAir::all()` (session/prove.rs:104-121) --
+What is here: six of the twelve chiplets of `ChipletAir::all()` (session/prove.rs:104-121) --
 * `BytePairLutAir` (`primitives/byte_pair_lut.rs`): the one AIR of the stack with PREPROCESSED columns and a fixed height -- the
   2^16-row `(a, b, !a & b, a ^ b)` table committed once, three witness multiplicity columns, two LogUp columns;
 * `KeccakRoundAir` (`hash/keccak/round/{mod,program}.rs`): its consumer -- a three-address machine `c = ROL(a OP b, s)` whose 128-slot
@@ -14,11 +14,15 @@ What is here: five of the twelve chiplets of `ChipletAir::all()
 * `Poseidon2Air` (`transcript/poseidon2/{mod,math,program,messages,trace}.rs`): the permutation chiplet that serves those
   absorptions -- the VM's packed 16-row schedule plus thirteen cube registers per row (S-box outputs at degree 3), absorption chains
   and per-cycle In / Out multiplicities; 32 columns, 3 LogUp columns, sixteen periodic columns, log_quotient_degree 2;
+* `KeccakSpongeAir` (`hash/keccak/sponge/{mod,program,message,trace}.rs`): pad10*1, absorb and squeeze around the round chiplet's
+  permutations -- 67 columns (a padding state machine, lane halves, byte shadows), 24 flattened LogUp columns on Memory64 / the byte-pair
+  table / KeccakSponge, eleven periodic columns of period 32, log_quotient_degree 2.  With it a KECCAK-256 HASHING SESSION closes over
+  six real chiplets: bytes in (chunk tape), digest out (the round chiplet's output lanes);
 the precompile prover's LogUp adapter (natural last-row sigma closing, `logup/constraint.rs`: `dag.LogUp(closing="sigma_last_row")`),
 its bus registry (`relations.rs`) and `ChipletMultiAir::eval_external` (`session/prove.rs:259-272`: sum of the committed sigmas + the
 fixed boundary correction).
 
-What is not: the other seven chiplets (Keccak sponge, chunk nodes, eval, uint store / add, EC point store / add /
+What is not: the other six chiplets (the Keccak / chunk nodes, eval, uint store / add, EC point store / add /
 MSM: ~25 kLoC of the reference).  What the SPONGE would put on the Memory64 bus for the permutations of a trace (initial lanes, round
 constants, the consumed outputs: `sponge_side_requests`) comes from `requirer_air`, a one-interaction-per-row stand-in written against
 the same adapter, so that the statement closes; `eval_external` sums the `EcGroup` part of `fixed_boundary_correction` only (the
@@ -956,4 +960,364 @@ def sponge_side_requests(states, memory):
         base = KR_IP_BOUNDARY + pb + 23 * ROUND_PERIOD
         for slot in [SLOT_IOTA] + [SLOT_CHI_XOR_BEGIN + i for i in range(24)]:
             out.append((BUS_MEMORY64, 2, m64(base + slot, int(memory[n, base + slot - pb]))))
+    return out
+
+
+# ---- KeccakSponge: pad10*1, absorb, squeeze around the round chiplet's permutations (hash/keccak/sponge/{mod,program,message,trace}.rs) ---
+# One row per state lane, a period of 32 rows per Keccak-f permutation (sponge row r = 32 n + idx  <->  the round chiplet's address
+# 3200 n + idx: every per-row address is linear in `sponge_seq_id` and the periodic `p_idx`).  Slots 0..16 XOR the rate lanes in
+# (verbatim, or through the pad row's ANDNOT / XOR 0x01 / XOR chain, or not at all past the pad), 17..24 pass the capacity through, 25
+# mixes the trailing 0x80 into lane 16 on last blocks, 26..28 mop up the chunk lanes a last block leaves over, 29..31 idle.  The rows
+# provide the permutation's input lanes and round constants on Memory64, consume the previous permutation's outputs (inside an
+# invocation) or the squeezed lanes 4..24 (last block), consume the input from the chunk chiplet's tape, verify every XOR / ANDNOT byte
+# by byte against the byte-pair table, and consume one `KeccakSponge` request per invocation.  67 main columns (5 structural, 10 of the
+# padding state machine, 12 lane halves, 40 byte shadows), 24 flattened LogUp columns, 11 periodic columns, log_quotient_degree 2.
+SP_COLS, SP_AUX_COLS, SPONGE_PERIOD, SP_NUM_PERIODIC = 67, 24, 32, 11                                        # sponge/mod.rs:165, :190; program.rs:3-4
+SPC_SEQ_ID, SPC_ACT, SPC_BYTES_LEFT, SPC_IS_FIRST_BLOCK, SPC_CHUNK_PTR, SPC_IS_ZERO, SPC_IS_CHUNK_AVAIL, SPC_B = 0, 1, 2, 3, 4, 5, 6, 7
+SPC_CHUNK, SPC_STATE_PREV, SPC_STATE_NEW, SPC_STATE_OUT, SPC_CLEARED, SPC_PADDED = 15, 17, 19, 21, 23, 25      # `_LO`; `_HI` = + 1
+SPC_CHUNK_BYTES, SPC_STATE_PREV_BYTES, SPC_STATE_NEW_BYTES, SPC_CLEARED_BYTES, SPC_PADDED_BYTES = 27, 35, 43, 51, 59
+(SPP_IDX, SPP_FIRST, SPP_LAST, SPP_RATE_BLOCK, SPP_CAPACITY, SPP_RC_ACTIVE, SPP_SQUEEZE_ACTIVE, SPP_PAD_0X80, SPP_RC_LO, SPP_RC_HI,
+ SPP_EXTRA) = range(11)                                                                                        # program.rs:5-15
+SP_RATE_LANES, SP_RATE_BYTES, SP_LANE16_SLOT, SP_EXTRA_BEGIN, SP_NOP_BEGIN = 17, 136, 25, 26, 29                 # program.rs:16-24
+SP_PAD_CONST = 0x8000000000000000                                                                               # trace.rs:62
+
+
+def sponge_program():
+    """`sponge_program` (sponge/program.rs:52-74) -> 11 columns of 32."""
+    cols = [[0] * SPONGE_PERIOD for _ in range(SP_NUM_PERIODIC)]
+    for slot in range(SPONGE_PERIOD):
+        cols[SPP_IDX][slot] = slot
+        cols[SPP_FIRST][slot] = int(slot == 0)
+        cols[SPP_LAST][slot] = int(slot == SPONGE_PERIOD - 1)
+        cols[SPP_RATE_BLOCK][slot] = int(slot < SP_RATE_LANES)
+        cols[SPP_CAPACITY][slot] = int(SP_RATE_LANES <= slot < SP_LANE16_SLOT)
+        cols[SPP_RC_ACTIVE][slot] = int(slot < 24)
+        cols[SPP_SQUEEZE_ACTIVE][slot] = int(4 <= slot < SP_LANE16_SLOT)
+        cols[SPP_PAD_0X80][slot] = int(slot == SP_LANE16_SLOT)
+        cols[SPP_EXTRA][slot] = int(SP_EXTRA_BEGIN <= slot < SP_NOP_BEGIN)
+        if slot < 24:
+            cols[SPP_RC_LO][slot], cols[SPP_RC_HI][slot] = KECCAK_RC[slot] & 0xffffffff, KECCAK_RC[slot] >> 32
+    return cols
+
+
+def _sp_andnot_mask(j):     # trace.rs `andnot_mask`: 0xff..ff << 8 j (mod.rs ANDNOT_MASK_{LO,HI})
+    return (0xffffffffffffffff << (8 * j)) & 0xffffffffffffffff
+
+
+def _sp_padding_mask(j):    # trace.rs `padding_mask`: 0x01 << 8 j (mod.rs PADDING_MASK_{LO,HI})
+    return 1 << (8 * j)
+
+
+def keccak_sponge_air(host_aux=None):
+    """`KeccakSpongeAir::eval` (hash/keccak/sponge/mod.rs:356-598) and its `LookupAir::eval` (:631-1046)."""
+    b = dag.AirBuilder(SP_COLS, aux_width=SP_AUX_COLS, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
+                       num_public=NUM_PUBLIC_VALUES, periodic=sponge_program())
+    loc, nxt = [b.main(c) for c in range(SP_COLS)], [b.main(c, 1) for c in range(SP_COLS)]
+    one = b.const(1)
+    per = [b.periodic_value(i) for i in range(SP_NUM_PERIODIC)]
+    p_first, p_last, p_rate_block, p_capacity, p_extra = per[SPP_FIRST], per[SPP_LAST], per[SPP_RATE_BLOCK], per[SPP_CAPACITY], per[SPP_EXTRA]
+    p_state_lane = p_rate_block + p_capacity
+    act, act_next = loc[SPC_ACT], nxt[SPC_ACT]
+    seq, seq_next = loc[SPC_SEQ_ID], nxt[SPC_SEQ_ID]
+    bytes_left, bytes_left_next = loc[SPC_BYTES_LEFT], nxt[SPC_BYTES_LEFT]
+    chunk_ptr, chunk_ptr_next = loc[SPC_CHUNK_PTR], nxt[SPC_CHUNK_PTR]
+    ifb, ifb_next = loc[SPC_IS_FIRST_BLOCK], nxt[SPC_IS_FIRST_BLOCK]
+    is_zero, is_zero_next = loc[SPC_IS_ZERO], nxt[SPC_IS_ZERO]
+    ica, ica_next = loc[SPC_IS_CHUNK_AVAIL], nxt[SPC_IS_CHUNK_AVAIL]
+    sp_lo, sp_hi, sn_lo, sn_hi = loc[SPC_STATE_PREV], loc[SPC_STATE_PREV + 1], loc[SPC_STATE_NEW], loc[SPC_STATE_NEW + 1]
+    b_sum, b_weighted = b.const(0), b.const(0)
+    for j in range(8):
+        b_sum = b_sum + loc[SPC_B + j]
+        b_weighted = b_weighted + b.const(j) * loc[SPC_B + j]
+
+    def bool_check(x):
+        b.assert_zero((one - x) * x)
+    tr, first = b.is_transition(), b.is_first_row()
+    b.assert_zero(first * seq)
+    bool_check(act)
+    b.assert_zero(tr * ((one - act) * act_next))
+    b.assert_zero(tr * ((act - act_next) * (one - p_last * b_sum)))
+    b.assert_zero(tr * (seq_next - seq - one))
+    bool_check(ifb)
+    b.assert_zero((one - p_last) * (ifb_next - ifb))
+    b.assert_zero(act * p_rate_block * (bytes_left_next - bytes_left + b.const(8)))
+    enters = p_last * ifb_next
+    b.assert_zero(act * (one - enters) * (one - p_rate_block) * (bytes_left_next - bytes_left))
+    b.assert_zero(tr * ((one - enters) * (chunk_ptr_next - chunk_ptr - (p_rate_block + p_extra * b_sum) * ica)))
+    b.assert_zero((one - ica) * loc[SPC_CHUNK])
+    b.assert_zero((one - ica) * loc[SPC_CHUNK + 1])
+    bool_check(is_zero)
+    bool_check(ica)
+    for j in range(8):
+        bool_check(loc[SPC_B + j])
+    b.assert_zero((one - p_last) * is_zero * (one - is_zero_next))
+    b.assert_zero((one - p_last) * (one - ica) * ica_next)
+    b.assert_zero(p_first * is_zero)
+    for j in range(8):
+        b.assert_zero((one - p_last) * (nxt[SPC_B + j] - loc[SPC_B + j]))
+    b.assert_zero((one - p_rate_block) * (b_sum - is_zero))
+    b.assert_zero(act * p_last * ifb_next * (one - is_zero))
+    is_pad = is_zero_next - is_zero
+    b.assert_zero(p_rate_block * is_pad * (b_weighted - bytes_left))
+    b.assert_zero(p_state_lane * ifb * sp_lo)
+    b.assert_zero(p_state_lane * ifb * sp_hi)
+    b.assert_zero(p_rate_block * is_zero * (sn_lo - sp_lo))
+    b.assert_zero(p_rate_block * is_zero * (sn_hi - sp_hi))
+    b.assert_zero(p_capacity * (sn_lo - sp_lo))
+    b.assert_zero(p_capacity * (sn_hi - sp_hi))
+    for bytes_at, half_at in ((SPC_CHUNK_BYTES, SPC_CHUNK), (SPC_STATE_PREV_BYTES, SPC_STATE_PREV), (SPC_STATE_NEW_BYTES, SPC_STATE_NEW),
+                              (SPC_CLEARED_BYTES, SPC_CLEARED), (SPC_PADDED_BYTES, SPC_PADDED)):      # byte-shadow linking, utils.rs `halves_le`
+        b.assert_zero(_pack_le(loc[bytes_at:bytes_at + 4], 256) - loc[half_at])
+        b.assert_zero(_pack_le(loc[bytes_at + 4:bytes_at + 8], 256) - loc[half_at + 1])
+
+    lk = dag.LogUp(b, MAX_MESSAGE_WIDTH, NUM_BUS_IDS, closing="sigma_last_row")
+
+    class Side:
+        def __init__(self, bb):
+            self.bb = bb
+            c = bb.const
+            row, nrow = [bb.main(i) for i in range(SP_COLS)], [bb.main(i, 1) for i in range(SP_COLS)]
+            pv = [bb.periodic_value(i) for i in range(SP_NUM_PERIODIC)]
+            self.row = row
+            p_state_lane_ = pv[SPP_RATE_BLOCK] + pv[SPP_CAPACITY]
+            act_ = row[SPC_ACT]
+            b_sum_ = c(0)
+            self.andnot_mask_bytes, self.padding_mask_bytes = [c(0)] * 8, [c(0)] * 8
+            for j in range(8):
+                b_j = row[SPC_B + j]
+                b_sum_ = b_sum_ + b_j
+                for i in range(8):
+                    self.andnot_mask_bytes[i] = self.andnot_mask_bytes[i] + c((_sp_andnot_mask(j) >> (8 * i)) & 0xff) * b_j
+                    self.padding_mask_bytes[i] = self.padding_mask_bytes[i] + c((_sp_padding_mask(j) >> (8 * i)) & 0xff) * b_j
+            is_intra = c(1) - row[SPC_IS_FIRST_BLOCK]
+            is_first_row_of_invocation = pv[SPP_FIRST] * row[SPC_IS_FIRST_BLOCK]
+            is_pad_ = nrow[SPC_IS_ZERO] - row[SPC_IS_ZERO]
+            is_verbatim = c(1) - nrow[SPC_IS_ZERO]
+            hundred_seq = c(100) * row[SPC_SEQ_ID]
+            ninety_nine_idx = c(99) * pv[SPP_IDX]
+            self.addr_prev = hundred_seq - ninety_nine_idx - c(128)
+            self.addr_new = hundred_seq - ninety_nine_idx
+            self.addr_rc = hundred_seq + c(28) * pv[SPP_IDX] + c(25)
+            self.addr_squeeze = hundred_seq - ninety_nine_idx + c(3072)
+            self.addr_lane16 = hundred_seq - c(2484)
+            self.addr_chunk = c(CHUNK_ADDR_BASE) + row[SPC_CHUNK_PTR]
+            mult_prev_perm = c(2) * act_ * is_intra
+            mult_new_state = c(0) - c(2) * act_
+            mult_rc = c(0) - c(1) * act_ * pv[SPP_RC_ACTIVE]
+            mult_squeeze = c(2) * act_ * pv[SPP_SQUEEZE_ACTIVE] * b_sum_
+            mult_lane16_consume = c(2) * act_ * b_sum_
+            mult_lane16_provide = c(0) - c(2) * act_ * b_sum_
+            self.m = dict(new_state=p_state_lane_ * mult_new_state, prev_perm=p_state_lane_ * mult_prev_perm, rc=p_state_lane_ * mult_rc,
+                          lane16_consume=pv[SPP_PAD_0X80] * mult_lane16_consume, lane16_provide=pv[SPP_PAD_0X80] * mult_lane16_provide,
+                          squeeze=p_state_lane_ * mult_squeeze, pad=pv[SPP_RATE_BLOCK] * is_pad_ * act_,
+                          verbatim=pv[SPP_RATE_BLOCK] * is_verbatim * act_, lane16=pv[SPP_PAD_0X80] * b_sum_ * act_,
+                          ks_request=act_ * is_first_row_of_invocation,
+                          chunk_consume=act_ * (pv[SPP_RATE_BLOCK] + pv[SPP_EXTRA] * b_sum_) * row[SPC_IS_CHUNK_AVAIL])
+            self.rc_lo, self.rc_hi = pv[SPP_RC_LO], pv[SPP_RC_HI]
+
+    sides = {id(lk.ch_c): Side(lk.b), id(lk.ch_p): Side(lk.lb)}
+
+    def mult(name):
+        return sides[id(lk.ch_c)].m[name], sides[id(lk.ch_p)].m[name]
+
+    def mem64(addr, half_at=None, rc=False):
+        def msg(ch):
+            s_ = sides[id(ch)]
+            lo, hi = (s_.rc_lo, s_.rc_hi) if rc else (s_.row[half_at], s_.row[half_at + 1])
+            return ch.encode(BUS_MEMORY64, [getattr(s_, addr), lo, hi])
+        return msg
+
+    def bpl(op, a, bsrc, csrc, i):
+        """BytePairLutMsg { op, a, b, c } on byte i; a source is a column base, ("andnot" | "padding") for the mask bytes, or an int table."""
+        def pick(s_, src):
+            if src == "andnot":
+                return s_.andnot_mask_bytes[i]
+            if src == "padding":
+                return s_.padding_mask_bytes[i]
+            if isinstance(src, tuple):
+                return s_.bb.const(src[i])
+            return s_.row[src + i]
+
+        def msg(ch):
+            s_ = sides[id(ch)]
+            return ch.encode(BUS_BYTE_PAIR_LUT, [s_.bb.const(op), pick(s_, a), pick(s_, bsrc), pick(s_, csrc)])
+        return msg
+
+    def ks_request(ch):
+        s_ = sides[id(ch)]
+        return ch.encode(BUS_KECCAK_SPONGE, [s_.row[SPC_SEQ_ID], s_.row[SPC_CHUNK_PTR], s_.row[SPC_BYTES_LEFT]])
+
+    pad_const_bytes = tuple((SP_PAD_CONST >> (8 * i)) & 0xff for i in range(8))
+    columns = [[(mult("new_state"), mem64("addr_new", SPC_STATE_NEW)), (mult("prev_perm"), mem64("addr_prev", SPC_STATE_PREV))],
+               [(mult("rc"), mem64("addr_rc", rc=True)), (mult("lane16_consume"), mem64("addr_lane16", SPC_STATE_PREV)),
+                (mult("lane16_provide"), mem64("addr_lane16", SPC_STATE_NEW))],
+               [(mult("squeeze"), mem64("addr_squeeze", SPC_STATE_OUT))]]
+    for m_name, op, a, bsrc, csrc in (("pad", OP_ANDNOT, "andnot", SPC_CHUNK_BYTES, SPC_CLEARED_BYTES),
+                                      ("pad", OP_XOR, SPC_CLEARED_BYTES, "padding", SPC_PADDED_BYTES),
+                                      ("pad", OP_XOR, SPC_STATE_PREV_BYTES, SPC_PADDED_BYTES, SPC_STATE_NEW_BYTES),
+                                      ("verbatim", OP_XOR, SPC_STATE_PREV_BYTES, SPC_CHUNK_BYTES, SPC_STATE_NEW_BYTES),
+                                      ("lane16", OP_XOR, SPC_STATE_PREV_BYTES, pad_const_bytes, SPC_STATE_NEW_BYTES)):
+        for pair in range(4):
+            columns.append([(mult(m_name), bpl(op, a, bsrc, csrc, 2 * pair)), (mult(m_name), bpl(op, a, bsrc, csrc, 2 * pair + 1))])
+    columns.append([(mult("ks_request"), ks_request), (mult("chunk_consume"), mem64("addr_chunk", SPC_CHUNK))])
+    assert len(columns) == SP_AUX_COLS
+    for fractions in columns:
+        with lk.column() as col:
+            with col.group() as g:
+                with g.batch((lk.b.const(1), lk.lb.const(1))) as bt:
+                    for m_, msg in fractions:
+                        bt.insert(m_, msg)
+    lookup = lk.finish("keccak_sponge")
+    return dag.Air(b, _host_aux(lookup, host_aux), "keccak_sponge"), lookup
+
+
+class SpongeRequires:
+    """`SpongeRequires` (sponge/trace.rs:176-262): every invocation lays its chunk segment (`ChunkRequires.require`), runs its blocks
+    (FIPS 202 pad10*1 with the 0x01 / 0x80 bytes of Keccak-256, rate 136) recording what the sponge's rows request from the byte-pair
+    table, and allocates 32 sponge rows per block.  `perm_inputs` = the inputs of the permutations in global block order: what the
+    round chiplet's trace is generated from."""
+
+    def __init__(self, chunks=None, ledger=None):
+        self.chunks = ChunkRequires() if chunks is None else chunks
+        self.ledger = ledger                                            # BytePairLutRequires or None
+        self.invocations, self.next_sponge_seq, self.perm_inputs = [], 0, []
+
+    @staticmethod
+    def layout(n_bytes):
+        num_blocks = (n_bytes + SP_RATE_BYTES) // SP_RATE_BYTES          # Invocation::num_blocks
+        last = n_bytes - SP_RATE_BYTES * (num_blocks - 1)
+        return dict(num_blocks=num_blocks, pad_lane_idx=last // 8, byte_offset=last % 8, chunk_lanes=max(1, -(-n_bytes // 32)) * 4)
+
+    def _logic64(self, op, x, y):
+        if self.ledger is not None:
+            return self.ledger.require_logic64(op, x, y)
+        return (x ^ y) if op == OP_XOR else (~x & y) & 0xffffffffffffffff
+
+    def require(self, data):
+        """-> dict(keccak_digest = 32 bytes, sponge_head, chunk_head, chunk absorption index in the Poseidon2 ledger)."""
+        data = bytes(data)
+        chunk_head, _ = self.chunks.require(data)
+        lay = self.layout(len(data))
+        tape = [int.from_bytes(data[i:i + 8].ljust(8, b"\0"), "little") for i in range(0, len(data), 8)]
+        tape = (tape + [0] * lay["chunk_lanes"])[:lay["chunk_lanes"]]
+        pos, state, blocks = 0, [0] * 25, []
+        for block_n in range(lay["num_blocks"]):
+            is_last = block_n + 1 == lay["num_blocks"]
+            at_start = list(state)
+            for k in range(SP_RATE_LANES):
+                lane = tape[pos] if pos < len(tape) else 0
+                pos += 1
+                if not is_last or k < lay["pad_lane_idx"]:
+                    state[k] = self._logic64(OP_XOR, state[k], lane)
+                elif k == lay["pad_lane_idx"]:
+                    cleared = self._logic64(OP_ANDNOT, _sp_andnot_mask(lay["byte_offset"]), lane)
+                    padded = self._logic64(OP_XOR, cleared, _sp_padding_mask(lay["byte_offset"]))
+                    state[k] = self._logic64(OP_XOR, state[k], padded)
+            post_xorin = list(state)
+            if is_last:
+                state[16] = self._logic64(OP_XOR, state[16], SP_PAD_CONST)
+            self.perm_inputs.append(list(state))
+            state = keccak_f_reference(state)
+            blocks.append((at_start, post_xorin, list(state)))
+        head = self.next_sponge_seq
+        self.next_sponge_seq += lay["num_blocks"] * SPONGE_PERIOD
+        self.invocations.append(dict(input=data, layout=lay, chunk_head=chunk_head, sponge_head=head, blocks=blocks,
+                                     chunk_absorption=self.chunks.last))
+        digest = b"".join(int(x).to_bytes(8, "little") for x in state[0:4])
+        return dict(keccak_digest=digest, sponge_head=head, chunk_head=chunk_head, chunk_absorption=self.chunks.last)
+
+
+def keccak_sponge_trace(requires, min_height=0):
+    """`generate_trace` / `fill_state_lane_row` (sponge/trace.rs:388-585) -> uint64 [height, 67]."""
+    active = requires.next_sponge_seq
+    height = max(SPONGE_PERIOD, min_height, 1 << max(0, (active - 1).bit_length()) if active else SPONGE_PERIOD)
+    t = np.zeros((height, SP_COLS), dtype=np.uint64)
+
+    def put(r, half_at, bytes_at, value):
+        t[r, half_at], t[r, half_at + 1] = value & 0xffffffff, value >> 32
+        if bytes_at is not None:
+            t[r, bytes_at:bytes_at + 8] = [(value >> (8 * i)) & 0xff for i in range(8)]
+    row, chunk_ptr, bytes_left = 0, 0, 0
+    for rec in requires.invocations:
+        lay, data = rec["layout"], rec["input"]
+        bytes_left, chunk_ptr = len(data), 4 * rec["chunk_head"]
+        tape = [int.from_bytes(data[i:i + 8].ljust(8, b"\0"), "little") for i in range(0, len(data), 8)]
+        tape = (tape + [0] * lay["chunk_lanes"])[:lay["chunk_lanes"]]
+        pos, consumed = 0, 0
+        for block_n, (at_start, post_xorin, perm_out) in enumerate(rec["blocks"]):
+            is_last = block_n + 1 == lay["num_blocks"]
+            in_block = lay["chunk_lanes"] - consumed if is_last else SP_RATE_LANES
+            rate_avail = min(in_block, SP_RATE_LANES)
+            overshoot = in_block - rate_avail
+            for slot in range(SPONGE_PERIOD):
+                t[row, SPC_SEQ_ID], t[row, SPC_ACT], t[row, SPC_BYTES_LEFT] = row, 1, bytes_left % P
+                t[row, SPC_IS_FIRST_BLOCK], t[row, SPC_CHUNK_PTR] = int(block_n == 0), chunk_ptr
+                is_rate = slot < SP_RATE_LANES
+                t[row, SPC_IS_ZERO] = int(is_last and slot > lay["pad_lane_idx"])
+                is_extra = SP_EXTRA_BEGIN <= slot < SP_NOP_BEGIN
+                consume = (is_rate and slot < rate_avail) or (is_extra and slot - SP_EXTRA_BEGIN < overshoot)
+                avail_end = SP_EXTRA_BEGIN + overshoot if overshoot > 0 else rate_avail
+                t[row, SPC_IS_CHUNK_AVAIL] = int(slot < avail_end)
+                if is_last:
+                    t[row, SPC_B + lay["byte_offset"]] = 1
+                lane = 0
+                if consume:
+                    lane = tape[pos] if pos < len(tape) else 0
+                    pos += 1
+                put(row, SPC_CHUNK, SPC_CHUNK_BYTES, lane)
+                if is_rate:
+                    prev = at_start[slot]
+                    put(row, SPC_STATE_PREV, SPC_STATE_PREV_BYTES, prev)
+                    cleared = padded = 0
+                    if is_last and slot == lay["pad_lane_idx"]:
+                        cleared = ~_sp_andnot_mask(lay["byte_offset"]) & lane & 0xffffffffffffffff
+                        padded = cleared ^ _sp_padding_mask(lay["byte_offset"])
+                        new = prev ^ padded
+                    elif is_last and slot > lay["pad_lane_idx"]:
+                        new = prev
+                    else:
+                        new = prev ^ lane
+                    put(row, SPC_STATE_NEW, SPC_STATE_NEW_BYTES, new)
+                    put(row, SPC_CLEARED, SPC_CLEARED_BYTES, cleared)
+                    put(row, SPC_PADDED, SPC_PADDED_BYTES, padded)
+                    if is_last:
+                        put(row, SPC_STATE_OUT, None, perm_out[slot])
+                elif slot < SP_LANE16_SLOT:
+                    put(row, SPC_STATE_PREV, SPC_STATE_PREV_BYTES, at_start[slot])
+                    put(row, SPC_STATE_NEW, SPC_STATE_NEW_BYTES, at_start[slot])
+                    if is_last:
+                        put(row, SPC_STATE_OUT, None, perm_out[slot])
+                elif slot == SP_LANE16_SLOT:
+                    put(row, SPC_STATE_PREV, SPC_STATE_PREV_BYTES, post_xorin[16])
+                    put(row, SPC_STATE_NEW, SPC_STATE_NEW_BYTES, post_xorin[16] ^ SP_PAD_CONST if is_last else post_xorin[16])
+                if consume:
+                    chunk_ptr += 1
+                    consumed += 1
+                if is_rate:
+                    bytes_left -= 8
+                row += 1
+        assert row == rec["sponge_head"] + lay["num_blocks"] * SPONGE_PERIOD
+    while row < height:
+        t[row, SPC_SEQ_ID], t[row, SPC_BYTES_LEFT], t[row, SPC_CHUNK_PTR] = row, bytes_left % P, chunk_ptr
+        if row % SPONGE_PERIOD < SP_RATE_LANES:
+            bytes_left -= 8
+        row += 1
+    return t
+
+
+def keccak_hash_side_requests(sponge, round_memory):
+    """What the chiplets above the sponge (the Keccak node, the transcript: not ported) put on the buses of a Keccak hashing session:
+    they provide one `KeccakSponge` request per invocation `(first sponge row, chunk-tape base, length)`, read the four digest lanes of
+    every invocation's last permutation off the round chiplet's outputs (provided twice each, addresses 3200 n + 3072 + 0..3) and
+    consume the ChunkChain tuple; the chunk content digests' readers go through `poseidon2_out_requests`.
+    -> [(bus, multiplicity, fields)] for `requirer_air(payload=6)`."""
+    out = []
+    for rec in sponge.invocations:
+        out.append((BUS_KECCAK_SPONGE, P - 1, [rec["sponge_head"], 4 * rec["chunk_head"], len(rec["input"])]))
+        n = rec["sponge_head"] // SPONGE_PERIOD + rec["layout"]["num_blocks"] - 1
+        outs = keccak_round_outputs(round_memory, n)
+        for idx in range(4):
+            out.append((BUS_MEMORY64, 2, [PERM_CYCLE * n + 3072 + idx, outs[idx] & 0xffffffff, outs[idx] >> 32]))
+    for chunks, head, perm_start in sponge.chunks.records:
+        out.append((BUS_CHUNK_CHAIN, 1, [head, perm_start]))
     return out

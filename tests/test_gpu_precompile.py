@@ -355,3 +355,69 @@ def test_chunk_poseidon2_session_production_params_chains_stepped_on_the_device(
     assert ok, msg
     ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, external=PA.external_assertions(pkg))
     assert ok2 and (dig == got.digest).all()
+
+
+# ---- the Keccak-256 hashing session: six real chiplets, bytes in, digest out (hash/keccak/sponge) -------------------------------------------
+def keccak_hash_session(inputs):
+    """[KeccakRoundAir, BytePairLutAir, KeccakSpongeAir (67 columns, 24 flattened LogUp columns, 11 periodic), ChunkAir, Poseidon2Air, the
+    node / transcript side of the buses, EcGroupsAir]."""
+    ledger, p2 = PA.BytePairLutRequires(), PA.Poseidon2Requires()
+    chunks = PA.ChunkRequires(p2)
+    sp = PA.SpongeRequires(chunks, ledger)
+    digests = []
+    for data in inputs:
+        out = sp.require(data)
+        p2.require_digest(out["chunk_absorption"])
+        digests.append(out["keccak_digest"])
+    kr_trace, mem = PA.keccak_round_trace(sp.perm_inputs, ledger)
+    p2_main, outs = PA.poseidon2_chiplet_trace(p2)
+    others = PA.keccak_hash_side_requests(sp, mem) + PA.poseidon2_out_requests(p2, outs)
+    pairs = [PA.keccak_round_air(host_aux), PA.byte_pair_lut_air(host_aux), PA.keccak_sponge_air(host_aux), PA.chunk_air(host_aux),
+             PA.poseidon2_chiplet_air(host_aux), PA.requirer_air(host_aux, payload=6), PA.ec_groups_air(host_aux)]
+    traces = [kr_trace, PA.byte_pair_lut_trace(ledger), PA.keccak_sponge_trace(sp), PA.chunk_trace(chunks), p2_main,
+              PA.requirer_trace(others, payload=6), PA.ec_groups_trace()]
+    return [p[0] for p in pairs], [p[1] for p in pairs], traces, digests
+
+
+def _hash_inputs(n, max_len, seed):
+    rng = np.random.default_rng(seed)
+    return [b"", b"abc"] + [bytes(rng.integers(0, 256, int(rng.integers(0, max_len + 1)), dtype=np.uint8)) for _ in range(n)]
+
+
+@pytest.mark.parametrize("jit", ["0", "1"])
+def test_keccak_hash_session_device_proof_equals_oracle(ctx, jit, monkeypatch):
+    pkg = load_package()
+    monkeypatch.setenv("MH_JIT", jit)
+    airs_, lookups, traces, digests = keccak_hash_session(_hash_inputs(5, 300, 31))
+    assert digests[0].hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+    assert digests[1].hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
+    rnd = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
+    aux_dev, fin = pkg.DeviceLookup(ctx, lookups[2]).build_aux(ctx.upload_trace(traces[2]), rnd)      # the sponge's 24 columns
+    aux, exp_fin = ob.lookup_build_aux(lookups[2], traces[2], rnd)
+    assert (aux_dev.download() == aux).all() and fin == (int(exp_fin[0]), int(exp_fin[1])) and fin != (0, 0)
+    exp = ob.prove(airs_, traces, ROOT, FAST, init_state=protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST))
+    got, root, st, pre = device_prove(ctx, airs_, lookups, traces, FAST)
+    assert list(root) == [int(x) for x in exp["preprocessed_root"]]
+    assert (got.commitments == exp["commitments"]).all()
+    assert got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all()
+    assert (got.digest == exp["digest"]).all()
+    assert got.log_trace_heights == [int(t.shape[0]).bit_length() - 1 for t in traces]
+    ok, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, FAST, st, pre, got.fields, got.commitments, preprocessed_root=root,
+                         external=PA.external_assertions(pkg))
+    assert ok and (dig == got.digest).all()
+
+
+def test_keccak_hash_session_production_params(ctx):
+    """54 inputs of up to 1.4 KiB (323 permutations: the round chiplet at 2^19 rows), production parameters: verify-only through both
+    verifiers and `eval_external`."""
+    pkg = load_package()
+    airs_, lookups, traces, _ = keccak_hash_session(_hash_inputs(52, 1400, 6))
+    prm = dict(protocol.PROD_PARAMS)
+    got, root, st, pre = device_prove(ctx, airs_, lookups, traces, prm)
+    assert got.log_trace_heights[0] == 19 and got.log_trace_heights[1] == 16
+    ok, msg = ob.verify(airs_, got.log_trace_heights, ROOT, {"fields": got.fields, "commitments": got.commitments}, prm,
+                        init_state=st, pre_observe=pre, external=PA.external_assertions(pkg))
+    assert ok, msg
+    ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, preprocessed_root=root,
+                          external=PA.external_assertions(pkg))
+    assert ok2 and (dig == got.digest).all()

@@ -1,0 +1,225 @@
+"""The Keccak sponge chiplet of the precompile prover (`KeccakSpongeAir`, precompiles-prover/src/hash/keccak/sponge/{mod,program,message,
+trace}.rs) as ported in miden-vm_amd/precompile_airs.py: the reference's own unit tests (precompiles-prover/src/tests/keccak_sponge.rs and
+the test modules of program.rs / trace.rs) replayed, and the KECCAK-256 HASHING SESSION closed over six real chiplets --
+
+    [KeccakRoundAir, BytePairLutAir, KeccakSpongeAir, ChunkAir, Poseidon2Air, what the node / transcript chiplets above them put on
+     the buses (one KeccakSpongeMsg per invocation, the digest lanes' reads, the ChunkChain and Poseidon2Out consumes), EcGroupsAir]
+
+-- input bytes in, digest out: the chunk chiplet provides the tape, the sponge pads and absorbs it (every XOR / ANDNOT byte by byte
+against the table), hands the permutation inputs and round constants to the round chiplet over Memory64 and reads its outputs back.
+Host only; device parity in tests/test_gpu_precompile.py.
+
+Known answers: keccak256("") = c5d24601...5d85a470 (the reference's `empty_input_digest_is_keccak256_of_empty`, as eight u32 halves) and
+keccak256("abc") = 4e03657a...a12d6c45."""
+import numpy as np
+import pytest
+import oracle_binding as ob
+from __graft_entry__ import load_package
+
+pkg = load_package()
+from miden_vm_amd import precompile_airs as PA, dag, protocol  # noqa: E402
+
+P = dag.P
+RND = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
+FAST = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=5, query_pow_bits=3)
+ROOT = [71, 72, 73, 74]
+
+
+def host_aux(lookup, main, randomness, preprocessed=None):
+    return ob.lookup_build_aux(lookup, main, randomness, preprocessed)
+
+
+@pytest.fixture(scope="module")
+def sponge():
+    return PA.keccak_sponge_air(host_aux)
+
+
+def rnd_bytes(n, seed):
+    return bytes(np.random.default_rng(seed).integers(0, 256, n, dtype=np.uint8))
+
+
+def trace_of(inputs):
+    sp = PA.SpongeRequires()
+    outs = [sp.require(d) for d in inputs]
+    return PA.keccak_sponge_trace(sp), sp, outs
+
+
+def check_local(sponge, main, corrupt_aux=None):
+    air, lookup = sponge
+    aux, fin = ob.lookup_build_aux(lookup, main, RND, None)
+    if corrupt_aux is not None:
+        corrupt_aux(aux)
+    return ob.check_constraints(air, main, aux, [int(fin[0]), int(fin[1])], ROOT, RND, None)
+
+
+# ---- message, layout, program ------------------------------------------------------------------------------------------------------------
+def test_keccak_sponge_msg_encodes_with_keccak_sponge_bus_prefix():
+    enc = PA._encode((11, 0), (13, 0), PA.BUS_KECCAK_SPONGE, [42, 12, 200])
+    prefix = 11 + pow(13, PA.MAX_MESSAGE_WIDTH, P) * (PA.BUS_KECCAK_SPONGE + 1)
+    assert enc == ((prefix + 42 + 13 * 12 + 13 * 13 * 200) % P, 0) and PA.BUS_KECCAK_SPONGE == 5
+    assert PA._encode((7, 0), (5, 0), PA.BUS_KECCAK_SPONGE, [42, 12, 200]) != PA._encode((7, 0), (5, 0), PA.BUS_MEMORY64, [42, 12, 200])
+
+
+def test_main_column_layout_partitions_67_indices_and_air_layout_matches_spec(sponge):
+    assert (PA.SPC_SEQ_ID, PA.SPC_CHUNK_PTR, PA.SPC_B, PA.SPC_PADDED + 1, PA.SP_COLS) == (0, 4, 7, 26, 67)
+    assert PA.SPC_CHUNK == PA.SPC_B + 8 and PA.SPC_CHUNK_BYTES == 27 and PA.SPC_PADDED_BYTES + 8 == 67
+    h = dag.parse_air_blob(sponge[0].blob)
+    assert (h["preprocessed_width"], h["main_width"], h["num_public"], h["aux_width"], h["num_randomness"], h["num_aux_values"]) == (0, 67, 4, 24, 2, 1)
+    assert len(h["periodic"]) == 11 and all(len(c) == 32 for c in h["periodic"]) and h["periodic"] == PA.sponge_program()
+    assert h["log_quotient_degree"] == 2 and max(d for d, _ in sponge[0].constraint_degrees) == 5    # log_quotient_degree_matches_design_target
+    assert len(h["constraints"]) == 52 + (3 + 23)       # local | column 0 first / transition / last, 23 ungated fraction columns
+
+
+def test_the_period_32_program_is_the_reference_design():
+    """program.rs tests: p_idx enumerates the period, the row classes partition it, the selectors fire where the design says."""
+    c = PA.sponge_program()
+    assert c[PA.SPP_IDX] == list(range(32))
+    for slot in range(32):
+        assert c[PA.SPP_RATE_BLOCK][slot] + c[PA.SPP_CAPACITY][slot] + c[PA.SPP_PAD_0X80][slot] + c[PA.SPP_EXTRA][slot] + int(slot >= 29) == 1
+    assert [i for i in range(32) if c[PA.SPP_EXTRA][i]] == [26, 27, 28] and [i for i in range(32) if c[PA.SPP_FIRST][i]] == [0]
+    assert [i for i in range(32) if c[PA.SPP_LAST][i]] == [31] and [i for i in range(32) if c[PA.SPP_RC_ACTIVE][i]] == list(range(24))
+    assert [i for i in range(32) if c[PA.SPP_SQUEEZE_ACTIVE][i]] == list(range(4, 25)) and [i for i in range(32) if c[PA.SPP_PAD_0X80][i]] == [25]
+    assert [(hi << 32) | lo for lo, hi in zip(c[PA.SPP_RC_LO][:24], c[PA.SPP_RC_HI][:24])] == PA.KECCAK_RC
+
+
+def test_block_and_chunk_lane_counts_follow_fips_202():   # trace.rs `num_blocks_matches_fips_202_rule`, `chunk_lanes_round_up_to_32_byte_granularity`
+    assert [PA.SpongeRequires.layout(n)["num_blocks"] for n in (0, 7, 135, 136, 200, 272)] == [1, 1, 1, 2, 2, 3]
+    assert [PA.SpongeRequires.layout(n)["chunk_lanes"] for n in (0, 1, 32, 33, 200)] == [4, 4, 4, 8, 28]
+
+
+def test_known_answers():
+    _, _, outs = trace_of([b"", b"abc"])
+    assert outs[0]["keccak_digest"].hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+    assert [int.from_bytes(outs[0]["keccak_digest"][i:i + 4], "little") for i in range(0, 32, 4)] == [
+        0x0146d2c5, 0x3c23f786, 0xb27d7e92, 0xc003c7dc, 0x53b600e5, 0x3b2782ca, 0x04d8fa7b, 0x70a4855d]    # keccak_sponge.rs:321-340
+    assert outs[1]["keccak_digest"].hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
+
+
+# ---- constraints hold --------------------------------------------------------------------------------------------------------------------
+CASES = {"empty_invocation": [b""], "single_byte_invocation": [b"\xab"], "partial_lane_input": [bytes(i ^ 0x5a for i in range(11))],
+         "full_single_block": [rnd_bytes(135, 0xe087)], "block_aligned_input": [rnd_bytes(136, 0xe088)], "multi_block_input": [rnd_bytes(200, 0xe0c8)],
+         "overshoot_two_lanes": [rnd_bytes(271, 0xe10f)], "overshoot_one_lane": [rnd_bytes(407, 0xe197)],
+         "overshoot_then_invocation_seam": [rnd_bytes(271, 1), rnd_bytes(40, 2)], "with_dead_rows": [rnd_bytes(300, 0xdead)],
+         "empty_transcript": [], "empty_then_nonempty_seam": [b"", rnd_bytes(40, 3)], "multiple_invocations": [rnd_bytes(33, 4), rnd_bytes(40, 5)]}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_constraints_hold(sponge, name):
+    main, sp, _ = trace_of(CASES[name])
+    blocks = sum(len(d) // 136 + 1 for d in CASES[name])
+    assert main.shape == (max(32, 1 << max(0, (32 * blocks - 1).bit_length())), 67) and int(main[:, PA.SPC_ACT].sum()) == 32 * blocks
+    assert check_local(sponge, main) == (0, None), name
+
+
+def test_overshoot_lanes_are_mopped_up_on_the_extra_rows(sponge):
+    main, _, _ = trace_of([rnd_bytes(135, 0xe087)])               # 5 chunks = 20 lanes against 17 rate slots
+    assert [int(x) for x in main[:32, PA.SPC_IS_CHUNK_AVAIL]] == [1] * 29 + [0] * 3
+    assert int(main[29, PA.SPC_CHUNK_PTR]) == 20 and int(main[16, PA.SPC_B + 7]) == 1 and int(main[17, PA.SPC_IS_ZERO]) == 1
+
+
+# ---- corruptions ------------------------------------------------------------------------------------------------------------------------
+def test_corruptions_are_caught(sponge):
+    def corrupted(inputs, fn):
+        main, _, _ = trace_of(inputs)
+        fn(main)
+        return check_local(sponge, main)[0]
+
+    def set_cell(r, c, v):
+        def f(main):
+            main[r, c] = v
+        return f
+
+    def first_block_again(main):
+        main[32:64, PA.SPC_IS_FIRST_BLOCK] = 1
+    assert corrupted([b"\xab"], set_cell(5, PA.SPC_ACT, 2)) >= 1                           # non_binary_act_breaks_booleanity
+    assert corrupted([b"\xab"], set_cell(5, PA.SPC_CHUNK, 1)) >= 1                         # nonzero_chunk_on_chunks_unavailable_breaks_zero_fill
+    assert corrupted([rnd_bytes(271, 0xc0f1)], first_block_again) >= 1                      # new_invocation_after_non_last_block
+    assert corrupted([b"\xab"], set_cell(1, PA.SPC_SEQ_ID, 7)) >= 1                        # seq_id_breaks_row_counter_transition
+    main, _, _ = trace_of([b"\xab"])
+
+    def bump_aux(aux):                                                                      # aux_cell_breaks_logup_recurrence
+        flat = aux.reshape(aux.shape[0], -1)
+        flat[1, 0] = (int(flat[1, 0]) + 1) % P
+    assert check_local(sponge, main, corrupt_aux=bump_aux)[0] >= 1
+    # a wrong byte shadow, a wrong pad intermediate, a flipped result byte
+    assert corrupted([rnd_bytes(11, 9)], set_cell(0, PA.SPC_STATE_NEW_BYTES + 2, 0x11)) >= 1
+    assert corrupted([rnd_bytes(11, 9)], set_cell(1, PA.SPC_CLEARED, 5)) >= 1
+
+
+# ---- the Keccak-256 hashing session -------------------------------------------------------------------------------------------------------
+INPUTS = [b"", b"abc", rnd_bytes(135, 11), rnd_bytes(136, 12), rnd_bytes(200, 13), rnd_bytes(300, 14), b"abc"]
+
+
+def hashing_session(inputs, aux=host_aux):
+    ledger, p2 = PA.BytePairLutRequires(), PA.Poseidon2Requires()
+    chunks = PA.ChunkRequires(p2)
+    sp = PA.SpongeRequires(chunks, ledger)
+    digests = []
+    for data in inputs:
+        out = sp.require(data)
+        p2.require_digest(out["chunk_absorption"])
+        digests.append(out["keccak_digest"])
+    kr_trace, mem = PA.keccak_round_trace(sp.perm_inputs, ledger)
+    p2_main, outs = PA.poseidon2_chiplet_trace(p2)
+    others = PA.keccak_hash_side_requests(sp, mem) + PA.poseidon2_out_requests(p2, outs)
+    pairs = [PA.keccak_round_air(aux), PA.byte_pair_lut_air(aux), PA.keccak_sponge_air(aux), PA.chunk_air(aux), PA.poseidon2_chiplet_air(aux),
+             PA.requirer_air(aux, payload=6), PA.ec_groups_air(aux)]
+    traces = [kr_trace, PA.byte_pair_lut_trace(ledger), PA.keccak_sponge_trace(sp), PA.chunk_trace(chunks), p2_main,
+              PA.requirer_trace(others, payload=6), PA.ec_groups_trace()]
+    return pairs, traces, digests, sp, mem
+
+
+@pytest.fixture(scope="module")
+def session():
+    return hashing_session(INPUTS)
+
+
+def test_the_round_chiplet_computes_what_the_sponge_squeezes(session):
+    pairs, traces, digests, sp, mem = session
+    n = 0
+    for rec, digest in zip(sp.invocations, digests):
+        for at_start, post_xorin, perm_out in rec["blocks"]:
+            assert PA.keccak_round_outputs(mem, n) == perm_out                      # permutation n of the round chiplet = sponge period n
+            n += 1
+        assert b"".join(int(x).to_bytes(8, "little") for x in PA.keccak_round_outputs(mem, n - 1)[:4]) == digest
+    assert digests[1] == digests[6] and digests[1].hex().startswith("4e03657a")
+
+
+def test_the_hashing_session_closes_through_eval_external_only(session):
+    pairs, traces, _, _, _ = session
+    sig = []
+    for (air, lookup), t in zip(pairs, traces):
+        _, fin = ob.lookup_build_aux(lookup, t, RND, air.preprocessed)
+        sig.append([(int(fin[0]), int(fin[1]))])
+    assert PA.eval_external(RND, sig) == [(0, 0)]
+    assert all(s[0] != (0, 0) for s in sig)
+    for skip in range(5):                                                           # no real chiplet can be left out
+        assert PA.eval_external(RND, sig[:skip] + sig[skip + 1:]) != [(0, 0)]
+
+
+def test_the_hashing_session_proves_and_verifies_and_forgeries_do_not(session):
+    pairs, traces, _, _, _ = session
+    air_list = [p_[0] for p_ in pairs]
+    st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
+
+    def run(ts):
+        proof = ob.prove(air_list, ts, ROOT, FAST, init_state=st)
+        root = proof["preprocessed_root"]
+        pre = protocol.protocol_pre_observe(FAST, ROOT, preprocessed_root=root)
+        ok_o, _ = ob.verify(air_list, proof["log_heights"], ROOT, proof, FAST, external=PA.external_assertions(pkg))
+        ok_p, _ = pkg.verify(air_list, proof["log_heights"], ROOT, FAST, st, pre, proof["fields"], proof["commitments"], preprocessed_root=root,
+                             external=PA.external_assertions(pkg))
+        return proof, ok_o, ok_p
+    proof, ok_o, ok_p = run(traces)
+    assert ok_o and ok_p and proof["log_heights"] == [int(t.shape[0]).bit_length() - 1 for t in traces]
+    # one input byte changed on the tape only: the sponge's chunk consume no longer matches the chunk chiplet's provide
+    forged = traces[3].copy()
+    forged[1, PA.COL_F_BEGIN] = (int(forged[1, PA.COL_F_BEGIN]) ^ 1)
+    _, ok_o, ok_p = run(traces[:3] + [forged] + traces[4:])
+    assert not ok_o and not ok_p
+    # a claimed digest lane that the round chiplet did not compute
+    forged = traces[5].copy()
+    row = next(r for r in range(forged.shape[0]) if int(forged[r, 1]) == PA.BUS_MEMORY64 + 1 and int(forged[r, 0]) == 2)
+    forged[row, 3] = (int(forged[row, 3]) + 1) % P
+    _, ok_o, ok_p = run(traces[:5] + [forged] + traces[6:])
+    assert not ok_o and not ok_p
