@@ -449,10 +449,11 @@ def precompile_session_probe(pkg, ctx, n_perms=80, steps=3):
 
 
 def keccak_hash_session_probe(pkg, ctx, steps=3):
-    """Keccak-256 of 54 inputs (up to 1.4 KiB each, 40 KiB, 323 Keccak-f permutations: the round chiplet at 2^19 rows) proven over SIX real chiplets of the second
-    client: KeccakRoundAir (the permutations), BytePairLutAir (2^16-row PREPROCESSED table), KeccakSpongeAir (pad10*1, absorb, squeeze: 67
-    columns, 24 flattened LogUp columns), ChunkAir (the input tape), Poseidon2Air (the tape's content hash), EcGroupsAir, plus what the
-    node / transcript chiplets above them put on the buses; production parameters, every aux column on the device."""
+    """Keccak-256 of 54 inputs (up to 1.4 KiB each, 40 KiB, 323 Keccak-f permutations: the round chiplet at 2^19 rows) proven over SEVEN
+    real chiplets of the second client: KeccakRoundAir (the permutations), BytePairLutAir (2^16-row PREPROCESSED table), KeccakSpongeAir
+    (pad10*1, absorb, squeeze: 67 columns, 24 flattened LogUp columns), ChunkAir (the input tape), Poseidon2Air (the tape's content hash
+    and the node hashes), KeccakNodeAir (one transcript-DAG node per distinct input: `Binding(H_keccak, True, 0, 0)`), EcGroupsAir; outside
+    them only the transcript's readers of the bindings.  Production parameters, every aux column on the device."""
     import numpy as np
     from miden_vm_amd import protocol, precompile_airs as PA
     rng = np.random.default_rng(6)
@@ -461,18 +462,14 @@ def keccak_hash_session_probe(pkg, ctx, steps=3):
     ledger, p2 = PA.BytePairLutRequires(), PA.Poseidon2Requires()
     chunks = PA.ChunkRequires(p2)
     sp = PA.SpongeRequires(chunks, ledger)
-    digests = []
-    for data in inputs:
-        o = sp.require(data)
-        p2.require_digest(o["chunk_absorption"])
-        digests.append(o["keccak_digest"])
+    nd = PA.KeccakNodeRequires(sp)
+    outs = [nd.require(data) for data in inputs]
     kr_trace, mem = PA.keccak_round_trace(sp.perm_inputs, ledger)
-    p2_main, outs = PA.poseidon2_chiplet_trace(p2, permute_batch=ctx.poseidon2_permute)
-    others = PA.keccak_hash_side_requests(sp, mem) + PA.poseidon2_out_requests(p2, outs)
+    p2_main, _ = PA.poseidon2_chiplet_trace(p2, permute_batch=ctx.poseidon2_permute)
     pairs = [PA.keccak_round_air(), PA.byte_pair_lut_air(), PA.keccak_sponge_air(), PA.chunk_air(), PA.poseidon2_chiplet_air(),
-             PA.requirer_air(payload=6), PA.ec_groups_air()]
-    host = [kr_trace, PA.byte_pair_lut_trace(ledger), PA.keccak_sponge_trace(sp), PA.chunk_trace(chunks), p2_main,
-            PA.requirer_trace(others, payload=6), PA.ec_groups_trace()]
+             PA.keccak_node_air(), PA.requirer_air(payload=7), PA.ec_groups_air()]
+    host = [kr_trace, PA.byte_pair_lut_trace(ledger), PA.keccak_sponge_trace(sp), PA.chunk_trace(chunks), p2_main, PA.keccak_node_trace(nd),
+            PA.requirer_trace(PA.binding_requests(nd), payload=7), PA.ec_groups_trace()]
     gen_s = time.perf_counter() - t0
     airs_h = [p_[0] for p_ in pairs]
     prm = dict(protocol.PROD_PARAMS)
@@ -496,11 +493,12 @@ def keccak_hash_session_probe(pkg, ctx, steps=3):
     for t in traces:
         t.free()
     n_bytes = sum(len(x) for x in inputs)
-    return {"workload": "Keccak-256 hashing session: KeccakRoundAir, BytePairLutAir (preprocessed), KeccakSpongeAir 67 + 24 EF aux, ChunkAir, Poseidon2Air, the node side of the buses, EcGroupsAir; production parameters, aux columns on the device",
-            "inputs": len(inputs), "input_bytes": n_bytes, "keccak_permutations": len(sp.perm_inputs), "log_trace_heights": proof.log_trace_heights,
+    return {"workload": "Keccak-256 hashing session: KeccakRoundAir, BytePairLutAir (preprocessed), KeccakSpongeAir 67 + 24 EF aux, ChunkAir, Poseidon2Air, KeccakNodeAir 30 + 9 EF aux, the transcript's Binding readers, EcGroupsAir; production parameters, aux columns on the device",
+            "inputs": len(inputs), "distinct_inputs": len(nd.records), "input_bytes": n_bytes, "keccak_permutations": len(sp.perm_inputs),
+            "poseidon2_permutations": p2.next_seq, "log_trace_heights": proof.log_trace_heights,
             "ms_per_proof": dt * 1e3, "hashes_per_s": len(inputs) / dt, "keccak_permutations_per_s": len(sp.perm_inputs) / dt,
             "input_KiB_per_s": n_bytes / dt / 1024, "proof_bytes": len(proof.bytes), "verifies_with_eval_external": bool(ok),
-            "keccak256_of_empty": digests[0].hex(), "compiled_chunks": [a.compiled_chunks for a in dairs], "trace_generation_s": gen_s}
+            "keccak256_of_empty": outs[0]["keccak_digest"].hex(), "compiled_chunks": [a.compiled_chunks for a in dairs], "trace_generation_s": gen_s}
 
 
 def chunk_poseidon2_session_probe(pkg, ctx, steps=3):

@@ -747,6 +747,14 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
   if (lazy_vals)
     for (size_t i = 0; i < nodes.size(); i++)
       if (interior((uint32_t)i)) canon[i] = dot_of[i] >= 0 && dots[dot_of[i]].others.empty();
+  // ---- chains of one-sided lazy additions (`lz_add_c` / `lz_sub_c`: s = a + c, s < a ? s + eps : s) ----
+  // Each link is a carry-select whose two arms depend on the previous link; LLVM's DAG combiner walks both arms of every select when it
+  // reasons about the next one, without memoising: a chain of 23 links (the running sum over the 24 aux columns of the Keccak sponge)
+  // took 370 s in "DAG Combining 2" of ONE chunk, every other chunk of the same AIR 1-3 s.  A value that ends a run of MH_JIT_LZCHAIN
+  // links (default 16) goes through an empty asm statement: the combiner sees an opaque value and the walk starts over.  No
+  // instruction is emitted for it; AIRs whose chains are shorter get the same source as before.
+  const int lz_chain_max = env_int("MH_JIT_LZCHAIN", 16);
+  std::vector<uint16_t> lz_chain(nodes.size(), 0);
   // ---- source per chunk ----
   const bool lazy_loads = env_int("MH_JIT_LAZY", 1) != 0;
   char buf[256];
@@ -881,12 +889,19 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
         }
         std::string rhs = "e2{fold_value(d" + std::to_string(id) + "a), fold_value(d" + std::to_string(id) + "b)}";
         bool rc = true;  // the running sum is canonical so far
+        int links = 0, pieces = 0;
         for (uint32_t o : d.others) {
           const std::string O = ref(o);
           if (lazy_vals) {
             const std::string tp = std::string("<") + (rc ? "1" : "0") + ", " + (canon[o] ? "1" : "0") + ">(";
             rhs = (nodes[o].ext ? "lz_e2_add" : "lz_e2_addf") + tp + rhs + ", " + O + ")";
             rc = false;
+            if (lz_chain_max > 0 && ++links >= lz_chain_max) {  // see lz_chain above
+              body << "  e2 d" << id << "p" << pieces << " = " << rhs << "; asm(\"\" : \"+v\"(d" << id << "p" << pieces << ".c0), \"+v\"(d" << id << "p"
+                   << pieces << ".c1));\n";
+              rhs = "d" + std::to_string(id) + "p" + std::to_string(pieces++);
+              links = 0;
+            }
           } else {
             rhs = (nodes[o].ext ? "e2_add(" : "e2_addf(") + rhs + ", " + O + ")";
           }
@@ -900,6 +915,7 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
       const std::string A = ref(nd.a);
       const bool ea = nodes[nd.a].ext;
       std::string rhs;
+      bool opaque = false;
       if (lazy_vals) {
         const std::string ca = canon[nd.a] ? "1" : "0";
         if (nd.op == DOP_NEG) {
@@ -908,6 +924,13 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
           const std::string Bv = ref(nd.b);
           const bool eb = nodes[nd.b].ext;
           const std::string cb = canon[nd.b] ? "1" : "0", tab = "<" + ca + ", " + cb + ">(", tba = "<" + cb + ", " + ca + ">(";
+          // a one-sided lazy addition / subtraction (exactly the `_c` forms of the prelude) extends the chain of its lazy operand
+          const bool one_sided = (nd.op == DOP_ADD && (canon[nd.a] != 0) != (canon[nd.b] != 0)) || (nd.op == DOP_SUB && canon[nd.b] && !canon[nd.a]);
+          if (one_sided && lz_chain_max > 0) {
+            const uint32_t lazy_op = canon[nd.a] ? nd.b : nd.a;
+            lz_chain[id] = (uint16_t)(lz_chain[lazy_op] + 1);
+            if (lz_chain[id] >= lz_chain_max) opaque = true, lz_chain[id] = 0;
+          }
           if (nd.op == DOP_ADD)
             rhs = ea && eb ? "lz_e2_add" + tab + A + ", " + Bv + ")" : ea ? "lz_e2_addf" + tab + A + ", " + Bv + ")"
                   : eb     ? "lz_e2_addf" + tba + Bv + ", " + A + ")" : "lz_add" + tab + A + ", " + Bv + ")";
@@ -933,7 +956,12 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
           rhs = ea && eb ? "e2_mul(" + A + ", " + Bv + ")" : ea ? "e2_mulf(" + A + ", " + Bv + ")" : eb ? "e2_mulf(" + Bv + ", " + A + ")"
                                                                                                      : "gl_mul(" + A + ", " + Bv + ")";
       }
-      body << "  const " << (nd.ext ? "e2" : "u64") << " v" << id << " = " << rhs << ";\n";
+      if (opaque && nd.ext)
+        body << "  e2 v" << id << " = " << rhs << "; asm(\"\" : \"+v\"(v" << id << ".c0), \"+v\"(v" << id << ".c1));\n";
+      else if (opaque)
+        body << "  u64 v" << id << " = " << rhs << "; asm(\"\" : \"+v\"(v" << id << "));\n";
+      else
+        body << "  const " << (nd.ext ? "e2" : "u64") << " v" << id << " = " << rhs << ";\n";
       if (spilled[id] && def_chunk[id] == (int32_t)ci) {
         if (nd.ext)
           body << "  a.spill[" << slot[id] << "ull * a.spill_stride + qb] = v" << id << ".c0; a.spill[" << slot[id] + 1

@@ -1,7 +1,7 @@
 """The second client of the backend: AIRs of the precompile prover (`precompiles-prover/src`), hand-ported against `dag.AirBuilder`
 like the VM's three AIRs, and the statement layer of its session (`precompiles-prover/src/session/prove.rs`).
 
-What is here: six of the twelve chiplets of `ChipletAir::all()` (session/prove.rs:104-121) --
+What is here: seven of the twelve chiplets of `ChipletAir::all()` (session/prove.rs:104-121) --
 * `BytePairLutAir` (`primitives/byte_pair_lut.rs`): the one AIR of the stack with PREPROCESSED columns and a fixed height -- the
   2^16-row `(a, b, !a & b, a ^ b)` table committed once, three witness multiplicity columns, two LogUp columns;
 * `KeccakRoundAir` (`hash/keccak/round/{mod,program}.rs`): its consumer -- a three-address machine `c = ROL(a OP b, s)` whose 128-slot
@@ -18,11 +18,15 @@ What is here: six of the twelve chiplets of `ChipletAir::all()`
   permutations -- 67 columns (a padding state machine, lane halves, byte shadows), 24 flattened LogUp columns on Memory64 / the byte-pair
   table / KeccakSponge, eleven periodic columns of period 32, log_quotient_degree 2.  With it a KECCAK-256 HASHING SESSION closes over
   six real chiplets: bytes in (chunk tape), digest out (the round chiplet's output lanes);
+* `KeccakNodeAir` (`hash/keccak/node/{mod,trace}.rs`): one row per distinct hashed input -- issues the sponge's request, reads the digest
+  lanes, drives the two Poseidon2 permutations of the transcript-DAG node and provides `Binding(H_keccak, True, 0, 0)`; 30 columns, nine
+  flattened LogUp columns on six buses.  With it the hashing session runs over SEVEN real chiplets and only the transcript's readers of
+  the bindings stay outside;
 the precompile prover's LogUp adapter (natural last-row sigma closing, `logup/constraint.rs`: `dag.LogUp(closing="sigma_last_row")`),
 its bus registry (`relations.rs`) and `ChipletMultiAir::eval_external` (`session/prove.rs:259-272`: sum of the committed sigmas + the
 fixed boundary correction).
 
-What is not: the other six chiplets (the Keccak / chunk nodes, eval, uint store / add, EC point store / add /
+What is not: the other five chiplets (the chunk node, eval, uint store / add, EC point store / add /
 MSM: ~25 kLoC of the reference).  What the SPONGE would put on the Memory64 bus for the permutations of a trace (initial lanes, round
 constants, the consumed outputs: `sponge_side_requests`) comes from `requirer_air`, a one-interaction-per-row stand-in written against
 the same adapter, so that the statement closes; `eval_external` sums the `EcGroup` part of `fixed_boundary_correction` only (the
@@ -39,7 +43,7 @@ P = dag.P
 # relations.rs:52-80 (bus ids), :91 (MAX_MESSAGE_WIDTH), :78 (NUM_BUS_IDS); logup/mod.rs:103 (NUM_RANDOMNESS), :131 (NUM_PUBLIC_VALUES),
 # :146 (NUM_SIGMA_VALUES)
 BUS_BYTE_PAIR_LUT, BUS_RANGE16, BUS_MEMORY64, BUS_KECCAK_SPONGE, BUS_EC_GROUP = 0, 1, 4, 5, 14
-BUS_POSEIDON2_IN, BUS_POSEIDON2_OUT, BUS_CHUNK_CHAIN = 6, 7, 9
+BUS_POSEIDON2_IN, BUS_POSEIDON2_OUT, BUS_BINDING, BUS_CHUNK_CHAIN = 6, 7, 8, 9
 MAX_MESSAGE_WIDTH, NUM_BUS_IDS = 18, 21
 NUM_RANDOMNESS, NUM_PUBLIC_VALUES, NUM_SIGMA_VALUES = 2, 4, 1
 PLACEHOLDER_RELATION_DIGEST = (0, 0, 0, 0)  # session/prove.rs:40
@@ -1321,3 +1325,162 @@ def keccak_hash_side_requests(sponge, round_memory):
     for chunks, head, perm_start in sponge.chunks.records:
         out.append((BUS_CHUNK_CHAIN, 1, [head, perm_start]))
     return out
+
+
+# ---- KeccakNode: one Keccak invocation = one transcript-DAG node (hash/keccak/node/{mod,trace}.rs) ------------------------------------------
+# One row per DISTINCT hashed input.  The row issues the sponge's `KeccakSponge` request, consumes the chunk chain's `ChunkChain` tuple,
+# reads the four digest lanes D off the round chiplet's outputs (twice each, as they are provided), drives two Poseidon2 permutations --
+# H_digest_chunks = hash of D as a one-chunk payload under `Tag::CHUNKS`, H_keccak = hash of [H_input_chunks | H_digest_chunks] under the
+# Keccak-256 assertion tag [precompile id, 0, len_bytes, 0] -- reads H_input_chunks at the tail of the chunk chain, and provides
+# `Binding(H_keccak, True, 0, 0)` once per reader.  30 main columns, nine flattened LogUp columns, no periodic columns, lqd 1.
+KN_COLS, KN_AUX_COLS = 30, 9                                                                                  # node/mod.rs:122-153
+(KNC_ACT, KNC_SPONGE_HEAD, KNC_N_PERMS, KNC_CHUNK_HEAD, KNC_N_CHUNKS, KNC_PERM_CHUNKS, KNC_LEN, KNC_PERM_DIGEST_CHUNKS, KNC_PERM_KECCAK,
+ KNC_D) = range(10)
+KNC_H_INPUT_CHUNKS, KNC_H_DIGEST_CHUNKS, KNC_H_KECCAK, KNC_OUT_MULT = 17, 21, 25, 29
+# `Keccak256Precompile::id()` = `precompile_id("keccak256")` (core/src/deferred/precompile.rs:68-78): the first eight bytes, little-endian,
+# of BLAKE3("miden-deferred-precompile/v1:9:keccak256"); checked against the library's BLAKE3 in tests/test_precompile_node.py
+KECCAK256_PRECOMPILE_ID = 1416710563871706399
+KECCAK256_ASSERT_TAG_ID = 0                                                                                     # precompiles/src/hash/mod.rs:39, :66
+VALUE_TAG_TRUE = 0                                                                                              # transcript/binding.rs:38-46
+
+
+def keccak_node_air(host_aux=None):
+    """`KeccakNodeAir::eval` (hash/keccak/node/mod.rs:196-262) and its `LookupAir::eval` (:287-559): col 0 the KeccakSponge request |
+    col 1 Binding provide + ChunkChain consume | col 2 Poseidon2Out(H_input_chunks) | cols 3-4 the four digest lanes | cols 5-6 the
+    digest-chunks permutation | cols 7-8 the Keccak-node permutation."""
+    b = dag.AirBuilder(KN_COLS, aux_width=KN_AUX_COLS, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
+                       num_public=NUM_PUBLIC_VALUES)
+    loc, nxt = [b.main(c) for c in range(KN_COLS)], [b.main(c, 1) for c in range(KN_COLS)]
+    one = b.const(1)
+    act, act_next = loc[KNC_ACT], nxt[KNC_ACT]
+    b.assert_zero(b.is_first_row() * loc[KNC_SPONGE_HEAD])
+    b.assert_zero(b.is_first_row() * loc[KNC_CHUNK_HEAD])
+    b.assert_zero((one - act) * act)
+    b.assert_zero(b.is_transition() * ((one - act) * act_next))
+    b.assert_zero((one - act) * loc[KNC_OUT_MULT])
+    b.assert_zero(b.is_transition() * (act_next * (nxt[KNC_SPONGE_HEAD] - loc[KNC_SPONGE_HEAD] - b.const(32) * loc[KNC_N_PERMS])))
+    b.assert_zero(b.is_transition() * (act_next * (nxt[KNC_CHUNK_HEAD] - loc[KNC_CHUNK_HEAD] - loc[KNC_N_CHUNKS])))
+    lk = dag.LogUp(b, MAX_MESSAGE_WIDTH, NUM_BUS_IDS, closing="sigma_last_row")
+
+    def side(ch):
+        bb = lk.b if ch is lk.ch_c else lk.lb
+        return bb, [bb.main(c) for c in range(KN_COLS)]
+
+    def ks_request(ch):
+        bb, r = side(ch)
+        return ch.encode(BUS_KECCAK_SPONGE, [r[KNC_SPONGE_HEAD], bb.const(4) * r[KNC_CHUNK_HEAD], r[KNC_LEN]])
+
+    def binding(ch):       # BindingMsg::truth(h_keccak) (transcript/binding.rs:74-81, :109-121)
+        bb, r = side(ch)
+        return ch.encode(BUS_BINDING, r[KNC_H_KECCAK:KNC_H_KECCAK + 4] + [bb.const(VALUE_TAG_TRUE), bb.const(0), bb.const(0)])
+
+    def chunk_chain(ch):
+        _, r = side(ch)
+        return ch.encode(BUS_CHUNK_CHAIN, [r[KNC_CHUNK_HEAD], r[KNC_PERM_CHUNKS]])
+
+    def p2_out(perm, at):
+        def msg(ch):
+            bb, r = side(ch)
+            perm_seq_id = r[KNC_PERM_CHUNKS] + r[KNC_N_CHUNKS] - bb.const(1) if perm is None else r[perm]
+            return ch.encode(BUS_POSEIDON2_OUT, [perm_seq_id] + r[at:at + 4])
+        return msg
+
+    def d_lane(j):
+        def msg(ch):
+            bb, r = side(ch)
+            base = bb.const(100) * r[KNC_SPONGE_HEAD] + bb.const(3200) * r[KNC_N_PERMS] - bb.const(128)
+            return ch.encode(BUS_MEMORY64, [base + bb.const(j), r[KNC_D + 2 * j], r[KNC_D + 2 * j + 1]])
+        return msg
+
+    def p2_in(perm, tag, src):
+        def msg(ch):
+            bb, r = side(ch)
+            if src == "cap_chunks":
+                c = [bb.const(x) for x in TAG_CHUNKS_WORD]
+            elif src == "cap_keccak":
+                c = [bb.const(KECCAK256_PRECOMPILE_ID), bb.const(KECCAK256_ASSERT_TAG_ID), r[KNC_LEN], bb.const(0)]
+            else:
+                c = r[src:src + 4]
+            return ch.encode(BUS_POSEIDON2_IN, [r[perm], bb.const(tag)] + c)
+        return msg
+
+    def mults(fn):
+        return fn(lk.b), fn(lk.lb)
+    neg_act = mults(lambda bb: bb.const(0) - bb.main(KNC_ACT))
+    pos_act = mults(lambda bb: bb.main(KNC_ACT))
+    pos_act_x2 = mults(lambda bb: bb.const(2) * bb.main(KNC_ACT))
+    neg_out_mult = mults(lambda bb: bb.const(0) - bb.main(KNC_OUT_MULT))
+    dc, kk = KNC_PERM_DIGEST_CHUNKS, KNC_PERM_KECCAK
+    columns = ([(neg_act, ks_request)], [(neg_out_mult, binding), (pos_act, chunk_chain)], [(pos_act, p2_out(None, KNC_H_INPUT_CHUNKS))],
+               [(pos_act_x2, d_lane(0)), (pos_act_x2, d_lane(1))], [(pos_act_x2, d_lane(2)), (pos_act_x2, d_lane(3))],
+               [(pos_act, p2_in(dc, POSEIDON2_IN_TAG_RATE0, KNC_D)), (pos_act, p2_in(dc, POSEIDON2_IN_TAG_RATE1, KNC_D + 4))],
+               [(pos_act, p2_in(dc, POSEIDON2_IN_TAG_CAP, "cap_chunks")), (pos_act, p2_out(dc, KNC_H_DIGEST_CHUNKS))],
+               [(pos_act, p2_in(kk, POSEIDON2_IN_TAG_RATE0, KNC_H_INPUT_CHUNKS)), (pos_act, p2_in(kk, POSEIDON2_IN_TAG_RATE1, KNC_H_DIGEST_CHUNKS))],
+               [(pos_act, p2_in(kk, POSEIDON2_IN_TAG_CAP, "cap_keccak")), (pos_act, p2_out(kk, KNC_H_KECCAK))])
+    assert len(columns) == KN_AUX_COLS
+    for fractions in columns:
+        with lk.column() as col:
+            with col.group() as g:
+                with g.batch((lk.b.const(1), lk.lb.const(1))) as bt:
+                    for m_, msg in fractions:
+                        bt.insert(m_, msg)
+    lookup = lk.finish("keccak_node")
+    return dag.Air(b, _host_aux(lookup, host_aux), "keccak_node"), lookup
+
+
+class KeccakNodeRequires:
+    """`KeccakNodeRequires` (hash/keccak/node/trace.rs:146-240): the dedup point of the hashing stack -- a repeated input only raises its
+    node's `out_mult`; a new one lays its sponge invocation (and through it the chunk chain), reads the chunk-content digest, and lays the
+    two one-shot Poseidon2 permutations of the node."""
+
+    def __init__(self, sponge):
+        self.sponge, self.p2 = sponge, sponge.chunks.p2
+        self.records, self.by_input = [], {}
+
+    def require(self, data):
+        """-> dict(keccak_digest, h_keccak, node_row)"""
+        data = bytes(data)
+        idx = self.by_input.get(data)
+        if idx is not None:
+            self.records[idx]["out_mult"] += 1
+            return dict(keccak_digest=self.records[idx]["keccak_digest"], h_keccak=self.records[idx]["h_keccak"], node_row=idx)
+        out = self.sponge.require(data)
+        chain = out["chunk_absorption"]
+        h_input_chunks = self.p2.digest(chain)
+        self.p2.require_digest(chain)
+        d = [int.from_bytes(out["keccak_digest"][i:i + 4], "little") for i in range(0, 32, 4)]
+        dc = self.p2.require_absorption(TAG_CHUNKS_WORD, [(d[0:4], d[4:8])])
+        self.p2.require_digest(dc)
+        h_digest_chunks = self.p2.digest(dc)
+        kk = self.p2.require_absorption([KECCAK256_PRECOMPILE_ID, KECCAK256_ASSERT_TAG_ID, len(data), 0], [(h_input_chunks, h_digest_chunks)])
+        self.p2.require_digest(kk)
+        h_keccak = self.p2.digest(kk)
+        lay = self.sponge.invocations[-1]["layout"]
+        self.records.append(dict(len_bytes=len(data), d=d, h_input_chunks=h_input_chunks, h_digest_chunks=h_digest_chunks, h_keccak=h_keccak,
+                                 chunk_head=out["chunk_head"], perm_chunks=self.p2.span(chain)[0], perm_digest_chunks=self.p2.span(dc)[0],
+                                 perm_keccak=self.p2.span(kk)[0], sponge_head=out["sponge_head"], out_mult=1, keccak_digest=out["keccak_digest"],
+                                 n_sponge_perms=lay["num_blocks"], n_chunks=lay["chunk_lanes"] // 4))
+        self.by_input[data] = len(self.records) - 1
+        return dict(keccak_digest=out["keccak_digest"], h_keccak=h_keccak, node_row=len(self.records) - 1)
+
+
+def keccak_node_trace(requires, min_height=0):
+    """`generate_trace` / `push_row` (hash/keccak/node/trace.rs:52-113): one row per record, zero rows after."""
+    n = len(requires.records)
+    height = max(2, min_height, 1 << max(0, (n - 1).bit_length()) if n else 1)
+    t = np.zeros((height, KN_COLS), dtype=np.uint64)
+    for r, rec in enumerate(requires.records):
+        t[r, 0:9] = [1, rec["sponge_head"], rec["n_sponge_perms"], rec["chunk_head"], rec["n_chunks"], rec["perm_chunks"], rec["len_bytes"],
+                     rec["perm_digest_chunks"], rec["perm_keccak"]]
+        t[r, KNC_D:KNC_D + 8] = rec["d"]
+        t[r, KNC_H_INPUT_CHUNKS:KNC_H_INPUT_CHUNKS + 4] = rec["h_input_chunks"]
+        t[r, KNC_H_DIGEST_CHUNKS:KNC_H_DIGEST_CHUNKS + 4] = rec["h_digest_chunks"]
+        t[r, KNC_H_KECCAK:KNC_H_KECCAK + 4] = rec["h_keccak"]
+        t[r, KNC_OUT_MULT] = rec["out_mult"]
+    return t
+
+
+def binding_requests(node_requires):
+    """The transcript's readers of the nodes' truth bindings: `Binding(H_keccak, True, 0, 0)` consumed once per `require` of that input --
+    the only side of the Keccak hashing stack that is still a stand-in.  -> [(bus, multiplicity, fields)] for `requirer_air(payload=7)`."""
+    return [(BUS_BINDING, rec["out_mult"], list(rec["h_keccak"]) + [VALUE_TAG_TRUE, 0, 0]) for rec in node_requires.records]

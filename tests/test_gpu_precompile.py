@@ -407,14 +407,47 @@ def test_keccak_hash_session_device_proof_equals_oracle(ctx, jit, monkeypatch):
     assert ok and (dig == got.digest).all()
 
 
-def test_keccak_hash_session_production_params(ctx):
-    """54 inputs of up to 1.4 KiB (323 permutations: the round chiplet at 2^19 rows), production parameters: verify-only through both
-    verifiers and `eval_external`."""
+def keccak_node_session(inputs, permute_batch=None):
+    """The same with `KeccakNodeAir` in place of most of the stand-in: SEVEN real chiplets, only the transcript's Binding readers outside."""
+    ledger, p2 = PA.BytePairLutRequires(), PA.Poseidon2Requires()
+    chunks = PA.ChunkRequires(p2)
+    sp = PA.SpongeRequires(chunks, ledger)
+    nd = PA.KeccakNodeRequires(sp)
+    outs = [nd.require(d) for d in inputs]
+    kr_trace, mem = PA.keccak_round_trace(sp.perm_inputs, ledger)
+    p2_main, _ = PA.poseidon2_chiplet_trace(p2, permute_batch=permute_batch)
+    pairs = [PA.keccak_round_air(host_aux), PA.byte_pair_lut_air(host_aux), PA.keccak_sponge_air(host_aux), PA.chunk_air(host_aux),
+             PA.poseidon2_chiplet_air(host_aux), PA.keccak_node_air(host_aux), PA.requirer_air(host_aux, payload=7), PA.ec_groups_air(host_aux)]
+    traces = [kr_trace, PA.byte_pair_lut_trace(ledger), PA.keccak_sponge_trace(sp), PA.chunk_trace(chunks), p2_main, PA.keccak_node_trace(nd),
+              PA.requirer_trace(PA.binding_requests(nd), payload=7), PA.ec_groups_trace()]
+    return [p[0] for p in pairs], [p[1] for p in pairs], traces, outs
+
+
+def test_keccak_node_session_device_proof_equals_oracle(ctx, monkeypatch):
+    """Eight AIRs (one preprocessed), repeated inputs deduplicated by the node; compiled chunks."""
     pkg = load_package()
-    airs_, lookups, traces, _ = keccak_hash_session(_hash_inputs(52, 1400, 6))
+    monkeypatch.setenv("MH_JIT", "1")
+    inputs = _hash_inputs(4, 300, 33)
+    airs_, lookups, traces, outs = keccak_node_session(inputs + [b"abc", inputs[3]])
+    assert outs[1]["keccak_digest"].hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45" and outs[6]["node_row"] == 1
+    exp = ob.prove(airs_, traces, ROOT, FAST, init_state=protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST))
+    got, root, st, pre = device_prove(ctx, airs_, lookups, traces, FAST)
+    assert (got.commitments == exp["commitments"]).all()
+    assert got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all()
+    assert (got.digest == exp["digest"]).all()
+    ok, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, FAST, st, pre, got.fields, got.commitments, preprocessed_root=root,
+                         external=PA.external_assertions(pkg))
+    assert ok and (dig == got.digest).all()
+
+
+def test_keccak_node_session_production_params(ctx):
+    """54 inputs of up to 1.4 KiB (323 Keccak-f permutations: the round chiplet at 2^19 rows; 1 408 Poseidon2 permutations), production
+    parameters, the Poseidon2 chains stepped with the device permutation: verify-only through both verifiers and `eval_external`."""
+    pkg = load_package()
+    airs_, lookups, traces, _ = keccak_node_session(_hash_inputs(52, 1400, 6), permute_batch=ctx.poseidon2_permute)
     prm = dict(protocol.PROD_PARAMS)
     got, root, st, pre = device_prove(ctx, airs_, lookups, traces, prm)
-    assert got.log_trace_heights[0] == 19 and got.log_trace_heights[1] == 16
+    assert got.log_trace_heights[0] == 19 and got.log_trace_heights[1] == 16 and got.log_trace_heights[5] == 6
     ok, msg = ob.verify(airs_, got.log_trace_heights, ROOT, {"fields": got.fields, "commitments": got.commitments}, prm,
                         init_state=st, pre_observe=pre, external=PA.external_assertions(pkg))
     assert ok, msg

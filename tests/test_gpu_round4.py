@@ -263,7 +263,9 @@ GEN_SWITCHES = [{}, {"MH_JIT_RECOMP": "0"}, {"MH_JIT_RECOMP": "1000", "MH_JIT_CH
                 {"MH_JIT_LAZYVAL": "1", "MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=0"},
                 # the register budget: every chunk above 96 / 64 registers is cut again (up to three rounds of re-cutting), or never
                 {"MH_JIT_MAXREGS": "96"}, {"MH_JIT_MAXREGS": "64", "MH_JIT_CHUNK": "500"}, {"MH_JIT_SPLIT": "0", "MH_JIT_CHUNK": "500"},
-                {"MH_JIT_CUTK": "60"}]
+                {"MH_JIT_CUTK": "60"},
+                # the carry-select chain breaker (opaque values every 4 one-sided lazy additions / never)
+                {"MH_JIT_LZCHAIN": "4"}, {"MH_JIT_LZCHAIN": "0"}]
 
 
 @pytest.mark.parametrize("env", GEN_SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "defaults")

@@ -223,3 +223,19 @@ def test_the_hashing_session_proves_and_verifies_and_forgeries_do_not(session):
     forged[row, 3] = (int(forged[row, 3]) + 1) % P
     _, ok_o, ok_p = run(traces[:5] + [forged] + traces[6:])
     assert not ok_o and not ok_p
+
+
+def test_the_sponge_chunks_compile_in_seconds_not_minutes(tmp_path, sponge):
+    """The running sum over the sponge's 24 aux columns is a chain of 23 one-sided lazy additions; LLVM's DAG combiner needed 370 s for the
+    chunk that holds it until the generator started handing every 16th link over as an opaque value (air_jit.cpp: MH_JIT_LZCHAIN).
+    Offline compile (hiprtc for gfx950, no GPU), comgr's own cache off."""
+    import os, subprocess, sys, time
+    env = dict(os.environ, AMD_COMGR_CACHE="0")
+    blob = tmp_path / "sponge.dag"
+    sponge[0].blob.tofile(blob)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.perf_counter()
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "jit_precompile.py"), str(tmp_path / "cache"), str(blob)], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0 and "5 kernels" in out.stdout, out.stdout + out.stderr
+    assert time.perf_counter() - t0 < 120
