@@ -450,10 +450,11 @@ def precompile_session_probe(pkg, ctx, n_perms=80, steps=3):
 
 def keccak_hash_session_probe(pkg, ctx, steps=3):
     """Keccak-256 of 54 inputs (up to 1.4 KiB each, 40 KiB, 323 Keccak-f permutations: the round chiplet at 2^19 rows) proven over SEVEN
-    real chiplets of the second client: KeccakRoundAir (the permutations), BytePairLutAir (2^16-row PREPROCESSED table), KeccakSpongeAir
-    (pad10*1, absorb, squeeze: 67 columns, 24 flattened LogUp columns), ChunkAir (the input tape), Poseidon2Air (the tape's content hash
-    and the node hashes), KeccakNodeAir (one transcript-DAG node per distinct input: `Binding(H_keccak, True, 0, 0)`), EcGroupsAir; outside
-    them only the transcript's readers of the bindings.  Production parameters, every aux column on the device."""
+    real chiplets of the second client, in the shape and order the reference's session runs them: ChunkNodeAir (the input tape and one
+    transcript-DAG node per distinct input -- `Binding(H_keccak, True, 0, 0)` -- on one row range), Poseidon2Air (the tape's content hash and
+    the node hashes), KeccakRoundAir (the permutations), BytePairLutAir (2^16-row PREPROCESSED table), KeccakSpongeAir (pad10*1, absorb,
+    squeeze: 67 columns, 24 flattened LogUp columns), EcGroupsAir; outside them only the transcript's readers of the bindings.  Production
+    parameters, every aux column on the device."""
     import numpy as np
     from miden_vm_amd import protocol, precompile_airs as PA
     rng = np.random.default_rng(6)
@@ -466,18 +467,20 @@ def keccak_hash_session_probe(pkg, ctx, steps=3):
     outs = [nd.require(data) for data in inputs]
     kr_trace, mem = PA.keccak_round_trace(sp.perm_inputs, ledger)
     p2_main, _ = PA.poseidon2_chiplet_trace(p2, permute_batch=ctx.poseidon2_permute)
-    pairs = [PA.keccak_round_air(), PA.byte_pair_lut_air(), PA.keccak_sponge_air(), PA.chunk_air(), PA.poseidon2_chiplet_air(),
-             PA.keccak_node_air(), PA.requirer_air(payload=7), PA.ec_groups_air()]
-    host = [kr_trace, PA.byte_pair_lut_trace(ledger), PA.keccak_sponge_trace(sp), PA.chunk_trace(chunks), p2_main, PA.keccak_node_trace(nd),
+    # `ChipletAir::all()` order (session/prove.rs:111-126): ChunkNode (chunk + Keccak node on one row range), Poseidon2, KeccakRound,
+    # BytePairLut, KeccakSponge, [TranscriptEval: its Binding readers], EcGroups
+    pairs = [PA.chunk_node_air(), PA.poseidon2_chiplet_air(), PA.keccak_round_air(), PA.byte_pair_lut_air(), PA.keccak_sponge_air(),
+             PA.requirer_air(payload=7), PA.ec_groups_air()]
+    host = [PA.chunk_node_trace(chunks, nd), p2_main, kr_trace, PA.byte_pair_lut_trace(ledger), PA.keccak_sponge_trace(sp),
             PA.requirer_trace(PA.binding_requests(nd), payload=7), PA.ec_groups_trace()]
     gen_s = time.perf_counter() - t0
     airs_h = [p_[0] for p_ in pairs]
     prm = dict(protocol.PROD_PARAMS)
     root_pub = [71, 72, 73, 74]
     dairs = [pkg.DeviceAir(ctx, a) for a in airs_h]
-    raw = ctx.upload_trace(airs_h[1].preprocessed)
+    raw = ctx.upload_trace(airs_h[3].preprocessed)
     com = pkg.commit_traces(ctx, [raw], prm["log_blowup"])
-    dairs[1].attach_preprocessed(com.tree(), 0, raw=raw)
+    dairs[3].attach_preprocessed(com.tree(), 0, raw=raw)
     for d, (_, lk) in zip(dairs, pairs):
         d.attach_lookup(pkg.DeviceLookup(ctx, lk))
     st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
@@ -493,7 +496,7 @@ def keccak_hash_session_probe(pkg, ctx, steps=3):
     for t in traces:
         t.free()
     n_bytes = sum(len(x) for x in inputs)
-    return {"workload": "Keccak-256 hashing session: KeccakRoundAir, BytePairLutAir (preprocessed), KeccakSpongeAir 67 + 24 EF aux, ChunkAir, Poseidon2Air, KeccakNodeAir 30 + 9 EF aux, the transcript's Binding readers, EcGroupsAir; production parameters, aux columns on the device",
+    return {"workload": "Keccak-256 hashing session in ChipletAir::all() order: ChunkNodeAir 42 + 14 EF aux, Poseidon2Air, KeccakRoundAir, BytePairLutAir (preprocessed), KeccakSpongeAir 67 + 24 EF aux, the transcript's Binding readers, EcGroupsAir; production parameters, aux columns on the device",
             "inputs": len(inputs), "distinct_inputs": len(nd.records), "input_bytes": n_bytes, "keccak_permutations": len(sp.perm_inputs),
             "poseidon2_permutations": p2.next_seq, "log_trace_heights": proof.log_trace_heights,
             "ms_per_proof": dt * 1e3, "hashes_per_s": len(inputs) / dt, "keccak_permutations_per_s": len(sp.perm_inputs) / dt,

@@ -22,6 +22,8 @@ What is here: seven of the twelve chiplets of `ChipletAir::all(
   lanes, drives the two Poseidon2 permutations of the transcript-DAG node and provides `Binding(H_keccak, True, 0, 0)`; 30 columns, nine
   flattened LogUp columns on six buses.  With it the hashing session runs over SEVEN real chiplets and only the transcript's readers of
   the bindings stay outside;
+* `ChunkNodeAir` (`hash/chunk_node/{mod,trace}.rs`): the form `ChipletAir::all()` really runs -- the chunk and the Keccak node chiplets
+  side by side on one row range (42 columns, 14 LogUp columns, one sigma); composed here from the same two halves;
 the precompile prover's LogUp adapter (natural last-row sigma closing, `logup/constraint.rs`: `dag.LogUp(closing="sigma_last_row")`),
 its bus registry (`relations.rs`) and `ChipletMultiAir::eval_external` (`session/prove.rs:259-272`: sum of the committed sigmas + the
 fixed boundary correction).
@@ -285,13 +287,9 @@ TAG_CHUNKS_WORD = (2, 0, 0, 0)                                          # Tag::C
 POSEIDON2_IN_TAG_RATE0, POSEIDON2_IN_TAG_RATE1, POSEIDON2_IN_TAG_CAP = 0, 1, 2   # transcript/poseidon2/messages.rs:19-23
 
 
-def chunk_air(host_aux=None):
-    """`ChunkAir::eval` (hash/chunk/mod.rs:149-200): `chunk_seq_id` = the row index, `perm_seq_id` + 1 inside a chain and free at chain
-    heads, `act` sticky downward, `is_head` boolean and dead on inactive rows; and its `LookupAir::eval` (:223-360): col 0 lane0 |
-    col 1 lane1 + lane2 | col 2 lane3 + rate0 | col 3 rate1 + cap | col 4 the ChunkChain emit."""
-    b = dag.AirBuilder(CHUNK_COLS, aux_width=CHUNK_AUX_COLS, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
-                       num_public=NUM_PUBLIC_VALUES)
-    loc, nxt = [b.main(c) for c in range(CHUNK_COLS)], [b.main(c, 1) for c in range(CHUNK_COLS)]
+def _chunk_local(b, off=0):
+    """The local constraints of `ChunkAir::eval` (hash/chunk/mod.rs:149-200) over the main columns [off, off + 12)."""
+    loc, nxt = [b.main(off + c) for c in range(CHUNK_COLS)], [b.main(off + c, 1) for c in range(CHUNK_COLS)]
     one = b.const(1)
     chunk_seq_id, chunk_seq_id_next = loc[COL_CHUNK_SEQ_ID], nxt[COL_CHUNK_SEQ_ID]
     perm_seq_id, perm_seq_id_next = loc[COL_PERM_SEQ_ID], nxt[COL_PERM_SEQ_ID]
@@ -303,11 +301,13 @@ def chunk_air(host_aux=None):
     b.assert_zero(b.is_transition() * ((one - act) * act_next))
     b.assert_zero((one - is_head) * is_head)                            # assert_bool(is_head)
     b.assert_zero(is_head * (one - act))
-    lk = dag.LogUp(b, MAX_MESSAGE_WIDTH, NUM_BUS_IDS, closing="sigma_last_row")
 
+
+def _chunk_columns(lk, off=0):
+    """The five flattened LogUp columns of `ChunkAir` (hash/chunk/mod.rs:223-360) -> [[(multiplicity pair, message)]]."""
     def side(ch):
         bb = lk.b if ch is lk.ch_c else lk.lb
-        row = [bb.main(c) for c in range(CHUNK_COLS)]
+        row = [bb.main(off + c) for c in range(CHUNK_COLS)]
         return bb, row, row[COL_F_BEGIN:COL_F_BEGIN + CHUNK_NUM_F]
 
     def lane(j):        # Memory64Msg { addr: CHUNK_ADDR_BASE + 4 chunk_seq_id + j, lo: f[2j], hi: f[2j + 1] } (hash/memory64.rs:55-64)
@@ -332,18 +332,33 @@ def chunk_air(host_aux=None):
 
     def mults(fn):
         return fn(lk.b), fn(lk.lb)
-    neg_act = mults(lambda bb: bb.const(0) - bb.main(COL_CHUNK_ACT))
-    pos_act = mults(lambda bb: bb.main(COL_CHUNK_ACT))
-    pos_act_head = mults(lambda bb: bb.main(COL_CHUNK_ACT) * bb.main(COL_IS_HEAD))
-    neg_act_head = mults(lambda bb: bb.const(0) - bb.main(COL_CHUNK_ACT) * bb.main(COL_IS_HEAD))
-    columns = ([(neg_act, lane(0))], [(neg_act, lane(1)), (neg_act, lane(2))], [(neg_act, lane(3)), (pos_act, p2_in(POSEIDON2_IN_TAG_RATE0, 0))],
-               [(pos_act, p2_in(POSEIDON2_IN_TAG_RATE1, 1)), (pos_act_head, p2_in(POSEIDON2_IN_TAG_CAP, None))], [(neg_act_head, emit)])
-    for fractions in columns:                                           # frac_col!
+    neg_act = mults(lambda bb: bb.const(0) - bb.main(off + COL_CHUNK_ACT))
+    pos_act = mults(lambda bb: bb.main(off + COL_CHUNK_ACT))
+    pos_act_head = mults(lambda bb: bb.main(off + COL_CHUNK_ACT) * bb.main(off + COL_IS_HEAD))
+    neg_act_head = mults(lambda bb: bb.const(0) - bb.main(off + COL_CHUNK_ACT) * bb.main(off + COL_IS_HEAD))
+    return [[(neg_act, lane(0))], [(neg_act, lane(1)), (neg_act, lane(2))], [(neg_act, lane(3)), (pos_act, p2_in(POSEIDON2_IN_TAG_RATE0, 0))],
+            [(pos_act, p2_in(POSEIDON2_IN_TAG_RATE1, 1)), (pos_act_head, p2_in(POSEIDON2_IN_TAG_CAP, None))], [(neg_act_head, emit)]]
+
+
+def _emit_frac_cols(lk, columns):
+    """`frac_col!` (logup/mod.rs:13-28) per entry: one column = one group = one batch of its fractions under the flag ONE."""
+    for fractions in columns:
         with lk.column() as col:
             with col.group() as g:
                 with g.batch((lk.b.const(1), lk.lb.const(1))) as bt:
                     for mult, msg in fractions:
                         bt.insert(mult, msg)
+
+
+def chunk_air(host_aux=None):
+    """`ChunkAir::eval` (hash/chunk/mod.rs:149-200): `chunk_seq_id` = the row index, `perm_seq_id` + 1 inside a chain and free at chain
+    heads, `act` sticky downward, `is_head` boolean and dead on inactive rows; and its `LookupAir::eval` (:223-360): col 0 lane0 |
+    col 1 lane1 + lane2 | col 2 lane3 + rate0 | col 3 rate1 + cap | col 4 the ChunkChain emit."""
+    b = dag.AirBuilder(CHUNK_COLS, aux_width=CHUNK_AUX_COLS, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
+                       num_public=NUM_PUBLIC_VALUES)
+    _chunk_local(b)
+    lk = dag.LogUp(b, MAX_MESSAGE_WIDTH, NUM_BUS_IDS, closing="sigma_last_row")
+    _emit_frac_cols(lk, _chunk_columns(lk))
     lookup = lk.finish("chunk")
     return dag.Air(b, _host_aux(lookup, host_aux), "chunk"), lookup
 
@@ -1344,13 +1359,9 @@ KECCAK256_ASSERT_TAG_ID = 0                                                     
 VALUE_TAG_TRUE = 0                                                                                              # transcript/binding.rs:38-46
 
 
-def keccak_node_air(host_aux=None):
-    """`KeccakNodeAir::eval` (hash/keccak/node/mod.rs:196-262) and its `LookupAir::eval` (:287-559): col 0 the KeccakSponge request |
-    col 1 Binding provide + ChunkChain consume | col 2 Poseidon2Out(H_input_chunks) | cols 3-4 the four digest lanes | cols 5-6 the
-    digest-chunks permutation | cols 7-8 the Keccak-node permutation."""
-    b = dag.AirBuilder(KN_COLS, aux_width=KN_AUX_COLS, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
-                       num_public=NUM_PUBLIC_VALUES)
-    loc, nxt = [b.main(c) for c in range(KN_COLS)], [b.main(c, 1) for c in range(KN_COLS)]
+def _node_local(b, off=0):
+    """The local constraints of `KeccakNodeAir::eval` (hash/keccak/node/mod.rs:196-262) over the main columns [off, off + 30)."""
+    loc, nxt = [b.main(off + c) for c in range(KN_COLS)], [b.main(off + c, 1) for c in range(KN_COLS)]
     one = b.const(1)
     act, act_next = loc[KNC_ACT], nxt[KNC_ACT]
     b.assert_zero(b.is_first_row() * loc[KNC_SPONGE_HEAD])
@@ -1360,11 +1371,13 @@ def keccak_node_air(host_aux=None):
     b.assert_zero((one - act) * loc[KNC_OUT_MULT])
     b.assert_zero(b.is_transition() * (act_next * (nxt[KNC_SPONGE_HEAD] - loc[KNC_SPONGE_HEAD] - b.const(32) * loc[KNC_N_PERMS])))
     b.assert_zero(b.is_transition() * (act_next * (nxt[KNC_CHUNK_HEAD] - loc[KNC_CHUNK_HEAD] - loc[KNC_N_CHUNKS])))
-    lk = dag.LogUp(b, MAX_MESSAGE_WIDTH, NUM_BUS_IDS, closing="sigma_last_row")
 
+
+def _node_columns(lk, off=0):
+    """The nine flattened LogUp columns of `KeccakNodeAir` (hash/keccak/node/mod.rs:287-559) -> [[(multiplicity pair, message)]]."""
     def side(ch):
         bb = lk.b if ch is lk.ch_c else lk.lb
-        return bb, [bb.main(c) for c in range(KN_COLS)]
+        return bb, [bb.main(off + c) for c in range(KN_COLS)]
 
     def ks_request(ch):
         bb, r = side(ch)
@@ -1406,26 +1419,65 @@ def keccak_node_air(host_aux=None):
 
     def mults(fn):
         return fn(lk.b), fn(lk.lb)
-    neg_act = mults(lambda bb: bb.const(0) - bb.main(KNC_ACT))
-    pos_act = mults(lambda bb: bb.main(KNC_ACT))
-    pos_act_x2 = mults(lambda bb: bb.const(2) * bb.main(KNC_ACT))
-    neg_out_mult = mults(lambda bb: bb.const(0) - bb.main(KNC_OUT_MULT))
+    neg_act = mults(lambda bb: bb.const(0) - bb.main(off + KNC_ACT))
+    pos_act = mults(lambda bb: bb.main(off + KNC_ACT))
+    pos_act_x2 = mults(lambda bb: bb.const(2) * bb.main(off + KNC_ACT))
+    neg_out_mult = mults(lambda bb: bb.const(0) - bb.main(off + KNC_OUT_MULT))
     dc, kk = KNC_PERM_DIGEST_CHUNKS, KNC_PERM_KECCAK
-    columns = ([(neg_act, ks_request)], [(neg_out_mult, binding), (pos_act, chunk_chain)], [(pos_act, p2_out(None, KNC_H_INPUT_CHUNKS))],
-               [(pos_act_x2, d_lane(0)), (pos_act_x2, d_lane(1))], [(pos_act_x2, d_lane(2)), (pos_act_x2, d_lane(3))],
-               [(pos_act, p2_in(dc, POSEIDON2_IN_TAG_RATE0, KNC_D)), (pos_act, p2_in(dc, POSEIDON2_IN_TAG_RATE1, KNC_D + 4))],
-               [(pos_act, p2_in(dc, POSEIDON2_IN_TAG_CAP, "cap_chunks")), (pos_act, p2_out(dc, KNC_H_DIGEST_CHUNKS))],
-               [(pos_act, p2_in(kk, POSEIDON2_IN_TAG_RATE0, KNC_H_INPUT_CHUNKS)), (pos_act, p2_in(kk, POSEIDON2_IN_TAG_RATE1, KNC_H_DIGEST_CHUNKS))],
-               [(pos_act, p2_in(kk, POSEIDON2_IN_TAG_CAP, "cap_keccak")), (pos_act, p2_out(kk, KNC_H_KECCAK))])
+    return [[(neg_act, ks_request)], [(neg_out_mult, binding), (pos_act, chunk_chain)], [(pos_act, p2_out(None, KNC_H_INPUT_CHUNKS))],
+            [(pos_act_x2, d_lane(0)), (pos_act_x2, d_lane(1))], [(pos_act_x2, d_lane(2)), (pos_act_x2, d_lane(3))],
+            [(pos_act, p2_in(dc, POSEIDON2_IN_TAG_RATE0, KNC_D)), (pos_act, p2_in(dc, POSEIDON2_IN_TAG_RATE1, KNC_D + 4))],
+            [(pos_act, p2_in(dc, POSEIDON2_IN_TAG_CAP, "cap_chunks")), (pos_act, p2_out(dc, KNC_H_DIGEST_CHUNKS))],
+            [(pos_act, p2_in(kk, POSEIDON2_IN_TAG_RATE0, KNC_H_INPUT_CHUNKS)), (pos_act, p2_in(kk, POSEIDON2_IN_TAG_RATE1, KNC_H_DIGEST_CHUNKS))],
+            [(pos_act, p2_in(kk, POSEIDON2_IN_TAG_CAP, "cap_keccak")), (pos_act, p2_out(kk, KNC_H_KECCAK))]]
+
+
+def keccak_node_air(host_aux=None):
+    """`KeccakNodeAir::eval` (hash/keccak/node/mod.rs:196-262) and its `LookupAir::eval` (:287-559): col 0 the KeccakSponge request |
+    col 1 Binding provide + ChunkChain consume | col 2 Poseidon2Out(H_input_chunks) | cols 3-4 the four digest lanes | cols 5-6 the
+    digest-chunks permutation | cols 7-8 the Keccak-node permutation."""
+    b = dag.AirBuilder(KN_COLS, aux_width=KN_AUX_COLS, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
+                       num_public=NUM_PUBLIC_VALUES)
+    _node_local(b)
+    lk = dag.LogUp(b, MAX_MESSAGE_WIDTH, NUM_BUS_IDS, closing="sigma_last_row")
+    columns = _node_columns(lk)
     assert len(columns) == KN_AUX_COLS
-    for fractions in columns:
-        with lk.column() as col:
-            with col.group() as g:
-                with g.batch((lk.b.const(1), lk.lb.const(1))) as bt:
-                    for m_, msg in fractions:
-                        bt.insert(m_, msg)
+    _emit_frac_cols(lk, columns)
     lookup = lk.finish("keccak_node")
     return dag.Air(b, _host_aux(lookup, host_aux), "keccak_node"), lookup
+
+
+# ---- ChunkNode: the chunk chiplet and the Keccak node chiplet on one row range (hash/chunk_node/{mod,trace}.rs) ---------------------------
+# What `ChipletAir::all()` (session/prove.rs:111-126) actually runs: both period-1 AIRs side by side in disjoint column ranges -- main
+# columns 0..12 = ChunkAir's layout, 12..42 = KeccakNodeAir's, LogUp columns 0..5 = the chunk's (column 0 its anchor), 5..14 = the
+# node's (its anchor an ordinary column here); no mode selector, no cross-gating, one sigma; the height = the larger of the two.
+CN_COLS, CN_AUX_COLS, CN_NODE_OFFSET = CHUNK_COLS + KN_COLS, CHUNK_AUX_COLS + KN_AUX_COLS, CHUNK_COLS
+
+
+def chunk_node_air(host_aux=None):
+    """`ChunkNodeAir::eval` (hash/chunk_node/mod.rs:106-190: the chunk's seven constraints, then the node's seven) and its `LookupAir::eval`
+    (the chunk's five columns, then the node's nine: COLUMN_SHAPE [1, 2, 2, 2, 1, 1, 2, 1, 2, 2, 2, 2, 2, 2])."""
+    b = dag.AirBuilder(CN_COLS, aux_width=CN_AUX_COLS, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
+                       num_public=NUM_PUBLIC_VALUES)
+    _chunk_local(b)
+    _node_local(b, CN_NODE_OFFSET)
+    lk = dag.LogUp(b, MAX_MESSAGE_WIDTH, NUM_BUS_IDS, closing="sigma_last_row")
+    columns = _chunk_columns(lk) + _node_columns(lk, CN_NODE_OFFSET)
+    assert [len(c) for c in columns] == [1, 2, 2, 2, 1, 1, 2, 1, 2, 2, 2, 2, 2, 2]
+    _emit_frac_cols(lk, columns)
+    lookup = lk.finish("chunk_node")
+    return dag.Air(b, _host_aux(lookup, host_aux), "chunk_node"), lookup
+
+
+def chunk_node_trace(chunk_requires, node_requires):
+    """`generate_trace` (hash/chunk_node/trace.rs:24-45): the node's rows decide the least height of the chunk side, the node side is
+    zero-filled up to the chunk side's height."""
+    node_main = keccak_node_trace(node_requires)
+    chunk_main = chunk_trace(chunk_requires, node_main.shape[0])
+    t = np.zeros((chunk_main.shape[0], CN_COLS), dtype=np.uint64)
+    t[:, :CHUNK_COLS] = chunk_main
+    t[:node_main.shape[0], CHUNK_COLS:] = node_main
+    return t
 
 
 class KeccakNodeRequires:

@@ -51,9 +51,10 @@ def device_prove(ctx, airs_, lookups, traces, params):
     """Setup = commit the table once (Preprocessed::build), then the session's proof with every aux column from the device."""
     pkg = load_package()
     dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
-    raw = ctx.upload_trace(airs_[1].preprocessed)
+    (table,) = [i for i, a in enumerate(airs_) if a.preprocessed is not None]      # the byte-pair table, wherever the statement puts it
+    raw = ctx.upload_trace(airs_[table].preprocessed)
     com = pkg.commit_traces(ctx, [raw], params["log_blowup"])
-    dairs[1].attach_preprocessed(com.tree(), 0, raw=raw)
+    dairs[table].attach_preprocessed(com.tree(), 0, raw=raw)
     for d, lk in zip(dairs, lookups):
         d.attach_lookup(pkg.DeviceLookup(ctx, lk))
     st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
@@ -408,7 +409,9 @@ def test_keccak_hash_session_device_proof_equals_oracle(ctx, jit, monkeypatch):
 
 
 def keccak_node_session(inputs, permute_batch=None):
-    """The same with `KeccakNodeAir` in place of most of the stand-in: SEVEN real chiplets, only the transcript's Binding readers outside."""
+    """The same with the node chiplet in place of most of the stand-in, in the shape and ORDER the reference's session runs
+    (`ChipletAir::all()`, session/prove.rs:111-126): ChunkNodeAir (the chunk and the Keccak node chiplets on one row range, 42 columns, 14
+    LogUp columns), Poseidon2Air, KeccakRoundAir, BytePairLutAir, KeccakSpongeAir, [the transcript's Binding readers], EcGroupsAir."""
     ledger, p2 = PA.BytePairLutRequires(), PA.Poseidon2Requires()
     chunks = PA.ChunkRequires(p2)
     sp = PA.SpongeRequires(chunks, ledger)
@@ -416,15 +419,15 @@ def keccak_node_session(inputs, permute_batch=None):
     outs = [nd.require(d) for d in inputs]
     kr_trace, mem = PA.keccak_round_trace(sp.perm_inputs, ledger)
     p2_main, _ = PA.poseidon2_chiplet_trace(p2, permute_batch=permute_batch)
-    pairs = [PA.keccak_round_air(host_aux), PA.byte_pair_lut_air(host_aux), PA.keccak_sponge_air(host_aux), PA.chunk_air(host_aux),
-             PA.poseidon2_chiplet_air(host_aux), PA.keccak_node_air(host_aux), PA.requirer_air(host_aux, payload=7), PA.ec_groups_air(host_aux)]
-    traces = [kr_trace, PA.byte_pair_lut_trace(ledger), PA.keccak_sponge_trace(sp), PA.chunk_trace(chunks), p2_main, PA.keccak_node_trace(nd),
+    pairs = [PA.chunk_node_air(host_aux), PA.poseidon2_chiplet_air(host_aux), PA.keccak_round_air(host_aux), PA.byte_pair_lut_air(host_aux),
+             PA.keccak_sponge_air(host_aux), PA.requirer_air(host_aux, payload=7), PA.ec_groups_air(host_aux)]
+    traces = [PA.chunk_node_trace(chunks, nd), p2_main, kr_trace, PA.byte_pair_lut_trace(ledger), PA.keccak_sponge_trace(sp),
               PA.requirer_trace(PA.binding_requests(nd), payload=7), PA.ec_groups_trace()]
     return [p[0] for p in pairs], [p[1] for p in pairs], traces, outs
 
 
 def test_keccak_node_session_device_proof_equals_oracle(ctx, monkeypatch):
-    """Eight AIRs (one preprocessed), repeated inputs deduplicated by the node; compiled chunks."""
+    """Seven AIRs in the reference's order (the preprocessed table fourth), repeated inputs deduplicated by the node; compiled chunks."""
     pkg = load_package()
     monkeypatch.setenv("MH_JIT", "1")
     inputs = _hash_inputs(4, 300, 33)
@@ -447,7 +450,7 @@ def test_keccak_node_session_production_params(ctx):
     airs_, lookups, traces, _ = keccak_node_session(_hash_inputs(52, 1400, 6), permute_batch=ctx.poseidon2_permute)
     prm = dict(protocol.PROD_PARAMS)
     got, root, st, pre = device_prove(ctx, airs_, lookups, traces, prm)
-    assert got.log_trace_heights[0] == 19 and got.log_trace_heights[1] == 16 and got.log_trace_heights[5] == 6
+    assert got.log_trace_heights[2] == 19 and got.log_trace_heights[3] == 16 and got.log_trace_heights[0] == 11
     ok, msg = ob.verify(airs_, got.log_trace_heights, ROOT, {"fields": got.fields, "commitments": got.commitments}, prm,
                         init_state=st, pre_observe=pre, external=PA.external_assertions(pkg))
     assert ok, msg

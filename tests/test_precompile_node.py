@@ -205,3 +205,62 @@ def test_the_session_proves_and_verifies_and_forgeries_do_not(session):
     forged[0, 2] = (int(forged[0, 2]) + 1) % P
     _, ok_o, ok_p = run(traces[:6] + [forged] + traces[7:])
     assert not ok_o and not ok_p
+
+
+# ---- ChunkNode: the AIR the session really runs (hash/chunk_node) -----------------------------------------------------------------------
+def chunk_node_session(inputs, aux=host_aux):
+    """The hashing part of `SessionTraces::mains` in `ChipletAir::all()` order (session/prove.rs:111-126): ChunkNode, Poseidon2, KeccakRound,
+    BytePairLut, KeccakSponge, [TranscriptEval: here the Binding readers], ..., EcGroups."""
+    ledger, p2 = PA.BytePairLutRequires(), PA.Poseidon2Requires()
+    chunks = PA.ChunkRequires(p2)
+    sp = PA.SpongeRequires(chunks, ledger)
+    nd = PA.KeccakNodeRequires(sp)
+    for d in inputs:
+        nd.require(d)
+    kr_trace, _ = PA.keccak_round_trace(sp.perm_inputs, ledger)
+    p2_main, _ = PA.poseidon2_chiplet_trace(p2)
+    pairs = [PA.chunk_node_air(aux), PA.poseidon2_chiplet_air(aux), PA.keccak_round_air(aux), PA.byte_pair_lut_air(aux), PA.keccak_sponge_air(aux),
+             PA.requirer_air(aux, payload=7), PA.ec_groups_air(aux)]
+    traces = [PA.chunk_node_trace(chunks, nd), p2_main, kr_trace, PA.byte_pair_lut_trace(ledger), PA.keccak_sponge_trace(sp),
+              PA.requirer_trace(PA.binding_requests(nd), payload=7), PA.ec_groups_trace()]
+    return pairs, traces, chunks, nd
+
+
+def test_chunk_node_is_the_two_airs_side_by_side(session):
+    cn, _ = PA.chunk_node_air(host_aux)
+    h = dag.parse_air_blob(cn.blob)
+    assert (h["main_width"], h["aux_width"], h["num_aux_values"], h["num_public"], h["log_quotient_degree"]) == (42, 14, 1, 4, 1)
+    assert len(h["periodic"]) == 0 and len(h["constraints"]) == 7 + 7 + (3 + 13) and PA.CN_NODE_OFFSET == 12
+    pairs, traces, chunks, nd = chunk_node_session(INPUTS)
+    t = traces[0]
+    assert t.shape == (32, 42)                                          # 17 chunks against five node rows: the larger side decides
+    assert (t[:, :12] == PA.chunk_trace(chunks, 8)).all() and (t[:8, 12:] == PA.keccak_node_trace(nd)).all() and not t[8:, 12:].any()
+    # one sigma for both sides = the sum of the two stand-alone chiplets' sigmas
+    _, fin = ob.lookup_build_aux(pairs[0][1], t, RND, None)
+    _, fin_c = ob.lookup_build_aux(PA.chunk_air(host_aux)[1], PA.chunk_trace(chunks), RND, None)
+    _, fin_n = ob.lookup_build_aux(PA.keccak_node_air(host_aux)[1], PA.keccak_node_trace(nd), RND, None)
+    assert (int(fin[0]), int(fin[1])) == ((int(fin_c[0]) + int(fin_n[0])) % P, (int(fin_c[1]) + int(fin_n[1])) % P)
+    aux, fin = ob.lookup_build_aux(pairs[0][1], t, RND, None)
+    assert ob.check_constraints(cn, t, aux, [int(fin[0]), int(fin[1])], ROOT, RND, None) == (0, None)
+    bad = t.copy()
+    bad[3, 12 + PA.KNC_ACT] = 2                                          # the node side's booleanity, on a row the chunk side also uses
+    aux, fin = ob.lookup_build_aux(pairs[0][1], bad, RND, None)
+    assert ob.check_constraints(cn, bad, aux, [int(fin[0]), int(fin[1])], ROOT, RND, None)[0] >= 1
+
+
+def test_the_session_in_the_reference_order_closes_and_proves():
+    pairs, traces, _, _ = chunk_node_session(INPUTS)
+    sig = []
+    for (air, lookup), t in zip(pairs, traces):
+        _, fin = ob.lookup_build_aux(lookup, t, RND, air.preprocessed)
+        sig.append([(int(fin[0]), int(fin[1]))])
+    assert PA.eval_external(RND, sig) == [(0, 0)]
+    air_list = [p_[0] for p_ in pairs]
+    st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
+    proof = ob.prove(air_list, traces, ROOT, FAST, init_state=st)
+    root = proof["preprocessed_root"]
+    pre = protocol.protocol_pre_observe(FAST, ROOT, preprocessed_root=root)
+    ok_o, _ = ob.verify(air_list, proof["log_heights"], ROOT, proof, FAST, external=PA.external_assertions(pkg))
+    ok_p, _ = pkg.verify(air_list, proof["log_heights"], ROOT, FAST, st, pre, proof["fields"], proof["commitments"], preprocessed_root=root,
+                         external=PA.external_assertions(pkg))
+    assert ok_o and ok_p and proof["log_heights"][0] == 5
