@@ -1,7 +1,8 @@
 """The second client of the backend: AIRs of the precompile prover (`precompiles-prover/src`), hand-ported against `dag.AirBuilder`
 like the VM's three AIRs, and the statement layer of its session (`precompiles-prover/src/session/prove.rs`).
 
-What is here: seven of the twelve chiplets of `ChipletAir::all()` (session/prove.rs:104-121) --
+What is here: the HASHING HALF of the session -- six of the twelve AIRs of `ChipletAir::all()` (session/prove.rs:111-126:
+ChunkNode, Poseidon2, KeccakRound, BytePairLut, KeccakSponge, EcGroups; ChunkNode also as its two stand-alone halves) --
 * `BytePairLutAir` (`primitives/byte_pair_lut.rs`): the one AIR of the stack with PREPROCESSED columns and a fixed height -- the
   2^16-row `(a, b, !a & b, a ^ b)` table committed once, three witness multiplicity columns, two LogUp columns;
 * `KeccakRoundAir` (`hash/keccak/round/{mod,program}.rs`): its consumer -- a three-address machine `c = ROL(a OP b, s)` whose 128-slot
@@ -28,15 +29,18 @@ the precompile prover's LogUp adapter (natural last-row sigma closing, `logup/co
 its bus registry (`relations.rs`) and `ChipletMultiAir::eval_external` (`session/prove.rs:259-272`: sum of the committed sigmas + the
 fixed boundary correction).
 
-What is not: the other five chiplets (the chunk node, eval, uint store / add, EC point store / add /
-MSM: ~25 kLoC of the reference).  What the SPONGE would put on the Memory64 bus for the permutations of a trace (initial lanes, round
-constants, the consumed outputs: `sponge_side_requests`) comes from `requirer_air`, a one-interaction-per-row stand-in written against
-the same adapter, so that the statement closes; `eval_external` sums the `EcGroup` part of `fixed_boundary_correction` only (the
-`UintVal` part belongs to the uint store).  Pinned here: the round program's operation counts (program.rs tests: 22 / 52 / 25 / 5 / 24),
-the machine computes FIPS 202 Keccak-f (checked against a plain implementation), every bus balances.  Not pinned (no Rust): the
+What is not: the other six AIRs (TranscriptEval, the uint store / multiplier and adder, the EC point store / adder / MSM: ~15 kLoC of the
+reference).  Where a statement needs the other side of a bus that only they touch -- the transcript's readers of the `Binding` tuples in
+the hashing session, or, in the smaller sessions of the tests, whatever is left out (`sponge_side_requests`, `chunk_side_requests`,
+`keccak_hash_side_requests`, `poseidon2_out_requests`, `binding_requests`) -- it comes from `requirer_air`, a one-interaction-per-row
+stand-in written against the same adapter; `eval_external` sums the `EcGroup` part of `fixed_boundary_correction` only (the `UintVal`
+part belongs to the uint store).  Pinned: the reference's own unit tests of every ported chiplet replayed (tests/test_precompile_*.py:
+programs, layouts, quotient degrees, message encodings, accepting and corrupted traces), FIPS 202 (the round machine against a plain
+Keccak-f; keccak256 of the empty input and of "abc" end to end), every bus of every statement balances.  Not pinned (no Rust): the
 reference's own evaluation of the same constraints (exported symbolic DAGs, tools/ref_fixtures), and the quotient degree its symbolic
-builder assigns to the Keccak chiplet (this builder counts a periodic value as degree 1: log_quotient_degree 2, the reference's notes say 1).
-Parity of the device path is held by tests/test_precompile_airs.py and tests/test_gpu_precompile.py."""
+builder assigns to the Keccak ROUND chiplet (this builder counts a periodic value as degree 1: log_quotient_degree 2, the reference's
+notes say 1; for the chunk, Poseidon2, sponge and node chiplets the reference's tests assert 1 / 2 / 2 / 1 and this builder gives the same).
+Parity of the device path is held by tests/test_gpu_precompile.py."""
 import numpy as np
 from . import dag
 
