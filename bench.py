@@ -557,6 +557,52 @@ def chunk_poseidon2_session_probe(pkg, ctx, steps=3):
             "trace_generation_s": gen_s}
 
 
+def uint_add_session_probe(pkg, ctx, steps=3):
+    """The second client's modular-addition chiplet (precompiles-prover/src/uint/add: `UintAddAir`, a + b = c mod p over stored 256-bit
+    values by a vertical Schwartz-Zippel identity at the LogUp challenge -- a main-trace constraint over the extension field that reads a
+    verifier challenge): 2^16 relations (2^17 rows x 30 + 3 EF), the store's and the readers' sides of its two buses from the stand-in,
+    the group table; production parameters, aux columns on the device, verified through `eval_external`."""
+    import random
+    from miden_vm_amd import protocol, precompile_airs as PA
+    rng = random.Random(9)
+    t0 = time.perf_counter()
+    bound = rng.getrandbits(255) | (1 << 254) | 1
+    store = PA.UintStore()
+    fp = store.pin_modulus(1, bound)
+    add = PA.UintAddRequires()
+    n_ops = 1 << 16
+    vals = [rng.randrange(1, bound + 1) for _ in range(n_ops + 1)]
+    ptrs = [store.intern(v, fp) for v in vals]
+    for i in range(n_ops):
+        add.record(ptrs[i], ptrs[i + 1], store.intern((vals[i] + vals[i + 1]) % (bound + 1), fp), fp, 1)
+    main = PA.uint_add_trace(add, store)
+    others = store.uint_val_requests() + PA.uint_add_consumer_requests(add)
+    pairs = [PA.uint_add_air(), PA.requirer_air(payload=10), PA.ec_groups_air()]
+    host = [main, PA.requirer_trace(others, payload=10), PA.ec_groups_trace()]
+    gen_s = time.perf_counter() - t0
+    airs_h = [p_[0] for p_ in pairs]
+    prm = dict(protocol.PROD_PARAMS)
+    root_pub = [71, 72, 73, 74]
+    dairs = [pkg.DeviceAir(ctx, a) for a in airs_h]
+    for d, (_, lk) in zip(dairs, pairs):
+        d.attach_lookup(pkg.DeviceLookup(ctx, lk))
+    st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
+    pre = protocol.protocol_pre_observe(prm, root_pub)
+    traces = [ctx.upload_trace(t) for t in host]
+    proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    ok, _ = pkg.verify(airs_h, proof.log_trace_heights, root_pub, prm, st, pre, proof.fields, proof.commitments, external=PA.external_assertions(pkg))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    dt = (time.perf_counter() - t0) / steps
+    for t in traces:
+        t.free()
+    return {"workload": "uint-add session: UintAddAir 30 + 3 EF aux (one periodic selector), the store's and the readers' bus sides (12 + 1 EF aux), EcGroupsAir; production parameters, aux columns on the device",
+            "relations": n_ops, "log_trace_heights": proof.log_trace_heights, "ms_per_proof": dt * 1e3, "modular_additions_per_s": n_ops / dt,
+            "proof_bytes": len(proof.bytes), "verifies_with_eval_external": bool(ok), "compiled_chunks": [a.compiled_chunks for a in dairs],
+            "trace_generation_s": gen_s}
+
+
 def chunk_session_probe(pkg, ctx, steps=3):
     """The second client's chunk chiplet (precompiles-prover/src/hash/chunk: `ChunkAir`, twelve columns, five flattened LogUp columns on
     the Memory64 / Poseidon2In / ChunkChain buses): 1.07 MiB of hasher input in 64 invocations (35 076 chunks, 2^16 rows), the other sides
@@ -1147,6 +1193,10 @@ def main():
             out["keccak_hash_session"] = keccak_hash_session_probe(pkg, ctx)
         except Exception as e:
             out["keccak_hash_session"] = {"error": repr(e)[:300]}
+        try:
+            out["uint_add_session"] = uint_add_session_probe(pkg, ctx)
+        except Exception as e:
+            out["uint_add_session"] = {"error": repr(e)[:300]}
         try:
             # the service-level probes run in a process of their own (tools/bench_inflight_h2d.py, no torch in it): measured in THIS
             # process, which also hosts PyTorch's HIP runtime, the same loops lose the copy / kernel overlap (k = 1 with its uploads

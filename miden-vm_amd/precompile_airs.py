@@ -1,8 +1,8 @@
 """The second client of the backend: AIRs of the precompile prover (`precompiles-prover/src`), hand-ported against `dag.AirBuilder`
 like the VM's three AIRs, and the statement layer of its session (`precompiles-prover/src/session/prove.rs`).
 
-What is here: the HASHING HALF of the session -- six of the twelve AIRs of `ChipletAir::all()` (session/prove.rs:111-126:
-ChunkNode, Poseidon2, KeccakRound, BytePairLut, KeccakSponge, EcGroups; ChunkNode also as its two stand-alone halves) --
+What is here: seven of the twelve AIRs of `ChipletAir::all()` (session/prove.rs:111-126) -- the whole HASHING HALF of the
+session (ChunkNode, Poseidon2, KeccakRound, BytePairLut, KeccakSponge; ChunkNode also as its two stand-alone halves), EcGroups, and UintAdd --
 * `BytePairLutAir` (`primitives/byte_pair_lut.rs`): the one AIR of the stack with PREPROCESSED columns and a fixed height -- the
   2^16-row `(a, b, !a & b, a ^ b)` table committed once, three witness multiplicity columns, two LogUp columns;
 * `KeccakRoundAir` (`hash/keccak/round/{mod,program}.rs`): its consumer -- a three-address machine `c = ROL(a OP b, s)` whose 128-slot
@@ -25,11 +25,14 @@ ChunkNode, Poseidon2, KeccakRound, BytePairLut, KeccakSponge, EcGroups; ChunkNod
   the bindings stay outside;
 * `ChunkNodeAir` (`hash/chunk_node/{mod,trace}.rs`): the form `ChipletAir::all()` really runs -- the chunk and the Keccak node chiplets
   side by side on one row range (42 columns, 14 LogUp columns, one sigma); composed here from the same two halves;
+* `UintAddAir` (`uint/add/{mod,trace}.rs`): a + b = c (mod p) over stored 256-bit values -- a "vertical Schwartz-Zippel" identity at the
+  LogUp challenge beta: the one MAIN constraint of this stack over the extension field that reads a verifier challenge; ternary carries,
+  zero-sentinel modes (negation, equality certificate), a nonzero certificate; 30 columns, three LogUp columns, period 2;
 the precompile prover's LogUp adapter (natural last-row sigma closing, `logup/constraint.rs`: `dag.LogUp(closing="sigma_last_row")`),
 its bus registry (`relations.rs`) and `ChipletMultiAir::eval_external` (`session/prove.rs:259-272`: sum of the committed sigmas + the
 fixed boundary correction).
 
-What is not: the other six AIRs (TranscriptEval, the uint store / multiplier and adder, the EC point store / adder / MSM: ~15 kLoC of the
+What is not: the other five AIRs (TranscriptEval, the uint store / multiplier, the EC point store / adder / MSM: ~14 kLoC of the
 reference).  Where a statement needs the other side of a bus that only they touch -- the transcript's readers of the `Binding` tuples in
 the hashing session, or, in the smaller sessions of the tests, whatever is left out (`sponge_side_requests`, `chunk_side_requests`,
 `keccak_hash_side_requests`, `poseidon2_out_requests`, `binding_requests`) -- it comes from `requirer_air`, a one-interaction-per-row
@@ -49,7 +52,7 @@ P = dag.P
 # relations.rs:52-80 (bus ids), :91 (MAX_MESSAGE_WIDTH), :78 (NUM_BUS_IDS); logup/mod.rs:103 (NUM_RANDOMNESS), :131 (NUM_PUBLIC_VALUES),
 # :146 (NUM_SIGMA_VALUES)
 BUS_BYTE_PAIR_LUT, BUS_RANGE16, BUS_MEMORY64, BUS_KECCAK_SPONGE, BUS_EC_GROUP = 0, 1, 4, 5, 14
-BUS_POSEIDON2_IN, BUS_POSEIDON2_OUT, BUS_BINDING, BUS_CHUNK_CHAIN = 6, 7, 8, 9
+BUS_POSEIDON2_IN, BUS_POSEIDON2_OUT, BUS_BINDING, BUS_CHUNK_CHAIN, BUS_UINT_VAL, BUS_UINT_ADD = 6, 7, 8, 9, 10, 11
 MAX_MESSAGE_WIDTH, NUM_BUS_IDS = 18, 21
 NUM_RANDOMNESS, NUM_PUBLIC_VALUES, NUM_SIGMA_VALUES = 2, 4, 1
 PLACEHOLDER_RELATION_DIGEST = (0, 0, 0, 0)  # session/prove.rs:40
@@ -1540,3 +1543,221 @@ def binding_requests(node_requires):
     """The transcript's readers of the nodes' truth bindings: `Binding(H_keccak, True, 0, 0)` consumed once per `require` of that input --
     the only side of the Keccak hashing stack that is still a stand-in.  -> [(bus, multiplicity, fields)] for `requirer_air(payload=7)`."""
     return [(BUS_BINDING, rec["out_mult"], list(rec["h_keccak"]) + [VALUE_TAG_TRUE, 0, 0]) for rec in node_requires.records]
+
+
+# ---- UintAdd: a + b = c (mod p) over stored 256-bit values (uint/add/{mod,trace}.rs) -------------------------------------------------------
+# A relation AIR over the uint store: a, b, c and the modulus (stored as bound = p - 1) are pulled in over `UintVal`, the chiplet ties
+# their pointers to the modular-sum identity and provides `UintAdd(bound_ptr, a_ptr, b_ptr, c_ptr, nz)`.  The identity is checked by a
+# "vertical Schwartz-Zippel": with the eight 32-bit limbs of each value as coefficients,
+#     a(beta) + b(beta) - c(beta) - k (bound(beta) + 1) + (beta - 2^32) Gamma(beta) = 0,   Gamma = seven ternary carries,
+# at the LogUp challenge beta -- ONE extension-field constraint on the two-row window of a block (open row a || b, closing row c || p),
+# no accumulator column.  Two zero-sentinel modes (is_c_zero: a + b = 0, negation; is_b_zero: a = c, the equality certificate) and a
+# nonzero certificate for b (nz: w * sum of b's limbs = 1).  30 main columns, three LogUp columns, one periodic selector of period 2, lqd 1.
+UA_COLS, UA_AUX_COLS, UA_NUM_LIMBS, UA_PERIOD = 30, 3, 8, 2                                                    # uint/add/mod.rs:146-171
+UA_CELL_HI, UA_CELL_FLAG, UA_CELL_W, UA_CELL_WS, UA_CELL_B_ON = 8, 20, 21, 22, 23                               # open row: is_b_zero | w | wS | b_on
+UA_CELL_K, UA_CELL_C_ON, UA_CELL_MULT, UA_CELL_IS_C_ZERO = 20, 21, 22, 23                                       # closing row: k | c_on | mult | is_c_zero
+UA_COL_A_PTR, UA_COL_B_PTR, UA_COL_C_PTR, UA_COL_BOUND_PTR, UA_COL_ACT, UA_COL_NZ = 24, 25, 26, 27, 28, 29
+UA_GAMMA_SLOTS = ((0, 16), (0, 17), (0, 18), (0, 19), (1, 16), (1, 17), (1, 18))                               # (block row, cell) of gamma_0..6
+
+
+def uint_add_air(host_aux=None):
+    """`UintAddAir::eval` (uint/add/mod.rs:262-474) and its `LookupAir::eval` (:534-633): col 0 the `a` consume | col 1 the gated `b` and
+    `c` consumes | col 2 the modulus consume + the UintAdd provide."""
+    b = dag.AirBuilder(UA_COLS, aux_width=UA_AUX_COLS, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
+                       num_public=NUM_PUBLIC_VALUES, periodic=[[1, 0]])
+    loc, nxt = [b.main(c) for c in range(UA_COLS)], [b.main(c, 1) for c in range(UA_COLS)]
+    one = b.const(1)
+    ab_sel = b.periodic_value(0)
+    cp_sel = one - ab_sel
+    beta = b.randomness(1)
+    bp = [b.const(1)]
+    for _ in range(1, 8):
+        bp.append(bp[-1] * beta)
+    t32 = b.const(1 << 32)
+
+    def at_beta(cells):
+        acc = b.const(0)
+        for j in range(UA_NUM_LIMBS):
+            acc = acc + bp[j] * cells[j]
+        return acc
+    a_beta, b_beta = at_beta(loc[0:8]), at_beta(loc[UA_CELL_HI:UA_CELL_HI + 8])
+    c_beta, p_beta = at_beta(nxt[0:8]), at_beta(nxt[UA_CELL_HI:UA_CELL_HI + 8])
+    is_b_zero, is_c_zero_next, k_next = loc[UA_CELL_FLAG], nxt[UA_CELL_IS_C_ZERO], nxt[UA_CELL_K]
+    carry = b.const(0)
+    for j, (row, cell) in enumerate(UA_GAMMA_SLOTS):
+        w = bp[j + 1] - bp[j] * t32
+        carry = carry + w * (loc[cell] if row == 0 else nxt[cell])
+    identity = a_beta + b_beta * (one - is_b_zero) - c_beta * (one - is_c_zero_next) - (p_beta + bp[0]) * k_next + carry
+    b.assert_zero_ext(identity * ab_sel)
+    for cell in range(16, 20):                                          # ternary carries, ungated
+        g = loc[cell]
+        b.assert_zero(g * (one - g) * (one + g))
+    for col in (UA_CELL_FLAG, UA_CELL_B_ON):                            # a boolean on both rows of the block
+        b.assert_zero(loc[col] * (one - loc[col]))
+    act, nz = loc[UA_COL_ACT], loc[UA_COL_NZ]
+    b.assert_zero(act * (one - act))
+    b.assert_zero(nz * (one - nz))
+    b.assert_zero(cp_sel * (one - act) * loc[UA_CELL_MULT])
+    is_c_zero = loc[UA_CELL_IS_C_ZERO]
+    b.assert_zero(cp_sel * is_c_zero * loc[UA_COL_C_PTR])
+    b.assert_zero(ab_sel * is_b_zero * loc[UA_COL_B_PTR])
+    b.assert_zero(ab_sel * (loc[UA_CELL_B_ON] - act * (one - is_b_zero)))
+    b.assert_zero(cp_sel * (loc[UA_CELL_C_ON] - act * (one - is_c_zero)))
+    s_sum = b.const(0)
+    for j in range(UA_NUM_LIMBS):
+        s_sum = s_sum + loc[UA_CELL_HI + j]
+    w_, ws = loc[UA_CELL_W], loc[UA_CELL_WS]
+    b.assert_zero(ab_sel * (ws - w_ * s_sum))
+    b.assert_zero(ab_sel * nz * (ws - one))
+    for col in (UA_COL_A_PTR, UA_COL_B_PTR, UA_COL_C_PTR, UA_COL_BOUND_PTR, UA_COL_ACT, UA_COL_NZ):
+        b.assert_zero(ab_sel * (nxt[col] - loc[col]))
+
+    lk = dag.LogUp(b, MAX_MESSAGE_WIDTH, NUM_BUS_IDS, closing="sigma_last_row")
+
+    def side(ch):
+        bb = lk.b if ch is lk.ch_c else lk.lb
+        return bb, [bb.main(c) for c in range(UA_COLS)]
+
+    def uint_val(ptr_col, lo):           # UintValMsg { ptr, bound_ptr, limbs } (uint/mod.rs:116-134)
+        def msg(ch):
+            _, r = side(ch)
+            return ch.encode(BUS_UINT_VAL, [r[ptr_col], r[UA_COL_BOUND_PTR]] + r[lo:lo + 8])
+        return msg
+
+    def uint_add(ch):                    # UintAddMsg (uint/add/mod.rs:116-141)
+        _, r = side(ch)
+        return ch.encode(BUS_UINT_ADD, [r[UA_COL_BOUND_PTR], r[UA_COL_A_PTR], r[UA_COL_B_PTR], r[UA_COL_C_PTR], r[UA_COL_NZ]])
+
+    def mults(fn):
+        return fn(lk.b), fn(lk.lb)
+
+    def sel(bb, closing):
+        return bb.const(1) - bb.periodic_value(0) if closing else bb.periodic_value(0)
+    m_a = mults(lambda bb: sel(bb, False) * bb.main(UA_COL_ACT))
+    m_b = mults(lambda bb: sel(bb, False) * bb.main(UA_CELL_B_ON))
+    m_c = mults(lambda bb: sel(bb, True) * bb.main(UA_CELL_C_ON))
+    m_p = mults(lambda bb: sel(bb, True) * bb.main(UA_COL_ACT))
+    m_provide = mults(lambda bb: (bb.const(0) - bb.main(UA_CELL_MULT)) * sel(bb, True))
+    _emit_frac_cols(lk, [[(m_a, uint_val(UA_COL_A_PTR, 0))], [(m_b, uint_val(UA_COL_B_PTR, UA_CELL_HI)), (m_c, uint_val(UA_COL_C_PTR, 0))],
+                         [(m_p, uint_val(UA_COL_BOUND_PTR, UA_CELL_HI)), (m_provide, uint_add)]])
+    lookup = lk.finish("uint_add")
+    return dag.Air(b, _host_aux(lookup, host_aux), "uint_add"), lookup
+
+
+class UintStore:
+    """The part of `UintStoreRequires` (uint/trace.rs) the relation chiplets drive: 256-bit values at pointers, each under a modulus row
+    (`bound` = p - 1 stored at `bound_ptr`, a modulus row being its own bound), interned by (value, bound_ptr); `require_uintval` counts
+    the readers of a row.  The store AIR itself (UintStoreMul) is not ported: `uint_val_requests` is what it puts on the UintVal bus."""
+
+    def __init__(self):
+        self.rows, self.by_value, self.reads, self.next_ptr = {}, {}, {}, 1
+
+    def pin_modulus(self, ptr, bound):
+        self.rows[ptr] = (int(bound), ptr)
+        self.by_value[(int(bound), ptr)] = ptr
+        self.next_ptr = max(self.next_ptr, ptr + 1)
+        return ptr
+
+    def intern_pinned(self, ptr, value, bound_ptr):
+        assert 0 <= value <= self.rows[bound_ptr][0]
+        self.rows[ptr] = (int(value), bound_ptr)
+        self.by_value.setdefault((int(value), bound_ptr), ptr)
+        self.next_ptr = max(self.next_ptr, ptr + 1)
+        return ptr
+
+    def intern(self, value, bound_ptr):
+        key = (int(value), bound_ptr)
+        if key not in self.by_value:
+            self.intern_pinned(self.next_ptr, value, bound_ptr)
+        return self.by_value[key]
+
+    def value(self, ptr):
+        return self.rows[ptr][0]
+
+    def require_uintval(self, ptr):
+        self.reads[ptr] = self.reads.get(ptr, 0) + 1
+
+    def uint_val_requests(self):
+        """-> [(BUS_UINT_VAL, -readers, [ptr, bound_ptr, eight 32-bit limbs])] for `requirer_air(payload=10)`."""
+        out = []
+        for ptr, n in sorted(self.reads.items()):
+            v, bound_ptr = self.rows[ptr]
+            out.append((BUS_UINT_VAL, P - n, [ptr, bound_ptr] + [(v >> (32 * j)) & 0xffffffff for j in range(8)]))
+        return out
+
+
+class UintAddRequires:
+    """`UintAddRequires` (uint/add/trace.rs:37-103): relations deduplicated, multiplicities summed.  An op = (a, b or None, c or None,
+    bound, nz) over store pointers."""
+
+    def __init__(self):
+        self.ops, self.dedup = [], {}
+
+    def _push(self, op, mult):
+        if op in self.dedup:
+            self.ops[self.dedup[op]][1] += mult
+        else:
+            self.dedup[op] = len(self.ops)
+            self.ops.append([op, mult])
+
+    def record(self, a, b, c, bound, mult):
+        self._push((a, b, c, bound, False), mult)
+
+    def record_nz(self, a, b, c, bound, mult):
+        self._push((a, b, c, bound, True), mult)
+
+    def record_to_zero(self, a, b, bound, mult):
+        self._push((a, b, None, bound, False), mult)
+
+    def record_eq(self, a, c, bound, mult):
+        self._push((a, None, c, bound, False), mult)
+
+
+def _ua_carries(limb):      # uint/add/trace.rs `add_carries`: the binary carry out of limbs 0..6, and the bit-256 carry
+    out, carry = [], 0
+    for j in range(7):
+        carry = (limb(j) + carry) >> 32
+        out.append(carry)
+    return out, (limb(7) + carry) >> 32
+
+
+def uint_add_trace(requires, store, min_height=0):
+    """`generate_trace` / `witness` (uint/add/trace.rs:104-215): one two-row block per relation, zero blocks after; the reads of the
+    four operands are recorded in the store."""
+    n_ops = max(1, len(requires.ops))
+    height = max(min_height, 1 << (n_ops * UA_PERIOD - 1).bit_length())
+    t = np.zeros((height, UA_COLS), dtype=np.uint64)
+    limbs = lambda v: [(v >> (32 * j)) & 0xffffffff for j in range(8)]                                      # noqa: E731
+    for i, ((a, bptr, cptr, bound, nz), mult) in enumerate(requires.ops):
+        for ptr in (a, bptr, cptr, bound):
+            if ptr is not None:
+                store.require_uintval(ptr)
+        bound_v, a_v = store.value(bound), store.value(a)
+        b_v = store.value(bptr) if bptr is not None else 0
+        c_v = store.value(cptr) if cptr is not None else 0
+        assert (a_v + b_v) % (bound_v + 1) == c_v, "a + b must reduce to c"
+        al, bl, cl, pl = limbs(a_v), limbs(b_v), limbs(c_v), limbs(bound_v)
+        gamma_pos, top = _ua_carries(lambda j: al[j] + bl[j])
+        k = int(top != 0 or a_v + b_v > bound_v)
+        gamma_neg, top_neg = _ua_carries(lambda j: cl[j] + k * pl[j] + (k if j == 0 else 0))
+        assert top == top_neg
+        r0, r1 = 2 * i, 2 * i + 1
+        t[r0, 0:8], t[r0, 8:16], t[r1, 0:8], t[r1, 8:16] = al, bl, cl, pl
+        for j, (row, cell) in enumerate(UA_GAMMA_SLOTS):
+            t[r0 + row, cell] = (gamma_pos[j] - gamma_neg[j]) % P
+        t[r0, UA_CELL_FLAG], t[r1, UA_CELL_IS_C_ZERO] = int(bptr is None), int(cptr is None)
+        t[r0, UA_CELL_B_ON], t[r1, UA_CELL_C_ON] = int(bptr is not None), int(cptr is not None)
+        t[r1, UA_CELL_K], t[r1, UA_CELL_MULT] = k, mult % P
+        if nz:
+            s_sum = sum(bl)
+            assert s_sum != 0, "nz certifies b != 0"
+            w = pow(s_sum, P - 2, P)
+            t[r0, UA_CELL_W], t[r0, UA_CELL_WS] = w, w * s_sum % P
+        t[r0:r1 + 1, UA_COL_A_PTR:UA_COL_NZ + 1] = [a, bptr or 0, cptr or 0, bound, 1, int(nz)]
+    return t
+
+
+def uint_add_consumer_requests(requires):
+    """The readers of the relations (the eval chip's add / sub / neg nodes, the EC group law: not ported):
+    -> [(BUS_UINT_ADD, multiplicity, [bound_ptr, a_ptr, b_ptr, c_ptr, nz])]"""
+    return [(BUS_UINT_ADD, mult, [bound, a, bptr or 0, cptr or 0, int(nz)]) for (a, bptr, cptr, bound, nz), mult in requires.ops if mult]

@@ -457,3 +457,65 @@ def test_keccak_node_session_production_params(ctx):
     ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, preprocessed_root=root,
                           external=PA.external_assertions(pkg))
     assert ok2 and (dig == got.digest).all()
+
+
+# ---- UintAdd: a main-trace constraint over the extension field that reads a verifier challenge (uint/add) ------------------------------------
+def uint_add_session(n_ops, seed=41):
+    """[UintAddAir (the vertical Schwartz-Zippel identity at the LogUp challenge beta), the store's UintVal provides and the readers'
+    UintAdd consumes, EcGroupsAir]: all five block forms (plain, reduction, negation, equality, nonzero certificate)."""
+    import random
+    rng = random.Random(seed)
+    bound = rng.getrandbits(255) | (1 << 254) | 1
+    store = PA.UintStore()
+    fp = store.pin_modulus(1, bound)
+    add = PA.UintAddRequires()
+    vals = [rng.randrange(1, bound + 1) for _ in range(n_ops + 1)]
+    ptrs = [store.intern(v, fp) for v in vals]
+    for i in range(n_ops):
+        form = i % 8
+        if form == 5:
+            add.record_to_zero(ptrs[i], store.intern((bound + 1 - vals[i]) % (bound + 1), fp), fp, 1)
+        elif form == 6:
+            add.record_eq(ptrs[i], ptrs[i], fp, 2)
+        elif form == 7:
+            add.record_nz(ptrs[i], ptrs[i + 1], store.intern((vals[i] + vals[i + 1]) % (bound + 1), fp), fp, 1)
+        else:
+            add.record(ptrs[i], ptrs[i + 1], store.intern((vals[i] + vals[i + 1]) % (bound + 1), fp), fp, 1 + i % 3)
+    main = PA.uint_add_trace(add, store)
+    others = store.uint_val_requests() + PA.uint_add_consumer_requests(add)
+    pairs = [PA.uint_add_air(host_aux), PA.requirer_air(host_aux, payload=10), PA.ec_groups_air(host_aux)]
+    traces = [main, PA.requirer_trace(others, payload=10), PA.ec_groups_trace()]
+    return [p[0] for p in pairs], [p[1] for p in pairs], traces
+
+
+@pytest.mark.parametrize("jit", ["0", "1"])
+def test_uint_add_session_device_proof_equals_oracle(ctx, jit, monkeypatch):
+    pkg = load_package()
+    monkeypatch.setenv("MH_JIT", jit)
+    airs_, lookups, traces = uint_add_session(100)
+    exp = ob.prove(airs_, traces, ROOT, FAST, init_state=protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST))
+    got, st, pre = chunk_device_prove(ctx, airs_, lookups, traces, FAST)
+    assert (got.commitments == exp["commitments"]).all()
+    assert got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all()
+    assert (got.digest == exp["digest"]).all()
+    ok, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, FAST, st, pre, got.fields, got.commitments, external=PA.external_assertions(pkg))
+    assert ok and (dig == got.digest).all()
+    forged = traces[0].copy()
+    forged[1, 3] = (int(forged[1, 3]) + 1) % P                           # a limb of c: no valid proof of the forged trace
+    bad, _, _ = chunk_device_prove(ctx, airs_, lookups, [forged] + traces[1:], FAST)
+    ok, _ = pkg.verify(airs_, bad.log_trace_heights, ROOT, FAST, st, pre, bad.fields, bad.commitments, external=PA.external_assertions(pkg))
+    assert not ok
+
+
+def test_uint_add_session_production_params(ctx):
+    """2^14 modular additions over 256-bit values (2^15 rows), production parameters: verify-only through both verifiers."""
+    pkg = load_package()
+    airs_, lookups, traces = uint_add_session(1 << 14, seed=9)
+    prm = dict(protocol.PROD_PARAMS)
+    got, st, pre = chunk_device_prove(ctx, airs_, lookups, traces, prm)
+    assert got.log_trace_heights[0] == 15
+    ok, msg = ob.verify(airs_, got.log_trace_heights, ROOT, {"fields": got.fields, "commitments": got.commitments}, prm,
+                        init_state=st, pre_observe=pre, external=PA.external_assertions(pkg))
+    assert ok, msg
+    ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, external=PA.external_assertions(pkg))
+    assert ok2 and (dig == got.digest).all()

@@ -11,3 +11,4 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 print(json.dumps(bench.chunk_session_probe(pkg, ctx, steps)))
 print(json.dumps(bench.chunk_poseidon2_session_probe(pkg, ctx, steps)))
 print(json.dumps(bench.keccak_hash_session_probe(pkg, ctx, steps)))
+print(json.dumps(bench.uint_add_session_probe(pkg, ctx, steps)))
