@@ -603,6 +603,39 @@ def uint_add_session_probe(pkg, ctx, steps=3):
             "trace_generation_s": gen_s}
 
 
+def ec_store_session_probe(pkg, ctx, steps=3):
+    """The second client's point store (precompiles-prover/src/ec: `EcPointStoreAir`, 14 columns, five flattened LogUp columns -- the
+    EcPoint provide, the EcGroup and closure-certificate consumes, the curve-membership trio u = x^2 + a, w = x u + b, y^2 = w as three
+    degree-3 UintMul consumes) next to the group table it reads: 2^15 - 1 points of secp256k1 bound by value (98 301 membership relations),
+    the foreign sides of the UintMul / EcPoint buses from the stand-in; production parameters, aux columns on the device."""
+    from miden_vm_amd import protocol, precompile_airs as PA
+    t0 = time.perf_counter()
+    n_points = (1 << 15) - 1
+    pairs, host, _ = PA.ec_store_session(n_points)
+    gen_s = time.perf_counter() - t0
+    airs_h = [p_[0] for p_ in pairs]
+    prm = dict(protocol.PROD_PARAMS)
+    root_pub = [81, 82, 83, 84]
+    dairs = [pkg.DeviceAir(ctx, a) for a in airs_h]
+    for d, (_, lk) in zip(dairs, pairs):
+        d.attach_lookup(pkg.DeviceLookup(ctx, lk))
+    st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
+    pre = protocol.protocol_pre_observe(prm, root_pub)
+    traces = [ctx.upload_trace(t) for t in host]
+    proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    ok, _ = pkg.verify(airs_h, proof.log_trace_heights, root_pub, prm, st, pre, proof.fields, proof.commitments, external=PA.external_assertions(pkg))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    dt = (time.perf_counter() - t0) / steps
+    for t in traces:
+        t.free()
+    return {"workload": "ec-store session: EcPointStoreAir 14 + 5 EF aux, EcGroupsAir 6 + 1, the foreign bus sides (12 + 1 EF aux); production parameters, aux columns on the device",
+            "points": n_points + 1, "log_trace_heights": proof.log_trace_heights, "ms_per_proof": dt * 1e3, "bound_points_per_s": n_points / dt,
+            "proof_bytes": len(proof.bytes), "verifies_with_eval_external": bool(ok), "compiled_chunks": [a.compiled_chunks for a in dairs],
+            "trace_generation_s": gen_s}
+
+
 def chunk_session_probe(pkg, ctx, steps=3):
     """The second client's chunk chiplet (precompiles-prover/src/hash/chunk: `ChunkAir`, twelve columns, five flattened LogUp columns on
     the Memory64 / Poseidon2In / ChunkChain buses): 1.07 MiB of hasher input in 64 invocations (35 076 chunks, 2^16 rows), the other sides
@@ -1197,6 +1230,10 @@ def main():
             out["uint_add_session"] = uint_add_session_probe(pkg, ctx)
         except Exception as e:
             out["uint_add_session"] = {"error": repr(e)[:300]}
+        try:
+            out["ec_store_session"] = ec_store_session_probe(pkg, ctx)
+        except Exception as e:
+            out["ec_store_session"] = {"error": repr(e)[:300]}
         try:
             # the service-level probes run in a process of their own (tools/bench_inflight_h2d.py, no torch in it): measured in THIS
             # process, which also hosts PyTorch's HIP runtime, the same loops lose the copy / kernel overlap (k = 1 with its uploads

@@ -1649,26 +1649,33 @@ class UintStore:
     (`bound` = p - 1 stored at `bound_ptr`, a modulus row being its own bound), interned by (value, bound_ptr); `require_uintval` counts
     the readers of a row.  The store AIR itself (UintStoreMul) is not ported: `uint_val_requests` is what it puts on the UintVal bus."""
 
+    PIN_NAMESPACE_END = 1 << 16                                         # uint/trace.rs:97: pinned rows below, interned transients from here on
+
     def __init__(self):
-        self.rows, self.by_value, self.reads, self.next_ptr = {}, {}, {}, 1
+        self.rows, self.by_value, self.reads, self.next_ptr = {}, {}, {}, self.PIN_NAMESPACE_END
+
+    def _insert(self, ptr, value, bound_ptr):
+        assert ptr not in self.rows, f"duplicate uint ptr {ptr}"
+        assert (int(value), bound_ptr) not in self.by_value, "value already interned: pin before computing"
+        self.rows[ptr] = (int(value), bound_ptr)
+        self.by_value[(int(value), bound_ptr)] = ptr
+        return ptr
 
     def pin_modulus(self, ptr, bound):
-        self.rows[ptr] = (int(bound), ptr)
-        self.by_value[(int(bound), ptr)] = ptr
-        self.next_ptr = max(self.next_ptr, ptr + 1)
-        return ptr
+        assert 1 <= ptr < self.PIN_NAMESPACE_END, "pinned uint ptr outside the pin namespace [1, 2^16)"
+        return self._insert(ptr, bound, ptr)
 
     def intern_pinned(self, ptr, value, bound_ptr):
-        assert 0 <= value <= self.rows[bound_ptr][0]
-        self.rows[ptr] = (int(value), bound_ptr)
-        self.by_value.setdefault((int(value), bound_ptr), ptr)
-        self.next_ptr = max(self.next_ptr, ptr + 1)
-        return ptr
+        assert 1 <= ptr < self.PIN_NAMESPACE_END, "pinned uint ptr outside the pin namespace [1, 2^16)"
+        assert 0 <= value <= self.rows[bound_ptr][0], "value exceeds its modulus bound"
+        return self._insert(ptr, value, bound_ptr)
 
     def intern(self, value, bound_ptr):
         key = (int(value), bound_ptr)
         if key not in self.by_value:
-            self.intern_pinned(self.next_ptr, value, bound_ptr)
+            assert 0 <= value <= self.rows[bound_ptr][0], "value exceeds its modulus bound"
+            self._insert(self.next_ptr, value, bound_ptr)
+            self.next_ptr += 1
         return self.by_value[key]
 
     def value(self, ptr):
@@ -1761,3 +1768,289 @@ def uint_add_consumer_requests(requires):
     """The readers of the relations (the eval chip's add / sub / neg nodes, the EC group law: not ported):
     -> [(BUS_UINT_ADD, multiplicity, [bound_ptr, a_ptr, b_ptr, c_ptr, nz])]"""
     return [(BUS_UINT_ADD, mult, [bound, a, bptr or 0, cptr or 0, int(nz)]) for (a, bptr, cptr, bound, nz), mult in requires.ops if mult]
+
+
+# ---- EcPointStore: the points of the curves, their bindings and the curve-membership trio (ec/{mod,trace,require}.rs) ----------------
+# One row = one point: its pointer (consecutive from 1 while `act`), its group's five-tuple (pulled from EcGroupsAir over `EcGroup`), the
+# pointers of x and y in the uint store, and either the membership certificate u = x^2 + a, w = x u + b, y^2 = w as three consumed
+# `UintMul` relations, or the flag of the point at infinity (no coordinates, no trio), or a closure certificate consumed from EcGroupAdd
+# (`is_cert`: a sum of two points of the curve is on the curve).  Provides `EcPoint(ptr, group, x_ptr, y_ptr, is_pai)` to its readers.
+# 14 main columns, five LogUp columns, lqd 1.
+BUS_UINT_MUL, BUS_EC_POINT, BUS_EC_ON_CURVE_CERT = 12, 15, 17                                                   # relations.rs:52-80
+EP_COLS, EP_AUX_COLS = 14, 5                                                                                    # ec/mod.rs:104-123
+(EP_COL_PTR, EP_COL_GROUP_PTR, EP_COL_A_PTR, EP_COL_B_PTR, EP_COL_BOUND_PTR, EP_COL_SBOUND_PTR, EP_COL_X_PTR, EP_COL_Y_PTR, EP_COL_U_PTR,
+ EP_COL_W_PTR, EP_COL_IS_PAI, EP_COL_ECPOINT_MULT, EP_COL_ACT, EP_COL_IS_CERT) = range(14)
+
+
+def ec_point_store_air(host_aux=None):
+    """`EcPointStoreAir::eval` (ec/mod.rs:160-204) and its `LookupAir::eval` (:232-384): col 0 the EcPoint provide | col 1 the EcGroup
+    consume + the closure-certificate consume | cols 2-4 the membership trio u, w, y (one degree-3 multiplicity each)."""
+    b = dag.AirBuilder(EP_COLS, aux_width=EP_AUX_COLS, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
+                       num_public=NUM_PUBLIC_VALUES)
+    loc, nxt = [b.main(c) for c in range(EP_COLS)], [b.main(c, 1) for c in range(EP_COLS)]
+    one = b.const(1)
+    is_pai, is_cert, act, act_next = loc[EP_COL_IS_PAI], loc[EP_COL_IS_CERT], loc[EP_COL_ACT], nxt[EP_COL_ACT]
+    ptr, ptr_next = loc[EP_COL_PTR], nxt[EP_COL_PTR]
+    b.assert_zero(is_pai * (one - is_pai))
+    b.assert_zero(is_cert * (one - is_cert))
+    b.assert_zero(act * (one - act))
+    b.assert_zero(is_pai * is_cert)
+    for col in (EP_COL_X_PTR, EP_COL_Y_PTR, EP_COL_U_PTR, EP_COL_W_PTR):  # the point at infinity names no coordinates
+        b.assert_zero(is_pai * loc[col])
+    for col in (EP_COL_U_PTR, EP_COL_W_PTR):                            # a closure-certified point names no trio
+        b.assert_zero(is_cert * loc[col])
+    b.assert_zero((one - act) * loc[EP_COL_ECPOINT_MULT])
+    b.assert_zero(b.is_transition() * ((one - act) * act_next))
+    b.assert_zero(b.is_transition() * (act_next * (ptr_next - ptr - one)))
+    b.assert_zero(b.is_first_row() * (ptr - act))
+
+    lk = dag.LogUp(b, MAX_MESSAGE_WIDTH, NUM_BUS_IDS, closing="sigma_last_row")
+
+    def row(ch):
+        bb = lk.b if ch is lk.ch_c else lk.lb
+        return bb, [bb.main(c) for c in range(EP_COLS)]
+
+    def ec_point(ch):                    # EcPointMsg (ec/mod.rs:71-99)
+        _, r = row(ch)
+        return ch.encode(BUS_EC_POINT, [r[EP_COL_PTR], r[EP_COL_GROUP_PTR], r[EP_COL_X_PTR], r[EP_COL_Y_PTR], r[EP_COL_IS_PAI]])
+
+    def ec_group(ch):                    # EcGroupMsg (ec/mod.rs:36-64)
+        _, r = row(ch)
+        return ch.encode(BUS_EC_GROUP, [r[EP_COL_GROUP_PTR], r[EP_COL_A_PTR], r[EP_COL_B_PTR], r[EP_COL_BOUND_PTR], r[EP_COL_SBOUND_PTR]])
+
+    def cert(ch):                        # EcOnCurveCertMsg { group_ptr, r_ptr } (ec/add/mod.rs:169-183)
+        _, r = row(ch)
+        return ch.encode(BUS_EC_ON_CURVE_CERT, [r[EP_COL_GROUP_PTR], r[EP_COL_PTR]])
+
+    def mac(kappa_c, a_col, b_col, c_col, r_col):     # UintMulMsg (uint/mul/mod.rs:136-170) with kappa_a = 1, is_sub = 0
+        def msg(ch):
+            bb, r = row(ch)
+            return ch.encode(BUS_UINT_MUL, [bb.const(1), bb.const(kappa_c), r[a_col], r[b_col], r[c_col], r[r_col], r[EP_COL_BOUND_PTR],
+                                            bb.const(0)])
+        return msg
+
+    def mults(fn):
+        return fn(lk.b), fn(lk.lb)
+    neg_mult = mults(lambda bb: bb.const(0) - bb.main(EP_COL_ECPOINT_MULT))
+    m_act = mults(lambda bb: bb.main(EP_COL_ACT))
+    m_cert = mults(lambda bb: bb.main(EP_COL_ACT) * bb.main(EP_COL_IS_CERT))
+    member = lambda bb: bb.main(EP_COL_ACT) * (bb.const(1) - bb.main(EP_COL_IS_PAI)) * (bb.const(1) - bb.main(EP_COL_IS_CERT))  # noqa: E731
+    _emit_frac_cols(lk, [[(neg_mult, ec_point)], [(m_act, ec_group), (m_cert, cert)],
+                         [(mults(member), mac(1, EP_COL_X_PTR, EP_COL_X_PTR, EP_COL_A_PTR, EP_COL_U_PTR))],
+                         [(mults(member), mac(1, EP_COL_X_PTR, EP_COL_U_PTR, EP_COL_B_PTR, EP_COL_W_PTR))],
+                         [(mults(member), mac(0, EP_COL_Y_PTR, EP_COL_Y_PTR, EP_COL_BOUND_PTR, EP_COL_W_PTR))]])
+    lookup = lk.finish("ec_point_store")
+    return dag.Air(b, _host_aux(lookup, host_aux), "ec_point_store"), lookup
+
+
+class UintMulRequires:
+    """The ledger of `UintMulRequires::record` / `record_sub` (uint/mul/trace.rs): scaled multiply-accumulates
+    kappa_a a b +- kappa_c c = r (mod bound + 1) over store pointers, deduplicated, multiplicities summed.  The chiplet that proves them
+    (UintStoreMul) is not ported: `uint_mul_requests` is what it puts on the UintMul bus."""
+
+    def __init__(self):
+        self.ops, self.dedup = [], {}
+
+    def record(self, kappa_a, a, b, kappa_c, c, r, bound, mult, is_sub=False):
+        op = (kappa_a, kappa_c, a, b, c, r, bound, int(is_sub))
+        if op in self.dedup:
+            self.ops[self.dedup[op]][1] += mult
+        else:
+            self.dedup[op] = len(self.ops)
+            self.ops.append([op, mult])
+
+    def uint_mul_requests(self):
+        """-> [(BUS_UINT_MUL, -multiplicity, [kappa_a, kappa_c, a_ptr, b_ptr, c_ptr, r_ptr, bound_ptr, is_sub])] for `requirer_air(payload=10)`."""
+        return [(BUS_UINT_MUL, P - mult, list(op)) for op, mult in self.ops if mult]
+
+
+class EcStore:
+    """`EcStoreRequires` (ec/trace.rs:111-340): the group table (the VM-owned fixed curves preseeded, the others interned by
+    (a_ptr, b_ptr, bound_ptr)) and the point store (finite points interned by (group, x_ptr, y_ptr), one canonical point at infinity per
+    group), with the demand on both provides.  Pointers are row numbers + 1."""
+
+    def __init__(self):
+        self.groups, self.points = [], []          # [a, b, bound, scalar_bound or None] | (group, None | (x, y, None | (u, w)))
+        self.by_coords, self.by_curve, self.group_demand, self.point_demand, self.pai_rows = {}, {}, {}, {}, {}
+        for (ptr, a, bp, bound, sbound) in FIXED_EC_GROUPS:
+            assert ptr == len(self.groups) + 1
+            self.by_curve[(a, bp, bound)] = ptr
+            self.groups.append([a, bp, bound, sbound])
+
+    def create_group(self, a, b, bound):
+        if (a, b, bound) not in self.by_curve:
+            self.groups.append([a, b, bound, None])
+            self.by_curve[(a, b, bound)] = len(self.groups)
+        return self.by_curve[(a, b, bound)]
+
+    def set_scalar_bound(self, group, sbound):
+        g = self.groups[group - 1]
+        assert g[3] in (None, sbound), "conflicting scalar bound for the group"
+        g[3] = sbound
+
+    def _new_point(self, group, binding):
+        self.group_demand[group] = self.group_demand.get(group, 0) + 1
+        self.points.append((group, binding))
+        return len(self.points)
+
+    def add_point(self, group, x, y, u, w):
+        if (group, x, y) not in self.by_coords:
+            self.by_coords[(group, x, y)] = self._new_point(group, (x, y, (u, w)))
+        return self.by_coords[(group, x, y)]
+
+    def add_point_cert(self, group, x, y):
+        if (group, x, y) in self.by_coords:
+            return self.by_coords[(group, x, y)], False
+        self.by_coords[(group, x, y)] = self._new_point(group, (x, y, None))
+        return self.by_coords[(group, x, y)], True
+
+    def point_by_coords(self, group, x, y):
+        return self.by_coords.get((group, x, y))
+
+    def add_pai(self, group):
+        if group not in self.pai_rows:
+            self.pai_rows[group] = self._new_point(group, None)
+        return self.pai_rows[group]
+
+    def require_ecgroup(self, group):
+        self.group_demand[group] = self.group_demand.get(group, 0) + 1
+
+    def require_fixed_groups(self):
+        for (ptr, *_rest) in FIXED_EC_GROUPS:
+            self.require_ecgroup(ptr)
+
+    def require_ecpoint(self, point):
+        self.point_demand[point] = self.point_demand.get(point, 0) + 1
+
+    def group_params(self, group):
+        return tuple(self.groups[group - 1][:3])
+
+    def group_sbound(self, group):
+        g = self.groups[group - 1]
+        return g[2] if g[3] is None else g[3]
+
+    def point_params(self, point):
+        group, binding = self.points[point - 1]
+        return group, (None if binding is None else binding[:2])
+
+    def group_pai(self, group):
+        return self.pai_rows[group]
+
+    def ec_point_requests(self):
+        """The readers of the points (EcGroupAdd, EcMsm: not ported) -> [(BUS_EC_POINT, demand, [ptr, group, x_ptr, y_ptr, is_pai])]."""
+        out = []
+        for ptr, n in sorted(self.point_demand.items()):
+            group, binding = self.points[ptr - 1]
+            out.append((BUS_EC_POINT, n, [ptr, group] + ([0, 0, 1] if binding is None else [binding[0], binding[1], 0])))
+        return out
+
+    def cert_requests(self):
+        """What EcGroupAdd provides for the closure-certified points -> [(BUS_EC_ON_CURVE_CERT, -1, [group, ptr])]."""
+        return [(BUS_EC_ON_CURVE_CERT, P - 1, [group, i + 1]) for i, (group, binding) in enumerate(self.points)
+                if binding is not None and binding[2] is None]
+
+
+class EcRequire:
+    """The part of `EcRequire` (ec/require.rs:28-120) that binds points: coordinates enter by value and are interned in the uint store,
+    the membership trio is recorded in the MAC ledger (`UintRequire::mac` / `mac_into`, uint/require.rs:129-205)."""
+
+    def __init__(self, ec, store, muls):
+        self.ec, self.store, self.muls = ec, store, muls
+
+    def _mac(self, kappa_a, a, b, kappa_c, c, into=None):
+        bound = self.store.rows[a][1]
+        assert self.store.rows[b][1] == bound and self.store.rows[c][1] == bound, "mac operands must share a modulus"
+        r_v = (kappa_a * self.store.value(a) * self.store.value(b) + kappa_c * self.store.value(c)) % (self.store.value(bound) + 1)
+        if into is None:
+            into = self.store.intern(r_v, bound)
+        assert self.store.rows[into] == (r_v, bound), "kappa_a a b + kappa_c c must reduce to the stored r"
+        self.muls.record(kappa_a, a, b, kappa_c, c, into, bound, 1)
+        return into
+
+    def create_group(self, a, b, bound):
+        assert b != 0, "b = 0 puts (0, 0) on the curve"
+        group = self.ec.create_group(self.store.intern(a, bound), self.store.intern(b, bound), bound)
+        return group, self.ec.add_pai(group)
+
+    def constrain_scalar_bound(self, group, sbound):
+        self.ec.set_scalar_bound(group, sbound)
+
+    def add_point(self, group, x, y):
+        bound = self.ec.group_params(group)[2]
+        return self.add_point_at(group, self.store.intern(x, bound), self.store.intern(y, bound))
+
+    def add_point_at(self, group, x, y):
+        existing = self.ec.point_by_coords(group, x, y)
+        if existing is not None:
+            return existing
+        a, b, bound = self.ec.group_params(group)
+        u = self._mac(1, x, x, 1, a)
+        w = self._mac(1, x, u, 1, b)
+        self._mac(1, y, y, 0, bound, into=w)                            # y^2 = w, the dummy addend rides the modulus pointer under kappa_c = 0
+        return self.ec.add_point(group, x, y, u, w)
+
+    def point_on_group(self, group, x_ptr, y_ptr):
+        self.ec.add_pai(group)
+        point = self.add_point_at(group, x_ptr, y_ptr)
+        self.ec.require_ecpoint(point)
+        return point
+
+    def pai_on_group(self, group):
+        pai = self.ec.add_pai(group)
+        self.ec.require_ecpoint(pai)
+        return pai
+
+
+def ec_store_traces(ec, min_height=0):
+    """`generate_traces` (ec/trace.rs:347-411) -> (the EcGroupsAir main, the EcPointStoreAir main): heights = the next powers of two, at
+    least 2; group pads run the pointer chain on with `mult` = 0, point pads are all zero (`act` = 0)."""
+    gh = max(2, min_height, 1 << (max(1, len(ec.groups)) - 1).bit_length())
+    groups = np.zeros((gh, EC_GROUPS_COLS), dtype=np.uint64)
+    groups[:, 0] = np.arange(1, gh + 1, dtype=np.uint64)
+    for i, (a, bp, bound, _sb) in enumerate(ec.groups):
+        groups[i, 1:6] = [a, bp, bound, ec.group_sbound(i + 1), ec.group_demand.get(i + 1, 0) % P]
+    ph = max(2, min_height, 1 << (max(1, len(ec.points)) - 1).bit_length())
+    points = np.zeros((ph, EP_COLS), dtype=np.uint64)
+    for i, (group, binding) in enumerate(ec.points):
+        a, bp, bound = ec.group_params(group)
+        x, y, membership = (0, 0, None) if binding is None else binding
+        u, w = membership or (0, 0)
+        points[i] = [i + 1, group, a, bp, bound, ec.group_sbound(group), x, y, u, w, int(binding is None),
+                     ec.point_demand.get(i + 1, 0) % P, 1, int(binding is not None and membership is None)]
+    return groups, points
+
+
+K1_BOUND = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2E                                    # secp256k1: p - 1
+K1_G = (0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798, 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8)
+
+
+def k1_multiples(n):
+    """A workload for the probes and tests: G, 2 G, ..., n G on y^2 = x^3 + 7 over the secp256k1 field (chord and tangent, affine)."""
+    p, (gx, gy) = K1_BOUND + 1, K1_G
+    out, (x, y) = [K1_G], K1_G
+    for _ in range(n - 1):
+        lam = 3 * x * x * pow(2 * y, p - 2, p) % p if (x, y) == K1_G else (y - gy) * pow(x - gx, p - 2, p) % p
+        x3 = (lam * lam - x - gx) % p
+        x, y = x3, (lam * (x - x3) - y) % p
+        out.append((x, y))
+    return out
+
+
+def ec_store_session(n_points, host_aux=None, min_height=8):
+    """[EcPointStoreAir, EcGroupsAir, the foreign sides of the UintMul / EcPoint buses]: a curve created over a pinned modulus, its point
+    at infinity and `n_points` multiples of the base point bound by value, every second one with a reader; the VM-owned curve slot read
+    once by the verifier's boundary term.  -> ([(air, lookup)], [traces], ledgers)"""
+    store, muls, ec = UintStore(), UintMulRequires(), EcStore()
+    fp = store.pin_modulus(1, K1_BOUND)
+    req = EcRequire(ec, store, muls)
+    group, _pai = req.create_group(0, 7, fp)
+    for i, (x, y) in enumerate(k1_multiples(n_points)):
+        point = req.add_point(group, x, y)
+        if i % 2:
+            ec.require_ecpoint(point)
+    req.pai_on_group(group)
+    ec.require_fixed_groups()
+    groups, points = ec_store_traces(ec, min_height=min_height)
+    foreign = muls.uint_mul_requests() + ec.ec_point_requests() + ec.cert_requests()
+    pairs = [ec_point_store_air(host_aux), ec_groups_air(host_aux), requirer_air(host_aux, payload=10)]
+    return pairs, [points, groups, requirer_trace(foreign, payload=10)], (store, muls, ec)

@@ -519,3 +519,43 @@ def test_uint_add_session_production_params(ctx):
     assert ok, msg
     ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, external=PA.external_assertions(pkg))
     assert ok2 and (dig == got.digest).all()
+
+
+def ec_store_session(n_points):
+    """[EcPointStoreAir (14 columns, the membership trio as three degree-3 consumes), EcGroupsAir, the foreign sides]: the EcGroup bus
+    closes between the two real AIRs."""
+    pairs, traces, _ = PA.ec_store_session(n_points, host_aux)
+    return [p[0] for p in pairs], [p[1] for p in pairs], traces
+
+
+@pytest.mark.parametrize("jit", ["0", "1"])
+def test_ec_store_session_device_proof_equals_oracle(ctx, jit, monkeypatch):
+    pkg = load_package()
+    monkeypatch.setenv("MH_JIT", jit)
+    airs_, lookups, traces = ec_store_session(100)
+    exp = ob.prove(airs_, traces, ROOT, FAST, init_state=protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST))
+    got, st, pre = chunk_device_prove(ctx, airs_, lookups, traces, FAST)
+    assert (got.commitments == exp["commitments"]).all()
+    assert got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all()
+    assert (got.digest == exp["digest"]).all()
+    ok, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, FAST, st, pre, got.fields, got.commitments, external=PA.external_assertions(pkg))
+    assert ok and (dig == got.digest).all()
+    forged = traces[0].copy()
+    forged[3, PA.EP_COL_Y_PTR] = forged[4, PA.EP_COL_Y_PTR]              # off the curve: the y^2 relation it names was never recorded
+    bad, _, _ = chunk_device_prove(ctx, airs_, lookups, [forged] + traces[1:], FAST)
+    ok, _ = pkg.verify(airs_, bad.log_trace_heights, ROOT, FAST, st, pre, bad.fields, bad.commitments, external=PA.external_assertions(pkg))
+    assert not ok
+
+
+def test_ec_store_session_production_params(ctx):
+    """4000 bound points of secp256k1 (2^12 rows, 12 000 membership relations), production parameters: verify-only through both verifiers."""
+    pkg = load_package()
+    airs_, lookups, traces = ec_store_session(4000)
+    prm = dict(protocol.PROD_PARAMS)
+    got, st, pre = chunk_device_prove(ctx, airs_, lookups, traces, prm)
+    assert list(got.log_trace_heights[:2]) == [12, 3]
+    ok, msg = ob.verify(airs_, got.log_trace_heights, ROOT, {"fields": got.fields, "commitments": got.commitments}, prm,
+                        init_state=st, pre_observe=pre, external=PA.external_assertions(pkg))
+    assert ok, msg
+    ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, external=PA.external_assertions(pkg))
+    assert ok2 and (dig == got.digest).all()

@@ -12,3 +12,4 @@ print(json.dumps(bench.chunk_session_probe(pkg, ctx, steps)))
 print(json.dumps(bench.chunk_poseidon2_session_probe(pkg, ctx, steps)))
 print(json.dumps(bench.keccak_hash_session_probe(pkg, ctx, steps)))
 print(json.dumps(bench.uint_add_session_probe(pkg, ctx, steps)))
+print(json.dumps(bench.ec_store_session_probe(pkg, ctx, steps)))
