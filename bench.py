@@ -603,6 +603,50 @@ def uint_add_session_probe(pkg, ctx, steps=3):
             "trace_generation_s": gen_s}
 
 
+def ec_add_session_probe(pkg, ctx, steps=3):
+    """The second client's group-law chiplet (precompiles-prover/src/ec/add: `EcGroupAddAir`, 21 columns, twelve flattened LogUp columns on
+    seven buses, four-row blocks; every piece of field arithmetic a pointer-level certificate consumed from the uint chiplets) inside the
+    reference's "arithmetic + EC stack" in its order: 40 scalar multiples k G over secp256k1 by double-and-add with 256-bit scalars =
+    ~15 000 proven point additions (doubles, chords, pass-throughs; results minted with closure certificates), five real chiplets --
+    BytePairLutAir (preprocessed), UintAddAir, EcGroupsAir, EcPointStoreAir, EcGroupAddAir -- and the uint store / multiplier's bus sides
+    from the stand-in; production parameters, aux columns on the device, verified through `eval_external`."""
+    import random
+    from miden_vm_amd import protocol, precompile_airs as PA
+    rng = random.Random(5)
+    t0 = time.perf_counter()
+    scalars = [rng.getrandbits(256) % PA.K1_BOUND for _ in range(40)]
+    pairs, host, (results, (store, adds, muls, ec, ec_add)) = PA.ec_add_session(scalars)
+    gen_s = time.perf_counter() - t0
+    x_ptr, y_ptr = ec.point_params(results[0])[1]
+    airs_h = [p_[0] for p_ in pairs]
+    prm = dict(protocol.PROD_PARAMS)
+    root_pub = [91, 92, 93, 94]
+    dairs = [pkg.DeviceAir(ctx, a) for a in airs_h]
+    raw = ctx.upload_trace(airs_h[0].preprocessed)
+    com = pkg.commit_traces(ctx, [raw], prm["log_blowup"])
+    dairs[0].attach_preprocessed(com.tree(), 0, raw=raw)
+    for d, (_, lk) in zip(dairs, pairs):
+        d.attach_lookup(pkg.DeviceLookup(ctx, lk))
+    st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
+    pre = protocol.protocol_pre_observe(prm, root_pub, preprocessed_root=com.root())
+    traces = [ctx.upload_trace(t) for t in host]
+    proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    ok, _ = pkg.verify(airs_h, proof.log_trace_heights, root_pub, prm, st, pre, proof.fields, proof.commitments, preprocessed_root=com.root(),
+                       external=PA.external_assertions(pkg))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    dt = (time.perf_counter() - t0) / steps
+    for t in traces:
+        t.free()
+    n_adds = len(ec_add.ops)
+    return {"workload": "EC addition session in SessionTraces::mains order: BytePairLutAir (preprocessed), the uint store / multiplier's bus sides (12 + 1 EF aux), UintAddAir 30 + 3, EcGroupsAir, EcPointStoreAir 14 + 5, EcGroupAddAir 21 + 12 EF aux; production parameters, aux columns on the device",
+            "scalar_multiplications": len(scalars), "point_additions": n_adds, "modular_additions": len(adds.ops), "modular_macs": len(muls.ops),
+            "stored_points": len(ec.points), "log_trace_heights": proof.log_trace_heights, "ms_per_proof": dt * 1e3,
+            "point_additions_per_s": n_adds / dt, "proof_bytes": len(proof.bytes), "verifies_with_eval_external": bool(ok),
+            "first_multiple_x": hex(store.value(x_ptr)), "compiled_chunks": [a.compiled_chunks for a in dairs], "trace_generation_s": gen_s}
+
+
 def ec_store_session_probe(pkg, ctx, steps=3):
     """The second client's point store (precompiles-prover/src/ec: `EcPointStoreAir`, 14 columns, five flattened LogUp columns -- the
     EcPoint provide, the EcGroup and closure-certificate consumes, the curve-membership trio u = x^2 + a, w = x u + b, y^2 = w as three
@@ -1234,6 +1278,10 @@ def main():
             out["ec_store_session"] = ec_store_session_probe(pkg, ctx)
         except Exception as e:
             out["ec_store_session"] = {"error": repr(e)[:300]}
+        try:
+            out["ec_add_session"] = ec_add_session_probe(pkg, ctx)
+        except Exception as e:
+            out["ec_add_session"] = {"error": repr(e)[:300]}
         try:
             # the service-level probes run in a process of their own (tools/bench_inflight_h2d.py, no torch in it): measured in THIS
             # process, which also hosts PyTorch's HIP runtime, the same loops lose the copy / kernel overlap (k = 1 with its uploads

@@ -1954,18 +1954,42 @@ class EcRequire:
     """The part of `EcRequire` (ec/require.rs:28-120) that binds points: coordinates enter by value and are interned in the uint store,
     the membership trio is recorded in the MAC ledger (`UintRequire::mac` / `mac_into`, uint/require.rs:129-205)."""
 
-    def __init__(self, ec, store, muls):
-        self.ec, self.store, self.muls = ec, store, muls
+    def __init__(self, ec, store, muls, adds=None, ec_add=None):
+        self.ec, self.store, self.muls, self.adds, self.ec_add = ec, store, muls, adds, ec_add
 
-    def _mac(self, kappa_a, a, b, kappa_c, c, into=None):
+    def _mac(self, kappa_a, a, b, kappa_c, c, into=None, is_sub=False):
         bound = self.store.rows[a][1]
         assert self.store.rows[b][1] == bound and self.store.rows[c][1] == bound, "mac operands must share a modulus"
-        r_v = (kappa_a * self.store.value(a) * self.store.value(b) + kappa_c * self.store.value(c)) % (self.store.value(bound) + 1)
+        sign = -1 if is_sub else 1
+        r_v = (kappa_a * self.store.value(a) * self.store.value(b) + sign * kappa_c * self.store.value(c)) % (self.store.value(bound) + 1)
         if into is None:
             into = self.store.intern(r_v, bound)
-        assert self.store.rows[into] == (r_v, bound), "kappa_a a b + kappa_c c must reduce to the stored r"
-        self.muls.record(kappa_a, a, b, kappa_c, c, into, bound, 1)
+        assert self.store.rows[into] == (r_v, bound), "kappa_a a b +- kappa_c c must reduce to the stored r"
+        self.muls.record(kappa_a, a, b, kappa_c, c, into, bound, 1, is_sub=is_sub)
         return into
+
+    def _modulus(self, *ptrs):
+        bound = self.store.rows[ptrs[0]][1]
+        assert all(self.store.rows[p_][1] == bound for p_ in ptrs), "operands must share a modulus"
+        return bound, self.store.value(bound) + 1
+
+    def _uint_add(self, a, b):           # `UintRequire::add` (uint/require.rs:61-70)
+        bound, m = self._modulus(a, b)
+        c = self.store.intern((self.store.value(a) + self.store.value(b)) % m, bound)
+        self.adds.record(a, b, c, bound, 1)
+        return c
+
+    def _uint_sub(self, x, y, nonzero=False):       # `sub` / `sub_nonzero` (:72-96): z = x - y as the arrangement y + z = x
+        bound, m = self._modulus(x, y)
+        assert not nonzero or self.store.value(x) != self.store.value(y), "sub_nonzero requires x != y"
+        z = self.store.intern((self.store.value(x) - self.store.value(y)) % m, bound)
+        (self.adds.record_nz if nonzero else self.adds.record)(y, z, x, bound, 1)
+        return z
+
+    def _add_to_zero(self, a, b):        # `add_to_zero` (:107-115)
+        bound, m = self._modulus(a, b)
+        assert (self.store.value(a) + self.store.value(b)) % m == 0, "a + b must reduce to zero"
+        self.adds.record_to_zero(a, b, bound, 1)
 
     def create_group(self, a, b, bound):
         assert b != 0, "b = 0 puts (0, 0) on the curve"
@@ -2000,6 +2024,69 @@ class EcRequire:
         self.ec.require_ecpoint(pai)
         return pai
 
+    def add(self, p, q, mult):
+        """`EcRequire::add` / `add_inner` (ec/require.rs:138-243): the case by value, the certificates into the uint ledgers, the op into
+        the adder's; -> the result's pointer."""
+        group = self.ec.point_params(p)[0]
+        existing = self.ec_add.consume(group, p, q, mult)
+        if existing is not None:
+            return existing
+        a, b, bound = self.ec.group_params(group)
+        (p_group, p_coords), (q_group, q_coords) = self.ec.point_params(p), self.ec.point_params(q)
+        assert p_group == group and q_group == group, "add operands must belong to the group"
+        transients, mints = None, False
+        if p_coords is None and q_coords is None:
+            assert p == q, "PAI + PAI takes the canonical PAI twice"
+            case, r = "pai_both", p
+        elif p_coords is None:
+            case, r = "pai_p", q
+        elif q_coords is None:
+            case, r = "pai_q", p
+        else:
+            m = self.store.value(bound) + 1
+            (px, py), (qx, qy) = p_coords, q_coords
+            x1, y1, x2, y2 = (self.store.value(v) for v in (px, py, qx, qy))
+            if x1 != x2:                 # the chord: d = x2 - x1 certified nonzero, lambda d + y1 = y2
+                d = self._uint_sub(qx, px, nonzero=True)
+                lam = self.store.intern((y2 - y1) * pow(x2 - x1, m - 2, m) % m, bound)
+                self._mac(1, lam, d, 1, py, into=qy)
+                case, (transients, r, mints) = "generic", self._add_tail(d, lam, px, py, qx, group)
+            elif (y1 + y2) % m == 0:     # P + (-P), the 2-torsion doubling included: the negation tuple is the whole certificate
+                self._add_to_zero(py, qy)
+                case, r = "cancel", self.ec.group_pai(group)
+            else:                        # the tangent: s = 3 x^2 + a, 2 lambda y = s
+                assert y1 == y2, "on the curve x1 = x2 forces y2 = +-y1"
+                s_ptr = self._mac(3, px, px, 1, a)
+                lam = self.store.intern(self.store.value(s_ptr) * pow(2 * y1, m - 2, m) % m, bound)
+                self._mac(2, lam, py, 0, bound, into=s_ptr)
+                case, (transients, r, mints) = "double", self._add_tail(s_ptr, lam, px, py, qx, group)
+        self.ec_add.record(dict(case=case, group=group, bound=bound, a=a, b=b, p=p, q=q, r=r, p_coords=p_coords, q_coords=q_coords,
+                                transients=transients, mints=mints), mult)
+        return r
+
+    def _add_tail(self, slope_aux, lam, px, py, qx, group):
+        """`add_tail` (ec/require.rs:411-438): x3 = lambda^2 - x1 - x2, e = x1 - x3, y3 = lambda e - y1; a doubling folds t = 2 x1 into the
+        multiply-subtract.  A result the store does not hold yet is minted (closure certificate instead of a membership trio)."""
+        if px == qx:
+            t, x3 = 0, self._mac(1, lam, lam, 2, px, is_sub=True)
+        else:
+            t = self._uint_add(px, qx)
+            x3 = self._mac(1, lam, lam, 1, t, is_sub=True)
+        e = self._uint_sub(px, x3)
+        y3 = self._mac(1, lam, e, 1, py, is_sub=True)
+        r, mints = self.ec.add_point_cert(group, x3, y3)
+        return [slope_aux, lam, t, y3, e, x3], r, mints
+
+    def neg(self, p, mult):
+        """`EcRequire::neg` (ec/require.rs:381-401): -P interned by value, P + (-P) = PAI as a cancel block certifies the negation."""
+        group, (px, py) = self.ec.point_params(p)
+        bound = self.ec.group_params(group)[2]
+        neg_py = self.store.intern(-self.store.value(py) % (self.store.value(bound) + 1), bound)
+        r = self.add_point_at(group, px, neg_py)
+        pai = self.add(p, r, mult)
+        self.ec.require_ecpoint(pai)
+        return group, r, pai
+
 
 def ec_store_traces(ec, min_height=0):
     """`generate_traces` (ec/trace.rs:347-411) -> (the EcGroupsAir main, the EcPointStoreAir main): heights = the next powers of two, at
@@ -2018,6 +2105,172 @@ def ec_store_traces(ec, min_height=0):
         points[i] = [i + 1, group, a, bp, bound, ec.group_sbound(group), x, y, u, w, int(binding is None),
                      ec.point_demand.get(i + 1, 0) % P, 1, int(binding is not None and membership is None)]
     return groups, points
+
+
+# ---- EcGroupAdd: R = P + Q for any two stored points (ec/add/{mod,trace}.rs, ec/require.rs) ----------------------------------------------
+# One four-row block per addition: a near-one-hot over five cases (P at infinity, Q at infinity, cancel, double, generic) whose flags ride
+# the consumed `EcPoint` tuples as their `is_pai` fields, and every piece of field arithmetic as a pointer-level certificate consumed from
+# the uint relation chiplets -- the chord or tangent slope, x3 = lambda^2 - x1 - x2 and y3 = lambda (x1 - x3) - y1 as scaled
+# multiply-subtracts, d = x2 - x1 with its nonzero certificate, y1 + y2 = 0 for the cancel case; no coordinate limb enters this trace.  A
+# freshly computed result mints a closure certificate (`EcOnCurveCert`) for its point-store row, under a strict pointer ordering
+# r > p, r > q witnessed by Range16 limbs.  21 main columns, twelve flattened LogUp columns on seven buses, four periodic one-hots, lqd 1.
+BUS_EC_GROUP_ADD = 16                                                                                           # relations.rs:52-80
+EA_COLS, EA_AUX_COLS, EA_PERIOD, EA_NUM_CELLS = 21, 12, 4, 3                                                    # ec/add/mod.rs:187-229
+(EA_COL_PX, EA_COL_PY, EA_COL_QX, EA_COL_QY, EA_COL_A_PTR, EA_COL_B_PTR, EA_COL_BOUND_PTR, EA_COL_PAI_P, EA_COL_PAI_Q, EA_COL_CANCEL,
+ EA_COL_DBL, EA_COL_GEN, EA_COL_ACT, EA_COL_MINTS, EA_COL_RP_LO, EA_COL_RP_HI, EA_COL_RQ_LO, EA_COL_RQ_HI) = range(3, 21)
+EA_ROW_SLOPE, EA_ROW_TAIL, EA_ROW_RES, EA_ROW_TERM = 0, 1, 2, 3
+EA_CELL_SLOPE_AUX, EA_CELL_LAMBDA, EA_CELL_T = 0, 1, 2                  # slope row
+EA_CELL_Y3, EA_CELL_E, EA_CELL_X3 = 0, 1, 2                             # tail row
+EA_CELL_R, EA_CELL_SBOUND, EA_CELL_GROUP = 0, 1, 2                      # res row
+EA_TERM_CELL_MULT, EA_TERM_CELL_P, EA_TERM_CELL_Q = 0, 1, 2             # term row
+
+
+def ec_group_add_air(host_aux=None):
+    """`EcGroupAddAir::eval` (ec/add/mod.rs:283-398) and its `LookupAir::eval` (:423-847): col 0 the EcGroupAdd provide | 1 the operands'
+    EcPoint consumes | 2 the result's (live / the PAI row of a cancel) | 3 the EcGroup consume + cancel's y1 + y2 = 0 | 4 generic: d, the
+    chord | 5 double: the tangent numerator, the slope pin | 6 generic: t, x3 | 7 e, y3 | 8 double: x3 | 9, 10 the ordering limbs | 11 the
+    closure-certificate provide."""
+    b = dag.AirBuilder(EA_COLS, aux_width=EA_AUX_COLS, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
+                       num_public=NUM_PUBLIC_VALUES, periodic=[[int(r == role) for r in range(EA_PERIOD)] for role in range(EA_PERIOD)])
+    loc, nxt = [b.main(c) for c in range(EA_COLS)], [b.main(c, 1) for c in range(EA_COLS)]
+    one = b.const(1)
+    sel = [b.periodic_value(i) for i in range(EA_PERIOD)]
+    pai_p, pai_q, cancel, dbl, generic = (loc[c] for c in (EA_COL_PAI_P, EA_COL_PAI_Q, EA_COL_CANCEL, EA_COL_DBL, EA_COL_GEN))
+    act, mints = loc[EA_COL_ACT], loc[EA_COL_MINTS]
+    for flag in (pai_p, pai_q, cancel, dbl, generic, act, mints):
+        b.assert_zero(flag * (one - flag))
+    b.assert_zero(pai_p + pai_q + cancel + dbl + generic - act - pai_p * pai_q)          # one case per live block; both pass flags at PAI + PAI
+    b.assert_zero((cancel + dbl) * (loc[EA_COL_PX] - loc[EA_COL_QX]))                     # x1 = x2: pointer equality is value equality
+    b.assert_zero(dbl * (loc[EA_COL_PY] - loc[EA_COL_QY]))
+    r_cell, p_cell, q_cell = loc[EA_CELL_R], nxt[EA_TERM_CELL_P], nxt[EA_TERM_CELL_Q]
+    b.assert_zero(sel[EA_ROW_RES] * pai_p * (r_cell - q_cell))                            # the pass-through ties
+    b.assert_zero(sel[EA_ROW_RES] * pai_q * (r_cell - p_cell))
+    b.assert_zero(mints * (one - dbl - generic))                                          # only a fresh result mints
+    two16 = b.const(1 << 16)
+    b.assert_zero(sel[EA_ROW_RES] * mints * (r_cell - p_cell - one - loc[EA_COL_RP_LO] - two16 * loc[EA_COL_RP_HI]))
+    b.assert_zero(sel[EA_ROW_RES] * mints * (r_cell - q_cell - one - loc[EA_COL_RQ_LO] - two16 * loc[EA_COL_RQ_HI]))
+    not_term = one - sel[EA_ROW_TERM]
+    for col in range(EA_COL_PX, EA_COLS):
+        b.assert_zero(not_term * (nxt[col] - loc[col]))
+
+    lk = dag.LogUp(b, MAX_MESSAGE_WIDTH, NUM_BUS_IDS, closing="sigma_last_row")
+
+    def win(ch):
+        bb = lk.b if ch is lk.ch_c else lk.lb
+        return bb, [bb.main(c) for c in range(EA_COLS)], [bb.main(c, 1) for c in range(EA_COLS)]
+
+    def message(bus, fields):            # fields: callables (bb, local, next) -> expression, or plain integers
+        def msg(ch):
+            bb, lo, nx = win(ch)
+            return ch.encode(bus, [bb.const(f) if isinstance(f, int) else f(bb, lo, nx) for f in fields])
+        return msg
+    L = lambda c: (lambda bb, lo, nx: lo[c])                                              # noqa: E731
+    N = lambda c: (lambda bb, lo, nx: nx[c])                                              # noqa: E731
+    px, py, qx, qy, a_ptr, bound = L(EA_COL_PX), L(EA_COL_PY), L(EA_COL_QX), L(EA_COL_QY), L(EA_COL_A_PTR), L(EA_COL_BOUND_PTR)
+    slope_aux, lam, t = L(EA_CELL_SLOPE_AUX), L(EA_CELL_LAMBDA), L(EA_CELL_T)
+    e, x3_next, y3_next = N(EA_CELL_E), N(EA_CELL_X3), N(EA_CELL_Y3)
+    group_local, r_local, p_ptr, q_ptr = L(EA_CELL_GROUP), L(EA_CELL_R), N(EA_TERM_CELL_P), N(EA_TERM_CELL_Q)
+
+    def uint_add(a, bb_, c, nz):         # UintAddMsg (uint/add/mod.rs:116-141)
+        return message(BUS_UINT_ADD, [bound, a, bb_, c, nz])
+
+    def uint_mul(ka, kc, a, bb_, c, r, is_sub):     # UintMulMsg (uint/mul/mod.rs:136-170)
+        return message(BUS_UINT_MUL, [ka, kc, a, bb_, c, r, bound, is_sub])
+
+    def ec_point(ptr, group, x, y, is_pai):         # EcPointMsg (ec/mod.rs:71-99)
+        return message(BUS_EC_POINT, [ptr, group, x, y, is_pai])
+
+    def mults(fn):
+        return fn(lk.b), fn(lk.lb)
+
+    def gate(row, cols, neg=False):      # (sum of the flag columns) * the row's one-hot
+        def fn(bb):
+            acc = bb.main(cols[0])
+            for c in cols[1:]:
+                acc = acc + bb.main(c)
+            acc = acc * bb.periodic_value(row)
+            return bb.const(0) - acc if neg else acc
+        return mults(fn)
+    at_res_act = gate(EA_ROW_RES, [EA_COL_ACT])
+    at_slope_gen, at_slope_dbl = gate(EA_ROW_SLOPE, [EA_COL_GEN]), gate(EA_ROW_SLOPE, [EA_COL_DBL])
+    at_slope_tail = gate(EA_ROW_SLOPE, [EA_COL_DBL, EA_COL_GEN])
+    at_res_cancel = gate(EA_ROW_RES, [EA_COL_CANCEL])
+    at_res_mints = mults(lambda bb: bb.periodic_value(EA_ROW_RES) * bb.main(EA_COL_MINTS))
+    neg_res_mints = mults(lambda bb: bb.const(0) - bb.periodic_value(EA_ROW_RES) * bb.main(EA_COL_MINTS))
+    provide = mults(lambda bb: (bb.const(0) - bb.main(EA_TERM_CELL_MULT, 1)) * bb.periodic_value(EA_ROW_RES))
+    range16 = lambda c: message(BUS_RANGE16, [L(c)])                                      # noqa: E731
+    _emit_frac_cols(lk, [
+        [(provide, message(BUS_EC_GROUP_ADD, [group_local, p_ptr, q_ptr, r_local]))],
+        [(at_res_act, ec_point(p_ptr, group_local, px, py, L(EA_COL_PAI_P))), (at_res_act, ec_point(q_ptr, group_local, qx, qy, L(EA_COL_PAI_Q)))],
+        [(gate(EA_ROW_TAIL, [EA_COL_DBL, EA_COL_GEN]), ec_point(N(EA_CELL_R), N(EA_CELL_GROUP), L(EA_CELL_X3), L(EA_CELL_Y3), 0)),
+         (at_res_cancel, ec_point(r_local, group_local, 0, 0, 1))],
+        [(gate(EA_ROW_RES, [EA_COL_CANCEL, EA_COL_DBL, EA_COL_GEN]),
+          message(BUS_EC_GROUP, [group_local, a_ptr, L(EA_COL_B_PTR), bound, L(EA_CELL_SBOUND)])),
+         (at_res_cancel, uint_add(py, qy, 0, 0))],
+        [(at_slope_gen, uint_add(px, slope_aux, qx, 1)), (at_slope_gen, uint_mul(1, 1, lam, slope_aux, py, qy, 0))],
+        [(at_slope_dbl, uint_mul(3, 1, px, px, a_ptr, slope_aux, 0)), (at_slope_dbl, uint_mul(2, 0, lam, py, bound, slope_aux, 0))],
+        [(at_slope_gen, uint_add(px, qx, t, 0)), (at_slope_gen, uint_mul(1, 1, lam, lam, t, x3_next, 1))],
+        [(at_slope_tail, uint_add(x3_next, e, px, 0)), (at_slope_tail, uint_mul(1, 1, lam, e, py, y3_next, 1))],
+        [(at_slope_dbl, uint_mul(1, 2, lam, lam, px, x3_next, 1))],
+        [(at_res_mints, range16(EA_COL_RP_LO)), (at_res_mints, range16(EA_COL_RP_HI))],
+        [(at_res_mints, range16(EA_COL_RQ_LO)), (at_res_mints, range16(EA_COL_RQ_HI))],
+        [(neg_res_mints, message(BUS_EC_ON_CURVE_CERT, [group_local, r_local]))]])
+    lookup = lk.finish("ec_group_add")
+    return dag.Air(b, _host_aux(lookup, host_aux), "ec_group_add"), lookup
+
+
+class EcAddRequires:
+    """`EcAddRequires` (ec/add/trace.rs:71-103): the recorded additions, one per (group, p, q); a repeat adds to the multiplicity of the
+    relation's provide.  An op = dict(case, group, bound, a, b, p, q, r, p_coords, q_coords, transients, mints)."""
+    CASE_FLAGS = {"pai_p": (1, 0, 0, 0, 0), "pai_q": (0, 1, 0, 0, 0), "pai_both": (1, 1, 0, 0, 0), "cancel": (0, 0, 1, 0, 0),
+                  "double": (0, 0, 0, 1, 0), "generic": (0, 0, 0, 0, 1)}
+
+    def __init__(self):
+        self.ops, self.dedup = [], {}
+
+    def consume(self, group, p, q, mult):
+        i = self.dedup.get((group, p, q))
+        if i is None:
+            return None
+        self.ops[i][1] += mult
+        return self.ops[i][0]["r"]
+
+    def record(self, op, mult):
+        self.dedup[(op["group"], op["p"], op["q"])] = len(self.ops)
+        self.ops.append([op, mult])
+
+    def consumer_requests(self):
+        """The readers of the relations (the MSM ladder, the eval chip: not ported) -> [(BUS_EC_GROUP_ADD, multiplicity, [group, p, q, r])]"""
+        return [(BUS_EC_GROUP_ADD, mult, [op["group"], op["p"], op["q"], op["r"]]) for op, mult in self.ops if mult]
+
+
+def ec_group_add_trace(requires, ec, bpl, min_height=0):
+    """`generate_trace` / `op_block` (ec/add/trace.rs:105-237): one four-row block per op, all-zero blocks after; routes the demand of its
+    consumes -- the operands' and the result's `EcPoint`, the live cases' `EcGroup`, the ordering limbs' Range16 -- into the ledgers, so it
+    runs BEFORE the EC stores' and the table's traces are laid."""
+    height = max(min_height, 1 << (max(1, len(requires.ops)) * EA_PERIOD - 1).bit_length())
+    t = np.zeros((height, EA_COLS), dtype=np.uint64)
+    for i, (op, mult) in enumerate(requires.ops):
+        ec.require_ecpoint(op["p"])
+        ec.require_ecpoint(op["q"])
+        flags = EcAddRequires.CASE_FLAGS[op["case"]]
+        if any(flags[2:]):
+            ec.require_ecgroup(op["group"])
+            ec.require_ecpoint(op["r"])
+        rp = rq = 0
+        if op["mints"]:
+            rp, rq = op["r"] - op["p"] - 1, op["r"] - op["q"] - 1
+            for w in (rp & 0xffff, rp >> 16, rq & 0xffff, rq >> 16):
+                bpl.require_range16(w)
+        r0 = EA_PERIOD * i
+        transients = op["transients"] or [0] * 6
+        t[r0 + EA_ROW_SLOPE, 0:3], t[r0 + EA_ROW_TAIL, 0:3] = transients[0:3], transients[3:6]
+        t[r0 + EA_ROW_RES, 0:3] = [op["r"], ec.group_sbound(op["group"]), op["group"]]
+        t[r0 + EA_ROW_TERM, 0:3] = [mult % P, op["p"], op["q"]]
+        (pxv, pyv), (qxv, qyv) = op["p_coords"] or (0, 0), op["q_coords"] or (0, 0)
+        t[r0:r0 + EA_PERIOD, EA_COL_PX:EA_COLS] = [pxv, pyv, qxv, qyv, op["a"], op["b"], op["bound"], *flags, 1, int(op["mints"]),
+                                                   rp & 0xffff, rp >> 16, rq & 0xffff, rq >> 16]
+    return t
 
 
 K1_BOUND = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2E                                    # secp256k1: p - 1
@@ -2054,3 +2307,32 @@ def ec_store_session(n_points, host_aux=None, min_height=8):
     foreign = muls.uint_mul_requests() + ec.ec_point_requests() + ec.cert_requests()
     pairs = [ec_point_store_air(host_aux), ec_groups_air(host_aux), requirer_air(host_aux, payload=10)]
     return pairs, [points, groups, requirer_trace(foreign, payload=10)], (store, muls, ec)
+
+
+def ec_add_session(scalars, host_aux=None, min_height=8):
+    """The reference's "arithmetic + EC stack" (tests/ec_add.rs, `SessionTraces::mains` order) on a workload: k G for every k of `scalars`
+    by double-and-add over secp256k1, every addition a proven `EcGroupAdd` relation with one reader -- doubles, chords, pass-throughs from
+    the point at infinity, results minted with closure certificates or deduplicated onto stored rows.  [BytePairLutAir (preprocessed),
+    the uint store / multiplier's sides of UintVal and UintMul + the relations' readers, UintAddAir, EcGroupsAir, EcPointStoreAir,
+    EcGroupAddAir].  -> ([(air, lookup)], [traces], (results, ledgers))"""
+    store, adds, muls, ec, ec_add, bpl = UintStore(), UintAddRequires(), UintMulRequires(), EcStore(), EcAddRequires(), BytePairLutRequires()
+    fp = store.pin_modulus(1, K1_BOUND)
+    req = EcRequire(ec, store, muls, adds, ec_add)
+    group, pai = req.create_group(0, 7, fp)
+    g_pt = req.add_point(group, *K1_G)
+    results = []
+    for k in scalars:
+        acc = pai
+        for bit in bin(k)[2:]:
+            acc = req.add(acc, acc, 1)
+            if bit == "1":
+                acc = req.add(acc, g_pt, 1)
+        results.append(acc)
+    ec.require_fixed_groups()
+    add = uint_add_trace(adds, store, min_height=min_height)
+    ec_add_main = ec_group_add_trace(ec_add, ec, bpl, min_height=min_height)
+    foreign = requirer_trace(store.uint_val_requests() + muls.uint_mul_requests() + ec_add.consumer_requests(), payload=10)
+    groups, points = ec_store_traces(ec, min_height=min_height)
+    pairs = [byte_pair_lut_air(host_aux), requirer_air(host_aux, payload=10), uint_add_air(host_aux), ec_groups_air(host_aux),
+             ec_point_store_air(host_aux), ec_group_add_air(host_aux)]
+    return pairs, [byte_pair_lut_trace(bpl), foreign, add, groups, points, ec_add_main], (results, (store, adds, muls, ec, ec_add))

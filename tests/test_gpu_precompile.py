@@ -559,3 +559,51 @@ def test_ec_store_session_production_params(ctx):
     assert ok, msg
     ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, external=PA.external_assertions(pkg))
     assert ok2 and (dig == got.digest).all()
+
+
+def ec_add_session(scalars):
+    """The reference's arithmetic + EC stack (tests/ec_add.rs) in its order: [BytePairLutAir (preprocessed), the uint store / multiplier's
+    bus sides, UintAddAir, EcGroupsAir, EcPointStoreAir, EcGroupAddAir (21 columns, twelve flattened LogUp columns on seven buses)]."""
+    pairs, traces, _ = PA.ec_add_session(scalars, host_aux)
+    return [p[0] for p in pairs], [p[1] for p in pairs], traces
+
+
+@pytest.mark.parametrize("jit", ["0", "1"])
+def test_ec_add_session_device_proof_equals_oracle(ctx, jit, monkeypatch):
+    pkg = load_package()
+    monkeypatch.setenv("MH_JIT", jit)
+    airs_, lookups, traces = ec_add_session([0xb5, 77, 0xb5, 1, 2, 3])
+    exp = ob.prove(airs_, traces, ROOT, FAST, init_state=protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST))
+    got, root, st, pre = device_prove(ctx, airs_, lookups, traces, FAST)
+    assert list(root) == [int(x) for x in exp["preprocessed_root"]]
+    assert (got.commitments == exp["commitments"]).all()
+    assert got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all()
+    assert (got.digest == exp["digest"]).all()
+    ok, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, FAST, st, pre, got.fields, got.commitments, preprocessed_root=root,
+                         external=PA.external_assertions(pkg))
+    assert ok and (dig == got.digest).all()
+    forged = traces[5].copy()
+    forged[0:4, PA.EA_COL_MINTS] = 0
+    forged[PA.EA_ROW_RES, PA.EA_CELL_R] = 2                             # the first block's result repointed at G: no valid proof
+    bad, root, st, pre = device_prove(ctx, airs_, lookups, traces[:5] + [forged], FAST)
+    ok, _ = pkg.verify(airs_, bad.log_trace_heights, ROOT, FAST, st, pre, bad.fields, bad.commitments, preprocessed_root=root,
+                       external=PA.external_assertions(pkg))
+    assert not ok
+
+
+def test_ec_add_session_production_params(ctx):
+    """64 scalar multiples by double-and-add (64-bit scalars: ~6 000 proven point additions), production parameters: verify-only through
+    both verifiers."""
+    import random
+    pkg = load_package()
+    rng = random.Random(5)
+    airs_, lookups, traces = ec_add_session([rng.getrandbits(64) | 1 << 63 for _ in range(64)])
+    prm = dict(protocol.PROD_PARAMS)
+    got, root, st, pre = device_prove(ctx, airs_, lookups, traces, prm)
+    assert got.log_trace_heights[0] == 16 and got.log_trace_heights[5] >= 14
+    ok, msg = ob.verify(airs_, got.log_trace_heights, ROOT, {"fields": got.fields, "commitments": got.commitments}, prm,
+                        init_state=st, pre_observe=pre, external=PA.external_assertions(pkg))
+    assert ok, msg
+    ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, preprocessed_root=root,
+                          external=PA.external_assertions(pkg))
+    assert ok2 and (dig == got.digest).all()
