@@ -1,8 +1,9 @@
 """The second client of the backend: AIRs of the precompile prover (`precompiles-prover/src`), hand-ported against `dag.AirBuilder`
 like the VM's three AIRs, and the statement layer of its session (`precompiles-prover/src/session/prove.rs`).
 
-What is here: seven of the twelve AIRs of `ChipletAir::all()` (session/prove.rs:111-126) -- the whole HASHING HALF of the
-session (ChunkNode, Poseidon2, KeccakRound, BytePairLut, KeccakSponge; ChunkNode also as its two stand-alone halves), EcGroups, and UintAdd --
+What is here: nine of the twelve AIRs of `ChipletAir::all()` (session/prove.rs:111-126) -- the whole HASHING HALF of the
+session (ChunkNode, Poseidon2, KeccakRound, BytePairLut, KeccakSponge; ChunkNode also as its two stand-alone halves), UintAdd, and the
+elliptic-curve stores and group law (EcGroups, EcPointStore, EcGroupAdd) --
 * `BytePairLutAir` (`primitives/byte_pair_lut.rs`): the one AIR of the stack with PREPROCESSED columns and a fixed height -- the
   2^16-row `(a, b, !a & b, a ^ b)` table committed once, three witness multiplicity columns, two LogUp columns;
 * `KeccakRoundAir` (`hash/keccak/round/{mod,program}.rs`): its consumer -- a three-address machine `c = ROL(a OP b, s)` whose 128-slot
@@ -28,14 +29,25 @@ session (ChunkNode, Poseidon2, KeccakRound, BytePairLut, KeccakSponge; ChunkNode
 * `UintAddAir` (`uint/add/{mod,trace}.rs`): a + b = c (mod p) over stored 256-bit values -- a "vertical Schwartz-Zippel" identity at the
   LogUp challenge beta: the one MAIN constraint of this stack over the extension field that reads a verifier challenge; ternary carries,
   zero-sentinel modes (negation, equality certificate), a nonzero certificate; 30 columns, three LogUp columns, period 2;
+* `EcPointStoreAir` (`ec/{mod,trace,require}.rs`): one row per curve point -- its group's five-tuple pulled from `EcGroupsAir`, the
+  pointers of x and y, and the membership certificate u = x^2 + a, w = x u + b, y^2 = w as three consumed `UintMul` relations (or the
+  point-at-infinity flag, or a closure certificate from the adder); 14 columns, five LogUp columns;
+* `EcGroupAddAir` (`ec/add/{mod,trace}.rs`, `ec/require.rs`): R = P + Q for ANY two stored points -- a near-one-hot over five cases whose
+  flags ride the consumed `EcPoint` tuples, chord / tangent / tail arithmetic as pointer-level certificates consumed from the uint
+  relation chiplets (no limb enters the trace), fresh results minted with closure certificates under a Range16-witnessed pointer
+  ordering; 21 columns, twelve LogUp columns on seven buses, four-row blocks.  With it the reference's "arithmetic + EC stack" runs over
+  FIVE real chiplets (BytePairLut, UintAdd, EcGroups, EcPointStore, EcGroupAdd): scalar multiples of a curve point, proven;
 the precompile prover's LogUp adapter (natural last-row sigma closing, `logup/constraint.rs`: `dag.LogUp(closing="sigma_last_row")`),
 its bus registry (`relations.rs`) and `ChipletMultiAir::eval_external` (`session/prove.rs:259-272`: sum of the committed sigmas + the
 fixed boundary correction).
 
-What is not: the other five AIRs (TranscriptEval, the uint store / multiplier, the EC point store / adder / MSM: ~14 kLoC of the
-reference).  Where a statement needs the other side of a bus that only they touch -- the transcript's readers of the `Binding` tuples in
+What is not: the other three AIRs (TranscriptEval, the uint store / multiplier, the MSM ladder: ~9 kLoC of the reference).  UintStoreMul
+is also the one AIR of the session whose aux trace holds more than LogUp columns (three extension-field REGISTERS, Horner accumulators at
+the challenge beta): the device aux builder (`logup.hip`) builds LogUp columns only, such an AIR would go through the host callback
+(`mh_aux_builder`) as in the reference, where `build_aux_trace` is CPU code.  Where a statement needs the other side of a bus that only they touch -- the transcript's readers of the `Binding` tuples in
 the hashing session, or, in the smaller sessions of the tests, whatever is left out (`sponge_side_requests`, `chunk_side_requests`,
-`keccak_hash_side_requests`, `poseidon2_out_requests`, `binding_requests`) -- it comes from `requirer_air`, a one-interaction-per-row
+`keccak_hash_side_requests`, `poseidon2_out_requests`, `binding_requests`, the uint store's `uint_val_requests` and the multiplier's
+`uint_mul_requests` -- relations the ledgers check by value when they are recorded) -- it comes from `requirer_air`, a one-interaction-per-row
 stand-in written against the same adapter; `eval_external` sums the `EcGroup` part of `fixed_boundary_correction` only (the `UintVal`
 part belongs to the uint store).  Pinned: the reference's own unit tests of every ported chiplet replayed (tests/test_precompile_*.py:
 programs, layouts, quotient degrees, message encodings, accepting and corrupted traces), FIPS 202 (the round machine against a plain
@@ -1777,13 +1789,13 @@ def uint_add_consumer_requests(requires):
 # (`is_cert`: a sum of two points of the curve is on the curve).  Provides `EcPoint(ptr, group, x_ptr, y_ptr, is_pai)` to its readers.
 # 14 main columns, five LogUp columns, lqd 1.
 BUS_UINT_MUL, BUS_EC_POINT, BUS_EC_ON_CURVE_CERT = 12, 15, 17                                                   # relations.rs:52-80
-EP_COLS, EP_AUX_COLS = 14, 5                                                                                    # ec/mod.rs:104-123
+EP_COLS, EP_AUX_COLS = 14, 5                                                                                    # ec/mod.rs:153-197
 (EP_COL_PTR, EP_COL_GROUP_PTR, EP_COL_A_PTR, EP_COL_B_PTR, EP_COL_BOUND_PTR, EP_COL_SBOUND_PTR, EP_COL_X_PTR, EP_COL_Y_PTR, EP_COL_U_PTR,
  EP_COL_W_PTR, EP_COL_IS_PAI, EP_COL_ECPOINT_MULT, EP_COL_ACT, EP_COL_IS_CERT) = range(14)
 
 
 def ec_point_store_air(host_aux=None):
-    """`EcPointStoreAir::eval` (ec/mod.rs:160-204) and its `LookupAir::eval` (:232-384): col 0 the EcPoint provide | col 1 the EcGroup
+    """`EcPointStoreAir::eval` (ec/mod.rs:238-290) and its `LookupAir::eval` (:316-463): col 0 the EcPoint provide | col 1 the EcGroup
     consume + the closure-certificate consume | cols 2-4 the membership trio u, w, y (one degree-3 multiplicity each)."""
     b = dag.AirBuilder(EP_COLS, aux_width=EP_AUX_COLS, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
                        num_public=NUM_PUBLIC_VALUES)
@@ -1810,11 +1822,11 @@ def ec_point_store_air(host_aux=None):
         bb = lk.b if ch is lk.ch_c else lk.lb
         return bb, [bb.main(c) for c in range(EP_COLS)]
 
-    def ec_point(ch):                    # EcPointMsg (ec/mod.rs:71-99)
+    def ec_point(ch):                    # EcPointMsg (ec/mod.rs:122-148)
         _, r = row(ch)
         return ch.encode(BUS_EC_POINT, [r[EP_COL_PTR], r[EP_COL_GROUP_PTR], r[EP_COL_X_PTR], r[EP_COL_Y_PTR], r[EP_COL_IS_PAI]])
 
-    def ec_group(ch):                    # EcGroupMsg (ec/mod.rs:36-64)
+    def ec_group(ch):                    # EcGroupMsg (ec/mod.rs:90-116)
         _, r = row(ch)
         return ch.encode(BUS_EC_GROUP, [r[EP_COL_GROUP_PTR], r[EP_COL_A_PTR], r[EP_COL_B_PTR], r[EP_COL_BOUND_PTR], r[EP_COL_SBOUND_PTR]])
 
@@ -1844,7 +1856,7 @@ def ec_point_store_air(host_aux=None):
 
 
 class UintMulRequires:
-    """The ledger of `UintMulRequires::record` / `record_sub` (uint/mul/trace.rs): scaled multiply-accumulates
+    """The ledger of `UintMulRequires::record` / `record_sub` (uint/mul/trace.rs:191-245): scaled multiply-accumulates
     kappa_a a b +- kappa_c c = r (mod bound + 1) over store pointers, deduplicated, multiplicities summed.  The chiplet that proves them
     (UintStoreMul) is not ported: `uint_mul_requests` is what it puts on the UintMul bus."""
 
@@ -1951,8 +1963,8 @@ class EcStore:
 
 
 class EcRequire:
-    """The part of `EcRequire` (ec/require.rs:28-120) that binds points: coordinates enter by value and are interned in the uint store,
-    the membership trio is recorded in the MAC ledger (`UintRequire::mac` / `mac_into`, uint/require.rs:129-205)."""
+    """`EcRequire` (ec/require.rs:24-449): coordinates enter by value and are interned in the uint store,
+    the membership trio is recorded in the MAC ledger (`UintRequire::mac` / `mac_sub` / `mac_into`, uint/require.rs:152-230), the group law's certificates in both uint ledgers."""
 
     def __init__(self, ec, store, muls, adds=None, ec_add=None):
         self.ec, self.store, self.muls, self.adds, self.ec_add = ec, store, muls, adds, ec_add
@@ -1973,20 +1985,20 @@ class EcRequire:
         assert all(self.store.rows[p_][1] == bound for p_ in ptrs), "operands must share a modulus"
         return bound, self.store.value(bound) + 1
 
-    def _uint_add(self, a, b):           # `UintRequire::add` (uint/require.rs:61-70)
+    def _uint_add(self, a, b):           # `UintRequire::add` (uint/require.rs:68-79)
         bound, m = self._modulus(a, b)
         c = self.store.intern((self.store.value(a) + self.store.value(b)) % m, bound)
         self.adds.record(a, b, c, bound, 1)
         return c
 
-    def _uint_sub(self, x, y, nonzero=False):       # `sub` / `sub_nonzero` (:72-96): z = x - y as the arrangement y + z = x
+    def _uint_sub(self, x, y, nonzero=False):       # `sub` / `sub_nonzero` (:81-109): z = x - y as the arrangement y + z = x
         bound, m = self._modulus(x, y)
         assert not nonzero or self.store.value(x) != self.store.value(y), "sub_nonzero requires x != y"
         z = self.store.intern((self.store.value(x) - self.store.value(y)) % m, bound)
         (self.adds.record_nz if nonzero else self.adds.record)(y, z, x, bound, 1)
         return z
 
-    def _add_to_zero(self, a, b):        # `add_to_zero` (:107-115)
+    def _add_to_zero(self, a, b):        # `add_to_zero` (:122-133)
         bound, m = self._modulus(a, b)
         assert (self.store.value(a) + self.store.value(b)) % m == 0, "a + b must reduce to zero"
         self.adds.record_to_zero(a, b, bound, 1)
@@ -2025,7 +2037,7 @@ class EcRequire:
         return pai
 
     def add(self, p, q, mult):
-        """`EcRequire::add` / `add_inner` (ec/require.rs:138-243): the case by value, the certificates into the uint ledgers, the op into
+        """`EcRequire::add` / `add_inner` (ec/require.rs:185-298): the case by value, the certificates into the uint ledgers, the op into
         the adder's; -> the result's pointer."""
         group = self.ec.point_params(p)[0]
         existing = self.ec_add.consume(group, p, q, mult)
@@ -2065,7 +2077,7 @@ class EcRequire:
         return r
 
     def _add_tail(self, slope_aux, lam, px, py, qx, group):
-        """`add_tail` (ec/require.rs:411-438): x3 = lambda^2 - x1 - x2, e = x1 - x3, y3 = lambda e - y1; a doubling folds t = 2 x1 into the
+        """`add_tail` (ec/require.rs:422-449): x3 = lambda^2 - x1 - x2, e = x1 - x3, y3 = lambda e - y1; a doubling folds t = 2 x1 into the
         multiply-subtract.  A result the store does not hold yet is minted (closure certificate instead of a membership trio)."""
         if px == qx:
             t, x3 = 0, self._mac(1, lam, lam, 2, px, is_sub=True)
@@ -2078,7 +2090,7 @@ class EcRequire:
         return [slope_aux, lam, t, y3, e, x3], r, mints
 
     def neg(self, p, mult):
-        """`EcRequire::neg` (ec/require.rs:381-401): -P interned by value, P + (-P) = PAI as a cancel block certifies the negation."""
+        """`EcRequire::neg` (ec/require.rs:387-410): -P interned by value, P + (-P) = PAI as a cancel block certifies the negation."""
         group, (px, py) = self.ec.point_params(p)
         bound = self.ec.group_params(group)[2]
         neg_py = self.store.intern(-self.store.value(py) % (self.store.value(bound) + 1), bound)
@@ -2115,7 +2127,7 @@ def ec_store_traces(ec, min_height=0):
 # freshly computed result mints a closure certificate (`EcOnCurveCert`) for its point-store row, under a strict pointer ordering
 # r > p, r > q witnessed by Range16 limbs.  21 main columns, twelve flattened LogUp columns on seven buses, four periodic one-hots, lqd 1.
 BUS_EC_GROUP_ADD = 16                                                                                           # relations.rs:52-80
-EA_COLS, EA_AUX_COLS, EA_PERIOD, EA_NUM_CELLS = 21, 12, 4, 3                                                    # ec/add/mod.rs:187-229
+EA_COLS, EA_AUX_COLS, EA_PERIOD, EA_NUM_CELLS = 21, 12, 4, 3                                                    # ec/add/mod.rs:190-277
 (EA_COL_PX, EA_COL_PY, EA_COL_QX, EA_COL_QY, EA_COL_A_PTR, EA_COL_B_PTR, EA_COL_BOUND_PTR, EA_COL_PAI_P, EA_COL_PAI_Q, EA_COL_CANCEL,
  EA_COL_DBL, EA_COL_GEN, EA_COL_ACT, EA_COL_MINTS, EA_COL_RP_LO, EA_COL_RP_HI, EA_COL_RQ_LO, EA_COL_RQ_HI) = range(3, 21)
 EA_ROW_SLOPE, EA_ROW_TAIL, EA_ROW_RES, EA_ROW_TERM = 0, 1, 2, 3
@@ -2126,7 +2138,7 @@ EA_TERM_CELL_MULT, EA_TERM_CELL_P, EA_TERM_CELL_Q = 0, 1, 2             # term r
 
 
 def ec_group_add_air(host_aux=None):
-    """`EcGroupAddAir::eval` (ec/add/mod.rs:283-398) and its `LookupAir::eval` (:423-847): col 0 the EcGroupAdd provide | 1 the operands'
+    """`EcGroupAddAir::eval` (ec/add/mod.rs:329-429) and its `LookupAir::eval` (:455-847): col 0 the EcGroupAdd provide | 1 the operands'
     EcPoint consumes | 2 the result's (live / the PAI row of a cancel) | 3 the EcGroup consume + cancel's y1 + y2 = 0 | 4 generic: d, the
     chord | 5 double: the tangent numerator, the slope pin | 6 generic: t, x3 | 7 e, y3 | 8 double: x3 | 9, 10 the ordering limbs | 11 the
     closure-certificate provide."""
@@ -2177,7 +2189,7 @@ def ec_group_add_air(host_aux=None):
     def uint_mul(ka, kc, a, bb_, c, r, is_sub):     # UintMulMsg (uint/mul/mod.rs:136-170)
         return message(BUS_UINT_MUL, [ka, kc, a, bb_, c, r, bound, is_sub])
 
-    def ec_point(ptr, group, x, y, is_pai):         # EcPointMsg (ec/mod.rs:71-99)
+    def ec_point(ptr, group, x, y, is_pai):         # EcPointMsg (ec/mod.rs:122-148)
         return message(BUS_EC_POINT, [ptr, group, x, y, is_pai])
 
     def mults(fn):
@@ -2220,7 +2232,7 @@ def ec_group_add_air(host_aux=None):
 
 
 class EcAddRequires:
-    """`EcAddRequires` (ec/add/trace.rs:71-103): the recorded additions, one per (group, p, q); a repeat adds to the multiplicity of the
+    """`EcAddRequires` (ec/add/trace.rs:106-142): the recorded additions, one per (group, p, q); a repeat adds to the multiplicity of the
     relation's provide.  An op = dict(case, group, bound, a, b, p, q, r, p_coords, q_coords, transients, mints)."""
     CASE_FLAGS = {"pai_p": (1, 0, 0, 0, 0), "pai_q": (0, 1, 0, 0, 0), "pai_both": (1, 1, 0, 0, 0), "cancel": (0, 0, 1, 0, 0),
                   "double": (0, 0, 0, 1, 0), "generic": (0, 0, 0, 0, 1)}
@@ -2245,7 +2257,7 @@ class EcAddRequires:
 
 
 def ec_group_add_trace(requires, ec, bpl, min_height=0):
-    """`generate_trace` / `op_block` (ec/add/trace.rs:105-237): one four-row block per op, all-zero blocks after; routes the demand of its
+    """`generate_trace` / `op_block` (ec/add/trace.rs:146-251): one four-row block per op, all-zero blocks after; routes the demand of its
     consumes -- the operands' and the result's `EcPoint`, the live cases' `EcGroup`, the ordering limbs' Range16 -- into the ledgers, so it
     runs BEFORE the EC stores' and the table's traces are laid."""
     height = max(min_height, 1 << (max(1, len(requires.ops)) * EA_PERIOD - 1).bit_length())
