@@ -214,13 +214,18 @@ int mh_air_attach_preprocessed(mh_air* air, const mh_tree* tree, int matrix_inde
  * denominator node id).  Semantics (aux_builder.rs:202-258): f_c(r) = sum_j m_j(r) / d_j(r) over the fractions
  * of column c with m_j(r) != 0;  aux[r][c >= 1] = f_c(r);  aux[r][0] = sum_{r' < r} sum_c f_c(r');  the one
  * aux value = the sum over all rows (`committed_finals`).  A zero denominator is MH_ERR_INVALID.
+ * Optional tail, REGISTER columns behind the w[2] LogUp columns (precompiles-prover/src/tests/aux_register.rs; the extension-field
+ * accumulators of precompiles-prover/src/uint/store_mul/mod.rs:118-121, which that AIR's `build_aux_trace` computes on the CPU):
+ * count, then per register: keep node id (0xFFFFFFFF = the constant 1), build node id, n_terms <= 8, n_terms pairs (earlier register,
+ * coefficient node id).  Semantics: r_k[0] = 0,  r_k[i + 1] = keep(i) r_k[i] + sum_j coeff_j(i) r_j[i] + build(i);  aux column
+ * w[2] + k = r_k.  Registers stay out of the running sum and of the aux value; the AIR's own constraints tie them down.
  * `mh_air_attach_lookup` makes mh_prove / mh_session_commit_aux build that instance's aux trace on the device
  * (its `mh_aux_builder` callback is not called); the lookup must outlive the AIR's proofs. */
 typedef struct mh_lookup mh_lookup;
 int mh_lookup_load(mh_ctx* ctx, const uint64_t* blob, size_t n_words, mh_lookup** out);
 void mh_lookup_free(mh_lookup* l);
 int mh_air_attach_lookup(mh_air* air, const mh_lookup* l); /* l = NULL detaches */
-/* Stand-alone: aux trace (device resident, 2 * num_cols base columns) + accumulator final of `main_trace`. */
+/* Stand-alone: aux trace (device resident, 2 * (LogUp columns + registers) base columns) + accumulator final of `main_trace`. */
 int mh_lookup_build_aux(mh_ctx* ctx, const mh_lookup* l, const mh_trace* main_trace, const mh_trace* preprocessed /* or NULL */,
                         const uint64_t* randomness, size_t n_randomness, mh_trace** aux_out, uint64_t acc_final[2]);
 /* Copy a device trace back as a row-major [2^log_n][width] matrix (tests). */

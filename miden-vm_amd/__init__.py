@@ -428,14 +428,14 @@ class DeviceLookup:
         ctx._children.add(self)
 
     def build_aux(self, main_trace, randomness, preprocessed=None):
-        """-> (aux Trace on the device [n, 2 * num_cols], (c0, c1) accumulator final)."""
+        """-> (aux Trace on the device [n, 2 * (num_cols + registers)], (c0, c1) accumulator final)."""
         rnd = _arr([int(x) for r in randomness for x in r] or [0])
         h = C.c_void_p()
         fin = np.zeros(2, dtype=np.uint64)
         self.ctx.check(self.ctx.lib.mh_lookup_build_aux(self.ctx.h, self.h, main_trace.h, preprocessed.h if preprocessed is not None else None,
                                                         _ptr(rnd), C.c_size_t(len(randomness)),
                                                         C.byref(h), _ptr(fin)))
-        return Trace.from_handle(self.ctx, h, main_trace.log_n, 2 * self.lookup.num_cols), (int(fin[0]), int(fin[1]))
+        return Trace.from_handle(self.ctx, h, main_trace.log_n, 2 * self.lookup.num_aux_cols), (int(fin[0]), int(fin[1]))
 
     def free(self):
         if getattr(self, "h", None):

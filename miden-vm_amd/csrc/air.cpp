@@ -260,7 +260,33 @@ mh_lookup* mh_lookup::load(mh_ctx* ctx, const u64* w, size_t n) {
     for (size_t j = 0; j < 2 * cnt; j++) outs.push_back(w[p + j]);
     p += 2 * cnt;
   }
-  MH_REQUIRE(!outs.empty(), "lookup blob: no fractions");
+  lk->n_frac = outs.size() / 2;
+  if (p < n) {  // optional tail: register columns (keep node or NO_NODE, build node, terms (earlier register, coefficient node))
+    const size_t nr = w[p++];
+    MH_REQUIRE(nr < 4096, "lookup blob: bad register count");
+    for (size_t k = 0; k < nr; k++) {
+      MH_REQUIRE(p + 3 <= n, "lookup blob: truncated register list");
+      mh_lookup::Reg r;
+      if (w[p] != 0xFFFFFFFFull) {
+        r.keep_out = (int)outs.size();
+        outs.push_back(w[p]);
+      }
+      r.build_out = (int)outs.size();
+      outs.push_back(w[p + 1]);
+      const size_t nt = w[p + 2];
+      p += 3;
+      MH_REQUIRE(nt <= 8 && p + 2 * nt <= n, "lookup blob: a register reads at most eight earlier registers");
+      for (size_t t = 0; t < nt; t++) {
+        MH_REQUIRE(w[p + 2 * t] < k, "lookup blob: a register reads earlier registers only");
+        r.terms.push_back({(uint32_t)w[p + 2 * t], (int)outs.size()});
+        outs.push_back(w[p + 2 * t + 1]);
+      }
+      p += 2 * nt;
+      lk->regs.push_back(r);
+    }
+  }
+  MH_REQUIRE(p == n, "lookup blob: trailing words");
+  MH_REQUIRE(!outs.empty(), "lookup blob: no fractions and no registers");
   blob[9] = outs.size();
   blob.insert(blob.end(), outs.begin(), outs.end());
   DagIR ir = dag_parse(blob.data(), blob.size());

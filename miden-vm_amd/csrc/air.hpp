@@ -99,10 +99,19 @@ struct mh_lookup {
   size_t main_width = 0, num_cols = 0, num_randomness = 0, preprocessed_width = 0;
   std::vector<std::vector<u64>> periodic;
   std::vector<uint32_t> col_count;  // fractions of column c
-  std::vector<char> out_ext;        // per output (m_0, d_0, m_1, d_1, ...): EF-valued?
+  std::vector<char> out_ext;        // per output (m_0, d_0, m_1, d_1, ..., then the registers' keep / build / coefficients): EF-valued?
+  // Register columns behind the LogUp columns (the blob's optional tail): r[0] = 0, r[i + 1] = keep(i) r[i] + sum_j coeff_j(i) r_j[i] +
+  // build(i).  Fields are OUTPUT indices of the compiled program (keep_out < 0: keep = 1).
+  struct Reg {
+    int keep_out = -1, build_out = 0;
+    std::vector<std::pair<uint32_t, int>> terms;  // (earlier register, output index of its coefficient)
+  };
+  std::vector<Reg> regs;
+  size_t n_frac = 0;
   JitProgram* jit = nullptr;
   ~mh_lookup() { jit_program_free(jit); }
-  size_t n_fractions() const { return out_ext.size() / 2; }
+  size_t n_fractions() const { return n_frac; }
+  size_t num_aux_cols() const { return num_cols + regs.size(); }
   static mh_lookup* load(mh_ctx* c, const u64* w, size_t n);
 };
 

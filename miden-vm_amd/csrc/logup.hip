@@ -6,7 +6,8 @@
 //               fraction's multiplicity m and denominator d as planes [2 * K][n]  (air_jit.cpp, output mode);
 //   accumulate  (aux_builder.rs:202-258 accumulate_slow is the semantics; :290-330 the fused form)
 //               f_c(r) = sum_j m_j(r) / d_j(r);  aux[r][c >= 1] = f_c(r);
-//               aux[r][0] = sum_{r' < r} sum_c f_c(r')  (row 0 = 0);  acc_final = the sum over all rows.
+//               aux[r][0] = sum_{r' < r} sum_c f_c(r')  (row 0 = 0);  acc_final = the sum over all rows;
+//   registers   (optional, behind the LogUp columns) linear recurrences over the rows, by a scan over affine maps (below).
 // A fraction whose multiplicity is zero contributes zero, so the reference's conditional pushes and the
 // program's always-evaluated fractions give the same sums.
 // The aux trace is produced column-major in HBM (an mh_trace): it goes straight into the aux commitment, no
@@ -130,6 +131,99 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_add_offsets(u64* __restrict__ o
     if (base + i < n) dst[base + i] = gl_add(dst[base + i], off);
 }
 
+// ---- register columns: r[0] = 0, r[i + 1] = keep(i) r[i] + build(i) -- an exclusive scan over the affine maps x -> keep(i) x + build(i) ----
+// (precompiles-prover/src/uint/store_mul/trace.rs:73-140 computes its three registers row by row on the CPU; tests/aux_register.rs is the
+// smallest case.)  The composition (k2, b2) o (k1, b1) = (k2 k1, k2 b1 + b2) is associative, so the same three phases as the sums above
+// apply: tile aggregates, a walk over the tiles, the tiles again from their start values.  `build` already holds the contributions of
+// the earlier registers (k_reg_build).  Planes may be absent: keep0 == nullptr is keep = 1, a missing c1 plane is a base-field value.
+struct AffArgs {
+  const u64 *k0, *k1, *b0, *b1;
+  u64 *out0, *out1;
+  u64* tile_k;  // [2][tiles] aggregate keep of a tile
+  u64* tile_b;  // [2][tiles] aggregate build of a tile (phase 1), then the register's value at the tile's first row (phase 2)
+  size_t n, tiles;
+};
+struct Aff {
+  e2 k, b;
+};
+__device__ __forceinline__ Aff aff_then(Aff first, Aff then) { return {e2_mul(then.k, first.k), e2_add(e2_mul(then.k, first.b), then.b)}; }
+__device__ __forceinline__ Aff aff_load(const AffArgs& a, size_t i) {
+  if (i >= a.n) return {e2_make(1), e2_make(0)};
+  return {a.k0 ? e2{a.k0[i], a.k1 ? a.k1[i] : 0} : e2_make(1), e2{a.b0[i], a.b1 ? a.b1[i] : 0}};
+}
+template <bool APPLY>
+__global__ __launch_bounds__(SCAN_T) void k_affine_tiles(AffArgs a) {
+  __shared__ u64 part[4][SCAN_T];
+  const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+  Aff v[SCAN_ITEMS];
+  Aff acc = {e2_make(1), e2_make(0)};
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    v[i] = aff_load(a, base + i);
+    acc = aff_then(acc, v[i]);
+  }
+  auto put = [&](Aff x) {
+    part[0][threadIdx.x] = x.k.c0; part[1][threadIdx.x] = x.k.c1; part[2][threadIdx.x] = x.b.c0; part[3][threadIdx.x] = x.b.c1;
+  };
+  auto get = [&](unsigned t) { return Aff{e2{part[0][t], part[1][t]}, e2{part[2][t], part[3][t]}}; };
+  put(acc);
+  __syncthreads();
+  for (int off = 1; off < SCAN_T; off <<= 1) {  // Hillis-Steele over the 256 thread aggregates (earlier rows first)
+    const bool has = threadIdx.x >= (unsigned)off;
+    Aff before = has ? get(threadIdx.x - off) : Aff{e2_make(1), e2_make(0)};
+    __syncthreads();
+    if (has) put(aff_then(before, get(threadIdx.x)));
+    __syncthreads();
+  }
+  if (!APPLY) {
+    if (threadIdx.x == SCAN_T - 1) {
+      const Aff t = get(SCAN_T - 1);
+      a.tile_k[blockIdx.x] = t.k.c0; a.tile_k[a.tiles + blockIdx.x] = t.k.c1;
+      a.tile_b[blockIdx.x] = t.b.c0; a.tile_b[a.tiles + blockIdx.x] = t.b.c1;
+    }
+    return;
+  }
+  const e2 start = e2{a.tile_b[blockIdx.x], a.tile_b[a.tiles + blockIdx.x]};
+  const Aff pre = threadIdx.x ? get(threadIdx.x - 1) : Aff{e2_make(1), e2_make(0)};
+  e2 run = e2_add(e2_mul(pre.k, start), pre.b);
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    if (base + i < a.n) {
+      a.out0[base + i] = run.c0;
+      a.out1[base + i] = run.c1;
+    }
+    run = e2_add(e2_mul(v[i].k, run), v[i].b);
+  }
+}
+// phase 2: the register's value at the first row of every tile (a walk: at most n / 2048 steps)
+__global__ void k_affine_tile_starts(AffArgs a) {
+  if (blockIdx.x || threadIdx.x) return;
+  e2 run = e2_make(0);
+  for (size_t t = 0; t < a.tiles; t++) {
+    const e2 k = e2{a.tile_k[t], a.tile_k[a.tiles + t]}, b = e2{a.tile_b[t], a.tile_b[a.tiles + t]};
+    a.tile_b[t] = run.c0;
+    a.tile_b[a.tiles + t] = run.c1;
+    run = e2_add(e2_mul(k, run), b);
+  }
+}
+// build(i) += sum_j coeff_j(i) r_j[i] over the earlier registers a register reads
+struct RegBuildArgs {
+  const u64 *v0, *v1;
+  const u64 *u0[8], *u1[8], *r0[8], *r1[8];
+  int n_terms;
+  u64 *b0, *b1;
+  size_t n;
+};
+__global__ __launch_bounds__(256) void k_reg_build(RegBuildArgs a) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  e2 acc = e2{a.v0[i], a.v1 ? a.v1[i] : 0};
+  for (int t = 0; t < a.n_terms; t++)
+    acc = e2_add(acc, e2_mul(e2{a.u0[t][i], a.u1[t] ? a.u1[t][i] : 0}, e2{a.r0[t][i], a.r1[t][i]}));
+  a.b0[i] = acc.c0;
+  a.b1[i] = acc.c1;
+}
+
 // Build the aux trace of `lk` over `main` with the lookup challenges `randomness` (EF pairs).
 mh_trace* lookup_build_aux(mh_ctx* c, const mh_lookup* lk, const mh_trace* main, const mh_trace* prep, const std::vector<e2>& randomness,
                            e2* acc_final) {
@@ -162,7 +256,8 @@ mh_trace* lookup_build_aux(mh_ctx* c, const mh_lookup* lk, const mh_trace* main,
 
   trace_wait_ready(c, main);
   trace_wait_ready(c, prep);
-  DevBuf planes(4 * K * n * 8);  // outputs m_j, d_j: two planes each
+  const size_t n_out = lk->out_ext.size();
+  DevBuf planes(2 * n_out * n * 8);  // outputs m_j, d_j, then the registers' keep / build / coefficients: two planes each
   JitArgs j{};
   j.main_lde = main->cols.u();  // the trace itself: one "coset", B = 1
   j.aux_lde = main->cols.u();   // never read (a lookup program has no aux inputs)
@@ -175,7 +270,7 @@ mh_trace* lookup_build_aux(mh_ctx* c, const mh_lookup* lk, const mh_trace* main,
   j.randomness = dblob.u() + o_rnd;
   j.log_n = log_n;  // log_cosets = log_d = log_dl = jc_shift = t0 = 0: point q IS row r
   std::unique_ptr<mh_trace> aux(new mh_trace());
-  aux->ctx = c; aux->log_n = log_n; aux->width = 2 * lk->num_cols;
+  aux->ctx = c; aux->log_n = log_n; aux->width = 2 * lk->num_aux_cols();
   aux->cols.alloc(aux->width * n * 8);
   DevBuf totals(2 * n * 8);
   const size_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
@@ -192,6 +287,36 @@ mh_trace* lookup_build_aux(mh_ctx* c, const mh_lookup* lk, const mh_trace* main,
                        tiles);
     MH_LAUNCH(k_scan_tile_sums, dim3(2), dim3(SCAN_T), 0, c->stream, tile_sums.u(), tiles, grand.u());
     MH_LAUNCH(k_scan_add_offsets, dim3((unsigned)tiles, 2), dim3(SCAN_T), 0, c->stream, aux->cols.u(), tile_sums.u(), n, n, tiles);
+    if (!lk->regs.empty()) {
+      DevBuf tile_k(2 * tiles * 8), tile_b(2 * tiles * 8), tmp(2 * n * 8);
+      auto plane = [&](int out, int coord) -> const u64* {  // coordinate plane of a program output (nullptr: a base-field value's c1)
+        return coord && !lk->out_ext[out] ? nullptr : planes.u() + ((size_t)(2 * out + coord) << log_n);
+      };
+      for (size_t k = 0; k < lk->regs.size(); k++) {
+        const mh_lookup::Reg& g = lk->regs[k];
+        AffArgs a{};
+        a.n = n; a.tiles = tiles; a.tile_k = tile_k.u(); a.tile_b = tile_b.u();
+        a.out0 = aux->cols.u() + ((size_t)(2 * (lk->num_cols + k)) << log_n);
+        a.out1 = a.out0 + n;
+        if (g.keep_out >= 0) { a.k0 = plane(g.keep_out, 0); a.k1 = plane(g.keep_out, 1); }
+        a.b0 = plane(g.build_out, 0); a.b1 = plane(g.build_out, 1);
+        if (!g.terms.empty()) {
+          RegBuildArgs rb{};
+          rb.v0 = a.b0; rb.v1 = a.b1; rb.n_terms = (int)g.terms.size(); rb.n = n;
+          rb.b0 = tmp.u(); rb.b1 = tmp.u() + n;
+          for (size_t t = 0; t < g.terms.size(); t++) {
+            rb.u0[t] = plane(g.terms[t].second, 0); rb.u1[t] = plane(g.terms[t].second, 1);
+            rb.r0[t] = aux->cols.u() + ((size_t)(2 * (lk->num_cols + g.terms[t].first)) << log_n);
+            rb.r1[t] = rb.r0[t] + n;
+          }
+          MH_LAUNCH(k_reg_build, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, rb);
+          a.b0 = rb.b0; a.b1 = rb.b1;
+        }
+        MH_LAUNCH(k_affine_tiles<false>, dim3((unsigned)tiles), dim3(SCAN_T), 0, c->stream, a);
+        MH_LAUNCH(k_affine_tile_starts, dim3(1), dim3(1), 0, c->stream, a);
+        MH_LAUNCH(k_affine_tiles<true>, dim3((unsigned)tiles), dim3(SCAN_T), 0, c->stream, a);
+      }
+    }
   }
   u64 fin[2];
   u32 err = 0;

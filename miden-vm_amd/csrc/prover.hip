@@ -1055,7 +1055,7 @@ int mh_air_attach_lookup(mh_air* a, const mh_lookup* l) {
   MH_REQUIRE(a, "null argument");
   if (l) {
     MH_REQUIRE(l->main_width == a->main_width, "lookup program and AIR disagree on the trace width");
-    MH_REQUIRE(l->num_cols == a->aux_width, "lookup program and AIR disagree on the number of aux columns");
+    MH_REQUIRE(l->num_aux_cols() == a->aux_width, "lookup program and AIR disagree on the number of aux columns");
     MH_REQUIRE(a->num_aux_values == 1, "a LogUp AIR commits exactly one aux value (the accumulator's final)");
     MH_REQUIRE(l->num_randomness <= a->num_randomness, "lookup program needs more challenges than the AIR samples");
     MH_REQUIRE(l->preprocessed_width == 0 || l->preprocessed_width == a->preprocessed_width,

@@ -251,6 +251,19 @@ class LookupBuilder(AirBuilder):
                          preprocessed_width=preprocessed_width)
         self.num_cols = num_cols
         self.columns = [[] for _ in range(num_cols)]
+        self.registers = []
+
+    NO_NODE = 0xFFFFFFFF
+
+    def register(self, keep, build, terms=()):
+        """An aux REGISTER column after the LogUp columns (precompiles-prover/src/tests/aux_register.rs, uint/store_mul/mod.rs:118-121):
+        r[0] = 0,  r[i + 1] = keep(i) r[i] + sum_j coeff_j(i) r_j[i] + build(i)  over earlier registers r_j; keep = None stands for 1.
+        All of keep / coeff / build are expressions of this program (row window, periodic columns, challenges).  -> its index."""
+        lift = lambda e: e if isinstance(e, Expr) else self.const(e)     # noqa: E731
+        ts = [(int(j), lift(e).id) for j, e in terms]
+        assert all(0 <= j < len(self.registers) for j, _ in ts), "a register reads earlier registers only"
+        self.registers.append((self.NO_NODE if keep is None else lift(keep).id, lift(build).id, ts))
+        return len(self.registers) - 1
 
     def randomness(self, i):  # challenges are EF even though the program has no aux columns
         assert 0 <= i < self.num_randomness
@@ -274,6 +287,12 @@ class LookupBuilder(AirBuilder):
             w.append(len(col))
             for m, d in col:
                 w.extend((m, d))
+        if self.registers:               # optional tail: blobs without registers end here
+            w.append(len(self.registers))
+            for keep, build, ts in self.registers:
+                w.extend((keep, build, len(ts)))
+                for j, u in ts:
+                    w.extend((j, u))
         return np.array(w, dtype=np.uint64)
 
 
@@ -281,6 +300,8 @@ class Lookup:
     def __init__(self, builder, name="lookup"):
         self.name, self.main_width, self.num_cols, self.num_randomness = name, builder.main_width, builder.num_cols, builder.num_randomness
         self.preprocessed_width = builder.preprocessed_width
+        self.num_regs = len(builder.registers)
+        self.num_aux_cols = self.num_cols + self.num_regs               # the aux trace it builds: LogUp columns, then registers
         self.blob = builder.blob()
 
 
@@ -446,7 +467,7 @@ class LogUp:
         self.num_logup_cols = builder.aux_width if num_logup_cols is None else num_logup_cols
         self.b = builder
         self.lb = prover_builder if prover_builder is not None else LookupBuilder(
-            builder.main_width, num_cols=builder.aux_width, num_randomness=builder.num_randomness, periodic=builder.periodic,
+            builder.main_width, num_cols=self.num_logup_cols, num_randomness=builder.num_randomness, periodic=builder.periodic,
             preprocessed_width=builder.preprocessed_width)
         self.ch_c = LogUp.Challenges(self.b, max_message_width, num_bus_ids)
         self.ch_p = LogUp.Challenges(self.lb, max_message_width, num_bus_ids)
@@ -591,6 +612,14 @@ class LogUp:
                 b.assert_zero_ext(b.is_last_row() * cur)
             return False
 
+    def register(self, keep, build, terms=()):
+        """An aux register column behind the LogUp columns, prover side (`LookupBuilder.register`): keep / build / the coefficients are
+        callables f(builder) -> Expr evaluated on the lookup program's builder (keep may be None = 1).  The AIR's own constraints tie the
+        column (`builder.aux(idx)`) to the same recurrence.  -> the aux column index."""
+        k = self.lb.register(None if keep is None else keep(self.lb), build(self.lb), [(j - self.num_logup_cols, f(self.lb)) for j, f in terms])
+        assert self.num_logup_cols + k < self.b.aux_width, "more registers than aux columns behind the LogUp columns"
+        return self.num_logup_cols + k
+
     def column(self):
         c = LogUp._Column(self, self.column_idx)
         self.column_idx += 1
@@ -598,4 +627,5 @@ class LogUp:
 
     def finish(self, name="lookup"):
         assert self.column_idx == self.num_logup_cols, "every LogUp aux column needs its next_column call"
+        assert self.num_logup_cols + len(self.lb.registers) == self.b.aux_width, "every aux column is a LogUp column or a register"
         return Lookup(self.lb, name)

@@ -18,10 +18,23 @@ namespace oracle {
 
 static const uint64_t LOOKUP_MAGIC = 0x4d484c4b50303031ULL;  // "MHLKP001"
 
+// Aux REGISTER columns behind the LogUp columns (precompiles-prover/src/tests/aux_register.rs: an extension-field accumulator that must
+// live in the aux trace because it depends on the challenges, yet stays out of sigma; uint/store_mul/mod.rs:118-121 STORE_REG_ID,
+// MUL_REG_ID, MUL_REG_S): r[0] = 0, r[i + 1] = keep(i) r[i] + sum_j coeff_j(i) r_j[i] + build(i) over earlier registers r_j.  The
+// reference computes them in each AIR's own build_aux_trace (uint/store_mul/trace.rs:73-140); here the recurrence is data of the program.
+struct Register {
+  uint32_t keep = 0xFFFFFFFFu;  // node id, or NO_NODE = the constant 1
+  uint32_t build = 0;
+  std::vector<std::pair<uint32_t, uint32_t>> terms;  // (earlier register, coefficient node)
+};
+static const uint32_t NO_NODE = 0xFFFFFFFFu;
+
 struct Lookup {
   Air dag;  // header/periodic/nodes; `constraints` unused
   size_t num_cols = 0;
   std::vector<std::vector<std::pair<uint32_t, uint32_t>>> columns;  // (m node, d node)
+  std::vector<Register> registers;
+  size_t num_aux_cols() const { return num_cols + registers.size(); }
 
   static Lookup parse(const uint64_t* w, size_t n) {
     auto need = [&](bool ok) {
@@ -53,14 +66,37 @@ struct Lookup {
       }
       p += 2 * cnt;
     }
+    if (p < n) {  // optional tail: the register columns
+      const size_t nr = w[p++];
+      need(nr < 4096);
+      for (size_t k = 0; k < nr; k++) {
+        need(p + 3 <= n);
+        Register r;
+        need(w[p] == NO_NODE || w[p] < l.dag.nodes.size());
+        need(w[p + 1] < l.dag.nodes.size());
+        r.keep = (uint32_t)w[p];
+        r.build = (uint32_t)w[p + 1];
+        const size_t nt = w[p + 2];
+        p += 3;
+        need(nt < 4096 && p + 2 * nt <= n);
+        for (size_t t = 0; t < nt; t++) {
+          need(w[p + 2 * t] < k && w[p + 2 * t + 1] < l.dag.nodes.size());
+          r.terms.push_back({(uint32_t)w[p + 2 * t], (uint32_t)w[p + 2 * t + 1]});
+        }
+        p += 2 * nt;
+        l.registers.push_back(r);
+      }
+    }
+    need(p == n);
     return l;
   }
 };
 
-// main: row-major [n][main_width]; aux_out: row-major [n][2 * num_cols]; returns acc_final.
+// main: row-major [n][main_width]; aux_out: row-major [n][2 * (num_cols + registers)]; returns acc_final.
 static inline E2 lookup_build_aux(const Lookup& lk, const uint64_t* main, const uint64_t* prep /* [n][preprocessed_width] or null */, size_t n,
                                   const E2* randomness, uint64_t* aux_out) {
-  const size_t w = lk.dag.main_width, nc = lk.num_cols, pw = lk.dag.preprocessed_width;
+  const size_t w = lk.dag.main_width, nc = lk.num_cols, pw = lk.dag.preprocessed_width, nr = lk.registers.size(), aw = 2 * (nc + nr);
+  std::vector<E2> reg(nr, e2(0)), reg_next(nr);
   if (pw && !prep) throw std::runtime_error("lookup program reads preprocessed columns but none were supplied");
   std::vector<E2> val(lk.dag.nodes.size());
   std::vector<E2> per_row(nc);
@@ -86,8 +122,8 @@ static inline E2 lookup_build_aux(const Lookup& lk, const uint64_t* main, const 
       val[i] = v;
     }
     // aux row r = the accumulator BEFORE this row's contribution (aux_builder.rs:14-20)
-    aux_out[r * 2 * nc] = running.c0;
-    aux_out[r * 2 * nc + 1] = running.c1;
+    aux_out[r * aw] = running.c0;
+    aux_out[r * aw + 1] = running.c1;
     E2 row_total = e2(0);
     for (size_t c = 0; c < nc; c++) {
       E2 sum = e2(0);
@@ -99,12 +135,21 @@ static inline E2 lookup_build_aux(const Lookup& lk, const uint64_t* main, const 
       }
       per_row[c] = sum;
       if (c > 0) {
-        aux_out[r * 2 * nc + 2 * c] = sum.c0;
-        aux_out[r * 2 * nc + 2 * c + 1] = sum.c1;
+        aux_out[r * aw + 2 * c] = sum.c0;
+        aux_out[r * aw + 2 * c + 1] = sum.c1;
       }
       row_total = eadd(row_total, sum);
     }
     running = eadd(running, row_total);
+    for (size_t k = 0; k < nr; k++) {  // row r holds the registers BEFORE this row's step
+      const Register& g = lk.registers[k];
+      aux_out[r * aw + 2 * (nc + k)] = reg[k].c0;
+      aux_out[r * aw + 2 * (nc + k) + 1] = reg[k].c1;
+      E2 nx = g.keep == NO_NODE ? reg[k] : emul(val[g.keep], reg[k]);
+      for (auto& t : g.terms) nx = eadd(nx, emul(val[t.second], reg[t.first]));
+      reg_next[k] = eadd(nx, val[g.build]);
+    }
+    reg = reg_next;
   }
   return running;
 }

@@ -280,12 +280,12 @@ def verify(airs, log_heights, publics, proof, params=PROD_PARAMS, init_state=Non
 
 
 def lookup_build_aux(lookup, main, randomness, preprocessed=None):
-    """oracle/lookup.hpp: (aux[n, 2 * num_cols] uint64, acc_final[2]) of a dag.Lookup over a row-major main trace."""
+    """oracle/lookup.hpp: (aux[n, 2 * (num_cols + registers)] uint64, acc_final[2]) of a dag.Lookup over a row-major main trace."""
     m = arr(main)
     n = m.shape[0]
     blob = arr(lookup.blob)
     rnd = arr([int(x) for r in randomness for x in r] or [0])
-    aux = np.zeros((n, 2 * lookup.num_cols), dtype=np.uint64)
+    aux = np.zeros((n, 2 * lookup.num_aux_cols), dtype=np.uint64)
     fin = np.zeros(2, dtype=np.uint64)
     err = C.create_string_buffer(512)
     L = lib()

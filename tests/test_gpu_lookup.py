@@ -154,3 +154,46 @@ def test_range_check_proof_all_on_device(ctx):
     dair.attach_preprocessed(com.tree(), 0)
     with pytest.raises(pkg.MidenHipError, match="preprocessed"):
         pkg.prove(ctx, [dair], [ctx.upload_trace(main)], [], FAST, ob.challenger_state(), pre, None)
+
+
+# ---- register columns behind the LogUp columns (tests/test_aux_registers.py holds the AIRs and the host-side pins) --------------------
+@pytest.mark.parametrize("log_n", [4, 11, 12, 16, 20])
+def test_device_registers_equal_the_oracle_cell_for_cell(ctx, log_n):
+    """The reference's spike (precompiles-prover/src/tests/aux_register.rs: one empty LogUp column, one Horner register with an
+    extension-field keep) and the multiplier's shape (a periodic keep, a register reading an earlier one, a live LogUp column): one
+    tile, a tile boundary, many tiles."""
+    import test_aux_registers as R
+    pkg = load_package()
+    n = 1 << log_n
+    for (air, lookup), main in ((R.spike_air(), np.random.default_rng(log_n).integers(0, 1 << 32, (n, 1), dtype=np.uint64)),
+                                (R.chain_air(), R.chain_trace(n, seed=log_n))):
+        aux_dev, fin = pkg.DeviceLookup(ctx, lookup).build_aux(ctx.upload_trace(main), RND)
+        aux, exp_fin = ob.lookup_build_aux(lookup, main, RND)
+        got = aux_dev.download()
+        assert got.shape == aux.shape == (n, 2 * lookup.num_aux_cols)
+        bad = np.argwhere(got != aux)
+        assert bad.size == 0, f"{air.name}: first differing aux cell (row, col) = {bad[0]}"
+        assert fin == (int(exp_fin[0]), int(exp_fin[1]))
+
+
+@pytest.mark.parametrize("jit", ["0", "1"])
+def test_proofs_with_device_built_registers_equal_the_oracle(ctx, jit, monkeypatch):
+    import test_aux_registers as R
+    from miden_vm_amd import protocol
+    pkg = load_package()
+    monkeypatch.setenv("MH_JIT", jit)
+    root = [5, 6, 7, 8]
+    st = protocol.challenger_state((0, 0, 0, 0))
+    pre = protocol.protocol_pre_observe(FAST, root)
+
+    def never(idx, rnd):
+        raise AssertionError("host aux builder called")
+    for (air, lookup), main in ((R.spike_air(), np.random.default_rng(1).integers(0, 1 << 32, (32, 1), dtype=np.uint64)),
+                                (R.chain_air(), R.chain_trace(1 << 12, seed=9))):
+        exp = ob.prove([air], [main], root, FAST, init_state=st)
+        dair = pkg.DeviceAir(ctx, air)
+        dair.attach_lookup(pkg.DeviceLookup(ctx, lookup))
+        got = pkg.prove(ctx, [dair], [ctx.upload_trace(main)], root, FAST, st, pre, never)
+        assert (got.fields == exp["fields"]).all() and (got.commitments == exp["commitments"]).all() and (got.digest == exp["digest"]).all()
+        ok, dig = pkg.verify([air], got.log_trace_heights, root, FAST, st, pre, got.fields, got.commitments)
+        assert ok and (dig == got.digest).all()
