@@ -606,15 +606,16 @@ def uint_add_session_probe(pkg, ctx, steps=3):
 def ec_add_session_probe(pkg, ctx, steps=3):
     """The second client's group-law chiplet (precompiles-prover/src/ec/add: `EcGroupAddAir`, 21 columns, twelve flattened LogUp columns on
     seven buses, four-row blocks; every piece of field arithmetic a pointer-level certificate consumed from the uint chiplets) inside the
-    reference's "arithmetic + EC stack" in its order: 40 scalar multiples k G over secp256k1 by double-and-add with 256-bit scalars =
-    ~15 000 proven point additions (doubles, chords, pass-throughs; results minted with closure certificates), five real chiplets --
-    BytePairLutAir (preprocessed), UintAddAir, EcGroupsAir, EcPointStoreAir, EcGroupAddAir -- and the uint store / multiplier's bus sides
-    from the stand-in; production parameters, aux columns on the device, verified through `eval_external`."""
+    reference's "arithmetic + EC stack" in its order: 16 scalar multiples k G over secp256k1 by double-and-add with 256-bit scalars =
+    ~6 000 proven point additions (doubles, chords, pass-throughs; results minted with closure certificates) over SIX real chiplets --
+    BytePairLutAir (preprocessed), UintStoreMulAir (the uint store and the multiply-accumulate relation: 44 columns, 26 LogUp columns and
+    three extension-field registers built by a scan over affine maps), UintAddAir, EcGroupsAir, EcPointStoreAir, EcGroupAddAir -- every
+    bus between them closed by themselves; production parameters, aux columns on the device, verified through `eval_external`."""
     import random
     from miden_vm_amd import protocol, precompile_airs as PA
     rng = random.Random(5)
     t0 = time.perf_counter()
-    scalars = [rng.getrandbits(256) % PA.K1_BOUND for _ in range(40)]
+    scalars = [rng.getrandbits(256) % PA.K1_BOUND for _ in range(16)]
     pairs, host, (results, (store, adds, muls, ec, ec_add)) = PA.ec_add_session(scalars)
     gen_s = time.perf_counter() - t0
     x_ptr, y_ptr = ec.point_params(results[0])[1]
@@ -640,7 +641,8 @@ def ec_add_session_probe(pkg, ctx, steps=3):
     for t in traces:
         t.free()
     n_adds = len(ec_add.ops)
-    return {"workload": "EC addition session in SessionTraces::mains order: BytePairLutAir (preprocessed), the uint store / multiplier's bus sides (12 + 1 EF aux), UintAddAir 30 + 3, EcGroupsAir, EcPointStoreAir 14 + 5, EcGroupAddAir 21 + 12 EF aux; production parameters, aux columns on the device",
+    return {"workload": "EC addition session in SessionTraces::mains order: BytePairLutAir (preprocessed), UintStoreMulAir 44 + 29 EF aux (26 LogUp columns, 3 registers), UintAddAir 30 + 3, EcGroupsAir, EcPointStoreAir 14 + 5, EcGroupAddAir 21 + 12 EF aux, the additions' readers; production parameters, aux columns on the device",
+            "stored_uints": len(store.rows),
             "scalar_multiplications": len(scalars), "point_additions": n_adds, "modular_additions": len(adds.ops), "modular_macs": len(muls.ops),
             "stored_points": len(ec.points), "log_trace_heights": proof.log_trace_heights, "ms_per_proof": dt * 1e3,
             "point_additions_per_s": n_adds / dt, "proof_bytes": len(proof.bytes), "verifies_with_eval_external": bool(ok),

@@ -216,9 +216,9 @@ int mh_air_attach_preprocessed(mh_air* air, const mh_tree* tree, int matrix_inde
  * aux value = the sum over all rows (`committed_finals`).  A zero denominator is MH_ERR_INVALID.
  * Optional tail, REGISTER columns behind the w[2] LogUp columns (precompiles-prover/src/tests/aux_register.rs; the extension-field
  * accumulators of precompiles-prover/src/uint/store_mul/mod.rs:118-121, which that AIR's `build_aux_trace` computes on the CPU):
- * count, then per register: keep node id (0xFFFFFFFF = the constant 1), build node id, n_terms <= 8, n_terms pairs (earlier register,
- * coefficient node id).  Semantics: r_k[0] = 0,  r_k[i + 1] = keep(i) r_k[i] + sum_j coeff_j(i) r_j[i] + build(i);  aux column
- * w[2] + k = r_k.  Registers stay out of the running sum and of the aux value; the AIR's own constraints tie them down.
+ * count, then per register: keep node id (0xFFFFFFFF = the constant 1), build node id, n_terms <= 8, n_terms pairs (another register,
+ * coefficient node id; no cycles).  Semantics: r_k[0] = 0,  r_k[i + 1] = keep(i) r_k[i] + sum_j coeff_j(i) r_j[i] + build(i);  aux
+ * column w[2] + k = r_k.  Registers stay out of the running sum and of the aux value; the AIR's own constraints tie them down.
  * `mh_air_attach_lookup` makes mh_prove / mh_session_commit_aux build that instance's aux trace on the device
  * (its `mh_aux_builder` callback is not called); the lookup must outlive the AIR's proofs. */
 typedef struct mh_lookup mh_lookup;

@@ -277,12 +277,28 @@ mh_lookup* mh_lookup::load(mh_ctx* ctx, const u64* w, size_t n) {
       p += 3;
       MH_REQUIRE(nt <= 8 && p + 2 * nt <= n, "lookup blob: a register reads at most eight earlier registers");
       for (size_t t = 0; t < nt; t++) {
-        MH_REQUIRE(w[p + 2 * t] < k, "lookup blob: a register reads earlier registers only");
+        MH_REQUIRE(w[p + 2 * t] < nr && w[p + 2 * t] != k, "lookup blob: a register reads OTHER registers of the program");
         r.terms.push_back({(uint32_t)w[p + 2 * t], (int)outs.size()});
         outs.push_back(w[p + 2 * t + 1]);
       }
       p += 2 * nt;
       lk->regs.push_back(r);
+    }
+  }
+  {  // the order the scans run in: a register after the registers it reads (declaration order = aux column order is free)
+    std::vector<char> done(lk->regs.size(), 0);
+    while (lk->reg_order.size() < lk->regs.size()) {
+      const size_t before = lk->reg_order.size();
+      for (size_t k = 0; k < lk->regs.size(); k++) {
+        if (done[k]) continue;
+        bool ready = true;
+        for (auto& t : lk->regs[k].terms) ready = ready && done[t.first];
+        if (ready) {
+          done[k] = 1;
+          lk->reg_order.push_back((uint32_t)k);
+        }
+      }
+      MH_REQUIRE(lk->reg_order.size() > before, "lookup blob: the registers read each other in a cycle");
     }
   }
   MH_REQUIRE(p == n, "lookup blob: trailing words");

@@ -104,9 +104,10 @@ struct mh_lookup {
   // build(i).  Fields are OUTPUT indices of the compiled program (keep_out < 0: keep = 1).
   struct Reg {
     int keep_out = -1, build_out = 0;
-    std::vector<std::pair<uint32_t, int>> terms;  // (earlier register, output index of its coefficient)
+    std::vector<std::pair<uint32_t, int>> terms;  // (another register, output index of its coefficient)
   };
   std::vector<Reg> regs;
+  std::vector<uint32_t> reg_order;  // registers in dependency order
   size_t n_frac = 0;
   JitProgram* jit = nullptr;
   ~mh_lookup() { jit_program_free(jit); }

@@ -292,7 +292,7 @@ mh_trace* lookup_build_aux(mh_ctx* c, const mh_lookup* lk, const mh_trace* main,
       auto plane = [&](int out, int coord) -> const u64* {  // coordinate plane of a program output (nullptr: a base-field value's c1)
         return coord && !lk->out_ext[out] ? nullptr : planes.u() + ((size_t)(2 * out + coord) << log_n);
       };
-      for (size_t k = 0; k < lk->regs.size(); k++) {
+      for (const size_t k : lk->reg_order) {
         const mh_lookup::Reg& g = lk->regs[k];
         AffArgs a{};
         a.n = n; a.tiles = tiles; a.tile_k = tile_k.u(); a.tile_b = tile_b.u();

@@ -257,11 +257,12 @@ class LookupBuilder(AirBuilder):
 
     def register(self, keep, build, terms=()):
         """An aux REGISTER column after the LogUp columns (precompiles-prover/src/tests/aux_register.rs, uint/store_mul/mod.rs:118-121):
-        r[0] = 0,  r[i + 1] = keep(i) r[i] + sum_j coeff_j(i) r_j[i] + build(i)  over earlier registers r_j; keep = None stands for 1.
-        All of keep / coeff / build are expressions of this program (row window, periodic columns, challenges).  -> its index."""
+        r[0] = 0,  r[i + 1] = keep(i) r[i] + sum_j coeff_j(i) r_j[i] + build(i)  over OTHER registers r_j (any order of declaration, no
+        cycles); keep = None stands for 1.  All of keep / coeff / build are expressions of this program (row window, periodic columns,
+        challenges).  -> its index."""
         lift = lambda e: e if isinstance(e, Expr) else self.const(e)     # noqa: E731
         ts = [(int(j), lift(e).id) for j, e in terms]
-        assert all(0 <= j < len(self.registers) for j, _ in ts), "a register reads earlier registers only"
+        assert all(j >= 0 and j != len(self.registers) for j, _ in ts), "a register reads other registers"
         self.registers.append((self.NO_NODE if keep is None else lift(keep).id, lift(build).id, ts))
         return len(self.registers) - 1
 
@@ -288,6 +289,7 @@ class LookupBuilder(AirBuilder):
             for m, d in col:
                 w.extend((m, d))
         if self.registers:               # optional tail: blobs without registers end here
+            assert all(j < len(self.registers) for _, _, ts in self.registers for j, _ in ts), "a register reads a register that does not exist"
             w.append(len(self.registers))
             for keep, build, ts in self.registers:
                 w.extend((keep, build, len(ts)))

@@ -110,6 +110,11 @@ class BytePairLutRequires:
     def require_range16(self, w):
         self.counts[((w & 0xff) << 8) | (w >> 8), 2] += 1  # w = a + 256 b, LSB byte first
 
+    def require_range16_many(self, ws):
+        w = np.asarray(ws, dtype=np.int64).reshape(-1)
+        assert ((w >= 0) & (w < 1 << 16)).all(), "a limb outside the table's range"
+        self.counts[:, 2] += np.bincount(((w & 0xff) << 8) | (w >> 8), minlength=BPL_TRACE_HEIGHT).astype(np.uint64)
+
     def require_logic64(self, op, a, b):  # byte_pair_lut.rs:233-241
         for i in range(8):
             self.require(op, (a >> (8 * i)) & 0xff, (b >> (8 * i)) & 0xff)
@@ -1664,7 +1669,7 @@ class UintStore:
     PIN_NAMESPACE_END = 1 << 16                                         # uint/trace.rs:97: pinned rows below, interned transients from here on
 
     def __init__(self):
-        self.rows, self.by_value, self.reads, self.next_ptr = {}, {}, {}, self.PIN_NAMESPACE_END
+        self.rows, self.by_value, self.reads, self.limb_reads, self.next_ptr = {}, {}, {}, {}, self.PIN_NAMESPACE_END
 
     def _insert(self, ptr, value, bound_ptr):
         assert ptr not in self.rows, f"duplicate uint ptr {ptr}"
@@ -1695,6 +1700,9 @@ class UintStore:
 
     def require_uintval(self, ptr):
         self.reads[ptr] = self.reads.get(ptr, 0) + 1
+
+    def require_uintlimbs(self, ptr):
+        self.limb_reads[ptr] = self.limb_reads.get(ptr, 0) + 1
 
     def uint_val_requests(self):
         """-> [(BUS_UINT_VAL, -readers, [ptr, bound_ptr, eight 32-bit limbs])] for `requirer_air(payload=10)`."""
@@ -2285,6 +2293,328 @@ def ec_group_add_trace(requires, ec, bpl, min_height=0):
     return t
 
 
+# ---- UintStoreMul: the uint store and the scaled multiply-accumulate relation on one row range (uint/{mod,trace}.rs, uint/mul/{mod,trace}.rs,
+# uint/store_mul/{mod,trace}.rs) ------------------------------------------------------------------------------------------------------------
+# STORE (main columns 0..18, period 4): one block per stored 256-bit value -- v as sixteen Range16-checked 16-bit limbs on two rows, its
+# complement to the bound (comp = bound - v: the range check v <= bound) on a third, the bound as 4 x 32 + 4 x 32 bits with seven binary
+# carries and the pointer gap on the closing row.  v + comp = bound is checked by a vertical Schwartz-Zippel: an extension-field REGISTER
+# `id` in the aux trace accumulates the rows' limb sums at the LogUp challenge beta and must return to zero at every block end.  Provides
+# the value as `UintVal` (8 x 32) and `UintLimbs` (16 x 16); consumes its own bound's `UintVal` (only a self-referential row -- a modulus --
+# can answer that).  MUL (columns 18..44, period 8): kappa_a a b +- kappa_c c = r (mod bound + 1) over stored values: a, b, the bound as
+# 16-bit limb rows (pulled over `UintLimbs`), a 17-limb quotient, r and c as 32-bit rows (`UintVal`), 31 carry coefficients in 62
+# offset 16-bit halves spread over the free cells (`UM_GAMMA_SLOTS`); the identity
+#     kappa_a a(beta) b(beta) +- kappa_c C(beta^2) - q(beta) (bound(beta) + 1) - R(beta^2) + (beta - 2^16) Gamma(beta) = 0
+# again by registers: `S` stages kappa_a a(beta), then bound(beta) (a periodic keep gate), `id` accumulates S b(beta), -(S + 1) q(beta)
+# and the linear terms.  44 main columns, 26 LogUp columns + 3 registers, 13 periodic columns, lqd 1.
+BUS_UINT_LIMBS = 13                                                                                             # relations.rs:52-80
+US_CELLS, US_COL_PTR, US_COL_BOUND_PTR, US_COLS, US_PERIOD = 16, 16, 17, 18, 4                                  # uint/mod.rs:180-196
+US_HUB_UINTVAL_MULT, US_HUB_UINTLIMBS_MULT, US_CARRY_LO, US_CARRY_HI, US_TERM_GAP = 8, 9, 4, 12, 15
+UM_CELLS, UM_COLS, UM_PERIOD = 19, 26, 8                                                                        # uint/mul/mod.rs:175-206
+UM_COL_A_PTR, UM_COL_B_PTR, UM_COL_R_PTR, UM_COL_BOUND_PTR, UM_COL_KAPPA_A, UM_COL_ACT, UM_COL_BORROW = range(19, 26)
+UM_ROW_A, UM_ROW_B, UM_ROW_P, UM_ROW_Q, UM_ROW_R, UM_ROW_G0, UM_ROW_G1, UM_ROW_C = range(8)
+UM_S_KEEP = [1, 0, 1, 0, 0, 0, 0, 0]
+UM_TERM_MULT, UM_TERM_C_PTR, UM_TERM_KAPPA_C, UM_TERM_IS_SUB, UM_TERM_KAPPA_C_SIGNED = 8, 9, 10, 11, 12        # on the c row (:212-216)
+UM_NUM_Q_LIMBS, UM_NUM_GAMMA, UM_GAMMA_OFFSET = 17, 31, 1 << 31                                                 # :218-219, :346
+UM_GAMMA_SLOTS = ([(UM_ROW_G0, c) for c in range(19)] + [(UM_ROW_G1, c) for c in range(15)]                     # `gamma_slots` (:225-282)
+                  + [(r, c) for r in (UM_ROW_A, UM_ROW_B, UM_ROW_P) for c in range(16, 19)] + [(UM_ROW_Q, c) for c in range(17, 19)]
+                  + [(UM_ROW_R, c) for c in range(8, 19)] + [(UM_ROW_C, c) for c in range(13, 19)])
+USM_MUL_OFF, USM_COLS = US_COLS, US_COLS + UM_COLS                                                              # uint/store_mul/mod.rs:76-101
+USM_STORE_LOGUP_COLS, USM_MUL_LOGUP_COLS = 1 + 1 + 8 + 1, 1 + 2 + 10 + 1 + 1
+USM_LOGUP_COLS = USM_STORE_LOGUP_COLS + USM_MUL_LOGUP_COLS
+USM_STORE_REG_ID, USM_MUL_REG_ID, USM_MUL_REG_S, USM_AUX_COLS = USM_LOGUP_COLS, USM_LOGUP_COLS + 1, USM_LOGUP_COLS + 2, USM_LOGUP_COLS + 3
+USM_PCOL_S_KEEP, USM_PCOL_STORE_ROLE = UM_PERIOD, UM_PERIOD + 1        # periodic: mul's eight one-hots, S_KEEP, the store's four roles tiled twice
+assert len(UM_GAMMA_SLOTS) == 2 * UM_NUM_GAMMA == len(set(UM_GAMMA_SLOTS))
+
+
+def _usm_periodic():
+    cols = [[int(r == role) for r in range(UM_PERIOD)] for role in range(UM_PERIOD)]
+    cols.append(list(UM_S_KEEP))
+    cols += [[int(r % US_PERIOD == role) for r in range(UM_PERIOD)] for role in range(US_PERIOD)]
+    return cols
+
+
+def _usm_store_parts(bb):
+    """The store's `id` contribution of a row and the closing row's own share (uint/store_mul/mod.rs:202-262), on builder `bb`."""
+    loc = [bb.main(c) for c in range(US_COLS)]
+    v_lo, v_hi, comp, bound = (bb.periodic_value(USM_PCOL_STORE_ROLE + k) for k in range(4))
+    beta = bb.randomness(1)
+    bp = [bb.const(1)]
+    for _ in range(1, 8):
+        bp.append(bp[-1] * beta)
+    two16, t32 = bb.const(1 << 16), bb.const(1 << 32)
+    zero = bb.const(0)
+    lo07 = hi07 = hi815 = direct_lo = direct_hi = zero
+    for k in range(4):
+        r07, r815 = loc[2 * k] + two16 * loc[2 * k + 1], loc[8 + 2 * k] + two16 * loc[8 + 2 * k + 1]
+        lo07, hi07, hi815 = lo07 + bp[k] * r07, hi07 + bp[4 + k] * r07, hi815 + bp[4 + k] * r815
+        direct_lo, direct_hi = direct_lo + bp[k] * loc[k], direct_hi + bp[4 + k] * loc[8 + k]
+    carry_lo = carry_hi = zero
+    for j in range(4):
+        carry_lo = carry_lo + (bp[j + 1] - bp[j] * t32) * loc[US_CARRY_LO + j]
+    for j in range(4, 7):
+        carry_hi = carry_hi + (bp[j + 1] - bp[j] * t32) * loc[US_CARRY_HI + (j - 4)]
+    bound_own = carry_lo - direct_lo + carry_hi - direct_hi
+    contrib = lo07 * (v_lo + comp) + hi07 * v_hi + hi815 * comp + bound_own * bound
+    return contrib, bound_own, bound
+
+
+def _usm_mul_parts(bb):
+    """The multiplier's registers on builder `bb` (uint/store_mul/mod.rs:300-372): S' = keep S + build, id' = id + S u + v, and the c row's
+    own share of the closing check."""
+    loc = [bb.main(USM_MUL_OFF + c) for c in range(UM_COLS)]
+    sel = [bb.periodic_value(i) for i in range(UM_PERIOD)]
+    keep = bb.periodic_value(USM_PCOL_S_KEEP)
+    beta = bb.randomness(1)
+    bp = [bb.const(1)]
+    for _ in range(1, UM_NUM_GAMMA + 1):
+        bp.append(bp[-1] * beta)
+    t16, offset, one = bb.const(1 << 16), bb.const(UM_GAMMA_OFFSET), bb.const(1)
+    x_minus_t = beta - t16
+    kappa_a, act, borrow, kcs = loc[UM_COL_KAPPA_A], loc[UM_COL_ACT], loc[UM_COL_BORROW], loc[UM_TERM_KAPPA_C_SIGNED]
+    full16 = full_q = val = bb.const(0)
+    for i_ in range(UM_NUM_Q_LIMBS):
+        if i_ < 16:
+            full16 = full16 + bp[i_] * loc[i_]
+        full_q = full_q + bp[i_] * loc[i_]
+    for m in range(8):
+        val = val + bp[2 * m] * loc[m]
+    build = full16 * (sel[UM_ROW_A] * kappa_a) + full16 * sel[UM_ROW_P]
+    u = full16 * sel[UM_ROW_B] - full_q * sel[UM_ROW_Q]
+    carries, c_own = bb.const(0), val * kcs
+    for slot, (row, cell) in enumerate(UM_GAMMA_SLOTS):
+        w = x_minus_t * bp[slot // 2]
+        if slot % 2:
+            w = w * t16
+        gated = sel[row] * loc[cell]
+        own = loc[cell]
+        if slot % 2 == 0:
+            gated, own = gated - sel[row] * act * offset, own - act * offset
+        carries = carries + w * gated
+        if row == UM_ROW_C:
+            c_own = c_own + w * own
+    v = val * (sel[UM_ROW_C] * kcs) - val * sel[UM_ROW_R] - full_q * sel[UM_ROW_Q] + carries + (full16 + one) * (sel[UM_ROW_P] * borrow)
+    return dict(keep=keep, build=build, u=u, v=v, c_own=c_own, loc=loc, sel=sel)
+
+
+def uint_store_mul_air(host_aux=None):
+    """`UintStoreMulAir::eval` (uint/store_mul/mod.rs:191-417: the store's and the multiplier's constraints verbatim, side by side) and its
+    `LookupAir::eval` (:442-889): cols 0-10 the store's (UintVal provide | its bound's consume + the gap | eight Range16 pairs | UintLimbs
+    provide), cols 11-25 the multiplier's (UintMul provide | three UintLimbs consumes | ten Range16 columns over the 19 cells | the two
+    kappas | the r and c UintVal consumes); aux columns 26-28 = the registers (store id, mul id, mul S), built by the lookup program's
+    register tail (`dag.LogUp.register`)."""
+    b = dag.AirBuilder(USM_COLS, aux_width=USM_AUX_COLS, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
+                       num_public=NUM_PUBLIC_VALUES, periodic=_usm_periodic())
+    one = b.const(1)
+    # ---- store
+    loc, nxt = [b.main(c) for c in range(US_COLS)], [b.main(c, 1) for c in range(US_COLS)]
+    contrib, bound_own, bound_sel = _usm_store_parts(b)
+    sid, sid_next = b.aux(USM_STORE_REG_ID), b.aux(USM_STORE_REG_ID, 1)
+    b.assert_zero_ext(b.is_first_row() * sid)
+    b.assert_zero_ext(b.is_transition() * (sid_next - sid - contrib))
+    b.assert_zero_ext((sid + bound_own) * bound_sel)
+    b.assert_zero(b.is_first_row() * (loc[US_COL_PTR] - one))           # the pointer chain is rooted at 1: 0 stays the unstored sentinel
+    for cell in list(range(US_CARRY_LO, US_CARRY_LO + 4)) + list(range(US_CARRY_HI, US_CARRY_HI + 3)):
+        b.assert_zero(bound_sel * loc[cell] * (one - loc[cell]))
+    not_term = one - bound_sel
+    for col in (US_COL_PTR, US_COL_BOUND_PTR):
+        b.assert_zero(not_term * (nxt[col] - loc[col]))
+    b.assert_zero(b.is_transition() * (bound_sel * (loc[US_TERM_GAP] + loc[US_COL_PTR] + one - nxt[US_COL_PTR])))
+    # ---- mul
+    m = _usm_mul_parts(b)
+    ml, mn, sel = m["loc"], [b.main(USM_MUL_OFF + c, 1) for c in range(UM_COLS)], m["sel"]
+    mid, mid_next, s_reg, s_next = b.aux(USM_MUL_REG_ID), b.aux(USM_MUL_REG_ID, 1), b.aux(USM_MUL_REG_S), b.aux(USM_MUL_REG_S, 1)
+    b.assert_zero_ext(b.is_first_row() * s_reg)
+    b.assert_zero_ext(b.is_transition() * (s_next - s_reg * m["keep"] - m["build"]))
+    b.assert_zero_ext(b.is_first_row() * mid)
+    b.assert_zero_ext(b.is_transition() * (mid_next - mid - (s_reg * m["u"] + m["v"])))
+    b.assert_zero_ext((mid + m["c_own"]) * sel[UM_ROW_C])
+    act, borrow, is_sub = ml[UM_COL_ACT], ml[UM_COL_BORROW], ml[UM_TERM_IS_SUB]
+    b.assert_zero(act * (one - act))
+    b.assert_zero(sel[UM_ROW_C] * is_sub * (one - is_sub))
+    b.assert_zero(sel[UM_ROW_C] * (ml[UM_TERM_KAPPA_C_SIGNED] - ml[UM_TERM_KAPPA_C] * (one - b.const(2) * is_sub)))
+    b.assert_zero(borrow * (borrow - one) * (borrow - b.const(2)))
+    b.assert_zero(sel[UM_ROW_C] * borrow * (one - is_sub))
+    b.assert_zero(sel[UM_ROW_C] * (one - act) * ml[UM_TERM_MULT])
+    m_not_term = one - sel[UM_ROW_C]
+    for col in (UM_COL_A_PTR, UM_COL_B_PTR, UM_COL_R_PTR, UM_COL_BOUND_PTR, UM_COL_KAPPA_A, UM_COL_ACT, UM_COL_BORROW):
+        b.assert_zero(m_not_term * (mn[col] - ml[col]))
+
+    lk = dag.LogUp(b, MAX_MESSAGE_WIDTH, NUM_BUS_IDS, closing="sigma_last_row", num_logup_cols=USM_LOGUP_COLS)
+
+    def win(ch):
+        bb = lk.b if ch is lk.ch_c else lk.lb
+        return bb, [bb.main(c) for c in range(USM_COLS)], [bb.main(c, 1) for c in range(USM_COLS)]
+
+    def message(bus, fields):            # fields: callables (bb, local, next) -> expression
+        def msg(ch):
+            bb, lo, nx = win(ch)
+            return ch.encode(bus, [f(bb, lo, nx) for f in fields])
+        return msg
+    L = lambda c: (lambda bb, lo, nx: lo[c])                                              # noqa: E731
+    N = lambda c: (lambda bb, lo, nx: nx[c])                                              # noqa: E731
+    recomb = [(lambda k: (lambda bb, lo, nx: (lo if k < 4 else nx)[2 * (k % 4)] + bb.const(1 << 16) * (lo if k < 4 else nx)[2 * (k % 4) + 1]))(k)
+              for k in range(8)]
+    direct = [L(k) if k < 4 else L(4 + k) for k in range(8)]
+    raw = [L(j) if j < 8 else N(j - 8) for j in range(16)]
+    M = USM_MUL_OFF
+
+    def mults(fn):
+        return fn(lk.b), fn(lk.lb)
+    role = lambda bb, k: bb.periodic_value(USM_PCOL_STORE_ROLE + k)                       # noqa: E731
+    limb_gate = lambda cell: mults(lambda bb: role(bb, 0) + role(bb, 1) + role(bb, 2) if cell < 8 else role(bb, 2))   # noqa: E731
+    bound_gate = mults(lambda bb: role(bb, 3))
+    columns = [[(mults(lambda bb: (bb.const(0) - bb.main(US_HUB_UINTVAL_MULT, 1)) * role(bb, 0)),
+                 message(BUS_UINT_VAL, [L(US_COL_PTR), L(US_COL_BOUND_PTR)] + recomb))],
+               [(bound_gate, message(BUS_UINT_VAL, [L(US_COL_BOUND_PTR), L(US_COL_BOUND_PTR)] + direct)),
+                (bound_gate, message(BUS_RANGE16, [L(US_TERM_GAP)]))]]
+    for cell in range(0, US_CELLS, 2):
+        columns.append([(limb_gate(c), message(BUS_RANGE16, [L(c)])) for c in (cell, cell + 1)])
+    columns.append([(mults(lambda bb: (bb.const(0) - bb.main(US_HUB_UINTLIMBS_MULT, 1)) * role(bb, 0)),
+                     message(BUS_UINT_LIMBS, [L(US_COL_PTR), L(US_COL_BOUND_PTR)] + raw))])
+    # the multiplier's columns
+    row_act = lambda row: mults(lambda bb: bb.periodic_value(row) * bb.main(M + UM_COL_ACT))           # noqa: E731
+    columns.append([(mults(lambda bb: (bb.const(0) - bb.main(M + UM_TERM_MULT)) * bb.periodic_value(UM_ROW_C)),
+                     message(BUS_UINT_MUL, [L(M + UM_COL_KAPPA_A), L(M + UM_TERM_KAPPA_C), L(M + UM_COL_A_PTR), L(M + UM_COL_B_PTR), L(M + UM_TERM_C_PTR),
+                                            L(M + UM_COL_R_PTR), L(M + UM_COL_BOUND_PTR), L(M + UM_TERM_IS_SUB)]))])
+    limbs16 = [L(M + i_) for i_ in range(16)]
+    raw_consumes = [(row_act(row), message(BUS_UINT_LIMBS, [L(M + ptr), L(M + UM_COL_BOUND_PTR)] + limbs16))
+                    for row, ptr in ((UM_ROW_A, UM_COL_A_PTR), (UM_ROW_B, UM_COL_B_PTR), (UM_ROW_P, UM_COL_BOUND_PTR))]
+    columns += [raw_consumes[0:2], raw_consumes[2:3]]
+
+    def cell_gate(cell):
+        rows = ([UM_ROW_Q] if cell < UM_NUM_Q_LIMBS else []) + [r for r, c in UM_GAMMA_SLOTS if c == cell]
+
+        def fn(bb):
+            acc = bb.periodic_value(rows[0])
+            for r in rows[1:]:
+                acc = acc + bb.periodic_value(r)
+            return acc * bb.main(M + UM_COL_ACT)
+        return mults(fn)
+    cells = [(cell_gate(c), message(BUS_RANGE16, [L(M + c)])) for c in range(UM_CELLS)]
+    columns += [cells[c:c + 2] for c in range(0, UM_CELLS, 2)]
+    columns.append([(row_act(UM_ROW_C), message(BUS_RANGE16, [L(M + UM_COL_KAPPA_A)])), (row_act(UM_ROW_C), message(BUS_RANGE16, [L(M + UM_TERM_KAPPA_C)]))])
+    val_full = [L(M + i_) for i_ in range(8)]
+    columns.append([(row_act(UM_ROW_R), message(BUS_UINT_VAL, [L(M + UM_COL_R_PTR), L(M + UM_COL_BOUND_PTR)] + val_full)),
+                    (row_act(UM_ROW_C), message(BUS_UINT_VAL, [L(M + UM_TERM_C_PTR), L(M + UM_COL_BOUND_PTR)] + val_full))])
+    assert len(columns) == USM_LOGUP_COLS
+    _emit_frac_cols(lk, columns)
+    parts = _usm_mul_parts(lk.lb)
+    assert lk.register(None, lambda bb: _usm_store_parts(bb)[0]) == USM_STORE_REG_ID
+    assert lk.register(None, lambda bb: parts["v"], [(USM_MUL_REG_S, lambda bb: parts["u"])]) == USM_MUL_REG_ID     # id reads S, the column after it
+    assert lk.register(lambda bb: parts["keep"], lambda bb: parts["build"]) == USM_MUL_REG_S
+    lookup = lk.finish("uint_store_mul")
+    return dag.Air(b, _host_aux(lookup, host_aux), "uint_store_mul"), lookup
+
+
+def _limbs(v, bits, n):
+    return [(v >> (bits * j)) & ((1 << bits) - 1) for j in range(n)]
+
+
+def _um_witness(op, store, forge_q=None):
+    """`canonical_q` + `gamma_halves` (uint/mul/trace.rs:75-150; math.rs `mac_div_rem` / `mac_sub_div_rem`): the quotient's 17 limbs, the
+    borrow (moduli added back on a subtractive underflow), and the 31 carries of the synthetic division of the identity's coefficient
+    polynomial by (X - 2^16), each offset by 2^31 and split in 16-bit halves."""
+    kappa_a, kappa_c, a_ptr, b_ptr, c_ptr, r_ptr, bound_ptr, is_sub = op
+    a, bv, c, r, bound = (store.value(x) for x in (a_ptr, b_ptr, c_ptr, r_ptr, bound_ptr))
+    p_ = bound + 1
+    prod, lin = kappa_a * a * bv, kappa_c * c
+    if not is_sub:
+        q, rem, borrow = (prod + lin) // p_, (prod + lin) % p_, 0
+    elif prod >= lin:
+        q, rem, borrow = (prod - lin) // p_, (prod - lin) % p_, 0
+    else:
+        qd, rd = divmod(lin - prod, p_)
+        assert qd < 2, "mac_sub underflow exceeds 2p"
+        q, rem, borrow = 0, (0 if rd == 0 else p_ - rd), (qd if rd == 0 else qd + 1)
+    assert rem == r, "the op's r must be the canonical remainder"
+    assert q >> 272 == 0, "quotient exceeds 17 limbs"
+    ql = _limbs(q, 16, UM_NUM_Q_LIMBS)
+    if forge_q is not None:              # tests: another limb encoding of the same quotient (the carries follow it)
+        ql = forge_q(ql)
+    al, bl, pl, c32, r32 = _limbs(a, 16, 16), _limbs(bv, 16, 16), _limbs(bound, 16, 16), _limbs(c, 32, 8), _limbs(r, 32, 8)
+    c_sign = -1 if is_sub else 1
+    # the coefficients d_0..d_31 of kappa_a a(X) b(X) - q(X) (bound(X) + 1) + borrow (bound(X) + 1) +- kappa_c C(X^2) - R(X^2): sums of at most
+    # 17 products of 17-bit limbs times a 9-bit scale stay far inside int64
+    d = np.zeros(UM_NUM_GAMMA + 1, dtype=np.int64)
+    d[0:31] = kappa_a * np.convolve(np.array(al, dtype=np.int64), np.array(bl, dtype=np.int64))
+    d[0:32] -= np.convolve(np.array(ql, dtype=np.int64), np.array(pl, dtype=np.int64))
+    d[0:UM_NUM_Q_LIMBS] -= np.array(ql, dtype=np.int64)
+    d[0:16] += borrow * np.array(pl, dtype=np.int64)
+    d[0] += borrow
+    d[0:16:2] += c_sign * kappa_c * np.array(c32, dtype=np.int64) - np.array(r32, dtype=np.int64)
+    halves, prev = [], 0
+    for k in range(UM_NUM_GAMMA):
+        num = int(d[k]) + prev
+        assert num % (1 << 16) == 0, "synthetic division must be exact"
+        g = num >> 16
+        assert abs(g) < UM_GAMMA_OFFSET, "carry outside its 2^31 window"
+        halves.append(((g + UM_GAMMA_OFFSET) & 0xffff, (g + UM_GAMMA_OFFSET) >> 16))
+        prev = g
+    assert int(d[UM_NUM_GAMMA]) + prev == 0, "the coefficient polynomial must vanish at 2^16"
+    return (a, bv, c, r, bound), ql, borrow, halves
+
+
+def uint_store_mul_trace(store, muls, bpl, min_height=0):
+    """`generate_trace` (uint/store_mul/trace.rs:36-71) = the multiplier's blocks (uint/mul/trace.rs:247-372: eight rows per relation,
+    all-zero blocks after; its reads of a, b, the bound over UintLimbs and of c, r over UintVal, and every Range16 limb, routed into the
+    ledgers) NEXT TO the store's (uint/trace.rs:266-375: four rows per stored value in pointer order, self-referential zero blocks after),
+    the shared height the larger of the two.  Runs after every relation chiplet has recorded its reads of the store."""
+    mul_h = 1 << (max(1, len(muls.ops)) * UM_PERIOD - 1).bit_length()
+    mul = np.zeros((mul_h, UM_COLS), dtype=np.uint64)
+    limbs = []                           # every Range16-checked cell, handed to the table's ledger in one go
+    for i, (op, mult) in enumerate(muls.ops):
+        kappa_a, kappa_c, a_ptr, b_ptr, c_ptr, r_ptr, bound_ptr, is_sub = op
+        for ptr in (a_ptr, b_ptr, bound_ptr):
+            store.require_uintlimbs(ptr)
+        store.require_uintval(c_ptr)
+        store.require_uintval(r_ptr)
+        (a, bv, c, r, bound), ql, borrow, halves = _um_witness(op, store)
+        limbs += ql + [h for pair in halves for h in pair] + [kappa_a, kappa_c]
+        r0 = UM_PERIOD * i
+        mul[r0 + UM_ROW_A, 0:16], mul[r0 + UM_ROW_B, 0:16], mul[r0 + UM_ROW_P, 0:16] = _limbs(a, 16, 16), _limbs(bv, 16, 16), _limbs(bound, 16, 16)
+        mul[r0 + UM_ROW_Q, 0:UM_NUM_Q_LIMBS] = ql
+        for slot, (row, cell) in enumerate(UM_GAMMA_SLOTS):
+            mul[r0 + row, cell] = halves[slot // 2][slot % 2]
+        mul[r0 + UM_ROW_R, 0:8], mul[r0 + UM_ROW_C, 0:8] = _limbs(r, 32, 8), _limbs(c, 32, 8)
+        mul[r0 + UM_ROW_C, UM_TERM_MULT:UM_TERM_KAPPA_C_SIGNED + 1] = [mult % P, c_ptr, kappa_c, is_sub, (P - kappa_c) % P if is_sub else kappa_c]
+        mul[r0:r0 + UM_PERIOD, UM_COL_A_PTR:UM_COLS] = [a_ptr, b_ptr, r_ptr, bound_ptr, kappa_a, 1, borrow]
+    ptrs = sorted(store.rows)
+    self_demand = {}
+    for ptr in ptrs:                     # every stored value reads its bound (`insert_pinned` / `intern`: demand.require(bound_ptr))
+        self_demand[store.rows[ptr][1]] = self_demand.get(store.rows[ptr][1], 0) + 1
+    n_blocks = max(1, 1 << (max(1, len(ptrs)) - 1).bit_length(), mul_h // US_PERIOD, min_height // US_PERIOD)
+    next_ptr = (ptrs[-1] + 1) if ptrs else 1
+    blocks = [(ptr, store.rows[ptr][0], store.rows[ptr][1], False) for ptr in ptrs] + \
+             [(next_ptr + k, 0, next_ptr + k, True) for k in range(n_blocks - len(ptrs))]
+    st = np.zeros((n_blocks * US_PERIOD, US_COLS), dtype=np.uint64)
+    for i, (ptr, value, bound_ptr, is_pad) in enumerate(blocks):
+        bound_v = 0 if is_pad else store.value(bound_ptr)
+        comp = bound_v - value
+        assert comp >= 0, "stored value exceeds its bound"
+        v16, comp16, bound32 = _limbs(value, 16, 16), _limbs(comp, 16, 16), _limbs(bound_v, 32, 8)
+        v32, comp32 = _limbs(value, 32, 8), _limbs(comp, 32, 8)
+        carries, carry = [], 0
+        for j in range(7):
+            carry = (v32[j] + comp32[j] + carry) >> 32
+            carries.append(carry)
+        gap = blocks[i + 1][0] - ptr - 1 if i + 1 < len(blocks) else 0
+        assert 0 <= gap < 1 << 16, "pointer gap outside its Range16 window"
+        limbs += v16 + comp16 + [gap]
+        r0 = US_PERIOD * i
+        st[r0, 0:8], st[r0 + 1, 0:8], st[r0 + 2, 0:16] = v16[0:8], v16[8:16], comp16
+        st[r0 + 1, US_HUB_UINTVAL_MULT] = (store.reads.get(ptr, 0) + self_demand.get(ptr, 0) + int(is_pad)) % P
+        st[r0 + 1, US_HUB_UINTLIMBS_MULT] = store.limb_reads.get(ptr, 0) % P
+        st[r0 + 3, 0:4], st[r0 + 3, US_CARRY_LO:US_CARRY_LO + 4] = bound32[0:4], carries[0:4]
+        st[r0 + 3, 8:12], st[r0 + 3, US_CARRY_HI:US_CARRY_HI + 3] = bound32[4:8], carries[4:7]
+        st[r0 + 3, US_TERM_GAP] = gap
+        st[r0:r0 + US_PERIOD, US_COL_PTR], st[r0:r0 + US_PERIOD, US_COL_BOUND_PTR] = ptr, bound_ptr
+    bpl.require_range16_many(limbs)
+    out = np.zeros((st.shape[0], USM_COLS), dtype=np.uint64)
+    out[:, 0:US_COLS] = st
+    out[0:mul_h, USM_MUL_OFF:] = mul
+    return out
+
+
 K1_BOUND = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2E                                    # secp256k1: p - 1
 K1_G = (0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798, 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8)
 
@@ -2325,8 +2655,8 @@ def ec_add_session(scalars, host_aux=None, min_height=8):
     """The reference's "arithmetic + EC stack" (tests/ec_add.rs, `SessionTraces::mains` order) on a workload: k G for every k of `scalars`
     by double-and-add over secp256k1, every addition a proven `EcGroupAdd` relation with one reader -- doubles, chords, pass-throughs from
     the point at infinity, results minted with closure certificates or deduplicated onto stored rows.  [BytePairLutAir (preprocessed),
-    the uint store / multiplier's sides of UintVal and UintMul + the relations' readers, UintAddAir, EcGroupsAir, EcPointStoreAir,
-    EcGroupAddAir].  -> ([(air, lookup)], [traces], (results, ledgers))"""
+    UintStoreMulAir, UintAddAir, EcGroupsAir, EcPointStoreAir, EcGroupAddAir, the relations' readers]: SIX real chiplets, every bus
+    between them closed by themselves.  -> ([(air, lookup)], [traces], (results, ledgers))"""
     store, adds, muls, ec, ec_add, bpl = UintStore(), UintAddRequires(), UintMulRequires(), EcStore(), EcAddRequires(), BytePairLutRequires()
     fp = store.pin_modulus(1, K1_BOUND)
     req = EcRequire(ec, store, muls, adds, ec_add)
@@ -2343,8 +2673,9 @@ def ec_add_session(scalars, host_aux=None, min_height=8):
     ec.require_fixed_groups()
     add = uint_add_trace(adds, store, min_height=min_height)
     ec_add_main = ec_group_add_trace(ec_add, ec, bpl, min_height=min_height)
-    foreign = requirer_trace(store.uint_val_requests() + muls.uint_mul_requests() + ec_add.consumer_requests(), payload=10)
+    uint = uint_store_mul_trace(store, muls, bpl, min_height=min_height)
+    readers = requirer_trace(ec_add.consumer_requests(), payload=10)
     groups, points = ec_store_traces(ec, min_height=min_height)
-    pairs = [byte_pair_lut_air(host_aux), requirer_air(host_aux, payload=10), uint_add_air(host_aux), ec_groups_air(host_aux),
-             ec_point_store_air(host_aux), ec_group_add_air(host_aux)]
-    return pairs, [byte_pair_lut_trace(bpl), foreign, add, groups, points, ec_add_main], (results, (store, adds, muls, ec, ec_add))
+    pairs = [byte_pair_lut_air(host_aux), uint_store_mul_air(host_aux), uint_add_air(host_aux), ec_groups_air(host_aux),
+             ec_point_store_air(host_aux), ec_group_add_air(host_aux), requirer_air(host_aux, payload=10)]
+    return pairs, [byte_pair_lut_trace(bpl), uint, add, groups, points, ec_add_main, readers], (results, (store, adds, muls, ec, ec_add))

@@ -20,12 +20,12 @@ static const uint64_t LOOKUP_MAGIC = 0x4d484c4b50303031ULL;  // "MHLKP001"
 
 // Aux REGISTER columns behind the LogUp columns (precompiles-prover/src/tests/aux_register.rs: an extension-field accumulator that must
 // live in the aux trace because it depends on the challenges, yet stays out of sigma; uint/store_mul/mod.rs:118-121 STORE_REG_ID,
-// MUL_REG_ID, MUL_REG_S): r[0] = 0, r[i + 1] = keep(i) r[i] + sum_j coeff_j(i) r_j[i] + build(i) over earlier registers r_j.  The
+// MUL_REG_ID, MUL_REG_S): r[0] = 0, r[i + 1] = keep(i) r[i] + sum_j coeff_j(i) r_j[i] + build(i) over other registers r_j.  The
 // reference computes them in each AIR's own build_aux_trace (uint/store_mul/trace.rs:73-140); here the recurrence is data of the program.
 struct Register {
   uint32_t keep = 0xFFFFFFFFu;  // node id, or NO_NODE = the constant 1
   uint32_t build = 0;
-  std::vector<std::pair<uint32_t, uint32_t>> terms;  // (earlier register, coefficient node)
+  std::vector<std::pair<uint32_t, uint32_t>> terms;  // (other register, coefficient node)
 };
 static const uint32_t NO_NODE = 0xFFFFFFFFu;
 
@@ -80,7 +80,7 @@ struct Lookup {
         p += 3;
         need(nt < 4096 && p + 2 * nt <= n);
         for (size_t t = 0; t < nt; t++) {
-          need(w[p + 2 * t] < k && w[p + 2 * t + 1] < l.dag.nodes.size());
+          need(w[p + 2 * t] < nr && w[p + 2 * t] != k && w[p + 2 * t + 1] < l.dag.nodes.size());  // row by row, any order works
           r.terms.push_back({(uint32_t)w[p + 2 * t], (uint32_t)w[p + 2 * t + 1]});
         }
         p += 2 * nt;

@@ -562,8 +562,9 @@ def test_ec_store_session_production_params(ctx):
 
 
 def ec_add_session(scalars):
-    """The reference's arithmetic + EC stack (tests/ec_add.rs) in its order: [BytePairLutAir (preprocessed), the uint store / multiplier's
-    bus sides, UintAddAir, EcGroupsAir, EcPointStoreAir, EcGroupAddAir (21 columns, twelve flattened LogUp columns on seven buses)]."""
+    """The reference's arithmetic + EC stack (tests/ec_add.rs) in its order, every chiplet real: [BytePairLutAir (preprocessed),
+    UintStoreMulAir (44 columns, 26 LogUp columns + 3 extension-field registers), UintAddAir, EcGroupsAir, EcPointStoreAir, EcGroupAddAir
+    (21 columns, twelve flattened LogUp columns on seven buses)] + the readers of the proven additions."""
     pairs, traces, _ = PA.ec_add_session(scalars, host_aux)
     return [p[0] for p in pairs], [p[1] for p in pairs], traces
 
@@ -573,6 +574,10 @@ def test_ec_add_session_device_proof_equals_oracle(ctx, jit, monkeypatch):
     pkg = load_package()
     monkeypatch.setenv("MH_JIT", jit)
     airs_, lookups, traces = ec_add_session([0xb5, 77, 0xb5, 1, 2, 3])
+    rnd = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
+    aux_dev, fin = pkg.DeviceLookup(ctx, lookups[1]).build_aux(ctx.upload_trace(traces[1]), rnd)     # 26 LogUp columns, then the three registers
+    aux, exp_fin = ob.lookup_build_aux(lookups[1], traces[1], rnd)
+    assert aux.shape[1] == 58 and (aux_dev.download() == aux).all() and fin == (int(exp_fin[0]), int(exp_fin[1]))
     exp = ob.prove(airs_, traces, ROOT, FAST, init_state=protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST))
     got, root, st, pre = device_prove(ctx, airs_, lookups, traces, FAST)
     assert list(root) == [int(x) for x in exp["preprocessed_root"]]
@@ -585,7 +590,7 @@ def test_ec_add_session_device_proof_equals_oracle(ctx, jit, monkeypatch):
     forged = traces[5].copy()
     forged[0:4, PA.EA_COL_MINTS] = 0
     forged[PA.EA_ROW_RES, PA.EA_CELL_R] = 2                             # the first block's result repointed at G: no valid proof
-    bad, root, st, pre = device_prove(ctx, airs_, lookups, traces[:5] + [forged], FAST)
+    bad, root, st, pre = device_prove(ctx, airs_, lookups, traces[:5] + [forged] + traces[6:], FAST)
     ok, _ = pkg.verify(airs_, bad.log_trace_heights, ROOT, FAST, st, pre, bad.fields, bad.commitments, preprocessed_root=root,
                        external=PA.external_assertions(pkg))
     assert not ok
