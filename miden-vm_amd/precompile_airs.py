@@ -1,9 +1,9 @@
 """The second client of the backend: AIRs of the precompile prover (`precompiles-prover/src`), hand-ported against `dag.AirBuilder`
 like the VM's three AIRs, and the statement layer of its session (`precompiles-prover/src/session/prove.rs`).
 
-What is here: nine of the twelve AIRs of `ChipletAir::all()` (session/prove.rs:111-126) -- the whole HASHING HALF of the
-session (ChunkNode, Poseidon2, KeccakRound, BytePairLut, KeccakSponge; ChunkNode also as its two stand-alone halves), UintAdd, and the
-elliptic-curve stores and group law (EcGroups, EcPointStore, EcGroupAdd) --
+What is here: ten of the twelve AIRs of `ChipletAir::all()` (session/prove.rs:111-126) -- the whole HASHING HALF of the
+session (ChunkNode, Poseidon2, KeccakRound, BytePairLut, KeccakSponge; ChunkNode also as its two stand-alone halves), the 256-bit
+ARITHMETIC (UintStoreMul, UintAdd), and the elliptic-curve stores and group law (EcGroups, EcPointStore, EcGroupAdd) --
 * `BytePairLutAir` (`primitives/byte_pair_lut.rs`): the one AIR of the stack with PREPROCESSED columns and a fixed height -- the
   2^16-row `(a, b, !a & b, a ^ b)` table committed once, three witness multiplicity columns, two LogUp columns;
 * `KeccakRoundAir` (`hash/keccak/round/{mod,program}.rs`): its consumer -- a three-address machine `c = ROL(a OP b, s)` whose 128-slot
@@ -35,16 +35,19 @@ elliptic-curve stores and group law (EcGroups, EcPointStore, EcGroupAdd) --
 * `EcGroupAddAir` (`ec/add/{mod,trace}.rs`, `ec/require.rs`): R = P + Q for ANY two stored points -- a near-one-hot over five cases whose
   flags ride the consumed `EcPoint` tuples, chord / tangent / tail arithmetic as pointer-level certificates consumed from the uint
   relation chiplets (no limb enters the trace), fresh results minted with closure certificates under a Range16-witnessed pointer
-  ordering; 21 columns, twelve LogUp columns on seven buses, four-row blocks.  With it the reference's "arithmetic + EC stack" runs over
-  FIVE real chiplets (BytePairLut, UintAdd, EcGroups, EcPointStore, EcGroupAdd): scalar multiples of a curve point, proven;
+  ordering; 21 columns, twelve LogUp columns on seven buses, four-row blocks;
+* `UintStoreMulAir` (`uint/{mod,trace}.rs`, `uint/mul/{mod,trace}.rs`, `uint/store_mul/{mod,trace}.rs`): the range-checked store of the
+  256-bit values and the scaled multiply-accumulate relation kappa_a a b +- kappa_c c = r (mod p) side by side on one row range; both
+  identities are vertical Schwartz-Zippel checks carried by three extension-field REGISTERS in the aux trace -- the one AIR of the
+  session whose `build_aux_trace` computes more than LogUp sums: here the lookup program's register tail, built on the device by a scan
+  over affine maps; 44 columns, 26 LogUp columns + 3 registers, 13 periodic columns.  With it the reference's "arithmetic + EC stack"
+  runs over SIX real chiplets (BytePairLut, UintStoreMul, UintAdd, EcGroups, EcPointStore, EcGroupAdd) with no stand-in: scalar
+  multiples of a curve point, every field operation proven;
 the precompile prover's LogUp adapter (natural last-row sigma closing, `logup/constraint.rs`: `dag.LogUp(closing="sigma_last_row")`),
 its bus registry (`relations.rs`) and `ChipletMultiAir::eval_external` (`session/prove.rs:259-272`: sum of the committed sigmas + the
 fixed boundary correction).
 
-What is not: the other three AIRs (TranscriptEval, the uint store / multiplier, the MSM ladder: ~9 kLoC of the reference).  UintStoreMul
-is also the one AIR of the session whose aux trace holds more than LogUp columns (three extension-field REGISTERS, Horner accumulators at
-the challenge beta): the device aux builder (`logup.hip`) builds LogUp columns only, such an AIR would go through the host callback
-(`mh_aux_builder`) as in the reference, where `build_aux_trace` is CPU code.  Where a statement needs the other side of a bus that only they touch -- the transcript's readers of the `Binding` tuples in
+What is not: the other two AIRs (TranscriptEval, the MSM ladder: ~4 kLoC of the reference).  Where a statement needs the other side of a bus that only they touch -- the transcript's readers of the `Binding` tuples in
 the hashing session, or, in the smaller sessions of the tests, whatever is left out (`sponge_side_requests`, `chunk_side_requests`,
 `keccak_hash_side_requests`, `poseidon2_out_requests`, `binding_requests`, the uint store's `uint_val_requests` and the multiplier's
 `uint_mul_requests` -- relations the ledgers check by value when they are recorded) -- it comes from `requirer_air`, a one-interaction-per-row
