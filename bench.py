@@ -610,7 +610,7 @@ def ec_add_session_probe(pkg, ctx, steps=3):
     ~6 000 proven point additions (doubles, chords, pass-throughs; results minted with closure certificates) over SIX real chiplets --
     BytePairLutAir (preprocessed), UintStoreMulAir (the uint store and the multiply-accumulate relation: 44 columns, 26 LogUp columns and
     three extension-field registers built by a scan over affine maps), UintAddAir, EcGroupsAir, EcPointStoreAir, EcGroupAddAir -- every
-    bus between them closed by themselves; production parameters, aux columns on the device, verified through `eval_external`."""
+    bus between them closed by themselves, over the session's fixed environment (the full `fixed_boundary_correction`); production parameters, aux columns on the device, verified through `eval_external`."""
     import random
     from miden_vm_amd import protocol, precompile_airs as PA
     rng = random.Random(5)
@@ -633,7 +633,7 @@ def ec_add_session_probe(pkg, ctx, steps=3):
     traces = [ctx.upload_trace(t) for t in host]
     proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
     ok, _ = pkg.verify(airs_h, proof.log_trace_heights, root_pub, prm, st, pre, proof.fields, proof.commitments, preprocessed_root=com.root(),
-                       external=PA.external_assertions(pkg))
+                       external=PA.external_assertions(pkg, fixed_uints=True))
     t0 = time.perf_counter()
     for _ in range(steps):
         proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)

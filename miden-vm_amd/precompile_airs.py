@@ -80,6 +80,12 @@ BPL_MAIN_COLS, BPL_AUX_COLS, BPL_PREP_COLS = 3, 2, 4
 # precompiles/src/math/curve/mod.rs:57-62, precompiles/src/math/uint/domain.rs:9-13: the fixed environment (session/fixed.rs)
 K1_GROUP_PTR, K1_A_PTR, K1_B_PTR, U256_BOUND_PTR, K1_BASE_BOUND_PTR, K1_SCALAR_BOUND_PTR = 1, 8, 9, 1, 2, 3
 FIXED_EC_GROUPS = [(K1_GROUP_PTR, K1_A_PTR, K1_B_PTR, K1_BASE_BOUND_PTR, K1_SCALAR_BOUND_PTR)]  # fixed_ecgroup_msgs, CurveId::ALL
+# `fixed_uints` (session/fixed.rs:15-31): (ptr, bound_ptr, value) -- the three domain bounds (moduli rows: their own bound; U256's is 2^256 - 1,
+# precompiles/src/math/{u256,k1_base,k1_scalar}.rs `minus_one`), then secp256k1's coefficients under the base-field bound
+FIXED_UINTS = [(U256_BOUND_PTR, U256_BOUND_PTR, (1 << 256) - 1),
+               (K1_BASE_BOUND_PTR, K1_BASE_BOUND_PTR, 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2E),
+               (K1_SCALAR_BOUND_PTR, K1_SCALAR_BOUND_PTR, 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364140),
+               (K1_A_PTR, K1_BASE_BOUND_PTR, 0), (K1_B_PTR, K1_BASE_BOUND_PTR, 7)]
 
 
 def _host_aux(air_lookup, host_aux, preprocessed=None):
@@ -284,22 +290,26 @@ def _encode(alpha, beta, bus, fields):
     return ((alpha[0] + (bus + 1) * pw[0] + acc[0]) % P, (alpha[1] + (bus + 1) * pw[1] + acc[1]) % P)
 
 
-def eval_external(randomness, aux_values):
-    """`ChipletMultiAir::eval_external`: sigma_sum(aux_values) + fixed_boundary_correction(challenges) (the `EcGroup` consumes of the
-    fixed curve groups; the `UintVal` ones belong to the uint store, not ported).  randomness = [alpha, beta] as (c0, c1) pairs;
-    aux_values[i] = AIR i's committed values (one sigma each).  -> [one EF value that must vanish]."""
+def eval_external(randomness, aux_values, fixed_uints=False):
+    """`ChipletMultiAir::eval_external` (session/prove.rs:243-256): sigma_sum(aux_values) + fixed_boundary_correction(challenges) (:205-216)
+    -- the verifier's `EcGroup` consumes of the fixed curve groups and, with `fixed_uints` (statements that run the real uint store with
+    the fixed environment installed), its `UintVal` consumes of the five fixed uints (session/fixed.rs).  randomness = [alpha, beta] as
+    (c0, c1) pairs; aux_values[i] = AIR i's committed values (one sigma each).  -> [one EF value that must vanish]."""
     alpha, beta = randomness[0], randomness[1]
     s = (0, 0)
     for av in aux_values:
         s = ((s[0] + av[0][0]) % P, (s[1] + av[0][1]) % P)
-    for g in FIXED_EC_GROUPS:
-        inv = _e_inv(_encode(alpha, beta, BUS_EC_GROUP, list(g)))
+    msgs = [(BUS_EC_GROUP, list(g)) for g in FIXED_EC_GROUPS]
+    if fixed_uints:
+        msgs += [(BUS_UINT_VAL, [ptr, bound_ptr] + [(v >> (32 * j)) & 0xffffffff for j in range(8)]) for ptr, bound_ptr, v in FIXED_UINTS]
+    for bus, fields in msgs:
+        inv = _e_inv(_encode(alpha, beta, bus, fields))
         s = ((s[0] + inv[0]) % P, (s[1] + inv[1]) % P)
     return [s]
 
 
-def external_assertions(pkg):
-    return pkg.external_callback(lambda rnd, aux_values, lhs: eval_external(rnd, aux_values))
+def external_assertions(pkg, fixed_uints=False):
+    return pkg.external_callback(lambda rnd, aux_values, lhs: eval_external(rnd, aux_values, fixed_uints))
 
 
 # ---- Chunk: the input-byte tape of the hashers (hash/chunk/{mod,message,trace}.rs) ------------------------------------------------------
@@ -1685,6 +1695,13 @@ class UintStore:
         assert 1 <= ptr < self.PIN_NAMESPACE_END, "pinned uint ptr outside the pin namespace [1, 2^16)"
         return self._insert(ptr, bound, ptr)
 
+    def install_fixed_uints(self):
+        """`Session::install_fixed_uints` (session/mod.rs:127-138): the VM-owned rows, each read once by the verifier's boundary term."""
+        for ptr, bound_ptr, value in FIXED_UINTS:
+            (self.pin_modulus(ptr, value) if ptr == bound_ptr else self.intern_pinned(ptr, value, bound_ptr))
+            self.require_uintval(ptr)
+        return self
+
     def intern_pinned(self, ptr, value, bound_ptr):
         assert 1 <= ptr < self.PIN_NAMESPACE_END, "pinned uint ptr outside the pin namespace [1, 2^16)"
         assert 0 <= value <= self.rows[bound_ptr][0], "value exceeds its modulus bound"
@@ -2659,11 +2676,14 @@ def ec_add_session(scalars, host_aux=None, min_height=8):
     by double-and-add over secp256k1, every addition a proven `EcGroupAdd` relation with one reader -- doubles, chords, pass-throughs from
     the point at infinity, results minted with closure certificates or deduplicated onto stored rows.  [BytePairLutAir (preprocessed),
     UintStoreMulAir, UintAddAir, EcGroupsAir, EcPointStoreAir, EcGroupAddAir, the relations' readers]: SIX real chiplets, every bus
-    between them closed by themselves.  -> ([(air, lookup)], [traces], (results, ledgers))"""
+    between them closed by themselves, over the session's fixed environment (the VM-owned moduli, curve coefficients and group slot):
+    the statement closes through `eval_external(.., fixed_uints=True)`.  -> ([(air, lookup)], [traces], (results, ledgers))"""
     store, adds, muls, ec, ec_add, bpl = UintStore(), UintAddRequires(), UintMulRequires(), EcStore(), EcAddRequires(), BytePairLutRequires()
-    fp = store.pin_modulus(1, K1_BOUND)
+    store.install_fixed_uints()          # `Session::new`: the fixed environment; the statement closes through the FULL boundary correction
+    fp = K1_BASE_BOUND_PTR
     req = EcRequire(ec, store, muls, adds, ec_add)
     group, pai = req.create_group(0, 7, fp)
+    assert group == K1_GROUP_PTR, "the curve's coefficients resolve to the VM-owned rows, the group to the VM-owned slot"
     g_pt = req.add_point(group, *K1_G)
     results = []
     for k in scalars:

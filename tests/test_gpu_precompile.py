@@ -585,14 +585,14 @@ def test_ec_add_session_device_proof_equals_oracle(ctx, jit, monkeypatch):
     assert got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all()
     assert (got.digest == exp["digest"]).all()
     ok, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, FAST, st, pre, got.fields, got.commitments, preprocessed_root=root,
-                         external=PA.external_assertions(pkg))
+                         external=PA.external_assertions(pkg, fixed_uints=True))
     assert ok and (dig == got.digest).all()
     forged = traces[5].copy()
     forged[0:4, PA.EA_COL_MINTS] = 0
     forged[PA.EA_ROW_RES, PA.EA_CELL_R] = 2                             # the first block's result repointed at G: no valid proof
     bad, root, st, pre = device_prove(ctx, airs_, lookups, traces[:5] + [forged] + traces[6:], FAST)
     ok, _ = pkg.verify(airs_, bad.log_trace_heights, ROOT, FAST, st, pre, bad.fields, bad.commitments, preprocessed_root=root,
-                       external=PA.external_assertions(pkg))
+                       external=PA.external_assertions(pkg, fixed_uints=True))
     assert not ok
 
 
@@ -607,8 +607,8 @@ def test_ec_add_session_production_params(ctx):
     got, root, st, pre = device_prove(ctx, airs_, lookups, traces, prm)
     assert got.log_trace_heights[0] == 16 and got.log_trace_heights[5] >= 14
     ok, msg = ob.verify(airs_, got.log_trace_heights, ROOT, {"fields": got.fields, "commitments": got.commitments}, prm,
-                        init_state=st, pre_observe=pre, external=PA.external_assertions(pkg))
+                        init_state=st, pre_observe=pre, external=PA.external_assertions(pkg, fixed_uints=True))
     assert ok, msg
     ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, preprocessed_root=root,
-                          external=PA.external_assertions(pkg))
+                          external=PA.external_assertions(pkg, fixed_uints=True))
     assert ok2 and (dig == got.digest).all()

@@ -392,4 +392,6 @@ def test_the_session_builder_computes_multiples_and_closes(airs):
     cases = [op["case"] for op, _ in ec_add.ops]
     assert {"pai_both", "pai_p", "double", "generic"} <= set(cases) and max(m for _, m in ec_add.ops) > 1
     check_all(pairs, traces)
-    assert PA.eval_external(RND, [[sigma(pair, t)] for pair, t in zip(pairs, traces)]) == [(0, 0)]
+    sig = [[sigma(pair, t)] for pair, t in zip(pairs, traces)]
+    assert PA.eval_external(RND, sig, fixed_uints=True) == [(0, 0)] and PA.eval_external(RND, sig) != [(0, 0)], "the full boundary correction"
+    assert ec.group_params(1) == (PA.K1_A_PTR, PA.K1_B_PTR, PA.K1_BASE_BOUND_PTR) and len(ec.groups) == 1, "the VM-owned curve slot"
