@@ -134,7 +134,7 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_add_offsets(u64* __restrict__ o
 // ---- register columns: r[0] = 0, r[i + 1] = keep(i) r[i] + build(i) -- an exclusive scan over the affine maps x -> keep(i) x + build(i) ----
 // (precompiles-prover/src/uint/store_mul/trace.rs:73-140 computes its three registers row by row on the CPU; tests/aux_register.rs is the
 // smallest case.)  The composition (k2, b2) o (k1, b1) = (k2 k1, k2 b1 + b2) is associative, so the same three phases as the sums above
-// apply: tile aggregates, a walk over the tiles, the tiles again from their start values.  `build` already holds the contributions of
+// apply: tile aggregates, a scan over the tiles' aggregates, the tiles again from their start values.  `build` already holds the contributions of
 // the earlier registers (k_reg_build).  Planes may be absent: keep0 == nullptr is keep = 1, a missing c1 plane is a base-field value.
 struct AffArgs {
   const u64 *k0, *k1, *b0, *b1;
@@ -195,15 +195,43 @@ __global__ __launch_bounds__(SCAN_T) void k_affine_tiles(AffArgs a) {
     run = e2_add(e2_mul(v[i].k, run), v[i].b);
   }
 }
-// phase 2: the register's value at the first row of every tile (a walk: at most n / 2048 steps)
-__global__ void k_affine_tile_starts(AffArgs a) {
-  if (blockIdx.x || threadIdx.x) return;
-  e2 run = e2_make(0);
-  for (size_t t = 0; t < a.tiles; t++) {
-    const e2 k = e2{a.tile_k[t], a.tile_k[a.tiles + t]}, b = e2{a.tile_b[t], a.tile_b[a.tiles + t]};
-    a.tile_b[t] = run.c0;
-    a.tile_b[a.tiles + t] = run.c1;
-    run = e2_add(e2_mul(k, run), b);
+// phase 2: the register's value at the first row of every tile: one workgroup scans the tile aggregates, 256 tiles per round
+__global__ __launch_bounds__(SCAN_T) void k_affine_tile_starts(AffArgs a) {
+  __shared__ u64 part[4][SCAN_T];
+  __shared__ u64 carry[2];
+  auto put = [&](Aff x) {
+    part[0][threadIdx.x] = x.k.c0; part[1][threadIdx.x] = x.k.c1; part[2][threadIdx.x] = x.b.c0; part[3][threadIdx.x] = x.b.c1;
+  };
+  auto get = [&](unsigned t) { return Aff{e2{part[0][t], part[1][t]}, e2{part[2][t], part[3][t]}}; };
+  if (threadIdx.x == 0) carry[0] = carry[1] = 0;
+  __syncthreads();
+  for (size_t base = 0; base < a.tiles; base += SCAN_T) {
+    const size_t t = base + threadIdx.x;
+    const Aff own = t < a.tiles ? Aff{e2{a.tile_k[t], a.tile_k[a.tiles + t]}, e2{a.tile_b[t], a.tile_b[a.tiles + t]}} : Aff{e2_make(1), e2_make(0)};
+    put(own);
+    __syncthreads();
+    for (int off = 1; off < SCAN_T; off <<= 1) {
+      const bool has = threadIdx.x >= (unsigned)off;
+      Aff before = has ? get(threadIdx.x - off) : Aff{e2_make(1), e2_make(0)};
+      __syncthreads();
+      if (has) put(aff_then(before, get(threadIdx.x)));
+      __syncthreads();
+    }
+    const e2 start = e2{carry[0], carry[1]};
+    const Aff pre = threadIdx.x ? get(threadIdx.x - 1) : Aff{e2_make(1), e2_make(0)};
+    const Aff all = get(SCAN_T - 1);
+    __syncthreads();
+    if (t < a.tiles) {
+      const e2 v = e2_add(e2_mul(pre.k, start), pre.b);
+      a.tile_b[t] = v.c0;
+      a.tile_b[a.tiles + t] = v.c1;
+    }
+    if (threadIdx.x == 0) {
+      const e2 nx = e2_add(e2_mul(all.k, start), all.b);
+      carry[0] = nx.c0;
+      carry[1] = nx.c1;
+    }
+    __syncthreads();
   }
 }
 // build(i) += sum_j coeff_j(i) r_j[i] over the earlier registers a register reads
@@ -313,7 +341,7 @@ mh_trace* lookup_build_aux(mh_ctx* c, const mh_lookup* lk, const mh_trace* main,
           a.b0 = rb.b0; a.b1 = rb.b1;
         }
         MH_LAUNCH(k_affine_tiles<false>, dim3((unsigned)tiles), dim3(SCAN_T), 0, c->stream, a);
-        MH_LAUNCH(k_affine_tile_starts, dim3(1), dim3(1), 0, c->stream, a);
+        MH_LAUNCH(k_affine_tile_starts, dim3(1), dim3(SCAN_T), 0, c->stream, a);
         MH_LAUNCH(k_affine_tiles<true>, dim3((unsigned)tiles), dim3(SCAN_T), 0, c->stream, a);
       }
     }

@@ -82,6 +82,12 @@ def _prove_worker(rank, world, port, case, ret):
             airs_, traces, pub = [air], [A.logup_trace(8)], []
             prm = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=6,
                        query_pow_bits=3)
+        elif case == "registers":  # aux register columns behind the LogUp columns (tests/test_aux_registers.py), built on every rank
+            import test_aux_registers as R
+            air, lookup = R.chain_air()
+            airs_, traces, pub = [air], [R.chain_trace(1 << 9, seed=4)], [5, 6, 7, 8]
+            prm = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=6,
+                       query_pow_bits=3)
         else:  # two AIRs with aux columns, selectors, periodic columns, different heights (D = 2)
             t1, pub = A.fib_trace(8)
             airs_, traces = [A.periodic_air(3), A.fib_air()], [A.periodic_trace(6), t1]
@@ -102,6 +108,9 @@ def _prove_worker(rank, world, port, case, ret):
             need_cb = False
         if case == "logup_compiled":
             assert dairs[0].compiled_chunks > 1
+            dairs[0].attach_lookup(pkg.DeviceLookup(ctx, lookup))
+            need_cb = False
+        if case == "registers":
             dairs[0].attach_lookup(pkg.DeviceLookup(ctx, lookup))
             need_cb = False
 
@@ -136,7 +145,7 @@ def _prove_worker(rank, world, port, case, ret):
 
 
 @pytest.mark.parametrize("world,case", [(2, "miden_small"), (8, "miden_small"), (2, "multi"), (2, "logup_compiled"), (2, "range_preprocessed"), (4, "miden"),
-                                        (8, "miden")])
+                                        (8, "miden"), (2, "registers"), (4, "registers")])
 def test_sharded_proof_equals_single_gpu_proof(world, case):
     port = 29500 + (os.getpid() + 31 * world + len(case)) % 2000
     mgr = mp.get_context("spawn").Manager()
