@@ -603,6 +603,44 @@ def uint_add_session_probe(pkg, ctx, steps=3):
             "trace_generation_s": gen_s}
 
 
+def uint_arith_session_probe(pkg, ctx, steps=3):
+    """The second client's 256-bit arithmetic with every chiplet real (precompiles-prover/src/uint: `UintStoreMulAir` -- the range-checked
+    store and kappa_a a b +- kappa_c c = r (mod p) by vertical Schwartz-Zippel identities carried in three aux REGISTER columns -- and
+    `UintAddAir`): a Horner evaluation over the secp256k1 base field, 2^14 proven multiply-accumulates + 2^14 proven modular additions over
+    49 159 stored values (2^18 rows x 44 + 29 EF, 2^15 x 30 + 3), the 2^16-row preprocessed table, the fixed environment; production parameters, aux columns
+    (26 LogUp + 3 registers) on the device, verified through the full `eval_external`."""
+    from miden_vm_amd import protocol, precompile_airs as PA
+    t0 = time.perf_counter()
+    n_steps = 1 << 14
+    pairs, host, (final, (store, adds, muls)) = PA.uint_arith_session(n_steps)
+    gen_s = time.perf_counter() - t0
+    airs_h = [p_[0] for p_ in pairs]
+    prm = dict(protocol.PROD_PARAMS)
+    root_pub = [101, 102, 103, 104]
+    dairs = [pkg.DeviceAir(ctx, a) for a in airs_h]
+    raw = ctx.upload_trace(airs_h[0].preprocessed)
+    com = pkg.commit_traces(ctx, [raw], prm["log_blowup"])
+    dairs[0].attach_preprocessed(com.tree(), 0, raw=raw)
+    for d, (_, lk) in zip(dairs, pairs):
+        d.attach_lookup(pkg.DeviceLookup(ctx, lk))
+    st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
+    pre = protocol.protocol_pre_observe(prm, root_pub, preprocessed_root=com.root())
+    traces = [ctx.upload_trace(t) for t in host]
+    proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    ok, _ = pkg.verify(airs_h, proof.log_trace_heights, root_pub, prm, st, pre, proof.fields, proof.commitments, preprocessed_root=com.root(),
+                       external=PA.external_assertions(pkg, fixed_uints=True))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    dt = (time.perf_counter() - t0) / steps
+    for t in traces:
+        t.free()
+    return {"workload": "uint arithmetic session: BytePairLutAir (preprocessed), UintStoreMulAir 44 + 29 EF aux (26 LogUp columns, 3 registers), UintAddAir 30 + 3, EcGroupsAir, the relations' readers; the fixed environment; production parameters, aux columns on the device",
+            "modular_macs": len(muls.ops), "modular_additions": len(adds.ops), "stored_uints": len(store.rows), "log_trace_heights": proof.log_trace_heights,
+            "ms_per_proof": dt * 1e3, "modular_macs_per_s": len(muls.ops) / dt, "proof_bytes": len(proof.bytes), "verifies_with_eval_external": bool(ok),
+            "horner_value": hex(final), "compiled_chunks": [a.compiled_chunks for a in dairs], "trace_generation_s": gen_s}
+
+
 def ec_add_session_probe(pkg, ctx, steps=3):
     """The second client's group-law chiplet (precompiles-prover/src/ec/add: `EcGroupAddAir`, 21 columns, twelve flattened LogUp columns on
     seven buses, four-row blocks; every piece of field arithmetic a pointer-level certificate consumed from the uint chiplets) inside the
@@ -1284,6 +1322,10 @@ def main():
             out["ec_add_session"] = ec_add_session_probe(pkg, ctx)
         except Exception as e:
             out["ec_add_session"] = {"error": repr(e)[:300]}
+        try:
+            out["uint_arith_session"] = uint_arith_session_probe(pkg, ctx)
+        except Exception as e:
+            out["uint_arith_session"] = {"error": repr(e)[:300]}
         try:
             # the service-level probes run in a process of their own (tools/bench_inflight_h2d.py, no torch in it): measured in THIS
             # process, which also hosts PyTorch's HIP runtime, the same loops lose the copy / kernel overlap (k = 1 with its uploads

@@ -210,7 +210,7 @@ def ec_groups_trace(groups=None, log_n=3):
     return t
 
 
-# ---- the requests of the chiplets that are not ported --------------------------------------------------------------------------------
+# ---- the requests of chiplets a statement leaves out ---------------------------------------------------------------------------------
 REQUIRER_COLS = 2 + 4  # multiplicity | bus id + 1 | up to four payload felts
 
 
@@ -1677,7 +1677,8 @@ def uint_add_air(host_aux=None):
 class UintStore:
     """The part of `UintStoreRequires` (uint/trace.rs) the relation chiplets drive: 256-bit values at pointers, each under a modulus row
     (`bound` = p - 1 stored at `bound_ptr`, a modulus row being its own bound), interned by (value, bound_ptr); `require_uintval` counts
-    the readers of a row.  The store AIR itself (UintStoreMul) is not ported: `uint_val_requests` is what it puts on the UintVal bus."""
+    the readers of a row.  `uint_store_mul_trace` lays it out as the store's half of `UintStoreMulAir`; the smaller sessions that leave that
+    AIR out take its side of the UintVal bus from `uint_val_requests`."""
 
     PIN_NAMESPACE_END = 1 << 16                                         # uint/trace.rs:97: pinned rows below, interned transients from here on
 
@@ -1805,7 +1806,7 @@ def uint_add_trace(requires, store, min_height=0):
 
 
 def uint_add_consumer_requests(requires):
-    """The readers of the relations (the eval chip's add / sub / neg nodes, the EC group law: not ported):
+    """The readers of the relations in sessions without them (the EC group law; the eval chip's add / sub / neg nodes are not ported):
     -> [(BUS_UINT_ADD, multiplicity, [bound_ptr, a_ptr, b_ptr, c_ptr, nz])]"""
     return [(BUS_UINT_ADD, mult, [bound, a, bptr or 0, cptr or 0, int(nz)]) for (a, bptr, cptr, bound, nz), mult in requires.ops if mult]
 
@@ -1886,7 +1887,7 @@ def ec_point_store_air(host_aux=None):
 class UintMulRequires:
     """The ledger of `UintMulRequires::record` / `record_sub` (uint/mul/trace.rs:191-245): scaled multiply-accumulates
     kappa_a a b +- kappa_c c = r (mod bound + 1) over store pointers, deduplicated, multiplicities summed.  The chiplet that proves them
-    (UintStoreMul) is not ported: `uint_mul_requests` is what it puts on the UintMul bus."""
+    is UintStoreMul (`uint_store_mul_trace`); sessions that leave it out take its side of the UintMul bus from `uint_mul_requests`."""
 
     def __init__(self):
         self.ops, self.dedup = [], {}
@@ -1977,7 +1978,7 @@ class EcStore:
         return self.pai_rows[group]
 
     def ec_point_requests(self):
-        """The readers of the points (EcGroupAdd, EcMsm: not ported) -> [(BUS_EC_POINT, demand, [ptr, group, x_ptr, y_ptr, is_pai])]."""
+        """The readers of the points in sessions without them (EcGroupAdd; EcMsm and the eval chip are not ported) -> [(BUS_EC_POINT, demand, [ptr, group, x_ptr, y_ptr, is_pai])]."""
         out = []
         for ptr, n in sorted(self.point_demand.items()):
             group, binding = self.points[ptr - 1]
@@ -2702,3 +2703,26 @@ def ec_add_session(scalars, host_aux=None, min_height=8):
     pairs = [byte_pair_lut_air(host_aux), uint_store_mul_air(host_aux), uint_add_air(host_aux), ec_groups_air(host_aux),
              ec_point_store_air(host_aux), ec_group_add_air(host_aux), requirer_air(host_aux, payload=10)]
     return pairs, [byte_pair_lut_trace(bpl), uint, add, groups, points, ec_add_main, readers], (results, (store, adds, muls, ec, ec_add))
+
+
+def uint_arith_session(n_steps, seed=7, host_aux=None, min_height=8):
+    """The 256-bit arithmetic of the session on a workload, every chiplet real: a Horner evaluation acc <- acc x + c_i (mod p) over the
+    secp256k1 base field, `n_steps` proven multiply-accumulates, each followed by a proven modular addition s_i = acc + c_i, over the
+    fixed environment.  [BytePairLutAir (preprocessed), UintStoreMulAir, UintAddAir, EcGroupsAir, the relations' readers].
+    -> ([(air, lookup)], [traces], (final value, ledgers))"""
+    import random
+    rng = random.Random(seed)
+    store, adds, muls, bpl = UintStore().install_fixed_uints(), UintAddRequires(), UintMulRequires(), BytePairLutRequires()
+    fp, m = K1_BASE_BOUND_PTR, K1_BOUND + 1
+    req = EcRequire(None, store, muls, adds, None)
+    x = store.intern(rng.randrange(2, m), fp)
+    acc = store.intern(rng.randrange(m), fp)
+    for _ in range(n_steps):
+        c = store.intern(rng.randrange(m), fp)
+        acc = req._mac(1, acc, x, 1, c)
+        req._uint_add(acc, c)
+    add = uint_add_trace(adds, store, min_height=min_height)
+    uint = uint_store_mul_trace(store, muls, bpl, min_height=min_height)
+    readers = requirer_trace([(bus, (P - mult) % P, f) for bus, mult, f in muls.uint_mul_requests()] + uint_add_consumer_requests(adds), payload=10)
+    pairs = [byte_pair_lut_air(host_aux), uint_store_mul_air(host_aux), uint_add_air(host_aux), ec_groups_air(host_aux), requirer_air(host_aux, payload=10)]
+    return pairs, [byte_pair_lut_trace(bpl), uint, add, ec_groups_trace(), readers], (store.value(acc), (store, adds, muls))

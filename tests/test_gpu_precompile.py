@@ -612,3 +612,23 @@ def test_ec_add_session_production_params(ctx):
     ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, preprocessed_root=root,
                           external=PA.external_assertions(pkg, fixed_uints=True))
     assert ok2 and (dig == got.digest).all()
+
+
+def test_uint_arith_session_production_params(ctx):
+    """4 000 proven multiply-accumulates and as many modular additions over the secp256k1 base field, the store, the multiplier and the
+    adder real, over the fixed environment; production parameters: device aux == oracle on the 58-word rows, verify through both verifiers."""
+    pkg = load_package()
+    pairs, traces, _ = PA.uint_arith_session(4000, host_aux=host_aux)
+    airs_, lookups = [p[0] for p in pairs], [p[1] for p in pairs]
+    prm = dict(protocol.PROD_PARAMS)
+    got, root, st, pre = device_prove(ctx, airs_, lookups, traces, prm)
+    assert got.log_trace_heights[1] == 15
+    ok, msg = ob.verify(airs_, got.log_trace_heights, ROOT, {"fields": got.fields, "commitments": got.commitments}, prm,
+                        init_state=st, pre_observe=pre, external=PA.external_assertions(pkg, fixed_uints=True))
+    assert ok, msg
+    ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, preprocessed_root=root,
+                          external=PA.external_assertions(pkg, fixed_uints=True))
+    assert ok2 and (dig == got.digest).all()
+    ok3, _ = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, preprocessed_root=root,
+                        external=PA.external_assertions(pkg))
+    assert not ok3, "without the verifier's UintVal consumes of the fixed rows the statement does not close"

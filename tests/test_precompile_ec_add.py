@@ -1,9 +1,9 @@
 """The group-law chiplet of the precompile prover (`EcGroupAddAir`, precompiles-prover/src/ec/add/{mod,trace}.rs, the recording layer
 ec/require.rs) as ported in miden-vm_amd/precompile_airs.py: the reference's own unit tests (precompiles-prover/src/tests/ec_add.rs)
 replayed over the reference's "arithmetic + EC stack" in its order -- [BytePairLutAir, the uint store / multiplier's sides of the UintVal and
-UintMul buses, UintAddAir, EcGroupsAir, EcPointStoreAir, EcGroupAddAir] -- FIVE real chiplets and one stand-in (UintStoreMul is not ported:
-its provides are the ledgers' own tuples, whose arithmetic the ledgers check by value when they are recorded).  Host only; device parity in
-tests/test_gpu_precompile.py.
+UintMul buses, UintAddAir, EcGroupsAir, EcPointStoreAir, EcGroupAddAir] -- FIVE real chiplets here, with UintStoreMul's provides taken from
+the ledgers' own tuples (checked by value when they are recorded); tests/test_precompile_uint_store_mul.py closes the same stack over
+all SIX real chiplets.  Host only; device parity in tests/test_gpu_precompile.py.
 
   ec_add_matches_k256 (here against an independent affine chord-and-tangent in Python integers), create_group_dedups_by_curve,
   generic_add_computes_kat (3G), duplicate_adds_collapse, double_binds_canonically, cancel_resolves_to_canonical_pai,

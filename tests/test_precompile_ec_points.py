@@ -9,8 +9,8 @@ tests/test_gpu_precompile.py.
   pai_with_coordinates_rejected, duplicate_point_ptr_rejected, phantom_group_unbalances, group_ptr_chain_is_ungated,
   forged_group_mult_unbalances, empty_stores_hold, inactive_point_row_cannot_provide
 
-The EcGroup bus closes between the two real AIRs.  The membership trio's provider (UintStoreMul) is not ported: its side of the UintMul
-bus is the MAC ledger's own tuples -- whose arithmetic the ledger checks by value when they are recorded -- so `off_curve_point_unbalances`
+The EcGroup bus closes between the two real AIRs.  The membership trio's provider (UintStoreMul) is left out of these statements (it joins
+in tests/test_precompile_uint_store_mul.py): its side of the UintMul bus is the MAC ledger's own tuples -- whose arithmetic the ledger checks by value when they are recorded -- so `off_curve_point_unbalances`
 rejects for the reference's reason: the forged row names a relation nothing recorded."""
 import numpy as np
 import pytest

@@ -11,7 +11,7 @@ Schwartz-Zippel" a(beta) + b(beta) - c(beta) - k (bound(beta) + 1) + (beta - 2^3
   add_inactive_block_cannot_provide, nz_cert_forged_zero_rejected, nz_cert_wrong_ws_rejected
   add_buses_balance_against_store, negation_holds_and_balances, equality_certificate_holds_and_balances, nz_cert_holds_and_balances,
   add_pad_blocks_stay_off_the_bus                                        balance against the store's UintVal provides (the store AIR is
-                                                                        not ported: its tuples come from the `UintStore` ledger)
+                                                                        left out here: its tuples come from the `UintStore` ledger)
   duplicate_relations_collapse, log_quotient_degree_matches_design_target (1)"""
 import random
 import numpy as np

@@ -306,3 +306,14 @@ def test_the_six_chiplet_stack_proves_and_forgeries_do_not(stack_airs):
     forged = mains[1].copy()
     forged[PA.UM_ROW_R, PA.USM_MUL_OFF + 2] = (int(forged[PA.UM_ROW_R, PA.USM_MUL_OFF + 2]) + 1) % P     # a limb of a product: the register does not close
     assert run([mains[0], forged] + mains[2:]) == (False, False)
+
+
+def test_the_arithmetic_session_builder_closes_over_the_fixed_environment():
+    pairs, traces, (final, (store, adds, muls)) = PA.uint_arith_session(20, host_aux=host_aux)
+    assert len(muls.ops) == 20 and len(adds.ops) == 20 and traces[1].shape == (512, 44), "5 fixed + 2 + 60 values = 67 blocks pad to 128"
+    for pair, t in zip(pairs, traces):
+        assert check(pair, t) == (0, None), pair[0].name
+    sig = [[sigma(pair, t)] for pair, t in zip(pairs, traces)]
+    assert PA.eval_external(RND, sig, fixed_uints=True) == [(0, 0)] and PA.eval_external(RND, sig) != [(0, 0)]
+    assert [int(traces[1][4 * k, PA.US_COL_PTR]) for k in range(6)] == [1, 2, 3, 8, 9, 1 << 16], "the fixed rows, then the transients"
+    assert [int(traces[1][4 * k + 3, PA.US_TERM_GAP]) for k in range(5)] == [0, 0, 4, 0, (1 << 16) - 10]
