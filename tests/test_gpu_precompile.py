@@ -622,7 +622,7 @@ def test_uint_arith_session_production_params(ctx):
     airs_, lookups = [p[0] for p in pairs], [p[1] for p in pairs]
     prm = dict(protocol.PROD_PARAMS)
     got, root, st, pre = device_prove(ctx, airs_, lookups, traces, prm)
-    assert got.log_trace_heights[1] == 15
+    assert got.log_trace_heights[1] == 16
     ok, msg = ob.verify(airs_, got.log_trace_heights, ROOT, {"fields": got.fields, "commitments": got.commitments}, prm,
                         init_state=st, pre_observe=pre, external=PA.external_assertions(pkg, fixed_uints=True))
     assert ok, msg
