@@ -603,6 +603,49 @@ def uint_add_session_probe(pkg, ctx, steps=3):
             "trace_generation_s": gen_s}
 
 
+def ec_msm_session_probe(pkg, ctx, steps=3):
+    """The second client's MSM chiplet (precompiles-prover/src/ec/msm: `EcMsmAir`, symbolic multi-scalar-multiplication expressions built
+    by intro / neg / combine steps the AIR checks one by one: variable-length blocks, merge walks over sorted term lists, a strict pointer
+    ordering) on top of the arithmetic + EC stack, SEVEN real chiplets over the fixed environment: sum of eight terms k_i P_i with 256-bit
+    scalars by Straus' interleaved double-and-add over expressions (~1 280 proven merge steps, each with a proven point addition and its
+    proven field arithmetic); production parameters, aux columns on the device, verified through the full `eval_external`."""
+    import random
+    from miden_vm_amd import protocol, precompile_airs as PA
+    rng = random.Random(8)
+    t0 = time.perf_counter()
+    terms = [(rng.getrandbits(256) % PA.K1_BOUND, m) for m in (1, 2, 3, 5, 7, 11, 13, 17)]
+    pairs, host, (val, expr, (store, adds, muls, ec, ec_add, msm)) = PA.ec_msm_session(terms)
+    gen_s = time.perf_counter() - t0
+    x_ptr, _ = ec.point_params(val)[1]
+    airs_h = [p_[0] for p_ in pairs]
+    prm = dict(protocol.PROD_PARAMS)
+    root_pub = [111, 112, 113, 114]
+    dairs = [pkg.DeviceAir(ctx, a) for a in airs_h]
+    raw = ctx.upload_trace(airs_h[0].preprocessed)
+    com = pkg.commit_traces(ctx, [raw], prm["log_blowup"])
+    dairs[0].attach_preprocessed(com.tree(), 0, raw=raw)
+    for d, (_, lk) in zip(dairs, pairs):
+        d.attach_lookup(pkg.DeviceLookup(ctx, lk))
+    st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
+    pre = protocol.protocol_pre_observe(prm, root_pub, preprocessed_root=com.root())
+    traces = [ctx.upload_trace(t) for t in host]
+    ext = PA.external_assertions(pkg, fixed_uints=True)
+    proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    ok, _ = pkg.verify(airs_h, proof.log_trace_heights, root_pub, prm, st, pre, proof.fields, proof.commitments, preprocessed_root=com.root(), external=ext)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    dt = (time.perf_counter() - t0) / steps
+    for t in traces:
+        t.free()
+    return {"workload": "MSM session in SessionTraces::mains order: BytePairLutAir (preprocessed), UintStoreMulAir 44 + 29 EF aux, UintAddAir 30 + 3, EcGroupsAir, EcPointStoreAir 14 + 5, EcGroupAddAir 21 + 12, EcMsmAir 38 + 11 EF aux, the resolve's readers; the fixed environment; production parameters, aux columns on the device",
+            "msm_terms": len(terms), "scalar_bits": 256, "expressions": len(msm.exprs), "term_rows": sum(len(e["rows"]) for e in msm.exprs),
+            "point_additions": len(ec_add.ops), "modular_additions": len(adds.ops), "modular_macs": len(muls.ops), "stored_uints": len(store.rows),
+            "log_trace_heights": proof.log_trace_heights, "ms_per_proof": dt * 1e3, "msm_per_s": 1.0 / dt, "proof_bytes": len(proof.bytes),
+            "verifies_with_eval_external": bool(ok), "value_x": hex(store.value(x_ptr)), "compiled_chunks": [a.compiled_chunks for a in dairs],
+            "trace_generation_s": gen_s}
+
+
 def uint_arith_session_probe(pkg, ctx, steps=3):
     """The second client's 256-bit arithmetic with every chiplet real (precompiles-prover/src/uint: `UintStoreMulAir` -- the range-checked
     store and kappa_a a b +- kappa_c c = r (mod p) by vertical Schwartz-Zippel identities carried in three aux REGISTER columns -- and
@@ -1326,6 +1369,10 @@ def main():
             out["uint_arith_session"] = uint_arith_session_probe(pkg, ctx)
         except Exception as e:
             out["uint_arith_session"] = {"error": repr(e)[:300]}
+        try:
+            out["ec_msm_session"] = ec_msm_session_probe(pkg, ctx)
+        except Exception as e:
+            out["ec_msm_session"] = {"error": repr(e)[:300]}
         try:
             # the service-level probes run in a process of their own (tools/bench_inflight_h2d.py, no torch in it): measured in THIS
             # process, which also hosts PyTorch's HIP runtime, the same loops lose the copy / kernel overlap (k = 1 with its uploads

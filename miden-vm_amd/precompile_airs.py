@@ -2027,6 +2027,12 @@ class EcRequire:
         (self.adds.record_nz if nonzero else self.adds.record)(y, z, x, bound, 1)
         return z
 
+    def _uint_neg(self, v):              # `neg` (:111-120): z = -v as the negation tuple v + z = 0
+        bound, m = self._modulus(v)
+        z = self.store.intern(-self.store.value(v) % m, bound)
+        self.adds.record_to_zero(v, z, bound, 1)
+        return z
+
     def _add_to_zero(self, a, b):        # `add_to_zero` (:122-133)
         bound, m = self._modulus(a, b)
         assert (self.store.value(a) + self.store.value(b)) % m == 0, "a + b must reduce to zero"
@@ -2636,6 +2642,259 @@ def uint_store_mul_trace(store, muls, bpl, min_height=0):
     return out
 
 
+# ---- EcMsm: symbolic multi-scalar-multiplication expressions (ec/msm/{mod,trace,require}.rs) --------------------------------------------
+# A term = (base point, scalar) "P x s"; an expression = a run of term rows sharing one `expr_ptr`, with a value point `val` and the
+# invariant deref(val) = sum of s P.  Three rules build any addition chain: `intro` (<P x 1>, val = P), `neg` (every scalar negated,
+# val = -val_a as a trio-free certified point), `combine` (the two sorted term lists merged, scalars on a shared base added mod the scalar
+# bound, values added by a consumed `EcGroupAdd`).  The AIR checks that each step is sound, never which steps were taken: variable-length
+# blocks (the allocator chain expr_ptr' = expr_ptr + is_boundary), merge-walk cursors i, j over the operands' `MsmTerm` tuples, a strict
+# pointer ordering a_expr, b_expr < expr against circular derivations.  38 main columns, eleven flattened LogUp columns on nine buses, lqd 1.
+BUS_MSM_TERM, BUS_MSM_EXPR, BUS_MSM_CLAIM_TERM = 18, 19, 20                                                     # relations.rs:52-80
+MS_COLS, MS_AUX_COLS = 38, 11                                                                                   # ec/msm/mod.rs:168-236
+(MS_COL_ACT, MS_COL_EXPR_PTR, MS_COL_IS_BOUNDARY, MS_COL_GROUP_PTR, MS_COL_SBOUND_PTR, MS_COL_IDX, MS_COL_BASE, MS_COL_SCALAR, MS_COL_VAL,
+ MS_COL_MULT, MS_COL_IS_INTRO, MS_COL_IS_COMBINE, MS_COL_A_EXPR, MS_COL_B_EXPR, MS_COL_I, MS_COL_J, MS_COL_TAKE_A, MS_COL_TAKE_B,
+ MS_COL_TAKE_BOTH, MS_COL_BASE_A, MS_COL_S_A, MS_COL_BASE_B, MS_COL_S_B, MS_COL_VAL_A, MS_COL_VAL_B, MS_COL_A_PTR, MS_COL_B_PTR,
+ MS_COL_BOUND_PTR, MS_COL_A_DIFF_LO, MS_COL_A_DIFF_HI, MS_COL_B_DIFF_LO, MS_COL_B_DIFF_HI, MS_COL_IS_NEG, MS_COL_NEG_X, MS_COL_CLAIM_MULT,
+ MS_COL_NEG_YA, MS_COL_NEG_YR, MS_COL_NEG_MINTED) = range(38)
+
+
+def ec_msm_air(host_aux=None):
+    """`EcMsmAir::eval` (ec/msm/mod.rs:316-498) and its `LookupAir::eval` (:523-856): col 0 the MsmTerm provide | 1 the MsmExpr head + the
+    positionless MsmClaimTerm provides | 2 neg's closure certificate + intro's literal-1 scalar | 3 the walk's A term | 4 its B term + the
+    merged scalar | 5 neg's scalar and y flips | 6 the operands' heads | 7 combine's value addition + neg's operand point | 8 neg's result
+    point + the group | 9, 10 the ordering limbs."""
+    b = dag.AirBuilder(MS_COLS, aux_width=MS_AUX_COLS, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
+                       num_public=NUM_PUBLIC_VALUES)
+    loc, nxt = [b.main(c) for c in range(MS_COLS)], [b.main(c, 1) for c in range(MS_COLS)]
+    one = b.const(1)
+    act, act_next, is_boundary = loc[MS_COL_ACT], nxt[MS_COL_ACT], loc[MS_COL_IS_BOUNDARY]
+    is_intro, is_combine, is_neg, neg_minted, idx = loc[MS_COL_IS_INTRO], loc[MS_COL_IS_COMBINE], loc[MS_COL_IS_NEG], loc[MS_COL_NEG_MINTED], loc[MS_COL_IDX]
+    tr = b.is_transition()
+    for col in (MS_COL_ACT, MS_COL_IS_BOUNDARY, MS_COL_IS_INTRO, MS_COL_IS_COMBINE, MS_COL_IS_NEG, MS_COL_NEG_MINTED):
+        _assert_bool(b, loc[col])
+    b.assert_zero((one - is_neg) * neg_minted)
+    b.assert_zero(tr * ((one - act) * act_next))
+    b.assert_zero(is_intro + is_combine + is_neg - act)
+    b.assert_zero((one - act) * is_boundary)
+    b.assert_zero((one - act) * loc[MS_COL_MULT])
+    b.assert_zero((one - act) * loc[MS_COL_CLAIM_MULT])
+    b.assert_zero(b.is_first_row() * (loc[MS_COL_EXPR_PTR] - one))       # the allocator: pointers are run numbers
+    b.assert_zero(tr * (nxt[MS_COL_EXPR_PTR] - loc[MS_COL_EXPR_PTR] - is_boundary))
+    b.assert_zero(b.is_first_row() * idx)
+    b.assert_zero(tr * (nxt[MS_COL_IDX] - (one - is_boundary) * (idx + one)))
+    not_boundary = one - is_boundary
+    for col in (MS_COL_GROUP_PTR, MS_COL_SBOUND_PTR, MS_COL_VAL, MS_COL_MULT, MS_COL_CLAIM_MULT, MS_COL_IS_INTRO, MS_COL_IS_COMBINE, MS_COL_IS_NEG,
+                MS_COL_A_EXPR, MS_COL_B_EXPR, MS_COL_VAL_A, MS_COL_VAL_B, MS_COL_A_PTR, MS_COL_B_PTR, MS_COL_BOUND_PTR):
+        b.assert_zero(tr * (not_boundary * (nxt[col] - loc[col])))
+    b.assert_zero(is_intro * (one - is_boundary))
+    b.assert_zero(is_intro * (loc[MS_COL_VAL] - loc[MS_COL_BASE]))
+    take_a, take_b, take_both = loc[MS_COL_TAKE_A], loc[MS_COL_TAKE_B], loc[MS_COL_TAKE_BOTH]
+    for t in (take_a, take_b, take_both):
+        _assert_bool(b, t)
+    b.assert_zero(take_a + take_b + take_both - is_combine)
+    i_cur, j_cur = loc[MS_COL_I], loc[MS_COL_J]
+    b.assert_zero(b.is_first_row() * i_cur)
+    b.assert_zero(b.is_first_row() * j_cur)
+    adv_i, adv_j = take_a + take_both + is_neg, take_b + take_both
+    b.assert_zero(tr * (nxt[MS_COL_I] - (one - is_boundary) * (i_cur + adv_i)))
+    b.assert_zero(tr * (nxt[MS_COL_J] - (one - is_boundary) * (j_cur + adv_j)))
+    base_a, base_b, s_a, s_b = loc[MS_COL_BASE_A], loc[MS_COL_BASE_B], loc[MS_COL_S_A], loc[MS_COL_S_B]
+    b.assert_zero((take_a + take_both + is_neg) * (loc[MS_COL_BASE] - base_a) + take_b * (loc[MS_COL_BASE] - base_b))
+    b.assert_zero(take_a * (loc[MS_COL_SCALAR] - s_a) + take_b * (loc[MS_COL_SCALAR] - s_b))
+    b.assert_zero(take_both * (base_a - base_b))
+    two16 = b.const(1 << 16)
+    b.assert_zero((is_combine + is_neg) * is_boundary * (loc[MS_COL_EXPR_PTR] - loc[MS_COL_A_EXPR] - one - loc[MS_COL_A_DIFF_LO] - two16 * loc[MS_COL_A_DIFF_HI]))
+    b.assert_zero(is_combine * is_boundary * (loc[MS_COL_EXPR_PTR] - loc[MS_COL_B_EXPR] - one - loc[MS_COL_B_DIFF_LO] - two16 * loc[MS_COL_B_DIFF_HI]))
+
+    lk = dag.LogUp(b, MAX_MESSAGE_WIDTH, NUM_BUS_IDS, closing="sigma_last_row")
+
+    def message(bus, fields):            # fields: column numbers, callables bb -> expression, or ("const", value)
+        def msg(ch):
+            bb = lk.b if ch is lk.ch_c else lk.lb
+            return ch.encode(bus, [bb.main(f) if isinstance(f, int) else (bb.const(f[1]) if isinstance(f, tuple) else f(bb)) for f in fields])
+        return msg
+    K = lambda v: ("const", v)                                                            # noqa: E731
+
+    def mults(fn):
+        return fn(lk.b), fn(lk.lb)
+    m = lambda c: (lambda bb: bb.main(c))                                                 # noqa: E731
+    f_adv_i = lambda bb: bb.main(MS_COL_TAKE_A) + bb.main(MS_COL_TAKE_BOTH) + bb.main(MS_COL_IS_NEG)          # noqa: E731
+    f_adv_j = lambda bb: bb.main(MS_COL_TAKE_B) + bb.main(MS_COL_TAKE_BOTH)                                   # noqa: E731
+    bnd_a = mults(lambda bb: (bb.main(MS_COL_IS_COMBINE) + bb.main(MS_COL_IS_NEG)) * bb.main(MS_COL_IS_BOUNDARY))
+    bnd_b = mults(lambda bb: bb.main(MS_COL_IS_COMBINE) * bb.main(MS_COL_IS_BOUNDARY))
+    bnd_neg = mults(lambda bb: bb.main(MS_COL_IS_NEG) * bb.main(MS_COL_IS_BOUNDARY))
+    neg_mult = mults(lambda bb: bb.const(0) - bb.main(MS_COL_MULT))
+    neg_claim = mults(lambda bb: bb.const(0) - bb.main(MS_COL_CLAIM_MULT))
+    ec_point = lambda ptr, y: message(BUS_EC_POINT, [ptr, MS_COL_GROUP_PTR, MS_COL_NEG_X, y, K(0)])           # noqa: E731
+    _emit_frac_cols(lk, [
+        [(neg_mult, message(BUS_MSM_TERM, [MS_COL_EXPR_PTR, MS_COL_IDX, MS_COL_BASE, MS_COL_SCALAR]))],
+        [(mults(lambda bb: (bb.const(0) - bb.main(MS_COL_MULT) + (bb.const(0) - bb.main(MS_COL_CLAIM_MULT))) * bb.main(MS_COL_IS_BOUNDARY)),
+          message(BUS_MSM_EXPR, [MS_COL_EXPR_PTR, MS_COL_GROUP_PTR, MS_COL_VAL, lambda bb: bb.main(MS_COL_IDX) + bb.const(1)])),
+         (neg_claim, message(BUS_MSM_CLAIM_TERM, [MS_COL_EXPR_PTR, MS_COL_BASE, MS_COL_SCALAR]))],
+        [(mults(lambda bb: bb.const(0) - bb.main(MS_COL_NEG_MINTED) * bb.main(MS_COL_IS_BOUNDARY)), message(BUS_EC_ON_CURVE_CERT, [MS_COL_GROUP_PTR, MS_COL_VAL])),
+         (mults(m(MS_COL_IS_INTRO)), message(BUS_UINT_VAL, [MS_COL_SCALAR, MS_COL_SBOUND_PTR, K(1)] + [K(0)] * 7))],
+        [(mults(f_adv_i), message(BUS_MSM_TERM, [MS_COL_A_EXPR, MS_COL_I, MS_COL_BASE_A, MS_COL_S_A]))],
+        [(mults(f_adv_j), message(BUS_MSM_TERM, [MS_COL_B_EXPR, MS_COL_J, MS_COL_BASE_B, MS_COL_S_B])),
+         (mults(m(MS_COL_TAKE_BOTH)), message(BUS_UINT_ADD, [MS_COL_SBOUND_PTR, MS_COL_S_A, MS_COL_S_B, MS_COL_SCALAR, K(0)]))],
+        [(mults(m(MS_COL_IS_NEG)), message(BUS_UINT_ADD, [MS_COL_SBOUND_PTR, MS_COL_S_A, MS_COL_SCALAR, K(0), K(0)])),
+         (bnd_neg, message(BUS_UINT_ADD, [MS_COL_BOUND_PTR, MS_COL_NEG_YA, MS_COL_NEG_YR, K(0), K(0)]))],
+        [(bnd_a, message(BUS_MSM_EXPR, [MS_COL_A_EXPR, MS_COL_GROUP_PTR, MS_COL_VAL_A, lambda bb: bb.main(MS_COL_I) + f_adv_i(bb)])),
+         (bnd_b, message(BUS_MSM_EXPR, [MS_COL_B_EXPR, MS_COL_GROUP_PTR, MS_COL_VAL_B, lambda bb: bb.main(MS_COL_J) + f_adv_j(bb)]))],
+        [(bnd_b, message(BUS_EC_GROUP_ADD, [MS_COL_GROUP_PTR, MS_COL_VAL_A, MS_COL_VAL_B, MS_COL_VAL])), (bnd_neg, ec_point(MS_COL_VAL_A, MS_COL_NEG_YA))],
+        [(bnd_neg, ec_point(MS_COL_VAL, MS_COL_NEG_YR)),
+         (bnd_a, message(BUS_EC_GROUP, [MS_COL_GROUP_PTR, MS_COL_A_PTR, MS_COL_B_PTR, MS_COL_BOUND_PTR, MS_COL_SBOUND_PTR]))],
+        [(bnd_a, message(BUS_RANGE16, [MS_COL_A_DIFF_LO])), (bnd_a, message(BUS_RANGE16, [MS_COL_A_DIFF_HI]))],
+        [(bnd_b, message(BUS_RANGE16, [MS_COL_B_DIFF_LO])), (bnd_b, message(BUS_RANGE16, [MS_COL_B_DIFF_HI]))]])
+    lookup = lk.finish("ec_msm")
+    return dag.Air(b, _host_aux(lookup, host_aux), "ec_msm"), lookup
+
+
+def _assert_bool(b, x):                  # p3's `assert_bool`: x (x - 1)
+    b.assert_zero(x * (x - b.const(1)))
+
+
+class EcMsmRequires:
+    """`EcMsmRequires` (ec/msm/trace.rs:118-322) + the recording layer `intro` / `combine` / `neg` / `merge_terms` (ec/msm/require.rs):
+    expressions in allocation order, deduplicated by (rule, operands); every operand use adds to the operand's `mult`, every resolve (the
+    eval chip's absorb seam) to its `claim_mult`.  An expression = dict(kind, group, sbound, val, a_expr, b_expr, val_a, val_b, a_ptr,
+    b_ptr, bound_ptr, neg_x, neg_ya, neg_yr, neg_minted, rows, mult, claim_mult); a row = dict(base, scalar, i, j, take_a, take_b,
+    take_both, base_a, s_a, base_b, s_b)."""
+    ROW0 = dict(base=0, scalar=0, i=0, j=0, take_a=0, take_b=0, take_both=0, base_a=0, s_a=0, base_b=0, s_b=0)
+    EXPR0 = dict(a_expr=0, b_expr=0, val_a=0, val_b=0, a_ptr=0, b_ptr=0, bound_ptr=0, neg_x=0, neg_ya=0, neg_yr=0, neg_minted=0, mult=0, claim_mult=0)
+
+    def __init__(self, req):
+        self.req, self.exprs, self.dedup = req, [], {}                  # req: the EcRequire over the EC and uint ledgers
+
+    def _push(self, key, **fields):
+        self.exprs.append(dict(self.EXPR0, **fields))
+        self.dedup[key] = len(self.exprs)
+        return len(self.exprs)
+
+    def terms(self, e):
+        return [(r["base"], r["scalar"]) for r in self.exprs[e - 1]["rows"]]
+
+    def value(self, e):
+        return self.exprs[e - 1]["val"]
+
+    def consume_op(self, e, mult=1):
+        self.exprs[e - 1]["mult"] += mult
+
+    def consume_claim(self, e, mult=1):
+        self.exprs[e - 1]["claim_mult"] += mult
+
+    def intro(self, base):
+        if ("intro", base) in self.dedup:
+            return self.dedup[("intro", base)]
+        ec, store = self.req.ec, self.req.store
+        group = ec.point_params(base)[0]
+        sbound = ec.group_sbound(group)
+        one = store.intern(1, sbound)
+        return self._push(("intro", base), kind="intro", group=group, sbound=sbound, val=base, rows=[dict(self.ROW0, base=base, scalar=one)])
+
+    def combine(self, a, b):
+        if ("combine", a, b) in self.dedup:
+            return self.dedup[("combine", a, b)]
+        ea, ec = self.exprs[a - 1], self.req.ec
+        group, sbound = ea["group"], ea["sbound"]
+        a_terms, b_terms, val_a, val_b = self.terms(a), self.terms(b), self.value(a), self.value(b)
+        a_ptr, b_ptr, bound_ptr = ec.group_params(group)
+        rows, i, j = [], 0, 0            # `merge_terms`: the two lists sorted by base pointer, scalars on a shared base added mod the scalar bound
+        while i < len(a_terms) or j < len(b_terms):
+            a_first = j >= len(b_terms) or (i < len(a_terms) and a_terms[i][0] < b_terms[j][0])
+            b_first = i >= len(a_terms) or (j < len(b_terms) and b_terms[j][0] < a_terms[i][0])
+            if a_first:
+                base, sc = a_terms[i]
+                rows.append(dict(self.ROW0, take_a=1, i=i, j=j, base_a=base, s_a=sc, base=base, scalar=sc))
+                i += 1
+            elif b_first:
+                base, sc = b_terms[j]
+                rows.append(dict(self.ROW0, take_b=1, i=i, j=j, base_b=base, s_b=sc, base=base, scalar=sc))
+                j += 1
+            else:
+                (base, sa), (_, sb) = a_terms[i], b_terms[j]
+                rows.append(dict(self.ROW0, take_both=1, i=i, j=j, base_a=base, s_a=sa, base_b=base, s_b=sb, base=base, scalar=self.req._uint_add(sa, sb)))
+                i, j = i + 1, j + 1
+        val = self.req.add(val_a, val_b, 1)
+        ec.require_ecgroup(group)
+        c = self._push(("combine", a, b), kind="combine", group=group, sbound=sbound, val=val, a_expr=a, b_expr=b, val_a=val_a, val_b=val_b,
+                       a_ptr=a_ptr, b_ptr=b_ptr, bound_ptr=bound_ptr, rows=rows)
+        self.consume_op(a)
+        self.consume_op(b)
+        return c
+
+    def neg(self, a):
+        if ("neg", a) in self.dedup:
+            return self.dedup[("neg", a)]
+        ea, ec, store = self.exprs[a - 1], self.req.ec, self.req.store
+        group, sbound, val_a = ea["group"], ea["sbound"], ea["val"]
+        a_ptr, b_ptr, bound_ptr = ec.group_params(group)
+        rows = [dict(self.ROW0, i=i, base=base, base_a=base, s_a=sc, scalar=self.req._uint_neg(sc)) for i, (base, sc) in enumerate(self.terms(a))]
+        px, py = ec.point_params(val_a)[1]
+        neg_py = self.req._uint_neg(py)
+        val, minted = ec.add_point_cert(group, px, neg_py)              # -val_a = (x, -y): on the curve because val_a is; no group law, no trio
+        ec.require_ecpoint(val_a)
+        ec.require_ecpoint(val)
+        ec.require_ecgroup(group)
+        c = self._push(("neg", a), kind="neg", group=group, sbound=sbound, val=val, a_expr=a, val_a=val_a, a_ptr=a_ptr, b_ptr=b_ptr,
+                       bound_ptr=bound_ptr, neg_x=px, neg_ya=py, neg_yr=neg_py, neg_minted=int(minted), rows=rows)
+        self.consume_op(a)
+        return c
+
+    def resolve(self, e):
+        """The eval chip's `EcMsm` absorb seam (not ported): one reader of the expression's head and of each of its positionless terms."""
+        self.consume_claim(e)
+        return self.value(e)
+
+    def consumer_requests(self):
+        """What the eval chip puts on the MsmExpr / MsmClaimTerm buses for the resolved expressions."""
+        out = []
+        for k, e in enumerate(self.exprs):
+            if e["claim_mult"]:
+                out.append((BUS_MSM_EXPR, e["claim_mult"], [k + 1, e["group"], e["val"], len(e["rows"])]))
+                out += [(BUS_MSM_CLAIM_TERM, e["claim_mult"], [k + 1, r["base"], r["scalar"]]) for r in e["rows"]]
+        return out
+
+
+def ec_msm_trace(msm, store, bpl, min_height=0):
+    """`generate_trace` (ec/msm/trace.rs:324-427): one row per term, runs in allocation order; pads keep the next pointer with a counting
+    `idx`.  Routes the intro rows' reads of the literal 1 and the ordering limbs into the ledgers."""
+    n_real = sum(len(e["rows"]) for e in msm.exprs)
+    height = max(2, min_height, 1 << (max(1, n_real) - 1).bit_length())
+    t = np.zeros((height, MS_COLS), dtype=np.uint64)
+    r = 0
+    for k, e in enumerate(msm.exprs):
+        expr_ptr, n_rows = k + 1, len(e["rows"])
+        for idx, rv in enumerate(e["rows"]):
+            boundary = idx == n_rows - 1
+            row = t[r]
+            row[[MS_COL_ACT, MS_COL_EXPR_PTR, MS_COL_IS_BOUNDARY, MS_COL_GROUP_PTR, MS_COL_SBOUND_PTR, MS_COL_IDX, MS_COL_BASE, MS_COL_SCALAR, MS_COL_VAL]] = \
+                [1, expr_ptr, int(boundary), e["group"], e["sbound"], idx, rv["base"], rv["scalar"], e["val"]]
+            row[MS_COL_MULT], row[MS_COL_CLAIM_MULT] = e["mult"] % P, e["claim_mult"] % P
+            row[MS_COL_IS_INTRO], row[MS_COL_IS_COMBINE], row[MS_COL_IS_NEG] = e["kind"] == "intro", e["kind"] == "combine", e["kind"] == "neg"
+            if e["kind"] == "intro":
+                store.require_uintval(rv["scalar"])
+            else:
+                row[[MS_COL_A_EXPR, MS_COL_I, MS_COL_BASE_A, MS_COL_S_A, MS_COL_VAL_A, MS_COL_A_PTR, MS_COL_B_PTR, MS_COL_BOUND_PTR]] = \
+                    [e["a_expr"], rv["i"], rv["base_a"], rv["s_a"], e["val_a"], e["a_ptr"], e["b_ptr"], e["bound_ptr"]]
+                diffs = [expr_ptr - e["a_expr"] - 1]
+                if e["kind"] == "combine":
+                    row[[MS_COL_B_EXPR, MS_COL_J, MS_COL_TAKE_A, MS_COL_TAKE_B, MS_COL_TAKE_BOTH, MS_COL_BASE_B, MS_COL_S_B, MS_COL_VAL_B]] = \
+                        [e["b_expr"], rv["j"], rv["take_a"], rv["take_b"], rv["take_both"], rv["base_b"], rv["s_b"], e["val_b"]]
+                    diffs.append(expr_ptr - e["b_expr"] - 1)
+                if boundary:
+                    if e["kind"] == "neg":
+                        row[[MS_COL_NEG_X, MS_COL_NEG_YA, MS_COL_NEG_YR, MS_COL_NEG_MINTED]] = [e["neg_x"], e["neg_ya"], e["neg_yr"], e["neg_minted"]]
+                    for d_, (lo, hi) in zip(diffs, ((MS_COL_A_DIFF_LO, MS_COL_A_DIFF_HI), (MS_COL_B_DIFF_LO, MS_COL_B_DIFF_HI))):
+                        assert d_ >= 0, "an operand must be an earlier expression"
+                        row[lo], row[hi] = d_ & 0xffff, d_ >> 16
+                        bpl.require_range16(d_ & 0xffff)
+                        bpl.require_range16(d_ >> 16)
+            r += 1
+    t[r:, MS_COL_EXPR_PTR] = len(msm.exprs) + 1
+    t[r:, MS_COL_IDX] = np.arange(height - r, dtype=np.uint64)
+    return t
+
+
 K1_BOUND = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2E                                    # secp256k1: p - 1
 K1_G = (0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798, 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8)
 
@@ -2726,3 +2985,38 @@ def uint_arith_session(n_steps, seed=7, host_aux=None, min_height=8):
     readers = requirer_trace([(bus, (P - mult) % P, f) for bus, mult, f in muls.uint_mul_requests()] + uint_add_consumer_requests(adds), payload=10)
     pairs = [byte_pair_lut_air(host_aux), uint_store_mul_air(host_aux), uint_add_air(host_aux), ec_groups_air(host_aux), requirer_air(host_aux, payload=10)]
     return pairs, [byte_pair_lut_trace(bpl), uint, add, ec_groups_trace(), readers], (store.value(acc), (store, adds, muls))
+
+
+def ec_msm_session(terms, host_aux=None, min_height=8):
+    """sum_i k_i P_i as an MSM EXPRESSION over the fixed environment, SEVEN real chiplets: the points P_i = m_i G bound by value, one
+    `intro` each, then Straus' interleaved double-and-add over the expressions -- acc <- combine(acc, acc) (every scalar doubled mod the
+    group order: the merge of two equal term lists), acc <- combine(acc, <P_i x 1>) where bit i is set (a sorted merge; a shared base adds
+    its scalars) -- and the result resolved once by the eval chip's absorb seam (the only stand-in).  terms = [(k_i, m_i)].
+    [BytePairLutAir (preprocessed), UintStoreMulAir, UintAddAir, EcGroupsAir, EcPointStoreAir, EcGroupAddAir, EcMsmAir, the resolve's
+    readers].  -> ([(air, lookup)], [traces], (value point, expression, ledgers))"""
+    store, adds, muls, ec, ec_add, bpl = UintStore().install_fixed_uints(), UintAddRequires(), UintMulRequires(), EcStore(), EcAddRequires(), BytePairLutRequires()
+    req = EcRequire(ec, store, muls, adds, ec_add)
+    group, _pai = req.create_group(0, 7, K1_BASE_BOUND_PTR)
+    mult = k1_multiples(max(m_ for _, m_ in terms))
+    msm = EcMsmRequires(req)
+    intros = [msm.intro(req.add_point(group, *mult[m_ - 1])) for _, m_ in terms]
+    acc = None
+    for bit in range(max(k for k, _ in terms).bit_length() - 1, -1, -1):
+        if acc is not None:
+            acc = msm.combine(acc, acc)
+        for (k, _), e in zip(terms, intros):
+            if (k >> bit) & 1:
+                acc = e if acc is None else msm.combine(acc, e)
+    val = msm.resolve(acc)
+    ec.require_ecpoint(val)                                             # the eval chip reads the value point it binds
+    ec.require_fixed_groups()
+    add = uint_add_trace(adds, store, min_height=min_height)
+    ec_add_main = ec_group_add_trace(ec_add, ec, bpl, min_height=min_height)
+    msm_main = ec_msm_trace(msm, store, bpl, min_height=min_height)
+    uint = uint_store_mul_trace(store, muls, bpl, min_height=min_height)
+    groups, points = ec_store_traces(ec, min_height=min_height)
+    g_, (vx, vy, _m) = ec.points[val - 1]
+    readers = requirer_trace(msm.consumer_requests() + [(BUS_EC_POINT, 1, [val, g_, vx, vy, 0])], payload=10)
+    pairs = [byte_pair_lut_air(host_aux), uint_store_mul_air(host_aux), uint_add_air(host_aux), ec_groups_air(host_aux),
+             ec_point_store_air(host_aux), ec_group_add_air(host_aux), ec_msm_air(host_aux), requirer_air(host_aux, payload=10)]
+    return pairs, [byte_pair_lut_trace(bpl), uint, add, groups, points, ec_add_main, msm_main, readers], (val, acc, (store, adds, muls, ec, ec_add, msm))

@@ -632,3 +632,45 @@ def test_uint_arith_session_production_params(ctx):
     ok3, _ = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, preprocessed_root=root,
                         external=PA.external_assertions(pkg))
     assert not ok3, "without the verifier's UintVal consumes of the fixed rows the statement does not close"
+
+
+@pytest.mark.parametrize("jit", ["0", "1"])
+def test_ec_msm_session_device_proof_equals_oracle(ctx, jit, monkeypatch):
+    """0xb5 G + 0x4d (3 G) as an MSM expression over the fixed environment: SEVEN real chiplets (the store and multiplier with their
+    registers, the adder, the EC stores, the group law, `EcMsmAir` with its variable-length blocks and merge walks)."""
+    pkg = load_package()
+    monkeypatch.setenv("MH_JIT", jit)
+    pairs, traces, _ = PA.ec_msm_session([(0xb5, 1), (0x4d, 3)], host_aux)
+    airs_, lookups = [p[0] for p in pairs], [p[1] for p in pairs]
+    ext = PA.external_assertions(pkg, fixed_uints=True)
+    exp = ob.prove(airs_, traces, ROOT, FAST, init_state=protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST))
+    got, root, st, pre = device_prove(ctx, airs_, lookups, traces, FAST)
+    assert list(root) == [int(x) for x in exp["preprocessed_root"]]
+    assert (got.commitments == exp["commitments"]).all()
+    assert got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all()
+    assert (got.digest == exp["digest"]).all()
+    ok, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, FAST, st, pre, got.fields, got.commitments, preprocessed_root=root, external=ext)
+    assert ok and (dig == got.digest).all()
+    forged = traces[6].copy()
+    forged[2, PA.MS_COL_VAL] = int(forged[0, PA.MS_COL_VAL])            # an expression's value repointed: no valid proof
+    bad, root, st, pre = device_prove(ctx, airs_, lookups, traces[:6] + [forged] + traces[7:], FAST)
+    ok, _ = pkg.verify(airs_, bad.log_trace_heights, ROOT, FAST, st, pre, bad.fields, bad.commitments, preprocessed_root=root, external=ext)
+    assert not ok
+
+
+def test_ec_msm_session_production_params(ctx):
+    """A four-term MSM with 64-bit scalars (~190 merge walks over up to four terms), production parameters: verify-only through both
+    verifiers."""
+    import random
+    pkg = load_package()
+    rng = random.Random(11)
+    pairs, traces, _ = PA.ec_msm_session([(rng.getrandbits(64) | 1 << 63, m) for m in (1, 2, 5, 9)], host_aux)
+    airs_, lookups = [p[0] for p in pairs], [p[1] for p in pairs]
+    ext = PA.external_assertions(pkg, fixed_uints=True)
+    prm = dict(protocol.PROD_PARAMS)
+    got, root, st, pre = device_prove(ctx, airs_, lookups, traces, prm)
+    ok, msg = ob.verify(airs_, got.log_trace_heights, ROOT, {"fields": got.fields, "commitments": got.commitments}, prm,
+                        init_state=st, pre_observe=pre, external=ext)
+    assert ok, msg
+    ok2, dig = pkg.verify(airs_, got.log_trace_heights, ROOT, prm, st, pre, got.fields, got.commitments, preprocessed_root=root, external=ext)
+    assert ok2 and (dig == got.digest).all()

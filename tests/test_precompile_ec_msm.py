@@ -1,0 +1,206 @@
+"""The MSM chiplet of the precompile prover (`EcMsmAir`, precompiles-prover/src/ec/msm/{mod,trace,require}.rs) as ported in
+miden-vm_amd/precompile_airs.py: the unit tests of its trace module (ec/msm/trace.rs `mod tests`) replayed, and the chiplet inside the
+arithmetic + EC stack -- SEVEN real chiplets [BytePairLutAir, UintStoreMulAir, UintAddAir, EcGroupsAir, EcPointStoreAir, EcGroupAddAir,
+EcMsmAir]; what is left outside is the eval chip's resolve of the final expression (its `MsmExpr` head, its positionless `MsmClaimTerm`
+set and the value point's `EcPoint`).  Host only; device parity in tests/test_gpu_precompile.py.
+
+  intro_constraints_hold, combine_constraints_hold, neg_constraints_hold, forged_pad_mult_rejected, forged_take_flag_on_intro_rejected,
+  log_quotient_degree_matches_design_target (1); merge walks with disjoint and shared bases, scalars that wrap the group order, a negated
+  expression (value = the certified point (x, -y)), deduplicated steps, circular derivations; k1 G + k2 P as an expression: its value is
+  the point an independent group law computes, its single-base form merges to one term with the scalar k mod n"""
+import numpy as np
+import pytest
+import oracle_binding as ob
+from __graft_entry__ import load_package
+
+pkg = load_package()
+from miden_vm_amd import precompile_airs as PA, dag, protocol  # noqa: E402
+import test_precompile_ec_add as EA  # noqa: E402
+
+P = dag.P
+RND, FAST = EA.RND, EA.FAST
+ROOT = [111, 112, 113, 114]
+N_ORDER = PA.FIXED_UINTS[2][2] + 1                                      # the secp256k1 group order
+
+
+def host_aux(lookup, main, randomness, preprocessed=None):
+    return ob.lookup_build_aux(lookup, main, randomness, preprocessed)
+
+
+@pytest.fixture(scope="module")
+def msm_air():
+    return PA.ec_msm_air(host_aux)
+
+
+def sigma(pair, main):
+    air, lookup = pair
+    _, fin = ob.lookup_build_aux(lookup, main, RND, air.preprocessed)
+    return int(fin[0]), int(fin[1])
+
+
+def check(pair, main):
+    air, lookup = pair
+    aux, fin = ob.lookup_build_aux(lookup, main, RND, air.preprocessed)
+    return ob.check_constraints(air, main, aux, [int(fin[0]), int(fin[1])], ROOT, RND, air.preprocessed)
+
+
+class Bare:
+    """ec/msm/trace.rs `mod tests`: expressions over bare pointers, no stores behind them (local constraints only)."""
+
+    def __init__(self):
+        self.msm = PA.EcMsmRequires(None)
+
+    def intro(self, base, one=9, group=1, sbound=7):
+        return self.msm._push(("intro", base), kind="intro", group=group, sbound=sbound, val=base, rows=[dict(self.msm.ROW0, base=base, scalar=one)])
+
+    def combine(self, a, b, val, rows, group=1, sbound=7):
+        return self.msm._push(("combine", a, b), kind="combine", group=group, sbound=sbound, val=val, a_expr=a, b_expr=b, val_a=self.msm.value(a),
+                              val_b=self.msm.value(b), a_ptr=2, b_ptr=3, bound_ptr=1, rows=[dict(self.msm.ROW0, **r) for r in rows])
+
+    def trace(self):
+        return PA.ec_msm_trace(self.msm, PA.UintStore(), PA.BytePairLutRequires())
+
+
+def two_intro_combine():
+    t = Bare()
+    ga, qb = t.intro(3), t.intro(4)
+    c = t.combine(ga, qb, 5, [dict(take_a=1, i=0, j=0, base_a=3, s_a=9, base=3, scalar=9), dict(take_b=1, i=1, j=0, base_b=4, s_b=9, base=4, scalar=9)])
+    for e in (ga, qb, c):
+        t.msm.consume_op(e)
+    return t, (ga, qb, c)
+
+
+def test_layout_and_log_quotient_degree(msm_air):
+    h = dag.parse_air_blob(msm_air[0].blob)
+    assert (h["main_width"], h["aux_width"], h["num_randomness"], h["num_aux_values"], h["num_public"], h["periodic"]) == (38, 11, 2, 1, 4, [])
+    assert h["log_quotient_degree"] == 1 and max(d for d, _ in msm_air[0].constraint_degrees) == 3
+    assert (PA.MS_COL_VAL, PA.MS_COL_IS_COMBINE, PA.MS_COL_BOUND_PTR, PA.MS_COL_IS_NEG, PA.MS_COL_CLAIM_MULT, PA.MS_COL_NEG_MINTED) == (8, 11, 27, 32, 34, 37)
+    assert (PA.BUS_MSM_TERM, PA.BUS_MSM_EXPR, PA.BUS_MSM_CLAIM_TERM) == (18, 19, 20)
+
+
+def test_intro_combine_and_neg_constraints_hold(msm_air):
+    t = Bare()
+    g, q = t.intro(3), t.intro(4)
+    t.msm.consume_op(g, 2)
+    t.msm.consume_op(q, 1)
+    main = t.trace()
+    assert main.shape == (2, 38) and check(msm_air, main) == (0, None)          # intro_constraints_hold
+    t, (ga, qb, c) = two_intro_combine()
+    main = t.trace()
+    assert main.shape == (4, 38) and [int(v) for v in main[:, PA.MS_COL_EXPR_PTR]] == [1, 2, 3, 3] and check(msm_air, main) == (0, None)   # combine_constraints_hold
+    n = t.msm._push(("neg", c), kind="neg", group=1, sbound=7, val=6, a_expr=c, val_a=5, a_ptr=2, b_ptr=3, bound_ptr=1, neg_x=4, neg_ya=5, neg_yr=6,
+                    neg_minted=1, rows=[dict(t.msm.ROW0, i=i, base=base, base_a=base, s_a=9, scalar=10) for i, base in enumerate((3, 4))])
+    t.msm.consume_op(n)
+    main = t.trace()
+    assert main.shape == (8, 38) and check(msm_air, main) == (0, None)          # neg_constraints_hold
+    assert [int(v) for v in main[6:, PA.MS_COL_EXPR_PTR]] == [5, 5] and [int(v) for v in main[6:, PA.MS_COL_IDX]] == [0, 1], "pads keep the next pointer"
+
+
+def test_local_forgeries_are_rejected(msm_air):
+    t = Bare()
+    t.msm.consume_op(t.intro(3))
+    main = t.trace()
+    forged = main.copy()
+    forged[1, PA.MS_COL_MULT] = 1                                       # forged_pad_mult_rejected
+    assert check(msm_air, forged)[0] != 0
+    forged = main.copy()
+    forged[0, PA.MS_COL_TAKE_A] = 1                                     # forged_take_flag_on_intro_rejected
+    assert check(msm_air, forged)[0] != 0
+    t, (ga, qb, c) = two_intro_combine()
+    main = t.trace()
+    forged = main.copy()
+    forged[3, PA.MS_COL_A_EXPR] = 3                                     # a circular derivation: the operand is the expression itself
+    assert check(msm_air, forged)[0] != 0
+    forged = main.copy()
+    forged[3, PA.MS_COL_VAL] = 9                                        # the value changes inside a run
+    assert check(msm_air, forged)[0] != 0
+    forged = main.copy()
+    forged[2, PA.MS_COL_BASE] = 4                                       # take_a must copy A's base
+    assert check(msm_air, forged)[0] != 0
+
+
+def affine_sum(terms):
+    m, mult = PA.K1_BOUND + 1, PA.k1_multiples(max(t[1] for t in terms))
+    acc = None
+    for k, mm in terms:
+        pt, add = None, mult[mm - 1]
+        for bit in bin(k % N_ORDER)[2:]:
+            pt = EA.affine_add(pt, pt, 0, m)
+            if bit == "1":
+                pt = EA.affine_add(pt, add, 0, m)
+        acc = EA.affine_add(acc, pt, 0, m)
+    return acc
+
+
+@pytest.mark.parametrize("terms", [[(5, 1)], [(0xb5, 1), (0x4d, 3)], [(6, 2), (3, 1), (5, 7)]], ids=["one base", "two bases", "three bases"])
+def test_msm_sessions_close_over_seven_real_chiplets_and_compute_the_sum(terms):
+    pairs, traces, (val, expr, (store, adds, muls, ec, ec_add, msm)) = PA.ec_msm_session(terms, host_aux)
+    x_ptr, y_ptr = ec.point_params(val)[1]
+    assert (store.value(x_ptr), store.value(y_ptr)) == affine_sum(terms), "the expression's value is the sum"
+    got_terms = {base: store.value(sc) for base, sc in msm.terms(expr)}
+    want = {}
+    for k, m_ in terms:
+        base = ec.point_by_coords(1, *(store.by_value[(c, PA.K1_BASE_BOUND_PTR)] for c in PA.k1_multiples(m_)[-1]))
+        want[base] = (want.get(base, 0) + k) % N_ORDER
+    assert got_terms == want, "one term per base, the scalars merged mod the group order"
+    assert [b for b, _ in msm.terms(expr)] == sorted(b for b, _ in msm.terms(expr)), "terms sorted by base pointer"
+    for pair, t in zip(pairs, traces):
+        assert check(pair, t) == (0, None), pair[0].name
+    sig = [[sigma(pair, t)] for pair, t in zip(pairs, traces)]
+    assert PA.eval_external(RND, sig, fixed_uints=True) == [(0, 0)]
+    forged = traces[6].copy()
+    last = max(r for r in range(forged.shape[0]) if int(forged[r, PA.MS_COL_ACT]))
+    forged[last, PA.MS_COL_SCALAR] = int(forged[0, PA.MS_COL_SCALAR])   # the final term's scalar swapped for the literal 1: local constraints may hold, no bus closes
+    sig[6] = [sigma(pairs[6], forged)]
+    assert PA.eval_external(RND, sig, fixed_uints=True) != [(0, 0)]
+
+
+def test_scalars_wrap_the_group_order_and_negation_certifies_its_value():
+    """(n - 1) G + 2 G: the merged scalar wraps to 1; then the negated expression: value (x, -y), minted with a closure certificate."""
+    store, adds, muls, ec, ec_add, bpl = PA.UintStore().install_fixed_uints(), PA.UintAddRequires(), PA.UintMulRequires(), PA.EcStore(), PA.EcAddRequires(), PA.BytePairLutRequires()
+    req = PA.EcRequire(ec, store, muls, adds, ec_add)
+    group, _ = req.create_group(0, 7, PA.K1_BASE_BOUND_PTR)
+    g = req.add_point(group, *PA.K1_G)
+    msm = PA.EcMsmRequires(req)
+    e = msm.intro(g)
+    n_e = msm.neg(e)                                                    # <G x (n - 1)>, value -G
+    assert store.value(msm.terms(n_e)[0][1]) == N_ORDER - 1
+    vx, vy = ec.point_params(msm.value(n_e))[1]
+    assert (store.value(vx), store.value(vy)) == (PA.K1_G[0], PA.K1_BOUND + 1 - PA.K1_G[1]) and msm.exprs[n_e - 1]["neg_minted"] == 1
+    two = msm.combine(e, e)
+    s = msm.combine(n_e, two)                                           # (n - 1) + 2 = 1 (mod n); -G + 2G = G: the value dedups onto G's row
+    assert store.value(msm.terms(s)[0][1]) == 1 and msm.value(s) == g and msm.combine(e, e) == two and msm.neg(e) == n_e
+    msm.resolve(s)
+    ec.require_ecpoint(g)
+    ec.require_fixed_groups()
+    add = PA.uint_add_trace(adds, store, min_height=8)
+    ec_add_main = PA.ec_group_add_trace(ec_add, ec, bpl, min_height=8)
+    msm_main = PA.ec_msm_trace(msm, store, bpl, min_height=8)
+    uint = PA.uint_store_mul_trace(store, muls, bpl, min_height=8)
+    groups, points = PA.ec_store_traces(ec, min_height=8)
+    readers = PA.requirer_trace(msm.consumer_requests() + [(PA.BUS_EC_POINT, 1, [g, group, *ec.point_params(g)[1], 0])], payload=10)
+    pairs = [PA.byte_pair_lut_air(host_aux), PA.uint_store_mul_air(host_aux), PA.uint_add_air(host_aux), PA.ec_groups_air(host_aux),
+             PA.ec_point_store_air(host_aux), PA.ec_group_add_air(host_aux), PA.ec_msm_air(host_aux), PA.requirer_air(host_aux, payload=10)]
+    traces = [PA.byte_pair_lut_trace(bpl), uint, add, groups, points, ec_add_main, msm_main, readers]
+    for pair, t in zip(pairs, traces):
+        assert check(pair, t) == (0, None), pair[0].name
+    assert PA.eval_external(RND, [[sigma(pair, t)] for pair, t in zip(pairs, traces)], fixed_uints=True) == [(0, 0)]
+
+
+def test_the_msm_statement_proves_and_forgeries_do_not():
+    pairs, traces, _ = PA.ec_msm_session([(5, 1), (3, 2)], host_aux)
+    air_list = [p_[0] for p_ in pairs]
+    st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
+    ext = PA.external_assertions(pkg, fixed_uints=True)
+
+    def run(ts):
+        proof = ob.prove(air_list, ts, ROOT, FAST, init_state=st)
+        pre = protocol.protocol_pre_observe(FAST, ROOT, preprocessed_root=proof["preprocessed_root"])
+        ok_o, _ = ob.verify(air_list, proof["log_heights"], ROOT, proof, FAST, external=ext)
+        ok_p, _ = pkg.verify(air_list, proof["log_heights"], ROOT, FAST, st, pre, proof["fields"], proof["commitments"],
+                             preprocessed_root=proof["preprocessed_root"], external=ext)
+        return ok_o, ok_p
+    assert run(traces) == (True, True)
+    forged = traces[6].copy()
+    forged[2, PA.MS_COL_VAL] = int(forged[0, PA.MS_COL_VAL])            # an expression's value repointed: its EcGroupAdd consume names an addition nobody proved
+    assert run(traces[:6] + [forged] + traces[7:]) == (False, False)
