@@ -2900,6 +2900,399 @@ def ec_msm_trace(msm, store, bpl, min_height=0):
     return t
 
 
+# ---- TranscriptEval: the transcript's hasher and binder (transcript/eval/{mod,trace}.rs, transcript/{binding,nodes}.rs, poseidon2/digest.rs) --
+# One node of the transcript DAG per active row: it hashes the node's preimage on the Poseidon2 chiplet (`lhs || rhs` under a capacity
+# that names the node kind) and settles the node's `Binding` tuple.  Kinds, a one-hot over the active row: the AND combinator folding two
+# `True` bindings (the root on row 0: its hash IS the public input), the ZERO_HASH leaf, uint leaves (a stored value under the VM's VALUE
+# capacity, or an explicit pin claim folded into the spine), uint ops (add / sub / mul bind the result pointer as a `Uint` binding and
+# consume the relation tuple that wires the pointers; `is` binds True), EC create / point at infinity, EC ops, and the one multi-row node,
+# an EcMsm absorb run (one Poseidon2 absorption span over the claim's (point, scalar) child digests, its terms matched as a positionless
+# set against the MSM chiplet).  All value soundness lives at the relation chiplets and stores; this chip is hashing and pointer wiring.
+# 39 main columns, sixteen flattened LogUp columns on eleven buses, lqd 1; public values = the transcript root.
+UINT256_PRECOMPILE_ID = 5689961814541250448     # `precompile_id("uint256")`: BLAKE3("miden-deferred-precompile/v1:7:uint256")[0..8] LE (core/src/deferred/precompile.rs:68-78)
+CURVE_PRECOMPILE_ID = 7090426675861304240       # `precompile_id("curve")`; both checked against the library's BLAKE3 in tests/test_precompile_eval.py
+TAG_AND_WORD = (1, 0, 0, 0)                                             # Tag::AND.as_word() (core/src/deferred/node.rs:53, :91-93)
+UINT_PIN_CLAIM_TAG = 3                                                  # transcript/nodes.rs
+VALUE_TAG_UINT, VALUE_TAG_GROUP = 1, 2                                  # transcript/binding.rs `ValueTag`
+UINT_OP_IDS = dict(add=1, sub=2, mul=3, **{"is": 4})                    # UintPrecompile::{ADD,SUB,MUL,EQ}_OP_ID (precompiles/src/math/uint/precompile.rs:131-135)
+EC_OP_IDS = dict(add=1, sub=2, **{"is": 3})                             # CurvePrecompile::{ADD,SUB,EQ}_OP_ID, MSM_OP_ID = 4 (curve/mod.rs:492-496)
+EC_MSM_OP_ID = 4
+TE_COLS, TE_AUX_COLS = 39, 16                                           # transcript/eval/mod.rs:107-259, :330-349
+(TE_COL_ACT, TE_COL_PERM_SEQ_ID) = 0, 1
+TE_COL_LHS, TE_COL_RHS, TE_COL_H = 2, 6, 10
+(TE_COL_IS_ZERO, TE_COL_OUT_MULT, TE_COL_IS_AND, TE_COL_IS_UINT_LEAF, TE_COL_IS_UINT_OP, TE_COL_IS_EC_CREATE, TE_COL_IS_EC_PAI, TE_COL_IS_EC_OP,
+ TE_COL_IS_ADD, TE_COL_IS_SUB, TE_COL_IS_MUL, TE_COL_IS_IS, TE_COL_IS_PINNED, TE_COL_PTR, TE_COL_BOUND_PTR, TE_COL_TAG_ARG1, TE_COL_A_PTR,
+ TE_COL_B_PTR, TE_COL_TAG_ARG0, TE_COL_EC_GROUP_PTR, TE_COL_IS_EC_MSM, TE_COL_IS_MSM_LAST, TE_COL_MSM_IDX, TE_COL_MSM_EXPR, TE_COL_MSM_IS_HEAD) = range(14, 39)
+
+
+def transcript_eval_air(host_aux=None):
+    """`TranscriptEvalAir::eval` (transcript/eval/mod.rs:384-661) and its `LookupAir::eval` (:686-1164): col 0 consume-lhs (True) | 1
+    consume-rhs + the True provide | 2, 3 the unhash permutation (rate0 + rate1 | capacity + digest) | 4 the leaf's UintVal | 5 the Uint /
+    pinned provide | 6 the op children's Uint bindings | 7 UintAdd | 8 UintMul | 9 the EC operands' Group bindings | 10 the Group provide |
+    11 EcPoint | 12 EcGroupAdd | 13 the MSM head's capacity | 14 the MSM term's child bindings | 15 MsmClaimTerm + MsmExpr."""
+    b = dag.AirBuilder(TE_COLS, aux_width=TE_AUX_COLS, num_randomness=NUM_RANDOMNESS, num_aux_values=NUM_SIGMA_VALUES,
+                       num_public=NUM_PUBLIC_VALUES)
+    loc, nxt = [b.main(c) for c in range(TE_COLS)], [b.main(c, 1) for c in range(TE_COLS)]
+    one, tr, first = b.const(1), b.is_transition(), b.is_first_row()
+    act, is_zero, out_mult = loc[TE_COL_ACT], loc[TE_COL_IS_ZERO], loc[TE_COL_OUT_MULT]
+    h = loc[TE_COL_H:TE_COL_H + 4]
+    _assert_bool(b, act)
+    b.assert_zero(tr * ((one - act) * nxt[TE_COL_ACT]))
+    _assert_bool(b, is_zero)
+    for h_i in h:
+        b.assert_zero(is_zero * h_i)
+    for i_ in range(4):
+        b.assert_zero(first * (h[i_] - b.public(i_)))                   # the root pin: row 0's hash is the public transcript root
+    b.assert_zero((one - act) * out_mult)
+    is_and, is_uint_leaf, is_uint_op = loc[TE_COL_IS_AND], loc[TE_COL_IS_UINT_LEAF], loc[TE_COL_IS_UINT_OP]
+    is_ec_create, is_ec_pai, is_ec_op = loc[TE_COL_IS_EC_CREATE], loc[TE_COL_IS_EC_PAI], loc[TE_COL_IS_EC_OP]
+    is_ec_msm, is_msm_last, is_pinned = loc[TE_COL_IS_EC_MSM], loc[TE_COL_IS_MSM_LAST], loc[TE_COL_IS_PINNED]
+    for col in (TE_COL_IS_AND, TE_COL_IS_UINT_LEAF, TE_COL_IS_UINT_OP, TE_COL_IS_EC_CREATE, TE_COL_IS_EC_PAI, TE_COL_IS_EC_OP, TE_COL_IS_EC_MSM,
+                TE_COL_IS_MSM_LAST, TE_COL_IS_PINNED):
+        _assert_bool(b, loc[col])
+    b.assert_zero(is_msm_last * (one - is_ec_msm))
+    is_add, is_sub, is_mul, is_is = loc[TE_COL_IS_ADD], loc[TE_COL_IS_SUB], loc[TE_COL_IS_MUL], loc[TE_COL_IS_IS]
+    for col in (TE_COL_IS_ADD, TE_COL_IS_SUB, TE_COL_IS_MUL, TE_COL_IS_IS):
+        _assert_bool(b, loc[col])
+    is_op = is_add + is_sub + is_mul + is_is
+    b.assert_zero(is_op - is_uint_op - is_ec_op)
+    b.assert_zero(is_ec_op * is_mul)
+    b.assert_zero(first * (is_zero + is_and + is_is + is_pinned - one))  # the root binds True
+    is_create = is_ec_create + is_ec_pai
+    for i_ in range(4):
+        b.assert_zero(is_ec_pai * loc[TE_COL_LHS + i_])
+        b.assert_zero(is_ec_pai * loc[TE_COL_RHS + i_])
+    group_ptr = loc[TE_COL_EC_GROUP_PTR]
+    is_result_op = is_op - is_is
+    b.assert_zero(is_and + is_zero + is_uint_leaf + is_uint_op + is_ec_create + is_ec_pai + is_ec_op + is_ec_msm - act)
+    not_uint_leaf = one - is_uint_leaf
+    ptr, bound_ptr = loc[TE_COL_PTR], loc[TE_COL_BOUND_PTR]
+    b.assert_zero(not_uint_leaf * is_pinned)
+    b.assert_zero((not_uint_leaf - is_result_op - is_ec_create - is_ec_pai - is_msm_last) * ptr)
+    b.assert_zero((not_uint_leaf - is_uint_op - is_ec_create - is_ec_msm) * bound_ptr)
+    b.assert_zero((one - is_create) * (loc[TE_COL_TAG_ARG1] - (is_uint_leaf * bound_ptr + is_pinned * (ptr - bound_ptr))))
+    a_ptr, b_ptr = loc[TE_COL_A_PTR], loc[TE_COL_B_PTR]
+    b.assert_zero((one - is_op - is_ec_create - is_ec_msm) * a_ptr)
+    b.assert_zero((one - is_op - is_ec_create - is_ec_msm) * b_ptr)
+    b.assert_zero(is_is * (b_ptr - a_ptr))
+    uint_op_id = is_add + is_sub * b.const(UINT_OP_IDS["sub"]) + is_mul * b.const(UINT_OP_IDS["mul"]) + is_is * b.const(UINT_OP_IDS["is"])
+    ec_op_id = is_add * b.const(EC_OP_IDS["add"]) + is_sub * b.const(EC_OP_IDS["sub"]) + is_is * b.const(EC_OP_IDS["is"])
+    b.assert_zero(loc[TE_COL_TAG_ARG0] - (is_pinned * bound_ptr + is_uint_op * uint_op_id + is_ec_op * ec_op_id))
+    b.assert_zero((one - is_ec_op * (one - is_is) - is_ec_msm) * group_ptr)
+    # the EcMsm absorb run: the head consumes the IV capacity, continuations run on the next Poseidon2 cycles, the tail reads the digest
+    is_ec_msm_next, is_msm_head, is_msm_head_next = nxt[TE_COL_IS_EC_MSM], loc[TE_COL_MSM_IS_HEAD], nxt[TE_COL_MSM_IS_HEAD]
+    _assert_bool(b, is_msm_head)
+    b.assert_zero(is_msm_head * (one - is_ec_msm))
+    continues = is_ec_msm * (one - is_msm_last)
+    starts = is_ec_msm_next * (one - is_ec_msm + is_msm_last)
+    b.assert_zero(first * (is_ec_msm * (is_msm_head - one)))
+    b.assert_zero(tr * (continues * (one - is_ec_msm_next)))
+    b.assert_zero(tr * (continues * is_msm_head_next))
+    b.assert_zero(tr * (starts * (is_msm_head_next - one)))
+    b.assert_zero(tr * (continues * (nxt[TE_COL_PERM_SEQ_ID] - loc[TE_COL_PERM_SEQ_ID] - one)))
+    b.assert_zero(first * (is_ec_msm * loc[TE_COL_MSM_IDX]))
+    b.assert_zero(tr * (starts * nxt[TE_COL_MSM_IDX]))
+    b.assert_zero(tr * (continues * (nxt[TE_COL_MSM_IDX] - loc[TE_COL_MSM_IDX] - one)))
+    b.assert_zero(tr * (continues * (nxt[TE_COL_MSM_EXPR] - loc[TE_COL_MSM_EXPR])))
+    b.assert_zero(tr * (continues * (nxt[TE_COL_EC_GROUP_PTR] - loc[TE_COL_EC_GROUP_PTR])))
+
+    lk = dag.LogUp(b, MAX_MESSAGE_WIDTH, NUM_BUS_IDS, closing="sigma_last_row")
+
+    def message(bus, fields):            # fields: column numbers, ("const", v), or callables (bb, row) -> expression
+        def msg(ch):
+            bb = lk.b if ch is lk.ch_c else lk.lb
+            row = [bb.main(c) for c in range(TE_COLS)]
+            return ch.encode(bus, [row[f] if isinstance(f, int) else (bb.const(f[1]) if isinstance(f, tuple) else f(bb, row)) for f in fields])
+        return msg
+    K = lambda v: ("const", v)                                                            # noqa: E731
+    cols = lambda at: [at + i_ for i_ in range(4)]                                        # noqa: E731
+
+    def mults(fn):
+        def both(bb):
+            return fn(bb, [bb.main(c) for c in range(TE_COLS)])
+        return both(lk.b), both(lk.lb)
+    binding = lambda h_at, tag, ptr_f, bound_f: message(BUS_BINDING, cols(h_at) + [tag, ptr_f, bound_f])   # noqa: E731
+    truth = lambda h_at: binding(h_at, K(VALUE_TAG_TRUE), K(0), K(0))                     # noqa: E731
+    group_b = lambda h_at, ptr_col: binding(h_at, K(VALUE_TAG_GROUP), ptr_col, K(0))      # noqa: E731
+    uint_b = lambda h_at, ptr_col: binding(h_at, K(VALUE_TAG_UINT), ptr_col, TE_COL_BOUND_PTR)   # noqa: E731
+    p2_in = lambda tag, fields: message(BUS_POSEIDON2_IN, [TE_COL_PERM_SEQ_ID, K(tag)] + fields)   # noqa: E731
+    f_create = lambda r: r[TE_COL_IS_EC_CREATE] + r[TE_COL_IS_EC_PAI]                     # noqa: E731
+    f_node = lambda r: r[TE_COL_IS_AND] + r[TE_COL_IS_UINT_LEAF] + r[TE_COL_IS_UINT_OP] + f_create(r) + r[TE_COL_IS_EC_OP] + r[TE_COL_IS_EC_MSM]   # noqa: E731
+    f_static = lambda r: r[TE_COL_IS_AND] + r[TE_COL_IS_UINT_LEAF] + r[TE_COL_IS_UINT_OP] + f_create(r) + r[TE_COL_IS_EC_OP]   # noqa: E731
+    f_neg_out = lambda bb, r: bb.const(0) - r[TE_COL_OUT_MULT]                            # noqa: E731
+    cap = [lambda bb, r: r[TE_COL_IS_AND] * bb.const(TAG_AND_WORD[0]) + (r[TE_COL_IS_UINT_LEAF] + r[TE_COL_IS_UINT_OP]) * bb.const(UINT256_PRECOMPILE_ID)
+           + r[TE_COL_IS_PINNED] * (bb.const(UINT_PIN_CLAIM_TAG) - bb.const(UINT256_PRECOMPILE_ID)) + (f_create(r) + r[TE_COL_IS_EC_OP]) * bb.const(CURVE_PRECOMPILE_ID),
+           lambda bb, r: r[TE_COL_IS_AND] * bb.const(TAG_AND_WORD[1]) + r[TE_COL_TAG_ARG0],
+           lambda bb, r: r[TE_COL_IS_AND] * bb.const(TAG_AND_WORD[2]) + r[TE_COL_TAG_ARG1],
+           lambda bb, r: r[TE_COL_IS_AND] * bb.const(TAG_AND_WORD[3])]
+    transient = lambda bb, r: bb.const(1) - r[TE_COL_IS_PINNED]                           # noqa: E731
+    add_or = lambda x_add, x_sub: (lambda bb, r: r[TE_COL_IS_ADD] * r[x_add] + r[TE_COL_IS_SUB] * r[x_sub])   # noqa: E731
+    ec_result = lambda bb, r: r[TE_COL_IS_EC_OP] * (bb.const(1) - r[TE_COL_IS_IS])        # noqa: E731
+    _emit_frac_cols(lk, [
+        [(mults(lambda bb, r: r[TE_COL_IS_AND]), truth(TE_COL_LHS))],
+        [(mults(lambda bb, r: r[TE_COL_IS_AND]), truth(TE_COL_RHS)),
+         (mults(lambda bb, r: f_neg_out(bb, r) * (r[TE_COL_IS_AND] + r[TE_COL_IS_ZERO] + r[TE_COL_IS_IS])), truth(TE_COL_H))],
+        [(mults(lambda bb, r: f_node(r)), p2_in(POSEIDON2_IN_TAG_RATE0, cols(TE_COL_LHS))), (mults(lambda bb, r: f_node(r)), p2_in(POSEIDON2_IN_TAG_RATE1, cols(TE_COL_RHS)))],
+        [(mults(lambda bb, r: f_static(r)), p2_in(POSEIDON2_IN_TAG_CAP, cap)),
+         (mults(lambda bb, r: f_node(r) - r[TE_COL_IS_EC_MSM] + r[TE_COL_IS_MSM_LAST]), message(BUS_POSEIDON2_OUT, [TE_COL_PERM_SEQ_ID] + cols(TE_COL_H)))],
+        [(mults(lambda bb, r: r[TE_COL_IS_UINT_LEAF]), message(BUS_UINT_VAL, [TE_COL_PTR, TE_COL_BOUND_PTR] + cols(TE_COL_LHS) + cols(TE_COL_RHS)))],
+        [(mults(lambda bb, r: f_neg_out(bb, r) * (r[TE_COL_IS_UINT_LEAF] + r[TE_COL_IS_UINT_OP] * (bb.const(1) - r[TE_COL_IS_IS]))),
+          binding(TE_COL_H, lambda bb, r: transient(bb, r) * bb.const(VALUE_TAG_UINT), lambda bb, r: transient(bb, r) * r[TE_COL_PTR],
+                  lambda bb, r: transient(bb, r) * r[TE_COL_BOUND_PTR]))],
+        [(mults(lambda bb, r: r[TE_COL_IS_UINT_OP] + r[TE_COL_IS_EC_CREATE]), uint_b(TE_COL_LHS, TE_COL_A_PTR)),
+         (mults(lambda bb, r: r[TE_COL_IS_UINT_OP] + r[TE_COL_IS_EC_CREATE]), uint_b(TE_COL_RHS, TE_COL_B_PTR))],
+        [(mults(lambda bb, r: r[TE_COL_IS_UINT_OP] * (r[TE_COL_IS_ADD] + r[TE_COL_IS_SUB])),
+          message(BUS_UINT_ADD, [TE_COL_BOUND_PTR, add_or(TE_COL_A_PTR, TE_COL_B_PTR), add_or(TE_COL_B_PTR, TE_COL_PTR), add_or(TE_COL_PTR, TE_COL_A_PTR), K(0)]))],
+        [(mults(lambda bb, r: r[TE_COL_IS_MUL]),
+          message(BUS_UINT_MUL, [K(1), K(0), TE_COL_A_PTR, TE_COL_B_PTR, TE_COL_BOUND_PTR, TE_COL_PTR, TE_COL_BOUND_PTR, K(0)]))],
+        [(mults(lambda bb, r: r[TE_COL_IS_EC_OP]), group_b(TE_COL_LHS, TE_COL_A_PTR)), (mults(lambda bb, r: r[TE_COL_IS_EC_OP]), group_b(TE_COL_RHS, TE_COL_B_PTR))],
+        [(mults(lambda bb, r: f_neg_out(bb, r) * (f_create(r) + ec_result(bb, r) + r[TE_COL_IS_MSM_LAST])), group_b(TE_COL_H, TE_COL_PTR))],
+        [(mults(lambda bb, r: f_create(r)), message(BUS_EC_POINT, [TE_COL_PTR, TE_COL_TAG_ARG1, TE_COL_A_PTR, TE_COL_B_PTR, TE_COL_IS_EC_PAI]))],
+        [(mults(ec_result), message(BUS_EC_GROUP_ADD, [TE_COL_EC_GROUP_PTR, add_or(TE_COL_A_PTR, TE_COL_PTR),
+                                                       lambda bb, r: (r[TE_COL_IS_ADD] + r[TE_COL_IS_SUB]) * r[TE_COL_B_PTR], add_or(TE_COL_PTR, TE_COL_A_PTR)]))],
+        [(mults(lambda bb, r: r[TE_COL_MSM_IS_HEAD]), p2_in(POSEIDON2_IN_TAG_CAP, [K(CURVE_PRECOMPILE_ID), K(EC_MSM_OP_ID), K(0), K(0)]))],
+        [(mults(lambda bb, r: r[TE_COL_IS_EC_MSM]), group_b(TE_COL_LHS, TE_COL_A_PTR)), (mults(lambda bb, r: r[TE_COL_IS_EC_MSM]), uint_b(TE_COL_RHS, TE_COL_B_PTR))],
+        [(mults(lambda bb, r: r[TE_COL_IS_EC_MSM]), message(BUS_MSM_CLAIM_TERM, [TE_COL_MSM_EXPR, TE_COL_A_PTR, TE_COL_B_PTR])),
+         (mults(lambda bb, r: r[TE_COL_IS_MSM_LAST]),
+          message(BUS_MSM_EXPR, [TE_COL_MSM_EXPR, TE_COL_EC_GROUP_PTR, TE_COL_PTR, lambda bb, r: r[TE_COL_MSM_IDX] + bb.const(1)]))]])
+    lookup = lk.finish("transcript_eval")
+    return dag.Air(b, _host_aux(lookup, host_aux), "transcript_eval"), lookup
+
+
+class TranscriptEvalRequires:
+    """`TranscriptEvalRequires` (transcript/eval/trace.rs:294-893): the transcript DAG as it is recorded -- `Truthy` handles (linear: each is
+    consumed exactly once, by an AND or as the root), uint and EC value nodes (deduplicated, consumed by their readers' count), every node's
+    unhash permutation on the Poseidon2 ledger, every relation an op node names in the uint / EC ledgers.  Handles are dicts:
+    Truthy {id, hash}; UintNode {id, hash, ptr, bound_ptr}; EcNode {id, hash, point}."""
+
+    def __init__(self, p2, req, msm=None):
+        self.p2, self.req, self.msm = p2, req, msm                      # Poseidon2Requires | EcRequire over the uint / EC ledgers | EcMsmRequires
+        self.next_id, self.live, self.consumers, self.nodes, self.uint_dedup, self.ec_dedup = 0, set(), {}, [], {}, {}
+
+    def _one_shot(self, cap, lo, hi):
+        idx = self.p2.require_absorption(cap, [(lo, hi)])
+        self.p2.require_digest(idx)
+        return tuple(int(x) for x in self.p2.digest(idx)), self.p2.span(idx)[0]
+
+    def _fresh(self, hash_):
+        self.next_id += 1
+        self.live.add(self.next_id - 1)
+        return dict(id=self.next_id - 1, hash=tuple(hash_))
+
+    def _value(self, kind, hash_, perm, **fields):
+        self.next_id += 1
+        self.nodes.append(dict(id=self.next_id - 1, kind=kind, hash=hash_, perm=perm, **fields))
+        self.consumers[self.next_id - 1] = 0
+        return self.next_id - 1
+
+    def _consume(self, t):
+        assert t["id"] in self.live, "Truthy consumed twice"
+        self.live.remove(t["id"])
+
+    def issue(self, hash_):              # a `Binding(h, True)` provided elsewhere: the Keccak node's
+        return self._fresh(hash_)
+
+    def zero(self):
+        t = self._fresh((0, 0, 0, 0))
+        self.nodes.append(dict(id=t["id"], kind="zero", hash=(0, 0, 0, 0), perm=None))
+        return t
+
+    def record_and(self, a, b):
+        self._consume(a)
+        self._consume(b)
+        hash_, perm = self._one_shot(TAG_AND_WORD, a["hash"], b["hash"])
+        out = self._fresh(hash_)
+        self.nodes.append(dict(id=out["id"], kind="and", hash=hash_, perm=perm, lhs=a["hash"], rhs=b["hash"]))
+        return out
+
+    def _uint_leaf(self, ptr, pinned):
+        store = self.req.store
+        value, bound_ptr = store.rows[ptr]
+        limbs = [(value >> (32 * j)) & 0xffffffff for j in range(8)]
+        cap = (UINT_PIN_CLAIM_TAG, bound_ptr, ptr, 0) if pinned else (UINT256_PRECOMPILE_ID, 0, bound_ptr, 0)   # `P2Cap::uint_pin_claim` / `uint_value`
+        store.require_uintval(ptr)
+        hash_, perm = self._one_shot(cap, limbs[0:4], limbs[4:8])
+        return hash_, perm, dict(ptr=ptr, bound_ptr=bound_ptr, pinned=pinned, lo=limbs[0:4], hi=limbs[4:8])
+
+    def uint_leaf(self, ptr):
+        if ("leaf", ptr) not in self.uint_dedup:
+            hash_, perm, f = self._uint_leaf(ptr, False)
+            self.uint_dedup[("leaf", ptr)] = dict(id=self._value("uint_leaf", hash_, perm, **f), hash=hash_, ptr=ptr, bound_ptr=f["bound_ptr"])
+        return self.uint_dedup[("leaf", ptr)]
+
+    def pin_uint(self, ptr):
+        hash_, perm, f = self._uint_leaf(ptr, True)
+        t = self._fresh(hash_)
+        self.nodes.append(dict(id=t["id"], kind="uint_leaf", hash=hash_, perm=perm, **f))
+        return t
+
+    def uint_op(self, op, a, b):
+        assert op in ("add", "sub", "mul") and a["bound_ptr"] == b["bound_ptr"], "op operands must share a modulus"
+        key = (op, a["hash"], b["hash"])
+        if key not in self.uint_dedup:
+            r_ptr = {"add": lambda: self.req._uint_add(a["ptr"], b["ptr"]), "sub": lambda: self.req._uint_sub(a["ptr"], b["ptr"]),
+                     "mul": lambda: self.req._mac(1, a["ptr"], b["ptr"], 0, a["bound_ptr"])}[op]()
+            self.consumers[a["id"]] += 1
+            self.consumers[b["id"]] += 1
+            hash_, perm = self._one_shot((UINT256_PRECOMPILE_ID, UINT_OP_IDS[op], 0, 0), a["hash"], b["hash"])
+            nid = self._value("uint_op", hash_, perm, op=op, lhs=a["hash"], rhs=b["hash"], a_ptr=a["ptr"], b_ptr=b["ptr"], r_ptr=r_ptr, bound_ptr=a["bound_ptr"])
+            self.uint_dedup[key] = dict(id=nid, hash=hash_, ptr=r_ptr, bound_ptr=a["bound_ptr"])
+        return self.uint_dedup[key]
+
+    def record_is(self, a, b):
+        assert a["bound_ptr"] == b["bound_ptr"] and a["ptr"] == b["ptr"], "Is operands are unequal (distinct interned pointers): the claim is unprovable"
+        self.consumers[a["id"]] += 1
+        self.consumers[b["id"]] += 1
+        hash_, perm = self._one_shot((UINT256_PRECOMPILE_ID, UINT_OP_IDS["is"], 0, 0), a["hash"], b["hash"])
+        out = self._fresh(hash_)
+        self.nodes.append(dict(id=out["id"], kind="uint_op", hash=hash_, perm=perm, op="is", lhs=a["hash"], rhs=b["hash"], a_ptr=a["ptr"], b_ptr=b["ptr"],
+                               r_ptr=0, bound_ptr=a["bound_ptr"]))
+        return out
+
+    def ec_create(self, group, x, y):
+        key = ("create", group, x["hash"], y["hash"])
+        if key not in self.ec_dedup:
+            assert x["bound_ptr"] == y["bound_ptr"], "coordinates must share a modulus"
+            point = self.req.point_on_group(group, x["ptr"], y["ptr"])
+            self.consumers[x["id"]] += 1
+            self.consumers[y["id"]] += 1
+            hash_, perm = self._one_shot((CURVE_PRECOMPILE_ID, 0, group, 0), x["hash"], y["hash"])
+            nid = self._value("ec_create", hash_, perm, lhs=x["hash"], rhs=y["hash"], x_ptr=x["ptr"], y_ptr=y["ptr"], group=group, point=point,
+                              bound_ptr=x["bound_ptr"], is_pai=False)
+            self.ec_dedup[key] = dict(id=nid, hash=hash_, point=point)
+        return self.ec_dedup[key]
+
+    def ec_pai(self, group):
+        key = ("create", group, (0, 0, 0, 0), (0, 0, 0, 0))
+        if key not in self.ec_dedup:
+            pai = self.req.pai_on_group(group)
+            hash_, perm = self._one_shot((CURVE_PRECOMPILE_ID, 0, group, 0), (0, 0, 0, 0), (0, 0, 0, 0))
+            nid = self._value("ec_create", hash_, perm, lhs=(0, 0, 0, 0), rhs=(0, 0, 0, 0), x_ptr=0, y_ptr=0, group=group, point=pai, bound_ptr=0, is_pai=True)
+            self.ec_dedup[key] = dict(id=nid, hash=hash_, point=pai)
+        return self.ec_dedup[key]
+
+    def ec_add(self, p, q):
+        key = ("add", p["hash"], q["hash"])
+        if key not in self.ec_dedup:
+            group = self.req.ec.point_params(p["point"])[0]
+            r = self.req.add(p["point"], q["point"], 1)
+            self.consumers[p["id"]] += 1
+            self.consumers[q["id"]] += 1
+            hash_, perm = self._one_shot((CURVE_PRECOMPILE_ID, EC_OP_IDS["add"], 0, 0), p["hash"], q["hash"])
+            nid = self._value("ec_op", hash_, perm, op="add", lhs=p["hash"], rhs=q["hash"], p_ptr=p["point"], q_ptr=q["point"], r_ptr=r, group=group)
+            self.ec_dedup[key] = dict(id=nid, hash=hash_, point=r)
+        return self.ec_dedup[key]
+
+    def ec_is(self, p, q):
+        assert p["point"] == q["point"], "Is operands are unequal points (distinct interned pointers): unprovable"
+        self.consumers[p["id"]] += 1
+        self.consumers[q["id"]] += 1
+        hash_, perm = self._one_shot((CURVE_PRECOMPILE_ID, EC_OP_IDS["is"], 0, 0), p["hash"], q["hash"])
+        out = self._fresh(hash_)
+        self.nodes.append(dict(id=out["id"], kind="ec_op", hash=hash_, perm=perm, op="is", lhs=p["hash"], rhs=q["hash"], p_ptr=p["point"], q_ptr=q["point"],
+                               r_ptr=0, group=0))
+        return out
+
+    def record_ec_msm(self, expr, terms):
+        """`record_ec_msm` (:757-838): the claim sum of scalar x base over `terms` = [(EcNode, UintNode)] in the CALLER's order, resolved against
+        the MSM chiplet's expression `expr` (whose term SET it must be); one Poseidon2 absorption span over the children's digests."""
+        if ("msm", expr) not in self.ec_dedup:
+            e = self.msm.exprs[expr - 1]
+            assert sorted((t[0]["point"], t[1]["ptr"]) for t in terms) == sorted(self.msm.terms(expr)), "the claim's terms are the expression's term set"
+            assert all(t[1]["bound_ptr"] == e["sbound"] for t in terms), "term scalars are stored under the claim's scalar bound"
+            blocks = [(t[0]["hash"], t[1]["hash"]) for t in terms]
+            idx = self.p2.require_absorption((CURVE_PRECOMPILE_ID, EC_MSM_OP_ID, 0, 0), blocks)
+            self.p2.require_digest(idx)
+            from . import miden_air as MA
+            absorbs, cap, head = [], [CURVE_PRECOMPILE_ID, EC_MSM_OP_ID, 0, 0], self.p2.span(idx)[0]
+            for k, ((base, scalar), (r0, r1)) in enumerate(zip(terms, blocks)):
+                out = MA.permute(list(r0) + list(r1) + list(cap))
+                cap = out[8:12]
+                absorbs.append(dict(base_hash=base["hash"], scalar_hash=scalar["hash"], base_ptr=base["point"], scalar_ptr=scalar["ptr"], perm=head + k,
+                                    digest=tuple(int(x) for x in out[0:4])))
+                self.consumers[base["id"]] += 1
+                self.consumers[scalar["id"]] += 1
+            assert absorbs[-1]["digest"] == tuple(int(x) for x in self.p2.digest(idx))
+            val = self.msm.resolve(expr)
+            nid = self._value("ec_msm", absorbs[-1]["digest"], None, absorbs=absorbs, expr=expr, group=e["group"], val=val, bound=e["sbound"])
+            self.ec_dedup[("msm", expr)] = dict(id=nid, hash=absorbs[-1]["digest"], point=val)
+        return self.ec_dedup[("msm", expr)]
+
+    def fold(self, truthies):
+        """`Session::assert_and_fold`: a left fold of the claims into one root (a lone claim is its own root)."""
+        acc = truthies[0]
+        for t in truthies[1:]:
+            acc = self.record_and(acc, t)
+        return acc
+
+
+def transcript_eval_trace(requires, root, min_height=0):
+    """`generate_trace` / `push_node_row` (transcript/eval/trace.rs:895-1155): row 0 = the root (`out_mult` 0: it absorbs the Binding sigma),
+    then every other node -- a True-binding node once, a value node by its readers' count, an EcMsm claim as its absorb run -- then ONE merged
+    ZERO_HASH row for all zero leaves, then all-zero rows.  -> (main, the public root)"""
+    assert requires.live == {root["id"]}, "the transcript has stray unasserted claims, or the root is not live"
+    assert all(requires.consumers.values()), "a value node nobody reads"
+    by_id = {n["id"]: n for n in requires.nodes}
+    assert root["id"] in by_id, "the root must be a recorded node (zero leaf, AND, Is or pin), not a raw handle"
+    rows, zero_mult = [(by_id[root["id"]], 0)], 0
+    for n in requires.nodes:
+        if n["id"] == root["id"]:
+            continue
+        if n["kind"] == "zero":
+            zero_mult += 1
+        else:
+            truthy = n["kind"] == "and" or (n["kind"] == "uint_leaf" and n["pinned"]) or (n["kind"] in ("uint_op", "ec_op") and n["op"] == "is")
+            rows.append((n, 1 if truthy else requires.consumers[n["id"]]))
+    if zero_mult:
+        rows.append((dict(kind="zero", hash=(0, 0, 0, 0), perm=None), zero_mult))
+    n_rows = sum(len(n["absorbs"]) if n["kind"] == "ec_msm" else 1 for n, _ in rows)
+    t = np.zeros((max(2, min_height, 1 << (n_rows - 1).bit_length()), TE_COLS), dtype=np.uint64)
+    r = 0
+    for n, out_mult in rows:
+        if n["kind"] == "ec_msm":
+            k = len(n["absorbs"])
+            for idx, a in enumerate(n["absorbs"]):
+                row = t[r]
+                row[[TE_COL_ACT, TE_COL_IS_EC_MSM, TE_COL_IS_MSM_LAST, TE_COL_MSM_IS_HEAD, TE_COL_PERM_SEQ_ID]] = [1, 1, int(idx == k - 1), int(idx == 0), a["perm"]]
+                row[TE_COL_LHS:TE_COL_LHS + 4], row[TE_COL_RHS:TE_COL_RHS + 4], row[TE_COL_H:TE_COL_H + 4] = a["base_hash"], a["scalar_hash"], a["digest"]
+                row[[TE_COL_A_PTR, TE_COL_B_PTR, TE_COL_MSM_IDX, TE_COL_MSM_EXPR, TE_COL_EC_GROUP_PTR, TE_COL_BOUND_PTR]] = \
+                    [a["base_ptr"], a["scalar_ptr"], idx, n["expr"], n["group"], n["bound"]]
+                if idx == k - 1:
+                    row[TE_COL_PTR], row[TE_COL_OUT_MULT] = n["val"], out_mult % P
+                r += 1
+            continue
+        row = t[r]
+        r += 1
+        row[TE_COL_ACT], row[TE_COL_OUT_MULT] = 1, out_mult % P
+        if n["kind"] == "zero":
+            row[TE_COL_IS_ZERO] = 1
+            continue
+        row[TE_COL_PERM_SEQ_ID] = n["perm"]
+        row[TE_COL_H:TE_COL_H + 4] = n["hash"]
+        if n["kind"] == "uint_leaf":
+            row[TE_COL_LHS:TE_COL_LHS + 4], row[TE_COL_RHS:TE_COL_RHS + 4] = n["lo"], n["hi"]
+            row[[TE_COL_IS_UINT_LEAF, TE_COL_IS_PINNED, TE_COL_PTR, TE_COL_BOUND_PTR]] = [1, int(n["pinned"]), n["ptr"], n["bound_ptr"]]
+            if n["pinned"]:
+                row[TE_COL_TAG_ARG0], row[TE_COL_TAG_ARG1] = n["bound_ptr"], n["ptr"]
+            else:
+                row[TE_COL_TAG_ARG1] = n["bound_ptr"]
+            continue
+        row[TE_COL_LHS:TE_COL_LHS + 4], row[TE_COL_RHS:TE_COL_RHS + 4] = n["lhs"], n["rhs"]
+        op_col = dict(add=TE_COL_IS_ADD, sub=TE_COL_IS_SUB, mul=TE_COL_IS_MUL, **{"is": TE_COL_IS_IS})
+        if n["kind"] == "and":
+            row[TE_COL_IS_AND] = 1
+        elif n["kind"] == "uint_op":
+            row[[TE_COL_IS_UINT_OP, op_col[n["op"]], TE_COL_PTR, TE_COL_BOUND_PTR, TE_COL_A_PTR, TE_COL_B_PTR, TE_COL_TAG_ARG0]] = \
+                [1, 1, n["r_ptr"], n["bound_ptr"], n["a_ptr"], n["b_ptr"], UINT_OP_IDS[n["op"]]]
+        elif n["kind"] == "ec_create":
+            row[[TE_COL_IS_EC_PAI if n["is_pai"] else TE_COL_IS_EC_CREATE, TE_COL_PTR, TE_COL_BOUND_PTR, TE_COL_A_PTR, TE_COL_B_PTR, TE_COL_TAG_ARG1]] = \
+                [1, n["point"], n["bound_ptr"], n["x_ptr"], n["y_ptr"], n["group"]]
+        else:
+            row[[TE_COL_IS_EC_OP, op_col[n["op"]], TE_COL_PTR, TE_COL_A_PTR, TE_COL_B_PTR, TE_COL_TAG_ARG0, TE_COL_EC_GROUP_PTR]] = \
+                [1, 1, n["r_ptr"], n["p_ptr"], n["q_ptr"], EC_OP_IDS[n["op"]], n["group"]]
+    return t, [int(x) for x in t[0, TE_COL_H:TE_COL_H + 4]]
+
+
 K1_BOUND = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2E                                    # secp256k1: p - 1
 K1_G = (0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798, 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8)
 
@@ -3025,3 +3418,73 @@ def ec_msm_session(terms, host_aux=None, min_height=8):
     pairs = [byte_pair_lut_air(host_aux), uint_store_mul_air(host_aux), uint_add_air(host_aux), ec_groups_air(host_aux),
              ec_point_store_air(host_aux), ec_group_add_air(host_aux), ec_msm_air(host_aux), requirer_air(host_aux, payload=10)]
     return pairs, [byte_pair_lut_trace(bpl), uint, add, groups, points, ec_add_main, msm_main, readers], (val, acc, (store, adds, muls, ec, ec_add, msm))
+
+
+def precompile_session(inputs, host_aux=None, min_height=8, permute_batch=None):
+    """A whole deferred-precompile SESSION: all twelve AIRs of `ChipletAir::all()` in its order (session/prove.rs:111-126) -- [ChunkNode,
+    Poseidon2, KeccakRound, BytePairLut, KeccakSponge, TranscriptEval, UintStoreMul, UintAdd, EcGroups, EcPointStore, EcGroupAdd, EcMsm] --
+    over the fixed environment, no stand-in: every bus closes between real chiplets and the verifier's boundary terms, and the public
+    input is the transcript root the eval chip's first row is pinned to.  The transcript folds these claims:
+      keccak256(data) for every `data` of `inputs` (the digests are the session's outputs);
+      over the secp256k1 base field: ((a b + c) - c) is (a b), on stored 256-bit values;
+      a pinned value claim (the stored uint at protocol address 100 is what it is);
+      on secp256k1: 5 G + 7 G is 12 G, the sum by the group law chiplet, 12 G bound by its coordinates;
+      an MSM claim: 0xb5 G + 0x4d (3 G) resolved from the MSM chiplet's expression, is the point with the coordinates an affine sum gives;
+      the ZERO_HASH leaf (the AND identity).
+    -> ([(air, lookup)], [traces], dict(public_root, keccak_digests, ledgers))"""
+    bpl, p2 = BytePairLutRequires(), Poseidon2Requires()
+    chunks = ChunkRequires(p2)
+    sponge = SpongeRequires(chunks, bpl)
+    node = KeccakNodeRequires(sponge)
+    store, adds, muls, ec, ec_add = UintStore().install_fixed_uints(), UintAddRequires(), UintMulRequires(), EcStore(), EcAddRequires()
+    req = EcRequire(ec, store, muls, adds, ec_add)
+    msm = EcMsmRequires(req)
+    ev = TranscriptEvalRequires(p2, req, msm)
+    fp, m = K1_BASE_BOUND_PTR, K1_BOUND + 1
+    claims, digests = [], []
+    for data in inputs:
+        out = node.require(data)
+        digests.append(out["keccak_digest"])
+        claims.append(ev.issue(out["h_keccak"]))
+    a, b_, c = (ev.uint_leaf(store.intern(v, fp)) for v in (K1_G[0], K1_G[1], 0x1234567890abcdef << 128 | 77))
+    prod = ev.uint_op("mul", a, b_)
+    claims.append(ev.record_is(ev.uint_op("sub", ev.uint_op("add", prod, c), c), prod))
+    claims.append(ev.pin_uint(store.intern_pinned(100, (K1_G[0] * 3 + 1) % m, fp)))
+    group, _pai = req.create_group(0, 7, fp)
+    mult = k1_multiples(12)
+    point = lambda k: ev.ec_create(group, ev.uint_leaf(store.intern(mult[k - 1][0], fp)), ev.uint_leaf(store.intern(mult[k - 1][1], fp)))   # noqa: E731
+    claims.append(ev.ec_is(ev.ec_add(point(5), point(7)), point(12)))
+    terms, e_acc = [(0xb5, 1), (0x4d, 3)], None
+    intros = [msm.intro(point(mm)["point"]) for _, mm in terms]
+    for bit in range(max(k for k, _ in terms).bit_length() - 1, -1, -1):
+        if e_acc is not None:
+            e_acc = msm.combine(e_acc, e_acc)
+        for (k, _), e in zip(terms, intros):
+            if (k >> bit) & 1:
+                e_acc = e if e_acc is None else msm.combine(e_acc, e)
+    by_base = dict(msm.terms(e_acc))
+    claim_terms = [(point(mm), ev.uint_leaf(by_base[point(mm)["point"]])) for _, mm in reversed(terms)]      # the CALLER's order, not the chiplet's
+    msm_node = ev.record_ec_msm(e_acc, claim_terms)
+    vx, vy = ec.point_params(msm_node["point"])[1]
+    claims.append(ev.ec_is(msm_node, ev.ec_create(group, ev.uint_leaf(vx), ev.uint_leaf(vy))))
+    claims.append(ev.zero())
+    root = ev.fold(claims)
+    ec.require_fixed_groups()
+    # the dependency-ordered sweep (`SessionTraces`): relations before the stores that read their demand, the Poseidon2 ledger after every
+    # node that hashes, the table last
+    eval_main, public_root = transcript_eval_trace(ev, root, min_height=min_height)
+    add = uint_add_trace(adds, store, min_height=min_height)
+    ec_add_main = ec_group_add_trace(ec_add, ec, bpl, min_height=min_height)
+    msm_main = ec_msm_trace(msm, store, bpl, min_height=min_height)
+    uint = uint_store_mul_trace(store, muls, bpl, min_height=min_height)
+    groups, points = ec_store_traces(ec, min_height=min_height)
+    kr_main, _mem = keccak_round_trace(sponge.perm_inputs, bpl)
+    p2_main, _ = poseidon2_chiplet_trace(p2, permute_batch=permute_batch)
+    chunk_node = chunk_node_trace(chunks, node)
+    sponge_main = keccak_sponge_trace(sponge)
+    pairs = [chunk_node_air(host_aux), poseidon2_chiplet_air(host_aux), keccak_round_air(host_aux), byte_pair_lut_air(host_aux), keccak_sponge_air(host_aux),
+             transcript_eval_air(host_aux), uint_store_mul_air(host_aux), uint_add_air(host_aux), ec_groups_air(host_aux), ec_point_store_air(host_aux),
+             ec_group_add_air(host_aux), ec_msm_air(host_aux)]
+    traces = [chunk_node, p2_main, kr_main, byte_pair_lut_trace(bpl), sponge_main, eval_main, uint, add, groups, points, ec_add_main, msm_main]
+    return pairs, traces, dict(public_root=public_root, keccak_digests=digests, msm_value=(store.value(vx), store.value(vy)),
+                               ledgers=dict(p2=p2, store=store, adds=adds, muls=muls, ec=ec, ec_add=ec_add, msm=msm, eval=ev, node=node))

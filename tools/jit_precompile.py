@@ -28,7 +28,7 @@ def shipped_blobs():
                                 ("requirer7", PA.requirer_air(payload=7)), ("chunk", PA.chunk_air()), ("poseidon2_chiplet", PA.poseidon2_chiplet_air()),
                                 ("keccak_sponge", PA.keccak_sponge_air()), ("keccak_node", PA.keccak_node_air()), ("chunk_node", PA.chunk_node_air()),
                                 ("uint_add", PA.uint_add_air()), ("requirer10", PA.requirer_air(payload=10)),
-                                ("ec_point_store", PA.ec_point_store_air()), ("ec_group_add", PA.ec_group_add_air()), ("uint_store_mul", PA.uint_store_mul_air()), ("ec_msm", PA.ec_msm_air())):
+                                ("ec_point_store", PA.ec_point_store_air()), ("ec_group_add", PA.ec_group_add_air()), ("uint_store_mul", PA.uint_store_mul_air()), ("ec_msm", PA.ec_msm_air()), ("transcript_eval", PA.transcript_eval_air())):
         out += [(name + ".dag", air.blob), (name + ".lkp", lookup.blob)]
     return out
 
