@@ -603,6 +603,49 @@ def uint_add_session_probe(pkg, ctx, steps=3):
             "trace_generation_s": gen_s}
 
 
+def precompile_full_session_probe(pkg, ctx, steps=3):
+    """The second client's WHOLE session: all twelve AIRs of `ChipletAir::all()` in the reference's order (precompiles-prover/src/session/
+    prove.rs:111-126) -- [ChunkNode, Poseidon2, KeccakRound, BytePairLut, KeccakSponge, TranscriptEval, UintStoreMul, UintAdd, EcGroups,
+    EcPointStore, EcGroupAdd, EcMsm] -- over the fixed environment, no stand-in, the transcript root as the public input: 24 Keccak-256
+    claims, a 256-bit arithmetic claim, a pin claim, an EC addition claim and an MSM claim folded into one root; production parameters,
+    every aux column on the device, verified through the full `eval_external`."""
+    import numpy as np
+    from miden_vm_amd import protocol, precompile_airs as PA
+    rng = np.random.default_rng(12)
+    t0 = time.perf_counter()
+    inputs = [b"", b"abc"] + [bytes(rng.integers(0, 256, int(rng.integers(0, 1201)), dtype=np.uint8)) for _ in range(22)]
+    pairs, host, info = PA.precompile_session(inputs, permute_batch=ctx.poseidon2_permute)
+    gen_s = time.perf_counter() - t0
+    airs_h, root_pub = [p_[0] for p_ in pairs], info["public_root"]
+    prm = dict(protocol.PROD_PARAMS)
+    dairs = [pkg.DeviceAir(ctx, a) for a in airs_h]
+    raw = ctx.upload_trace(airs_h[3].preprocessed)
+    com = pkg.commit_traces(ctx, [raw], prm["log_blowup"])
+    dairs[3].attach_preprocessed(com.tree(), 0, raw=raw)
+    for d, (_, lk) in zip(dairs, pairs):
+        d.attach_lookup(pkg.DeviceLookup(ctx, lk))
+    st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
+    pre = protocol.protocol_pre_observe(prm, root_pub, preprocessed_root=com.root())
+    traces = [ctx.upload_trace(t) for t in host]
+    ext = PA.external_assertions(pkg, fixed_uints=True)
+    proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    ok, _ = pkg.verify(airs_h, proof.log_trace_heights, root_pub, prm, st, pre, proof.fields, proof.commitments, preprocessed_root=com.root(), external=ext)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    dt = (time.perf_counter() - t0) / steps
+    for t in traces:
+        t.free()
+    led = info["ledgers"]
+    return {"workload": "the whole deferred-precompile session: ChipletAir::all() = ChunkNodeAir, Poseidon2Air, KeccakRoundAir, BytePairLutAir (preprocessed), KeccakSpongeAir, TranscriptEvalAir, UintStoreMulAir, UintAddAir, EcGroupsAir, EcPointStoreAir, EcGroupAddAir, EcMsmAir; the fixed environment; the transcript root as the public input; production parameters, aux columns on the device",
+            "keccak_claims": len(inputs), "input_bytes": sum(len(x) for x in inputs), "transcript_nodes": len(led["eval"].nodes),
+            "poseidon2_permutations": led["p2"].next_seq, "keccak_permutations": len(led["node"].sponge.perm_inputs), "point_additions": len(led["ec_add"].ops),
+            "modular_macs": len(led["muls"].ops), "modular_additions": len(led["adds"].ops), "public_root": [int(x) for x in root_pub],
+            "log_trace_heights": proof.log_trace_heights, "ms_per_proof": dt * 1e3, "proof_bytes": len(proof.bytes),
+            "verifies_with_eval_external": bool(ok), "keccak256_of_empty": bytes(info["keccak_digests"][0]).hex(),
+            "compiled_chunks": [a.compiled_chunks for a in dairs], "trace_generation_s": gen_s}
+
+
 def ec_msm_session_probe(pkg, ctx, steps=3):
     """The second client's MSM chiplet (precompiles-prover/src/ec/msm: `EcMsmAir`, symbolic multi-scalar-multiplication expressions built
     by intro / neg / combine steps the AIR checks one by one: variable-length blocks, merge walks over sorted term lists, a strict pointer
@@ -1373,6 +1416,10 @@ def main():
             out["ec_msm_session"] = ec_msm_session_probe(pkg, ctx)
         except Exception as e:
             out["ec_msm_session"] = {"error": repr(e)[:300]}
+        try:
+            out["precompile_full_session"] = precompile_full_session_probe(pkg, ctx)
+        except Exception as e:
+            out["precompile_full_session"] = {"error": repr(e)[:300]}
         try:
             # the service-level probes run in a process of their own (tools/bench_inflight_h2d.py, no torch in it): measured in THIS
             # process, which also hosts PyTorch's HIP runtime, the same loops lose the copy / kernel overlap (k = 1 with its uploads

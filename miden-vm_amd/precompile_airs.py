@@ -1,9 +1,10 @@
 """The second client of the backend: AIRs of the precompile prover (`precompiles-prover/src`), hand-ported against `dag.AirBuilder`
 like the VM's three AIRs, and the statement layer of its session (`precompiles-prover/src/session/prove.rs`).
 
-What is here: eleven of the twelve AIRs of `ChipletAir::all()` (session/prove.rs:111-126) -- the whole HASHING HALF of the
-session (ChunkNode, Poseidon2, KeccakRound, BytePairLut, KeccakSponge; ChunkNode also as its two stand-alone halves), the 256-bit
-ARITHMETIC (UintStoreMul, UintAdd), and the whole ELLIPTIC-CURVE half (EcGroups, EcPointStore, EcGroupAdd, EcMsm) --
+What is here: ALL TWELVE AIRs of `ChipletAir::all()` (session/prove.rs:111-126) -- the HASHING half of the session
+(ChunkNode, Poseidon2, KeccakRound, BytePairLut, KeccakSponge; ChunkNode also as its two stand-alone halves), the TRANSCRIPT evaluator
+(TranscriptEval), the 256-bit ARITHMETIC (UintStoreMul, UintAdd), and the ELLIPTIC-CURVE half (EcGroups, EcPointStore, EcGroupAdd, EcMsm)
+-- and `precompile_session`, a whole deferred-precompile session over them: no stand-in, the transcript root as the public input --
 * `BytePairLutAir` (`primitives/byte_pair_lut.rs`): the one AIR of the stack with PREPROCESSED columns and a fixed height -- the
   2^16-row `(a, b, !a & b, a ^ b)` table committed once, three witness multiplicity columns, two LogUp columns;
 * `KeccakRoundAir` (`hash/keccak/round/{mod,program}.rs`): its consumer -- a three-address machine `c = ROL(a OP b, s)` whose 128-slot
@@ -48,11 +49,17 @@ ARITHMETIC (UintStoreMul, UintAdd), and the whole ELLIPTIC-CURVE half (EcGroups,
   merge-walk cursors over the operands' sorted term lists, scalars on a shared base added mod the group order, values added by a consumed
   `EcGroupAdd`, a strict pointer ordering against circular derivations); 38 columns, eleven LogUp columns on nine buses.  SEVEN real
   chiplets prove sum k_i P_i; only the eval chip's resolve of the final expression stays outside;
+* `TranscriptEvalAir` (`transcript/eval/{mod,trace}.rs`, `transcript/{binding,nodes}.rs`): the transcript's hasher and binder -- one DAG
+  node per row (AND combinators, the ZERO_HASH leaf, uint leaves and pin claims, uint ops, EC create / infinity, EC ops, the multi-row
+  EcMsm absorb run), each hashed on the Poseidon2 chiplet under a capacity that names its kind and settled on the `Binding` bus; row 0
+  is the root and its hash is the PUBLIC INPUT; 39 columns, sixteen LogUp columns on eleven buses.  With it nothing is left outside:
+  `precompile_session` runs the twelve chiplets in the reference's order;
 the precompile prover's LogUp adapter (natural last-row sigma closing, `logup/constraint.rs`: `dag.LogUp(closing="sigma_last_row")`),
 its bus registry (`relations.rs`) and `ChipletMultiAir::eval_external` (`session/prove.rs:259-272`: sum of the committed sigmas + the
 fixed boundary correction).
 
-What is not: `TranscriptEvalAir`, the transcript's hasher and binder (~2.3 kLoC of the reference).  Where a statement needs the other side of a bus that only they touch -- the transcript's readers of the `Binding` tuples in
+What is not: nothing of the session's AIRs (the reference's `Session` front end -- its claim-building API over these ledgers -- is the part
+`precompile_session` only sketches: `EcRequire.sub`, transcript-level dedup of repeated subtrees).  Where one of the SMALLER statements needs the other side of a bus that only they touch -- the transcript's readers of the `Binding` tuples in
 the hashing session, or, in the smaller sessions of the tests, whatever is left out (`sponge_side_requests`, `chunk_side_requests`,
 `keccak_hash_side_requests`, `poseidon2_out_requests`, `binding_requests`, the uint store's `uint_val_requests` and the multiplier's
 `uint_mul_requests` -- relations the ledgers check by value when they are recorded) -- it comes from `requirer_air`, a one-interaction-per-row
