@@ -132,7 +132,7 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_add_offsets(u64* __restrict__ o
 }
 
 // ---- register columns: r[0] = 0, r[i + 1] = keep(i) r[i] + build(i) -- an exclusive scan over the affine maps x -> keep(i) x + build(i) ----
-// (precompiles-prover/src/uint/store_mul/trace.rs:73-140 computes its three registers row by row on the CPU; tests/aux_register.rs is the
+// (precompiles-prover/src/uint/store_mul/trace.rs:74-218 computes its three registers row by row on the CPU; tests/aux_register.rs is the
 // smallest case.)  The composition (k2, b2) o (k1, b1) = (k2 k1, k2 b1 + b2) is associative, so the same three phases as the sums above
 // apply: tile aggregates, a scan over the tiles' aggregates, the tiles again from their start values.  `build` already holds the contributions of
 // the earlier registers (k_reg_build).  Planes may be absent: keep0 == nullptr is keep = 1, a missing c1 plane is a base-field value.

@@ -2373,7 +2373,7 @@ def _usm_periodic():
 
 
 def _usm_store_parts(bb):
-    """The store's `id` contribution of a row and the closing row's own share (uint/store_mul/mod.rs:202-262), on builder `bb`."""
+    """The store's `id` contribution of a row and the closing row's own share (uint/store_mul/mod.rs:197-302), on builder `bb`."""
     loc = [bb.main(c) for c in range(US_COLS)]
     v_lo, v_hi, comp, bound = (bb.periodic_value(USM_PCOL_STORE_ROLE + k) for k in range(4))
     beta = bb.randomness(1)
@@ -2398,7 +2398,7 @@ def _usm_store_parts(bb):
 
 
 def _usm_mul_parts(bb):
-    """The multiplier's registers on builder `bb` (uint/store_mul/mod.rs:300-372): S' = keep S + build, id' = id + S u + v, and the c row's
+    """The multiplier's registers on builder `bb` (uint/store_mul/mod.rs:304-440): S' = keep S + build, id' = id + S u + v, and the c row's
     own share of the closing check."""
     loc = [bb.main(USM_MUL_OFF + c) for c in range(UM_COLS)]
     sel = [bb.periodic_value(i) for i in range(UM_PERIOD)]
@@ -2436,8 +2436,8 @@ def _usm_mul_parts(bb):
 
 
 def uint_store_mul_air(host_aux=None):
-    """`UintStoreMulAir::eval` (uint/store_mul/mod.rs:191-417: the store's and the multiplier's constraints verbatim, side by side) and its
-    `LookupAir::eval` (:442-889): cols 0-10 the store's (UintVal provide | its bound's consume + the gap | eight Range16 pairs | UintLimbs
+    """`UintStoreMulAir::eval` (uint/store_mul/mod.rs:196-446: the store's and the multiplier's constraints verbatim, side by side) and its
+    `LookupAir::eval` (:471-889): cols 0-10 the store's (UintVal provide | its bound's consume + the gap | eight Range16 pairs | UintLimbs
     provide), cols 11-25 the multiplier's (UintMul provide | three UintLimbs consumes | ten Range16 columns over the 19 cells | the two
     kappas | the r and c UintVal consumes); aux columns 26-28 = the registers (store id, mul id, mul S), built by the lookup program's
     register tail (`dag.LogUp.register`)."""
@@ -2550,7 +2550,7 @@ def _limbs(v, bits, n):
 
 
 def _um_witness(op, store, forge_q=None):
-    """`canonical_q` + `gamma_halves` (uint/mul/trace.rs:75-150; math.rs `mac_div_rem` / `mac_sub_div_rem`): the quotient's 17 limbs, the
+    """`canonical_q` + `gamma_halves` (uint/mul/trace.rs:90-180; math.rs `mac_div_rem` / `mac_sub_div_rem`): the quotient's 17 limbs, the
     borrow (moduli added back on a subtractive underflow), and the 31 carries of the synthetic division of the identity's coefficient
     polynomial by (X - 2^16), each offset by 2^31 and split in 16-bit halves."""
     kappa_a, kappa_c, a_ptr, b_ptr, c_ptr, r_ptr, bound_ptr, is_sub = op
@@ -2594,9 +2594,9 @@ def _um_witness(op, store, forge_q=None):
 
 
 def uint_store_mul_trace(store, muls, bpl, min_height=0):
-    """`generate_trace` (uint/store_mul/trace.rs:36-71) = the multiplier's blocks (uint/mul/trace.rs:247-372: eight rows per relation,
+    """`generate_trace` (uint/store_mul/trace.rs:43-72) = the multiplier's blocks (uint/mul/trace.rs:278-384: eight rows per relation,
     all-zero blocks after; its reads of a, b, the bound over UintLimbs and of c, r over UintVal, and every Range16 limb, routed into the
-    ledgers) NEXT TO the store's (uint/trace.rs:266-375: four rows per stored value in pointer order, self-referential zero blocks after),
+    ledgers) NEXT TO the store's (uint/trace.rs:273-386: four rows per stored value in pointer order, self-referential zero blocks after),
     the shared height the larger of the two.  Runs after every relation chiplet has recorded its reads of the store."""
     mul_h = 1 << (max(1, len(muls.ops)) * UM_PERIOD - 1).bit_length()
     mul = np.zeros((mul_h, UM_COLS), dtype=np.uint64)
@@ -2662,7 +2662,7 @@ def uint_store_mul_trace(store, muls, bpl, min_height=0):
 # blocks (the allocator chain expr_ptr' = expr_ptr + is_boundary), merge-walk cursors i, j over the operands' `MsmTerm` tuples, a strict
 # pointer ordering a_expr, b_expr < expr against circular derivations.  38 main columns, eleven flattened LogUp columns on nine buses, lqd 1.
 BUS_MSM_TERM, BUS_MSM_EXPR, BUS_MSM_CLAIM_TERM = 18, 19, 20                                                     # relations.rs:52-80
-MS_COLS, MS_AUX_COLS = 38, 11                                                                                   # ec/msm/mod.rs:168-236
+MS_COLS, MS_AUX_COLS = 38, 11                                                                                   # ec/msm/mod.rs:157-273
 (MS_COL_ACT, MS_COL_EXPR_PTR, MS_COL_IS_BOUNDARY, MS_COL_GROUP_PTR, MS_COL_SBOUND_PTR, MS_COL_IDX, MS_COL_BASE, MS_COL_SCALAR, MS_COL_VAL,
  MS_COL_MULT, MS_COL_IS_INTRO, MS_COL_IS_COMBINE, MS_COL_A_EXPR, MS_COL_B_EXPR, MS_COL_I, MS_COL_J, MS_COL_TAKE_A, MS_COL_TAKE_B,
  MS_COL_TAKE_BOTH, MS_COL_BASE_A, MS_COL_S_A, MS_COL_BASE_B, MS_COL_S_B, MS_COL_VAL_A, MS_COL_VAL_B, MS_COL_A_PTR, MS_COL_B_PTR,
@@ -2671,7 +2671,7 @@ MS_COLS, MS_AUX_COLS = 38, 11                                                   
 
 
 def ec_msm_air(host_aux=None):
-    """`EcMsmAir::eval` (ec/msm/mod.rs:316-498) and its `LookupAir::eval` (:523-856): col 0 the MsmTerm provide | 1 the MsmExpr head + the
+    """`EcMsmAir::eval` (ec/msm/mod.rs:316-488) and its `LookupAir::eval` (:510-856): col 0 the MsmTerm provide | 1 the MsmExpr head + the
     positionless MsmClaimTerm provides | 2 neg's closure certificate + intro's literal-1 scalar | 3 the walk's A term | 4 its B term + the
     merged scalar | 5 neg's scalar and y flips | 6 the operands' heads | 7 combine's value addition + neg's operand point | 8 neg's result
     point + the group | 9, 10 the ordering limbs."""
@@ -2766,7 +2766,7 @@ def _assert_bool(b, x):                  # p3's `assert_bool`: x (x - 1)
 
 
 class EcMsmRequires:
-    """`EcMsmRequires` (ec/msm/trace.rs:118-322) + the recording layer `intro` / `combine` / `neg` / `merge_terms` (ec/msm/require.rs):
+    """`EcMsmRequires` (ec/msm/trace.rs:146-388) + the recording layer `intro` / `combine` / `neg` / `merge_terms` (ec/msm/require.rs):
     expressions in allocation order, deduplicated by (rule, operands); every operand use adds to the operand's `mult`, every resolve (the
     eval chip's absorb seam) to its `claim_mult`.  An expression = dict(kind, group, sbound, val, a_expr, b_expr, val_a, val_b, a_ptr,
     b_ptr, bound_ptr, neg_x, neg_ya, neg_yr, neg_minted, rows, mult, claim_mult); a row = dict(base, scalar, i, j, take_a, take_b,
@@ -2868,7 +2868,7 @@ class EcMsmRequires:
 
 
 def ec_msm_trace(msm, store, bpl, min_height=0):
-    """`generate_trace` (ec/msm/trace.rs:324-427): one row per term, runs in allocation order; pads keep the next pointer with a counting
+    """`generate_trace` (ec/msm/trace.rs:390-500): one row per term, runs in allocation order; pads keep the next pointer with a counting
     `idx`.  Routes the intro rows' reads of the literal 1 and the ordering limbs into the ledgers."""
     n_real = sum(len(e["rows"]) for e in msm.exprs)
     height = max(2, min_height, 1 << (max(1, n_real) - 1).bit_length())
@@ -2924,7 +2924,7 @@ VALUE_TAG_UINT, VALUE_TAG_GROUP = 1, 2                                  # transc
 UINT_OP_IDS = dict(add=1, sub=2, mul=3, **{"is": 4})                    # UintPrecompile::{ADD,SUB,MUL,EQ}_OP_ID (precompiles/src/math/uint/precompile.rs:131-135)
 EC_OP_IDS = dict(add=1, sub=2, **{"is": 3})                             # CurvePrecompile::{ADD,SUB,EQ}_OP_ID, MSM_OP_ID = 4 (curve/mod.rs:492-496)
 EC_MSM_OP_ID = 4
-TE_COLS, TE_AUX_COLS = 39, 16                                           # transcript/eval/mod.rs:107-259, :330-349
+TE_COLS, TE_AUX_COLS = 39, 16                                           # transcript/eval/mod.rs:110-306, :330-348
 (TE_COL_ACT, TE_COL_PERM_SEQ_ID) = 0, 1
 TE_COL_LHS, TE_COL_RHS, TE_COL_H = 2, 6, 10
 (TE_COL_IS_ZERO, TE_COL_OUT_MULT, TE_COL_IS_AND, TE_COL_IS_UINT_LEAF, TE_COL_IS_UINT_OP, TE_COL_IS_EC_CREATE, TE_COL_IS_EC_PAI, TE_COL_IS_EC_OP,
@@ -2933,7 +2933,7 @@ TE_COL_LHS, TE_COL_RHS, TE_COL_H = 2, 6, 10
 
 
 def transcript_eval_air(host_aux=None):
-    """`TranscriptEvalAir::eval` (transcript/eval/mod.rs:384-661) and its `LookupAir::eval` (:686-1164): col 0 consume-lhs (True) | 1
+    """`TranscriptEvalAir::eval` (transcript/eval/mod.rs:393-661) and its `LookupAir::eval` (:688-1164): col 0 consume-lhs (True) | 1
     consume-rhs + the True provide | 2, 3 the unhash permutation (rate0 + rate1 | capacity + digest) | 4 the leaf's UintVal | 5 the Uint /
     pinned provide | 6 the op children's Uint bindings | 7 UintAdd | 8 UintMul | 9 the EC operands' Group bindings | 10 the Group provide |
     11 EcPoint | 12 EcGroupAdd | 13 the MSM head's capacity | 14 the MSM term's child bindings | 15 MsmClaimTerm + MsmExpr."""

@@ -21,7 +21,7 @@ static const uint64_t LOOKUP_MAGIC = 0x4d484c4b50303031ULL;  // "MHLKP001"
 // Aux REGISTER columns behind the LogUp columns (precompiles-prover/src/tests/aux_register.rs: an extension-field accumulator that must
 // live in the aux trace because it depends on the challenges, yet stays out of sigma; uint/store_mul/mod.rs:118-121 STORE_REG_ID,
 // MUL_REG_ID, MUL_REG_S): r[0] = 0, r[i + 1] = keep(i) r[i] + sum_j coeff_j(i) r_j[i] + build(i) over other registers r_j.  The
-// reference computes them in each AIR's own build_aux_trace (uint/store_mul/trace.rs:73-140); here the recurrence is data of the program.
+// reference computes them in each AIR's own build_aux_trace (uint/store_mul/trace.rs:74-218); here the recurrence is data of the program.
 struct Register {
   uint32_t keep = 0xFFFFFFFFu;  // node id, or NO_NODE = the constant 1
   uint32_t build = 0;

@@ -8,7 +8,7 @@ tests/test_gpu_lookup.py.
   ext_register_verifies_and_stays_out_of_sigma      the reference's own spike (precompiles-prover/src/tests/aux_register.rs) replayed: one
                                                     empty LogUp column, one Horner register acc' = acc beta + x; sigma = 0, every
                                                     constraint holds, the register is what Horner says
-  a chain of registers with a live LogUp column     the multiplier's shape (uint/store_mul/mod.rs:300-372): S' = keep S + build with a
+  a chain of registers with a live LogUp column     the multiplier's shape (uint/store_mul/mod.rs:304-440): S' = keep S + build with a
                                                     periodic keep, id' = id + S U + V reading S; against a plain Python evaluation
   proofs                                            oracle proofs of both AIRs verify with both verifiers; a forged register cell does not"""
 import numpy as np
