@@ -58,8 +58,9 @@ the precompile prover's LogUp adapter (natural last-row sigma closing, `logup/co
 its bus registry (`relations.rs`) and `ChipletMultiAir::eval_external` (`session/prove.rs:259-272`: sum of the committed sigmas + the
 fixed boundary correction).
 
-What is not: nothing of the session's AIRs (the reference's `Session` front end -- its claim-building API over these ledgers -- is the part
-`precompile_session` only sketches: `EcRequire.sub`, transcript-level dedup of repeated subtrees).  Where one of the SMALLER statements needs the other side of a bus that only they touch -- the transcript's readers of the `Binding` tuples in
+`Session` / `SessionTraces` mirror the reference's claim-building front end (session/mod.rs: `keccak`, `pin_uint`, `uint_leaf`, `uint_add` /
+`_sub` / `_mul` / `_is`, `ec_create` / `_pai` / `_add` / `_sub` / `_is`, `msm_intro` / `_combine` / `_neg`, `ec_msm`, `assert_and`, `assert_and_fold`,
+`finish`) over these ledgers.  Where one of the SMALLER statements needs the other side of a bus that only they touch -- the transcript's readers of the `Binding` tuples in
 the hashing session, or, in the smaller sessions of the tests, whatever is left out (`sponge_side_requests`, `chunk_side_requests`,
 `keccak_hash_side_requests`, `poseidon2_out_requests`, `binding_requests`, the uint store's `uint_val_requests` and the multiplier's
 `uint_mul_requests` -- relations the ledgers check by value when they are recorded) -- it comes from `requirer_air`, a one-interaction-per-row
@@ -2136,6 +2137,34 @@ class EcRequire:
         r, mints = self.ec.add_point_cert(group, x3, y3)
         return [slope_aux, lam, t, y3, e, x3], r, mints
 
+    def sub(self, p, q, mult):
+        """`EcRequire::sub` / `sub_value` (ec/require.rs:300-379): R = P - Q by value (the chord or tangent against -Q), bound by value, then the
+        rearranged addition R + Q = P recorded -- it must deduplicate onto P."""
+        group = self.ec.point_params(p)[0]
+        (_, p_c), (_, q_c) = self.ec.point_params(p), self.ec.point_params(q)
+        a_ptr, _b, bound = self.ec.group_params(group)
+        m = self.store.value(bound) + 1
+        if q_c is None:
+            val = None if p_c is None else tuple(self.store.value(v) for v in p_c)
+        elif p_c is None:
+            val = (self.store.value(q_c[0]), -self.store.value(q_c[1]) % m)
+        else:
+            (x1, y1), x2, y2 = (self.store.value(v) for v in p_c), self.store.value(q_c[0]), -self.store.value(q_c[1]) % m
+            if x1 != x2:
+                lam = (y2 - y1) * pow(x2 - x1, m - 2, m) % m
+            elif (y1 + y2) % m == 0:
+                lam = None                                              # P = Q: P - Q is the point at infinity
+            else:
+                lam = (3 * x1 * x1 + self.store.value(a_ptr)) * pow(2 * y1, m - 2, m) % m
+            if lam is None:
+                val = None
+            else:
+                x3 = (lam * lam - x1 - x2) % m
+                val = (x3, (lam * (x1 - x3) - y1) % m)
+        r = self.ec.group_pai(group) if val is None else self.add_point(group, *val)
+        assert self.add(r, q, mult) == p, "R + Q must deduplicate onto P"
+        return r
+
     def neg(self, p, mult):
         """`EcRequire::neg` (ec/require.rs:387-410): -P interned by value, P + (-P) = PAI as a cancel block certifies the negation."""
         group, (px, py) = self.ec.point_params(p)
@@ -3190,6 +3219,18 @@ class TranscriptEvalRequires:
             self.ec_dedup[key] = dict(id=nid, hash=hash_, point=r)
         return self.ec_dedup[key]
 
+    def ec_sub(self, p, q):
+        key = ("sub", p["hash"], q["hash"])
+        if key not in self.ec_dedup:
+            group = self.req.ec.point_params(p["point"])[0]
+            r = self.req.sub(p["point"], q["point"], 1)
+            self.consumers[p["id"]] += 1
+            self.consumers[q["id"]] += 1
+            hash_, perm = self._one_shot((CURVE_PRECOMPILE_ID, EC_OP_IDS["sub"], 0, 0), p["hash"], q["hash"])
+            nid = self._value("ec_op", hash_, perm, op="sub", lhs=p["hash"], rhs=q["hash"], p_ptr=p["point"], q_ptr=q["point"], r_ptr=r, group=group)
+            self.ec_dedup[key] = dict(id=nid, hash=hash_, point=r)
+        return self.ec_dedup[key]
+
     def ec_is(self, p, q):
         assert p["point"] == q["point"], "Is operands are unequal points (distinct interned pointers): unprovable"
         self.consumers[p["id"]] += 1
@@ -3427,71 +3468,172 @@ def ec_msm_session(terms, host_aux=None, min_height=8):
     return pairs, [byte_pair_lut_trace(bpl), uint, add, groups, points, ec_add_main, msm_main, readers], (val, acc, (store, adds, muls, ec, ec_add, msm))
 
 
+class Session:
+    """`Session` (session/mod.rs:95-503): the claim-building front end over the twelve chiplets' ledgers, with the reference's method names.
+    Handles are the dicts of `TranscriptEvalRequires`.  `finish(root)` lays the twelve traces in dependency order (`Session::finish`,
+    :446-502) and returns a `SessionTraces`."""
+
+    def __init__(self):
+        self.bpl, self.p2 = BytePairLutRequires(), Poseidon2Requires()
+        self.chunk = ChunkRequires(self.p2)
+        self.sponge = SpongeRequires(self.chunk, self.bpl)
+        self.node = KeccakNodeRequires(self.sponge)
+        self.store, self.adds, self.muls, self.ec, self.ec_adds = UintStore().install_fixed_uints(), UintAddRequires(), UintMulRequires(), EcStore(), EcAddRequires()
+        self.ec.require_fixed_groups()                                  # `Session::new`: the fixed environment (:122-123)
+        self.req = EcRequire(self.ec, self.store, self.muls, self.adds, self.ec_adds)
+        self.msm = EcMsmRequires(self.req)
+        self.eval = TranscriptEvalRequires(self.p2, self.req, self.msm)
+        self.keccak_digests = []
+
+    def keccak(self, data):
+        """-> (the Keccak-256 digest, a Truthy handle to the `Binding(H_keccak, True)` claim)"""
+        out = self.node.require(data)
+        self.keccak_digests.append(out["keccak_digest"])
+        return out["keccak_digest"], self.eval.issue(out["h_keccak"])
+
+    def pin_uint(self, ptr, value, bound_ptr):
+        (self.store.pin_modulus(ptr, value) if ptr == bound_ptr else self.store.intern_pinned(ptr, value, bound_ptr))
+        return self.eval.pin_uint(ptr)
+
+    def uint_leaf(self, value, bound_ptr):
+        return self.eval.uint_leaf(self.store.intern(value, bound_ptr))
+
+    def uint_add(self, a, b):
+        return self.eval.uint_op("add", a, b)
+
+    def uint_sub(self, a, b):
+        return self.eval.uint_op("sub", a, b)
+
+    def uint_mul(self, a, b):
+        return self.eval.uint_op("mul", a, b)
+
+    def uint_is(self, a, b):
+        return self.eval.record_is(a, b)
+
+    def ec_create(self, group_ptr, x, y):
+        assert x["bound_ptr"] == y["bound_ptr"] == self.ec.group_params(group_ptr)[2], "coordinates are stored under the group's base-field modulus"
+        return self.eval.ec_create(group_ptr, x, y)
+
+    def ec_pai(self, group_ptr):
+        return self.eval.ec_pai(group_ptr)
+
+    def ec_add(self, p, q):
+        return self.eval.ec_add(p, q)
+
+    def ec_sub(self, p, q):
+        return self.eval.ec_sub(p, q)
+
+    def ec_is(self, p, q):
+        return self.eval.ec_is(p, q)
+
+    def msm_intro(self, point):
+        return self.msm.intro(point["point"])
+
+    def msm_combine(self, a, b):
+        return self.msm.combine(a, b)
+
+    def msm_neg(self, a):
+        return self.msm.neg(a)
+
+    def ec_msm(self, expr, terms):
+        assert len(terms) == len(self.msm.terms(expr)), "ec_msm needs exactly one (base, scalar) pair per claim term"
+        assert len({t[0]["point"] for t in terms}) == len(terms), "duplicate base in ec_msm claim"
+        return self.eval.record_ec_msm(expr, terms)
+
+    def msm_value_coords(self, expr):
+        x_ptr, y_ptr = self.ec.point_params(self.msm.value(expr))[1]
+        return self.store.value(x_ptr), self.store.value(y_ptr)
+
+    def zero(self):
+        return self.eval.zero()
+
+    def assert_and(self, a, b):
+        return self.eval.record_and(a, b)
+
+    def assert_and_fold(self, handles):
+        acc = self.zero()
+        for h in handles:
+            acc = self.assert_and(acc, h)
+        return acc
+
+    def finish(self, root, min_height=8, permute_batch=None):
+        """`Session::finish`: the eval trace first (it fixes the public root), the hashing stack, then the relations before the stores that read
+        their demand -- the adder, the MSM (its intros read the literal 1), the store / multiplier, the group law, the EC stores -- and the
+        table last, after every Range16 consumer."""
+        eval_main, public_root = transcript_eval_trace(self.eval, root, min_height=min_height)
+        chunk_node = chunk_node_trace(self.chunk, self.node)
+        p2_main, _ = poseidon2_chiplet_trace(self.p2, permute_batch=permute_batch)
+        sponge_main = keccak_sponge_trace(self.sponge)
+        round_main, _mem = keccak_round_trace(self.sponge.perm_inputs, self.bpl)
+        add = uint_add_trace(self.adds, self.store, min_height=min_height)
+        msm_main = ec_msm_trace(self.msm, self.store, self.bpl, min_height=min_height)
+        ec_add_main = ec_group_add_trace(self.ec_adds, self.ec, self.bpl, min_height=min_height)
+        uint = uint_store_mul_trace(self.store, self.muls, self.bpl, min_height=min_height)
+        groups, points = ec_store_traces(self.ec, min_height=min_height)
+        mains = [chunk_node, p2_main, round_main, byte_pair_lut_trace(self.bpl), sponge_main, eval_main, uint, add, groups, points, ec_add_main, msm_main]
+        return SessionTraces(mains, public_root)
+
+
+class SessionTraces:
+    """`SessionTraces` (session/mod.rs:513-583): the twelve mains in `ChipletAir::all()` order, the public root = every AIR's `air_inputs`."""
+    NAMES = ("chunk_node", "poseidon2", "keccak_round", "byte_pair_lut", "keccak_sponge", "transcript_eval", "uint_store_mul", "uint_add", "ec_groups",
+             "ec_point_store", "ec_group_add", "ec_msm")
+
+    def __init__(self, mains, public_root):
+        self._mains, self.public_root = mains, public_root
+
+    def mains(self):
+        return list(self._mains)
+
+    def air_inputs(self):
+        return list(self.public_root)
+
+    @staticmethod
+    def airs(host_aux=None):
+        """`ChipletAir::all()` (session/prove.rs:111-126) -> [(air, lookup)]"""
+        return [chunk_node_air(host_aux), poseidon2_chiplet_air(host_aux), keccak_round_air(host_aux), byte_pair_lut_air(host_aux), keccak_sponge_air(host_aux),
+                transcript_eval_air(host_aux), uint_store_mul_air(host_aux), uint_add_air(host_aux), ec_groups_air(host_aux), ec_point_store_air(host_aux),
+                ec_group_add_air(host_aux), ec_msm_air(host_aux)]
+
+
 def precompile_session(inputs, host_aux=None, min_height=8, permute_batch=None):
-    """A whole deferred-precompile SESSION: all twelve AIRs of `ChipletAir::all()` in its order (session/prove.rs:111-126) -- [ChunkNode,
-    Poseidon2, KeccakRound, BytePairLut, KeccakSponge, TranscriptEval, UintStoreMul, UintAdd, EcGroups, EcPointStore, EcGroupAdd, EcMsm] --
-    over the fixed environment, no stand-in: every bus closes between real chiplets and the verifier's boundary terms, and the public
-    input is the transcript root the eval chip's first row is pinned to.  The transcript folds these claims:
+    """A whole deferred-precompile SESSION through the `Session` front end: all twelve AIRs of `ChipletAir::all()` in its order
+    (session/prove.rs:111-126) -- [ChunkNode, Poseidon2, KeccakRound, BytePairLut, KeccakSponge, TranscriptEval, UintStoreMul, UintAdd,
+    EcGroups, EcPointStore, EcGroupAdd, EcMsm] -- over the fixed environment, no stand-in: every bus closes between real chiplets and the
+    verifier's boundary terms, and the public input is the transcript root the eval chip's first row is pinned to.  The transcript folds
+    (`assert_and_fold`) these claims:
       keccak256(data) for every `data` of `inputs` (the digests are the session's outputs);
       over the secp256k1 base field: ((a b + c) - c) is (a b), on stored 256-bit values;
       a pinned value claim (the stored uint at protocol address 100 is what it is);
-      on secp256k1: 5 G + 7 G is 12 G, the sum by the group law chiplet, 12 G bound by its coordinates;
-      an MSM claim: 0xb5 G + 0x4d (3 G) resolved from the MSM chiplet's expression, is the point with the coordinates an affine sum gives;
-      the ZERO_HASH leaf (the AND identity).
-    -> ([(air, lookup)], [traces], dict(public_root, keccak_digests, ledgers))"""
-    bpl, p2 = BytePairLutRequires(), Poseidon2Requires()
-    chunks = ChunkRequires(p2)
-    sponge = SpongeRequires(chunks, bpl)
-    node = KeccakNodeRequires(sponge)
-    store, adds, muls, ec, ec_add = UintStore().install_fixed_uints(), UintAddRequires(), UintMulRequires(), EcStore(), EcAddRequires()
-    req = EcRequire(ec, store, muls, adds, ec_add)
-    msm = EcMsmRequires(req)
-    ev = TranscriptEvalRequires(p2, req, msm)
+      on secp256k1: 5 G + 7 G is 12 G and 12 G - 7 G is 5 G, the sums by the group law chiplet, the points bound by their coordinates;
+      an MSM claim: 0xb5 G + 0x4d (3 G) resolved from the MSM chiplet's expression, is the point with the coordinates an affine sum gives.
+    -> ([(air, lookup)], [traces], dict(public_root, keccak_digests, msm_value, ledgers))"""
+    s = Session()
     fp, m = K1_BASE_BOUND_PTR, K1_BOUND + 1
-    claims, digests = [], []
-    for data in inputs:
-        out = node.require(data)
-        digests.append(out["keccak_digest"])
-        claims.append(ev.issue(out["h_keccak"]))
-    a, b_, c = (ev.uint_leaf(store.intern(v, fp)) for v in (K1_G[0], K1_G[1], 0x1234567890abcdef << 128 | 77))
-    prod = ev.uint_op("mul", a, b_)
-    claims.append(ev.record_is(ev.uint_op("sub", ev.uint_op("add", prod, c), c), prod))
-    claims.append(ev.pin_uint(store.intern_pinned(100, (K1_G[0] * 3 + 1) % m, fp)))
-    group, _pai = req.create_group(0, 7, fp)
+    claims = [s.keccak(data)[1] for data in inputs]
+    a, b_, c = (s.uint_leaf(v, fp) for v in (K1_G[0], K1_G[1], 0x1234567890abcdef << 128 | 77))
+    prod = s.uint_mul(a, b_)
+    claims.append(s.uint_is(s.uint_sub(s.uint_add(prod, c), c), prod))
+    claims.append(s.pin_uint(100, (K1_G[0] * 3 + 1) % m, fp))
     mult = k1_multiples(12)
-    point = lambda k: ev.ec_create(group, ev.uint_leaf(store.intern(mult[k - 1][0], fp)), ev.uint_leaf(store.intern(mult[k - 1][1], fp)))   # noqa: E731
-    claims.append(ev.ec_is(ev.ec_add(point(5), point(7)), point(12)))
+    point = lambda k: s.ec_create(K1_GROUP_PTR, s.uint_leaf(mult[k - 1][0], fp), s.uint_leaf(mult[k - 1][1], fp))      # noqa: E731
+    claims.append(s.ec_is(s.ec_add(point(5), point(7)), point(12)))
+    claims.append(s.ec_is(s.ec_sub(point(12), point(7)), point(5)))
     terms, e_acc = [(0xb5, 1), (0x4d, 3)], None
-    intros = [msm.intro(point(mm)["point"]) for _, mm in terms]
+    intros = [s.msm_intro(point(mm)) for _, mm in terms]
     for bit in range(max(k for k, _ in terms).bit_length() - 1, -1, -1):
         if e_acc is not None:
-            e_acc = msm.combine(e_acc, e_acc)
+            e_acc = s.msm_combine(e_acc, e_acc)
         for (k, _), e in zip(terms, intros):
             if (k >> bit) & 1:
-                e_acc = e if e_acc is None else msm.combine(e_acc, e)
-    by_base = dict(msm.terms(e_acc))
-    claim_terms = [(point(mm), ev.uint_leaf(by_base[point(mm)["point"]])) for _, mm in reversed(terms)]      # the CALLER's order, not the chiplet's
-    msm_node = ev.record_ec_msm(e_acc, claim_terms)
-    vx, vy = ec.point_params(msm_node["point"])[1]
-    claims.append(ev.ec_is(msm_node, ev.ec_create(group, ev.uint_leaf(vx), ev.uint_leaf(vy))))
-    claims.append(ev.zero())
-    root = ev.fold(claims)
-    ec.require_fixed_groups()
-    # the dependency-ordered sweep (`SessionTraces`): relations before the stores that read their demand, the Poseidon2 ledger after every
-    # node that hashes, the table last
-    eval_main, public_root = transcript_eval_trace(ev, root, min_height=min_height)
-    add = uint_add_trace(adds, store, min_height=min_height)
-    ec_add_main = ec_group_add_trace(ec_add, ec, bpl, min_height=min_height)
-    msm_main = ec_msm_trace(msm, store, bpl, min_height=min_height)
-    uint = uint_store_mul_trace(store, muls, bpl, min_height=min_height)
-    groups, points = ec_store_traces(ec, min_height=min_height)
-    kr_main, _mem = keccak_round_trace(sponge.perm_inputs, bpl)
-    p2_main, _ = poseidon2_chiplet_trace(p2, permute_batch=permute_batch)
-    chunk_node = chunk_node_trace(chunks, node)
-    sponge_main = keccak_sponge_trace(sponge)
-    pairs = [chunk_node_air(host_aux), poseidon2_chiplet_air(host_aux), keccak_round_air(host_aux), byte_pair_lut_air(host_aux), keccak_sponge_air(host_aux),
-             transcript_eval_air(host_aux), uint_store_mul_air(host_aux), uint_add_air(host_aux), ec_groups_air(host_aux), ec_point_store_air(host_aux),
-             ec_group_add_air(host_aux), ec_msm_air(host_aux)]
-    traces = [chunk_node, p2_main, kr_main, byte_pair_lut_trace(bpl), sponge_main, eval_main, uint, add, groups, points, ec_add_main, msm_main]
-    return pairs, traces, dict(public_root=public_root, keccak_digests=digests, msm_value=(store.value(vx), store.value(vy)),
-                               ledgers=dict(p2=p2, store=store, adds=adds, muls=muls, ec=ec, ec_add=ec_add, msm=msm, eval=ev, node=node))
+                e_acc = e if e_acc is None else s.msm_combine(e_acc, e)
+    by_base = dict(s.msm.terms(e_acc))
+    claim_terms = [(point(mm), s.eval.uint_leaf(by_base[point(mm)["point"]])) for _, mm in reversed(terms)]       # the CALLER's order, not the chiplet's
+    msm_node = s.ec_msm(e_acc, claim_terms)
+    vx, vy = s.msm_value_coords(e_acc)
+    claims.append(s.ec_is(msm_node, s.ec_create(K1_GROUP_PTR, s.uint_leaf(vx, fp), s.uint_leaf(vy, fp))))
+    root = s.assert_and_fold(claims)
+    st = s.finish(root, min_height=min_height, permute_batch=permute_batch)
+    return SessionTraces.airs(host_aux), st.mains(), dict(public_root=st.public_root, keccak_digests=s.keccak_digests, msm_value=(vx, vy), session=s,
+                                                          ledgers=dict(p2=s.p2, store=s.store, adds=s.adds, muls=s.muls, ec=s.ec, ec_add=s.ec_adds, msm=s.msm,
+                                                                       eval=s.eval, node=s.node))

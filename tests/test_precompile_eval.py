@@ -9,8 +9,8 @@ like the eleven others -- one more blob.)
   the reference's unit tests (src/tests/eval.rs) replayed: corruption_non_binary_act, corruption_non_binary_is_zero,
   corruption_zero_leaf_h_not_zero, corruption_first_row_root_pin, corruption_empty_root_not_zero, corruption_out_mult_on_padding,
   corruption_act_sticky_down, corruption_pinned_leaf_cap_slot_mismatch; log_quotient_degree 1; the precompile ids as BLAKE3 derivations;
-  the session: Keccak-256 claims (known answers), a 256-bit arithmetic claim, a pin claim, an EC addition claim, an MSM claim resolved
-  in the caller's term order, the ZERO_HASH leaf -- folded into one public root; forged roots, claims and relations are rejected"""
+  the session: Keccak-256 claims (known answers), a 256-bit arithmetic claim, a pin claim, an EC addition and an EC subtraction claim, an MSM claim
+  resolved in the caller's term order -- folded onto the ZERO_HASH leaf into one public root (the reference's `Session` front end); forged roots, claims and relations are rejected"""
 import numpy as np
 import pytest
 import oracle_binding as ob
@@ -129,7 +129,10 @@ def test_the_whole_session_closes_with_no_stand_in(session):
     kinds = {c: int(ev_main[:, c].sum()) for c in (PA.TE_COL_IS_AND, PA.TE_COL_IS_UINT_LEAF, PA.TE_COL_IS_UINT_OP, PA.TE_COL_IS_EC_CREATE, PA.TE_COL_IS_EC_OP,
                                                   PA.TE_COL_IS_EC_MSM, PA.TE_COL_IS_ZERO, PA.TE_COL_IS_PINNED)}
     assert all(kinds.values()), "every node kind the generator lays is in this transcript"
-    assert kinds[PA.TE_COL_IS_AND] == 8 and kinds[PA.TE_COL_IS_EC_MSM] == 2, "nine claims fold in eight ANDs; a two-term absorb run"
+    assert kinds[PA.TE_COL_IS_AND] == 9 and kinds[PA.TE_COL_IS_EC_MSM] == 2, "`assert_and_fold`: nine claims folded onto the ZERO_HASH leaf; a two-term absorb run"
+    assert int(ev_main[:, PA.TE_COL_IS_SUB].sum()) == 2, "a uint subtraction and an EC subtraction (R + Q = P, the roles mixed on the bus)"
+    s = info["session"]
+    assert s.msm_value_coords(s.msm.dedup[("combine", max(k for k in s.msm.dedup if k[0] == "combine")[1], max(k for k in s.msm.dedup if k[0] == "combine")[2])]) == info["msm_value"]
 
 
 def test_forged_roots_claims_and_relations_are_rejected(session):
@@ -187,3 +190,32 @@ def test_the_whole_session_proves_and_verifies(session):
                           preprocessed_root=proof["preprocessed_root"], external=ext)[0]
     assert not pkg.verify(air_list, proof["log_heights"], root, FAST, st, pre, proof["fields"], proof["commitments"],
                           preprocessed_root=proof["preprocessed_root"], external=PA.external_assertions(pkg))[0], "without the UintVal boundary terms"
+
+
+def test_the_session_front_end_other_calls():
+    """`Session` (session/mod.rs) calls the first transcript does not make: subtraction to and from the point at infinity, a negated MSM
+    expression resolved as a claim, a transcript whose root is a single fold."""
+    s = PA.Session()
+    fp, m = PA.K1_BASE_BOUND_PTR, PA.K1_BOUND + 1
+    digest, t_k = s.keccak(b"abc")
+    assert bytes(digest).hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
+    mult = PA.k1_multiples(3)
+    pt = lambda x, y: s.ec_create(PA.K1_GROUP_PTR, s.uint_leaf(x, fp), s.uint_leaf(y, fp))       # noqa: E731
+    g, g3 = pt(*mult[0]), pt(*mult[2])
+    pai = s.ec_pai(PA.K1_GROUP_PTR)
+    claims = [t_k, s.ec_is(s.ec_sub(g3, g3), pai), s.ec_is(s.ec_sub(pai, g), pt(mult[0][0], m - mult[0][1])), s.ec_is(s.ec_sub(g3, pai), g3)]
+    ne = s.msm_neg(s.msm_intro(g))                                      # <G x (n - 1)>, value -G
+    n_minus_1 = s.eval.uint_leaf(s.msm.terms(ne)[0][1])
+    assert s.store.value(n_minus_1["ptr"]) == PA.FIXED_UINTS[2][2] and s.msm_value_coords(ne) == (mult[0][0], m - mult[0][1])
+    claims.append(s.ec_is(s.ec_msm(ne, [(g, n_minus_1)]), pt(mult[0][0], m - mult[0][1])))
+    st = s.finish(s.assert_and_fold(claims))
+    pairs = PA.SessionTraces.airs(host_aux)
+    assert [p[0].name for p in pairs][5] == "transcript_eval" and len(st.mains()) == 12 and st.air_inputs() == st.public_root
+    for pair, t in zip(pairs, st.mains()):
+        assert check(pair, t, st.public_root) == (0, None), pair[0].name
+    assert PA.eval_external(RND, [[sigma(pair, t)] for pair, t in zip(pairs, st.mains())], fixed_uints=True) == [(0, 0)]
+    s2 = PA.Session()
+    with pytest.raises(AssertionError):
+        s2.uint_is(s2.uint_leaf(5, fp), s2.uint_leaf(6, fp))            # an unprovable claim is refused when it is made
+    with pytest.raises(AssertionError):
+        s2.finish(s2.assert_and_fold([s2.keccak(b"")[1]]))              # ... and the leaves made for it are stray values: no trace (`assert_no_stray_values`)
