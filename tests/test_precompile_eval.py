@@ -3,8 +3,7 @@ transcript/{binding,nodes}.rs, transcript/poseidon2/digest.rs) as ported in mide
 AIRs of `ChipletAir::all()` -- and with it the WHOLE deferred-precompile session: all twelve chiplets in the reference's order, over the
 fixed environment, NO stand-in; every bus closes between real chiplets and the verifier's boundary terms, and the public input is the
 transcript root the evaluator's first row is pinned to.  Host only: the oracle proves, the oracle's verifier and the library's (host code)
-verify through `ChipletMultiAir::eval_external`.  (The device prover was out of GPU budget when this chiplet landed: the backend treats it
-like the eleven others -- one more blob.)
+verify through `ChipletMultiAir::eval_external`.  Device: tests/test_zz_gpu_whole_session.py.
 
   the reference's unit tests (src/tests/eval.rs) replayed: corruption_non_binary_act, corruption_non_binary_is_zero,
   corruption_zero_leaf_h_not_zero, corruption_first_row_root_pin, corruption_empty_root_not_zero, corruption_out_mult_on_padding,
