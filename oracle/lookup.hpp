@@ -87,6 +87,23 @@ struct Lookup {
         l.registers.push_back(r);
       }
     }
+    {  // the registers must not read each other in a cycle (the device scans a register after the registers it reads)
+      std::vector<char> done(l.registers.size(), 0);
+      size_t laid = 0;
+      while (laid < l.registers.size()) {
+        const size_t before = laid;
+        for (size_t k = 0; k < l.registers.size(); k++) {
+          if (done[k]) continue;
+          bool ready = true;
+          for (auto& t : l.registers[k].terms) ready = ready && done[t.first];
+          if (ready) {
+            done[k] = 1;
+            laid++;
+          }
+        }
+        need(laid > before);
+      }
+    }
     need(p == n);
     return l;
   }

@@ -185,3 +185,35 @@ def test_proofs_with_registers_verify_and_forged_registers_do_not(make, trace):
     bad = ob.prove([b2], [main], root, FAST, init_state=st)
     assert not ob.verify([b2], bad["log_heights"], root, bad, FAST)[0]
     assert not pkg.verify([b2], bad["log_heights"], root, FAST, st, pre, bad["fields"], bad["commitments"])[0]
+
+
+def test_malformed_register_tails_are_refused_by_the_oracle_and_by_the_library():
+    """The register tail of the "MHLKP001" blob (include/midenhip.h): a register that reads itself, a register that does not exist, a cycle,
+    a truncated tail and trailing words are format errors on both sides (the library's parser runs host-side in `mh_jit_precompile`)."""
+    _, lookup = chain_air()
+    w = [int(v) for v in lookup.blob]
+    tail = 1 + 3 + (3 + 2) + 3                                          # count | (keep, build, 0) | (keep, build, 1, j, u) | (keep, build, 0)
+    head, regs = w[:-tail], w[-tail:]
+    assert regs[0] == 3 and regs[4 + 2] == 1 and regs[4 + 3] == 0, "register 1 (id) reads register 0 (S)"
+    main = chain_trace(8)
+
+    class _L:
+        num_aux_cols = 5
+
+    def both_refuse(words):
+        _L.blob = np.array(words, dtype=np.uint64)
+        with pytest.raises(RuntimeError):
+            ob.lookup_build_aux(_L, main, RND, None)
+        with pytest.raises(pkg.MidenHipError):
+            pkg.jit_precompile(_L.blob)
+    both_refuse(head + regs[:4 + 3] + [1] + regs[4 + 4:])               # id reads itself
+    both_refuse(head + regs[:4 + 3] + [7] + regs[4 + 4:])               # ... or a register that does not exist
+    cyc = list(regs)
+    cyc[1:4] = [cyc[1], cyc[2], 1]                                      # S gains a term ...
+    cyc[4:4] = [1, regs[4 + 4]]                                         # ... reading id, which reads S
+    both_refuse(head + cyc)
+    both_refuse(head + regs[:-1])                                       # truncated
+    both_refuse(head + regs + [0])                                      # trailing words
+    _L.blob = np.array(head + regs, dtype=np.uint64)
+    aux, _ = ob.lookup_build_aux(_L, main, RND, None)
+    assert aux.shape == (8, 10) and pkg.jit_precompile(_L.blob) >= 1
