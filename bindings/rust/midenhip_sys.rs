@@ -155,6 +155,7 @@ unsafe extern "C" {
     /// mh_verify_ex for MH_LMCS_RPO (3) / MH_LMCS_RPX (4) / MH_LMCS_POSEIDON2 (0)
     pub fn mh_verify_lmcs(lmcs: c_int, params: *const mh_pcs_params, n_airs: c_int, air_blobs: *const *const u64, air_blob_words: *const usize, log_trace_heights: *const u8, public_values: *const u64, n_public_values: usize, challenger_state: *const u64, pre_observe: *const u64, n_pre_observe: usize, fields: *const u64, n_fields: usize, commitments: *const u64, n_commitments: usize, preprocessed_root: *const u64, external: mh_external_assertions, external_user: *mut c_void, digest: *mut u64, err: *mut c_char, err_cap: usize) -> c_int;
     pub fn mh_external_logup_balance(user: *mut c_void, randomness: *const u64, n_randomness: usize, aux_values: *const *const u64, n_aux_values: *const usize, log_trace_heights: *const u8, n_airs: c_int, assertions_out: *mut u64, cap: usize) -> c_int;
+    pub fn mh_external_precompile_session(user: *mut c_void, randomness: *const u64, n_randomness: usize, aux_values: *const *const u64, n_aux_values: *const usize, log_trace_heights: *const u8, n_airs: c_int, assertions_out: *mut u64, cap: usize) -> c_int;
     pub fn mh_proof_deserialize(bytes: *const u8, len: usize, out: *mut *mut mh_proof) -> c_int;
     pub fn mh_trace_upload_sharded(ctx: *mut mh_ctx, comm: *const mh_comm, rowmajor: *const u64, log_n: c_int, width: usize, out: *mut *mut mh_trace) -> c_int;
     pub fn mh_rccl_unique_id(id: *mut u8) -> c_int;

@@ -413,6 +413,13 @@ int mh_verify_lmcs(int lmcs, const mh_pcs_params* params, int n_airs, const uint
 int mh_external_logup_balance(void* user, const uint64_t* randomness, size_t n_randomness, const uint64_t* const* aux_values,
                               const size_t* n_aux_values, const uint8_t* log_trace_heights, int n_airs, uint64_t* assertions_out,
                               size_t cap);
+/* A ready-made mh_external_assertions for the second client: `ChipletMultiAir::eval_external` of the precompile prover's session
+ * (precompiles-prover/src/session/prove.rs:243-256) = the sum of the committed sigmas + `fixed_boundary_correction` (:205-216), the
+ * verifier's consumes of the session's fixed environment (session/fixed.rs: the VM-owned curve group's `EcGroup` tuple, the five fixed
+ * uints' `UintVal` tuples).  user = NULL: the whole correction; user -> int 1: the EcGroup part only (statements without the uint store). */
+int mh_external_precompile_session(void* user, const uint64_t* randomness, size_t n_randomness, const uint64_t* const* aux_values,
+                                   const size_t* n_aux_values, const uint8_t* log_trace_heights, int n_airs, uint64_t* assertions_out,
+                                   size_t cap);
 
 /* ---- the Miden VM statement: prove_stark's own shape (prover/src/lib.rs:317-355) --------------------------------------------------
  * Three matrices + 32 public values + aux inputs in, proof out -- the statement layer the reference's `MidenMultiAir` adds to the

@@ -31,7 +31,7 @@ EXPORTS = [
     "mh_session_commit_quotient", "mh_session_ood_point_ok", "mh_session_ood", "mh_session_deep", "mh_session_fri_commit",
     "mh_session_fri_fold", "mh_session_fri_final", "mh_session_open", "mh_grind",
     "mh_host_alloc", "mh_host_free", "mh_verify", "mh_trace_from_device", "mh_lookup_load", "mh_lookup_free", "mh_air_attach_lookup", "mh_air_attach_preprocessed", "mh_lookup_build_aux", "mh_trace_download",
-    "mh_verify_ex", "mh_external_logup_balance", "mh_proof_deserialize", "mh_ctx_set_lmcs", "mh_ctx_get_lmcs", "mh_blake3", "mh_verify_lmcs", "mh_grind_bytes",
+    "mh_verify_ex", "mh_external_logup_balance", "mh_external_precompile_session", "mh_proof_deserialize", "mh_ctx_set_lmcs", "mh_ctx_get_lmcs", "mh_blake3", "mh_verify_lmcs", "mh_grind_bytes",
     "mh_rccl_unique_id", "mh_comm_create_rccl", "mh_comm_destroy", "mh_comm_selftest",
     "mh_local_fabric_create", "mh_local_fabric_destroy", "mh_local_fabric_abort", "mh_comm_create_local",
     "mh_miden_load", "mh_miden_free", "mh_prove_miden", "mh_prove_miden_traces", "mh_verify_miden", "mh_miden_pcs_params",
@@ -681,8 +681,8 @@ def verify(airs, log_trace_heights, public_values, params, challenger_state, pre
            preprocessed_root=None, external=None, lmcs="poseidon2"):
     """mh_verify / mh_verify_ex (host only, no GPU): airs = dag.Air objects in instance order; preprocessed_root = the setup
     commitment when some AIR has preprocessed columns (it must also be in pre_observe); external = the statement's cross-AIR
-    assertions: an EXTERNAL_FN / external_callback(...) object, or the string "logup_balance" for the library's
-    mh_external_logup_balance.  Returns (ok, digest or message)."""
+    assertions: an EXTERNAL_FN / external_callback(...) object, the string "logup_balance" for the library's
+    mh_external_logup_balance, or "precompile_session" / "precompile_session_ec_only" for its mh_external_precompile_session.  Returns (ok, digest or message)."""
     lib = load_library()
     n = len(airs)
     blobs = [_arr(a.blob) for a in airs]
@@ -696,12 +696,17 @@ def verify(airs, log_trace_heights, public_values, params, challenger_state, pre
     digest = np.zeros(4, dtype=np.uint64)
     err = C.create_string_buffer(512)
     proot = _arr(preprocessed_root) if preprocessed_root is not None else None
+    ext_user = None
+    if external in ("precompile_session", "precompile_session_ec_only"):   # the library's ChipletMultiAir::eval_external (session/prove.rs:243-256)
+        flag = C.c_int(1 if external.endswith("ec_only") else 0)
+        ext_user = C.cast(C.pointer(flag), C.c_void_p)
+        external = C.cast(lib.mh_external_precompile_session, EXTERNAL_FN)
     if lmcs != "poseidon2":  # mh_verify_lmcs: the other algebraic configurations ("rpo", "rpx")
         ext = C.cast(lib.mh_external_logup_balance, EXTERNAL_FN) if external == "logup_balance" else external
         rc = lib.mh_verify_lmcs(C.c_int(Ctx.LMCS[lmcs]), C.byref(p), C.c_int(n), bp, bl, lh, _ptr(pub), C.c_size_t(len(public_values)),
                                 _ptr(st), _ptr(pre), C.c_size_t(len(pre_observe)), _ptr(f), C.c_size_t(f.size), _ptr(c),
                                 C.c_size_t(c.size // 4), _ptr(proot) if proot is not None else None,
-                                ext if ext is not None else C.cast(None, EXTERNAL_FN), None, _ptr(digest), err, C.c_size_t(512))
+                                ext if ext is not None else C.cast(None, EXTERNAL_FN), ext_user, _ptr(digest), err, C.c_size_t(512))
     elif external is None:
         rc = lib.mh_verify(C.byref(p), C.c_int(n), bp, bl, lh, _ptr(pub), C.c_size_t(len(public_values)), _ptr(st), _ptr(pre),
                            C.c_size_t(len(pre_observe)), _ptr(f), C.c_size_t(f.size), _ptr(c), C.c_size_t(c.size // 4),
@@ -710,7 +715,7 @@ def verify(airs, log_trace_heights, public_values, params, challenger_state, pre
         ext = C.cast(lib.mh_external_logup_balance, EXTERNAL_FN) if external == "logup_balance" else external
         rc = lib.mh_verify_ex(C.byref(p), C.c_int(n), bp, bl, lh, _ptr(pub), C.c_size_t(len(public_values)), _ptr(st), _ptr(pre),
                               C.c_size_t(len(pre_observe)), _ptr(f), C.c_size_t(f.size), _ptr(c), C.c_size_t(c.size // 4),
-                              _ptr(proot) if proot is not None else None, ext, None, _ptr(digest), err, C.c_size_t(512))
+                              _ptr(proot) if proot is not None else None, ext, ext_user, _ptr(digest), err, C.c_size_t(512))
     return (True, digest) if rc == 0 else (False, err.value.decode())
 
 

@@ -182,6 +182,12 @@ def test_the_whole_session_proves_and_verifies(session):
     ok_p, _ = pkg.verify(air_list, proof["log_heights"], root, FAST, st, pre, proof["fields"], proof["commitments"],
                          preprocessed_root=proof["preprocessed_root"], external=ext)
     assert ok_p
+    # the statement layer in the LIBRARY (mh_external_precompile_session: no Python between a C caller and the session's verdict)
+    ok_c, dig_c = pkg.verify(air_list, proof["log_heights"], root, FAST, st, pre, proof["fields"], proof["commitments"],
+                             preprocessed_root=proof["preprocessed_root"], external="precompile_session")
+    assert ok_c and (dig_c == proof["digest"]).all()
+    assert not pkg.verify(air_list, proof["log_heights"], root, FAST, st, pre, proof["fields"], proof["commitments"],
+                          preprocessed_root=proof["preprocessed_root"], external="precompile_session_ec_only")[0]
     wrong = [(root[0] + 1) % P] + root[1:]
     pre_w = protocol.protocol_pre_observe(FAST, wrong, preprocessed_root=proof["preprocessed_root"])
     assert not ob.verify(air_list, proof["log_heights"], wrong, proof, FAST, external=ext)[0], "the proof is of THIS root"
@@ -218,3 +224,24 @@ def test_the_session_front_end_other_calls():
         s2.uint_is(s2.uint_leaf(5, fp), s2.uint_leaf(6, fp))            # an unprovable claim is refused when it is made
     with pytest.raises(AssertionError):
         s2.finish(s2.assert_and_fold([s2.keccak(b"")[1]]))              # ... and the leaves made for it are stray values: no trace (`assert_no_stray_values`)
+
+
+def test_the_library_eval_external_equals_the_python_one():
+    """`mh_external_precompile_session` against `PA.eval_external` on random challenges and sigmas, both forms of the correction."""
+    import ctypes as C
+    lib = pkg.load_library()
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        rnd = [tuple(int(x) for x in rng.integers(0, P, 2, dtype=np.uint64)) for _ in range(2)]
+        sig = [[tuple(int(x) for x in rng.integers(0, P, 2, dtype=np.uint64))] for _ in range(12)]
+        for flag, fixed_uints in ((0, True), (1, False)):
+            r = np.array([x for pair in rnd for x in pair], dtype=np.uint64)
+            rows = [np.array(list(s_[0]), dtype=np.uint64) for s_ in sig]
+            ptrs = (C.POINTER(C.c_uint64) * 12)(*[row.ctypes.data_as(C.POINTER(C.c_uint64)) for row in rows])
+            counts = (C.c_size_t * 12)(*[1] * 12)
+            out = np.zeros(2, dtype=np.uint64)
+            user = C.c_int(flag)
+            lib.mh_external_precompile_session.restype = C.c_int
+            n = lib.mh_external_precompile_session(C.byref(user), r.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(2), ptrs, counts, None, C.c_int(12),
+                                                   out.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(1))
+            assert n == 1 and [(int(out[0]), int(out[1]))] == PA.eval_external(rnd, sig, fixed_uints=fixed_uints), (trial, flag)
