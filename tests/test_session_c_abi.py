@@ -1,0 +1,47 @@
+"""The second client's verifier side from plain C (host only): examples/verify_session_c_abi.c is compiled with gcc against
+include/midenhip.h + libmidenhip.so, reads a whole deferred-precompile session's proof (twelve AIRs, the oracle's) from a file and
+verifies it through mh_verify_ex with the library's own `ChipletMultiAir::eval_external` (mh_external_precompile_session): no Python
+between the C caller and the verdict.  Accepted for the true root with the full boundary correction; rejected for another root and with
+the EcGroup-only correction."""
+import os, subprocess
+import numpy as np
+import oracle_binding as ob
+from __graft_entry__ import load_package
+
+pkg = load_package()
+from miden_vm_amd import precompile_airs as PA, protocol  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAST = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=5, query_pow_bits=3)
+ORDER = ("log_blowup", "log_folding_arity", "log_final_degree", "folding_pow_bits", "deep_pow_bits", "num_queries", "query_pow_bits")
+
+
+def test_a_c_program_verifies_the_whole_session(tmp_path):
+    exe = str(tmp_path / "verify_session")
+    lib_dir = os.path.join(ROOT, "miden-vm_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "verify_session_c_abi.c"),
+                           "-L" + lib_dir, "-lmidenhip", "-Wl,-rpath," + lib_dir, "-o", exe])
+    pairs, traces, info = PA.precompile_session([b"abc", b"the quick brown fox"], lambda *a: ob.lookup_build_aux(*a))
+    airs, root = [p[0] for p in pairs], info["public_root"]
+    st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
+    proof = ob.prove(airs, traces, root, FAST, init_state=st)
+    pre = protocol.protocol_pre_observe(FAST, root, preprocessed_root=proof["preprocessed_root"])
+    fields, commitments = np.asarray(proof["fields"], dtype=np.uint64), np.asarray(proof["commitments"], dtype=np.uint64).reshape(-1)
+    words = [int.from_bytes(b"MHSESS01", "little"), len(airs), len(root), len(pre), fields.size, commitments.size // 4, 1]
+    words += [FAST[k] for k in ORDER] + [int(h) for h in proof["log_heights"]] + [int(x) for x in root] + [int(x) for x in st] + [int(x) for x in pre]
+    words += [int(x) for x in fields] + [int(x) for x in commitments] + [int(x) for x in proof["preprocessed_root"]]
+    for a in airs:
+        words += [len(a.blob)] + [int(x) for x in a.blob]
+    path = str(tmp_path / "session_proof.bin")
+    np.array(words, dtype="<u8").tofile(path)
+
+    def run(*flags):
+        r = subprocess.run([exe, path, *flags], capture_output=True, text=True, timeout=120)
+        return r.returncode, r.stdout.strip()
+    rc, out = run()
+    want = "".join(f"{int(x):016x}" for x in proof["digest"])
+    assert rc == 0 and out == "ACCEPTED digest " + want, out
+    rc, out = run("--root-off-by-one")
+    assert rc == 1 and out.startswith("REJECTED"), out
+    rc, out = run("--ec-only")
+    assert rc == 1 and out.startswith("REJECTED"), out
