@@ -31,6 +31,10 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on t
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
+GEN_NOTE = ("Python TEST generator (miden-vm_amd/testing/precompile_trace.py: the reference builds these matrices in precompiles-prover/src/**/trace.rs), "
+            "not product; excluded from every rate")
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -365,13 +369,14 @@ def precompile_session_probe(pkg, ctx, n_perms=80, steps=3):
     (`precompile_pcs_params`), every aux column built on the device, verified through `ChipletMultiAir::eval_external`."""
     import numpy as np
     from miden_vm_amd import protocol, precompile_airs as PA
+    from miden_vm_amd.testing import precompile_trace as PT
     rng = np.random.default_rng(3)
     states = [[int(x) for x in rng.integers(0, 1 << 63, 25)] for _ in range(n_perms)]
     t0 = time.perf_counter()
-    ledger = PA.BytePairLutRequires()
-    trace, mem = PA.keccak_round_trace(states, ledger)
+    ledger = PT.BytePairLutRequires()
+    trace, mem = PT.keccak_round_trace(states, ledger)
     pairs = [PA.keccak_round_air(), PA.byte_pair_lut_air(), PA.ec_groups_air(), PA.requirer_air()]
-    host = [trace, PA.byte_pair_lut_trace(ledger), PA.ec_groups_trace(), PA.requirer_trace(PA.sponge_side_requests(states, mem))]
+    host = [trace, PT.byte_pair_lut_trace(ledger), PT.ec_groups_trace(), PT.requirer_trace(PT.sponge_side_requests(states, mem))]
     gen_s = time.perf_counter() - t0
     airs_h = [p_[0] for p_ in pairs]
     prm = dict(protocol.PROD_PARAMS)
@@ -445,7 +450,7 @@ def precompile_session_probe(pkg, ctx, n_perms=80, steps=3):
             "proof_bytes": len(proof.bytes), "verifies_with_eval_external": bool(ok),
             "compiled_chunks": [a.compiled_chunks for a in dairs], "chunk_max_vgprs": [a.compiled_max_vgprs for a in dairs],
             "kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items() if not k.startswith("span:") and v["ms"] > 0.05},
-            "trace_generation_s": gen_s, "setup_s": setup_s, "device_built_traces": dev}
+            "test_trace_generator_s": {"seconds": gen_s, "note": GEN_NOTE}, "setup_s": setup_s, "device_built_traces": dev}
 
 
 def keccak_hash_session_probe(pkg, ctx, steps=3):
@@ -457,22 +462,23 @@ def keccak_hash_session_probe(pkg, ctx, steps=3):
     parameters, every aux column on the device."""
     import numpy as np
     from miden_vm_amd import protocol, precompile_airs as PA
+    from miden_vm_amd.testing import precompile_trace as PT
     rng = np.random.default_rng(6)
     inputs = [b"", b"abc"] + [bytes(rng.integers(0, 256, int(rng.integers(0, 1401)), dtype=np.uint8)) for _ in range(52)]
     t0 = time.perf_counter()
-    ledger, p2 = PA.BytePairLutRequires(), PA.Poseidon2Requires()
-    chunks = PA.ChunkRequires(p2)
-    sp = PA.SpongeRequires(chunks, ledger)
-    nd = PA.KeccakNodeRequires(sp)
+    ledger, p2 = PT.BytePairLutRequires(), PT.Poseidon2Requires()
+    chunks = PT.ChunkRequires(p2)
+    sp = PT.SpongeRequires(chunks, ledger)
+    nd = PT.KeccakNodeRequires(sp)
     outs = [nd.require(data) for data in inputs]
-    kr_trace, mem = PA.keccak_round_trace(sp.perm_inputs, ledger)
-    p2_main, _ = PA.poseidon2_chiplet_trace(p2, permute_batch=ctx.poseidon2_permute)
+    kr_trace, mem = PT.keccak_round_trace(sp.perm_inputs, ledger)
+    p2_main, _ = PT.poseidon2_chiplet_trace(p2, permute_batch=ctx.poseidon2_permute)
     # `ChipletAir::all()` order (session/prove.rs:111-126): ChunkNode (chunk + Keccak node on one row range), Poseidon2, KeccakRound,
     # BytePairLut, KeccakSponge, [TranscriptEval: its Binding readers], EcGroups
     pairs = [PA.chunk_node_air(), PA.poseidon2_chiplet_air(), PA.keccak_round_air(), PA.byte_pair_lut_air(), PA.keccak_sponge_air(),
              PA.requirer_air(payload=7), PA.ec_groups_air()]
-    host = [PA.chunk_node_trace(chunks, nd), p2_main, kr_trace, PA.byte_pair_lut_trace(ledger), PA.keccak_sponge_trace(sp),
-            PA.requirer_trace(PA.binding_requests(nd), payload=7), PA.ec_groups_trace()]
+    host = [PT.chunk_node_trace(chunks, nd), p2_main, kr_trace, PT.byte_pair_lut_trace(ledger), PT.keccak_sponge_trace(sp),
+            PT.requirer_trace(PT.binding_requests(nd), payload=7), PT.ec_groups_trace()]
     gen_s = time.perf_counter() - t0
     airs_h = [p_[0] for p_ in pairs]
     prm = dict(protocol.PROD_PARAMS)
@@ -501,7 +507,7 @@ def keccak_hash_session_probe(pkg, ctx, steps=3):
             "poseidon2_permutations": p2.next_seq, "log_trace_heights": proof.log_trace_heights,
             "ms_per_proof": dt * 1e3, "hashes_per_s": len(inputs) / dt, "keccak_permutations_per_s": len(sp.perm_inputs) / dt,
             "input_KiB_per_s": n_bytes / dt / 1024, "proof_bytes": len(proof.bytes), "verifies_with_eval_external": bool(ok),
-            "keccak256_of_empty": outs[0]["keccak_digest"].hex(), "compiled_chunks": [a.compiled_chunks for a in dairs], "trace_generation_s": gen_s}
+            "keccak256_of_empty": outs[0]["keccak_digest"].hex(), "compiled_chunks": [a.compiled_chunks for a in dairs], "test_trace_generator_s": {"seconds": gen_s, "note": GEN_NOTE}}
 
 
 def chunk_poseidon2_session_probe(pkg, ctx, steps=3):
@@ -512,19 +518,20 @@ def chunk_poseidon2_session_probe(pkg, ctx, steps=3):
     generator steps through the absorption chains with the device permutation (`mh_poseidon2_permute`)."""
     import numpy as np
     from miden_vm_amd import protocol, precompile_airs as PA
+    from miden_vm_amd.testing import precompile_trace as PT
     rng = np.random.default_rng(4)
     t0 = time.perf_counter()
-    ledger = PA.Poseidon2Requires()
-    req = PA.ChunkRequires(ledger)
+    ledger = PT.Poseidon2Requires()
+    req = PT.ChunkRequires(ledger)
     inputs = [bytes(rng.integers(0, 256, int(rng.integers(0, 32769)), dtype=np.uint8)) for _ in range(63)]
     inputs.append(inputs[0])
     for data in inputs:
         req.require(data)
         ledger.require_digest(req.last)
-    p2_main, outs = PA.poseidon2_chiplet_trace(ledger, permute_batch=ctx.poseidon2_permute)
-    others = PA.chunk_side_requests(req, poseidon2_chiplet=True) + PA.poseidon2_out_requests(ledger, outs)
+    p2_main, outs = PT.poseidon2_chiplet_trace(ledger, permute_batch=ctx.poseidon2_permute)
+    others = PT.chunk_side_requests(req, poseidon2_chiplet=True) + PT.poseidon2_out_requests(ledger, outs)
     pairs = [PA.chunk_air(), PA.poseidon2_chiplet_air(), PA.requirer_air(payload=6), PA.ec_groups_air()]
-    host = [PA.chunk_trace(req), p2_main, PA.requirer_trace(others, payload=6), PA.ec_groups_trace()]
+    host = [PT.chunk_trace(req), p2_main, PT.requirer_trace(others, payload=6), PT.ec_groups_trace()]
     gen_s = time.perf_counter() - t0
     airs_h = [p_[0] for p_ in pairs]
     prm = dict(protocol.PROD_PARAMS)
@@ -554,7 +561,7 @@ def chunk_poseidon2_session_probe(pkg, ctx, steps=3):
             "permutations_per_s": ledger.next_seq / dt, "input_MiB_per_s": n_bytes / dt / (1 << 20), "proof_bytes": len(proof.bytes),
             "verifies_with_eval_external": bool(ok), "compiled_chunks": [a.compiled_chunks for a in dairs],
             "kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items() if not k.startswith("span:") and v["ms"] > 0.05},
-            "trace_generation_s": gen_s}
+            "test_trace_generator_s": {"seconds": gen_s, "note": GEN_NOTE}}
 
 
 def uint_add_session_probe(pkg, ctx, steps=3):
@@ -564,21 +571,22 @@ def uint_add_session_probe(pkg, ctx, steps=3):
     the group table; production parameters, aux columns on the device, verified through `eval_external`."""
     import random
     from miden_vm_amd import protocol, precompile_airs as PA
+    from miden_vm_amd.testing import precompile_trace as PT
     rng = random.Random(9)
     t0 = time.perf_counter()
     bound = rng.getrandbits(255) | (1 << 254) | 1
-    store = PA.UintStore()
+    store = PT.UintStore()
     fp = store.pin_modulus(1, bound)
-    add = PA.UintAddRequires()
+    add = PT.UintAddRequires()
     n_ops = 1 << 16
     vals = [rng.randrange(1, bound + 1) for _ in range(n_ops + 1)]
     ptrs = [store.intern(v, fp) for v in vals]
     for i in range(n_ops):
         add.record(ptrs[i], ptrs[i + 1], store.intern((vals[i] + vals[i + 1]) % (bound + 1), fp), fp, 1)
-    main = PA.uint_add_trace(add, store)
-    others = store.uint_val_requests() + PA.uint_add_consumer_requests(add)
+    main = PT.uint_add_trace(add, store)
+    others = store.uint_val_requests() + PT.uint_add_consumer_requests(add)
     pairs = [PA.uint_add_air(), PA.requirer_air(payload=10), PA.ec_groups_air()]
-    host = [main, PA.requirer_trace(others, payload=10), PA.ec_groups_trace()]
+    host = [main, PT.requirer_trace(others, payload=10), PT.ec_groups_trace()]
     gen_s = time.perf_counter() - t0
     airs_h = [p_[0] for p_ in pairs]
     prm = dict(protocol.PROD_PARAMS)
@@ -600,7 +608,7 @@ def uint_add_session_probe(pkg, ctx, steps=3):
     return {"workload": "uint-add session: UintAddAir 30 + 3 EF aux (one periodic selector), the store's and the readers' bus sides (12 + 1 EF aux), EcGroupsAir; production parameters, aux columns on the device",
             "relations": n_ops, "log_trace_heights": proof.log_trace_heights, "ms_per_proof": dt * 1e3, "modular_additions_per_s": n_ops / dt,
             "proof_bytes": len(proof.bytes), "verifies_with_eval_external": bool(ok), "compiled_chunks": [a.compiled_chunks for a in dairs],
-            "trace_generation_s": gen_s}
+            "test_trace_generator_s": {"seconds": gen_s, "note": GEN_NOTE}}
 
 
 def precompile_full_session_probe(pkg, ctx, steps=3):
@@ -611,10 +619,11 @@ def precompile_full_session_probe(pkg, ctx, steps=3):
     every aux column on the device, verified through the full `eval_external`."""
     import numpy as np
     from miden_vm_amd import protocol, precompile_airs as PA
+    from miden_vm_amd.testing import precompile_trace as PT
     rng = np.random.default_rng(12)
     t0 = time.perf_counter()
     inputs = [b"", b"abc"] + [bytes(rng.integers(0, 256, int(rng.integers(0, 1201)), dtype=np.uint8)) for _ in range(22)]
-    pairs, host, info = PA.precompile_session(inputs, permute_batch=ctx.poseidon2_permute)
+    pairs, host, info = PT.precompile_session(inputs, permute_batch=ctx.poseidon2_permute)
     gen_s = time.perf_counter() - t0
     airs_h, root_pub = [p_[0] for p_ in pairs], info["public_root"]
     prm = dict(protocol.PROD_PARAMS)
@@ -634,16 +643,22 @@ def precompile_full_session_probe(pkg, ctx, steps=3):
     for _ in range(steps):
         proof = pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
     dt = (time.perf_counter() - t0) / steps
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    pkg.prove(ctx, dairs, traces, root_pub, prm, st, pre, None)
+    prof = ctx.prof()
+    ctx.prof_enable(False)
     for t in traces:
         t.free()
     led = info["ledgers"]
-    return {"workload": "the whole deferred-precompile session: ChipletAir::all() = ChunkNodeAir, Poseidon2Air, KeccakRoundAir, BytePairLutAir (preprocessed), KeccakSpongeAir, TranscriptEvalAir, UintStoreMulAir, UintAddAir, EcGroupsAir, EcPointStoreAir, EcGroupAddAir, EcMsmAir; the fixed environment; the transcript root as the public input; production parameters, aux columns on the device",
+    return {"kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items() if not k.startswith("span:") and v["ms"] > 0.05},
+            "workload": "the whole deferred-precompile session: ChipletAir::all() = ChunkNodeAir, Poseidon2Air, KeccakRoundAir, BytePairLutAir (preprocessed), KeccakSpongeAir, TranscriptEvalAir, UintStoreMulAir, UintAddAir, EcGroupsAir, EcPointStoreAir, EcGroupAddAir, EcMsmAir; the fixed environment; the transcript root as the public input; production parameters, aux columns on the device",
             "keccak_claims": len(inputs), "input_bytes": sum(len(x) for x in inputs), "transcript_nodes": len(led["eval"].nodes),
             "poseidon2_permutations": led["p2"].next_seq, "keccak_permutations": len(led["node"].sponge.perm_inputs), "point_additions": len(led["ec_add"].ops),
             "modular_macs": len(led["muls"].ops), "modular_additions": len(led["adds"].ops), "public_root": [int(x) for x in root_pub],
             "log_trace_heights": proof.log_trace_heights, "ms_per_proof": dt * 1e3, "proof_bytes": len(proof.bytes),
             "verifies_with_eval_external": bool(ok), "keccak256_of_empty": bytes(info["keccak_digests"][0]).hex(),
-            "compiled_chunks": [a.compiled_chunks for a in dairs], "trace_generation_s": gen_s}
+            "compiled_chunks": [a.compiled_chunks for a in dairs], "test_trace_generator_s": {"seconds": gen_s, "note": GEN_NOTE}}
 
 
 def ec_msm_session_probe(pkg, ctx, steps=3):
@@ -654,10 +669,11 @@ def ec_msm_session_probe(pkg, ctx, steps=3):
     proven field arithmetic); production parameters, aux columns on the device, verified through the full `eval_external`."""
     import random
     from miden_vm_amd import protocol, precompile_airs as PA
+    from miden_vm_amd.testing import precompile_trace as PT
     rng = random.Random(8)
     t0 = time.perf_counter()
     terms = [(rng.getrandbits(256) % PA.K1_BOUND, m) for m in (1, 2, 3, 5, 7, 11, 13, 17)]
-    pairs, host, (val, expr, (store, adds, muls, ec, ec_add, msm)) = PA.ec_msm_session(terms)
+    pairs, host, (val, expr, (store, adds, muls, ec, ec_add, msm)) = PT.ec_msm_session(terms)
     gen_s = time.perf_counter() - t0
     x_ptr, _ = ec.point_params(val)[1]
     airs_h = [p_[0] for p_ in pairs]
@@ -686,7 +702,7 @@ def ec_msm_session_probe(pkg, ctx, steps=3):
             "point_additions": len(ec_add.ops), "modular_additions": len(adds.ops), "modular_macs": len(muls.ops), "stored_uints": len(store.rows),
             "log_trace_heights": proof.log_trace_heights, "ms_per_proof": dt * 1e3, "msm_per_s": 1.0 / dt, "proof_bytes": len(proof.bytes),
             "verifies_with_eval_external": bool(ok), "value_x": hex(store.value(x_ptr)), "compiled_chunks": [a.compiled_chunks for a in dairs],
-            "trace_generation_s": gen_s}
+            "test_trace_generator_s": {"seconds": gen_s, "note": GEN_NOTE}}
 
 
 def uint_arith_session_probe(pkg, ctx, steps=3):
@@ -696,9 +712,10 @@ def uint_arith_session_probe(pkg, ctx, steps=3):
     49 159 stored values (2^18 rows x 44 + 29 EF, 2^15 x 30 + 3), the 2^16-row preprocessed table, the fixed environment; production parameters, aux columns
     (26 LogUp + 3 registers) on the device, verified through the full `eval_external`."""
     from miden_vm_amd import protocol, precompile_airs as PA
+    from miden_vm_amd.testing import precompile_trace as PT
     t0 = time.perf_counter()
     n_steps = 1 << 14
-    pairs, host, (final, (store, adds, muls)) = PA.uint_arith_session(n_steps)
+    pairs, host, (final, (store, adds, muls)) = PT.uint_arith_session(n_steps)
     gen_s = time.perf_counter() - t0
     airs_h = [p_[0] for p_ in pairs]
     prm = dict(protocol.PROD_PARAMS)
@@ -724,7 +741,7 @@ def uint_arith_session_probe(pkg, ctx, steps=3):
     return {"workload": "uint arithmetic session: BytePairLutAir (preprocessed), UintStoreMulAir 44 + 29 EF aux (26 LogUp columns, 3 registers), UintAddAir 30 + 3, EcGroupsAir, the relations' readers; the fixed environment; production parameters, aux columns on the device",
             "modular_macs": len(muls.ops), "modular_additions": len(adds.ops), "stored_uints": len(store.rows), "log_trace_heights": proof.log_trace_heights,
             "ms_per_proof": dt * 1e3, "modular_macs_per_s": len(muls.ops) / dt, "proof_bytes": len(proof.bytes), "verifies_with_eval_external": bool(ok),
-            "horner_value": hex(final), "compiled_chunks": [a.compiled_chunks for a in dairs], "trace_generation_s": gen_s}
+            "horner_value": hex(final), "compiled_chunks": [a.compiled_chunks for a in dairs], "test_trace_generator_s": {"seconds": gen_s, "note": GEN_NOTE}}
 
 
 def ec_add_session_probe(pkg, ctx, steps=3):
@@ -737,10 +754,11 @@ def ec_add_session_probe(pkg, ctx, steps=3):
     bus between them closed by themselves, over the session's fixed environment (the full `fixed_boundary_correction`); production parameters, aux columns on the device, verified through `eval_external`."""
     import random
     from miden_vm_amd import protocol, precompile_airs as PA
+    from miden_vm_amd.testing import precompile_trace as PT
     rng = random.Random(5)
     t0 = time.perf_counter()
     scalars = [rng.getrandbits(256) % PA.K1_BOUND for _ in range(16)]
-    pairs, host, (results, (store, adds, muls, ec, ec_add)) = PA.ec_add_session(scalars)
+    pairs, host, (results, (store, adds, muls, ec, ec_add)) = PT.ec_add_session(scalars)
     gen_s = time.perf_counter() - t0
     x_ptr, y_ptr = ec.point_params(results[0])[1]
     airs_h = [p_[0] for p_ in pairs]
@@ -770,7 +788,7 @@ def ec_add_session_probe(pkg, ctx, steps=3):
             "scalar_multiplications": len(scalars), "point_additions": n_adds, "modular_additions": len(adds.ops), "modular_macs": len(muls.ops),
             "stored_points": len(ec.points), "log_trace_heights": proof.log_trace_heights, "ms_per_proof": dt * 1e3,
             "point_additions_per_s": n_adds / dt, "proof_bytes": len(proof.bytes), "verifies_with_eval_external": bool(ok),
-            "first_multiple_x": hex(store.value(x_ptr)), "compiled_chunks": [a.compiled_chunks for a in dairs], "trace_generation_s": gen_s}
+            "first_multiple_x": hex(store.value(x_ptr)), "compiled_chunks": [a.compiled_chunks for a in dairs], "test_trace_generator_s": {"seconds": gen_s, "note": GEN_NOTE}}
 
 
 def ec_store_session_probe(pkg, ctx, steps=3):
@@ -779,9 +797,10 @@ def ec_store_session_probe(pkg, ctx, steps=3):
     degree-3 UintMul consumes) next to the group table it reads: 2^15 - 1 points of secp256k1 bound by value (98 301 membership relations),
     the foreign sides of the UintMul / EcPoint buses from the stand-in; production parameters, aux columns on the device."""
     from miden_vm_amd import protocol, precompile_airs as PA
+    from miden_vm_amd.testing import precompile_trace as PT
     t0 = time.perf_counter()
     n_points = (1 << 15) - 1
-    pairs, host, _ = PA.ec_store_session(n_points)
+    pairs, host, _ = PT.ec_store_session(n_points)
     gen_s = time.perf_counter() - t0
     airs_h = [p_[0] for p_ in pairs]
     prm = dict(protocol.PROD_PARAMS)
@@ -803,7 +822,7 @@ def ec_store_session_probe(pkg, ctx, steps=3):
     return {"workload": "ec-store session: EcPointStoreAir 14 + 5 EF aux, EcGroupsAir 6 + 1, the foreign bus sides (12 + 1 EF aux); production parameters, aux columns on the device",
             "points": n_points + 1, "log_trace_heights": proof.log_trace_heights, "ms_per_proof": dt * 1e3, "bound_points_per_s": n_points / dt,
             "proof_bytes": len(proof.bytes), "verifies_with_eval_external": bool(ok), "compiled_chunks": [a.compiled_chunks for a in dairs],
-            "trace_generation_s": gen_s}
+            "test_trace_generator_s": {"seconds": gen_s, "note": GEN_NOTE}}
 
 
 def chunk_session_probe(pkg, ctx, steps=3):
@@ -813,15 +832,16 @@ def chunk_session_probe(pkg, ctx, steps=3):
     verified through `ChipletMultiAir::eval_external`."""
     import numpy as np
     from miden_vm_amd import protocol, precompile_airs as PA
+    from miden_vm_amd.testing import precompile_trace as PT
     rng = np.random.default_rng(4)
     t0 = time.perf_counter()
-    req = PA.ChunkRequires()
+    req = PT.ChunkRequires()
     inputs = [bytes(rng.integers(0, 256, int(rng.integers(0, 32769)), dtype=np.uint8)) for _ in range(63)]
     inputs.append(inputs[0])
     for data in inputs:
         req.require(data)
     pairs = [PA.chunk_air(), PA.requirer_air(payload=6), PA.ec_groups_air()]
-    host = [PA.chunk_trace(req), PA.requirer_trace(PA.chunk_side_requests(req), payload=6), PA.ec_groups_trace()]
+    host = [PT.chunk_trace(req), PT.requirer_trace(PT.chunk_side_requests(req), payload=6), PT.ec_groups_trace()]
     gen_s = time.perf_counter() - t0
     airs_h = [p_[0] for p_ in pairs]
     prm = dict(protocol.PROD_PARAMS)
@@ -844,7 +864,7 @@ def chunk_session_probe(pkg, ctx, steps=3):
     return {"workload": "chunk session: ChunkAir 12 + 5 EF aux, the other sides of its three buses (8 + 1 EF aux), EcGroupsAir; production parameters, aux columns on the device",
             "input_bytes": n_bytes, "chunks": req.next_chunk_seq, "log_trace_heights": proof.log_trace_heights, "ms_per_proof": dt * 1e3,
             "input_MiB_per_s": n_bytes / dt / (1 << 20), "proof_bytes": len(proof.bytes), "verifies_with_eval_external": bool(ok),
-            "compiled_chunks": [a.compiled_chunks for a in dairs], "trace_generation_s": gen_s}
+            "compiled_chunks": [a.compiled_chunks for a in dairs], "test_trace_generator_s": {"seconds": gen_s, "note": GEN_NOTE}}
 
 
 def miden_real_probe(pkg, ctx, iters=9250, steps=3, lmcs="poseidon2", inputs=None):
@@ -1102,7 +1122,11 @@ def main():
                     help="rows of the ONE proof sharded over the GPUs (N > 1)")
     ap.add_argument("--comm", default=os.environ.get("MIDEN_BENCH_COMM", "rccl"), choices=["rccl", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the h2d_inclusive, miden_shape and in_flight probes")
+    ap.add_argument("--no-extras", action="store_true", help="headline, roofline and CPU baseline only (no h2d_inclusive / real-statement probes)")
+    ap.add_argument("--extras", action="store_true",
+                    help="also the twenty side probes (miden_shape, jit_load, chiplets_air, the second client's per-chiplet sessions, in-flight "
+                         "proofs, the other hash configurations); the default line carries the headline, the H2D-inclusive figure, the real "
+                         "statement under Poseidon2 and Blake3 and the whole precompile session")
     ap.add_argument("--cpu-log-n", type=int, default=18)
     args = ap.parse_args()
 
@@ -1145,6 +1169,7 @@ def main():
 
     ctx = pkg.Ctx(dev_index)
     mode, comm, comm_name, fallback = "single", None, None, None
+    comm_log = []  # one entry per communicator tried: its bring-up steps with their wall times -- a failure on the 8-GPU box is read from the line
     if world > 1:
         import threading
         from miden_vm_amd import sharding
@@ -1156,8 +1181,17 @@ def main():
             box = {}
 
             def attempt():
+                steps_ = box.setdefault("steps", [])
+                t_ = time.perf_counter()
+
+                def mark(name):
+                    nonlocal t_
+                    now = time.perf_counter()
+                    steps_.append([name, round(now - t_, 3)])
+                    t_ = now
                 try:
                     torch.cuda.set_device(dev_index)  # the current device is per thread
+                    box["at"] = "create (unique id broadcast + communicator init)"
                     if choice == "rccl":
                         c_ = sharding.RcclComm(ctx, rank, world)
                     elif choice == "torch-nccl":
@@ -1165,13 +1199,19 @@ def main():
                     else:
                         c_ = sharding.TorchComm(rank, world)
                     box["comm"] = c_
+                    mark("create")
+                    box["at"] = "selftest (all_to_all / all_gather / gather_to / broadcast on small buffers)"
                     sharding.comm_selftest(ctx, c_)
+                    mark("selftest")
+                    box["at"] = "trial proof (2^12 rows, sharded)"
                     trial = ShardedRunner(pkg, ctx, 12, c_)  # a small sharded proof before the big trace is built
                     trial.step()
                     box["ok"] = trial.proof is not None
                     trial.trace.free()
+                    mark("trial_proof_2p12")
+                    box["at"] = "done"
                 except Exception as e:
-                    box["err"] = repr(e)[:160]
+                    box["err"] = f"{box.get('at', '?')}: {repr(e)[:160]}"
 
             try:
                 if choice == "torch-nccl":
@@ -1182,10 +1222,11 @@ def main():
                 th.start()
                 th.join(timeout=float(os.environ.get("MIDEN_BENCH_COMM_TIMEOUT", "240")))
                 if th.is_alive():
-                    box["err"] = "timed out"
+                    box["err"] = f"timed out after {os.environ.get('MIDEN_BENCH_COMM_TIMEOUT', '240')} s in: {box.get('at', 'thread start')}"
             except Exception as e:
                 box["err"] = repr(e)[:160]
             ok = bool(box.get("ok")) and "err" not in box
+            comm_log.append({"choice": choice, "ok_on_rank0": ok, "steps_s": list(box.get("steps", [])), **({"error": box["err"]} if "err" in box else {})})
             if not ok:
                 fallback = (fallback or "") + f"{choice}: {box.get('err', 'no proof')}; "
             if all_ok(ok):
@@ -1264,6 +1305,10 @@ def main():
     }
     if fallback:
         out["config"]["fallback"] = fallback
+    if comm_log:
+        out["config"]["comm"] = {"chosen": comm_name, "mode": mode, "attempts": comm_log, "collective_timeout_s": float(os.environ.get("MH_COMM_TIMEOUT_S", "120")),
+                                 "note": "rank 0's view; every attempt runs on a watchdog thread (MIDEN_BENCH_COMM_TIMEOUT) and the ranks agree on its outcome "
+                                         "over the gloo control plane; inside the library every collective is bounded by MH_COMM_TIMEOUT_S (error code, no hang)"}
     if mode == "sharded":
         # the measured split of this rank's time next to the model of DESIGN.md section 5 (miden-vm_amd/sharding.py), so that the
         # line can be read against a prediction: sharded kernels, the replicated inverse transforms, collectives
@@ -1349,10 +1394,11 @@ def main():
             del pin, owner
         except Exception as e:
             out["h2d_inclusive"] = {"error": repr(e)[:200]}
-        try:
-            out["miden_shape"] = miden_shape_probe(pkg, ctx)
-        except Exception as e:
-            out["miden_shape"] = {"error": repr(e)[:200]}
+        if args.extras:
+            try:
+                out["miden_shape"] = miden_shape_probe(pkg, ctx)
+            except Exception as e:
+                out["miden_shape"] = {"error": repr(e)[:200]}
         try:
             from miden_vm_amd.testing import core_trace as _ct
             t_gen = time.perf_counter()
@@ -1366,12 +1412,18 @@ def main():
                 c3.close()
             # BASELINE.json configs[0]: a ~2^16-row program, the reference's own CPU-runnable case, as a latency
             # point of the real statement: 575 iterations of the same loop body = 2^16 core rows
-            small = _ct.prove_inputs(_ct.CoreVM(stack_inputs=list(range(16))), _ct.bench_program(575))
-            r16 = miden_real_probe(pkg, ctx, inputs=small, steps=5)
-            out["miden_real_2p16"] = {k: r16[k] for k in ("log_trace_heights", "ms_per_proof", "rows_per_s", "h2d_inclusive_ms", "proof_bytes",
-                                                           "verifies_with_eval_external", "kernels_ms")}
+            if args.extras:
+                small = _ct.prove_inputs(_ct.CoreVM(stack_inputs=list(range(16))), _ct.bench_program(575))
+                r16 = miden_real_probe(pkg, ctx, inputs=small, steps=5)
+                out["miden_real_2p16"] = {k: r16[k] for k in ("log_trace_heights", "ms_per_proof", "rows_per_s", "h2d_inclusive_ms", "proof_bytes",
+                                                               "verifies_with_eval_external", "kernels_ms")}
         except Exception as e:
             out["miden_real"] = {"error": repr(e)[:300]}
+        try:
+            out["precompile_full_session"] = precompile_full_session_probe(pkg, ctx)
+        except Exception as e:
+            out["precompile_full_session"] = {"error": repr(e)[:300]}
+    if world == 1 and args.extras and not args.no_extras:
         try:
             out["jit_load"] = jit_load_probe(pkg, ctx)
         except Exception as e:
@@ -1417,10 +1469,6 @@ def main():
         except Exception as e:
             out["ec_msm_session"] = {"error": repr(e)[:300]}
         try:
-            out["precompile_full_session"] = precompile_full_session_probe(pkg, ctx)
-        except Exception as e:
-            out["precompile_full_session"] = {"error": repr(e)[:300]}
-        try:
             # the service-level probes run in a process of their own (tools/bench_inflight_h2d.py, no torch in it): measured in THIS
             # process, which also hosts PyTorch's HIP runtime, the same loops lose the copy / kernel overlap (k = 1 with its uploads
             # pipelined: 56.0 ms here against 47.8 ms stand-alone on the same box)
@@ -1444,7 +1492,36 @@ def main():
         out["cpu_baseline"] = cpu_baseline(runner, args.cpu_log_n)
     elif rank == 0:
         out["cpu_baseline"] = None
+    if world > 1:
+        out["scale_note"] = (f"N = 1 proves 2^{args.log_n} rows per step, N > 1 ONE proof of 2^{args.shard_log_n} rows sharded over the GPUs: a speed-up "
+                             "against the N = 1 line is a ratio of rows/s on two instances.  One MI355X proves 2^24 x 51 + 8 EF at 22.7 M rows/s "
+                             "(739 ms, profiles/r03_config_shapes.txt; 2^20: 22.8 M rows/s) -- within 1 % of the 2^20 rate, so the ratio of the "
+                             "lines is the strong-scaling speed-up of the 2^24 instance to that accuracy")
     if rank == 0:
+        # The driver keeps the parsed contract keys and the last 4 kB of the line: what matters goes LAST, compact.
+        def top_kernels(d, k=4):
+            km = (d or {}).get("kernels_ms") or {}
+            return dict(sorted(km.items(), key=lambda kv: -kv[1])[:k])
+        def brief(d, keys):
+            return {k: d.get(k) for k in keys if isinstance(d, dict) and k in d} if isinstance(d, dict) else d
+        summary = {"headline_ms": round(out["ms_per_step"], 3), "headline_rows_per_s": round(out["value"]),
+                   "roofline_frac_hbm": (out.get("roofline") or {}).get("frac"), "roofline_frac_valu": (out.get("roofline_valu") or {}).get("frac"),
+                   "h2d_inclusive_ms": (out.get("h2d_inclusive") or {}).get("ms_per_step")}
+        for key in ("miden_real", "miden_real_blake3", "precompile_full_session"):
+            d = out.get(key)
+            if isinstance(d, dict) and "error" not in d:
+                summary[key] = {**brief(d, ("log_trace_heights", "ms_per_proof", "h2d_inclusive_ms", "proof_bytes", "verifies_with_eval_external")),
+                                "top_kernels_ms": top_kernels(d)}
+            elif d is not None:
+                summary[key] = d
+        if isinstance(out.get("miden_real_sharded"), dict):
+            summary["miden_real_sharded"] = brief(out["miden_real_sharded"], ("ms_per_proof", "rows_per_s", "log_trace_heights", "error"))
+        if isinstance(out.get("cpu_baseline"), dict):
+            summary["cpu_baseline"] = brief(out["cpu_baseline"], ("value", "unit", "cores", "kind"))
+        first = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"]
+        last = ["roofline", "roofline_valu", "cpu_baseline", "h2d_inclusive", "scale_note"]
+        bulky = [k for k in out if k not in first and k not in last]
+        out = {**{k: out[k] for k in first if k in out}, **{k: out[k] for k in bulky}, **{k: out[k] for k in last if k in out}, "summary": summary}
         print(json.dumps(out), flush=True)
     if comm is not None and hasattr(comm, "close"):
         comm.close()

@@ -13,6 +13,7 @@ pub const MH_ERR_INVALID: c_int = 1;
 pub const MH_ERR_HIP: c_int = 2;
 pub const MH_ERR_OOM: c_int = 3;
 pub const MH_ERR_INTERNAL: c_int = 4;
+pub const MH_ERR_COMM: c_int = 5;
 
 /// PcsParams (crates/lifted-stark/src/pcs/params.rs:52-96).
 #[repr(C)]

@@ -26,6 +26,7 @@ extern "C" {
 #define MH_ERR_HIP 2
 #define MH_ERR_OOM 3
 #define MH_ERR_INTERNAL 4
+#define MH_ERR_COMM 5      /* a collective of a sharded proof failed or did not complete within $MH_COMM_TIMEOUT_S (default 120 s) */
 
 typedef struct mh_ctx mh_ctx;
 typedef struct mh_trace mh_trace; /* device-resident trace matrix (column-major) */

@@ -2,11 +2,13 @@
 #include "air_jit.hpp"
 #include "gl.cuh"
 #include <hip/hiprtc.h>
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <mutex>
 #include <set>
 #include <sstream>
@@ -49,7 +51,9 @@ FI u64 gl_reduce128_lazy(u64 hi, u64 lo) {  // gl_reduce128 without its last lin
 }
 FI u64 gl_mul_c(u64 a, u64 b) { const u128 p = (u128)a * b; return gl_reduce128((u64)(p >> 64), (u64)p); }  // one 64 x 64 -> 128 product (four v_mad_u64_u32), not __umul64hi + a second low product
 #ifndef MH_JIT_ASM_MUL
-#define MH_JIT_ASM_MUL 2  // 0: plain C products, 1: the asm product everywhere, 2: for base-field gates only (measured: core AIR 19.6 / 19.9 / 18.7 ms)
+// 0: plain C products, 1: the asm product everywhere, 2: for base-field gates only (round 4, core AIR: 19.6 / 19.9 / 18.7 ms),
+// 3: the merged-statement asm product everywhere, extension-field products included (round 6, the default; lz_mul_asm3 below)
+#define MH_JIT_ASM_MUL 3
 #endif
 #if MH_JIT_ASM_MUL
 // the 13-instruction SGPR-carry-chain product of poseidon2_fast.cuh (p2f_mul_nv: non-volatile statements carrying their own
@@ -188,11 +192,56 @@ FI u64 lz_mul_asm(u64 a, u64 b) {  // the 13 instructions of gl_mul above, witho
 }
 #endif
 #if MH_JIT_ASM_MUL
+// The same 13 instructions with the carry chains INSIDE two statements (MH_JIT_ASM_MUL=3, round 6).  In the form above every carry is
+// an SGPR-pair output of its own statement (eleven per product, six of them never read): the scheduler interleaves several products
+// and the pairs of all of them are alive at once -- in the chunks of extension-field gates, next to the uniform coefficients the scalar
+// unit holds there, hipcc spilled them into VGPR lanes (116 v_writelane / v_readlane pairs per chunk, round 5), which is why the EF
+// products stayed in C at 25 instructions each: 618 of them per point in the core AIR, 30 % of its VALU instructions.  Here the
+// unused carry-outs go to vcc, the chains k1 -> k2 -> k3 and bb -> bw -> c3 -> mk run through vcc inside one statement each with their
+// wait states, and only `cm` and `c1` (one pair each, from a v_mad_u64_u32 to the next statement) are ever allocated.
+FI u64 lz_mul_asm3(u64 a, u64 b) {
+  u64 p00, m, hi, t, cm, c1, s1;
+  u32 w1, accl, acch, rl, rh;
+  const u32 zero = 0;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p00) : "v"(jlo(a)), "v"(jlo(b)) : "vcc");
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(m) : "v"(jlo(a)), "v"(jhi(b)) : "vcc");
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m), "=s"(cm) : "v"(jhi(a)), "v"(jlo(b)), "0"(m));
+  // in place: w1 over p00.hi -- (p00.lo, w1) is then a register pair --, and (accl, acch) over (m.lo, m.hi), free once w1 has read m.lo
+  w1 = jhi(p00); accl = jlo(m); acch = jhi(m);
+  asm("v_add_co_u32_e64 %0, vcc, %0, %1\n\t"          // w1 = p00.hi + m.lo            (k1 -> vcc)
+      "s_nop 1\n\t"
+      "v_addc_co_u32_e64 %1, vcc, %2, 0, vcc\n\t"      // accl = m.hi + k1              (k2 -> vcc)
+      "s_or_b64 vcc, vcc, %4\n\t"                      // k3 = k2 | cm
+      "v_addc_co_u32_e64 %2, vcc, %3, 0, vcc"            // acch = k3
+      : "+v"(w1), "+v"(accl), "+v"(acch) : "v"(zero), "s"(cm) : "vcc");
+  const u64 acc = ((u64)acch << 32) | accl;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(hi) : "v"(jhi(a)), "v"(jhi(b)), "v"(acc) : "vcc");
+  const u64 lo = ((u64)w1 << 32) | jlo(p00);
+  asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t), "=s"(c1) : "v"(jlo(hi)), "v"(lo));
+  asm("s_nop 1\n\t"
+      "v_subb_co_u32_e64 %0, vcc, %4, %6, %2\n\t"      // rl = t.lo - hi.hi - c1        (bb -> vcc)
+      "v_addc_co_u32_e64 %1, %3, %5, 0, %2\n\t"        // rh = t.hi + c1
+      "s_nop 0\n\t"
+      "v_subb_co_u32_e64 %1, vcc, %1, 0, vcc\n\t"      // rh -= bb                      (bw -> vcc)
+      "s_nop 1\n\t"
+      "v_addc_co_u32_e64 %0, %2, %0, 0, vcc\n\t"       // rl += bw                      (c3 -> %2)
+      "s_nop 0\n\t"
+      "s_andn2_b64 %2, vcc, %2\n\t"                    // mk = bw & ~c3
+      "v_subb_co_u32_e64 %1, vcc, %1, 0, %2"             // rh -= mk
+      : "=&v"(rl), "=&v"(rh), "+s"(c1), "=&s"(s1) : "v"(jlo(t)), "v"(jhi(t)), "v"(jhi(hi)) : "vcc");
+  return ((u64)rh << 32) | rl;
+}
+#endif
+#if MH_JIT_ASM_MUL == 3
+#define lz_mul lz_mul_asm3
+#elif MH_JIT_ASM_MUL
 #define lz_mul lz_mul_asm
 #else
 #define lz_mul lz_mul_c
 #endif
-#if MH_JIT_ASM_MUL == 1
+#if MH_JIT_ASM_MUL == 3
+#define lz_mul_ef lz_mul_asm3
+#elif MH_JIT_ASM_MUL == 1
 #define lz_mul_ef lz_mul_asm
 #else
 #define lz_mul_ef lz_mul_c
@@ -218,12 +267,18 @@ FI e2 lz_e2_mulf(e2 a, u64 b) { return {lz_mul_ef(a.c0, b), lz_mul_ef(a.c1, b)};
 struct JitArgs {
   const u64* main_lde; const u64* aux_lde; const u64* prep_lde; u64* spill; u64* acc; const u64* tw; const u64* coset_tab;
   const u64* inv_first; const u64* inv_last; const u64* periodic; const u64* publics; const u64* randomness;
-  const u64* aux_values; const u64* alpha_pows; const u64* uni;
-  u64 wh_inv, q0, q_count, spill_stride;
-  int log_n, log_cosets, log_d, log_dl, jc_shift;
+  const u64* aux_values; const u64* alpha_pows; const u64* uni; const u64* acc_in;
+  u64 wh_inv, q0, q_count, spill_stride, beta0, beta1;
+  int log_n, log_cosets, log_d, log_dl, jc_shift, log_n_prev;
   u32 t0, periodic_rows;
 };
-static_assert(sizeof(JitArgs) == 184, "JitArgs layout");
+static_assert(sizeof(JitArgs) == 208, "JitArgs layout");
+// one kernel for the whole DAG (MH_JIT_FUSE): nothing moves across a region boundary -- neither by the scheduler nor as a value the
+// compiler remembers from an earlier load (a cell read again in a later region is LOADED again: its register was given back)
+// The branch on an opaque uniform value (never taken: one s_cmp + s_cbranch) makes every region a basic block of its own: the
+// compiler's per-block passes (CodeGenPrepare, instruction selection, machine CSE, the scheduler) are quadratic in the block size --
+// the core AIR's 50 k instructions as ONE block took 130 s to compile, as eight blocks they take what the eight chunk kernels took.
+#define MH_REGION_FENCE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" : "+s"(mh_live) : : "memory"); if (mh_live == 0) return; } while (0)
 )SRC";
 
 struct Ev {
@@ -370,8 +425,10 @@ struct JitProgram {
   std::vector<hipModule_t> modules;
   std::vector<hipFunction_t> fns;
   hipFunction_t fn_uni = nullptr;  // fills JitArgs::uni (null: the DAG has no uniform gate)
-  size_t n_spill = 0;  // u64 slots per point crossing chunk boundaries
+  size_t n_spill = 0;  // u64 slots per point crossing chunk boundaries (HBM planes)
   size_t n_uni = 0;    // u64 entries of the uniform table
+  bool fused = false;  // one kernel for the whole DAG (MH_JIT_FUSE): regions instead of chunk kernels, k_quot_finish inside
+  size_t n_regions = 0;
 };
 
 void jit_program_free(JitProgram* p) {
@@ -379,7 +436,8 @@ void jit_program_free(JitProgram* p) {
   for (hipModule_t m : p->modules) (void)hipModuleUnload(m);
   delete p;
 }
-size_t jit_program_chunks(const JitProgram* p) { return p ? p->fns.size() : 0; }
+size_t jit_program_chunks(const JitProgram* p) { return !p ? 0 : p->fused ? p->n_regions : p->fns.size(); }
+bool jit_program_fused(const JitProgram* p) { return p && p->fused; }
 // Largest VGPR count over the compiled chunks (what bounds their occupancy: 512 / VGPRs waves per SIMD on gfx950); 0 = none / unknown.
 int jit_program_max_vgprs(const JitProgram* p) {
   int mx = 0;
@@ -394,11 +452,12 @@ int jit_program_max_vgprs(const JitProgram* p) {
 thread_local bool g_jit_compile_only = false;
 thread_local int g_jit_last_chunks = 0;
 
-static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const std::vector<size_t>* forced_cuts, int depth);
-JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) { return jit_program_build_cuts(ctx, ir, nullptr, 0); }
+static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const std::vector<size_t>* forced_cuts, int depth, int press_max);
+JitProgram* jit_program_build(mh_ctx* ctx, const DagIR& ir) { return jit_program_build_cuts(ctx, ir, nullptr, 0, 0); }
 // forced_cuts: the chunk end positions (ascending, last = the number of events) of a retry after a chunk came back from the compiler
 // with scratch memory -- see the end of the compile step
-static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const std::vector<size_t>* forced_cuts, int depth) {
+// press_max: fused programs only -- the largest number of 64-bit words a region may hold alive at once (0: $MH_JIT_FUSE_PRESS)
+static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const std::vector<size_t>* forced_cuts, int depth, int press_max) {
   const int mode = ir.outputs ? 1 : env_int("MH_JIT", -1);  // 0: never, 1: always, default: large DAGs only
   if (mode == 0) return nullptr;
   const std::vector<DagNode>& nodes = ir.nodes;
@@ -702,6 +761,71 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
       }
     }
   }
+  // ---- fused programs: a region holds at most `press_max` words alive ----
+  // The register file gives a lane 128 64-bit words at two waves per SIMD; the limb accumulators of the fold, the selectors and the
+  // addresses take ~25 of them for the whole kernel, a product in flight ~8.  What a region keeps alive is known here exactly: walk
+  // its items, a value (computed, recomputed, loaded from its slot, or a cell read where first used) lives from its definition to its
+  // last use INSIDE the region.  A region above the bound is cut in two where the fewest words cross, and everything is planned
+  // again -- without compiling: the compiler is asked once, and only if it still reports scratch memory the bound is lowered.
+  const bool fuse_mode = !ir.outputs && env_int("MH_JIT_FUSE", 0) != 0;
+  if (fuse_mode && !press_max) press_max = std::max(16, env_int("MH_JIT_FUSE_PRESS", 84));
+  if (fuse_mode) {
+    std::vector<long> press(n_chunks, 0);
+    std::vector<uint32_t> o;
+    for (size_t ci = 0; ci < n_chunks; ci++) {
+      std::map<uint64_t, std::pair<long, long>> span;  // key -> (definition, last use) in item positions; key = node id (cells share their node)
+      auto use = [&](uint32_t id, long i) {
+        const DagNode& nd = nodes[id];
+        const bool cell = nd.op == DOP_MAIN || nd.op == DOP_AUX || nd.op == DOP_PREP || nd.op == DOP_PERIODIC;
+        if (!cell && !interior(id)) return;
+        auto it = span.find(id);
+        if (it == span.end()) span[id] = {i, i};  // a cell: read where first used
+        else it->second.second = i;
+      };
+      long i = 0;
+      for (const Item& it : items[ci]) {
+        if (it.fold_k >= 0) use(it.node, i);
+        else if (it.fold_k == -2) span[it.node] = {i, i};
+        else {
+          ops(it.node, o);
+          for (uint32_t c : o) use(c, i);
+          span[it.node] = {i, i};
+        }
+        i++;
+      }
+      std::vector<long> diff((size_t)i + 2, 0);
+      for (auto& kv : span) {
+        const long w = nodes[kv.first].ext ? 2 : 1;
+        diff[kv.second.first] += w;
+        diff[kv.second.second + 1] -= w;
+      }
+      long run = 0;
+      for (long k = 0; k <= i; k++) { run += diff[k]; press[ci] = std::max(press[ci], run); }
+    }
+    if (env_int("MH_JIT_STATS", 0)) {
+      fprintf(stderr, "[mh jit] fused: words alive per region (bound %d):", press_max);
+      for (long v : press) fprintf(stderr, " %ld", v);
+      fprintf(stderr, "\n");
+    }
+    if (depth < 12 && env_int("MH_JIT_SPLIT", 1)) {
+      std::vector<size_t> cuts;
+      bool any = false;
+      for (size_t ci = 0; ci < n_chunks; ci++) {
+        const size_t lo = chunks[ci].ev_lo, hi = chunks[ci].ev_hi;
+        if (press[ci] > press_max && hi - lo >= 8) {
+          size_t best_m = 0;
+          long best_x = -1;
+          for (size_t m = lo + (hi - lo) / 3; m <= lo + 2 * (hi - lo) / 3; m++) {
+            if (m <= lo || m >= hi || seq[m].fold_k >= 0) continue;
+            if (best_x < 0 || crossing[m - 1] < best_x) { best_x = crossing[m - 1]; best_m = m; }
+          }
+          if (best_m) { cuts.push_back(best_m); any = true; }
+        }
+        cuts.push_back(hi);
+      }
+      if (any) return jit_program_build_cuts(ctx, ir, &cuts, depth + 1, press_max);
+    }
+  }
   // spill planes (one u64 plane per base value, two per EF value), reused once the last reader has run
   std::vector<int32_t> slot(nodes.size(), -1);
   size_t n_spill = 0;
@@ -755,6 +879,96 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
   // instruction is emitted for it; AIRs whose chains are shorter get the same source as before.
   const int lz_chain_max = env_int("MH_JIT_LZCHAIN", 16);
   std::vector<uint16_t> lz_chain(nodes.size(), 0);
+  // ---- ONE kernel for the whole DAG (MH_JIT_FUSE, constraint programs): the chunks become REGIONS of one straight-line kernel ----
+  // What the separate chunk kernels paid for being separate: every value crossing a cut went through an HBM plane (24 + 24 words per
+  // point in the core AIR), the partial alpha-folds through a read-modify-write of the quotient buffer per chunk (+ a reduction of the
+  // limb accumulators per chunk), every chunk re-read its cells from HBM (the core AIR's 51 columns are read 283 times by 8 chunks),
+  // and every launch ended in a tail.  Fused: a workgroup = 256 consecutive rows of one coset; crossing values live in LDS slots
+  // `L[slot][tid]`; the limb accumulators stay in registers from the first constraint to the last and k_quot_finish is applied in the
+  // same kernel (ONE 16-byte store per point); the columns most regions read are staged once per workgroup in LDS tiles
+  // `T[col][257]` -- the next-row cell of lane i is the current-row cell of lane i + 1, entry 256 is the first row after the tile --
+  // and a region fence (MH_REGION_FENCE) keeps the compiler from holding anything across a boundary that the plan gave back.
+  const bool fuse = fuse_mode;
+  const size_t n_regions = n_chunks;
+  std::vector<size_t> region_ends;
+  for (const Chunk& ch : chunks) region_ends.push_back(ch.ev_hi);
+  size_t lds_words = 0, n_spill_hbm = 0;
+  std::vector<int32_t> tile_main, tile_aux, tile_prep;  // LDS word offset of a staged column (aux: per base plane), -1: read from HBM
+  std::vector<int32_t> slot_lds, slot_hbm;              // per spill slot: its LDS word offset, or its HBM plane
+  if (fuse) {
+    size_t w_main = 0, w_aux = 0, w_prep = 0;
+    for (const DagNode& nd : nodes) {
+      if (nd.op == DOP_MAIN) w_main = std::max<size_t>(w_main, nd.a + 1);
+      if (nd.op == DOP_AUX) w_aux = std::max<size_t>(w_aux, nd.a + 1);
+      if (nd.op == DOP_PREP) w_prep = std::max<size_t>(w_prep, nd.a + 1);
+    }
+    tile_main.assign(w_main, -1); tile_aux.assign(2 * w_aux, -1); tile_prep.assign(w_prep, -1);
+    const size_t budget_words = (size_t)std::max(0, env_int("MH_JIT_LDS_KB", 64)) * 1024 / 8;  // per workgroup of 256 lanes
+    // Candidates for the LDS, by the HBM accesses (8 bytes per point each) they save: a spill slot saves the store and the loads of
+    // every value that passes through it (2-3 for most), a column read by k regions saves k - 1 reads (up to 7 in the core AIR).
+    struct Cand { int kind; uint32_t idx; long saves; size_t words; };  // kind 0 / 1 / 2: main / aux / preprocessed column, 3: spill slot
+    std::vector<Cand> cands;
+    {
+      std::vector<std::set<size_t>> um(w_main), ua(w_aux), up(w_prep);
+      std::vector<long> slot_saves(n_spill, 0);
+      std::vector<uint32_t> o;
+      auto leaf = [&](uint32_t id, size_t ci) {
+        const DagNode& nd = nodes[id];
+        if (nd.op == DOP_MAIN) um[nd.a].insert(ci);
+        else if (nd.op == DOP_AUX) ua[nd.a].insert(ci);
+        else if (nd.op == DOP_PREP) up[nd.a].insert(ci);
+      };
+      for (size_t ci = 0; ci < n_chunks; ci++)
+        for (const Item& it : items[ci]) {
+          if (it.fold_k == -2) {
+            for (int k = 0; k < (nodes[it.node].ext ? 2 : 1); k++) slot_saves[slot[it.node] + k]++;
+            continue;
+          }
+          if (it.fold_k >= 0) { leaf(it.node, ci); continue; }
+          ops(it.node, o);
+          for (uint32_t c : o) leaf(c, ci);
+        }
+      for (size_t id = 0; id < nodes.size(); id++)
+        if (spilled[id])
+          for (int k = 0; k < (nodes[id].ext ? 2 : 1); k++) slot_saves[slot[id] + k]++;
+      for (size_t i = 0; i < w_main; i++) if (um[i].size() >= 2) cands.push_back({0, (uint32_t)i, (long)um[i].size() - 1, 257});
+      for (size_t i = 0; i < w_aux; i++) if (ua[i].size() >= 2) cands.push_back({1, (uint32_t)i, 2 * ((long)ua[i].size() - 1), 514});
+      for (size_t i = 0; i < w_prep; i++) if (up[i].size() >= 2) cands.push_back({2, (uint32_t)i, (long)up[i].size() - 1, 257});
+      for (size_t i = 0; i < n_spill; i++) cands.push_back({3, (uint32_t)i, slot_saves[i], 256});
+    }
+    std::stable_sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) { return x.saves * (long)y.words > y.saves * (long)x.words; });
+    slot_lds.assign(n_spill, -1);
+    long saved = 0, all = 0;
+    size_t n_cols = 0, n_slots_lds = 0;
+    for (const Cand& cd : cands) {
+      all += cd.saves;
+      if (lds_words + cd.words > budget_words) continue;
+      if (cd.kind == 0) tile_main[cd.idx] = (int32_t)lds_words;
+      else if (cd.kind == 2) tile_prep[cd.idx] = (int32_t)lds_words;
+      else if (cd.kind == 1) { tile_aux[2 * cd.idx] = (int32_t)lds_words; tile_aux[2 * cd.idx + 1] = (int32_t)lds_words + 257; }
+      else slot_lds[cd.idx] = (int32_t)lds_words;
+      (cd.kind == 3 ? n_slots_lds : n_cols)++;
+      lds_words += cd.words;
+      saved += cd.saves;
+    }
+    slot_hbm.assign(n_spill, -1);
+    for (size_t i = 0; i < n_spill; i++)
+      if (slot_lds[i] < 0) slot_hbm[i] = (int32_t)n_spill_hbm++;
+    if (env_int("MH_JIT_STATS", 0))
+      fprintf(stderr, "[mh jit] fused: %zu regions, %zu of %zu spill slots and %zu columns in LDS (%zu KB per workgroup): %ld of %ld avoidable 8-byte HBM accesses per point avoided\n",
+              n_regions, n_slots_lds, n_spill, n_cols, lds_words * 8 / 1024, saved, all);
+  }
+  // a spilled word: its LDS slot `L[off + tid]` (fused, as planned above) or its HBM plane
+  auto spill_ref = [&](int32_t s) -> std::string {
+    char b[96];
+    if (fuse && slot_lds[s] >= 0) snprintf(b, sizeof b, "L[%d + tid]", slot_lds[s]);
+    else snprintf(b, sizeof b, "a.spill[%dull * a.spill_stride + qb]", fuse ? slot_hbm[s] : s);
+    return b;
+  };
+  std::ostringstream fused_regions;
+  bool fuse_need_x = false, fuse_need_fl = false, fuse_any_fold = false;
+  const bool fuse_fold_persist = env_int("MH_JIT_FUSE_FOLDREG", 1) != 0;
+  int fold_terms = 0;  // folds since the limb accumulators were last reduced (per chunk; fused: across regions)
   // ---- source per chunk ----
   const bool lazy_loads = env_int("MH_JIT_LAZY", 1) != 0;
   char buf[256];
@@ -777,8 +991,11 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
           snprintf(buf, sizeof buf, "m%u_%u", nd.a, nd.b);
           name = buf;
           if (declared.insert(name).second) {
-            snprintf(buf, sizeof buf, "  const u64 %s = a.main_lde[((%uull * B + jc) << a.log_n) + %s];\n", name.c_str(), nd.a,
-                     nd.b ? "rn" : "r");
+            if (fuse && tile_main[nd.a] >= 0)
+              snprintf(buf, sizeof buf, "  const u64 %s = L[%d + tid];\n", name.c_str(), tile_main[nd.a] + (nd.b ? 1 : 0));
+            else
+              snprintf(buf, sizeof buf, "  const u64 %s = a.main_lde[((%uull * B + jc) << a.log_n) + %s];\n", name.c_str(), nd.a,
+                       nd.b ? "rn" : "r");
             ld << buf;
           }
           return name;
@@ -787,18 +1004,27 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
           name = buf;
           if (declared.insert(name).second) {
             const char* rr = nd.b ? "rn" : "r";
-            snprintf(buf, sizeof buf, "  const e2 %s = {a.aux_lde[((%uull * B + jc) << a.log_n) + %s], ", name.c_str(), 2 * nd.a, rr);
-            ld << buf;
-            snprintf(buf, sizeof buf, "a.aux_lde[((%uull * B + jc) << a.log_n) + %s]};\n", 2 * nd.a + 1, rr);
-            ld << buf;
+            if (fuse && tile_aux[2 * nd.a] >= 0) {
+              snprintf(buf, sizeof buf, "  const e2 %s = {L[%d + tid], L[%d + tid]};\n", name.c_str(), tile_aux[2 * nd.a] + (nd.b ? 1 : 0),
+                       tile_aux[2 * nd.a + 1] + (nd.b ? 1 : 0));
+              ld << buf;
+            } else {
+              snprintf(buf, sizeof buf, "  const e2 %s = {a.aux_lde[((%uull * B + jc) << a.log_n) + %s], ", name.c_str(), 2 * nd.a, rr);
+              ld << buf;
+              snprintf(buf, sizeof buf, "a.aux_lde[((%uull * B + jc) << a.log_n) + %s]};\n", 2 * nd.a + 1, rr);
+              ld << buf;
+            }
           }
           return name;
         case DOP_PREP:
           snprintf(buf, sizeof buf, "p%u_%u", nd.a, nd.b);
           name = buf;
           if (declared.insert(name).second) {
-            snprintf(buf, sizeof buf, "  const u64 %s = a.prep_lde[((%uull * B + jc) << a.log_n) + %s];\n", name.c_str(), nd.a,
-                     nd.b ? "rn" : "r");
+            if (fuse && tile_prep[nd.a] >= 0)
+              snprintf(buf, sizeof buf, "  const u64 %s = L[%d + tid];\n", name.c_str(), tile_prep[nd.a] + (nd.b ? 1 : 0));
+            else
+              snprintf(buf, sizeof buf, "  const u64 %s = a.prep_lde[((%uull * B + jc) << a.log_n) + %s];\n", name.c_str(), nd.a,
+                       nd.b ? "rn" : "r");
             ld << buf;
           }
           return name;
@@ -834,17 +1060,15 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
       return buf;  // computed, recomputed or loaded earlier in this chunk (items)
     };
     bool any_fold = false;
-    int fold_terms = 0;
+    if (!fuse) fold_terms = 0;
     for (const Item& it : items[ci]) {
       const uint32_t id = it.node;
       const DagNode& nd = nodes[id];
       if (it.fold_k == -2) {  // produced by an earlier chunk: from its spill plane(s)
         if (nd.ext)
-          snprintf(buf, sizeof buf, "  const e2 v%u = {a.spill[%dull * a.spill_stride + qb], a.spill[%dull * a.spill_stride + qb]};\n", id,
-                   slot[id], slot[id] + 1);
+          ld << "  const e2 v" << id << " = {" << spill_ref(slot[id]) << ", " << spill_ref(slot[id] + 1) << "};\n";
         else
-          snprintf(buf, sizeof buf, "  const u64 v%u = a.spill[%dull * a.spill_stride + qb];\n", id, slot[id]);
-        ld << buf;
+          ld << "  const u64 v" << id << " = " << spill_ref(slot[id]) << ";\n";
         continue;
       }
       if (it.fold_k >= 0) {
@@ -908,8 +1132,7 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
         }
         body << "  const e2 v" << id << " = " << rhs << ";\n";
         if (spilled[id] && def_chunk[id] == (int32_t)ci)
-          body << "  a.spill[" << slot[id] << "ull * a.spill_stride + qb] = v" << id << ".c0; a.spill[" << slot[id] + 1
-               << "ull * a.spill_stride + qb] = v" << id << ".c1;\n";
+          body << "  " << spill_ref(slot[id]) << " = v" << id << ".c0; " << spill_ref(slot[id] + 1) << " = v" << id << ".c1;\n";
         continue;
       }
       const std::string A = ref(nd.a);
@@ -964,11 +1187,24 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
         body << "  const " << (nd.ext ? "e2" : "u64") << " v" << id << " = " << rhs << ";\n";
       if (spilled[id] && def_chunk[id] == (int32_t)ci) {
         if (nd.ext)
-          body << "  a.spill[" << slot[id] << "ull * a.spill_stride + qb] = v" << id << ".c0; a.spill[" << slot[id] + 1
-               << "ull * a.spill_stride + qb] = v" << id << ".c1;\n";
+          body << "  " << spill_ref(slot[id]) << " = v" << id << ".c0; " << spill_ref(slot[id] + 1) << " = v" << id << ".c1;\n";
         else
-          body << "  a.spill[" << slot[id] << "ull * a.spill_stride + qb] = v" << id << ";\n";
+          body << "  " << spill_ref(slot[id]) << " = v" << id << ";\n";
       }
+    }
+    if (fuse) {  // a region of the fused kernel: its own scope (names may repeat), fenced from the next
+      fuse_need_x |= need_x;
+      fuse_need_fl |= need_fl;
+      fuse_any_fold |= any_fold;
+      fused_regions << "  {  // region " << ci << "\n" << decl.str() << body.str();
+      // MH_JIT_FUSE_FOLDREG=0: the limb accumulators (24 registers) are reduced into `acc` (4) at the end of every region that folds
+      if (!fuse_fold_persist && any_fold) {
+        fused_regions << "#if MH_JIT_FOLD\n  acc = e2_add(acc, e2{fold_value(f0), fold_value(f1)}); f0 = {0, 0, 0, 0, 0, 0}; f1 = {0, 0, 0, 0, 0, 0};\n#endif\n";
+        fold_terms = 0;
+      }
+      fused_regions << "  }\n";
+      if (ci + 1 < n_chunks) fused_regions << "  MH_REGION_FENCE();\n";
+      continue;
     }
     std::ostringstream src;
     src << JIT_PRELUDE;
@@ -999,6 +1235,57 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
     src << "}\n";
     ch.src = src.str();
   }
+  if (fuse) {
+    std::ostringstream src;
+    src << JIT_PRELUDE;
+    // two waves per SIMD: 256 registers per lane (the unified file holds 512), two workgroups of 256 lanes and <= 80 KB of LDS per CU
+    src << "#ifndef MH_JIT_WAVES\n#define MH_JIT_WAVES 2\n#endif\n"
+           "__attribute__((amdgpu_waves_per_eu(MH_JIT_WAVES, MH_JIT_WAVES)))\n"
+           "extern \"C\" __global__ __launch_bounds__(256) void mh_jit_chunk(JitArgs a) {\n";
+    if (lds_words) src << "  __shared__ u64 L[" << lds_words << "];\n";
+    src << "  const u32 tid = threadIdx.x; (void)tid;\n"
+           "  u32 mh_live = 1;\n"
+           "  const u64 qb = blockIdx.x * 256ull + tid;\n"   // the host launches whole workgroups only (n >= 256 rows, blocks of 2^k >= 256 points)
+           "  const u64 q = a.q0 + qb;\n"
+           "  const u64 n = 1ull << a.log_n, D = 1ull << a.log_d, Dl = 1ull << a.log_dl, B = 1ull << a.log_cosets;\n"
+           "  const u64 t = q >> a.log_n, r = q & (n - 1), rn = (r + 1) & (n - 1);\n"
+           "  const u64 jc = t << a.jc_shift;\n"
+           "  (void)D; (void)Dl; (void)B; (void)rn; (void)jc;\n";
+    // stage the tiles: every lane its own row, the last lane also the first row after the tile (rn wraps at the end of the coset)
+    bool any_tile = false;
+    auto stage = [&](const char* mat, size_t plane, int32_t off) {
+      if (off < 0) return;
+      any_tile = true;
+      src << "  { const u64* cp = a." << mat << " + ((" << plane << "ull * B + jc) << a.log_n); L[" << off << " + tid] = cp[r]; if (tid == 255) L[" << off + 256
+          << "] = cp[rn]; }\n";
+    };
+    for (size_t i = 0; i < tile_main.size(); i++) stage("main_lde", i, tile_main[i]);
+    for (size_t i = 0; i < tile_aux.size(); i++) stage("aux_lde", i, tile_aux[i]);
+    for (size_t i = 0; i < tile_prep.size(); i++) stage("prep_lde", i, tile_prep[i]);
+    if (any_tile) src << "  __syncthreads();\n";
+    if (fuse_need_x || fuse_need_fl)
+      src << "  const u64 half = n >> 1;\n"
+             "  const u64 w = (r < half || half == 0) ? a.tw[half ? r : 0] : gl_neg(a.tw[r - half]);\n"
+             "  const u64 x = gl_mul(a.coset_tab[t], w);\n"
+             "  const u64 sel_trans = gl_sub(x, a.wh_inv); (void)sel_trans;\n";
+    if (fuse_need_fl)
+      src << "  const u64 sel_first = gl_mul(a.coset_tab[Dl + t], a.inv_first[q]);\n"
+             "  const u64 sel_last = gl_mul(a.coset_tab[Dl + t], a.inv_last[q]);\n";
+    src << "  e2 acc = {0, 0};\n  fold_acc f0 = {0, 0, 0, 0, 0, 0}, f1 = {0, 0, 0, 0, 0, 0}; (void)f0; (void)f1;\n";
+    src << "  MH_REGION_FENCE();\n" << fused_regions.str();
+    if (fuse_any_fold) src << "#if MH_JIT_FOLD\n  acc = e2_add(acc, e2{fold_value(f0), fold_value(f1)});\n#endif\n";
+    // k_quot_finish (quotient.hip) in the same kernel: * 1/Z_H of the coset, + beta * the previous AIRs' accumulation
+    src << "  e2 qv = e2_mulf(acc, a.coset_tab[2 * Dl + t]);\n"
+           "  if (a.acc_in) {\n"
+           "    const u64 rp = r & ((1ull << a.log_n_prev) - 1);\n"
+           "    const e2 old = {a.acc_in[((2 * t) << a.log_n_prev) + rp], a.acc_in[((2 * t + 1) << a.log_n_prev) + rp]};\n"
+           "    qv = e2_add(e2_mul(old, e2{a.beta0, a.beta1}), qv);\n"
+           "  }\n"
+           "  a.acc[((2 * t) << a.log_n) + r] = qv.c0;\n  a.acc[((2 * t + 1) << a.log_n) + r] = qv.c1;\n}\n";
+    chunks.clear();
+    chunks.push_back({0, seq.size(), src.str(), {}, {}});
+  }
+  const size_t n_main_kernels = chunks.size();  // chunk kernels, or the one fused kernel
   // ---- the uniform kernel: every live uniform gate, in node order (operands precede their gate), canonical arithmetic, one lane ----
   if (n_uni) {
     std::ostringstream src;
@@ -1112,7 +1399,17 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
   // 264-register chunks took the quotient from 13.4 to 18.7 ms).  Such a chunk is cut in two at the
   // position of its middle third with the fewest crossing values, and everything is generated again (at most three times;
   // $MH_JIT_SPLIT=0: keep what the first cut gave). ----
-  if (depth < 3 && env_int("MH_JIT_SPLIT", 1)) {
+  if (fuse) {
+    // The fused kernel must fit 256 registers without scratch memory (two waves per SIMD).  When it does not, the bound on the words a
+    // region holds alive is lowered by an eighth and the regions above it are cut again.
+    unsigned scratch = 0, vg = 0;
+    const bool known = code_object_info(chunks[0].code, &scratch, &vg);
+    if (env_int("MH_JIT_STATS", 0) && known) fprintf(stderr, "[mh jit]   fused kernel: %u VGPRs, %u bytes of scratch, %zu regions\n", vg, scratch, n_regions);
+    // (a few dwords of scratch are tolerated: the scheduler fills the 256 registers it is given and the allocator then misses by a
+    // handful of values -- 18 spilled dwords in the core AIR's 50 k instructions; cutting regions to remove them costs recomputation)
+    if (known && ((int)scratch > env_int("MH_JIT_FUSE_SCRATCH", 128) || (int)vg > env_int("MH_JIT_FUSE_MAXREGS", 256)) && press_max * 7 / 8 >= env_int("MH_JIT_FUSE_PRESS_MIN", 56) && env_int("MH_JIT_SPLIT", 1))
+      return jit_program_build_cuts(ctx, ir, &region_ends, 0, press_max * 7 / 8);  // the same regions, those above the lower bound cut again
+  } else if (depth < 3 && env_int("MH_JIT_SPLIT", 1)) {
     // the unified VGPR + AGPR budget of a chunk.  256 would still be two waves per SIMD, but a chunk AT the limit is fragile (one box of
     // the pool ran the core AIR's 256-register chunk five times slower than the others: 3.5 ms instead of 0.65 per 2^22 points) and
     // cutting it costs nothing: core AIR 256 / 248 / 200 / 168 -> 13.46 / 13.27 / 13.17 / 13.97 ms (round 5)
@@ -1123,7 +1420,7 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
     const int soft_regs = env_int("MH_JIT_SOFTREGS", 168), soft_cross = env_int("MH_JIT_SOFTCROSS", 32);
     std::vector<size_t> cuts;
     bool any = false;
-    for (size_t ci = 0; ci < n_chunks; ci++) {
+    for (size_t ci = 0; ci < n_main_kernels; ci++) {
       unsigned scratch = 0, vg = 0;
       const size_t lo = chunks[ci].ev_lo, hi = chunks[ci].ev_hi;
       if (code_object_info(chunks[ci].code, &scratch, &vg) && (scratch > 0 || (int)vg > std::min(soft_regs, max_regs)) && hi - lo >= 8) {
@@ -1143,7 +1440,7 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
       }
       cuts.push_back(hi);
     }
-    if (any) return jit_program_build_cuts(ctx, ir, &cuts, depth + 1);
+    if (any) return jit_program_build_cuts(ctx, ir, &cuts, depth + 1, press_max);
   }
   if (env_int("MH_JIT_STATS", 0))
     for (size_t ci = 0; ci < n_kernels; ci++) {
@@ -1156,8 +1453,10 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
   }
   std::unique_ptr<JitProgram> prog(new JitProgram());
   prog->ctx = ctx;
-  prog->n_spill = n_spill;
+  prog->n_spill = fuse ? n_spill_hbm : n_spill;
   prog->n_uni = n_uni;
+  prog->fused = fuse;
+  prog->n_regions = n_regions;
   try {
     for (size_t ci = 0; ci < n_kernels; ci++) {
       hipModule_t m = nullptr;
@@ -1184,7 +1483,7 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
         HIP_CHECK(e);
       }
       prog->modules.push_back(m);
-      if (ci < n_chunks) prog->fns.push_back(f);
+      if (ci < n_main_kernels) prog->fns.push_back(f);
       else prog->fn_uni = f;
     }
   } catch (...) {
@@ -1198,9 +1497,10 @@ void jit_quotient_run(mh_ctx* c, const JitProgram* p, JitArgs a, size_t total) {
   // Points are swept in blocks so that the spill planes stay bounded (n_spill * 32 MB) for any trace height.  Cache-sized blocks do
   // not pay: the cells and planes of a 2^17 / 2^18-point block fit the 256 MB Infinity Cache, yet the core AIR's quotient takes
   // 19.5 / 16.8 ms against 15.6 / 14.5 / 14.3 / 14.2 ms with 2^19 / 2^21 / 2^22 / 2^23-point blocks (round 5; tails of half-filled
-  // launches cost more than the re-reads save).
-  const size_t block = std::min(total, (size_t)1 << std::max(10, env_int("MH_JIT_BLOCK_LOG", 22)));
-  DevBuf spill(std::max<size_t>(1, p->n_spill) * block * 8);
+  // launches cost more than the re-reads save).  A fused program whose crossing values all sit in LDS has no planes: one launch.
+  MH_REQUIRE(!p->fused || (a.log_n >= 8 && total % 256 == 0), "internal: fused constraint kernel on a trace below 2^8 rows");
+  const size_t block = p->fused && p->n_spill == 0 ? total : std::min(total, (size_t)1 << std::max(10, env_int("MH_JIT_BLOCK_LOG", 22)));
+  DevBuf spill(std::max<size_t>(1, p->n_spill) * (p->n_spill ? block : 1) * 8);
   a.spill = spill.u();
   a.spill_stride = block;
   DevBuf uni(std::max<size_t>(1, p->n_uni) * 8);

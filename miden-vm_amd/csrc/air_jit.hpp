@@ -32,17 +32,22 @@ struct JitArgs {
   const u64* aux_values;
   const u64* alpha_pows;
   const u64* uni;       // values of the DAG's uniform gates (no trace cell in their cone), filled once per call by the program's uniform kernel
+  const u64* acc_in;    // fused kernels apply k_quot_finish themselves: the previous AIRs' accumulation (planes [2 * Dl][n_prev]) or null
   u64 wh_inv;
   u64 q0, q_count;      // this launch covers points q0 .. q0 + q_count - 1
   u64 spill_stride;
-  int log_n, log_cosets, log_d, log_dl, jc_shift;
+  u64 beta0, beta1;     // ... and the batching challenge of that accumulation
+  int log_n, log_cosets, log_d, log_dl, jc_shift, log_n_prev;
   u32 t0, periodic_rows;
 };
-static_assert(sizeof(JitArgs) == 15 * 8 + 4 * 8 + 7 * 4 + 4, "JitArgs layout is mirrored in the generated source");
+static_assert(sizeof(JitArgs) == 16 * 8 + 6 * 8 + 6 * 4 + 2 * 4, "JitArgs layout is mirrored in the generated source");
 
 // Runs every chunk over all `total` points of the quotient coset(s); a.q0 / q_count / spill are filled here.
 void jit_quotient_run(mh_ctx* c, const JitProgram* p, JitArgs a, size_t total);
 size_t jit_program_chunks(const JitProgram* p);
+// A fused program (one kernel for the whole DAG, MH_JIT_FUSE) stages cells per workgroup of 256 consecutive rows: it needs traces of
+// at least 2^8 rows (below that the interpreter runs) and applies k_quot_finish itself (JitArgs::acc_in / beta / log_n_prev).
+bool jit_program_fused(const JitProgram* p);
 int jit_program_max_vgprs(const JitProgram* p);
 
 // mh_jit_precompile: while set (per thread), jit_program_build compiles the chunks into the cache directory and returns null without

@@ -103,17 +103,25 @@ int mh_ctx_trim(mh_ctx* c) {
   MH_REQUIRE(c, "null ctx");
   HIP_CHECK(hipSetDevice(c->device));
   c->sync();
+  // the full [z][pos] coset-scale tables of the LDE (ntt.hip coset_scale_full: 8 N bytes per output coset -- 64 MB per trace height at
+  // blowup 8, 1 GB at 2^24 rows) are rebuilt in one launch when next needed; a service that proves varied heights would otherwise
+  // accumulate gigabytes of them.  The small twiddle / coset tables stay.  They go FIRST: their buffers were taken from this pool
+  // inside a prove call, so releasing them hands them to the pool's free list, and only the trim below returns them to the driver
+  // (the order mh_ctx_destroy uses).
+  for (auto it = c->tables.begin(); it != c->tables.end();) {
+    if (it->first.rfind("cosetfull:", 0) == 0) {
+      c->table_index.erase(it->first);
+      it = c->tables.erase(it);
+    } else {
+      ++it;
+    }
+  }
   c->pool.trim();
   // page-locked aux scratch (host_take / host_give) is cached per size class: a long-lived context proving varied shapes would keep
   // every class for ever
   if (c->copy_stream) HIP_CHECK(hipStreamSynchronize(c->copy_stream));
   for (auto& b : c->host_pool) (void)hipHostFree(b.first);
   c->host_pool.clear();
-  // the full [z][pos] coset-scale tables of the LDE (ntt.hip coset_scale_full: 8 N bytes per output coset -- 64 MB per trace height at
-  // blowup 8, 1 GB at 2^24 rows) are rebuilt in one launch when next needed; a service that proves varied heights would otherwise
-  // accumulate gigabytes of them.  The small twiddle / coset tables stay.
-  for (auto it = c->tables.begin(); it != c->tables.end();)
-    it = it->first.rfind("cosetfull:", 0) == 0 ? c->tables.erase(it) : std::next(it);
   MH_CATCH
 }
 

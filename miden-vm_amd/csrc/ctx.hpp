@@ -22,6 +22,7 @@ struct MhError : std::runtime_error {
 #define MH_ERR_HIP 2
 #define MH_ERR_OOM 3
 #define MH_ERR_INTERNAL 4
+#define MH_ERR_COMM 5
 
 #define HIP_CHECK(expr)                                                                          \
   do {                                                                                           \

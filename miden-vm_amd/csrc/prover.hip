@@ -17,7 +17,9 @@
 #include "kernels.hpp"
 #include "poseidon2.cuh"
 #include <algorithm>
+#include <chrono>
 #include <cstring>
+#include <thread>
 #include <memory>
 #include <numeric>
 
@@ -133,6 +135,37 @@ mh_trace* trace_zeros(mh_ctx* c, int log_n, size_t width) {
 // ---- collectives of a sharded proof ------------------------------------------------------------------
 // Host-synchronous communicators (callbacks of a host layer) get a drained stream and must finish before returning;
 // the in-library RCCL communicator (comm_rccl.cpp, stream_ordered) enqueues on c->stream and needs neither.
+// A collective whose peer never arrives (a rank that died, a fabric link that does not come up) would leave this rank in
+// hipStreamSynchronize for ever: the first multi-GPU run of a deployment must end in an error code, not in a hang.  After a
+// stream-ordered collective has been enqueued the host waits for it with a bound ($MH_COMM_TIMEOUT_S seconds, default 120, 0 = no
+// watchdog: fully asynchronous as before); the transcript needs the roots a few microseconds later anyway, so the wait costs nothing
+// that was not already paid.  Host-synchronous communicators (callbacks) return when done and bound themselves.
+static void comm_bounded_wait(mh_ctx* c, const char* what) {
+  static const double limit_s = [] {
+    const char* v = getenv("MH_COMM_TIMEOUT_S");
+    return v && *v ? atof(v) : 120.0;
+  }();
+  if (limit_s <= 0) return;
+  hipEvent_t ev;
+  HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, c->stream);
+  const auto t0 = std::chrono::steady_clock::now();
+  long spins = 0;
+  while (e == hipSuccess) {
+    e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) break;
+    e = hipSuccess;
+    if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) {
+      (void)hipEventDestroy(ev);
+      char msg[160];
+      snprintf(msg, sizeof msg, "collective %s did not complete within %.0f s (MH_COMM_TIMEOUT_S): a peer rank is missing or the fabric is down", what, limit_s);
+      throw MhError(MH_ERR_COMM, msg);
+    }
+  }
+  (void)hipEventDestroy(ev);
+  HIP_CHECK(e);
+}
 void Dist::all_to_all(mh_ctx* c, const void* send, void* recv, size_t bytes_per_peer) const {
   if (!on()) {
     HIP_CHECK(hipMemcpyAsync(recv, send, bytes_per_peer, hipMemcpyDeviceToDevice, c->stream));
@@ -141,6 +174,7 @@ void Dist::all_to_all(mh_ctx* c, const void* send, void* recv, size_t bytes_per_
   if (!comm->stream_ordered) c->sync();
   ProfScope ps(c, "comm_all_to_all", (double)bytes_per_peer * world);
   MH_REQUIRE(comm->all_to_all(comm->user, send, recv, bytes_per_peer) == 0, "all_to_all failed: " + c->err);
+  if (comm->stream_ordered) comm_bounded_wait(c, "all_to_all");
 }
 void Dist::all_gather(mh_ctx* c, const void* send, void* recv, size_t bytes_per_rank) const {
   if (!on()) {
@@ -150,12 +184,14 @@ void Dist::all_gather(mh_ctx* c, const void* send, void* recv, size_t bytes_per_
   if (!comm->stream_ordered) c->sync();
   ProfScope ps(c, "comm_all_gather", (double)bytes_per_rank * world);
   MH_REQUIRE(comm->all_gather(comm->user, send, recv, bytes_per_rank) == 0, "all_gather failed: " + c->err);
+  if (comm->stream_ordered) comm_bounded_wait(c, "all_gather");
 }
 void Dist::all_reduce_sum(mh_ctx* c, u64* buf, size_t n) const {
   if (!on()) return;
   if (!comm->stream_ordered) c->sync();
   ProfScope ps(c, "comm_all_reduce", (double)n * 8);
   MH_REQUIRE(comm->all_reduce_sum_u64(comm->user, buf, n) == 0, "all_reduce failed: " + c->err);
+  if (comm->stream_ordered) comm_bounded_wait(c, "all_reduce");
 }
 
 // LDE of one uploaded trace into coset-major layout on the canonical shift of its own LDE order;

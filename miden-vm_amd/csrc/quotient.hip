@@ -297,7 +297,8 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
     MH_LAUNCH(k_selector_inverses, dim3((unsigned)((n * D + 1023) / 1024)), dim3(256), 0, c->stream, tw, dblob.u() + o_tab,
                        log_n, log_dl, wh_inv, inv_first.u(), inv_last.u());
   }
-  if (air->jit) {  // compiled chunks: large constraint systems
+  // compiled kernels: large constraint systems (a fused program stages 256-row tiles: traces below 2^8 rows take the interpreter)
+  if (air->jit && !(jit_program_fused(air->jit) && log_n < 8)) {
     JitArgs j{};
     j.main_lde = main.lde.u(); j.aux_lde = aux.lde.u();
     j.prep_lde = prep ? prep->lde.u() : nullptr;
@@ -312,9 +313,11 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
     j.jc_shift = log_blowup - log_d;
     j.t0 = (u32)t0;
     ProfScope ps(c, "quotient_eval", (double)n * D * (8.0 * air->touched_base_columns + 16.0));
+    j.acc_in = acc_in; j.log_n_prev = log_n_prev; j.beta0 = beta.c0; j.beta1 = beta.c1;
     jit_quotient_run(c, air->jit, j, n * D);
-    MH_LAUNCH(k_quot_finish, dim3((unsigned)((n * D + 255) / 256)), dim3(256), 0, c->stream, acc_out, dblob.u() + o_tab, log_n,
-                       log_dl, acc_in, log_n_prev, beta);
+    if (!jit_program_fused(air->jit))  // a fused program has applied 1/Z_H and the beta accumulation itself
+      MH_LAUNCH(k_quot_finish, dim3((unsigned)((n * D + 255) / 256)), dim3(256), 0, c->stream, acc_out, dblob.u() + o_tab, log_n,
+                         log_dl, acc_in, log_n_prev, beta);
     HIP_CHECK(hipStreamSynchronize(c->stream));
     return;
   }

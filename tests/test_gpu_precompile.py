@@ -13,6 +13,7 @@ import pytest
 import oracle_binding as ob
 from __graft_entry__ import load_package
 from miden_vm_amd import dag, protocol, precompile_airs as PA
+from miden_vm_amd.testing import precompile_trace as PT
 from test_gpu_prove import FAST
 
 pytestmark = pytest.mark.gpu
@@ -34,13 +35,13 @@ def host_aux(lookup, main, randomness, preprocessed=None):
 
 def session(n_ops, log_req, seed=5):
     rng = np.random.default_rng(seed)
-    ledger = PA.BytePairLutRequires()
-    reqs = PA.keccak_like_requests(rng, n_ops, ledger)
+    ledger = PT.BytePairLutRequires()
+    reqs = PT.keccak_like_requests(rng, n_ops, ledger)
     while len(reqs) < (1 << log_req):  # fill the requirer to its last row (which fires)
         ledger.require_range16(0xffff)
         reqs.append((PA.BUS_RANGE16, 1, [0xffff]))
     pairs = [PA.requirer_air(host_aux), PA.byte_pair_lut_air(host_aux), PA.ec_groups_air(host_aux)]
-    traces = [PA.requirer_trace(reqs, log_req), PA.byte_pair_lut_trace(ledger), PA.ec_groups_trace()]
+    traces = [PT.requirer_trace(reqs, log_req), PT.byte_pair_lut_trace(ledger), PT.ec_groups_trace()]
     return [p[0] for p in pairs], [p[1] for p in pairs], traces
 
 
@@ -124,11 +125,11 @@ def test_precompile_session_production_params_keccak_sized_load(ctx):
 def keccak_session(n_perms, seed=11):
     rng = np.random.default_rng(seed)
     states = [[0] * 25] + [[int(x) for x in rng.integers(0, 1 << 63, 25)] for _ in range(n_perms - 1)]
-    ledger = PA.BytePairLutRequires()
+    ledger = PT.BytePairLutRequires()
     kr = PA.keccak_round_air(host_aux)
-    trace, mem = PA.keccak_round_trace(states, ledger)
+    trace, mem = PT.keccak_round_trace(states, ledger)
     pairs = [kr, PA.byte_pair_lut_air(host_aux), PA.ec_groups_air(host_aux), PA.requirer_air(host_aux)]
-    traces = [trace, PA.byte_pair_lut_trace(ledger), PA.ec_groups_trace(), PA.requirer_trace(PA.sponge_side_requests(states, mem))]
+    traces = [trace, PT.byte_pair_lut_trace(ledger), PT.ec_groups_trace(), PT.requirer_trace(PT.sponge_side_requests(states, mem))]
     return [p[0] for p in pairs], [p[1] for p in pairs], traces
 
 
@@ -207,7 +208,7 @@ def test_keccak_session_from_device_built_traces(ctx):
         mem = np.zeros((7, 25 + 3200), dtype=np.uint64)
         assert kt.kt_download(mem.ctypes.data_as(C.c_void_p), mem_dev, C.c_size_t(mem.size)) == 0
         for n in range(7):
-            assert PA.keccak_round_outputs(mem, n) == PA.keccak_f_reference([int(x) for x in states[n]])
+            assert PT.keccak_round_outputs(mem, n) == PT.keccak_f_reference([int(x) for x in states[n]])
         got_host, root, st, pre = device_prove(ctx, airs_, lookups, traces, FAST)
         dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
         raw = ctx.upload_trace(airs_[1].preprocessed)
@@ -244,13 +245,13 @@ def chunk_session(n_invocations, max_len, seed=21):
     """[ChunkAir, the other sides of its three buses (Memory64 consumes of the hasher, Poseidon2In provides of the P2 chiplet, ChunkChain
     consumes of the node chiplet), EcGroupsAir]: no preprocessed AIR in this statement."""
     rng = np.random.default_rng(seed)
-    req = PA.ChunkRequires()
+    req = PT.ChunkRequires()
     inputs = [bytes(rng.integers(0, 256, int(rng.integers(0, max_len + 1)), dtype=np.uint8)) for _ in range(n_invocations)]
     inputs.append(inputs[0])                                            # a repeated input: its absorption chain is reused
     for data in inputs:
         req.require(data)
     pairs = [PA.chunk_air(host_aux), PA.requirer_air(host_aux, payload=6), PA.ec_groups_air(host_aux)]
-    traces = [PA.chunk_trace(req), PA.requirer_trace(PA.chunk_side_requests(req), payload=6), PA.ec_groups_trace()]
+    traces = [PT.chunk_trace(req), PT.requirer_trace(PT.chunk_side_requests(req), payload=6), PT.ec_groups_trace()]
     return [p[0] for p in pairs], [p[1] for p in pairs], traces
 
 
@@ -308,17 +309,17 @@ def chunk_poseidon2_session(n_invocations, max_len, seed=22, permute_batch=None)
     """[ChunkAir, Poseidon2Air (32 columns: state, witnessed S-boxes, thirteen cube registers; sixteen periodic columns; absorption
     chains), the remaining sides (Memory64 and ChunkChain consumes, the digests' readers on Poseidon2Out), EcGroupsAir]."""
     rng = np.random.default_rng(seed)
-    ledger = PA.Poseidon2Requires()
-    req = PA.ChunkRequires(ledger)
+    ledger = PT.Poseidon2Requires()
+    req = PT.ChunkRequires(ledger)
     inputs = [bytes(rng.integers(0, 256, int(rng.integers(0, max_len + 1)), dtype=np.uint8)) for _ in range(n_invocations)]
     inputs.append(inputs[0])
     for data in inputs:
         req.require(data)
         ledger.require_digest(req.last)
-    p2_main, outs = PA.poseidon2_chiplet_trace(ledger, permute_batch=permute_batch)
-    others = PA.chunk_side_requests(req, poseidon2_chiplet=True) + PA.poseidon2_out_requests(ledger, outs)
+    p2_main, outs = PT.poseidon2_chiplet_trace(ledger, permute_batch=permute_batch)
+    others = PT.chunk_side_requests(req, poseidon2_chiplet=True) + PT.poseidon2_out_requests(ledger, outs)
     pairs = [PA.chunk_air(host_aux), PA.poseidon2_chiplet_air(host_aux), PA.requirer_air(host_aux, payload=6), PA.ec_groups_air(host_aux)]
-    traces = [PA.chunk_trace(req), p2_main, PA.requirer_trace(others, payload=6), PA.ec_groups_trace()]
+    traces = [PT.chunk_trace(req), p2_main, PT.requirer_trace(others, payload=6), PT.ec_groups_trace()]
     return [p[0] for p in pairs], [p[1] for p in pairs], traces
 
 
@@ -363,21 +364,21 @@ def test_chunk_poseidon2_session_production_params_chains_stepped_on_the_device(
 def keccak_hash_session(inputs):
     """[KeccakRoundAir, BytePairLutAir, KeccakSpongeAir (67 columns, 24 flattened LogUp columns, 11 periodic), ChunkAir, Poseidon2Air, the
     node / transcript side of the buses, EcGroupsAir]."""
-    ledger, p2 = PA.BytePairLutRequires(), PA.Poseidon2Requires()
-    chunks = PA.ChunkRequires(p2)
-    sp = PA.SpongeRequires(chunks, ledger)
+    ledger, p2 = PT.BytePairLutRequires(), PT.Poseidon2Requires()
+    chunks = PT.ChunkRequires(p2)
+    sp = PT.SpongeRequires(chunks, ledger)
     digests = []
     for data in inputs:
         out = sp.require(data)
         p2.require_digest(out["chunk_absorption"])
         digests.append(out["keccak_digest"])
-    kr_trace, mem = PA.keccak_round_trace(sp.perm_inputs, ledger)
-    p2_main, outs = PA.poseidon2_chiplet_trace(p2)
-    others = PA.keccak_hash_side_requests(sp, mem) + PA.poseidon2_out_requests(p2, outs)
+    kr_trace, mem = PT.keccak_round_trace(sp.perm_inputs, ledger)
+    p2_main, outs = PT.poseidon2_chiplet_trace(p2)
+    others = PT.keccak_hash_side_requests(sp, mem) + PT.poseidon2_out_requests(p2, outs)
     pairs = [PA.keccak_round_air(host_aux), PA.byte_pair_lut_air(host_aux), PA.keccak_sponge_air(host_aux), PA.chunk_air(host_aux),
              PA.poseidon2_chiplet_air(host_aux), PA.requirer_air(host_aux, payload=6), PA.ec_groups_air(host_aux)]
-    traces = [kr_trace, PA.byte_pair_lut_trace(ledger), PA.keccak_sponge_trace(sp), PA.chunk_trace(chunks), p2_main,
-              PA.requirer_trace(others, payload=6), PA.ec_groups_trace()]
+    traces = [kr_trace, PT.byte_pair_lut_trace(ledger), PT.keccak_sponge_trace(sp), PT.chunk_trace(chunks), p2_main,
+              PT.requirer_trace(others, payload=6), PT.ec_groups_trace()]
     return [p[0] for p in pairs], [p[1] for p in pairs], traces, digests
 
 
@@ -413,17 +414,17 @@ def keccak_node_session(inputs, permute_batch=None):
     """The same with the node chiplet in place of most of the stand-in, in the shape and ORDER the reference's session runs
     (`ChipletAir::all()`, session/prove.rs:111-126): ChunkNodeAir (the chunk and the Keccak node chiplets on one row range, 42 columns, 14
     LogUp columns), Poseidon2Air, KeccakRoundAir, BytePairLutAir, KeccakSpongeAir, [the transcript's Binding readers], EcGroupsAir."""
-    ledger, p2 = PA.BytePairLutRequires(), PA.Poseidon2Requires()
-    chunks = PA.ChunkRequires(p2)
-    sp = PA.SpongeRequires(chunks, ledger)
-    nd = PA.KeccakNodeRequires(sp)
+    ledger, p2 = PT.BytePairLutRequires(), PT.Poseidon2Requires()
+    chunks = PT.ChunkRequires(p2)
+    sp = PT.SpongeRequires(chunks, ledger)
+    nd = PT.KeccakNodeRequires(sp)
     outs = [nd.require(d) for d in inputs]
-    kr_trace, mem = PA.keccak_round_trace(sp.perm_inputs, ledger)
-    p2_main, _ = PA.poseidon2_chiplet_trace(p2, permute_batch=permute_batch)
+    kr_trace, mem = PT.keccak_round_trace(sp.perm_inputs, ledger)
+    p2_main, _ = PT.poseidon2_chiplet_trace(p2, permute_batch=permute_batch)
     pairs = [PA.chunk_node_air(host_aux), PA.poseidon2_chiplet_air(host_aux), PA.keccak_round_air(host_aux), PA.byte_pair_lut_air(host_aux),
              PA.keccak_sponge_air(host_aux), PA.requirer_air(host_aux, payload=7), PA.ec_groups_air(host_aux)]
-    traces = [PA.chunk_node_trace(chunks, nd), p2_main, kr_trace, PA.byte_pair_lut_trace(ledger), PA.keccak_sponge_trace(sp),
-              PA.requirer_trace(PA.binding_requests(nd), payload=7), PA.ec_groups_trace()]
+    traces = [PT.chunk_node_trace(chunks, nd), p2_main, kr_trace, PT.byte_pair_lut_trace(ledger), PT.keccak_sponge_trace(sp),
+              PT.requirer_trace(PT.binding_requests(nd), payload=7), PT.ec_groups_trace()]
     return [p[0] for p in pairs], [p[1] for p in pairs], traces, outs
 
 
@@ -467,9 +468,9 @@ def uint_add_session(n_ops, seed=41):
     import random
     rng = random.Random(seed)
     bound = rng.getrandbits(255) | (1 << 254) | 1
-    store = PA.UintStore()
+    store = PT.UintStore()
     fp = store.pin_modulus(1, bound)
-    add = PA.UintAddRequires()
+    add = PT.UintAddRequires()
     vals = [rng.randrange(1, bound + 1) for _ in range(n_ops + 1)]
     ptrs = [store.intern(v, fp) for v in vals]
     for i in range(n_ops):
@@ -482,10 +483,10 @@ def uint_add_session(n_ops, seed=41):
             add.record_nz(ptrs[i], ptrs[i + 1], store.intern((vals[i] + vals[i + 1]) % (bound + 1), fp), fp, 1)
         else:
             add.record(ptrs[i], ptrs[i + 1], store.intern((vals[i] + vals[i + 1]) % (bound + 1), fp), fp, 1 + i % 3)
-    main = PA.uint_add_trace(add, store)
-    others = store.uint_val_requests() + PA.uint_add_consumer_requests(add)
+    main = PT.uint_add_trace(add, store)
+    others = store.uint_val_requests() + PT.uint_add_consumer_requests(add)
     pairs = [PA.uint_add_air(host_aux), PA.requirer_air(host_aux, payload=10), PA.ec_groups_air(host_aux)]
-    traces = [main, PA.requirer_trace(others, payload=10), PA.ec_groups_trace()]
+    traces = [main, PT.requirer_trace(others, payload=10), PT.ec_groups_trace()]
     return [p[0] for p in pairs], [p[1] for p in pairs], traces
 
 
@@ -525,7 +526,7 @@ def test_uint_add_session_production_params(ctx):
 def ec_store_session(n_points):
     """[EcPointStoreAir (14 columns, the membership trio as three degree-3 consumes), EcGroupsAir, the foreign sides]: the EcGroup bus
     closes between the two real AIRs."""
-    pairs, traces, _ = PA.ec_store_session(n_points, host_aux)
+    pairs, traces, _ = PT.ec_store_session(n_points, host_aux)
     return [p[0] for p in pairs], [p[1] for p in pairs], traces
 
 
@@ -566,7 +567,7 @@ def ec_add_session(scalars):
     """The reference's arithmetic + EC stack (tests/ec_add.rs) in its order, every chiplet real: [BytePairLutAir (preprocessed),
     UintStoreMulAir (44 columns, 26 LogUp columns + 3 extension-field registers), UintAddAir, EcGroupsAir, EcPointStoreAir, EcGroupAddAir
     (21 columns, twelve flattened LogUp columns on seven buses)] + the readers of the proven additions."""
-    pairs, traces, _ = PA.ec_add_session(scalars, host_aux)
+    pairs, traces, _ = PT.ec_add_session(scalars, host_aux)
     return [p[0] for p in pairs], [p[1] for p in pairs], traces
 
 
@@ -619,7 +620,7 @@ def test_uint_arith_session_production_params(ctx):
     """4 000 proven multiply-accumulates and as many modular additions over the secp256k1 base field, the store, the multiplier and the
     adder real, over the fixed environment; production parameters: device aux == oracle on the 58-word rows, verify through both verifiers."""
     pkg = load_package()
-    pairs, traces, _ = PA.uint_arith_session(4000, host_aux=host_aux)
+    pairs, traces, _ = PT.uint_arith_session(4000, host_aux=host_aux)
     airs_, lookups = [p[0] for p in pairs], [p[1] for p in pairs]
     prm = dict(protocol.PROD_PARAMS)
     got, root, st, pre = device_prove(ctx, airs_, lookups, traces, prm)
@@ -641,7 +642,7 @@ def test_ec_msm_session_device_proof_equals_oracle(ctx, jit, monkeypatch):
     registers, the adder, the EC stores, the group law, `EcMsmAir` with its variable-length blocks and merge walks)."""
     pkg = load_package()
     monkeypatch.setenv("MH_JIT", jit)
-    pairs, traces, _ = PA.ec_msm_session([(0xb5, 1), (0x4d, 3)], host_aux)
+    pairs, traces, _ = PT.ec_msm_session([(0xb5, 1), (0x4d, 3)], host_aux)
     airs_, lookups = [p[0] for p in pairs], [p[1] for p in pairs]
     ext = PA.external_assertions(pkg, fixed_uints=True)
     exp = ob.prove(airs_, traces, ROOT, FAST, init_state=protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST))
@@ -665,7 +666,7 @@ def test_ec_msm_session_production_params(ctx):
     import random
     pkg = load_package()
     rng = random.Random(11)
-    pairs, traces, _ = PA.ec_msm_session([(rng.getrandbits(64) | 1 << 63, m) for m in (1, 2, 5, 9)], host_aux)
+    pairs, traces, _ = PT.ec_msm_session([(rng.getrandbits(64) | 1 << 63, m) for m in (1, 2, 5, 9)], host_aux)
     airs_, lookups = [p[0] for p in pairs], [p[1] for p in pairs]
     ext = PA.external_assertions(pkg, fixed_uints=True)
     prm = dict(protocol.PROD_PARAMS)

@@ -265,7 +265,12 @@ GEN_SWITCHES = [{}, {"MH_JIT_RECOMP": "0"}, {"MH_JIT_RECOMP": "1000", "MH_JIT_CH
                 {"MH_JIT_MAXREGS": "96"}, {"MH_JIT_MAXREGS": "64", "MH_JIT_CHUNK": "500"}, {"MH_JIT_SPLIT": "0", "MH_JIT_CHUNK": "500"},
                 {"MH_JIT_CUTK": "60"},
                 # the carry-select chain breaker (opaque values every 4 one-sided lazy additions / never)
-                {"MH_JIT_LZCHAIN": "4"}, {"MH_JIT_LZCHAIN": "0"}]
+                {"MH_JIT_LZCHAIN": "4"}, {"MH_JIT_LZCHAIN": "0"},
+                # round 6: the base-gates-only asm product of round 4-5 next to the merged-statement default; ONE kernel for the whole DAG
+                # (regions, LDS slots and tiles, k_quot_finish inside), without LDS (HBM planes, cells from HBM), with small regions
+                {"MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=2"}, {"MH_JIT_FUSE": "1"}, {"MH_JIT_FUSE": "1", "MH_JIT_LDS_KB": "0"},
+                {"MH_JIT_FUSE": "1", "MH_JIT_LDS_KB": "80", "MH_JIT_CHUNK": "100"},
+                {"MH_JIT_FUSE": "1", "MH_JIT_FUSE_FOLDREG": "0", "MH_JIT_FUSE_PRESS": "40"}]
 
 
 @pytest.mark.parametrize("env", GEN_SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "defaults")

@@ -218,7 +218,10 @@ JIT_SWITCHES = [{}, {"MH_JIT_RECOMP": "0"}, {"MH_JIT_RECOMP": "1000", "MH_JIT_CH
                 {"MH_JIT_DOT": "2"}, {"MH_JIT_FLAGS": "-DMH_JIT_FOLD=0"}, {"MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=0"},
                 {"MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=1"}, {"MH_JIT_FLAGS": "-DMH_JIT_WAVES=3"},
                 {"MH_JIT_LAZYVAL": "0"}, {"MH_JIT_UNI": "0"}, {"MH_JIT_CUTWIN": "0"}, {"MH_JIT_CUTK": "60"}, {"MH_JIT_MAXREGS": "96"}, {"MH_JIT_SPLIT": "0"},
-                {"MH_JIT_FLAGS": "-DMH_JIT_FOLDV=0"}, {"MH_JIT_LZCHAIN": "4"}, {"MH_JIT_LZCHAIN": "0"}]
+                {"MH_JIT_FLAGS": "-DMH_JIT_FOLDV=0"}, {"MH_JIT_LZCHAIN": "4"}, {"MH_JIT_LZCHAIN": "0"},
+                # round 6: the former product forms next to the merged-statement default (3), one kernel for the whole DAG
+                {"MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=2"}, {"MH_JIT_FUSE": "1"}, {"MH_JIT_FUSE": "1", "MH_JIT_LDS_KB": "0"},
+                {"MH_JIT_FUSE": "1", "MH_JIT_FUSE_FOLDREG": "0", "MH_JIT_FUSE_PRESS": "40"}]
 
 
 @pytest.mark.parametrize("env", JIT_SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "defaults")

@@ -162,18 +162,19 @@ def test_fast_build_gives_the_same_whole_proofs():
     from __graft_entry__ import load_package
     load_package()
     from miden_vm_amd import dag, protocol, precompile_airs as PA
+    from miden_vm_amd.testing import precompile_trace as PT
     fast = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=5, query_pow_bits=3)
 
     def host_aux(lookup, main, randomness, preprocessed=None):
         return ob.lookup_build_aux(lookup, main, randomness, preprocessed)
     rng = np.random.default_rng(5)
-    ledger = PA.BytePairLutRequires()
-    reqs = PA.keccak_like_requests(rng, 5, ledger)
+    ledger = PT.BytePairLutRequires()
+    reqs = PT.keccak_like_requests(rng, 5, ledger)
     pairs = [PA.requirer_air(host_aux), PA.byte_pair_lut_air(host_aux), PA.ec_groups_air(host_aux)]
     t_fib, pub_fib = A.fib_trace(7)
     cases = [([dag.dummy_miden_air(51, 8)], [A.dummy_trace(8, 51)], [], dict(protocol.PROD_PARAMS)),
              ([A.fib_air()], [t_fib], pub_fib, fast),
-             ([p[0] for p in pairs], [PA.requirer_trace(reqs), PA.byte_pair_lut_trace(ledger), PA.ec_groups_trace()], [71, 72, 73, 74], fast)]
+             ([p[0] for p in pairs], [PT.requirer_trace(reqs), PT.byte_pair_lut_trace(ledger), PT.ec_groups_trace()], [71, 72, 73, 74], fast)]
     for airs_, traces, pub, prm in cases:
         ref = ob.prove(airs_, traces, pub, prm)
         ob.use_fast_library(True)

@@ -14,6 +14,7 @@ from __graft_entry__ import load_package
 
 pkg = load_package()
 from miden_vm_amd import precompile_airs as PA, dag, protocol  # noqa: E402
+from miden_vm_amd.testing import precompile_trace as PT  # noqa: E402
 
 P = dag.P
 RND = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
@@ -35,13 +36,13 @@ def airs():
 def session(airs):
     """[requirer 2^9 rows (every row fires, the last one too), byte-pair table 2^16, group table 2^3]"""
     rng = np.random.default_rng(5)
-    ledger = PA.BytePairLutRequires()
-    reqs = PA.keccak_like_requests(rng, 42, ledger)  # 42 * 12 = 504 requests
+    ledger = PT.BytePairLutRequires()
+    reqs = PT.keccak_like_requests(rng, 42, ledger)  # 42 * 12 = 504 requests
     reqs += [(PA.BUS_RANGE16, 1, [0xffff])] * 8       # -> 512: the requirer's last row fires; table row 0xffff gets multiplicity 8
     for _ in range(8):
         ledger.require_range16(0xffff)
     assert len(reqs) == 512
-    traces = [PA.requirer_trace(reqs, 9), PA.byte_pair_lut_trace(ledger), PA.ec_groups_trace()]
+    traces = [PT.requirer_trace(reqs, 9), PT.byte_pair_lut_trace(ledger), PT.ec_groups_trace()]
     return [airs["req"][0], airs["bpl"][0], airs["groups"][0]], traces
 
 
@@ -59,7 +60,7 @@ def test_preprocessed_table_is_the_lex_enumeration():
         assert list(t[idx]) == [a, b, (~a & 0xff) & b, a ^ b]
     assert int(t[:, 2].max()) < 256 and int(t[:, 3].max()) < 256
     # BytePairOp::apply_u64 commutes with the byte split (require_logic64, byte_pair_lut.rs:233-256)
-    led = PA.BytePairLutRequires()
+    led = PT.BytePairLutRequires()
     x, y = 0x0123456789abcdef, 0xfedcba9876543210
     assert led.require_logic64(PA.OP_XOR, x, y) == x ^ y and led.require_logic64(PA.OP_ANDNOT, x, y) == (~x & y) & ((1 << 64) - 1)
     assert int(led.counts.sum()) == 16
@@ -179,9 +180,9 @@ def test_precompile_pcs_params_are_the_vm_production_parameters():
 def keccak(airs):
     rng = np.random.default_rng(11)
     states = [[0] * 25] + [[int(x) for x in rng.integers(0, 1 << 63, 25)] for _ in range(2)]  # three permutations: lanes of 2 + 1
-    ledger = PA.BytePairLutRequires()
+    ledger = PT.BytePairLutRequires()
     kr = PA.keccak_round_air(host_aux)
-    trace, mem = PA.keccak_round_trace(states, ledger)
+    trace, mem = PT.keccak_round_trace(states, ledger)
     return dict(states=states, ledger=ledger, air=kr, trace=trace, mem=mem)
 
 
@@ -211,9 +212,9 @@ def test_round_program_is_the_reference_design():
 
 
 def test_round_machine_computes_keccak_f(keccak):
-    assert PA.keccak_f_reference([0] * 25)[0] == 0xf1258f7940e1dde7  # FIPS 202: first lane of Keccak-f[1600] of the zero state
+    assert PT.keccak_f_reference([0] * 25)[0] == 0xf1258f7940e1dde7  # FIPS 202: first lane of Keccak-f[1600] of the zero state
     for n, st in enumerate(keccak["states"]):
-        assert PA.keccak_round_outputs(keccak["mem"], n) == PA.keccak_f_reference(st)
+        assert PT.keccak_round_outputs(keccak["mem"], n) == PT.keccak_f_reference(st)
     t = keccak["trace"]
     assert t.shape == (8192, 68)                      # two permutation cycles of 3200 rows in lane 0 -> 2^13
     assert int(t[0, 0]) == 25 and int(t[0, 34]) == 25 + 2 * 3200  # lane 1 starts at its block's address frame
@@ -248,9 +249,9 @@ def test_keccak_round_constraints_and_perturbations(keccak):
 
 
 def keccak_session(airs, keccak):
-    reqs = PA.sponge_side_requests(keccak["states"], keccak["mem"])
+    reqs = PT.sponge_side_requests(keccak["states"], keccak["mem"])
     air_list = [keccak["air"][0], airs["bpl"][0], airs["groups"][0], airs["req"][0]]
-    traces = [keccak["trace"], PA.byte_pair_lut_trace(keccak["ledger"]), PA.ec_groups_trace(), PA.requirer_trace(reqs)]
+    traces = [keccak["trace"], PT.byte_pair_lut_trace(keccak["ledger"]), PT.ec_groups_trace(), PT.requirer_trace(reqs)]
     return air_list, [keccak["air"][1], airs["bpl"][1], airs["groups"][1], airs["req"][1]], traces
 
 
@@ -284,11 +285,11 @@ def test_keccak_session_proves_and_verifies(airs, keccak):
 # ---- the reference's own unit tests of the byte-pair table, replayed (precompiles-prover/src/tests/byte_pair_lut.rs) -----------------
 def test_reference_unit_cases_of_the_byte_pair_table(airs):
     # `andnot_uses_keccak_chi_convention`, `op_tags_match_relation_encoding` (:29-38)
-    led = PA.BytePairLutRequires()
+    led = PT.BytePairLutRequires()
     assert led.require(PA.OP_ANDNOT, 0xf0, 0xcc) == (~0xf0 & 0xff) & 0xcc and led.require(PA.OP_XOR, 0xab, 0xcd) == 0xab ^ 0xcd
     assert (PA.OP_ANDNOT, PA.OP_XOR) == (0, 1)
     # `require_increments_multiplicity`, `require_range16_increments_dedicated_multiplicity` (:41-64)
-    led = PA.BytePairLutRequires()
+    led = PT.BytePairLutRequires()
     led.require(PA.OP_XOR, 0xab, 0xcd)
     assert led.counts[(0xab << 8) | 0xcd, 1] == 1
     led.require(PA.OP_XOR, 0xab, 0xcd)
@@ -299,13 +300,13 @@ def test_reference_unit_cases_of_the_byte_pair_table(airs):
     table = PA.byte_pair_preprocessed()
     a, b = np.arange(1 << 16, dtype=np.uint64) >> np.uint64(8), np.arange(1 << 16, dtype=np.uint64) & np.uint64(0xff)
     assert (table[:, 0] == a).all() and (table[:, 1] == b).all() and (table[:, 2] == ((~a & np.uint64(0xff)) & b)).all() and (table[:, 3] == (a ^ b)).all()
-    empty = PA.byte_pair_lut_trace(PA.BytePairLutRequires())
+    empty = PT.byte_pair_lut_trace(PT.BytePairLutRequires())
     assert empty.shape == (1 << 16, 3) and int(empty.sum()) == 0
     # `trace_row_carries_results_and_multiplicities_at_lex_index` (:137-186)
-    led = PA.BytePairLutRequires()
+    led = PT.BytePairLutRequires()
     led.require(PA.OP_XOR, 0x05, 0x03); led.require(PA.OP_XOR, 0x05, 0x03); led.require(PA.OP_ANDNOT, 0x05, 0x03)
     led.require(PA.OP_ANDNOT, 0x01, 0x02); led.require_range16(0x0301)
-    t = PA.byte_pair_lut_trace(led)
+    t = PT.byte_pair_lut_trace(led)
     assert list(table[0x0102, 2:]) == [0x02, 0x03] and list(t[0x0102]) == [1, 0, 0]
     assert list(table[0x0103, 2:]) == [(~1 & 0xff) & 3, 1 ^ 3] and list(t[0x0103]) == [0, 0, 1]
     assert list(table[0x0503, 2:]) == [0x02, 0x06] and list(t[0x0503]) == [1, 2, 0]
@@ -314,13 +315,13 @@ def test_reference_unit_cases_of_the_byte_pair_table(airs):
     # sigma = - sum of 1 / enc over every individual lookup, with the reference test's challenges alpha = (3, 7)? -> any (alpha, beta) works
     bp_calls = [(PA.OP_XOR, 0x05, 0x03), (PA.OP_XOR, 0x05, 0x03), (PA.OP_ANDNOT, 0x05, 0x03), (PA.OP_ANDNOT, 0x10, 0x20)]
     r16_calls = [0x0301, 0x0301, 0x2010]
-    led = PA.BytePairLutRequires()
+    led = PT.BytePairLutRequires()
     for op, x, y in bp_calls:
         led.require(op, x, y)
     for w in r16_calls:
         led.require_range16(w)
     air, lookup = airs["bpl"]
-    aux, fin = ob.lookup_build_aux(lookup, PA.byte_pair_lut_trace(led), RND, air.preprocessed)
+    aux, fin = ob.lookup_build_aux(lookup, PT.byte_pair_lut_trace(led), RND, air.preprocessed)
     assert aux.shape == (1 << 16, 4) and int(aux[0, 0]) == 0 and int(aux[0, 1]) == 0   # two EF columns; the running sum starts at zero
     total = (0, 0)
     for op, x, y in bp_calls:
@@ -347,21 +348,21 @@ def test_reference_unit_cases_of_the_keccak_round_chiplet():
     patterned = [(i * 0x9e3779b97f4a7c15) & PA.M64 for i in range(25)]
     rng = np.random.default_rng(0xcaca0)
     for st in ([0] * 25, patterned, *[[int(x) for x in rng.integers(0, 1 << 63, 25)] for _ in range(3)]):
-        t, mem = PA.keccak_round_trace([st])
-        assert PA.keccak_round_outputs(mem, 0) == PA.keccak_f_reference(st)
+        t, mem = PT.keccak_round_trace([st])
+        assert PT.keccak_round_outputs(mem, 0) == PT.keccak_f_reference(st)
     # `keccak_round_constraints_hold_on_canonical_input` (:187-194): one permutation -> height next_pow2(3200) = 4096
-    t, _ = PA.keccak_round_trace([[0] * 25])
+    t, _ = PT.keccak_round_trace([[0] * 25])
     assert t.shape[0] == 4096 and check_local(t) == (0, None)
     # `keccak_round_constraints_hold_on_random_input`
-    t, _ = PA.keccak_round_trace([[int(x) for x in np.random.default_rng(0xc037f).integers(0, 1 << 63, 25)]])
+    t, _ = PT.keccak_round_trace([[int(x) for x in np.random.default_rng(0xc037f).integers(0, 1 << 63, 25)]])
     assert check_local(t) == (0, None)
     # `keccak_round_multi_perm_oracle_and_constraints` (:214-236): three permutations, lanes of 2 + 1 -> next_pow2(2 * 3200) = 8192
     states = [[int(x) for x in np.random.default_rng(0xc0ffee + k).integers(0, 1 << 63, 25)] for k in range(3)]
-    t, mem = PA.keccak_round_trace(states)
-    assert [PA.keccak_round_outputs(mem, n) for n in range(3)] == [PA.keccak_f_reference(s) for s in states]
+    t, mem = PT.keccak_round_trace(states)
+    assert [PT.keccak_round_outputs(mem, n) for n in range(3)] == [PT.keccak_f_reference(s) for s in states]
     assert t.shape[0] == 8192 and check_local(t) == (0, None)
     # `corruption_rot_limb_breaks_rotation_decomposition_binding` (:246-256): SLOT_D_ROL_BEGIN of round 0, lane 0 is an active ROL row
-    t, _ = PA.keccak_round_trace([[0] * 25])
+    t, _ = PT.keccak_round_trace([[0] * 25])
     t[PA.SLOT_D_ROL_BEGIN, PA.KR_ROT] = (int(t[PA.SLOT_D_ROL_BEGIN, PA.KR_ROT]) + 1) % P
     bad, first = check_local(t)
     assert bad >= 1 and first[0] == PA.SLOT_D_ROL_BEGIN

@@ -21,6 +21,7 @@ from __graft_entry__ import load_package
 
 pkg = load_package()
 from miden_vm_amd import precompile_airs as PA, dag, protocol  # noqa: E402
+from miden_vm_amd.testing import precompile_trace as PT  # noqa: E402
 
 P = dag.P
 RND = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
@@ -42,10 +43,10 @@ def inv(length, seed):
 
 
 def trace_of(invocations):
-    req = PA.ChunkRequires()
+    req = PT.ChunkRequires()
     for data in invocations:
         req.require(data)
-    return PA.chunk_trace(req), req
+    return PT.chunk_trace(req), req
 
 
 def check_local(chunk, main):
@@ -132,9 +133,9 @@ def test_constraints_hold_with_perm_seq_id_jump_at_head(chunk):
 
 
 def test_chunks_from_bytes_is_the_reference_packing():
-    assert PA.chunks_from_bytes(bytes([1, 2, 3, 4, 5])) == [[0x04030201, 5, 0, 0, 0, 0, 0, 0]]      # core/src/utils/mod.rs:132-134
-    assert PA.chunks_from_bytes(b"") == [[0] * 8]                                                    # "a single all-zero chunk"
-    assert len(PA.chunks_from_bytes(bytes(32))) == 1 and len(PA.chunks_from_bytes(bytes(33))) == 2
+    assert PT.chunks_from_bytes(bytes([1, 2, 3, 4, 5])) == [[0x04030201, 5, 0, 0, 0, 0, 0, 0]]      # core/src/utils/mod.rs:132-134
+    assert PT.chunks_from_bytes(b"") == [[0] * 8]                                                    # "a single all-zero chunk"
+    assert len(PT.chunks_from_bytes(bytes(32))) == 1 and len(PT.chunks_from_bytes(bytes(33))) == 2
 
 
 def test_a_repeated_input_reuses_its_absorption_chain(chunk):
@@ -162,9 +163,9 @@ def test_corruption_is_caught(chunk, name, invocations, row, col, value):
 def statement(chunk):
     invocations = [inv(33, 0xa1), inv(40, 0xb2), inv(129, 0xc3), inv(40, 0xb2), inv(200, 0xc8)]
     main, req = trace_of(invocations)
-    others = PA.chunk_side_requests(req)
+    others = PT.chunk_side_requests(req)
     pairs = [chunk, PA.requirer_air(host_aux, payload=6), PA.ec_groups_air(host_aux)]
-    traces = [main, PA.requirer_trace(others, payload=6), PA.ec_groups_trace()]
+    traces = [main, PT.requirer_trace(others, payload=6), PT.ec_groups_trace()]
     return pairs, traces
 
 

@@ -19,6 +19,7 @@ from __graft_entry__ import load_package
 
 pkg = load_package()
 from miden_vm_amd import precompile_airs as PA, dag, protocol  # noqa: E402
+from miden_vm_amd.testing import precompile_trace as PT  # noqa: E402
 
 P = dag.P
 RND = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
@@ -52,11 +53,11 @@ class EcStack:
     """tests/ec_add.rs `EcStack`: the store rooted at pointer 1, the ad-hoc modulus pinned at FP, the five ledgers."""
 
     def __init__(self, bound):
-        self.store = PA.UintStore()
+        self.store = PT.UintStore()
         self.store.pin_modulus(1, 0)
         self.fp = self.store.pin_modulus(FP, bound)
-        self.adds, self.muls, self.ec, self.ec_add = PA.UintAddRequires(), PA.UintMulRequires(), PA.EcStore(), PA.EcAddRequires()
-        self.req = PA.EcRequire(self.ec, self.store, self.muls, self.adds, self.ec_add)
+        self.adds, self.muls, self.ec, self.ec_add = PT.UintAddRequires(), PT.UintMulRequires(), PT.EcStore(), PT.EcAddRequires()
+        self.req = PT.EcRequire(self.ec, self.store, self.muls, self.adds, self.ec_add)
 
     def point_coords(self, point):
         x_ptr, y_ptr = self.ec.point_params(point)[1]
@@ -65,12 +66,12 @@ class EcStack:
     def traces(self, min_height=0):
         """The dependency-ordered sweep of `EcStack::traces`: relations before the stores that read their demand, every Range16 consumer
         before the table."""
-        bpl = PA.BytePairLutRequires()
-        add = PA.uint_add_trace(self.adds, self.store, min_height=min_height)
-        ec_add = PA.ec_group_add_trace(self.ec_add, self.ec, bpl, min_height=min_height)
-        uint = PA.requirer_trace(self.store.uint_val_requests() + self.muls.uint_mul_requests() + self.ec_add.consumer_requests(), payload=10)
-        groups, points = PA.ec_store_traces(self.ec, min_height=min_height)
-        return [PA.byte_pair_lut_trace(bpl), uint, add, groups, points, ec_add]
+        bpl = PT.BytePairLutRequires()
+        add = PT.uint_add_trace(self.adds, self.store, min_height=min_height)
+        ec_add = PT.ec_group_add_trace(self.ec_add, self.ec, bpl, min_height=min_height)
+        uint = PT.requirer_trace(self.store.uint_val_requests() + self.muls.uint_mul_requests() + self.ec_add.consumer_requests(), payload=10)
+        groups, points = PT.ec_store_traces(self.ec, min_height=min_height)
+        return [PT.byte_pair_lut_trace(bpl), uint, add, groups, points, ec_add]
 
 
 def k1_stack():
@@ -143,7 +144,7 @@ def affine_add(p1, p2, a, m):
 
 def validated_stack():
     """`k256_validated_stack`: generic and double pairs, a cancel, the three pass-throughs -- every result checked by value."""
-    m, mult = P_MINUS_1 + 1, PA.k1_multiples(13)
+    m, mult = P_MINUS_1 + 1, PT.k1_multiples(13)
     kg = lambda k: mult[k - 1]                                          # noqa: E731
     s = EcStack(P_MINUS_1)
     group, pai = s.req.create_group(0, 7, s.fp)
@@ -252,14 +253,14 @@ def test_negation_rides_a_cancel_block(airs):
     group, r, pai = k1.req.neg(k1.g_pt, 1)
     assert k1.point_coords(r) == (GX, NEG_GY) and pai == k1.pai
     mains = k1.traces()
-    uint = PA.requirer_trace(k1.store.uint_val_requests() + k1.muls.uint_mul_requests() + k1.ec_add.consumer_requests()
+    uint = PT.requirer_trace(k1.store.uint_val_requests() + k1.muls.uint_mul_requests() + k1.ec_add.consumer_requests()
                              + [(PA.BUS_EC_POINT, 1, [pai, group, 0, 0, 1])], payload=10)     # the negation's reader also pins the PAI result slot
     check_all(airs, mains)
     assert not residual_is_zero(airs, mains) and residual_is_zero(airs, mains[:UINT] + [uint] + mains[UINT + 1:])
 
 
 def test_empty_trace_holds(airs):
-    main = PA.ec_group_add_trace(PA.EcAddRequires(), PA.EcStore(), PA.BytePairLutRequires())
+    main = PT.ec_group_add_trace(PT.EcAddRequires(), PT.EcStore(), PT.BytePairLutRequires())
     assert main.shape == (PA.EA_PERIOD, 21) and not main.any()
     assert check_local(airs[EC_ADD], main) == (0, None) and sigma(airs[EC_ADD], main) == (0, 0)
 
@@ -383,8 +384,8 @@ def test_arithmetic_ec_stack_proves_and_forgeries_do_not(airs):
 
 def test_the_session_builder_computes_multiples_and_closes(airs):
     scalars = [1, 2, 3, 7, 12, 13, 12]
-    pairs, traces, (results, (store, adds, muls, ec, ec_add)) = PA.ec_add_session(scalars, host_aux)
-    mult = PA.k1_multiples(13)
+    pairs, traces, (results, (store, adds, muls, ec, ec_add)) = PT.ec_add_session(scalars, host_aux)
+    mult = PT.k1_multiples(13)
     for k, r in zip(scalars, results):
         x_ptr, y_ptr = ec.point_params(r)[1]
         assert (store.value(x_ptr), store.value(y_ptr)) == mult[k - 1], k

@@ -15,6 +15,7 @@ from __graft_entry__ import load_package
 
 pkg = load_package()
 from miden_vm_amd import precompile_airs as PA, dag, protocol  # noqa: E402
+from miden_vm_amd.testing import precompile_trace as PT  # noqa: E402
 import test_precompile_ec_add as EA  # noqa: E402
 
 P = dag.P
@@ -48,7 +49,7 @@ class Bare:
     """ec/msm/trace.rs `mod tests`: expressions over bare pointers, no stores behind them (local constraints only)."""
 
     def __init__(self):
-        self.msm = PA.EcMsmRequires(None)
+        self.msm = PT.EcMsmRequires(None)
 
     def intro(self, base, one=9, group=1, sbound=7):
         return self.msm._push(("intro", base), kind="intro", group=group, sbound=sbound, val=base, rows=[dict(self.msm.ROW0, base=base, scalar=one)])
@@ -58,7 +59,7 @@ class Bare:
                               val_b=self.msm.value(b), a_ptr=2, b_ptr=3, bound_ptr=1, rows=[dict(self.msm.ROW0, **r) for r in rows])
 
     def trace(self):
-        return PA.ec_msm_trace(self.msm, PA.UintStore(), PA.BytePairLutRequires())
+        return PT.ec_msm_trace(self.msm, PT.UintStore(), PT.BytePairLutRequires())
 
 
 def two_intro_combine():
@@ -120,7 +121,7 @@ def test_local_forgeries_are_rejected(msm_air):
 
 
 def affine_sum(terms):
-    m, mult = PA.K1_BOUND + 1, PA.k1_multiples(max(t[1] for t in terms))
+    m, mult = PA.K1_BOUND + 1, PT.k1_multiples(max(t[1] for t in terms))
     acc = None
     for k, mm in terms:
         pt, add = None, mult[mm - 1]
@@ -134,13 +135,13 @@ def affine_sum(terms):
 
 @pytest.mark.parametrize("terms", [[(5, 1)], [(0xb5, 1), (0x4d, 3)], [(6, 2), (3, 1), (5, 7)]], ids=["one base", "two bases", "three bases"])
 def test_msm_sessions_close_over_seven_real_chiplets_and_compute_the_sum(terms):
-    pairs, traces, (val, expr, (store, adds, muls, ec, ec_add, msm)) = PA.ec_msm_session(terms, host_aux)
+    pairs, traces, (val, expr, (store, adds, muls, ec, ec_add, msm)) = PT.ec_msm_session(terms, host_aux)
     x_ptr, y_ptr = ec.point_params(val)[1]
     assert (store.value(x_ptr), store.value(y_ptr)) == affine_sum(terms), "the expression's value is the sum"
     got_terms = {base: store.value(sc) for base, sc in msm.terms(expr)}
     want = {}
     for k, m_ in terms:
-        base = ec.point_by_coords(1, *(store.by_value[(c, PA.K1_BASE_BOUND_PTR)] for c in PA.k1_multiples(m_)[-1]))
+        base = ec.point_by_coords(1, *(store.by_value[(c, PA.K1_BASE_BOUND_PTR)] for c in PT.k1_multiples(m_)[-1]))
         want[base] = (want.get(base, 0) + k) % N_ORDER
     assert got_terms == want, "one term per base, the scalars merged mod the group order"
     assert [b for b, _ in msm.terms(expr)] == sorted(b for b, _ in msm.terms(expr)), "terms sorted by base pointer"
@@ -157,11 +158,11 @@ def test_msm_sessions_close_over_seven_real_chiplets_and_compute_the_sum(terms):
 
 def test_scalars_wrap_the_group_order_and_negation_certifies_its_value():
     """(n - 1) G + 2 G: the merged scalar wraps to 1; then the negated expression: value (x, -y), minted with a closure certificate."""
-    store, adds, muls, ec, ec_add, bpl = PA.UintStore().install_fixed_uints(), PA.UintAddRequires(), PA.UintMulRequires(), PA.EcStore(), PA.EcAddRequires(), PA.BytePairLutRequires()
-    req = PA.EcRequire(ec, store, muls, adds, ec_add)
+    store, adds, muls, ec, ec_add, bpl = PT.UintStore().install_fixed_uints(), PT.UintAddRequires(), PT.UintMulRequires(), PT.EcStore(), PT.EcAddRequires(), PT.BytePairLutRequires()
+    req = PT.EcRequire(ec, store, muls, adds, ec_add)
     group, _ = req.create_group(0, 7, PA.K1_BASE_BOUND_PTR)
     g = req.add_point(group, *PA.K1_G)
-    msm = PA.EcMsmRequires(req)
+    msm = PT.EcMsmRequires(req)
     e = msm.intro(g)
     n_e = msm.neg(e)                                                    # <G x (n - 1)>, value -G
     assert store.value(msm.terms(n_e)[0][1]) == N_ORDER - 1
@@ -173,22 +174,22 @@ def test_scalars_wrap_the_group_order_and_negation_certifies_its_value():
     msm.resolve(s)
     ec.require_ecpoint(g)
     ec.require_fixed_groups()
-    add = PA.uint_add_trace(adds, store, min_height=8)
-    ec_add_main = PA.ec_group_add_trace(ec_add, ec, bpl, min_height=8)
-    msm_main = PA.ec_msm_trace(msm, store, bpl, min_height=8)
-    uint = PA.uint_store_mul_trace(store, muls, bpl, min_height=8)
-    groups, points = PA.ec_store_traces(ec, min_height=8)
-    readers = PA.requirer_trace(msm.consumer_requests() + [(PA.BUS_EC_POINT, 1, [g, group, *ec.point_params(g)[1], 0])], payload=10)
+    add = PT.uint_add_trace(adds, store, min_height=8)
+    ec_add_main = PT.ec_group_add_trace(ec_add, ec, bpl, min_height=8)
+    msm_main = PT.ec_msm_trace(msm, store, bpl, min_height=8)
+    uint = PT.uint_store_mul_trace(store, muls, bpl, min_height=8)
+    groups, points = PT.ec_store_traces(ec, min_height=8)
+    readers = PT.requirer_trace(msm.consumer_requests() + [(PA.BUS_EC_POINT, 1, [g, group, *ec.point_params(g)[1], 0])], payload=10)
     pairs = [PA.byte_pair_lut_air(host_aux), PA.uint_store_mul_air(host_aux), PA.uint_add_air(host_aux), PA.ec_groups_air(host_aux),
              PA.ec_point_store_air(host_aux), PA.ec_group_add_air(host_aux), PA.ec_msm_air(host_aux), PA.requirer_air(host_aux, payload=10)]
-    traces = [PA.byte_pair_lut_trace(bpl), uint, add, groups, points, ec_add_main, msm_main, readers]
+    traces = [PT.byte_pair_lut_trace(bpl), uint, add, groups, points, ec_add_main, msm_main, readers]
     for pair, t in zip(pairs, traces):
         assert check(pair, t) == (0, None), pair[0].name
     assert PA.eval_external(RND, [[sigma(pair, t)] for pair, t in zip(pairs, traces)], fixed_uints=True) == [(0, 0)]
 
 
 def test_the_msm_statement_proves_and_forgeries_do_not():
-    pairs, traces, _ = PA.ec_msm_session([(5, 1), (3, 2)], host_aux)
+    pairs, traces, _ = PT.ec_msm_session([(5, 1), (3, 2)], host_aux)
     air_list = [p_[0] for p_ in pairs]
     st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
     ext = PA.external_assertions(pkg, fixed_uints=True)

@@ -19,6 +19,7 @@ from __graft_entry__ import load_package
 
 pkg = load_package()
 from miden_vm_amd import precompile_airs as PA, dag, protocol  # noqa: E402
+from miden_vm_amd.testing import precompile_trace as PT  # noqa: E402
 
 P = dag.P
 RND = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
@@ -42,14 +43,14 @@ class Fixture:
     """tests/ec.rs `fixture`: the modulus pinned @1, the curve y^2 = x^3 + a x + b over p = bound + 1, one finite point."""
 
     def __init__(self, bound, a, b, x, y):
-        self.store, self.muls, self.ec = PA.UintStore(), PA.UintMulRequires(), PA.EcStore()
+        self.store, self.muls, self.ec = PT.UintStore(), PT.UintMulRequires(), PT.EcStore()
         self.fp = self.store.pin_modulus(1, bound)
-        self.req = PA.EcRequire(self.ec, self.store, self.muls)
+        self.req = PT.EcRequire(self.ec, self.store, self.muls)
         self.group, self.pai = self.req.create_group(a, b, self.fp)
         self.point = self.req.add_point(self.group, x, y)
 
     def traces(self):
-        return PA.ec_store_traces(self.ec)
+        return PT.ec_store_traces(self.ec)
 
     def foreign(self):
         return self.muls.uint_mul_requests() + self.ec.ec_point_requests() + self.ec.cert_requests()
@@ -67,7 +68,7 @@ def check_local(pair, main, rnd=RND):
 
 def balanced(airs, groups, points, foreign):
     """tests/ec.rs `residual` == 0: the sum of the three sigmas (plus the verifier's boundary terms) vanishes."""
-    traces = [points, groups, PA.requirer_trace(foreign, payload=10)]
+    traces = [points, groups, PT.requirer_trace(foreign, payload=10)]
     sig = []
     for (air, lookup), t in zip(airs, traces):
         _, fin = ob.lookup_build_aux(lookup, t, RND, None)
@@ -168,13 +169,13 @@ def test_local_forgeries_are_rejected(airs):
 
 
 def test_group_ptr_chain_is_ungated(airs):
-    ec = PA.EcStore()
+    ec = PT.EcStore()
     live = len(PA.FIXED_EC_GROUPS)
     while live & (live - 1) == 0:                                       # tests/ec.rs `group_trace_with_pad_row`
         base = 10_000 + live * 3
         ec.create_group(base, base + 1, base + 2)
         live += 1
-    groups, _ = PA.ec_store_traces(ec)
+    groups, _ = PT.ec_store_traces(ec)
     assert groups.shape[0] > live and check_local(airs[1], groups) == (0, None)
     forged = groups.copy()
     forged[live, 0] = 1                                                 # a pad row's ptr := 1
@@ -182,7 +183,7 @@ def test_group_ptr_chain_is_ungated(airs):
 
 
 def test_empty_stores_hold_and_inactive_rows_cannot_provide(airs):
-    groups, points = PA.ec_store_traces(PA.EcStore())
+    groups, points = PT.ec_store_traces(PT.EcStore())
     assert groups.shape == (2, 6) and points.shape == (2, 14) and not points.any()
     assert check_local(airs[1], groups) == (0, None) and check_local(airs[0], points) == (0, None)
     assert balanced(airs, groups, points, [])[0]
@@ -219,9 +220,9 @@ def test_the_statement_proves_and_verifies_and_forgeries_do_not(airs):
         fx.req.add_point(fx.group, *_k1_multiple(k))
     fx.req.point_on_group(fx.group, *fx.ec.point_params(fx.point)[1])
     fx.ec.require_fixed_groups()
-    groups, points = PA.ec_store_traces(fx.ec, min_height=8)
+    groups, points = PT.ec_store_traces(fx.ec, min_height=8)
     assert points.shape == (16, 14) and groups.shape == (8, 6)
-    traces = [points, groups, PA.requirer_trace(fx.foreign(), payload=10)]
+    traces = [points, groups, PT.requirer_trace(fx.foreign(), payload=10)]
     sig = []
     for (air, lookup), t in zip(airs, traces):
         assert check_local((air, lookup), t) == (0, None)
@@ -248,19 +249,19 @@ def test_the_statement_proves_and_verifies_and_forgeries_do_not(airs):
 
 
 def _k1_multiple(k):
-    return PA.k1_multiples(k)[-1]
+    return PT.k1_multiples(k)[-1]
 
 
 def test_the_multiples_helper_agrees_with_a_known_point():
     assert _k1_multiple(2) == (0xC6047F9441ED7D6D3045406E95C07CD85C778E4B8CEF3CA7ABAC09B95C709EE5,
                                0x1AE168FEA63DC339A3C58419466CEAEEF7F632653266D0E1236431A950CFE52A)
-    for x, y in PA.k1_multiples(40):
+    for x, y in PT.k1_multiples(40):
         assert (y * y - x ** 3 - 7) % (K1_BOUND + 1) == 0
     assert (PA.K1_BOUND, PA.K1_G) == (K1_BOUND, (K1_GX, K1_GY))
 
 
 def test_the_session_builder_closes(airs):
-    pairs, traces, (store, muls, ec) = PA.ec_store_session(100, host_aux)
+    pairs, traces, (store, muls, ec) = PT.ec_store_session(100, host_aux)
     assert traces[0].shape == (128, 14) and len(ec.points) == 101 and len(muls.ops) == 300
     sig = []
     for (air, lookup), t in zip(pairs, traces):

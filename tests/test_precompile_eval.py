@@ -17,6 +17,7 @@ from __graft_entry__ import load_package
 
 pkg = load_package()
 from miden_vm_amd import precompile_airs as PA, dag, protocol, miden_air as MA  # noqa: E402
+from miden_vm_amd.testing import precompile_trace as PT  # noqa: E402
 
 P = dag.P
 RND = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
@@ -34,7 +35,7 @@ def te():
 
 @pytest.fixture(scope="module")
 def session():
-    return PA.precompile_session([b"", b"abc", b"abc", bytes(range(200))], host_aux)
+    return PT.precompile_session([b"", b"abc", b"abc", bytes(range(200))], host_aux)
 
 
 def sigma(pair, main):
@@ -52,11 +53,11 @@ def check(pair, main, publics):
 def and_chain(k, seed):
     """src/tests/eval.rs `build_eval_trace`: k issued handles folded onto a ZERO_HASH leaf."""
     rng = np.random.default_rng(seed)
-    ev = PA.TranscriptEvalRequires(PA.Poseidon2Requires(), None)
+    ev = PT.TranscriptEvalRequires(PT.Poseidon2Requires(), None)
     acc = ev.zero()
     for _ in range(k):
         acc = ev.record_and(acc, ev.issue([int(x) for x in rng.integers(0, P, 4, dtype=np.uint64)]))
-    return PA.transcript_eval_trace(ev, acc)
+    return PT.transcript_eval_trace(ev, acc)
 
 
 def test_layout_ids_and_log_quotient_degree(te):
@@ -95,11 +96,11 @@ def test_and_chains_hold_and_the_reference_corruptions_are_rejected(te):
 
 
 def test_corruption_pinned_leaf_cap_slot_mismatch(te):
-    store = PA.UintStore()
+    store = PT.UintStore()
     store.pin_modulus(7, int(np.random.default_rng(0xf0f63d).integers(1, 1 << 62)) << 190 | 5)
-    ev = PA.TranscriptEvalRequires(PA.Poseidon2Requires(), PA.EcRequire(None, store, None))
+    ev = PT.TranscriptEvalRequires(PT.Poseidon2Requires(), PT.EcRequire(None, store, None))
     root = ev.record_and(ev.zero(), ev.pin_uint(7))
-    main, public_root = PA.transcript_eval_trace(ev, root)
+    main, public_root = PT.transcript_eval_trace(ev, root)
     assert check(te, main, public_root) == (0, None)
     pin_row = int(np.nonzero(main[:, PA.TE_COL_IS_PINNED])[0][0])
     assert [int(main[pin_row, c]) for c in (PA.TE_COL_TAG_ARG0, PA.TE_COL_TAG_ARG1)] == [7, 7], "the pin claim's capacity: [3, bound_ptr, pin_ptr, 0]"
@@ -200,11 +201,11 @@ def test_the_whole_session_proves_and_verifies(session):
 def test_the_session_front_end_other_calls():
     """`Session` (session/mod.rs) calls the first transcript does not make: subtraction to and from the point at infinity, a negated MSM
     expression resolved as a claim, a transcript whose root is a single fold."""
-    s = PA.Session()
+    s = PT.Session()
     fp, m = PA.K1_BASE_BOUND_PTR, PA.K1_BOUND + 1
     digest, t_k = s.keccak(b"abc")
     assert bytes(digest).hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
-    mult = PA.k1_multiples(3)
+    mult = PT.k1_multiples(3)
     pt = lambda x, y: s.ec_create(PA.K1_GROUP_PTR, s.uint_leaf(x, fp), s.uint_leaf(y, fp))       # noqa: E731
     g, g3 = pt(*mult[0]), pt(*mult[2])
     pai = s.ec_pai(PA.K1_GROUP_PTR)
@@ -214,12 +215,12 @@ def test_the_session_front_end_other_calls():
     assert s.store.value(n_minus_1["ptr"]) == PA.FIXED_UINTS[2][2] and s.msm_value_coords(ne) == (mult[0][0], m - mult[0][1])
     claims.append(s.ec_is(s.ec_msm(ne, [(g, n_minus_1)]), pt(mult[0][0], m - mult[0][1])))
     st = s.finish(s.assert_and_fold(claims))
-    pairs = PA.SessionTraces.airs(host_aux)
+    pairs = PT.SessionTraces.airs(host_aux)
     assert [p[0].name for p in pairs][5] == "transcript_eval" and len(st.mains()) == 12 and st.air_inputs() == st.public_root
     for pair, t in zip(pairs, st.mains()):
         assert check(pair, t, st.public_root) == (0, None), pair[0].name
     assert PA.eval_external(RND, [[sigma(pair, t)] for pair, t in zip(pairs, st.mains())], fixed_uints=True) == [(0, 0)]
-    s2 = PA.Session()
+    s2 = PT.Session()
     with pytest.raises(AssertionError):
         s2.uint_is(s2.uint_leaf(5, fp), s2.uint_leaf(6, fp))            # an unprovable claim is refused when it is made
     with pytest.raises(AssertionError):

@@ -21,6 +21,7 @@ from __graft_entry__ import load_package
 
 pkg = load_package()
 from miden_vm_amd import precompile_airs as PA, miden_air as MA, dag, protocol  # noqa: E402
+from miden_vm_amd.testing import precompile_trace as PT  # noqa: E402
 
 P = dag.P
 RND = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
@@ -90,15 +91,15 @@ def test_main_column_layout_and_air_layout_match_spec(node):
 def test_generated_row_uses_vm_chunk_and_keccak_node_digests():
     """On a REAL invocation: the row's three hashes are what the deferred-node hashing gives (`Node::chunks([D]).digest()`,
     `Keccak256Precompile::assert_node(len, H_input_chunks, H_digest_chunks).digest()`: Poseidon2 absorptions under the two tags)."""
-    sp = PA.SpongeRequires()
-    nd = PA.KeccakNodeRequires(sp)
+    sp = PT.SpongeRequires()
+    nd = PT.KeccakNodeRequires(sp)
     data = bytes(range(200))
     out = nd.require(data)
-    row = PA.keccak_node_trace(nd)[0]
+    row = PT.keccak_node_trace(nd)[0]
     d = [int(x) for x in row[PA.KNC_D:PA.KNC_D + 8]]
     assert b"".join(x.to_bytes(4, "little") for x in d) == out["keccak_digest"]
     cap, h_in = list(PA.TAG_CHUNKS_WORD), None
-    for f in PA.chunks_from_bytes(data):
+    for f in PT.chunks_from_bytes(data):
         st = MA.permute(f + cap)
         cap, h_in = st[8:12], st[0:4]
     h_dc = p2_one_shot(PA.TAG_CHUNKS_WORD, d[0:4], d[4:8])
@@ -111,7 +112,7 @@ def test_generated_row_uses_vm_chunk_and_keccak_node_digests():
 
 def test_constraints_hold(node):
     for forged in (Forged().add(0x11, 50), Forged().add(0xa0, 50).add(0xa1, 100).add(0xa2, 200), Forged()):
-        main = PA.keccak_node_trace(forged)
+        main = PT.keccak_node_trace(forged)
         assert main.shape == (max(2, 1 << max(0, (len(forged.records) - 1).bit_length())), 30)
         assert check_local(node, main) == (0, None)
 
@@ -124,7 +125,7 @@ def test_corruption_is_caught(node, name, two, row, col, value):
     forged = Forged().add(0xa0, 50)
     if two:
         forged.add(0xa1, 100)
-    main = PA.keccak_node_trace(forged)
+    main = PT.keccak_node_trace(forged)
     assert check_local(node, main) == (0, None)
     main[row, col] = int(main[row, col]) + 1 if value is None else value
     assert check_local(node, main)[0] >= 1, name
@@ -139,17 +140,17 @@ INPUTS = [b"", b"abc", rnd_bytes(135, 11), rnd_bytes(136, 12), rnd_bytes(300, 14
 
 
 def node_session(inputs, aux=host_aux, permute_batch=None):
-    ledger, p2 = PA.BytePairLutRequires(), PA.Poseidon2Requires()
-    chunks = PA.ChunkRequires(p2)
-    sp = PA.SpongeRequires(chunks, ledger)
-    nd = PA.KeccakNodeRequires(sp)
+    ledger, p2 = PT.BytePairLutRequires(), PT.Poseidon2Requires()
+    chunks = PT.ChunkRequires(p2)
+    sp = PT.SpongeRequires(chunks, ledger)
+    nd = PT.KeccakNodeRequires(sp)
     outs = [nd.require(d) for d in inputs]
-    kr_trace, mem = PA.keccak_round_trace(sp.perm_inputs, ledger)
-    p2_main, _ = PA.poseidon2_chiplet_trace(p2, permute_batch=permute_batch)
+    kr_trace, mem = PT.keccak_round_trace(sp.perm_inputs, ledger)
+    p2_main, _ = PT.poseidon2_chiplet_trace(p2, permute_batch=permute_batch)
     pairs = [PA.keccak_round_air(aux), PA.byte_pair_lut_air(aux), PA.keccak_sponge_air(aux), PA.chunk_air(aux), PA.poseidon2_chiplet_air(aux),
              PA.keccak_node_air(aux), PA.requirer_air(aux, payload=7), PA.ec_groups_air(aux)]
-    traces = [kr_trace, PA.byte_pair_lut_trace(ledger), PA.keccak_sponge_trace(sp), PA.chunk_trace(chunks), p2_main, PA.keccak_node_trace(nd),
-              PA.requirer_trace(PA.binding_requests(nd), payload=7), PA.ec_groups_trace()]
+    traces = [kr_trace, PT.byte_pair_lut_trace(ledger), PT.keccak_sponge_trace(sp), PT.chunk_trace(chunks), p2_main, PT.keccak_node_trace(nd),
+              PT.requirer_trace(PT.binding_requests(nd), payload=7), PT.ec_groups_trace()]
     return pairs, traces, outs, nd
 
 
@@ -211,18 +212,18 @@ def test_the_session_proves_and_verifies_and_forgeries_do_not(session):
 def chunk_node_session(inputs, aux=host_aux):
     """The hashing part of `SessionTraces::mains` in `ChipletAir::all()` order (session/prove.rs:111-126): ChunkNode, Poseidon2, KeccakRound,
     BytePairLut, KeccakSponge, [TranscriptEval: here the Binding readers], ..., EcGroups."""
-    ledger, p2 = PA.BytePairLutRequires(), PA.Poseidon2Requires()
-    chunks = PA.ChunkRequires(p2)
-    sp = PA.SpongeRequires(chunks, ledger)
-    nd = PA.KeccakNodeRequires(sp)
+    ledger, p2 = PT.BytePairLutRequires(), PT.Poseidon2Requires()
+    chunks = PT.ChunkRequires(p2)
+    sp = PT.SpongeRequires(chunks, ledger)
+    nd = PT.KeccakNodeRequires(sp)
     for d in inputs:
         nd.require(d)
-    kr_trace, _ = PA.keccak_round_trace(sp.perm_inputs, ledger)
-    p2_main, _ = PA.poseidon2_chiplet_trace(p2)
+    kr_trace, _ = PT.keccak_round_trace(sp.perm_inputs, ledger)
+    p2_main, _ = PT.poseidon2_chiplet_trace(p2)
     pairs = [PA.chunk_node_air(aux), PA.poseidon2_chiplet_air(aux), PA.keccak_round_air(aux), PA.byte_pair_lut_air(aux), PA.keccak_sponge_air(aux),
              PA.requirer_air(aux, payload=7), PA.ec_groups_air(aux)]
-    traces = [PA.chunk_node_trace(chunks, nd), p2_main, kr_trace, PA.byte_pair_lut_trace(ledger), PA.keccak_sponge_trace(sp),
-              PA.requirer_trace(PA.binding_requests(nd), payload=7), PA.ec_groups_trace()]
+    traces = [PT.chunk_node_trace(chunks, nd), p2_main, kr_trace, PT.byte_pair_lut_trace(ledger), PT.keccak_sponge_trace(sp),
+              PT.requirer_trace(PT.binding_requests(nd), payload=7), PT.ec_groups_trace()]
     return pairs, traces, chunks, nd
 
 
@@ -234,11 +235,11 @@ def test_chunk_node_is_the_two_airs_side_by_side(session):
     pairs, traces, chunks, nd = chunk_node_session(INPUTS)
     t = traces[0]
     assert t.shape == (32, 42)                                          # 17 chunks against five node rows: the larger side decides
-    assert (t[:, :12] == PA.chunk_trace(chunks, 8)).all() and (t[:8, 12:] == PA.keccak_node_trace(nd)).all() and not t[8:, 12:].any()
+    assert (t[:, :12] == PT.chunk_trace(chunks, 8)).all() and (t[:8, 12:] == PT.keccak_node_trace(nd)).all() and not t[8:, 12:].any()
     # one sigma for both sides = the sum of the two stand-alone chiplets' sigmas
     _, fin = ob.lookup_build_aux(pairs[0][1], t, RND, None)
-    _, fin_c = ob.lookup_build_aux(PA.chunk_air(host_aux)[1], PA.chunk_trace(chunks), RND, None)
-    _, fin_n = ob.lookup_build_aux(PA.keccak_node_air(host_aux)[1], PA.keccak_node_trace(nd), RND, None)
+    _, fin_c = ob.lookup_build_aux(PA.chunk_air(host_aux)[1], PT.chunk_trace(chunks), RND, None)
+    _, fin_n = ob.lookup_build_aux(PA.keccak_node_air(host_aux)[1], PT.keccak_node_trace(nd), RND, None)
     assert (int(fin[0]), int(fin[1])) == ((int(fin_c[0]) + int(fin_n[0])) % P, (int(fin_c[1]) + int(fin_n[1])) % P)
     aux, fin = ob.lookup_build_aux(pairs[0][1], t, RND, None)
     assert ob.check_constraints(cn, t, aux, [int(fin[0]), int(fin[1])], ROOT, RND, None) == (0, None)

@@ -22,6 +22,7 @@ from __graft_entry__ import load_package
 
 pkg = load_package()
 from miden_vm_amd import precompile_airs as PA, miden_air as MA, dag, protocol  # noqa: E402
+from miden_vm_amd.testing import precompile_trace as PT  # noqa: E402
 
 P = dag.P
 RND = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
@@ -52,7 +53,7 @@ def absorption(seed, n_blocks=1, in_mult=1, out_mult=1, zero=False):
 def build_requires(absorptions):
     """tests/poseidon2.rs `build_requires`: `require_absorption` in_multiplicity times (interning collapses them), `require_digest`
     out_multiplicity times."""
-    req, idxs = PA.Poseidon2Requires(), []
+    req, idxs = PT.Poseidon2Requires(), []
     for a in absorptions:
         for _ in range(min(a["in_mult"], 8)):
             idx = req.require_absorption(a["cap"], a["blocks"])
@@ -144,7 +145,7 @@ def test_periodic_program_is_the_reference_program(p2):
 def test_one_shot_digest_matches_reference_on_zero_and_random_input():
     for a in (absorption(0, zero=True), absorption(0xc0115eed)):
         req, (idx,) = build_requires([a])
-        main, outs = PA.poseidon2_chiplet_trace(req)
+        main, outs = PT.poseidon2_chiplet_trace(req)
         assert req.digest(idx) == reference_digest(a) and req.span(idx) == (0, 1)
         assert [int(x) for x in main[15, PA.P2C_STATE:PA.P2C_STATE + 4]] == reference_digest(a) == [int(x) for x in outs[0, 0:4]]
 
@@ -152,7 +153,7 @@ def test_one_shot_digest_matches_reference_on_zero_and_random_input():
 def test_three_block_digest_matches_chained_reference_permutation():
     a = absorption(0x0c0a1ced, n_blocks=3)
     req, (idx,) = build_requires([a])
-    main, outs = PA.poseidon2_chiplet_trace(req)
+    main, outs = PT.poseidon2_chiplet_trace(req)
     assert req.digest(idx) == reference_digest(a) == [int(x) for x in outs[2, 0:4]] and req.span(idx) == (0, 3)
     assert [int(x) for x in main[16, PA.P2C_STATE + 8:PA.P2C_STATE + 12]] == [int(x) for x in main[15, PA.P2C_STATE + 8:PA.P2C_STATE + 12]]
 
@@ -173,7 +174,7 @@ def test_multi_absorption_outputs_have_non_overlapping_perm_spans():
     ("mixed_one_shot_and_chain", [absorption(0xa500), absorption(0xa501), absorption(0xa502, 2)])], ids=lambda v: v if isinstance(v, str) else "")
 def test_constraints_hold(p2, name, absorptions):
     req, _ = build_requires(absorptions)
-    main, _ = PA.poseidon2_chiplet_trace(req)
+    main, _ = PT.poseidon2_chiplet_trace(req)
     cycles = sum(len(a["blocks"]) for a in absorptions)
     assert main.shape == (max(16, 1 << (16 * cycles - 1).bit_length()), 32)
     assert check_local(p2, main) == (0, None), name
@@ -204,7 +205,7 @@ def _bump(row, col):
     ("is_absorb_at_row_0_breaks_boundary", 1, _set_rows(PA.P2C_IS_ABSORB, 1, range(16)))])
 def test_corruption_is_caught(p2, name, n_blocks, corrupt):
     req, _ = build_requires([absorption(0xc0, n_blocks)])
-    main, _ = PA.poseidon2_chiplet_trace(req)
+    main, _ = PT.poseidon2_chiplet_trace(req)
     assert check_local(p2, main) == (0, None)
     corrupt(main)
     bad, _ = check_local(p2, main)
@@ -213,7 +214,7 @@ def test_corruption_is_caught(p2, name, n_blocks, corrupt):
 
 def test_a_wrong_cube_register_and_a_wrong_witness_are_caught(p2):
     req, _ = build_requires([absorption(5, 2)])
-    main, _ = PA.poseidon2_chiplet_trace(req)
+    main, _ = PT.poseidon2_chiplet_trace(req)
     for row, col in ((0, PA.P2C_CUBE + 3), (6, PA.P2C_CUBE + 1), (11, PA.P2C_CUBE + 12), (8, PA.P2C_WITNESS + 2), (2, PA.P2C_WITNESS)):
         bad_main = main.copy()
         bad_main[row, col] = (int(bad_main[row, col]) + 1) % P
@@ -224,8 +225,8 @@ def test_a_wrong_cube_register_and_a_wrong_witness_are_caught(p2):
 @pytest.fixture(scope="module")
 def statement(p2):
     rng = np.random.default_rng(8)
-    ledger = PA.Poseidon2Requires()
-    chunks = PA.ChunkRequires(ledger)
+    ledger = PT.Poseidon2Requires()
+    chunks = PT.ChunkRequires(ledger)
     inputs = [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in (33, 40, 129, 200)]
     readers = []
     for data in inputs + [inputs[1]]:                                   # a repeated input: the chain is reused, in_mult 2
@@ -235,12 +236,12 @@ def statement(p2):
         ledger.require_digest(idx)
     one_shot = ledger.require_absorption([9, 9, 9, 9], [(chunk4(rng), chunk4(rng))])   # another caller's one-shot in the same ledger
     ledger.require_digest(one_shot)
-    p2_main, outs = PA.poseidon2_chiplet_trace(ledger)
-    others = PA.chunk_side_requests(chunks, poseidon2_chiplet=True) + PA.poseidon2_out_requests(ledger, outs)
+    p2_main, outs = PT.poseidon2_chiplet_trace(ledger)
+    others = PT.chunk_side_requests(chunks, poseidon2_chiplet=True) + PT.poseidon2_out_requests(ledger, outs)
     a = ledger.absorptions[one_shot]
     others += [(PA.BUS_POSEIDON2_IN, 1, [a[2], tag] + list(c)) for tag, c in ((0, a[1][0][0]), (1, a[1][0][1]), (2, a[0]))]
     pairs = [PA.chunk_air(host_aux), p2, PA.requirer_air(host_aux, payload=6), PA.ec_groups_air(host_aux)]
-    traces = [PA.chunk_trace(chunks), p2_main, PA.requirer_trace(others, payload=6), PA.ec_groups_trace()]
+    traces = [PT.chunk_trace(chunks), p2_main, PT.requirer_trace(others, payload=6), PT.ec_groups_trace()]
     return pairs, traces, ledger
 
 

@@ -18,6 +18,7 @@ from __graft_entry__ import load_package
 
 pkg = load_package()
 from miden_vm_amd import precompile_airs as PA, dag, protocol  # noqa: E402
+from miden_vm_amd.testing import precompile_trace as PT  # noqa: E402
 
 P = dag.P
 RND = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
@@ -39,9 +40,9 @@ def rnd_bytes(n, seed):
 
 
 def trace_of(inputs):
-    sp = PA.SpongeRequires()
+    sp = PT.SpongeRequires()
     outs = [sp.require(d) for d in inputs]
-    return PA.keccak_sponge_trace(sp), sp, outs
+    return PT.keccak_sponge_trace(sp), sp, outs
 
 
 def check_local(sponge, main, corrupt_aux=None):
@@ -83,8 +84,8 @@ def test_the_period_32_program_is_the_reference_design():
 
 
 def test_block_and_chunk_lane_counts_follow_fips_202():   # trace.rs `num_blocks_matches_fips_202_rule`, `chunk_lanes_round_up_to_32_byte_granularity`
-    assert [PA.SpongeRequires.layout(n)["num_blocks"] for n in (0, 7, 135, 136, 200, 272)] == [1, 1, 1, 2, 2, 3]
-    assert [PA.SpongeRequires.layout(n)["chunk_lanes"] for n in (0, 1, 32, 33, 200)] == [4, 4, 4, 8, 28]
+    assert [PT.SpongeRequires.layout(n)["num_blocks"] for n in (0, 7, 135, 136, 200, 272)] == [1, 1, 1, 2, 2, 3]
+    assert [PT.SpongeRequires.layout(n)["chunk_lanes"] for n in (0, 1, 32, 33, 200)] == [4, 4, 4, 8, 28]
 
 
 def test_known_answers():
@@ -151,21 +152,21 @@ INPUTS = [b"", b"abc", rnd_bytes(135, 11), rnd_bytes(136, 12), rnd_bytes(200, 13
 
 
 def hashing_session(inputs, aux=host_aux):
-    ledger, p2 = PA.BytePairLutRequires(), PA.Poseidon2Requires()
-    chunks = PA.ChunkRequires(p2)
-    sp = PA.SpongeRequires(chunks, ledger)
+    ledger, p2 = PT.BytePairLutRequires(), PT.Poseidon2Requires()
+    chunks = PT.ChunkRequires(p2)
+    sp = PT.SpongeRequires(chunks, ledger)
     digests = []
     for data in inputs:
         out = sp.require(data)
         p2.require_digest(out["chunk_absorption"])
         digests.append(out["keccak_digest"])
-    kr_trace, mem = PA.keccak_round_trace(sp.perm_inputs, ledger)
-    p2_main, outs = PA.poseidon2_chiplet_trace(p2)
-    others = PA.keccak_hash_side_requests(sp, mem) + PA.poseidon2_out_requests(p2, outs)
+    kr_trace, mem = PT.keccak_round_trace(sp.perm_inputs, ledger)
+    p2_main, outs = PT.poseidon2_chiplet_trace(p2)
+    others = PT.keccak_hash_side_requests(sp, mem) + PT.poseidon2_out_requests(p2, outs)
     pairs = [PA.keccak_round_air(aux), PA.byte_pair_lut_air(aux), PA.keccak_sponge_air(aux), PA.chunk_air(aux), PA.poseidon2_chiplet_air(aux),
              PA.requirer_air(aux, payload=6), PA.ec_groups_air(aux)]
-    traces = [kr_trace, PA.byte_pair_lut_trace(ledger), PA.keccak_sponge_trace(sp), PA.chunk_trace(chunks), p2_main,
-              PA.requirer_trace(others, payload=6), PA.ec_groups_trace()]
+    traces = [kr_trace, PT.byte_pair_lut_trace(ledger), PT.keccak_sponge_trace(sp), PT.chunk_trace(chunks), p2_main,
+              PT.requirer_trace(others, payload=6), PT.ec_groups_trace()]
     return pairs, traces, digests, sp, mem
 
 
@@ -179,9 +180,9 @@ def test_the_round_chiplet_computes_what_the_sponge_squeezes(session):
     n = 0
     for rec, digest in zip(sp.invocations, digests):
         for at_start, post_xorin, perm_out in rec["blocks"]:
-            assert PA.keccak_round_outputs(mem, n) == perm_out                      # permutation n of the round chiplet = sponge period n
+            assert PT.keccak_round_outputs(mem, n) == perm_out                      # permutation n of the round chiplet = sponge period n
             n += 1
-        assert b"".join(int(x).to_bytes(8, "little") for x in PA.keccak_round_outputs(mem, n - 1)[:4]) == digest
+        assert b"".join(int(x).to_bytes(8, "little") for x in PT.keccak_round_outputs(mem, n - 1)[:4]) == digest
     assert digests[1] == digests[6] and digests[1].hex().startswith("4e03657a")
 
 

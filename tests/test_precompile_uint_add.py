@@ -21,6 +21,7 @@ from __graft_entry__ import load_package
 
 pkg = load_package()
 from miden_vm_amd import precompile_airs as PA, dag, protocol  # noqa: E402
+from miden_vm_amd.testing import precompile_trace as PT  # noqa: E402
 
 P = dag.P
 RND = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]
@@ -43,7 +44,7 @@ def random_modulus(rng):         # tests/uint.rs: a random asymmetric modulus; t
 
 def sample(rng, force_reduction=False):
     bound = random_modulus(rng)
-    store = PA.UintStore()
+    store = PT.UintStore()
     fp = store.pin_modulus(1, bound)
     if force_reduction:
         a = bv = bound
@@ -52,7 +53,7 @@ def sample(rng, force_reduction=False):
         a, bv = rng.randrange(bound + 1), rng.randrange(bound + 1)
         a_ptr, b_ptr = store.intern_pinned(2, a, fp), store.intern_pinned(3, bv, fp)
     c_ptr = store.intern((a + bv) % (bound + 1), fp)
-    add = PA.UintAddRequires()
+    add = PT.UintAddRequires()
     add.record(a_ptr, b_ptr, c_ptr, fp, 0)
     return add, store, int(a + bv > bound), (a, bv, bound, fp, a_ptr, b_ptr, c_ptr)
 
@@ -67,7 +68,7 @@ def balances(ua, main, store, add):
     """tests/uint_add.rs `fold_balance` over add + store (+ table): here the store's provides and the readers' consumes are the ledgers'
     own tuples, and the balance is the statement's external assertion."""
     pairs = [ua, PA.requirer_air(host_aux, payload=10), PA.ec_groups_air(host_aux)]
-    traces = [main, PA.requirer_trace(store.uint_val_requests() + PA.uint_add_consumer_requests(add), payload=10), PA.ec_groups_trace()]
+    traces = [main, PT.requirer_trace(store.uint_val_requests() + PT.uint_add_consumer_requests(add), payload=10), PT.ec_groups_trace()]
     sig = []
     for (air, lookup), t in zip(pairs, traces):
         _, fin = ob.lookup_build_aux(lookup, t, RND, None)
@@ -86,18 +87,18 @@ def test_layout_and_log_quotient_degree(ua):
 def test_add_constraints_hold_with_and_without_reduction(ua):
     rng = random.Random(0xadd1)
     add, store, _, _ = sample(rng)
-    main = PA.uint_add_trace(add, store)
+    main = PT.uint_add_trace(add, store)
     assert main.shape == (2, 30), "one op = one period-2 block"
     assert any(int(main[r, c]) for r, c in PA.UA_GAMMA_SLOTS), "the add must carry across limbs"
     assert check_local(ua, main) == (0, None)
     add, store, k, _ = sample(random.Random(0xaddc0de), force_reduction=True)
     assert k == 1
-    main = PA.uint_add_trace(add, store)
+    main = PT.uint_add_trace(add, store)
     assert int(main[1, PA.UA_CELL_K]) == 1 and check_local(ua, main) == (0, None)
     for seed in range(20):                                              # other challenges, other operands: the identity is an identity
         add, store, _, _ = sample(random.Random(seed))
         rnd = [(seed * 7 + 1, seed + 5), (0x9e3779b97f4a7c15 % P, seed * 13 + 2)]
-        assert check_local(ua, PA.uint_add_trace(add, store), rnd) == (0, None)
+        assert check_local(ua, PT.uint_add_trace(add, store), rnd) == (0, None)
 
 
 def test_sub_as_arrangement(ua):
@@ -105,20 +106,20 @@ def test_sub_as_arrangement(ua):
     bound = random_modulus(rng)
     x, y = rng.randrange(bound + 1), rng.randrange(bound + 1)
     z = (x - y) % (bound + 1)
-    store = PA.UintStore()
+    store = PT.UintStore()
     fp = store.pin_modulus(1, bound)
-    add = PA.UintAddRequires()
+    add = PT.UintAddRequires()
     add.record(store.intern_pinned(2, y, fp), store.intern_pinned(3, z, fp), store.intern_pinned(4, x, fp), fp, 0)
-    assert check_local(ua, PA.uint_add_trace(add, store)) == (0, None)
+    assert check_local(ua, PT.uint_add_trace(add, store)) == (0, None)
 
 
 def test_duplicate_relations_collapse():
     rng = random.Random(0x0ded0add)
     add, store, _, (a, bv, bound, fp, a_ptr, b_ptr, c_ptr) = sample(rng)
-    add = PA.UintAddRequires()
+    add = PT.UintAddRequires()
     add.record(a_ptr, b_ptr, c_ptr, fp, 1)
     add.record(a_ptr, b_ptr, c_ptr, fp, 1)
-    main = PA.uint_add_trace(add, store)
+    main = PT.uint_add_trace(add, store)
     assert main.shape[0] == 2 and int(main[1, PA.UA_CELL_MULT]) == 2
 
 
@@ -127,9 +128,9 @@ def test_forged_blocks_are_rejected(ua, name):
     rng = random.Random(hash(name) & 0xffff)
     add, store, _, (a, bv, bound, fp, a_ptr, b_ptr, c_ptr) = sample(rng)
     if name.startswith("nz"):
-        add = PA.UintAddRequires()
+        add = PT.UintAddRequires()
         add.record_nz(a_ptr, b_ptr, c_ptr, fp, 0)
-    main = PA.uint_add_trace(add, store)
+    main = PT.uint_add_trace(add, store)
     assert check_local(ua, main) == (0, None)
     if name == "wrong_result":
         main[1, 0] = (int(main[1, 0]) + 1) % P
@@ -148,31 +149,31 @@ def test_sentinel_pointers_and_inactive_blocks(ua):
     rng = random.Random(5)
     bound = random_modulus(rng)
     a = rng.randrange(1, bound + 1)
-    store = PA.UintStore()
+    store = PT.UintStore()
     fp = store.pin_modulus(1, bound)
     a_ptr = store.intern_pinned(2, a, fp)
-    add = PA.UintAddRequires()
+    add = PT.UintAddRequires()
     add.record_eq(a_ptr, a_ptr, fp, 0)
-    main = PA.uint_add_trace(add, store)
+    main = PT.uint_add_trace(add, store)
     assert int(main[0, PA.UA_CELL_FLAG]) == 1 and int(main[0, 8]) == 0 and check_local(ua, main) == (0, None)
     main[0:2, PA.UA_COL_B_PTR] = 3                                      # is_b_zero_rejects_named_operand_ptr
     assert check_local(ua, main)[0] >= 1
     neg_ptr = store.intern_pinned(3, (bound + 1 - a) % (bound + 1), fp)
-    add = PA.UintAddRequires()
+    add = PT.UintAddRequires()
     add.record_to_zero(a_ptr, neg_ptr, fp, 0)
-    main = PA.uint_add_trace(add, store)
+    main = PT.uint_add_trace(add, store)
     assert check_local(ua, main) == (0, None)
     main[0:2, PA.UA_COL_C_PTR] = 4                                      # is_c_zero_rejects_named_result_ptr
     assert check_local(ua, main)[0] >= 1
     # three ops pad to four blocks; the pad block cannot provide (add_inactive_block_cannot_provide)
     ops = [rng.randrange(bound + 1) for _ in range(3)]
-    store = PA.UintStore()
+    store = PT.UintStore()
     fp = store.pin_modulus(1, bound)
     ptrs = [store.intern_pinned(2 + i, x, fp) for i, x in enumerate(ops)]
-    add = PA.UintAddRequires()
+    add = PT.UintAddRequires()
     for l, r in ((0, 1), (1, 2), (0, 0)):
         add.record(ptrs[l], ptrs[r], store.intern((ops[l] + ops[r]) % (bound + 1), fp), fp, 0)
-    main = PA.uint_add_trace(add, store)
+    main = PT.uint_add_trace(add, store)
     assert main.shape[0] == 8 and check_local(ua, main) == (0, None)
     main[7, PA.UA_CELL_MULT] = 1
     assert check_local(ua, main)[0] >= 1
@@ -182,11 +183,11 @@ def test_sentinel_pointers_and_inactive_blocks(ua):
 def test_buses_balance_against_the_store(ua, mode):
     rng = random.Random(0xba1add + len(mode))
     bound = random_modulus(rng)
-    store = PA.UintStore()
+    store = PT.UintStore()
     fp = store.pin_modulus(1, bound)
     a, bv = rng.randrange(1, bound + 1), rng.randrange(1, bound + 1)
     a_ptr, b_ptr = store.intern_pinned(2, a, fp), store.intern_pinned(3, bv, fp)
-    add = PA.UintAddRequires()
+    add = PT.UintAddRequires()
     if mode == "add":
         add.record(a_ptr, b_ptr, store.intern((a + bv) % (bound + 1), fp), fp, 0)
     elif mode == "negation":
@@ -198,7 +199,7 @@ def test_buses_balance_against_the_store(ua, mode):
     else:
         for l, r in ((a, bv), (bv, bv), (a, a)):
             add.record(store.intern(l, fp), store.intern(r, fp), store.intern((l + r) % (bound + 1), fp), fp, 1)
-    main = PA.uint_add_trace(add, store)
+    main = PT.uint_add_trace(add, store)
     if mode == "nz":
         assert int(main[0, PA.UA_COL_NZ]) == 1 and int(main[0, PA.UA_CELL_W]) != 0 and int(main[0, PA.UA_CELL_WS]) == 1
     assert check_local(ua, main) == (0, None)
@@ -212,9 +213,9 @@ def test_buses_balance_against_the_store(ua, mode):
 def test_the_statement_proves_and_verifies_and_forgeries_do_not(ua):
     rng = random.Random(77)
     bound = random_modulus(rng)
-    store = PA.UintStore()
+    store = PT.UintStore()
     fp = store.pin_modulus(1, bound)
-    add = PA.UintAddRequires()
+    add = PT.UintAddRequires()
     vals = [rng.randrange(1, bound + 1) for _ in range(11)]
     ptrs = [store.intern(v, fp) for v in vals]
     for i in range(10):
@@ -222,7 +223,7 @@ def test_the_statement_proves_and_verifies_and_forgeries_do_not(ua):
     add.record_to_zero(ptrs[0], store.intern((bound + 1 - vals[0]) % (bound + 1), fp), fp, 1)
     add.record_eq(ptrs[3], ptrs[3], fp, 2)
     add.record_nz(ptrs[4], ptrs[5], store.intern((vals[4] + vals[5]) % (bound + 1), fp), fp, 1)
-    main = PA.uint_add_trace(add, store)
+    main = PT.uint_add_trace(add, store)
     ok, pairs, traces = balances(ua, main, store, add)
     assert ok and main.shape == (32, 30)
     air_list = [p_[0] for p_ in pairs]

@@ -23,6 +23,7 @@ from __graft_entry__ import load_package
 
 pkg = load_package()
 from miden_vm_amd import precompile_airs as PA, dag, protocol  # noqa: E402
+from miden_vm_amd.testing import precompile_trace as PT  # noqa: E402
 import test_precompile_ec_add as EA  # noqa: E402
 
 P = dag.P
@@ -78,15 +79,15 @@ class Stack:
     """tests/uint_mul.rs `store_with` + `record_mac`: a store with a pinned modulus and operands, MAC relations with one reader each."""
 
     def __init__(self, bound, operands=()):
-        self.store, self.muls = PA.UintStore(), PA.UintMulRequires()
+        self.store, self.muls = PT.UintStore(), PT.UintMulRequires()
         self.fp = self.store.pin_modulus(1, bound)
-        self.req = PA.EcRequire(None, self.store, self.muls)
+        self.req = PT.EcRequire(None, self.store, self.muls)
         self.ptrs = [self.store.intern(v, self.fp) for v in operands]
 
     def traces(self):
-        bpl = PA.BytePairLutRequires()
-        main = PA.uint_store_mul_trace(self.store, self.muls, bpl)
-        return main, PA.byte_pair_lut_trace(bpl), PA.requirer_trace([(bus, (P - m) % P, f) for bus, m, f in self.muls.uint_mul_requests()], payload=10)
+        bpl = PT.BytePairLutRequires()
+        main = PT.uint_store_mul_trace(self.store, self.muls, bpl)
+        return main, PT.byte_pair_lut_trace(bpl), PT.requirer_trace([(bus, (P - m) % P, f) for bus, m, f in self.muls.uint_mul_requests()], payload=10)
 
 
 def test_layout_and_log_quotient_degree(usm):
@@ -127,17 +128,17 @@ def test_uint_store_rejects_tampered_and_out_of_range_values(usm):
     forged[0, 0] = (int(forged[0, 0]) + 1) % P                          # a limb of v: v + comp != bound, the register does not close
     assert check(usm, forged)[0] != 0
     # v > bound with a wrapped complement (bound - v mod 2^256): the limbs add up, the 256-bit sum overflows, and there is no eighth carry
-    v = PA._limbs(rng.randrange(bound + 1), 16, 16)
-    v[15] = PA._limbs(bound, 16, 16)[15] | 0x8000
+    v = PT._limbs(rng.randrange(bound + 1), 16, 16)
+    v[15] = PT._limbs(bound, 16, 16)[15] | 0x8000
     v256 = sum(x << (16 * j) for j, x in enumerate(v))
     comp256 = (bound - v256) % (1 << 256)
     carries, carry = [], 0
     for j in range(7):
-        carry = (PA._limbs(v256, 32, 8)[j] + PA._limbs(comp256, 32, 8)[j] + carry) >> 32
+        carry = (PT._limbs(v256, 32, 8)[j] + PT._limbs(comp256, 32, 8)[j] + carry) >> 32
         carries.append(carry)
     forged = main.copy()
     base = 4 if int(main[4, PA.US_COL_PTR]) != 1 else 0                  # the value's block (the modulus is block 0)
-    forged[base, 0:8], forged[base + 1, 0:8], forged[base + 2, 0:16] = v[0:8], v[8:16], PA._limbs(comp256, 16, 16)
+    forged[base, 0:8], forged[base + 1, 0:8], forged[base + 2, 0:16] = v[0:8], v[8:16], PT._limbs(comp256, 16, 16)
     forged[base + 3, PA.US_CARRY_LO:PA.US_CARRY_LO + 4], forged[base + 3, PA.US_CARRY_HI:PA.US_CARRY_HI + 3] = carries[0:4], carries[4:7]
     assert check(usm, forged)[0] != 0
     forged = main.copy()
@@ -155,7 +156,7 @@ def test_uint_store_gaps_self_referential_padding_and_the_empty_store(usm, bpl_a
     assert [int(main[4 * k, PA.US_COL_PTR]) for k in range(4)] == [1, 5, 100, 101] and [int(main[4 * k + 3, PA.US_TERM_GAP]) for k in range(4)] == [3, 94, 0, 0]
     assert check(usm, main) == (0, None) and closes([usm, bpl_air], [main, table]), "non-trivial gaps + self-referential padding still balance"
     empty = Stack.__new__(Stack)
-    empty.store, empty.muls = PA.UintStore(), PA.UintMulRequires()
+    empty.store, empty.muls = PT.UintStore(), PT.UintMulRequires()
     main, table, _ = empty.traces()
     assert main.shape == (8, 44) and [int(main[4 * k, PA.US_COL_PTR]) for k in range(2)] == [1, 2], "one idle multiplier block = two padding values"
     assert check(usm, main) == (0, None) and closes([usm, bpl_air], [main, table]), "an empty store still closes its buses"
@@ -236,7 +237,7 @@ def test_mul_rejects_wrong_results_and_unchecked_quotients(usm, bpl_air, readers
     assert check(usm, forged)[0] != 0
     # mul_q_range_checks_are_load_bearing: (q0 + 2^16, q1 - 1) is the same quotient at 2^16, the synthetic division still closes with the
     # carries that follow it: every constraint holds, only the table rejects the seventeen-bit limb
-    (_vals, ql, borrow, halves) = PA._um_witness(st.muls.ops[0][0], st.store, forge_q=lambda q: [q[0] + (1 << 16), q[1] - 1] + q[2:])
+    (_vals, ql, borrow, halves) = PT._um_witness(st.muls.ops[0][0], st.store, forge_q=lambda q: [q[0] + (1 << 16), q[1] - 1] + q[2:])
     assert ql[1] >= 0
     forged = main.copy()
     forged[PA.UM_ROW_Q, M:M + PA.UM_NUM_Q_LIMBS] = ql
@@ -254,12 +255,12 @@ def test_mul_rejects_wrong_results_and_unchecked_quotients(usm, bpl_air, readers
 def real_stack_traces(s, min_height=0):
     """`EcStack::traces` (tests/ec_add.rs:137-146) with the real UintStoreMul: relations first, then the store that reads their demand, the
     table last.  -> mains in NUM_STACK order (+ the readers of the EcGroupAdd relations, if any)."""
-    bpl = PA.BytePairLutRequires()
-    add = PA.uint_add_trace(s.adds, s.store, min_height=min_height)
-    ec_add = PA.ec_group_add_trace(s.ec_add, s.ec, bpl, min_height=min_height)
-    uint = PA.uint_store_mul_trace(s.store, s.muls, bpl, min_height=min_height)
-    groups, points = PA.ec_store_traces(s.ec, min_height=min_height)
-    return [PA.byte_pair_lut_trace(bpl), uint, add, groups, points, ec_add]
+    bpl = PT.BytePairLutRequires()
+    add = PT.uint_add_trace(s.adds, s.store, min_height=min_height)
+    ec_add = PT.ec_group_add_trace(s.ec_add, s.ec, bpl, min_height=min_height)
+    uint = PT.uint_store_mul_trace(s.store, s.muls, bpl, min_height=min_height)
+    groups, points = PT.ec_store_traces(s.ec, min_height=min_height)
+    return [PT.byte_pair_lut_trace(bpl), uint, add, groups, points, ec_add]
 
 
 @pytest.fixture(scope="module")
@@ -309,7 +310,7 @@ def test_the_six_chiplet_stack_proves_and_forgeries_do_not(stack_airs):
 
 
 def test_the_arithmetic_session_builder_closes_over_the_fixed_environment():
-    pairs, traces, (final, (store, adds, muls)) = PA.uint_arith_session(20, host_aux=host_aux)
+    pairs, traces, (final, (store, adds, muls)) = PT.uint_arith_session(20, host_aux=host_aux)
     assert len(muls.ops) == 20 and len(adds.ops) == 20 and traces[1].shape == (512, 44), "5 fixed + 2 + 60 values = 67 blocks pad to 128"
     for pair, t in zip(pairs, traces):
         assert check(pair, t) == (0, None), pair[0].name

@@ -10,6 +10,7 @@ from __graft_entry__ import load_package
 
 pkg = load_package()
 from miden_vm_amd import precompile_airs as PA, protocol  # noqa: E402
+from miden_vm_amd.testing import precompile_trace as PT  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAST = dict(log_blowup=3, log_folding_arity=2, log_final_degree=2, folding_pow_bits=1, deep_pow_bits=2, num_queries=5, query_pow_bits=3)
@@ -21,7 +22,7 @@ def test_a_c_program_verifies_the_whole_session(tmp_path):
     lib_dir = os.path.join(ROOT, "miden-vm_amd", "lib")
     subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "verify_session_c_abi.c"),
                            "-L" + lib_dir, "-lmidenhip", "-Wl,-rpath," + lib_dir, "-o", exe])
-    pairs, traces, info = PA.precompile_session([b"abc", b"the quick brown fox"], lambda *a: ob.lookup_build_aux(*a))
+    pairs, traces, info = PT.precompile_session([b"abc", b"the quick brown fox"], lambda *a: ob.lookup_build_aux(*a))
     airs, root = [p[0] for p in pairs], info["public_root"]
     st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)
     proof = ob.prove(airs, traces, root, FAST, init_state=st)

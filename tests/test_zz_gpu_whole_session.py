@@ -8,6 +8,7 @@ import pytest
 import oracle_binding as ob
 from __graft_entry__ import load_package
 from miden_vm_amd import precompile_airs as PA, dag, protocol
+from miden_vm_amd.testing import precompile_trace as PT
 
 pytestmark = pytest.mark.gpu
 P = dag.P
@@ -36,7 +37,7 @@ def test_the_whole_precompile_session_device_proof_equals_oracle(ctx):
     accepted by the oracle's verifier and the library's, only with the full `eval_external` and only for this root (MH_TEST_SESSION_ORACLE=1
     also compares the proof with the oracle's, field for field)."""
     pkg = load_package()
-    pairs, traces, info = PA.precompile_session([b"", b"abc", b"abc", bytes(range(200))], host_aux)
+    pairs, traces, info = PT.precompile_session([b"", b"abc", b"abc", bytes(range(200))], host_aux)
     airs_, lookups, root_pub = [p[0] for p in pairs], [p[1] for p in pairs], info["public_root"]
     ext = PA.external_assertions(pkg, fixed_uints=True)
     st = protocol.challenger_state(PA.PLACEHOLDER_RELATION_DIGEST)

@@ -10,11 +10,12 @@ from __graft_entry__ import load_package
 
 load_package()
 from miden_vm_amd import precompile_airs as PA  # noqa: E402
+from miden_vm_amd.testing import precompile_trace as PT  # noqa: E402
 
 
 def session_blobs():
     """-> [(file stem, dag blob, lkp blob)]"""
-    return [(f"{i:02d}_{name}", air.blob, lookup.blob) for i, (name, (air, lookup)) in enumerate(zip(PA.SessionTraces.NAMES, PA.SessionTraces.airs()))]
+    return [(f"{i:02d}_{name}", air.blob, lookup.blob) for i, (name, (air, lookup)) in enumerate(zip(PT.SessionTraces.NAMES, PT.SessionTraces.airs()))]
 
 
 if __name__ == "__main__":
