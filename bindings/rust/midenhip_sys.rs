@@ -6,7 +6,7 @@
 use core::ffi::{c_char, c_double, c_int, c_long, c_void};
 
 macro_rules! opaque { ($($n:ident),*) => { $( #[repr(C)] pub struct $n { _p: [u8; 0] } )* } }
-opaque!(mh_ctx, mh_trace, mh_tree, mh_air, mh_proof, mh_shard, mh_lookup, mh_session, mh_miden);
+opaque!(mh_ctx, mh_trace, mh_tree, mh_air, mh_proof, mh_shard, mh_lookup, mh_session, mh_miden, mh_precompile);
 
 pub const MH_OK: c_int = 0;
 pub const MH_ERR_INVALID: c_int = 1;
@@ -157,6 +157,17 @@ unsafe extern "C" {
     pub fn mh_verify_lmcs(lmcs: c_int, params: *const mh_pcs_params, n_airs: c_int, air_blobs: *const *const u64, air_blob_words: *const usize, log_trace_heights: *const u8, public_values: *const u64, n_public_values: usize, challenger_state: *const u64, pre_observe: *const u64, n_pre_observe: usize, fields: *const u64, n_fields: usize, commitments: *const u64, n_commitments: usize, preprocessed_root: *const u64, external: mh_external_assertions, external_user: *mut c_void, digest: *mut u64, err: *mut c_char, err_cap: usize) -> c_int;
     pub fn mh_external_logup_balance(user: *mut c_void, randomness: *const u64, n_randomness: usize, aux_values: *const *const u64, n_aux_values: *const usize, log_trace_heights: *const u8, n_airs: c_int, assertions_out: *mut u64, cap: usize) -> c_int;
     pub fn mh_external_precompile_session(user: *mut c_void, randomness: *const u64, n_randomness: usize, aux_values: *const *const u64, n_aux_values: *const usize, log_trace_heights: *const u8, n_airs: c_int, assertions_out: *mut u64, cap: usize) -> c_int;
+    pub fn mh_external_precompile_session_ec_only(user: *mut c_void, randomness: *const u64, n_randomness: usize, aux_values: *const *const u64, n_aux_values: *const usize, log_trace_heights: *const u8, n_airs: c_int, assertions_out: *mut u64, cap: usize) -> c_int;
+    // the precompile prover's session: SessionTraces::prove_stark's own shape (csrc/precompile.cpp)
+    pub fn mh_precompile_pcs_params(out: *mut mh_pcs_params);
+    pub fn mh_precompile_load(ctx: *mut mh_ctx, out: *mut *mut mh_precompile) -> c_int;
+    pub fn mh_precompile_free(s: *mut mh_precompile);
+    pub fn mh_precompile_air_blob(which: c_int, lookup: c_int, words_out: *mut *const u64, n_words: *mut usize) -> c_int;
+    pub fn mh_precompile_preprocessed_root(s: *mut mh_precompile, hash_fn: c_int, root: *mut u64) -> c_int;
+    pub fn mh_precompile_pre_observe(p: *const mh_pcs_params, preprocessed_root: *const u64, public_root: *const u64, out: *mut u64) -> c_int;
+    pub fn mh_prove_precompile(ctx: *mut mh_ctx, s: *mut mh_precompile, hash_fn: c_int, mains_rowmajor: *const *const u64, log_heights: *const c_int, public_root: *const u64, out: *mut *mut mh_proof) -> c_int;
+    pub fn mh_prove_precompile_traces(ctx: *mut mh_ctx, s: *mut mh_precompile, hash_fn: c_int, traces: *const *mut mh_trace, public_root: *const u64, out: *mut *mut mh_proof) -> c_int;
+    pub fn mh_verify_precompile(hash_fn: c_int, preprocessed_root: *const u64, public_root: *const u64, proof_bytes: *const u8, n_bytes: usize, digest: *mut u64, err: *mut c_char, err_cap: usize) -> c_int;
     pub fn mh_proof_deserialize(bytes: *const u8, len: usize, out: *mut *mut mh_proof) -> c_int;
     pub fn mh_trace_upload_sharded(ctx: *mut mh_ctx, comm: *const mh_comm, rowmajor: *const u64, log_n: c_int, width: usize, out: *mut *mut mh_trace) -> c_int;
     pub fn mh_rccl_unique_id(id: *mut u8) -> c_int;

@@ -68,11 +68,10 @@ int main(int argc, char** argv) {
   fclose(f);
   if (forge_root) publics[0] += 1; /* another transcript root: the statement the proof is NOT of (pre_observe still frames the true one) */
 
-  int flag = 1;
   uint64_t digest[4] = {0, 0, 0, 0};
   char err[512] = {0};
   int rc = mh_verify_ex(&params, (int)n_airs, blobs, blob_words, heights, publics, n_public, state, pre, n_pre, fields, n_fields, commitments,
-                        n_commitments, root, mh_external_precompile_session, ec_only ? (void*)&flag : NULL, digest, err, sizeof err);
+                        n_commitments, root, ec_only ? mh_external_precompile_session_ec_only : mh_external_precompile_session, NULL, digest, err, sizeof err);
   if (rc == MH_OK)
     printf("ACCEPTED digest %016llx%016llx%016llx%016llx\n", (unsigned long long)digest[0], (unsigned long long)digest[1],
            (unsigned long long)digest[2], (unsigned long long)digest[3]);

@@ -417,10 +417,53 @@ int mh_external_logup_balance(void* user, const uint64_t* randomness, size_t n_r
 /* A ready-made mh_external_assertions for the second client: `ChipletMultiAir::eval_external` of the precompile prover's session
  * (precompiles-prover/src/session/prove.rs:243-256) = the sum of the committed sigmas + `fixed_boundary_correction` (:205-216), the
  * verifier's consumes of the session's fixed environment (session/fixed.rs: the VM-owned curve group's `EcGroup` tuple, the five fixed
- * uints' `UintVal` tuples).  user = NULL: the whole correction; user -> int 1: the EcGroup part only (statements without the uint store). */
+ * uints' `UintVal` tuples).  Every AIR must expose exactly one aux value (its sigma): any other shape returns -1.  `user` is unused.
+ * `mh_external_precompile_session_ec_only` is the reduced form for statements that leave the uint store out (the EcGroup part of the
+ * correction only) -- a callback of its own name so that the real statement cannot be weakened by a flag passed by mistake. */
 int mh_external_precompile_session(void* user, const uint64_t* randomness, size_t n_randomness, const uint64_t* const* aux_values,
                                    const size_t* n_aux_values, const uint8_t* log_trace_heights, int n_airs, uint64_t* assertions_out,
                                    size_t cap);
+int mh_external_precompile_session_ec_only(void* user, const uint64_t* randomness, size_t n_randomness, const uint64_t* const* aux_values,
+                                           const size_t* n_aux_values, const uint8_t* log_trace_heights, int n_airs,
+                                           uint64_t* assertions_out, size_t cap);
+
+/* ---- the precompile prover's session: SessionTraces::prove_stark's own shape (precompiles-prover/src/session/prove.rs:295-330, 385-416)
+ * Twelve main traces + the transcript root in, proof out -- the statement layer `ChipletMultiAir` adds to the proof system, in the
+ * library (csrc/precompile.cpp) so that a C caller restates nothing:
+ *   - the twelve AIRs of `ChipletAir::all()` (session/prove.rs:111-126: ChunkNode, Poseidon2, KeccakRound, BytePairLut, KeccakSponge,
+ *     TranscriptEval, UintStoreMul, UintAdd, EcGroups, EcPointStore, EcGroupAdd, EcMsm) with their lookup programs, embedded as the
+ *     blobs of miden-vm_amd/blobs/precompile; every aux column (LogUp sums and UintStoreMul's three registers) is built on the device;
+ *   - BytePairLutAir's preprocessed 2^16 x 4 table (primitives/byte_pair_lut.rs:262-277), generated by mh_precompile_load and
+ *     committed once per hash function, on first use (the reference's session/preprocessed_cache.rs);
+ *   - `precompile_pcs_params()` (stark_config.rs:60-71), the placeholder relation digest 0^4 (session/prove.rs:40), the transcript
+ *     prefix `observe_protocol_params` | preprocessed commitment | len(air_inputs) = 4, the root, 0, 0 (the default `MultiAir::observe`,
+ *     crates/lifted-air/src/air.rs:307-324);
+ *   - `ChipletMultiAir::eval_external` = mh_external_precompile_session.
+ * mains_rowmajor[i]: AIR i's main trace, row-major, height 2^log_heights[i], width as the AIR declares (42, 32, 68, 3, 67, 39, 44,
+ * 30, 6, 14, 21, 38), canonical felts; index 3 (BytePairLut) has 2^16 rows.  public_root: the transcript root (`air_inputs`).
+ * hash_fn = MH_LMCS_*. */
+#define MH_PRECOMPILE_NUM_AIRS 12
+#define MH_PRECOMPILE_PRE_OBSERVE_FELTS 19 /* 8 protocol parameters + 4 (preprocessed commitment) + 1 + 4 + 2 (statement framing) */
+typedef struct mh_precompile mh_precompile; /* the twelve AIRs loaded on a context, lookups attached, the byte-pair table uploaded */
+void mh_precompile_pcs_params(mh_pcs_params* out);
+int mh_precompile_load(mh_ctx* ctx, mh_precompile** out);
+void mh_precompile_free(mh_precompile* s);
+/* the embedded blobs, for a caller that drives the generic entry points itself: lookup = 0 the constraint DAG, 1 the lookup program */
+int mh_precompile_air_blob(int which, int lookup, const uint64_t** words_out, size_t* n_words);
+/* the setup commitment of the byte-pair table under hash_fn (made on first use, then cached in `s`): what a verifier must be given */
+int mh_precompile_preprocessed_root(mh_precompile* s, int hash_fn, uint64_t root[4]);
+int mh_precompile_pre_observe(const mh_pcs_params* p, const uint64_t preprocessed_root[4], const uint64_t public_root[4],
+                              uint64_t out[MH_PRECOMPILE_PRE_OBSERVE_FELTS]);
+int mh_prove_precompile(mh_ctx* ctx, mh_precompile* s, int hash_fn, const uint64_t* const mains_rowmajor[MH_PRECOMPILE_NUM_AIRS],
+                        const int log_heights[MH_PRECOMPILE_NUM_AIRS], const uint64_t public_root[4], mh_proof** out);
+/* the same over device-resident traces, in `ChipletAir::all()` order */
+int mh_prove_precompile_traces(mh_ctx* ctx, mh_precompile* s, int hash_fn, mh_trace* const traces[MH_PRECOMPILE_NUM_AIRS],
+                               const uint64_t public_root[4], mh_proof** out);
+/* `verify_stark` (session/prove.rs:365-383, 386-425): StarkProofData bytes -> MH_OK + the transcript digest, or MH_ERR_INVALID + reason.
+ * Host only (no context, no GPU); preprocessed_root = mh_precompile_preprocessed_root of a prover-side context (the reference's
+ * verifier recomputes it from the table; this library has no CPU path for an LDE + Merkle commitment, by design). */
+int mh_verify_precompile(int hash_fn, const uint64_t preprocessed_root[4], const uint64_t public_root[4], const uint8_t* proof_bytes,
+                         size_t n_bytes, uint64_t digest[4], char* err, size_t err_cap);
 
 /* ---- the Miden VM statement: prove_stark's own shape (prover/src/lib.rs:317-355) --------------------------------------------------
  * Three matrices + 32 public values + aux inputs in, proof out -- the statement layer the reference's `MidenMultiAir` adds to the

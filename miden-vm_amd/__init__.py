@@ -31,7 +31,8 @@ EXPORTS = [
     "mh_session_commit_quotient", "mh_session_ood_point_ok", "mh_session_ood", "mh_session_deep", "mh_session_fri_commit",
     "mh_session_fri_fold", "mh_session_fri_final", "mh_session_open", "mh_grind",
     "mh_host_alloc", "mh_host_free", "mh_verify", "mh_trace_from_device", "mh_lookup_load", "mh_lookup_free", "mh_air_attach_lookup", "mh_air_attach_preprocessed", "mh_lookup_build_aux", "mh_trace_download",
-    "mh_verify_ex", "mh_external_logup_balance", "mh_external_precompile_session", "mh_proof_deserialize", "mh_ctx_set_lmcs", "mh_ctx_get_lmcs", "mh_blake3", "mh_verify_lmcs", "mh_grind_bytes",
+    "mh_verify_ex", "mh_external_logup_balance", "mh_external_precompile_session", "mh_external_precompile_session_ec_only", "mh_precompile_pcs_params", "mh_precompile_load", "mh_precompile_free",
+    "mh_precompile_air_blob", "mh_precompile_preprocessed_root", "mh_precompile_pre_observe", "mh_prove_precompile", "mh_prove_precompile_traces", "mh_verify_precompile", "mh_proof_deserialize", "mh_ctx_set_lmcs", "mh_ctx_get_lmcs", "mh_blake3", "mh_verify_lmcs", "mh_grind_bytes",
     "mh_rccl_unique_id", "mh_comm_create_rccl", "mh_comm_destroy", "mh_comm_selftest",
     "mh_local_fabric_create", "mh_local_fabric_destroy", "mh_local_fabric_abort", "mh_comm_create_local",
     "mh_miden_load", "mh_miden_free", "mh_prove_miden", "mh_prove_miden_traces", "mh_verify_miden", "mh_miden_pcs_params",
@@ -698,9 +699,7 @@ def verify(airs, log_trace_heights, public_values, params, challenger_state, pre
     proot = _arr(preprocessed_root) if preprocessed_root is not None else None
     ext_user = None
     if external in ("precompile_session", "precompile_session_ec_only"):   # the library's ChipletMultiAir::eval_external (session/prove.rs:243-256)
-        flag = C.c_int(1 if external.endswith("ec_only") else 0)
-        ext_user = C.cast(C.pointer(flag), C.c_void_p)
-        external = C.cast(lib.mh_external_precompile_session, EXTERNAL_FN)
+        external = C.cast(lib.mh_external_precompile_session_ec_only if external.endswith("ec_only") else lib.mh_external_precompile_session, EXTERNAL_FN)
     if lmcs != "poseidon2":  # mh_verify_lmcs: the other algebraic configurations ("rpo", "rpx")
         ext = C.cast(lib.mh_external_logup_balance, EXTERNAL_FN) if external == "logup_balance" else external
         rc = lib.mh_verify_lmcs(C.c_int(Ctx.LMCS[lmcs]), C.byref(p), C.c_int(n), bp, bl, lh, _ptr(pub), C.c_size_t(len(public_values)),
@@ -769,6 +768,85 @@ def verify_miden(public_values, aux_inputs, proof_bytes, hash_fn="poseidon2"):
     lib.mh_verify_miden.argtypes = [C.c_int, u64p, u64p, C.c_size_t, C.c_void_p, C.c_size_t, u64p, C.c_char_p, C.c_size_t]
     rc = lib.mh_verify_miden(Ctx.LMCS[hash_fn], _ptr(pv), _ptr(aux), len(aux_inputs), buf, len(proof_bytes), _ptr(digest), err, 512)
     return (True, digest) if rc == 0 else (False, err.value.decode())
+
+
+class Precompile:
+    """mh_precompile_load: the twelve AIRs of `ChipletAir::all()` with their lookup programs on a context, the byte-pair table uploaded
+    (its commitment is made per hash function on first use and kept: session/preprocessed_cache.rs).
+    prove(mains[12], public_root[4]) -> Proof: host row-major matrices (mh_prove_precompile) or Trace objects (mh_prove_precompile_traces)
+    -- `SessionTraces::prove_stark`'s shape (precompiles-prover/src/session/prove.rs:295-330)."""
+    WIDTHS = (42, 32, 68, 3, 67, 39, 44, 30, 6, 14, 21, 38)
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx.check(ctx.lib.mh_precompile_load(ctx.h, C.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+
+    def preprocessed_root(self, hash_fn="poseidon2"):
+        root = np.zeros(4, dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.mh_precompile_preprocessed_root(self.h, C.c_int(Ctx.LMCS[hash_fn]), _ptr(root)))
+        return root
+
+    def prove(self, mains, public_root, hash_fn="poseidon2"):
+        lib = self.ctx.lib
+        assert len(mains) == 12
+        root = _arr([int(x) for x in public_root])
+        assert root.size == 4
+        out = C.c_void_p()
+        if all(isinstance(m, Trace) for m in mains):
+            tr = (C.c_void_p * 12)(*[m.h for m in mains])
+            rc = lib.mh_prove_precompile_traces(self.ctx.h, self.h, C.c_int(Ctx.LMCS[hash_fn]), tr, _ptr(root), C.byref(out))
+        else:
+            hs = [np.ascontiguousarray(m, dtype=np.uint64) for m in mains]
+            lg = [int(m.shape[0]).bit_length() - 1 for m in hs]
+            assert tuple(m.shape[1] for m in hs) == self.WIDTHS and all(m.shape[0] == 1 << l for m, l in zip(hs, lg))
+            ptrs = (u64p * 12)(*[_ptr(m) for m in hs])
+            rc = lib.mh_prove_precompile(self.ctx.h, self.h, C.c_int(Ctx.LMCS[hash_fn]), ptrs, (C.c_int * 12)(*lg), _ptr(root), C.byref(out))
+        self.ctx.check(rc)
+        return Proof(lib, out)
+
+    def free(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            self.ctx.lib.mh_precompile_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def verify_precompile(preprocessed_root, public_root, proof_bytes, hash_fn="poseidon2"):
+    """mh_verify_precompile (host only): StarkProofData bytes of a precompile-session proof -> (True, digest) or (False, reason)."""
+    lib = load_library()
+    pr, root = _arr([int(x) for x in preprocessed_root]), _arr([int(x) for x in public_root])
+    buf = (C.c_uint8 * max(1, len(proof_bytes))).from_buffer_copy(bytes(proof_bytes) or b"\0")
+    digest, err = np.zeros(4, dtype=np.uint64), C.create_string_buffer(512)
+    lib.mh_verify_precompile.argtypes = [C.c_int, u64p, u64p, C.c_void_p, C.c_size_t, u64p, C.c_char_p, C.c_size_t]
+    rc = lib.mh_verify_precompile(Ctx.LMCS[hash_fn], _ptr(pr), _ptr(root), buf, len(proof_bytes), _ptr(digest), err, 512)
+    return (True, digest) if rc == 0 else (False, err.value.decode())
+
+
+def precompile_pre_observe(params, preprocessed_root, public_root):
+    """mh_precompile_pre_observe: observe_protocol_params | preprocessed commitment | the default statement framing (19 felts)."""
+    lib = load_library()
+    p = params if isinstance(params, PcsParams) else PcsParams.from_dict(params)
+    pr, root, out = _arr([int(x) for x in preprocessed_root]), _arr([int(x) for x in public_root]), np.zeros(19, dtype=np.uint64)
+    if lib.mh_precompile_pre_observe(C.byref(p), _ptr(pr), _ptr(root), _ptr(out)) != 0:
+        raise MidenHipError("mh_precompile_pre_observe failed")
+    return [int(x) for x in out]
+
+
+def precompile_air_blob(which, lookup=False):
+    """mh_precompile_air_blob: the embedded constraint DAG (lookup=False) or lookup program of AIR `which` of `ChipletAir::all()`."""
+    lib = load_library()
+    w, n = u64p(), C.c_size_t(0)
+    if lib.mh_precompile_air_blob(C.c_int(which), C.c_int(1 if lookup else 0), C.byref(w), C.byref(n)) != 0:
+        raise MidenHipError("mh_precompile_air_blob: no such AIR")
+    return np.ctypeslib.as_array(w, shape=(n.value,)).copy()
 
 
 def miden_pre_observe(params, public_values, aux_inputs):

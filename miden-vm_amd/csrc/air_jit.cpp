@@ -51,9 +51,8 @@ FI u64 gl_reduce128_lazy(u64 hi, u64 lo) {  // gl_reduce128 without its last lin
 }
 FI u64 gl_mul_c(u64 a, u64 b) { const u128 p = (u128)a * b; return gl_reduce128((u64)(p >> 64), (u64)p); }  // one 64 x 64 -> 128 product (four v_mad_u64_u32), not __umul64hi + a second low product
 #ifndef MH_JIT_ASM_MUL
-// 0: plain C products, 1: the asm product everywhere, 2: for base-field gates only (round 4, core AIR: 19.6 / 19.9 / 18.7 ms),
-// 3: the merged-statement asm product everywhere, extension-field products included (round 6, the default; lz_mul_asm3 below)
-#define MH_JIT_ASM_MUL 3
+// 0: plain C products, 1: the asm product everywhere (the default since round 6), 2: for base-field gates only (rounds 4-5)
+#define MH_JIT_ASM_MUL 1
 #endif
 #if MH_JIT_ASM_MUL
 // the 13-instruction SGPR-carry-chain product of poseidon2_fast.cuh (p2f_mul_nv: non-volatile statements carrying their own
@@ -192,56 +191,22 @@ FI u64 lz_mul_asm(u64 a, u64 b) {  // the 13 instructions of gl_mul above, witho
 }
 #endif
 #if MH_JIT_ASM_MUL
-// The same 13 instructions with the carry chains INSIDE two statements (MH_JIT_ASM_MUL=3, round 6).  In the form above every carry is
-// an SGPR-pair output of its own statement (eleven per product, six of them never read): the scheduler interleaves several products
-// and the pairs of all of them are alive at once -- in the chunks of extension-field gates, next to the uniform coefficients the scalar
-// unit holds there, hipcc spilled them into VGPR lanes (116 v_writelane / v_readlane pairs per chunk, round 5), which is why the EF
-// products stayed in C at 25 instructions each: 618 of them per point in the core AIR, 30 % of its VALU instructions.  Here the
-// unused carry-outs go to vcc, the chains k1 -> k2 -> k3 and bb -> bw -> c3 -> mk run through vcc inside one statement each with their
-// wait states, and only `cm` and `c1` (one pair each, from a v_mad_u64_u32 to the next statement) are ever allocated.
-FI u64 lz_mul_asm3(u64 a, u64 b) {
-  u64 p00, m, hi, t, cm, c1, s1;
-  u32 w1, accl, acch, rl, rh;
-  const u32 zero = 0;
-  asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p00) : "v"(jlo(a)), "v"(jlo(b)) : "vcc");
-  asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(m) : "v"(jlo(a)), "v"(jhi(b)) : "vcc");
-  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m), "=s"(cm) : "v"(jhi(a)), "v"(jlo(b)), "0"(m));
-  // in place: w1 over p00.hi -- (p00.lo, w1) is then a register pair --, and (accl, acch) over (m.lo, m.hi), free once w1 has read m.lo
-  w1 = jhi(p00); accl = jlo(m); acch = jhi(m);
-  asm("v_add_co_u32_e64 %0, vcc, %0, %1\n\t"          // w1 = p00.hi + m.lo            (k1 -> vcc)
-      "s_nop 1\n\t"
-      "v_addc_co_u32_e64 %1, vcc, %2, 0, vcc\n\t"      // accl = m.hi + k1              (k2 -> vcc)
-      "s_or_b64 vcc, vcc, %4\n\t"                      // k3 = k2 | cm
-      "v_addc_co_u32_e64 %2, vcc, %3, 0, vcc"            // acch = k3
-      : "+v"(w1), "+v"(accl), "+v"(acch) : "v"(zero), "s"(cm) : "vcc");
-  const u64 acc = ((u64)acch << 32) | accl;
-  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(hi) : "v"(jhi(a)), "v"(jhi(b)), "v"(acc) : "vcc");
-  const u64 lo = ((u64)w1 << 32) | jlo(p00);
-  asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t), "=s"(c1) : "v"(jlo(hi)), "v"(lo));
-  asm("s_nop 1\n\t"
-      "v_subb_co_u32_e64 %0, vcc, %4, %6, %2\n\t"      // rl = t.lo - hi.hi - c1        (bb -> vcc)
-      "v_addc_co_u32_e64 %1, %3, %5, 0, %2\n\t"        // rh = t.hi + c1
-      "s_nop 0\n\t"
-      "v_subb_co_u32_e64 %1, vcc, %1, 0, vcc\n\t"      // rh -= bb                      (bw -> vcc)
-      "s_nop 1\n\t"
-      "v_addc_co_u32_e64 %0, %2, %0, 0, vcc\n\t"       // rl += bw                      (c3 -> %2)
-      "s_nop 0\n\t"
-      "s_andn2_b64 %2, vcc, %2\n\t"                    // mk = bw & ~c3
-      "v_subb_co_u32_e64 %1, vcc, %1, 0, %2"             // rh -= mk
-      : "=&v"(rl), "=&v"(rh), "+s"(c1), "=&s"(s1) : "v"(jlo(t)), "v"(jhi(t)), "v"(jhi(hi)) : "vcc");
-  return ((u64)rh << 32) | rl;
-}
-#endif
-#if MH_JIT_ASM_MUL == 3
-#define lz_mul lz_mul_asm3
-#elif MH_JIT_ASM_MUL
 #define lz_mul lz_mul_asm
 #else
 #define lz_mul lz_mul_c
 #endif
-#if MH_JIT_ASM_MUL == 3
-#define lz_mul_ef lz_mul_asm3
-#elif MH_JIT_ASM_MUL == 1
+// Extension-field products: the asm product too since round 6 (MH_JIT_ASM_MUL=1).  Round 5 kept them in C (25 VALU per base product
+// against 13: 618 of them per point in the core AIR, 30 % of its instructions) because the asm form's SGPR carries spilled into VGPR
+// lanes in the EF chunks; with the any-representative arithmetic, the uniform table and the 200-register chunk budget in place that no
+// longer happens (0 v_writelane in all ten chunks) and the core AIR's quotient goes 12.98 -> 12.80 ms for 10 % fewer VALU
+// instructions -- the chunks are bound by dependent-issue and load latency at 2-3 waves per SIMD, not by the instruction count alone.
+// Tried on top and dropped (round 6, profiles/r06_jit_core.txt): the carry chains of a product MERGED into two multi-instruction
+// statements (k1 -> k2 -> k3 and bb -> bw -> c3 -> mk through vcc, two SGPR pairs per product instead of eleven outputs): correct in
+// isolation (tools/jit_mulcheck: 6.3 M products incl. 48 k on the borrow path), wrong digests / a memory fault inside the chunks --
+// the statements contain s_or_b64 / s_andn2_b64, which write SCC, and hipcc keeps SCC alive across an asm statement that does not
+// declare it (the carry of its own s_add_u32 / s_addc_u32 address arithmetic) -- and 1-7 % SLOWER once fenced: the scheduler can no
+// longer interleave the links of several products.
+#if MH_JIT_ASM_MUL == 1
 #define lz_mul_ef lz_mul_asm
 #else
 #define lz_mul_ef lz_mul_c
@@ -1061,9 +1026,44 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
     };
     bool any_fold = false;
     if (!fuse) fold_terms = 0;
-    for (const Item& it : items[ci]) {
+    // $MH_JIT_PREFETCH = K > 0: a load (cell, periodic value, spilled value) is issued K items AHEAD of its first use instead of at it
+    // -- between "all at the top" (MH_JIT_LAZY=0: every cell of the chunk alive from its first instruction) and "at first use" (the
+    // wave waits out the full HBM latency unless the compiler hoists the load itself).
+    std::vector<Item> order;
+    {
+      const long K = std::max(0, env_int("MH_JIT_PREFETCH", 0));
+      const std::vector<Item>& its = items[ci];
+      if (K == 0 || !lazy_loads) {
+        order = its;
+      } else {
+        std::vector<char> emitted(its.size(), 0);
+        std::set<uint32_t> seen_leaf;
+        std::vector<uint32_t> o;
+        size_t ahead = 0;  // items below this index have been scanned for loads
+        auto scan = [&](size_t j) {
+          const Item& x = its[j];
+          if (x.fold_k == -2) { order.push_back(x); emitted[j] = 1; return; }
+          auto leaf = [&](uint32_t c) {
+            const int op = nodes[c].op;
+            if ((op == DOP_MAIN || op == DOP_AUX || op == DOP_PREP || op == DOP_PERIODIC) && seen_leaf.insert(c).second) order.push_back({c, -3});
+          };
+          if (x.fold_k >= 0) { leaf(x.node); return; }
+          ops(x.node, o);
+          for (uint32_t c : o) leaf(c);
+        };
+        for (size_t i = 0; i < its.size(); i++) {
+          for (; ahead < its.size() && ahead <= i + (size_t)K; ahead++) scan(ahead);
+          if (!emitted[i]) order.push_back(its[i]);
+        }
+      }
+    }
+    for (const Item& it : order) {
       const uint32_t id = it.node;
       const DagNode& nd = nodes[id];
+      if (it.fold_k == -3) {  // prefetch: the leaf's load goes here
+        (void)ref(id);
+        continue;
+      }
       if (it.fold_k == -2) {  // produced by an earlier chunk: from its spill plane(s)
         if (nd.ext)
           ld << "  const e2 v" << id << " = {" << spill_ref(slot[id]) << ", " << spill_ref(slot[id] + 1) << "};\n";

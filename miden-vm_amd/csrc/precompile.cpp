@@ -1,0 +1,243 @@
+// The precompile prover's session statement above the proof system, in C++ behind the C ABI: what a caller of
+// `SessionTraces::prove_stark(hash_fn)` (precompiles-prover/src/session/prove.rs:295-330, 385-416: twelve main traces + the transcript
+// root -> StarkProofData bytes) gets from `ChipletMultiAir` in the reference, with no Python and no Rust in between -- the second
+// client's counterpart of csrc/miden.cpp.
+//
+//   * the twelve AIRs of `ChipletAir::all()` (session/prove.rs:111-126) and their lookup programs (LogUp columns, and the three
+//     register columns of UintStoreMul), embedded as the blobs of miden-vm_amd/blobs/precompile (tests/test_precompile_blobs.py keeps
+//     them equal to what precompile_airs.py generates); every aux column is built on the device;
+//   * the one PREPROCESSED matrix of the stack, BytePairLutAir's 2^16-row table (a, b, !a & b, a ^ b)
+//     (primitives/byte_pair_lut.rs:262-277), generated here, committed ONCE per hash function and kept -- the reference's
+//     `session/preprocessed_cache.rs`;
+//   * `precompile_pcs_params()` (stark_config.rs:60-71), the placeholder relation digest (session/prove.rs:40), the statement framing
+//     of the default `MultiAir::observe` (crates/lifted-air/src/air.rs:307-324) after `observe_protocol_params` and the preprocessed
+//     commitment (crates/lifted-stark/src/prover/mod.rs:282-286);
+//   * `ChipletMultiAir::eval_external` (session/prove.rs:243-256) = mh_external_precompile_session (csrc/verifier.cpp).
+//
+// Written against the public ABI only (include/midenhip.h).  The Python test layer (miden-vm_amd/__init__.py + precompile_airs.py)
+// does the same steps one by one; tests/test_gpu_precompile_c_abi.py compares the two and the oracle byte for byte.
+#include "../../include/midenhip.h"
+#include "ctx.hpp"
+#include "gl.cuh"
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#define MH_EMBED(sym, path)                                                                                           \
+  asm(".section .rodata\n.balign 8\n.global " #sym "\n" #sym ":\n.incbin \"" path "\"\n.global " #sym "_end\n" #sym "_end:\n.previous\n"); \
+  extern "C" const unsigned char sym[], sym##_end[];
+#define MH_EMBED_AIR(n, stem) MH_EMBED(mh_blob_pc##n##_dag, "../blobs/precompile/" stem ".dag") MH_EMBED(mh_blob_pc##n##_lkp, "../blobs/precompile/" stem ".lkp")
+MH_EMBED_AIR(0, "00_chunk_node")
+MH_EMBED_AIR(1, "01_poseidon2")
+MH_EMBED_AIR(2, "02_keccak_round")
+MH_EMBED_AIR(3, "03_byte_pair_lut")
+MH_EMBED_AIR(4, "04_keccak_sponge")
+MH_EMBED_AIR(5, "05_transcript_eval")
+MH_EMBED_AIR(6, "06_uint_store_mul")
+MH_EMBED_AIR(7, "07_uint_add")
+MH_EMBED_AIR(8, "08_ec_groups")
+MH_EMBED_AIR(9, "09_ec_point_store")
+MH_EMBED_AIR(10, "10_ec_group_add")
+MH_EMBED_AIR(11, "11_ec_msm")
+
+namespace {
+
+constexpr int N_AIRS = MH_PRECOMPILE_NUM_AIRS;
+constexpr int BYTE_PAIR_LUT = 3;          // its index in ChipletAir::all()
+constexpr int LOG_BPL_HEIGHT = 16;        // BPL_TRACE_HEIGHT (byte_pair_lut.rs)
+constexpr size_t N_PUBLIC = 4;            // air_inputs = the transcript root (session/mod.rs `air_inputs`)
+constexpr int N_LMCS = 5;                 // MH_LMCS_POSEIDON2 .. MH_LMCS_RPX
+
+std::vector<u64> words(const unsigned char* b, const unsigned char* e) {
+  std::vector<u64> v((size_t)(e - b) / 8);
+  memcpy(v.data(), b, v.size() * 8);
+  return v;
+}
+struct Blobs {
+  std::vector<u64> dag[N_AIRS], lkp[N_AIRS];
+  Blobs() {
+#define MH_TAKE(n) dag[n] = words(mh_blob_pc##n##_dag, mh_blob_pc##n##_dag_end); lkp[n] = words(mh_blob_pc##n##_lkp, mh_blob_pc##n##_lkp_end);
+    MH_TAKE(0) MH_TAKE(1) MH_TAKE(2) MH_TAKE(3) MH_TAKE(4) MH_TAKE(5) MH_TAKE(6) MH_TAKE(7) MH_TAKE(8) MH_TAKE(9) MH_TAKE(10) MH_TAKE(11)
+#undef MH_TAKE
+  }
+};
+const Blobs& blobs() {
+  static const Blobs b;
+  return b;
+}
+
+bool lmcs_ok(int h) { return h >= 0 && h < N_LMCS; }
+
+}  // namespace
+
+struct mh_precompile {
+  mh_ctx* ctx = nullptr;
+  mh_air* airs[N_AIRS] = {};
+  mh_lookup* lookups[N_AIRS] = {};
+  mh_trace* table = nullptr;            // the byte-pair table, uploaded once
+  mh_tree* table_tree[N_LMCS] = {};     // ... committed once per hash function (preprocessed_cache.rs)
+  u64 table_root[N_LMCS][4] = {};
+};
+
+extern "C" {
+
+void mh_precompile_pcs_params(mh_pcs_params* out) {  // stark_config.rs:60-71
+  if (!out) return;
+  out->log_blowup = 3; out->log_folding_arity = 2; out->log_final_degree = 7; out->folding_pow_bits = 4;
+  out->deep_pow_bits = 12; out->num_queries = 27; out->query_pow_bits = 16;
+}
+
+int mh_precompile_air_blob(int which, int lookup, const uint64_t** words_out, size_t* n_words) {
+  if (which < 0 || which >= N_AIRS || !words_out || !n_words) return MH_ERR_INVALID;
+  const std::vector<u64>& v = lookup ? blobs().lkp[which] : blobs().dag[which];
+  *words_out = v.data();
+  *n_words = v.size();
+  return MH_OK;
+}
+
+int mh_precompile_pre_observe(const mh_pcs_params* p, const uint64_t preprocessed_root[4], const uint64_t public_root[4],
+                              uint64_t out[MH_PRECOMPILE_PRE_OBSERVE_FELTS]) {
+  if (!p || !preprocessed_root || !public_root || !out) return MH_ERR_INVALID;
+  size_t k = 0;
+  // observe_protocol_params (stark_config.rs, as air/src/config.rs:188-198)
+  const u64 head[8] = {(u64)p->num_queries, (u64)p->query_pow_bits, (u64)p->deep_pow_bits, (u64)p->folding_pow_bits, (u64)p->log_blowup,
+                       (u64)p->log_final_degree, (u64)1 << p->log_folding_arity, 0};
+  for (u64 v : head) out[k++] = v;
+  for (int i = 0; i < 4; i++) out[k++] = preprocessed_root[i];          // prover/mod.rs:282-286
+  out[k++] = N_PUBLIC;                                                  // lifted-air/src/air.rs:307-324: len(air_inputs), air_inputs,
+  for (int i = 0; i < 4; i++) out[k++] = gl_canon(public_root[i]);
+  out[k++] = 0;                                                         // max_aux_inputs,
+  out[k++] = 0;                                                         // len(aux_inputs)
+  return k == MH_PRECOMPILE_PRE_OBSERVE_FELTS ? MH_OK : MH_ERR_INTERNAL;
+}
+
+void mh_precompile_free(mh_precompile* s) {
+  if (!s) return;
+  for (int i = 0; i < N_AIRS; i++) {
+    if (s->airs[i]) mh_air_free(s->airs[i]);
+    if (s->lookups[i]) mh_lookup_free(s->lookups[i]);
+  }
+  for (mh_tree* t : s->table_tree)
+    if (t) mh_tree_free(t);
+  if (s->table) mh_trace_free(s->table);
+  delete s;
+}
+
+int mh_precompile_load(mh_ctx* ctx, mh_precompile** out) {
+  if (!ctx || !out) return MH_ERR_INVALID;
+  std::unique_ptr<mh_precompile, void (*)(mh_precompile*)> s(new mh_precompile(), mh_precompile_free);
+  s->ctx = ctx;
+  const Blobs& b = blobs();
+  for (int i = 0; i < N_AIRS; i++) {
+    int rc = mh_air_load(ctx, b.dag[i].data(), b.dag[i].size(), &s->airs[i]);
+    if (rc == MH_OK) rc = mh_lookup_load(ctx, b.lkp[i].data(), b.lkp[i].size(), &s->lookups[i]);
+    if (rc == MH_OK) rc = mh_air_attach_lookup(s->airs[i], s->lookups[i]);
+    if (rc != MH_OK) return rc;
+  }
+  // `preprocessed_table` (byte_pair_lut.rs:262-277): every (a, b) in lexicographic order, row a << 8 | b = (a, b, !a & b, a ^ b)
+  std::vector<u64> tab((size_t)4 << LOG_BPL_HEIGHT);
+  for (u64 idx = 0; idx < ((u64)1 << LOG_BPL_HEIGHT); idx++) {
+    const u64 a = idx >> 8, bb = idx & 0xff;
+    tab[4 * idx] = a; tab[4 * idx + 1] = bb; tab[4 * idx + 2] = (~a & 0xff) & bb; tab[4 * idx + 3] = a ^ bb;
+  }
+  const int rc = mh_trace_upload(ctx, tab.data(), LOG_BPL_HEIGHT, 4, &s->table);
+  if (rc != MH_OK) return rc;
+  *out = s.release();
+  return MH_OK;
+}
+
+// the setup commitment under `hash_fn`, made on first use and kept (session/preprocessed_cache.rs keeps one per StarkConfig)
+static int table_commitment(mh_precompile* s, int hash_fn, const mh_pcs_params& prm) {
+  if (s->table_tree[hash_fn]) return MH_OK;
+  const int old = mh_ctx_get_lmcs(s->ctx);
+  int rc = mh_ctx_set_lmcs(s->ctx, hash_fn);
+  if (rc != MH_OK) return rc;
+  mh_trace* one[1] = {s->table};
+  rc = mh_commit_traces(s->ctx, 1, one, prm.log_blowup, &s->table_tree[hash_fn], s->table_root[hash_fn]);
+  const std::string err = s->ctx->err;
+  (void)mh_ctx_set_lmcs(s->ctx, old);
+  if (rc != MH_OK) s->ctx->err = err;
+  return rc;
+}
+
+int mh_precompile_preprocessed_root(mh_precompile* s, int hash_fn, uint64_t root[4]) {
+  if (!s || !root || !lmcs_ok(hash_fn)) return MH_ERR_INVALID;
+  mh_pcs_params prm;
+  mh_precompile_pcs_params(&prm);
+  const int rc = table_commitment(s, hash_fn, prm);
+  if (rc != MH_OK) return rc;
+  memcpy(root, s->table_root[hash_fn], 32);
+  return MH_OK;
+}
+
+static int prove_common(mh_ctx* ctx, mh_precompile* s, int hash_fn, const uint64_t* const* host_rm, const int* log_heights, mh_trace* const* traces,
+                        const uint64_t* public_root, mh_proof** out) {
+  if (!ctx || !s || s->ctx != ctx || !out || !public_root || !lmcs_ok(hash_fn)) return MH_ERR_INVALID;
+  mh_pcs_params prm;
+  mh_precompile_pcs_params(&prm);
+  int rc = table_commitment(s, hash_fn, prm);
+  if (rc != MH_OK) return rc;
+  rc = mh_air_attach_preprocessed(s->airs[BYTE_PAIR_LUT], s->table_tree[hash_fn], 0, s->table);
+  if (rc != MH_OK) return rc;
+  u64 pre[MH_PRECOMPILE_PRE_OBSERVE_FELTS], state[12] = {0};  // PLACEHOLDER_RELATION_DIGEST = 0^4 in the capacity (session/prove.rs:40)
+  rc = mh_precompile_pre_observe(&prm, s->table_root[hash_fn], public_root, pre);
+  if (rc != MH_OK) return rc;
+  u64 pub[N_PUBLIC];
+  for (size_t i = 0; i < N_PUBLIC; i++) pub[i] = gl_canon(public_root[i]);
+  const int old = mh_ctx_get_lmcs(ctx);
+  rc = mh_ctx_set_lmcs(ctx, hash_fn);
+  if (rc != MH_OK) return rc;
+  if (traces)
+    rc = mh_prove(ctx, &prm, N_AIRS, s->airs, traces, pub, N_PUBLIC, state, pre, MH_PRECOMPILE_PRE_OBSERVE_FELTS, nullptr, nullptr, out);
+  else
+    rc = mh_prove_host(ctx, &prm, N_AIRS, s->airs, host_rm, log_heights, pub, N_PUBLIC, state, pre, MH_PRECOMPILE_PRE_OBSERVE_FELTS, nullptr, nullptr,
+                       out);
+  const std::string err = ctx->err;
+  (void)mh_ctx_set_lmcs(ctx, old);
+  if (rc != MH_OK) ctx->err = err;
+  return rc;
+}
+
+int mh_prove_precompile(mh_ctx* ctx, mh_precompile* s, int hash_fn, const uint64_t* const mains_rowmajor[MH_PRECOMPILE_NUM_AIRS],
+                        const int log_heights[MH_PRECOMPILE_NUM_AIRS], const uint64_t public_root[4], mh_proof** out) {
+  if (!mains_rowmajor || !log_heights) return MH_ERR_INVALID;
+  if (log_heights[BYTE_PAIR_LUT] != LOG_BPL_HEIGHT) {  // the table's multiplicity columns: one row per (a, b)
+    if (ctx) ctx->err = "mh_prove_precompile: the BytePairLut trace (index 3) has 2^16 rows";
+    return MH_ERR_INVALID;
+  }
+  return prove_common(ctx, s, hash_fn, mains_rowmajor, log_heights, nullptr, public_root, out);
+}
+int mh_prove_precompile_traces(mh_ctx* ctx, mh_precompile* s, int hash_fn, mh_trace* const traces[MH_PRECOMPILE_NUM_AIRS],
+                               const uint64_t public_root[4], mh_proof** out) {
+  if (!traces) return MH_ERR_INVALID;
+  return prove_common(ctx, s, hash_fn, nullptr, nullptr, traces, public_root, out);
+}
+
+int mh_verify_precompile(int hash_fn, const uint64_t preprocessed_root[4], const uint64_t public_root[4], const uint8_t* proof_bytes,
+                         size_t n_bytes, uint64_t digest[4], char* err, size_t err_cap) {
+  auto fail = [&](const char* msg) {
+    if (err && err_cap) snprintf(err, err_cap, "%s", msg);
+    return MH_ERR_INVALID;
+  };
+  if (!proof_bytes || !digest || !preprocessed_root || !public_root || !lmcs_ok(hash_fn)) return fail("null or malformed argument");
+  mh_pcs_params prm;
+  mh_precompile_pcs_params(&prm);
+  u64 pre[MH_PRECOMPILE_PRE_OBSERVE_FELTS], state[12] = {0};
+  if (mh_precompile_pre_observe(&prm, preprocessed_root, public_root, pre) != MH_OK) return fail("malformed statement");
+  mh_proof* p = nullptr;
+  if (mh_proof_deserialize(proof_bytes, n_bytes, &p) != MH_OK) return fail("malformed proof bytes");
+  std::unique_ptr<mh_proof, void (*)(mh_proof*)> hold(p, mh_proof_free);
+  if (mh_proof_num_traces(p) != N_AIRS) return fail("a precompile-session proof has twelve traces");
+  const Blobs& b = blobs();
+  const uint64_t* blob_ptr[N_AIRS];
+  size_t blob_len[N_AIRS];
+  for (int i = 0; i < N_AIRS; i++) { blob_ptr[i] = b.dag[i].data(); blob_len[i] = b.dag[i].size(); }
+  u64 pub[N_PUBLIC];
+  for (size_t i = 0; i < N_PUBLIC; i++) pub[i] = gl_canon(public_root[i]);
+  return mh_verify_lmcs(hash_fn, &prm, N_AIRS, blob_ptr, blob_len, mh_proof_log_trace_heights(p), pub, N_PUBLIC, state, pre,
+                        MH_PRECOMPILE_PRE_OBSERVE_FELTS, mh_proof_fields(p), mh_proof_num_fields(p), mh_proof_commitments(p),
+                        mh_proof_num_commitments(p), preprocessed_root, mh_external_precompile_session, nullptr, digest, err, err_cap);
+}
+
+}  // extern "C"

@@ -616,12 +616,16 @@ int mh_external_logup_balance(void* user, const uint64_t* randomness, size_t n_r
 // (session/fixed.rs): one `EcGroup` tuple per VM-owned curve group and one `UintVal` tuple per fixed uint (the three domain bounds,
 // secp256k1's two coefficients), each as the inverse of its encoded denominator under `Challenges::new(alpha, beta, MAX_MESSAGE_WIDTH = 18,
 // NUM_BUS_IDS = 21)` (logup/mod.rs; relations.rs:52-91): bus_prefix[b] = alpha + beta^18 (b + 1), message = prefix + sum_i beta^i f_i.
-// user = NULL: the whole correction; user -> int 1: the EcGroup part only (statements that leave the uint store out).
-int mh_external_precompile_session(void* user, const uint64_t* randomness, size_t n_randomness, const uint64_t* const* aux_values,
-                                   const size_t* n_aux_values, const uint8_t* log_trace_heights, int n_airs, uint64_t* assertions_out,
-                                   size_t cap) {
-  (void)log_trace_heights;
+// Every AIR of the session commits exactly ONE sigma (`aux_values[i]` is AIR i's exposed permutation values -- exactly one, its
+// sigma: session/prove.rs:243-247): any other shape is refused, as csrc/miden.cpp refuses it for the VM statement.
+// `mh_external_precompile_session` is the whole correction -- what the reference's verifier checks; the reduced form the smaller
+// test statements need (those that leave the uint store out: the EcGroup part only) is a callback of its own name,
+// `mh_external_precompile_session_ec_only`, so that no flag passed by mistake weakens the real one.
+static int precompile_session_external(bool fixed_uints, const uint64_t* randomness, size_t n_randomness, const uint64_t* const* aux_values,
+                                       const size_t* n_aux_values, int n_airs, uint64_t* assertions_out, size_t cap) {
   if (!assertions_out || cap < 1 || n_airs < 0 || n_randomness < 2 || !randomness || (n_airs && (!aux_values || !n_aux_values))) return -1;
+  for (int i = 0; i < n_airs; i++)
+    if (n_aux_values[i] != 1 || !aux_values[i]) return -1;
   static const int MAX_MESSAGE_WIDTH = 18, BUS_UINT_VAL = 10, BUS_EC_GROUP = 14;
   static const u64 U256_BOUND_PTR = 1, K1_BASE_BOUND_PTR = 2, K1_SCALAR_BOUND_PTR = 3, K1_A_PTR = 8, K1_B_PTR = 9, K1_GROUP_PTR = 1;
   struct FixedUint {
@@ -638,8 +642,7 @@ int mh_external_precompile_session(void* user, const uint64_t* randomness, size_
   bp[0] = e2_make(1);
   for (int i = 1; i <= MAX_MESSAGE_WIDTH; i++) bp[i] = e2_mul(bp[i - 1], beta);
   e2 acc = e2_make(0);
-  for (int i = 0; i < n_airs; i++)
-    if (n_aux_values[i]) acc = e2_add(acc, e2{gl_canon(aux_values[i][0]), gl_canon(aux_values[i][1])});
+  for (int i = 0; i < n_airs; i++) acc = e2_add(acc, e2{gl_canon(aux_values[i][0]), gl_canon(aux_values[i][1])});
   bool zero_denominator = false;
   auto consume = [&](int bus, const u64* fields, int n) {
     e2 d = e2_add(alpha, e2_mulf(bp[MAX_MESSAGE_WIDTH], (u64)(bus + 1)));
@@ -652,7 +655,7 @@ int mh_external_precompile_session(void* user, const uint64_t* randomness, size_
   };
   const u64 k1_group[5] = {K1_GROUP_PTR, K1_A_PTR, K1_B_PTR, K1_BASE_BOUND_PTR, K1_SCALAR_BOUND_PTR};
   consume(BUS_EC_GROUP, k1_group, 5);
-  if (!(user && *(const int*)user == 1))
+  if (fixed_uints)
     for (const FixedUint& u : uints) {
       u64 f[10] = {u.ptr, u.bound_ptr};
       for (int j = 0; j < 8; j++) f[2 + j] = u.limbs[j];
@@ -662,5 +665,17 @@ int mh_external_precompile_session(void* user, const uint64_t* randomness, size_
   assertions_out[0] = acc.c0;
   assertions_out[1] = acc.c1;
   return 1;
+}
+int mh_external_precompile_session(void* user, const uint64_t* randomness, size_t n_randomness, const uint64_t* const* aux_values,
+                                   const size_t* n_aux_values, const uint8_t* log_trace_heights, int n_airs, uint64_t* assertions_out,
+                                   size_t cap) {
+  (void)user; (void)log_trace_heights;
+  return precompile_session_external(true, randomness, n_randomness, aux_values, n_aux_values, n_airs, assertions_out, cap);
+}
+int mh_external_precompile_session_ec_only(void* user, const uint64_t* randomness, size_t n_randomness, const uint64_t* const* aux_values,
+                                           const size_t* n_aux_values, const uint8_t* log_trace_heights, int n_airs, uint64_t* assertions_out,
+                                           size_t cap) {
+  (void)user; (void)log_trace_heights;
+  return precompile_session_external(false, randomness, n_randomness, aux_values, n_aux_values, n_airs, assertions_out, cap);
 }
 }  // extern "C"

@@ -228,7 +228,9 @@ def test_the_session_front_end_other_calls():
 
 
 def test_the_library_eval_external_equals_the_python_one():
-    """`mh_external_precompile_session` against `PA.eval_external` on random challenges and sigmas, both forms of the correction."""
+    """`mh_external_precompile_session` / `_ec_only` against `PA.eval_external` on random challenges and sigmas, both forms of the
+    correction; the `user` pointer is ignored (a flag passed by mistake cannot weaken the statement); an AIR that exposes no sigma,
+    or two, is refused (`aux_values[i]` is exactly one value: session/prove.rs:243-247)."""
     import ctypes as C
     lib = pkg.load_library()
     rng = np.random.default_rng(5)
@@ -241,8 +243,13 @@ def test_the_library_eval_external_equals_the_python_one():
             ptrs = (C.POINTER(C.c_uint64) * 12)(*[row.ctypes.data_as(C.POINTER(C.c_uint64)) for row in rows])
             counts = (C.c_size_t * 12)(*[1] * 12)
             out = np.zeros(2, dtype=np.uint64)
-            user = C.c_int(flag)
-            lib.mh_external_precompile_session.restype = C.c_int
-            n = lib.mh_external_precompile_session(C.byref(user), r.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(2), ptrs, counts, None, C.c_int(12),
-                                                   out.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(1))
+            user = C.c_int(1)   # round 5's "EcGroup part only" flag: no longer read
+            fn = lib.mh_external_precompile_session_ec_only if flag else lib.mh_external_precompile_session
+            fn.restype = C.c_int
+            n = fn(C.byref(user), r.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(2), ptrs, counts, None, C.c_int(12),
+                   out.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(1))
             assert n == 1 and [(int(out[0]), int(out[1]))] == PA.eval_external(rnd, sig, fixed_uints=fixed_uints), (trial, flag)
+            for bad in (0, 2):
+                counts_bad = (C.c_size_t * 12)(*([1] * 5 + [bad] + [1] * 6))
+                assert fn(None, r.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(2), ptrs, counts_bad, None, C.c_int(12),
+                          out.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_size_t(1)) == -1
