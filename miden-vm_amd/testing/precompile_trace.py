@@ -327,14 +327,13 @@ def keccak_round_trace(states, requires=None, rcs=None):
     program row r at 25 + r) and the 3200 program rows are stepped once for all permutations (numpy).  -> (trace, memory)."""
     rcs = KECCAK_RC if rcs is None else rcs
     num_perms = len(states)
-    assert num_perms >= 1
     active = KR_NUM_ROUNDS * ROUND_PERIOD
-    ppl = -(-num_perms // KR_NUM_LANES)
+    ppl = -(-max(num_perms, 1) // KR_NUM_LANES)                        # `generate_trace` (round/mod.rs:974): a session without Keccak claims lays one inactive cycle
     height = max(2, 1 << (ppl * PERM_CYCLE - 1).bit_length())
     program = keccak_round_slots()
     u = np.uint64
     mem = np.zeros((num_perms, KR_IP_BOUNDARY + PERM_CYCLE), dtype=np.uint64)
-    mem[:, :25] = np.array([[int(v) for v in st] for st in states], dtype=np.uint64)
+    mem[:, :25] = np.array([[int(v) for v in st] for st in states], dtype=np.uint64).reshape(num_perms, 25)
     for r in range(KR_NUM_ROUNDS):
         mem[:, KR_IP_BOUNDARY + r * ROUND_PERIOD] = u(rcs[r])
     cyc = np.zeros((num_perms, PERM_CYCLE, KR_LANE_WIDTH), dtype=np.uint64)  # the rows of one permutation cycle, ip filled in below

@@ -14,7 +14,41 @@ proved by the oracle and checked by both verifiers.  Host only; device parity in
   one_shot / three_block digests = the chained reference permutation; spans contiguous and non-overlapping
   constraints_hold_on_*                                  one-shot zero / random, two and three blocks, an interned absorption (7 + 7),
                                                         multiplicities past 2^16, asymmetric (1 in, 7 out), one-shots mixed with a chain
-  corruption_*                                           the eight of the reference"""
+  corruption_*                                           the eight of the reference
+
+Reference test (precompiles-prover/src/tests/poseidon2.rs, 29 tests) -> local test, one by one (round 6):
+  p2_caps_match_vm_sources                               -> test_p2_chunk_cap_is_the_chunks_tag (the chunk capacity; the uint / curve capacities against the VM's
+                                                            `Node::digest` in tests/test_ref_precompile_dag.py::test_uint_value_hash_matches_vm_node_and_eq_op_cap)
+  poseidon2_in_msg_encodes_with_in_bus_prefix            -> test_poseidon2_in_msg_encodes_with_in_bus_prefix
+  poseidon2_in_msg_tags_produce_distinct_encodings       -> test_poseidon2_in_msg_tags_produce_distinct_encodings
+  poseidon2_out_msg_encodes_with_out_bus_prefix          -> test_poseidon2_out_msg_encodes_with_out_bus_prefix
+  poseidon2_in_and_out_buses_have_disjoint_prefixes      -> test_poseidon2_in_and_out_buses_have_disjoint_prefixes
+  main_column_layout_matches_spec                        -> test_main_column_layout_and_air_layout_match_spec
+  lifted_air_validates_and_layout_matches_spec           -> test_main_column_layout_and_air_layout_match_spec
+  log_quotient_degree_matches_design_target              -> test_main_column_layout_and_air_layout_match_spec (2), tests/test_precompile_degrees.py
+  periodic_columns_have_period_16                        -> test_periodic_program_is_the_reference_program
+  one_shot_digest_matches_reference_on_zero_input        -> test_one_shot_digest_matches_reference_on_zero_and_random_input
+  one_shot_digest_matches_reference_on_random_input      -> test_one_shot_digest_matches_reference_on_zero_and_random_input
+  three_block_digest_matches_chained_reference_permutation -> test_three_block_digest_matches_chained_reference_permutation
+  multi_absorption_outputs_have_non_overlapping_perm_spans -> test_multi_absorption_outputs_have_non_overlapping_perm_spans
+  constraints_hold_on_one_shot_zero_input                -> test_constraints_hold[one_shot_zero_input]
+  constraints_hold_on_one_shot_random_input              -> test_constraints_hold[one_shot_random_input]
+  constraints_hold_on_two_block_absorption               -> test_constraints_hold[two_block_absorption]
+  constraints_hold_on_three_block_absorption             -> test_constraints_hold[three_block_absorption]
+  constraints_hold_on_interned_absorption                -> test_constraints_hold[interned_absorption]
+  constraints_hold_on_multiplicity_beyond_range16_cap    -> test_constraints_hold[multiplicity_beyond_range16_cap]
+  constraints_hold_on_asymmetric_multiplicities          -> test_constraints_hold[asymmetric_multiplicities]
+  constraints_hold_on_mixed_one_shot_and_chain           -> test_constraints_hold[mixed_one_shot_and_chain]
+  corruption_seq_id_breaks_row_counter                   -> test_corruption_is_caught[seq_id_breaks_row_counter]
+  corruption_non_binary_is_absorb_breaks_booleanity      -> test_corruption_is_caught[non_binary_is_absorb_breaks_booleanity]
+  corruption_in_multiplicity_non_constant_breaks_constancy  -> test_corruption_is_caught[in_multiplicity_non_constant_breaks_constancy]
+  corruption_out_multiplicity_non_constant_breaks_constancy -> test_corruption_is_caught[out_multiplicity_non_constant_breaks_constancy]
+  corruption_capacity_mismatch_in_chain_breaks_carry     -> test_corruption_is_caught[capacity_mismatch_in_chain_breaks_carry]
+  corruption_is_absorb_non_constant_breaks_within_cycle  -> test_corruption_is_caught[is_absorb_non_constant_breaks_within_cycle]
+  corruption_state_at_step_breaks_transition             -> test_corruption_is_caught[state_at_step_breaks_transition]
+  corruption_is_absorb_at_row_0_breaks_boundary          -> test_corruption_is_caught[is_absorb_at_row_0_breaks_boundary]
+None skipped.  Beyond the reference: a wrong cube register / witness (test_a_wrong_cube_register_and_a_wrong_witness_are_caught), the statement
+closed through eval_external and proved."""
 import numpy as np
 import pytest
 import oracle_binding as ob

@@ -10,7 +10,37 @@ against the table), hands the permutation inputs and round constants to the roun
 Host only; device parity in tests/test_gpu_precompile.py.
 
 Known answers: keccak256("") = c5d24601...5d85a470 (the reference's `empty_input_digest_is_keccak256_of_empty`, as eight u32 halves) and
-keccak256("abc") = 4e03657a...a12d6c45."""
+keccak256("abc") = 4e03657a...a12d6c45.
+
+Reference test (precompiles-prover/src/tests/keccak_sponge.rs, 26 tests) -> local test, one by one (round 6):
+  keccak_sponge_msg_encodes_with_keccak_sponge_bus_prefix     -> test_keccak_sponge_msg_encodes_with_keccak_sponge_bus_prefix
+  keccak_sponge_msg_encoding_is_bus_distinct_from_memory64    -> test_keccak_sponge_msg_encodes_with_keccak_sponge_bus_prefix (its last assertion)
+  main_column_layout_partitions_67_indices                    -> test_main_column_layout_partitions_67_indices_and_air_layout_matches_spec
+  lifted_air_validates_and_layout_matches_spec                -> test_main_column_layout_partitions_67_indices_and_air_layout_matches_spec
+  periodic_columns_match_program                              -> test_main_column_layout_partitions_67_indices_and_air_layout_matches_spec (blob periodic == sponge_program()),
+                                                                 test_the_period_32_program_is_the_reference_design
+  log_quotient_degree_matches_design_target                   -> test_main_column_layout_partitions_67_indices_and_air_layout_matches_spec (2), tests/test_precompile_degrees.py
+  constraints_hold_on_empty_invocation                        -> test_constraints_hold[empty_invocation]
+  constraints_hold_on_single_byte_invocation                  -> test_constraints_hold[single_byte_invocation]
+  constraints_hold_on_partial_lane_input                      -> test_constraints_hold[partial_lane_input]
+  constraints_hold_on_full_single_block                       -> test_constraints_hold[full_single_block]
+  constraints_hold_on_block_aligned_input                     -> test_constraints_hold[block_aligned_input]
+  constraints_hold_on_multi_block_input                       -> test_constraints_hold[multi_block_input]
+  constraints_hold_on_overshoot_two_lanes                     -> test_constraints_hold[overshoot_two_lanes], test_overshoot_lanes_are_mopped_up_on_the_extra_rows
+  constraints_hold_on_overshoot_one_lane                      -> test_constraints_hold[overshoot_one_lane]
+  constraints_hold_on_overshoot_then_invocation_seam          -> test_constraints_hold[overshoot_then_invocation_seam]
+  constraints_hold_with_dead_rows                             -> test_constraints_hold[with_dead_rows]
+  constraints_hold_on_empty_input                             -> test_constraints_hold[empty_invocation] (the same invocation: an empty input; the two reference tests differ in their seed only)
+  constraints_hold_on_empty_transcript                        -> test_constraints_hold[empty_transcript]
+  empty_input_digest_is_keccak256_of_empty                    -> test_known_answers (the eight u32 halves of keccak_sponge.rs:321-340)
+  constraints_hold_on_empty_then_nonempty_seam                -> test_constraints_hold[empty_then_nonempty_seam]
+  constraints_hold_on_multiple_invocations                    -> test_constraints_hold[multiple_invocations]
+  corruption_non_binary_act_breaks_booleanity                 -> test_corruptions_are_caught (1st assertion)
+  corruption_nonzero_chunk_on_chunks_unavailable_breaks_zero_fill -> test_corruptions_are_caught (2nd)
+  corruption_new_invocation_after_non_last_block              -> test_corruptions_are_caught (3rd)
+  corruption_seq_id_breaks_row_counter_transition             -> test_corruptions_are_caught (4th)
+  corruption_aux_cell_breaks_logup_recurrence                 -> test_corruptions_are_caught (5th: an aux cell bumped under check_constraints)
+None skipped.  Beyond the reference: program.rs / trace.rs module tests, a wrong byte shadow / pad intermediate, the hashing session over six chiplets."""
 import numpy as np
 import pytest
 import oracle_binding as ob
@@ -238,5 +268,7 @@ def test_the_sponge_chunks_compile_in_seconds_not_minutes(tmp_path, sponge):
     t0 = time.perf_counter()
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "jit_precompile.py"), str(tmp_path / "cache"), str(blob)], env=env, capture_output=True,
                          text=True, timeout=300)
-    assert out.returncode == 0 and "5 kernels" in out.stdout, out.stdout + out.stderr
+    import re
+    m = re.search(r"(\d+) kernels", out.stdout)                          # the cut count follows the generator's register estimate (5 in round 5, 6 with the asm product)
+    assert out.returncode == 0 and m and 3 <= int(m.group(1)) <= 8, out.stdout + out.stderr
     assert time.perf_counter() - t0 < 120
