@@ -6,6 +6,10 @@
 # DEEP PoW 12, 27 queries, query PoW 16
 PROD_PARAMS = dict(log_blowup=3, log_folding_arity=2, log_final_degree=7, folding_pow_bits=4, deep_pow_bits=12,
                    num_queries=27, query_pow_bits=16)
+# BASELINE.json configs[4] ("128-bit security, FRI blowup 16"): NOT a reference configuration -- the parameters
+# chosen and documented here: blowup 16 (4 bits per query), 28 queries = 112 bits, + 16 bits of query PoW = 128; the rest as in production
+CONFIG5_PARAMS = dict(log_blowup=4, log_folding_arity=2, log_final_degree=7, folding_pow_bits=4, deep_pow_bits=12,
+                      num_queries=28, query_pow_bits=16)
 PARAM_ORDER = ("log_blowup", "log_folding_arity", "log_final_degree", "folding_pow_bits", "deep_pow_bits", "num_queries",
                "query_pow_bits")
 

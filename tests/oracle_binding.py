@@ -181,7 +181,7 @@ AUX_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, u64p, u64p, u64p)
 # protocol constants and pre-observe framing live in the product package (pure data, no oracle dependency there)
 from __graft_entry__ import load_package as _load_package
 _load_package()
-from miden_vm_amd.protocol import PROD_PARAMS, PARAM_ORDER, protocol_pre_observe, challenger_state  # noqa: E402,F401
+from miden_vm_amd.protocol import PROD_PARAMS, CONFIG5_PARAMS, PARAM_ORDER, protocol_pre_observe, challenger_state  # noqa: E402,F401
 
 
 def params_array(p):

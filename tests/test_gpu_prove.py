@@ -164,6 +164,10 @@ def test_blowup16_more_queries(ctx):
     prm = dict(log_blowup=4, log_folding_arity=2, log_final_degree=3, folding_pow_bits=2, deep_pow_bits=5, num_queries=12,
                query_pow_bits=6)
     check_same(ctx, [dag.dummy_miden_air(16, 1)], [A.dummy_trace(7, 16)], [], prm)
+    from miden_vm_amd import miden_air as MA                        # ... and the real Poseidon2PermutationAir (host-built aux on both sides)
+    rng = np.random.default_rng(2)
+    tr = MA.poseidon2_permutation_trace(7, rng.integers(0, ob.P, (6, 12), dtype=np.uint64), rng.integers(1, 4, 6, dtype=np.uint64))
+    check_same(ctx, [MA.poseidon2_permutation_air(host_aux=ob.lookup_build_aux)[0]], [tr], [], prm)
 
 
 def test_full_size_proof_verifies(ctx):
@@ -221,11 +225,34 @@ def test_config4_2p24_rows_one_gpu(ctx):
 
 
 def test_config5_blowup16_128bit_2p20(ctx):
-    """BASELINE configs[4] shape: Poseidon2-permutation-AIR-sized trace (2^20 x 16 + 1 EF aux), FRI blowup 16,
-    ~128-bit parameters (28 queries x 4 bits + 16 bits of query PoW)."""
-    prm = dict(log_blowup=4, log_folding_arity=2, log_final_degree=7, folding_pow_bits=4, deep_pow_bits=12, num_queries=28,
-               query_pow_bits=16)
-    _prove_and_verify(ctx, [dag.dummy_miden_air(16, 1)], [A.dummy_trace(20, 16, seed=9)], prm)
+    """BASELINE configs[4] at full size on the REAL Poseidon2PermutationAir (miden_air.py; the reference's
+    air/src/constraints/poseidon2_permutation/{mod,state}.rs): 2^20 x 16 + 1 EF aux column, 65 535 permutation requests, FRI blowup 16,
+    the documented 128-bit parameters (28 queries x 4 bits + 16 bits of query PoW, protocol.CONFIG5_PARAMS).  The LogUp column is built
+    on the device; both verifiers accept, a damaged trace is refused.  Device == oracle for the same statement at 2^18:
+    tests/test_gpu_round3.py::test_full_transcript_config5_blowup16_at_2_18; sharded at world 8: tests/test_gpu_sharded.py case config5."""
+    from miden_vm_amd import miden_air as MA
+    pkg = load_package()
+    prm = ob.CONFIG5_PARAMS
+    air, lookup = MA.poseidon2_permutation_air()
+    rng = np.random.default_rng(9)
+    k = (1 << 16) - 1
+    tr = MA.poseidon2_permutation_trace(20, rng.integers(0, ob.P, (k, 12), dtype=np.uint64), rng.integers(1, 5, k, dtype=np.uint64))
+    dair = pkg.DeviceAir(ctx, air)
+    assert dair.compiled_chunks > 0
+    dair.attach_lookup(pkg.DeviceLookup(ctx, lookup))
+    pre = ob.protocol_pre_observe(prm, [])
+    got = pkg.prove(ctx, [dair], [ctx.upload_trace(tr)], [], prm, ob.challenger_state(), pre, None)
+    assert got.log_trace_heights == [20]
+    ok, msg = ob.verify([air], [20], [], {"fields": got.fields, "commitments": got.commitments}, prm)
+    assert ok, msg
+    assert (msg == got.digest).all()
+    ok2, dig2 = pkg.verify([air], [20], [], prm, ob.challenger_state(), pre, got.fields, got.commitments)
+    assert ok2 and (dig2 == got.digest).all()
+    bad = tr.copy()
+    bad[12345, 7] = (int(bad[12345, 7]) + 1) % ob.P
+    devb = pkg.prove(ctx, [dair], [ctx.upload_trace(bad)], [], prm, ob.challenger_state(), pre, None)
+    assert not ob.verify([air], [20], [], {"fields": devb.fields, "commitments": devb.commitments}, prm)[0]
+    assert not pkg.verify([air], [20], [], prm, ob.challenger_state(), pre, devb.fields, devb.commitments)[0]
 
 
 def test_rejects_bad_shapes(ctx):

@@ -49,9 +49,27 @@ def test_full_transcript_config2_mixed_heights(ctx, fast_oracle):
 
 
 def test_full_transcript_config5_blowup16_at_2_18(ctx, fast_oracle):
-    prm = dict(log_blowup=4, log_folding_arity=2, log_final_degree=7, folding_pow_bits=4, deep_pow_bits=12, num_queries=28,
-               query_pow_bits=16)
-    check_same(ctx, [dag.dummy_miden_air(16, 1)], [A.dummy_trace(18, 16, seed=9)], [], prm)
+    """BASELINE configs[4] on the REAL Poseidon2PermutationAir (air/src/constraints/poseidon2_permutation/{mod,state}.rs; 16 main + 1 EF
+    aux + 16 periodic columns, degree 8) at 2^18 rows, blowup 16, the documented 128-bit parameters (protocol.CONFIG5_PARAMS): the
+    device proof -- compiled constraint chunks, the LogUp column from the lookup program on the GPU -- equals the oracle's (aux column
+    built by its host callback) field for field, and both verifiers accept it."""
+    pkg = load_package()
+    prm = ob.CONFIG5_PARAMS
+    air, lookup = MA.poseidon2_permutation_air(host_aux=ob.lookup_build_aux)
+    tr = p2_statement(18, (1 << 14) - 1, seed=9)                      # every cycle but the last carries a request
+    exp = ob.prove([air], [tr], [], prm)
+    dair = pkg.DeviceAir(ctx, air)
+    assert dair.compiled_chunks > 0
+    dair.attach_lookup(pkg.DeviceLookup(ctx, lookup))
+    pre = ob.protocol_pre_observe(prm, [])
+    got = pkg.prove(ctx, [dair], [ctx.upload_trace(tr)], [], prm, ob.challenger_state(), pre, None)
+    assert (got.commitments == exp["commitments"]).all()
+    assert got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all()
+    assert (got.digest == exp["digest"]).all()
+    ok, msg = ob.verify([air], [18], [], {"fields": got.fields, "commitments": got.commitments}, prm)
+    assert ok, msg
+    ok2, dig = pkg.verify([air], [18], [], prm, ob.challenger_state(), pre, got.fields, got.commitments)
+    assert ok2 and (dig == got.digest).all()
 
 
 @pytest.mark.parametrize("log_n,width", [(21, 3), (22, 2), (23, 1)])

@@ -264,6 +264,9 @@ def test_local_communicator_selftest(world):
 
 @pytest.mark.parametrize("world,case", [(2, "miden_small"), (4, "miden"), (8, "miden"), (2, "multi"), (8, "miden18"), (2, "miden20"),
                                         (4, "p2air"), (8, "p2air"),
+                                        # round 6: BASELINE configs[4] -- the real Poseidon2PermutationAir alone, blowup 16 (sixteen cosets over
+                                        # eight ranks), the documented 128-bit parameters
+                                        (2, "config5"), (8, "config5"),
                                         # round 4: more ranks than quotient chunks (D = 2: chunk t lives on rank t * G / 2, the others
                                         # idle through constraint evaluation), mixed per-AIR quotient degrees (D_j in {2, 2, 8}: native
                                         # chunks gathered, upsampled on every rank), both instance orders; the real chiplets AIR
@@ -287,6 +290,13 @@ def test_sharded_proof_through_a_stream_ordered_communicator(world, case):
         airs_ = [dag.dummy_miden_air(51, 4, num_aux_values=1), p2]
         traces = [A.dummy_trace(12, 51, seed=2), MA.poseidon2_permutation_trace(11, rng.integers(0, ob.P, (60, 12), dtype=np.uint64), rng.integers(1, 4, 60, dtype=np.uint64))]
         pub, prm, lookups = [], ob.PROD_PARAMS, {1: lk}
+    elif case == "config5":
+        from miden_vm_amd import miden_air as MA
+        p2, lk = MA.poseidon2_permutation_air(host_aux=ob.lookup_build_aux)
+        rng = np.random.default_rng(9)
+        k = (1 << 9) - 1
+        airs_, traces = [p2], [MA.poseidon2_permutation_trace(13, rng.integers(0, ob.P, (k, 12), dtype=np.uint64), rng.integers(1, 5, k, dtype=np.uint64))]
+        pub, prm, lookups = [], ob.CONFIG5_PARAMS, {0: lk}
     elif case in ("mixed", "mixed_rev"):  # test_gpu_prove.py::test_mixed_quotient_degrees, sharded
         tf, pub = A.fib_trace(7)
         airs_ = [A.periodic_air(3), A.fib_air(), dag.dummy_miden_air(11, 2, num_public=3)]

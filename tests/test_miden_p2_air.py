@@ -234,3 +234,21 @@ def test_generator_switches_compile_offline(env, tmp_path, monkeypatch):
     air, _ = MA.poseidon2_permutation_air()
     n = load_package().jit_precompile(air.blob, str(tmp_path))
     assert n >= 2 and len(os.listdir(str(tmp_path))) >= n    # a chunk cut again for the register budget leaves its first code object too
+
+
+def test_config5_parameters_on_the_real_air_both_verifiers():
+    """BASELINE configs[4] (blowup 16, the documented 128-bit parameters: protocol.CONFIG5_PARAMS = 28 queries x 4 bits + 16 bits of
+    query PoW) on this AIR at a size the oracle proves in seconds; the full size and the device run are tests/test_gpu_prove.py::
+    test_config5_blowup16_128bit_2p20 and tests/test_gpu_round3.py::test_full_transcript_config5_blowup16_at_2_18."""
+    prm = ob.CONFIG5_PARAMS
+    assert prm["log_blowup"] == 4 and prm["num_queries"] * prm["log_blowup"] + prm["query_pow_bits"] == 128
+    air, _ = p2_air()
+    st, mult = requests(31)
+    tr = MA.poseidon2_permutation_trace(9, st, mult)
+    proof = ob.prove([air], [tr], [], prm)
+    ok, msg = ob.verify([air], [9], [], proof, prm)
+    assert ok, msg
+    pkg = load_package()
+    ok2, dig = pkg.verify([air], [9], [], prm, ob.challenger_state(), ob.protocol_pre_observe(prm, []), proof["fields"], proof["commitments"])
+    assert ok2 and (dig == proof["digest"]).all()
+    assert not ob.verify([air], [9], [], proof, ob.PROD_PARAMS)[0]          # the parameters are part of the statement

@@ -33,14 +33,20 @@ def run(name, airs_, traces, prm, lookups=None, reps=3):
         d.free()
 
 
-P16 = dict(log_blowup=4, log_folding_arity=2, log_final_degree=7, folding_pow_bits=4, deep_pow_bits=12, num_queries=28, query_pow_bits=16)
+P16 = ob.CONFIG5_PARAMS
 run("configs[1] miden:20:51:8 (bench.py workload)", [dag.dummy_miden_air(51, 8)], [A.dummy_trace(20, 51)], ob.PROD_PARAMS)
 run("configs[2] shape: 2^22x51(+4) 2^21x22(+3) 2^20x16(+1)", [dag.dummy_miden_air(51, 4), dag.dummy_miden_air(22, 3), dag.dummy_miden_air(16, 1)],
     [A.dummy_trace(22, 51, 3), A.dummy_trace(21, 22, 4), A.dummy_trace(20, 16, 5)], ob.PROD_PARAMS)
 run("  ... with a Miden-sized constraint DAG on the 2^22 core", [A.synthetic_big_air(51, 4), dag.dummy_miden_air(22, 3), dag.dummy_miden_air(16, 1)],
     [A.dummy_trace(22, 51, 3), A.dummy_trace(21, 22, 4), A.dummy_trace(20, 16, 5)], ob.PROD_PARAMS)
 run("configs[3] size: 2^24x51(+8) on one GPU", [dag.dummy_miden_air(51, 8)], [A.dummy_trace(24, 51, 8)], ob.PROD_PARAMS, reps=2)
-run("configs[4] shape: 2^20x16(+1), blowup 16, 128-bit", [dag.dummy_miden_air(16, 1)], [A.dummy_trace(20, 16, 9)], P16)
+run("configs[4] shape (DummyMidenAir): 2^20x16(+1), blowup 16", [dag.dummy_miden_air(16, 1)], [A.dummy_trace(20, 16, 9)], P16)
+from miden_vm_amd import miden_air as MA
+_p2, _lk = MA.poseidon2_permutation_air()
+_rng = np.random.default_rng(9)
+_k = (1 << 16) - 1
+run("configs[4] REAL Poseidon2PermutationAir 2^20x16(+1), blowup 16, 128-bit", [_p2],
+    [MA.poseidon2_permutation_trace(20, _rng.integers(0, ob.P, (_k, 12), dtype=np.uint64), _rng.integers(1, 5, _k, dtype=np.uint64))], P16, lookups=[_lk])
 run("miden-bench --log-folding-arity 3 (FRI arity 8), miden:20:51:8", [dag.dummy_miden_air(51, 8)], [A.dummy_trace(20, 51)],
     dict(ob.PROD_PARAMS, log_folding_arity=3))
 air, lookup = A.logup_air()
