@@ -1514,6 +1514,10 @@ def main():
                                 "top_kernels_ms": top_kernels(d)}
             elif d is not None:
                 summary[key] = d
+        if comm_log:  # the bring-up ladder in the part of the line the driver's tail keeps
+            summary["comm"] = {"chosen": comm_name, "mode": mode, "fallback": fallback,
+                               "attempts": [{"choice": a["choice"], "ok": a["ok_on_rank0"], "s": round(sum(t for _, t in a["steps_s"]), 2),
+                                             **({"error": a["error"][:120]} if "error" in a else {})} for a in comm_log]}
         if isinstance(out.get("miden_real_sharded"), dict):
             summary["miden_real_sharded"] = brief(out["miden_real_sharded"], ("ms_per_proof", "rows_per_s", "log_trace_heights", "error"))
         if isinstance(out.get("cpu_baseline"), dict):

@@ -54,6 +54,14 @@ FI u64 gl_mul_c(u64 a, u64 b) { const u128 p = (u128)a * b; return gl_reduce128(
 // 0: plain C products, 1: the asm product everywhere (the default since round 6), 2: for base-field gates only (rounds 4-5)
 #define MH_JIT_ASM_MUL 1
 #endif
+#ifndef MH_JIT_NOPS
+#define MH_JIT_NOPS 1  // 0: TIMING PROBE ONLY (no wait states between a carry's writer and its reader: gfx950 documents 2)
+#endif
+#if MH_JIT_NOPS
+#define JNOP "s_nop 1\n\t"
+#else
+#define JNOP ""
+#endif
 #if MH_JIT_ASM_MUL
 // the 13-instruction SGPR-carry-chain product of poseidon2_fast.cuh (p2f_mul_nv: non-volatile statements carrying their own
 // wait states), canonicalised on exit -- an experiment switch (-DMH_JIT_ASM_MUL=1 through $MH_JIT_FLAGS), see DESIGN.md section 3
@@ -67,17 +75,17 @@ FI u64 gl_mul(u64 a, u64 b) {
   asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(m), "=s"(d1) : "v"(jlo(a)), "v"(jhi(b)));
   asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m), "=s"(cm) : "v"(jhi(a)), "v"(jlo(b)), "0"(m));
   asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(w1), "=s"(k1) : "v"(jhi(p00)), "v"(jlo(m)));
-  asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(accl), "=s"(k2) : "v"(jhi(m)), "s"(k1));
+  asm(JNOP "v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(accl), "=s"(k2) : "v"(jhi(m)), "s"(k1));
   const u64 k3 = cm | k2;
   asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(acch), "=s"(d2) : "v"(zero), "s"(k3));
   const u64 acc = ((u64)acch << 32) | accl;
   asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(hi), "=s"(d3) : "v"(jhi(a)), "v"(jhi(b)), "v"(acc));
   const u64 lo = ((u64)w1 << 32) | jlo(p00);
   asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t), "=s"(c1) : "v"(jlo(hi)), "v"(lo));
-  asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(rl), "=s"(bb) : "v"(jlo(t)), "v"(jhi(hi)), "s"(c1));
-  asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh), "=s"(d4) : "v"(jhi(t)), "s"(c1));
-  asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh), "=s"(bw) : "0"(rh), "s"(bb));
-  asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rl), "=s"(c3) : "0"(rl), "s"(bw));
+  asm(JNOP "v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(rl), "=s"(bb) : "v"(jlo(t)), "v"(jhi(hi)), "s"(c1));
+  asm(JNOP "v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh), "=s"(d4) : "v"(jhi(t)), "s"(c1));
+  asm(JNOP "v_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh), "=s"(bw) : "0"(rh), "s"(bb));
+  asm(JNOP "v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rl), "=s"(c3) : "0"(rl), "s"(bw));
   const u64 mk = bw & ~c3;
   asm("v_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh), "=s"(d5) : "0"(rh), "s"(mk));
   const u64 r = ((u64)rh << 32) | rl;
@@ -120,16 +128,24 @@ FI e2 e2_mulf(e2 a, u64 b) { return {gl_mul_ef(a.c0, b), gl_mul_ef(a.c1, b)}; }
 struct fold_acc { u64 w0, w1, w2, w3, w4, w5; };
 // acc + a * x as ONE v_mad_u64_u32 with the uniform limb in an SGPR; inline asm because LLVM reassociates the C form of these sums
 // (every product of the chunk then stays live to the end: 512 VGPRs and scratch)
-FI void fold_mad(u64& acc, u32 a, u32 x) {
-  u64 d, cy;
-  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "s"(a), "v"(x), "v"(acc));
+// The carry-out nobody reads goes to one of six fixed scratch SGPR pairs, a different one for each of the six products of fold_limbs:
+// hipcc separates two asm statements that touch a common register by an s_nop (its dst-forwarding rule cannot look inside) and would
+// hand every dead carry the same pair -- 12 s_nop per base constraint (ISA of the core AIR's chunks, round 6).
+template <int I> FI void fold_mad(u64& acc, u32 a, u32 x) {
+  u64 d;
+  if (I == 0) asm("v_mad_u64_u32 %0, s[88:89], %1, %2, %3" : "=v"(d) : "s"(a), "v"(x), "v"(acc) : "s88", "s89");
+  else if (I == 1) asm("v_mad_u64_u32 %0, s[90:91], %1, %2, %3" : "=v"(d) : "s"(a), "v"(x), "v"(acc) : "s90", "s91");
+  else if (I == 2) asm("v_mad_u64_u32 %0, s[92:93], %1, %2, %3" : "=v"(d) : "s"(a), "v"(x), "v"(acc) : "s92", "s93");
+  else if (I == 3) asm("v_mad_u64_u32 %0, s[94:95], %1, %2, %3" : "=v"(d) : "s"(a), "v"(x), "v"(acc) : "s94", "s95");
+  else if (I == 4) asm("v_mad_u64_u32 %0, s[96:97], %1, %2, %3" : "=v"(d) : "s"(a), "v"(x), "v"(acc) : "s96", "s97");
+  else asm("v_mad_u64_u32 %0, s[98:99], %1, %2, %3" : "=v"(d) : "s"(a), "v"(x), "v"(acc) : "s98", "s99");
   acc = d;
 }
 FI void fold_limbs(fold_acc& f, u64 alpha, u64 x) {  // three 22-bit limbs of alpha x two 32-bit halves of x: 54-bit products
   const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
   const u32 a0 = (u32)alpha & 0x3fffffu, a1 = (u32)(alpha >> 22) & 0x3fffffu, a2 = (u32)(alpha >> 44);
-  fold_mad(f.w0, a0, x0); fold_mad(f.w1, a1, x0); fold_mad(f.w2, a2, x0);
-  fold_mad(f.w3, a0, x1); fold_mad(f.w4, a1, x1); fold_mad(f.w5, a2, x1);
+  fold_mad<0>(f.w0, a0, x0); fold_mad<1>(f.w1, a1, x0); fold_mad<2>(f.w2, a2, x0);
+  fold_mad<3>(f.w3, a0, x1); fold_mad<4>(f.w4, a1, x1); fold_mad<5>(f.w5, a2, x1);
 }
 FI u64 fold_value(const fold_acc& f) {  // w0 + 2^22 w1 + 2^44 w2 + 2^32 (w3 + 2^22 w4 + 2^44 w5) mod p, canonical
 #if MH_JIT_FOLDV == 0
@@ -174,17 +190,17 @@ FI u64 lz_mul_asm(u64 a, u64 b) {  // the 13 instructions of gl_mul above, witho
   asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(m), "=s"(d1) : "v"(jlo(a)), "v"(jhi(b)));
   asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m), "=s"(cm) : "v"(jhi(a)), "v"(jlo(b)), "0"(m));
   asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(w1), "=s"(k1) : "v"(jhi(p00)), "v"(jlo(m)));
-  asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(accl), "=s"(k2) : "v"(jhi(m)), "s"(k1));
+  asm(JNOP "v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(accl), "=s"(k2) : "v"(jhi(m)), "s"(k1));
   const u64 k3 = cm | k2;
   asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(acch), "=s"(d2) : "v"(zero), "s"(k3));
   const u64 acc = ((u64)acch << 32) | accl;
   asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(hi), "=s"(d3) : "v"(jhi(a)), "v"(jhi(b)), "v"(acc));
   const u64 lo = ((u64)w1 << 32) | jlo(p00);
   asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t), "=s"(c1) : "v"(jlo(hi)), "v"(lo));
-  asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(rl), "=s"(bb) : "v"(jlo(t)), "v"(jhi(hi)), "s"(c1));
-  asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh), "=s"(d4) : "v"(jhi(t)), "s"(c1));
-  asm("s_nop 1\n\tv_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh), "=s"(bw) : "0"(rh), "s"(bb));
-  asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rl), "=s"(c3) : "0"(rl), "s"(bw));
+  asm(JNOP "v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(rl), "=s"(bb) : "v"(jlo(t)), "v"(jhi(hi)), "s"(c1));
+  asm(JNOP "v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh), "=s"(d4) : "v"(jhi(t)), "s"(c1));
+  asm(JNOP "v_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh), "=s"(bw) : "0"(rh), "s"(bb));
+  asm(JNOP "v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rl), "=s"(c3) : "0"(rl), "s"(bw));
   const u64 mk = bw & ~c3;
   asm("v_subb_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rh), "=s"(d5) : "0"(rh), "s"(mk));
   return ((u64)rh << 32) | rl;
@@ -194,6 +210,150 @@ FI u64 lz_mul_asm(u64 a, u64 b) {  // the 13 instructions of gl_mul above, witho
 #define lz_mul lz_mul_asm
 #else
 #define lz_mul lz_mul_c
+#endif
+// N independent products, stage by stage (the interleaving of poseidon2_fast.cuh's p2f_mulN): stage k of every product, then stage k + 1.
+// A carry's reader then sits N - 1 instructions behind its writer, so for N >= 3 the two wait states gfx950 wants between a VALU that writes
+// an SGPR and a VALU that reads it exist by construction and N = 2 needs one `s_nop 0` per link -- against lz_mul_asm's five `s_nop 1`
+// per product PLUS the `s_nop 0` hipcc puts between any two asm statements that share a register (its dst-forwarding rule cannot look
+// inside): ~20 wait states per 13-instruction product in the chunks of the core AIR (ISA counts: DESIGN.md section 3c, round 6).
+// ONE asm statement per stage (N instructions; the stages S9 / S10, which read the same carry, share one): the order inside a statement is
+// fixed, the order of the statements follows from their data dependences, so they need not be `volatile` -- a volatile statement without
+// a memory clobber still counts as a memory access for hipcc's uniform-load analysis, which then reads alpha^k and the uniform table
+// through vector loads and cuts the fold's limbs on the VALU (measured on the first form of this function: +13 % VALU, 262 VGPRs in one
+// chunk).  Outputs are early-clobber: a later instruction of the statement must not find its input overwritten.  The generator groups
+// products whose operands are ready (MH_JIT_MULGROUP); results are any representative, as lz_mul's.  Text generated by
+// tools/gen_jit_mulN.py.
+template <int N> FI void lz_mulN(u64 (&r)[N], const u64 (&a)[N], const u64 (&b)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; i++) r[i] = lz_mul(a[i], b[i]);
+}
+#if MH_JIT_ASM_MUL
+template <> __device__ inline __attribute__((always_inline)) void lz_mulN<2>(u64 (&r)[2], const u64 (&a)[2], const u64 (&b)[2]) {
+  u64 p00[2], m[2], hi[2], t[2], lo[2], acc[2], cm[2], k1[2], k2[2], k3[2], c1[2], bb[2], bw[2], c3[2], mk[2], d[4];
+  u32 w1[2], accl[2], acch[2], rl[2], rh[2];
+  const u32 zero = 0;
+  asm("v_mad_u64_u32 %0, %1, %8, %9, 0\n\tv_mad_u64_u32 %2, %3, %10, %11, 0\n\tv_mad_u64_u32 %4, %5, %12, %13, 0\n\tv_mad_u64_u32 %6, %7, %14, %15, 0"
+      : "=&v"(p00[0]), "=&s"(d[0]), "=&v"(m[0]), "=&s"(d[1]), "=&v"(p00[1]), "=&s"(d[2]), "=&v"(m[1]), "=&s"(d[3])
+      : "v"(jlo(a[0])), "v"(jlo(b[0])), "v"(jlo(a[0])), "v"(jhi(b[0])), "v"(jlo(a[1])), "v"(jlo(b[1])), "v"(jlo(a[1])), "v"(jhi(b[1])));
+  asm("v_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %2, %3, %7, %8, %2"
+      : "=&v"(m[0]), "=&s"(cm[0]), "=&v"(m[1]), "=&s"(cm[1])
+      : "v"(jhi(a[0])), "v"(jlo(b[0])), "0"(m[0]), "v"(jhi(a[1])), "v"(jlo(b[1])), "2"(m[1]));
+  asm("v_add_co_u32_e64 %0, %1, %4, %5\n\tv_add_co_u32_e64 %2, %3, %6, %7"
+      : "=&v"(w1[0]), "=&s"(k1[0]), "=&v"(w1[1]), "=&s"(k1[1])
+      : "v"(jhi(p00[0])), "v"(jlo(m[0])), "v"(jhi(p00[1])), "v"(jlo(m[1])));
+  asm("s_nop 0\n\t" "v_addc_co_u32_e64 %0, %1, %4, 0, %5\n\tv_addc_co_u32_e64 %2, %3, %6, 0, %7"
+      : "=&v"(accl[0]), "=&s"(k2[0]), "=&v"(accl[1]), "=&s"(k2[1])
+      : "v"(jhi(m[0])), "s"(k1[0]), "v"(jhi(m[1])), "s"(k1[1]));
+  for (int i = 0; i < 2; i++) k3[i] = cm[i] | k2[i];  // scalar unit; cm and k2 exclude each other (a carried m leaves m.hi <= 2^32 - 5)
+  asm("v_addc_co_u32_e64 %0, %1, %4, 0, %5\n\tv_addc_co_u32_e64 %2, %3, %6, 0, %7"
+      : "=&v"(acch[0]), "=&s"(d[0]), "=&v"(acch[1]), "=&s"(d[1])
+      : "v"(zero), "s"(k3[0]), "v"(zero), "s"(k3[1]));
+  for (int i = 0; i < 2; i++) { acc[i] = ((u64)acch[i] << 32) | accl[i]; lo[i] = ((u64)w1[i] << 32) | jlo(p00[i]); }
+  asm("v_mad_u64_u32 %0, %1, %4, %5, %6\n\tv_mad_u64_u32 %2, %3, %7, %8, %9"
+      : "=&v"(hi[0]), "=&s"(d[0]), "=&v"(hi[1]), "=&s"(d[1])
+      : "v"(jhi(a[0])), "v"(jhi(b[0])), "v"(acc[0]), "v"(jhi(a[1])), "v"(jhi(b[1])), "v"(acc[1]));
+  asm("v_mad_u64_u32 %0, %1, %4, -1, %5\n\tv_mad_u64_u32 %2, %3, %6, -1, %7"
+      : "=&v"(t[0]), "=&s"(c1[0]), "=&v"(t[1]), "=&s"(c1[1])
+      : "v"(jlo(hi[0])), "v"(lo[0]), "v"(jlo(hi[1])), "v"(lo[1]));
+  asm("s_nop 0\n\t" "v_subb_co_u32_e64 %0, %1, %8, %9, %10\n\tv_subb_co_u32_e64 %2, %3, %11, %12, %13\n\tv_addc_co_u32_e64 %4, %5, %14, 0, %15\n\tv_addc_co_u32_e64 %6, %7, %16, 0, %17"
+      : "=&v"(rl[0]), "=&s"(bb[0]), "=&v"(rl[1]), "=&s"(bb[1]), "=&v"(rh[0]), "=&s"(d[0]), "=&v"(rh[1]), "=&s"(d[1])
+      : "v"(jlo(t[0])), "v"(jhi(hi[0])), "s"(c1[0]), "v"(jlo(t[1])), "v"(jhi(hi[1])), "s"(c1[1]), "v"(jhi(t[0])), "s"(c1[0]), "v"(jhi(t[1])), "s"(c1[1]));
+  asm("v_subb_co_u32_e64 %0, %1, %0, 0, %5\n\tv_subb_co_u32_e64 %2, %3, %2, 0, %7"
+      : "=&v"(rh[0]), "=&s"(bw[0]), "=&v"(rh[1]), "=&s"(bw[1])
+      : "0"(rh[0]), "s"(bb[0]), "2"(rh[1]), "s"(bb[1]));
+  asm("s_nop 0\n\t" "v_addc_co_u32_e64 %0, %1, %0, 0, %5\n\tv_addc_co_u32_e64 %2, %3, %2, 0, %7"
+      : "=&v"(rl[0]), "=&s"(c3[0]), "=&v"(rl[1]), "=&s"(c3[1])
+      : "0"(rl[0]), "s"(bw[0]), "2"(rl[1]), "s"(bw[1]));
+  for (int i = 0; i < 2; i++) mk[i] = bw[i] & ~c3[i];  // scalar unit
+  asm("v_subb_co_u32_e64 %0, %1, %0, 0, %5\n\tv_subb_co_u32_e64 %2, %3, %2, 0, %7"
+      : "=&v"(rh[0]), "=&s"(d[0]), "=&v"(rh[1]), "=&s"(d[1])
+      : "0"(rh[0]), "s"(mk[0]), "2"(rh[1]), "s"(mk[1]));
+  for (int i = 0; i < 2; i++) r[i] = ((u64)rh[i] << 32) | rl[i];
+}
+template <> __device__ inline __attribute__((always_inline)) void lz_mulN<3>(u64 (&r)[3], const u64 (&a)[3], const u64 (&b)[3]) {
+  u64 p00[3], m[3], hi[3], t[3], lo[3], acc[3], cm[3], k1[3], k2[3], k3[3], c1[3], bb[3], bw[3], c3[3], mk[3], d[6];
+  u32 w1[3], accl[3], acch[3], rl[3], rh[3];
+  const u32 zero = 0;
+  asm("v_mad_u64_u32 %0, %1, %12, %13, 0\n\tv_mad_u64_u32 %2, %3, %14, %15, 0\n\tv_mad_u64_u32 %4, %5, %16, %17, 0\n\tv_mad_u64_u32 %6, %7, %18, %19, 0\n\tv_mad_u64_u32 %8, %9, %20, %21, 0\n\tv_mad_u64_u32 %10, %11, %22, %23, 0"
+      : "=&v"(p00[0]), "=&s"(d[0]), "=&v"(m[0]), "=&s"(d[1]), "=&v"(p00[1]), "=&s"(d[2]), "=&v"(m[1]), "=&s"(d[3]), "=&v"(p00[2]), "=&s"(d[4]), "=&v"(m[2]), "=&s"(d[5])
+      : "v"(jlo(a[0])), "v"(jlo(b[0])), "v"(jlo(a[0])), "v"(jhi(b[0])), "v"(jlo(a[1])), "v"(jlo(b[1])), "v"(jlo(a[1])), "v"(jhi(b[1])), "v"(jlo(a[2])), "v"(jlo(b[2])), "v"(jlo(a[2])), "v"(jhi(b[2])));
+  asm("v_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %2, %3, %9, %10, %2\n\tv_mad_u64_u32 %4, %5, %12, %13, %4"
+      : "=&v"(m[0]), "=&s"(cm[0]), "=&v"(m[1]), "=&s"(cm[1]), "=&v"(m[2]), "=&s"(cm[2])
+      : "v"(jhi(a[0])), "v"(jlo(b[0])), "0"(m[0]), "v"(jhi(a[1])), "v"(jlo(b[1])), "2"(m[1]), "v"(jhi(a[2])), "v"(jlo(b[2])), "4"(m[2]));
+  asm("v_add_co_u32_e64 %0, %1, %6, %7\n\tv_add_co_u32_e64 %2, %3, %8, %9\n\tv_add_co_u32_e64 %4, %5, %10, %11"
+      : "=&v"(w1[0]), "=&s"(k1[0]), "=&v"(w1[1]), "=&s"(k1[1]), "=&v"(w1[2]), "=&s"(k1[2])
+      : "v"(jhi(p00[0])), "v"(jlo(m[0])), "v"(jhi(p00[1])), "v"(jlo(m[1])), "v"(jhi(p00[2])), "v"(jlo(m[2])));
+  asm("v_addc_co_u32_e64 %0, %1, %6, 0, %7\n\tv_addc_co_u32_e64 %2, %3, %8, 0, %9\n\tv_addc_co_u32_e64 %4, %5, %10, 0, %11"
+      : "=&v"(accl[0]), "=&s"(k2[0]), "=&v"(accl[1]), "=&s"(k2[1]), "=&v"(accl[2]), "=&s"(k2[2])
+      : "v"(jhi(m[0])), "s"(k1[0]), "v"(jhi(m[1])), "s"(k1[1]), "v"(jhi(m[2])), "s"(k1[2]));
+  for (int i = 0; i < 3; i++) k3[i] = cm[i] | k2[i];  // scalar unit; cm and k2 exclude each other (a carried m leaves m.hi <= 2^32 - 5)
+  asm("v_addc_co_u32_e64 %0, %1, %6, 0, %7\n\tv_addc_co_u32_e64 %2, %3, %8, 0, %9\n\tv_addc_co_u32_e64 %4, %5, %10, 0, %11"
+      : "=&v"(acch[0]), "=&s"(d[0]), "=&v"(acch[1]), "=&s"(d[1]), "=&v"(acch[2]), "=&s"(d[2])
+      : "v"(zero), "s"(k3[0]), "v"(zero), "s"(k3[1]), "v"(zero), "s"(k3[2]));
+  for (int i = 0; i < 3; i++) { acc[i] = ((u64)acch[i] << 32) | accl[i]; lo[i] = ((u64)w1[i] << 32) | jlo(p00[i]); }
+  asm("v_mad_u64_u32 %0, %1, %6, %7, %8\n\tv_mad_u64_u32 %2, %3, %9, %10, %11\n\tv_mad_u64_u32 %4, %5, %12, %13, %14"
+      : "=&v"(hi[0]), "=&s"(d[0]), "=&v"(hi[1]), "=&s"(d[1]), "=&v"(hi[2]), "=&s"(d[2])
+      : "v"(jhi(a[0])), "v"(jhi(b[0])), "v"(acc[0]), "v"(jhi(a[1])), "v"(jhi(b[1])), "v"(acc[1]), "v"(jhi(a[2])), "v"(jhi(b[2])), "v"(acc[2]));
+  asm("v_mad_u64_u32 %0, %1, %6, -1, %7\n\tv_mad_u64_u32 %2, %3, %8, -1, %9\n\tv_mad_u64_u32 %4, %5, %10, -1, %11"
+      : "=&v"(t[0]), "=&s"(c1[0]), "=&v"(t[1]), "=&s"(c1[1]), "=&v"(t[2]), "=&s"(c1[2])
+      : "v"(jlo(hi[0])), "v"(lo[0]), "v"(jlo(hi[1])), "v"(lo[1]), "v"(jlo(hi[2])), "v"(lo[2]));
+  asm("v_subb_co_u32_e64 %0, %1, %12, %13, %14\n\tv_subb_co_u32_e64 %2, %3, %15, %16, %17\n\tv_subb_co_u32_e64 %4, %5, %18, %19, %20\n\tv_addc_co_u32_e64 %6, %7, %21, 0, %22\n\tv_addc_co_u32_e64 %8, %9, %23, 0, %24\n\tv_addc_co_u32_e64 %10, %11, %25, 0, %26"
+      : "=&v"(rl[0]), "=&s"(bb[0]), "=&v"(rl[1]), "=&s"(bb[1]), "=&v"(rl[2]), "=&s"(bb[2]), "=&v"(rh[0]), "=&s"(d[0]), "=&v"(rh[1]), "=&s"(d[1]), "=&v"(rh[2]), "=&s"(d[2])
+      : "v"(jlo(t[0])), "v"(jhi(hi[0])), "s"(c1[0]), "v"(jlo(t[1])), "v"(jhi(hi[1])), "s"(c1[1]), "v"(jlo(t[2])), "v"(jhi(hi[2])), "s"(c1[2]), "v"(jhi(t[0])), "s"(c1[0]), "v"(jhi(t[1])), "s"(c1[1]), "v"(jhi(t[2])), "s"(c1[2]));
+  asm("v_subb_co_u32_e64 %0, %1, %0, 0, %7\n\tv_subb_co_u32_e64 %2, %3, %2, 0, %9\n\tv_subb_co_u32_e64 %4, %5, %4, 0, %11"
+      : "=&v"(rh[0]), "=&s"(bw[0]), "=&v"(rh[1]), "=&s"(bw[1]), "=&v"(rh[2]), "=&s"(bw[2])
+      : "0"(rh[0]), "s"(bb[0]), "2"(rh[1]), "s"(bb[1]), "4"(rh[2]), "s"(bb[2]));
+  asm("v_addc_co_u32_e64 %0, %1, %0, 0, %7\n\tv_addc_co_u32_e64 %2, %3, %2, 0, %9\n\tv_addc_co_u32_e64 %4, %5, %4, 0, %11"
+      : "=&v"(rl[0]), "=&s"(c3[0]), "=&v"(rl[1]), "=&s"(c3[1]), "=&v"(rl[2]), "=&s"(c3[2])
+      : "0"(rl[0]), "s"(bw[0]), "2"(rl[1]), "s"(bw[1]), "4"(rl[2]), "s"(bw[2]));
+  for (int i = 0; i < 3; i++) mk[i] = bw[i] & ~c3[i];  // scalar unit
+  asm("v_subb_co_u32_e64 %0, %1, %0, 0, %7\n\tv_subb_co_u32_e64 %2, %3, %2, 0, %9\n\tv_subb_co_u32_e64 %4, %5, %4, 0, %11"
+      : "=&v"(rh[0]), "=&s"(d[0]), "=&v"(rh[1]), "=&s"(d[1]), "=&v"(rh[2]), "=&s"(d[2])
+      : "0"(rh[0]), "s"(mk[0]), "2"(rh[1]), "s"(mk[1]), "4"(rh[2]), "s"(mk[2]));
+  for (int i = 0; i < 3; i++) r[i] = ((u64)rh[i] << 32) | rl[i];
+}
+template <> __device__ inline __attribute__((always_inline)) void lz_mulN<4>(u64 (&r)[4], const u64 (&a)[4], const u64 (&b)[4]) {
+  u64 p00[4], m[4], hi[4], t[4], lo[4], acc[4], cm[4], k1[4], k2[4], k3[4], c1[4], bb[4], bw[4], c3[4], mk[4], d[8];
+  u32 w1[4], accl[4], acch[4], rl[4], rh[4];
+  const u32 zero = 0;
+  asm("v_mad_u64_u32 %0, %1, %16, %17, 0\n\tv_mad_u64_u32 %2, %3, %18, %19, 0\n\tv_mad_u64_u32 %4, %5, %20, %21, 0\n\tv_mad_u64_u32 %6, %7, %22, %23, 0\n\tv_mad_u64_u32 %8, %9, %24, %25, 0\n\tv_mad_u64_u32 %10, %11, %26, %27, 0\n\tv_mad_u64_u32 %12, %13, %28, %29, 0\n\tv_mad_u64_u32 %14, %15, %30, %31, 0"
+      : "=&v"(p00[0]), "=&s"(d[0]), "=&v"(m[0]), "=&s"(d[1]), "=&v"(p00[1]), "=&s"(d[2]), "=&v"(m[1]), "=&s"(d[3]), "=&v"(p00[2]), "=&s"(d[4]), "=&v"(m[2]), "=&s"(d[5]), "=&v"(p00[3]), "=&s"(d[6]), "=&v"(m[3]), "=&s"(d[7])
+      : "v"(jlo(a[0])), "v"(jlo(b[0])), "v"(jlo(a[0])), "v"(jhi(b[0])), "v"(jlo(a[1])), "v"(jlo(b[1])), "v"(jlo(a[1])), "v"(jhi(b[1])), "v"(jlo(a[2])), "v"(jlo(b[2])), "v"(jlo(a[2])), "v"(jhi(b[2])), "v"(jlo(a[3])), "v"(jlo(b[3])), "v"(jlo(a[3])), "v"(jhi(b[3])));
+  asm("v_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %2, %3, %11, %12, %2\n\tv_mad_u64_u32 %4, %5, %14, %15, %4\n\tv_mad_u64_u32 %6, %7, %17, %18, %6"
+      : "=&v"(m[0]), "=&s"(cm[0]), "=&v"(m[1]), "=&s"(cm[1]), "=&v"(m[2]), "=&s"(cm[2]), "=&v"(m[3]), "=&s"(cm[3])
+      : "v"(jhi(a[0])), "v"(jlo(b[0])), "0"(m[0]), "v"(jhi(a[1])), "v"(jlo(b[1])), "2"(m[1]), "v"(jhi(a[2])), "v"(jlo(b[2])), "4"(m[2]), "v"(jhi(a[3])), "v"(jlo(b[3])), "6"(m[3]));
+  asm("v_add_co_u32_e64 %0, %1, %8, %9\n\tv_add_co_u32_e64 %2, %3, %10, %11\n\tv_add_co_u32_e64 %4, %5, %12, %13\n\tv_add_co_u32_e64 %6, %7, %14, %15"
+      : "=&v"(w1[0]), "=&s"(k1[0]), "=&v"(w1[1]), "=&s"(k1[1]), "=&v"(w1[2]), "=&s"(k1[2]), "=&v"(w1[3]), "=&s"(k1[3])
+      : "v"(jhi(p00[0])), "v"(jlo(m[0])), "v"(jhi(p00[1])), "v"(jlo(m[1])), "v"(jhi(p00[2])), "v"(jlo(m[2])), "v"(jhi(p00[3])), "v"(jlo(m[3])));
+  asm("v_addc_co_u32_e64 %0, %1, %8, 0, %9\n\tv_addc_co_u32_e64 %2, %3, %10, 0, %11\n\tv_addc_co_u32_e64 %4, %5, %12, 0, %13\n\tv_addc_co_u32_e64 %6, %7, %14, 0, %15"
+      : "=&v"(accl[0]), "=&s"(k2[0]), "=&v"(accl[1]), "=&s"(k2[1]), "=&v"(accl[2]), "=&s"(k2[2]), "=&v"(accl[3]), "=&s"(k2[3])
+      : "v"(jhi(m[0])), "s"(k1[0]), "v"(jhi(m[1])), "s"(k1[1]), "v"(jhi(m[2])), "s"(k1[2]), "v"(jhi(m[3])), "s"(k1[3]));
+  for (int i = 0; i < 4; i++) k3[i] = cm[i] | k2[i];  // scalar unit; cm and k2 exclude each other (a carried m leaves m.hi <= 2^32 - 5)
+  asm("v_addc_co_u32_e64 %0, %1, %8, 0, %9\n\tv_addc_co_u32_e64 %2, %3, %10, 0, %11\n\tv_addc_co_u32_e64 %4, %5, %12, 0, %13\n\tv_addc_co_u32_e64 %6, %7, %14, 0, %15"
+      : "=&v"(acch[0]), "=&s"(d[0]), "=&v"(acch[1]), "=&s"(d[1]), "=&v"(acch[2]), "=&s"(d[2]), "=&v"(acch[3]), "=&s"(d[3])
+      : "v"(zero), "s"(k3[0]), "v"(zero), "s"(k3[1]), "v"(zero), "s"(k3[2]), "v"(zero), "s"(k3[3]));
+  for (int i = 0; i < 4; i++) { acc[i] = ((u64)acch[i] << 32) | accl[i]; lo[i] = ((u64)w1[i] << 32) | jlo(p00[i]); }
+  asm("v_mad_u64_u32 %0, %1, %8, %9, %10\n\tv_mad_u64_u32 %2, %3, %11, %12, %13\n\tv_mad_u64_u32 %4, %5, %14, %15, %16\n\tv_mad_u64_u32 %6, %7, %17, %18, %19"
+      : "=&v"(hi[0]), "=&s"(d[0]), "=&v"(hi[1]), "=&s"(d[1]), "=&v"(hi[2]), "=&s"(d[2]), "=&v"(hi[3]), "=&s"(d[3])
+      : "v"(jhi(a[0])), "v"(jhi(b[0])), "v"(acc[0]), "v"(jhi(a[1])), "v"(jhi(b[1])), "v"(acc[1]), "v"(jhi(a[2])), "v"(jhi(b[2])), "v"(acc[2]), "v"(jhi(a[3])), "v"(jhi(b[3])), "v"(acc[3]));
+  asm("v_mad_u64_u32 %0, %1, %8, -1, %9\n\tv_mad_u64_u32 %2, %3, %10, -1, %11\n\tv_mad_u64_u32 %4, %5, %12, -1, %13\n\tv_mad_u64_u32 %6, %7, %14, -1, %15"
+      : "=&v"(t[0]), "=&s"(c1[0]), "=&v"(t[1]), "=&s"(c1[1]), "=&v"(t[2]), "=&s"(c1[2]), "=&v"(t[3]), "=&s"(c1[3])
+      : "v"(jlo(hi[0])), "v"(lo[0]), "v"(jlo(hi[1])), "v"(lo[1]), "v"(jlo(hi[2])), "v"(lo[2]), "v"(jlo(hi[3])), "v"(lo[3]));
+  asm("v_subb_co_u32_e64 %0, %1, %16, %17, %18\n\tv_subb_co_u32_e64 %2, %3, %19, %20, %21\n\tv_subb_co_u32_e64 %4, %5, %22, %23, %24\n\tv_subb_co_u32_e64 %6, %7, %25, %26, %27\n\tv_addc_co_u32_e64 %8, %9, %28, 0, %29\n\tv_addc_co_u32_e64 %10, %11, %30, 0, %31\n\tv_addc_co_u32_e64 %12, %13, %32, 0, %33\n\tv_addc_co_u32_e64 %14, %15, %34, 0, %35"
+      : "=&v"(rl[0]), "=&s"(bb[0]), "=&v"(rl[1]), "=&s"(bb[1]), "=&v"(rl[2]), "=&s"(bb[2]), "=&v"(rl[3]), "=&s"(bb[3]), "=&v"(rh[0]), "=&s"(d[0]), "=&v"(rh[1]), "=&s"(d[1]), "=&v"(rh[2]), "=&s"(d[2]), "=&v"(rh[3]), "=&s"(d[3])
+      : "v"(jlo(t[0])), "v"(jhi(hi[0])), "s"(c1[0]), "v"(jlo(t[1])), "v"(jhi(hi[1])), "s"(c1[1]), "v"(jlo(t[2])), "v"(jhi(hi[2])), "s"(c1[2]), "v"(jlo(t[3])), "v"(jhi(hi[3])), "s"(c1[3]), "v"(jhi(t[0])), "s"(c1[0]), "v"(jhi(t[1])), "s"(c1[1]), "v"(jhi(t[2])), "s"(c1[2]), "v"(jhi(t[3])), "s"(c1[3]));
+  asm("v_subb_co_u32_e64 %0, %1, %0, 0, %9\n\tv_subb_co_u32_e64 %2, %3, %2, 0, %11\n\tv_subb_co_u32_e64 %4, %5, %4, 0, %13\n\tv_subb_co_u32_e64 %6, %7, %6, 0, %15"
+      : "=&v"(rh[0]), "=&s"(bw[0]), "=&v"(rh[1]), "=&s"(bw[1]), "=&v"(rh[2]), "=&s"(bw[2]), "=&v"(rh[3]), "=&s"(bw[3])
+      : "0"(rh[0]), "s"(bb[0]), "2"(rh[1]), "s"(bb[1]), "4"(rh[2]), "s"(bb[2]), "6"(rh[3]), "s"(bb[3]));
+  asm("v_addc_co_u32_e64 %0, %1, %0, 0, %9\n\tv_addc_co_u32_e64 %2, %3, %2, 0, %11\n\tv_addc_co_u32_e64 %4, %5, %4, 0, %13\n\tv_addc_co_u32_e64 %6, %7, %6, 0, %15"
+      : "=&v"(rl[0]), "=&s"(c3[0]), "=&v"(rl[1]), "=&s"(c3[1]), "=&v"(rl[2]), "=&s"(c3[2]), "=&v"(rl[3]), "=&s"(c3[3])
+      : "0"(rl[0]), "s"(bw[0]), "2"(rl[1]), "s"(bw[1]), "4"(rl[2]), "s"(bw[2]), "6"(rl[3]), "s"(bw[3]));
+  for (int i = 0; i < 4; i++) mk[i] = bw[i] & ~c3[i];  // scalar unit
+  asm("v_subb_co_u32_e64 %0, %1, %0, 0, %9\n\tv_subb_co_u32_e64 %2, %3, %2, 0, %11\n\tv_subb_co_u32_e64 %4, %5, %4, 0, %13\n\tv_subb_co_u32_e64 %6, %7, %6, 0, %15"
+      : "=&v"(rh[0]), "=&s"(d[0]), "=&v"(rh[1]), "=&s"(d[1]), "=&v"(rh[2]), "=&s"(d[2]), "=&v"(rh[3]), "=&s"(d[3])
+      : "0"(rh[0]), "s"(mk[0]), "2"(rh[1]), "s"(mk[1]), "4"(rh[2]), "s"(mk[2]), "6"(rh[3]), "s"(mk[3]));
+  for (int i = 0; i < 4; i++) r[i] = ((u64)rh[i] << 32) | rl[i];
+}
 #endif
 // Extension-field products: the asm product too since round 6 (MH_JIT_ASM_MUL=1).  Round 5 kept them in C (25 VALU per base product
 // against 13: 618 of them per point in the core AIR, 30 % of its instructions) because the asm form's SGPR carries spilled into VGPR
@@ -1057,9 +1217,28 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
         }
       }
     }
-    for (const Item& it : order) {
+    // $MH_JIT_MULGROUP = G > 1 (default 0 = off): products are emitted in stage-interleaved groups of up to G (prelude: lz_mulN).  A MUL
+    // gate contributes 1 (base x base), 2 (EF x base) or 4 (EF x EF, schoolbook) products; a group is filled with the MUL gates among the
+    // next $MH_JIT_MULWIN items whose operands are defined already (cells, uniform values, gates emitted above) -- they are hoisted to
+    // the group's position, everything else keeps its place.  Round 6, core AIR, ISA of the nine chunks: 38.5 k -> 11.6 k wait states and
+    // 89 k -> 63 k issue slots per wave (VALU + 2 %), every digest unchanged -- and SLOWER on the device: 12.81 ms -> 14.10 (G = 4, window
+    // 32), 12.97 (window 0: a gate's own products only), 13.25 (G = 4 with MH_JIT_PREFETCH=64): the stage statements are rigid blocks
+    // that need all their operands at once (cell loads exposed at two waves per SIMD), hoisting costs registers (two more chunks after
+    // the re-split), and what the 13 free-floating statements of lz_mul_asm let hipcc's scheduler interleave is worth more than the wait
+    // states they carry -- those overlap with the other wave's VALU issue.  Kept as a switch (bit-exactness and offline-compile tests).
+    const long mul_group = lazy_vals ? std::max(0, env_int("MH_JIT_MULGROUP", 0)) : 0;
+    const long mul_win = std::max(0, env_int("MH_JIT_MULWIN", 32));
+    std::vector<char> taken(order.size(), 0);
+    std::vector<char> defd(nodes.size(), 0);  // gates whose value has a name in this chunk so far
+    auto n_products = [&](uint32_t g) { const bool ea = nodes[nodes[g].a].ext, eb = nodes[nodes[g].b].ext; return ea && eb ? 4 : (ea || eb ? 2 : 1); };
+    auto groupable = [&](const Item& x) { return x.fold_k == -1 && nodes[x.node].op == DOP_MUL && dot_of[x.node] < 0; };
+    auto ready = [&](uint32_t c) { return !interior(c) || defd[c]; };
+    for (size_t oi = 0; oi < order.size(); oi++) {
+      if (taken[oi]) continue;
+      const Item& it = order[oi];
       const uint32_t id = it.node;
       const DagNode& nd = nodes[id];
+      if (it.fold_k == -1 || it.fold_k == -2) defd[id] = 1;  // (set before the emission below: nothing reads it in between)
       if (it.fold_k == -3) {  // prefetch: the leaf's load goes here
         (void)ref(id);
         continue;
@@ -1134,6 +1313,71 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
         if (spilled[id] && def_chunk[id] == (int32_t)ci)
           body << "  " << spill_ref(slot[id]) << " = v" << id << ".c0; " << spill_ref(slot[id] + 1) << " = v" << id << ".c1;\n";
         continue;
+      }
+      if (mul_group > 1 && groupable(it)) {
+        std::vector<size_t> unit{oi};
+        long np = n_products(id);
+        defd[id] = 0;  // not an operand of its own group
+        for (size_t oj = oi + 1; oj < order.size() && oj <= oi + (size_t)mul_win && np < mul_group; oj++) {
+          if (taken[oj] || !groupable(order[oj])) continue;
+          const uint32_t g = order[oj].node;
+          if (!ready(nodes[g].a) || !ready(nodes[g].b) || np + n_products(g) > std::max(mul_group, 4L)) continue;
+          unit.push_back(oj);
+          np += n_products(g);
+        }
+        defd[id] = 1;
+        if (np >= 2) {
+          std::vector<std::string> pa, pb;
+          for (size_t u : unit) {
+            const DagNode& g = nodes[order[u].node];
+            const std::string A = ref(g.a), Bv = ref(g.b);
+            const bool ea = nodes[g.a].ext, eb = nodes[g.b].ext;
+            if (ea && eb) {  // schoolbook: a0 b0, a1 b1, a0 b1, a1 b0
+              pa.insert(pa.end(), {A + ".c0", A + ".c1", A + ".c0", A + ".c1"});
+              pb.insert(pb.end(), {Bv + ".c0", Bv + ".c1", Bv + ".c1", Bv + ".c0"});
+            } else if (ea || eb) {
+              const std::string& E = ea ? A : Bv;
+              const std::string& F = ea ? Bv : A;
+              pa.insert(pa.end(), {E + ".c0", E + ".c1"});
+              pb.insert(pb.end(), {F, F});
+            } else {
+              pa.push_back(A);
+              pb.push_back(Bv);
+            }
+          }
+          body << "  u64 g" << id << "r[" << np << "]; { const u64 ga[" << np << "] = {";
+          for (size_t k = 0; k < pa.size(); k++) body << (k ? ", " : "") << pa[k];
+          body << "}, gb[" << np << "] = {";
+          for (size_t k = 0; k < pb.size(); k++) body << (k ? ", " : "") << pb[k];
+          body << "}; lz_mulN<" << np << ">(g" << id << "r, ga, gb); }\n";
+          long k = 0;
+          for (size_t u : unit) {
+            const uint32_t gid = order[u].node;
+            const DagNode& g = nodes[gid];
+            const bool ea = nodes[g.a].ext, eb = nodes[g.b].ext;
+            const std::string R = "g" + std::to_string(id) + "r[";
+            if (ea && eb) {
+              body << "  const e2 v" << gid << " = {lz_add_g(" << R << k << "], lz_mul7(" << R << k + 1 << "])), lz_add_g(" << R << k + 2 << "], " << R
+                   << k + 3 << "])};\n";
+              k += 4;
+            } else if (ea || eb) {
+              body << "  const e2 v" << gid << " = {" << R << k << "], " << R << k + 1 << "]};\n";
+              k += 2;
+            } else {
+              body << "  const u64 v" << gid << " = " << R << k << "];\n";
+              k += 1;
+            }
+            if (spilled[gid] && def_chunk[gid] == (int32_t)ci) {
+              if (g.ext)
+                body << "  " << spill_ref(slot[gid]) << " = v" << gid << ".c0; " << spill_ref(slot[gid] + 1) << " = v" << gid << ".c1;\n";
+              else
+                body << "  " << spill_ref(slot[gid]) << " = v" << gid << ";\n";
+            }
+            taken[u] = 1;
+            defd[gid] = 1;
+          }
+          continue;
+        }
       }
       const std::string A = ref(nd.a);
       const bool ea = nodes[nd.a].ext;

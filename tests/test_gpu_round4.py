@@ -270,7 +270,10 @@ GEN_SWITCHES = [{}, {"MH_JIT_RECOMP": "0"}, {"MH_JIT_RECOMP": "1000", "MH_JIT_CH
                 # (regions, LDS slots and tiles, k_quot_finish inside), without LDS (HBM planes, cells from HBM), with small regions
                 {"MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=2"}, {"MH_JIT_FUSE": "1"}, {"MH_JIT_FUSE": "1", "MH_JIT_LDS_KB": "0"},
                 {"MH_JIT_FUSE": "1", "MH_JIT_LDS_KB": "80", "MH_JIT_CHUNK": "100"},
-                {"MH_JIT_FUSE": "1", "MH_JIT_FUSE_FOLDREG": "0", "MH_JIT_FUSE_PRESS": "40"}]
+                {"MH_JIT_FUSE": "1", "MH_JIT_FUSE_FOLDREG": "0", "MH_JIT_FUSE_PRESS": "40"},
+                # round 6: products in stage-interleaved groups (lz_mulN): four with a window of 32 items, two, a gate's own products only
+                {"MH_JIT_MULGROUP": "4"}, {"MH_JIT_MULGROUP": "2", "MH_JIT_MULWIN": "8"}, {"MH_JIT_MULGROUP": "4", "MH_JIT_MULWIN": "0"},
+                {"MH_JIT_MULGROUP": "3", "MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=0"}]
 
 
 @pytest.mark.parametrize("env", GEN_SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "defaults")

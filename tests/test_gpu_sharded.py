@@ -571,3 +571,32 @@ def test_sharded_trace_upload(world):
     for back, got, _ in res:
         assert (back == canon).all()
         assert got.bytes == res[0][2].bytes
+
+
+def test_the_bench_launcher_path_at_two_ranks_on_one_device(tmp_path):
+    """What the driver runs on the multi-GPU node -- `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` -- end to end at
+    N = 2 on the one device of the test box: rendezvous on 127.0.0.1, the communicator ladder (RCCL refuses two ranks on one device, so the
+    first rung must FAIL with an error on the line, not hang, and the ladder must land on the torch communicator), the 2^12 trial proof, one
+    proof sharded over both ranks, the real statement sharded (a short program), and the one JSON line with `config.comm`, `scale_note` and
+    the summary last."""
+    import json, subprocess
+    env = dict(os.environ, MIDEN_BENCH_COMM_TIMEOUT="90", MH_COMM_TIMEOUT_S="60", MIDEN_BENCH_REAL_ITERS="60", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29500 + (os.getpid() + 1777) % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--shard-log-n", "14"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["value"] > 0 and d["scaling"] == "strong"
+    comm = d["config"]["comm"]
+    assert comm["mode"] == "sharded" and comm["chosen"] == "torch", comm
+    assert [a["choice"] for a in comm["attempts"]] == ["rccl", "torch"], comm
+    assert not comm["attempts"][0]["ok_on_rank0"] and "error" in comm["attempts"][0]
+    assert [s[0] for s in comm["attempts"][1]["steps_s"]] == ["create", "selftest", "trial_proof_2p12"]
+    assert "rccl" in d["config"]["fallback"]
+    assert "2^14" in d["scale_note"] and d["config"]["log_trace_rows"] == 14
+    assert list(d)[-1] == "summary" and d["summary"]["comm"]["chosen"] == "torch"
+    real = d["miden_real_sharded"]
+    assert "error" not in real, real
+    assert d["sharded_breakdown"]["comm_ms"]

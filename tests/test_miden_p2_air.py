@@ -221,7 +221,10 @@ JIT_SWITCHES = [{}, {"MH_JIT_RECOMP": "0"}, {"MH_JIT_RECOMP": "1000", "MH_JIT_CH
                 {"MH_JIT_FLAGS": "-DMH_JIT_FOLDV=0"}, {"MH_JIT_LZCHAIN": "4"}, {"MH_JIT_LZCHAIN": "0"},
                 # round 6: the former product forms next to the merged-statement default (3), one kernel for the whole DAG
                 {"MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=2"}, {"MH_JIT_FUSE": "1"}, {"MH_JIT_FUSE": "1", "MH_JIT_LDS_KB": "0"},
-                {"MH_JIT_FUSE": "1", "MH_JIT_FUSE_FOLDREG": "0", "MH_JIT_FUSE_PRESS": "40"}]
+                {"MH_JIT_FUSE": "1", "MH_JIT_FUSE_FOLDREG": "0", "MH_JIT_FUSE_PRESS": "40"},
+                # round 6: products in stage-interleaved groups (lz_mulN): four with a window of 32 items, two, a gate's own products only
+                {"MH_JIT_MULGROUP": "4"}, {"MH_JIT_MULGROUP": "2", "MH_JIT_MULWIN": "8"}, {"MH_JIT_MULGROUP": "4", "MH_JIT_MULWIN": "0"},
+                {"MH_JIT_MULGROUP": "3", "MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=0"}]
 
 
 @pytest.mark.parametrize("env", JIT_SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "defaults")
