@@ -15,7 +15,7 @@
 //   * `ChipletMultiAir::eval_external` (session/prove.rs:243-256) = mh_external_precompile_session (csrc/verifier.cpp).
 //
 // Written against the public ABI only (include/midenhip.h).  The Python test layer (miden-vm_amd/__init__.py + precompile_airs.py)
-// does the same steps one by one; tests/test_gpu_precompile_c_abi.py compares the two and the oracle byte for byte.
+// does the same steps one by one; tests/test_gpu_precompile_c_abi.py compares the two with the CPU restatement of the test suite, byte for byte.
 #include "../../include/midenhip.h"
 #include "ctx.hpp"
 #include "gl.cuh"

@@ -263,6 +263,8 @@ void verify_impl(const mh_pcs_params& pp, const std::vector<DagIR>& airs, const 
   for (int b : {pp.deep_pow_bits, pp.folding_pow_bits, pp.query_pow_bits})
     if (b < 0 || b > 32) throw Reject("proof-of-work bits must be in 0..32");
   if (pp.log_final_degree < 0 || pp.log_final_degree > 32) throw Reject("log_final_degree must be in 0..32");
+  // PcsParams::new (pcs/params.rs:62-69): FinalDegreeUnreachable -- the reference's verifier can only be built from valid parameters
+  if (pp.log_final_degree + lb < la - 1) throw Reject("final degree unreachable by fixed-arity folding");
   for (size_t i = 0; i < n_airs; i++) {
     if (lhs[i] < 1) throw Reject("trace too small");
     size_t pmax = 0;

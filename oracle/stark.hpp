@@ -35,6 +35,15 @@ namespace oracle {
 struct PcsParams {
   int log_blowup, log_folding_arity, log_final_degree, folding_pow_bits, deep_pow_bits, num_queries, query_pow_bits;
 };
+// PcsParams::new (crates/lifted-stark/src/pcs/params.rs:45-84): InvalidFoldingArity, ZeroBlowup, ZeroQueries, FinalDegreeUnreachable
+// (log_final_degree + log_blowup >= log_folding_arity - 1).  nullptr = valid.
+static inline const char* pcs_params_error(const PcsParams& p) {
+  if (p.log_folding_arity < 1 || p.log_folding_arity > 3) return "invalid folding arity (log_arity must be 1, 2, or 3)";
+  if (p.log_blowup <= 0) return "log_blowup must be > 0";
+  if (p.num_queries <= 0) return "num_queries must be > 0";
+  if (p.log_final_degree < 0 || p.log_final_degree + p.log_blowup < p.log_folding_arity - 1) return "final degree unreachable by fixed-arity folding";
+  return nullptr;
+}
 
 // build_aux_trace callback (crates/lifted-air/src/air.rs LiftedAir::build_aux_trace): fills the
 // flattened EF aux trace (n x 2*aux_width, row-major) and 2*num_aux_values felts. Non-zero = abort.
@@ -185,6 +194,10 @@ static inline Proof prove(ProverInput& in) {
   const int lb = pp.log_blowup;
   const size_t B = (size_t)1 << lb;
   const size_t n_airs = in.airs.size();
+  if (const char* e = pcs_params_error(pp)) throw std::runtime_error(e);
+  // ProverStatement::new (crates/lifted-air: InstanceError::TraceHeightTooSmall): a trace needs a transition
+  for (int lh : in.log_heights)
+    if (lh < 1) throw std::runtime_error("trace height too small (at least 2 rows)");
   std::vector<int> order = proof_order(in.log_heights);
   const int log_n_max = in.log_heights[order.back()];
   const int L = log_n_max + lb;
@@ -683,6 +696,7 @@ static inline Digest verify(const VerifierInput& in, const Proof& proof) {
   const PcsParams& pp = in.params;
   const int lb = pp.log_blowup;
   const size_t n_airs = in.airs.size();
+  if (const char* e = pcs_params_error(pp)) throw VerifyError(e);
   if (proof.log_trace_heights.size() != n_airs) throw VerifyError("trace count mismatch");
   std::vector<int> lhs(proof.log_trace_heights.begin(), proof.log_trace_heights.end());
   for (size_t i = 0; i < n_airs; i++) {

@@ -236,6 +236,11 @@ def prove(airs, traces, publics, params=PROD_PARAMS, init_state=None, pre_observ
     pub = arr(list(publics) or [0])
     st = arr(init_state if init_state is not None else challenger_state())
     preps = [arr(a.preprocessed) if getattr(a, "preprocessed", None) is not None else None for a in airs]
+    for i, (a, m) in enumerate(zip(airs, preps)):       # validate_preprocessed (crates/lifted-stark/src/preprocessed.rs): WidthMismatch / HeightMismatch
+        if m is not None and m.shape[1] != a.preprocessed_width:
+            raise ValueError(f"preprocessed width mismatch for AIR {i}: the AIR declares {a.preprocessed_width}, the matrix has {m.shape[1]}")
+        if m is not None and m.shape[0] != traces[i].shape[0]:
+            raise ValueError(f"preprocessed height mismatch for AIR {i}: main {traces[i].shape[0]}, preprocessed {m.shape[0]}")
     prep_root = preprocessed_commitment(airs, [int(x) for x in lhs], params)
     pre = arr(pre_observe if pre_observe is not None else protocol_pre_observe(params, publics, preprocessed_root=prep_root))
     prep_ptrs = (u64p * n)(*[ptr(m) if m is not None else None for m in preps]) if prep_root is not None else None

@@ -15,20 +15,26 @@ def align(w, a=8):
     return (w + a - 1) // a * a
 
 
-def missing_siblings(indices, depth):
-    """lmcs/tree_indices.rs:185-240: number of sibling digests a batch opening carries, level by level."""
-    cur, count = sorted(set(indices)), 0
+def missing_sibling_nodes(indices, depth):
+    """lmcs/tree_indices.rs:185-240 (MissingSiblingsIter): the (depth, position) of every sibling digest a batch opening carries, bottom-up,
+    left to right -- the order of the hinted commitments on the wire."""
+    cur, out, d = sorted(set(indices)), [], depth
     for _ in range(depth):
         nxt, i = [], 0
         while i < len(cur):
             present = i + 1 < len(cur) and cur[i + 1] == cur[i] ^ 1
             if not present:
-                count += 1
+                out.append((d, cur[i] ^ 1))
             if not nxt or nxt[-1] != cur[i] >> 1:
                 nxt.append(cur[i] >> 1)
             i += 2 if present else 1
-        cur = nxt
-    return count
+        cur, d = nxt, d - 1
+    return out
+
+
+def missing_siblings(indices, depth):
+    """The NUMBER of sibling digests a batch opening carries."""
+    return len(missing_sibling_nodes(indices, depth))
 
 
 def fri_num_rounds(p, log_lde):
@@ -75,7 +81,8 @@ class Streams:
         return w
 
 
-def parse(airs, log_heights, publics, params, fields, commitments, preprocessed_root=None, init_state=None, aux_inputs=(), alignment=8):
+def parse(airs, log_heights, publics, params, fields, commitments, preprocessed_root=None, init_state=None, aux_inputs=(), alignment=8,
+          pre_observe=None):
     """-> dict with the named pieces of StarkProof + PcsProof, `digest`, and `sizes` (felts / commitments per section).
     alignment = lmcs.alignment() of the configuration (proof.rs:268): 8 (Poseidon2 / RPO / RPX), 1 (Blake3), 17 (Keccak); the
     challenger is the oracle's for the configuration set with ob.set_lmcs."""
@@ -87,7 +94,8 @@ def parse(airs, log_heights, publics, params, fields, commitments, preprocessed_
     log_n = max(log_heights)
     L = log_n + lb
     ch = ob.Challenger(init_state if init_state is not None else ob.challenger_state())
-    ch.observe(ob.protocol_pre_observe(params, publics, aux_inputs, preprocessed_root=preprocessed_root))
+    # pre_observe: a caller's own transcript prefix (e.g. the bare `MultiAir::observe` framing of the lifted-stark crate's tests)
+    ch.observe(pre_observe if pre_observe is not None else ob.protocol_pre_observe(params, publics, aux_inputs, preprocessed_root=preprocessed_root))
     ch.observe([n] + [int(h) for h in log_heights])                        # order.rs:154-163 observe_shape
     s = Streams(fields, commitments, ch)
     out, sizes = {}, {}

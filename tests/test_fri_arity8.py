@@ -97,3 +97,51 @@ def test_fri_round_counts_arity8():
     assert proof["commitments"].shape[0] >= n_roots
     ok, _ = ob.verify([A.fib_air()], proof["log_heights"], pub, proof, p)
     assert ok
+
+
+# ---- the rest of the reference's fold tests (round 6: crates/lifted-stark/src/pcs/fri/fold/{mod,arity4,arity8}.rs, 6 tests) -----------------
+#   test_fold                          -> test_fold_recovers_f_of_beta (above)
+#   test_fold_evals_against_naive_dft  -> test_fold_evals_against_naive_dft
+#   test_ifft4, test_ifft8             -> test_fold_evals_against_naive_dft at s = 1 (the inverse transform of a bit-reversed coset row IS what fold_evals
+#                                         evaluates at beta: the coefficients come back exactly -- the reference's functions return them scaled by the arity)
+#   test_fold_matrix                   -> scalar vs packed equivalence of the reference's OWN two code paths: n/a for a restatement with one path; the
+#                                         device's fold kernel against the row function is tests/test_gpu_prove.py (whole proofs, arity 2 / 4 / 8)
+#   test_fold_low_degree               -> test_folding_preserves_low_degree
+def ef_dft(vals, inverse=False):
+    """DFT of extension-field values: the transform is linear over the base field, so it acts on the two coordinates separately."""
+    c0 = ob.dft(np.array([v[0] for v in vals], dtype=np.uint64), inverse=inverse)
+    c1 = ob.dft(np.array([v[1] for v in vals], dtype=np.uint64), inverse=inverse)
+    return [(int(a), int(b)) for a, b in zip(c0, c1)]
+
+
+@pytest.mark.parametrize("log_arity", [1, 2, 3])
+def test_fold_evals_against_naive_dft(log_arity):
+    rng = np.random.default_rng(42)
+    arity = 1 << log_arity
+    coeffs = [(rnd(rng), rnd(rng)) for _ in range(arity)]
+    for s in (1, rnd(rng, 1)):                           # s = 1: test_ifft4 / test_ifft8's plain subgroup; a random shift: the coset DFT
+        scaled = [emul(c, (pow(s, k, P), 0)) for k, c in enumerate(coeffs)]                # coset DFT = DFT of c_k s^k
+        evals = ef_dft(scaled)
+        evals_br = [evals[bitrev(i, log_arity)] for i in range(arity)]
+        beta = (rnd(rng), rnd(rng))
+        assert fold_row(evals_br, log_arity, pow(s, P - 2, P), beta) == horner(coeffs, beta)
+        assert ef_dft(evals, inverse=True) == scaled      # the exact inverse transform (test_ifft4 / test_ifft8 return arity x these)
+
+
+@pytest.mark.parametrize("log_arity", [1, 2, 3])
+def test_folding_preserves_low_degree(log_arity):
+    """A degree-16 polynomial on a 64-point domain (blowup 4), folded once with arity 2 / 4 / 8: the folded evaluations interpolate to a
+    polynomial of degree < 16 / arity -- every higher coefficient is exactly zero."""
+    rng = np.random.default_rng(42)
+    arity, log_lde, deg = 1 << log_arity, 6, 16
+    coeffs = [(rnd(rng), rnd(rng)) for _ in range(deg)] + [(0, 0)] * ((1 << log_lde) - deg)
+    evals = ef_dft(coeffs)
+    evals_br = [evals[bitrev(i, log_lde)] for i in range(1 << log_lde)]
+    n_cosets = (1 << log_lde) >> log_arity
+    g_inv = pow(int(ob.lib().orc_two_adic_generator(log_lde)), P - 2, P)
+    s_invs = [pow(g_inv, bitrev(i, log_lde - log_arity), P) for i in range(n_cosets)]       # g^-i, bit-reversed
+    beta = (rnd(rng), rnd(rng))
+    folded = [fold_row(evals_br[r * arity:(r + 1) * arity], log_arity, s_invs[r], beta) for r in range(n_cosets)]
+    nat = [folded[bitrev(i, log_lde - log_arity)] for i in range(n_cosets)]
+    fc = ef_dft(nat, inverse=True)
+    assert all(c == (0, 0) for c in fc[deg // arity:]) and any(c != (0, 0) for c in fc[:deg // arity])

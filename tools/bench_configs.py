@@ -34,6 +34,29 @@ def run(name, airs_, traces, prm, lookups=None, reps=3):
 
 
 P16 = ob.CONFIG5_PARAMS
+
+
+def run_fib(iters_log=16):
+    """BASELINE configs[0]: fib.masm (`repeat.N swap dup.1 add end`, one basic block) with N = 2^16, the REAL three-AIR statement through
+    mh_prove_miden_traces (traces resident), under Poseidon2 and the reference's default Blake3."""
+    from miden_vm_amd.testing import core_trace as CV
+    r = CV.prove_inputs(CV.CoreVM(stack_inputs=(0, 1) + (0,) * 14), CV.Span(["SWAP", "DUP1", "ADD"] * (1 << iters_log)))
+    m = pkg.Miden(ctx)
+    dtr = [ctx.upload_trace(r[k]) for k in ("core", "chiplets", "poseidon2")]
+    for h in ("poseidon2", "blake3"):
+        m.prove(*dtr, r["public_values"], r["aux_inputs"], hash_fn=h)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            p = m.prove(*dtr, r["public_values"], r["aux_inputs"], hash_fn=h)
+        dt = (time.perf_counter() - t0) / 3
+        ok = pkg.verify_miden(r["public_values"], r["aux_inputs"], p.bytes, hash_fn=h)[0]
+        print(f"{'configs[0] fib.masm 2^%d iterations, real statement 2^18 / 2^13 / 2^16, %s' % (iters_log, h):58s} {dt * 1e3:9.1f} ms  "
+              f"{r['core'].shape[0] / dt / 1e6:7.2f} M rows/s  proof {len(p.bytes) / 1024:6.1f} KiB  verifies {ok}", flush=True)
+    for d in dtr:
+        d.free()
+
+
+run_fib()
 run("configs[1] miden:20:51:8 (bench.py workload)", [dag.dummy_miden_air(51, 8)], [A.dummy_trace(20, 51)], ob.PROD_PARAMS)
 run("configs[2] shape: 2^22x51(+4) 2^21x22(+3) 2^20x16(+1)", [dag.dummy_miden_air(51, 4), dag.dummy_miden_air(22, 3), dag.dummy_miden_air(16, 1)],
     [A.dummy_trace(22, 51, 3), A.dummy_trace(21, 22, 4), A.dummy_trace(20, 16, 5)], ob.PROD_PARAMS)
