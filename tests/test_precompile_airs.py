@@ -15,6 +15,7 @@ from __graft_entry__ import load_package
 pkg = load_package()
 from miden_vm_amd import precompile_airs as PA, dag, protocol  # noqa: E402
 from miden_vm_amd.testing import precompile_trace as PT  # noqa: E402
+pytestmark = pytest.mark.usefixtures("fast_oracle_build")   # session-sized oracle proofs: the fast build of the checker (tests/conftest.py)
 
 P = dag.P
 RND = [(0x1234567890abcdef % P, 0x0fedcba987654321), (3141592653589793, 2718281828459045)]

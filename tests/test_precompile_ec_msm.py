@@ -17,6 +17,7 @@ pkg = load_package()
 from miden_vm_amd import precompile_airs as PA, dag, protocol  # noqa: E402
 from miden_vm_amd.testing import precompile_trace as PT  # noqa: E402
 import test_precompile_ec_add as EA  # noqa: E402
+pytestmark = pytest.mark.usefixtures("fast_oracle_build")   # session-sized oracle proofs: the fast build of the checker (tests/conftest.py)
 
 P = dag.P
 RND, FAST = EA.RND, EA.FAST

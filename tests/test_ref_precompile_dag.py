@@ -51,6 +51,7 @@ from __graft_entry__ import load_package
 pkg = load_package()
 from miden_vm_amd import precompile_airs as PA, dag, protocol, miden_air as MA  # noqa: E402
 from miden_vm_amd.testing import precompile_trace as PT  # noqa: E402
+pytestmark = pytest.mark.usefixtures("fast_oracle_build")   # session-sized oracle proofs: the fast build of the checker (tests/conftest.py)
 
 P = dag.P
 FP, FQ, GROUP = PA.K1_BASE_BOUND_PTR, PA.K1_SCALAR_BOUND_PTR, PA.K1_GROUP_PTR

@@ -34,6 +34,7 @@ pkg = load_package()
 from miden_vm_amd import precompile_airs as PA, dag  # noqa: E402
 from miden_vm_amd.testing import precompile_trace as PT  # noqa: E402
 import test_ref_precompile_dag as D  # noqa: E402
+pytestmark = pytest.mark.usefixtures("fast_oracle_build")   # session-sized oracle proofs: the fast build of the checker (tests/conftest.py)
 
 P = dag.P
 FP, SN, GROUP = PA.K1_BASE_BOUND_PTR, PA.K1_SCALAR_BOUND_PTR, PA.K1_GROUP_PTR
