@@ -15,6 +15,6 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INS
 # the real statement (kernel stats) and the per-chunk view of the core AIR's constraint kernels (trace + PMC)
 rocprofv3 --kernel-trace --stats -d $O/kt_real -o kt --output-format csv -- python tools/bench_miden_real.py > $O/real.log 2>&1
 tail -1 $O/real.log | cut -c1-300
-MH_JIT_CACHE_DIR=/tmp/jc bash tools/prof_jit_core.sh r5_final > $O/jit_core.txt 2>&1
-tail -5 $O/jit_core.txt
+if [ "${MH_PROF_JIT_CORE:-0}" = 1 ]; then MH_JIT_CACHE_DIR=/tmp/jc bash tools/prof_jit_core.sh final > $O/jit_core.txt 2>&1; tail -5 $O/jit_core.txt; fi
+if [ "${MH_PROF_GPUTEST:-0}" = 1 ]; then timeout 2700 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; tail -4 $O/pytest_gpu.txt; fi
 ls -R $O | head -60
