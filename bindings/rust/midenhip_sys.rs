@@ -78,6 +78,8 @@ unsafe extern "C" {
     pub fn mh_ctx_create(device_id: c_int, out: *mut *mut mh_ctx) -> c_int;
     pub fn mh_ctx_destroy(ctx: *mut mh_ctx);
     pub fn mh_ctx_trim(ctx: *mut mh_ctx) -> c_int;
+    /// out = [pool bytes, table bytes, device free, device total]
+    pub fn mh_ctx_mem_stats(ctx: *mut mh_ctx, out: *mut u64) -> c_int;
     pub fn mh_last_error(ctx: *const mh_ctx) -> *const c_char;
     pub fn mh_device_count() -> c_int;
     /// MH_LMCS_POSEIDON2 = 0, MH_LMCS_BLAKE3 = 1 (the hasher of mh_commit_traces / mh_tree_open on this context)

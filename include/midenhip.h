@@ -39,6 +39,9 @@ int mh_ctx_create(int device_id, mh_ctx** out);
 void mh_ctx_destroy(mh_ctx* ctx);
 /* Release the device buffers the context keeps pooled between proofs (freed automatically on OOM and at destroy). */
 int mh_ctx_trim(mh_ctx* ctx);
+/* Device memory as a long-lived service sees it: out[0] = bytes cached in the context's buffer pool (returned by mh_ctx_trim),
+ * out[1] = bytes of twiddle / coset tables the context keeps, out[2] = free and out[3] = total bytes of the device (hipMemGetInfo). */
+int mh_ctx_mem_stats(mh_ctx* ctx, uint64_t out[4]);
 const char* mh_last_error(const mh_ctx* ctx);
 int mh_device_count(void);
 

@@ -20,7 +20,7 @@ P = 0xFFFFFFFF00000001
 u64p = C.POINTER(C.c_uint64)
 
 EXPORTS = [
-    "mh_ctx_create", "mh_ctx_destroy", "mh_ctx_trim", "mh_last_error", "mh_device_count", "mh_prof_enable", "mh_prof_filter", "mh_prof_reset",
+    "mh_ctx_create", "mh_ctx_destroy", "mh_ctx_trim", "mh_ctx_mem_stats", "mh_last_error", "mh_device_count", "mh_prof_enable", "mh_prof_filter", "mh_prof_reset",
     "mh_prof_get", "mh_prof_dump", "mh_poseidon2_permute", "mh_poseidon2_register_rate", "mh_coset_lde_batch", "mh_trace_upload", "mh_trace_upload_async", "mh_trace_upload_cols_async", "mh_trace_wait", "mh_trace_free",
     "mh_commit_traces", "mh_tree_free", "mh_tree_root", "mh_tree_log_height", "mh_tree_open", "mh_tree_download_lde",
     "mh_tree_download_layers", "mh_air_load", "mh_air_free", "mh_air_log_quotient_degree", "mh_air_compiled_chunks", "mh_air_compiled_max_vgprs", "mh_jit_precompile", "mh_prove", "mh_prove_host", "mh_proof_free",
@@ -177,6 +177,12 @@ class Ctx:
     def trim(self):
         """Release the device buffers pooled between proofs."""
         self.check(self.lib.mh_ctx_trim(self.h))
+
+    def mem_stats(self):
+        """(pool bytes, table bytes, device free, device total): what a long-lived service watches (mh_ctx_mem_stats)."""
+        out = (C.c_uint64 * 4)()
+        self.check(self.lib.mh_ctx_mem_stats(self.h, out))
+        return dict(zip(("pool", "tables", "free", "total"), (int(v) for v in out)))
 
     LMCS = {"poseidon2": 0, "blake3": 1, "keccak": 2, "rpo": 3, "rpx": 4}
 

@@ -10,6 +10,9 @@
 #pragma once
 #include "ctx.hpp"
 #include <vector>
+#include <mutex>
+#include <map>
+#include <array>
 
 enum DagOp : uint32_t {
   DOP_CONST = 0, DOP_MAIN = 1, DOP_AUX = 2, DOP_PUBLIC = 3, DOP_PERIODIC = 4, DOP_IS_FIRST = 5, DOP_IS_LAST = 6,
@@ -79,6 +82,11 @@ struct mh_air {
   DevBuf d_code;
   JitProgram* jit = nullptr;  // specialised constraint kernels (large DAGs), else the interpreter runs
   const struct mh_lookup* lookup = nullptr;  // attached LogUp program: the aux trace is built on the device
+  // PeriodicLde::build (prover/periodic.rs:49-77) per (log_n, log_blowup, log_d): the table depends on the AIR and the domain only, never
+  // on a challenge, and costs O(P^2 D) field operations per column on the host -- 3.4 ms per proof for the 128-slot round programme of
+  // KeccakRoundAir, a stall of the stream in the middle of every session proof until round 6 cached it here
+  mutable std::mutex ptab_mu;
+  mutable std::map<std::array<int, 3>, std::vector<u64>> ptab_cache;
   ~mh_air() { jit_program_free(jit); }
 
   size_t max_period() const {

@@ -1760,5 +1760,5 @@ void jit_quotient_run(mh_ctx* c, const JitProgram* p, JitArgs a, size_t total) {
     for (hipFunction_t f : p->fns)
       HIP_CHECK(hipModuleLaunchKernel(f, (unsigned)((a.q_count + 255) / 256), 1, 1, 256, 1, 1, 0, c->stream, params, nullptr));
   }
-  HIP_CHECK(hipStreamSynchronize(c->stream));  // the spill area dies with this scope
+  // no host wait: the spill area and the uniform table are pool buffers, their reuse is ordered on the stream
 }

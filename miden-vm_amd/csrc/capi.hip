@@ -125,6 +125,20 @@ int mh_ctx_trim(mh_ctx* c) {
   MH_CATCH
 }
 
+int mh_ctx_mem_stats(mh_ctx* c, uint64_t out[4]) {
+  MH_TRY(c)
+  MH_REQUIRE(c && out, "null argument");
+  HIP_CHECK(hipSetDevice(c->device));
+  size_t fr = 0, tot = 0, tab = 0;
+  HIP_CHECK(hipMemGetInfo(&fr, &tot));
+  for (auto& kv : c->tables) tab += kv.second.bytes;
+  out[0] = c->pool.cached_bytes;
+  out[1] = tab;
+  out[2] = fr;
+  out[3] = tot;
+  MH_CATCH
+}
+
 const char* mh_last_error(const mh_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 
 int mh_prof_enable(mh_ctx* c, int on) {

@@ -233,10 +233,18 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
       p = e2_mul(p, alpha);
     }
   }
-  // periodic table on the quotient coset (prover/periodic.rs:49-77), O(P^2 D) on the host
+  // periodic table on the quotient coset (prover/periodic.rs:49-77), O(P^2 D) on the host -- once per (AIR, domain): cached in the AIR
   const size_t Pm = air->max_period();
   const size_t prow = Pm ? Pm * Dg : 1;
-  std::vector<u64> ptab(std::max<size_t>(1, air->periodic.size() * prow));
+  std::vector<u64> ptab;
+  const std::array<int, 3> pkey{log_n, log_blowup, log_d};
+  {
+    std::lock_guard<std::mutex> lk(air->ptab_mu);
+    auto it = air->ptab_cache.find(pkey);
+    if (it != air->ptab_cache.end()) ptab = it->second;
+  }
+  if (ptab.empty()) {
+  ptab.assign(std::max<size_t>(1, air->periodic.size() * prow), 0);
   if (Pm) {
     int logP = 0;
     while (((size_t)1 << logP) < Pm) logP++;
@@ -264,6 +272,10 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
         y = gl_mul(y, wPD);
       }
     }
+  }
+  std::lock_guard<std::mutex> lk(air->ptab_mu);
+  if (air->ptab_cache.size() >= 16) air->ptab_cache.clear();  // a service proving many heights with one AIR: bounded
+  air->ptab_cache[pkey] = ptab;
   }
   std::vector<u64> pub(std::max<size_t>(1, publics.size())), rnd(2 * std::max<size_t>(1, randomness.size())),
       av(2 * std::max<size_t>(1, aux_values.size()));
@@ -318,8 +330,7 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
     if (!jit_program_fused(air->jit))  // a fused program has applied 1/Z_H and the beta accumulation itself
       MH_LAUNCH(k_quot_finish, dim3((unsigned)((n * D + 255) / 256)), dim3(256), 0, c->stream, acc_out, dblob.u() + o_tab, log_n,
                          log_dl, acc_in, log_n_prev, beta);
-    HIP_CHECK(hipStreamSynchronize(c->stream));
-    return;
+    return;  // no host wait: the tables are pool buffers (stream-ordered reuse), the parameter block went through the h2d ring
   }
   QuotArgs a{};
   a.code = (const AirIns*)air->d_code.p;
@@ -352,7 +363,8 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
     ProfScope ps(c, "quotient_eval", (double)n * D * (8.0 * air->touched_base_columns + 16.0));
     MH_LAUNCH(k_eval_quotient, dim3((unsigned)((n * D + T - 1) / T)), dim3(T), lds, c->stream, a);
   }
-  HIP_CHECK(hipStreamSynchronize(c->stream));  // tables die with this scope
+  // no host wait here either: the next AIR's tables are prepared while this one's kernels run (the tables of this scope are pool
+  // buffers: their reuse is ordered on the stream; copy-stream users fence on it, prover.hip)
 }
 
 // ---- per-AIR quotient degree below the batch degree (prover/mod.rs:520-528, quotient.rs:45-58) ------
@@ -411,5 +423,4 @@ void quotient_upsample_accumulate(mh_ctx* c, const u64* q_small, int log_n, int 
   if (total)
     MH_LAUNCH(k_quot_regroup_accumulate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, lde.u(), log_n, log_dj,
                        log_d, acc_in, log_n_prev, beta, acc_out, t_first, n_local);
-  HIP_CHECK(hipStreamSynchronize(c->stream));
 }
