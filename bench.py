@@ -1324,7 +1324,7 @@ def main():
                       if log_n >= 22 else None),
             "model_note": "per-rank ms predicted from the single-GPU spans of profiles/r03_config_shapes.txt (2^24: 739 ms) with "
                           "60 GB/s per xGMI link and direction; replicated = inverse NTTs + host-serial tree tops / transcript"}
-    pmc_json = next(f for f in ("r05_pmc_leaf_absorb.json", "r04_pmc_leaf_absorb.json", "r03_pmc_leaf_absorb.json", "r02_pmc_leaf_absorb.json")
+    pmc_json = next(f for f in ("r06_pmc_leaf_absorb.json", "r05_pmc_leaf_absorb.json", "r04_pmc_leaf_absorb.json", "r03_pmc_leaf_absorb.json", "r02_pmc_leaf_absorb.json")
                     if os.path.exists(os.path.join(ROOT, "profiles", f)))
     # the dominant class of the full pass must be the one the timed region recorded; if a configuration moves it, say so and fall back
     full_dom = max((k for k in prof if not k.startswith(("comm_", "span:")) and k != "lde_intt"), key=lambda k: prof[k]["ms"]) if prof else None
