@@ -1543,7 +1543,7 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
         case DOP_AUX_VALUE: snprintf(buf, sizeof buf, "e2{a.aux_values[%u], a.aux_values[%u]}", 2 * nd.a, 2 * nd.a + 1); return buf;
         default: break;
       }
-      snprintf(buf, sizeof buf, "u%u", id);
+      snprintf(buf, sizeof buf, "un%u", id);
       return buf;
     };
     for (size_t i = 0; i < nodes.size(); i++) {
@@ -1563,9 +1563,11 @@ static JitProgram* jit_program_build_cuts(mh_ctx* ctx, const DagIR& ir, const st
         else if (nd.op == DOP_SUB) rhs = ea ? "e2_subf(" + A + ", " + Bv + ")" : "e2_fsub(" + A + ", " + Bv + ")";
         else rhs = std::string("e2_") + f2 + "f(" + (ea ? A + ", " + Bv : Bv + ", " + A) + ")";
       }
-      src << "  const " << (nd.ext ? "e2" : "u64") << " u" << i << " = " << rhs << ";\n";
-      if (nd.ext) src << "  U[" << uni_slot[i] << "] = u" << i << ".c0; U[" << uni_slot[i] + 1 << "] = u" << i << ".c1;\n";
-      else src << "  U[" << uni_slot[i] << "] = u" << i << ";\n";
+      // "un<id>", not "u<id>": node 32 / 64 / 128 would shadow the prelude's u32 / u64 / u128 for the rest of the kernel (found by the
+      // randomised parity test, tests/test_gpu_fuzz_parity.py, on its first statement)
+      src << "  const " << (nd.ext ? "e2" : "u64") << " un" << i << " = " << rhs << ";\n";
+      if (nd.ext) src << "  U[" << uni_slot[i] << "] = un" << i << ".c0; U[" << uni_slot[i] + 1 << "] = un" << i << ".c1;\n";
+      else src << "  U[" << uni_slot[i] << "] = un" << i << ";\n";
     }
     src << "}\n";
     chunks.push_back({0, 0, src.str(), {}, {}});  // compiled and cached with the chunks; launched once per call, ahead of them

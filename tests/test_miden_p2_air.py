@@ -255,3 +255,31 @@ def test_config5_parameters_on_the_real_air_both_verifiers():
     ok2, dig = pkg.verify([air], [9], [], prm, ob.challenger_state(), ob.protocol_pre_observe(prm, []), proof["fields"], proof["commitments"])
     assert ok2 and (dig == proof["digest"]).all()
     assert not ob.verify([air], [9], [], proof, ob.PROD_PARAMS)[0]          # the parameters are part of the statement
+
+
+def test_uniform_gates_at_node_ids_32_64_128_compile(tmp_path, monkeypatch):
+    """The uniform kernel named its values `u<node id>`: a uniform gate at node 32, 64 or 128 shadowed the prelude's u32 / u64 / u128
+    types for the rest of the kernel and the chunk did not compile (found by tests/test_gpu_fuzz_parity.py on its first statement; none of
+    the shipped AIRs has a uniform gate at such an id).  Offline hiprtc compile of a DAG built to put one at each of the three."""
+    monkeypatch.setenv("MH_JIT_CHUNK", "24")
+    monkeypatch.setenv("MH_JIT", "1")            # a DAG this small would take the interpreter
+    b = dag.AirBuilder(4, aux_width=1, num_randomness=2, num_aux_values=1, num_public=2)
+    p0, p1, r0 = b.public(0), b.public(1), b.randomness(0)
+    gates = {32: lambda: p0 + p1, 64: lambda: p0 * r0, 128: lambda: p1 * p1}     # two base-field and one EF-valued uniform gate
+    acc, k, made = b.main(0), 1, []
+    while len(b.nodes) < 130:
+        if len(b.nodes) in gates:
+            u = gates[len(b.nodes)]()
+            assert u.id in gates, u.id
+            made.append(u.id)
+            b.assert_zero_ext(b.aux(0) * u + acc) if u.ext else b.assert_zero(acc * u + b.main(1))
+        elif min(g - len(b.nodes) for g in gates if g > len(b.nodes)) <= 4 if len(b.nodes) < 128 else False:
+            k += 1
+            b.const(1000 + k)                      # one node at a time up to the next target id
+        else:
+            k += 1
+            acc = acc * b.main(k % 4) + b.const(k) if k % 3 else acc + b.main(k % 4, 1)
+    assert made == [32, 64, 128]
+    b.assert_zero(acc)
+    air = dag.Air(b, None, "uniform-ids")
+    assert load_package().jit_precompile(air.blob, str(tmp_path)) >= 2
