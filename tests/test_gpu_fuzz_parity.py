@@ -79,3 +79,52 @@ def test_random_statements_device_equals_oracle():
     for seed in range(first, first + n):
         run_one(pkg, ctx, seed)
     ctx.close()
+
+
+def test_random_statements_sharded_equal_single_gpu():
+    """The same random statements through the SHARDED prover at world 2 / 4 / 8 -- thread ranks on one device joined by
+    the stream-ordered local communicator, what the RCCL communicator is on a multi-GPU node: every rank's proof must equal the single-GPU proof
+    of the same context (which the test above holds equal to the oracle's).  Shapes no fixed case covers: more ranks than LDE cosets or
+    quotient chunks, traces shorter than the world, mixed heights and degrees, preprocessed columns, every FRI arity.
+    MH_FUZZ_SHARDED_SEEDS=N (default 12)."""
+    from test_gpu_sharded import _thread_ranks
+    first, n = int(os.environ.get("MH_FUZZ_FIRST", "1")), int(os.environ.get("MH_FUZZ_SHARDED_SEEDS", "12"))
+    pub = [5, 7]
+    for seed in range(first, first + n):
+        airs_, traces, params, lmcs, jit = random_statement(seed)
+        world = int(np.random.default_rng(77 + seed).choice([w for w in (2, 4, 8) if w <= 1 << params["log_blowup"]]))   # one LDE coset per rank at least
+        what = f"seed {seed}: world {world}, heights {[t.shape[0] for t in traces]}, widths {[t.shape[1] for t in traces]}, {params}"
+
+        def body(pkg, sharding, rank, ctx, comm):
+            dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+            dtr = [ctx.upload_trace(t) for t in traces]
+            # the preprocessed setup is part of the statement: committed sharded like every other tree
+            with_prep = [i for i in sorted(range(len(airs_)), key=lambda i: (traces[i].shape[0], i)) if airs_[i].preprocessed is not None]
+            root = None
+            if with_prep:
+                com = sharding.commit_traces_sharded(pkg, ctx, comm, [ctx.upload_trace(airs_[i].preprocessed) for i in with_prep], params["log_blowup"])
+                for k, i in enumerate(with_prep):
+                    dairs[i].attach_preprocessed(com.tree(), k)
+                root = com.root()
+            pre = ob.protocol_pre_observe(params, pub, preprocessed_root=root)
+
+            def aux_builder(idx, rnd):
+                return airs_[idx].build_aux(traces[idx], rnd)
+
+            got = sharding.prove_sharded(pkg, ctx, comm, dairs, dtr, pub, params, ob.challenger_state(), pre, aux_builder)
+            return got.fields.copy(), [c.copy() for c in got.commitments], got.digest.copy(), root
+
+        res = _thread_ranks(world, body)
+        pkg = load_package()
+        ctx = pkg.Ctx(0)
+        try:
+            dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+            root = attach_preprocessed(ctx, airs_, dairs, traces, params)
+            ref = pkg.prove(ctx, dairs, [ctx.upload_trace(t) for t in traces], pub, params, ob.challenger_state(),
+                            ob.protocol_pre_observe(params, pub, preprocessed_root=root), lambda idx, rnd: airs_[idx].build_aux(traces[idx], rnd))
+            for r, (f, cm, dg, rt) in enumerate(res):
+                assert (rt is None) == (root is None) and (rt is None or (np.asarray(rt) == np.asarray(root)).all()), f"{what}: rank {r} setup root"
+                assert f.size == ref.fields.size and (f == ref.fields).all(), f"{what}: rank {r} transcript differs"
+                assert all((a == b).all() for a, b in zip(cm, ref.commitments)) and (dg == ref.digest).all(), f"{what}: rank {r}"
+        finally:
+            ctx.close()
