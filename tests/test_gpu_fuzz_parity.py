@@ -128,3 +128,86 @@ def test_random_statements_sharded_equal_single_gpu():
                 assert all((a == b).all() for a, b in zip(cm, ref.commitments)) and (dg == ref.digest).all(), f"{what}: rank {r}"
         finally:
             ctx.close()
+
+
+def random_lookup(seed, log_n):
+    """A random lookup program (LogUp columns + register columns): per column a few fractions whose multiplicities and denominators are
+    random expressions over the row window, periodic columns (when the trace is long enough), constants and the EF challenges."""
+    from miden_vm_amd import dag
+    rng = np.random.default_rng(0x10090000 + seed)
+    width = int(rng.integers(1, 12))
+    periodic = A.PERIODIC_COLS if log_n >= 3 else ()
+    num_cols = int(rng.integers(1, 7))
+    b = dag.LookupBuilder(width, num_cols=num_cols, num_randomness=2, periodic=periodic)
+
+    def leaf(allow_ef):
+        k = int(rng.integers(0, 6 if periodic else 5))
+        if k == 0:
+            return b.main(int(rng.integers(0, width)), int(rng.integers(0, 2)))
+        if k == 1:
+            return b.const(int(rng.integers(0, ob.P, dtype=np.uint64)))
+        if k == 2:
+            return b.const(int(rng.integers(0, 5)))
+        if k == 3:
+            return b.randomness(int(rng.integers(0, 2))) if allow_ef else b.main(int(rng.integers(0, width)))
+        if k == 4:
+            return b.main(int(rng.integers(0, width)))
+        return b.periodic_value(int(rng.integers(0, 2)))
+
+    def expr(depth, allow_ef=True):
+        if depth == 0 or rng.random() < 0.3:
+            return leaf(allow_ef)
+        op = int(rng.integers(0, 4))
+        x = expr(depth - 1, allow_ef)
+        if op == 3:
+            return -x
+        y = expr(depth - 1, allow_ef)
+        return x + y if op == 0 else x - y if op == 1 else x * y
+
+    for col in range(num_cols):
+        for _ in range(int(rng.integers(0 if col else 1, 5))):
+            # a denominator that is nonzero with overwhelming probability: challenge + random expression
+            b.fraction(col, expr(2, allow_ef=bool(rng.random() < 0.3)), b.randomness(0) + expr(3))
+    for k in range(int(rng.integers(0, 3))):
+        terms = [(j, expr(1)) for j in range(k) if rng.random() < 0.5]
+        b.register(None if rng.random() < 0.3 else expr(2), expr(2), terms)
+    return dag.Lookup(b, f"random:{seed}"), width
+
+
+def test_random_lookup_programs_device_equals_oracle():
+    """Random lookup programs on random traces of 2^1 .. 2^13 rows: the aux trace built on the device (fraction evaluation, batch inversion,
+    the running sum's scan, register columns by scans over affine maps) equals the oracle's cell for cell, and so does the final.
+    MH_FUZZ_LOOKUP_SEEDS=N (default 40)."""
+    pkg = load_package()
+    ctx = pkg.Ctx(0)
+    first, n = int(os.environ.get("MH_FUZZ_FIRST", "1")), int(os.environ.get("MH_FUZZ_LOOKUP_SEEDS", "40"))
+    refused = 0
+    for seed in range(first, first + n):
+        rng = np.random.default_rng(0xa0000 + seed)
+        log_n = int(rng.integers(1, 14))
+        lookup, width = random_lookup(seed, log_n)
+        main = rng.integers(0, ob.P, (1 << log_n, width), dtype=np.uint64)
+        if rng.random() < 0.3:
+            main[:, 0] = rng.integers(0, 3, 1 << log_n, dtype=np.uint64)          # small values: repeated denominators, zero multiplicities
+        rnd = [(int(rng.integers(1, ob.P, dtype=np.uint64)), int(rng.integers(0, ob.P, dtype=np.uint64))) for _ in range(2)]
+        what = f"seed {seed}: 2^{log_n} rows x {width}, {lookup.num_cols} LogUp columns + {lookup.num_regs} registers"
+        dl = pkg.DeviceLookup(ctx, lookup)
+        dtr = ctx.upload_trace(main)
+        try:
+            aux, exp_fin = ob.lookup_build_aux(lookup, main, rnd)
+        except RuntimeError as e:               # a denominator that vanishes (r0 + (-r0) happens): the device must refuse it too
+            assert "non-zero" in str(e), what
+            with pytest.raises(pkg.MidenHipError, match="denominator"):
+                dl.build_aux(dtr, rnd)
+            refused += 1
+            continue
+        aux_dev, fin = dl.build_aux(dtr, rnd)
+        got = aux_dev.download()
+        assert got.shape == aux.shape, what
+        bad = np.argwhere(got != aux)
+        assert bad.size == 0, f"{what}: first differing aux cell (row, col) = {bad[0]}"
+        assert fin == (int(exp_fin[0]), int(exp_fin[1])), what
+        for h in (aux_dev, dtr, dl):
+            h.free()
+    assert refused < n / 4          # the generator must mostly produce programs that run
+    ctx.close()

@@ -108,3 +108,42 @@ def test_preprocessed_commitment_is_checked():
     p2 = ob.prove([A.fib_air()], [t], pub, ARITY4)
     assert not pkg.verify([A.fib_air()], p2["log_heights"], pub, ARITY4, ob.challenger_state(), ob.protocol_pre_observe(ARITY4, pub),
                           p2["fields"], p2["commitments"], preprocessed_root=root)[0]
+
+
+@pytest.mark.parametrize("name,airs_,traces,pub,prm", list(cases()), ids=[c[0] for c in cases()])
+def test_verifiers_agree_on_random_tamperings(name, airs_, traces, pub, prm):
+    """Differential soundness check of the two verifier restatements on EVERY statement kind above (multi-AIR, LogUp, preprocessed, both
+    arities): ~130 random single-site tamperings of a valid proof each -- a field incremented, replaced by a random element, set to zero,
+    two neighbours swapped, one digest word of a commitment changed.  The product's host verifier and the oracle's must return the same
+    verdict every time (a verifier that accepts what the other rejects has a hole), and all but a handful must be rejections (an altered
+    proof-of-work witness can stay valid, swapping equal neighbours changes nothing)."""
+    proof = ob.prove(airs_, traces, pub, prm)
+    f, c, lhs = proof["fields"], proof["commitments"], proof["log_heights"]
+    rng = np.random.default_rng(abs(hash(name)) % (1 << 32))
+    rejected = total = 0
+    for kind in ("inc", "rand", "zero", "swap"):
+        for pos in rng.integers(0, f.size - 1, 30):
+            bad = f.copy()
+            if kind == "inc":
+                bad[pos] = (int(bad[pos]) + 1) % A.P
+            elif kind == "rand":
+                bad[pos] = rng.integers(0, A.P, dtype=np.uint64)
+            elif kind == "zero":
+                bad[pos] = 0
+            else:
+                bad[pos], bad[pos + 1] = f[pos + 1], f[pos]
+            if (bad == f).all():
+                continue
+            ok_p, _ = product_verify(airs_, lhs, pub, prm, bad, c)
+            ok_o, _ = ob.verify(airs_, lhs, pub, {"fields": bad, "commitments": c}, prm)
+            assert ok_p == ok_o, f"{name}: verifiers disagree on `{kind}` at field {pos} of {f.size}: product {ok_p}, oracle {ok_o}"
+            total += 1
+            rejected += not ok_p
+    for pos in range(len(c)):
+        bad = c.copy()
+        w = int(rng.integers(0, 4))
+        bad[pos, w] = (int(bad[pos, w]) + 1) % A.P
+        ok_p, _ = product_verify(airs_, lhs, pub, prm, f, bad)
+        ok_o, _ = ob.verify(airs_, lhs, pub, {"fields": f, "commitments": bad}, prm)
+        assert not ok_p and not ok_o, f"{name}: commitment {pos} altered and accepted"
+    assert rejected >= total - 8, (rejected, total)
