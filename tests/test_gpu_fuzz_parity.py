@@ -19,6 +19,27 @@ pytestmark = pytest.mark.gpu
 LMCS = ["poseidon2", "blake3", "keccak", "rpo", "rpx"]
 
 
+def wide_air(seed, width, aux_width, max_degree):
+    """A constraint system without periodic columns (any trace height down to 2 rows) over MANY columns: a few products of random cells of
+    the row window, aux cells and challenges mixed in; the aux trace is random (parity, not validity)."""
+    from miden_vm_amd import dag
+    rng = np.random.default_rng(0x51de0000 + seed)
+    b = dag.AirBuilder(width, aux_width=aux_width, num_randomness=2, num_aux_values=aux_width, num_public=2)
+    for _ in range(int(rng.integers(1, 6))):
+        e = b.main(int(rng.integers(0, width)), int(rng.integers(0, 2)))
+        for _ in range(int(rng.integers(0, max_degree))):
+            e = e * b.main(int(rng.integers(0, width)), int(rng.integers(0, 2))) + b.public(int(rng.integers(0, 2)))
+        if aux_width and rng.random() < 0.6:
+            e = e + b.aux(int(rng.integers(0, aux_width)), int(rng.integers(0, 2))) * b.randomness(int(rng.integers(0, 2))) + b.aux_value(int(rng.integers(0, aux_width)))
+        (b.assert_zero_ext if e.ext else b.assert_zero)(e * b.is_transition() if rng.random() < 0.3 and e.deg < max_degree else e)
+
+    def build_aux(main, randomness):
+        r2 = np.random.default_rng(seed + 5000)
+        return r2.integers(0, A.P, (main.shape[0], 2 * aux_width), dtype=np.uint64), [int(x) for x in r2.integers(0, A.P, 2 * aux_width, dtype=np.uint64)]
+
+    return dag.Air(b, build_aux if aux_width else None, f"wide:{seed}")
+
+
 def random_statement(seed):
     rng = np.random.default_rng(0x5eed0000 + seed)
     n_airs = int(rng.choice([1, 1, 2, 3]))
@@ -26,6 +47,12 @@ def random_statement(seed):
     max_degree = min(1 + (1 << log_blowup), int(rng.integers(2, 10)))      # quotient degree <= blowup
     airs_, traces = [], []
     for k in range(n_airs):
+        if rng.random() < 0.3:                                              # wide / tall / tiny instances: 1..130 columns, 2^1..2^14 rows, 0..5 aux columns
+            log_n = int(rng.choice([1, 2, 3, 5, 8, 11, 12, 13, 14]))
+            width = int(rng.integers(1, 131)) if log_n <= 12 else int(rng.integers(1, 60))
+            airs_.append(wide_air(1000 * seed + k, width, int(rng.integers(0, 6)), max_degree))
+            traces.append(A.dummy_trace(log_n, width, seed=seed * 7 + k))
+            continue
         log_n = int(rng.integers(3, 12))                                    # random_air reads periodic columns of period 4 and 8
         width = int(rng.integers(2, 24))
         airs_.append(A.random_air(1000 * seed + k, width=width, aux_width=int(rng.integers(1, 4)), n_constraints=int(rng.integers(1, 40)),
@@ -53,6 +80,8 @@ def run_one(pkg, ctx, seed):
         dtr = [ctx.upload_trace(t) for t in traces]
 
         def aux_builder(idx, rnd):
+            if airs_[idx].build_aux is None:
+                return np.zeros((traces[idx].shape[0], 0), dtype=np.uint64), []
             return airs_[idx].build_aux(traces[idx], rnd)
 
         got = pkg.prove(ctx, dairs, dtr, pub, params, ob.challenger_state(), pre, aux_builder)
@@ -85,14 +114,15 @@ def test_random_statements_sharded_equal_single_gpu():
     """The same random statements through the SHARDED prover at world 2 / 4 / 8 -- thread ranks on one device joined by
     the stream-ordered local communicator, what the RCCL communicator is on a multi-GPU node: every rank's proof must equal the single-GPU proof
     of the same context (which the test above holds equal to the oracle's).  Shapes no fixed case covers: more ranks than LDE cosets or
-    quotient chunks, traces shorter than the world, mixed heights and degrees, preprocessed columns, every FRI arity.
+    quotient chunks, two-row traces, 130-column traces, mixed heights and degrees, preprocessed columns, every FRI arity.
     MH_FUZZ_SHARDED_SEEDS=N (default 12)."""
     from test_gpu_sharded import _thread_ranks
     first, n = int(os.environ.get("MH_FUZZ_FIRST", "1")), int(os.environ.get("MH_FUZZ_SHARDED_SEEDS", "12"))
     pub = [5, 7]
     for seed in range(first, first + n):
         airs_, traces, params, lmcs, jit = random_statement(seed)
-        world = int(np.random.default_rng(77 + seed).choice([w for w in (2, 4, 8) if w <= 1 << params["log_blowup"]]))   # one LDE coset per rank at least
+        world = int(np.random.default_rng(77 + seed).choice([w for w in (2, 4, 8) if w <= 1 << params["log_blowup"] and (w == 2 or w <= min(t.shape[0] for t in traces))]))
+        # (one LDE coset per rank at least, no trace shorter than the world: both are refused by every rank with MH_ERR_INVALID)
         what = f"seed {seed}: world {world}, heights {[t.shape[0] for t in traces]}, widths {[t.shape[1] for t in traces]}, {params}"
 
         def body(pkg, sharding, rank, ctx, comm):
@@ -109,6 +139,8 @@ def test_random_statements_sharded_equal_single_gpu():
             pre = ob.protocol_pre_observe(params, pub, preprocessed_root=root)
 
             def aux_builder(idx, rnd):
+                if airs_[idx].build_aux is None:
+                    return np.zeros((traces[idx].shape[0], 0), dtype=np.uint64), []
                 return airs_[idx].build_aux(traces[idx], rnd)
 
             got = sharding.prove_sharded(pkg, ctx, comm, dairs, dtr, pub, params, ob.challenger_state(), pre, aux_builder)
@@ -121,7 +153,8 @@ def test_random_statements_sharded_equal_single_gpu():
             dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
             root = attach_preprocessed(ctx, airs_, dairs, traces, params)
             ref = pkg.prove(ctx, dairs, [ctx.upload_trace(t) for t in traces], pub, params, ob.challenger_state(),
-                            ob.protocol_pre_observe(params, pub, preprocessed_root=root), lambda idx, rnd: airs_[idx].build_aux(traces[idx], rnd))
+                            ob.protocol_pre_observe(params, pub, preprocessed_root=root),
+                            lambda idx, rnd: airs_[idx].build_aux(traces[idx], rnd) if airs_[idx].build_aux else (np.zeros((traces[idx].shape[0], 0), dtype=np.uint64), []))
             for r, (f, cm, dg, rt) in enumerate(res):
                 assert (rt is None) == (root is None) and (rt is None or (np.asarray(rt) == np.asarray(root)).all()), f"{what}: rank {r} setup root"
                 assert f.size == ref.fields.size and (f == ref.fields).all(), f"{what}: rank {r} transcript differs"

@@ -227,16 +227,48 @@ JIT_SWITCHES = [{}, {"MH_JIT_RECOMP": "0"}, {"MH_JIT_RECOMP": "1000", "MH_JIT_CH
                 {"MH_JIT_MULGROUP": "3", "MH_JIT_FLAGS": "-DMH_JIT_ASM_MUL=0"}]
 
 
-@pytest.mark.parametrize("env", JIT_SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "defaults")
-def test_generator_switches_compile_offline(env, tmp_path, monkeypatch):
+_SWITCH_CHILD = """
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+from __graft_entry__ import load_package
+pkg = load_package()
+from miden_vm_amd import miden_air as MA
+air, _ = MA.poseidon2_permutation_air()
+n = pkg.jit_precompile(air.blob, sys.argv[2])
+print(json.dumps([n, len(os.listdir(sys.argv[2]))]))
+"""
+_switch_results = {}
+
+
+def _compile_all_switches(tmp_root):
+    """Every switch combination in a process of its own (the switches are environment variables), eight at a time: the 27 hiprtc
+    compilations of this AIR took the CPU suite two minutes one after the other."""
+    import subprocess, sys
+    from concurrent.futures import ThreadPoolExecutor
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def one(i):
+        d = os.path.join(tmp_root, f"sw{i}")
+        os.makedirs(d, exist_ok=True)
+        r = subprocess.run([sys.executable, "-c", _SWITCH_CHILD, root, d], capture_output=True, text=True, timeout=900, env=dict(os.environ, **JIT_SWITCHES[i]))
+        return (json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None), r.stderr[-2000:]
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+        for i, res in enumerate(ex.map(one, range(len(JIT_SWITCHES)))):
+            _switch_results[i] = res
+
+
+@pytest.mark.parametrize("idx", range(len(JIT_SWITCHES)), ids=[",".join(f"{k}={v}" for k, v in e.items()) or "defaults" for e in JIT_SWITCHES])
+def test_generator_switches_compile_offline(idx, tmp_path_factory):
     """mh_jit_precompile (hiprtc for gfx950, no GPU) of this AIR's chunks under every generator switch: recompute-or-spill threshold,
     chunk budget, loads at the top / at first use, dot gates, the per-constraint fold, the three forms of the product, an occupancy
     target.  (That they all give the SAME proof is tests/test_gpu_round4.py::test_generator_switches_are_bit_exact.)"""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    air, _ = MA.poseidon2_permutation_air()
-    n = load_package().jit_precompile(air.blob, str(tmp_path))
-    assert n >= 2 and len(os.listdir(str(tmp_path))) >= n    # a chunk cut again for the register budget leaves its first code object too
+    if not _switch_results:
+        _compile_all_switches(str(tmp_path_factory.mktemp("jit_switches")))
+    res, err = _switch_results[idx]
+    assert res is not None, err
+    n, files = res
+    assert n >= 2 and files >= n    # a chunk cut again for the register budget leaves its first code object too
 
 
 def test_config5_parameters_on_the_real_air_both_verifiers():
