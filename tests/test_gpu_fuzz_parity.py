@@ -73,11 +73,37 @@ def run_one(pkg, ctx, seed):
     ob.set_lmcs(lmcs)
     ctx.set_lmcs(lmcs)
     try:
-        exp = ob.prove(airs_, traces, pub, params)
         dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
         root = attach_preprocessed(ctx, airs_, dairs, traces, params)
         pre = ob.protocol_pre_observe(params, pub, preprocessed_root=root)
-        dtr = [ctx.upload_trace(t) for t in traces]
+        # the hand-over: the three upload entry points at random, and cells >= p in the host matrix (a `Felt` is not necessarily canonical
+        # in memory, SURVEY 8b: the library reduces on load; the oracle was given the canonical matrix)
+        rs = np.random.default_rng(0xabc00 + seed)
+        dtr, keep = [], []
+        for t in traces:
+            raw = t.copy()
+            for _ in range(int(rs.integers(0, 4))):
+                i, j = int(rs.integers(0, t.shape[0])), int(rs.integers(0, t.shape[1]))
+                if int(t[i, j]) < (1 << 32) - 1:
+                    raw[i, j] = int(t[i, j]) + A.P
+                elif rs.random() < 0.5:
+                    small = int(rs.integers(0, 1 << 31))
+                    t[i, j] = small                              # (the oracle's copy: traces is what ob.prove reads below)
+                    raw[i, j] = small + A.P
+            how = int(rs.integers(0, 3))
+            if how == 0:
+                dtr.append(ctx.upload_trace(raw))
+            elif how == 1:
+                pin, owner = pkg.pinned_array(ctx.lib, raw.shape)
+                pin[:] = raw
+                keep.append((pin, owner))
+                dtr.append(pkg.Trace.upload_async(ctx, pin))
+            else:
+                pin, owner = pkg.pinned_array(ctx.lib, raw.shape[::-1])
+                pin[:] = raw.T
+                keep.append((pin, owner))
+                dtr.append(pkg.Trace.upload_cols_async(ctx, pin))
+        exp = ob.prove(airs_, traces, pub, params)               # after the cells above were fixed
 
         def aux_builder(idx, rnd):
             if airs_[idx].build_aux is None:
