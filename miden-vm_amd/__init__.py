@@ -461,8 +461,10 @@ class Proof:
 
     def __init__(self, lib, h):
         nf, nc, nt = lib.mh_proof_num_fields(h), lib.mh_proof_num_commitments(h), lib.mh_proof_num_traces(h)
-        self.fields = np.ctypeslib.as_array(lib.mh_proof_fields(h), shape=(max(nf, 1),))[:nf].copy()
-        self.commitments = np.ctypeslib.as_array(lib.mh_proof_commitments(h), shape=(max(nc, 1) * 4,))[:nc * 4].copy().reshape(-1, 4)
+        # an empty vector's data pointer may be null (mh_session_open of a statement whose openings need no sibling: every path node is
+        # an ancestor of another query) -- found by tests/test_gpu_fuzz_parity.py
+        self.fields = np.ctypeslib.as_array(lib.mh_proof_fields(h), shape=(nf,)).copy() if nf else np.zeros(0, dtype=np.uint64)
+        self.commitments = (np.ctypeslib.as_array(lib.mh_proof_commitments(h), shape=(nc * 4,)).copy() if nc else np.zeros(0, dtype=np.uint64)).reshape(-1, 4)
         self.digest = np.ctypeslib.as_array(lib.mh_proof_digest(h), shape=(4,)).copy()
         lh = lib.mh_proof_log_trace_heights(h)
         self.log_trace_heights = [int(lh[i]) for i in range(nt)]

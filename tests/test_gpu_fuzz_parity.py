@@ -270,3 +270,26 @@ def test_random_lookup_programs_device_equals_oracle():
             h.free()
     assert refused < n / 4          # the generator must mostly produce programs that run
     ctx.close()
+
+
+def test_random_statements_staged_session_equals_one_shot():
+    """The staged session (mh_session_* + mh_grind driven by a HOST-owned transcript: what a Rust shim that keeps p3's DuplexChallenger
+    binds) on random statements under the Poseidon2 configuration: the transcript it records equals mh_prove's, field for
+    field.  MH_FUZZ_STAGED_SEEDS=N (default 12)."""
+    from test_gpu_prove import staged_prove
+    pkg = load_package()
+    ctx = pkg.Ctx(0)
+    first, n = int(os.environ.get("MH_FUZZ_FIRST", "1")), int(os.environ.get("MH_FUZZ_STAGED_SEEDS", "12"))
+    pub = [5, 7]
+    for seed in range(first, first + n):
+        airs_, traces, params, _, _ = random_statement(seed)
+        what = f"seed {seed}: heights {[t.shape[0] for t in traces]}, widths {[t.shape[1] for t in traces]}, {params}"
+        dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+        root = attach_preprocessed(ctx, airs_, dairs, traces, params)
+        one = pkg.prove(ctx, dairs, [ctx.upload_trace(t) for t in traces], pub, params, ob.challenger_state(),
+                        ob.protocol_pre_observe(params, pub, preprocessed_root=root),
+                        lambda idx, rnd: airs_[idx].build_aux(traces[idx], rnd) if airs_[idx].build_aux else (np.zeros((traces[idx].shape[0], 0), dtype=np.uint64), []))
+        f, c, d = staged_prove(ctx, airs_, traces, pub, params, device_grind=bool(seed & 1))
+        assert f.size == one.fields.size and (f == one.fields).all(), what
+        assert c.shape == np.asarray(one.commitments).shape and (c == one.commitments).all() and (d == one.digest).all(), what
+    ctx.close()
