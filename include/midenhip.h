@@ -512,7 +512,8 @@ void mh_proof_free(mh_proof* p);
 size_t mh_proof_num_fields(const mh_proof* p);
 size_t mh_proof_num_commitments(const mh_proof* p);
 const uint64_t* mh_proof_fields(const mh_proof* p);       /* TranscriptData::fields */
-const uint64_t* mh_proof_commitments(const mh_proof* p);  /* TranscriptData::commitments, 4 felts each */
+const uint64_t* mh_proof_commitments(const mh_proof* p);  /* TranscriptData::commitments, 4 felts each.  Either pointer may be NULL when its
+                                                             count is 0 (mh_session_open of openings that need no sibling) */
 const uint64_t* mh_proof_digest(const mh_proof* p);       /* StarkOutput::digest, 4 felts */
 size_t mh_proof_num_traces(const mh_proof* p);
 const uint8_t* mh_proof_log_trace_heights(const mh_proof* p);
