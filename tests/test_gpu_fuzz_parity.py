@@ -149,9 +149,10 @@ def test_random_statements_sharded_equal_single_gpu():
         airs_, traces, params, lmcs, jit = random_statement(seed)
         world = int(np.random.default_rng(77 + seed).choice([w for w in (2, 4, 8) if w <= 1 << params["log_blowup"] and (w == 2 or w <= min(t.shape[0] for t in traces))]))
         # (one LDE coset per rank at least, no trace shorter than the world: both are refused by every rank with MH_ERR_INVALID)
-        what = f"seed {seed}: world {world}, heights {[t.shape[0] for t in traces]}, widths {[t.shape[1] for t in traces]}, {params}"
+        what = f"seed {seed}: world {world}, heights {[t.shape[0] for t in traces]}, widths {[t.shape[1] for t in traces]}, {params}, {lmcs}"
 
         def body(pkg, sharding, rank, ctx, comm):
+            ctx.set_lmcs(lmcs)                                              # any of the five hash configurations
             dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
             dtr = [ctx.upload_trace(t) for t in traces]
             # the preprocessed setup is part of the statement: committed sharded like every other tree
@@ -176,6 +177,7 @@ def test_random_statements_sharded_equal_single_gpu():
         pkg = load_package()
         ctx = pkg.Ctx(0)
         try:
+            ctx.set_lmcs(lmcs)
             dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
             root = attach_preprocessed(ctx, airs_, dairs, traces, params)
             ref = pkg.prove(ctx, dairs, [ctx.upload_trace(t) for t in traces], pub, params, ob.challenger_state(),
