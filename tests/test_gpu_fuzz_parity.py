@@ -295,3 +295,82 @@ def test_random_statements_staged_session_equals_one_shot():
         assert f.size == one.fields.size and (f == one.fields).all(), what
         assert c.shape == np.asarray(one.commitments).shape and (c == one.commitments).all() and (d == one.digest).all(), what
     ctx.close()
+
+
+def test_invalid_statements_are_refused_not_crashed():
+    """SURVEY.md section 8b "Errors": shape errors are detected before any crypto work, the C side returns codes, nothing unwinds across the ABI.
+    A random valid statement gets ONE invalidating change -- a trace one column too wide or too narrow, PCS parameters PcsParams::new refuses
+    (zero blowup, arity 0 / 16, zero queries, an unreachable final degree), a blowup below the constraint degree, a public value missing, a
+    trace list shorter than the AIR list, a truncated AIR blob, a preprocessed AIR without its setup tree -- and mh_prove must return an
+    error (MidenHipError here), after which the SAME context proves the unchanged statement to the oracle's bytes.  MH_FUZZ_INVALID_SEEDS=N
+    (default 30)."""
+    pkg = load_package()
+    ctx = pkg.Ctx(0)
+    first, n = int(os.environ.get("MH_FUZZ_FIRST", "1")), int(os.environ.get("MH_FUZZ_INVALID_SEEDS", "30"))
+    pub = [5, 7]
+    kinds = ["wide", "narrow", "blowup0", "arity0", "arity16", "queries0", "final", "low_blowup", "publics", "fewer_traces", "blob", "no_setup"]
+    seen, by_type = set(), {}
+    for seed in range(first, first + n):
+        airs_, traces, params, _, _ = random_statement(seed)
+        rng = np.random.default_rng(0xbad000 + seed)
+        kind = kinds[int(rng.integers(0, len(kinds)))]
+        k = int(rng.integers(0, len(airs_)))
+        b_airs, b_traces, b_params, b_pub = list(airs_), [t.copy() for t in traces], dict(params), list(pub)
+        if kind == "wide":
+            b_traces[k] = np.concatenate([b_traces[k], b_traces[k][:, :1]], axis=1)
+        elif kind == "narrow":
+            if b_traces[k].shape[1] < 2:
+                continue
+            b_traces[k] = np.ascontiguousarray(b_traces[k][:, :-1])
+        elif kind == "blowup0":
+            b_params["log_blowup"] = 0
+        elif kind == "arity0":
+            b_params["log_folding_arity"] = 0
+        elif kind == "arity16":
+            b_params["log_folding_arity"] = 4
+        elif kind == "queries0":
+            b_params["num_queries"] = 0
+        elif kind == "final":
+            b_params.update(log_blowup=1, log_folding_arity=3, log_final_degree=0)
+        elif kind == "low_blowup":
+            need = max(a.log_quotient_degree for a in airs_)
+            if need < 2:
+                continue
+            b_params["log_blowup"] = need - 1                 # quotient degree above the blowup
+        elif kind == "publics":
+            b_pub = b_pub[:1]
+        elif kind == "fewer_traces":
+            if len(airs_) < 2:
+                continue
+            b_traces = b_traces[:-1]
+        elif kind == "blob":
+            class Cut:                                        # what DeviceAir reads of an AIR
+                pass
+            cut = Cut()
+            cut.__dict__.update(airs_[k].__dict__)
+            cut.blob = airs_[k].blob[:int(rng.integers(1, airs_[k].blob.size))]
+            b_airs[k] = cut
+        elif kind == "no_setup":
+            if not any(a.preprocessed is not None for a in airs_):
+                continue
+        what = f"seed {seed}: `{kind}` on instance {k}, heights {[t.shape[0] for t in traces]}, {params}"
+        with pytest.raises(pkg.MidenHipError) as ei:         # the C library itself, not an assertion of the Python layer
+            dairs = [pkg.DeviceAir(ctx, a) for a in b_airs]
+            root = attach_preprocessed(ctx, airs_, dairs, traces, b_params) if kind not in ("no_setup", "blowup0") else None
+            dtr = [ctx.upload_trace(t) for t in b_traces]
+            pkg.prove(ctx, dairs, dtr, b_pub, b_params, ob.challenger_state(), ob.protocol_pre_observe(b_params, b_pub, preprocessed_root=root),
+                      lambda idx, rnd: airs_[idx].build_aux(traces[idx], rnd) if airs_[idx].build_aux else (np.zeros((traces[idx].shape[0], 0), dtype=np.uint64), []))
+        seen.add(kind)
+        by_type.setdefault((kind, ei.type.__name__), str(ei.value)[:90])
+        # the context is still good: the unchanged statement, to the oracle's bytes
+        dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+        root = attach_preprocessed(ctx, airs_, dairs, traces, params)
+        got = pkg.prove(ctx, dairs, [ctx.upload_trace(t) for t in traces], pub, params, ob.challenger_state(), ob.protocol_pre_observe(params, pub, preprocessed_root=root),
+                        lambda idx, rnd: airs_[idx].build_aux(traces[idx], rnd) if airs_[idx].build_aux else (np.zeros((traces[idx].shape[0], 0), dtype=np.uint64), []))
+        exp = ob.prove(airs_, traces, pub, params)
+        assert got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all() and (got.digest == exp["digest"]).all(), what
+    assert len(seen) >= min(8, n // 4), seen
+    if os.environ.get("MH_FUZZ_VERBOSE"):
+        for key, msg in sorted(by_type.items()):
+            print("refusal", key, "--", msg)
+    ctx.close()
