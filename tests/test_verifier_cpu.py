@@ -147,3 +147,33 @@ def test_verifiers_agree_on_random_tamperings(name, airs_, traces, pub, prm):
         ok_o, _ = ob.verify(airs_, lhs, pub, {"fields": f, "commitments": bad}, prm)
         assert not ok_p and not ok_o, f"{name}: commitment {pos} altered and accepted"
     assert rejected >= total - 8, (rejected, total)
+
+
+@pytest.mark.parametrize("lmcs", ["blake3", "keccak", "rpo", "rpx"])
+def test_verifiers_agree_on_random_tamperings_under_the_other_configurations(lmcs):
+    """The same differential check under the four other hash configurations of `ProvingOptions` (the byte challengers of Blake3 / Keccak, the
+    RPO / RPX sponges): a multi-AIR statement, 100 random single-site tamperings, equal verdicts."""
+    t1, pub = A.fib_trace(7)
+    airs_, traces, prm = [A.periodic_air(3), A.fib_air()], [A.periodic_trace(5), t1], ARITY4
+    ob.set_lmcs(lmcs)
+    try:
+        proof = ob.prove(airs_, traces, pub, prm)
+        f, c, lhs = proof["fields"], proof["commitments"], proof["log_heights"]
+        pre = ob.protocol_pre_observe(prm, pub)
+        ok, dig = pkg.verify(airs_, lhs, pub, prm, ob.challenger_state(), pre, f, c, lmcs=lmcs)
+        assert ok and (dig == proof["digest"]).all(), dig
+        rng = np.random.default_rng(len(lmcs) * 977)
+        rejected = 0
+        for i in range(100):
+            bad = f.copy()
+            pos = int(rng.integers(0, f.size))
+            bad[pos] = (int(bad[pos]) + 1) % A.P if i % 2 else rng.integers(0, A.P, dtype=np.uint64)
+            if (bad == f).all():
+                continue
+            ok_p, _ = pkg.verify(airs_, lhs, pub, prm, ob.challenger_state(), pre, bad, c, lmcs=lmcs)
+            ok_o, _ = ob.verify(airs_, lhs, pub, {"fields": bad, "commitments": c}, prm)
+            assert ok_p == ok_o, f"{lmcs}: verifiers disagree at field {pos}: product {ok_p}, oracle {ok_o}"
+            rejected += not ok_p
+        assert rejected >= 92
+    finally:
+        ob.set_lmcs("poseidon2")
