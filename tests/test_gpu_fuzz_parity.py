@@ -374,3 +374,36 @@ def test_invalid_statements_are_refused_not_crashed():
         for key, msg in sorted(by_type.items()):
             print("refusal", key, "--", msg)
     ctx.close()
+
+
+def test_random_sessions_through_the_precompile_entry():
+    """The second client's whole session (twelve AIRs, `SessionTraces::prove_stark`'s shape: mh_prove_precompile) over RANDOM Keccak claims:
+    0..10 inputs of 0..700 bytes, the sponge's rate boundaries (135 / 136 / 137 / 272 bytes) included, next to the fixed arithmetic / EC / MSM
+    claims of the test session.  Every session's witness must satisfy the twelve hand-ported constraint systems and close every bus
+    (mh_verify_precompile runs the full `ChipletMultiAir::eval_external`), under Poseidon2 and the reference's default Blake3; another root is
+    refused.  The trace heights change with the inputs, so this also walks the LMCS lifting across many height mixes.
+    MH_FUZZ_SESSION_SEEDS=N (default 3)."""
+    from miden_vm_amd.testing import precompile_trace as PT
+    pkg = load_package()
+    ctx = pkg.Ctx(0)
+    pc = pkg.Precompile(ctx)
+    first, n = int(os.environ.get("MH_FUZZ_FIRST", "1")), int(os.environ.get("MH_FUZZ_SESSION_SEEDS", "3"))
+    shapes = set()
+    for seed in range(first, first + n):
+        rng = np.random.default_rng(0x5e55 + seed)
+        lens = [int(rng.choice([0, 1, 31, 32, 33, 135, 136, 137, 271, 272, 273, int(rng.integers(0, 701))])) for _ in range(int(rng.integers(0, 11)))]
+        inputs = [bytes(rng.integers(0, 256, k, dtype=np.uint8)) for k in lens]
+        if inputs and rng.random() < 0.3:
+            inputs.append(inputs[0])                                     # a repeated input: one node, two readers
+        _, traces, info = PT.precompile_session(inputs, permute_batch=ctx.poseidon2_permute)
+        root = info["public_root"]
+        what = f"seed {seed}: input lengths {lens}, heights 2^{[int(t.shape[0]).bit_length() - 1 for t in traces]}"
+        shapes.add(tuple(t.shape[0] for t in traces))
+        for hash_fn in ("poseidon2", "blake3"):
+            proof = pc.prove(traces, root, hash_fn=hash_fn)
+            setup = pc.preprocessed_root(hash_fn)
+            ok, dig = pkg.verify_precompile(setup, root, proof.bytes, hash_fn=hash_fn)
+            assert ok and (dig == proof.digest).all(), f"{what}, {hash_fn}: {dig}"
+            assert not pkg.verify_precompile(setup, [(int(root[0]) + 1) % A.P] + [int(x) for x in root[1:]], proof.bytes, hash_fn=hash_fn)[0], what
+    assert len(shapes) >= min(n, 2)
+    ctx.close()
