@@ -184,6 +184,54 @@ __global__ __launch_bounds__(256) void k_selector_inverses(const u64* tw, const 
   }
 }
 
+// PeriodicLde::build (prover/periodic.rs:49-77): every periodic column on the n * 2^log_d-point quotient coset, as `Pm * 2^log_d` values per column
+// (Pm = the longest period; a column of period P repeats).  O(Pm^2 2^log_d) field operations per column on the host, and a function of the AIR
+// and the domain only -- never of a challenge -- so it is computed once per (log_n, log_blowup, log_d) and kept in the mh_air (bounded).
+static std::vector<u64> periodic_lde_table(const mh_air* air, int log_n, int log_blowup, int log_d) {
+  const size_t Pm = air->max_period();
+  const size_t Dg = (size_t)1 << log_d, prow = Pm ? Pm * Dg : 1;
+  const std::array<int, 3> key{log_n, log_blowup, log_d};
+  {
+    std::lock_guard<std::mutex> lk(air->ptab_mu);
+    auto it = air->ptab_cache.find(key);
+    if (it != air->ptab_cache.end()) return it->second;
+  }
+  std::vector<u64> ptab(std::max<size_t>(1, air->periodic.size() * prow), 0);
+  if (Pm) {
+    int logP = 0;
+    while (((size_t)1 << logP) < Pm) logP++;
+    MH_REQUIRE(logP <= log_n, "periodic column longer than the trace");
+    const u64 g = gl_lde_shift(log_n + log_blowup);
+    const u64 pshift = gl_exp_pow2(g, log_n - logP);
+    const u64 wP = gl_two_adic_generator(logP), wPD = gl_two_adic_generator(logP + log_d);
+    const u64 pinv = gl_inv((u64)Pm);
+    for (size_t col = 0; col < air->periodic.size(); col++) {
+      const auto& pc = air->periodic[col];
+      // coefficients of the interpolant over the order-Pm subgroup (column repeated to Pm)
+      std::vector<u64> coef(Pm);
+      for (size_t k = 0; k < Pm; k++) {
+        u64 s = 0, wk = gl_inv(gl_pow(wP, k)), x = 1;
+        for (size_t r = 0; r < Pm; r++) {
+          s = gl_add(s, gl_mul(pc[r % pc.size()] % GL_P, x));
+          x = gl_mul(x, wk);
+        }
+        coef[k] = gl_mul(s, pinv);
+      }
+      u64 y = pshift;
+      for (size_t m = 0; m < prow; m++) {
+        u64 v = 0;
+        for (size_t k = Pm; k-- > 0;) v = gl_add(gl_mul(v, y), coef[k]);
+        ptab[col * prow + m] = v;
+        y = gl_mul(y, wPD);
+      }
+    }
+  }
+  std::lock_guard<std::mutex> lk(air->ptab_mu);
+  if (air->ptab_cache.size() >= 16) air->ptab_cache.clear();  // a service proving many heights with one AIR
+  air->ptab_cache[key] = ptab;
+  return ptab;
+}
+
 // Evaluate AIR `air` (trace height 2^log_n, LDE matrices main/aux) on its quotient coset and fold the
 // result into the accumulator.  Requires the AIR's quotient degree to equal the batch degree
 // (`log_d`); see prover.cpp for the upsample path.
@@ -233,50 +281,10 @@ void quotient_eval_accumulate(mh_ctx* c, const mh_air* air, const LdeMatrix& mai
       p = e2_mul(p, alpha);
     }
   }
-  // periodic table on the quotient coset (prover/periodic.rs:49-77), O(P^2 D) on the host -- once per (AIR, domain): cached in the AIR
+  // periodic table on the quotient coset (prover/periodic.rs:49-77): once per (AIR, domain), cached in the AIR
   const size_t Pm = air->max_period();
   const size_t prow = Pm ? Pm * Dg : 1;
-  std::vector<u64> ptab;
-  const std::array<int, 3> pkey{log_n, log_blowup, log_d};
-  {
-    std::lock_guard<std::mutex> lk(air->ptab_mu);
-    auto it = air->ptab_cache.find(pkey);
-    if (it != air->ptab_cache.end()) ptab = it->second;
-  }
-  if (ptab.empty()) {
-  ptab.assign(std::max<size_t>(1, air->periodic.size() * prow), 0);
-  if (Pm) {
-    int logP = 0;
-    while (((size_t)1 << logP) < Pm) logP++;
-    MH_REQUIRE(logP <= log_n, "periodic column longer than the trace");
-    const u64 pshift = gl_exp_pow2(g, log_n - logP);
-    const u64 wP = gl_two_adic_generator(logP), wPD = gl_two_adic_generator(logP + log_d);
-    const u64 pinv = gl_inv((u64)Pm);
-    for (size_t col = 0; col < air->periodic.size(); col++) {
-      const auto& pc = air->periodic[col];
-      // coefficients of the interpolant over the order-Pm subgroup (column repeated to Pm)
-      std::vector<u64> coef(Pm);
-      for (size_t k = 0; k < Pm; k++) {
-        u64 s = 0, wk = gl_inv(gl_pow(wP, k)), x = 1;
-        for (size_t r = 0; r < Pm; r++) {
-          s = gl_add(s, gl_mul(pc[r % pc.size()] % GL_P, x));
-          x = gl_mul(x, wk);
-        }
-        coef[k] = gl_mul(s, pinv);
-      }
-      u64 y = pshift;
-      for (size_t m = 0; m < prow; m++) {
-        u64 v = 0;
-        for (size_t k = Pm; k-- > 0;) v = gl_add(gl_mul(v, y), coef[k]);
-        ptab[col * prow + m] = v;
-        y = gl_mul(y, wPD);
-      }
-    }
-  }
-  std::lock_guard<std::mutex> lk(air->ptab_mu);
-  if (air->ptab_cache.size() >= 16) air->ptab_cache.clear();  // a service proving many heights with one AIR: bounded
-  air->ptab_cache[pkey] = ptab;
-  }
+  const std::vector<u64> ptab = periodic_lde_table(air, log_n, log_blowup, log_d);
   std::vector<u64> pub(std::max<size_t>(1, publics.size())), rnd(2 * std::max<size_t>(1, randomness.size())),
       av(2 * std::max<size_t>(1, aux_values.size()));
   for (size_t i = 0; i < publics.size(); i++) pub[i] = gl_canon(publics[i]);
