@@ -407,3 +407,57 @@ def test_random_sessions_through_the_precompile_entry():
             assert not pkg.verify_precompile(setup, [(int(root[0]) + 1) % A.P] + [int(x) for x in root[1:]], proof.bytes, hash_fn=hash_fn)[0], what
     assert len(shapes) >= min(n, 2)
     ctx.close()
+
+
+def test_concurrent_contexts_prove_random_statements():
+    """SURVEY.md section 8b "Threading": one ctx per proving thread, no global state, re-entrant across contexts.  Four threads, a context each, prove
+    DIFFERENT random statements at the same time on one device (buffer pools, table caches, the kernel generator's cache and the profiler are per
+    context or locked) while a fifth keeps creating, trimming and destroying contexts; every proof must equal the oracle's, computed beforehand.
+    MH_FUZZ_THREAD_SEEDS=N statements per thread (default 10)."""
+    import threading
+    pkg = load_package()
+    first, n = int(os.environ.get("MH_FUZZ_FIRST", "1")), int(os.environ.get("MH_FUZZ_THREAD_SEEDS", "10"))
+    pub, T = [5, 7], 4
+    work = []
+    for seed in range(first, first + T * n):
+        airs_, traces, params, _, _ = random_statement(seed)
+        work.append((seed, airs_, traces, params, ob.prove(airs_, traces, pub, params)))
+    errors, stop = [], threading.Event()
+
+    def prover(tid):
+        try:
+            ctx = pkg.Ctx(0)
+            for seed, airs_, traces, params, exp in work[tid::T]:
+                dairs = [pkg.DeviceAir(ctx, a) for a in airs_]
+                root = attach_preprocessed(ctx, airs_, dairs, traces, params)
+                got = pkg.prove(ctx, dairs, [ctx.upload_trace(t) for t in traces], pub, params, ob.challenger_state(),
+                                ob.protocol_pre_observe(params, pub, preprocessed_root=root),
+                                lambda idx, rnd: airs_[idx].build_aux(traces[idx], rnd) if airs_[idx].build_aux else (np.zeros((traces[idx].shape[0], 0), dtype=np.uint64), []))
+                if not (got.fields.size == exp["fields"].size and (got.fields == exp["fields"]).all() and (got.digest == exp["digest"]).all()):
+                    errors.append(f"thread {tid}, seed {seed}: proof differs from the oracle's")
+                if seed % 3 == 0:
+                    ctx.trim()
+            ctx.close()
+        except Exception as e:  # pragma: no cover
+            errors.append(f"thread {tid}: {e!r}")
+
+    def churn():
+        try:
+            while not stop.is_set():
+                c = pkg.Ctx(0)
+                c.poseidon2_permute(np.arange(24, dtype=np.uint64).reshape(2, 12))
+                c.trim()
+                c.close()
+        except Exception as e:  # pragma: no cover
+            errors.append(f"churn: {e!r}")
+
+    threads = [threading.Thread(target=prover, args=(t,)) for t in range(T)]
+    ch = threading.Thread(target=churn)
+    ch.start()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=900)
+    stop.set()
+    ch.join(timeout=60)
+    assert not errors, errors[:5]
