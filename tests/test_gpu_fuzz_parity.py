@@ -461,3 +461,29 @@ def test_concurrent_contexts_prove_random_statements():
     stop.set()
     ch.join(timeout=60)
     assert not errors, errors[:5]
+
+
+def test_random_programs_through_mh_prove_miden():
+    """Random programs (tests/random_programs.py, held to the three AIRs on the CPU by tests/test_random_programs.py) executed by the test VM and
+    proven through `prove_stark`'s own shape, mh_prove_miden (three host matrices + public values + aux inputs -> bytes), at the production
+    parameters under Poseidon2 and the reference's default Blake3: mh_verify_miden accepts each proof for its own program hash only.
+    MH_FUZZ_PROGRAM_SEEDS=N (default 4)."""
+    import random_programs as RP
+    from miden_vm_amd.testing import core_trace as CV
+    pkg = load_package()
+    ctx = pkg.Ctx(0)
+    miden = pkg.Miden(ctx)
+    first, n = int(os.environ.get("MH_FUZZ_FIRST", "1")), int(os.environ.get("MH_FUZZ_PROGRAM_SEEDS", "4"))
+    heights = set()
+    for seed in range(first, first + n):
+        r = CV.prove_inputs(CV.CoreVM(stack_inputs=tuple(range(1, 17))), RP.random_program(seed, depth=3 + seed % 3))
+        heights.add((r["core"].shape[0], r["chiplets"].shape[0], r["poseidon2"].shape[0]))
+        for hash_fn in ("poseidon2", "blake3"):
+            proof = miden.prove(r["core"], r["chiplets"], r["poseidon2"], r["public_values"], r["aux_inputs"], hash_fn=hash_fn)
+            ok, dig = pkg.verify_miden(r["public_values"], r["aux_inputs"], proof.bytes, hash_fn=hash_fn)
+            assert ok and (dig == proof.digest).all(), f"seed {seed}, {hash_fn}: {dig}"
+            bad = list(r["aux_inputs"])
+            bad[0] = (bad[0] + 1) % A.P                                                     # another program hash
+            assert not pkg.verify_miden(r["public_values"], bad, proof.bytes, hash_fn=hash_fn)[0], seed
+    assert len(heights) >= min(2, n)
+    ctx.close()
