@@ -5,7 +5,8 @@ column makes "live" unambiguous: ChunkNodeAir (the chunk part under COL_CHUNK_AC
 KeccakRoundAir (per lane, KR_COL_ACT) and KeccakSpongeAir (SPC_ACT).  Expected misses, as in the reference: KeccakRoundAir's eight rotation
 cells KR_ROT.. are read on ROL slots only (hash/keccak/round/mod.rs:296-300, the `act * is_rol` gate) and its operand B on XOR / ANDNOT slots only,
 so those cells are free on the other slots of the 128-slot programme; the sponge's byte-shadow cells are read on the rows whose slot absorbs or squeezes that byte.  Everything else must be caught.
-(The other chiplets are surveyed in DESIGN.md section 8: their free-cell maps are not written down yet.)"""
+BytePairLutAir has no free cell in any row, EcPointStoreAir none in an active row.  (The other six chiplets are surveyed in DESIGN.md section 8: their
+free-cell maps are not written down yet.)"""
 import os
 import numpy as np
 import pytest
@@ -50,6 +51,9 @@ def caught(session, k, bad):
     (7, "uint_add", [(0, 30, PA.UA_COL_ACT)], None),
     (2, "keccak_round", [(0, 34, PA.KR_COL_ACT), (34, 68, 34 + PA.KR_COL_ACT)], "round_program"),
     (4, "keccak_sponge", [(0, 67, PA.SPC_ACT)], lambda row, col: col >= PA.SPC_B),
+    # no free cell at all: the byte-pair table in every row (act_col None), the point store under its activity column
+    (3, "byte_pair_lut", [(0, 3, None)], None),
+    (9, "ec_point_store", [(0, 14, PA.EP_COL_ACT)], None),
 ])
 def test_perturbed_cells_of_active_rows_are_caught(session, k, name, parts, free):
     _, traces, _, _ = session
@@ -57,7 +61,7 @@ def test_perturbed_cells_of_active_rows_are_caught(session, k, name, parts, free
     rng = np.random.default_rng(1000 + k)
     missed, total = [], 0
     for lo, hi, act_col in parts:
-        rows = np.nonzero(t[:, act_col])[0]
+        rows = np.nonzero(t[:, act_col])[0] if act_col is not None else np.arange(t.shape[0])
         assert len(rows) > 0, name
         for _ in range(int(os.environ.get("MH_PERTURB_N", "30"))):
             row, col = int(rows[int(rng.integers(0, len(rows)))]), int(rng.integers(lo, hi))
