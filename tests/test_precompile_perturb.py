@@ -54,6 +54,8 @@ def caught(session, k, bad):
     # no free cell at all: the byte-pair table in every row (act_col None), the point store under its activity column
     (3, "byte_pair_lut", [(0, 3, None)], None),
     (9, "ec_point_store", [(0, 14, PA.EP_COL_ACT)], None),
+    # one row per group, provided at multiplicity -mult (ec/groups.rs:163-202): the five-tuple of a group nobody reads (mult = 0) is free, its pointer is not
+    (8, "ec_groups", [(0, 6, None)], "unread_group"),
 ])
 def test_perturbed_cells_of_active_rows_are_caught(session, k, name, parts, free):
     _, traces, _, _ = session
@@ -77,6 +79,9 @@ def test_perturbed_cells_of_active_rows_are_caught(session, k, name, parts, free
             slot, c = row % 128, col % 34
             reads_b = per[PA.PCOL_IS_XOR][slot] + per[PA.PCOL_IS_ANDNOT][slot]
             return (PA.KR_ROT <= c < PA.KR_ROT + 8 and not per[PA.PCOL_IS_ROL][slot]) or (PA.KR_B <= c < PA.KR_B + 8 and not reads_b)
+    if free == "unread_group":
+        def free(row, col):
+            return 1 <= col <= 4 and int(t[row, 5]) == 0
     for row, col in missed:
         assert free is not None and free(row, col), f"{name}: cell ({row}, {col}) of an active row is constrained by nothing"
-    assert len(missed) <= total // 3, (name, missed)
+    assert len(missed) <= total // 3 or name == "ec_groups", (name, missed)     # (one group of eight rows is read in this session)
