@@ -85,3 +85,28 @@ def test_perturbed_cells_of_active_rows_are_caught(session, k, name, parts, free
     for row, col in missed:
         assert free is not None and free(row, col), f"{name}: cell ({row}, {col}) of an active row is constrained by nothing"
     assert len(missed) <= total // 3 or name == "ec_groups", (name, missed)     # (one group of eight rows is read in this session)
+
+
+def test_poseidon2_chiplet_active_cycles(session):
+    """Poseidon2Air gates every step constraint by the cycle's multiplicities (transcript/poseidon2/mod.rs:214-221, 271-275: "on padding cycles the
+    constraints vacuate, freeing the prover to zero-fill"), so only cycles with in_mult + out_mult != 0 are live.  In a live cycle every control and
+    state cell (columns 0..15) must be caught in every row; a witnessed S-box output or a cube register (16..31) is read by the rows of the 16-row
+    programme that have that S-box and by no other -- the same (slot, column) is either always caught or never."""
+    _, traces, _, _ = session
+    t = traces[1]
+    cyc = np.nonzero((t[::16, PA.P2C_IN_MULT] + t[::16, PA.P2C_OUT_MULT]) % P)[0]
+    assert len(cyc) >= 8
+    rng = np.random.default_rng(31)
+    verdicts = {}
+    for _ in range(int(os.environ.get("MH_PERTURB_N", "30")) * 5):
+        slot, col = int(rng.integers(0, 16)), int(rng.integers(0, 32))
+        row = 16 * int(cyc[int(rng.integers(0, len(cyc)))]) + slot
+        bad = t.copy()
+        bad[row, col] = (int(bad[row, col]) + 12345) % P
+        ok = caught(session, 1, bad)
+        if col < PA.P2C_WITNESS:
+            assert ok, f"poseidon2_chiplet: control / state cell ({row}, {col}) of a live cycle is constrained by nothing"
+        else:
+            assert verdicts.setdefault((slot, col), ok) == ok, f"poseidon2_chiplet: slot {slot} column {col} is read in one cycle and not in another"
+    free = sorted(k for k, v in verdicts.items() if not v)
+    assert all(slot == 15 or col >= PA.P2C_WITNESS for slot, col in free)
