@@ -110,3 +110,49 @@ def test_poseidon2_chiplet_active_cycles(session):
             assert verdicts.setdefault((slot, col), ok) == ok, f"poseidon2_chiplet: slot {slot} column {col} is read in one cycle and not in another"
     free = sorted(k for k, v in verdicts.items() if not v)
     assert all(slot == 15 or col >= PA.P2C_WITNESS for slot, col in free)
+
+
+def test_ec_group_add_active_blocks(session):
+    """EcGroupAddAir: four-row blocks, a near-one-hot over five cases.  In an active block (EA_COL_ACT) the operand pointers, the curve pointers and
+    the case flags (columns EA_COL_PX .. EA_COL_MINTS) must be caught in every row; the three role-polymorphic cells and the ordering limbs are read
+    by the (row of the block, case, mints) combinations that use them: the same combination always gives the same verdict."""
+    _, traces, _, _ = session
+    t = traces[10]
+    rows = np.nonzero(t[:, PA.EA_COL_ACT])[0]
+    assert len(rows) >= 8
+    rng = np.random.default_rng(41)
+    verdicts = {}
+    for _ in range(int(os.environ.get("MH_PERTURB_N", "30")) * 5):
+        row, col = int(rows[int(rng.integers(0, len(rows)))]), int(rng.integers(0, PA.EA_COLS))
+        bad = t.copy()
+        bad[row, col] = (int(bad[row, col]) + 12345) % P
+        ok = caught(session, 10, bad)
+        if PA.EA_COL_PX <= col <= PA.EA_COL_MINTS:
+            assert ok, f"ec_group_add: block scalar ({row}, {col}) of an active block is constrained by nothing"
+        else:
+            case = tuple(int(t[row, c]) for c in (PA.EA_COL_PAI_P, PA.EA_COL_PAI_Q, PA.EA_COL_CANCEL, PA.EA_COL_DBL, PA.EA_COL_GEN, PA.EA_COL_MINTS))
+            assert verdicts.setdefault((row % 4, col, case), ok) == ok, f"ec_group_add: ({row % 4}, {col}, {case}) read in one block and not in another"
+    assert any(verdicts.values())
+
+
+def test_transcript_eval_active_rows(session):
+    """TranscriptEvalAir: one transcript node per row, role-polymorphic pointer and tag cells behind node-family and operation one-hots.  On an active row
+    (TE_COL_ACT) the activity flag, the permutation handle and the node's hash h must always be caught; every other cell is read by the node kinds that use
+    it: the same (column, kind) -- kind = the row's one-hots and whether it has readers -- always gives the same verdict."""
+    _, traces, _, _ = session
+    t = traces[5]
+    rows = np.nonzero(t[:, PA.TE_COL_ACT])[0]
+    assert len(rows) >= 12
+    rng = np.random.default_rng(51)
+    flags = [c for c in range(PA.TE_COL_IS_ZERO, PA.TE_COL_IS_PINNED + 1) if c != PA.TE_COL_OUT_MULT] + [PA.TE_COL_IS_EC_MSM, PA.TE_COL_IS_MSM_LAST, PA.TE_COL_MSM_IS_HEAD]
+    verdicts = {}
+    for _ in range(int(os.environ.get("MH_PERTURB_N", "30")) * 8):
+        row, col = int(rows[int(rng.integers(0, len(rows)))]), int(rng.integers(0, PA.TE_COLS))
+        bad = t.copy()
+        bad[row, col] = (int(bad[row, col]) + 12345) % P
+        ok = caught(session, 5, bad)
+        kind = tuple(int(t[row, c]) for c in flags) + (int(t[row, PA.TE_COL_OUT_MULT]) != 0,)
+        if col in (PA.TE_COL_ACT, PA.TE_COL_PERM_SEQ_ID) or PA.TE_COL_H <= col < PA.TE_COL_H + 4:
+            assert ok, f"transcript_eval: cell ({row}, {col}) of an active row is constrained by nothing"
+        assert verdicts.setdefault((col, kind), ok) == ok, f"transcript_eval: column {col} read on one row of kind {kind} and not on another"
+    assert sum(verdicts.values()) >= 0.6 * len(verdicts), "most cells of active rows are read"
