@@ -156,3 +156,27 @@ def test_transcript_eval_active_rows(session):
             assert ok, f"transcript_eval: cell ({row}, {col}) of an active row is constrained by nothing"
         assert verdicts.setdefault((col, kind), ok) == ok, f"transcript_eval: column {col} read on one row of kind {kind} and not on another"
     assert sum(verdicts.values()) >= 0.6 * len(verdicts), "most cells of active rows are read"
+
+
+@pytest.mark.parametrize("k,name,period", [(11, "ec_msm", 1), (6, "uint_store_mul", 8)])
+def test_cells_are_read_consistently_per_row_kind(session, k, name, period):
+    """EcMsmAir and UintStoreMulAir: role-polymorphic rows whose read sets are not written down here.  What can be held without that map: the KIND of a row
+    -- the values of every column that is boolean over the whole trace, and the row's place in the chiplet's periodic programme -- decides which cells the
+    constraints and buses read; so the same (column, kind) must give the same verdict wherever it occurs, and on rows whose kind has a flag set most cells
+    must be read."""
+    _, traces, _, _ = session
+    t = traces[k]
+    bool_cols = [c for c in range(t.shape[1]) if ((t[:, c] == 0) | (t[:, c] == 1)).all() and (t[:, c] == 1).any()]
+    assert bool_cols, name
+    rng = np.random.default_rng(61 + k)
+    verdicts, on_flagged = {}, []
+    for _ in range(int(os.environ.get("MH_PERTURB_N", "30")) * 8):
+        row, col = int(rng.integers(0, t.shape[0])), int(rng.integers(0, t.shape[1]))
+        bad = t.copy()
+        bad[row, col] = (int(bad[row, col]) + 12345) % P
+        ok = caught(session, k, bad)
+        kind = (row % period,) + tuple(int(t[row, c]) for c in bool_cols)
+        assert verdicts.setdefault((col, kind), ok) == ok, f"{name}: column {col} read on one row of kind {kind} and not on another"
+        if any(kind[1:]):
+            on_flagged.append(ok)
+    assert on_flagged and sum(on_flagged) >= 0.5 * len(on_flagged), (name, sum(on_flagged), len(on_flagged))
