@@ -45,11 +45,11 @@ def test_random_programs_satisfy_the_three_airs_and_close(airs):
 
 
 def test_one_cell_perturbations_of_random_programs_are_caught(airs):
-    """Soundness of the ports on op mixes the reference's 27 snapshots do not contain: random cells of the program rows of the core trace and of the
-    live chiplet rows, changed one at a time -- a constraint must fail or the buses must stop closing, except in the cells the constraint systems
+    """Soundness of the ports on op mixes the reference's 27 snapshots do not contain: random cells of the program rows of the core trace, of the
+    live chiplet rows and of ANY row of the permutation trace, changed one at a time -- a constraint must fail or the buses must stop closing, except in the cells the constraint systems
     leave free (the sets tests/test_ref_traces.py names: ctx / fn_hash / hasher-state columns / group count on rows that do not read them, h0 at depth
     16, b1 on rows that do not shift; chiplets: a controller padding row's state, a later chiplet's unused columns).  MH_FUZZ_PERTURB_SEEDS programs
-    (default 6) x 40 cells."""
+    (default 6) x 60 cells."""
     import numpy as np
     first, n = int(os.environ.get("MH_FUZZ_FIRST", "1")), int(os.environ.get("MH_FUZZ_PERTURB_SEEDS", "6"))
     free_core = set([CO.CTX] + list(CO.FN_HASH) + list(CO.DEC_HASHER) + [CO.DEC_GROUP_COUNT, CO.STACK_B1, CO.STACK_H0])
@@ -67,7 +67,7 @@ def test_one_cell_perturbations_of_random_programs_are_caught(airs):
         halt = [0, 0, 1, 1, 1, 1, 1]
         program_rows = int(np.argmax((r["core"][:, CO.DEC_OP_BITS] == halt).all(axis=1)))        # the first HALT row
         live = int(np.argmax((r["chiplets"][:, 0:5] == 1).all(axis=1))) or r["chiplets"].shape[0]  # the first padding row
-        for key, idx, rows in (("core", 0, program_rows), ("chiplets", 1, live)):
+        for key, idx, rows in (("core", 0, program_rows), ("chiplets", 1, live), ("poseidon2", 2, r["poseidon2"].shape[0])):
             air, lookup = airs[idx]
             for _ in range(20):
                 row, col = int(rng.integers(0, rows)), int(rng.integers(0, traces[key].shape[1]))
@@ -81,6 +81,7 @@ def test_one_cell_perturbations_of_random_programs_are_caught(airs):
                     caught += 1
                     continue
                 missed_free += 1
+                assert key != "poseidon2", f"seed {seed}: the permutation AIR has no free cell (padding cycles are real permutations), yet ({row}, {col}) passes"
                 if key == "core":
                     assert col in free_core, f"seed {seed}: core cell ({row}, {col}) is not constrained"
                     if col == CO.STACK_H0:
