@@ -2,7 +2,8 @@
 library reads bytes an adversary wrote).  Random mutations -- bit flips, truncations, length fields overwritten, spliced garbage -- of
 valid proof bytes go through mh_proof_deserialize and, when they parse, through mh_verify; mutated constraint-DAG and lookup blobs go
 through mh_verify and mh_jit_precompile; mutated proof bytes through mh_verify_miden.  Every call must RETURN (an error code or a verdict):
-the loop runs in a child process under faulthandler, a crash or a hang fails the test.  No GPU."""
+the loop runs in a child process under faulthandler, a crash or a hang fails the test.  No GPU.  (tests/test_fuzz_host.py damages blobs and
+transcript WORDS; this one works on BYTES -- the serialized proof, the statement-level verifier -- and is the loop tools/asan_host.sh runs under AddressSanitizer.)"""
 import os
 import subprocess
 import sys

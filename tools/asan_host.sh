@@ -21,5 +21,5 @@ gcc -fPIC -c $B/fatbin_stubs.c -o $B/zz_fatbin_stubs.o
 /opt/rocm/bin/hipcc --offload-host-only -shared -fPIC -fsanitize=address -shared-libasan -o /tmp/libmidenhip_asan.so $B/*.o -lhiprtc -ldl
 cd $ROOT
 export MIDENHIP_LIB=/tmp/libmidenhip_asan.so LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=1
-MH_ROBUST_N=${MH_ROBUST_N:-1500} python -m pytest -x -q tests/test_abi_robustness.py tests/test_verifier_cpu.py tests/test_proof_structure.py tests/test_abi.py \
+MH_ROBUST_N=${MH_ROBUST_N:-1500} python -m pytest -x -q tests/test_abi_robustness.py tests/test_fuzz_host.py tests/test_verifier_cpu.py tests/test_proof_structure.py tests/test_abi.py \
   tests/test_host_compress_simd.py tests/test_ref_lifted_stark.py tests/test_session_c_abi.py -p no:cacheprovider 2>&1 | tail -15
