@@ -470,6 +470,7 @@ def test_random_programs_through_mh_prove_miden():
     MH_FUZZ_PROGRAM_SEEDS=N (default 4)."""
     import random_programs as RP
     from miden_vm_amd.testing import core_trace as CV
+    from miden_vm_amd import core_air as CO
     pkg = load_package()
     ctx = pkg.Ctx(0)
     miden = pkg.Miden(ctx)
@@ -485,5 +486,23 @@ def test_random_programs_through_mh_prove_miden():
             bad = list(r["aux_inputs"])
             bad[0] = (bad[0] + 1) % A.P                                                     # another program hash
             assert not pkg.verify_miden(r["public_values"], bad, proof.bytes, hash_fn=hash_fn)[0], seed
+        # soundness through the device: one cell of a constrained column of a program row damaged (an operand on the stack, an opcode bit, a chiplet
+        # selector or state cell, a permutation state cell) -> the library still makes a proof, and the verifier must refuse it
+        rng = np.random.default_rng(0xdead + seed)
+        halt = [0, 0, 1, 1, 1, 1, 1]
+        n_prog = int(np.argmax((r["core"][:, CO.DEC_OP_BITS] == halt).all(axis=1)))
+        which = int(rng.integers(0, 3))
+        mats = [r["core"].copy(), r["chiplets"].copy(), r["poseidon2"].copy()]
+        if which == 0:
+            row, col = int(rng.integers(0, n_prog)), int(rng.choice(list(CO.STACK_TOP[:4]) + list(CO.DEC_OP_BITS)))
+        elif which == 1:
+            ch = r["chiplets"]                                                             # a state cell of a live hasher-controller row (not a padding slot)
+            live = [i for i in range(ch.shape[0]) if int(ch[i, 0]) == 0 and not (int(ch[i, 1]) == 0 and int(ch[i, 2]) == 1)]
+            row, col = int(live[int(rng.integers(0, len(live)))]), 4 + int(rng.integers(0, 12))
+        else:
+            row, col = int(rng.integers(0, mats[2].shape[0])), int(rng.integers(0, 16))
+        mats[which][row, col] = (int(mats[which][row, col]) + 12345) % A.P
+        forged = miden.prove(mats[0], mats[1], mats[2], r["public_values"], r["aux_inputs"])
+        assert not pkg.verify_miden(r["public_values"], r["aux_inputs"], forged.bytes)[0], f"seed {seed}: a damaged trace ({which}, {row}, {col}) was accepted"
     assert len(heights) >= min(2, n)
     ctx.close()
