@@ -384,6 +384,7 @@ def test_random_sessions_through_the_precompile_entry():
     refused.  The trace heights change with the inputs, so this also walks the LMCS lifting across many height mixes.
     MH_FUZZ_SESSION_SEEDS=N (default 3)."""
     from miden_vm_amd.testing import precompile_trace as PT
+    from miden_vm_amd import precompile_airs as PA
     pkg = load_package()
     ctx = pkg.Ctx(0)
     pc = pkg.Precompile(ctx)
@@ -405,6 +406,21 @@ def test_random_sessions_through_the_precompile_entry():
             ok, dig = pkg.verify_precompile(setup, root, proof.bytes, hash_fn=hash_fn)
             assert ok and (dig == proof.digest).all(), f"{what}, {hash_fn}: {dig}"
             assert not pkg.verify_precompile(setup, [(int(root[0]) + 1) % A.P] + [int(x) for x in root[1:]], proof.bytes, hash_fn=hash_fn)[0], what
+        # soundness through the device: one cell damaged in a chiplet that has no free cell there (tests/test_precompile_perturb.py: the byte-pair table in any
+        # row, the point store and the chunk / node chiplet in their active rows) -> a proof is still made, the verifier must refuse it
+        k, act = [(3, None), (9, PA.EP_COL_ACT), (0, PA.COL_CHUNK_ACT)][int(rng.integers(0, 3))]
+        t = traces[k]
+        rows = np.arange(t.shape[0]) if act is None else np.nonzero(t[:, act])[0]
+        if len(rows) == 0:                                               # (a session without Keccak claims has no active chunk row)
+            k, t = 3, traces[3]
+            rows = np.arange(t.shape[0])
+        row = int(rows[int(rng.integers(0, len(rows)))])
+        col = int(rng.integers(0, 12 if k == 0 else t.shape[1]))
+        bad = [x for x in traces]
+        bad[k] = t.copy()
+        bad[k][row, col] = (int(t[row, col]) + 12345) % A.P
+        forged = pc.prove(bad, root)
+        assert not pkg.verify_precompile(pc.preprocessed_root(), root, forged.bytes)[0], f"{what}: damaged cell ({k}, {row}, {col}) accepted"
     assert len(shapes) >= min(n, 2)
     ctx.close()
 
