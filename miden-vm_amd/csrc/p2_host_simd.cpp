@@ -8,6 +8,7 @@
 // tests/test_host_compress_simd.py (host, no GPU) and through every tree root of the GPU parity tests.
 // Compiled for the host only (no -x hip); selected at run time when the CPU has AVX-512 F + DQ.
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <immintrin.h>
 
@@ -119,7 +120,8 @@ P2V_TARGET void permute8(v8 s[12]) {
 }  // namespace
 
 bool p2_host_simd_available() {
-  static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq");
+  // MH_HOST_SIMD=0: the scalar host functions (what a CPU without AVX-512 runs), for tests and comparisons
+  static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && !(getenv("MH_HOST_SIMD") && atoi(getenv("MH_HOST_SIMD")) == 0);
   return ok;
 }
 

@@ -177,3 +177,13 @@ def test_verifiers_agree_on_random_tamperings_under_the_other_configurations(lmc
         assert rejected >= 92
     finally:
         ob.set_lmcs("poseidon2")
+
+
+def test_the_scalar_host_path_gives_the_same_verdicts():
+    """The verifier hashes eight leaves / eight tree nodes per AVX-512 permutation under Poseidon2 when the CPU has it (csrc/verifier.cpp `leaf_digests`,
+    `compress_many`); MH_HOST_SIMD=0 selects the scalar functions a CPU without AVX-512 runs.  The acceptance and tamper tests of this file once more,
+    in a child process with that switch: the two paths must agree with the oracle, hence with each other."""
+    import os, subprocess, sys
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", __file__, "-k", "accepts_oracle_proofs or rejects_what or random_tamperings[multi"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, MH_HOST_SIMD="0"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
