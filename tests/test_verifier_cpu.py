@@ -1,6 +1,7 @@
 """CPU: the product's host-only verifier (mh_verify, csrc/verifier.cpp) against the oracle.  Two restatements of
 the reference's verifier must agree: mh_verify accepts every proof the oracle prover makes (same digest as the
 oracle verifier), and rejects what the oracle verifier rejects -- tampered fields, commitments, parameters."""
+import zlib
 import numpy as np
 import pytest
 import oracle_binding as ob
@@ -119,7 +120,7 @@ def test_verifiers_agree_on_random_tamperings(name, airs_, traces, pub, prm):
     proof-of-work witness can stay valid, swapping equal neighbours changes nothing)."""
     proof = ob.prove(airs_, traces, pub, prm)
     f, c, lhs = proof["fields"], proof["commitments"], proof["log_heights"]
-    rng = np.random.default_rng(abs(hash(name)) % (1 << 32))
+    rng = np.random.default_rng(zlib.crc32(name.encode()))        # (str hashes differ from process to process)
     rejected = total = 0
     for kind in ("inc", "rand", "zero", "swap"):
         for pos in rng.integers(0, f.size - 1, 30):
