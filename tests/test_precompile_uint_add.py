@@ -14,6 +14,7 @@ Schwartz-Zippel" a(beta) + b(beta) - c(beta) - k (bound(beta) + 1) + (beta - 2^3
                                                                         left out here: its tuples come from the `UintStore` ledger)
   duplicate_relations_collapse, log_quotient_degree_matches_design_target (1)"""
 import random
+import zlib
 import numpy as np
 import pytest
 import oracle_binding as ob
@@ -125,7 +126,7 @@ def test_duplicate_relations_collapse():
 
 @pytest.mark.parametrize("name", ["wrong_result", "is_b_zero_rejects_unequal_values", "nz_cert_forged_zero", "nz_cert_wrong_ws"])
 def test_forged_blocks_are_rejected(ua, name):
-    rng = random.Random(hash(name) & 0xffff)
+    rng = random.Random(zlib.crc32(name.encode()) & 0xffff)   # (str hashes differ from process to process)
     add, store, _, (a, bv, bound, fp, a_ptr, b_ptr, c_ptr) = sample(rng)
     if name.startswith("nz"):
         add = PT.UintAddRequires()
